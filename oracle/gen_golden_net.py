@@ -1,0 +1,140 @@
+"""Generate tests/golden/net_*.npz by running the REFERENCE itself (CPU) in this container.
+
+Run (py3.10 + torch):  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_net.py
+Needs /root/reference (read-only); never runs on the GPU box.  The reference's
+`NetDesc` / `infer_step` are imported, loaded (strict=True) with the seeded weights of
+cerberus_amd.weights.make_state_dict, and run on seeded uint8 tiles.  What is stored is
+DATA only: inputs' seeds, crops of the reference's logits, its infer_step outputs
+(crops) and whole-tensor float64 statistics.
+
+Inert stubs: cv2 / skimage / termcolor / docopt are not installed here and are only
+reached by *imports* of models/run_desc.py -> misc/utils.py, never by infer_step's
+arithmetic.  `.to("cuda")` (models/run_desc.py:440) is neutralised
+because this container has no GPU.
+"""
+import os
+import sys
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+for m in ["cv2", "skimage", "skimage.filters", "skimage.morphology", "termcolor", "matplotlib", "matplotlib.pyplot",
+          "tensorboardX", "imgaug", "imgaug.augmenters"]:
+    if m not in sys.modules:
+        try:
+            __import__(m)
+        except Exception:
+            sys.modules[m] = MagicMock()
+
+_orig_to = torch.Tensor.to
+
+
+def _to(self, *a, **k):
+    if a and a[0] == "cuda":
+        return self
+    return _orig_to(self, *a, **k)
+
+
+torch.Tensor.to = _to
+
+from models.net_desc import create_model  # noqa: E402  (reference)
+from models.run_desc import infer_step as ref_infer_step  # noqa: E402  (reference)
+
+from cerberus_amd.weights import default_model_kwargs, make_state_dict, state_dict_sha256  # noqa: E402
+from oracle import net_ref  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+CROPS = [(0, 0), (96, 96), (192, 192)]  # top-left corners of 64x64 windows (corner / centre / far corner)
+CS = 64
+
+
+def crops(a, axes=(1, 2)):
+    """a: (N,H,W,C) -> (N, ncrop, CS, CS, C)"""
+    return np.stack([a[:, y:y + CS, x:x + CS] for (y, x) in CROPS], axis=1)
+
+
+def run_case(tag, tile_seed, n, hw, out_shape, tasks, weight_seed=0):
+    kw = default_model_kwargs(tasks)
+    sd_np = make_state_dict(weight_seed, kw["decoder_kwargs"], kw["considered_tasks"])
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    model = create_model(**kw)
+    model.load_state_dict(sd, strict=True)  # pins the key schema too
+    model.eval()
+    tiles = np.random.RandomState(tile_seed).randint(0, 256, (n, hw, hw, 3)).astype(np.uint8)
+    x = torch.from_numpy(tiles).float().permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        ref_logits = model(x)
+        ref_feats = model.backbone(x / 255.0)
+    ref_out = ref_infer_step(torch.from_numpy(tiles), model, out_shape, kw["considered_tasks"])
+
+    # oracle vs reference (same machine, same torch) -- must agree to rounding
+    orc_logits = net_ref.net_forward(sd, x, kw["decoder_kwargs"], kw["considered_tasks"])
+    orc_out = net_ref.infer_step(sd, tiles, out_shape, kw["considered_tasks"], kw["decoder_kwargs"])
+    store = {"tile_seed": tile_seed, "weight_seed": weight_seed, "n": n, "hw": hw, "out_shape": out_shape,
+             "tasks": np.array(tasks), "weights_sha256": state_dict_sha256(sd_np)}
+    for k, v in ref_logits.items():
+        d = (orc_logits[k] - v).abs().max().item()
+        print("%-12s logits %-18s absmax %.4f  oracle-vs-ref maxdiff %.3e" % (tag, tuple(v.shape), v.abs().max().item(), d))
+        assert d < 2e-4, (k, d)
+        a = v.permute(0, 2, 3, 1).contiguous().numpy()
+        if a.shape[1] >= 256:
+            store["logits_crops/" + k] = crops(a)
+        else:
+            store["logits_full/" + k] = a
+        store["logits_mean/" + k] = np.float64(a.astype(np.float64).mean())
+        store["logits_absmean/" + k] = np.float64(np.abs(a.astype(np.float64)).mean())
+    for i, f in enumerate(ref_feats):
+        a = f.numpy().astype(np.float64)
+        store["feat_mean/x%d" % i] = a.mean()
+        store["feat_absmean/x%d" % i] = np.abs(a).mean()
+    for i in range(n):
+        for k, v in ref_out[i].items():
+            o = orc_out[i][k]
+            assert o.shape == v.shape and o.dtype == v.dtype, (k, o.shape, v.shape, o.dtype, v.dtype)
+            if v.dtype == np.float32:
+                d = np.abs(o - v).max()
+                assert d < 1e-5, (k, d)
+            else:
+                mism = (o != v).mean()
+                assert mism < 1e-3, (k, mism)
+    for k in ref_out[0].keys():
+        a = np.stack([ref_out[i][k] for i in range(n)])
+        store["out_dtype/" + k] = str(a.dtype)
+        if a.ndim == 3:
+            a4 = a[..., None]
+        else:
+            a4 = a
+        if a.shape[1] >= 256:
+            store["out_crops/" + k] = crops(a4)
+        else:
+            store["out_full/" + k] = a4
+        if a.dtype == np.float32 and "INST" in k:
+            sat = np.mean((a < 1e-6) | (a > 1 - 1e-6))
+            fg = np.mean(a[..., 0] > 0.5)
+            print("%-12s out %-12s saturated frac %.4f  inner>0.5 frac %.3f" % (tag, k, sat, fg))
+        if "TYPE" in k:
+            print("%-12s out %-12s class hist %s" % (tag, k, np.bincount(a.ravel(), minlength=3)))
+        if k == "Patch-Class":
+            print("%-12s Patch-Class ids %s" % (tag, a[:, 0, 0]))
+    path = os.path.join(ROOT, "tests", "golden", "net_%s.npz" % tag)
+    np.savez_compressed(path, **store)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    all_tasks = list(default_model_kwargs()["considered_tasks"])
+    # cfg-1: one 256^2 tile, nuclei head only (BASELINE.json configs[0])
+    run_case("cfg1_nuclei", tile_seed=0, n=1, hw=256, out_shape=256, tasks=["Nuclei"])
+    # cfg-2 subset: 2 tiles, all six heads
+    run_case("cfg2_all", tile_seed=1, n=2, hw=256, out_shape=256, tasks=all_tasks)
+    # reference-default geometry 448 -> 144 (centre crop path of infer_step)
+    run_case("g448_all", tile_seed=2, n=1, hw=448, out_shape=144, tasks=all_tasks)
