@@ -1,0 +1,76 @@
+"""ctypes binding of libcerberus_hip.so (include/cerberus_hip.h).  Fails loudly: there is NO CPU / eager fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcerberus_hip.so")
+
+EXPORTS = [
+    "cerb_version", "cerb_last_error", "cerb_net_create", "cerb_net_destroy", "cerb_net_load_tensor",
+    "cerb_net_finalize", "cerb_net_forward", "cerb_net_flops", "cerb_pp_workspace_bytes", "cerb_postproc_nuclei",
+    "cerb_postproc_gland", "cerb_postproc_lumen", "cerb_mask_lumen_by_gland", "cerb_event_create",
+    "cerb_event_record", "cerb_event_elapsed_ms", "cerb_event_destroy",
+]
+
+
+class ForwardIO(C.Structure):
+    _fields_ = [
+        ("tiles", C.c_void_p),
+        ("n", C.c_int), ("h", C.c_int), ("w", C.c_int),
+        ("out_h", C.c_int), ("out_w", C.c_int),
+        ("out", C.POINTER(C.c_void_p)),
+        ("logits", C.POINTER(C.c_void_p)),
+        ("tile_off", C.c_void_p),
+        ("tile_stride", C.c_longlong),
+        ("row_stride", C.c_longlong),
+        ("type_is_u8", C.c_int),
+        ("feats", C.POINTER(C.c_void_p)),
+    ]
+
+
+class CerberusHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (building is `python -m cerberus_amd.build` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CerberusHipError(
+            "libcerberus_hip.so not found at %s -- run `python -m cerberus_amd.build` (needs hipcc). "
+            "There is no CPU fallback for the Cerberus HIP path." % LIB_PATH
+        )
+    L = C.CDLL(LIB_PATH)
+    L.cerb_last_error.restype = C.c_char_p
+    L.cerb_net_create.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    L.cerb_net_destroy.argtypes = [C.c_void_p]
+    L.cerb_net_destroy.restype = None
+    L.cerb_net_load_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]
+    L.cerb_net_finalize.argtypes = [C.c_void_p]
+    L.cerb_net_forward.argtypes = [C.c_void_p, C.POINTER(ForwardIO), C.c_void_p]
+    L.cerb_net_flops.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.cerb_net_flops.restype = C.c_double
+    L.cerb_pp_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    L.cerb_pp_workspace_bytes.restype = C.c_size_t
+    L.cerb_postproc_nuclei.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]
+    for f in (L.cerb_postproc_gland, L.cerb_postproc_lumen):
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                      C.c_size_t, C.c_void_p]
+    L.cerb_mask_lumen_by_gland.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
+    L.cerb_event_create.argtypes = [C.POINTER(C.c_void_p)]
+    L.cerb_event_record.argtypes = [C.c_void_p, C.c_void_p]
+    L.cerb_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    L.cerb_event_destroy.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise CerberusHipError(lib().cerb_last_error().decode("utf-8", "replace"))

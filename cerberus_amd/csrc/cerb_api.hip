@@ -1,0 +1,571 @@
+// C-ABI implementation (include/cerberus_hip.h) for the network part of the Cerberus tile path:
+// weight intake (BN folding + MFMA packing), workspace, and the forward schedule
+//   stem -> maxpool -> 16 BasicBlocks -> conv_map -> Patch-Class branch -> 5 dense decoders (grouped launches) -> heads.
+// Host code only; kernels live in conv_igemm.hip / net_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cerberus_hip.h"
+#include "cerb_common.h"
+
+// launchers implemented in the kernel translation units
+hipError_t cerb_launch_conv(const ConvParams& p, int ks, int stride, int mode, hipStream_t st);
+extern "C" int cerb_conv_chunk(int ks, int stride);
+struct StemParams {
+    const unsigned char* tiles;
+    const float* wpack;
+    const float* bias;
+    float* out;
+    int N, H, W, tiles_x, tiles_y;
+};
+hipError_t cerb_launch_stem(StemParams p, hipStream_t st);
+hipError_t cerb_launch_maxpool(const float* in, float* out, int N, int H, int W, int C, hipStream_t st);
+hipError_t cerb_launch_head(const HeadParams& p, hipStream_t st);
+struct PatchClassParams {
+    const float* x4;
+    const float* bn1_s;
+    const float* bn1_b;
+    const float* w1t;
+    const float* b1;
+    const float* w2t;
+    const float* b2;
+    int N, Hf, Wf, out_ch;
+    int out_h, out_w;
+    float* logits;
+    float* out;
+    const long long* tile_off;
+    long long tile_stride, row_stride;
+};
+hipError_t cerb_launch_patch_class(const PatchClassParams& p, hipStream_t st);
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) {
+    g_err = m;
+    return 1;
+}
+#define HIP_OK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+extern "C" int cerb_version(void) { return 1; }
+extern "C" const char* cerb_last_error(void) { return g_err.c_str(); }
+
+// ---------------------------------------------------------------------------------------------------------------
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct DevBuf {
+    float* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        if (hipMalloc(&p, need) != hipSuccess) return 1;
+        bytes = need;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct PackedConv {
+    int cin = 0, cout = 0, ks = 0, stride = 1, groups = 1;
+    float* w = nullptr;  // device
+    float* b = nullptr;  // device
+};
+
+struct DecoderCfg {
+    std::string name, head;
+    int out_ch = 0;
+    int kind = 0;  // 0 INST, 1 TYPE, 2 OUT (Patch-Class)
+};
+
+struct cerb_net {
+    std::vector<DecoderCfg> dec;
+    std::vector<int> dense_idx;  // indices into dec of the dense (non Patch-Class) decoders
+    int pc_idx = -1;
+    std::map<std::string, HostTensor> host;
+    bool finalized = false;
+    // packed device weights
+    float *stem_w = nullptr, *stem_b = nullptr;
+    std::map<std::string, PackedConv> conv;  // backbone convs + conv_map + grouped decoder convs ("dec.<u>.<j>")
+    std::vector<float*> head_w1, head_b1, head_w2, head_b2;  // per dense decoder
+    float *pc_bn1s = nullptr, *pc_bn1b = nullptr, *pc_w1t = nullptr, *pc_b1 = nullptr, *pc_w2t = nullptr, *pc_b2 = nullptr;
+    std::vector<void*> dev_allocs;
+    // workspace
+    DevBuf x0, pool, x[5], ta, tb, cm, dmid, dout[4];
+    ~cerb_net() {
+        for (void* p : dev_allocs) (void)hipFree(p);
+        x0.release(); pool.release(); ta.release(); tb.release(); cm.release(); dmid.release();
+        for (auto& b : x) b.release();
+        for (auto& b : dout) b.release();
+    }
+};
+
+static int upload(cerb_net* net, const std::vector<float>& v, float** out) {
+    float* d = nullptr;
+    HIP_OK(hipMalloc(&d, v.size() * sizeof(float)));
+    net->dev_allocs.push_back(d);
+    HIP_OK(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = d;
+    return 0;
+}
+
+extern "C" int cerb_net_create(const char* const* decoder_names, const char* const* head_names, const int* out_ch,
+                               int n_decoders, cerb_net** out_net) {
+    if (!decoder_names || !head_names || !out_ch || !out_net || n_decoders <= 0) return fail("cerb_net_create: bad arguments");
+    cerb_net* net = new cerb_net();
+    for (int i = 0; i < n_decoders; ++i) {
+        DecoderCfg d;
+        d.name = decoder_names[i];
+        d.head = head_names[i];
+        d.out_ch = out_ch[i];
+        if (d.name == "Patch-Class") {
+            d.kind = 2;
+            if (d.out_ch < 1 || d.out_ch > 16) { delete net; return fail("Patch-Class: out_ch must be 1..16"); }
+            net->pc_idx = i;
+        } else {
+            if (d.head == "INST") d.kind = 0;
+            else if (d.head == "TYPE") d.kind = 1;
+            else { delete net; return fail("decoder " + d.name + ": head must be INST or TYPE, got " + d.head); }
+            if (d.kind == 0 && d.out_ch != 3) { delete net; return fail("INST heads must have 3 channels (infer_step keeps channels 1..2)"); }
+            if (d.out_ch < 2 || d.out_ch > 8) { delete net; return fail("head out_ch must be 2..8"); }
+            net->dense_idx.push_back(i);
+        }
+        net->dec.push_back(d);
+    }
+    *out_net = net;
+    return 0;
+}
+
+extern "C" void cerb_net_destroy(cerb_net* net) { delete net; }
+
+extern "C" int cerb_net_load_tensor(cerb_net* net, const char* key, const float* data, const int64_t* shape, int ndim) {
+    if (!net || !key) return fail("cerb_net_load_tensor: bad arguments");
+    if (net->finalized) return fail("cerb_net_load_tensor: network already finalized");
+    std::string k(key);
+    if (k.size() > 19 && k.compare(k.size() - 19, 19, "num_batches_tracked") == 0) return 0;  // integer bookkeeping, unused in eval
+    if (k.rfind("backbone.fc.", 0) == 0) return 0;  // resnet.py:212-213: fc exists but is never called
+    if (!data && ndim > 0) return fail("cerb_net_load_tensor: null data for " + k);
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        t.shape.push_back(shape[i]);
+        n *= (size_t)shape[i];
+    }
+    t.data.assign(data, data + n);
+    net->host[k] = std::move(t);
+    return 0;
+}
+
+// ---- BN folding helpers ----------------------------------------------------------------------------------------
+struct Fold {
+    std::vector<float> scale, shift;
+};
+static int get(cerb_net* net, const std::string& k, std::vector<int64_t> shape, const HostTensor** out) {
+    auto it = net->host.find(k);
+    if (it == net->host.end()) return fail("missing key in state dict: " + k);
+    if (it->second.shape != shape) {
+        std::string s = "shape mismatch for " + k + ": got [";
+        for (auto v : it->second.shape) s += std::to_string(v) + ",";
+        s += "] expected [";
+        for (auto v : shape) s += std::to_string(v) + ",";
+        return fail(s + "]");
+    }
+    *out = &it->second;
+    return 0;
+}
+static int bn_fold(cerb_net* net, const std::string& p, int ch, Fold* f) {
+    const HostTensor *w, *b, *m, *v;
+    if (get(net, p + ".weight", {ch}, &w) || get(net, p + ".bias", {ch}, &b) || get(net, p + ".running_mean", {ch}, &m) ||
+        get(net, p + ".running_var", {ch}, &v))
+        return 1;
+    f->scale.resize(ch);
+    f->shift.resize(ch);
+    for (int c = 0; c < ch; ++c) {
+        const float s = w->data[c] / std::sqrt(v->data[c] + 1e-5f);
+        f->scale[c] = s;
+        f->shift[c] = b->data[c] - m->data[c] * s;
+    }
+    return 0;
+}
+
+// Pack one [Cout][Cin][ks][ks] conv (scaled per cout) into the layout conv_igemm.hip streams:
+//   [cb][chunk][tap][G][s][lane][t]  ->  W[cb*64 + s*32 + (lane&31)][chunk*CB + G*8 + 4*(lane>>5) + t][tap]
+static void pack_conv(const float* w, const float* scale, int cout, int cin, int ks, int CB, std::vector<float>* out) {
+    const int T = ks * ks, NG = CB / 8, nchunk = cin / CB, ncb = cout / 64;
+    const size_t base = out->size();
+    out->resize(base + (size_t)cout * cin * T);
+    float* o = out->data() + base;
+    size_t idx = 0;
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int tap = 0; tap < T; ++tap)
+                for (int G = 0; G < NG; ++G)
+                    for (int s = 0; s < 2; ++s)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int t = 0; t < 4; ++t) {
+                                const int co = cb * 64 + s * 32 + (lane & 31);
+                                const int ci = ch * CB + G * 8 + 4 * (lane >> 5) + t;
+                                o[idx++] = w[((size_t)co * cin + ci) * T + tap] * (scale ? scale[co] : 1.f);
+                            }
+}
+
+static int make_conv(cerb_net* net, const std::string& name, const std::vector<std::string>& wkeys,
+                     const std::vector<std::string>& bkeys, const std::vector<std::string>& bnkeys, int cout, int cin, int ks,
+                     int stride) {
+    // one entry per group
+    const int CB = cerb_conv_chunk(ks, stride);
+    if (cout % 64 || cin % CB) return fail("conv " + name + ": unsupported channel counts");
+    std::vector<float> wp, bp;
+    for (size_t g = 0; g < wkeys.size(); ++g) {
+        const HostTensor* w;
+        if (get(net, wkeys[g], {cout, cin, ks, ks}, &w)) return 1;
+        Fold f;
+        bool have_bn = !bnkeys.empty();
+        if (have_bn && bn_fold(net, bnkeys[g], cout, &f)) return 1;
+        pack_conv(w->data.data(), have_bn ? f.scale.data() : nullptr, cout, cin, ks, CB, &wp);
+        const HostTensor* b = nullptr;
+        if (!bkeys.empty() && get(net, bkeys[g], {cout}, &b)) return 1;
+        for (int c = 0; c < cout; ++c) {
+            float v = b ? b->data[c] : 0.f;
+            if (have_bn) v = v * f.scale[c] + f.shift[c];
+            bp.push_back(v);
+        }
+    }
+    PackedConv pc;
+    pc.cin = cin; pc.cout = cout; pc.ks = ks; pc.stride = stride; pc.groups = (int)wkeys.size();
+    if (upload(net, wp, &pc.w) || upload(net, bp, &pc.b)) return 1;
+    net->conv[name] = pc;
+    return 0;
+}
+
+static const int kLayers[4] = {3, 4, 6, 3};
+static const int kFilters[5] = {64, 64, 128, 256, 512};
+
+extern "C" int cerb_net_finalize(cerb_net* net) {
+    if (!net) return fail("cerb_net_finalize: null handle");
+    if (net->finalized) return 0;
+    // ---- stem (7x7, Cin=3) ------------------------------------------------------------------------------------
+    {
+        const HostTensor* w;
+        if (get(net, "backbone.conv1.weight", {64, 3, 7, 7}, &w)) return 1;
+        Fold f;
+        if (bn_fold(net, "backbone.bn1", 64, &f)) return 1;
+        std::vector<float> wp(7 * 12 * 2 * 64, 0.f);
+        for (int ky = 0; ky < 7; ++ky)
+            for (int t = 0; t < 12; ++t)
+                for (int s = 0; s < 2; ++s)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int co = s * 32 + (lane & 31), kk = 2 * t + (lane >> 5);
+                        float v = 0.f;
+                        if (kk < 21) {
+                            const int kx = kk / 3, c = kk % 3;
+                            v = w->data[(((size_t)co * 3 + c) * 7 + ky) * 7 + kx] * f.scale[co];
+                        }
+                        wp[((ky * 12 + t) * 2 + s) * 64 + lane] = v;
+                    }
+        if (upload(net, wp, &net->stem_w) || upload(net, f.shift, &net->stem_b)) return 1;
+    }
+    // ---- residual trunk ---------------------------------------------------------------------------------------
+    int inpl = 64;
+    for (int li = 0; li < 4; ++li) {
+        const int planes = kFilters[li + 1];
+        for (int b = 0; b < kLayers[li]; ++b) {
+            const std::string p = "backbone.layer" + std::to_string(li + 1) + "." + std::to_string(b);
+            const int stride = (b == 0 && li > 0) ? 2 : 1;
+            if (make_conv(net, p + ".conv1", {p + ".conv1.weight"}, {}, {p + ".bn1"}, planes, inpl, 3, stride)) return 1;
+            if (make_conv(net, p + ".conv2", {p + ".conv2.weight"}, {}, {p + ".bn2"}, planes, planes, 3, 1)) return 1;
+            if (stride != 1 || inpl != planes)
+                if (make_conv(net, p + ".downsample", {p + ".downsample.0.weight"}, {}, {p + ".downsample.1"}, planes, inpl, 1, stride)) return 1;
+            inpl = planes;
+        }
+    }
+    if (make_conv(net, "conv_map", {"conv_map.weight"}, {}, {}, 256, 512, 1, 1)) return 1;
+    // ---- dense decoders: grouped over decoders ----------------------------------------------------------------
+    const int dec_in[4] = {256, 128, 64, 64};
+    const int dec_u[4][2] = {{256, 128}, {128, 64}, {64, 64}, {64, 64}};
+    if (!net->dense_idx.empty()) {
+        for (int u = 0; u < 4; ++u) {
+            int c = dec_in[u];
+            for (int j = 0; j < 2; ++j) {
+                std::vector<std::string> wk, bk, bnk;
+                for (int di : net->dense_idx) {
+                    const std::string p = "decoder_head." + net->dec[di].name + "." + std::to_string(u) + ".block." + std::to_string(j);
+                    wk.push_back(p + ".conv.weight");
+                    bk.push_back(p + ".conv.bias");
+                    bnk.push_back(p + ".bn");
+                }
+                if (make_conv(net, "dec." + std::to_string(u) + "." + std::to_string(j), wk, bk, bnk, dec_u[u][j], c, 3, 1)) return 1;
+                c = dec_u[u][j];
+            }
+        }
+        for (int di : net->dense_idx) {
+            const DecoderCfg& d = net->dec[di];
+            const std::string p = "output_head." + d.name + "." + d.head + ".x";
+            const HostTensor *w1, *b1, *w2, *b2;
+            Fold f;
+            if (get(net, p + ".0.block.0.conv.weight", {96, 64, 1, 1}, &w1) || get(net, p + ".0.block.0.conv.bias", {96}, &b1) ||
+                bn_fold(net, p + ".0.block.0.bn", 96, &f) || get(net, p + ".1.conv.weight", {d.out_ch, 96, 1, 1}, &w2) ||
+                get(net, p + ".1.conv.bias", {d.out_ch}, &b2))
+                return 1;
+            std::vector<float> w1p(3 * 8 * 64 * 4), b1p(96), w2p(48 * 64, 0.f), b2p(32, 0.f);
+            for (int blk = 0; blk < 3; ++blk)
+                for (int G = 0; G < 8; ++G)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int t = 0; t < 4; ++t) {
+                            const int hid = blk * 32 + (lane & 31), ci = G * 8 + 4 * (lane >> 5) + t;
+                            w1p[((blk * 8 + G) * 64 + lane) * 4 + t] = w1->data[(size_t)hid * 64 + ci] * f.scale[hid];
+                        }
+            for (int c = 0; c < 96; ++c) b1p[c] = b1->data[c] * f.scale[c] + f.shift[c];
+            for (int blk = 0; blk < 3; ++blk)
+                for (int r = 0; r < 16; ++r)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int i = lane & 31, hh = lane >> 5;
+                        const int hid = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        w2p[(blk * 16 + r) * 64 + lane] = (i < d.out_ch) ? w2->data[(size_t)i * 96 + hid] : 0.f;
+                    }
+            for (int c = 0; c < d.out_ch; ++c) b2p[c] = b2->data[c];
+            float *dw1, *db1, *dw2, *db2;
+            if (upload(net, w1p, &dw1) || upload(net, b1p, &db1) || upload(net, w2p, &dw2) || upload(net, b2p, &db2)) return 1;
+            net->head_w1.push_back(dw1); net->head_b1.push_back(db1); net->head_w2.push_back(dw2); net->head_b2.push_back(db2);
+        }
+    }
+    // ---- Patch-Class branch -----------------------------------------------------------------------------------
+    if (net->pc_idx >= 0) {
+        const int oc = net->dec[net->pc_idx].out_ch;
+        const std::string p = "decoder_head.Patch-Class";
+        Fold f1, f2;
+        const HostTensor *w1, *b1, *w2, *b2;
+        if (bn_fold(net, p + ".bn1", 512, &f1) || bn_fold(net, p + ".bn2", 256, &f2) || get(net, p + ".conv1.weight", {256, 512, 1, 1}, &w1) ||
+            get(net, p + ".conv1.bias", {256}, &b1) || get(net, p + ".conv2.weight", {oc, 256, 1, 1}, &w2) || get(net, p + ".conv2.bias", {oc}, &b2))
+            return 1;
+        std::vector<float> w1t(512 * 256), b1f(256), w2t(256 * 16, 0.f), b2f(16, 0.f);
+        for (int o = 0; o < 256; ++o) {
+            for (int c = 0; c < 512; ++c) w1t[(size_t)c * 256 + o] = w1->data[(size_t)o * 512 + c] * f2.scale[o];
+            b1f[o] = b1->data[o] * f2.scale[o] + f2.shift[o];
+        }
+        for (int o = 0; o < oc; ++o) {
+            for (int c = 0; c < 256; ++c) w2t[(size_t)c * 16 + o] = w2->data[(size_t)o * 256 + c];
+            b2f[o] = b2->data[o];
+        }
+        if (upload(net, f1.scale, &net->pc_bn1s) || upload(net, f1.shift, &net->pc_bn1b) || upload(net, w1t, &net->pc_w1t) ||
+            upload(net, b1f, &net->pc_b1) || upload(net, w2t, &net->pc_w2t) || upload(net, b2f, &net->pc_b2))
+            return 1;
+    }
+    net->host.clear();
+    net->finalized = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static int run_conv(cerb_net* net, const std::string& name, const float* in, const float* prev, const float* resid, float* out, int N,
+                    int H, int W, int relu, int mode, long long in_gs, long long prev_gs, hipStream_t st, double* macs) {
+    auto it = net->conv.find(name);
+    if (it == net->conv.end()) return fail("internal: conv " + name + " not packed");
+    const PackedConv& c = it->second;
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.in = in; p.prev = prev; p.wpack = c.w; p.bias = c.b; p.resid = resid; p.out = out;
+    p.N = N; p.H = H; p.W = W; p.Cin = c.cin; p.Cout = c.cout;
+    p.Ho = (c.stride == 2) ? H / 2 : H;
+    p.Wo = (c.stride == 2) ? W / 2 : W;
+    p.relu = relu;
+    p.groups = c.groups;
+    p.in_gs = in_gs; p.prev_gs = prev_gs;
+    p.w_gs = (long long)c.cout * c.cin * c.ks * c.ks;
+    p.bias_gs = c.cout;
+    p.resid_gs = 0;
+    p.out_gs = (long long)N * p.Ho * p.Wo * c.cout;
+    if (macs) {
+        *macs += (double)c.groups * N * p.Ho * p.Wo * (double)c.cout * c.cin * c.ks * c.ks;
+        if (!out) return 0;
+    }
+    HIP_OK(cerb_launch_conv(p, c.ks, c.stride, mode, st));
+    return 0;
+}
+
+static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st, double* macs) {
+    const bool dry = (macs != nullptr) && (io->tiles == nullptr);
+    const int N = io->n, H = io->h, W = io->w;
+    if (N <= 0 || H <= 0 || W <= 0 || (H % 16) || (W % 16)) return fail("cerb_net_forward: tile H,W must be positive multiples of 16");
+    const int out_h = io->out_h > 0 ? io->out_h : H, out_w = io->out_w > 0 ? io->out_w : W;
+    if (out_h > H || out_w > W) return fail("cerb_net_forward: crop larger than tile");
+    const int hs[5] = {H, H / 2, H / 4, H / 8, H / 16}, ws[5] = {W, W / 2, W / 4, W / 8, W / 16};
+    const size_t D = net->dense_idx.size();
+    if (!dry) {
+        if (net->x0.ensure((size_t)N * H * W * 64 * 4) || net->pool.ensure((size_t)N * hs[1] * ws[1] * 64 * 4)) return fail("workspace allocation failed");
+        for (int i = 1; i < 5; ++i)
+            if (net->x[i].ensure((size_t)N * hs[i] * ws[i] * kFilters[i] * 4)) return fail("workspace allocation failed");
+        if (net->ta.ensure((size_t)N * hs[1] * ws[1] * 64 * 4) || net->tb.ensure((size_t)N * hs[1] * ws[1] * 64 * 4) ||
+            net->cm.ensure((size_t)N * hs[4] * ws[4] * 256 * 4))
+            return fail("workspace allocation failed");
+        if (D) {
+            // dmid holds the first conv of a level: sizes (per decoder) 32^2*256, 64^2*128, 128^2*64, 256^2*64 -> max is the last
+            if (net->dmid.ensure(D * (size_t)N * H * W * 64 * 4)) return fail("workspace allocation failed");
+            const int oc[4] = {128, 64, 64, 64};
+            for (int u = 0; u < 4; ++u)
+                if (net->dout[u].ensure(D * (size_t)N * hs[3 - u] * ws[3 - u] * oc[u] * 4)) return fail("workspace allocation failed");
+        }
+    }
+    // ---- encoder ----------------------------------------------------------------------------------------------
+    if (macs) *macs += (double)N * H * W * 64.0 * 147.0;
+    if (!dry) {
+        StemParams sp;
+        sp.tiles = io->tiles; sp.wpack = net->stem_w; sp.bias = net->stem_b; sp.out = net->x0.p; sp.N = N; sp.H = H; sp.W = W;
+        sp.tiles_x = sp.tiles_y = 0;
+        HIP_OK(cerb_launch_stem(sp, st));
+        HIP_OK(cerb_launch_maxpool(net->x0.p, net->pool.p, N, H, W, 64, st));
+    }
+    float* cur = dry ? nullptr : net->pool.p;
+    int inpl = 64;
+    for (int li = 0; li < 4; ++li) {
+        const int planes = kFilters[li + 1];
+        const int Hi = (li == 0) ? hs[1] : hs[li], Wi = (li == 0) ? ws[1] : ws[li];  // input resolution of this layer
+        for (int b = 0; b < kLayers[li]; ++b) {
+            const std::string p = "backbone.layer" + std::to_string(li + 1) + "." + std::to_string(b);
+            const int stride = (b == 0 && li > 0) ? 2 : 1;
+            const int hin = (b == 0) ? Hi : hs[li + 1], win = (b == 0) ? Wi : ws[li + 1];
+            float* t1 = dry ? nullptr : net->ta.p;
+            // block output: ping-pong between tb and x[li+1]; make the LAST block of the layer land in x[li+1]
+            const bool last = (b == kLayers[li] - 1);
+            float* outb = dry ? nullptr : (((kLayers[li] - 1 - b) % 2 == 0) ? net->x[li + 1].p : net->tb.p);
+            (void)last;
+            const float* idt = cur;
+            if (run_conv(net, p + ".conv1", cur, nullptr, nullptr, t1, N, hin, win, 1, 0, 0, 0, st, macs)) return 1;
+            if (stride != 1 || inpl != planes) {
+                // downsample(x): 1x1 stride-2 conv + BN, written to dmid-free scratch: reuse pool buffer (dead after layer1.0)
+                float* ds = dry ? nullptr : net->pool.p;
+                if (run_conv(net, p + ".downsample", cur, nullptr, nullptr, ds, N, hin, win, 0, 0, 0, 0, st, macs)) return 1;
+                idt = ds;
+            }
+            if (run_conv(net, p + ".conv2", t1, nullptr, idt, outb, N, hs[li + 1], ws[li + 1], 1, 0, 0, 0, st, macs)) return 1;
+            cur = outb;
+            inpl = planes;
+        }
+    }
+    if (run_conv(net, "conv_map", dry ? nullptr : net->x[4].p, nullptr, nullptr, dry ? nullptr : net->cm.p, N, hs[4], ws[4], 0, 0, 0, 0, st, macs)) return 1;
+
+    const long long tile_stride = io->tile_stride ? io->tile_stride : (long long)out_h * out_w;
+    const long long row_stride = io->row_stride ? io->row_stride : out_w;
+    // ---- Patch-Class ------------------------------------------------------------------------------------------
+    if (net->pc_idx >= 0) {
+        if (macs) *macs += (double)N * (512.0 * 256 + 256.0 * net->dec[net->pc_idx].out_ch);
+        const bool want = io->out && io->out[net->pc_idx];
+        const bool wantl = io->logits && io->logits[net->pc_idx];
+        if (!dry && (want || wantl)) {
+            PatchClassParams pp;
+            memset(&pp, 0, sizeof(pp));
+            pp.x4 = net->x[4].p; pp.bn1_s = net->pc_bn1s; pp.bn1_b = net->pc_bn1b; pp.w1t = net->pc_w1t; pp.b1 = net->pc_b1;
+            pp.w2t = net->pc_w2t; pp.b2 = net->pc_b2;
+            pp.N = N; pp.Hf = hs[4]; pp.Wf = ws[4]; pp.out_ch = net->dec[net->pc_idx].out_ch;
+            pp.out_h = out_h; pp.out_w = out_w;
+            pp.logits = wantl ? io->logits[net->pc_idx] : nullptr;
+            pp.out = want ? (float*)io->out[net->pc_idx] : nullptr;
+            pp.tile_off = io->tile_off; pp.tile_stride = tile_stride; pp.row_stride = row_stride;
+            HIP_OK(cerb_launch_patch_class(pp, st));
+        }
+    }
+    // ---- dense decoders (all decoders of a level in ONE grouped launch) ---------------------------------------
+    if (D) {
+        const float* skips[4] = {dry ? nullptr : net->x[3].p, dry ? nullptr : net->x[2].p, dry ? nullptr : net->x[1].p, dry ? nullptr : net->x0.p};
+        const float* prev = dry ? nullptr : net->cm.p;
+        long long prev_gs = 0;  // conv_map output is shared by every decoder
+        const int oc[4] = {128, 64, 64, 64};
+        for (int u = 0; u < 4; ++u) {
+            const int hh = hs[3 - u], ww = ws[3 - u];
+            const std::string n0 = "dec." + std::to_string(u) + ".0", n1 = "dec." + std::to_string(u) + ".1";
+            const int cmid = net->conv[n0].cout;
+            if (run_conv(net, n0, skips[u], prev, nullptr, dry ? nullptr : net->dmid.p, N, hh, ww, 1, 1, 0, prev_gs, st, macs)) return 1;
+            if (run_conv(net, n1, dry ? nullptr : net->dmid.p, nullptr, nullptr, dry ? nullptr : net->dout[u].p, N, hh, ww, 1, 0,
+                         (long long)N * hh * ww * cmid, 0, st, macs))
+                return 1;
+            prev = dry ? nullptr : net->dout[u].p;
+            prev_gs = (long long)N * hh * ww * oc[u];
+        }
+        for (size_t k = 0; k < D; ++k) {
+            const int di = net->dense_idx[k];
+            const DecoderCfg& d = net->dec[di];
+            if (macs) *macs += (double)N * H * W * (64.0 * 96 + 96.0 * d.out_ch);
+            const bool want = io->out && io->out[di];
+            const bool wantl = io->logits && io->logits[di];
+            if (dry || !(want || wantl)) continue;
+            HeadParams hp;
+            memset(&hp, 0, sizeof(hp));
+            hp.feat = net->dout[3].p + k * (size_t)N * H * W * 64;
+            hp.w1p = net->head_w1[k]; hp.b1 = net->head_b1[k]; hp.w2p = net->head_w2[k]; hp.b2 = net->head_b2[k];
+            hp.N = N; hp.H = H; hp.W = W; hp.out_ch = d.out_ch; hp.kind = d.kind;
+            hp.crop_y0 = (int)((H - out_h) * 0.5); hp.crop_x0 = (int)((W - out_w) * 0.5);  // cropping_center, misc/utils.py:94-104
+            hp.out_h = want ? out_h : 0; hp.out_w = want ? out_w : 0;
+            hp.logits = wantl ? io->logits[di] : nullptr;
+            if (want) {
+                if (d.kind == 0) hp.out_inst = (float*)io->out[di];
+                else if (io->type_is_u8) hp.out_type_u8 = (unsigned char*)io->out[di];
+                else hp.out_type_i64 = (long long*)io->out[di];
+            }
+            hp.tile_off = io->tile_off; hp.tile_stride = tile_stride; hp.row_stride = row_stride;
+            HIP_OK(cerb_launch_head(hp, st));
+        }
+    }
+    if (!dry && io->feats) {
+        const float* src[6] = {net->x0.p, net->x[1].p, net->x[2].p, net->x[3].p, net->cm.p, net->x[4].p};
+        const size_t nb[6] = {(size_t)N * H * W * 64, (size_t)N * hs[1] * ws[1] * 64, (size_t)N * hs[2] * ws[2] * 128,
+                              (size_t)N * hs[3] * ws[3] * 256, (size_t)N * hs[4] * ws[4] * 256, (size_t)N * hs[4] * ws[4] * 512};
+        for (int i = 0; i < 6; ++i)
+            if (io->feats[i]) HIP_OK(hipMemcpyAsync(io->feats[i], src[i], nb[i] * 4, hipMemcpyDeviceToDevice, st));
+    }
+    return 0;
+}
+
+extern "C" int cerb_net_forward(cerb_net* net, const cerb_forward_io* io, void* hip_stream) {
+    if (!net || !io) return fail("cerb_net_forward: null argument");
+    if (!net->finalized) return fail("cerb_net_forward: call cerb_net_finalize first");
+    if (!io->tiles) return fail("cerb_net_forward: null tiles pointer");
+    return forward_impl(net, io, (hipStream_t)hip_stream, nullptr);
+}
+
+extern "C" double cerb_net_flops(const cerb_net* net, int n, int h, int w) {
+    if (!net || !net->finalized) return -1.0;
+    cerb_forward_io io;
+    memset(&io, 0, sizeof(io));
+    io.n = n; io.h = h; io.w = w;
+    double macs = 0.0;
+    if (forward_impl(const_cast<cerb_net*>(net), &io, nullptr, &macs)) return -1.0;
+    return 2.0 * macs;
+}
+
+// ---- events ----------------------------------------------------------------------------------------------------
+extern "C" int cerb_event_create(void** ev) {
+    hipEvent_t e;
+    HIP_OK(hipEventCreate(&e));
+    *ev = (void*)e;
+    return 0;
+}
+extern "C" int cerb_event_record(void* ev, void* hip_stream) {
+    HIP_OK(hipEventRecord((hipEvent_t)ev, (hipStream_t)hip_stream));
+    return 0;
+}
+extern "C" int cerb_event_elapsed_ms(void* a, void* b, float* ms) {
+    HIP_OK(hipEventSynchronize((hipEvent_t)b));
+    HIP_OK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return 0;
+}
+extern "C" int cerb_event_destroy(void* ev) {
+    HIP_OK(hipEventDestroy((hipEvent_t)ev));
+    return 0;
+}

@@ -1,0 +1,58 @@
+// Shared declarations for the gfx950 kernels of the Cerberus tiled-inference path.
+// Everything here is CDNA4-only (wave64, v_mfma_f32_32x32x2_f32); there is no other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CERB_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution (conv_igemm.hip).  "Swapped" GEMM: D[cout][pixel] = W[cout][k] X[k][pixel]
+// so that one lane owns one pixel and 4 consecutive couts per accumulator quad -> float4 NHWC stores,
+// and the accumulators are directly the B operand of a following 1x1 GEMM (head fusion).
+// ---------------------------------------------------------------------------------------------
+struct ConvParams {
+    const float* in;     // NHWC fp32 [G][N][H][W][Cin]  (MODE 1: the skip tensor)
+    const float* prev;   // MODE 1 only: [G][N][H/2][W/2][Cin], bilinearly upsampled x2 and added to `in`
+    const float* wpack;  // packed, BN-folded weights (see pack_conv_weights)
+    const float* bias;   // [G][Cout] BN-folded bias
+    const float* resid;  // optional residual [G][N][Ho][Wo][Cout] added before ReLU
+    float* out;          // [G][N][Ho][Wo][Cout]
+    int N, H, W, Cin, Ho, Wo, Cout;
+    int relu;
+    int tiles_x, tiles_y;  // output tiles per image
+    int groups;
+    long long in_gs, prev_gs, w_gs, bias_gs, resid_gs, out_gs;  // per-group strides in elements
+};
+
+// Fused output head (head.hip): 1x1 64->96 (+BN+ReLU) -> 1x1 96->out_ch -> softmax -> INST probs / TYPE argmax
+struct HeadParams {
+    const float* feat;   // [N][H][W][64] NHWC (decoder output)
+    const float* w1p;    // packed W1 (BN folded): [3 blk][8 G][64 lane][4]
+    const float* b1;     // [96]
+    const float* w2p;    // packed W2: [48 step][64 lane]  (rows >= out_ch are zero)
+    const float* b2;     // [32] (padded)
+    int N, H, W;
+    int out_ch;          // 3 or 7 (<= 8)
+    int kind;            // 0 = INST (write softmax ch 1..2 as float2), 1 = TYPE (write argmax)
+    int crop_y0, crop_x0, out_h, out_w;   // centre crop window in tile coordinates
+    float* logits;       // optional [N][H][W][out_ch] NHWC (tests)
+    float* out_inst;     // kind 0: float [..][2]
+    unsigned char* out_type_u8;  // kind 1, optional
+    long long* out_type_i64;     // kind 1, optional
+    const long long* tile_off;   // optional per-tile element offset (in pixels) into the destination canvas
+    long long tile_stride;       // pixels between consecutive tiles when tile_off == nullptr
+    long long row_stride;        // pixels between consecutive output rows
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    // Bijective blockIdx -> logical id so that each XCD (bid % 8) owns a contiguous chunk of logical ids
+    // (neighbouring tiles / cout-blocks share halo + weights in that XCD's L2).  Speed only.
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

@@ -1,0 +1,364 @@
+// Non-3x3 kernels of the Cerberus network path for gfx950:
+//   stem_conv7x7_kernel  : uint8 tile -> /255 -> 7x7 s1 p3 conv (3->64) + BN + ReLU   (reference resnet.py:195-197,276-278;
+//                          net_desc.py:147 for the /255)
+//   maxpool3x3s2_kernel  : MaxPool2d(3, stride 2, pad 1)                              (reference resnet.py:201,280)
+//   head_kernel          : 1x1 64->96 +BN+ReLU -> 1x1 96->out -> softmax -> crop -> INST probs / TYPE argmax, written
+//                          straight into the destination canvas (reference net_layers.py:31-38, run_desc.py:451-491)
+//   patch_class_kernel   : centre-crop 9x9 -> avg-pool -> BN-ReLU-1x1-BN-ReLU-1x1 -> argmax(softmax) -> broadcast
+//                          (reference net_desc.py:169-180, run_desc.py:457-487)
+#include "cerb_common.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stem: implicit GEMM with K = 7 rows x 24 (= 7 taps x 3 ch = 21, zero-padded to 24), swapped GEMM as in conv_igemm.
+// B operand (pixels) is read from an LDS tile of floats laid out [row][col*3 + c]; for tap-row ky the 21 values a pixel
+// needs are contiguous, so k-step t / k-slot h reads LDS[(py+ky)][px*3 + 2t + h].
+// ---------------------------------------------------------------------------------------------------------------
+struct StemParams {
+    const unsigned char* tiles;  // [N][H][W][3]
+    const float* wpack;          // [7 ky][12 t][2 s][64 lane]
+    const float* bias;           // [64]
+    float* out;                  // [N][H][W][64]
+    int N, H, W, tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemParams p) {
+    constexpr int TH = 8, TW = 32, IH = TH + 6, IW = TW + 6, ROW = 120;  // ROW >= IW*3 + 3 (k padding)
+    __shared__ __attribute__((aligned(16))) float wl[7 * 12 * 2 * 64];
+    __shared__ __attribute__((aligned(16))) float xl[IH * ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    for (int i = tid; i < 7 * 12 * 2 * 64; i += 256) wl[i] = p.wpack[i];
+    const int ntile = p.N * p.tiles_y * p.tiles_x;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        int t_ = tile;
+        const int tx = t_ % p.tiles_x;
+        t_ /= p.tiles_x;
+        const int ty = t_ % p.tiles_y;
+        const int n = t_ / p.tiles_y;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        __syncthreads();
+        const unsigned char* img = p.tiles + (long long)n * p.H * p.W * 3;
+        for (int i = tid; i < IH * ROW; i += 256) {
+            const int iy = i / ROW, c = i % ROW;
+            const int gy = oy0 - 3 + iy, gx = ox0 - 3 + c / 3;
+            float v = 0.f;
+            if (c < IW * 3 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                v = (float)img[((long long)gy * p.W + gx) * 3 + c % 3] / 255.0f;
+            xl[i] = v;
+        }
+        __syncthreads();
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[s][q][r] = 0.f;
+        const int b0 = (wave * 2 + 0) * ROW + j * 3 + h;  // subtile q = row (wave*2+q), pixel col j
+        const int b1 = (wave * 2 + 1) * ROW + j * 3 + h;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+            for (int t = 0; t < 12; ++t) {
+                const float a0 = wl[((ky * 12 + t) * 2 + 0) * 64 + lane];
+                const float a1 = wl[((ky * 12 + t) * 2 + 1) * 64 + lane];
+                const float x0 = xl[b0 + ky * ROW + 2 * t];
+                const float x1 = xl[b1 + ky * ROW + 2 * t];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, x0, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x0, acc[1][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, x1, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x1, acc[1][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int oy = oy0 + wave * 2 + q, ox = ox0 + j;
+            if (oy >= p.H || ox >= p.W) continue;
+            float* o = p.out + (((long long)n * p.H + oy) * p.W + ox) * 64;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int co = s * 32 + rq * 8 + h * 4;
+                    f32x4 v = {acc[s][q][rq * 4 + 0], acc[s][q][rq * 4 + 1], acc[s][q][rq * 4 + 2], acc[s][q][rq * 4 + 3]};
+                    v = v + *reinterpret_cast<const f32x4*>(p.bias + co);
+                    v[0] = fmaxf(v[0], 0.f);
+                    v[1] = fmaxf(v[1], 0.f);
+                    v[2] = fmaxf(v[2], 0.f);
+                    v[3] = fmaxf(v[3], 0.f);
+                    *reinterpret_cast<f32x4*>(o + co) = v;
+                }
+        }
+    }
+}
+
+hipError_t cerb_launch_stem(StemParams p, hipStream_t st) {
+    p.tiles_x = (p.W + 31) / 32;
+    p.tiles_y = (p.H + 7) / 8;
+    const long long ntile = (long long)p.N * p.tiles_x * p.tiles_y;
+    const unsigned grid = (unsigned)(ntile < 256 * 6 ? ntile : 256 * 6);
+    hipLaunchKernelGGL(stem_conv7x7_kernel, dim3(grid), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int C, int Ho, int Wo) {
+    const long long total = (long long)N * Ho * Wo * (C / 4);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % (C / 4));
+        long long r = i / (C / 4);
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int y = oy * 2 - 1 + ky;
+            if (y < 0 || y >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int x = ox * 2 - 1 + kx;
+                if (x < 0 || x >= W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(in + (((long long)n * H + y) * W + x) * C + c4 * 4);
+                m[0] = fmaxf(m[0], v[0]);
+                m[1] = fmaxf(m[1], v[1]);
+                m[2] = fmaxf(m[2], v[2]);
+                m[3] = fmaxf(m[3], v[3]);
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = m;
+    }
+}
+
+hipError_t cerb_launch_maxpool(const float* in, float* out, int N, int H, int W, int C, hipStream_t st) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)N * Ho * Wo * (C / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, N, H, W, C, Ho, Wo);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Output head.  Everything stays in registers: GEMM1 is swapped (hidden x pixel) so its accumulators ARE the B
+// operand of GEMM2 (k-slot h at step (blk,r) <-> hidden unit blk*32 + (r&3) + 8*(r>>2) + 4*h).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const long long npix = (long long)p.N * p.H * p.W;
+    const long long pbase = (long long)blockIdx.x * 256 + wave * 64;
+
+    f32x16 acc1[3][2];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[b][q][r] = 0.f;
+
+    long long pix[2];
+    const float* xp[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        pix[q] = pbase + q * 32 + j;
+        const long long pc = pix[q] < npix ? pix[q] : npix - 1;
+        xp[q] = p.feat + pc * 64 + 4 * h;
+    }
+    const f32x4* w1v = reinterpret_cast<const f32x4*>(p.w1p) + lane;
+#pragma unroll
+    for (int G = 0; G < 8; ++G) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(xp[0] + G * 8);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(xp[1] + G * 8);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const f32x4 a = w1v[(b * 8 + G) * 64];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc1[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], x0[t], acc1[b][0], 0, 0, 0);
+                acc1[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], x1[t], acc1[b][1], 0, 0, 0);
+            }
+        }
+    }
+    // + bias, ReLU (BN folded into W1/b1)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b1 + b * 32 + rq * 8 + h * 4);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc1[b][q][rq * 4 + e] = fmaxf(acc1[b][q][rq * 4 + e] + bb[e], 0.f);
+        }
+    // GEMM2: logits[out][pixel]
+    f32x16 acc2[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[q][r] = 0.f;
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float a = p.w2p[(b * 16 + r) * 64 + lane];
+            acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc1[b][0][r], acc2[0], 0, 0, 0);
+            acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc1[b][1][r], acc2[1], 0, 0, 0);
+        }
+    // lane (pixel j, half h) holds logits 4h..4h+3 in acc2[q][0..3]
+    const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.b2 + 4 * h);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float mine[4], other[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mine[e] = acc2[q][e] + b2[e];
+            other[e] = __shfl_xor(mine[e], 32);
+        }
+        float lg[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lg[e] = h ? other[e] : mine[e];
+            lg[4 + e] = h ? mine[e] : other[e];
+        }
+        if (h != 0 || pix[q] >= npix) continue;
+        const long long P = pix[q];
+        if (p.logits) {
+            for (int e = 0; e < p.out_ch; ++e) p.logits[P * p.out_ch + e] = lg[e];
+        }
+        // softmax over out_ch (max-subtracted, as torch.softmax)
+        float mx = lg[0];
+#pragma unroll
+        for (int e = 1; e < 8; ++e)
+            if (e < p.out_ch) mx = fmaxf(mx, lg[e]);
+        float ex[8], sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ex[e] = (e < p.out_ch) ? expf(lg[e] - mx) : 0.f;
+            sum += ex[e];
+        }
+        const int x = (int)(P % p.W);
+        const long long r_ = P / p.W;
+        const int y = (int)(r_ % p.H);
+        const int n = (int)(r_ / p.H);
+        const int cy = y - p.crop_y0, cx = x - p.crop_x0;
+        if (cy < 0 || cy >= p.out_h || cx < 0 || cx >= p.out_w) continue;
+        const long long dst = (p.tile_off ? p.tile_off[n] : (long long)n * p.tile_stride) + (long long)cy * p.row_stride + cx;
+        if (p.kind == 0) {
+            float2 o;
+            o.x = ex[1] / sum;
+            o.y = ex[2] / sum;
+            *reinterpret_cast<float2*>(p.out_inst + dst * 2) = o;
+        } else {
+            int best = 0;
+            float bv = ex[0] / sum;
+#pragma unroll
+            for (int e = 1; e < 8; ++e) {
+                const float pe = ex[e] / sum;
+                if (e < p.out_ch && pe > bv) {
+                    bv = pe;
+                    best = e;
+                }
+            }
+            if (p.out_type_i64) p.out_type_i64[dst] = best;
+            if (p.out_type_u8) p.out_type_u8[dst] = (unsigned char)best;
+        }
+    }
+}
+
+hipError_t cerb_launch_head(const HeadParams& p, hipStream_t st) {
+    const long long npix = (long long)p.N * p.H * p.W;
+    const long long blocks = (npix + 255) / 256;
+    hipLaunchKernelGGL(head_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct PatchClassParams {
+    const float* x4;      // [N][Hf][Wf][512] (pre-conv_map bottom features, net_desc.py:152)
+    const float* bn1_s;   // [512] scale
+    const float* bn1_b;   // [512] shift
+    const float* w1t;     // [512][256]  (conv1 with bn2 folded, transposed for coalescing)
+    const float* b1;      // [256]
+    const float* w2t;     // [256][16]   (conv2, transposed, padded)
+    const float* b2;      // [16]
+    int N, Hf, Wf, out_ch;
+    int out_h, out_w;
+    float* logits;        // optional [N][out_ch]
+    float* out;           // optional: class id broadcast, addressed like the heads
+    const long long* tile_off;
+    long long tile_stride, row_stride;
+};
+
+__global__ __launch_bounds__(256) void patch_class_kernel(PatchClassParams p) {
+    __shared__ float v[512];
+    __shared__ float hid[256];
+    __shared__ float lg[16];
+    __shared__ int cls_s;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    int y0 = 0, x0 = 0, ch = p.Hf, cw = p.Wf;
+    if (p.Hf != 9 && p.Wf != 9) {  // net_desc.py:173-174 (crops only when both differ from 9)
+        y0 = (int)((p.Hf - 9) * 0.5);
+        x0 = (int)((p.Wf - 9) * 0.5);
+        ch = 9;
+        cw = 9;
+    }
+    const float* x = p.x4 + (long long)n * p.Hf * p.Wf * 512;
+    for (int c = tid; c < 512; c += 256) {
+        float s = 0.f;
+        for (int yy = 0; yy < ch; ++yy)
+            for (int xx = 0; xx < cw; ++xx) s += x[((long long)(y0 + yy) * p.Wf + (x0 + xx)) * 512 + c];
+        s = s / (float)(ch * cw);
+        s = s * p.bn1_s[c] + p.bn1_b[c];
+        v[c] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    {
+        float s = 0.f;
+        for (int c = 0; c < 512; ++c) s = fmaf(p.w1t[c * 256 + tid], v[c], s);
+        hid[tid] = fmaxf(s + p.b1[tid], 0.f);
+    }
+    __syncthreads();
+    if (tid < 16) {
+        float s = 0.f;
+        if (tid < p.out_ch) {
+            for (int c = 0; c < 256; ++c) s = fmaf(p.w2t[c * 16 + tid], hid[c], s);
+            s += p.b2[tid];
+            if (p.logits) p.logits[n * p.out_ch + tid] = s;
+        }
+        lg[tid] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float mx = lg[0];
+        for (int e = 1; e < p.out_ch; ++e) mx = fmaxf(mx, lg[e]);
+        float sum = 0.f, ex[16];
+        for (int e = 0; e < p.out_ch; ++e) {
+            ex[e] = expf(lg[e] - mx);
+            sum += ex[e];
+        }
+        int best = 0;
+        float bv = ex[0] / sum;
+        for (int e = 1; e < p.out_ch; ++e) {
+            const float pe = ex[e] / sum;
+            if (pe > bv) {
+                bv = pe;
+                best = e;
+            }
+        }
+        cls_s = best;
+    }
+    __syncthreads();
+    if (p.out) {
+        const float cf = (float)cls_s;
+        const long long base = p.tile_off ? p.tile_off[n] : (long long)n * p.tile_stride;
+        for (int i = tid; i < p.out_h * p.out_w; i += 256) {
+            const int yy = i / p.out_w, xx = i % p.out_w;
+            p.out[base + (long long)yy * p.row_stride + xx] = cf;
+        }
+    }
+}
+
+hipError_t cerb_launch_patch_class(const PatchClassParams& p, hipStream_t st) {
+    hipLaunchKernelGGL(patch_class_kernel, dim3(p.N), dim3(256), 0, st, p);
+    return hipGetLastError();
+}

@@ -1,0 +1,241 @@
+"""Host-side mirror of the reference's decoder-head API (models/net_desc.py) on top of libcerberus_hip.so.
+
+    create_model(**model_kwargs) -> NetDesc            (reference models/net_desc.py:203-204)
+    NetDesc.forward(imgs NCHW float 0..255) -> OrderedDict[str, Tensor NCHW logits]   (reference :144-200)
+    NetDesc.state_dict() / load_state_dict(sd, strict=True)  -- the reference's 558 key names (infer/base.py:28-45)
+
+plus the device-resident fast path used by infer_step and the WSI driver:
+
+    NetDesc.infer_tiles(tiles uint8 NHWC cuda, output_shape, head_name_list, ...) -> dict of CUDA tensors
+
+All arithmetic happens in hand-written gfx950 kernels behind the C ABI; PyTorch only provides device memory and
+the stream.  There is no CPU path: without a GPU / the built library every compute call raises.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from .weights import DEFAULT_DECODER_KWARGS, make_state_dict, state_dict_schema
+
+HEAD_NAME_MAP = {  # reference models/run_desc.py:466-473
+    "Gland": "Gland-INST",
+    "Gland#TYPE": "Gland-TYPE",
+    "Lumen": "Lumen-INST",
+    "Nuclei": "Nuclei-INST",
+    "Nuclei#TYPE": "Nuclei-TYPE",
+    "Patch-Class": "Patch-Class",
+}
+
+
+class NetDesc(torch.nn.Module):
+    """U-Net style network with a shared ResNet34 encoder and per-task decoders (reference net_desc.py:16-103)."""
+
+    def __init__(
+        self,
+        encoder_backbone_name=None,
+        backbone_imagenet_pretrained=False,
+        fullnet_custom_pretrained=False,
+        decoder_kwargs={},
+        considered_tasks=[],
+        subtype_gland=False,
+        subtype_nuclei=False,
+    ):
+        super().__init__()
+        if encoder_backbone_name != "resnet34":
+            # the other backbones are out of scope of the MI355X path
+            raise NotImplementedError("cerberus_amd implements encoder_backbone_name='resnet34' only, got %r" % (encoder_backbone_name,))
+        self.encoder_backbone_name = encoder_backbone_name
+        self.net_code = encoder_backbone_name[:3]
+        self.considered_tasks = list(considered_tasks)
+        self.subtype_gland = subtype_gland
+        self.subtype_nuclei = subtype_nuclei
+        self.decoder_info_list = OrderedDict((k, OrderedDict(v)) for k, v in (decoder_kwargs or DEFAULT_DECODER_KWARGS).items())
+        self._decoders = []  # (decoder_name, head_name, out_ch, output_key)
+        for name, heads in self.decoder_info_list.items():
+            if name not in self.considered_tasks:
+                continue
+            if len(heads) != 1:
+                raise NotImplementedError("one output head per decoder (as in models/paramset.yml); got %r for %s" % (dict(heads), name))
+            (hname, och), = heads.items()
+            key = name if name == "Patch-Class" else name.split("#")[0] + "-" + hname
+            self._decoders.append((name, hname, int(och), key))
+        self._schema = state_dict_schema(self.decoder_info_list, self.considered_tasks)
+        # deterministic seeded initialisation (the reference draws kaiming-normal weights here, net_desc.py:89-101)
+        self._sd = OrderedDict((k, torch.from_numpy(v)) for k, v in make_state_dict(0, self.decoder_info_list, self.considered_tasks).items())
+        self._handle = None
+        self.training = False
+
+    # ---- state dict (reference key names) -----------------------------------------------------------------
+    def state_dict(self, *args, **kwargs):
+        return OrderedDict((k, v.clone()) for k, v in self._sd.items())
+
+    def load_state_dict(self, state_dict, strict=True):
+        expected = OrderedDict((k, shp) for k, shp, _ in self._schema)
+        missing = [k for k in expected if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in expected]
+        errors = []
+        if strict and missing:
+            errors.append("Missing key(s) in state_dict: " + ", ".join('"%s"' % k for k in missing) + ".")
+        if strict and unexpected:
+            errors.append("Unexpected key(s) in state_dict: " + ", ".join('"%s"' % k for k in unexpected) + ".")
+        new_sd = OrderedDict(self._sd)
+        for k, shp in expected.items():
+            if k not in state_dict:
+                continue
+            v = state_dict[k]
+            v = v.detach().cpu() if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))
+            if tuple(v.shape) != tuple(shp):
+                errors.append("size mismatch for %s: copying a param with shape %s from checkpoint, the shape in current model is %s."
+                              % (k, tuple(v.shape), tuple(shp)))
+                continue
+            new_sd[k] = v.to(torch.int64) if k.endswith("num_batches_tracked") else v.to(torch.float32).contiguous()
+        if errors:
+            raise RuntimeError("Error(s) in loading state_dict for NetDesc:\n\t" + "\n\t".join(errors))
+        self._sd = new_sd
+        self._release()
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    # ---- nn.Module conveniences ----------------------------------------------------------------------------
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("cerberus_amd.NetDesc is inference-only (training is SURVEY.md par.8f 'next')")
+        self.training = False
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def _release(self):
+        if self._handle is not None:
+            _lib.lib().cerb_net_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    # ---- library handle --------------------------------------------------------------------------------------
+    def _ensure_handle(self):
+        if self._handle is not None:
+            return self._handle
+        if not torch.cuda.is_available():
+            raise _lib.CerberusHipError("cerberus_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        L = _lib.lib()
+        n = len(self._decoders)
+        names = (C.c_char_p * n)(*[d[0].encode() for d in self._decoders])
+        heads = (C.c_char_p * n)(*[d[1].encode() for d in self._decoders])
+        och = (C.c_int * n)(*[d[2] for d in self._decoders])
+        h = C.c_void_p()
+        _lib.check(L.cerb_net_create(names, heads, och, n, C.byref(h)))
+        try:
+            for k, v in self._sd.items():
+                if v.dtype != torch.float32:
+                    continue
+                a = np.ascontiguousarray(v.numpy())
+                shp = (C.c_int64 * a.ndim)(*a.shape)
+                _lib.check(L.cerb_net_load_tensor(h, k.encode(), a.ctypes.data_as(C.c_void_p), shp, a.ndim))
+            _lib.check(L.cerb_net_finalize(h))
+        except Exception:
+            L.cerb_net_destroy(h)
+            raise
+        self._handle = h
+        return h
+
+    def flops(self, n, h, w):
+        return float(_lib.lib().cerb_net_flops(self._ensure_handle(), n, h, w))
+
+    def _run(self, tiles_u8, out_h, out_w, outs, logits, tile_off=None, tile_stride=0, row_stride=0, type_is_u8=False, feats=None):
+        assert tiles_u8.is_cuda and tiles_u8.dtype == torch.uint8 and tiles_u8.dim() == 4 and tiles_u8.shape[3] == 3
+        tiles_u8 = tiles_u8.contiguous()
+        n, h, w, _ = tiles_u8.shape
+        nd = len(self._decoders)
+        io = _lib.ForwardIO()
+        io.tiles = tiles_u8.data_ptr()
+        io.n, io.h, io.w, io.out_h, io.out_w = n, h, w, out_h, out_w
+        out_arr = (C.c_void_p * nd)(*[(t.data_ptr() if t is not None else None) for t in outs])
+        io.out = out_arr
+        if logits is not None:
+            lg_arr = (C.c_void_p * nd)(*[(t.data_ptr() if t is not None else None) for t in logits])
+            io.logits = lg_arr
+        if tile_off is not None:
+            assert tile_off.is_cuda and tile_off.dtype == torch.int64 and tile_off.numel() == n
+            io.tile_off = tile_off.data_ptr()
+        io.tile_stride, io.row_stride, io.type_is_u8 = int(tile_stride), int(row_stride), int(bool(type_is_u8))
+        if feats is not None:
+            f_arr = (C.c_void_p * 6)(*[(t.data_ptr() if t is not None else None) for t in feats])
+            io.feats = f_arr
+        stream = torch.cuda.current_stream(tiles_u8.device).cuda_stream
+        with torch.cuda.device(tiles_u8.device):
+            _lib.check(_lib.lib().cerb_net_forward(self._ensure_handle(), C.byref(io), C.c_void_p(stream)))
+
+    # ---- reference-compatible forward: logits ----------------------------------------------------------------
+    def forward(self, imgs, train_decoder_list=[]):
+        """imgs: NCHW float tensor holding 0..255 pixel values (what infer_step passes, run_desc.py:440-449),
+        or uint8 NHWC.  Returns OrderedDict key -> NCHW fp32 logits on the GPU (reference net_desc.py:144-200)."""
+        if imgs.dtype == torch.uint8 and imgs.shape[-1] == 3:
+            tiles = imgs
+        else:
+            q = imgs.round()
+            if not torch.equal(q, imgs) or imgs.min() < 0 or imgs.max() > 255:
+                raise NotImplementedError("the HIP path ingests uint8 RGB tiles; forward() accepts float inputs only when they hold integers in 0..255")
+            tiles = imgs.permute(0, 2, 3, 1).to(torch.uint8)
+        tiles = tiles.cuda().contiguous()
+        n, h, w, _ = tiles.shape
+        lg = []
+        for name, hname, och, key in self._decoders:
+            if name == "Patch-Class":
+                lg.append(torch.empty((n, och), dtype=torch.float32, device=tiles.device))
+            else:
+                lg.append(torch.empty((n, h, w, och), dtype=torch.float32, device=tiles.device))
+        self._run(tiles, h, w, [None] * len(self._decoders), lg)
+        out = OrderedDict()
+        for (name, hname, och, key), t in zip(self._decoders, lg):
+            out[key] = t.view(n, och, 1, 1) if name == "Patch-Class" else t.permute(0, 3, 1, 2)
+        return out
+
+    # ---- device-resident output wrapper (softmax / crop / argmax fused into the head kernels) ---------------
+    def infer_tiles(self, tiles_u8, output_shape, head_name_list=None, type_dtype=torch.int64):
+        """F7 of SURVEY.md par.8a on device: returns OrderedDict head-key -> CUDA tensor
+        ('*-INST' (N,oh,ow,2) float32; '*-TYPE' (N,oh,ow) int64|uint8; 'Patch-Class' (N,oh,ow) float32)."""
+        if not isinstance(output_shape, (list, tuple)):
+            output_shape = [output_shape, output_shape]
+        oh, ow = int(output_shape[0]), int(output_shape[1])
+        tiles_u8 = tiles_u8.cuda()
+        n = tiles_u8.shape[0]
+        wanted = None if head_name_list is None else set(HEAD_NAME_MAP[h] for h in head_name_list)
+        outs, res = [], OrderedDict()
+        for name, hname, och, key in self._decoders:
+            if wanted is not None and key not in wanted:
+                outs.append(None)
+                continue
+            if hname == "INST":
+                t = torch.empty((n, oh, ow, 2), dtype=torch.float32, device=tiles_u8.device)
+            elif hname == "TYPE":
+                t = torch.empty((n, oh, ow), dtype=type_dtype, device=tiles_u8.device)
+            else:
+                t = torch.empty((n, oh, ow), dtype=torch.float32, device=tiles_u8.device)
+            outs.append(t)
+            res[key] = t
+        self._run(tiles_u8, oh, ow, outs, None, type_is_u8=(type_dtype == torch.uint8))
+        if head_name_list is not None:  # reference orders the result by head_name_list (run_desc.py:475-492)
+            res = OrderedDict((HEAD_NAME_MAP[h], res[HEAD_NAME_MAP[h]]) for h in head_name_list)
+        return res
+
+    def encoder_features(self, tiles_u8):
+        """Test hook: NHWC dumps of x0, x1, x2, x3, conv_map(x4), x4."""
+        tiles_u8 = tiles_u8.cuda().contiguous()
+        n, h, w, _ = tiles_u8.shape
+        shp = [(h, w, 64), (h // 2, w // 2, 64), (h // 4, w // 4, 128), (h // 8, w // 8, 256), (h // 16, w // 16, 256), (h // 16, w // 16, 512)]
+        feats = [torch.empty((n,) + s, dtype=torch.float32, device=tiles_u8.device) for s in shp]
+        self._run(tiles_u8, h, w, [None] * len(self._decoders), None, feats=feats)
+        return feats
+
+
+def create_model(**kwargs):
+    return NetDesc(**kwargs)

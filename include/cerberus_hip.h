@@ -1,0 +1,105 @@
+/* cerberus_hip.h -- C ABI of libcerberus_hip.so: the MI355X (gfx950) tiled-inference hot path of Cerberus.
+ *
+ * This is the drop-in boundary.  The reference is pure Python; the objects this ABI
+ * replaces are cited per entry point as <reference file>:<line>.  No torch types cross the boundary: plain
+ * pointers (device pointers are raw hipMalloc/torch addresses), sizes, and a hipStream_t passed as void*.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; cerb_last_error() returns a thread-local
+ *     message (the reference's only error convention is Python exceptions / assert, e.g.
+ *     loader/postproc.py:390,395 and load_state_dict(strict=True) at infer/base.py:45).
+ *   - one cerb_net per GPU / per process; calls on one handle must be serialised by the caller (the reference
+ *     calls run_step from the main thread only, infer/tile.py:349-359).
+ *   - the library owns packed weights and its workspace; the caller owns every input/output buffer.
+ *   - activations are NHWC fp32; image tiles are NHWC uint8 (what infer_step receives, models/run_desc.py:439-441).
+ */
+#ifndef CERBERUS_HIP_H
+#define CERBERUS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cerb_net cerb_net;
+
+int cerb_version(void);
+const char* cerb_last_error(void);
+
+/* ---- network construction: replaces create_model / NetDesc.__init__ (models/net_desc.py:23-103,203) ----------
+ * decoder_names[i]  e.g. "Lumen","Gland","Nuclei","Nuclei#TYPE","Gland#TYPE","Patch-Class"  (decoder_kwargs order,
+ *                   already filtered by considered_tasks, models/net_desc.py:61-63)
+ * head_names[i]     "INST" | "TYPE" | "OUT"        (the single output head of that decoder)
+ * out_ch[i]         number of output channels of that head (3,3,3,7,3,9 in models/paramset.yml:46-60)
+ * Only encoder_backbone_name == "resnet34" exists in this library. */
+int cerb_net_create(const char* const* decoder_names, const char* const* head_names, const int* out_ch,
+                    int n_decoders, cerb_net** out_net);
+void cerb_net_destroy(cerb_net* net);
+
+/* ---- weights: replaces net.load_state_dict(saved_state_dict, strict=True) (infer/base.py:28-45) ----------------
+ * One call per state-dict entry, using the reference's key names (backbone.layer1.0.conv1.weight, ...).  `data`
+ * is a HOST pointer to contiguous fp32 in PyTorch's layout (conv: [Cout][Cin][kh][kw]); the library copies it.
+ * Keys with integer payloads (num_batches_tracked) and the unused backbone.fc.* are accepted and ignored.
+ * cerb_net_finalize folds eval-mode BatchNorm into the convolutions, packs for the MFMA kernels, uploads, and
+ * fails (strict) if any required key is missing or has the wrong shape. */
+int cerb_net_load_tensor(cerb_net* net, const char* key, const float* data, const int64_t* shape, int ndim);
+int cerb_net_finalize(cerb_net* net);
+
+/* ---- forward + output wrapper: replaces infer_step (models/run_desc.py:439-502) incl. NetDesc.forward
+ * (models/net_desc.py:144-200), softmax / channel slice / centre crop / argmax, and -- through tile_off /
+ * row_stride -- the stitching of infer/tile.py:141-163 (outputs can be written straight into a slide canvas).
+ *
+ * For decoder i (same order as cerb_net_create):
+ *   INST head : out[i] -> float  [..][2]   softmax channels 1..2        (run_desc.py:452-455)
+ *   TYPE head : out[i] -> int64 or uint8 class id (argmax of softmax)   (run_desc.py:490-491), see type_is_u8
+ *   OUT  head : out[i] -> float class id broadcast over out_h x out_w   (Patch-Class, run_desc.py:480-487)
+ * Destination addressing (in pixels): tile n, row y, col x  ->  (tile_off ? tile_off[n] : n*tile_stride)
+ *                                                               + y*row_stride + x
+ * logits[i] (optional, may be NULL) receives the raw head logits NHWC [N][H][W][out_ch] ([N][out_ch] for OUT). */
+typedef struct cerb_forward_io {
+    const uint8_t* tiles;      /* device, [N][H][W][3] uint8 RGB */
+    int n, h, w;               /* batch, tile height/width (multiples of 16) */
+    int out_h, out_w;          /* centre-crop size (cropping_center, misc/utils.py:94-104) */
+    void* const* out;          /* [n_decoders] device pointers (NULL = head not wanted) */
+    float* const* logits;      /* optional [n_decoders] device pointers or NULL */
+    const long long* tile_off; /* optional device array [N] of pixel offsets into the destination */
+    long long tile_stride;     /* used when tile_off == NULL; 0 means out_h*out_w */
+    long long row_stride;      /* 0 means out_w */
+    int type_is_u8;            /* 0: TYPE heads write int64 (reference dtype); 1: uint8 (device-resident canvas) */
+    float* const* feats;       /* optional [6]: x0,x1,x2,x3,conv_map(x4),x4 NHWC dumps for tests, or NULL */
+} cerb_forward_io;
+
+int cerb_net_forward(cerb_net* net, const cerb_forward_io* io, void* hip_stream);
+
+/* FLOPs (2*MAC) of one forward for the given geometry -- used by bench.py for the roofline figure. */
+double cerb_net_flops(const cerb_net* net, int n, int h, int w);
+
+/* ---- post-processing: replaces PostProcInstErodedContourMap.post_process (loader/postproc.py:268-407) -----------
+ * inst : device float [H][W][2] (ch0 = inner, ch1 = contour), `pix_stride` floats between consecutive pixels
+ *        (2 for a packed INST map) and `row_stride` floats between rows -- lets it read a canvas window in place.
+ * labels_out : device int32 [H][W]; ids as the reference assigns them (raster order of first pixel).
+ * n_inst_out : device int32[1]; number of instances.  n_ambiguous_out : device int32[1] (nuclei only): number of
+ *        watershed regions whose result depends on skimage's heap-internal order between seed pixels with
+ *        bit-identical priority (see DESIGN.md "watershed ties"); 0 means the label map is provably identical.
+ * ws / ws_bytes : caller-allocated device workspace of at least cerb_pp_workspace_bytes(H, W). */
+size_t cerb_pp_workspace_bytes(int h, int w);
+int cerb_postproc_nuclei(const float* inst, int h, int w, long long row_stride, int pix_stride, int32_t* labels_out,
+                         int32_t* n_inst_out, int32_t* n_ambiguous_out, void* ws, size_t ws_bytes, void* hip_stream);
+int cerb_postproc_gland(const float* inst, int h, int w, long long row_stride, int pix_stride, float ds_factor,
+                        int32_t* labels_out, int32_t* n_inst_out, void* ws, size_t ws_bytes, void* hip_stream);
+int cerb_postproc_lumen(const float* inst, int h, int w, long long row_stride, int pix_stride, float ds_factor,
+                        int32_t* labels_out, int32_t* n_inst_out, void* ws, size_t ws_bytes, void* hip_stream);
+/* Lumen *= (Gland > 0)   (infer/tile.py:187-191, infer/wsi.py:799-804) */
+int cerb_mask_lumen_by_gland(int32_t* lumen_labels, const int32_t* gland_labels, long long n_pix, void* hip_stream);
+
+/* ---- device timing helper: HIP events on the given stream (bench.py; torch.cuda.Event only sees torch's stream) */
+int cerb_event_create(void** ev);
+int cerb_event_record(void* ev, void* hip_stream);
+int cerb_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms); /* synchronises on ev_stop */
+int cerb_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CERBERUS_HIP_H */
