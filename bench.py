@@ -1,0 +1,192 @@
+"""bench.py -- headline benchmark of the Cerberus tiled-inference hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of 32 synthetic 256x256x3 uint8 tiles (BASELINE.json
+configs[1]: full Cerberus, ResNet34 + 6 heads, fp32): forward of all heads, fused softmax / crop / argmax, outputs
+scattered straight into this rank's device-resident canvas.  Inputs are resident in HBM before the timed region.
+Multi-GPU: tiles shard embarrassingly -> one process per GPU, every rank runs its own batches, no
+data-path collective; weak scaling.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+BATCH, TILE = 32, 256
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def cpu_baseline(sd, kw, n_tiles=8, iters=2):
+    """Oracle (CPU restatement of the reference path, PyTorch-CPU fp32) on the host cores -- reported, not optimised."""
+    from oracle import net_ref
+
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = min(avail, 16)  # oneDNN with one thread per logical CPU of a 256-thread host is pathologically slow (10 s/tile)
+    torch.set_num_threads(cores)
+    tiles = np.random.RandomState(1).randint(0, 256, (n_tiles, TILE, TILE, 3)).astype(np.uint8)
+    t0 = time.perf_counter()
+    net_ref.infer_step(sd, tiles[:1], TILE, kw["considered_tasks"], kw["decoder_kwargs"])  # warm-up, also sizes the sample
+    t1 = time.perf_counter() - t0
+    if t1 * n_tiles * iters > 30.0:  # keep the CPU leg to ~10-30 s
+        iters = 1
+        n_tiles = max(1, min(n_tiles, int(20.0 / t1)))
+        tiles = tiles[:n_tiles]
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        net_ref.infer_step(sd, tiles, TILE, kw["considered_tasks"], kw["decoder_kwargs"])
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(iters * n_tiles * TILE * TILE / dt / 1e6, 4),
+        "unit": "Mpx/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d x %d tiles of %dx%d, all six heads, forward + infer_step wrapper, torch-CPU fp32, %d threads (host has %d)"
+        % (iters, n_tiles, TILE, TILE, cores, avail),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from cerberus_amd.net_desc import create_model
+    from cerberus_amd.weights import default_model_kwargs, make_state_dict
+
+    kw = default_model_kwargs()
+    sd = {k: torch.from_numpy(v) for k, v in make_state_dict(0).items()}
+    model = create_model(**kw)
+    model.load_state_dict(sd, strict=True)
+
+    # synthetic slide strip resident in HBM: this rank's batches (seeded per rank), and its output canvas
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    tiles = torch.randint(0, 256, (BATCH, TILE, TILE, 3), dtype=torch.uint8, device=dev, generator=g)
+    gy, gx = 4, 8  # canvas of 4 x 8 tiles
+    Wc = gx * TILE
+    canvas = {
+        "Lumen": torch.zeros((gy * TILE, Wc, 2), dtype=torch.float32, device=dev),
+        "Gland": torch.zeros((gy * TILE, Wc, 2), dtype=torch.float32, device=dev),
+        "Nuclei": torch.zeros((gy * TILE, Wc, 2), dtype=torch.float32, device=dev),
+        "Nuclei#TYPE": torch.zeros((gy * TILE, Wc), dtype=torch.uint8, device=dev),
+        "Gland#TYPE": torch.zeros((gy * TILE, Wc), dtype=torch.uint8, device=dev),
+        "Patch-Class": torch.zeros((gy * TILE, Wc), dtype=torch.float32, device=dev),
+    }
+    outs = [canvas[d[0]] for d in model._decoders]
+    off = torch.tensor([(i // gx) * TILE * Wc + (i % gx) * TILE for i in range(BATCH)], dtype=torch.int64, device=dev)
+
+    def step():
+        model._run(tiles, TILE, TILE, outs, None, tile_off=off, row_stride=Wc, type_is_u8=True)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline leg: per-launch HIP-event timing of ONE more step (outside the timed region) -------------
+    model.profile(True)
+    step()
+    torch.cuda.synchronize()
+    recs = model.profile_records()
+    model.profile(False)
+    fam = {}
+    for name, kern, fl, ms in recs:
+        f = fam.setdefault(kern, [0.0, 0.0, 0])
+        f[0] += fl
+        f[1] += ms
+        f[2] += 1
+    dom = max(fam.items(), key=lambda kv: kv[1][1])
+    dom_name, (dom_fl, dom_ms, dom_cnt) = dom
+    achieved = dom_fl / (dom_ms * 1e-3) / 1e12
+    total_ms = sum(r[3] for r in recs)
+    roofline = {
+        "bound": "mfma",
+        "kernel": dom_name,
+        "achieved": round(achieved, 2),
+        "peak": PEAK_F32_MFMA_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+        "traffic": None,
+        "launches": dom_cnt,
+        "avg_launch_ms": round(dom_ms / dom_cnt, 4),
+        "kernel_share_of_step": round(dom_ms / total_ms, 4),
+    }
+
+    if rank == 0:
+        px = world * args.steps * BATCH * TILE * TILE
+        flops_step = model.flops(BATCH, TILE, TILE)
+        line = {
+            "metric": "Mpx/sec WSI tiled inference (all heads)",
+            "value": round(px / dt / 1e6, 3),
+            "unit": "Mpx/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "Full Cerberus (ResNet34 encoder + 6 decoder heads) batch=32 256x256x3 uint8 tiles, fp32, all heads + fused "
+                            "softmax/crop/argmax scattered into a device-resident canvas (BASELINE.json configs[1])",
+                "batch_tiles": BATCH,
+                "tile": TILE,
+                "gflop_per_tile": round(flops_step / BATCH / 1e9, 3),
+                "whole_step_tflops": round(flops_step / (dt / args.steps) / 1e12 * world, 2),
+                "parallelism": "tile-sharded x%d, no data-path collective" % world,
+            },
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd, kw)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,7 +9,8 @@ EXPORTS = [
     "cerb_version", "cerb_last_error", "cerb_net_create", "cerb_net_destroy", "cerb_net_load_tensor",
     "cerb_net_finalize", "cerb_net_forward", "cerb_net_flops", "cerb_pp_workspace_bytes", "cerb_postproc_nuclei",
     "cerb_postproc_gland", "cerb_postproc_lumen", "cerb_mask_lumen_by_gland", "cerb_event_create",
-    "cerb_event_record", "cerb_event_elapsed_ms", "cerb_event_destroy",
+    "cerb_event_record", "cerb_event_elapsed_ms", "cerb_event_destroy", "cerb_net_profile_enable",
+    "cerb_net_profile_count", "cerb_net_profile_get",
 ]
 
 
@@ -63,6 +64,9 @@ def lib():
         f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                       C.c_size_t, C.c_void_p]
     L.cerb_mask_lumen_by_gland.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
+    L.cerb_net_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    L.cerb_net_profile_count.argtypes = [C.c_void_p]
+    L.cerb_net_profile_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float)]
     L.cerb_event_create.argtypes = [C.POINTER(C.c_void_p)]
     L.cerb_event_record.argtypes = [C.c_void_p, C.c_void_p]
     L.cerb_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]

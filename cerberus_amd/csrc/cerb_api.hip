@@ -109,7 +109,13 @@ struct cerb_net {
     std::vector<void*> dev_allocs;
     // workspace
     DevBuf x0, pool, x[5], ta, tb, cm, dmid, dout[4];
+    // optional per-launch timing (HIP events on the caller's stream)
+    bool profiling = false;
+    struct ProfRec { std::string name, kernel; double flops; hipEvent_t e0, e1; };
+    std::vector<ProfRec> prof;
+    size_t prof_n = 0;
     ~cerb_net() {
+        for (auto& r : prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         for (void* p : dev_allocs) (void)hipFree(p);
         x0.release(); pool.release(); ta.release(); tb.release(); cm.release(); dmid.release();
         for (auto& b : x) b.release();
@@ -374,6 +380,26 @@ extern "C" int cerb_net_finalize(cerb_net* net) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+static int prof_begin(cerb_net* net, const std::string& name, const std::string& kernel, double flops, hipStream_t st) {
+    if (!net->profiling) return 0;
+    if (net->prof_n == net->prof.size()) {
+        cerb_net::ProfRec r;
+        HIP_OK(hipEventCreate(&r.e0));
+        HIP_OK(hipEventCreate(&r.e1));
+        net->prof.push_back(r);
+    }
+    cerb_net::ProfRec& r = net->prof[net->prof_n];
+    r.name = name; r.kernel = kernel; r.flops = flops;
+    HIP_OK(hipEventRecord(r.e0, st));
+    return 0;
+}
+static int prof_end(cerb_net* net, hipStream_t st) {
+    if (!net->profiling) return 0;
+    HIP_OK(hipEventRecord(net->prof[net->prof_n].e1, st));
+    net->prof_n++;
+    return 0;
+}
+
 static int run_conv(cerb_net* net, const std::string& name, const float* in, const float* prev, const float* resid, float* out, int N,
                     int H, int W, int relu, int mode, long long in_gs, long long prev_gs, hipStream_t st, double* macs) {
     auto it = net->conv.find(name);
@@ -396,7 +422,12 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
         *macs += (double)c.groups * N * p.Ho * p.Wo * (double)c.cout * c.cin * c.ks * c.ks;
         if (!out) return 0;
     }
+    const double fl = 2.0 * (double)c.groups * N * p.Ho * p.Wo * (double)c.cout * c.cin * c.ks * c.ks;
+    const std::string kn = "conv_igemm<ks" + std::to_string(c.ks) + ",s" + std::to_string(c.stride) + ",mode" + std::to_string(mode) +
+                           (p.Wo < 32 ? ",16x16>" : ",8x32>");
+    if (prof_begin(net, name, kn, fl, st)) return 1;
     HIP_OK(cerb_launch_conv(p, c.ks, c.stride, mode, st));
+    if (prof_end(net, st)) return 1;
     return 0;
 }
 
@@ -429,8 +460,12 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
         StemParams sp;
         sp.tiles = io->tiles; sp.wpack = net->stem_w; sp.bias = net->stem_b; sp.out = net->x0.p; sp.N = N; sp.H = H; sp.W = W;
         sp.tiles_x = sp.tiles_y = 0;
+        if (prof_begin(net, "stem", "stem_conv7x7", 2.0 * N * H * W * 64.0 * 147.0, st)) return 1;
         HIP_OK(cerb_launch_stem(sp, st));
+        if (prof_end(net, st)) return 1;
+        if (prof_begin(net, "maxpool", "maxpool3x3s2", 0.0, st)) return 1;
         HIP_OK(cerb_launch_maxpool(net->x0.p, net->pool.p, N, H, W, 64, st));
+        if (prof_end(net, st)) return 1;
     }
     float* cur = dry ? nullptr : net->pool.p;
     int inpl = 64;
@@ -478,7 +513,9 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
             pp.logits = wantl ? io->logits[net->pc_idx] : nullptr;
             pp.out = want ? (float*)io->out[net->pc_idx] : nullptr;
             pp.tile_off = io->tile_off; pp.tile_stride = tile_stride; pp.row_stride = row_stride;
+            if (prof_begin(net, "patch_class", "patch_class", 2.0 * N * (512.0 * 256 + 256.0 * pp.out_ch), st)) return 1;
             HIP_OK(cerb_launch_patch_class(pp, st));
+            if (prof_end(net, st)) return 1;
         }
     }
     // ---- dense decoders (all decoders of a level in ONE grouped launch) ---------------------------------------
@@ -519,7 +556,9 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
                 else hp.out_type_i64 = (long long*)io->out[di];
             }
             hp.tile_off = io->tile_off; hp.tile_stride = tile_stride; hp.row_stride = row_stride;
+            if (prof_begin(net, "head." + d.name, "head", 2.0 * N * H * W * (64.0 * 96 + 96.0 * d.out_ch), st)) return 1;
             HIP_OK(cerb_launch_head(hp, st));
+            if (prof_end(net, st)) return 1;
         }
     }
     if (!dry && io->feats) {
@@ -536,6 +575,7 @@ extern "C" int cerb_net_forward(cerb_net* net, const cerb_forward_io* io, void* 
     if (!net || !io) return fail("cerb_net_forward: null argument");
     if (!net->finalized) return fail("cerb_net_forward: call cerb_net_finalize first");
     if (!io->tiles) return fail("cerb_net_forward: null tiles pointer");
+    net->prof_n = 0;
     return forward_impl(net, io, (hipStream_t)hip_stream, nullptr);
 }
 
@@ -547,6 +587,25 @@ extern "C" double cerb_net_flops(const cerb_net* net, int n, int h, int w) {
     double macs = 0.0;
     if (forward_impl(const_cast<cerb_net*>(net), &io, nullptr, &macs)) return -1.0;
     return 2.0 * macs;
+}
+
+// ---- per-launch profile (bench.py roofline leg) ----------------------------------------------------------------
+extern "C" int cerb_net_profile_enable(cerb_net* net, int enable) {
+    if (!net) return fail("cerb_net_profile_enable: null handle");
+    net->profiling = enable != 0;
+    net->prof_n = 0;
+    return 0;
+}
+extern "C" int cerb_net_profile_count(cerb_net* net) { return net ? (int)net->prof_n : 0; }
+extern "C" int cerb_net_profile_get(cerb_net* net, int idx, char* name, int name_cap, char* kernel, int kernel_cap, double* flops, float* ms) {
+    if (!net || idx < 0 || (size_t)idx >= net->prof_n) return fail("cerb_net_profile_get: index out of range");
+    cerb_net::ProfRec& r = net->prof[idx];
+    HIP_OK(hipEventSynchronize(r.e1));
+    HIP_OK(hipEventElapsedTime(ms, r.e0, r.e1));
+    snprintf(name, name_cap, "%s", r.name.c_str());
+    snprintf(kernel, kernel_cap, "%s", r.kernel.c_str());
+    *flops = r.flops;
+    return 0;
 }
 
 // ---- events ----------------------------------------------------------------------------------------------------

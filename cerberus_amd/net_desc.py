@@ -150,6 +150,20 @@ class NetDesc(torch.nn.Module):
     def flops(self, n, h, w):
         return float(_lib.lib().cerb_net_flops(self._ensure_handle(), n, h, w))
 
+    def profile(self, enable=True):
+        _lib.check(_lib.lib().cerb_net_profile_enable(self._ensure_handle(), int(enable)))
+
+    def profile_records(self):
+        """[(layer name, kernel family, flops, ms)] of the last forward run with profiling enabled."""
+        L, h = _lib.lib(), self._ensure_handle()
+        out = []
+        nm, kn = C.create_string_buffer(128), C.create_string_buffer(128)
+        fl, ms = C.c_double(), C.c_float()
+        for i in range(L.cerb_net_profile_count(h)):
+            _lib.check(L.cerb_net_profile_get(h, i, nm, 128, kn, 128, C.byref(fl), C.byref(ms)))
+            out.append((nm.value.decode(), kn.value.decode(), fl.value, ms.value))
+        return out
+
     def _run(self, tiles_u8, out_h, out_w, outs, logits, tile_off=None, tile_stride=0, row_stride=0, type_is_u8=False, feats=None):
         assert tiles_u8.is_cuda and tiles_u8.dtype == torch.uint8 and tiles_u8.dim() == 4 and tiles_u8.shape[3] == 3
         tiles_u8 = tiles_u8.contiguous()
@@ -178,6 +192,7 @@ class NetDesc(torch.nn.Module):
     def forward(self, imgs, train_decoder_list=[]):
         """imgs: NCHW float tensor holding 0..255 pixel values (what infer_step passes, run_desc.py:440-449),
         or uint8 NHWC.  Returns OrderedDict key -> NCHW fp32 logits on the GPU (reference net_desc.py:144-200)."""
+        self._ensure_handle()
         if imgs.dtype == torch.uint8 and imgs.shape[-1] == 3:
             tiles = imgs
         else:
@@ -206,6 +221,7 @@ class NetDesc(torch.nn.Module):
         if not isinstance(output_shape, (list, tuple)):
             output_shape = [output_shape, output_shape]
         oh, ow = int(output_shape[0]), int(output_shape[1])
+        self._ensure_handle()  # raises CerberusHipError when there is no GPU / no built library
         tiles_u8 = tiles_u8.cuda()
         n = tiles_u8.shape[0]
         wanted = None if head_name_list is None else set(HEAD_NAME_MAP[h] for h in head_name_list)
@@ -229,6 +245,7 @@ class NetDesc(torch.nn.Module):
 
     def encoder_features(self, tiles_u8):
         """Test hook: NHWC dumps of x0, x1, x2, x3, conv_map(x4), x4."""
+        self._ensure_handle()
         tiles_u8 = tiles_u8.cuda().contiguous()
         n, h, w, _ = tiles_u8.shape
         shp = [(h, w, 64), (h // 2, w // 2, 64), (h // 4, w // 4, 128), (h // 8, w // 8, 256), (h // 16, w // 16, 256), (h // 16, w // 16, 512)]

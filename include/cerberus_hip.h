@@ -75,6 +75,14 @@ int cerb_net_forward(cerb_net* net, const cerb_forward_io* io, void* hip_stream)
 /* FLOPs (2*MAC) of one forward for the given geometry -- used by bench.py for the roofline figure. */
 double cerb_net_flops(const cerb_net* net, int n, int h, int w);
 
+/* Per-launch timing of the NEXT forwards with HIP events on the caller's stream (bench.py roofline leg; adds two
+ * event records per kernel, so never enabled inside a timed region).  After a forward + stream sync,
+ * cerb_net_profile_get(i) returns layer name, kernel family, algorithmic FLOPs and elapsed ms of launch i. */
+int cerb_net_profile_enable(cerb_net* net, int enable);
+int cerb_net_profile_count(cerb_net* net);
+int cerb_net_profile_get(cerb_net* net, int idx, char* name, int name_cap, char* kernel, int kernel_cap, double* flops,
+                         float* ms);
+
 /* ---- post-processing: replaces PostProcInstErodedContourMap.post_process (loader/postproc.py:268-407) -----------
  * inst : device float [H][W][2] (ch0 = inner, ch1 = contour), `pix_stride` floats between consecutive pixels
  *        (2 for a packed INST map) and `row_stride` floats between rows -- lets it read a canvas window in place.

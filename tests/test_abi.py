@@ -1,0 +1,43 @@
+"""The C-ABI library loads and exports every symbol include/cerberus_hip.h declares (no compute calls, no GPU)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "cerberus_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(cerb_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported():
+    from cerberus_amd import _lib
+
+    assert os.path.exists(_lib.LIB_PATH), "run `python -m cerberus_amd.build` first"
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(L, n), "libcerberus_hip.so does not export %s" % n
+    # the python binding lists exactly what the header declares
+    assert sorted(_lib.EXPORTS) == names
+
+
+def test_version_and_error_string():
+    from cerberus_amd import _lib
+
+    L = _lib.lib()
+    assert L.cerb_version() >= 1
+    assert isinstance(L.cerb_last_error(), bytes)
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under cerberus_amd/ may import or load it."""
+    pkg = os.path.join(ROOT, "cerberus_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src, f

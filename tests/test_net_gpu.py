@@ -1,0 +1,150 @@
+"""Parity of the HIP network path (through the C ABI) with the CPU oracle and the reference's golden vectors.
+Tolerance: 1e-4 absolute on float probability maps (BASELINE.json north_star); integer maps must agree except where
+the oracle's own top-2 softmax margin is below 1e-5 (fp32 rounding-order ties)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cerberus_amd.net_desc import create_model
+from cerberus_amd.run_desc import infer_step
+from cerberus_amd.weights import default_model_kwargs, make_state_dict
+from oracle import net_ref
+
+pytestmark = pytest.mark.gpu
+PROB_TOL = 1e-4
+CROPS = [(0, 0), (96, 96), (192, 192)]
+CS = 64
+
+
+def _crops(a):
+    return np.stack([a[:, y:y + CS, x:x + CS] for (y, x) in CROPS], axis=1)
+
+
+def _model(tasks, seed=0):
+    kw = default_model_kwargs(tasks)
+    sd = {k: torch.from_numpy(v) for k, v in make_state_dict(seed, kw["decoder_kwargs"], kw["considered_tasks"]).items()}
+    m = create_model(**kw)
+    m.load_state_dict(sd, strict=True)
+    return m, sd, kw
+
+
+@pytest.fixture(scope="module")
+def full_model():
+    return _model(None)
+
+
+def test_native_library_is_loaded():
+    from cerberus_amd import _lib
+
+    _lib.lib()
+    maps = open("/proc/self/maps").read()
+    assert "libcerberus_hip.so" in maps
+
+
+def test_encoder_and_logits_vs_oracle(full_model):
+    m, sd, kw = full_model
+    tiles = np.random.RandomState(11).randint(0, 256, (2, 256, 256, 3)).astype(np.uint8)
+    x = torch.from_numpy(tiles).float().permute(0, 3, 1, 2).contiguous()
+    ref, feats, bottom = net_ref.net_forward(sd, x, kw["decoder_kwargs"], kw["considered_tasks"], return_feats=True)
+    got = m.encoder_features(torch.from_numpy(tiles).cuda())
+    for a, b in zip(got, feats[:4] + [feats[4], bottom]):
+        assert (a.cpu().permute(0, 3, 1, 2) - b).abs().max().item() < 1e-4
+    out = m(x.cuda())  # reference-style forward: float NCHW 0..255 -> logits NCHW
+    assert list(out.keys()) == ["Lumen-INST", "Gland-INST", "Nuclei-INST", "Nuclei-TYPE", "Gland-TYPE", "Patch-Class"]
+    for k, v in out.items():
+        assert v.shape == ref[k].shape
+        assert (v.cpu() - ref[k]).abs().max().item() < 2e-4, k
+
+
+@pytest.mark.parametrize("tag", ["cfg1_nuclei", "cfg2_all", "g448_all"])
+def test_infer_step_vs_reference_golden(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "net_%s.npz" % tag))
+    tasks = [str(t) for t in g["tasks"]]
+    m, sd, kw = _model(tasks, int(g["weight_seed"]))
+    n, hw, osz = int(g["n"]), int(g["hw"]), int(g["out_shape"])
+    tiles = np.random.RandomState(int(g["tile_seed"])).randint(0, 256, (n, hw, hw, 3)).astype(np.uint8)
+    out = infer_step(torch.from_numpy(tiles), m, osz, tasks)
+    assert isinstance(out, list) and len(out) == n
+    lg = m(torch.from_numpy(tiles))
+    for k in out[0].keys():
+        a = np.stack([out[i][k] for i in range(n)])
+        assert str(a.dtype) == str(g["out_dtype/" + k]), k  # float32 / int64 protocol of run_desc.py:439-502
+        assert a.shape[1:3] == (osz, osz)
+        a4 = a[..., None] if a.ndim == 3 else a
+        key = "out_crops/" + k
+        ref = g[key] if key in g else g["out_full/" + k]
+        got = _crops(a4) if key in g else a4
+        if a.dtype == np.float32:
+            assert np.abs(got - ref).max() < PROB_TOL, k
+        else:
+            assert (got != ref).mean() < 1e-4, k
+    for k, v in lg.items():
+        a = v.permute(0, 2, 3, 1).contiguous().cpu().numpy()
+        key = "logits_crops/" + k
+        ref = g[key] if key in g else g["logits_full/" + k]
+        got = _crops(a) if key in g else a
+        assert np.abs(got - ref).max() < 3e-4, k
+
+
+def test_infer_step_full_tensor_vs_oracle(full_model):
+    m, sd, kw = full_model
+    tiles = np.random.RandomState(5).randint(0, 256, (3, 256, 256, 3)).astype(np.uint8)
+    got = infer_step(torch.from_numpy(tiles), m, 256, kw["considered_tasks"])
+    ref = net_ref.infer_step(sd, tiles, 256, kw["considered_tasks"], kw["decoder_kwargs"])
+    for i in range(3):
+        assert list(got[i].keys()) == list(ref[i].keys())
+        for k in ref[i]:
+            a, b = got[i][k], ref[i][k]
+            assert a.shape == b.shape and a.dtype == b.dtype, k
+            if a.dtype == np.float32:
+                assert np.abs(a - b).max() < PROB_TOL, k
+            else:
+                assert (a != b).mean() < 1e-4, k
+
+
+def test_ragged_batch_sizes_and_crop(full_model):
+    """batch 1 (the squeeze/unsqueeze special case of run_desc.py:484-487) and a non-multiple-of-32 tile size."""
+    m, sd, kw = full_model
+    tiles = np.random.RandomState(6).randint(0, 256, (1, 304, 304, 3)).astype(np.uint8)
+    got = infer_step(torch.from_numpy(tiles), m, [144, 160], kw["considered_tasks"])
+    ref = net_ref.infer_step(sd, tiles, [144, 160], kw["considered_tasks"], kw["decoder_kwargs"])
+    for k in ref[0]:
+        a, b = got[0][k], ref[0][k]
+        assert a.shape == b.shape and a.dtype == b.dtype, k
+        if a.dtype == np.float32:
+            assert np.abs(a - b).max() < PROB_TOL, k
+        else:
+            assert (a != b).mean() < 1e-4, k
+
+
+def test_linearity_property_of_identical_tiles(full_model):
+    """Size-independent property: a batch of identical tiles gives identical outputs per sample, and outputs do not
+    depend on the batch they were computed in (eval-mode BN, no cross-tile state -- SURVEY.md par.8e)."""
+    m, sd, kw = full_model
+    t = torch.randint(0, 256, (1, 256, 256, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(3))
+    other = torch.randint(0, 256, (6, 256, 256, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(4))
+    a = m.infer_tiles(t.cuda(), 256)
+    b = m.infer_tiles(torch.cat([other[:3], t, other[3:]]).cuda(), 256)
+    for k in a:
+        assert torch.equal(a[k][0], b[k][3]), k
+
+
+def test_scatter_into_canvas(full_model):
+    """tile_off/row_stride addressing == the stitching of infer/tile.py:141-163 for non-overlapping patches."""
+    m, sd, kw = full_model
+    tiles = torch.randint(0, 256, (4, 256, 256, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(8)).cuda()
+    dense = m.infer_tiles(tiles, 256)
+    W = 512
+    canvas = torch.zeros((512, W, 2), dtype=torch.float32, device="cuda")
+    tmap = torch.zeros((512, W), dtype=torch.uint8, device="cuda")
+    off = torch.tensor([0, 256, 256 * W, 256 * W + 256], dtype=torch.int64, device="cuda")
+    outs = [None] * 6
+    outs[2] = canvas
+    outs[3] = tmap
+    m._run(tiles, 256, 256, outs, None, tile_off=off, row_stride=W, type_is_u8=True)
+    torch.cuda.synchronize()
+    for i, (y, x) in enumerate([(0, 0), (0, 256), (256, 0), (256, 256)]):
+        assert torch.equal(canvas[y:y + 256, x:x + 256], dense["Nuclei-INST"][i])
+        assert torch.equal(tmap[y:y + 256, x:x + 256].long(), dense["Nuclei-TYPE"][i])
