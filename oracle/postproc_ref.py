@@ -1,0 +1,107 @@
+"""ORACLE (test infrastructure only): ctypes wrapper of oracle/postproc_ref.c, same call protocol as the reference's
+PostProcInstErodedContourMap.post_process (loader/postproc.py:383-407).  Never imported by cerberus_amd/."""
+import copy
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libpostproc_ref.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(_HERE, "postproc_ref.c")
+        if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", _HERE])
+        _lib = C.CDLL(_SO)
+        for f in ("ref_proc_gland", "ref_proc_lumen"):
+            getattr(_lib, f).argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        _lib.ref_proc_nuclei.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _lib.ref_label4.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _lib.ref_watershed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _lib.ref_fill_holes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        _lib.ref_dilate_ellipse.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _lib.ref_erode_cross3.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _lib.ref_remove_small_labels.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_int]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def label4(mask):
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    out = np.zeros(m.shape, np.int32)
+    n = lib().ref_label4(_p(m), m.shape[0], m.shape[1], _p(out))
+    return out, n
+
+
+def watershed(image_f32, markers_i32, mask):
+    img = np.ascontiguousarray(image_f32, dtype=np.float32)
+    mk = np.ascontiguousarray(markers_i32, dtype=np.int32)
+    ms = np.ascontiguousarray(mask, dtype=np.uint8)
+    out = np.zeros(img.shape, np.int32)
+    lib().ref_watershed(_p(img), _p(mk), _p(ms), img.shape[0], img.shape[1], _p(out))
+    return out
+
+
+def fill_holes(mask):
+    m = np.ascontiguousarray(mask, dtype=np.uint8).copy()
+    lib().ref_fill_holes(_p(m), m.shape[0], m.shape[1])
+    return m
+
+
+def dilate_ellipse(mask, k):
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    out = np.zeros_like(m)
+    lib().ref_dilate_ellipse(_p(m), m.shape[0], m.shape[1], int(k), _p(out))
+    return out
+
+
+def erode_cross3(mask):
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    out = np.zeros_like(m)
+    lib().ref_erode_cross3(_p(m), m.shape[0], m.shape[1], _p(out))
+    return out
+
+
+def proc(inst_fg, tissue, ds_factor=1.0):
+    """inst_fg (H,W,2) float32 -> instance map with the reference's dtype (int32 for the nuclei watershed branch,
+    float64 otherwise: postproc.py:290,331,380)."""
+    a = np.ascontiguousarray(inst_fg, dtype=np.float32)
+    H, W = a.shape[:2]
+    out = np.zeros((H, W), np.int32)
+    t = tissue.upper()
+    if t == "NUCLEI":
+        ran = lib().ref_proc_nuclei(_p(a), H, W, _p(out))
+        return out if ran else out.astype(np.float64)
+    if t == "GLAND":
+        lib().ref_proc_gland(_p(a), H, W, C.c_float(ds_factor), _p(out))
+    elif t == "LUMEN":
+        lib().ref_proc_lumen(_p(a), H, W, C.c_float(ds_factor), _p(out))
+    else:
+        raise AssertionError(tissue)
+    return out.astype(np.float64)
+
+
+class PostProcInstErodedContourMap(object):
+    @classmethod
+    def post_process(cls, raw_map, idx_dict, tissue_mode, ds_factor=1.0):
+        assert tissue_mode.upper() in ("LUMEN", "GLAND", "NUCLEI")
+        tissue_ch = "%s-INST" % tissue_mode
+        idx_dict = copy.deepcopy(idx_dict)
+        assert tissue_ch in list(idx_dict.keys())
+        inst_fg = raw_map[..., idx_dict[tissue_ch][0]: idx_dict[tissue_ch][1]]
+        inst_map = proc(inst_fg, tissue_mode, ds_factor)
+        type_ch = tissue_mode + "-" + "TYPE"
+        if type_ch in list(idx_dict.keys()):
+            type_map = np.squeeze(raw_map[..., idx_dict[type_ch][0]: idx_dict[type_ch][1]])
+        else:
+            type_map = None
+        return inst_map, type_map
