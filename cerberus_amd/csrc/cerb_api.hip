@@ -55,6 +55,7 @@ static int fail(const std::string& m) {
         if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));     \
     } while (0)
 
+int cerb_set_error(const std::string& m) { return fail(m); }  // shared with postproc.hip
 extern "C" int cerb_version(void) { return 1; }
 extern "C" const char* cerb_last_error(void) { return g_err.c_str(); }
 

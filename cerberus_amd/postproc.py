@@ -1,0 +1,114 @@
+"""Mirror of the reference's instance post-processing (loader/postproc.py:268-407) on top of the HIP kernels.
+
+    PostProcInstErodedContourMap.post_process(raw_map, idx_dict, tissue_mode, ds_factor=1.0) -> (inst_map, type_map)
+
+keeps the reference's signature, assertions and return dtypes (int32 for the nuclei watershed branch, float64
+otherwise) when called with numpy arrays.  The device-resident entry points used by the tile / WSI drivers are
+`postproc_device` (one INST map -> int32 label map, all on the GPU) and `mask_lumen_by_gland`.
+
+Handles are not picklable, so this runs in the main process (the reference's nr_post_proc_workers=0 path,
+infer/tile.py:413-416).  There is no CPU fallback.
+"""
+import copy
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_ws_cache = {}
+
+
+def _workspace(device, h, w):
+    need = int(_lib.lib().cerb_pp_workspace_bytes(int(h), int(w)))
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < need:
+        _ws_cache[key] = t = torch.empty(need, dtype=torch.uint8, device=device)
+    return t
+
+
+def postproc_device(inst, tissue_mode, ds_factor=1.0, out=None):
+    """inst: CUDA float32 tensor (H,W,2) or a strided (H,W,>=2) window of a canvas (channel 0 inner, 1 contour).
+    Returns (labels int32 CUDA (H,W), info) with info = {'n_inst': 0-d CUDA int32 (-1: empty nuclei map),
+    'n_ambiguous': 0-d CUDA int32 (nuclei only)}.  Nothing is synchronised for nuclei."""
+    if not torch.cuda.is_available():
+        raise _lib.CerberusHipError("cerberus_amd needs a ROCm GPU; there is no CPU fallback")
+    L = _lib.lib()
+    assert inst.is_cuda and inst.dtype == torch.float32 and inst.dim() == 3 and inst.shape[2] >= 2
+    assert inst.stride(2) == 1, "inner/contour channels must be adjacent"
+    h, w = int(inst.shape[0]), int(inst.shape[1])
+    dev = inst.device
+    labels = out if out is not None else torch.empty((h, w), dtype=torch.int32, device=dev)
+    assert labels.is_contiguous() and labels.dtype == torch.int32 and tuple(labels.shape) == (h, w)
+    meta = torch.zeros(2, dtype=torch.int32, device=dev)
+    ws = _workspace(dev, h, w)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    t = tissue_mode.upper()
+    with torch.cuda.device(dev):
+        if t == "NUCLEI":
+            _lib.check(L.cerb_postproc_nuclei(inst.data_ptr(), h, w, inst.stride(0), inst.stride(1), labels.data_ptr(), meta.data_ptr(),
+                                              meta.data_ptr() + 4, ws.data_ptr(), ws.numel(), C.c_void_p(stream)))
+        elif t in ("GLAND", "LUMEN"):
+            fn = L.cerb_postproc_gland if t == "GLAND" else L.cerb_postproc_lumen
+            _lib.check(fn(inst.data_ptr(), h, w, inst.stride(0), inst.stride(1), C.c_float(ds_factor), labels.data_ptr(), meta.data_ptr(),
+                          ws.data_ptr(), ws.numel(), C.c_void_p(stream)))
+        else:
+            raise AssertionError(tissue_mode)
+    return labels, {"n_inst": meta[0], "n_ambiguous": meta[1]}
+
+
+def mask_lumen_by_gland(lumen, gland):
+    """Lumen *= (Gland > 0)   (infer/tile.py:187-191) in place on the GPU."""
+    assert lumen.is_cuda and gland.is_cuda and lumen.dtype == torch.int32 and gland.dtype == torch.int32
+    assert lumen.is_contiguous() and gland.is_contiguous() and lumen.shape == gland.shape
+    stream = torch.cuda.current_stream(lumen.device).cuda_stream
+    with torch.cuda.device(lumen.device):
+        _lib.check(_lib.lib().cerb_mask_lumen_by_gland(lumen.data_ptr(), gland.data_ptr(), lumen.numel(), C.c_void_p(stream)))
+    return lumen
+
+
+class PostProcInstErodedContourMap(object):
+    """Drop-in for the reference class of the same name (loader/postproc.py:268)."""
+
+    last_info = None
+
+    @classmethod
+    def post_process(cls, raw_map, idx_dict, tissue_mode, ds_factor=1.0):
+        assert tissue_mode.upper() in ("LUMEN", "GLAND", "NUCLEI")
+        tissue_ch = f"{tissue_mode}-INST"
+        idx_dict = copy.deepcopy(idx_dict)
+        assert tissue_ch in list(idx_dict.keys())
+        is_np = isinstance(raw_map, np.ndarray)
+        dev_map = torch.from_numpy(np.ascontiguousarray(raw_map, dtype=np.float32)).cuda() if is_np else raw_map
+        inst_fg = dev_map[..., idx_dict[tissue_ch][0]: idx_dict[tissue_ch][1]]
+        assert inst_fg.shape[-1] == 2
+        labels, info = postproc_device(inst_fg, tissue_mode, ds_factor)
+        cls.last_info = info
+        type_ch = tissue_mode + "-" + "TYPE"
+        if type_ch in list(idx_dict.keys()):
+            type_map = raw_map[..., idx_dict[type_ch][0]: idx_dict[type_ch][1]]
+            type_map = np.squeeze(type_map) if is_np else torch.squeeze(type_map)
+        else:
+            type_map = None
+        if not is_np:
+            return labels, type_map
+        inst_map = labels.cpu().numpy()
+        # reference dtypes: int32 out of skimage.watershed, float64 zeros / canvases otherwise (postproc.py:290,331,380)
+        if tissue_mode.upper() != "NUCLEI" or int(info["n_inst"].item()) < 0:
+            inst_map = inst_map.astype(np.float64)
+        return inst_map, type_map
+
+
+def smoke_postproc():
+    """Tiny on-GPU check against the oracle (called by __graft_entry__.smoke())."""
+    from oracle import postproc_ref, synth
+
+    m = synth.nuclei_maps(160, 192, 3, 2500.0, noise=0.02)
+    got, info = postproc_device(torch.from_numpy(m).cuda(), "Nuclei")
+    ref = postproc_ref.proc(m, "Nuclei")
+    assert np.array_equal(got.cpu().numpy(), ref), "nuclei label map differs from the oracle"
+    g = synth.blob_maps(256, 256, 4, 8, 18.0, 40.0, rim=4.0, sharp=1.0)
+    got, _ = postproc_device(torch.from_numpy(g).cuda(), "Gland")
+    assert np.array_equal(got.cpu().numpy(), postproc_ref.proc(g, "Gland").astype(np.int32)), "gland label map differs from the oracle"

@@ -87,7 +87,9 @@ int cerb_net_profile_get(cerb_net* net, int idx, char* name, int name_cap, char*
  * inst : device float [H][W][2] (ch0 = inner, ch1 = contour), `pix_stride` floats between consecutive pixels
  *        (2 for a packed INST map) and `row_stride` floats between rows -- lets it read a canvas window in place.
  * labels_out : device int32 [H][W]; ids as the reference assigns them (raster order of first pixel).
- * n_inst_out : device int32[1]; number of instances.  n_ambiguous_out : device int32[1] (nuclei only): number of
+ * n_inst_out : device int32[1]; number of instances (nuclei: number of watershed markers; -1 when the map has no
+ *        foreground at all, the branch in which the reference returns an all-zero float64 map, postproc.py:379-380).
+ *        n_ambiguous_out : device int32[1] (nuclei only): number of
  *        watershed regions whose result depends on skimage's heap-internal order between seed pixels with
  *        bit-identical priority (see DESIGN.md "watershed ties"); 0 means the label map is provably identical.
  * ws / ws_bytes : caller-allocated device workspace of at least cerb_pp_workspace_bytes(H, W). */

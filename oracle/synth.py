@@ -13,7 +13,6 @@ def _sigmoid(x):
 def blob_maps(H, W, seed, n_blobs, rmin, rmax, sharp=1.5, noise=0.0, holes=0.0, rim=2.0, border_bias=False):
     """Returns (H,W,2) float32: ch0 inner prob, ch1 contour prob."""
     rs = np.random.RandomState(seed)
-    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
     d = np.full((H, W), -1e9, np.float32)  # signed distance-ish field: max over blobs of (r - dist)
     for i in range(n_blobs):
         r = rs.uniform(rmin, rmax)
@@ -23,14 +22,23 @@ def blob_maps(H, W, seed, n_blobs, rmin, rmax, sharp=1.5, noise=0.0, holes=0.0, 
             cy, cx = rs.uniform(0, H), rs.uniform(0, W)
         ax = rs.uniform(0.7, 1.3)
         th = rs.uniform(0, np.pi)
-        dy, dx = yy - cy, xx - cx
+        hole = holes > 0 and rs.rand() < holes
+        # each blob only touches a window around itself (cost O(blob area), not O(H*W))
+        ext = int(np.ceil(r * 1.45 + 14.0))
+        y0, y1 = max(0, int(cy) - ext), min(H, int(cy) + ext + 1)
+        x0, x1 = max(0, int(cx) - ext), min(W, int(cx) + ext + 1)
+        if y0 >= y1 or x0 >= x1:
+            continue
+        yy, xx = np.mgrid[y0:y1, x0:x1].astype(np.float32)
+        dy, dx = yy - np.float32(cy), xx - np.float32(cx)
         u = (np.cos(th) * dx + np.sin(th) * dy) * ax
         v = (-np.sin(th) * dx + np.cos(th) * dy) / ax
         dist = np.sqrt(u * u + v * v)
         f = r - dist
-        if holes > 0 and rs.rand() < holes:
+        if hole:
             f = np.minimum(f, dist - 0.35 * r)  # annulus: a hole in the middle
-        d = np.maximum(d, f.astype(np.float32))
+        d[y0:y1, x0:x1] = np.maximum(d[y0:y1, x0:x1], f.astype(np.float32))
+    d = np.maximum(d, np.float32(-40.0))
     inner = _sigmoid(sharp * (d - rim))
     cnt = _sigmoid(sharp * (rim - np.abs(d - 0.5 * rim))) * 0.95
     if noise > 0:
