@@ -393,6 +393,7 @@ __global__ __launch_bounds__(256) void ws_flood_kernel(const float* __restrict__
         u32 age = 0;
         bool have_prev_seed = false, ambiguous = false;
         u32 prev_seed_val = 0;
+        int prev_seed_lab = 0;
         while (n > 0) {
             const u64 k = hk[0];
             const u32 p = hi[0];
@@ -402,13 +403,17 @@ __global__ __launch_bounds__(256) void ws_flood_kernel(const float* __restrict__
                 const u32 li = hi[n];
                 heap_sift_down(hk, hi, n, 0, lk, li);
             }
-            if ((u32)k == 0u) {  // a seed (age 0): equal-priority seeds are where skimage's heap order is not canonical
+            const int lab = __hip_atomic_load(&out[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((u32)k == 0u) {
+                // A seed (age 0).  skimage's pop order between seeds with bit-identical priority depends on its binary
+                // heap's layout; that order can only change the result when the tied seeds carry DIFFERENT labels
+                // (same-label ties only permute ages inside one label's own front) -- see DESIGN.md "watershed ties".
                 const u32 v = (u32)(k >> 32);
-                if (have_prev_seed && v == prev_seed_val) ambiguous = true;
+                if (have_prev_seed && v == prev_seed_val && lab != prev_seed_lab) ambiguous = true;
                 have_prev_seed = true;
                 prev_seed_val = v;
+                prev_seed_lab = lab;
             }
-            const int lab = __hip_atomic_load(&out[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int y = (int)(p / (u32)W), x = (int)(p % (u32)W);
             // lanes 0..3 look at the four neighbours in skimage's order: up, left, right, down
             long long q = -1;

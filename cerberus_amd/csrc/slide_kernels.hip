@@ -1,0 +1,118 @@
+// Slide-level data movement of the WSI path on gfx950 (HBM-bound byte work):
+//   cerb_synth_slide     : counter-based synthetic RGB slide (value depends only on seed and absolute (y,x,c), so any
+//                          sharding of the slide over GPUs sees the same pixels)
+//   cerb_gather_patches  : patch extraction with mirror padding -- replaces the padded-image slicing of
+//                          reference loader/infer_loader.py:54-69 + np.pad(..., "reflect") of infer/tile.py:69 and the
+//                          WSIStreamDataset reads of infer/wsi.py:936-950 for a device-resident slide
+//   cerb_downsample2_inst: x0.5 bilinear resize of an INST probability map (cv2.resize(fx=0.5, INTER_LINEAR),
+//                          reference infer/wsi.py:786-788) == exact 2x2 box average at this scale
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/cerberus_hip.h"
+
+int cerb_set_error(const std::string& m);
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+__global__ void synth_slide_kernel(uint8_t* __restrict__ out, long long h, long long w, long long y0, long long x0, uint32_t seed) {
+    const long long n = h * w;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        const long long y = y0 + p / w, x = x0 + p % w;
+        const uint32_t hsh = mix32((uint32_t)x * 0x9E3779B1u ^ mix32((uint32_t)y + seed * 0x85EBCA77u));
+        out[p * 3 + 0] = (uint8_t)(hsh);
+        out[p * 3 + 1] = (uint8_t)(hsh >> 8);
+        out[p * 3 + 2] = (uint8_t)(hsh >> 16);
+    }
+}
+
+__device__ __forceinline__ long long reflect_idx(long long i, long long n) {  // numpy "reflect": no edge repeat, period 2(n-1)
+    if (n == 1) return 0;
+    const long long period = 2 * (n - 1);
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - i;
+}
+
+// tiles[k][y][x][c] = slide[reflect(tl_y[k] + y - slide_y0)][reflect(tl_x[k] + x)][c]; reflection is about the FULL slide
+// extent (full_h rows starting at absolute row 0); rows outside [slide_y0, slide_y0 + h) after reflection are an error the
+// host prevents by giving each rank its band plus halo.
+__global__ void gather_patches_kernel(const uint8_t* __restrict__ slide, long long h, long long w, long long slide_y0, long long full_h,
+                                      const long long* __restrict__ tl_y, const long long* __restrict__ tl_x, int win,
+                                      uint8_t* __restrict__ tiles) {
+    const int k = blockIdx.y;
+    const long long ty = tl_y[k], tx = tl_x[k];
+    const int per = win * win;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per; i += gridDim.x * blockDim.x) {
+        const int y = i / win, x = i % win;
+        const long long sy = reflect_idx(ty + y, full_h) - slide_y0;
+        const long long sx = reflect_idx(tx + x, w);
+        uint8_t r = 0, g = 0, b = 0;
+        if (sy >= 0 && sy < h) {
+            const uint8_t* s = slide + (sy * w + sx) * 3;
+            r = s[0];
+            g = s[1];
+            b = s[2];
+        }
+        uint8_t* d = tiles + ((long long)k * per + i) * 3;
+        d[0] = r;
+        d[1] = g;
+        d[2] = b;
+    }
+}
+
+__global__ void downsample2_inst_kernel(const float* __restrict__ src, long long row_stride, int pix_stride, int ho, int wo, float* __restrict__ dst) {
+    const long long n = (long long)ho * wo;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(p / wo), x = (int)(p % wo);
+        const float* a = src + (2ll * y) * row_stride + (2ll * x) * pix_stride;
+        const float* b = a + row_stride;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float top = a[c] * 0.5f + a[pix_stride + c] * 0.5f;
+            const float bot = b[c] * 0.5f + b[pix_stride + c] * 0.5f;
+            dst[p * 2 + c] = top * 0.5f + bot * 0.5f;
+        }
+    }
+}
+
+static unsigned grid_for(long long n) {
+    long long b = (n + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+#define SK_CHECK()                                                                                    \
+    do {                                                                                              \
+        hipError_t e_ = hipGetLastError();                                                            \
+        if (e_ != hipSuccess) return cerb_set_error(std::string("kernel launch: ") + hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int cerb_synth_slide(uint8_t* out, long long h, long long w, long long y0, long long x0, uint32_t seed, void* hip_stream) {
+    if (!out || h <= 0 || w <= 0) return cerb_set_error("cerb_synth_slide: bad arguments");
+    hipLaunchKernelGGL(synth_slide_kernel, dim3(grid_for(h * w)), dim3(256), 0, (hipStream_t)hip_stream, out, h, w, y0, x0, seed);
+    SK_CHECK();
+    return 0;
+}
+extern "C" int cerb_gather_patches(const uint8_t* slide, long long h, long long w, long long slide_y0, long long full_h, const long long* tl_y,
+                                   const long long* tl_x, int n, int win, uint8_t* tiles, void* hip_stream) {
+    if (!slide || !tl_y || !tl_x || !tiles || n <= 0 || win <= 0 || h <= 0 || w <= 0) return cerb_set_error("cerb_gather_patches: bad arguments");
+    hipLaunchKernelGGL(gather_patches_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)hip_stream, slide, h, w, slide_y0, full_h, tl_y, tl_x, win, tiles);
+    SK_CHECK();
+    return 0;
+}
+extern "C" int cerb_downsample2_inst(const float* src, long long row_stride, int pix_stride, int h, int w, float* dst, void* hip_stream) {
+    if (!src || !dst || h < 2 || w < 2) return cerb_set_error("cerb_downsample2_inst: bad arguments");
+    hipLaunchKernelGGL(downsample2_inst_kernel, dim3(grid_for((long long)(h / 2) * (w / 2))), dim3(256), 0, (hipStream_t)hip_stream, src, row_stride,
+                       pix_stride, h / 2, w / 2, dst);
+    SK_CHECK();
+    return 0;
+}

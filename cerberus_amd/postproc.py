@@ -100,15 +100,3 @@ class PostProcInstErodedContourMap(object):
             inst_map = inst_map.astype(np.float64)
         return inst_map, type_map
 
-
-def smoke_postproc():
-    """Tiny on-GPU check against the oracle (called by __graft_entry__.smoke())."""
-    from oracle import postproc_ref, synth
-
-    m = synth.nuclei_maps(160, 192, 3, 2500.0, noise=0.02)
-    got, info = postproc_device(torch.from_numpy(m).cuda(), "Nuclei")
-    ref = postproc_ref.proc(m, "Nuclei")
-    assert np.array_equal(got.cpu().numpy(), ref), "nuclei label map differs from the oracle"
-    g = synth.blob_maps(256, 256, 4, 8, 18.0, 40.0, rim=4.0, sharp=1.0)
-    got, _ = postproc_device(torch.from_numpy(g).cuda(), "Gland")
-    assert np.array_equal(got.cpu().numpy(), postproc_ref.proc(g, "Gland").astype(np.int32)), "gland label map differs from the oracle"

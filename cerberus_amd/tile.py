@@ -1,0 +1,231 @@
+"""Tile-mode inference manager: mirror of the reference's infer/base.py + infer/tile.py on the HIP path.
+
+Kept from the reference: patch geometry (`_prepare_patching`, infer/tile.py:43-106), the channel layout of the
+stitched canvas (infer/tile.py:116-134), the post-processing dispatch and the lumen-inside-gland rule (:168-191), the
+x2 nearest up-scaling of the saved maps (:196-199), the `.mat` outputs and the resume-by-skip rule (:225-238, :261-287).
+
+Different by design (MI355X-first):
+  * every patch is inferred ONCE.  With patch_output_overlap == 0 the reference appends every patch twice and
+    averages (infer/tile.py:90-103,160): (x + x) / (2 + 1e-8 -> 2.0f) == x exactly in float32, so the stitched maps
+    are identical.
+  * stitching is not a host loop: the head kernels write each patch's centre crop straight into device-resident
+    per-head canvases (tile_off / row_stride of cerb_net_forward), and post-processing reads those canvases in place;
+    only the final integer label maps leave the GPU.
+  * post-processing runs in the main process (GPU handles are not picklable) -- the reference's
+    nr_post_proc_workers=0 path.
+Not implemented (SURVEY.md par.8f "next" rows): contour tracing (cv2.findContours) and the overlay jpg.
+"""
+import math
+import os
+import pathlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .net_desc import create_model
+from .postproc import mask_lumen_by_gland, postproc_device
+from .run_desc import infer_step
+
+POSTPROC_CODES = ("IP-ERODED-CONTOUR-3", "IP-ERODED-CONTOUR-11")  # -> PostProcInstErodedContourMap (infer/tile.py:35-40)
+
+
+def _prepare_patching(img, input_size, output_size, output_overlap_size):
+    """Mirror padding + patch placement; same return values as the reference (infer/tile.py:43-106):
+    padded_img, info_list int32 [P, 2(in/out), 2(tl/br), 2(y/x)], [padt, padl]."""
+    win, step = int(input_size), int(output_size)
+    im_h, im_w = img.shape[:2]
+
+    def last_step(length):
+        nr = math.ceil((length - step) / step)
+        return int((nr + 1) * step)
+
+    last_h, last_w = last_step(im_h), last_step(im_w)
+    diff = win - step
+    padt = padl = diff // 2
+    padb, padr = last_h + win - im_h, last_w + win - im_w
+    padded = np.pad(img, ((padt, padb), (padl, padr), (0, 0)), "reflect")
+    ys = np.arange(0, last_h, step, dtype=np.int32)
+    xs = np.arange(0, last_w, step, dtype=np.int32)
+    # the reference's np.meshgrid(y, x) (xy indexing) flattens with x slow, y fast
+    in_tl = np.stack([np.tile(ys, len(xs)), np.repeat(xs, len(ys))], axis=-1).astype(np.int32)
+    out_tl = in_tl + diff // 2
+
+    def boxes(i_tl, o_tl):
+        i_br, o_br = i_tl + win, o_tl + step
+        keep = ~np.any(i_br > np.array(padded.shape[:2]), axis=-1)
+        return np.stack([np.stack([i_tl[keep], i_br[keep]], axis=1), np.stack([o_tl[keep], o_br[keep]], axis=1)], axis=1)
+
+    info = boxes(in_tl, out_tl)
+    if output_overlap_size == 0:
+        # reference quirk kept for protocol parity: the patch list is appended to itself (infer/tile.py:90-103)
+        o2 = out_tl + output_overlap_size
+        info = np.concatenate([info, boxes(o2 - diff // 2, o2)], axis=0)
+    return padded, info, [padt, padl]
+
+
+def channel_layout(decoder_kwargs):
+    """idx_dict of the stitched canvas (infer/tile.py:119-134): INST -> nr_chans-1 channels, TYPE / other -> 1."""
+    idx, n = OrderedDict(), 0
+    for tissue_name, info in decoder_kwargs.items():
+        for chann_type, nr in info.items():
+            s = n
+            if chann_type == "INST":
+                n += nr - 1
+                idx[tissue_name + "-INST"] = [s, n]
+            elif chann_type == "TYPE":
+                n += 1
+                idx[tissue_name.split("#")[0] + "-TYPE"] = [s, n]
+            else:
+                n += 1
+                idx[tissue_name] = [s, n]
+    return idx, n
+
+
+def inst_info_table(inst_map, type_map=None):
+    """Per-instance box / centroid / majority type (the non-contour part of get_inst_info_dict,
+    loader/postproc.py:12-75).  Host numpy over the final integer maps; contour tracing is a 'next' row."""
+    inst_map = np.asarray(inst_map)
+    ids = np.unique(inst_map)
+    ids = ids[ids != 0]
+    info = OrderedDict()
+    if ids.size == 0:
+        return info
+    lab = inst_map.astype(np.int64)
+    H, W = lab.shape
+    yy, xx = np.divmod(np.arange(H * W), W)
+    flat = lab.ravel()
+    sel = flat > 0
+    f, y, x = flat[sel], yy[sel], xx[sel]
+    order = np.argsort(f, kind="stable")
+    f, y, x = f[order], y[order], x[order]
+    starts = np.flatnonzero(np.r_[True, f[1:] != f[:-1]])
+    ends = np.r_[starts[1:], f.size]
+    t = type_map.ravel()[sel][order] if type_map is not None else None
+    for s, e in zip(starts, ends):
+        iid = int(f[s])
+        rmin, rmax, cmin, cmax = y[s:e].min(), y[s:e].max() + 1, x[s:e].min(), x[s:e].max() + 1
+        d = {
+            "box": np.array([[rmin, cmin], [rmax, cmax]]),
+            "centroid": np.array([x[s:e].mean(), y[s:e].mean()]),  # cv2.moments m10/m00, m01/m00 of the binary mask
+            "contour": None,
+        }
+        if t is not None:
+            tl, tc = np.unique(t[s:e], return_counts=True)
+            o = np.argsort(-tc, kind="stable")
+            tl, tc = tl[o], tc[o]
+            it = tl[0]
+            if it == 0 and len(tl) > 1:  # pick the 2nd most dominant if exist (postproc.py:69-71)
+                it = tl[1]
+            d["type"] = int(it)
+            d["type_prob"] = float(dict(zip(tl, tc))[it] / ((e - s) + 1.0e-6))
+        info[iid] = d
+    return info
+
+
+class InferManager(object):
+    """Tile inference manager (reference infer/base.py:9-54 + infer/tile.py:215-429)."""
+
+    def __init__(self, **kwargs):
+        self.run_step = None
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+        self._load_model()
+
+    def _load_model(self):
+        net = create_model(**self.model_args)
+        ckpt = getattr(self, "checkpoint_path", None)
+        if ckpt is not None:
+            saved = torch.load(ckpt, map_location="cpu")["desc"]
+            if all(k.split(".")[0] == "module" for k in saved.keys()):  # data-parallel checkpoint (infer/base.py:30-44)
+                saved = {".".join(k.split(".")[1:]): v for k, v in saved.items()}
+            net.load_state_dict(saved, strict=True)
+        self.net = net
+        self.run_step = lambda input_batch, output_shape: infer_step(input_batch, net, output_shape, self.model_args["considered_tasks"])
+
+    # ---- one image, everything on the GPU ---------------------------------------------------------------------
+    def infer_image(self, img, patch_input_shape, patch_output_shape, batch_size=32, postproc_list=("gland", "lumen", "nuclei", "patch-class")):
+        """img: HxWx3 uint8 RGB (numpy).  Returns dict with device tensors:
+        'raw': per-head stitched canvases cropped to the source image, 'inst': {Tissue: int32 label map},
+        'type': {Tissue: uint8 map or None}, 'pclass': float32 map or None, 'info': per-tissue postproc info."""
+        net = self.net
+        dev = torch.device("cuda", torch.cuda.current_device())
+        padded, info, src_pos = _prepare_patching(img, patch_input_shape, patch_output_shape, 0)
+        uniq = info[: info.shape[0] // 2]  # second half duplicates the first (see module docstring)
+        hw = np.max(info[:, 1, 1], axis=0).tolist()
+        Hc, Wc = int(hw[0]), int(hw[1])
+        pad_dev = torch.from_numpy(np.ascontiguousarray(padded)).to(dev)
+        canv = OrderedDict()
+        for name, hname, och, key in net._decoders:
+            if hname == "INST":
+                canv[key] = torch.zeros((Hc, Wc, 2), dtype=torch.float32, device=dev)
+            elif hname == "TYPE":
+                canv[key] = torch.zeros((Hc, Wc), dtype=torch.uint8, device=dev)
+            else:
+                canv[key] = torch.zeros((Hc, Wc), dtype=torch.float32, device=dev)
+        outs = [canv[d[3]] for d in net._decoders]
+        win, osz = int(patch_input_shape), int(patch_output_shape)
+        for b0 in range(0, uniq.shape[0], batch_size):
+            chunk = uniq[b0:b0 + batch_size]
+            tiles = torch.stack([pad_dev[int(i[0, 0, 0]):int(i[0, 0, 0]) + win, int(i[0, 0, 1]):int(i[0, 0, 1]) + win] for i in chunk])
+            off = torch.tensor([int(i[1, 0, 0]) * Wc + int(i[1, 0, 1]) for i in chunk], dtype=torch.int64, device=dev)
+            net._run(tiles, osz, osz, outs, None, tile_off=off, row_stride=Wc, type_is_u8=True)
+        y0, x0 = src_pos
+        sh, sw = img.shape[:2]
+        raw = OrderedDict((k, v[y0:y0 + sh, x0:x0 + sw]) for k, v in canv.items())
+        inst, types, pp_info = OrderedDict(), OrderedDict(), OrderedDict()
+        pclass = None
+        for tissue in postproc_list:
+            tissue = tissue.capitalize()
+            code = self.decoder_dict.get(tissue + "-INST") if getattr(self, "decoder_dict", None) else "IP-ERODED-CONTOUR-3"
+            if tissue + "-INST" in raw:
+                if code not in POSTPROC_CODES:
+                    raise NotImplementedError("post-proc code %r: only IP-ERODED-CONTOUR-* (PostProcInstErodedContourMap) is on the HIP path" % code)
+                inst[tissue], pp_info[tissue] = postproc_device(raw[tissue + "-INST"], tissue)
+                types[tissue] = raw.get(tissue + "-TYPE")
+            elif tissue == "Patch-class":
+                pclass = raw.get("Patch-Class")
+        if "Lumen" in inst and "Gland" in inst:
+            mask_lumen_by_gland(inst["Lumen"], inst["Gland"])
+        return {"raw": raw, "inst": inst, "type": types, "pclass": pclass, "info": pp_info}
+
+    # ---- reference CLI behaviour --------------------------------------------------------------------------------
+    def process_file_list(self, run_args):
+        """Process every *.png / *.jpg of input_dir (tiles < 5000x5000) and write <tissue>_mat/<name>.mat + pclass_mat."""
+        import scipy.io as sio
+        from PIL import Image
+
+        for k, v in run_args.items():
+            setattr(self, k, v)
+        files = []
+        for root, _, fs in os.walk(self.input_dir):
+            files += [os.path.join(root, f) for f in fs if f.lower().endswith((".png", ".jpg"))]
+        todo = []
+        for fp in sorted(files):
+            base = os.path.basename(fp).split(".")[0]
+            if any(not os.path.exists("%s/%s_mat/%s.mat" % (self.output_dir, t, base)) for t in self.postproc_list):
+                todo.append(fp)
+        assert len(todo) > 0, "Not Detected Any Files From Path"
+        for fp in todo:
+            img = np.array(Image.open(fp).convert("RGB"))
+            res = self.infer_image(img, self.patch_input_shape, self.patch_output_shape, self.batch_size, self.postproc_list)
+            base = pathlib.Path(fp).stem
+            prev_type = None
+            for tissue, lab in res["inst"].items():
+                lab_np = lab.cpu().numpy()
+                lab2 = np.repeat(np.repeat(lab_np, 2, axis=0), 2, axis=1)  # cv2.resize(fx=2, fy=2, INTER_NEAREST)
+                tmap = res["type"].get(tissue)
+                tmap_np = tmap.cpu().numpy() if tmap is not None else None
+                if tissue != "Lumen" and tmap_np is not None:
+                    prev_type = np.repeat(np.repeat(tmap_np, 2, axis=0), 2, axis=1)
+                info = inst_info_table(lab2, prev_type)  # the reference re-uses the previous tissue's type map for Lumen
+                os.makedirs("%s/%s_mat/" % (self.output_dir, tissue.lower()), exist_ok=True)
+                mat = {"inst_map": lab_np.astype(np.float64) if tissue != "Nuclei" else lab_np,
+                       "type": [d.get("type", -1) for d in info.values()], "id": list(info.keys())}
+                if tmap_np is not None:
+                    mat["type_map"] = tmap_np.astype(np.float32)
+                sio.savemat("%s/%s_mat/%s.mat" % (self.output_dir, tissue.lower(), base), mat)
+            if res["pclass"] is not None:
+                os.makedirs("%s/pclass_mat/" % self.output_dir, exist_ok=True)
+                sio.savemat("%s/pclass_mat/%s.mat" % (self.output_dir, base), {"pclass": res["pclass"].cpu().numpy()})
+            print("Done Assembling %s" % base)

