@@ -140,6 +140,14 @@ def main():
     dom_name, (dom_fl, dom_ms, dom_cnt) = dom
     achieved = dom_fl / (dom_ms * 1e-3) / 1e12
     total_ms = sum(r[3] for r in recs)
+    # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate runs of this same command; gfx950 read-side x2 correction applied by scripts/rocprof_summary.py)
+    traffic = None
+    sym = {"conv_igemm<ks3,s1,mode0,8x32>": "void conv_igemm_kernel<3, 1, 8, 32, 32, 0>(ConvParams)",
+           "conv_igemm<ks3,s1,mode1,8x32>": "void conv_igemm_kernel<3, 1, 8, 32, 32, 1>(ConvParams)"}.get(dom_name)
+    pmc_path = os.path.join(ROOT, "profiles", "r01_bench_pmc_hbm.json")
+    if sym and os.path.exists(pmc_path):
+        traffic = json.load(open(pmc_path)).get(sym, {}).get("hbm_bytes_per_launch")
     roofline = {
         "bound": "mfma",
         "kernel": dom_name,
@@ -147,7 +155,9 @@ def main():
         "peak": PEAK_F32_MFMA_TFLOPS,
         "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-        "traffic": None,
+        "traffic": traffic,
+        "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_bench_pmc_hbm.json)",
+        "flop_per_launch": round(dom_fl / dom_cnt / 1e9, 3),
         "launches": dom_cnt,
         "avg_launch_ms": round(dom_ms / dom_cnt, 4),
         "kernel_share_of_step": round(dom_ms / total_ms, 4),

@@ -1,0 +1,58 @@
+"""Turn rocprofv3 rocpd databases (gpurun_out/...) into the small text/JSON summaries committed under profiles/.
+
+  python scripts/rocprof_summary.py stats  <results.db>  <out.txt>
+  python scripts/rocprof_summary.py pmc    <fetch.db> <write.db> <out.json>
+
+PMC post-processing follows /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KiB, collected in
+separate passes; on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced stream, so reads are
+doubled.  WRITE_SIZE is uncalibrated (taken as reported)."""
+import json
+import sqlite3
+import sys
+
+
+def stats(db, out):
+    c = sqlite3.connect(db)
+    rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels order by total_duration desc"))
+    with open(out, "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats summary (durations in microseconds)\n")
+        f.write("%-90s %8s %14s %12s %8s\n" % ("kernel", "calls", "total_us", "avg_us", "pct"))
+        for n, calls, tot, avg, pct in rows:
+            f.write("%-90s %8d %14.1f %12.3f %8.2f\n" % (n[:90], calls, tot, avg, pct))
+        # register / LDS footprint per kernel
+        f.write("\n# per-kernel launch footprint (first dispatch of each symbol)\n")
+        f.write("%-90s %6s %6s %8s %10s\n" % ("kernel", "vgpr", "sgpr", "lds", "wg"))
+        seen = set()
+        for n, v, s, lds, wg in c.execute("select name, vgpr_count, sgpr_count, lds_size, workgroup_x from kernels"):
+            if n in seen:
+                continue
+            seen.add(n)
+            f.write("%-90s %6s %6s %8s %10s\n" % (n[:90], v, s, lds, wg))
+    print("wrote", out)
+
+
+def pmc(fetch_db, write_db, out):
+    res = {}
+    for key, db in (("FETCH_SIZE", fetch_db), ("WRITE_SIZE", write_db)):
+        c = sqlite3.connect(db)
+        for name, n, avg in c.execute(
+            "select kernel_name, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name", (key,)
+        ):
+            if "at::native" in name:
+                continue
+            r = res.setdefault(name, {})
+            r[key + "_KiB_avg_per_launch"] = avg
+            r[key + "_launches"] = n
+    for name, r in res.items():
+        f = r.get("FETCH_SIZE_KiB_avg_per_launch", 0.0) or 0.0
+        w = r.get("WRITE_SIZE_KiB_avg_per_launch", 0.0) or 0.0
+        r["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0  # gfx950: FETCH_SIZE counts 64 B per 128-B request
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    print("wrote", out)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
