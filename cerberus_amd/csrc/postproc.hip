@@ -125,18 +125,38 @@ __device__ __forceinline__ void uf_union(int* L, int a, int b) {
     } while (!done);
 }
 
-// fg: foreground predicate bytes compared against `val` (lets one byte plane serve a mask and its complement)
-__global__ void ccl_init_kernel(const uint8_t* __restrict__ fg, uint8_t val, int* __restrict__ L, int n) {
-    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
-        L[p] = (fg[p] == val) ? (int)p : -1;
+// fg: foreground predicate bytes compared against `val` (lets one byte plane serve a mask and its complement).
+// Run-based initialisation: a wave owns 64 consecutive pixels; every pixel is linked straight to the first pixel of its
+// horizontal run inside that 64-pixel chunk (ballot + count-leading-zeros, no atomics), so the merge pass only needs one
+// union per run and row pair instead of two per pixel.
+__global__ void ccl_init_kernel(const uint8_t* __restrict__ fg, uint8_t val, int* __restrict__ L, int n, int W) {
+    const int lane = threadIdx.x & 63;
+    for (long long p0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) - lane; p0 < n; p0 += (long long)gridDim.x * blockDim.x) {
+        const long long p = p0 + lane;
+        const bool f = p < n && fg[p] == val;
+        const bool link = f && lane > 0 && (p % W) != 0 && fg[p - 1] == val;  // joined to the previous lane's pixel
+        const u64 starts = __ballot(f && !link);
+        if (f) {
+            const u64 below = starts & ((2ull << lane) - 1);  // run starts at or below this lane
+            L[p] = (int)(p0 + 63 - __clzll((long long)below));
+        } else if (p < n)
+            L[p] = -1;
+    }
 }
 __global__ void ccl_merge_kernel(const uint8_t* __restrict__ fg, uint8_t val, int* L, int H, int W) {
     const long long n = (long long)H * W;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
         if (fg[p] != val) continue;
         const int x = (int)(p % W);
-        if (x > 0 && fg[p - 1] == val) uf_union(L, (int)p, (int)p - 1);
-        if (p >= W && fg[p - W] == val) uf_union(L, (int)p, (int)(p - W));
+        const bool left = x > 0 && fg[p - 1] == val;
+        const bool chunk_start = (p & 63) == 0 || !left;  // first pixel of its run inside the 64-pixel chunk
+        if (left && (p & 63) == 0) uf_union(L, (int)p, (int)p - 1);  // run continues across the chunk boundary
+        if (p >= W && fg[p - W] == val) {
+            // one union per (upper run, lower run) pair: at the first column where they overlap either the lower run starts
+            // here, or the upper run does (its left neighbour is background)
+            const bool up_starts = !(x > 0 && fg[p - W - 1] == val);
+            if (chunk_start || up_starts) uf_union(L, (int)p, (int)(p - W));
+        }
     }
 }
 __global__ void ccl_flatten_kernel(int* L, int n) {
@@ -153,7 +173,7 @@ static unsigned grid_for(long long n) {
 }
 static int ccl_run(const uint8_t* fg, uint8_t val, int* L, int H, int W, hipStream_t st) {
     const int n = H * W;
-    hipLaunchKernelGGL(ccl_init_kernel, dim3(grid_for(n)), dim3(256), 0, st, fg, val, L, n);
+    hipLaunchKernelGGL(ccl_init_kernel, dim3(grid_for(n)), dim3(256), 0, st, fg, val, L, n, W);
     hipLaunchKernelGGL(ccl_merge_kernel, dim3(grid_for(n)), dim3(256), 0, st, fg, val, L, H, W);
     hipLaunchKernelGGL(ccl_flatten_kernel, dim3(grid_for(n)), dim3(256), 0, st, L, n);
     KCHECK();
@@ -274,10 +294,13 @@ __global__ void ws_cap_kernel(const int* __restrict__ L, const int* __restrict__
 }
 __global__ void ws_seed_kernel(const float* __restrict__ inst, long long row_stride, int pix_stride, const uint8_t* __restrict__ mask,
                                const int* __restrict__ out, const int* __restrict__ L, const int* __restrict__ hoff, int* __restrict__ hcnt,
-                               u64* __restrict__ hkey, u32* __restrict__ hidx, int H, int W) {
+                               u64* __restrict__ hkey, u32* __restrict__ hidx, int H, int W, int* __restrict__ unl) {
     const long long n = (long long)H * W;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
-        if (!out[p]) continue;
+        if (!out[p]) {
+            if (mask[p]) atomicAdd(&unl[L[p]], 1);  // floodable pixel of its component
+            continue;
+        }
         const int y = (int)(p / W), x = (int)(p % W);
         bool active = false;
         if (y > 0 && mask[p - W] && !out[p - W]) active = true;
@@ -292,10 +315,50 @@ __global__ void ws_seed_kernel(const float* __restrict__ inst, long long row_str
         hidx[slot] = (u32)p;
     }
 }
-// compact list of component roots that own at least one seed
-__global__ void ws_worklist_kernel(const int* __restrict__ hcnt, int* __restrict__ wl, int* __restrict__ wl_n, int n) {
+// bounding box of every kept mask component, keyed by its root pixel (only outline pixels issue atomics)
+struct CBox {
+    int y1, y2, x1, x2;  // inclusive
+};
+__global__ void ws_bbox_init_kernel(const int* __restrict__ L, const uint8_t* __restrict__ mask, CBox* __restrict__ bb, int H, int W) {
+    const long long n = (long long)H * W;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
-        if (hcnt[p] > 0) wl[atomicAdd(wl_n, 1)] = (int)p;
+        if (L[p] == (int)p && mask[p]) bb[p] = CBox{H, -1, W, -1};
+}
+__global__ void ws_bbox_kernel(const int* __restrict__ L, const uint8_t* __restrict__ mask, CBox* bb, int H, int W) {
+    const long long n = (long long)H * W;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        if (!mask[p]) continue;
+        const int y = (int)(p / W), x = (int)(p % W);
+        if (y > 0 && y < H - 1 && x > 0 && x < W - 1 && mask[p - W] && mask[p + W] && mask[p - 1] && mask[p + 1]) continue;
+        CBox* b = bb + L[p];
+        atomicMin(&b->y1, y);
+        atomicMax(&b->y2, y);
+        atomicMin(&b->x1, x);
+        atomicMax(&b->x2, x);
+    }
+}
+// Compact lists of component roots that own at least one seed, in three tiers:
+//   window tier : bounding box (+1 px ring) fits WS_WIN_CAP pixels and area <= WS_LDS_CAP -> whole flood in LDS   (front of wl)
+//   LDS-heap tier: area <= WS_LDS_CAP                                                     -> heap in LDS           (wl2)
+//   global tier : everything else                                                        -> heap in global memory (back of wl)
+//   big-window  : bounding box fits WS_BIGWIN_CAP pixels and (seeds + unlabelled mask pixels) <= WS_BIGHEAP_CAP: one wave per
+//                 workgroup with ~150 KB of LDS                                                                  (wl3)
+#define WS_LDS_CAP 1024
+#define WS_WIN_CAP 2304
+#define WS_BIGWIN_CAP 16384
+#define WS_BIGHEAP_CAP 2048
+__global__ void ws_worklist_kernel(const int* __restrict__ hcnt, const int* __restrict__ area, const int* __restrict__ unl, const CBox* __restrict__ bb,
+                                   int* __restrict__ wl, int* __restrict__ wl2, int* __restrict__ wl3, int* __restrict__ counts, int n) {
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
+        if (hcnt[p] > 0) {
+            const CBox b = bb[p];
+            const long long win = (long long)(b.y2 - b.y1 + 3) * (b.x2 - b.x1 + 3);
+            const int need = hcnt[p] + unl[p];  // every queue entry is a seed or a pixel that was unlabelled at the start
+            if (need <= WS_LDS_CAP && win <= WS_WIN_CAP) wl[atomicAdd(counts + 0, 1)] = (int)p;
+            else if (need <= WS_BIGHEAP_CAP && win <= WS_BIGWIN_CAP) wl3[atomicAdd(counts + 3, 1)] = (int)p;
+            else if (area[p] <= WS_LDS_CAP) wl2[atomicAdd(counts + 1, 1)] = (int)p;
+            else wl[n - 1 - atomicAdd(counts + 2, 1)] = (int)p;
+        }
 }
 
 struct HeapRef {
@@ -304,25 +367,28 @@ struct HeapRef {
 };
 __device__ __forceinline__ bool hless(u64 k1, u32 i1, u64 k2, u32 i2) { return k1 < k2 || (k1 == k2 && i1 < i2); }
 
-// wave-wide argmin of (key, idx); every lane returns the winning lane id
+// wave-wide min of a u32: 4 DPP row rotations (min inside each 16-lane row), then the 4 row results via readlane.
+__device__ __forceinline__ u32 wave_min_u32(u32 v) {
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xf, 0xf, false));  // row_ror:1
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xf, 0xf, false));  // row_ror:2
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xf, 0xf, false));  // row_ror:4
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false));  // row_ror:8
+    const u32 r0 = (u32)__builtin_amdgcn_readlane((int)v, 0), r1 = (u32)__builtin_amdgcn_readlane((int)v, 16);
+    const u32 r2 = (u32)__builtin_amdgcn_readlane((int)v, 32), r3 = (u32)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
+// wave-wide argmin of (key, idx), lexicographic (priority value, age, pixel index); every lane returns the winning lane id
 __device__ __forceinline__ int wave_argmin(u64 k, u32 i, bool valid, u64* kout, u32* iout) {
-    u64 bk = valid ? k : ~0ull;
-    u32 bi = valid ? i : ~0u;
-    int bl = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const u64 ok = __shfl_xor(bk, d);
-        const u32 oi = __shfl_xor(bi, d);
-        const int ol = __shfl_xor(bl, d);
-        if (hless(ok, oi, bk, bi) || (ok == bk && oi == bi && ol < bl)) {
-            bk = ok;
-            bi = oi;
-            bl = ol;
-        }
-    }
-    *kout = bk;
-    *iout = bi;
-    return bl;
+    const u32 hi = valid ? (u32)(k >> 32) : ~0u;
+    const u32 mh = wave_min_u32(hi);
+    const bool c1 = valid && hi == mh;
+    const u32 ml = wave_min_u32(c1 ? (u32)k : ~0u);
+    const bool c2 = c1 && (u32)k == ml;
+    const u32 mi = wave_min_u32(c2 ? i : ~0u);
+    const u64 win = __ballot(c2 && i == mi);
+    *kout = ((u64)mh << 32) | ml;
+    *iout = mi;
+    return win ? __ffsll((long long)win) - 1 : 0;
 }
 
 // 64-ary heap, node i has children 64 i + 1 .. 64 i + 64.  All lanes call these with uniform arguments.
@@ -375,12 +441,12 @@ __device__ __forceinline__ void heap_push(volatile u64* hk, volatile u32* hi, in
 __global__ __launch_bounds__(256) void ws_flood_kernel(const float* __restrict__ inst, long long row_stride, int pix_stride,
                                                        const uint8_t* __restrict__ mask, int* out, const int* __restrict__ wl,
                                                        const int* __restrict__ wl_n, const int* __restrict__ hoff, const int* __restrict__ hcnt,
-                                                       u64* hkey, u32* hidx, int H, int W, int* __restrict__ n_ambiguous) {
+                                                       u64* hkey, u32* hidx, int H, int W, int* __restrict__ n_ambiguous, int wl_len) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int nw = gridDim.x * (blockDim.x >> 6);
     for (int w = wid; w < *wl_n; w += nw) {
-        const int root = wl[w];
+        const int root = wl[wl_len - 1 - w];  // large-component list grows from the back of wl
         volatile u64* hk = hkey + hoff[root];
         volatile u32* hi = hidx + hoff[root];
         int n = hcnt[root];
@@ -444,6 +510,321 @@ __global__ __launch_bounds__(256) void ws_flood_kernel(const float* __restrict__
     }
 }
 
+// Window tier: the whole flood of a small component runs out of LDS.  Per wave: a (bbox + 1 px ring) window with the
+// per-pixel state (-1 outside this component's mask, 0 unlabelled, > 0 label) and the monotone-mapped priority, plus the
+// 64-ary heap (key = priority << 32 | age, index = window index, whose order equals raster order inside the component).
+// Seeds are found by the wave itself; no global memory is touched between the window load and the final write-back.
+template <int WIN_CAP, int HEAP_CAP, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void ws_flood_window_kernel(const float* __restrict__ inst, long long row_stride, int pix_stride,
+                                                                     const uint8_t* __restrict__ mask, const int* __restrict__ L, int* out,
+                                                                     const int* __restrict__ wl, const int* __restrict__ wl_n,
+                                                                     const CBox* __restrict__ bb, int H, int W, int* __restrict__ n_ambiguous) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wid = blockIdx.x * WAVES + wv, nw = gridDim.x * WAVES;
+    constexpr size_t PER_WAVE = (size_t)HEAP_CAP * 8 + (size_t)WIN_CAP * 8 + (size_t)HEAP_CAP * 2;
+    unsigned char* mine = s_raw + (size_t)wv * PER_WAVE;
+    volatile u64* hk = reinterpret_cast<u64*>(mine);
+    volatile int* st = reinterpret_cast<int*>(mine + (size_t)HEAP_CAP * 8);
+    volatile u32* vl = reinterpret_cast<u32*>(mine + (size_t)HEAP_CAP * 8 + (size_t)WIN_CAP * 4);
+    volatile unsigned short* hi = reinterpret_cast<unsigned short*>(mine + (size_t)HEAP_CAP * 8 + (size_t)WIN_CAP * 8);
+    for (int w = wid; w < *wl_n; w += nw) {
+        const int root = wl[w];
+        const CBox b = bb[root];
+        const int wh = b.y2 - b.y1 + 3, ww = b.x2 - b.x1 + 3, wn = wh * ww;
+        // ---- load the window -----------------------------------------------------------------------------------------
+        for (int i = lane; i < wn; i += 64) {
+            const int y = b.y1 - 1 + i / ww, x = b.x1 - 1 + i % ww;
+            int s = -1;
+            u32 v = 0;
+            if (y >= 0 && y < H && x >= 0 && x < W) {
+                const long long p = (long long)y * W + x;
+                if (mask[p] && L[p] == root) {
+                    s = out[p];
+                    v = order_key(-inst[y * row_stride + (long long)x * pix_stride]);
+                }
+            }
+            st[i] = s;
+            vl[i] = v;
+        }
+        // ---- seeds: labelled pixels with an unlabelled in-mask neighbour (window order == raster order) -----------------
+        int n = 0;
+        for (int i0 = 0; i0 < wn; i0 += 64) {
+            const int i = i0 + lane;
+            bool seed = false;
+            if (i < wn && st[i] > 0) seed = st[i - ww] == 0 || st[i - 1] == 0 || st[i + 1] == 0 || st[i + ww] == 0;
+            const u64 m = __ballot(seed);
+            if (seed) {
+                const int slot = n + __popcll(m & ((1ull << lane) - 1));
+                hk[slot] = (u64)vl[i] << 32;  // age 0
+                hi[slot] = (unsigned short)i;
+            }
+            n += __popcll(m);
+        }
+        // ---- heapify (Floyd) ----------------------------------------------------------------------------------------------
+        for (int i = (n - 2) >> 6; i >= 0 && n > 1; --i) {
+            const u64 k = hk[i];
+            const u32 x = hi[i];
+            int pos = i;
+            for (;;) {
+                const int c0 = 64 * pos + 1;
+                if (c0 >= n) break;
+                const int c = c0 + lane;
+                const bool valid = c < n;
+                const u64 ck = valid ? hk[c] : 0;
+                const u32 ci = valid ? hi[c] : 0;
+                u64 mk;
+                u32 mi;
+                const int ml = wave_argmin(ck, ci, valid, &mk, &mi);
+                if (!hless(mk, mi, k, x)) break;
+                if (lane == 0) {
+                    hk[pos] = mk;
+                    hi[pos] = (unsigned short)mi;
+                }
+                pos = c0 + ml;
+            }
+            if (lane == 0) {
+                hk[pos] = k;
+                hi[pos] = (unsigned short)x;
+            }
+        }
+        // ---- flood ------------------------------------------------------------------------------------------------------------
+        u32 age = 0;
+        bool have_prev_seed = false, ambiguous = false;
+        u32 prev_seed_val = 0;
+        int prev_seed_lab = 0;
+        while (n > 0) {
+            const u64 k = hk[0];
+            const int wi = hi[0];
+            const int lab = st[wi];
+            --n;
+            if (n > 0) {
+                const u64 lk = hk[n];
+                const u32 li = hi[n];
+                int pos = 0;
+                for (;;) {
+                    const int c0 = 64 * pos + 1;
+                    if (c0 >= n) break;
+                    const int c = c0 + lane;
+                    const bool valid = c < n;
+                    const u64 ck = valid ? hk[c] : 0;
+                    const u32 ci = valid ? hi[c] : 0;
+                    u64 mk;
+                    u32 mi;
+                    const int ml = wave_argmin(ck, ci, valid, &mk, &mi);
+                    if (!hless(mk, mi, lk, li)) break;
+                    if (lane == 0) {
+                        hk[pos] = mk;
+                        hi[pos] = (unsigned short)mi;
+                    }
+                    pos = c0 + ml;
+                }
+                if (lane == 0) {
+                    hk[pos] = lk;
+                    hi[pos] = (unsigned short)li;
+                }
+            }
+            if ((u32)k == 0u) {  // seed: see ws_flood_kernel
+                const u32 v = (u32)(k >> 32);
+                if (have_prev_seed && v == prev_seed_val && lab != prev_seed_lab) ambiguous = true;
+                have_prev_seed = true;
+                prev_seed_val = v;
+                prev_seed_lab = lab;
+            }
+            // lanes 0..3: up, left, right, down (skimage's neighbour order); the ring of -1 makes bounds checks unnecessary
+            const int nq = wi + (lane == 0 ? -ww : lane == 1 ? -1 : lane == 2 ? 1 : ww);
+            bool elig = false;
+            u32 v = 0;
+            if (lane < 4) {
+                elig = st[nq] == 0;
+                if (elig) {
+                    st[nq] = lab;
+                    v = vl[nq];
+                }
+            }
+            const u64 em = __ballot(elig);
+            for (int t = 0; t < 4; ++t) {
+                if (!((em >> t) & 1)) continue;
+                ++age;
+                const u64 nk = ((u64)__shfl(v, t) << 32) | age;
+                const u32 nx = (u32)__shfl(nq, t);
+                int jn = n++;
+                while (jn > 0) {
+                    const int par = (jn - 1) >> 6;
+                    const u64 pk = hk[par];
+                    const u32 pi = hi[par];
+                    if (!hless(nk, nx, pk, pi)) break;
+                    if (lane == 0) {
+                        hk[jn] = pk;
+                        hi[jn] = (unsigned short)pi;
+                    }
+                    jn = par;
+                }
+                if (lane == 0) {
+                    hk[jn] = nk;
+                    hi[jn] = (unsigned short)nx;
+                }
+            }
+        }
+        // ---- write back -----------------------------------------------------------------------------------------------------
+        for (int i = lane; i < wn; i += 64) {
+            const int s = st[i];
+            if (s > 0) out[(long long)(b.y1 - 1 + i / ww) * W + (b.x1 - 1 + i % ww)] = s;
+        }
+        if (ambiguous && lane == 0) atomicAdd(n_ambiguous, 1);
+    }
+}
+
+// Same flood, heap in LDS (one 1024-entry heap per wave; the heap never exceeds the component's area) with the label kept
+// beside the pixel index, and the neighbour probe fused into ONE global round trip per pop (mask, label and priority of the
+// four neighbours are fetched together by lanes 0..3).
+__global__ __launch_bounds__(256) void ws_flood_lds_kernel(const float* __restrict__ inst, long long row_stride, int pix_stride,
+                                                           const uint8_t* __restrict__ mask, int* out, const int* __restrict__ wl,
+                                                           const int* __restrict__ wl_n, const int* __restrict__ hoff,
+                                                           const int* __restrict__ hcnt, const u64* __restrict__ hkey,
+                                                           const u32* __restrict__ hidx, int H, int W, int* __restrict__ n_ambiguous) {
+    __shared__ u64 s_key[4][WS_LDS_CAP];
+    __shared__ u32 s_idx[4][WS_LDS_CAP];
+    __shared__ int s_lab[4][WS_LDS_CAP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wid = blockIdx.x * 4 + wv, nw = gridDim.x * 4;
+    volatile u64* hk = s_key[wv];
+    volatile u32* hi = s_idx[wv];
+    volatile int* hl = s_lab[wv];
+    for (int w = wid; w < *wl_n; w += nw) {
+        const int root = wl[w];
+        int n = hcnt[root];
+        const int base = hoff[root];
+        for (int i = lane; i < n; i += 64) {
+            const u32 px = hidx[base + i];
+            hk[i] = hkey[base + i];
+            hi[i] = px;
+            hl[i] = out[px];
+        }
+        // heapify (Floyd) -- (key, idx) order; the label rides along
+        for (int i = (n - 2) >> 6; i >= 0 && n > 1; --i) {
+            u64 k = hk[i];
+            u32 x = hi[i];
+            int lb = hl[i], pos = i;
+            for (;;) {
+                const int c0 = 64 * pos + 1;
+                if (c0 >= n) break;
+                const int c = c0 + lane;
+                const bool valid = c < n;
+                const u64 ck = valid ? hk[c] : 0;
+                const u32 ci = valid ? hi[c] : 0;
+                u64 mk;
+                u32 mi;
+                const int ml = wave_argmin(ck, ci, valid, &mk, &mi);
+                if (!hless(mk, mi, k, x)) break;
+                const int ml_lab = hl[c0 + ml];
+                if (lane == 0) {
+                    hk[pos] = mk;
+                    hi[pos] = mi;
+                    hl[pos] = ml_lab;
+                }
+                pos = c0 + ml;
+            }
+            if (lane == 0) {
+                hk[pos] = k;
+                hi[pos] = x;
+                hl[pos] = lb;
+            }
+        }
+        u32 age = 0;
+        bool have_prev_seed = false, ambiguous = false;
+        u32 prev_seed_val = 0;
+        int prev_seed_lab = 0;
+        while (n > 0) {
+            const u64 k = hk[0];
+            const u32 p = hi[0];
+            const int lab = hl[0];
+            --n;
+            if (n > 0) {  // move the last entry to the root and sift it down
+                const u64 lk = hk[n];
+                const u32 li = hi[n];
+                const int ll = hl[n];
+                int pos = 0;
+                for (;;) {
+                    const int c0 = 64 * pos + 1;
+                    if (c0 >= n) break;
+                    const int c = c0 + lane;
+                    const bool valid = c < n;
+                    const u64 ck = valid ? hk[c] : 0;
+                    const u32 ci = valid ? hi[c] : 0;
+                    u64 mk;
+                    u32 mi;
+                    const int ml = wave_argmin(ck, ci, valid, &mk, &mi);
+                    if (!hless(mk, mi, lk, li)) break;
+                    const int ml_lab = hl[c0 + ml];
+                    if (lane == 0) {
+                        hk[pos] = mk;
+                        hi[pos] = mi;
+                        hl[pos] = ml_lab;
+                    }
+                    pos = c0 + ml;
+                }
+                if (lane == 0) {
+                    hk[pos] = lk;
+                    hi[pos] = li;
+                    hl[pos] = ll;
+                }
+            }
+            if ((u32)k == 0u) {  // seed: see ws_flood_kernel
+                const u32 v = (u32)(k >> 32);
+                if (have_prev_seed && v == prev_seed_val && lab != prev_seed_lab) ambiguous = true;
+                have_prev_seed = true;
+                prev_seed_val = v;
+                prev_seed_lab = lab;
+            }
+            const int y = (int)(p / (u32)W), x = (int)(p % (u32)W);
+            long long q = -1;
+            if (lane == 0 && y > 0) q = (long long)p - W;
+            if (lane == 1 && x > 0) q = (long long)p - 1;
+            if (lane == 2 && x < W - 1) q = (long long)p + 1;
+            if (lane == 3 && y < H - 1) q = (long long)p + W;
+            bool elig = false;
+            float v = 0.f;
+            if (q >= 0) {
+                // one round trip: mask, current label and priority of the neighbour
+                const uint8_t mq = mask[q];
+                const int oq = __hip_atomic_load(&out[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int qy = (int)(q / W), qx = (int)(q % W);
+                v = -inst[qy * row_stride + (long long)qx * pix_stride];
+                elig = mq && oq == 0;
+                if (elig) __hip_atomic_store(&out[q], lab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const u64 em = __ballot(elig);
+            for (int t = 0; t < 4; ++t) {
+                if (!((em >> t) & 1)) continue;
+                ++age;
+                const u64 nk = ((u64)order_key(__shfl(v, t)) << 32) | age;
+                const u32 nx = (u32)__shfl((int)q, t);
+                int jn = n++;
+                while (jn > 0) {
+                    const int par = (jn - 1) >> 6;
+                    const u64 pk = hk[par];
+                    const u32 pi = hi[par];
+                    if (!hless(nk, nx, pk, pi)) break;
+                    const int pl = hl[par];
+                    if (lane == 0) {
+                        hk[jn] = pk;
+                        hi[jn] = pi;
+                        hl[jn] = pl;
+                    }
+                    jn = par;
+                }
+                if (lane == 0) {
+                    hk[jn] = nk;
+                    hi[jn] = nx;
+                    hl[jn] = lab;
+                }
+            }
+        }
+        if (ambiguous && lane == 0) atomicAdd(n_ambiguous, 1);
+    }
+}
+
 // =================================================================================================================
 // Gland / lumen: threshold, per-instance crop -> dilate -> fill holes -> paste
 // =================================================================================================================
@@ -474,6 +855,8 @@ __global__ void box_accum_kernel(const int* __restrict__ lab, Box* b, int H, int
         const int l = lab[p];
         if (!l) continue;
         const int y = (int)(p / W), x = (int)(p % W);
+        // only pixels on the instance outline can be bounding-box extremes (keeps the atomics off the interior)
+        if (y > 0 && y < H - 1 && x > 0 && x < W - 1 && lab[p - W] == l && lab[p + W] == l && lab[p - 1] == l && lab[p + 1] == l) continue;
         atomicMin(&b[l].y1, y);
         atomicMax(&b[l].y2, y + 1);
         atomicMin(&b[l].x1, x);
@@ -638,6 +1021,7 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
     int* wl = (int*)cv.take((size_t)n * 4);
     u64* hkey = (u64*)cv.take((size_t)n * 8);
     u32* hidx = (u32*)cv.take((size_t)n * 4);
+    CBox* cbox = (CBox*)cv.take((size_t)n * sizeof(CBox));
     uint8_t* msk0 = (uint8_t*)cv.take(n);
     uint8_t* msk = (uint8_t*)cv.take(n);
     uint8_t* mrk = (uint8_t*)cv.take(n);
@@ -673,10 +1057,33 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
     hipLaunchKernelGGL(ws_cap_kernel, dim3(g), dim3(256), 0, st, LA, areaA, msk, hcnt, n);
     if (scan_exclusive(hcnt, hoff, n, scantmp, st)) return 1;
     PP_OK(hipMemsetAsync(hcnt, 0, (size_t)n * 4, st));
-    hipLaunchKernelGGL(ws_seed_kernel, dim3(g), dim3(256), 0, st, inst, row_stride, pix_stride, msk, labels_out, LA, hoff, hcnt, hkey, hidx, H, W);
-    hipLaunchKernelGGL(ws_worklist_kernel, dim3(g), dim3(256), 0, st, hcnt, wl, small + 1, n);
-    hipLaunchKernelGGL(ws_flood_kernel, dim3(256 * 4), dim3(256), 0, st, inst, row_stride, pix_stride, msk, labels_out, wl, small + 1, hoff, hcnt,
-                       hkey, hidx, H, W, small + 3);
+    int* unl = areaB;  // free again: per-root count of unlabelled mask pixels
+    int* wl3 = marker; // free after ws_init_out_kernel: big-window tier list
+    PP_OK(hipMemsetAsync(unl, 0, (size_t)n * 4, st));
+    hipLaunchKernelGGL(ws_seed_kernel, dim3(g), dim3(256), 0, st, inst, row_stride, pix_stride, msk, labels_out, LA, hoff, hcnt, hkey, hidx, H, W, unl);
+    hipLaunchKernelGGL(ws_bbox_init_kernel, dim3(g), dim3(256), 0, st, LA, msk, cbox, H, W);
+    hipLaunchKernelGGL(ws_bbox_kernel, dim3(g), dim3(256), 0, st, LA, msk, cbox, H, W);
+    int* counts = small + 8;  // [0] window tier, [1] LDS-heap tier, [2] global tier
+    hipLaunchKernelGGL(ws_worklist_kernel, dim3(g), dim3(256), 0, st, hcnt, areaA, unl, cbox, wl, rank, wl3, counts, n);
+    {
+        auto k_small = ws_flood_window_kernel<WS_WIN_CAP, WS_LDS_CAP, 2>;
+        auto k_big = ws_flood_window_kernel<WS_BIGWIN_CAP, WS_BIGHEAP_CAP, 1>;
+        constexpr int lds_small = 2 * (WS_LDS_CAP * 10 + WS_WIN_CAP * 8), lds_big = WS_BIGHEAP_CAP * 10 + WS_BIGWIN_CAP * 8;
+        static bool attr_done = false;
+        if (!attr_done) {
+            PP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_small), hipFuncAttributeMaxDynamicSharedMemorySize, lds_small));
+            PP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_big), hipFuncAttributeMaxDynamicSharedMemorySize, lds_big));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(k_small, dim3(256 * 2), dim3(128), lds_small, st, inst, row_stride, pix_stride, msk, LA, labels_out, wl, counts + 0, cbox,
+                           H, W, small + 3);
+        hipLaunchKernelGGL(k_big, dim3(256), dim3(64), lds_big, st, inst, row_stride, pix_stride, msk, LA, labels_out, wl3, counts + 3, cbox, H, W,
+                           small + 3);
+    }
+    hipLaunchKernelGGL(ws_flood_lds_kernel, dim3(256 * 2), dim3(256), 0, st, inst, row_stride, pix_stride, msk, labels_out, rank, counts + 1, hoff,
+                       hcnt, hkey, hidx, H, W, small + 3);
+    hipLaunchKernelGGL(ws_flood_kernel, dim3(256 * 4), dim3(256), 0, st, inst, row_stride, pix_stride, msk, labels_out, wl, counts + 2, hoff, hcnt,
+                       hkey, hidx, H, W, small + 3, n);
     KCHECK();
     if (n_ambiguous_out) PP_OK(hipMemcpyAsync(n_ambiguous_out, small + 3, 4, hipMemcpyDeviceToDevice, st));
     return 0;
