@@ -883,81 +883,93 @@ struct Spans {
     int k, a;
     int j1[32], j2[32];
 };
-// one workgroup per instance: dilation of (lab == id) by the ellipse, clipped to the crop.  dil: crop-local bytes.
+// The crops of a batch are laid out back to back (crop-local row-major); the kernels below run over that flat element
+// space so large and small instances share the machine.  coff[id] = start of instance id's crop; element e belongs to the
+// last instance whose start is <= e.
+__device__ __forceinline__ int find_inst(const int* __restrict__ coff, int first, int cnt, int e_abs) {
+    int lo = first, hi = first + cnt - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (coff[mid] <= e_abs) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+// dilation of (lab == id) by the ellipse, clipped to the crop (cv2.dilate on the crop; the border never wins the max)
 __global__ __launch_bounds__(256) void gl_dilate_kernel(const int* __restrict__ lab, const Box* __restrict__ box, const int* __restrict__ coff,
-                                                        int first, int W, Spans se, uint8_t* __restrict__ dil) {
-    const int id = first + blockIdx.x;
-    const Box c = box[id];
-    const int ch = c.y2 - c.y1, cw = c.x2 - c.x1;
-    uint8_t* d = dil + coff[id] - coff[first];
-    for (int i = threadIdx.x; i < ch * cw; i += blockDim.x) {
+                                                        int first, int cnt, int tot, int W, Spans se, uint8_t* __restrict__ dil) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += gridDim.x * blockDim.x) {
+        const int id = find_inst(coff, first, cnt, e + coff[first]);
+        const Box c = box[id];
+        const int ch = c.y2 - c.y1, cw = c.x2 - c.x1;
+        const int i = e - (coff[id] - coff[first]);
         const int y = i / cw, x = i % cw;
         uint8_t v = 0;
         for (int r = 0; r < se.k && !v; ++r) {
             const int yy = y + r - se.a;
             if (yy < 0 || yy >= ch) continue;
-            for (int j = se.j1[r]; j < se.j2[r]; ++j) {
-                const int xx = x + j - se.a;
-                if (xx < 0 || xx >= cw) continue;
-                if (lab[(long long)(c.y1 + yy) * W + c.x1 + xx] == id) {
+            const int xa = max(x + se.j1[r] - se.a, 0), xb = min(x + se.j2[r] - se.a, cw);
+            const int* row = lab + (long long)(c.y1 + yy) * W + c.x1;
+            for (int xx = xa; xx < xb; ++xx)
+                if (row[xx] == id) {
                     v = 1;
                     break;
                 }
-            }
         }
-        d[i] = v;
+        dil[e] = v;
     }
 }
-// background CCL inside every crop of the batch (one workgroup per instance, crop-local union-find)
-__global__ __launch_bounds__(256) void gl_bg_init_kernel(const uint8_t* __restrict__ dil, const Box* __restrict__ box, const int* __restrict__ coff,
-                                                         int first, int* __restrict__ L, int* __restrict__ border) {
-    const int id = first + blockIdx.x;
-    const Box c = box[id];
-    const int ch = c.y2 - c.y1, cw = c.x2 - c.x1;
-    const int base = coff[id] - coff[first];
-    for (int i = threadIdx.x; i < ch * cw; i += blockDim.x) {
-        L[base + i] = dil[base + i] ? -1 : base + i;
-        border[base + i] = 0;
+// background CCL inside every crop of the batch (crop-local 4-connectivity, shared union-find array)
+__global__ __launch_bounds__(256) void gl_bg_init_kernel(const uint8_t* __restrict__ dil, int tot, int* __restrict__ L, int* __restrict__ border) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += gridDim.x * blockDim.x) {
+        L[e] = dil[e] ? -1 : e;
+        border[e] = 0;
     }
 }
 __global__ __launch_bounds__(256) void gl_bg_merge_kernel(const uint8_t* __restrict__ dil, const Box* __restrict__ box, const int* __restrict__ coff,
-                                                          int first, int* L) {
-    const int id = first + blockIdx.x;
-    const Box c = box[id];
-    const int ch = c.y2 - c.y1, cw = c.x2 - c.x1;
-    const int base = coff[id] - coff[first];
-    for (int i = threadIdx.x; i < ch * cw; i += blockDim.x) {
-        if (dil[base + i]) continue;
+                                                          int first, int cnt, int tot, int* L) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += gridDim.x * blockDim.x) {
+        if (dil[e]) continue;
+        const int id = find_inst(coff, first, cnt, e + coff[first]);
+        const Box c = box[id];
+        const int cw = c.x2 - c.x1;
+        const int i = e - (coff[id] - coff[first]);
         const int x = i % cw;
-        if (x > 0 && !dil[base + i - 1]) uf_union(L, base + i, base + i - 1);
-        if (i >= cw && !dil[base + i - cw]) uf_union(L, base + i, base + i - cw);
+        const bool left = x > 0 && !dil[e - 1];
+        if (i >= cw && !dil[e - cw]) {
+            // one union per pair of vertically adjacent background runs (see ccl_merge_kernel)
+            const bool up_starts = !(x > 0 && !dil[e - cw - 1]);
+            if (!left || up_starts) uf_union(L, e, e - cw);
+        }
+        if (left) uf_union(L, e, e - 1);
     }
 }
-__global__ __launch_bounds__(256) void gl_bg_border_kernel(const Box* __restrict__ box, const int* __restrict__ coff, int first, int* L,
-                                                           int* __restrict__ border) {
-    const int id = first + blockIdx.x;
-    const Box c = box[id];
-    const int ch = c.y2 - c.y1, cw = c.x2 - c.x1;
-    const int base = coff[id] - coff[first];
-    for (int i = threadIdx.x; i < ch * cw; i += blockDim.x) {
-        if (L[base + i] < 0) continue;
-        const int r = uf_find(L, base + i);
-        L[base + i] = r;
+__global__ __launch_bounds__(256) void gl_bg_border_kernel(const Box* __restrict__ box, const int* __restrict__ coff, int first, int cnt, int tot,
+                                                           int* L, int* __restrict__ border) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += gridDim.x * blockDim.x) {
+        if (L[e] < 0) continue;
+        const int r = uf_find(L, e);
+        L[e] = r;
+        const int id = find_inst(coff, first, cnt, e + coff[first]);
+        const Box c = box[id];
+        const int ch = c.y2 - c.y1, cw = c.x2 - c.x1;
+        const int i = e - (coff[id] - coff[first]);
         const int y = i / cw, x = i % cw;
         if (y == 0 || y == ch - 1 || x == 0 || x == cw - 1) border[r] = 1;
     }
 }
 __global__ __launch_bounds__(256) void gl_paste_kernel(const uint8_t* __restrict__ dil, const Box* __restrict__ box, const int* __restrict__ coff,
-                                                       int first, const int* __restrict__ L, const int* __restrict__ border, int W,
+                                                       int first, int cnt, int tot, const int* __restrict__ L, const int* __restrict__ border, int W,
                                                        int* __restrict__ out) {
-    const int id = first + blockIdx.x;
-    const Box c = box[id];
-    const int ch = c.y2 - c.y1, cw = c.x2 - c.x1;
-    const int base = coff[id] - coff[first];
-    for (int i = threadIdx.x; i < ch * cw; i += blockDim.x) {
-        bool in = dil[base + i];
-        if (!in) in = !border[L[base + i]];  // hole of the dilated instance inside its crop
-        if (in) atomicMax(&out[(long long)(c.y1 + i / cw) * W + c.x1 + i % cw], id);  // ids ascend: later id overwrites
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += gridDim.x * blockDim.x) {
+        bool in = dil[e];
+        if (!in) in = !border[L[e]];  // hole of the dilated instance inside its crop
+        if (!in) continue;
+        const int id = find_inst(coff, first, cnt, e + coff[first]);
+        const Box c = box[id];
+        const int cw = c.x2 - c.x1;
+        const int i = e - (coff[id] - coff[first]);
+        atomicMax(&out[(long long)(c.y1 + i / cw) * W + c.x1 + i % cw], id);  // ids ascend: later id overwrites
     }
 }
 __global__ void mask_lumen_kernel(int* __restrict__ lumen, const int* __restrict__ gland, long long n) {
@@ -1159,11 +1171,13 @@ static int gland_lumen(const float* inst, int H, int W, long long row_stride, in
         }
         while (last + 1 <= n_inst && tot + (size_t)h_area[last + 1] <= crop_cap) tot += (size_t)h_area[++last];
         const int cnt = last - first + 1;
-        hipLaunchKernelGGL(gl_dilate_kernel, dim3(cnt), dim3(256), 0, st, lab, box, coff, first, W, se, dil);
-        hipLaunchKernelGGL(gl_bg_init_kernel, dim3(cnt), dim3(256), 0, st, dil, box, coff, first, cL, cB);
-        hipLaunchKernelGGL(gl_bg_merge_kernel, dim3(cnt), dim3(256), 0, st, dil, box, coff, first, cL);
-        hipLaunchKernelGGL(gl_bg_border_kernel, dim3(cnt), dim3(256), 0, st, box, coff, first, cL, cB);
-        hipLaunchKernelGGL(gl_paste_kernel, dim3(cnt), dim3(256), 0, st, dil, box, coff, first, cL, cB, W, labels_out);
+        const int tot_i = (int)tot;
+        const unsigned gb = grid_for(tot_i);
+        hipLaunchKernelGGL(gl_dilate_kernel, dim3(gb), dim3(256), 0, st, lab, box, coff, first, cnt, tot_i, W, se, dil);
+        hipLaunchKernelGGL(gl_bg_init_kernel, dim3(gb), dim3(256), 0, st, dil, tot_i, cL, cB);
+        hipLaunchKernelGGL(gl_bg_merge_kernel, dim3(gb), dim3(256), 0, st, dil, box, coff, first, cnt, tot_i, cL);
+        hipLaunchKernelGGL(gl_bg_border_kernel, dim3(gb), dim3(256), 0, st, box, coff, first, cnt, tot_i, cL, cB);
+        hipLaunchKernelGGL(gl_paste_kernel, dim3(gb), dim3(256), 0, st, dil, box, coff, first, cnt, tot_i, cL, cB, W, labels_out);
         first = last + 1;
     }
     free(h_off);
