@@ -47,7 +47,15 @@ def cpu_baseline(sd, kw, n_tiles=8, iters=2):
     for _ in range(iters):
         net_ref.infer_step(sd, tiles, TILE, kw["considered_tasks"], kw["decoder_kwargs"])
     dt = time.perf_counter() - t0
+    # post-processing oracle (C restatement of loader/postproc.py + skimage/scipy, one core) on a 2048^2 structured map
+    from oracle import postproc_ref, synth
+
+    pm = synth.nuclei_maps(2048, 2048, 7, 600.0, noise=0.02)
+    t0 = time.perf_counter()
+    postproc_ref.proc(pm, "Nuclei")
+    pp_dt = time.perf_counter() - t0
     return {
+        "postproc_nuclei_Mpx_s_1core": round(2048 * 2048 / pp_dt / 1e6, 2),
         "value": round(iters * n_tiles * TILE * TILE / dt / 1e6, 4),
         "unit": "Mpx/s",
         "cores": cores,
@@ -63,6 +71,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help='torch.distributed backend ("nccl" = RCCL over xGMI; "gloo" only for plumbing tests)')
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -73,8 +82,12 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -120,7 +133,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -163,6 +176,38 @@ def main():
         "kernel_share_of_step": round(dom_ms / total_ms, 4),
     }
 
+    # ---- post-processing leg (reported beside the headline; P1-P5 of SURVEY.md par.8a): on-GPU label maps from a seeded
+    # structured probability map (600 nuclei / Mpx, radius 4-9 px; glands 14-60 px) and from this step's own canvas -------
+    postproc = None
+    if rank == 0:
+        from cerberus_amd.postproc import postproc_device
+        from oracle import synth  # structured synthetic INPUT generator only (numpy), not a checker here
+
+        PH = 2048
+        maps = {
+            "Nuclei": torch.from_numpy(synth.nuclei_maps(PH, PH, 7, 600.0, noise=0.02)).to(dev),
+            "Gland": torch.from_numpy(synth.blob_maps(PH, PH, 9, 120, 14.0, 60.0, rim=4.0, sharp=1.0, noise=0.02, holes=0.3)).to(dev),
+        }
+        maps["Lumen"] = maps["Gland"]
+        postproc = {"map": "%dx%d structured synthetic" % (PH, PH), "unit": "Mpx/s", "algorithmic_bytes_per_px": 12}
+        for t in ("Nuclei", "Gland", "Lumen"):
+            postproc_device(maps[t], t)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                lab, info = postproc_device(maps[t], t)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 3 * 1e3
+            postproc[t] = {"ms": round(ms, 3), "Mpx_s": round(PH * PH / ms / 1e3, 1), "n_inst": int(info["n_inst"].item()),
+                           "hbm_frac_of_8TBs": round(12.0 * PH * PH / (ms * 1e-3) / 8e12, 5)}
+        # the three label maps of this step's own 1024 x 2048 canvas (random-weight network => degenerate maps)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in ("Nuclei", "Gland", "Lumen"):
+            postproc_device(canvas[t], t)
+        torch.cuda.synchronize()
+        postproc["own_canvas_all_tissues_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+
     if rank == 0:
         px = world * args.steps * BATCH * TILE * TILE
         flops_step = model.flops(BATCH, TILE, TILE)
@@ -189,6 +234,7 @@ def main():
                 "parallelism": "tile-sharded x%d, no data-path collective" % world,
             },
             "roofline": roofline,
+            "postproc": postproc,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, kw)

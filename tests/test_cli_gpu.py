@@ -1,0 +1,50 @@
+"""Integration: the reference's command lines end to end on synthetic inputs (SURVEY.md par.4 'integration' row)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_run_infer_tile_cli(tmp_path):
+    import scipy.io as sio
+    from PIL import Image
+
+    inp, out = tmp_path / "in", tmp_path / "out"
+    inp.mkdir()
+    rs = np.random.RandomState(3)
+    for name, hw in (("a", (300, 421)), ("b", (256, 256))):
+        Image.fromarray(rs.randint(0, 256, hw + (3,)).astype(np.uint8)).save(str(inp / (name + ".png")))
+    cmd = [sys.executable, os.path.join(ROOT, "run_infer_tile.py"), "--input_dir=%s" % inp, "--output_dir=%s" % out, "--batch_size=8",
+           "--patch_input_shape=256", "--patch_output_shape=256"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for t in ("gland", "lumen", "nuclei"):
+        m = sio.loadmat(str(out / ("%s_mat" % t) / "a.mat"))
+        assert m["inst_map"].shape == (300, 421)  # label map at source resolution (infer/tile.py:274-281)
+        assert set(m.keys()) >= {"inst_map", "type", "id"}
+    assert sio.loadmat(str(out / "pclass_mat" / "b.mat"))["pclass"].shape == (256, 256)
+    # resume-by-skip (infer/tile.py:225-238) is kept verbatim, including the reference's quirk: it looks for
+    # "patch-class_mat/<name>.mat" (the class map is written to "pclass_mat/"), so with the CLI's target list every image
+    # is always re-processed; without patch-class in the list the skip works and the reference's assert fires.
+    r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r2.returncode == 0 and "Done Assembling a" in r2.stdout
+
+
+def test_run_infer_wsi_cli_synthetic(tmp_path):
+    spec = tmp_path / "slides"
+    spec.mkdir()
+    (spec / "s1.txt").write_text("synthetic:700x900:5")
+    out = tmp_path / "out"
+    cmd = [sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--input_dir=%s" % spec, "--wsi_file_ext=.txt", "--output_dir=%s" % out,
+           "--batch_size=6", "--patch_input_shape=448", "--patch_output_shape=144"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    z = np.load(str(out / "s1.npz"))
+    assert z["Nuclei"].shape == (700, 900) and z["Gland"].shape == (350, 450) and z["Lumen"].shape == (350, 450)
+    assert z["type_Nuclei-TYPE"].dtype == np.uint8
