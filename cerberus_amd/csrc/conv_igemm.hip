@@ -23,8 +23,15 @@
 // wave) ahead of use, straight from L2 into VGPRs.
 #include "cerb_common.h"
 
+// CERB_WLDS = 1 (experiment, OFF): the weights of a chunk are staged into LDS next to the pixel tile so the MFMA loop
+// waits only on LDS (lgkmcnt) -- tests the idea that in-order vmcnt couples weight waits to older HBM loads / stores.
+// It needs 123-138 KB of LDS => one workgroup per CU, one wave per SIMD, and measured 116 vs 122 TFLOP/s for the
+// global->VGPR weight stream with two co-resident workgroups, so the default stays 0 (DESIGN.md "what did not work").
+#ifndef CERB_WLDS
+#define CERB_WLDS 0
+#endif
 #ifndef CERB_SCHED_GROUPS
-#define CERB_SCHED_GROUPS 0
+#define CERB_SCHED_GROUPS (CERB_WLDS ? 3 : 0)
 #endif
 
 template <int KS, int STRIDE, int TH, int TW, int CB, int MODE>
@@ -45,7 +52,9 @@ struct ConvCfg {
     static constexpr int NA = AR * AC * PARTS;
     static constexpr int AITER = (NA + 255) / 256;
     static constexpr int AUX_FLOATS = (MODE == 1) ? AR * AC * PS : 0;
-    static constexpr int LDS_FLOATS = MAIN_FLOATS + AUX_FLOATS;
+    static constexpr int W_FLOATS = CERB_WLDS ? NQ * 2 * 256 : 0;  // one chunk of packed weights
+    static constexpr int WITER = NQ / 2;                            // float4 weight-staging slices per thread
+    static constexpr int LDS_FLOATS = MAIN_FLOATS + AUX_FLOATS + W_FLOATS;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     // MODE 1 schedule inside a chunk (in 8-channel steps): skip slices at steps 0..ITER-1, prev slices next, then the
     // auxiliary tile is written + one barrier, then one combine per step
@@ -59,11 +68,12 @@ struct Item {
 };
 
 template <int KS, int STRIDE, int TH, int TW, int CB, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, CERB_WLDS ? 1 : 2) void conv_igemm_kernel(ConvParams p) {
     using C = ConvCfg<KS, STRIDE, TH, TW, CB, MODE>;
     static_assert(TH * TW == 256, "tile must hold 256 pixels (4 waves x 2 x 32)");
     static_assert(MODE == 0 || (KS == 3 && STRIDE == 1 && C::S_COMB + C::ITER <= C::NQ), "MODE 1 schedule must fit in one chunk");
     static_assert(C::ITER <= 2 * C::NQ || KS == 1, "every staging slice needs a step");
+    static_assert(C::NQ % 2 == 0, "weight staging assumes an even number of steps per chunk");
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
@@ -99,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
         return w;
     };
     auto wbase = [&](const Item& w) {
-        return reinterpret_cast<const f32x4*>(p.wpack + w.g * p.w_gs + (long long)w.cb * nchunk * C::NQ * 2 * 256) + lane;
+        return reinterpret_cast<const f32x4*>(p.wpack + w.g * p.w_gs + (long long)w.cb * nchunk * C::NQ * 2 * 256) + (CERB_WLDS ? tid : lane);
     };
 
     // ---- staging of one slice (256 float4 elements) of chunk (w, ch) into registers --------------------------------------
@@ -108,6 +118,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     f32x4 v[C::ITER];
     f32x4 pvv[C::AITER > 0 ? C::AITER : 1];  // MODE 1: in-flight slices of the half-resolution `prev` tile
     float* aux = lds + C::MAIN_FLOATS;
+#if CERB_WLDS
+    f32x4 wst[C::WITER];                                                  // in-flight slices of the next chunk's weights
+    f32x4* wl = reinterpret_cast<f32x4*>(lds + C::MAIN_FLOATS + C::AUX_FLOATS);  // [step][half][lane] float4, as packed
+#endif
     auto slice_coords = [&](const Item& w, int s, int& part, int& gy, int& gx) {
         const int f = tid + s * 256;
         const int pix = f / C::PARTS;
@@ -117,33 +131,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
         gx = w.ox0 * STRIDE - C::PAD + ix;
         return f < C::NF && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
     };
-    auto issue = [&](const Item& w, int ch, int s) {  // skip / plain input slice -> v[s] (zero outside the image)
+    // The loads are UNCONDITIONAL (addresses clamped into the tensor) so that the chunk body stays one basic block the
+    // scheduler can interleave with the MFMAs; out-of-image / out-of-tile elements are zeroed when the slice is written to LDS.
+    auto issue = [&](const Item& w, int ch, int s) {  // skip / plain input slice -> v[s]
         int part, gy, gx;
-        const bool ok = slice_coords(w, s, part, gy, gx);
-        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        slice_coords(w, s, part, gy, gx);
+        const int cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
+        const float* in = p.in + w.g * p.in_gs + (long long)w.n * p.H * p.W * p.Cin;
 #ifdef CERB_ABL_NOSTAGE
-        (void)ok;
-        if (false) {
+        v[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        (void)in; (void)cy; (void)cx; (void)ch;
 #else
-        if (ok) {
+        v[s] = *reinterpret_cast<const f32x4*>(in + ((long long)cy * p.W + cx) * p.Cin + ch * CB + part * 4);
 #endif
-            const float* in = p.in + w.g * p.in_gs + (long long)w.n * p.H * p.W * p.Cin;
-            x = *reinterpret_cast<const f32x4*>(in + ((long long)gy * p.W + gx) * p.Cin + ch * CB + part * 4);
-        }
-        v[s] = x;
     };
     auto issue_prev = [&](const Item& w, int ch, int k) {  // MODE 1: slice k of the clamped half-resolution tile
-        const int f = tid + k * 256;
+        const int f = min(tid + k * 256, C::NA - 1);
         const int apix = f / C::PARTS, part = f % C::PARTS;
         const int ar = apix / C::AC, ac = apix % C::AC;
         const int Hp = p.H >> 1, Wp = p.W >> 1;
         const int py = min(max((w.oy0 >> 1) - 1 + ar, 0), Hp - 1), px = min(max((w.ox0 >> 1) - 1 + ac, 0), Wp - 1);
-        f32x4 x = {0.f, 0.f, 0.f, 0.f};
-        if (f < C::NA) {
-            const float* pv = p.prev + w.g * p.prev_gs + (long long)w.n * Hp * Wp * p.Cin;
-            x = *reinterpret_cast<const f32x4*>(pv + ((long long)py * Wp + px) * p.Cin + ch * CB + part * 4);
-        }
-        pvv[k] = x;
+        const float* pv = p.prev + w.g * p.prev_gs + (long long)w.n * Hp * Wp * p.Cin;
+        pvv[k] = *reinterpret_cast<const f32x4*>(pv + ((long long)py * Wp + px) * p.Cin + ch * CB + part * 4);
     };
     auto write_prev = [&]() {
 #pragma unroll
@@ -154,21 +163,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     };
     auto combine = [&](const Item& w, int s) {  // MODE 1: v[s] += bilinear_x2(prev)  (net_layers.py:45-46, net_desc.py:188)
         int part, gy, gx;
-        if (!slice_coords(w, s, part, gy, gx)) return;
+        slice_coords(w, s, part, gy, gx);
         const int Hp = p.H >> 1, Wp = p.W >> 1;
         // src = 0.5*(dst+0.5)-0.5 clamped at 0 (align_corners=False): y0 = (gy-1)>>1 for gy>=1, 0 for gy==0;
-        // fractional offset 0 (clamped edge), 0.25 (odd dst) or 0.75 (even dst)
+        // fractional offset 0 (clamped edge), 0.25 (odd dst) or 0.75 (even dst).  Out-of-image elements compute garbage from
+        // clamped window indices and are zeroed at the LDS write.
         const int y0 = gy > 0 ? (gy - 1) >> 1 : 0, x0 = gx > 0 ? (gx - 1) >> 1 : 0;
         const int y1 = y0 + (y0 < Hp - 1), x1 = x0 + (x0 < Wp - 1);
         const float ly = gy > 0 ? ((gy & 1) ? 0.25f : 0.75f) : 0.f;
         const float lx = gx > 0 ? ((gx & 1) ? 0.25f : 0.75f) : 0.f;
         const float hy = 1.f - ly, hx = 1.f - lx;
         const int ry = (w.oy0 >> 1) - 1, rx = (w.ox0 >> 1) - 1;
+        const int a0_ = min(max(y0 - ry, 0), C::AR - 1), a1_ = min(max(y1 - ry, 0), C::AR - 1);
+        const int c0_ = min(max(x0 - rx, 0), C::AC - 1), c1_ = min(max(x1 - rx, 0), C::AC - 1);
         const float* a = aux + part * 4;
-        const f32x4 p00 = *reinterpret_cast<const f32x4*>(a + ((y0 - ry) * C::AC + (x0 - rx)) * C::PS);
-        const f32x4 p01 = *reinterpret_cast<const f32x4*>(a + ((y0 - ry) * C::AC + (x1 - rx)) * C::PS);
-        const f32x4 p10 = *reinterpret_cast<const f32x4*>(a + ((y1 - ry) * C::AC + (x0 - rx)) * C::PS);
-        const f32x4 p11 = *reinterpret_cast<const f32x4*>(a + ((y1 - ry) * C::AC + (x1 - rx)) * C::PS);
+        const f32x4 p00 = *reinterpret_cast<const f32x4*>(a + (a0_ * C::AC + c0_) * C::PS);
+        const f32x4 p01 = *reinterpret_cast<const f32x4*>(a + (a0_ * C::AC + c1_) * C::PS);
+        const f32x4 p10 = *reinterpret_cast<const f32x4*>(a + (a1_ * C::AC + c0_) * C::PS);
+        const f32x4 p11 = *reinterpret_cast<const f32x4*>(a + (a1_ * C::AC + c1_) * C::PS);
         v[s] = v[s] + (hy * (hx * p00 + lx * p01) + ly * (hx * p10 + lx * p11));
     };
 
@@ -194,12 +206,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
         for (int s = 0; s < C::ITER; ++s) combine(w, s);
     }
     const f32x4* wv = wbase(w);
+#if CERB_WLDS
+#pragma unroll
+    for (int k = 0; k < C::WITER; ++k) wst[k] = wv[k * 256];
+#else
     constexpr int WD = (MODE == 0) ? 3 : 2;  // weight prefetch distance in steps (registers: 8 per step)
     f32x4 wq[WD + 1][2];  // weight stream window: steps q .. q+WD
 #pragma unroll
     for (int d = 0; d < WD; ++d)
 #pragma unroll
         for (int s = 0; s < 2; ++s) wq[d][s] = wv[(d * 2 + s) * 64];
+#endif
 
     for (;;) {
         f32x16 acc[2][2];
@@ -219,17 +236,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
             for (int s = 0; s < C::ITER; ++s) {
                 const int f = tid + s * 256;
-                if (f < C::NF) *reinterpret_cast<f32x4*>(lds + (f / C::PARTS) * C::PS + (f % C::PARTS) * 4) = v[s];
+                int part, gy, gx;
+                const bool ok = slice_coords(w, s, part, gy, gx);  // conv zero padding / outside the tile
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                if (f < C::NF) *reinterpret_cast<f32x4*>(lds + (f / C::PARTS) * C::PS + (f % C::PARTS) * 4) = ok ? v[s] : z;
             }
+#if CERB_WLDS
+#pragma unroll
+            for (int k = 0; k < C::WITER; ++k) wl[tid + k * 256] = wst[k];
+#endif
             __syncthreads();
 
             const bool last_ch = (ch == nchunk - 1);
-            const bool pf = !last_ch || more_items;  // is there a chunk to prefetch?
             const Item wp_ = last_ch ? wnx : w;
             const int chp = last_ch ? 0 : ch + 1;
             // weight stream pointer for steps beyond this chunk: the next chunk is contiguous; the next item restarts
+#if CERB_WLDS
+            const f32x4* wnext = last_ch ? wv_nx : wv + (long long)(ch + 1) * C::NQ * 128;  // next chunk's packed weights (+tid)
+            f32x4 a0 = wl[lane], a1 = wl[64 + lane], an0 = a0, an1 = a1;
+#else
             const f32x4* wcur = wv + (long long)ch * C::NQ * 128;
             const f32x4* wover = last_ch ? (wv_nx - (long long)C::NQ * 128) : wcur;
+#endif
 
             f32x4 b0 = *reinterpret_cast<const f32x4*>(lds + ldsb[0]), b1 = *reinterpret_cast<const f32x4*>(lds + ldsb[1]);
             f32x4 bn0 = b0, bn1 = b1;
@@ -240,7 +268,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
                     const int q = tap * C::NG + G;
                     {  // weights WD steps ahead (issued BEFORE this step's staging loads: vmcnt retires in order, so a
                        // wait for weights also waits for every older staging load), pixels (LDS) one step ahead
-#ifdef CERB_ABL_NOWLOAD
+#if CERB_WLDS
+                        if (q + 1 < C::NQ) {
+                            an0 = wl[((q + 1) * 2 + 0) * 64 + lane];
+                            an1 = wl[((q + 1) * 2 + 1) * 64 + lane];
+                        }
+                        if ((q & 1) == 0 && q / 2 < C::WITER) wst[q / 2] = wnext[(q / 2) * 256];
+#elif defined(CERB_ABL_NOWLOAD)
                         wq[WD][0] = wq[0][1];
                         wq[WD][1] = wq[0][0];
 #else
@@ -256,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
                         }
                     }
                     // ---- staging of the next chunk in the shadow of this step's MFMAs -----------------------------------
-                    if (pf) {
+                    {
 #pragma unroll
                         for (int s = q; s < C::ITER; s += C::NQ) issue(wp_, chp, s);
                         if (MODE == 1) {
@@ -280,6 +314,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
                     }
 #endif
                     __builtin_amdgcn_sched_barrier(0);
+#if CERB_WLDS
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc[0][0], 0, 0, 0);
+                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b0[t], acc[1][0], 0, 0, 0);
+                        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b1[t], acc[0][1], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc[1][1], 0, 0, 0);
+                    }
+                    a0 = an0;
+                    a1 = an1;
+#else
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0][0][t], b0[t], acc[0][0], 0, 0, 0);
@@ -292,6 +337,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
                         wq[d][0] = wq[d + 1][0];
                         wq[d][1] = wq[d + 1][1];
                     }
+#endif
                     b0 = bn0;
                     b1 = bn1;
                 }
@@ -355,7 +401,7 @@ static hipError_t launch_cfg(ConvParams p, hipStream_t st) {
         attr_done = true;
     }
     // persistent grid: every workgroup resident at once (2 per CU when LDS allows), each walks a contiguous item range
-    const int blocks_per_cu = (C::LDS_BYTES * 2 <= 160 * 1024) ? 2 : 1;
+    const int blocks_per_cu = (!CERB_WLDS && C::LDS_BYTES * 2 <= 160 * 1024) ? 2 : 1;
     long long grid = 256ll * blocks_per_cu;
     if (grid > items) grid = items;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), C::LDS_BYTES, st, p);
