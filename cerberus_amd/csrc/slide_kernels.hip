@@ -116,3 +116,96 @@ extern "C" int cerb_downsample2_inst(const float* src, long long row_stride, int
     SK_CHECK();
     return 0;
 }
+
+// =================================================================================================================
+// Instance table: the segmented reductions of get_inst_info_dict (loader/postproc.py:12-75)
+// -- bounding box, area, first moments (cv2.moments m10/m00, m01/m00 of the binary instance mask) and the histogram of
+// the type map over the instance -- computed on the device from the label map; contour tracing stays a "next" row.
+// table layout per instance id (1-based row id-1): int64[16] = {area, sum_x, sum_y, y1, y2(excl), x1, x2(excl), 0,
+//                                                              type_count[0..7]}
+// =================================================================================================================
+__global__ void inst_table_init_kernel(long long* __restrict__ t, int n_inst, int H, int W) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_inst; i += gridDim.x * blockDim.x) {
+        long long* r = t + 16ll * i;
+        for (int k = 0; k < 16; ++k) r[k] = 0;
+        r[3] = H;
+        r[5] = W;
+    }
+}
+__device__ __forceinline__ long long wave_sum_ll(long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
+    return v;
+}
+__global__ void inst_table_kernel(const int* __restrict__ lab, long long lab_row_stride, const uint8_t* __restrict__ type, long long type_row_stride,
+                                  int H, int W, int n_inst, unsigned long long* __restrict__ t) {
+    const long long n = (long long)H * W;
+    const int lane = threadIdx.x & 63;
+    for (long long p0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) - lane; p0 < n; p0 += (long long)gridDim.x * blockDim.x) {
+        const long long p = p0 + lane;
+        int y = 0, x = 0, l = 0, ty = 0;
+        if (p < n) {
+            y = (int)(p / W);
+            x = (int)(p % W);
+            l = lab[y * lab_row_stride + x];
+            if (l < 0 || l > n_inst) l = 0;
+            if (l && type) ty = type[y * type_row_stride + x] & 7;
+        }
+        const unsigned long long act = __ballot(l != 0);
+        if (!act) continue;
+        const int l0 = __shfl(l, __ffsll((long long)act) - 1);
+        const bool uniform = __ballot(l != 0 && l != l0) == 0;  // interior of a large instance: one atomic set per wave
+        if (uniform) {
+            const long long sx = wave_sum_ll(l ? x : 0), sy = wave_sum_ll(l ? y : 0);
+            const int y1 = wave_min_i(l ? y : H), y2 = wave_max_i(l ? y + 1 : 0), x1 = wave_min_i(l ? x : W), x2 = wave_max_i(l ? x + 1 : 0);
+            unsigned long long* r = t + 16ll * (l0 - 1);
+            if (type) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int c = __popcll(__ballot(l != 0 && ty == k));
+                    if (lane == 0 && c) atomicAdd(r + 8 + k, (unsigned long long)c);
+                }
+            }
+            if (lane == 0) {
+                atomicAdd(r + 0, (unsigned long long)__popcll(act));
+                atomicAdd(r + 1, (unsigned long long)sx);
+                atomicAdd(r + 2, (unsigned long long)sy);
+                atomicMin((long long*)r + 3, (long long)y1);
+                atomicMax((long long*)r + 4, (long long)y2);
+                atomicMin((long long*)r + 5, (long long)x1);
+                atomicMax((long long*)r + 6, (long long)x2);
+            }
+        } else if (l) {
+            unsigned long long* r = t + 16ll * (l - 1);
+            atomicAdd(r + 0, 1ull);
+            atomicAdd(r + 1, (unsigned long long)x);
+            atomicAdd(r + 2, (unsigned long long)y);
+            atomicMin((long long*)r + 3, (long long)y);
+            atomicMax((long long*)r + 4, (long long)y + 1);
+            atomicMin((long long*)r + 5, (long long)x);
+            atomicMax((long long*)r + 6, (long long)x + 1);
+            if (type) atomicAdd(r + 8 + ty, 1ull);
+        }
+    }
+}
+extern "C" int cerb_inst_table(const int32_t* labels, long long lab_row_stride, const uint8_t* type_map, long long type_row_stride, int h, int w,
+                               int n_inst, long long* table, void* hip_stream) {
+    if (!labels || !table || h <= 0 || w <= 0 || n_inst < 0) return cerb_set_error("cerb_inst_table: bad arguments");
+    if (n_inst == 0) return 0;
+    hipStream_t st = (hipStream_t)hip_stream;
+    hipLaunchKernelGGL(inst_table_init_kernel, dim3(grid_for(n_inst)), dim3(256), 0, st, table, n_inst, h, w);
+    hipLaunchKernelGGL(inst_table_kernel, dim3(grid_for((long long)h * w)), dim3(256), 0, st, labels, lab_row_stride, type_map, type_row_stride, h, w,
+                       n_inst, (unsigned long long*)table);
+    SK_CHECK();
+    return 0;
+}

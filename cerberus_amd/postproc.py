@@ -100,3 +100,62 @@ class PostProcInstErodedContourMap(object):
             inst_map = inst_map.astype(np.float64)
         return inst_map, type_map
 
+
+
+def inst_table_device(inst_map, type_map=None, n_inst=None):
+    """Per-instance reductions on the GPU.  inst_map: CUDA int32 (H,W); type_map: CUDA uint8 (H,W) or None.
+    Returns a CUDA int64 tensor [n_inst, 16] (layout: include/cerberus_hip.h, cerb_inst_table)."""
+    assert inst_map.is_cuda and inst_map.dtype == torch.int32 and inst_map.dim() == 2 and inst_map.stride(1) == 1
+    if n_inst is None:
+        n_inst = int(inst_map.max().item()) if inst_map.numel() else 0
+    table = torch.empty((max(n_inst, 0), 16), dtype=torch.int64, device=inst_map.device)
+    if n_inst <= 0:
+        return table
+    tp, ts = None, 0
+    if type_map is not None:
+        assert type_map.is_cuda and type_map.dtype == torch.uint8 and type_map.shape == inst_map.shape and type_map.stride(1) == 1
+        tp, ts = type_map.data_ptr(), type_map.stride(0)
+    stream = torch.cuda.current_stream(inst_map.device).cuda_stream
+    with torch.cuda.device(inst_map.device):
+        _lib.check(_lib.lib().cerb_inst_table(inst_map.data_ptr(), inst_map.stride(0), tp, ts, int(inst_map.shape[0]), int(inst_map.shape[1]),
+                                              int(n_inst), table.data_ptr(), C.c_void_p(stream)))
+    return table
+
+
+def get_inst_info_dict(inst_map, type_map=None, ds_factor=1.0):
+    """Mirror of the reference's get_inst_info_dict (loader/postproc.py:12-98) without contour tracing:
+    dict id -> {'box': [[rmin,cmin],[rmax,cmax]], 'centroid': [x, y], 'contour': None, 'type', 'type_prob'}.
+
+    inst_map / type_map may be CUDA tensors (label map int32, class map uint8) or numpy arrays.  The per-instance sums
+    come from cerb_inst_table on the GPU; only the small table is copied to the host.
+    Reference rule `contour.shape[0] < 3 -> skip` (postproc.py:34-35): with CHAIN_APPROX_SIMPLE a 4-connected instance has
+    fewer than 3 contour points exactly when it is a one-pixel-wide straight run, i.e. its box has height 1 or width 1 --
+    those instances are skipped here too (derived, not pinned against OpenCV: it is not installed in this image)."""
+    from collections import OrderedDict
+
+    if isinstance(inst_map, np.ndarray):
+        inst_map = torch.from_numpy(np.ascontiguousarray(inst_map).astype(np.int32)).cuda()
+    if type_map is not None and isinstance(type_map, np.ndarray):
+        type_map = torch.from_numpy(np.ascontiguousarray(type_map).astype(np.uint8)).cuda()
+    tab = inst_table_device(inst_map.contiguous(), None if type_map is None else type_map.contiguous()).cpu().numpy()
+    info = OrderedDict()
+    for i in range(tab.shape[0]):
+        area, sx, sy, y1, y2, x1, x2 = [int(v) for v in tab[i, :7]]
+        if area == 0 or (y2 - y1) < 2 or (x2 - x1) < 2:
+            continue
+        d = {"box": np.array([[y1, x1], [y2, x2]]), "centroid": np.array([sx / area, sy / area]), "contour": None}
+        if type_map is not None:
+            cnt = tab[i, 8:16]
+            order = sorted(range(8), key=lambda k: (-int(cnt[k]), k))  # dominant class first
+            order = [k for k in order if cnt[k] > 0]
+            t = order[0]
+            if t == 0 and len(order) > 1:  # pick the 2nd most dominant if exist (postproc.py:69-71)
+                t = order[1]
+            d["type"] = int(t)
+            d["type_prob"] = float(cnt[t] / (area + 1.0e-6))
+        info[i + 1] = d
+    if ds_factor != 1.0:  # resize to the resolution used for processing (postproc.py:78-96)
+        for k, d in info.items():
+            d["box"] = np.round(d["box"] / ds_factor).astype("int")
+            d["centroid"] = np.round(d["centroid"] / ds_factor).astype("int")
+    return info

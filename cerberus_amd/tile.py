@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from .net_desc import create_model
-from .postproc import mask_lumen_by_gland, postproc_device
+from .postproc import get_inst_info_dict, mask_lumen_by_gland, postproc_device
 from .run_desc import infer_step
 
 POSTPROC_CODES = ("IP-ERODED-CONTOUR-3", "IP-ERODED-CONTOUR-11")  # -> PostProcInstErodedContourMap (infer/tile.py:35-40)
@@ -211,14 +211,18 @@ class InferManager(object):
             res = self.infer_image(img, self.patch_input_shape, self.patch_output_shape, self.batch_size, self.postproc_list)
             base = pathlib.Path(fp).stem
             prev_type = None
+
+            def up2(t):  # cv2.resize(fx=2, fy=2, INTER_NEAREST) of an integer map, on the device
+                return t.repeat_interleave(2, dim=0).repeat_interleave(2, dim=1).contiguous()
+
             for tissue, lab in res["inst"].items():
                 lab_np = lab.cpu().numpy()
-                lab2 = np.repeat(np.repeat(lab_np, 2, axis=0), 2, axis=1)  # cv2.resize(fx=2, fy=2, INTER_NEAREST)
                 tmap = res["type"].get(tissue)
                 tmap_np = tmap.cpu().numpy() if tmap is not None else None
-                if tissue != "Lumen" and tmap_np is not None:
-                    prev_type = np.repeat(np.repeat(tmap_np, 2, axis=0), 2, axis=1)
-                info = inst_info_table(lab2, prev_type)  # the reference re-uses the previous tissue's type map for Lumen
+                if tissue != "Lumen" and tmap is not None:
+                    prev_type = up2(tmap)
+                # instance table on the GPU; the reference re-uses the previous tissue's type map for Lumen (infer/tile.py:196-202)
+                info = get_inst_info_dict(up2(lab), prev_type)
                 os.makedirs("%s/%s_mat/" % (self.output_dir, tissue.lower()), exist_ok=True)
                 mat = {"inst_map": lab_np.astype(np.float64) if tissue != "Nuclei" else lab_np,
                        "type": [d.get("type", -1) for d in info.values()], "id": list(info.keys())}

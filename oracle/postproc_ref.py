@@ -105,3 +105,33 @@ class PostProcInstErodedContourMap(object):
         else:
             type_map = None
         return inst_map, type_map
+
+
+def inst_info_ref(inst_map, type_map=None):
+    """ORACLE restatement of get_inst_info_dict (loader/postproc.py:12-75) WITHOUT its OpenCV parts: box from
+    get_bounding_box (misc/utils.py:82-91), centroid = cv2.moments m10/m00, m01/m00 of the cropped binary mask (= mean x, mean
+    y), majority type vote incl. the 'skip background if a second class exists' rule.  cv2.findContours is absent in this
+    image, so the contour and the `< 3 contour points -> skip` filter are not restated (parity unpinned for them)."""
+    from collections import OrderedDict
+
+    info = OrderedDict()
+    for inst_id in np.unique(inst_map)[1:]:
+        m = inst_map == inst_id
+        rows, cols = np.any(m, axis=1), np.any(m, axis=0)
+        rmin, rmax = np.where(rows)[0][[0, -1]]
+        cmin, cmax = np.where(cols)[0][[0, -1]]
+        rmax += 1
+        cmax += 1
+        ys, xs = np.nonzero(m)
+        d = {"box": np.array([[rmin, cmin], [rmax, cmax]]), "centroid": np.array([xs.mean(), ys.mean()])}
+        if type_map is not None:
+            t = type_map[m]
+            tl, tc = np.unique(t, return_counts=True)
+            lst = sorted(zip(tl, tc), key=lambda x: x[1], reverse=True)
+            it = lst[0][0]
+            if it == 0 and len(lst) > 1:
+                it = lst[1][0]
+            d["type"] = int(it)
+            d["type_prob"] = float(dict(lst)[it] / (m.sum() + 1.0e-6))
+        info[int(inst_id)] = d
+    return info

@@ -91,3 +91,25 @@ def test_idempotent_and_deterministic():
     a, _ = postproc_device(m, "Nuclei")
     b, _ = postproc_device(m, "Nuclei")
     assert torch.equal(a, b)
+
+
+def test_instance_table_vs_oracle():
+    """cerb_inst_table / get_inst_info_dict (box, centroid, majority type) vs the numpy restatement of loader/postproc.py:12-75."""
+    from cerberus_amd.postproc import get_inst_info_dict
+
+    m = synth.blob_maps(700, 900, 71, 60, 10.0, 45.0, rim=4.0, sharp=1.0, noise=0.02, border_bias=True)
+    lab, _ = postproc_device(torch.from_numpy(m).cuda(), "Gland")
+    rs = np.random.RandomState(5)
+    typ = (rs.rand(700, 900) < 0.6).astype(np.uint8) * rs.randint(1, 7, (700, 900)).astype(np.uint8)
+    got = get_inst_info_dict(lab, torch.from_numpy(typ).cuda())
+    ref = pr.inst_info_ref(lab.cpu().numpy(), typ)
+    thin = [k for k, d in ref.items() if (d["box"][1] - d["box"][0]).min() < 2]
+    assert sorted(got.keys()) == sorted(k for k in ref if k not in thin) and len(got) > 5
+    for k, d in got.items():
+        r = ref[k]
+        assert np.array_equal(d["box"], r["box"]) and np.allclose(d["centroid"], r["centroid"], rtol=0, atol=1e-9)
+        assert d["type"] == r["type"] and abs(d["type_prob"] - r["type_prob"]) < 1e-12
+    half = get_inst_info_dict(lab, None, ds_factor=0.5)
+    k0 = next(iter(got))
+    assert np.array_equal(half[k0]["box"], np.round(got[k0]["box"] / 0.5).astype(int)) and "type" not in half[k0]
+    assert get_inst_info_dict(torch.zeros((8, 8), dtype=torch.int32, device="cuda")) == {}
