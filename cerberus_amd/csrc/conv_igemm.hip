@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, CERB_WLDS ? 1 : 2) void conv_igemm_kernel(Conv
 #pragma unroll
     for (int k = 0; k < C::WITER; ++k) wst[k] = wv[k * 256];
 #else
-    constexpr int WD = (MODE == 0) ? 3 : 2;  // weight prefetch distance in steps (registers: 8 per step)
+    constexpr int WD = (MODE == 0 && STRIDE == 1) ? 3 : 2;  // weight prefetch distance in steps (registers: 8 per step)
     f32x4 wq[WD + 1][2];  // weight stream window: steps q .. q+WD
 #pragma unroll
     for (int d = 0; d < WD; ++d)
