@@ -65,20 +65,27 @@ struct HostTensor {
     std::vector<float> data;
 };
 
+extern "C" size_t cerb_conv_guard_bytes(void);
+// Activation buffer with a zero-filled guard band in front of and behind the payload: conv_igemm reads halo tiles with
+// unclamped addresses (row wrap / out-of-image elements are masked later), so every byte it can touch must exist and hold
+// a finite value.  The whole allocation is zeroed once; kernels only ever write payload bytes.
 struct DevBuf {
-    float* p = nullptr;
+    float* p = nullptr;  // payload
+    char* raw = nullptr;
     size_t bytes = 0;
     int ensure(size_t need) {
         if (need <= bytes) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
-        if (hipMalloc(&p, need) != hipSuccess) return 1;
+        release();
+        const size_t g = cerb_conv_guard_bytes();
+        if (hipMalloc(&raw, need + 2 * g) != hipSuccess) return 1;
+        if (hipMemset(raw, 0, need + 2 * g) != hipSuccess) return 1;
+        p = reinterpret_cast<float*>(raw + g);
         bytes = need;
         return 0;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (raw) (void)hipFree(raw);
+        raw = nullptr;
         p = nullptr;
         bytes = 0;
     }
