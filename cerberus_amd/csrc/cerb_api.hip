@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -16,6 +17,7 @@
 
 // launchers implemented in the kernel translation units
 hipError_t cerb_launch_conv(const ConvParams& p, int ks, int stride, int mode, hipStream_t st);
+hipError_t cerb_launch_wino(ConvParams p, hipStream_t st);
 extern "C" int cerb_conv_chunk(int ks, int stride);
 struct StemParams {
     const unsigned char* tiles;
@@ -93,8 +95,9 @@ struct DevBuf {
 
 struct PackedConv {
     int cin = 0, cout = 0, ks = 0, stride = 1, groups = 1;
-    float* w = nullptr;  // device
-    float* b = nullptr;  // device
+    float* w = nullptr;     // device
+    float* wino = nullptr;  // device, 3x3 stride-1 only: Winograd F(2x2,3x3) transformed weights (conv_wino.hip)
+    float* b = nullptr;     // device
 };
 
 struct DecoderCfg {
@@ -240,13 +243,49 @@ static void pack_conv(const float* w, const float* scale, int cout, int cin, int
                             }
 }
 
+// Winograd F(2x2,3x3) filter transform U = G g G^T (in double, rounded once) in the layout conv_wino.hip streams:
+//   [cb][chunk][a][b][G][s][lane][t]  ->  U[a][b] of W[cb*64 + s*32 + (lane&31)][chunk*32 + G*8 + 4*(lane>>5) + t]
+static void pack_wino(const float* w, const float* scale, int cout, int cin, std::vector<float>* out) {
+    static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int nchunk = cin / 32, ncb = cout / 64;
+    const size_t base = out->size();
+    out->resize(base + (size_t)cout * cin * 16);
+    float* o = out->data() + base;
+    std::vector<float> U((size_t)cout * cin * 16);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            double g[3][3], t[4][3];
+            for (int y = 0; y < 3; ++y)
+                for (int x = 0; x < 3; ++x) g[y][x] = (double)(w[((size_t)co * cin + ci) * 9 + y * 3 + x] * (scale ? scale[co] : 1.f));
+            for (int a = 0; a < 4; ++a)
+                for (int x = 0; x < 3; ++x) t[a][x] = Gm[a][0] * g[0][x] + Gm[a][1] * g[1][x] + Gm[a][2] * g[2][x];
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b)
+                    U[((size_t)co * cin + ci) * 16 + a * 4 + b] = (float)(t[a][0] * Gm[b][0] + t[a][1] * Gm[b][1] + t[a][2] * Gm[b][2]);
+        }
+    size_t idx = 0;
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b)
+                    for (int G = 0; G < 4; ++G)
+                        for (int s = 0; s < 2; ++s)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int t = 0; t < 4; ++t) {
+                                    const int co = cb * 64 + s * 32 + (lane & 31);
+                                    const int ci = ch * 32 + G * 8 + 4 * (lane >> 5) + t;
+                                    o[idx++] = U[((size_t)co * cin + ci) * 16 + a * 4 + b];
+                                }
+}
+
 static int make_conv(cerb_net* net, const std::string& name, const std::vector<std::string>& wkeys,
                      const std::vector<std::string>& bkeys, const std::vector<std::string>& bnkeys, int cout, int cin, int ks,
                      int stride) {
     // one entry per group
     const int CB = cerb_conv_chunk(ks, stride);
     if (cout % 64 || cin % CB) return fail("conv " + name + ": unsupported channel counts");
-    std::vector<float> wp, bp;
+    std::vector<float> wp, bp, wwino;
+    const bool wino = (ks == 3 && stride == 1 && cin % 32 == 0);
     for (size_t g = 0; g < wkeys.size(); ++g) {
         const HostTensor* w;
         if (get(net, wkeys[g], {cout, cin, ks, ks}, &w)) return 1;
@@ -254,6 +293,7 @@ static int make_conv(cerb_net* net, const std::string& name, const std::vector<s
         bool have_bn = !bnkeys.empty();
         if (have_bn && bn_fold(net, bnkeys[g], cout, &f)) return 1;
         pack_conv(w->data.data(), have_bn ? f.scale.data() : nullptr, cout, cin, ks, CB, &wp);
+        if (wino) pack_wino(w->data.data(), have_bn ? f.scale.data() : nullptr, cout, cin, &wwino);
         const HostTensor* b = nullptr;
         if (!bkeys.empty() && get(net, bkeys[g], {cout}, &b)) return 1;
         for (int c = 0; c < cout; ++c) {
@@ -265,6 +305,7 @@ static int make_conv(cerb_net* net, const std::string& name, const std::vector<s
     PackedConv pc;
     pc.cin = cin; pc.cout = cout; pc.ks = ks; pc.stride = stride; pc.groups = (int)wkeys.size();
     if (upload(net, wp, &pc.w) || upload(net, bp, &pc.b)) return 1;
+    if (wino && upload(net, wwino, &pc.wino)) return 1;
     net->conv[name] = pc;
     return 0;
 }
@@ -431,6 +472,15 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
         if (!out) return 0;
     }
     const double fl = 2.0 * (double)c.groups * N * p.Ho * p.Wo * (double)c.cout * c.cin * c.ks * c.ks;
+    static const int use_wino = [] { const char* e = getenv("CERB_WINO"); return e ? atoi(e) : 0; }();
+    if (use_wino && c.wino && mode == 0) {
+        p.wpack = c.wino;
+        p.w_gs = (long long)c.cout * c.cin * 16;
+        if (prof_begin(net, name, "conv_wino<f2x2,8x16>", fl, st)) return 1;
+        HIP_OK(cerb_launch_wino(p, st));
+        if (prof_end(net, st)) return 1;
+        return 0;
+    }
     const std::string kn = "conv_igemm<ks" + std::to_string(c.ks) + ",s" + std::to_string(c.stride) + ",mode" + std::to_string(mode) +
                            (p.Wo < 32 ? ",16x16>" : ",8x32>");
     if (prof_begin(net, name, kn, fl, st)) return 1;

@@ -1,0 +1,309 @@
+// conv_wino.hip -- 3x3 stride-1 convolution (+ folded BN bias, residual, ReLU) as Winograd F(2x2, 3x3) on the gfx950 fp32
+// matrix cores.  Replaces, for the layers that dominate the forward pass:
+//   reference models/utils/conv_layers.py:24-60 (_ConvLayer: Conv2d 3x3 pad 1 -> BatchNorm2d -> ReLU, eval mode) and
+//   reference models/backbone/resnet.py:81-97 (BasicBlock conv3x3 + bn (+ identity) + relu)
+//
+// Why: fp32 MFMA and fp32 VALU share the SIMD's lanes, so the direct implicit GEMM (conv_igemm.hip) tops out near the
+// 157 TFLOP/s matrix roof.  F(2x2,3x3) needs 16 multiplies per 2x2 output patch instead of 36 (2.25x fewer MFMA cycles); the
+// transforms are additions only (B^T d B on the input, A^T m A on the output) and cost ~6 % of the MFMA time.  Products are
+// exact fp32 FMAs; the only numerical difference to the direct form is the summation order (error stays ~1e-6 relative).
+//
+//   Y = A^T [ sum_cin (G g G^T) (.) (B^T d B) ] A            d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
+//
+// Work decomposition (one workgroup = 4 waves):
+//   * item = 8 x 16 output pixels (4 x 8 Winograd tiles = the 32 columns of an MFMA) x 64 output channels;
+//   * wave a owns row a of the 4x4 transformed patch: positions xi = (a, b), b = 0..3.  For each xi it runs the GEMM
+//     M_xi[cout 64][tile 32] += U_xi[cout][cin] V_xi[cin][tile] with v_mfma_f32_32x32x2_f32 -> 4 x 2 accumulators (128 VGPRs);
+//   * input transform: thread (tile t, channel quad c) loads its 4x4 patch of float4 straight from global memory (per-lane
+//     offset is kernel-invariant, the (row, col) part rides in the scalar offset), transforms it in registers and writes the
+//     16 V values to LDS [xi][tile][36] -- the B operand is then one ds_read_b128 per 4 MFMA k-steps, as in conv_igemm;
+//   * weights are pre-transformed on the host (cerb_api.hip: pack_wino) and streamed from L2 as 1 KiB blocks per wave;
+//   * output transform: each wave reduces over b in registers (T_a[j] = sum_b M[a][b] A[b][j]), the four waves exchange
+//     T through LDS (64 KiB, reusing the V region) and each finishes one (column parity, cout half) quarter of the outputs:
+//     Y[i][j] = sum_a A^T[i][a] T_a[j], + bias (+ residual), ReLU, float4 NHWC stores.
+// Zero padding comes from the zero guard band around activation buffers (cerb_api.hip: DevBuf) for rows above/below the whole
+// tensor and from an explicit mask (uniform branch, border items only) for everything else.
+#include "cerb_common.h"
+
+namespace {
+constexpr int WTY = 4, WTX = 8;          // Winograd tiles per workgroup
+constexpr int NT = WTY * WTX;            // 32 = N of the MFMA
+constexpr int OTH = 2 * WTY, OTW = 2 * WTX;  // output pixels per workgroup: 8 x 16
+constexpr int CB = 32;                   // input channels per LDS pass
+constexpr int PS = CB + 4;               // LDS stride of one tile's channel vector (floats)
+constexpr int V_FLOATS = 16 * NT * PS;   // 18432 floats = 72 KiB -> two workgroups per CU
+constexpr int LDS_BYTES = V_FLOATS * 4;
+constexpr int NQ = 16;                   // steps per chunk for one wave: 4 positions x 4 eight-channel groups
+constexpr int WD = 2;                    // weight prefetch distance in steps
+constexpr int CHUNK_W_BYTES = 16 * 4 * 2 * 1024;  // packed weights of one (cout block, chunk): 128 KiB
+constexpr int WAVE_W_BYTES = 4 * 4 * 2 * 1024;    // one wave's share of it
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, soff, 0);
+}
+
+struct Item {
+    int g, cb, n, oy0, ox0, tx, ty;
+};
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int a = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's row of the transformed patch (scalar)
+    const int j = lane & 31;                                 // MFMA column = Winograd tile / row = cout within a half
+    const int h = lane >> 5;                                 // k-slot
+
+    // ---- this workgroup's contiguous item range (same scheme as conv_igemm) ------------------------------------------------
+    const int ncb = p.Cout >> 6;
+    const int per_group = p.N * p.tiles_y * p.tiles_x * ncb;
+    const int total = per_group * p.groups;
+    const int nchunk = p.Cin / CB;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int base_cnt = total / (int)gridDim.x, rem_cnt = total % (int)gridDim.x;
+    int item = lb * base_cnt + min(lb, rem_cnt);
+    const int item_end = item + base_cnt + (lb < rem_cnt ? 1 : 0);
+    if (item >= item_end) return;
+
+    auto decode = [&](int it) {
+        Item w;
+        w.g = it / per_group;
+        int L = it - w.g * per_group;
+        w.cb = L % ncb;
+        int t_ = L / ncb;
+        w.tx = t_ % p.tiles_x;
+        t_ /= p.tiles_x;
+        w.ty = t_ % p.tiles_y;
+        w.n = t_ / p.tiles_y;
+        w.oy0 = w.ty * OTH;
+        w.ox0 = w.tx * OTW;
+        return w;
+    };
+    auto advance = [&](Item w) {
+        if (++w.cb == ncb) {
+            w.cb = 0;
+            if (++w.tx == p.tiles_x) {
+                w.tx = 0;
+                if (++w.ty == p.tiles_y) {
+                    w.ty = 0;
+                    if (++w.n == p.N) {
+                        w.n = 0;
+                        ++w.g;
+                    }
+                }
+            }
+        }
+        w.oy0 = w.ty * OTH;
+        w.ox0 = w.tx * OTW;
+        return w;
+    };
+    auto in_base = [&](const Item& w) {  // top-left input pixel of the item's patch grid (may lie in the guard band)
+        return reinterpret_cast<const char*>(p.in + w.g * p.in_gs) + ((((long long)w.n * p.H + (w.oy0 - 1)) * p.W + (w.ox0 - 1)) * p.Cin) * 4;
+    };
+    auto w_base = [&](const Item& w) {  // this wave's slice of the item's weight stream
+        return reinterpret_cast<const char*>(p.wpack + w.g * p.w_gs) + (long long)w.cb * nchunk * CHUNK_W_BYTES + a * WAVE_W_BYTES;
+    };
+    auto touches_border = [&](const Item& w) { return w.oy0 < 1 || w.ox0 < 1 || w.oy0 + OTH + 1 > p.H || w.ox0 + OTW + 1 > p.W; };
+
+    // ---- lane invariants -----------------------------------------------------------------------------------------------------
+    // input transform: thread = (tile t, channel quad c)
+    const int t = tid >> 3, c = tid & 7, tty = t >> 3, ttx = t & 7;
+    const unsigned ioff = (unsigned)((((2 * tty) * p.W + 2 * ttx) * p.Cin + 4 * c) * 4);
+    const int vw = t * PS + 4 * c;                 // V write position (floats); position xi adds xi*NT*PS
+    const int vr = (a * 4 * NT + j) * PS + 4 * h;  // V read position for b = 0, G = 0; (b, G) adds b*NT*PS + 8 G
+    const unsigned wlane = (unsigned)lane * 16u;
+    const int rowb = p.W * p.Cin * 4, pixb = p.Cin * 4;
+    // output: this wave finishes column parity jj and cout half sh of every tile
+    const int jj = a & 1, sh = a >> 1;
+    const int oty = j >> 3, otx = j & 7;
+    const unsigned ooff = (unsigned)((((2 * oty) * p.Wo + 2 * otx + jj) * p.Cout + 32 * sh + 4 * h) * 4);
+
+    f32x4 d[4][4];  // raw patch of the NEXT chunk while the matrix pipe works, transformed in place at the chunk boundary
+    auto issue = [&](__amdgpu_buffer_rsrc_t r, int chunk_off, int k) { d[k >> 2][k & 3] = buf_load(r, ioff, chunk_off + (k >> 2) * rowb + (k & 3) * pixb); };
+    auto mask_border = [&](const Item& w) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gy = w.oy0 - 1 + 2 * tty + r, gx = w.ox0 - 1 + 2 * ttx + q;
+                const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                d[r][q] = ok ? d[r][q] : z;
+            }
+    };
+    auto transform = [&]() {  // d <- B^T d B
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f32x4 t0 = d[r][0] - d[r][2], t1 = d[r][1] + d[r][2], t2 = d[r][2] - d[r][1], t3 = d[r][1] - d[r][3];
+            d[r][0] = t0, d[r][1] = t1, d[r][2] = t2, d[r][3] = t3;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t0 = d[0][q] - d[2][q], t1 = d[1][q] + d[2][q], t2 = d[2][q] - d[1][q], t3 = d[1][q] - d[3][q];
+            d[0][q] = t0, d[1][q] = t1, d[2][q] = t2, d[3][q] = t3;
+        }
+    };
+    auto write_v = [&]() {
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) *reinterpret_cast<f32x4*>(lds + xi * NT * PS + vw) = d[xi >> 2][xi & 3];
+    };
+
+    // ---- prologue --------------------------------------------------------------------------------------------------------------
+    Item w = decode(item);
+    {
+        const __amdgpu_buffer_rsrc_t r0 = make_rsrc(in_base(w));
+#pragma unroll
+        for (int k = 0; k < 16; ++k) issue(r0, 0, k);
+    }
+    __amdgpu_buffer_rsrc_t rw = make_rsrc(w_base(w));
+    f32x4 wq[WD + 1][2];
+#pragma unroll
+    for (int dd = 0; dd < WD; ++dd)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) wq[dd][s] = buf_load(rw, wlane, (dd * 2 + s) * 1024);
+
+    for (;;) {
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[b][s][r] = 0.f;
+
+        const bool more_items = item + 1 < item_end;
+        const Item wnx = more_items ? advance(w) : w;
+        const __amdgpu_buffer_rsrc_t rw_nx = more_items ? make_rsrc(w_base(wnx)) : rw;
+        const bool mask_cur = touches_border(w);
+
+        for (int ch = 0; ch < nchunk; ++ch) {
+            if (mask_cur) mask_border(w);
+            transform();
+            __syncthreads();  // every wave finished reading the previous chunk's V (or the previous item's T exchange)
+            write_v();
+            __syncthreads();
+
+            const bool last_ch = (ch == nchunk - 1);
+            const Item wp_ = last_ch ? wnx : w;
+            const __amdgpu_buffer_rsrc_t r_stage = make_rsrc(in_base(wp_));
+            const int stage_off = (last_ch ? 0 : ch + 1) * (CB * 4);
+            const int wcur_off = ch * CHUNK_W_BYTES;
+            const __amdgpu_buffer_rsrc_t rw_over = last_ch ? rw_nx : rw;
+            const int wover_off = last_ch ? 0 : (ch + 1) * CHUNK_W_BYTES;
+
+            f32x4 bq = *reinterpret_cast<const f32x4*>(lds + vr), bn = bq;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                for (int G = 0; G < 4; ++G) {
+                    const int q = b * 4 + G;
+                    if (q + WD < NQ) {
+                        wq[WD][0] = buf_load(rw, wlane, wcur_off + ((q + WD) * 2 + 0) * 1024);
+                        wq[WD][1] = buf_load(rw, wlane, wcur_off + ((q + WD) * 2 + 1) * 1024);
+                    } else {
+                        wq[WD][0] = buf_load(rw_over, wlane, wover_off + ((q + WD - NQ) * 2 + 0) * 1024);
+                        wq[WD][1] = buf_load(rw_over, wlane, wover_off + ((q + WD - NQ) * 2 + 1) * 1024);
+                    }
+                    if (q + 1 < NQ) bn = *reinterpret_cast<const f32x4*>(lds + vr + ((q + 1) >> 2) * NT * PS + ((q + 1) & 3) * 8);
+                    if (q < 8) {  // next chunk's patch: two loads per step, all in flight half a chunk before the transform
+                        issue(r_stage, stage_off, 2 * q);
+                        issue(r_stage, stage_off, 2 * q + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0][0][tt], bq[tt], acc[b][0], 0, 0, 0);
+                        acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0][1][tt], bq[tt], acc[b][1], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int dd = 0; dd < WD; ++dd) {
+                        wq[dd][0] = wq[dd + 1][0];
+                        wq[dd][1] = wq[dd + 1][1];
+                    }
+                    bq = bn;
+                }
+            }
+        }
+
+        // ---- output transform ---------------------------------------------------------------------------------------------------
+        {
+            // over b, in registers: T[0] = M0 + M1 + M2, T[1] = M1 - M2 - M3
+            __syncthreads();  // V no longer read by anyone
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f32x16 T0 = acc[0][s] + acc[1][s] + acc[2][s];
+                const f32x16 T1 = acc[1][s] - acc[2][s] - acc[3][s];
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const f32x4 v0 = {T0[rq * 4 + 0], T0[rq * 4 + 1], T0[rq * 4 + 2], T0[rq * 4 + 3]};
+                    const f32x4 v1 = {T1[rq * 4 + 0], T1[rq * 4 + 1], T1[rq * 4 + 2], T1[rq * 4 + 3]};
+                    *reinterpret_cast<f32x4*>(lds + ((((a * 2 + 0) * 2 + s) * 4 + rq) * 64 + lane) * 4) = v0;
+                    *reinterpret_cast<f32x4*>(lds + ((((a * 2 + 1) * 2 + s) * 4 + rq) * 64 + lane) * 4) = v1;
+                }
+            }
+            __syncthreads();
+            const float* bias = p.bias + w.g * p.bias_gs + w.cb * 64 + 32 * sh + 4 * h;
+            const long long origin = (((long long)w.n * p.Ho + w.oy0) * p.Wo + w.ox0) * p.Cout + w.cb * 64;  // floats, uniform
+            const __amdgpu_buffer_rsrc_t r_out = make_rsrc(p.out + w.g * p.out_gs + origin);
+            const __amdgpu_buffer_rsrc_t r_res = make_rsrc(p.resid ? p.resid + w.g * p.resid_gs + origin : p.out);
+            const bool has_res = p.resid != nullptr;
+            const bool partial = (w.oy0 + OTH > p.Ho) || (w.ox0 + OTW > p.Wo);
+            const bool col_ok = !partial || (w.ox0 + 2 * otx + jj < p.Wo);
+            const int orow = p.Wo * p.Cout * 4;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                f32x4 tq[4];
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa) tq[aa] = *reinterpret_cast<const f32x4*>(lds + ((((aa * 2 + jj) * 2 + sh) * 4 + rq) * 64 + lane) * 4);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + rq * 8);
+                f32x4 y[2];
+                y[0] = tq[0] + tq[1] + tq[2] + bv;
+                y[1] = tq[1] - tq[2] - tq[3] + bv;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (partial && !(col_ok && w.oy0 + 2 * oty + i < p.Ho)) continue;
+                    f32x4 o = y[i];
+                    if (has_res) o = o + buf_load(r_res, ooff, i * orow + rq * 32);
+                    if (p.relu) {
+                        o[0] = fmaxf(o[0], 0.f);
+                        o[1] = fmaxf(o[1], 0.f);
+                        o[2] = fmaxf(o[2], 0.f);
+                        o[3] = fmaxf(o[3], 0.f);
+                    }
+                    buf_store(o, r_out, ooff, i * orow + rq * 32);
+                }
+            }
+        }
+        if (!more_items) break;
+        ++item;
+        w = wnx;
+        rw = rw_nx;
+    }
+}
+
+// Host-side launcher (called from cerb_api.hip).  p.wpack must hold the Winograd-packed weights (pack_wino).
+hipError_t cerb_launch_wino(ConvParams p, hipStream_t st) {
+    if (p.Cin % CB || p.Cout % 64) return hipErrorInvalidValue;
+    p.tiles_x = (p.Wo + OTW - 1) / OTW;
+    p.tiles_y = (p.Ho + OTH - 1) / OTH;
+    const long long items = (long long)p.groups * p.N * p.tiles_x * p.tiles_y * (p.Cout / 64);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    long long grid = 512;  // persistent: two workgroups per CU
+    if (grid > items) grid = items;
+    hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)grid), dim3(256), LDS_BYTES, st, p);
+    return hipGetLastError();
+}
