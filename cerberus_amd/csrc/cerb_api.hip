@@ -18,6 +18,8 @@
 // launchers implemented in the kernel translation units
 hipError_t cerb_launch_conv(const ConvParams& p, int ks, int stride, int mode, hipStream_t st);
 hipError_t cerb_launch_wino(ConvParams p, hipStream_t st);
+hipError_t cerb_launch_upsample2_add(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C,
+                                     long long prev_gs, hipStream_t st);
 extern "C" int cerb_conv_chunk(int ks, int stride);
 struct StemParams {
     const unsigned char* tiles;
@@ -119,7 +121,7 @@ struct cerb_net {
     float *pc_bn1s = nullptr, *pc_bn1b = nullptr, *pc_w1t = nullptr, *pc_b1 = nullptr, *pc_w2t = nullptr, *pc_b2 = nullptr;
     std::vector<void*> dev_allocs;
     // workspace
-    DevBuf x0, pool, x[5], ta, tb, cm, dmid, dout[4];
+    DevBuf x0, pool, x[5], ta, tb, cm, dmid, dsum, dout[4];
     // optional per-launch timing (HIP events on the caller's stream)
     bool profiling = false;
     struct ProfRec { std::string name, kernel; double flops; hipEvent_t e0, e1; };
@@ -128,7 +130,7 @@ struct cerb_net {
     ~cerb_net() {
         for (auto& r : prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         for (void* p : dev_allocs) (void)hipFree(p);
-        x0.release(); pool.release(); ta.release(); tb.release(); cm.release(); dmid.release();
+        x0.release(); pool.release(); ta.release(); tb.release(); cm.release(); dmid.release(); dsum.release();
         for (auto& b : x) b.release();
         for (auto& b : dout) b.release();
     }
@@ -449,6 +451,13 @@ static int prof_end(cerb_net* net, hipStream_t st) {
     return 0;
 }
 
+// 3x3 stride-1 convolutions run as Winograd F(2x2,3x3) (conv_wino.hip); CERB_WINO=0 selects the direct implicit GEMM
+// (conv_igemm.hip) for A/B measurements.
+static int cerb_use_wino() {
+    static const int v = [] { const char* e = getenv("CERB_WINO"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
 static int run_conv(cerb_net* net, const std::string& name, const float* in, const float* prev, const float* resid, float* out, int N,
                     int H, int W, int relu, int mode, long long in_gs, long long prev_gs, hipStream_t st, double* macs) {
     auto it = net->conv.find(name);
@@ -472,8 +481,7 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
         if (!out) return 0;
     }
     const double fl = 2.0 * (double)c.groups * N * p.Ho * p.Wo * (double)c.cout * c.cin * c.ks * c.ks;
-    static const int use_wino = [] { const char* e = getenv("CERB_WINO"); return e ? atoi(e) : 0; }();
-    if (use_wino && c.wino && mode == 0) {
+    if (cerb_use_wino() && c.wino && mode == 0) {
         p.wpack = c.wino;
         p.w_gs = (long long)c.cout * c.cin * 16;
         if (prof_begin(net, name, "conv_wino<f2x2,8x16>", fl, st)) return 1;
@@ -507,6 +515,7 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
         if (D) {
             // dmid holds the first conv of a level: sizes (per decoder) 32^2*256, 64^2*128, 128^2*64, 256^2*64 -> max is the last
             if (net->dmid.ensure(D * (size_t)N * H * W * 64 * 4)) return fail("workspace allocation failed");
+            if (cerb_use_wino() && net->dsum.ensure(D * (size_t)N * H * W * 64 * 4)) return fail("workspace allocation failed");
             const int oc[4] = {128, 64, 64, 64};
             for (int u = 0; u < 4; ++u)
                 if (net->dout[u].ensure(D * (size_t)N * hs[3 - u] * ws[3 - u] * oc[u] * 4)) return fail("workspace allocation failed");
@@ -586,7 +595,14 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
             const int hh = hs[3 - u], ww = ws[3 - u];
             const std::string n0 = "dec." + std::to_string(u) + ".0", n1 = "dec." + std::to_string(u) + ".1";
             const int cmid = net->conv[n0].cout;
-            if (run_conv(net, n0, skips[u], prev, nullptr, dry ? nullptr : net->dmid.p, N, hh, ww, 1, 1, 0, prev_gs, st, macs)) return 1;
+            const int cin0 = net->conv[n0].cin;
+            if (cerb_use_wino() && net->conv[n0].wino && !dry) {
+                // skip + upsample2x(prev) as one HBM pass, then the Winograd conv over the materialised sum
+                if (prof_begin(net, n0 + ".up", "upsample2_add", 0.0, st)) return 1;
+                HIP_OK(cerb_launch_upsample2_add(skips[u], prev, net->dsum.p, (int)D, N, hh, ww, cin0, prev_gs, st));
+                if (prof_end(net, st)) return 1;
+                if (run_conv(net, n0, net->dsum.p, nullptr, nullptr, net->dmid.p, N, hh, ww, 1, 0, (long long)N * hh * ww * cin0, 0, st, macs)) return 1;
+            } else if (run_conv(net, n0, skips[u], prev, nullptr, dry ? nullptr : net->dmid.p, N, hh, ww, 1, 1, 0, prev_gs, st, macs)) return 1;
             if (run_conv(net, n1, dry ? nullptr : net->dmid.p, nullptr, nullptr, dry ? nullptr : net->dout[u].p, N, hh, ww, 1, 0,
                          (long long)N * hh * ww * cmid, 0, st, macs))
                 return 1;
