@@ -24,6 +24,8 @@
 //     Y[i][j] = sum_a A^T[i][a] T_a[j], + bias (+ residual), ReLU, float4 NHWC stores.
 // Zero padding comes from the zero guard band around activation buffers (cerb_api.hip: DevBuf) for rows above/below the whole
 // tensor and from an explicit mask (uniform branch, border items only) for everything else.
+#include <type_traits>
+
 #include "cerb_common.h"
 
 namespace {
@@ -36,6 +38,7 @@ constexpr int V_FLOATS = 16 * NT * PS;   // 18432 floats = 72 KiB -> two workgro
 constexpr int LDS_BYTES = V_FLOATS * 4;
 constexpr int NQ = 16;                   // steps per chunk for one wave: 4 positions x 4 eight-channel groups
 constexpr int WD = 2;                    // weight prefetch distance in steps
+constexpr int NPRE = 4;                  // extra weight steps of the NEXT item requested before an item's output stores
 constexpr int CHUNK_W_BYTES = 16 * 4 * 2 * 1024;  // packed weights of one (cout block, chunk): 128 KiB
 constexpr int WAVE_W_BYTES = 4 * 4 * 2 * 1024;    // one wave's share of it
 
@@ -122,10 +125,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
     const int vr = (a * 4 * NT + j) * PS + 4 * h;  // V read position for b = 0, G = 0; (b, G) adds b*NT*PS + 8 G
     const unsigned wlane = (unsigned)lane * 16u;
     const int rowb = p.W * p.Cin * 4, pixb = p.Cin * 4;
-    // output: this wave finishes column parity jj and cout half sh of every tile
-    const int jj = a & 1, sh = a >> 1;
-    const int oty = j >> 3, otx = j & 7;
-    const unsigned ooff = (unsigned)((((2 * oty) * p.Wo + 2 * otx + jj) * p.Cout + 32 * sh + 4 * h) * 4);
+    // output stage: thread = (column pp of the 16-pixel-wide item, cout quad cq) for all 8 rows -> a wave's store covers 1 KiB
+    const int cq = tid & 15, pp = tid >> 4;
+    const unsigned ooff = (unsigned)((pp * p.Cout + 4 * cq) * 4);
+    // T exchange (floats): block (a, jj, s, rq) at ((a*2+jj)*8 + s*4+rq) * TB, lane (j, h) at h*TH + j*4.  The 16-byte skews make
+    // both the per-wave writes (16 lanes = 16 tiles) and the remapped reads (16 lanes = 16 cout quads) hit distinct banks.
+    constexpr int TB = 264, TH = 132;
+    const int tw = h * TH + j * 4;
+    const int tr = ((pp & 1) * 8 + (cq >> 1)) * TB + (cq & 1) * TH + (pp >> 1) * 4;  // + aa*16*TB + k*32
 
     f32x4 d[4][4];  // raw patch of the NEXT chunk while the matrix pipe works, transformed in place at the chunk boundary
     auto issue = [&](__amdgpu_buffer_rsrc_t r, int chunk_off, int k) { d[k >> 2][k & 3] = buf_load(r, ioff, chunk_off + (k >> 2) * rowb + (k & 3) * pixb); };
@@ -170,22 +177,43 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
     for (int dd = 0; dd < WD; ++dd)
 #pragma unroll
         for (int s = 0; s < 2; ++s) wq[dd][s] = buf_load(rw, wlane, (dd * 2 + s) * 1024);
+    // gfx9-family vmcnt retires loads AND stores in issue order: a load issued after an item's output stores cannot be
+    // waited for before those stores are acknowledged.  Everything the first steps of the next item need (weights of steps
+    // WD .. WD+NPRE-1, the bias) is therefore requested BEFORE the stores, into registers the dead accumulators free up.
+    f32x4 wpre[NPRE][2];
+#pragma unroll
+    for (int dd = 0; dd < NPRE; ++dd)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) wpre[dd][s] = buf_load(rw, wlane, ((WD + dd) * 2 + s) * 1024);
+    // The folded-BN bias enters through position (1,1): A^T[i][1] * A[1][j] = 1 for all four outputs, so the accumulator of
+    // xi = (1,1) starts at the bias and every other accumulator starts at the MFMA's constant-zero C operand.  Waves a != 1
+    // read through a zero-length buffer descriptor (out-of-range buffer loads return 0).
+    f32x4 bnext[2][4];
+    auto load_bias = [&](const Item& wi) {
+        const float* bias = p.bias + wi.g * p.bias_gs + wi.cb * 64;
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, a == 1 ? 256 : 0, 0x00020000);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) bnext[s][rq] = buf_load(rb, (unsigned)h * 16u, (32 * s + 8 * rq) * 4);
+    };
+    load_bias(w);
 
     for (;;) {
         f32x16 acc[4][2];
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[b][s][r] = 0.f;
-
         const bool more_items = item + 1 < item_end;
         const Item wnx = more_items ? advance(w) : w;
         const __amdgpu_buffer_rsrc_t rw_nx = more_items ? make_rsrc(w_base(wnx)) : rw;
         const bool mask_cur = touches_border(w);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[1][s][rq * 4 + e] = bnext[s][rq][e];
 
-        for (int ch = 0; ch < nchunk; ++ch) {
+        auto chunk = [&](auto first_tag, int ch) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             if (mask_cur) mask_border(w);
             transform();
             __syncthreads();  // every wave finished reading the previous chunk's V (or the previous item's T exchange)
@@ -206,7 +234,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
 #pragma unroll
                 for (int G = 0; G < 4; ++G) {
                     const int q = b * 4 + G;
-                    if (q + WD < NQ) {
+                    if (FIRST && q < NPRE) {
+                        wq[WD][0] = wpre[q][0];
+                        wq[WD][1] = wpre[q][1];
+                    } else if (q + WD < NQ) {
                         wq[WD][0] = buf_load(rw, wlane, wcur_off + ((q + WD) * 2 + 0) * 1024);
                         wq[WD][1] = buf_load(rw, wlane, wcur_off + ((q + WD) * 2 + 1) * 1024);
                     } else {
@@ -221,8 +252,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) {
-                        acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0][0][tt], bq[tt], acc[b][0], 0, 0, 0);
-                        acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0][1][tt], bq[tt], acc[b][1], 0, 0, 0);
+                        if (FIRST && G == 0 && tt == 0 && b != 1) {
+                            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0][0][tt], bq[tt], z, 0, 0, 0);
+                            acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0][1][tt], bq[tt], z, 0, 0, 0);
+                        } else {
+                            acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0][0][tt], bq[tt], acc[b][0], 0, 0, 0);
+                            acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0][1][tt], bq[tt], acc[b][1], 0, 0, 0);
+                        }
                     }
 #pragma unroll
                     for (int dd = 0; dd < WD; ++dd) {
@@ -232,12 +269,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
                     bq = bn;
                 }
             }
-        }
+        };
+        chunk(std::true_type{}, 0);
+        for (int ch = 1; ch < nchunk; ++ch) chunk(std::false_type{}, ch);
 
         // ---- output transform ---------------------------------------------------------------------------------------------------
         {
-            // over b, in registers: T[0] = M0 + M1 + M2, T[1] = M1 - M2 - M3
             __syncthreads();  // V no longer read by anyone
+            // over b, in registers: T[0] = M0 + M1 + M2, T[1] = M1 - M2 - M3
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const f32x16 T0 = acc[0][s] + acc[1][s] + acc[2][s];
@@ -246,40 +285,44 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
                 for (int rq = 0; rq < 4; ++rq) {
                     const f32x4 v0 = {T0[rq * 4 + 0], T0[rq * 4 + 1], T0[rq * 4 + 2], T0[rq * 4 + 3]};
                     const f32x4 v1 = {T1[rq * 4 + 0], T1[rq * 4 + 1], T1[rq * 4 + 2], T1[rq * 4 + 3]};
-                    *reinterpret_cast<f32x4*>(lds + ((((a * 2 + 0) * 2 + s) * 4 + rq) * 64 + lane) * 4) = v0;
-                    *reinterpret_cast<f32x4*>(lds + ((((a * 2 + 1) * 2 + s) * 4 + rq) * 64 + lane) * 4) = v1;
+                    *reinterpret_cast<f32x4*>(lds + ((a * 2 + 0) * 8 + s * 4 + rq) * TB + tw) = v0;
+                    *reinterpret_cast<f32x4*>(lds + ((a * 2 + 1) * 8 + s * 4 + rq) * TB + tw) = v1;
                 }
             }
+            // acc is dead: request what the next item's first steps need before this item's stores enter the vmcnt queue
+#pragma unroll
+            for (int dd = 0; dd < NPRE; ++dd)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) wpre[dd][s] = buf_load(rw_nx, wlane, ((WD + dd) * 2 + s) * 1024);
+            load_bias(wnx);
             __syncthreads();
-            const float* bias = p.bias + w.g * p.bias_gs + w.cb * 64 + 32 * sh + 4 * h;
             const long long origin = (((long long)w.n * p.Ho + w.oy0) * p.Wo + w.ox0) * p.Cout + w.cb * 64;  // floats, uniform
             const __amdgpu_buffer_rsrc_t r_out = make_rsrc(p.out + w.g * p.out_gs + origin);
             const __amdgpu_buffer_rsrc_t r_res = make_rsrc(p.resid ? p.resid + w.g * p.resid_gs + origin : p.out);
             const bool has_res = p.resid != nullptr;
             const bool partial = (w.oy0 + OTH > p.Ho) || (w.ox0 + OTW > p.Wo);
-            const bool col_ok = !partial || (w.ox0 + 2 * otx + jj < p.Wo);
+            const bool col_ok = !partial || (w.ox0 + pp < p.Wo);
             const int orow = p.Wo * p.Cout * 4;
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
+            for (int k = 0; k < 4; ++k) {  // tile row k -> output rows 2k, 2k+1
                 f32x4 tq[4];
 #pragma unroll
-                for (int aa = 0; aa < 4; ++aa) tq[aa] = *reinterpret_cast<const f32x4*>(lds + ((((aa * 2 + jj) * 2 + sh) * 4 + rq) * 64 + lane) * 4);
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + rq * 8);
+                for (int aa = 0; aa < 4; ++aa) tq[aa] = *reinterpret_cast<const f32x4*>(lds + tr + aa * 16 * TB + k * 32);
                 f32x4 y[2];
-                y[0] = tq[0] + tq[1] + tq[2] + bv;
-                y[1] = tq[1] - tq[2] - tq[3] + bv;
+                y[0] = tq[0] + tq[1] + tq[2];
+                y[1] = tq[1] - tq[2] - tq[3];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    if (partial && !(col_ok && w.oy0 + 2 * oty + i < p.Ho)) continue;
+                    if (partial && !(col_ok && w.oy0 + 2 * k + i < p.Ho)) continue;
                     f32x4 o = y[i];
-                    if (has_res) o = o + buf_load(r_res, ooff, i * orow + rq * 32);
+                    if (has_res) o = o + buf_load(r_res, ooff, (2 * k + i) * orow);
                     if (p.relu) {
                         o[0] = fmaxf(o[0], 0.f);
                         o[1] = fmaxf(o[1], 0.f);
                         o[2] = fmaxf(o[2], 0.f);
                         o[3] = fmaxf(o[3], 0.f);
                     }
-                    buf_store(o, r_out, ooff, i * orow + rq * 32);
+                    buf_store(o, r_out, ooff, (2 * k + i) * orow);
                 }
             }
         }
