@@ -148,46 +148,52 @@ hipError_t cerb_launch_maxpool(const float* in, float* out, int N, int H, int W,
 __global__ void upsample2_add_kernel(const float* __restrict__ skip, const float* __restrict__ prev, float* __restrict__ out, int groups,
                                      int N, int H, int W, int C, long long prev_gs) {
     const int Hp = H >> 1, Wp = W >> 1, C4 = C >> 2;
-    const long long total = (long long)groups * N * (Hp + 1) * (Wp + 1) * C4;
+    const long long total = (long long)N * (Hp + 1) * (Wp + 1) * C4;
+    const long long out_gs = (long long)N * H * W * C;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
         long long r = i / C4;
         const int bn = (int)(r % (Wp + 1)) - 1;
         r /= (Wp + 1);
         const int bm = (int)(r % (Hp + 1)) - 1;
-        r /= (Hp + 1);
-        const int n = (int)(r % N);
-        const int g = (int)(r / N);
+        const int n = (int)(r / (Hp + 1));
         const int m0 = max(bm, 0), m1 = min(bm + 1, Hp - 1), n0 = max(bn, 0), n1 = min(bn + 1, Wp - 1);
-        const float* pb = prev + g * prev_gs + (long long)n * Hp * Wp * C + c4 * 4;
-        const f32x4 p00 = *reinterpret_cast<const f32x4*>(pb + ((long long)m0 * Wp + n0) * C);
-        const f32x4 p01 = *reinterpret_cast<const f32x4*>(pb + ((long long)m0 * Wp + n1) * C);
-        const f32x4 p10 = *reinterpret_cast<const f32x4*>(pb + ((long long)m1 * Wp + n0) * C);
-        const f32x4 p11 = *reinterpret_cast<const f32x4*>(pb + ((long long)m1 * Wp + n1) * C);
-        // same association as the direct kernel's fused form: hy*(hx*a + lx*b) + ly*(hx*c + lx*d)
-        const f32x4 top_l = 0.75f * p00 + 0.25f * p01, top_r = 0.25f * p00 + 0.75f * p01;
-        const f32x4 bot_l = 0.75f * p10 + 0.25f * p11, bot_r = 0.25f * p10 + 0.75f * p11;
-        const f32x4 u[2][2] = {{0.75f * top_l + 0.25f * bot_l, 0.75f * top_r + 0.25f * bot_r},
-                               {0.25f * top_l + 0.75f * bot_l, 0.25f * top_r + 0.75f * bot_r}};
+        // the skip pixels are shared by every decoder (group): read once, reuse `groups` times
+        f32x4 sk[2][2];
+        bool ok[2][2];
+        long long o[2][2];
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
-            const int y = 2 * bm + 1 + dy;
-            if (y < 0 || y >= H) continue;
+        for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
-                const int x = 2 * bn + 1 + dx;
-                if (x < 0 || x >= W) continue;
-                const long long o = (((long long)n * H + y) * W + x) * C + c4 * 4;
-                const f32x4 sk = *reinterpret_cast<const f32x4*>(skip + o);
-                *reinterpret_cast<f32x4*>(out + (long long)g * N * H * W * C + o) = sk + u[dy][dx];
+                const int y = 2 * bm + 1 + dy, x = 2 * bn + 1 + dx;
+                ok[dy][dx] = y >= 0 && y < H && x >= 0 && x < W;
+                o[dy][dx] = (((long long)n * H + y) * W + x) * C + c4 * 4;
+                if (ok[dy][dx]) sk[dy][dx] = *reinterpret_cast<const f32x4*>(skip + o[dy][dx]);
             }
+        const long long pb = (long long)n * Hp * Wp * C + c4 * 4;
+        for (int g = 0; g < groups; ++g) {
+            const float* pg = prev + g * prev_gs + pb;
+            const f32x4 p00 = *reinterpret_cast<const f32x4*>(pg + ((long long)m0 * Wp + n0) * C);
+            const f32x4 p01 = *reinterpret_cast<const f32x4*>(pg + ((long long)m0 * Wp + n1) * C);
+            const f32x4 p10 = *reinterpret_cast<const f32x4*>(pg + ((long long)m1 * Wp + n0) * C);
+            const f32x4 p11 = *reinterpret_cast<const f32x4*>(pg + ((long long)m1 * Wp + n1) * C);
+            const f32x4 top_l = 0.75f * p00 + 0.25f * p01, top_r = 0.25f * p00 + 0.75f * p01;
+            const f32x4 bot_l = 0.75f * p10 + 0.25f * p11, bot_r = 0.25f * p10 + 0.75f * p11;
+            const f32x4 u[2][2] = {{0.75f * top_l + 0.25f * bot_l, 0.75f * top_r + 0.25f * bot_r},
+                                   {0.25f * top_l + 0.75f * bot_l, 0.25f * top_r + 0.75f * bot_r}};
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx)
+                    if (ok[dy][dx]) __builtin_nontemporal_store(sk[dy][dx] + u[dy][dx], reinterpret_cast<f32x4*>(out + g * out_gs + o[dy][dx]));
         }
     }
 }
 
 hipError_t cerb_launch_upsample2_add(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C,
                                      long long prev_gs, hipStream_t st) {
-    const long long total = (long long)groups * N * (H / 2 + 1) * (W / 2 + 1) * (C / 4);
+    const long long total = (long long)N * (H / 2 + 1) * (W / 2 + 1) * (C / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(upsample2_add_kernel, dim3((unsigned)blocks), dim3(256), 0, st, skip, prev, out, groups, N, H, W, C, prev_gs);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # developer ablation: rebuild conv_wino with -D flags on the GPU box and print the kernel-family table
 cd "$(dirname "$0")/.."
-for FL in ${CERB_VARIANTS:-"" "-DWABL_NOVW" "-DWABL_NOEPI" "-DWABL_NOEPI -DWABL_NOVW" "-DWABL_NOEPI -DWABL_NOVW -DWABL_NOXF -DWABL_NOIN -DWABL_NOW"}; do
+for FL in ${CERB_VARIANTS:-""}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $FL -c cerberus_amd/csrc/conv_wino.hip -o cerberus_amd/csrc/conv_wino.o || exit 1
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o cerberus_amd/libcerberus_hip.so cerberus_amd/csrc/conv_igemm.o cerberus_amd/csrc/conv_wino.o cerberus_amd/csrc/net_kernels.o cerberus_amd/csrc/postproc.o cerberus_amd/csrc/slide_kernels.o cerberus_amd/csrc/cerb_api.o || exit 1
   echo "=== flags: [$FL]"
