@@ -156,11 +156,16 @@ def main():
     # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # separate runs of this same command; gfx950 read-side x2 correction applied by scripts/rocprof_summary.py)
     traffic = None
-    sym = {"conv_igemm<ks3,s1,mode0,8x32>": "void conv_igemm_kernel<3, 1, 8, 32, 32, 0>(ConvParams)",
+    sym = {"conv_wino<f2x2,8x16>": "conv_wino_kernel(ConvParams)",
+           "conv_igemm<ks3,s1,mode0,8x32>": "void conv_igemm_kernel<3, 1, 8, 32, 32, 0>(ConvParams)",
            "conv_igemm<ks3,s1,mode1,8x32>": "void conv_igemm_kernel<3, 1, 8, 32, 32, 1>(ConvParams)"}.get(dom_name)
     pmc_path = os.path.join(ROOT, "profiles", "r01_bench_pmc_hbm.json")
     if sym and os.path.exists(pmc_path):
         traffic = json.load(open(pmc_path)).get(sym, {}).get("hbm_bytes_per_launch")
+    # `achieved` is ALGORITHMIC work (direct-convolution FLOPs, SURVEY par.8d) per second.  The Winograd F(2x2,3x3) kernel
+    # executes 16 multiplies per 2x2 output patch and input channel instead of 36, so its matrix pipe runs 4/9 of those FLOPs:
+    # `frac` can exceed 1; `executed_frac` is the share of the fp32 MFMA roof the kernel's own instructions fill.
+    exec_ratio = 16.0 / 36.0 if dom_name.startswith("conv_wino") else 1.0
     roofline = {
         "bound": "mfma",
         "kernel": dom_name,
@@ -168,6 +173,8 @@ def main():
         "peak": PEAK_F32_MFMA_TFLOPS,
         "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+        "executed_mfma_tflops": round(achieved * exec_ratio, 2),
+        "executed_frac": round(achieved * exec_ratio / PEAK_F32_MFMA_TFLOPS, 4),
         "traffic": traffic,
         "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_bench_pmc_hbm.json)",
         "flop_per_launch": round(dom_fl / dom_cnt / 1e9, 3),

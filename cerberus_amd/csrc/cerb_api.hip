@@ -124,6 +124,7 @@ struct cerb_net {
     DevBuf x0, pool, x[5], ta, tb, cm, dmid, dsum, dout[4];
     // optional per-launch timing (HIP events on the caller's stream)
     bool profiling = false;
+    int conv_algo = 1;  // cerb_net_set_conv_algo: 1 = Winograd F(2x2,3x3) for 3x3 stride-1 convs (default), 0 = direct implicit GEMM
     struct ProfRec { std::string name, kernel; double flops; hipEvent_t e0, e1; };
     std::vector<ProfRec> prof;
     size_t prof_n = 0;
@@ -451,13 +452,6 @@ static int prof_end(cerb_net* net, hipStream_t st) {
     return 0;
 }
 
-// 3x3 stride-1 convolutions run as Winograd F(2x2,3x3) (conv_wino.hip); CERB_WINO=0 selects the direct implicit GEMM
-// (conv_igemm.hip) for A/B measurements.
-static int cerb_use_wino() {
-    static const int v = [] { const char* e = getenv("CERB_WINO"); return e ? atoi(e) : 1; }();
-    return v;
-}
-
 static int run_conv(cerb_net* net, const std::string& name, const float* in, const float* prev, const float* resid, float* out, int N,
                     int H, int W, int relu, int mode, long long in_gs, long long prev_gs, hipStream_t st, double* macs) {
     auto it = net->conv.find(name);
@@ -481,7 +475,7 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
         if (!out) return 0;
     }
     const double fl = 2.0 * (double)c.groups * N * p.Ho * p.Wo * (double)c.cout * c.cin * c.ks * c.ks;
-    if (cerb_use_wino() && c.wino && mode == 0) {
+    if (net->conv_algo && c.wino && mode == 0) {
         p.wpack = c.wino;
         p.w_gs = (long long)c.cout * c.cin * 16;
         if (prof_begin(net, name, "conv_wino<f2x2,8x16>", fl, st)) return 1;
@@ -515,7 +509,7 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
         if (D) {
             // dmid holds the first conv of a level: sizes (per decoder) 32^2*256, 64^2*128, 128^2*64, 256^2*64 -> max is the last
             if (net->dmid.ensure(D * (size_t)N * H * W * 64 * 4)) return fail("workspace allocation failed");
-            if (cerb_use_wino() && net->dsum.ensure(D * (size_t)N * H * W * 64 * 4)) return fail("workspace allocation failed");
+            if (net->conv_algo && net->dsum.ensure(D * (size_t)N * H * W * 64 * 4)) return fail("workspace allocation failed");
             const int oc[4] = {128, 64, 64, 64};
             for (int u = 0; u < 4; ++u)
                 if (net->dout[u].ensure(D * (size_t)N * hs[3 - u] * ws[3 - u] * oc[u] * 4)) return fail("workspace allocation failed");
@@ -596,7 +590,7 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
             const std::string n0 = "dec." + std::to_string(u) + ".0", n1 = "dec." + std::to_string(u) + ".1";
             const int cmid = net->conv[n0].cout;
             const int cin0 = net->conv[n0].cin;
-            if (cerb_use_wino() && net->conv[n0].wino && !dry) {
+            if (net->conv_algo && net->conv[n0].wino && !dry) {
                 // skip + upsample2x(prev) as one HBM pass, then the Winograd conv over the materialised sum
                 if (prof_begin(net, n0 + ".up", "upsample2_add", 0.0, st)) return 1;
                 HIP_OK(cerb_launch_upsample2_add(skips[u], prev, net->dsum.p, (int)D, N, hh, ww, cin0, prev_gs, st));
@@ -664,6 +658,13 @@ extern "C" double cerb_net_flops(const cerb_net* net, int n, int h, int w) {
 }
 
 // ---- per-launch profile (bench.py roofline leg) ----------------------------------------------------------------
+extern "C" int cerb_net_set_conv_algo(cerb_net* net, int algo) {
+    if (!net) return fail("cerb_net_set_conv_algo: null handle");
+    if (algo != 0 && algo != 1) return fail("cerb_net_set_conv_algo: algo must be 0 (direct) or 1 (Winograd)");
+    net->conv_algo = algo;
+    return 0;
+}
+
 extern "C" int cerb_net_profile_enable(cerb_net* net, int enable) {
     if (!net) return fail("cerb_net_profile_enable: null handle");
     net->profiling = enable != 0;
