@@ -121,8 +121,8 @@ extern "C" int cerb_downsample2_inst(const float* src, long long row_stride, int
 // Instance table: the segmented reductions of get_inst_info_dict (loader/postproc.py:12-75)
 // -- bounding box, area, first moments (cv2.moments m10/m00, m01/m00 of the binary instance mask) and the histogram of
 // the type map over the instance -- computed on the device from the label map; contour tracing stays a "next" row.
-// table layout per instance id (1-based row id-1): int64[16] = {area, sum_x, sum_y, y1, y2(excl), x1, x2(excl), 0,
-//                                                              type_count[0..7]}
+// table layout per instance id (1-based row id-1): int64[16] = {area, sum_x, sum_y, y1, y2(excl), x1, x2(excl), first,
+//                                                              type_count[0..7]},  first = min(y*W + x) over its pixels
 // =================================================================================================================
 __global__ void inst_table_init_kernel(long long* __restrict__ t, int n_inst, int H, int W) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_inst; i += gridDim.x * blockDim.x) {
@@ -130,6 +130,7 @@ __global__ void inst_table_init_kernel(long long* __restrict__ t, int n_inst, in
         for (int k = 0; k < 16; ++k) r[k] = 0;
         r[3] = H;
         r[5] = W;
+        r[7] = (long long)H * W;
     }
 }
 __device__ __forceinline__ long long wave_sum_ll(long long v) {
@@ -184,6 +185,7 @@ __global__ void inst_table_kernel(const int* __restrict__ lab, long long lab_row
                 atomicMax((long long*)r + 4, (long long)y2);
                 atomicMin((long long*)r + 5, (long long)x1);
                 atomicMax((long long*)r + 6, (long long)x2);
+                atomicMin((long long*)r + 7, p0 + (__ffsll((long long)act) - 1));
             }
         } else if (l) {
             unsigned long long* r = t + 16ll * (l - 1);
@@ -194,6 +196,7 @@ __global__ void inst_table_kernel(const int* __restrict__ lab, long long lab_row
             atomicMax((long long*)r + 4, (long long)y + 1);
             atomicMin((long long*)r + 5, (long long)x);
             atomicMax((long long*)r + 6, (long long)x + 1);
+            atomicMin((long long*)r + 7, p);
             if (type) atomicAdd(r + 8 + ty, 1ull);
         }
     }
@@ -206,6 +209,28 @@ extern "C" int cerb_inst_table(const int32_t* labels, long long lab_row_stride, 
     hipLaunchKernelGGL(inst_table_init_kernel, dim3(grid_for(n_inst)), dim3(256), 0, st, table, n_inst, h, w);
     hipLaunchKernelGGL(inst_table_kernel, dim3(grid_for((long long)h * w)), dim3(256), 0, st, labels, lab_row_stride, type_map, type_row_stride, h, w,
                        n_inst, (unsigned long long*)table);
+    SK_CHECK();
+    return 0;
+}
+
+// =================================================================================================================
+// cerb_relabel: out[y][x] = map[labels[y][x]] (map[0] must be 0; ids outside [0, n_map) become 0).  Used by the sharded
+// post-processing (cerberus_amd/shard_postproc.py) to turn band-local instance ids into slide-global ones.
+// =================================================================================================================
+__global__ void relabel_kernel(const int* __restrict__ lab, long long lab_row_stride, const int* __restrict__ map, int n_map, int H, int W,
+                               int* __restrict__ out, long long out_row_stride) {
+    const long long n = (long long)H * W;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(p / W), x = (int)(p % W);
+        const int l = lab[y * lab_row_stride + x];
+        out[y * out_row_stride + x] = (l > 0 && l < n_map) ? map[l] : 0;
+    }
+}
+extern "C" int cerb_relabel(const int32_t* labels, long long lab_row_stride, const int32_t* map, int n_map, int h, int w, int32_t* out,
+                            long long out_row_stride, void* hip_stream) {
+    if (!labels || !map || !out || h <= 0 || w <= 0 || n_map < 1) return cerb_set_error("cerb_relabel: bad arguments");
+    hipLaunchKernelGGL(relabel_kernel, dim3(grid_for((long long)h * w)), dim3(256), 0, (hipStream_t)hip_stream, labels, lab_row_stride, map, n_map,
+                       h, w, out, out_row_stride);
     SK_CHECK();
     return 0;
 }

@@ -1,0 +1,290 @@
+"""Band-local post-processing for the multi-GPU slide path.
+
+The reference post-processes a slide in 4096^2 tiles and repairs the seams with 64-px margins, boundary strips and shapely
+de-duplication (infer/wsi.py:81-268), and names instances with uuid4 (infer/wsi.py:265,831).  Here every rank owns one
+contiguous band of canvas rows and labels it in ONE pass:
+
+  1. halo exchange: each rank receives `margin` rows of the probability canvas from the rank above and below (two
+     point-to-point messages per rank over the direct xGMI link; the only data-path traffic of this stage);
+  2. local labelling of window = halo + band + halo with the ordinary single-GPU kernels (cerb_postproc_*), instance table
+     (cerb_inst_table: bounding rows + first pixel of every instance);
+  3. ownership: an instance belongs to the rank whose band contains its FIRST pixel in raster order (its top row), so
+     every instance has exactly one owner and only ever extends downwards out of its owner's band;
+  4. one all-gather of the per-rank owned counts -> exclusive prefix sum -> slide-global ids that are unique and ordered by
+     (band, first pixel); one all-gather of the few (first pixel -> global id) pairs of instances that cross a band's lower
+     edge, so the rank below names its part of them identically;
+  5. cerb_relabel writes the band's rows with global ids.
+
+An instance whose bounding rows come within `guard` rows of an artificial window edge may be cut (or, for glands, padded
+differently before dilation); those are counted in info['n_truncated'] -- 0 means the band result is provably the one a
+single GPU computes on the whole slide (up to the id bijection).  Choose margin >= tallest instance + guard.
+
+The phase functions are pure per-rank steps; `run_local` chains them for ranks simulated in one process (GPU test),
+`run_distributed` uses torch.distributed (RCCL on the GPU box, gloo in the CPU tests).  `label_fn` / `table_fn` default to the
+HIP kernels and fail loudly without a GPU; the gloo test injects numpy stand-ins to exercise the protocol itself."""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+
+def _device_label_fn(window, tissue, ds_factor):
+    from .postproc import postproc_device
+
+    lab, info = postproc_device(window, tissue, ds_factor)
+    n = int(info["n_inst"].item())
+    return lab, max(n, 0)
+
+
+def _device_table_fn(lab, n):
+    from .postproc import inst_table_device
+
+    return inst_table_device(lab, None, n)
+
+
+def _device_relabel_fn(lab_rows, mapping):
+    import ctypes as C
+
+    from . import _lib
+
+    out = torch.empty_like(lab_rows)
+    stream = torch.cuda.current_stream(lab_rows.device).cuda_stream
+    with torch.cuda.device(lab_rows.device):
+        _lib.check(_lib.lib().cerb_relabel(lab_rows.data_ptr(), lab_rows.stride(0), mapping.data_ptr(), int(mapping.numel()),
+                                           int(lab_rows.shape[0]), int(lab_rows.shape[1]), out.data_ptr(), out.stride(0), C.c_void_p(stream)))
+    return out
+
+
+class BandState(object):
+    """Per-rank, per-tissue state carried between the phases."""
+
+    def __init__(self, rank, world, band, y0_global, margin, guard, tissue, ds_factor=1.0):
+        assert band.dim() == 3 and band.shape[2] == 2, "band: (rows, W, 2) probability canvas of this rank"
+        self.rank, self.world = rank, world
+        self.band = band
+        self.y0 = int(y0_global)  # global canvas row of band row 0 (at the resolution of `band`)
+        self.margin, self.guard = int(margin), int(guard)
+        self.tissue, self.ds = tissue, float(ds_factor)
+        if world > 1:
+            assert band.shape[0] >= margin, "band shorter than the halo margin: use fewer ranks or a smaller margin"
+
+    # ---- phase 1: what the neighbours need -------------------------------------------------------------------------
+    def strips(self):
+        """(rows for the rank above = my first `margin` rows, rows for the rank below = my last `margin` rows)"""
+        up = self.band[: self.margin].contiguous() if self.rank > 0 else None
+        down = self.band[self.band.shape[0] - self.margin:].contiguous() if self.rank < self.world - 1 else None
+        return up, down
+
+    # ---- phase 2: label the window ------------------------------------------------------------------------------------
+    def label(self, from_above, from_below, label_fn=_device_label_fn, table_fn=_device_table_fn):
+        parts = [p for p in (from_above, self.band, from_below) if p is not None]
+        window = torch.cat(parts, dim=0) if len(parts) > 1 else self.band
+        self.top = 0 if from_above is None else int(from_above.shape[0])
+        self.h_band = int(self.band.shape[0])
+        self.h_win, self.w = int(window.shape[0]), int(window.shape[1])
+        self.lab, self.n = label_fn(window, self.tissue, self.ds)
+        if self.n > 0:
+            tab = table_fn(self.lab, self.n)
+            tab = tab.cpu().numpy() if torch.is_tensor(tab) else np.asarray(tab)
+        else:
+            tab = np.zeros((0, 16), np.int64)
+        area, y1, y2, first = tab[:, 0], tab[:, 3], tab[:, 4], tab[:, 7]
+        self.y2 = y2
+        alive = area > 0
+        fy = first // self.w
+        # global key of an instance: its first pixel in slide raster order
+        self.key = (fy - self.top + self.y0) * self.w + (first % self.w)
+        self.owned = alive & (fy >= self.top) & (fy < self.top + self.h_band)
+        self.in_band = alive & (y2 > self.top) & (y1 < self.top + self.h_band)
+        art_top, art_bot = from_above is not None, from_below is not None
+        cut = np.zeros(len(tab), bool)
+        if art_top:
+            cut |= y1 < self.guard
+        if art_bot:
+            cut |= y2 > self.h_win - self.guard
+        self.n_truncated = int((cut & self.in_band).sum())
+        # rank-local order of the owned instances = order of their first pixels
+        own_idx = np.nonzero(self.owned)[0]
+        self.own_sorted = own_idx[np.argsort(self.key[own_idx], kind="stable")]
+        self.n_owned = int(len(own_idx))
+        return self.n_owned
+
+    # ---- phase 3: global ids -------------------------------------------------------------------------------------------
+    def publish(self, offset):
+        """Global ids of my owned instances (offset = owned counts of the ranks above); returns the int64 [k, 2] table
+        (key, global id) of the owned instances that extend below my band -- the only ones another rank has to name."""
+        self.gid = np.zeros(len(self.key), np.int64)
+        self.gid[self.own_sorted] = offset + 1 + np.arange(self.n_owned)
+        crossing = self.owned & (self.y2 > self.top + self.h_band)
+        return np.stack([self.key[crossing], self.gid[crossing]], axis=1).astype(np.int64).reshape(-1, 2)
+
+    def resolve(self, published_from_above, relabel_fn=_device_relabel_fn):
+        """Name the instances I see but do not own (their owner is a rank above), relabel my band rows."""
+        lut = {}
+        for tab in published_from_above:
+            for k, g in np.asarray(tab).reshape(-1, 2):
+                lut[int(k)] = int(g)
+        foreign = np.nonzero(self.in_band & ~self.owned)[0]
+        unresolved = 0
+        for i in foreign:
+            g = lut.get(int(self.key[i]))
+            if g is None:
+                unresolved += 1
+            else:
+                self.gid[i] = g
+        self.n_unresolved = unresolved
+        mapping = np.zeros(len(self.key) + 1, np.int32)
+        mapping[1:] = self.gid
+        rows = self.lab[self.top: self.top + self.h_band]
+        if torch.is_tensor(rows):
+            out = relabel_fn(rows, torch.from_numpy(mapping).to(rows.device))
+        else:
+            out = relabel_fn(rows, mapping)
+        info = {"n_owned": self.n_owned, "n_truncated": self.n_truncated, "n_unresolved": self.n_unresolved}
+        return out, info
+
+
+def run_local(bands, tissue, margin, guard, ds_factor=1.0, label_fn=_device_label_fn, table_fn=_device_table_fn,
+              relabel_fn=_device_relabel_fn):
+    """All ranks simulated in one process: `bands` = list of (rows_r, W, 2) tensors in slide order.
+    Returns (list of int32 band label maps with global ids, total instance count, list of per-rank info)."""
+    world = len(bands)
+    y0 = np.concatenate([[0], np.cumsum([b.shape[0] for b in bands])]).astype(np.int64)
+    states = [BandState(r, world, bands[r], y0[r], margin, guard, tissue, ds_factor) for r in range(world)]
+    strips = [s.strips() for s in states]
+    counts = []
+    for r, s in enumerate(states):
+        above = strips[r - 1][1] if r > 0 else None          # the rank above sends its last rows down
+        below = strips[r + 1][0] if r < world - 1 else None  # the rank below sends its first rows up
+        counts.append(s.label(above, below, label_fn, table_fn))
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    pubs = [s.publish(int(offs[r])) for r, s in enumerate(states)]
+    outs, infos = [], []
+    for r, s in enumerate(states):
+        o, i = s.resolve(pubs[:r], relabel_fn)
+        outs.append(o)
+        infos.append(i)
+    return outs, int(offs[-1]), infos
+
+
+def run_distributed(band, y0_global, tissue, margin, guard, dist, ds_factor=1.0, label_fn=_device_label_fn,
+                    table_fn=_device_table_fn, relabel_fn=_device_relabel_fn):
+    """One rank of the real thing.  `dist` = torch.distributed (initialised).  Returns (band labels with global ids,
+    total instance count over all ranks, info dict)."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    st = BandState(rank, world, band, y0_global, margin, guard, tissue, ds_factor)
+    up, down = st.strips()
+    above = torch.empty_like(up) if rank > 0 else None
+    below = torch.empty_like(down) if rank < world - 1 else None
+    ops = []
+    if rank > 0:
+        ops += [dist.P2POp(dist.isend, up, rank - 1), dist.P2POp(dist.irecv, above, rank - 1)]
+    if rank < world - 1:
+        ops += [dist.P2POp(dist.isend, down, rank + 1), dist.P2POp(dist.irecv, below, rank + 1)]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    n_owned = st.label(above, below, label_fn, table_fn)
+    dev = band.device
+    cnt = torch.tensor([n_owned], dtype=torch.int64, device=dev)
+    allc = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(allc, cnt)
+    counts = [int(c.item()) for c in allc]
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    pub = st.publish(int(offs[rank]))
+    # variable-length (key, id) tables: lengths first, then one padded all-gather
+    ln = torch.tensor([pub.shape[0]], dtype=torch.int64, device=dev)
+    alln = [torch.zeros_like(ln) for _ in range(world)]
+    dist.all_gather(alln, ln)
+    lens = [int(x.item()) for x in alln]
+    mx = max(max(lens), 1)
+    buf = torch.zeros((mx, 2), dtype=torch.int64, device=dev)
+    if pub.shape[0]:
+        buf[: pub.shape[0]] = torch.from_numpy(pub).to(dev)
+    allp = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(allp, buf)
+    pubs = [allp[r][: lens[r]].cpu().numpy() for r in range(rank)]
+    out, info = st.resolve(pubs, relabel_fn)
+    info["n_total"] = int(offs[-1])
+    return out, int(offs[-1]), info
+
+
+def assemble(band_labels):
+    """Concatenate band label maps (slide order) -- the root-side stitch of the (much smaller) int32 results."""
+    return torch.cat(list(band_labels), dim=0) if torch.is_tensor(band_labels[0]) else np.concatenate(list(band_labels), axis=0)
+
+
+def same_partition(a, b):
+    """True iff label maps a and b describe the same instances up to a renaming of the ids."""
+    a, b = np.asarray(a).ravel().astype(np.int64), np.asarray(b).ravel().astype(np.int64)
+    if not np.array_equal(a > 0, b > 0):
+        return False
+    pairs = np.unique(np.stack([a, b], axis=1), axis=0)
+    return len(np.unique(pairs[:, 0])) == len(pairs) and len(np.unique(pairs[:, 1])) == len(pairs)
+
+
+def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guard=48):
+    """Per-rank replacement of WSIRunner.postprocess for band canvases: label maps of THIS rank's band with slide-global
+    ids, nothing gathered.  canv: the band canvases of this rank (full-resolution rows of equal count on every rank except
+    the last).  Gland / lumen run at x0.5 in wsi_mode (infer/wsi.py:786-804); their margin / guard are halved accordingly."""
+    from .postproc import mask_lumen_by_gland
+    from .wsi import downsample2_inst
+
+    inst, info = OrderedDict(), OrderedDict()
+    rows = int(next(iter(canv.values())).shape[0])
+    cnt = torch.tensor([rows], dtype=torch.int64, device=next(iter(canv.values())).device)
+    allr = [torch.zeros_like(cnt) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(allr, cnt)
+    else:
+        allr = [cnt]
+    y0 = int(sum(int(x.item()) for x in allr[:rank]))
+    for t in ("Nuclei", "Gland", "Lumen"):
+        key = t + "-INST"
+        if key not in canv:
+            continue
+        half = wsi_mode and t != "Nuclei"
+        band = downsample2_inst(canv[key]) if half else canv[key]
+        m, g, yy, ds = (margin // 2, guard // 2, y0 // 2, 0.5) if half else (margin, guard, y0, 1.0)
+        if world > 1:
+            inst[t], _, info[t] = run_distributed(band, yy, t, m, g, dist, ds)
+        else:
+            outs, n, infos = run_local([band], t, m, g, ds)
+            inst[t], info[t] = outs[0], dict(infos[0], n_total=n)
+    if "Lumen" in inst and "Gland" in inst:
+        mask_lumen_by_gland(inst["Lumen"], inst["Gland"])
+    return inst, info
+
+
+def _gather_rows(lab, rows_per_rank, cols, dist, rank, world):
+    """Concatenate per-rank label bands (rows_per_rank[r] valid rows each) on the root; None elsewhere."""
+    hmax = max(rows_per_rank)
+    pad = torch.zeros((hmax, cols), dtype=lab.dtype, device=lab.device)
+    pad[: lab.shape[0], : min(cols, lab.shape[1])] = lab[:, :cols]
+    lst = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, lst, dst=0)
+    if rank != 0:
+        return None
+    return torch.cat([lst[i][: rows_per_rank[i]] for i in range(world)], dim=0)
+
+
+def postprocess_bands_and_gather(run, H, W, rank, world, dist, margin=512, guard=48):
+    """The multi-GPU tail of a slide: band-local label maps with slide-global ids, then only the int32 label bands and the
+    uint8 / float class canvases travel to the root (12 + 3 B/px instead of the 36 B/px of raw probability canvases).
+    `run` is this rank's WSIRunner after infer_band.  Returns (inst, info, small) -- inst / small are None off the root."""
+    from .wsi import band_partition, gather_bands
+
+    geo = run.geo
+    valid = max(0, min(run.band_h, H - run.r0 * geo.out))
+    band = OrderedDict((k, v[:valid, :W]) for k, v in run.canv.items())
+    inst_b, info = sharded_postprocess(band, rank, world, dist, wsi_mode=True, margin=margin, guard=guard)
+    bounds = band_partition(geo.rows, world)
+    rows = [max(0, min((bounds[i + 1] - bounds[i]) * geo.out, H - bounds[i] * geo.out)) for i in range(world)]
+    inst = OrderedDict() if rank == 0 else None
+    for t, lab in inst_b.items():
+        half = t != "Nuclei"
+        g = _gather_rows(lab, [r // 2 for r in rows] if half else rows, W // 2 if half else W, dist, rank, world)
+        if rank == 0:
+            inst[t] = g
+    small = gather_bands(OrderedDict((k, v) for k, v in run.canv.items() if not k.endswith("INST")), geo, rank, world, dist)
+    return inst, info, small

@@ -126,11 +126,17 @@ int cerb_downsample2_inst(const float* src, long long row_stride, int pix_stride
 
 /* ---- instance table: the segmented reductions of get_inst_info_dict (loader/postproc.py:12-75) on the device --------
  * labels: int32 label map (row stride in elements); type_map: optional uint8 class map (NULL = none).
- * table : device int64 [n_inst][16], row id-1 = {area, sum_x, sum_y, y1, y2 (exclusive), x1, x2 (exclusive), 0,
- *         type_count[0..7]}  ->  box [[y1,x1],[y2,x2]], centroid (sum_x/area, sum_y/area) == cv2.moments m10/m00, m01/m00,
+ * table : device int64 [n_inst][16], row id-1 = {area, sum_x, sum_y, y1, y2 (exclusive), x1, x2 (exclusive), first,
+ *         type_count[0..7]}, first = min(y*w + x) over the instance's pixels (its first pixel in raster order)  ->  box [[y1,x1],[y2,x2]], centroid (sum_x/area, sum_y/area) == cv2.moments m10/m00, m01/m00,
  *         majority type / type_prob.  Contour tracing (cv2.findContours) is not part of this entry point. */
 int cerb_inst_table(const int32_t* labels, long long lab_row_stride, const uint8_t* type_map, long long type_row_stride,
                     int h, int w, int n_inst, long long* table, void* hip_stream);
+
+/* out[y][x] = map[labels[y][x]] with map[0] == 0; ids outside [0, n_map) become 0.  Turns band-local instance ids into
+ * slide-global ones after the count exchange of the sharded post-processing (the reference only needs ids to be unique:
+ * uuid4 at infer/wsi.py:265,831). */
+int cerb_relabel(const int32_t* labels, long long lab_row_stride, const int32_t* map, int n_map, int h, int w, int32_t* out,
+                 long long out_row_stride, void* hip_stream);
 
 /* ---- device timing helper: HIP events on the given stream (bench.py; torch.cuda.Event only sees torch's stream) */
 int cerb_event_create(void** ev);

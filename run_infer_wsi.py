@@ -104,11 +104,17 @@ if __name__ == "__main__":
         run.infer_band(slab, y0)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        full = run.gather_to_root(dist)
-        if rank == 0:
+        if world > 1:
+            # band-local labelling with slide-global ids; only int32 label bands and the class maps travel to the root
+            from cerberus_amd.shard_postproc import postprocess_bands_and_gather
+
+            inst, info, full = postprocess_bands_and_gather(run, H, W, rank, world, dist)
+        else:
+            full = run.gather_to_root(dist)
             inst, info = WSIRunner.postprocess(full, wsi_mode=True)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if rank == 0:
             np.savez_compressed("%s/%s.npz" % (args["--output_dir"], base), **{k: v.cpu().numpy() for k, v in inst.items()},
                                 **{"type_" + k: v.cpu().numpy() for k, v in full.items() if k.endswith("TYPE")}, pclass=full.get("Patch-Class").cpu().numpy()[::4, ::4])
             print("%s: Inference Time: %.3f  Post Proc Time: %.3f  (%.1f Mpx/s inference)" % (base, t1 - t0, t2 - t1, H * W / (t1 - t0) / 1e6))

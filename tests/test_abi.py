@@ -25,6 +25,24 @@ def test_header_symbols_exported():
     assert sorted(_lib.EXPORTS) == names
 
 
+def test_every_binding_declares_its_argument_types():
+    """A ctypes entry point without argtypes truncates 64-bit pointers to int: every export taking arguments must set them,
+    with the arity of the header's declaration."""
+    from cerberus_amd import _lib
+
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "cerberus_hip.h")).read(), flags=re.S)
+    L = _lib.lib()
+    for name in _lib.EXPORTS:
+        m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, txt, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        arity = 0 if params in ("", "void") else params.count(",") + 1
+        at = getattr(L, name).argtypes
+        if arity == 0:
+            continue
+        assert at is not None and len(at) == arity, "%s: header has %d parameters, binding declares %s" % (name, arity, at)
+
+
 def test_version_and_error_string():
     from cerberus_amd import _lib
 

@@ -184,3 +184,40 @@ def test_direct_conv_algo_vs_reference_golden(golden_dir, tag):
         else:
             assert (got != ref).mean() < 1e-4, k
             assert (a != b).mean() < 1e-4, k
+
+
+def _dice(pred, ref):
+    """models/run_desc.py:526-531,608-617: 2*sum(pred & ref) / (sum(pred) + sum(ref) + 1e-8)"""
+    pred, ref = pred.astype(np.float64), ref.astype(np.float64)
+    return 2.0 * (pred * ref).sum() / (pred.sum() + ref.sum() + 1e-8)
+
+
+def test_dice_vs_reference_golden(golden_dir):
+    """SURVEY par.8d: per-head Dice of the HIP path against the reference's own outputs -- INST foreground (> 0.5) per channel
+    and every TYPE class with support in the fixture."""
+    g = np.load(os.path.join(golden_dir, "net_cfg2_all.npz"))
+    tasks = [str(t) for t in g["tasks"]]
+    m, sd, kw = _model(tasks, int(g["weight_seed"]))
+    n, hw, osz = int(g["n"]), int(g["hw"]), int(g["out_shape"])
+    tiles = np.random.RandomState(int(g["tile_seed"])).randint(0, 256, (n, hw, hw, 3)).astype(np.uint8)
+    out = infer_step(torch.from_numpy(tiles), m, osz, tasks)
+    checked = 0
+    for k in out[0].keys():
+        a = np.stack([out[i][k] for i in range(n)])
+        a4 = a[..., None] if a.ndim == 3 else a
+        key = "out_crops/" + k
+        ref = g[key] if key in g else g["out_full/" + k]
+        got = _crops(a4) if key in g else a4
+        if k.endswith("-INST"):
+            for c in range(2):
+                r, p = ref[..., c] > 0.5, got[..., c] > 0.5
+                if r.sum() > 50:
+                    assert _dice(p, r) > 0.9995, (k, c)
+                    checked += 1
+        elif k.endswith("-TYPE"):
+            for cls in np.unique(ref):
+                r, p = ref == cls, got == cls
+                if r.sum() > 50:
+                    assert _dice(p, r) > 0.9995, (k, int(cls))
+                    checked += 1
+    assert checked >= 6

@@ -113,3 +113,55 @@ def test_instance_table_vs_oracle():
     k0 = next(iter(got))
     assert np.array_equal(half[k0]["box"], np.round(got[k0]["box"] / 0.5).astype(int)) and "type" not in half[k0]
     assert get_inst_info_dict(torch.zeros((8, 8), dtype=torch.int32, device="cuda")) == {}
+
+
+def test_inst_table_first_pixel_and_relabel():
+    """cerb_inst_table column 7 (first pixel in raster order) and cerb_relabel."""
+    from cerberus_amd.postproc import inst_table_device
+    from cerberus_amd.shard_postproc import _device_relabel_fn
+
+    m = synth.nuclei_maps(512, 640, 21, 700.0, noise=0.02)
+    lab, info = postproc_device(torch.from_numpy(m).cuda(), "Nuclei")
+    n = int(info["n_inst"].item())
+    tab = inst_table_device(lab, None, n).cpu().numpy()
+    L = lab.cpu().numpy()
+    ys, xs = np.nonzero(L)
+    first = np.full(n, L.size, np.int64)
+    np.minimum.at(first, L[ys, xs] - 1, ys * L.shape[1] + xs)
+    assert np.array_equal(tab[:, 7], first)
+    mapping = np.zeros(n + 1, np.int32)
+    mapping[1:] = np.random.RandomState(1).permutation(n) + 100
+    out = _device_relabel_fn(lab[100:300], torch.from_numpy(mapping).cuda()).cpu().numpy()
+    assert np.array_equal(out, mapping[L[100:300]])
+
+
+@pytest.mark.parametrize("tissue,ds", [("Nuclei", 1.0), ("Gland", 0.5), ("Lumen", 0.5)])
+def test_sharded_postproc_equals_whole_map(tissue, ds):
+    """SURVEY par.8e: three bands labelled locally (halo, ownership by first pixel, global id offsets) == the whole map labelled
+    on one GPU, up to the id bijection; ids dense and ordered by (band, first pixel)."""
+    from cerberus_amd import shard_postproc as sp
+
+    H, W = 1536, 1024
+    if tissue == "Nuclei":
+        m = synth.nuclei_maps(H, W, 31, 600.0, noise=0.02)
+    else:
+        m = synth.blob_maps(H, W, 33, 60, 10.0, 40.0, rim=4.0, sharp=1.0, noise=0.02, holes=0.3)
+    full = torch.from_numpy(m).cuda()
+    ref, info = postproc_device(full, tissue, ds)
+    n_ref = int(info["n_inst"].item())
+    bands = [full[0:512], full[512:1024], full[1024:1536]]
+    outs, n_total, infos = sp.run_local(bands, tissue, 192, 24, ds)
+    assert all(i["n_truncated"] == 0 and i["n_unresolved"] == 0 for i in infos), infos
+    lab = sp.assemble(outs).cpu().numpy()
+    r = ref.cpu().numpy()
+    n_alive = len(np.unique(r)) - 1  # glands overwritten entirely by a later paste leave no pixels
+    assert n_total == n_alive and n_alive <= n_ref and n_alive > 20
+    assert sorted(np.unique(lab)[1:]) == list(range(1, n_total + 1))
+    assert sp.same_partition(r, lab)
+    cross = (set(np.unique(lab[511])) & set(np.unique(lab[512]))) | (set(np.unique(lab[1023])) & set(np.unique(lab[1024])))
+    assert len(cross - {0}) > 0
+    # first pixels of the ids are increasing: (band, first pixel) order
+    ys, xs = np.nonzero(lab)
+    first = np.full(n_total, lab.size, np.int64)
+    np.minimum.at(first, lab[ys, xs] - 1, ys * W + xs)
+    assert np.all(np.diff(first) > 0)
