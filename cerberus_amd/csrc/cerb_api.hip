@@ -69,29 +69,29 @@ struct HostTensor {
     std::vector<float> data;
 };
 
-extern "C" size_t cerb_conv_guard_bytes(void);
+extern "C" size_t cerb_conv_guard_bytes(int tile_w);
 // Activation buffer with a zero-filled guard band in front of and behind the payload: conv_igemm reads halo tiles with
 // unclamped addresses (row wrap / out-of-image elements are masked later), so every byte it can touch must exist and hold
 // a finite value.  The whole allocation is zeroed once; kernels only ever write payload bytes.
 struct DevBuf {
     float* p = nullptr;  // payload
     char* raw = nullptr;
-    size_t bytes = 0;
-    int ensure(size_t need) {
-        if (need <= bytes) return 0;
+    size_t bytes = 0, guard = 0;
+    int ensure(size_t need, size_t g) {
+        if (need <= bytes && g <= guard) return 0;
         release();
-        const size_t g = cerb_conv_guard_bytes();
         if (hipMalloc(&raw, need + 2 * g) != hipSuccess) return 1;
         if (hipMemset(raw, 0, need + 2 * g) != hipSuccess) return 1;
         p = reinterpret_cast<float*>(raw + g);
         bytes = need;
+        guard = g;
         return 0;
     }
     void release() {
         if (raw) (void)hipFree(raw);
         raw = nullptr;
         p = nullptr;
-        bytes = 0;
+        bytes = guard = 0;
     }
 };
 
@@ -499,20 +499,21 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
     if (out_h > H || out_w > W) return fail("cerb_net_forward: crop larger than tile");
     const int hs[5] = {H, H / 2, H / 4, H / 8, H / 16}, ws[5] = {W, W / 2, W / 4, W / 8, W / 16};
     const size_t D = net->dense_idx.size();
+    const size_t guard = cerb_conv_guard_bytes(W);
     if (!dry) {
-        if (net->x0.ensure((size_t)N * H * W * 64 * 4) || net->pool.ensure((size_t)N * hs[1] * ws[1] * 64 * 4)) return fail("workspace allocation failed");
+        if (net->x0.ensure((size_t)N * H * W * 64 * 4, guard) || net->pool.ensure((size_t)N * hs[1] * ws[1] * 64 * 4, guard)) return fail("workspace allocation failed");
         for (int i = 1; i < 5; ++i)
-            if (net->x[i].ensure((size_t)N * hs[i] * ws[i] * kFilters[i] * 4)) return fail("workspace allocation failed");
-        if (net->ta.ensure((size_t)N * hs[1] * ws[1] * 64 * 4) || net->tb.ensure((size_t)N * hs[1] * ws[1] * 64 * 4) ||
-            net->cm.ensure((size_t)N * hs[4] * ws[4] * 256 * 4))
+            if (net->x[i].ensure((size_t)N * hs[i] * ws[i] * kFilters[i] * 4, guard)) return fail("workspace allocation failed");
+        if (net->ta.ensure((size_t)N * hs[1] * ws[1] * 64 * 4, guard) || net->tb.ensure((size_t)N * hs[1] * ws[1] * 64 * 4, guard) ||
+            net->cm.ensure((size_t)N * hs[4] * ws[4] * 256 * 4, guard))
             return fail("workspace allocation failed");
         if (D) {
             // dmid holds the first conv of a level: sizes (per decoder) 32^2*256, 64^2*128, 128^2*64, 256^2*64 -> max is the last
-            if (net->dmid.ensure(D * (size_t)N * H * W * 64 * 4)) return fail("workspace allocation failed");
-            if (net->conv_algo && net->dsum.ensure(D * (size_t)N * H * W * 64 * 4)) return fail("workspace allocation failed");
+            if (net->dmid.ensure(D * (size_t)N * H * W * 64 * 4, guard)) return fail("workspace allocation failed");
+            if (net->conv_algo && net->dsum.ensure(D * (size_t)N * H * W * 64 * 4, guard)) return fail("workspace allocation failed");
             const int oc[4] = {128, 64, 64, 64};
             for (int u = 0; u < 4; ++u)
-                if (net->dout[u].ensure(D * (size_t)N * hs[3 - u] * ws[3 - u] * oc[u] * 4)) return fail("workspace allocation failed");
+                if (net->dout[u].ensure(D * (size_t)N * hs[3 - u] * ws[3 - u] * oc[u] * 4, guard)) return fail("workspace allocation failed");
         }
     }
     // ---- encoder ----------------------------------------------------------------------------------------------

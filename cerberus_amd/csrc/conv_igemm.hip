@@ -469,9 +469,11 @@ static hipError_t launch_cfg(ConvParams p, hipStream_t st) {
 // Chunk size (channels staged per LDS pass) per kernel family -- also used by the weight packer.
 extern "C" int cerb_conv_chunk(int ks, int stride) { return (stride == 2) ? 16 : 32; }
 
-// Bytes of zero-filled guard band every activation buffer needs in front of and behind its payload: a halo tile may start
-// up to (PAD rows + PAD pixels) before a tensor and end as much after it; 448-wide, 64-channel maps need 116 KB.
-extern "C" size_t cerb_conv_guard_bytes(void) { return 1u << 20; }
+// Bytes of zero-filled guard band every activation buffer needs in front of and behind its payload.  Halo tiles / Winograd
+// patch grids are read with unclamped addresses: up to one row + one pixel before a tensor, and after it up to (tile rows
+// hanging over the last image + 1) rows -- at most 16 for the 16x16 tiles of the deepest level.  The widest row of any level of
+// a tile_w-wide input is tile_w x 64 channels x 4 B (levels 2..4 are tile_w/4 x 128, /8 x 256, /16 x 512 = half of that).
+extern "C" size_t cerb_conv_guard_bytes(int tile_w) { return (size_t)17 * (size_t)tile_w * 64 * 4 + (64u << 10); }
 
 hipError_t cerb_launch_conv(const ConvParams& p, int ks, int stride, int mode, hipStream_t st) {
     const bool small = p.Wo < 32;  // 16x16 tiles for the deepest levels (16^2 / 28^2 maps)

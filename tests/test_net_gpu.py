@@ -221,3 +221,27 @@ def test_dice_vs_reference_golden(golden_dir):
                     assert _dice(p, r) > 0.9995, (k, int(cls))
                     checked += 1
     assert checked >= 6
+
+
+def test_large_odd_tile_guard_band():
+    """One 1040 x 1040 tile (levels 1040/520/260/130/65: partial Winograd / MFMA tiles at every deep level, rows hanging past the
+    last image row) -- exercises the size of the zero guard band around the activation buffers.  Nuclei decoder only."""
+    m, sd, kw = _model(["Nuclei"])
+    tiles = np.random.RandomState(13).randint(0, 256, (1, 1040, 1040, 3)).astype(np.uint8)
+    got = infer_step(torch.from_numpy(tiles), m, 1040, kw["considered_tasks"])
+    ref = net_ref.infer_step(sd, tiles, 1040, kw["considered_tasks"], kw["decoder_kwargs"])
+    for k in ref[0]:
+        a, b = got[0][k], ref[0][k]
+        assert a.shape == b.shape and a.dtype == b.dtype, k
+        if a.dtype == np.float32:
+            assert np.abs(a - b).max() < PROB_TOL, k
+        else:
+            assert (a != b).mean() < 1e-4, k
+    m.set_conv_algo(0)
+    try:
+        direct = infer_step(torch.from_numpy(tiles), m, 1040, kw["considered_tasks"])
+    finally:
+        m.set_conv_algo(1)
+    for k in ref[0]:
+        if ref[0][k].dtype == np.float32:
+            assert np.abs(direct[0][k] - ref[0][k]).max() < PROB_TOL, k
