@@ -234,3 +234,89 @@ extern "C" int cerb_relabel(const int32_t* labels, long long lab_row_stride, con
     SK_CHECK();
     return 0;
 }
+
+// =================================================================================================================
+// cerb_inst_contour_count / cerb_inst_contour_points: outer border of every instance, as the reference extracts it with
+// cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE)[0][0] on the instance's cropped binary mask (loader/postproc.py:29-41).
+// Restated from Suzuki & Abe's border following (CVGIP 30, 1985) with OpenCV's conventions: 8-connected foreground, chain codes
+// 0..7 = E, NE, N, NW, W, SW, S, SE, the trace starts at the instance's first pixel in raster order, looks clockwise from NW for
+// its first neighbour and then always continues counter-clockwise from the direction it came from; CHAIN_APPROX_SIMPLE keeps a
+// point exactly when the chain code changes.  One thread follows one instance (serial by nature; a slide has 10^5..10^6
+// instances); `first` comes from cerb_inst_table column 7.  Two passes: count, (exclusive scan by the caller), write.
+// An instance made of several 8-connected pieces yields the border of the piece holding its first pixel.
+// =================================================================================================================
+template <bool WRITE>
+__global__ void inst_contour_kernel(const int* __restrict__ lab, long long stride, int H, int W, int n_inst, const long long* __restrict__ table,
+                                    int* __restrict__ counts, const long long* __restrict__ offsets, int* __restrict__ points) {
+    const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1}, DY[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_inst; i += gridDim.x * blockDim.x) {
+        const long long* r = table + 16ll * i;
+        const int id = i + 1;
+        int n = 0;
+        int* out = WRITE ? points + 2 * offsets[i] : nullptr;
+        if (r[0] > 0) {
+            const long long first = r[7];
+            const int x0 = (int)(first % W), y0 = (int)(first / W);
+            auto fg = [&](int x, int y) { return x >= 0 && x < W && y >= 0 && y < H && lab[y * stride + x] == id; };
+            auto emit = [&](int x, int y) {
+                if (WRITE) {
+                    out[2 * n] = x;
+                    out[2 * n + 1] = y;
+                }
+                ++n;
+            };
+            int s = 4;
+            const int s_stop = 4;
+            int x1 = 0, y1 = 0;
+            do {
+                s = (s - 1) & 7;
+                x1 = x0 + DX[s];
+                y1 = y0 + DY[s];
+            } while (!fg(x1, y1) && s != s_stop);
+            if (s == s_stop) {
+                emit(x0, y0);  // single-pixel domain
+            } else {
+                int x3 = x0, y3 = y0, px = x0, py = y0, prev_s = s ^ 4;
+                const long long guard = 4ll * (r[0] + 4) + 16;  // a border visits each pixel at most 4 times
+                for (long long it = 0; it < guard; ++it) {
+                    int x4, y4;
+                    do {  // counter-clockwise from the direction just after the one we came from
+                        ++s;
+                        x4 = x3 + DX[s & 7];
+                        y4 = y3 + DY[s & 7];
+                    } while (!fg(x4, y4));
+                    s &= 7;
+                    if (s != prev_s) {
+                        emit(px, py);
+                        prev_s = s;
+                    }
+                    px += DX[s];
+                    py += DY[s];
+                    if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) break;
+                    x3 = x4;
+                    y3 = y4;
+                    s = (s + 4) & 7;
+                }
+            }
+        }
+        if (!WRITE) counts[i] = n;
+    }
+}
+extern "C" int cerb_inst_contour_count(const int32_t* labels, long long lab_row_stride, int h, int w, int n_inst, const long long* table,
+                                       int32_t* counts, void* hip_stream) {
+    if (!labels || !table || !counts || h <= 0 || w <= 0 || n_inst < 0) return cerb_set_error("cerb_inst_contour_count: bad arguments");
+    if (n_inst == 0) return 0;
+    hipLaunchKernelGGL(inst_contour_kernel<false>, dim3((n_inst + 63) / 64), dim3(64), 0, (hipStream_t)hip_stream, labels, lab_row_stride, h, w, n_inst,
+                       table, counts, (const long long*)nullptr, (int*)nullptr);
+    SK_CHECK();
+    return 0;
+}
+extern "C" int cerb_inst_contour_points(const int32_t* labels, long long lab_row_stride, int h, int w, int n_inst, const long long* table,
+                                        const long long* offsets, int32_t* points, void* hip_stream) {
+    if (!labels || !table || !offsets || !points || h <= 0 || w <= 0 || n_inst < 0) return cerb_set_error("cerb_inst_contour_points: bad arguments");
+    if (n_inst == 0) return 0;
+    hipLaunchKernelGGL(inst_contour_kernel<true>, dim3((n_inst + 63) / 64), dim3(64), 0, (hipStream_t)hip_stream, labels, lab_row_stride, h, w, n_inst,
+                       table, (int*)nullptr, offsets, points);
+    SK_CHECK();
+    return 0;
+}

@@ -122,28 +122,53 @@ def inst_table_device(inst_map, type_map=None, n_inst=None):
     return table
 
 
+def inst_contours_device(inst_map, table):
+    """Outer border of every instance (cerb_inst_contour_count / _points: Suzuki-Abe border following with
+    CHAIN_APPROX_SIMPLE, one GPU thread per instance).  inst_map: CUDA int32 (H,W); table: cerb_inst_table output (CUDA).
+    Returns (counts int32 [n] on the host, points int32 [total, 2] (x, y) on the host, offsets int64 [n] on the host)."""
+    n = int(table.shape[0])
+    if n == 0:
+        return np.zeros(0, np.int32), np.zeros((0, 2), np.int32), np.zeros(0, np.int64)
+    L = _lib.lib()
+    h, w = int(inst_map.shape[0]), int(inst_map.shape[1])
+    stream = torch.cuda.current_stream(inst_map.device).cuda_stream
+    counts = torch.empty(n, dtype=torch.int32, device=inst_map.device)
+    with torch.cuda.device(inst_map.device):
+        _lib.check(L.cerb_inst_contour_count(inst_map.data_ptr(), inst_map.stride(0), h, w, n, table.data_ptr(), counts.data_ptr(), C.c_void_p(stream)))
+        incl = torch.cumsum(counts.to(torch.int64), 0)
+        offsets = (incl - counts).contiguous()
+        total = int(incl[-1].item())
+        points = torch.empty((max(total, 1), 2), dtype=torch.int32, device=inst_map.device)
+        _lib.check(L.cerb_inst_contour_points(inst_map.data_ptr(), inst_map.stride(0), h, w, n, table.data_ptr(), offsets.data_ptr(), points.data_ptr(),
+                                              C.c_void_p(stream)))
+    return counts.cpu().numpy(), points[:total].cpu().numpy(), offsets.cpu().numpy()
+
+
 def get_inst_info_dict(inst_map, type_map=None, ds_factor=1.0):
-    """Mirror of the reference's get_inst_info_dict (loader/postproc.py:12-98) without contour tracing:
-    dict id -> {'box': [[rmin,cmin],[rmax,cmax]], 'centroid': [x, y], 'contour': None, 'type', 'type_prob'}.
+    """Mirror of the reference's get_inst_info_dict (loader/postproc.py:12-98):
+    dict id -> {'box': [[rmin,cmin],[rmax,cmax]], 'centroid': [x, y], 'contour': int32 (K,2) of (x, y), 'type', 'type_prob'}.
 
     inst_map / type_map may be CUDA tensors (label map int32, class map uint8) or numpy arrays.  The per-instance sums
-    come from cerb_inst_table on the GPU; only the small table is copied to the host.
-    Reference rule `contour.shape[0] < 3 -> skip` (postproc.py:34-35): with CHAIN_APPROX_SIMPLE a 4-connected instance has
-    fewer than 3 contour points exactly when it is a one-pixel-wide straight run, i.e. its box has height 1 or width 1 --
-    those instances are skipped here too (derived, not pinned against OpenCV: it is not installed in this image)."""
+    (cerb_inst_table) and the border following (cerb_inst_contour_*) run on the GPU; only the table and the compact point
+    list are copied to the host.  Instances whose contour has fewer than 3 points are skipped (postproc.py:34-35).
+    OpenCV is not installed in this image: contours are restated from Suzuki-Abe + OpenCV's conventions, not pinned."""
     from collections import OrderedDict
 
     if isinstance(inst_map, np.ndarray):
         inst_map = torch.from_numpy(np.ascontiguousarray(inst_map).astype(np.int32)).cuda()
     if type_map is not None and isinstance(type_map, np.ndarray):
         type_map = torch.from_numpy(np.ascontiguousarray(type_map).astype(np.uint8)).cuda()
-    tab = inst_table_device(inst_map.contiguous(), None if type_map is None else type_map.contiguous()).cpu().numpy()
+    inst_map = inst_map.contiguous()
+    tab_dev = inst_table_device(inst_map, None if type_map is None else type_map.contiguous())
+    cnts, pts, offs = inst_contours_device(inst_map, tab_dev)
+    tab = tab_dev.cpu().numpy()
     info = OrderedDict()
     for i in range(tab.shape[0]):
         area, sx, sy, y1, y2, x1, x2 = [int(v) for v in tab[i, :7]]
-        if area == 0 or (y2 - y1) < 2 or (x2 - x1) < 2:
+        if area == 0 or cnts[i] < 3:
             continue
-        d = {"box": np.array([[y1, x1], [y2, x2]]), "centroid": np.array([sx / area, sy / area]), "contour": None}
+        d = {"box": np.array([[y1, x1], [y2, x2]]), "centroid": np.array([sx / area, sy / area]),
+             "contour": pts[offs[i]: offs[i] + cnts[i]].copy()}
         if type_map is not None:
             cnt = tab[i, 8:16]
             order = sorted(range(8), key=lambda k: (-int(cnt[k]), k))  # dominant class first
@@ -158,4 +183,5 @@ def get_inst_info_dict(inst_map, type_map=None, ds_factor=1.0):
         for k, d in info.items():
             d["box"] = np.round(d["box"] / ds_factor).astype("int")
             d["centroid"] = np.round(d["centroid"] / ds_factor).astype("int")
+            d["contour"] = np.round(d["contour"] / ds_factor).astype("int")
     return info

@@ -181,3 +181,35 @@ class WSIRunner(object):
         if "Lumen" in inst and "Gland" in inst:
             mask_lumen_by_gland(inst["Lumen"], inst["Gland"])
         return inst, info
+
+
+def build_wsi_inst_info(inst, canv, slide_hw, proc_mag, ds_factor=0.5):
+    """The dictionary the reference dumps as dat/<slide>.dat (infer/wsi.py:805-853): per tissue {uuid4 hex -> {'box':
+    [x1, y1, x2, y2], 'centroid', 'contour', 'type', 'type_prob'}} plus resolution metadata.  Gland / lumen label maps are
+    at x`ds_factor` and their coordinates are scaled back (get_inst_info_dict(..., ds_factor)); nuclei are at full
+    resolution.  Per-instance reductions and border following run on the GPU (cerb_inst_table / cerb_inst_contour_*).
+    Deviation: the class map handed to the half-resolution tissues is the strided sub-sample of the uint8 class canvas; the
+    reference bilinearly resizes class ids together with the probabilities (cv2.resize, infer/wsi.py:786-788)."""
+    import uuid
+
+    from .postproc import get_inst_info_dict
+
+    out = OrderedDict()
+    for tissue, lab in inst.items():
+        tkey = tissue + "-TYPE"
+        half = tuple(lab.shape) != tuple(int(v) for v in slide_hw)
+        tmap = canv.get(tkey)
+        if tmap is not None and half:
+            tmap = tmap[::2, ::2][: lab.shape[0], : lab.shape[1]].contiguous()
+        info = get_inst_info_dict(lab.contiguous(), tmap, ds_factor if half else 1.0)
+        d = OrderedDict()
+        for _, v in info.items():
+            b = v["box"]
+            v["box"] = np.array([b[0][1], b[0][0], b[1][1], b[1][0]])
+            d[uuid.uuid4().hex] = v
+        out[tissue] = d
+    out["proc_resolution"] = {"resolution": float(proc_mag), "units": "mpp"}
+    out["base_resolution"] = {"resolution": float(proc_mag), "units": "mpp"}  # arrays / synthetic slides carry no pyramid
+    out["proc_dimensions"] = np.array([int(slide_hw[0]), int(slide_hw[1])])  # YX
+    out["base_dimensions"] = np.array([int(slide_hw[0]), int(slide_hw[1])])
+    return out

@@ -132,6 +132,17 @@ int cerb_downsample2_inst(const float* src, long long row_stride, int pix_stride
 int cerb_inst_table(const int32_t* labels, long long lab_row_stride, const uint8_t* type_map, long long type_row_stride,
                     int h, int w, int n_inst, long long* table, void* hip_stream);
 
+/* Outer border of every instance = cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE)[0][0] of loader/postproc.py:29-41
+ * (Suzuki-Abe border following, 8-connected foreground, start at the instance's first pixel -- `table` is cerb_inst_table's
+ * output -- first move downwards/counter-clockwise, a point is kept where the chain code changes).  Two passes:
+ *   cerb_inst_contour_count  -> counts[i]  = number of points of instance i+1 (0 for absent ids)
+ *   cerb_inst_contour_points -> points[2*(offsets[i] + k)] = x, [.. + 1] = y of point k; offsets = exclusive scan of counts (int64).
+ * OpenCV is not installed in this image: restated from the published algorithm, not pinned against the library. */
+int cerb_inst_contour_count(const int32_t* labels, long long lab_row_stride, int h, int w, int n_inst, const long long* table,
+                            int32_t* counts, void* hip_stream);
+int cerb_inst_contour_points(const int32_t* labels, long long lab_row_stride, int h, int w, int n_inst, const long long* table,
+                             const long long* offsets, int32_t* points, void* hip_stream);
+
 /* out[y][x] = map[labels[y][x]] with map[0] == 0; ids outside [0, n_map) become 0.  Turns band-local instance ids into
  * slide-global ones after the count exchange of the sharded post-processing (the reference only needs ids to be unique:
  * uuid4 at infer/wsi.py:265,831). */

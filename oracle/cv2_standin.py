@@ -55,3 +55,62 @@ def dilate(src, kernel, iterations=1):
 def erode(src, kernel, iterations=1):
     assert iterations == 1
     return _morph(src, kernel, False)
+
+
+# ---- findContours (outer border of the first returned contour only) -----------------------------------------------------
+# TEST INFRASTRUCTURE.  Restatement of what loader/postproc.py:29-41 consumes: cv2.findContours(mask, RETR_TREE,
+# CHAIN_APPROX_SIMPLE)[0][0].  OpenCV (pinned opencv-python 4.6.0.66, environment.yml:31) is absent from this image, so this
+# follows Suzuki & Abe, "Topological structural analysis of digitized binary images by border following" (CVGIP 1985),
+# with OpenCV's documented conventions: 8-connected foreground; Freeman codes 0..7 = E, NE, N, NW, W, SW, S, SE (y down);
+# raster scan finds outer-border start pixels; top-level contours are returned most-recently-found first, so [0][0] is the
+# outer border of the component whose start pixel comes LAST in raster order; CHAIN_APPROX_SIMPLE keeps the points at which
+# the chain code changes.  PARITY UNPINNED against the real library.
+RETR_TREE, CHAIN_APPROX_SIMPLE, CHAIN_APPROX_NONE = 3, 2, 1
+_CODE = [(1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1), (0, 1), (1, 1)]  # (dx, dy)
+
+
+def _trace_outer(mask, x0, y0, method):
+    h, w = mask.shape
+
+    def fg(x, y):
+        return 0 <= x < w and 0 <= y < h and mask[y, x] != 0
+
+    pts = []
+    s = 4
+    while True:  # clockwise from NW for the first neighbour
+        s = (s - 1) & 7
+        x1, y1 = x0 + _CODE[s][0], y0 + _CODE[s][1]
+        if fg(x1, y1) or s == 4:
+            break
+    if s == 4 and not fg(x1, y1):
+        return [(x0, y0)]
+    x3, y3, px, py, prev = x0, y0, x0, y0, s ^ 4
+    while True:
+        while True:  # counter-clockwise, starting right after the direction we arrived from
+            s += 1
+            x4, y4 = x3 + _CODE[s & 7][0], y3 + _CODE[s & 7][1]
+            if fg(x4, y4):
+                break
+        s &= 7
+        if s != prev or method == CHAIN_APPROX_NONE:
+            pts.append((px, py))
+            prev = s
+        px, py = px + _CODE[s][0], py + _CODE[s][1]
+        if (x4, y4) == (x0, y0) and (x3, y3) == (x1, y1):
+            return pts
+        x3, y3 = x4, y4
+        s = (s + 4) & 7
+
+
+def findContours(mask, mode=RETR_TREE, method=CHAIN_APPROX_SIMPLE):
+    """Returns ([first_contour], None) with first_contour int32 (K, 1, 2) of (x, y) -- only element [0][0] is reproduced."""
+    from scipy import ndimage
+
+    mask = np.asarray(mask)
+    lab, n = ndimage.label(mask != 0, structure=np.ones((3, 3), int))
+    if n == 0:
+        return [], None
+    starts = ndimage.minimum(np.arange(mask.size).reshape(mask.shape), lab, index=np.arange(1, n + 1))
+    last = int(np.max(starts))
+    pts = _trace_outer(mask, last % mask.shape[1], last // mask.shape[1], method)
+    return [np.array(pts, dtype=np.int32).reshape(-1, 1, 2)], None

@@ -108,11 +108,14 @@ class PostProcInstErodedContourMap(object):
 
 
 def inst_info_ref(inst_map, type_map=None):
-    """ORACLE restatement of get_inst_info_dict (loader/postproc.py:12-75) WITHOUT its OpenCV parts: box from
-    get_bounding_box (misc/utils.py:82-91), centroid = cv2.moments m10/m00, m01/m00 of the cropped binary mask (= mean x, mean
-    y), majority type vote incl. the 'skip background if a second class exists' rule.  cv2.findContours is absent in this
-    image, so the contour and the `< 3 contour points -> skip` filter are not restated (parity unpinned for them)."""
+    """ORACLE restatement of get_inst_info_dict (loader/postproc.py:12-75): box from get_bounding_box (misc/utils.py:82-91),
+    centroid = cv2.moments m10/m00, m01/m00 of the cropped binary mask (= mean x, mean y), contour =
+    findContours(crop, RETR_TREE, CHAIN_APPROX_SIMPLE)[0][0] shifted by the box origin with the `< 3 points -> skip` filter
+    (postproc.py:26-41; OpenCV is absent here, so findContours is oracle/cv2_standin.py's Suzuki-Abe restatement -- parity
+    unpinned for it), majority type vote incl. the 'skip background if a second class exists' rule."""
     from collections import OrderedDict
+
+    from . import cv2_standin as cv2
 
     info = OrderedDict()
     for inst_id in np.unique(inst_map)[1:]:
@@ -123,7 +126,13 @@ def inst_info_ref(inst_map, type_map=None):
         rmax += 1
         cmax += 1
         ys, xs = np.nonzero(m)
-        d = {"box": np.array([[rmin, cmin], [rmax, cmax]]), "centroid": np.array([xs.mean(), ys.mean()])}
+        crop = m[rmin:rmax, cmin:cmax].astype(np.uint8)
+        contour = np.squeeze(cv2.findContours(crop, cv2.RETR_TREE, cv2.CHAIN_APPROX_SIMPLE)[0][0].astype("int32"))
+        if contour.shape[0] < 3 or len(contour.shape) != 2:
+            continue
+        contour[:, 0] += cmin
+        contour[:, 1] += rmin
+        d = {"box": np.array([[rmin, cmin], [rmax, cmax]]), "centroid": np.array([xs.mean(), ys.mean()]), "contour": contour}
         if type_map is not None:
             t = type_map[m]
             tl, tc = np.unique(t, return_counts=True)

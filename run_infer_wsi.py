@@ -117,7 +117,17 @@ if __name__ == "__main__":
         if rank == 0:
             np.savez_compressed("%s/%s.npz" % (args["--output_dir"], base), **{k: v.cpu().numpy() for k, v in inst.items()},
                                 **{"type_" + k: v.cpu().numpy() for k, v in full.items() if k.endswith("TYPE")}, pclass=full.get("Patch-Class").cpu().numpy()[::4, ::4])
-            print("%s: Inference Time: %.3f  Post Proc Time: %.3f  (%.1f Mpx/s inference)" % (base, t1 - t0, t2 - t1, H * W / (t1 - t0) / 1e6))
+            # instance dictionary in the reference's wire format (joblib, infer/wsi.py:844-853)
+            import joblib
+
+            from cerberus_amd.wsi import build_wsi_inst_info
+
+            os.makedirs("%s/dat" % args["--output_dir"], exist_ok=True)
+            wsi_info = build_wsi_inst_info(inst, full, (H, W), float(args["--wsi_proc_mag"]))
+            joblib.dump(wsi_info, "%s/dat/%s.dat" % (args["--output_dir"], base))
+            t3 = time.perf_counter()
+            print("%s: Inference Time: %.3f  Post Proc Time: %.3f  Instance Table Time: %.3f  (%.1f Mpx/s inference)" % (
+                base, t1 - t0, t2 - t1, t3 - t2, H * W / (t1 - t0) / 1e6))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

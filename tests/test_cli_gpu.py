@@ -48,3 +48,11 @@ def test_run_infer_wsi_cli_synthetic(tmp_path):
     z = np.load(str(out / "s1.npz"))
     assert z["Nuclei"].shape == (700, 900) and z["Gland"].shape == (350, 450) and z["Lumen"].shape == (350, 450)
     assert z["type_Nuclei-TYPE"].dtype == np.uint8
+    import joblib
+
+    dat = joblib.load(str(out / "dat" / "s1.dat"))
+    assert set(dat.keys()) >= {"Nuclei", "Gland", "Lumen", "proc_resolution", "base_resolution", "proc_dimensions", "base_dimensions"}
+    assert list(dat["proc_dimensions"]) == [700, 900] and dat["proc_resolution"]["units"] == "mpp"
+    for t in ("Nuclei", "Gland", "Lumen"):
+        for uid, d in dat[t].items():
+            assert len(uid) == 32 and d["box"].shape == (4,) and d["contour"].ndim == 2 and d["contour"].shape[1] == 2 and (("type" in d) == (t != "Lumen"))
