@@ -71,8 +71,29 @@ struct Item {
 };
 }  // namespace
 
+#ifdef WPROF
+// developer instrumentation (scripts/dev_wprof.sh): cycles per phase, summed over wave 0 of every workgroup
+__device__ unsigned long long g_wprof[8];
+extern "C" int cerb_dev_wprof(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wprof), sizeof(g_wprof)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_wprof), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#define WPROF_T() (__builtin_readcyclecounter())
+#define WPROF_ACC(k, t0) prof_acc[k] += WPROF_T() - (t0)
+#else
+#define WPROF_T() 0ull
+#define WPROF_ACC(k, t0) ((void)(t0))
+#endif
+
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef WPROF
+    const unsigned long long t_kernel = WPROF_T();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int a = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's row of the transformed patch (scalar)
@@ -128,7 +149,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
     auto w_base = [&](const Item& w) {  // this wave's slice of the item's weight stream
         return reinterpret_cast<const char*>(p.wpack + w.g * p.w_gs) + (long long)w.cb * nchunk * CHUNK_W_BYTES + a * WAVE_W_BYTES;
     };
-    auto touches_border = [&](const Item& w) { return w.oy0 < 1 || w.ox0 < 1 || w.oy0 + OTH + 1 > p.H || w.ox0 + OTW + 1 > p.W; };
+    // An item that hangs over the image (H % 8 or W % 16 != 0: only the small odd maps) takes the generic path: per-pixel mask and
+    // transform at the chunk boundary.  Every other item is masked by edge: the zero padding is exactly patch row 0 of the top
+    // tile row, patch row 3 of the bottom tile row, patch column 0 / 3 of the left / right tile column.
+    auto hangs_over = [&](const Item& w) { return w.oy0 + OTH > p.H || w.ox0 + OTW > p.W; };
+    auto edge_bits = [&](const Item& w) {  // 1 top, 2 bottom, 4 left, 8 right
+        return (w.oy0 == 0 ? 1 : 0) | (w.oy0 + OTH == p.H ? 2 : 0) | (w.ox0 == 0 ? 4 : 0) | (w.ox0 + OTW == p.W ? 8 : 0);
+    };
 
     // ---- lane invariants -----------------------------------------------------------------------------------------------------
     // input transform: thread = (tile t, channel quad c)
@@ -152,6 +179,26 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
 
     f32x4 d[4][4];  // raw patch of the NEXT chunk while the matrix pipe works, transformed in place at the chunk boundary
     auto issue = [&](__amdgpu_buffer_rsrc_t r, int chunk_off, int k) { d[k >> 2][k & 3] = buf_load(r, ioff, chunk_off + (k >> 2) * rowb + (k & 3) * pixb); };
+    const bool lane_top = (tty == 0), lane_bot = (tty == WTY - 1), lane_left = (ttx == 0), lane_right = (ttx == WTX - 1);
+    auto mask_edges = [&](int bits) {  // 48 v_cndmask at most, none for interior items
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (bits & 3) {
+            const bool zt = (bits & 1) && lane_top, zb = (bits & 2) && lane_bot;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                d[0][q] = zt ? z : d[0][q];
+                d[3][q] = zb ? z : d[3][q];
+            }
+        }
+        if (bits & 12) {
+            const bool zl = (bits & 4) && lane_left, zr = (bits & 8) && lane_right;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                d[r][0] = zl ? z : d[r][0];
+                d[r][3] = zr ? z : d[r][3];
+            }
+        }
+    };
     auto mask_border = [&](const Item& w) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -191,14 +238,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) issue(r0, 0, k);
     }
-    if (!touches_border(w)) {
+    if (!hangs_over(w)) {
+        mask_edges(edge_bits(w));
         transform_rows(0);
         transform_rows(2);
         transform_cols(0);
         transform_cols(2);
     }
     __amdgpu_buffer_rsrc_t rw = make_rsrc(w_base(w));
-    f32x4 wq[WD + 1][2];
+    // weight stream window: the operands of step q live in slot q & 3 (three slots are live at a time; four names so that the
+    // slot of a step is the same in every chunk -- 16 steps per chunk -- and the unrolled body needs no register moves)
+    f32x4 wq[4][2];
 #pragma unroll
     for (int dd = 0; dd < WD; ++dd)
 #pragma unroll
@@ -225,12 +275,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
     };
     load_bias(w);
 
+#ifdef WPROF
+    unsigned long long prof_acc[4] = {0, 0, 0, 0};
+    const unsigned long long t_first = WPROF_T();
+#endif
     for (;;) {
         f32x16 acc[4][2];
         const bool more_items = item + 1 < item_end;
         const Item wnx = more_items ? advance(w) : w;
         const __amdgpu_buffer_rsrc_t rw_nx = more_items ? make_rsrc(w_base(wnx)) : rw;
-        const bool mask_cur = touches_border(w), mask_next = touches_border(wnx);
+        const bool mask_cur = hangs_over(w), mask_next = hangs_over(wnx);
+        const int edge_next = edge_bits(wnx), edge_cur = edge_bits(w);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -240,79 +295,85 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
 
         auto chunk = [&](auto first_tag, int ch) {
             constexpr bool FIRST = decltype(first_tag)::value;
-            if (mask_cur) {  // border item: zero the out-of-image pixels of the raw patch, then transform
+            const unsigned long long t_x = WPROF_T();
+            if (mask_cur) {  // item hanging over the image: per-pixel mask of the raw patch, then transform
                 mask_border(w);
                 transform_rows(0);
                 transform_rows(2);
                 transform_cols(0);
                 transform_cols(2);
             }
+            WPROF_ACC(3, t_x);
+            const unsigned long long t_b = WPROF_T();
             __syncthreads();  // every wave finished reading the previous chunk's V (or the previous item's T exchange)
             write_v();
             __syncthreads();
+            WPROF_ACC(0, t_b);
+            const unsigned long long t_m = WPROF_T();
 
             const bool last_ch = (ch == nchunk - 1);
             const Item wp_ = last_ch ? wnx : w;
             const bool mask_nx = last_ch ? mask_next : mask_cur;
+            const int edge_nx = last_ch ? edge_next : edge_cur;
             const __amdgpu_buffer_rsrc_t r_stage = make_rsrc(in_base(wp_));
             const int stage_off = (last_ch ? 0 : ch + 1) * (CB * 4);
             const int wcur_off = ch * CHUNK_W_BYTES;
             const __amdgpu_buffer_rsrc_t rw_over = last_ch ? rw_nx : rw;
             const int wover_off = last_ch ? 0 : (ch + 1) * CHUNK_W_BYTES;
 
-            f32x4 bq = *reinterpret_cast<const f32x4*>(lds + vr), bn = bq;
+            f32x4 bb[2];  // B operand of step q in bb[q & 1]
+            bb[0] = *reinterpret_cast<const f32x4*>(lds + vr);
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
 #pragma unroll
                 for (int G = 0; G < 4; ++G) {
                     const int q = b * 4 + G;
                     if (FIRST && q < NPRE) {
-                        wq[WD][0] = wpre[q][0];
-                        wq[WD][1] = wpre[q][1];
+                        // steps WD .. WD+NPRE-1 of an item's first chunk were requested before the previous item's stores (wpre)
                     } else if (q + WD < NQ) {
-                        wq[WD][0] = buf_load(rw, wlane, wcur_off + ((q + WD) * 2 + 0) * 1024);
-                        wq[WD][1] = buf_load(rw, wlane, wcur_off + ((q + WD) * 2 + 1) * 1024);
+                        wq[(q + WD) & 3][0] = buf_load(rw, wlane, wcur_off + ((q + WD) * 2 + 0) * 1024);
+                        wq[(q + WD) & 3][1] = buf_load(rw, wlane, wcur_off + ((q + WD) * 2 + 1) * 1024);
                     } else {
-                        wq[WD][0] = buf_load(rw_over, wlane, wover_off + ((q + WD - NQ) * 2 + 0) * 1024);
-                        wq[WD][1] = buf_load(rw_over, wlane, wover_off + ((q + WD - NQ) * 2 + 1) * 1024);
+                        wq[(q + WD) & 3][0] = buf_load(rw_over, wlane, wover_off + ((q + WD - NQ) * 2 + 0) * 1024);
+                        wq[(q + WD) & 3][1] = buf_load(rw_over, wlane, wover_off + ((q + WD - NQ) * 2 + 1) * 1024);
                     }
-                    if (q + 1 < NQ) bn = *reinterpret_cast<const f32x4*>(lds + vr + ((q + 1) >> 2) * NT * PS + ((q + 1) & 3) * 8);
+                    if (q + 1 < NQ) bb[(q + 1) & 1] = *reinterpret_cast<const f32x4*>(lds + vr + ((q + 1) >> 2) * NT * PS + ((q + 1) & 3) * 8);
                     if (q < 8) {  // next chunk's patch: two loads per step, all in flight half a chunk before the transform
                         issue(r_stage, stage_off, 2 * q);
                         issue(r_stage, stage_off, 2 * q + 1);
                     }
                     // the next chunk's patch landed (requested in steps 0..7): B^T d B runs here, in the shadow of the matrix pipe,
                     // so that the chunk boundary is only barrier - 16 LDS writes - barrier
-                    // (border items keep the raw patch: they are masked and transformed at the boundary instead)
+                    // (items hanging over the image keep the raw patch: they are masked and transformed at the boundary instead)
                     if (!mask_nx) {
+                        if (q == 11 && edge_nx) mask_edges(edge_nx);
                         if (q == 12 || q == 13) transform_rows((q - 12) * 2);
                         if (q == 14 || q == 15) transform_cols((q - 14) * 2);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    const bool pre = FIRST && q >= WD && q < WD + NPRE;  // compile-time after unrolling
+                    const f32x4 a0 = pre ? wpre[pre ? q - WD : 0][0] : wq[q & 3][0], a1 = pre ? wpre[pre ? q - WD : 0][1] : wq[q & 3][1];
+                    const f32x4 bq = bb[q & 1];
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) {
                         if (FIRST && G == 0 && tt == 0 && b != 1) {
                             const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                            acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0][0][tt], bq[tt], z, 0, 0, 0);
-                            acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0][1][tt], bq[tt], z, 0, 0, 0);
+                            acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[tt], bq[tt], z, 0, 0, 0);
+                            acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[tt], bq[tt], z, 0, 0, 0);
                         } else {
-                            acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0][0][tt], bq[tt], acc[b][0], 0, 0, 0);
-                            acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0][1][tt], bq[tt], acc[b][1], 0, 0, 0);
+                            acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[tt], bq[tt], acc[b][0], 0, 0, 0);
+                            acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[tt], bq[tt], acc[b][1], 0, 0, 0);
                         }
                     }
-#pragma unroll
-                    for (int dd = 0; dd < WD; ++dd) {
-                        wq[dd][0] = wq[dd + 1][0];
-                        wq[dd][1] = wq[dd + 1][1];
-                    }
-                    bq = bn;
                 }
             }
+            WPROF_ACC(1, t_m);
         };
         chunk(std::true_type{}, 0);
         for (int ch = 1; ch < nchunk; ++ch) chunk(std::false_type{}, ch);
 
         // ---- output transform ---------------------------------------------------------------------------------------------------
+        const unsigned long long t_e = WPROF_T();
         {
             // over b, in registers: T[0] = M0 + M1 + M2, T[1] = M1 - M2 - M3
 #pragma unroll
@@ -337,12 +398,20 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
             load_bias(wnx);
             __syncthreads();
             const long long origin = (((long long)w.n * p.Ho + w.oy0) * p.Wo + w.ox0) * p.Cout + w.cb * 64;  // floats, uniform
-            const __amdgpu_buffer_rsrc_t r_out = make_rsrc(p.out + w.g * p.out_gs + origin);
-            const __amdgpu_buffer_rsrc_t r_res = make_rsrc(p.resid ? p.resid + w.g * p.resid_gs + origin : p.out);
-            const bool has_res = p.resid != nullptr;
+            // Branch-free output stage: every lane issues every load / store.  hipcc's s_waitcnt insertion merges control-flow
+            // paths conservatively, so a store inside a branch makes every later wait on an OLDER load a vmcnt(0) -- i.e. a wait for
+            // the stores.  Pixels outside the image get an offset past the descriptor's range instead (the hardware drops
+            // out-of-range buffer stores and returns 0 for out-of-range loads); a missing residual is a zero-length descriptor.
+            const unsigned span = (unsigned)(OTH * p.Wo * p.Cout * 4);  // bytes from the item origin to past its last row
+            const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + w.g * p.out_gs + origin, 0, span, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_res =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid ? p.resid + w.g * p.resid_gs + origin : p.out), 0, p.resid ? span : 0, 0x00020000);
             const bool partial = (w.oy0 + OTH > p.Ho) || (w.ox0 + OTW > p.Wo);
             const bool col_ok = !partial || (w.ox0 + pp < p.Wo);
+            const int rows_ok = partial ? p.Ho - w.oy0 : OTH;  // uniform: output rows of this item inside the image
+            const unsigned ocol = col_ok ? ooff : 0x80000000u;
             const int orow = p.Wo * p.Cout * 4;
+            const float floor_ = p.relu ? 0.f : -3.402823466e38f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {  // tile row k -> output rows 2k, 2k+1
                 f32x4 tq[4];
@@ -353,24 +422,33 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
                 y[1] = tq[1] - tq[2] - tq[3];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    if (partial && !(col_ok && w.oy0 + 2 * k + i < p.Ho)) continue;
-                    f32x4 o = y[i];
-                    if (has_res) o = add4(o, buf_load(r_res, ooff, (2 * k + i) * orow));
-                    if (p.relu) {
-                        o[0] = fmaxf(o[0], 0.f);
-                        o[1] = fmaxf(o[1], 0.f);
-                        o[2] = fmaxf(o[2], 0.f);
-                        o[3] = fmaxf(o[3], 0.f);
-                    }
-                    buf_store(o, r_out, ooff, (2 * k + i) * orow);
+                    const unsigned vo = (2 * k + i < rows_ok) ? ocol : 0x80000000u;  // scalar compare + one v_cndmask (or none)
+                    f32x4 o = add4(y[i], buf_load(r_res, vo, (2 * k + i) * orow));
+                    o[0] = fmaxf(o[0], floor_);
+                    o[1] = fmaxf(o[1], floor_);
+                    o[2] = fmaxf(o[2], floor_);
+                    o[3] = fmaxf(o[3], floor_);
+                    buf_store(o, r_out, vo, (2 * k + i) * orow);
                 }
             }
         }
+        WPROF_ACC(2, t_e);
         if (!more_items) break;
         ++item;
         w = wnx;
         rw = rw_nx;
     }
+#ifdef WPROF
+    if (tid == 0) {
+        atomicAdd(&g_wprof[0], prof_acc[0]);
+        atomicAdd(&g_wprof[1], prof_acc[1]);
+        atomicAdd(&g_wprof[2], prof_acc[2]);
+        atomicAdd(&g_wprof[5], prof_acc[3]);
+        atomicAdd(&g_wprof[6], t_first - t_kernel);
+        atomicAdd(&g_wprof[3], WPROF_T() - t_kernel);
+        atomicAdd(&g_wprof[4], 1ull);
+    }
+#endif
 }
 
 // Host-side launcher (called from cerb_api.hip).  p.wpack must hold the Winograd-packed weights (pack_wino).
