@@ -358,10 +358,17 @@ __global__ __launch_bounds__(256) void patch_class_kernel(PatchClassParams p) {
     const int n = blockIdx.x, tid = threadIdx.x;
     int y0 = 0, x0 = 0, ch = p.Hf, cw = p.Wf;
     if (p.Hf != 9 && p.Wf != 9) {  // net_desc.py:173-174 (crops only when both differ from 9)
-        y0 = (int)((p.Hf - 9) * 0.5);
-        x0 = (int)((p.Wf - 9) * 0.5);
-        ch = 9;
-        cw = 9;
+        // cropping_center (models/utils/misc_utils.py:22-24) is the Python slice x[h0 : h0 + 9] with h0 = int((H - 9) * 0.5): for maps
+        // smaller than 9 the start is NEGATIVE and counts from the end (H = 6 -> rows [5, 6)), and the stop is clipped to H
+        auto py_slice = [](int len, int& start, int& count) {
+            const int h0 = (int)((len - 9) * 0.5);
+            const int a0 = h0 < 0 ? max(len + h0, 0) : min(h0, len);
+            const int a1 = min(h0 + 9, len);
+            start = a0;
+            count = max(a1 - a0, 0);
+        };
+        py_slice(p.Hf, y0, ch);
+        py_slice(p.Wf, x0, cw);
     }
     const float* x = p.x4 + (long long)n * p.Hf * p.Wf * 512;
     for (int c = tid; c < 512; c += 256) {

@@ -245,3 +245,25 @@ def test_large_odd_tile_guard_band():
     for k in ref[0]:
         if ref[0][k].dtype == np.float32:
             assert np.abs(direct[0][k] - ref[0][k]).max() < PROB_TOL, k
+
+
+@pytest.mark.parametrize("hw", [(96, 256), (64, 64), (128, 112)])
+def test_small_feature_maps_patch_class_crop(full_model, hw):
+    """Bottom feature maps smaller than 9 x 9: cropping_center's Python slice starts at a NEGATIVE index (misc_utils.py:22-24), e.g.
+    a 6-row map keeps only its last row.  All heads, logits and wrapper outputs."""
+    m, sd, kw = full_model
+    tiles = np.random.RandomState(hw[0]).randint(0, 256, (2,) + hw + (3,)).astype(np.uint8)
+    got = infer_step(torch.from_numpy(tiles), m, list(hw), kw["considered_tasks"])
+    ref = net_ref.infer_step(sd, tiles, list(hw), kw["considered_tasks"], kw["decoder_kwargs"])
+    for i in range(2):
+        for k in ref[i]:
+            a, b = got[i][k], ref[i][k]
+            assert a.shape == b.shape and a.dtype == b.dtype, k
+            if a.dtype == np.float32:
+                assert np.abs(a - b).max() < PROB_TOL, k
+            else:
+                assert (a != b).mean() < 1e-4, k
+    x = torch.from_numpy(tiles).float().permute(0, 3, 1, 2).contiguous()
+    lg = m(x.cuda())["Patch-Class"].cpu()
+    rl = net_ref.net_forward(sd, x, kw["decoder_kwargs"], kw["considered_tasks"])["Patch-Class"]
+    assert (lg - rl).abs().max().item() < 2e-4
