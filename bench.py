@@ -156,7 +156,8 @@ def main():
     # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # separate runs of this same command; gfx950 read-side x2 correction applied by scripts/rocprof_summary.py)
     traffic = None
-    sym = {"conv_wino<f2x2,8x16>": "conv_wino_kernel(ConvParams)",
+    sym = {"conv_wino<f2x2,8x16>": "void conv_wino_kernel<false>(ConvParams)",
+           "conv_wino<f2x2,8x16,res>": "void conv_wino_kernel<true>(ConvParams)",
            "conv_igemm<ks3,s1,mode0,8x32>": "void conv_igemm_kernel<3, 1, 8, 32, 32, 0>(ConvParams)",
            "conv_igemm<ks3,s1,mode1,8x32>": "void conv_igemm_kernel<3, 1, 8, 32, 32, 1>(ConvParams)"}.get(dom_name)
     pmc_path = os.path.join(ROOT, "profiles", "r01_bench_pmc_hbm.json")

@@ -478,7 +478,7 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
     if (net->conv_algo && c.wino && mode == 0) {
         p.wpack = c.wino;
         p.w_gs = (long long)c.cout * c.cin * 16;
-        if (prof_begin(net, name, "conv_wino<f2x2,8x16>", fl, st)) return 1;
+        if (prof_begin(net, name, resid ? "conv_wino<f2x2,8x16,res>" : "conv_wino<f2x2,8x16>", fl, st)) return 1;
         HIP_OK(cerb_launch_wino(p, st));
         if (prof_end(net, st)) return 1;
         return 0;

@@ -51,19 +51,11 @@ __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, unsigned vof
 }
 __device__ __forceinline__ void buf_store(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, soff, 0);
-}
-
-// Plain (unpacked) fp32 adds.  hipcc turns float4 additions into v_pk_add_f32, which costs the fp32 matrix pipe far more
-// issue time than two v_add_f32 when it runs beside MFMAs (MI355X_MICROARCH.md, per-instruction constants); subtractions
-// already compile to v_sub_f32.  The asm is not volatile, so the scheduler still places it freely.
-__device__ __forceinline__ float fadd(float x, float y) {
-    float r;
-    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-}
-__device__ __forceinline__ f32x4 add4(f32x4 x, f32x4 y) {
-    f32x4 r = {fadd(x[0], y[0]), fadd(x[1], y[1]), fadd(x[2], y[2]), fadd(x[3], y[3])};
-    return r;
+    // gfx950 hazard hipcc (ROCm 7.2) does not pad: buffer_store_dwordx4 whose soffset is an SGPR, followed directly by a VALU
+    // write of its data VGPRs, stores corrupted data (the compiler only inserts wait states for the immediate-soffset form).
+    // Found as run-to-run differing outputs; two wait states pinned behind the store cure it (scripts/dev_wrace.sh).
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 struct Item {
@@ -89,6 +81,7 @@ extern "C" int cerb_dev_wprof(unsigned long long* out, int reset) {
 #define WPROF_ACC(k, t0) ((void)(t0))
 #endif
 
+template <bool HAS_RES>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef WPROF
@@ -215,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
         x0 = x0 - x2;
         x3 = x1 - x3;
         const f32x4 o1 = x1;
-        x1 = add4(x1, x2);
+        x1 = x1 + x2;
         x2 = x2 - o1;
     };
     auto transform_rows = [&](int r0) {  // rows r0, r0+1 of d <- d B
@@ -378,9 +371,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
             // over b, in registers: T[0] = M0 + M1 + M2, T[1] = M1 - M2 - M3
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                f32x16 T0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) T0[r] = fadd(fadd(acc[0][s][r], acc[1][s][r]), acc[2][s][r]);
+                const f32x16 T0 = acc[0][s] + acc[1][s] + acc[2][s];
                 const f32x16 T1 = acc[1][s] - acc[2][s] - acc[3][s];
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
@@ -396,34 +387,41 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) wpre[dd][s] = buf_load(rw_nx, wlane, ((WD + dd) * 2 + s) * 1024);
             load_bias(wnx);
-            __syncthreads();
             const long long origin = (((long long)w.n * p.Ho + w.oy0) * p.Wo + w.ox0) * p.Cout + w.cb * 64;  // floats, uniform
             // Branch-free output stage: every lane issues every load / store.  hipcc's s_waitcnt insertion merges control-flow
             // paths conservatively, so a store inside a branch makes every later wait on an OLDER load a vmcnt(0) -- i.e. a wait for
             // the stores.  Pixels outside the image get an offset past the descriptor's range instead (the hardware drops
-            // out-of-range buffer stores and returns 0 for out-of-range loads); a missing residual is a zero-length descriptor.
+            // out-of-range buffer stores and returns 0 for out-of-range loads).
             const unsigned span = (unsigned)(OTH * p.Wo * p.Cout * 4);  // bytes from the item origin to past its last row
             const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + w.g * p.out_gs + origin, 0, span, 0x00020000);
-            const __amdgpu_buffer_rsrc_t r_res =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid ? p.resid + w.g * p.resid_gs + origin : p.out), 0, p.resid ? span : 0, 0x00020000);
             const bool partial = (w.oy0 + OTH > p.Ho) || (w.ox0 + OTW > p.Wo);
             const bool col_ok = !partial || (w.ox0 + pp < p.Wo);
             const int rows_ok = partial ? p.Ho - w.oy0 : OTH;  // uniform: output rows of this item inside the image
             const unsigned ocol = col_ok ? ooff : 0x80000000u;
             const int orow = p.Wo * p.Cout * 4;
             const float floor_ = p.relu ? 0.f : -3.402823466e38f;
+            // the residual (BasicBlock identity) is requested here, before the exchange barrier, so that its latency hides behind
+            // the barrier and the LDS reads -- 32 registers the dead accumulators leave free
+            f32x4 res[8];
+            if (HAS_RES) {
+                const __amdgpu_buffer_rsrc_t r_res =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid + w.g * p.resid_gs + origin), 0, span, 0x00020000);
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) res[r8] = buf_load(r_res, (r8 < rows_ok) ? ocol : 0x80000000u, r8 * orow);
+            }
+            __syncthreads();
 #pragma unroll
             for (int k = 0; k < 4; ++k) {  // tile row k -> output rows 2k, 2k+1
                 f32x4 tq[4];
 #pragma unroll
                 for (int aa = 0; aa < 4; ++aa) tq[aa] = *reinterpret_cast<const f32x4*>(lds + tr + aa * VW + k * 32);
                 f32x4 y[2];
-                y[0] = add4(add4(tq[0], tq[1]), tq[2]);
+                y[0] = tq[0] + tq[1] + tq[2];
                 y[1] = tq[1] - tq[2] - tq[3];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const unsigned vo = (2 * k + i < rows_ok) ? ocol : 0x80000000u;  // scalar compare + one v_cndmask (or none)
-                    f32x4 o = add4(y[i], buf_load(r_res, vo, (2 * k + i) * orow));
+                    f32x4 o = HAS_RES ? y[i] + res[2 * k + i] : y[i];
                     o[0] = fmaxf(o[0], floor_);
                     o[1] = fmaxf(o[1], floor_);
                     o[2] = fmaxf(o[2], floor_);
@@ -452,19 +450,25 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
 }
 
 // Host-side launcher (called from cerb_api.hip).  p.wpack must hold the Winograd-packed weights (pack_wino).
-hipError_t cerb_launch_wino(ConvParams p, hipStream_t st) {
-    if (p.Cin % CB || p.Cout % 64) return hipErrorInvalidValue;
+template <bool HAS_RES>
+static hipError_t launch_wino(ConvParams p, hipStream_t st) {
     p.tiles_x = (p.Wo + OTW - 1) / OTW;
     p.tiles_y = (p.Ho + OTH - 1) / OTH;
     const long long items = (long long)p.groups * p.N * p.tiles_x * p.tiles_y * (p.Cout / 64);
+    auto kern = conv_wino_kernel<HAS_RES>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     long long grid = 512;  // persistent: two workgroups per CU
     if (grid > items) grid = items;
-    hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)grid), dim3(256), LDS_BYTES, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS_BYTES, st, p);
     return hipGetLastError();
+}
+
+hipError_t cerb_launch_wino(ConvParams p, hipStream_t st) {
+    if (p.Cin % CB || p.Cout % 64) return hipErrorInvalidValue;
+    return p.resid ? launch_wino<true>(p, st) : launch_wino<false>(p, st);
 }
