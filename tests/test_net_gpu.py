@@ -267,3 +267,25 @@ def test_small_feature_maps_patch_class_crop(full_model, hw):
     lg = m(x.cuda())["Patch-Class"].cpu()
     rl = net_ref.net_forward(sd, x, kw["decoder_kwargs"], kw["considered_tasks"])["Patch-Class"]
     assert (lg - rl).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("algo", [1, 0])
+def test_forward_is_bitwise_reproducible(full_model, algo):
+    """Races and un-padded hardware hazards show up as run-to-run differences long before they show up as large errors (the
+    gfx950 buffer_store hazard of DESIGN par.4.1 did): the same batch through the same handle must give identical bits."""
+    m, sd, kw = full_model
+    tiles = torch.from_numpy(np.random.RandomState(21).randint(0, 256, (12, 256, 256, 3)).astype(np.uint8)).cuda()
+    m.set_conv_algo(algo)
+    try:
+        ref = None
+        for _ in range(4):
+            outs = m.infer_tiles(tiles, 256)
+            torch.cuda.synchronize()
+            cur = {k: o.clone() for k, o in outs.items()}
+            if ref is None:
+                ref = cur
+            else:
+                for k in ref:
+                    assert torch.equal(ref[k], cur[k]), k
+    finally:
+        m.set_conv_algo(1)

@@ -194,3 +194,15 @@ def test_contours_nuclei_and_degenerate_shapes():
     for k in got:
         assert np.array_equal(got[k]["contour"], ref[k]["contour"]), k
     assert got[5]["contour"].tolist() == [[10, 24], [10, 33], [21, 33], [21, 24]]
+
+
+@pytest.mark.parametrize("tissue", ["Nuclei", "Gland", "Lumen"])
+def test_postproc_is_bitwise_reproducible(tissue):
+    """The CCL / flood kernels use atomics and lock-free union-find; the label maps must not depend on scheduling."""
+    m = synth.nuclei_maps(1024, 1280, 41, 800.0, noise=0.05) if tissue == "Nuclei" else \
+        synth.blob_maps(1024, 1280, 43, 80, 10.0, 50.0, rim=4.0, sharp=1.0, noise=0.05, holes=0.4)
+    md = torch.from_numpy(m).cuda()
+    ref, info0 = postproc_device(md, tissue)
+    for _ in range(4):
+        lab, info = postproc_device(md, tissue)
+        assert torch.equal(lab, ref) and int(info["n_inst"]) == int(info0["n_inst"])
