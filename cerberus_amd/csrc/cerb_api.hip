@@ -382,21 +382,23 @@ extern "C" int cerb_net_finalize(cerb_net* net) {
                 bn_fold(net, p + ".0.block.0.bn", 96, &f) || get(net, p + ".1.conv.weight", {d.out_ch, 96, 1, 1}, &w2) ||
                 get(net, p + ".1.conv.bias", {d.out_ch}, &b2))
                 return 1;
-            std::vector<float> w1p(3 * 8 * 64 * 4), b1p(96), w2p(48 * 64, 0.f), b2p(32, 0.f);
-            for (int blk = 0; blk < 3; ++blk)
-                for (int G = 0; G < 8; ++G)
+            // layouts of head_kernel (v_mfma_f32_16x16x4_f32, lane = (row/col l & 15, k-slot l >> 4)):
+            //   w1p[blk 6][g 4][lane][t]  = W1[16 blk + (l & 15)][16 g + 4 (l >> 4) + t]  (BN folded)
+            //   w2p[blk 6][lane][r]       = W2[l & 15][16 blk + 4 (l >> 4) + r]           (rows >= out_ch are zero)
+            std::vector<float> w1p(6 * 4 * 64 * 4), b1p(96), w2p(6 * 64 * 4, 0.f), b2p(32, 0.f);
+            for (int blk = 0; blk < 6; ++blk)
+                for (int G = 0; G < 4; ++G)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int t = 0; t < 4; ++t) {
-                            const int hid = blk * 32 + (lane & 31), ci = G * 8 + 4 * (lane >> 5) + t;
-                            w1p[((blk * 8 + G) * 64 + lane) * 4 + t] = w1->data[(size_t)hid * 64 + ci] * f.scale[hid];
+                            const int hid = blk * 16 + (lane & 15), ci = G * 16 + 4 * (lane >> 4) + t;
+                            w1p[((blk * 4 + G) * 64 + lane) * 4 + t] = w1->data[(size_t)hid * 64 + ci] * f.scale[hid];
                         }
             for (int c = 0; c < 96; ++c) b1p[c] = b1->data[c] * f.scale[c] + f.shift[c];
-            for (int blk = 0; blk < 3; ++blk)
-                for (int r = 0; r < 16; ++r)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int i = lane & 31, hh = lane >> 5;
-                        const int hid = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        w2p[(blk * 16 + r) * 64 + lane] = (i < d.out_ch) ? w2->data[(size_t)i * 96 + hid] : 0.f;
+            for (int blk = 0; blk < 6; ++blk)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = lane & 15, hid = blk * 16 + 4 * (lane >> 4) + r;
+                        w2p[(blk * 64 + lane) * 4 + r] = (o < d.out_ch) ? w2->data[(size_t)o * 96 + hid] : 0.f;
                     }
             for (int c = 0; c < d.out_ch; ++c) b2p[c] = b2->data[c];
             float *dw1, *db1, *dw2, *db2;

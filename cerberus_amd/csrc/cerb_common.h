@@ -31,9 +31,9 @@ struct ConvParams {
 // Fused output head (head.hip): 1x1 64->96 (+BN+ReLU) -> 1x1 96->out_ch -> softmax -> INST probs / TYPE argmax
 struct HeadParams {
     const float* feat;   // [N][H][W][64] NHWC (decoder output)
-    const float* w1p;    // packed W1 (BN folded): [3 blk][8 G][64 lane][4]
+    const float* w1p;    // packed W1 (BN folded): [6 blk][4 g][64 lane][4]  (cerb_api.hip: head packing)
     const float* b1;     // [96]
-    const float* w2p;    // packed W2: [48 step][64 lane]  (rows >= out_ch are zero)
+    const float* w2p;    // packed W2: [6 blk][64 lane][4]  (rows >= out_ch are zero)
     const float* b2;     // [32] (padded)
     int N, H, W;
     int out_ch;          // 3 or 7 (<= 8)

@@ -204,131 +204,150 @@ hipError_t cerb_launch_upsample2_add(const float* skip, const float* prev, float
 // Output head.  Everything stays in registers: GEMM1 is swapped (hidden x pixel) so its accumulators ARE the B
 // operand of GEMM2 (k-slot h at step (blk,r) <-> hidden unit blk*32 + (r&3) + 8*(r>>2) + 4*h).
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef HEAD_TPW
+#define HEAD_TPW 2  // 64-pixel tasks per wave
+#endif
+typedef float f32x4h __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    // v_mfma_f32_16x16x4_f32 throughout: D[16 x 16] += A[16 x 4] B[4 x 16]; lane l supplies row/column l & 15 and k-slot l >> 4,
+    // and holds D rows 4 (l >> 4) + r of column l & 15.  A wave owns 64 pixels = 4 pixel blocks of 16.
+    //   GEMM1 (hidden 96 = 6 blocks) x (64 channels = 16 k-steps): k-slot ks at step t of 16-channel group g <-> channel 16 g + 4 ks + t,
+    //     so one float4 per lane feeds 4 steps (features straight from global memory, W1 pre-packed the same way);
+    //   its accumulators (bias in the init, ReLU) are the B operand of GEMM2: step (blk, r), k-slot ks <-> hidden 16 blk + 4 ks + r;
+    //   GEMM2 pads out_ch to 16 rows (a 32x32 tile would pad to 32: 30 % of the head's MFMAs were padding before).
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, px = lane & 15, ks = lane >> 4;
     const long long npix = (long long)p.N * p.H * p.W;
-    const long long pbase = (long long)blockIdx.x * 256 + wave * 64;
-
-    f32x16 acc1[3][2];
+    const f32x4h* w1v = reinterpret_cast<const f32x4h*>(p.w1p) + lane;
+    const f32x4h* w2v = reinterpret_cast<const f32x4h*>(p.w2p) + lane;
+    auto feat_ptr = [&](long long base, int pb) {
+        const long long P = base + pb * 16 + px;
+        return p.feat + (P < npix ? P : npix - 1) * 64 + 4 * ks;
+    };
+    // a wave walks HEAD_TPW consecutive 64-pixel tasks; the first channel group of the next task is requested before this
+    // task's second GEMM and softmax, so the HBM latency of the feature read hides behind them
+    long long pbase = ((long long)blockIdx.x * 4 + wave) * (64 * HEAD_TPW);
+    f32x4h x[4];
 #pragma unroll
-    for (int b = 0; b < 3; ++b)
+    for (int pb = 0; pb < 4; ++pb) x[pb] = *reinterpret_cast<const f32x4h*>(feat_ptr(pbase, pb));
+#pragma unroll 1
+    for (int task = 0; task < HEAD_TPW; ++task, pbase += 64) {
+    f32x4h acc1[6][4];
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+    for (int blk = 0; blk < 6; ++blk) {
+        const f32x4h bb = *reinterpret_cast<const f32x4h*>(p.b1 + blk * 16 + ks * 4);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[b][q][r] = 0.f;
-
-    long long pix[2];
-    const float* xp[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        pix[q] = pbase + q * 32 + j;
-        const long long pc = pix[q] < npix ? pix[q] : npix - 1;
-        xp[q] = p.feat + pc * 64 + 4 * h;
+        for (int pb = 0; pb < 4; ++pb) acc1[blk][pb] = bb;
     }
-    const f32x4* w1v = reinterpret_cast<const f32x4*>(p.w1p) + lane;
+    const float* xp[4];
 #pragma unroll
-    for (int G = 0; G < 8; ++G) {
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(xp[0] + G * 8);
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(xp[1] + G * 8);
+    for (int pb = 0; pb < 4; ++pb) xp[pb] = feat_ptr(pbase, pb);
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const f32x4 a = w1v[(b * 8 + G) * 64];
+    for (int g = 0; g < 4; ++g) {
+        f32x4h xn[4];
+        if (g + 1 < 4) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc1[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], x0[t], acc1[b][0], 0, 0, 0);
-                acc1[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], x1[t], acc1[b][1], 0, 0, 0);
+            for (int pb = 0; pb < 4; ++pb) xn[pb] = *reinterpret_cast<const f32x4h*>(xp[pb] + (g + 1) * 16);
+        } else if (task + 1 < HEAD_TPW) {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) xn[pb] = *reinterpret_cast<const f32x4h*>(feat_ptr(pbase + 64, pb));
+        }
+#pragma unroll
+        for (int blk = 0; blk < 6; ++blk) {
+            const f32x4h a = w1v[(blk * 4 + g) * 64];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) acc1[blk][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], x[pb][t], acc1[blk][pb], 0, 0, 0);
+        }
+        if (g + 1 < 4 || task + 1 < HEAD_TPW) {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) x[pb] = xn[pb];
+        }
+    }
+    // ReLU (bias and folded BN are already inside)
+#pragma unroll
+    for (int blk = 0; blk < 6; ++blk)
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc1[blk][pb][r] = fmaxf(acc1[blk][pb][r], 0.f);
+    // GEMM2: logits[out 16][pixel 16] per pixel block; lane (px, ks) ends up with logits 4 ks + r of pixel px
+    f32x4h acc2[4];
+    {
+        const f32x4h b2 = *reinterpret_cast<const f32x4h*>(p.b2 + 4 * ks);
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) acc2[pb] = b2;
+    }
+#pragma unroll
+    for (int blk = 0; blk < 6; ++blk) {
+        const f32x4h a = w2v[blk * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) acc2[pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], acc1[blk][pb][r], acc2[pb], 0, 0, 0);
+    }
+    // lane group ks finishes pixel block ks: fetch its pixel's 8 logits from lanes px (rows 0..3) and 16 + px (rows 4..7)
+    float lg[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float lo = 0.f, hi = 0.f;
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            const float t0 = __shfl(acc2[pb][e], px), t1 = __shfl(acc2[pb][e], 16 + px);
+            lo = (ks == pb) ? t0 : lo;
+            hi = (ks == pb) ? t1 : hi;
+        }
+        lg[e] = lo;
+        lg[4 + e] = hi;
+    }
+    const long long P = pbase + ks * 16 + px;
+    if (P >= npix) continue;
+    if (p.logits) {
+        for (int e = 0; e < p.out_ch; ++e) p.logits[P * p.out_ch + e] = lg[e];
+    }
+    // softmax over out_ch (max-subtracted, as torch.softmax)
+    float mx = lg[0];
+#pragma unroll
+    for (int e = 1; e < 8; ++e)
+        if (e < p.out_ch) mx = fmaxf(mx, lg[e]);
+    float ex[8], sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ex[e] = (e < p.out_ch) ? expf(lg[e] - mx) : 0.f;
+        sum += ex[e];
+    }
+    const int x_ = (int)(P % p.W);
+    const long long r_ = P / p.W;
+    const int y_ = (int)(r_ % p.H);
+    const int n = (int)(r_ / p.H);
+    const int cy = y_ - p.crop_y0, cx = x_ - p.crop_x0;
+    if (cy < 0 || cy >= p.out_h || cx < 0 || cx >= p.out_w) continue;
+    const long long dst = (p.tile_off ? p.tile_off[n] : (long long)n * p.tile_stride) + (long long)cy * p.row_stride + cx;
+    if (p.kind == 0) {
+        float2 o;
+        o.x = ex[1] / sum;
+        o.y = ex[2] / sum;
+        *reinterpret_cast<float2*>(p.out_inst + dst * 2) = o;
+    } else {
+        int best = 0;
+        float bv = ex[0] / sum;
+#pragma unroll
+        for (int e = 1; e < 8; ++e) {
+            const float pe = ex[e] / sum;
+            if (e < p.out_ch && pe > bv) {
+                bv = pe;
+                best = e;
             }
         }
+        if (p.out_type_i64) p.out_type_i64[dst] = best;
+        if (p.out_type_u8) p.out_type_u8[dst] = (unsigned char)best;
     }
-    // + bias, ReLU (BN folded into W1/b1)
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b1 + b * 32 + rq * 8 + h * 4);
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc1[b][q][rq * 4 + e] = fmaxf(acc1[b][q][rq * 4 + e] + bb[e], 0.f);
-        }
-    // GEMM2: logits[out][pixel]
-    f32x16 acc2[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[q][r] = 0.f;
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float a = p.w2p[(b * 16 + r) * 64 + lane];
-            acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc1[b][0][r], acc2[0], 0, 0, 0);
-            acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc1[b][1][r], acc2[1], 0, 0, 0);
-        }
-    // lane (pixel j, half h) holds logits 4h..4h+3 in acc2[q][0..3]
-    const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.b2 + 4 * h);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        float mine[4], other[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            mine[e] = acc2[q][e] + b2[e];
-            other[e] = __shfl_xor(mine[e], 32);
-        }
-        float lg[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            lg[e] = h ? other[e] : mine[e];
-            lg[4 + e] = h ? mine[e] : other[e];
-        }
-        if (h != 0 || pix[q] >= npix) continue;
-        const long long P = pix[q];
-        if (p.logits) {
-            for (int e = 0; e < p.out_ch; ++e) p.logits[P * p.out_ch + e] = lg[e];
-        }
-        // softmax over out_ch (max-subtracted, as torch.softmax)
-        float mx = lg[0];
-#pragma unroll
-        for (int e = 1; e < 8; ++e)
-            if (e < p.out_ch) mx = fmaxf(mx, lg[e]);
-        float ex[8], sum = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            ex[e] = (e < p.out_ch) ? expf(lg[e] - mx) : 0.f;
-            sum += ex[e];
-        }
-        const int x = (int)(P % p.W);
-        const long long r_ = P / p.W;
-        const int y = (int)(r_ % p.H);
-        const int n = (int)(r_ / p.H);
-        const int cy = y - p.crop_y0, cx = x - p.crop_x0;
-        if (cy < 0 || cy >= p.out_h || cx < 0 || cx >= p.out_w) continue;
-        const long long dst = (p.tile_off ? p.tile_off[n] : (long long)n * p.tile_stride) + (long long)cy * p.row_stride + cx;
-        if (p.kind == 0) {
-            float2 o;
-            o.x = ex[1] / sum;
-            o.y = ex[2] / sum;
-            *reinterpret_cast<float2*>(p.out_inst + dst * 2) = o;
-        } else {
-            int best = 0;
-            float bv = ex[0] / sum;
-#pragma unroll
-            for (int e = 1; e < 8; ++e) {
-                const float pe = ex[e] / sum;
-                if (e < p.out_ch && pe > bv) {
-                    bv = pe;
-                    best = e;
-                }
-            }
-            if (p.out_type_i64) p.out_type_i64[dst] = best;
-            if (p.out_type_u8) p.out_type_u8[dst] = (unsigned char)best;
-        }
-    }
+    }  // task
 }
 
 hipError_t cerb_launch_head(const HeadParams& p, hipStream_t st) {
     const long long npix = (long long)p.N * p.H * p.W;
-    const long long blocks = (npix + 255) / 256;
+    const long long blocks = (npix + 256 * HEAD_TPW - 1) / (256 * HEAD_TPW);
     hipLaunchKernelGGL(head_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
     return hipGetLastError();
 }

@@ -1,0 +1,34 @@
+"""Developer probe (GPU box): the sharded post-processing protocol over the real backend ("nccl" = RCCL), two ranks.
+On a 1-GPU box both ranks share device 0 -- RCCL may refuse that ("duplicate GPU"); then the gloo run below still exercises
+the CUDA-tensor code path of run_distributed."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, torch.distributed as dist
+from cerberus_amd import shard_postproc as sp
+from cerberus_amd.postproc import postproc_device
+from oracle import synth
+
+backend = sys.argv[1]
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+if backend == "nccl":
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+else:
+    dist.init_process_group("gloo")
+H, W = 1536, 1024
+m = synth.nuclei_maps(H, W, 31, 600.0, noise=0.02)
+full = torch.from_numpy(m).cuda()
+b = [0, 768, H]
+band = full[b[rank]:b[rank + 1]].contiguous()
+if backend == "gloo":  # gloo moves CPU tensors: stage the strips through the host (what a gloo-only cluster would do)
+    class HostDist(object):
+        def __getattr__(self, n): return getattr(dist, n)
+    out, n_total, info = sp.run_distributed(band.cpu(), b[rank], "Nuclei", 192, 24, dist,
+                                            label_fn=lambda w_, t, ds: sp._device_label_fn(w_.cuda(), t, ds),
+                                            table_fn=sp._device_table_fn, relabel_fn=lambda rows, mp: sp._device_relabel_fn(rows, mp.cuda()))
+else:
+    out, n_total, info = sp.run_distributed(band, b[rank], "Nuclei", 192, 24, dist)
+ref, i0 = postproc_device(full, "Nuclei")
+same = sp.same_partition(ref[b[rank]:b[rank + 1]].cpu().numpy() > 0, out.cpu().numpy() > 0)
+print("rank %d backend %s: n_total %d (ref %d) info %s fg-equal %s" % (rank, backend, n_total, int(i0["n_inst"]), info, same), flush=True)
+dist.barrier(); dist.destroy_process_group()
