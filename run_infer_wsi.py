@@ -5,7 +5,7 @@ Usage:
             [--nr_post_proc_workers=<n>] [--batch_size=<n>] [--tile_shape=<n>] [--chunk_shape=<n>] \
             [--ambiguous_size=<int>] [--wsi_proc_mag=<n>] [--wsi_file_ext=<str>] [--cache_path=<path>] \
             [--logging_dir=<path>] [--input_dir=<path>] [--msk_dir=<path>] [--output_dir=<path>] [--patch_input_shape=<n>] \
-            [--patch_output_shape=<n>] [--wsi_bulk_idx=<n>] [--wsi_proc_step=<n>] [--save_thumb] [--save_mask]
+            [--patch_output_shape=<n>] [--wsi_bulk_idx=<n>] [--wsi_proc_step=<n>] [--save_thumb] [--save_mask] [--save_label_maps]
   run_infer_wsi.py (-h | --help)
   run_infer_wsi.py --version
 
@@ -33,6 +33,7 @@ Options:
   --wsi_proc_step=<n>         Increments for batch WSI processing. [default: 10]
   --save_thumb                Whether to save the slide thumbnail
   --save_mask                 Whether to save the slide mask
+  --save_label_maps           (not in the reference) also dump the label / class maps as <output_dir>/<slide>.npz
 
 """
 # Same command line as the reference's run_infer_wsi.py (flags verbatim, :4-35).  Slide-file decoding (tiatoolbox
@@ -83,7 +84,7 @@ if __name__ == "__main__":
     print("Number of WSIs in list:", len(names))
     for path in names:
         base = os.path.basename(path)[: -len(ext)] if ext else os.path.basename(path)
-        if os.path.exists("%s/%s.npz" % (args["--output_dir"], base)):  # resume-by-skip (infer/wsi.py:969-978)
+        if os.path.exists("%s/dat/%s.dat" % (args["--output_dir"], base)):  # resume-by-skip (infer/wsi.py:969-978)
             continue
         t0 = time.perf_counter()
         if path.endswith(".npy"):
@@ -115,8 +116,11 @@ if __name__ == "__main__":
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         if rank == 0:
-            np.savez_compressed("%s/%s.npz" % (args["--output_dir"], base), **{k: v.cpu().numpy() for k, v in inst.items()},
-                                **{"type_" + k: v.cpu().numpy() for k, v in full.items() if k.endswith("TYPE")}, pclass=full.get("Patch-Class").cpu().numpy()[::4, ::4])
+            if args["--save_label_maps"]:  # the reference keeps only the instance dictionary; the maps are for tests / inspection
+                np.savez_compressed("%s/%s.npz" % (args["--output_dir"], base), **{k: v.cpu().numpy() for k, v in inst.items()},
+                                    **{"type_" + k: v.cpu().numpy() for k, v in full.items() if k.endswith("TYPE")},
+                                    pclass=full.get("Patch-Class").cpu().numpy()[::4, ::4])
+            t_dump = time.perf_counter()
             # instance dictionary in the reference's wire format (joblib, infer/wsi.py:844-853)
             import joblib
 
@@ -127,7 +131,7 @@ if __name__ == "__main__":
             joblib.dump(wsi_info, "%s/dat/%s.dat" % (args["--output_dir"], base))
             t3 = time.perf_counter()
             print("%s: Inference Time: %.3f  Post Proc Time: %.3f  Instance Table Time: %.3f  (%.1f Mpx/s inference)" % (
-                base, t1 - t0, t2 - t1, t3 - t2, H * W / (t1 - t0) / 1e6))
+                base, t1 - t0, t2 - t1, t3 - t_dump, H * W / (t1 - t0) / 1e6))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -42,7 +42,7 @@ def test_run_infer_wsi_cli_synthetic(tmp_path):
     (spec / "s1.txt").write_text("synthetic:700x900:5")
     out = tmp_path / "out"
     cmd = [sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--input_dir=%s" % spec, "--wsi_file_ext=.txt", "--output_dir=%s" % out,
-           "--batch_size=6", "--patch_input_shape=448", "--patch_output_shape=144"]
+           "--batch_size=6", "--patch_input_shape=448", "--patch_output_shape=144", "--save_label_maps"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     z = np.load(str(out / "s1.npz"))
