@@ -18,6 +18,7 @@
 // launchers implemented in the kernel translation units
 hipError_t cerb_launch_conv(const ConvParams& p, int ks, int stride, int mode, hipStream_t st);
 hipError_t cerb_launch_wino(ConvParams p, hipStream_t st);
+hipError_t cerb_launch_wino3(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_upsample2_add(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C,
                                      long long prev_gs, hipStream_t st);
 extern "C" int cerb_conv_chunk(int ks, int stride);
@@ -99,6 +100,8 @@ struct PackedConv {
     int cin = 0, cout = 0, ks = 0, stride = 1, groups = 1;
     float* w = nullptr;     // device
     float* wino = nullptr;  // device, 3x3 stride-1 only: Winograd F(2x2,3x3) transformed weights (conv_wino.hip)
+    void* wino3 = nullptr;  // device, same weights split into three bf16 planes (conv_wino3.hip, conv_algo 2), packed lazily
+    std::vector<float> host_u;  // fp32 transformed weights kept on the host until conv_algo 2 is first used
     float* b = nullptr;     // device
 };
 
@@ -248,7 +251,7 @@ static void pack_conv(const float* w, const float* scale, int cout, int cin, int
 
 // Winograd F(2x2,3x3) filter transform U = G g G^T (in double, rounded once) in the layout conv_wino.hip streams:
 //   [cb][chunk][a][b][G][s][lane][t]  ->  U[a][b] of W[cb*64 + s*32 + (lane&31)][chunk*32 + G*8 + 4*(lane>>5) + t]
-static void pack_wino(const float* w, const float* scale, int cout, int cin, std::vector<float>* out) {
+static void pack_wino(const float* w, const float* scale, int cout, int cin, std::vector<float>* out, std::vector<float>* u_out) {
     static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     const int nchunk = cin / 32, ncb = cout / 64;
     const size_t base = out->size();
@@ -266,6 +269,7 @@ static void pack_wino(const float* w, const float* scale, int cout, int cin, std
                 for (int b = 0; b < 4; ++b)
                     U[((size_t)co * cin + ci) * 16 + a * 4 + b] = (float)(t[a][0] * Gm[b][0] + t[a][1] * Gm[b][1] + t[a][2] * Gm[b][2]);
         }
+    if (u_out) u_out->insert(u_out->end(), U.begin(), U.end());
     size_t idx = 0;
     for (int cb = 0; cb < ncb; ++cb)
         for (int ch = 0; ch < nchunk; ++ch)
@@ -281,13 +285,53 @@ static void pack_wino(const float* w, const float* scale, int cout, int cin, std
                                 }
 }
 
+// conv_wino3.hip layout: [cb][chunk][a][b][K-step s2][plane][cout half s][lane][8 bf16]
+//   element i of lane (j, h) = plane(U[a][b] of W[cb*64 + 32 s + j][chunk*32 + 16 s2 + 8 h + i]),  planes = hi, mid, lo of the bf16x3 split
+static uint16_t bf16_rne(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint32_t r = u + 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(r >> 16);
+}
+static float bf16_to_f(uint16_t v) {
+    const uint32_t u = (uint32_t)v << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static void pack_wino3(const float* U, int cout, int cin, std::vector<uint16_t>* out) {  // U: [cout][cin][16] from pack_wino's transform
+    const int nchunk = cin / 32, ncb = cout / 64;
+    const size_t base = out->size();
+    out->resize(base + (size_t)cout * cin * 16 * 3);
+    uint16_t* o = out->data() + base;
+    size_t idx = 0;
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b)
+                    for (int s2 = 0; s2 < 2; ++s2)
+                        for (int pl = 0; pl < 3; ++pl)
+                            for (int s = 0; s < 2; ++s)
+                                for (int lane = 0; lane < 64; ++lane)
+                                    for (int i = 0; i < 8; ++i) {
+                                        const int co = cb * 64 + s * 32 + (lane & 31);
+                                        const int ci = ch * 32 + s2 * 16 + 8 * (lane >> 5) + i;
+                                        const float x = U[((size_t)co * cin + ci) * 16 + a * 4 + b];
+                                        const uint16_t hi = bf16_rne(x);
+                                        const float r1 = x - bf16_to_f(hi);
+                                        const uint16_t mid = bf16_rne(r1);
+                                        const uint16_t lo = bf16_rne(r1 - bf16_to_f(mid));
+                                        o[idx++] = pl == 0 ? hi : pl == 1 ? mid : lo;
+                                    }
+}
+
 static int make_conv(cerb_net* net, const std::string& name, const std::vector<std::string>& wkeys,
                      const std::vector<std::string>& bkeys, const std::vector<std::string>& bnkeys, int cout, int cin, int ks,
                      int stride) {
     // one entry per group
     const int CB = cerb_conv_chunk(ks, stride);
     if (cout % 64 || cin % CB) return fail("conv " + name + ": unsupported channel counts");
-    std::vector<float> wp, bp, wwino;
+    std::vector<float> wp, bp, wwino, hu;
     const bool wino = (ks == 3 && stride == 1 && cin % 32 == 0);
     for (size_t g = 0; g < wkeys.size(); ++g) {
         const HostTensor* w;
@@ -296,7 +340,7 @@ static int make_conv(cerb_net* net, const std::string& name, const std::vector<s
         bool have_bn = !bnkeys.empty();
         if (have_bn && bn_fold(net, bnkeys[g], cout, &f)) return 1;
         pack_conv(w->data.data(), have_bn ? f.scale.data() : nullptr, cout, cin, ks, CB, &wp);
-        if (wino) pack_wino(w->data.data(), have_bn ? f.scale.data() : nullptr, cout, cin, &wwino);
+        if (wino) pack_wino(w->data.data(), have_bn ? f.scale.data() : nullptr, cout, cin, &wwino, &hu);
         const HostTensor* b = nullptr;
         if (!bkeys.empty() && get(net, bkeys[g], {cout}, &b)) return 1;
         for (int c = 0; c < cout; ++c) {
@@ -309,6 +353,7 @@ static int make_conv(cerb_net* net, const std::string& name, const std::vector<s
     pc.cin = cin; pc.cout = cout; pc.ks = ks; pc.stride = stride; pc.groups = (int)wkeys.size();
     if (upload(net, wp, &pc.w) || upload(net, bp, &pc.b)) return 1;
     if (wino && upload(net, wwino, &pc.wino)) return 1;
+    pc.host_u.swap(hu);
     net->conv[name] = pc;
     return 0;
 }
@@ -477,6 +522,24 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
         if (!out) return 0;
     }
     const double fl = 2.0 * (double)c.groups * N * p.Ho * p.Wo * (double)c.cout * c.cin * c.ks * c.ks;
+    if (net->conv_algo == 2 && c.wino && mode == 0) {
+        PackedConv& cm = it->second;
+        if (!cm.wino3) {  // first use: split the transformed weights into bf16 planes and upload
+            std::vector<uint16_t> w3;
+            for (int g = 0; g < cm.groups; ++g) pack_wino3(cm.host_u.data() + (size_t)g * cm.cout * cm.cin * 16, cm.cout, cm.cin, &w3);
+            void* d = nullptr;
+            HIP_OK(hipMalloc(&d, w3.size() * 2));
+            net->dev_allocs.push_back(d);
+            HIP_OK(hipMemcpy(d, w3.data(), w3.size() * 2, hipMemcpyHostToDevice));
+            cm.wino3 = d;
+        }
+        p.wpack = reinterpret_cast<const float*>(cm.wino3);
+        p.w_gs = (long long)c.cout * c.cin * 16 * 3 * 2;  // bytes per group
+        if (prof_begin(net, name, resid ? "conv_wino3<bf16x3,8x16,res>" : "conv_wino3<bf16x3,8x16>", fl, st)) return 1;
+        HIP_OK(cerb_launch_wino3(p, st));
+        if (prof_end(net, st)) return 1;
+        return 0;
+    }
     if (net->conv_algo && c.wino && mode == 0) {
         p.wpack = c.wino;
         p.w_gs = (long long)c.cout * c.cin * 16;
@@ -663,7 +726,7 @@ extern "C" double cerb_net_flops(const cerb_net* net, int n, int h, int w) {
 // ---- per-launch profile (bench.py roofline leg) ----------------------------------------------------------------
 extern "C" int cerb_net_set_conv_algo(cerb_net* net, int algo) {
     if (!net) return fail("cerb_net_set_conv_algo: null handle");
-    if (algo != 0 && algo != 1) return fail("cerb_net_set_conv_algo: algo must be 0 (direct) or 1 (Winograd)");
+    if (algo < 0 || algo > 2) return fail("cerb_net_set_conv_algo: algo must be 0 (direct), 1 (Winograd fp32) or 2 (Winograd, bf16x3 products)");
     net->conv_algo = algo;
     return 0;
 }

@@ -151,7 +151,8 @@ class NetDesc(torch.nn.Module):
         return float(_lib.lib().cerb_net_flops(self._ensure_handle(), n, h, w))
 
     def set_conv_algo(self, algo):
-        """0 = direct implicit GEMM, 1 = Winograd F(2x2,3x3) (default) for the 3x3 stride-1 convolutions."""
+        """0 = direct implicit GEMM, 1 = Winograd F(2x2,3x3) (default), 2 = experimental Winograd with bf16x3-split products
+        (see include/cerberus_hip.h) for the 3x3 stride-1 convolutions."""
         _lib.check(_lib.lib().cerb_net_set_conv_algo(self._ensure_handle(), int(algo)))
 
     def profile(self, enable=True):

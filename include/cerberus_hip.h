@@ -75,7 +75,10 @@ int cerb_net_forward(cerb_net* net, const cerb_forward_io* io, void* hip_stream)
 /* Algorithm of the 3x3 stride-1 convolutions (90 % of the FLOPs): 1 (default) = Winograd F(2x2,3x3) on the fp32 matrix
  * cores (conv_wino.hip; same fp32 products, different summation order, 2.25x fewer multiplies), 0 = direct implicit GEMM
  * (conv_igemm.hip).  cuDNN makes the same choice per layer for the reference (torch.backends.cudnn, models/run_desc.py:447).
- * Both meet the 1e-4 bar; the switch exists for A/B measurement and for the parity tests of the direct path. */
+ * Both meet the 1e-4 bar; the switch exists for A/B measurement and for the parity tests of the direct path.
+ * 2 = experimental: algorithm 1 with every fp32 product emulated by six bf16 MFMAs on a three-way bf16 split of both operands
+ * (conv_wino3.hip; fp32 accumulate, errors indistinguishable from algorithm 1 in the tests).  It leaves the fp32 matrix
+ * instruction, so it is never the default and never what bench.py's headline measures (BASELINE.json configs[1]: fp32). */
 int cerb_net_set_conv_algo(cerb_net* net, int algo);
 
 /* FLOPs (2*MAC) of one forward for the given geometry -- used by bench.py for the roofline figure. */

@@ -289,3 +289,34 @@ def test_forward_is_bitwise_reproducible(full_model, algo):
                     assert torch.equal(ref[k], cur[k]), k
     finally:
         m.set_conv_algo(1)
+
+
+def test_experimental_bf16x3_algo_meets_the_parity_bar(golden_dir):
+    """cerb_net_set_conv_algo(2): Winograd with bf16x3-split products (conv_wino3.hip, opt-in, never the default) against the
+    reference's golden vectors -- same 1e-4 bar; also exercises residual and grouped launches of that kernel."""
+    g = np.load(os.path.join(golden_dir, "net_cfg2_all.npz"))
+    tasks = [str(t) for t in g["tasks"]]
+    m, sd, kw = _model(tasks, int(g["weight_seed"]))
+    n, hw, osz = int(g["n"]), int(g["hw"]), int(g["out_shape"])
+    tiles = np.random.RandomState(int(g["tile_seed"])).randint(0, 256, (n, hw, hw, 3)).astype(np.uint8)
+    m.set_conv_algo(2)
+    try:
+        out = infer_step(torch.from_numpy(tiles), m, osz, tasks)
+        m.profile(True)
+        m.infer_tiles(torch.from_numpy(tiles).cuda(), osz)
+        torch.cuda.synchronize()
+        kernels = {r[1] for r in m.profile_records()}
+        m.profile(False)
+    finally:
+        m.set_conv_algo(1)
+    assert any(k.startswith("conv_wino3") for k in kernels) and not any(k.startswith("conv_wino<") for k in kernels)
+    for k in out[0].keys():
+        a = np.stack([out[i][k] for i in range(n)])
+        a4 = a[..., None] if a.ndim == 3 else a
+        key = "out_crops/" + k
+        ref = g[key] if key in g else g["out_full/" + k]
+        got = _crops(a4) if key in g else a4
+        if a.dtype == np.float32:
+            assert np.abs(got - ref).max() < PROB_TOL, k
+        else:
+            assert (got != ref).mean() < 1e-4, k
