@@ -138,3 +138,5 @@ if __name__ == "__main__":
     run_case("cfg2_all", tile_seed=1, n=2, hw=256, out_shape=256, tasks=all_tasks)
     # reference-default geometry 448 -> 144 (centre crop path of infer_step)
     run_case("g448_all", tile_seed=2, n=1, hw=448, out_shape=144, tasks=all_tasks)
+    # bottom feature map smaller than 9 x 9 (6 x 6): cropping_center's negative-start slice in the Patch-Class branch
+    run_case("small96_all", tile_seed=3, n=2, hw=96, out_shape=96, tasks=all_tasks)

@@ -58,7 +58,7 @@ def test_encoder_and_logits_vs_oracle(full_model):
         assert (v.cpu() - ref[k]).abs().max().item() < 2e-4, k
 
 
-@pytest.mark.parametrize("tag", ["cfg1_nuclei", "cfg2_all", "g448_all"])
+@pytest.mark.parametrize("tag", ["cfg1_nuclei", "cfg2_all", "g448_all", "small96_all"])
 def test_infer_step_vs_reference_golden(golden_dir, tag):
     g = np.load(os.path.join(golden_dir, "net_%s.npz" % tag))
     tasks = [str(t) for t in g["tasks"]]

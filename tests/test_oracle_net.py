@@ -17,7 +17,7 @@ def _crops(a):
     return np.stack([a[:, y:y + CS, x:x + CS] for (y, x) in CROPS], axis=1)
 
 
-@pytest.mark.parametrize("tag", ["cfg1_nuclei", "cfg2_all", "g448_all"])
+@pytest.mark.parametrize("tag", ["cfg1_nuclei", "cfg2_all", "g448_all", "small96_all"])
 def test_oracle_matches_reference_fixtures(golden_dir, tag):
     g = np.load(os.path.join(golden_dir, "net_%s.npz" % tag))
     tasks = [str(t) for t in g["tasks"]]
