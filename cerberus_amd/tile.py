@@ -30,6 +30,45 @@ from .run_desc import infer_step
 POSTPROC_CODES = ("IP-ERODED-CONTOUR-3", "IP-ERODED-CONTOUR-11")  # -> PostProcInstErodedContourMap (infer/tile.py:35-40)
 
 
+def _pad_reflect_numpy1(img, pads):
+    """np.pad(img, pads, "reflect") AS NUMPY < 2.0 COMPUTES IT (the reference pins numpy 1.21.5, environment.yml:11).  When a pad
+    is wider than the image side minus one, numpy 1.x fills it iteratively from whatever is already valid on BOTH sides, which
+    is not the periodic mirror numpy >= 2.0 produces; an image narrower than a quarter of the window shows the difference.
+    Restated from numpy/lib/arraypad.py (_set_reflect_both, 1.21); pinned by tests/golden/tile_patching.npz cases 8, 12, 15, 17, 27."""
+    img = np.asarray(img)
+    out_shape = tuple(img.shape[a] + pads[a][0] + pads[a][1] for a in range(img.ndim))
+    out = np.zeros(out_shape, img.dtype)
+    out[tuple(slice(pads[a][0], pads[a][0] + img.shape[a]) for a in range(img.ndim))] = img
+    for axis in range(img.ndim):
+        left, right = int(pads[axis][0]), int(pads[axis][1])
+        if left == 0 and right == 0:
+            continue
+        # view of everything already valid along the other axes (numpy pads axis after axis on the growing region of interest)
+        roi = tuple(slice(None) if a < axis else (slice(None) if a == axis else slice(pads[a][0], pads[a][0] + img.shape[a])) for a in range(img.ndim))
+        v = out[roi]
+        v = np.moveaxis(v, axis, 0)  # a view: writes go through to `out`
+        n = v.shape[0]
+        if img.shape[axis] == 1:  # numpy: a length-1 axis is padded with its edge value
+            v[:left] = v[left]
+            v[n - right:] = v[n - right - 1]
+            continue
+        while left > 0 or right > 0:
+            old_length = n - right - left - 1
+            if left > 0:
+                chunk = min(old_length, left)
+                stop = left
+                start = stop + chunk
+                v[left - chunk:left] = v[start:stop:-1]
+                left -= chunk
+            if right > 0:
+                chunk = min(old_length, right)
+                start = n - right - 2
+                stop = start - chunk
+                v[n - right:n - right + chunk] = v[start:stop:-1] if stop >= 0 else v[start::-1][:chunk]
+                right -= chunk
+    return out
+
+
 def _prepare_patching(img, input_size, output_size, output_overlap_size):
     """Mirror padding + patch placement; same return values as the reference (infer/tile.py:43-106):
     padded_img, info_list int32 [P, 2(in/out), 2(tl/br), 2(y/x)], [padt, padl]."""
@@ -44,7 +83,7 @@ def _prepare_patching(img, input_size, output_size, output_overlap_size):
     diff = win - step
     padt = padl = diff // 2
     padb, padr = last_h + win - im_h, last_w + win - im_w
-    padded = np.pad(img, ((padt, padb), (padl, padr), (0, 0)), "reflect")
+    padded = _pad_reflect_numpy1(img, ((padt, padb), (padl, padr), (0, 0)))
     ys = np.arange(0, last_h, step, dtype=np.int32)
     xs = np.arange(0, last_w, step, dtype=np.int32)
     # the reference's np.meshgrid(y, x) (xy indexing) flattens with x slow, y fast

@@ -40,6 +40,13 @@ from infer.tile import _prepare_patching  # noqa: E402  (reference)
 
 store = {}
 cases = [(300, 421, 256, 256, 0), (1000, 777, 448, 144, 0), (144, 144, 448, 144, 0), (513, 257, 256, 256, 0), (95, 130, 448, 144, 0)]
+_rs = np.random.RandomState(2024)  # + random geometries (window a multiple of 16, even window - output gap, a few overlaps)
+for _ in range(24):
+    _win = 16 * int(_rs.randint(6, 30))
+    _out = int(_rs.randint(_win // 3, _win + 1))
+    _out -= (_win - _out) % 2
+    _ovl = int(_rs.choice([0, 0, 0, 8, 32])) if _out > 64 else 0
+    cases.append((int(_rs.randint(20, 1200)), int(_rs.randint(20, 1200)), _win, _out, _ovl))
 for i, (h, w, win, out, ovl) in enumerate(cases):
     img = np.random.RandomState(100 + i).randint(0, 256, (h, w, 3)).astype(np.uint8)
     padded, info, pos = _prepare_patching(img, win, out, ovl)
