@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 for FL in ${CERB_VARIANTS:-"" "-DCERB_ABL_NOSTAGE" "-DCERB_ABL_NOEPI" "-DCERB_ABL_NOWLOAD"}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $FL -c cerberus_amd/csrc/conv_igemm.hip -o cerberus_amd/csrc/conv_igemm.o || exit 1
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o cerberus_amd/libcerberus_hip.so cerberus_amd/csrc/conv_igemm.o cerberus_amd/csrc/net_kernels.o cerberus_amd/csrc/postproc.o cerberus_amd/csrc/slide_kernels.o cerberus_amd/csrc/cerb_api.o || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o cerberus_amd/libcerberus_hip.so cerberus_amd/csrc/*.o || exit 1
   echo "=== flags: [$FL]"
   timeout 60 python -u scripts/dev_profile_layers.py 32 2>&1 | grep -E "^conv_igemm<ks3,s1|^total"
 done
