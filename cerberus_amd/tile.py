@@ -254,6 +254,7 @@ class InferManager(object):
             def up2(t):  # cv2.resize(fx=2, fy=2, INTER_NEAREST) of an integer map, on the device
                 return t.repeat_interleave(2, dim=0).repeat_interleave(2, dim=1).contiguous()
 
+            info_all = {}
             for tissue, lab in res["inst"].items():
                 lab_np = lab.cpu().numpy()
                 tmap = res["type"].get(tissue)
@@ -262,12 +263,18 @@ class InferManager(object):
                     prev_type = up2(tmap)
                 # instance table on the GPU; the reference re-uses the previous tissue's type map for Lumen (infer/tile.py:196-202)
                 info = get_inst_info_dict(up2(lab), prev_type)
+                info_all[tissue] = info
                 os.makedirs("%s/%s_mat/" % (self.output_dir, tissue.lower()), exist_ok=True)
                 mat = {"inst_map": lab_np.astype(np.float64) if tissue != "Nuclei" else lab_np,
                        "type": [d.get("type", -1) for d in info.values()], "id": list(info.keys())}
                 if tmap_np is not None:
                     mat["type_map"] = tmap_np.astype(np.float32)
                 sio.savemat("%s/%s_mat/%s.mat" % (self.output_dir, tissue.lower(), base), mat)
+            # overlay of the x2 nearest-upscaled source with every instance contour (infer/tile.py:251-257)
+            from .viz import up2_nearest, visualize_instances_dict_orig
+
+            os.makedirs("%s/overlay/" % self.output_dir, exist_ok=True)
+            Image.fromarray(visualize_instances_dict_orig(up2_nearest(img), info_all)).save("%s/overlay/%s.jpg" % (self.output_dir, base))
             if res["pclass"] is not None:
                 os.makedirs("%s/pclass_mat/" % self.output_dir, exist_ok=True)
                 sio.savemat("%s/pclass_mat/%s.mat" % (self.output_dir, base), {"pclass": res["pclass"].cpu().numpy()})

@@ -29,6 +29,8 @@ def test_run_infer_tile_cli(tmp_path):
         assert m["inst_map"].shape == (300, 421)  # label map at source resolution (infer/tile.py:274-281)
         assert set(m.keys()) >= {"inst_map", "type", "id"}
     assert sio.loadmat(str(out / "pclass_mat" / "b.mat"))["pclass"].shape == (256, 256)
+    ov = np.array(Image.open(str(out / "overlay" / "b.jpg")))
+    assert ov.shape[2] == 3 and ov.shape[0] == 2 * 256  # x2 nearest-upscaled source with the instance outlines
     # resume-by-skip (infer/tile.py:225-238) is kept verbatim, including the reference's quirk: it looks for
     # "patch-class_mat/<name>.mat" (the class map is written to "pclass_mat/"), so with the CLI's target list every image
     # is always re-processed; without patch-class in the list the skip works and the reference's assert fires.

@@ -193,3 +193,20 @@ def test_sharded_postproc_protocol_gloo(world, tissue):
     for e in edges:
         crossing |= (set(np.unique(lab[e - 1])) & set(np.unique(lab[e]))) - {0}
     assert len(crossing) > 0  # the case exercises instances that straddle a band edge
+
+
+def test_overlay_rendering():
+    """visualize_instances_dict_orig mirror: tissue draw order, type colours, closed outlines (PIL stand-in for cv2.drawContours)."""
+    from cerberus_amd.viz import DEFAULT_VIZ_INFO, up2_nearest, visualize_instances_dict_orig
+
+    img = np.full((60, 80, 3), 10, np.uint8)
+    sq = np.array([[10, 10], [10, 40], [50, 40], [50, 10]], np.int32)
+    tri = np.array([[60, 5], [60, 25], [75, 25]], np.int32)
+    out = visualize_instances_dict_orig(img, {"Nuclei": {1: {"contour": sq, "type": 3}, 2: {"contour": tri}}, "Lumen": {7: {"contour": sq + 2}}})
+    assert out.shape == img.shape and out.dtype == np.uint8 and np.array_equal(img, np.full((60, 80, 3), 10, np.uint8))
+    assert tuple(out[25, 10]) == DEFAULT_VIZ_INFO["nuclei"]["type_colour"][3]   # left edge of the typed square, drawn last
+    assert tuple(out[15, 60]) == DEFAULT_VIZ_INFO["nuclei"]["inst_colour"]      # untyped triangle
+    assert tuple(out[30, 30]) == (10, 10, 10)                                   # interior untouched (outline only)
+    assert (out == np.array(DEFAULT_VIZ_INFO["lumen"]["inst_colour"], np.uint8)).all(axis=2).sum() > 50
+    up = up2_nearest(np.arange(12, dtype=np.uint8).reshape(2, 2, 3))
+    assert up.shape == (4, 4, 3) and np.array_equal(up[0, 0], up[1, 1]) and np.array_equal(up[0, 2], up[1, 3])
