@@ -206,3 +206,23 @@ def test_postproc_is_bitwise_reproducible(tissue):
     for _ in range(4):
         lab, info = postproc_device(md, tissue)
         assert torch.equal(lab, ref) and int(info["n_inst"]) == int(info0["n_inst"])
+
+
+def test_sharded_postproc_flags_instances_taller_than_the_margin():
+    """The band result is only claimed exact when n_truncated == n_unresolved == 0: an instance that does not fit into the halo
+    must be counted, never silently cut."""
+    from cerberus_amd import shard_postproc as sp
+
+    H, W = 1200, 400
+    yy, xx = np.mgrid[0:H, 0:W]
+    m = np.zeros((H, W, 2), np.float32)
+    m[..., 0] = ((yy - 600) ** 2 + (xx - 200) ** 2 < 180 ** 2).astype(np.float32)   # one gland, 360 rows tall, centred on the band edge
+    m[..., 0] += ((yy - 100) ** 2 + (xx - 100) ** 2 < 40 ** 2).astype(np.float32)    # and a small one well inside band 0
+    full = torch.from_numpy(m).cuda()
+    outs, n_total, infos = sp.run_local([full[:600], full[600:]], "Gland", 128, 16, 1.0)
+    assert sum(i["n_truncated"] + i["n_unresolved"] for i in infos) >= 1, infos
+    # with a margin that holds the instance the same map is exact again
+    outs, n_total, infos = sp.run_local([full[:600], full[600:]], "Gland", 320, 16, 1.0)
+    assert all(i["n_truncated"] == 0 and i["n_unresolved"] == 0 for i in infos), infos
+    ref, _ = postproc_device(full, "Gland", 1.0)
+    assert n_total == 2 and sp.same_partition(ref.cpu().numpy(), sp.assemble(outs).cpu().numpy())
