@@ -258,6 +258,8 @@ def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guar
 
 def _gather_rows(lab, rows_per_rank, cols, dist, rank, world):
     """Concatenate per-rank label bands (rows_per_rank[r] valid rows each) on the root; None elsewhere."""
+    if world == 1:
+        return lab[: rows_per_rank[0], :cols].contiguous()
     hmax = max(rows_per_rank)
     pad = torch.zeros((hmax, cols), dtype=lab.dtype, device=lab.device)
     pad[: lab.shape[0], : min(cols, lab.shape[1])] = lab[:, :cols]

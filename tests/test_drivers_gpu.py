@@ -89,3 +89,22 @@ def test_wsi_runner_equals_tile_manager_and_sharding(manager, win, out):
     m = full["Gland-INST"].cpu().numpy()
     ds = (m[0::2, 0::2] * 0.5 + m[0::2, 1::2] * 0.5) * 0.5 + (m[1::2, 0::2] * 0.5 + m[1::2, 1::2] * 0.5) * 0.5
     assert np.array_equal(inst["Gland"].cpu().numpy(), pr.proc(np.ascontiguousarray(ds.astype(np.float32)), "Gland", 0.5).astype(np.int32))
+
+
+def test_band_postprocess_and_gather_single_rank_equals_root_path(manager):
+    """postprocess_bands_and_gather (the multi-GPU tail of run_infer_wsi.py) at world 1: same instances as the root-side
+    WSIRunner.postprocess on a slide whose size is not a multiple of the patch (canvas rows / columns beyond the slide are cropped)."""
+    from cerberus_amd.shard_postproc import postprocess_bands_and_gather, same_partition
+
+    H, W = 650, 730
+    slide = synth_slide(H, W, seed=9)
+    run = WSIRunner(manager.net, (H, W), 256, 256, batch_size=6)
+    run.infer_band(slide, 0)
+    inst_a, info_a = WSIRunner.postprocess(run.gather_to_root(), wsi_mode=True)
+    inst_b, info_b, small = postprocess_bands_and_gather(run, H, W, 0, 1, None)
+    assert set(small.keys()) == {"Nuclei-TYPE", "Gland-TYPE", "Patch-Class"} and small["Nuclei-TYPE"].shape == (H, W)
+    for t in ("Nuclei", "Gland", "Lumen"):
+        a, b = inst_a[t].cpu().numpy(), inst_b[t].cpu().numpy()
+        assert a.shape == b.shape, t
+        assert same_partition(a, b), t
+        assert info_b[t]["n_truncated"] == 0 and info_b[t]["n_unresolved"] == 0
