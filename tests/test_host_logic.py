@@ -132,6 +132,18 @@ def _oracle_label_fn(window, tissue, ds):
     return lab, int(lab.max())
 
 
+def _shard_case(world, tissue):
+    from oracle import synth
+
+    H, W = (720, 400) if world < 8 else (1040, 320)
+    if tissue == "Nuclei":
+        full = synth.nuclei_maps(H, W, 3, 900.0, noise=0.02)
+    else:
+        full = synth.blob_maps(H, W, 5, 40, 8.0, 22.0, rim=3.0, sharp=1.0, noise=0.02, holes=0.3)
+    bounds = {2: [0, 384, H], 3: [0, 256, 512, H], 8: [130 * i for i in range(8)] + [H]}[world]
+    return full, bounds
+
+
 def _shard_worker(rank, world, port, tissue, ret):
     import torch.distributed as dist
 
@@ -140,12 +152,7 @@ def _shard_worker(rank, world, port, tissue, ret):
 
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    H, W = 720, 400
-    if tissue == "Nuclei":
-        full = synth.nuclei_maps(H, W, 3, 900.0, noise=0.02)
-    else:
-        full = synth.blob_maps(H, W, 5, 40, 8.0, 22.0, rim=3.0, sharp=1.0, noise=0.02, holes=0.3)
-    bounds = [0, 256, 512, H] if world == 3 else [0, 384, H]
+    full, bounds = _shard_case(world, tissue)
     band = torch.from_numpy(full[bounds[rank]:bounds[rank + 1]].copy())
     ds = 1.0 if tissue == "Nuclei" else 0.3  # small ds: small structuring element / min sizes, instances stay inside the margin
     out, n_total, info = sp.run_distributed(band, bounds[rank], tissue, 96, 16, dist, ds, label_fn=_oracle_label_fn, table_fn=_np_table,
@@ -155,7 +162,7 @@ def _shard_worker(rank, world, port, tissue, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,tissue", [(2, "Nuclei"), (3, "Nuclei"), (3, "Gland")])
+@pytest.mark.parametrize("world,tissue", [(2, "Nuclei"), (3, "Nuclei"), (3, "Gland"), (8, "Nuclei")])
 def test_sharded_postproc_protocol_gloo(world, tissue):
     """Band-local labelling + halo exchange + count all-gather + crossing-instance table reproduce the whole-map labelling
     up to an id bijection; ids are unique, dense and ordered by (band, first pixel)."""
@@ -175,20 +182,15 @@ def test_sharded_postproc_protocol_gloo(world, tissue):
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    H, W = 720, 400
-    if tissue == "Nuclei":
-        full = synth.nuclei_maps(H, W, 3, 900.0, noise=0.02)
-        ref = pr.proc(full, "Nuclei").astype(np.int32)
-    else:
-        full = synth.blob_maps(H, W, 5, 40, 8.0, 22.0, rim=3.0, sharp=1.0, noise=0.02, holes=0.3)
-        ref = pr.proc(full, "Gland", 0.3).astype(np.int32)
+    full, bounds = _shard_case(world, tissue)
+    ref = (pr.proc(full, "Nuclei") if tissue == "Nuclei" else pr.proc(full, "Gland", 0.3)).astype(np.int32)
     lab = np.concatenate([g[1] for g in got], axis=0)
     n_ref = len(np.unique(ref)) - 1
     assert n_ref > 20
     assert all(g[3]["n_truncated"] == 0 and g[3]["n_unresolved"] == 0 for g in got), [g[3] for g in got]
     assert got[0][2] == n_ref and sorted(np.unique(lab)[1:]) == list(range(1, n_ref + 1))
     assert same_partition(ref, lab)
-    edges = [256, 512] if world == 3 else [384]
+    edges = bounds[1:-1]
     crossing = set()
     for e in edges:
         crossing |= (set(np.unique(lab[e - 1])) & set(np.unique(lab[e]))) - {0}
