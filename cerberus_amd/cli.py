@@ -28,14 +28,14 @@ WSI_OPTIONS = _COMMON + [
     ("--cache_path", True, "cache/", "accepted and ignored: there is no memmap cache"),
     ("--logging_dir", True, "logging/", "accepted and ignored"),
     ("--input_dir", True, None, "directory of slides (not searched recursively)"),
-    ("--msk_dir", True, None, "accepted and ignored: tissue masks are out of scope"),
-    ("--output_dir", True, "output/", "where dat/<slide>.dat (and <slide>.npz with --save_label_maps) are written"),
+    ("--msk_dir", True, None, "directory of tissue masks <slide>.png (any resolution); when given, only slides that have a mask are processed"),
+    ("--output_dir", True, "output/", "where dat/<slide>.dat, tissue/<slide>.mat (and <slide>.npz with --save_label_maps) are written"),
     ("--patch_input_shape", True, "448", "network input window (square)"),
     ("--patch_output_shape", True, "144", "centre crop kept from every window (square)"),
     ("--wsi_bulk_idx", True, "1", "accepted for compatibility"),
     ("--wsi_proc_step", True, "10", "accepted for compatibility"),
     ("--save_thumb", False, False, "accepted and ignored"),
-    ("--save_mask", False, False, "accepted and ignored"),
+    ("--save_mask", False, False, "write the tissue mask used as <output_dir>/mask/<slide>.png"),
     ("--save_label_maps", False, False, "(not in the reference) also dump the label / class maps as <output_dir>/<slide>.npz"),
 ]
 

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <string>
@@ -1201,6 +1202,96 @@ extern "C" int cerb_postproc_lumen(const float* inst, int H, int W, long long ro
 extern "C" int cerb_mask_lumen_by_gland(int32_t* lumen, const int32_t* gland, long long n_pix, void* hip_stream) {
     if (!lumen || !gland || n_pix < 0) return cerb_set_error("cerb_mask_lumen_by_gland: bad arguments");
     hipLaunchKernelGGL(mask_lumen_kernel, dim3(grid_for(n_pix)), dim3(256), 0, (hipStream_t)hip_stream, lumen, gland, n_pix);
+    KCHECK();
+    return 0;
+}
+
+// =================================================================================================================
+// Tissue-mask regions (infer/wsi.py:724 `measurements.label(wsi_mask)`): 4-connected components of mask != 0,
+// ids in raster order of each component's first pixel (scipy.ndimage.label's order).
+// =================================================================================================================
+__global__ void binarize_kernel(const uint8_t* __restrict__ m, long long row_stride, int H, int W, uint8_t* __restrict__ fg) {
+    const long long n = (long long)H * W;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
+        fg[p] = m[(p / W) * row_stride + (p % W)] != 0 ? 1 : 0;
+}
+extern "C" int cerb_label_mask(const uint8_t* mask, long long row_stride, int H, int W, int32_t* labels_out, int32_t* n_out, void* ws,
+                               size_t ws_bytes, void* hip_stream) {
+    if (!mask || !labels_out || !n_out || !ws || H <= 0 || W <= 0) return cerb_set_error("cerb_label_mask: bad arguments");
+    if (ws_bytes < cerb_pp_workspace_bytes(H, W)) return cerb_set_error("cerb_label_mask: workspace too small");
+    if ((long long)H * W >= (1ll << 31)) return cerb_set_error("cerb_label_mask: map too large (H*W must be < 2^31)");
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int n = H * W;
+    Carve cv{(char*)ws, ws_bytes};
+    int* L = (int*)cv.take((size_t)n * 4);
+    int* flag = (int*)cv.take((size_t)n * 4);
+    int* rank = (int*)cv.take((size_t)n * 4);
+    uint8_t* fg = (uint8_t*)cv.take(n);
+    int* scantmp = (int*)cv.take((size_t)(n / SCAN_ITEMS + 4096) * 4 * 2);
+    if (!scantmp) return cerb_set_error("cerb_label_mask: workspace carve failed");
+    const unsigned g = grid_for(n);
+    hipLaunchKernelGGL(binarize_kernel, dim3(g), dim3(256), 0, st, mask, row_stride, H, W, fg);
+    if (ccl_run(fg, 1, L, H, W, st)) return 1;
+    hipLaunchKernelGGL(ccl_keep_roots_kernel, dim3(g), dim3(256), 0, st, L, (const int*)L, INT_MIN, flag, n);  // every root: area test always true
+    if (scan_exclusive(flag, rank, n, scantmp, st)) return 1;
+    hipLaunchKernelGGL(ccl_relabel_kernel, dim3(g), dim3(256), 0, st, L, flag, rank, labels_out, n);
+    hipLaunchKernelGGL(count_from_scan_kernel, dim3(1), dim3(1), 0, st, flag, rank, n, n_out, (const int*)nullptr);
+    KCHECK();
+    return 0;
+}
+
+// =================================================================================================================
+// Which border cv2.findContours(...)[0][0] is, for an instance made of several 8-connected pieces (a lumen cut by its gland's
+// edge, a gland partly overwritten by a later one): OpenCV returns top-level contours most-recently-found first, so element
+// [0] is the outer border of the piece whose first pixel comes LAST in raster order (loader/postproc.py:29-33 takes [0][0]).
+// One union-find pass over "same id, 8-neighbour" links; start[id-1] = max over the pieces of their first pixel.
+// =================================================================================================================
+__global__ void cc8_init_kernel(const int* __restrict__ lab, long long ls, int H, int W, int* __restrict__ L) {
+    const long long n = (long long)H * W;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
+        L[p] = lab[(p / W) * ls + (p % W)] > 0 ? (int)p : -1;
+}
+__global__ void cc8_merge_kernel(const int* __restrict__ lab, long long ls, int H, int W, int* L) {
+    const long long n = (long long)H * W;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(p / W), x = (int)(p % W);
+        const int id = lab[y * ls + x];
+        if (id <= 0) continue;
+        if (x > 0 && lab[y * ls + x - 1] == id) uf_union(L, (int)p, (int)p - 1);
+        if (y > 0) {
+            const int* up = lab + (y - 1) * ls;
+            if (up[x] == id) uf_union(L, (int)p, (int)p - W);
+            else {  // the diagonal links only matter when the pixel above does not already join all three
+                if (x > 0 && up[x - 1] == id) uf_union(L, (int)p, (int)p - W - 1);
+                if (x + 1 < W && up[x + 1] == id) uf_union(L, (int)p, (int)p - W + 1);
+            }
+        }
+    }
+}
+__global__ void cc8_last_root_kernel(const int* __restrict__ lab, long long ls, int H, int W, const int* __restrict__ L, int n_inst,
+                                     long long* __restrict__ start) {
+    const long long n = (long long)H * W;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        if (L[p] != (int)p) continue;
+        const int id = lab[(p / W) * ls + (p % W)];
+        if (id >= 1 && id <= n_inst) atomicMax((unsigned long long*)&start[id - 1], (unsigned long long)p);
+    }
+}
+extern "C" int cerb_inst_contour_start(const int32_t* labels, long long lab_row_stride, int H, int W, int n_inst, long long* start, void* ws,
+                                       size_t ws_bytes, void* hip_stream) {
+    if (!labels || !start || !ws || H <= 0 || W <= 0 || n_inst < 0) return cerb_set_error("cerb_inst_contour_start: bad arguments");
+    if ((long long)H * W >= (1ll << 31)) return cerb_set_error("cerb_inst_contour_start: map too large (H*W must be < 2^31)");
+    if (ws_bytes < (size_t)H * W * 4) return cerb_set_error("cerb_inst_contour_start: workspace too small (4 bytes per pixel)");
+    if (n_inst == 0) return 0;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int n = H * W;
+    int* L = (int*)ws;
+    const unsigned g = grid_for(n);
+    PP_OK(hipMemsetAsync(start, 0, (size_t)n_inst * 8, st));
+    hipLaunchKernelGGL(cc8_init_kernel, dim3(g), dim3(256), 0, st, labels, lab_row_stride, H, W, L);
+    hipLaunchKernelGGL(cc8_merge_kernel, dim3(g), dim3(256), 0, st, labels, lab_row_stride, H, W, L);
+    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(g), dim3(256), 0, st, L, n);
+    hipLaunchKernelGGL(cc8_last_root_kernel, dim3(g), dim3(256), 0, st, labels, lab_row_stride, H, W, (const int*)L, n_inst, start);
     KCHECK();
     return 0;
 }

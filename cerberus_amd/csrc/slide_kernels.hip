@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cmath>
 #include <string>
 
 #include "../../include/cerberus_hip.h"
@@ -70,18 +71,54 @@ __global__ void gather_patches_kernel(const uint8_t* __restrict__ slide, long lo
     }
 }
 
-__global__ void downsample2_inst_kernel(const float* __restrict__ src, long long row_stride, int pix_stride, int ho, int wo, float* __restrict__ dst) {
+// cv2.resize(src, (0, 0), fx=0.5, fy=0.5, INTER_LINEAR): dst size cvRound(n * 0.5) (half to even), source coordinate 2 d + 0.5 ->
+// samples 2d and 2d+1 with weights (.5, .5); where 2d >= n - 1 (odd n, last output) the weights are (1, 0).  With a region
+// (infer/wsi.py:742-776) every source sample is first multiplied by [region_lab[nearest(sy, sx)] == region_id], the nearest
+// mapping being cv2.resize(INTER_NEAREST)'s min(floor(s * mh / h), mh - 1).
+__global__ void downsample2_inst_kernel(const float* __restrict__ src, long long row_stride, int pix_stride, int h, int w, int ho, int wo,
+                                        const int* __restrict__ region_lab, long long lab_row_stride, int mh, int mw, int region_id,
+                                        float* __restrict__ dst) {
     const long long n = (long long)ho * wo;
+    const double fy = 1.0 / ((double)h / (double)mh), fx = 1.0 / ((double)w / (double)mw);  // cv2: 1 / inv_scale
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
         const int y = (int)(p / wo), x = (int)(p % wo);
-        const float* a = src + (2ll * y) * row_stride + (2ll * x) * pix_stride;
-        const float* b = a + row_stride;
+        const int y0 = min(2 * y, h - 1), y1 = min(2 * y + 1, h - 1), x0 = min(2 * x, w - 1), x1 = min(2 * x + 1, w - 1);
+        const float wy1 = (2 * y < h - 1) ? 0.5f : 0.f, wx1 = (2 * x < w - 1) ? 0.5f : 0.f;
+        const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+        float m00 = 1.f, m01 = 1.f, m10 = 1.f, m11 = 1.f;
+        if (region_lab) {
+            const int my0 = min((int)floor(y0 * fy), mh - 1), my1 = min((int)floor(y1 * fy), mh - 1);
+            const int mx0 = min((int)floor(x0 * fx), mw - 1), mx1 = min((int)floor(x1 * fx), mw - 1);
+            m00 = region_lab[my0 * lab_row_stride + mx0] == region_id ? 1.f : 0.f;
+            m01 = region_lab[my0 * lab_row_stride + mx1] == region_id ? 1.f : 0.f;
+            m10 = region_lab[my1 * lab_row_stride + mx0] == region_id ? 1.f : 0.f;
+            m11 = region_lab[my1 * lab_row_stride + mx1] == region_id ? 1.f : 0.f;
+        }
+        const float* a = src + (long long)y0 * row_stride;
+        const float* b = src + (long long)y1 * row_stride;
+        const long long o0 = (long long)x0 * pix_stride, o1 = (long long)x1 * pix_stride;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const float top = a[c] * 0.5f + a[pix_stride + c] * 0.5f;
-            const float bot = b[c] * 0.5f + b[pix_stride + c] * 0.5f;
-            dst[p * 2 + c] = top * 0.5f + bot * 0.5f;
+            const float top = (a[o0 + c] * m00) * wx0 + (a[o1 + c] * m01) * wx1;
+            const float bot = (b[o0 + c] * m10) * wx0 + (b[o1 + c] * m11) * wx1;
+            dst[p * 2 + c] = top * wy0 + bot * wy1;
         }
+    }
+}
+// Patch-Class tissue map (infer/wsi.py:688-716): x0.25 INTER_NEAREST of the class canvas times the INTER_NEAREST-resized mask
+__global__ void pclass_tissue_kernel(const float* __restrict__ pclass, long long row_stride, int h, int w, const uint8_t* __restrict__ mask,
+                                     long long mask_row_stride, int mh, int mw, int ph, int pw, float* __restrict__ dst) {
+    const long long n = (long long)ph * pw;
+    const double fy = 1.0 / ((double)ph / (double)mh), fx = 1.0 / ((double)pw / (double)mw);
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(p / pw), x = (int)(p % pw);
+        const int sy = min(4 * y, h - 1), sx = min(4 * x, w - 1);  // floor(d / 0.25)
+        float v = pclass[sy * row_stride + sx];
+        if (mask) {
+            const int my = min((int)floor(y * fy), mh - 1), mx = min((int)floor(x * fx), mw - 1);
+            v *= mask[my * mask_row_stride + mx] != 0 ? 1.f : 0.f;
+        }
+        dst[p] = v;
     }
 }
 
@@ -109,10 +146,28 @@ extern "C" int cerb_gather_patches(const uint8_t* slide, long long h, long long 
     SK_CHECK();
     return 0;
 }
+static int half_size(int n) { return (int)lrint(n * 0.5); }  // cvRound
+extern "C" int cerb_half_size(int n) { return half_size(n); }
+extern "C" int cerb_downsample2_inst_region(const float* src, long long row_stride, int pix_stride, int h, int w, const int32_t* region_lab,
+                                            long long lab_row_stride, int mh, int mw, int region_id, float* dst, void* hip_stream) {
+    if (!src || !dst || h < 1 || w < 1 || (region_lab && (mh < 1 || mw < 1))) return cerb_set_error("cerb_downsample2_inst: bad arguments");
+    const int ho = half_size(h), wo = half_size(w);
+    if (ho < 1 || wo < 1) return cerb_set_error("cerb_downsample2_inst: map too small");
+    hipLaunchKernelGGL(downsample2_inst_kernel, dim3(grid_for((long long)ho * wo)), dim3(256), 0, (hipStream_t)hip_stream, src, row_stride, pix_stride,
+                       h, w, ho, wo, region_lab, lab_row_stride, region_lab ? mh : 1, region_lab ? mw : 1, region_id, dst);
+    SK_CHECK();
+    return 0;
+}
 extern "C" int cerb_downsample2_inst(const float* src, long long row_stride, int pix_stride, int h, int w, float* dst, void* hip_stream) {
-    if (!src || !dst || h < 2 || w < 2) return cerb_set_error("cerb_downsample2_inst: bad arguments");
-    hipLaunchKernelGGL(downsample2_inst_kernel, dim3(grid_for((long long)(h / 2) * (w / 2))), dim3(256), 0, (hipStream_t)hip_stream, src, row_stride,
-                       pix_stride, h / 2, w / 2, dst);
+    return cerb_downsample2_inst_region(src, row_stride, pix_stride, h, w, nullptr, 0, 0, 0, 0, dst, hip_stream);
+}
+extern "C" int cerb_pclass_tissue_map(const float* pclass, long long row_stride, int h, int w, const uint8_t* mask, long long mask_row_stride,
+                                      int mh, int mw, float* dst, void* hip_stream) {
+    if (!pclass || !dst || h < 1 || w < 1 || (mask && (mh < 1 || mw < 1))) return cerb_set_error("cerb_pclass_tissue_map: bad arguments");
+    const int ph = (int)lrint(h * 0.25), pw = (int)lrint(w * 0.25);
+    if (ph < 1 || pw < 1) return cerb_set_error("cerb_pclass_tissue_map: map too small");
+    hipLaunchKernelGGL(pclass_tissue_kernel, dim3(grid_for((long long)ph * pw)), dim3(256), 0, (hipStream_t)hip_stream, pclass, row_stride, h, w, mask,
+                       mask_row_stride, mask ? mh : 1, mask ? mw : 1, ph, pw, dst);
     SK_CHECK();
     return 0;
 }

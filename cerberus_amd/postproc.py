@@ -133,7 +133,12 @@ def inst_contours_device(inst_map, table):
     h, w = int(inst_map.shape[0]), int(inst_map.shape[1])
     stream = torch.cuda.current_stream(inst_map.device).cuda_stream
     counts = torch.empty(n, dtype=torch.int32, device=inst_map.device)
+    ws = _workspace(inst_map.device, h, w)
+    table = table.clone()  # column 7 becomes the start pixel of the border findContours lists first (several-piece instances)
+    start = torch.empty(n, dtype=torch.int64, device=inst_map.device)
     with torch.cuda.device(inst_map.device):
+        _lib.check(L.cerb_inst_contour_start(inst_map.data_ptr(), inst_map.stride(0), h, w, n, start.data_ptr(), ws.data_ptr(), ws.numel(), C.c_void_p(stream)))
+        table[:, 7] = start
         _lib.check(L.cerb_inst_contour_count(inst_map.data_ptr(), inst_map.stride(0), h, w, n, table.data_ptr(), counts.data_ptr(), C.c_void_p(stream)))
         incl = torch.cumsum(counts.to(torch.int64), 0)
         offsets = (incl - counts).contiguous()

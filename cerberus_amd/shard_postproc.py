@@ -274,18 +274,18 @@ def postprocess_bands_and_gather(run, H, W, rank, world, dist, margin=512, guard
     """The multi-GPU tail of a slide: band-local label maps with slide-global ids, then only the int32 label bands and the
     uint8 / float class canvases travel to the root (12 + 3 B/px instead of the 36 B/px of raw probability canvases).
     `run` is this rank's WSIRunner after infer_band.  Returns (inst, info, small) -- inst / small are None off the root."""
-    from .wsi import band_partition, gather_bands
+    from .wsi import gather_bands, half_size
 
     geo = run.geo
     valid = max(0, min(run.band_h, H - run.r0 * geo.out))
     band = OrderedDict((k, v[:valid, :W]) for k, v in run.canv.items())
     inst_b, info = sharded_postprocess(band, rank, world, dist, wsi_mode=True, margin=margin, guard=guard)
-    bounds = band_partition(geo.rows, world)
+    bounds = geo.bounds(world)
     rows = [max(0, min((bounds[i + 1] - bounds[i]) * geo.out, H - bounds[i] * geo.out)) for i in range(world)]
     inst = OrderedDict() if rank == 0 else None
     for t, lab in inst_b.items():
         half = t != "Nuclei"
-        g = _gather_rows(lab, [r // 2 for r in rows] if half else rows, W // 2 if half else W, dist, rank, world)
+        g = _gather_rows(lab, [half_size(r) for r in rows] if half else rows, half_size(W) if half else W, dist, rank, world)
         if rank == 0:
             inst[t] = g
     small = gather_bands(OrderedDict((k, v) for k, v in run.canv.items() if not k.endswith("INST")), geo, rank, world, dist)

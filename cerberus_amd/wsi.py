@@ -15,7 +15,7 @@ MI355X-first differences (DESIGN.md "WSI driver"):
   * tiles shard across GPUs by contiguous bands of patch rows: one process per GPU, weights replicated, no data-path
     collective during inference; one RCCL gather stitches the per-head maps on rank 0 (infer/base.py:46 DataParallel
     is the only multi-GPU mechanism the reference has).
-Slide file decoding (tiatoolbox WSIReader) and tissue-mask filtering are out of scope (synthetic / array slides).
+Slide file decoding (tiatoolbox WSIReader) is out of scope (synthetic / array slides); tissue masks: cerberus_amd/tissue.py.
 """
 import ctypes as C
 import math
@@ -37,20 +37,53 @@ def band_partition(n_rows, world_size):
     return b
 
 
+def band_partition_weighted(weights, world_size):
+    """Contiguous split of patch rows with per-row work `weights` (selected patches per row under a tissue mask): cut g is
+    the first row at which the running weight reaches g / world of the total; every rank keeps at least one row while rows
+    last.  Uniform weights reproduce band_partition up to rounding of the cut points."""
+    w = np.asarray(weights, np.float64)
+    n = len(w)
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    b = [0]
+    for g in range(1, world_size):
+        cut = int(np.searchsorted(cum, cum[-1] * g / world_size, side="left"))
+        cut = max(cut, b[-1] + 1)           # at least one row for the previous rank
+        cut = min(cut, n - (world_size - g))  # and one left for each later rank
+        b.append(max(min(cut, n), b[-1]))
+    b.append(n)
+    return b
+
+
 class SlideGeometry(object):
     """Patch placement for a slide of (H, W): output tiles of `out` px on a regular grid covering the slide, each
-    fed by a `win` px input window centred on it (context (win-out)//2, mirror padded at the slide border)."""
+    fed by a `win` px input window centred on it (context (win-out)//2, mirror padded at the slide border).
+    patch_sel: optional bool [rows, cols] -- the patches that hold tissue (cerberus_amd.tissue.select_patches); bands are
+    then balanced by the number of selected patches instead of by rows."""
 
-    def __init__(self, slide_hw, patch_input_shape, patch_output_shape):
+    def __init__(self, slide_hw, patch_input_shape, patch_output_shape, patch_sel=None):
         self.H, self.W = int(slide_hw[0]), int(slide_hw[1])
         self.win, self.out = int(patch_input_shape), int(patch_output_shape)
         assert self.win >= self.out and (self.win - self.out) % 2 == 0 and self.win % 16 == 0
         self.ctx = (self.win - self.out) // 2
         self.rows = math.ceil(self.H / self.out)
         self.cols = math.ceil(self.W / self.out)
+        self.patch_sel = None
+        if patch_sel is not None:
+            self.patch_sel = np.asarray(patch_sel, bool).reshape(self.rows, self.cols)
+
+    def out_boxes(self):
+        """int64 [rows*cols, 2, 2] ((y0, x0), (y1, x1)): the output box of every patch of the grid, row-major"""
+        rr, cc = np.meshgrid(np.arange(self.rows), np.arange(self.cols), indexing="ij")
+        tl = np.stack([rr.ravel() * self.out, cc.ravel() * self.out], axis=1)
+        return np.stack([tl, tl + self.out], axis=1).astype(np.int64)
+
+    def bounds(self, world_size):
+        if self.patch_sel is None or world_size == 1:
+            return band_partition(self.rows, world_size)
+        return band_partition_weighted(self.patch_sel.sum(axis=1) + 1e-3, world_size)
 
     def band(self, rank, world_size):
-        b = band_partition(self.rows, world_size)
+        b = self.bounds(world_size)
         return b[rank], b[rank + 1]
 
     def input_rows(self, r0, r1):
@@ -85,9 +118,14 @@ def gather_patches(slab, slab_y0, full_h, tl_y, tl_x, win):
     return tiles
 
 
+def half_size(n):
+    """side of cv2.resize(fx=0.5): cvRound(n * 0.5), half to even (== cerb_half_size)"""
+    return int(round(n * 0.5))
+
+
 def downsample2_inst(inst):
     h, w = int(inst.shape[0]), int(inst.shape[1])
-    out = torch.empty((h // 2, w // 2, 2), dtype=torch.float32, device=inst.device)
+    out = torch.empty((half_size(h), half_size(w), 2), dtype=torch.float32, device=inst.device)
     st = torch.cuda.current_stream(inst.device).cuda_stream
     with torch.cuda.device(inst.device):
         _lib.check(_lib.lib().cerb_downsample2_inst(inst.data_ptr(), inst.stride(0), inst.stride(1), h, w, out.data_ptr(), C.c_void_p(st)))
@@ -99,7 +137,7 @@ def gather_bands(canv, geo, rank, world, dist=None):
     canv: OrderedDict head-key -> this rank's band tensor [(r1-r0)*out, cols*out, ...] (any device).
     Every rank pads its band to the tallest band so one `dist.gather` per head suffices (backend "nccl" = RCCL over
     xGMI on the GPU box, "gloo" in the CPU tests)."""
-    bounds = band_partition(geo.rows, world)
+    bounds = geo.bounds(world)
     if world == 1 or dist is None:
         return OrderedDict((k, v[: geo.H, : geo.W]) for k, v in canv.items())
     max_rows = max(bounds[i + 1] - bounds[i] for i in range(world)) * geo.out
@@ -118,9 +156,9 @@ def gather_bands(canv, geo, rank, world, dist=None):
 class WSIRunner(object):
     """One per process / GPU."""
 
-    def __init__(self, net, slide_hw, patch_input_shape=256, patch_output_shape=256, batch_size=32, rank=0, world_size=1):
+    def __init__(self, net, slide_hw, patch_input_shape=256, patch_output_shape=256, batch_size=32, rank=0, world_size=1, patch_sel=None):
         self.net = net
-        self.geo = SlideGeometry(slide_hw, patch_input_shape, patch_output_shape)
+        self.geo = SlideGeometry(slide_hw, patch_input_shape, patch_output_shape, patch_sel)
         self.batch = int(batch_size)
         self.rank, self.world = int(rank), int(world_size)
         self.r0, self.r1 = self.geo.band(self.rank, self.world)
@@ -139,6 +177,9 @@ class WSIRunner(object):
         self._outs = [self.canv[d[3]] for d in net._decoders]
         # patch list of this band, row-major
         rr, cc = np.meshgrid(np.arange(self.r0, self.r1), np.arange(g.cols), indexing="ij")
+        if g.patch_sel is not None:  # patches without tissue never run; their canvas pixels stay 0 (infer/wsi.py:565-569)
+            keep = g.patch_sel[self.r0:self.r1]
+            rr, cc = rr[keep], cc[keep]
         self.n_patches = rr.size
         self._tl_y = torch.from_numpy((rr.ravel() * g.out - g.ctx).astype(np.int64)).to(self.dev)
         self._tl_x = torch.from_numpy((cc.ravel() * g.out - g.ctx).astype(np.int64)).to(self.dev)
@@ -175,7 +216,9 @@ class WSIRunner(object):
             if key not in canv:
                 continue
             if wsi_mode:
-                inst[t], info[t] = postproc_device(downsample2_inst(canv[key]), t, 0.5)
+                from .tissue import half_inst_region
+
+                inst[t], info[t] = postproc_device(half_inst_region(canv[key]), t, 0.5)
             else:
                 inst[t], info[t] = postproc_device(canv[key], t, 1.0)
         if "Lumen" in inst and "Gland" in inst:
@@ -183,19 +226,29 @@ class WSIRunner(object):
         return inst, info
 
 
-def build_wsi_inst_info(inst, canv, slide_hw, proc_mag, ds_factor=0.5):
+def build_wsi_inst_info(inst, canv, slide_hw, proc_mag, ds_factor=0.5, region_records=None):
     """The dictionary the reference dumps as dat/<slide>.dat (infer/wsi.py:805-853): per tissue {uuid4 hex -> {'box':
     [x1, y1, x2, y2], 'centroid', 'contour', 'type', 'type_prob'}} plus resolution metadata.  Gland / lumen label maps are
     at x`ds_factor` and their coordinates are scaled back (get_inst_info_dict(..., ds_factor)); nuclei are at full
     resolution.  Per-instance reductions and border following run on the GPU (cerb_inst_table / cerb_inst_contour_*).
     Deviation: the class map handed to the half-resolution tissues is the strided sub-sample of the uint8 class canvas; the
-    reference bilinearly resizes class ids together with the probabilities (cv2.resize, infer/wsi.py:786-788)."""
+    reference bilinearly resizes class ids together with the probabilities (cv2.resize, infer/wsi.py:786-788).
+    region_records: cerberus_amd.tissue.postprocess_regions(...) when the slide has a tissue mask -- the gland / lumen entries then
+    come from the per-region dictionaries (already in slide coordinates) and `inst` only supplies the nuclei."""
     import uuid
 
     from .postproc import get_inst_info_dict
 
     out = OrderedDict()
+    if region_records is not None:
+        for rec in region_records:
+            for tissue, d in rec["info"].items():
+                dst = out.setdefault(tissue, OrderedDict())
+                for v in d.values():
+                    dst[uuid.uuid4().hex] = v
     for tissue, lab in inst.items():
+        if region_records is not None and tissue != "Nuclei":
+            continue
         tkey = tissue + "-TYPE"
         half = tuple(lab.shape) != tuple(int(v) for v in slide_hw)
         tmap = canv.get(tkey)

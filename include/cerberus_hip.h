@@ -119,13 +119,30 @@ int cerb_mask_lumen_by_gland(int32_t* lumen_labels, const int32_t* gland_labels,
  *                       mirror-padded outside the slide like np.pad(..., "reflect") (infer/tile.py:69); `slide` holds
  *                       rows [slide_y0, slide_y0+h) of a slide that is full_h rows tall (a rank's band + halo).
  *                       Replaces loader/infer_loader.py:54-69 / infer/wsi.py:936-950 for a resident slide.
- * cerb_downsample2_inst: dst[h/2][w/2][2] = 2x2 box average of an INST map == cv2.resize(fx=0.5, INTER_LINEAR)
- *                       (infer/wsi.py:786-788). */
+ * cerb_downsample2_inst: dst[cerb_half_size(h)][cerb_half_size(w)][2] = cv2.resize(src, (0,0), fx=0.5, fy=0.5, INTER_LINEAR)
+ *                       of an INST map (infer/wsi.py:786-788): the 2x2 box average, and for an odd side whose half rounds up
+ *                       (cvRound, half to even) the last row / column replicated.
+ * cerb_downsample2_inst_region: the same after multiplying the map by one tissue region of the slide mask
+ *                       (infer/wsi.py:742-776): region_lab = int32 label map of the mask (cerb_label_mask) cropped to the
+ *                       region's bounding box [mh][mw], resized to [h][w] like cv2.resize(INTER_NEAREST); samples whose
+ *                       mask label != region_id count as 0.  region_lab NULL = no mask.
+ * cerb_pclass_tissue_map: dst[cvRound(h/4)][cvRound(w/4)] = cv2.resize(pclass, fx=fy=0.25, INTER_NEAREST) times the
+ *                       INTER_NEAREST-resized slide mask (infer/wsi.py:688-716); mask NULL = all tissue.
+ * cerb_label_mask     : 4-connected components of mask != 0, ids in raster order of first pixel (scipy.ndimage.label,
+ *                       infer/wsi.py:724); ws as for cerb_postproc_*; n_out = device int32[1] number of regions. */
 int cerb_synth_slide(uint8_t* out, long long h, long long w, long long y0, long long x0, uint32_t seed, void* hip_stream);
 int cerb_gather_patches(const uint8_t* slide, long long h, long long w, long long slide_y0, long long full_h,
                         const long long* tl_y, const long long* tl_x, int n, int win, uint8_t* tiles, void* hip_stream);
 int cerb_downsample2_inst(const float* src, long long row_stride, int pix_stride, int h, int w, float* dst,
                           void* hip_stream);
+int cerb_half_size(int n);
+int cerb_downsample2_inst_region(const float* src, long long row_stride, int pix_stride, int h, int w,
+                                 const int32_t* region_lab, long long lab_row_stride, int mh, int mw, int region_id,
+                                 float* dst, void* hip_stream);
+int cerb_pclass_tissue_map(const float* pclass, long long row_stride, int h, int w, const uint8_t* mask,
+                           long long mask_row_stride, int mh, int mw, float* dst, void* hip_stream);
+int cerb_label_mask(const uint8_t* mask, long long row_stride, int h, int w, int32_t* labels_out, int32_t* n_out,
+                    void* ws, size_t ws_bytes, void* hip_stream);
 
 /* ---- instance table: the segmented reductions of get_inst_info_dict (loader/postproc.py:12-75) on the device --------
  * labels: int32 label map (row stride in elements); type_map: optional uint8 class map (NULL = none).
@@ -136,11 +153,18 @@ int cerb_inst_table(const int32_t* labels, long long lab_row_stride, const uint8
                     int h, int w, int n_inst, long long* table, void* hip_stream);
 
 /* Outer border of every instance = cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE)[0][0] of loader/postproc.py:29-41
- * (Suzuki-Abe border following, 8-connected foreground, start at the instance's first pixel -- `table` is cerb_inst_table's
- * output -- first move downwards/counter-clockwise, a point is kept where the chain code changes).  Two passes:
+ * (Suzuki-Abe border following, 8-connected foreground, start at pixel table[i][7] -- `table` is cerb_inst_table's output,
+ * whose column 7 is the instance's first pixel: right for an instance that is ONE 8-connected piece; for several pieces
+ * overwrite the column with cerb_inst_contour_start's result -- first move downwards/counter-clockwise, a point is kept where
+ * the chain code changes).  Two passes:
  *   cerb_inst_contour_count  -> counts[i]  = number of points of instance i+1 (0 for absent ids)
  *   cerb_inst_contour_points -> points[2*(offsets[i] + k)] = x, [.. + 1] = y of point k; offsets = exclusive scan of counts (int64).
+ * cerb_inst_contour_start -> start[i] = y*w + x of the pixel whose border findContours returns FIRST: OpenCV lists top-level
+ *   contours most-recently-found first, so [0][0] belongs to the 8-connected piece whose first pixel comes last in raster
+ *   order (one union-find pass over the label map; ws >= 4*h*w bytes).
  * OpenCV is not installed in this image: restated from the published algorithm, not pinned against the library. */
+int cerb_inst_contour_start(const int32_t* labels, long long lab_row_stride, int h, int w, int n_inst, long long* start,
+                            void* ws, size_t ws_bytes, void* hip_stream);
 int cerb_inst_contour_count(const int32_t* labels, long long lab_row_stride, int h, int w, int n_inst, const long long* table,
                             int32_t* counts, void* hip_stream);
 int cerb_inst_contour_points(const int32_t* labels, long long lab_row_stride, int h, int w, int n_inst, const long long* table,

@@ -114,3 +114,49 @@ def findContours(mask, mode=RETR_TREE, method=CHAIN_APPROX_SIMPLE):
     last = int(np.max(starts))
     pts = _trace_outer(mask, last % mask.shape[1], last // mask.shape[1], method)
     return [np.array(pts, dtype=np.int32).reshape(-1, 1, 2)], None
+
+
+def _round_half_even(v):
+    return int(np.rint(v))  # cvRound
+
+
+def resize(src, dsize, fx=0.0, fy=0.0, interpolation=INTER_LINEAR):
+    """cv2.resize restated for the two modes infer/wsi.py reaches (:691-697, :706-710, :761-765, :786-788).  Unpinned: OpenCV
+    is absent.  Size: dsize, or cvRound(src * f) when dsize is (0, 0); inverse scale = f in the second case and dsize / ssize in
+    the first, source scale = 1 / inverse scale (double).  INTER_NEAREST: s = min(floor(d * scale), ssize - 1).  INTER_LINEAR:
+    f = (d + 0.5) * scale - 0.5, s = floor(f), w = f - s; s < 0 -> (0, w = 0); s >= ssize - 1 -> (ssize - 1, w = 0); float32
+    weights, horizontal pass then vertical pass, each d = a * (1 - w) + b * w."""
+    src = np.asarray(src)
+    H, W = src.shape[:2]
+    if dsize is None or tuple(dsize) == (0, 0):
+        inv_x, inv_y = float(fx), float(fy)
+        dw, dh = _round_half_even(W * inv_x), _round_half_even(H * inv_y)
+    else:
+        dw, dh = int(dsize[0]), int(dsize[1])
+        inv_x, inv_y = dw / W, dh / H
+    sx_scale, sy_scale = 1.0 / inv_x, 1.0 / inv_y
+
+    def nearest(n_dst, n_src, scale):
+        return np.minimum(np.floor(np.arange(n_dst) * scale).astype(np.int64), n_src - 1)
+
+    if interpolation == INTER_NEAREST:
+        return src[nearest(dh, H, sy_scale)][:, nearest(dw, W, sx_scale)].copy()
+    assert interpolation == INTER_LINEAR
+
+    def taps(n_dst, n_src, scale):
+        f = (np.arange(n_dst) + 0.5) * scale - 0.5
+        s = np.floor(f).astype(np.int64)
+        w = (f - s).astype(np.float32)
+        lo = s < 0
+        s[lo], w[lo] = 0, 0.0
+        hi = s >= n_src - 1
+        s[hi], w[hi] = n_src - 1, 0.0
+        return s, np.minimum(s + 1, n_src - 1), w
+
+    a = src.astype(np.float32)
+    x0, x1, wx = taps(dw, W, sx_scale)
+    y0, y1, wy = taps(dh, H, sy_scale)
+    shape_x = (1, dw) + (1,) * (a.ndim - 2)
+    hor = a[:, x0] * (np.float32(1) - wx).reshape(shape_x) + a[:, x1] * wx.reshape(shape_x)
+    shape_y = (dh, 1) + (1,) * (a.ndim - 2)
+    return (hor[y0] * (np.float32(1) - wy).reshape(shape_y) + hor[y1] * wy.reshape(shape_y)).astype(np.float32)

@@ -3,7 +3,9 @@ PNG / JPG image, or a `.txt` file holding `synthetic:<H>x<W>:<seed>` (slide-file
 of scope).  The slide band of this rank lives in HBM; patches are gathered, inferred and scattered on the device, the band is
 labelled on the device, and only the instance dictionary is written -- `dat/<slide>.dat` in the reference's joblib format
 (infer/wsi.py:844-853 there).  Flag names and defaults are the reference's (cerberus_amd/cli.py); the tiling / cache flags it
-parses and then overrides with constants are accepted and ignored.
+parses and then overrides with constants are accepted and ignored.  `--msk_dir` tissue masks are honoured: patches without
+tissue do not run, the Patch-Class map is masked, gland / lumen are labelled per tissue region (cerberus_amd/tissue.py); every
+slide also gets `tissue/<slide>.mat` (infer/wsi.py:688-716).
 
 Multi-GPU: launch under `python -m torch.distributed.run --nproc-per-node N run_infer_wsi.py ...`; patch rows shard into one
 contiguous band per rank, inference needs no collective, post-processing is band-local (cerberus_amd/shard_postproc.py)."""
@@ -14,6 +16,11 @@ import time
 import numpy as np
 
 from cerberus_amd.cli import WSI_OPTIONS, parse
+
+
+def _basename(path, ext):
+    base = os.path.basename(path)
+    return base[: -len(ext)] if ext else base
 
 
 def _open_slide(path):
@@ -65,35 +72,71 @@ def main(argv=None):
     ext = args["--wsi_file_ext"]
     slides = sorted(glob.glob(os.path.join(args["--input_dir"], "*" + ext))) if args["--input_dir"] else []
     step, bulk = int(args["--wsi_proc_step"]), int(args["--wsi_bulk_idx"])  # the reference's batch-of-slides window
+    msk_dir = args["--msk_dir"]
+    if msk_dir:  # only slides that have a mask are considered (run_infer_wsi.py:76-83 there)
+        slides = [p for p in slides if os.path.isfile(os.path.join(msk_dir, _basename(p, ext) + ".png"))]
     slides = slides[(bulk - 1) * step: bulk * step]
     print("Number of WSIs in list:", len(slides))
     win, out, batch = int(args["--patch_input_shape"]), int(args["--patch_output_shape"]), int(args["--batch_size"])
     for path in slides:
-        base = os.path.basename(path)
-        base = base[: -len(ext)] if ext else base
+        base = _basename(path, ext)
         dat_path = os.path.join(out_dir, "dat", base + ".dat")
         if os.path.exists(dat_path):  # a finished slide is skipped on re-runs
             continue
         t0 = time.perf_counter()
         host, H, W, seed = _open_slide(path)
-        run = WSIRunner(manager.net, (H, W), win, out, batch, rank, world)
+        mask, sel, regions = None, None, None
+        if msk_dir:
+            from cerberus_amd.tissue import TissueRegions, load_mask, select_patches
+            from cerberus_amd.wsi import SlideGeometry
+
+            mask = load_mask(os.path.join(msk_dir, base + ".png"))
+            sel = select_patches(mask, SlideGeometry((H, W), win, out).out_boxes(), (H, W))
+            if rank == 0 and args["--save_mask"]:
+                from PIL import Image
+
+                os.makedirs(os.path.join(out_dir, "mask"), exist_ok=True)
+                Image.fromarray(mask * 255).save(os.path.join(out_dir, "mask", base + ".png"))
+        run = WSIRunner(manager.net, (H, W), win, out, batch, rank, world, patch_sel=sel)
         y0, y1 = run.slab_rows()  # this rank's band + context halo
         slab = synth_slide(y1 - y0, W, y0=y0, seed=seed) if host is None else torch.from_numpy(np.ascontiguousarray(host[y0:y1])).cuda()
         run.infer_band(slab, y0)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        if world > 1:  # band-local labelling with slide-global ids; only int32 label bands and the class maps travel to the root
+        records = None
+        if world > 1 and mask is None:  # band-local labelling with slide-global ids; only int32 label bands and the class maps travel to the root
             from cerberus_amd.shard_postproc import postprocess_bands_and_gather
 
             inst, _, maps = postprocess_bands_and_gather(run, H, W, rank, world, dist)
-        else:
+        else:  # with a mask gland / lumen are labelled per tissue region (infer/wsi.py:730-835), on the root
             maps = run.gather_to_root(dist)
-            inst, _ = WSIRunner.postprocess(maps, wsi_mode=True)
+            if rank == 0 and mask is not None:
+                from cerberus_amd.postproc import postproc_device
+                from cerberus_amd.tissue import postprocess_regions
+
+                regions = TissueRegions(torch.from_numpy(mask).cuda())
+                inst = {"Nuclei": postproc_device(maps["Nuclei-INST"], "Nuclei")[0]} if "Nuclei-INST" in maps else {}
+                records = postprocess_regions(maps, (H, W), regions)
+            elif rank == 0:
+                inst, _ = WSIRunner.postprocess(maps, wsi_mode=True)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         if rank != 0:
             continue
+        if "Patch-Class" in maps:  # tissue-region map (infer/wsi.py:688-716)
+            import scipy.io as sio
+
+            from cerberus_amd.tissue import pclass_tissue_map
+
+            os.makedirs(os.path.join(out_dir, "tissue"), exist_ok=True)
+            pmap = pclass_tissue_map(maps["Patch-Class"], None if regions is None else regions.mask)
+            sio.savemat(os.path.join(out_dir, "tissue", base + ".mat"), {"pclass": pmap.cpu().numpy()})
         if args["--save_label_maps"]:  # the reference keeps only the instance dictionary; the maps are for tests / inspection
+            if records is not None:  # per-region maps live on their own half-resolution grids
+                for i, rec in enumerate(records):
+                    for k, v in rec["inst"].items():
+                        inst["%s_region%d" % (k, i)] = v
+                    inst["topleft_region%d" % i] = torch.tensor(rec["topleft"])
             np.savez_compressed(os.path.join(out_dir, base + ".npz"), **{k: v.cpu().numpy() for k, v in inst.items()},
                                 **{"type_" + k: v.cpu().numpy() for k, v in maps.items() if k.endswith("TYPE")},
                                 pclass=maps.get("Patch-Class").cpu().numpy()[::4, ::4])
@@ -101,7 +144,8 @@ def main(argv=None):
         import joblib
 
         os.makedirs(os.path.dirname(dat_path), exist_ok=True)
-        joblib.dump(build_wsi_inst_info(inst, maps, (H, W), float(args["--wsi_proc_mag"])), dat_path)
+        nuc_only = {k: v for k, v in inst.items() if k == "Nuclei"} if records is not None else inst
+        joblib.dump(build_wsi_inst_info(nuc_only, maps, (H, W), float(args["--wsi_proc_mag"]), region_records=records), dat_path)
         t4 = time.perf_counter()
         print("%s: Inference Time: %.3f  Post Proc Time: %.3f  Instance Table Time: %.3f  (%.1f Mpx/s inference)" % (
             base, t1 - t0, t2 - t1, t4 - t3, H * W / (t1 - t0) / 1e6))

@@ -58,3 +58,40 @@ def test_run_infer_wsi_cli_synthetic(tmp_path):
     for t in ("Nuclei", "Gland", "Lumen"):
         for uid, d in dat[t].items():
             assert len(uid) == 32 and d["box"].shape == (4,) and d["contour"].ndim == 2 and d["contour"].shape[1] == 2 and (("type" in d) == (t != "Lumen"))
+
+
+def test_run_infer_wsi_cli_with_tissue_mask(tmp_path):
+    """--msk_dir: slides without a mask are skipped, patches without tissue never run (their canvas pixels stay 0), the tissue
+    map and the dictionary are written (infer/wsi.py:533-569, 688-853)."""
+    import joblib
+    import scipy.io as sio
+    from PIL import Image
+
+    spec, msk, out = tmp_path / "slides", tmp_path / "masks", tmp_path / "out"
+    spec.mkdir()
+    msk.mkdir()
+    (spec / "s1.txt").write_text("synthetic:1000x1300:5")
+    (spec / "nomask.txt").write_text("synthetic:600x600:6")
+    m = np.zeros((100, 130), np.uint8)  # 1/10 resolution; two tissue regions in the left part of the slide
+    m[5:45, 4:50] = 255
+    m[60:95, 20:70] = 255
+    Image.fromarray(np.stack([m] * 3, -1)).save(str(msk / "s1.png"))
+    cmd = [sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--input_dir=%s" % spec, "--msk_dir=%s" % msk, "--wsi_file_ext=.txt",
+           "--output_dir=%s" % out, "--batch_size=6", "--patch_input_shape=256", "--patch_output_shape=256", "--save_label_maps", "--save_mask"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Number of WSIs in list: 1" in r.stdout and not (out / "dat" / "nomask.dat").exists()
+    z = np.load(str(out / "s1.npz"))
+    assert z["Nuclei"].shape == (1000, 1300)
+    # patch columns 3.. (x >= 768) hold no mask pixel (mask columns >= 70 are empty, 70 * 10 = 700 < 768): nothing ran there
+    assert z["pclass"][:, 768 // 4:].max() == 0 and z["Nuclei"][:, 768:].max() == 0 and z["type_Nuclei-TYPE"][:, 768:].max() == 0
+    assert "Gland_region0" in z.files and "Gland_region1" in z.files and list(z["topleft_region1"]) == [200, 600]
+    assert z["Gland_region0"].shape == (200, 230)  # the region's box (400 x 460 px at slide resolution) at x0.5
+    t = sio.loadmat(str(out / "tissue" / "s1.mat"))["pclass"]
+    assert t.shape == (250, 325) and t[:, 175:].max() == 0  # mask columns >= 70 -> tissue-map columns >= 175
+    assert np.array_equal(np.array(Image.open(str(out / "mask" / "s1.png"))) > 0, m > 0)
+    dat = joblib.load(str(out / "dat" / "s1.dat"))
+    assert set(dat.keys()) >= {"Nuclei", "proc_resolution", "base_resolution", "proc_dimensions", "base_dimensions"}
+    for tname in ("Gland", "Lumen"):
+        for d in dat.get(tname, {}).values():
+            assert d["box"].shape == (4,) and d["contour"].shape[1] == 2

@@ -196,6 +196,34 @@ def test_contours_nuclei_and_degenerate_shapes():
     assert got[5]["contour"].tolist() == [[10, 24], [10, 33], [21, 33], [21, 24]]
 
 
+def test_contour_of_an_instance_in_several_pieces():
+    """A lumen cut by its gland's edge, or a gland partly overwritten by a later one, is several 8-connected pieces under one id.
+    findContours(...)[0][0] (loader/postproc.py:29-33) is then the border of the piece found LAST in the raster scan (OpenCV lists
+    top-level contours most-recently-found first): cerb_inst_contour_start picks that piece; pieces joined only diagonally are one."""
+    from cerberus_amd.postproc import get_inst_info_dict
+
+    L = np.zeros((60, 70), np.int32)
+    L[2:12, 3:15] = 1       # piece A of instance 1 (first in raster order)
+    L[20:33, 40:60] = 1     # piece B
+    L[33:40, 60:66] = 1     # joined to B through one diagonal contact (32,59)-(33,60): same piece
+    L[45:50, 5:30] = 1      # piece C: starts last -> its border is the one reported
+    L[15:30, 5:20] = 2      # instance 2, one piece, with a hole
+    L[20:25, 10:15] = 0
+    L[52:58, 40:44] = 3     # instance 3: two pieces side by side on the same rows -> the right one starts later
+    L[52:58, 50:57] = 3
+    rs = np.random.RandomState(0)
+    R = (rs.rand(90, 110) < 0.55).astype(np.int32) * rs.randint(1, 6, (90, 110))  # salt: ids in many 8-connected fragments
+    for lab in (L, R):
+        got = get_inst_info_dict(lab)
+        ref = pr.inst_info_ref(lab)
+        assert sorted(got.keys()) == sorted(ref.keys())
+        for k in got:
+            assert np.array_equal(got[k]["contour"], ref[k]["contour"]), k
+    got = get_inst_info_dict(L)
+    assert got[1]["contour"].tolist() == [[5, 45], [5, 49], [29, 49], [29, 45]]
+    assert got[3]["contour"].tolist() == [[50, 52], [50, 57], [56, 57], [56, 52]]
+
+
 @pytest.mark.parametrize("tissue", ["Nuclei", "Gland", "Lumen"])
 def test_postproc_is_bitwise_reproducible(tissue):
     """The CCL / flood kernels use atomics and lock-free union-find; the label maps must not depend on scheduling."""
