@@ -64,7 +64,8 @@ def erode(src, kernel, iterations=1):
 # with OpenCV's documented conventions: 8-connected foreground; Freeman codes 0..7 = E, NE, N, NW, W, SW, S, SE (y down);
 # raster scan finds outer-border start pixels; top-level contours are returned most-recently-found first, so [0][0] is the
 # outer border of the component whose start pixel comes LAST in raster order; CHAIN_APPROX_SIMPLE keeps the points at which
-# the chain code changes.  PARITY UNPINNED against the real library.
+# the chain code changes.  Not modelled: a piece nested in a hole of another piece (not top-level under RETR_TREE).
+# PARITY UNPINNED against the real library.
 RETR_TREE, CHAIN_APPROX_SIMPLE, CHAIN_APPROX_NONE = 3, 2, 1
 _CODE = [(1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1), (0, 1), (1, 1)]  # (dx, dy)
 
