@@ -226,6 +226,19 @@ class WSIRunner(object):
         return inst, info
 
 
+def _uuid4_hex(n):
+    """n random uuid4().hex strings from one os.urandom call (a slide has ~1e6 instances; uuid.uuid4() costs a syscall each)."""
+    import os
+
+    if n == 0:
+        return []
+    raw = np.frombuffer(os.urandom(16 * n), np.uint8).reshape(n, 16).copy()
+    raw[:, 6] = (raw[:, 6] & 0x0F) | 0x40  # version 4
+    raw[:, 8] = (raw[:, 8] & 0x3F) | 0x80  # RFC 4122 variant
+    hx = raw.tobytes().hex()
+    return [hx[i:i + 32] for i in range(0, 32 * n, 32)]
+
+
 def build_wsi_inst_info(inst, canv, slide_hw, proc_mag, ds_factor=0.5, region_records=None):
     """The dictionary the reference dumps as dat/<slide>.dat (infer/wsi.py:805-853): per tissue {uuid4 hex -> {'box':
     [x1, y1, x2, y2], 'centroid', 'contour', 'type', 'type_prob'}} plus resolution metadata.  Gland / lumen label maps are
@@ -254,15 +267,21 @@ def build_wsi_inst_info(inst, canv, slide_hw, proc_mag, ds_factor=0.5, region_re
         tmap = canv.get(tkey)
         if tmap is not None and half:
             tmap = tmap[::2, ::2][: lab.shape[0], : lab.shape[1]].contiguous()
-        info = get_inst_info_dict(lab.contiguous(), tmap, ds_factor if half else 1.0)
-        d = OrderedDict()
-        for _, v in info.items():
-            b = v["box"]
-            v["box"] = np.array([b[0][1], b[0][0], b[1][1], b[1][0]])
-            d[uuid.uuid4().hex] = v
-        out[tissue] = d
+        info = get_inst_info_dict(lab.contiguous(), tmap, ds_factor if half else 1.0, flat_box=True)
+        out[tissue] = OrderedDict(zip(_uuid4_hex(len(info)), info.values()))
     out["proc_resolution"] = {"resolution": float(proc_mag), "units": "mpp"}
     out["base_resolution"] = {"resolution": float(proc_mag), "units": "mpp"}  # arrays / synthetic slides carry no pyramid
     out["proc_dimensions"] = np.array([int(slide_hw[0]), int(slide_hw[1])])  # YX
     out["base_dimensions"] = np.array([int(slide_hw[0]), int(slide_hw[1])])
     return out
+
+
+def write_dat(obj, path):
+    """dat/<slide>.dat (infer/wsi.py:853 `joblib.dump(wsi_inst_info, ...)`).  Written as a plain protocol-4 pickle: `joblib.load`
+    -- what consumers of the reference's files call -- reads it back to the same objects, and for a dictionary of ~1e6 instances
+    with three small arrays each it is an order of magnitude faster to write (and twice as fast to load) than joblib's per-array
+    wrapper stream."""
+    import pickle
+
+    with open(path, "wb") as fh:
+        pickle.dump(obj, fh, protocol=4)

@@ -47,7 +47,7 @@ def main(argv=None):
 
     from cerberus_amd.tile import InferManager
     from cerberus_amd.weights import DEFAULT_REQ_TARGET_CODE, default_model_kwargs
-    from cerberus_amd.wsi import WSIRunner, build_wsi_inst_info, synth_slide
+    from cerberus_amd.wsi import WSIRunner, build_wsi_inst_info, synth_slide, write_dat
 
     dist = None
     torch.cuda.set_device(local)
@@ -141,11 +141,9 @@ def main(argv=None):
                                 **{"type_" + k: v.cpu().numpy() for k, v in maps.items() if k.endswith("TYPE")},
                                 pclass=maps.get("Patch-Class").cpu().numpy()[::4, ::4])
         t3 = time.perf_counter()
-        import joblib
-
         os.makedirs(os.path.dirname(dat_path), exist_ok=True)
         nuc_only = {k: v for k, v in inst.items() if k == "Nuclei"} if records is not None else inst
-        joblib.dump(build_wsi_inst_info(nuc_only, maps, (H, W), float(args["--wsi_proc_mag"]), region_records=records), dat_path)
+        write_dat(build_wsi_inst_info(nuc_only, maps, (H, W), float(args["--wsi_proc_mag"]), region_records=records), dat_path)
         t4 = time.perf_counter()
         print("%s: Inference Time: %.3f  Post Proc Time: %.3f  Instance Table Time: %.3f  (%.1f Mpx/s inference)" % (
             base, t1 - t0, t2 - t1, t4 - t3, H * W / (t1 - t0) / 1e6))

@@ -212,3 +212,85 @@ def test_overlay_rendering():
     assert (out == np.array(DEFAULT_VIZ_INFO["lumen"]["inst_colour"], np.uint8)).all(axis=2).sum() > 50
     up = up2_nearest(np.arange(12, dtype=np.uint8).reshape(2, 2, 3))
     assert up.shape == (4, 4, 3) and np.array_equal(up[0, 0], up[1, 1]) and np.array_equal(up[0, 2], up[1, 3])
+
+
+def _info_slow(tab, cnts, pts, offs, has_type, ds):
+    """the per-instance loop info_from_table replaces (loader/postproc.py:12-98 semantics), kept here as its checker"""
+    from collections import OrderedDict
+
+    info = OrderedDict()
+    for i in range(tab.shape[0]):
+        area, sx, sy, y1, y2, x1, x2 = [int(v) for v in tab[i, :7]]
+        if area == 0 or cnts[i] < 3:
+            continue
+        d = {"box": np.array([[y1, x1], [y2, x2]]), "centroid": np.array([sx / area, sy / area]), "contour": pts[offs[i]: offs[i] + cnts[i]].copy()}
+        if has_type:
+            cnt = tab[i, 8:16]
+            order = [k for k in sorted(range(8), key=lambda k: (-int(cnt[k]), k)) if cnt[k] > 0]
+            t = order[0]
+            if t == 0 and len(order) > 1:
+                t = order[1]
+            d["type"], d["type_prob"] = int(t), float(cnt[t] / (area + 1.0e-6))
+        if ds != 1.0:
+            for f in ("box", "centroid", "contour"):
+                d[f] = np.round(d[f] / ds).astype("int")
+        info[i + 1] = d
+    return info
+
+
+def test_info_from_table_equals_the_per_instance_loop():
+    from cerberus_amd.postproc import info_from_table
+
+    rs = np.random.RandomState(11)
+    for has_type in (False, True):
+        for ds in (1.0, 0.5):
+            n = 300
+            tab = np.zeros((n, 16), np.int64)
+            tab[:, 0] = rs.randint(0, 50, n) * (rs.rand(n) < 0.9)
+            tab[:, 1:3] = rs.randint(0, 10 ** 6, (n, 2))
+            tab[:, 3:7] = rs.randint(0, 5000, (n, 4))
+            for i in range(n):  # type votes summing to the area, with ties and background-only rows
+                left = int(tab[i, 0])
+                for k in rs.permutation(8)[: rs.randint(1, 4)]:
+                    v = rs.randint(0, left + 1)
+                    tab[i, 8 + k] += v
+                    left -= v
+                tab[i, 8 + rs.randint(0, 8)] += left
+            cnts = rs.randint(0, 12, n).astype(np.int32)
+            offs = (np.cumsum(cnts) - cnts).astype(np.int64)
+            pts = rs.randint(0, 5000, (int(cnts.sum()), 2)).astype(np.int32)
+            got = info_from_table(tab, cnts, pts, offs, has_type, ds)
+            exp = _info_slow(tab, cnts, pts, offs, has_type, ds)
+            assert list(got.keys()) == list(exp.keys()) and len(got) > 100
+            for k in exp:
+                assert set(got[k].keys()) == set(exp[k].keys())
+                for f in ("box", "centroid", "contour"):
+                    assert np.array_equal(got[k][f], exp[k][f]) and got[k][f].dtype == exp[k][f].dtype, (k, f)
+                if has_type:
+                    assert got[k]["type"] == exp[k]["type"] and type(got[k]["type"]) is int
+                    assert got[k]["type_prob"] == exp[k]["type_prob"] and type(got[k]["type_prob"]) is float
+            flat = info_from_table(tab, cnts, pts, offs, has_type, ds, flat_box=True)
+            for k in exp:
+                b = exp[k]["box"]
+                assert flat[k]["box"].tolist() == [b[0][1], b[0][0], b[1][1], b[1][0]]
+
+
+def test_dat_writer_is_readable_by_joblib_and_uuids_are_version_4(tmp_path):
+    import uuid
+
+    import joblib
+
+    from cerberus_amd.wsi import _uuid4_hex, write_dat
+
+    ids = _uuid4_hex(5000)
+    assert len(set(ids)) == 5000 and _uuid4_hex(0) == []
+    for h in ids[:200]:
+        u = uuid.UUID(hex=h)
+        assert len(h) == 32 and u.version == 4 and u.variant == uuid.RFC_4122 and u.hex == h
+    obj = {"Nuclei": {ids[i]: {"box": np.arange(4) + i, "centroid": np.array([0.5, i]), "contour": np.arange(8, dtype=np.int32).reshape(4, 2), "type": 3, "type_prob": 0.25}
+                      for i in range(50)}, "proc_dimensions": np.array([7, 9])}
+    write_dat(obj, str(tmp_path / "s.dat"))
+    back = joblib.load(str(tmp_path / "s.dat"))
+    assert list(back["Nuclei"].keys()) == list(obj["Nuclei"].keys()) and back["proc_dimensions"].tolist() == [7, 9]
+    d = back["Nuclei"][ids[7]]
+    assert d["box"].tolist() == [7, 8, 9, 10] and d["contour"].dtype == np.int32 and d["type"] == 3
