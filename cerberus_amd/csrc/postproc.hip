@@ -295,7 +295,8 @@ __global__ void ws_cap_kernel(const int* __restrict__ L, const int* __restrict__
 }
 __global__ void ws_seed_kernel(const float* __restrict__ inst, long long row_stride, int pix_stride, const uint8_t* __restrict__ mask,
                                const int* __restrict__ out, const int* __restrict__ L, const int* __restrict__ hoff, int* __restrict__ hcnt,
-                               u64* __restrict__ hkey, u32* __restrict__ hidx, int H, int W, int* __restrict__ unl) {
+                               u64* __restrict__ hkey, u32* __restrict__ hidx, int H, int W, int* __restrict__ unl, int* __restrict__ lmin,
+                               int* __restrict__ lmax) {
     const long long n = (long long)H * W;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
         if (!out[p]) {
@@ -310,6 +311,8 @@ __global__ void ws_seed_kernel(const float* __restrict__ inst, long long row_str
         if (y < H - 1 && mask[p + W] && !out[p + W]) active = true;
         if (!active) continue;
         const int root = L[p];
+        atomicMin(&lmin[root], out[p]);
+        atomicMax(&lmax[root], out[p]);
         const int slot = hoff[root] + atomicAdd(&hcnt[root], 1);
         const float v = -inst[y * row_stride + (long long)x * pix_stride];  // watershed(-inst_inner_raw, ...)
         hkey[slot] = ((u64)order_key(v) << 32);  // age 0
@@ -348,10 +351,14 @@ __global__ void ws_bbox_kernel(const int* __restrict__ L, const uint8_t* __restr
 #define WS_WIN_CAP 2304
 #define WS_BIGWIN_CAP 16384
 #define WS_BIGHEAP_CAP 2048
+// A component all of whose seeds carry ONE label needs no priority flood: every unlabelled mask pixel of a 4-connected mask
+// component is reachable from a seed through unlabelled mask pixels, so the flood can only ever assign that label
+// (ws_fill_single_kernel).  Isolated nuclei -- the common case -- take this path; only touching clusters reach the heaps.
 __global__ void ws_worklist_kernel(const int* __restrict__ hcnt, const int* __restrict__ area, const int* __restrict__ unl, const CBox* __restrict__ bb,
-                                   int* __restrict__ wl, int* __restrict__ wl2, int* __restrict__ wl3, int* __restrict__ counts, int n) {
+                                   const int* __restrict__ lmin, const int* __restrict__ lmax, int* __restrict__ wl, int* __restrict__ wl2,
+                                   int* __restrict__ wl3, int* __restrict__ counts, int n) {
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
-        if (hcnt[p] > 0) {
+        if (hcnt[p] > 0 && lmin[p] != lmax[p]) {
             const CBox b = bb[p];
             const long long win = (long long)(b.y2 - b.y1 + 3) * (b.x2 - b.x1 + 3);
             const int need = hcnt[p] + unl[p];  // every queue entry is a seed or a pixel that was unlabelled at the start
@@ -360,6 +367,16 @@ __global__ void ws_worklist_kernel(const int* __restrict__ hcnt, const int* __re
             else if (area[p] <= WS_LDS_CAP) wl2[atomicAdd(counts + 1, 1)] = (int)p;
             else wl[n - 1 - atomicAdd(counts + 2, 1)] = (int)p;
         }
+}
+
+__global__ void ws_fill_single_kernel(const uint8_t* __restrict__ mask, const int* __restrict__ L, const int* __restrict__ lmin,
+                                      const int* __restrict__ lmax, int* __restrict__ out, int n) {
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        if (!mask[p] || out[p]) continue;
+        const int r = L[p];
+        const int a = lmin[r];
+        if (a == lmax[r]) out[p] = a;
+    }
 }
 
 struct HeapRef {
@@ -1039,6 +1056,7 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
     uint8_t* msk = (uint8_t*)cv.take(n);
     uint8_t* mrk = (uint8_t*)cv.take(n);
     int* scantmp = (int*)cv.take((size_t)(n / SCAN_ITEMS + 4096) * 4 * 2);
+    int* lmax = (int*)cv.take((size_t)n * 4);   // per mask component: largest seed label (smallest one lives in LB once the markers are final)
     int* small = (int*)cv.take(256);  // [0]=any [1]=worklist count [2]=n_inst scratch [3]=ambiguous scratch
     if (!small) return cerb_set_error("cerb_postproc_nuclei: workspace carve failed");
     const unsigned g = grid_for(n);
@@ -1073,11 +1091,16 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
     int* unl = areaB;  // free again: per-root count of unlabelled mask pixels
     int* wl3 = marker; // free after ws_init_out_kernel: big-window tier list
     PP_OK(hipMemsetAsync(unl, 0, (size_t)n * 4, st));
-    hipLaunchKernelGGL(ws_seed_kernel, dim3(g), dim3(256), 0, st, inst, row_stride, pix_stride, msk, labels_out, LA, hoff, hcnt, hkey, hidx, H, W, unl);
+    int* lmin = LB;    // free after ccl_relabel_kernel
+    PP_OK(hipMemsetAsync(lmin, 0x7f, (size_t)n * 4, st));
+    PP_OK(hipMemsetAsync(lmax, 0, (size_t)n * 4, st));
+    hipLaunchKernelGGL(ws_seed_kernel, dim3(g), dim3(256), 0, st, inst, row_stride, pix_stride, msk, labels_out, LA, hoff, hcnt, hkey, hidx, H, W, unl,
+                       lmin, lmax);
     hipLaunchKernelGGL(ws_bbox_init_kernel, dim3(g), dim3(256), 0, st, LA, msk, cbox, H, W);
     hipLaunchKernelGGL(ws_bbox_kernel, dim3(g), dim3(256), 0, st, LA, msk, cbox, H, W);
     int* counts = small + 8;  // [0] window tier, [1] LDS-heap tier, [2] global tier
-    hipLaunchKernelGGL(ws_worklist_kernel, dim3(g), dim3(256), 0, st, hcnt, areaA, unl, cbox, wl, rank, wl3, counts, n);
+    hipLaunchKernelGGL(ws_worklist_kernel, dim3(g), dim3(256), 0, st, hcnt, areaA, unl, cbox, lmin, lmax, wl, rank, wl3, counts, n);
+    hipLaunchKernelGGL(ws_fill_single_kernel, dim3(g), dim3(256), 0, st, msk, LA, lmin, lmax, labels_out, n);
     {
         auto k_small = ws_flood_window_kernel<WS_WIN_CAP, WS_LDS_CAP, 2>;
         auto k_big = ws_flood_window_kernel<WS_BIGWIN_CAP, WS_BIGHEAP_CAP, 1>;

@@ -1,0 +1,12 @@
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from cerberus_amd.postproc import postproc_device
+from oracle import synth
+H = W = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+m = torch.from_numpy(synth.nuclei_maps(H, W, 7, 1000.0, noise=0.02)).cuda()
+for rep in range(4):
+    torch.cuda.synchronize(); t0 = time.time()
+    lab, info = postproc_device(m, "Nuclei")
+    torch.cuda.synchronize(); dt = time.time() - t0
+print("Nuclei %dx%d: %.2f ms (%.0f Mpx/s) n_inst %d" % (H, W, dt * 1e3, H * W / dt / 1e6, int(info["n_inst"])), flush=True)
