@@ -4,6 +4,7 @@
 // Host code only; kernels live in conv_igemm.hip / net_kernels.hip.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -20,7 +21,7 @@ hipError_t cerb_launch_conv(const ConvParams& p, int ks, int stride, int mode, h
 hipError_t cerb_launch_wino(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino3(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_upsample2_add(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C,
-                                     long long prev_gs, hipStream_t st);
+                                     long long prev_gs, const int* roi, hipStream_t st);
 extern "C" int cerb_conv_chunk(int ks, int stride);
 struct StemParams {
     const unsigned char* tiles;
@@ -127,6 +128,7 @@ struct cerb_net {
     DevBuf x0, pool, x[5], ta, tb, cm, dmid, dsum, dout[4];
     // optional per-launch timing (HIP events on the caller's stream)
     bool profiling = false;
+    int crop_roi = 1;   // cerb_net_set_crop_roi: decoders / heads only compute what the centre crop keeps (conv_algo 1)
     int conv_algo = 1;  // cerb_net_set_conv_algo: 1 = Winograd F(2x2,3x3) for 3x3 stride-1 convs (default), 0 = direct implicit GEMM
     struct ProfRec { std::string name, kernel; double flops; hipEvent_t e0, e1; };
     std::vector<ProfRec> prof;
@@ -500,7 +502,8 @@ static int prof_end(cerb_net* net, hipStream_t st) {
 }
 
 static int run_conv(cerb_net* net, const std::string& name, const float* in, const float* prev, const float* resid, float* out, int N,
-                    int H, int W, int relu, int mode, long long in_gs, long long prev_gs, hipStream_t st, double* macs) {
+                    int H, int W, int relu, int mode, long long in_gs, long long prev_gs, hipStream_t st, double* macs,
+                    const int* roi = nullptr) {
     auto it = net->conv.find(name);
     if (it == net->conv.end()) return fail("internal: conv " + name + " not packed");
     const PackedConv& c = it->second;
@@ -543,7 +546,13 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
     if (net->conv_algo && c.wino && mode == 0) {
         p.wpack = c.wino;
         p.w_gs = (long long)c.cout * c.cin * 16;
-        if (prof_begin(net, name, resid ? "conv_wino<f2x2,8x16,res>" : "conv_wino<f2x2,8x16>", fl, st)) return 1;
+        double fl_done = fl;
+        if (roi && roi[1] > roi[0] && roi[3] > roi[2]) {  // region of interest: report the work of the items that run (8 x 16 px each)
+            p.roi_y0 = roi[0]; p.roi_y1 = roi[1]; p.roi_x0 = roi[2]; p.roi_x1 = roi[3];
+            const double ty = (roi[1] + 7) / 8 - roi[0] / 8, tx = (roi[3] + 15) / 16 - roi[2] / 16;
+            fl_done = fl * (ty * 8.0 * tx * 16.0) / ((double)p.Ho * p.Wo);
+        }
+        if (prof_begin(net, name, resid ? "conv_wino<f2x2,8x16,res>" : "conv_wino<f2x2,8x16>", fl_done, st)) return 1;
         HIP_OK(cerb_launch_wino(p, st));
         if (prof_end(net, st)) return 1;
         return 0;
@@ -651,6 +660,33 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
         const float* prev = dry ? nullptr : net->cm.p;
         long long prev_gs = 0;  // conv_map output is shared by every decoder
         const int oc[4] = {128, 64, 64, 64};
+        // Regions of interest (crop_rois below): with a centre crop smaller than the tile (the reference's default 448 -> 144 keeps
+        // 10 % of the pixels, infer/wsi.py / run_desc.py:452-491) only the part of every decoder map that the kept window depends on is
+        // computed: 3x3 convs widen the window by one pixel each, the bilinear x2 by one source pixel.  The encoder sees the whole tile
+        // (its receptive field covers it); results inside the window are bit-identical to the full computation.
+        int roi_out[4][4], roi_mid[4][4], roi_sum[4][4];
+        const bool any_logits = [&] {
+            if (!io->logits) return false;
+            for (size_t k = 0; k < net->dec.size(); ++k)
+                if (io->logits[k]) return true;
+            return false;
+        }();
+        const bool use_roi = !dry && net->crop_roi && net->conv_algo == 1 && !any_logits && (out_h < H || out_w < W);
+        if (use_roi) {
+            int y0 = (int)((H - out_h) * 0.5), x0 = (int)((W - out_w) * 0.5), y1 = y0 + out_h, x1 = x0 + out_w;
+            for (int u = 3; u >= 0; --u) {
+                const int hh = hs[3 - u], ww = ws[3 - u];
+                auto grow = [&](int* r, int d) {
+                    r[0] = std::max(0, y0 - d); r[1] = std::min(hh, y1 + d); r[2] = std::max(0, x0 - d); r[3] = std::min(ww, x1 + d);
+                };
+                grow(roi_out[u], 0);
+                grow(roi_mid[u], 1);
+                grow(roi_sum[u], 2);
+                // bilinear x2, align_corners = False: output o reads sources floor(o / 2 - 0.25) and the next one
+                y0 = std::max(0, roi_sum[u][0] / 2 - 1); y1 = std::min(hh / 2, (roi_sum[u][1] - 1) / 2 + 2);
+                x0 = std::max(0, roi_sum[u][2] / 2 - 1); x1 = std::min(ww / 2, (roi_sum[u][3] - 1) / 2 + 2);
+            }
+        }
         for (int u = 0; u < 4; ++u) {
             const int hh = hs[3 - u], ww = ws[3 - u];
             const std::string n0 = "dec." + std::to_string(u) + ".0", n1 = "dec." + std::to_string(u) + ".1";
@@ -659,12 +695,14 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
             if (net->conv_algo && net->conv[n0].wino && !dry) {
                 // skip + upsample2x(prev) as one HBM pass, then the Winograd conv over the materialised sum
                 if (prof_begin(net, n0 + ".up", "upsample2_add", 0.0, st)) return 1;
-                HIP_OK(cerb_launch_upsample2_add(skips[u], prev, net->dsum.p, (int)D, N, hh, ww, cin0, prev_gs, st));
+                HIP_OK(cerb_launch_upsample2_add(skips[u], prev, net->dsum.p, (int)D, N, hh, ww, cin0, prev_gs, use_roi ? roi_sum[u] : nullptr, st));
                 if (prof_end(net, st)) return 1;
-                if (run_conv(net, n0, net->dsum.p, nullptr, nullptr, net->dmid.p, N, hh, ww, 1, 0, (long long)N * hh * ww * cin0, 0, st, macs)) return 1;
+                if (run_conv(net, n0, net->dsum.p, nullptr, nullptr, net->dmid.p, N, hh, ww, 1, 0, (long long)N * hh * ww * cin0, 0, st, macs,
+                             use_roi ? roi_mid[u] : nullptr))
+                    return 1;
             } else if (run_conv(net, n0, skips[u], prev, nullptr, dry ? nullptr : net->dmid.p, N, hh, ww, 1, 1, 0, prev_gs, st, macs)) return 1;
             if (run_conv(net, n1, dry ? nullptr : net->dmid.p, nullptr, nullptr, dry ? nullptr : net->dout[u].p, N, hh, ww, 1, 0,
-                         (long long)N * hh * ww * cmid, 0, st, macs))
+                         (long long)N * hh * ww * cmid, 0, st, macs, use_roi ? roi_out[u] : nullptr))
                 return 1;
             prev = dry ? nullptr : net->dout[u].p;
             prev_gs = (long long)N * hh * ww * oc[u];
@@ -683,6 +721,7 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
             hp.N = N; hp.H = H; hp.W = W; hp.out_ch = d.out_ch; hp.kind = d.kind;
             hp.crop_y0 = (int)((H - out_h) * 0.5); hp.crop_x0 = (int)((W - out_w) * 0.5);  // cropping_center, misc/utils.py:94-104
             hp.out_h = want ? out_h : 0; hp.out_w = want ? out_w : 0;
+            hp.roi = use_roi ? 1 : 0;
             hp.logits = wantl ? io->logits[di] : nullptr;
             if (want) {
                 if (d.kind == 0) hp.out_inst = (float*)io->out[di];
@@ -690,7 +729,8 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
                 else hp.out_type_i64 = (long long*)io->out[di];
             }
             hp.tile_off = io->tile_off; hp.tile_stride = tile_stride; hp.row_stride = row_stride;
-            if (prof_begin(net, "head." + d.name, "head", 2.0 * N * H * W * (64.0 * 96 + 96.0 * d.out_ch), st)) return 1;
+            const double head_px = hp.roi ? (double)out_h * (((hp.crop_x0 + out_w + 15) / 16 - hp.crop_x0 / 16) * 16.0) : (double)H * W;
+            if (prof_begin(net, "head." + d.name, "head", 2.0 * N * head_px * (64.0 * 96 + 96.0 * d.out_ch), st)) return 1;
             HIP_OK(cerb_launch_head(hp, st));
             if (prof_end(net, st)) return 1;
         }
@@ -724,6 +764,11 @@ extern "C" double cerb_net_flops(const cerb_net* net, int n, int h, int w) {
 }
 
 // ---- per-launch profile (bench.py roofline leg) ----------------------------------------------------------------
+extern "C" int cerb_net_set_crop_roi(cerb_net* net, int enable) {
+    if (!net) return fail("cerb_net_set_crop_roi: null handle");
+    net->crop_roi = enable ? 1 : 0;
+    return 0;
+}
 extern "C" int cerb_net_set_conv_algo(cerb_net* net, int algo) {
     if (!net) return fail("cerb_net_set_conv_algo: null handle");
     if (algo < 0 || algo > 2) return fail("cerb_net_set_conv_algo: algo must be 0 (direct), 1 (Winograd fp32) or 2 (Winograd, bf16x3 products)");

@@ -23,7 +23,12 @@ struct ConvParams {
     float* out;          // [G][N][Ho][Wo][Cout]
     int N, H, W, Cin, Ho, Wo, Cout;
     int relu;
-    int tiles_x, tiles_y;  // output tiles per image
+    int tiles_x, tiles_y;  // output tiles per image (set by the launcher; with a region of interest: tiles of the region)
+    // Region of interest in OUTPUT pixels, [roi_y0, roi_y1) x [roi_x0, roi_x1); all zero = the whole map.  Only the work items that
+    // overlap it are computed (conv_wino: the decoder convs whose output is centre-cropped afterwards, cerb_api.hip: crop_rois);
+    // ty_off / tx_off are the launcher's item offsets of the region.
+    int roi_y0, roi_y1, roi_x0, roi_x1;
+    int ty_off, tx_off;
     int groups;
     long long in_gs, prev_gs, w_gs, bias_gs, resid_gs, out_gs;  // per-group strides in elements
 };
@@ -39,6 +44,8 @@ struct HeadParams {
     int out_ch;          // 3 or 7 (<= 8)
     int kind;            // 0 = INST (write softmax ch 1..2 as float2), 1 = TYPE (write argmax)
     int crop_y0, crop_x0, out_h, out_w;   // centre crop window in tile coordinates
+    int roi;             // 1: only the pixel blocks that overlap the crop window are computed (logits must be NULL)
+    int rows, row0, xa0, nxb;  // set by the launcher: the kernel walks 16-pixel blocks (n, row0 + r, xa0 + 16 xb), r < rows, xb < nxb
     float* logits;       // optional [N][H][W][out_ch] NHWC (tests)
     float* out_inst;     // kind 0: float [..][2]
     unsigned char* out_type_u8;  // kind 1, optional

@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
         t_ /= p.tiles_x;
         w.ty = t_ % p.tiles_y;
         w.n = t_ / p.tiles_y;
-        w.oy0 = w.ty * OTH;
-        w.ox0 = w.tx * OTW;
+        w.oy0 = (w.ty + p.ty_off) * OTH;
+        w.ox0 = (w.tx + p.tx_off) * OTW;
         return w;
     };
     auto advance = [&](Item w) {
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
                 }
             }
         }
-        w.oy0 = w.ty * OTH;
-        w.ox0 = w.tx * OTW;
+        w.oy0 = (w.ty + p.ty_off) * OTH;
+        w.ox0 = (w.tx + p.tx_off) * OTW;
         return w;
     };
     auto in_base = [&](const Item& w) {  // top-left input pixel of the item's patch grid (may lie in the guard band)
@@ -454,6 +454,13 @@ template <bool HAS_RES>
 static hipError_t launch_wino(ConvParams p, hipStream_t st) {
     p.tiles_x = (p.Wo + OTW - 1) / OTW;
     p.tiles_y = (p.Ho + OTH - 1) / OTH;
+    p.ty_off = p.tx_off = 0;
+    if (p.roi_y1 > p.roi_y0 && p.roi_x1 > p.roi_x0) {  // only the items overlapping the region of interest
+        p.ty_off = p.roi_y0 / OTH;
+        p.tx_off = p.roi_x0 / OTW;
+        p.tiles_y = (p.roi_y1 + OTH - 1) / OTH - p.ty_off;
+        p.tiles_x = (p.roi_x1 + OTW - 1) / OTW - p.tx_off;
+    }
     const long long items = (long long)p.groups * p.N * p.tiles_x * p.tiles_y * (p.Cout / 64);
     auto kern = conv_wino_kernel<HAS_RES>;
     static bool attr_done = false;

@@ -146,17 +146,18 @@ hipError_t cerb_launch_maxpool(const float* in, float* out, int N, int H, int W,
 // {0.75, 0.25}; m = -1 and m = Hp-1 are the clamped edge blocks (one of their two rows lies outside the image).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void upsample2_add_kernel(const float* __restrict__ skip, const float* __restrict__ prev, float* __restrict__ out, int groups,
-                                     int N, int H, int W, int C, long long prev_gs) {
+                                     int N, int H, int W, int C, long long prev_gs, int bm_lo, int bm_cnt, int bn_lo, int bn_cnt) {
+    // 2x2 output blocks (bm, bn), bm in [-1, H/2): the launcher restricts them to [bm_lo, bm_lo + bm_cnt) x [bn_lo, bn_lo + bn_cnt)
     const int Hp = H >> 1, Wp = W >> 1, C4 = C >> 2;
-    const long long total = (long long)N * (Hp + 1) * (Wp + 1) * C4;
+    const long long total = (long long)N * bm_cnt * bn_cnt * C4;
     const long long out_gs = (long long)N * H * W * C;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
         long long r = i / C4;
-        const int bn = (int)(r % (Wp + 1)) - 1;
-        r /= (Wp + 1);
-        const int bm = (int)(r % (Hp + 1)) - 1;
-        const int n = (int)(r / (Hp + 1));
+        const int bn = (int)(r % bn_cnt) + bn_lo;
+        r /= bn_cnt;
+        const int bm = (int)(r % bm_cnt) + bm_lo;
+        const int n = (int)(r / bm_cnt);
         const int m0 = max(bm, 0), m1 = min(bm + 1, Hp - 1), n0 = max(bn, 0), n1 = min(bn + 1, Wp - 1);
         // the skip pixels are shared by every decoder (group): read once, reuse `groups` times
         f32x4 sk[2][2];
@@ -191,12 +192,24 @@ __global__ void upsample2_add_kernel(const float* __restrict__ skip, const float
     }
 }
 
+// roi = {y0, y1, x0, x1} in output pixels (nullptr or empty = the whole map): only the 2x2 blocks overlapping it are written
 hipError_t cerb_launch_upsample2_add(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C,
-                                     long long prev_gs, hipStream_t st) {
-    const long long total = (long long)N * (H / 2 + 1) * (W / 2 + 1) * (C / 4);
+                                     long long prev_gs, const int* roi, hipStream_t st) {
+    int bm_lo = -1, bm_hi = H / 2 - 1, bn_lo = -1, bn_hi = W / 2 - 1;  // block bm covers output rows 2 bm + 1, 2 bm + 2
+    if (roi && roi[1] > roi[0] && roi[3] > roi[2]) {
+        auto lo = [](int v) { return (v - 2 >= 0 ? (v - 2) / 2 : -1); };  // largest bm with 2 bm + 2 <= v  (>= -1)
+        bm_lo = lo(roi[0]);
+        bn_lo = lo(roi[2]);
+        if ((roi[1] - 1) / 2 < bm_hi) bm_hi = (roi[1] - 1) / 2;  // smallest bm with 2 bm + 1 >= y1 - 1 is enough; one more is harmless
+        if ((roi[3] - 1) / 2 < bn_hi) bn_hi = (roi[3] - 1) / 2;
+    }
+    const int bm_cnt = bm_hi - bm_lo + 1, bn_cnt = bn_hi - bn_lo + 1;
+    const long long total = (long long)N * bm_cnt * bn_cnt * (C / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(upsample2_add_kernel, dim3((unsigned)blocks), dim3(256), 0, st, skip, prev, out, groups, N, H, W, C, prev_gs);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(upsample2_add_kernel, dim3((unsigned)blocks), dim3(256), 0, st, skip, prev, out, groups, N, H, W, C, prev_gs, bm_lo, bm_cnt, bn_lo,
+                       bn_cnt);
     return hipGetLastError();
 }
 
@@ -215,22 +228,52 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
     //     so one float4 per lane feeds 4 steps (features straight from global memory, W1 pre-packed the same way);
     //   its accumulators (bias in the init, ReLU) are the B operand of GEMM2: step (blk, r), k-slot ks <-> hidden 16 blk + 4 ks + r;
     //   GEMM2 pads out_ch to 16 rows (a 32x32 tile would pad to 32: 30 % of the head's MFMAs were padding before).
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, px = lane & 15, ks = lane >> 4;
-    const long long npix = (long long)p.N * p.H * p.W;
+    const int tid = threadIdx.x, lane = tid & 63, px = lane & 15, ks = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const f32x4h* w1v = reinterpret_cast<const f32x4h*>(p.w1p) + lane;
     const f32x4h* w2v = reinterpret_cast<const f32x4h*>(p.w2p) + lane;
-    auto feat_ptr = [&](long long base, int pb) {
-        const long long P = base + pb * 16 + px;
-        return p.feat + (P < npix ? P : npix - 1) * 64 + 4 * ks;
+    // work = 16-pixel blocks (n, row, xb) of the window the launcher chose (the whole map, or the 16-aligned cover of the crop
+    // window), walked in linear order.  A wave's block positions are wave-uniform: one 32-bit decode per wave, then increments
+    // with carry -- no per-lane division.
+    struct BPos {
+        int n, row, xb;
     };
-    // a wave walks HEAD_TPW consecutive 64-pixel tasks; the first channel group of the next task is requested before this
+    auto inc = [&](BPos b) {
+        if (++b.xb == p.nxb) {
+            b.xb = 0;
+            if (++b.row == p.rows) {
+                b.row = 0;
+                ++b.n;
+            }
+        }
+        return b;
+    };
+    auto ptr_of = [&](const BPos& b) {  // blocks past the end (n == N) and pixels past the row end are clamped here, dropped at the store
+        const int n = min(b.n, p.N - 1), x = min(p.xa0 + 16 * b.xb + px, p.W - 1);
+        return p.feat + (((long long)n * p.H + p.row0 + b.row) * p.W + x) * 64 + 4 * ks;
+    };
+    const unsigned nblk = (unsigned)p.N * (unsigned)p.rows * (unsigned)p.nxb;  // launcher: < 2^31
+    const unsigned b0 = ((unsigned)blockIdx.x * 4u + (unsigned)wave) * (4u * HEAD_TPW);
+    BPos cur[4], nxt[4];
+    {
+        const unsigned bc = b0 < nblk ? b0 : nblk;
+        const unsigned r = bc / (unsigned)p.nxb;
+        cur[0].xb = (int)(bc - r * (unsigned)p.nxb);
+        cur[0].n = (int)(r / (unsigned)p.rows);
+        cur[0].row = (int)(r - (unsigned)cur[0].n * (unsigned)p.rows);
+#pragma unroll
+        for (int pb = 1; pb < 4; ++pb) cur[pb] = inc(cur[pb - 1]);
+        nxt[0] = inc(cur[3]);
+#pragma unroll
+        for (int pb = 1; pb < 4; ++pb) nxt[pb] = inc(nxt[pb - 1]);
+    }
+    // a wave walks HEAD_TPW consecutive tasks of 4 blocks; the first channel group of the next task is requested before this
     // task's second GEMM and softmax, so the HBM latency of the feature read hides behind them
-    long long pbase = ((long long)blockIdx.x * 4 + wave) * (64 * HEAD_TPW);
     f32x4h x[4];
 #pragma unroll
-    for (int pb = 0; pb < 4; ++pb) x[pb] = *reinterpret_cast<const f32x4h*>(feat_ptr(pbase, pb));
+    for (int pb = 0; pb < 4; ++pb) x[pb] = *reinterpret_cast<const f32x4h*>(ptr_of(cur[pb]));
 #pragma unroll 1
-    for (int task = 0; task < HEAD_TPW; ++task, pbase += 64) {
+    for (int task = 0; task < HEAD_TPW; ++task) {
     f32x4h acc1[6][4];
 #pragma unroll
     for (int blk = 0; blk < 6; ++blk) {
@@ -240,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
     }
     const float* xp[4];
 #pragma unroll
-    for (int pb = 0; pb < 4; ++pb) xp[pb] = feat_ptr(pbase, pb);
+    for (int pb = 0; pb < 4; ++pb) xp[pb] = ptr_of(cur[pb]);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4h xn[4];
@@ -249,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
             for (int pb = 0; pb < 4; ++pb) xn[pb] = *reinterpret_cast<const f32x4h*>(xp[pb] + (g + 1) * 16);
         } else if (task + 1 < HEAD_TPW) {
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb) xn[pb] = *reinterpret_cast<const f32x4h*>(feat_ptr(pbase + 64, pb));
+            for (int pb = 0; pb < 4; ++pb) xn[pb] = *reinterpret_cast<const f32x4h*>(ptr_of(nxt[pb]));
         }
 #pragma unroll
         for (int blk = 0; blk < 6; ++blk) {
@@ -300,9 +343,25 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
         lg[e] = lo;
         lg[4 + e] = hi;
     }
-    const long long P = pbase + ks * 16 + px;
-    if (P >= npix) continue;
+    // lane group ks finishes block ks of this task
+    int n = cur[0].n, y_ = cur[0].row, xb_ = cur[0].xb;
+#pragma unroll
+    for (int pb = 1; pb < 4; ++pb) {
+        n = (ks == pb) ? cur[pb].n : n;
+        y_ = (ks == pb) ? cur[pb].row : y_;
+        xb_ = (ks == pb) ? cur[pb].xb : xb_;
+    }
+    y_ += p.row0;
+    const int x_ = p.xa0 + 16 * xb_ + px;
+    const bool live = n < p.N && x_ < p.W;
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) cur[pb] = nxt[pb];
+    nxt[0] = inc(cur[3]);
+#pragma unroll
+    for (int pb = 1; pb < 4; ++pb) nxt[pb] = inc(nxt[pb - 1]);
+    if (!live) continue;
     if (p.logits) {
+        const long long P = ((long long)n * p.H + y_) * p.W + x_;
         for (int e = 0; e < p.out_ch; ++e) p.logits[P * p.out_ch + e] = lg[e];
     }
     // softmax over out_ch (max-subtracted, as torch.softmax)
@@ -316,10 +375,6 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
         ex[e] = (e < p.out_ch) ? expf(lg[e] - mx) : 0.f;
         sum += ex[e];
     }
-    const int x_ = (int)(P % p.W);
-    const long long r_ = P / p.W;
-    const int y_ = (int)(r_ % p.H);
-    const int n = (int)(r_ / p.H);
     const int cy = y_ - p.crop_y0, cx = x_ - p.crop_x0;
     if (cy < 0 || cy >= p.out_h || cx < 0 || cx >= p.out_w) continue;
     const long long dst = (p.tile_off ? p.tile_off[n] : (long long)n * p.tile_stride) + (long long)cy * p.row_stride + cx;
@@ -345,9 +400,17 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
     }  // task
 }
 
-hipError_t cerb_launch_head(const HeadParams& p, hipStream_t st) {
-    const long long npix = (long long)p.N * p.H * p.W;
-    const long long blocks = (npix + 256 * HEAD_TPW - 1) / (256 * HEAD_TPW);
+hipError_t cerb_launch_head(const HeadParams& p_in, hipStream_t st) {
+    HeadParams p = p_in;
+    if (p.W % 16) return hipErrorInvalidValue;
+    p.rows = p.H; p.row0 = 0; p.xa0 = 0; p.nxb = p.W / 16;
+    if (p.roi && !p.logits && p.out_h > 0 && p.out_w > 0) {  // only the 16-aligned cover of the crop window
+        p.rows = p.out_h; p.row0 = p.crop_y0;
+        p.xa0 = p.crop_x0 & ~15;
+        p.nxb = (p.crop_x0 + p.out_w - p.xa0 + 15) / 16;
+    }
+    const long long nblk = (long long)p.N * p.rows * p.nxb;  // 16-pixel blocks; a workgroup takes 16 * HEAD_TPW of them
+    const long long blocks = (nblk + 16 * HEAD_TPW - 1) / (16 * HEAD_TPW);
     hipLaunchKernelGGL(head_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
     return hipGetLastError();
 }

@@ -155,6 +155,10 @@ class NetDesc(torch.nn.Module):
         (see include/cerberus_hip.h) for the 3x3 stride-1 convolutions."""
         _lib.check(_lib.lib().cerb_net_set_conv_algo(self._ensure_handle(), int(algo)))
 
+    def set_crop_roi(self, enable=True):
+        """Compute only what the centre crop keeps in the decoders / heads (default on; include/cerberus_hip.h)."""
+        _lib.check(_lib.lib().cerb_net_set_crop_roi(self._ensure_handle(), int(bool(enable))))
+
     def profile(self, enable=True):
         _lib.check(_lib.lib().cerb_net_profile_enable(self._ensure_handle(), int(enable)))
 

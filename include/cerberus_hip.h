@@ -80,6 +80,13 @@ int cerb_net_forward(cerb_net* net, const cerb_forward_io* io, void* hip_stream)
  * (conv_wino3.hip; fp32 accumulate, errors indistinguishable from algorithm 1 in the tests).  It leaves the fp32 matrix
  * instruction, so it is never the default and never what bench.py's headline measures (BASELINE.json configs[1]: fp32). */
 int cerb_net_set_conv_algo(cerb_net* net, int algo);
+/* Centre-crop regions of interest (default 1 = on).  infer_step keeps only the centre out_h x out_w window of every head
+ * (models/run_desc.py:452-491 cropping_center; the reference's default geometry 448 -> 144 keeps 10 % of the pixels it computes).
+ * With the switch on and conv_algo 1, every decoder level computes only the part of its maps that the kept window depends on
+ * (3x3 conv: +1 pixel per layer, bilinear x2: +1 source pixel) and the heads only the window; the encoder still sees the whole
+ * tile.  Results inside the window are bit-identical to the full computation (tests/test_net_gpu.py).  Ignored (full
+ * computation) when full-size logits are requested or out == in. */
+int cerb_net_set_crop_roi(cerb_net* net, int enable);
 
 /* FLOPs (2*MAC) of one forward for the given geometry -- used by bench.py for the roofline figure. */
 double cerb_net_flops(const cerb_net* net, int n, int h, int w);

@@ -320,3 +320,29 @@ def test_experimental_bf16x3_algo_meets_the_parity_bar(golden_dir):
             assert np.abs(got - ref).max() < PROB_TOL, k
         else:
             assert (got != ref).mean() < 1e-4, k
+
+
+@pytest.mark.parametrize("hw,out", [((448, 448), (144, 144)), ((256, 256), (144, 144)), ((304, 272), (100, 36)), ((96, 128), (32, 128)),
+                                    ((448, 448), (447, 3)), ((256, 256), (2, 2))])
+def test_crop_region_of_interest_is_bit_identical_to_the_full_computation(full_model, hw, out):
+    """cerb_net_set_crop_roi: with a centre crop the decoders and heads compute only what the kept window depends on (3x3 conv: one
+    pixel per layer, bilinear x2: one source pixel, item granularity on top).  Same kernels, same arithmetic for every kept pixel:
+    the outputs must be bit-identical to the full computation, whatever stale values the skipped regions of the buffers hold."""
+    m = full_model[0]
+    rs = np.random.RandomState(hw[0] + out[1])
+    tiles = torch.from_numpy(rs.randint(0, 256, (3,) + hw + (3,)).astype(np.uint8)).cuda()
+    other = torch.from_numpy(rs.randint(0, 256, (3,) + hw + (3,)).astype(np.uint8)).cuda()
+    try:
+        m.set_crop_roi(False)
+        full = {k: v.clone() for k, v in m.infer_tiles(tiles, list(out)).items()}
+        m.infer_tiles(other, list(hw))  # leave a different image's activations in every workspace buffer
+        m.set_crop_roi(True)
+        roi = m.infer_tiles(tiles, list(out))
+        for k in full:
+            assert torch.equal(full[k], roi[k]), k
+        # a second pass over the stale region-of-interest state of the first
+        roi2 = m.infer_tiles(tiles, list(out))
+        for k in full:
+            assert torch.equal(full[k], roi2[k]), k
+    finally:
+        m.set_crop_roi(True)
