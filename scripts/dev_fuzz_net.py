@@ -17,7 +17,7 @@ for i in range(n_cases):
     m = create_model(**kw); m.load_state_dict(sd, strict=True)
     h, w = 16 * int(rs.randint(1, 26)), 16 * int(rs.randint(1, 26))
     n = int(rs.randint(1, 4))
-    out = [int(rs.randint(1, h + 1)), int(rs.randint(1, w + 1))] if rs.randint(2) else [h, w]
+    out = [int(rs.randint(2, h + 1)), int(rs.randint(2, w + 1))] if rs.randint(2) else [h, w]  # a side of 1 trips the reference's own squeeze (run_desc.py:484-487)
     algo = int(rs.randint(2))
     m.set_conv_algo(algo)
     tiles = rs.randint(0, 256, (n, h, w, 3)).astype(np.uint8)
