@@ -221,6 +221,7 @@ hipError_t cerb_launch_upsample2_add(const float* skip, const float* prev, float
 #define HEAD_TPW 2  // 64-pixel tasks per wave
 #endif
 typedef float f32x4h __attribute__((ext_vector_type(4)));
+template <bool ROI>
 __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
     // v_mfma_f32_16x16x4_f32 throughout: D[16 x 16] += A[16 x 4] B[4 x 16]; lane l supplies row/column l & 15 and k-slot l >> 4,
     // and holds D rows 4 (l >> 4) + r of column l & 15.  A wave owns 64 pixels = 4 pixel blocks of 16.
@@ -229,12 +230,11 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
     //   its accumulators (bias in the init, ReLU) are the B operand of GEMM2: step (blk, r), k-slot ks <-> hidden 16 blk + 4 ks + r;
     //   GEMM2 pads out_ch to 16 rows (a 32x32 tile would pad to 32: 30 % of the head's MFMAs were padding before).
     const int tid = threadIdx.x, lane = tid & 63, px = lane & 15, ks = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const f32x4h* w1v = reinterpret_cast<const f32x4h*>(p.w1p) + lane;
     const f32x4h* w2v = reinterpret_cast<const f32x4h*>(p.w2p) + lane;
-    // work = 16-pixel blocks (n, row, xb) of the window the launcher chose (the whole map, or the 16-aligned cover of the crop
-    // window), walked in linear order.  A wave's block positions are wave-uniform: one 32-bit decode per wave, then increments
-    // with carry -- no per-lane division.
+    // Two walks over the pixels.  Whole map (ROI = false): a wave takes 64 consecutive pixels of the flattened [N][H][W] map.
+    // Crop window (ROI = true): 16-pixel blocks (n, row, xb) of the 16-aligned cover of the window in linear order; a wave's
+    // block positions are wave-uniform -- one 32-bit decode per wave, then increments with carry.
     struct BPos {
         int n, row, xb;
     };
@@ -248,14 +248,13 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
         }
         return b;
     };
-    auto ptr_of = [&](const BPos& b) {  // blocks past the end (n == N) and pixels past the row end are clamped here, dropped at the store
-        const int n = min(b.n, p.N - 1), x = min(p.xa0 + 16 * b.xb + px, p.W - 1);
-        return p.feat + (((long long)n * p.H + p.row0 + b.row) * p.W + x) * 64 + 4 * ks;
-    };
-    const unsigned nblk = (unsigned)p.N * (unsigned)p.rows * (unsigned)p.nxb;  // launcher: < 2^31
-    const unsigned b0 = ((unsigned)blockIdx.x * 4u + (unsigned)wave) * (4u * HEAD_TPW);
-    BPos cur[4], nxt[4];
-    {
+    const long long npix = (long long)p.N * p.H * p.W;
+    long long pbase = ((long long)blockIdx.x * 4 + (tid >> 6)) * (64 * HEAD_TPW);  // ROI = false
+    BPos cur[4], nxt[4];                                                           // ROI = true
+    if constexpr (ROI) {
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const unsigned nblk = (unsigned)p.N * (unsigned)p.rows * (unsigned)p.nxb;  // launcher: < 2^31
+        const unsigned b0 = ((unsigned)blockIdx.x * 4u + (unsigned)wave) * (4u * HEAD_TPW);
         const unsigned bc = b0 < nblk ? b0 : nblk;
         const unsigned r = bc / (unsigned)p.nxb;
         cur[0].xb = (int)(bc - r * (unsigned)p.nxb);
@@ -267,13 +266,22 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
 #pragma unroll
         for (int pb = 1; pb < 4; ++pb) nxt[pb] = inc(nxt[pb - 1]);
     }
+    auto ptr_of = [&](const BPos& b) {  // blocks past the end (n == N) and pixels past the row end are clamped here, dropped at the store
+        const int n = min(b.n, p.N - 1), x = min(p.xa0 + 16 * b.xb + px, p.W - 1);
+        return p.feat + (((long long)n * p.H + p.row0 + b.row) * p.W + x) * 64 + 4 * ks;
+    };
+    auto feat_ptr = [&](int pb, bool next) {
+        if constexpr (ROI) return ptr_of(next ? nxt[pb] : cur[pb]);
+        const long long P = pbase + (next ? 64 : 0) + pb * 16 + px;
+        return p.feat + (P < npix ? P : npix - 1) * 64 + 4 * ks;
+    };
     // a wave walks HEAD_TPW consecutive tasks of 4 blocks; the first channel group of the next task is requested before this
     // task's second GEMM and softmax, so the HBM latency of the feature read hides behind them
     f32x4h x[4];
 #pragma unroll
-    for (int pb = 0; pb < 4; ++pb) x[pb] = *reinterpret_cast<const f32x4h*>(ptr_of(cur[pb]));
+    for (int pb = 0; pb < 4; ++pb) x[pb] = *reinterpret_cast<const f32x4h*>(feat_ptr(pb, false));
 #pragma unroll 1
-    for (int task = 0; task < HEAD_TPW; ++task) {
+    for (int task = 0; task < HEAD_TPW; ++task, pbase += 64) {
     f32x4h acc1[6][4];
 #pragma unroll
     for (int blk = 0; blk < 6; ++blk) {
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
     }
     const float* xp[4];
 #pragma unroll
-    for (int pb = 0; pb < 4; ++pb) xp[pb] = ptr_of(cur[pb]);
+    for (int pb = 0; pb < 4; ++pb) xp[pb] = feat_ptr(pb, false);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4h xn[4];
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
             for (int pb = 0; pb < 4; ++pb) xn[pb] = *reinterpret_cast<const f32x4h*>(xp[pb] + (g + 1) * 16);
         } else if (task + 1 < HEAD_TPW) {
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb) xn[pb] = *reinterpret_cast<const f32x4h*>(ptr_of(nxt[pb]));
+            for (int pb = 0; pb < 4; ++pb) xn[pb] = *reinterpret_cast<const f32x4h*>(feat_ptr(pb, true));
         }
 #pragma unroll
         for (int blk = 0; blk < 6; ++blk) {
@@ -344,22 +352,33 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
         lg[4 + e] = hi;
     }
     // lane group ks finishes block ks of this task
-    int n = cur[0].n, y_ = cur[0].row, xb_ = cur[0].xb;
+    int n, y_, x_;
+    if constexpr (ROI) {
+        int xb_ = cur[0].xb;
+        n = cur[0].n;
+        y_ = cur[0].row;
 #pragma unroll
-    for (int pb = 1; pb < 4; ++pb) {
-        n = (ks == pb) ? cur[pb].n : n;
-        y_ = (ks == pb) ? cur[pb].row : y_;
-        xb_ = (ks == pb) ? cur[pb].xb : xb_;
+        for (int pb = 1; pb < 4; ++pb) {
+            n = (ks == pb) ? cur[pb].n : n;
+            y_ = (ks == pb) ? cur[pb].row : y_;
+            xb_ = (ks == pb) ? cur[pb].xb : xb_;
+        }
+        y_ += p.row0;
+        x_ = p.xa0 + 16 * xb_ + px;
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) cur[pb] = nxt[pb];
+        nxt[0] = inc(cur[3]);
+#pragma unroll
+        for (int pb = 1; pb < 4; ++pb) nxt[pb] = inc(nxt[pb - 1]);
+        if (n >= p.N || x_ >= p.W) continue;
+    } else {
+        const long long P = pbase + ks * 16 + px;
+        if (P >= npix) continue;
+        x_ = (int)(P % p.W);
+        const long long r_ = P / p.W;
+        y_ = (int)(r_ % p.H);
+        n = (int)(r_ / p.H);
     }
-    y_ += p.row0;
-    const int x_ = p.xa0 + 16 * xb_ + px;
-    const bool live = n < p.N && x_ < p.W;
-#pragma unroll
-    for (int pb = 0; pb < 4; ++pb) cur[pb] = nxt[pb];
-    nxt[0] = inc(cur[3]);
-#pragma unroll
-    for (int pb = 1; pb < 4; ++pb) nxt[pb] = inc(nxt[pb - 1]);
-    if (!live) continue;
     if (p.logits) {
         const long long P = ((long long)n * p.H + y_) * p.W + x_;
         for (int e = 0; e < p.out_ch; ++e) p.logits[P * p.out_ch + e] = lg[e];
@@ -411,7 +430,8 @@ hipError_t cerb_launch_head(const HeadParams& p_in, hipStream_t st) {
     }
     const long long nblk = (long long)p.N * p.rows * p.nxb;  // 16-pixel blocks; a workgroup takes 16 * HEAD_TPW of them
     const long long blocks = (nblk + 16 * HEAD_TPW - 1) / (16 * HEAD_TPW);
-    hipLaunchKernelGGL(head_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    if (p.rows == p.H && p.nxb * 16 == p.W) hipLaunchKernelGGL(head_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(head_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
