@@ -95,3 +95,32 @@ def test_run_infer_wsi_cli_with_tissue_mask(tmp_path):
     for tname in ("Gland", "Lumen"):
         for d in dat.get(tname, {}).values():
             assert d["box"].shape == (4,) and d["contour"].shape[1] == 2
+
+
+def test_bench_contract_single_and_two_ranks(tmp_path):
+    """bench.py prints ONE JSON line with the contract's keys; under torch.distributed.run with two ranks (both on this box's
+    single GPU, gloo for the barrier / max-reduction -- RCCL refuses two ranks on one device) rank 0 reports the whole job."""
+    import json
+
+    def run(cmd):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+
+    one = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline"):
+        assert k in one, k
+    assert one["n_gpus"] == 1 and one["steps"] == 3 and one["unit"] == "Mpx/s" and one["scaling"] == "weak" and one["vs_baseline"] is None
+    rf = one["roofline"]
+    assert rf["bound"] == "mfma" and rf["peak"] == 157.3 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 0.01
+    assert abs(one["value"] - 32 * 256 * 256 / (one["ms_per_step"] * 1e-3) / 1e6) / one["value"] < 0.01
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+               "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo"])
+    assert two["n_gpus"] == 2 and "cpu_baseline" not in two
+    # two ranks time-share one GPU here: each step takes about twice as long and the aggregate stays about the same
+    assert abs(two["value"] - 2 * 32 * 256 * 256 / (two["ms_per_step"] * 1e-3) / 1e6) / two["value"] < 0.01
+    assert 0.6 < two["value"] / one["value"] < 1.25
