@@ -347,8 +347,13 @@ __global__ void ws_bbox_kernel(const int* __restrict__ L, const uint8_t* __restr
 //   global tier : everything else                                                        -> heap in global memory (back of wl)
 //   big-window  : bounding box fits WS_BIGWIN_CAP pixels and (seeds + unlabelled mask pixels) <= WS_BIGHEAP_CAP: one wave per
 //                 workgroup with ~150 KB of LDS                                                                  (wl3)
+#ifndef WS_FLAT_QUEUE
+#define WS_FLAT_QUEUE 1
+#endif
 #define WS_LDS_CAP 1024
 #define WS_WIN_CAP 2304
+#define WS_TINY_CAP 512    // tiny-window tier: pairs / small clusters; 13 KB of LDS per wave -> 12 waves per CU instead of 4
+#define WS_TINY_WIN 1024
 #define WS_BIGWIN_CAP 16384
 #define WS_BIGHEAP_CAP 2048
 // A component all of whose seeds carry ONE label needs no priority flood: every unlabelled mask pixel of a 4-connected mask
@@ -356,13 +361,14 @@ __global__ void ws_bbox_kernel(const int* __restrict__ L, const uint8_t* __restr
 // (ws_fill_single_kernel).  Isolated nuclei -- the common case -- take this path; only touching clusters reach the heaps.
 __global__ void ws_worklist_kernel(const int* __restrict__ hcnt, const int* __restrict__ area, const int* __restrict__ unl, const CBox* __restrict__ bb,
                                    const int* __restrict__ lmin, const int* __restrict__ lmax, int* __restrict__ wl, int* __restrict__ wl2,
-                                   int* __restrict__ wl3, int* __restrict__ counts, int n) {
+                                   int* __restrict__ wl3, int* __restrict__ wl4, int* __restrict__ counts, int n) {
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
         if (hcnt[p] > 0 && lmin[p] != lmax[p]) {
             const CBox b = bb[p];
             const long long win = (long long)(b.y2 - b.y1 + 3) * (b.x2 - b.x1 + 3);
             const int need = hcnt[p] + unl[p];  // every queue entry is a seed or a pixel that was unlabelled at the start
-            if (need <= WS_LDS_CAP && win <= WS_WIN_CAP) wl[atomicAdd(counts + 0, 1)] = (int)p;
+            if (need <= WS_TINY_CAP && win <= WS_TINY_WIN) wl4[atomicAdd(counts + 4, 1)] = (int)p;
+            else if (need <= WS_LDS_CAP && win <= WS_WIN_CAP) wl[atomicAdd(counts + 0, 1)] = (int)p;
             else if (need <= WS_BIGHEAP_CAP && win <= WS_BIGWIN_CAP) wl3[atomicAdd(counts + 3, 1)] = (int)p;
             else if (area[p] <= WS_LDS_CAP) wl2[atomicAdd(counts + 1, 1)] = (int)p;
             else wl[n - 1 - atomicAdd(counts + 2, 1)] = (int)p;
@@ -579,6 +585,62 @@ __global__ __launch_bounds__(WAVES * 64) void ws_flood_window_kernel(const float
             }
             n += __popcll(m);
         }
+#if WS_FLAT_QUEUE
+        // ---- flood with an UNORDERED queue: the frontier of a nucleus cluster is a few dozen to a few hundred entries, so the
+        // minimum is found by one strided scan (each lane keeps the best of its entries) + one wave-wide argmin, the popped slot is
+        // refilled with the last entry and the (up to four) pushes are plain appends done by lanes 0..3 in parallel.  Same total
+        // order as the heap ((value, age), then window index), hence the same pops.
+        u32 age = 0;
+        bool have_prev_seed = false, ambiguous = false;
+        u32 prev_seed_val = 0;
+        int prev_seed_lab = 0;
+        while (n > 0) {
+            u64 bk = ~0ull;
+            u32 bi = ~0u;
+            int bpos = -1;
+            for (int c = lane; c < n; c += 64) {
+                const u64 ck = hk[c];
+                const u32 ci = hi[c];
+                if (bpos < 0 || hless(ck, ci, bk, bi)) {
+                    bk = ck;
+                    bi = ci;
+                    bpos = c;
+                }
+            }
+            u64 k;
+            u32 wi_u;
+            const int wl_ = wave_argmin(bk, bi, bpos >= 0, &k, &wi_u);
+            const int pos = __shfl(bpos, wl_);
+            const int wi = (int)wi_u;
+            const int lab = st[wi];
+            --n;
+            if (lane == 0 && pos != n) {
+                hk[pos] = hk[n];
+                hi[pos] = hi[n];
+            }
+            if ((u32)k == 0u) {  // seed: see ws_flood_kernel
+                const u32 v = (u32)(k >> 32);
+                if (have_prev_seed && v == prev_seed_val && lab != prev_seed_lab) ambiguous = true;
+                have_prev_seed = true;
+                prev_seed_val = v;
+                prev_seed_lab = lab;
+            }
+            // lanes 0..3: up, left, right, down (skimage's neighbour order); the ring of -1 makes bounds checks unnecessary
+            const int nq = wi + (lane == 0 ? -ww : lane == 1 ? -1 : lane == 2 ? 1 : ww);
+            bool elig = false;
+            if (lane < 4) elig = st[nq] == 0;
+            const u64 em = __ballot(elig);
+            if (elig) {
+                const int before = __popcll(em & ((1ull << lane) - 1));
+                st[nq] = lab;
+                hk[n + before] = ((u64)vl[nq] << 32) | (u64)(age + 1 + before);
+                hi[n + before] = (unsigned short)nq;
+            }
+            const int np = __popcll(em);
+            n += np;
+            age += np;
+        }
+#else
         // ---- heapify (Floyd) ----------------------------------------------------------------------------------------------
         for (int i = (n - 2) >> 6; i >= 0 && n > 1; --i) {
             const u64 k = hk[i];
@@ -684,6 +746,7 @@ __global__ __launch_bounds__(WAVES * 64) void ws_flood_window_kernel(const float
                 }
             }
         }
+#endif
         // ---- write back -----------------------------------------------------------------------------------------------------
         for (int i = lane; i < wn; i += 64) {
             const int s = st[i];
@@ -1032,6 +1095,29 @@ static void ellipse_spans(int k, Spans* s) {  // cv2.getStructuringElement(MORPH
     }
 }
 
+struct SideStreams {
+    hipStream_t s[3];
+    hipEvent_t fork, join[3];
+};
+static SideStreams* side_streams() {  // one set per device, created on first use (handles are used from one host thread, SURVEY par.8b)
+    static SideStreams* per_dev[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!per_dev[dev]) {
+        SideStreams* ss = new SideStreams();
+        bool ok = hipEventCreateWithFlags(&ss->fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 3 && ok; ++i)
+            ok = hipStreamCreateWithFlags(&ss->s[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&ss->join[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            delete ss;
+            return nullptr;
+        }
+        per_dev[dev] = ss;
+    }
+    return per_dev[dev];
+}
+
 extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long row_stride, int pix_stride, int32_t* labels_out,
                                     int32_t* n_inst_out, int32_t* n_ambiguous_out, void* ws, size_t ws_bytes, void* hip_stream) {
     hipStream_t st = (hipStream_t)hip_stream;
@@ -1056,6 +1142,7 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
     uint8_t* msk = (uint8_t*)cv.take(n);
     uint8_t* mrk = (uint8_t*)cv.take(n);
     int* scantmp = (int*)cv.take((size_t)(n / SCAN_ITEMS + 4096) * 4 * 2);
+    int* wl4 = (int*)cv.take((size_t)n * 4);    // tiny-window tier list
     int* lmax = (int*)cv.take((size_t)n * 4);   // per mask component: largest seed label (smallest one lives in LB once the markers are final)
     int* small = (int*)cv.take(256);  // [0]=any [1]=worklist count [2]=n_inst scratch [3]=ambiguous scratch
     if (!small) return cerb_set_error("cerb_postproc_nuclei: workspace carve failed");
@@ -1099,27 +1186,42 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
     hipLaunchKernelGGL(ws_bbox_init_kernel, dim3(g), dim3(256), 0, st, LA, msk, cbox, H, W);
     hipLaunchKernelGGL(ws_bbox_kernel, dim3(g), dim3(256), 0, st, LA, msk, cbox, H, W);
     int* counts = small + 8;  // [0] window tier, [1] LDS-heap tier, [2] global tier
-    hipLaunchKernelGGL(ws_worklist_kernel, dim3(g), dim3(256), 0, st, hcnt, areaA, unl, cbox, lmin, lmax, wl, rank, wl3, counts, n);
+    hipLaunchKernelGGL(ws_worklist_kernel, dim3(g), dim3(256), 0, st, hcnt, areaA, unl, cbox, lmin, lmax, wl, rank, wl3, wl4, counts, n);
     hipLaunchKernelGGL(ws_fill_single_kernel, dim3(g), dim3(256), 0, st, msk, LA, lmin, lmax, labels_out, n);
     {
+        auto k_tiny = ws_flood_window_kernel<WS_TINY_WIN, WS_TINY_CAP, 4>;
         auto k_small = ws_flood_window_kernel<WS_WIN_CAP, WS_LDS_CAP, 2>;
         auto k_big = ws_flood_window_kernel<WS_BIGWIN_CAP, WS_BIGHEAP_CAP, 1>;
         constexpr int lds_small = 2 * (WS_LDS_CAP * 10 + WS_WIN_CAP * 8), lds_big = WS_BIGHEAP_CAP * 10 + WS_BIGWIN_CAP * 8;
+        constexpr int lds_tiny = 4 * (WS_TINY_CAP * 10 + WS_TINY_WIN * 8);
         static bool attr_done = false;
         if (!attr_done) {
             PP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_small), hipFuncAttributeMaxDynamicSharedMemorySize, lds_small));
+            PP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tiny), hipFuncAttributeMaxDynamicSharedMemorySize, lds_tiny));
             PP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_big), hipFuncAttributeMaxDynamicSharedMemorySize, lds_big));
             attr_done = true;
         }
-        hipLaunchKernelGGL(k_small, dim3(256 * 2), dim3(128), lds_small, st, inst, row_stride, pix_stride, msk, LA, labels_out, wl, counts + 0, cbox,
+        // The tiers touch disjoint components and each one ends with the tail of its longest flood: fork them onto side streams
+        // (created once per device) so that the tails overlap instead of adding up; `st` resumes when all of them are done.
+        SideStreams* ss = side_streams();
+        if (!ss) return cerb_set_error("cerb_postproc_nuclei: side stream creation failed");
+        PP_OK(hipEventRecord(ss->fork, st));
+        for (int i = 0; i < 3; ++i) PP_OK(hipStreamWaitEvent(ss->s[i], ss->fork, 0));
+        hipLaunchKernelGGL(k_tiny, dim3(256 * 3), dim3(256), lds_tiny, ss->s[0], inst, row_stride, pix_stride, msk, LA, labels_out, wl4, counts + 4, cbox,
+                           H, W, small + 3);
+        hipLaunchKernelGGL(k_small, dim3(256 * 2), dim3(128), lds_small, ss->s[1], inst, row_stride, pix_stride, msk, LA, labels_out, wl, counts + 0, cbox,
                            H, W, small + 3);
         hipLaunchKernelGGL(k_big, dim3(256), dim3(64), lds_big, st, inst, row_stride, pix_stride, msk, LA, labels_out, wl3, counts + 3, cbox, H, W,
                            small + 3);
+        hipLaunchKernelGGL(ws_flood_lds_kernel, dim3(256 * 2), dim3(256), 0, ss->s[2], inst, row_stride, pix_stride, msk, labels_out, rank, counts + 1,
+                           hoff, hcnt, hkey, hidx, H, W, small + 3);
+        hipLaunchKernelGGL(ws_flood_kernel, dim3(256 * 4), dim3(256), 0, ss->s[2], inst, row_stride, pix_stride, msk, labels_out, wl, counts + 2, hoff,
+                           hcnt, hkey, hidx, H, W, small + 3, n);
+        for (int i = 0; i < 3; ++i) {
+            PP_OK(hipEventRecord(ss->join[i], ss->s[i]));
+            PP_OK(hipStreamWaitEvent(st, ss->join[i], 0));
+        }
     }
-    hipLaunchKernelGGL(ws_flood_lds_kernel, dim3(256 * 2), dim3(256), 0, st, inst, row_stride, pix_stride, msk, labels_out, rank, counts + 1, hoff,
-                       hcnt, hkey, hidx, H, W, small + 3);
-    hipLaunchKernelGGL(ws_flood_kernel, dim3(256 * 4), dim3(256), 0, st, inst, row_stride, pix_stride, msk, labels_out, wl, counts + 2, hoff, hcnt,
-                       hkey, hidx, H, W, small + 3, n);
     KCHECK();
     if (n_ambiguous_out) PP_OK(hipMemcpyAsync(n_ambiguous_out, small + 3, 4, hipMemcpyDeviceToDevice, st));
     return 0;
