@@ -598,14 +598,31 @@ __global__ __launch_bounds__(WAVES * 64) void ws_flood_window_kernel(const float
             u64 bk = ~0ull;
             u32 bi = ~0u;
             int bpos = -1;
-            for (int c = lane; c < n; c += 64) {
-                const u64 ck = hk[c];
-                const u32 ci = hi[c];
-                if (bpos < 0 || hless(ck, ci, bk, bi)) {
-                    bk = ck;
-                    bi = ci;
-                    bpos = c;
+            {
+                // four strided entries per lane and trip: the LDS reads of a trip are independent, so their latencies overlap
+                // (plain pointers for that; the empty asm keeps the compiler from carrying queue contents across pops)
+                asm volatile("" ::: "memory");
+                const u64* hkq = const_cast<const u64*>(hk);
+                const unsigned short* hiq = const_cast<const unsigned short*>(hi);
+                for (int c = lane; c < n; c += 256) {
+                    u64 ck[4];
+                    u32 ci[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int cc = c + 64 * u;
+                        const bool in = cc < n;
+                        ck[u] = in ? hkq[cc] : ~0ull;
+                        ci[u] = in ? (u32)hiq[cc] : ~0u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (c + 64 * u < n && (bpos < 0 || hless(ck[u], ci[u], bk, bi))) {
+                            bk = ck[u];
+                            bi = ci[u];
+                            bpos = c + 64 * u;
+                        }
                 }
+                asm volatile("" ::: "memory");
             }
             u64 k;
             u32 wi_u;
