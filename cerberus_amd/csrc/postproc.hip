@@ -335,10 +335,11 @@ __global__ void ws_bbox_kernel(const int* __restrict__ L, const uint8_t* __restr
         const int y = (int)(p / W), x = (int)(p % W);
         if (y > 0 && y < H - 1 && x > 0 && x < W - 1 && mask[p - W] && mask[p + W] && mask[p - 1] && mask[p + 1]) continue;
         CBox* b = bb + L[p];
-        atomicMin(&b->y1, y);
-        atomicMax(&b->y2, y);
-        atomicMin(&b->x1, x);
-        atomicMax(&b->x2, x);
+        const volatile CBox* vb = b;  // monotone extremes: skip the atomic when a plain read already covers the pixel
+        if (y < vb->y1) atomicMin(&b->y1, y);
+        if (y > vb->y2) atomicMax(&b->y2, y);
+        if (x < vb->x1) atomicMin(&b->x1, x);
+        if (x > vb->x2) atomicMax(&b->x2, x);
     }
 }
 // Compact lists of component roots that own at least one seed, in three tiers:
@@ -955,10 +956,13 @@ __global__ void box_accum_kernel(const int* __restrict__ lab, Box* b, int H, int
         const int y = (int)(p / W), x = (int)(p % W);
         // only pixels on the instance outline can be bounding-box extremes (keeps the atomics off the interior)
         if (y > 0 && y < H - 1 && x > 0 && x < W - 1 && lab[p - W] == l && lab[p + W] == l && lab[p - 1] == l && lab[p + 1] == l) continue;
-        atomicMin(&b[l].y1, y);
-        atomicMax(&b[l].y2, y + 1);
-        atomicMin(&b[l].x1, x);
-        atomicMax(&b[l].x2, x + 1);
+        // the extremes only ever move outwards, so a (possibly stale) plain read that already covers this pixel makes the atomic
+        // unnecessary -- a slide-sized ragged instance would otherwise serialise millions of atomics on one box
+        const volatile Box* vb = b + l;
+        if (y < vb->y1) atomicMin(&b[l].y1, y);
+        if (y + 1 > vb->y2) atomicMax(&b[l].y2, y + 1);
+        if (x < vb->x1) atomicMin(&b[l].x1, x);
+        if (x + 1 > vb->x2) atomicMax(&b[l].x2, x + 1);
     }
 }
 // crop = bounding box padded by 2*ksize on each side only where the padded edge stays inside (postproc.py:296-300)
