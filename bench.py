@@ -189,7 +189,7 @@ def main():
     postproc = None
     if rank == 0:
         from cerberus_amd.postproc import postproc_device
-        from oracle import synth  # structured synthetic INPUT generator only (numpy), not a checker here
+        from cerberus_amd import synth_maps as synth  # structured synthetic INPUT generator (numpy)
 
         PH = 2048
         maps = {
@@ -215,6 +215,7 @@ def main():
             postproc_device(canvas[t], t)
         torch.cuda.synchronize()
         postproc["own_canvas_all_tissues_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        postproc["own_canvas_note"] = "random-weight network => degenerate maps (canvas-sized components): the flood's serial worst case"
 
     if rank == 0:
         px = world * args.steps * BATCH * TILE * TILE

@@ -1,0 +1,58 @@
+"""Seeded structured probability maps (blobs with inner / contour channels, the shape of a trained Cerberus head's output): synthetic
+INPUT for the post-processing benchmarks and tests -- `bench.py`'s postproc leg, scripts/, and (re-exported by oracle/synth.py) the
+golden-vector generators.  numpy only; no checker lives here."""
+import numpy as np
+
+
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def blob_maps(H, W, seed, n_blobs, rmin, rmax, sharp=1.5, noise=0.0, holes=0.0, rim=2.0, border_bias=False):
+    """Returns (H,W,2) float32: ch0 inner prob, ch1 contour prob."""
+    rs = np.random.RandomState(seed)
+    d = np.full((H, W), -1e9, np.float32)  # signed distance-ish field: max over blobs of (r - dist)
+    for i in range(n_blobs):
+        r = rs.uniform(rmin, rmax)
+        if border_bias and i % 3 == 0:
+            cy, cx = (rs.choice([0.0, H - 1.0]), rs.uniform(0, W)) if rs.rand() < 0.5 else (rs.uniform(0, H), rs.choice([0.0, W - 1.0]))
+        else:
+            cy, cx = rs.uniform(0, H), rs.uniform(0, W)
+        ax = rs.uniform(0.7, 1.3)
+        th = rs.uniform(0, np.pi)
+        hole = holes > 0 and rs.rand() < holes
+        # each blob only touches a window around itself (cost O(blob area), not O(H*W))
+        ext = int(np.ceil(r * 1.45 + 14.0))
+        y0, y1 = max(0, int(cy) - ext), min(H, int(cy) + ext + 1)
+        x0, x1 = max(0, int(cx) - ext), min(W, int(cx) + ext + 1)
+        if y0 >= y1 or x0 >= x1:
+            continue
+        yy, xx = np.mgrid[y0:y1, x0:x1].astype(np.float32)
+        dy, dx = yy - np.float32(cy), xx - np.float32(cx)
+        u = (np.cos(th) * dx + np.sin(th) * dy) * ax
+        v = (-np.sin(th) * dx + np.cos(th) * dy) / ax
+        dist = np.sqrt(u * u + v * v)
+        f = r - dist
+        if hole:
+            f = np.minimum(f, dist - 0.35 * r)  # annulus: a hole in the middle
+        d[y0:y1, x0:x1] = np.maximum(d[y0:y1, x0:x1], f.astype(np.float32))
+    d = np.maximum(d, np.float32(-40.0))
+    inner = _sigmoid(sharp * (d - rim))
+    cnt = _sigmoid(sharp * (rim - np.abs(d - 0.5 * rim))) * 0.95
+    if noise > 0:
+        inner = inner + rs.normal(0, noise, inner.shape)
+        cnt = cnt + rs.normal(0, noise, cnt.shape)
+    out = np.stack([np.clip(inner, 0, 1), np.clip(cnt, 0, 1)], axis=-1)
+    return out.astype(np.float32)
+
+
+def nuclei_maps(H, W, seed, density_per_mpx=600.0, **kw):
+    n = max(1, int(round(density_per_mpx * H * W / 1e6)))
+    return blob_maps(H, W, seed, n, 4.0, 9.0, **kw)
+
+
+def gland_maps(H, W, seed, n=None, **kw):
+    n = n if n is not None else max(1, int(round(12.0 * H * W / 1e6)))
+    kw.setdefault("rim", 4.0)
+    kw.setdefault("sharp", 1.0)
+    return blob_maps(H, W, seed, n, 25.0, 150.0, **kw)
