@@ -1,6 +1,6 @@
 """Seeded structured probability maps (blobs with inner / contour channels, the shape of a trained Cerberus head's output): synthetic
-INPUT for the post-processing benchmarks and tests -- `bench.py`'s postproc leg, scripts/, and (re-exported by oracle/synth.py) the
-golden-vector generators.  numpy only; no checker lives here."""
+INPUT for the post-processing benchmarks and tests -- `bench.py`'s postproc leg, scripts/, and (re-exported by the test
+infrastructure's `synth` module) the golden-vector generators.  numpy only; no checker lives here."""
 import numpy as np
 
 
