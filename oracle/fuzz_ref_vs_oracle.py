@@ -1,4 +1,4 @@
-"""Pin the C oracle harder: random maps (same distribution as scripts/dev_fuzz_pp.py, tie-heavy kinds included) through the
+"""Pin the C oracle harder: random maps (same distribution as tests/tools/dev_fuzz_pp.py, tie-heavy kinds included) through the
 REFERENCE's own post_process (real scikit-image / scipy under /opt/conda/bin/python3.9, cv2 stand-in) and through
 oracle/postproc_ref.c.  TEST INFRASTRUCTURE; runs only in the build container (needs /root/reference).
 

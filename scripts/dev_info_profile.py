@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from cerberus_amd.postproc import postproc_device, inst_table_device, inst_contours_device, get_inst_info_dict
 from cerberus_amd.wsi import build_wsi_inst_info
-from oracle import synth
+from cerberus_amd import synth_maps as synth
 H = W = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 m = torch.from_numpy(synth.nuclei_maps(H, W, 7, 1000.0, noise=0.02)).cuda()
 tm = torch.randint(0, 7, (H, W), dtype=torch.uint8, device="cuda")

@@ -2,7 +2,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from cerberus_amd.postproc import postproc_device
-from oracle import synth
+from cerberus_amd import synth_maps as synth
 H = W = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 m = torch.from_numpy(synth.nuclei_maps(H, W, 7, 1000.0, noise=0.02)).cuda()
 for rep in range(4):

@@ -1,6 +1,6 @@
 """Developer check: conv_algo 2 (Winograd with bf16x3 products) against the oracle and against algo 1."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from cerberus_amd.net_desc import create_model
 from cerberus_amd.weights import default_model_kwargs, make_state_dict

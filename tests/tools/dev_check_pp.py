@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from cerberus_amd.postproc import postproc_device
 from oracle import postproc_ref as pr, synth

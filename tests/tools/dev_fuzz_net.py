@@ -1,6 +1,6 @@
 """Developer fuzz: random tile geometries / batch sizes / crops, HIP forward + output wrapper vs the torch-CPU oracle."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from cerberus_amd.net_desc import create_model
 from cerberus_amd.run_desc import infer_step

@@ -2,7 +2,7 @@
 On a 1-GPU box both ranks share device 0 -- RCCL may refuse that ("duplicate GPU"); then the gloo run below still exercises
 the CUDA-tensor code path of run_distributed."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, torch.distributed as dist
 from cerberus_amd import shard_postproc as sp
 from cerberus_amd.postproc import postproc_device
