@@ -11,6 +11,7 @@ Multi-GPU: launch under `python -m torch.distributed.run --nproc-per-node N run_
 contiguous band per rank, inference needs no collective, post-processing is band-local (cerberus_amd/shard_postproc.py)."""
 import glob
 import os
+import threading
 import time
 
 import numpy as np
@@ -21,6 +22,12 @@ from cerberus_amd.cli import WSI_OPTIONS, parse
 def _basename(path, ext):
     base = os.path.basename(path)
     return base[: -len(ext)] if ext else base
+
+
+def _write_then_rename(write, obj, path):
+    tmp = path + ".part"
+    write(obj, tmp)
+    os.replace(tmp, path)
 
 
 def _open_slide(path):
@@ -78,6 +85,7 @@ def main(argv=None):
     slides = slides[(bulk - 1) * step: bulk * step]
     print("Number of WSIs in list:", len(slides))
     win, out, batch = int(args["--patch_input_shape"]), int(args["--patch_output_shape"]), int(args["--batch_size"])
+    writer = None
     for path in slides:
         base = _basename(path, ext)
         dat_path = os.path.join(out_dir, "dat", base + ".dat")
@@ -143,10 +151,18 @@ def main(argv=None):
         t3 = time.perf_counter()
         os.makedirs(os.path.dirname(dat_path), exist_ok=True)
         nuc_only = {k: v for k, v in inst.items() if k == "Nuclei"} if records is not None else inst
-        write_dat(build_wsi_inst_info(nuc_only, maps, (H, W), float(args["--wsi_proc_mag"]), region_records=records), dat_path)
+        info = build_wsi_inst_info(nuc_only, maps, (H, W), float(args["--wsi_proc_mag"]), region_records=records)
+        # serialising ~1e6 per-instance dictionaries is host-only work: it overlaps the next slide's inference (written to a temporary
+        # name and renamed, so a finished dat/<slide>.dat is always complete -- the resume-by-skip above relies on that)
+        if writer is not None:
+            writer.join()
+        writer = threading.Thread(target=_write_then_rename, args=(write_dat, info, dat_path))
+        writer.start()
         t4 = time.perf_counter()
         print("%s: Inference Time: %.3f  Post Proc Time: %.3f  Instance Table Time: %.3f  (%.1f Mpx/s inference)" % (
             base, t1 - t0, t2 - t1, t4 - t3, H * W / (t1 - t0) / 1e6))
+    if writer is not None:
+        writer.join()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

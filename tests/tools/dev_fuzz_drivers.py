@@ -1,7 +1,7 @@
 """Developer fuzz: tile manager / WSI runner / sharding / sharded post-processing on random image sizes and patch geometries."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tests/: test_drivers_gpu._oracle_stitch
 import numpy as np, torch
 from cerberus_amd import shard_postproc as sp
 from cerberus_amd.postproc import postproc_device
