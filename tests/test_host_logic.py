@@ -73,12 +73,17 @@ def _free_port():
     return p
 
 
-def _gather_worker(rank, world, port, ret):
+def _gather_worker(rank, world, port, ret, masked=False):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    geo = SlideGeometry((1000, 700), 256, 256)  # 4 patch rows x 3 cols
+    # 4 patch rows x 3 cols; with a tissue mask the bands are balanced by selected patches (row 0 carries all the tissue here), so
+    # the ranks hold bands of different heights
+    sel = np.array([[1, 1, 1], [0, 0, 0], [0, 1, 0], [0, 0, 1]], bool) if masked else None
+    geo = SlideGeometry((1000, 700), 256, 256, patch_sel=sel)
+    if masked and world == 2:
+        assert geo.bounds(2) == [0, 1, 4]
     r0, r1 = geo.band(rank, world)
     full_ref = torch.arange(geo.rows * 256 * geo.cols * 256 * 2, dtype=torch.float32).view(geo.rows * 256, geo.cols * 256, 2)
     tref = (torch.arange(geo.rows * 256 * geo.cols * 256) % 251).to(torch.uint8).view(geo.rows * 256, geo.cols * 256)
@@ -93,14 +98,14 @@ def _gather_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_gather_stitch_gloo(world):
+@pytest.mark.parametrize("world,masked", [(2, False), (3, False), (2, True)])
+def test_gather_stitch_gloo(world, masked):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, ret, masked)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
