@@ -108,7 +108,11 @@ int cerb_net_profile_get(cerb_net* net, int idx, char* name, int name_cap, char*
  *        n_ambiguous_out : device int32[1] (nuclei only): number of
  *        watershed regions whose result depends on skimage's heap-internal order between seed pixels with
  *        bit-identical priority (see DESIGN.md "watershed ties"); 0 means the label map is provably identical.
- * ws / ws_bytes : caller-allocated device workspace of at least cerb_pp_workspace_bytes(H, W). */
+ * ws / ws_bytes : caller-allocated device workspace of at least cerb_pp_workspace_bytes(H, W).
+ * Streams: everything is ordered on `hip_stream`.  cerb_postproc_nuclei forks its independent flood tiers onto three internal
+ * side streams per device (created on first use, joined back into `hip_stream` with events before it returns) -- the only
+ * process-level state of the library; like the reference's run_step / post_process it is meant to be driven from one host
+ * thread per GPU (SURVEY par.8b). */
 size_t cerb_pp_workspace_bytes(int h, int w);
 int cerb_postproc_nuclei(const float* inst, int h, int w, long long row_stride, int pix_stride, int32_t* labels_out,
                          int32_t* n_inst_out, int32_t* n_ambiguous_out, void* ws, size_t ws_bytes, void* hip_stream);
