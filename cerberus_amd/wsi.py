@@ -188,13 +188,18 @@ class WSIRunner(object):
     def slab_rows(self):
         return self.geo.input_rows(self.r0, self.r1)
 
-    def infer_band(self, slab, slab_y0):
+    def infer_band(self, slab, slab_y0, ready=None):
         """slab: uint8 [rows, W, 3] holding absolute slide rows [slab_y0, slab_y0+rows) (this rank's band + halo).
-        Runs every patch of the band; outputs land in self.canv.  Returns the number of patches."""
+        Runs every patch of the band; outputs land in self.canv.  Returns the number of patches.
+        ready: optional callable(n_rows) that makes the first n_rows rows of `slab` valid for work queued on the current stream
+        (SlabUploader.upload_until: the band is then uploaded chunk by chunk underneath the inference of the rows above)."""
         g = self.geo
         assert slab.shape[1] == g.W
+        tl_y_host = self._tl_y.cpu().numpy() if ready is not None else None
         for b0 in range(0, self.n_patches, self.batch):
             b1 = min(self.n_patches, b0 + self.batch)
+            if ready is not None:  # mirror padding only ever folds back to rows above the window's last in-slide row
+                ready(min(int(tl_y_host[b0:b1].max()) + g.win, g.H) - slab_y0)
             tiles = gather_patches(slab, slab_y0, g.H, self._tl_y[b0:b1], self._tl_x[b0:b1], g.win)
             self.net._run(tiles, g.out, g.out, self._outs, None, tile_off=self._off[b0:b1], row_stride=self.canvas_w, type_is_u8=True)
         return self.n_patches
@@ -285,3 +290,39 @@ def write_dat(obj, path):
 
     with open(path, "wb") as fh:
         pickle.dump(obj, fh, protocol=4)
+
+
+class SlabUploader(object):
+    """Host-resident slide band -> device slab, chunk by chunk through two pinned staging buffers on a copy stream, so that the
+    upload (and the page-cache / mmap read behind it) runs underneath the inference of the rows already on the device instead of
+    in front of it.  `upload_until(n_rows)` issues whatever chunks are still missing for the first n_rows rows and makes the
+    CURRENT stream wait for them; chunks are issued in order on one copy stream, so waiting for the last one covers all."""
+
+    def __init__(self, host, y0, y1, device=None, chunk_bytes=64 << 20):
+        self.host, self.y0 = host, int(y0)
+        self.rows, self.w = int(y1 - y0), int(host.shape[1])
+        self.dev = device or torch.device("cuda", torch.cuda.current_device())
+        self.slab = torch.empty((self.rows, self.w, 3), dtype=torch.uint8, device=self.dev)
+        self.chunk = max(1, min(self.rows, int(chunk_bytes) // max(1, self.w * 3)))
+        self.pinned = [torch.empty((self.chunk, self.w, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.busy = [None, None]  # event after which a staging buffer may be overwritten
+        self.copy_stream = torch.cuda.Stream(device=self.dev)
+        self.next_row, self.k, self.last_event = 0, 0, None
+
+    def upload_until(self, n_rows):
+        n_rows = min(int(n_rows), self.rows)
+        while self.next_row < n_rows:
+            i = self.k & 1
+            if self.busy[i] is not None:
+                self.busy[i].synchronize()
+            n = min(self.chunk, self.rows - self.next_row)
+            np.copyto(self.pinned[i][:n].numpy(), self.host[self.y0 + self.next_row: self.y0 + self.next_row + n])
+            with torch.cuda.stream(self.copy_stream):
+                self.slab[self.next_row: self.next_row + n].copy_(self.pinned[i][:n], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.copy_stream)
+            self.busy[i] = self.last_event = ev
+            self.next_row += n
+            self.k += 1
+        if self.last_event is not None:
+            torch.cuda.current_stream(self.dev).wait_event(self.last_event)

@@ -54,7 +54,7 @@ def main(argv=None):
 
     from cerberus_amd.tile import InferManager
     from cerberus_amd.weights import DEFAULT_REQ_TARGET_CODE, default_model_kwargs
-    from cerberus_amd.wsi import WSIRunner, build_wsi_inst_info, synth_slide, write_dat
+    from cerberus_amd.wsi import SlabUploader, WSIRunner, build_wsi_inst_info, synth_slide, write_dat
 
     dist = None
     torch.cuda.set_device(local)
@@ -107,8 +107,13 @@ def main(argv=None):
                 Image.fromarray(mask * 255).save(os.path.join(out_dir, "mask", base + ".png"))
         run = WSIRunner(manager.net, (H, W), win, out, batch, rank, world, patch_sel=sel)
         y0, y1 = run.slab_rows()  # this rank's band + context halo
-        slab = synth_slide(y1 - y0, W, y0=y0, seed=seed) if host is None else torch.from_numpy(np.ascontiguousarray(host[y0:y1])).cuda()
-        run.infer_band(slab, y0)
+        if host is None:
+            run.infer_band(synth_slide(y1 - y0, W, y0=y0, seed=seed), y0)
+        elif isinstance(host, np.memmap):  # a slide on disk: read + upload chunk by chunk on a copy stream underneath the inference of
+            up = SlabUploader(host, y0, y1)  # the rows above (an array already in RAM goes up in one 50 GB/s copy: nothing to hide)
+            run.infer_band(up.slab, y0, ready=up.upload_until)
+        else:
+            run.infer_band(torch.from_numpy(np.ascontiguousarray(host[y0:y1])).cuda(), y0)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         records = None

@@ -47,6 +47,20 @@ def test_run_infer_wsi_cli_synthetic(tmp_path):
            "--batch_size=6", "--patch_input_shape=448", "--patch_output_shape=144", "--save_label_maps"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
+    # the same slide as a .npy file on disk (memory-mapped, uploaded chunk by chunk underneath the inference): identical maps
+    import torch
+
+    from cerberus_amd.wsi import synth_slide
+
+    npy = tmp_path / "npy"
+    npy.mkdir()
+    np.save(str(npy / "s1.npy"), synth_slide(700, 900, seed=5).cpu().numpy())
+    r2 = subprocess.run([c.replace(str(spec), str(npy)).replace(".txt", ".npy").replace(str(out), str(tmp_path / "out2")) for c in cmd],
+                        capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    za, zb = np.load(str(out / "s1.npz")), np.load(str(tmp_path / "out2" / "s1.npz"))
+    for k in za.files:
+        assert np.array_equal(za[k], zb[k]), k
     z = np.load(str(out / "s1.npz"))
     assert z["Nuclei"].shape == (700, 900) and z["Gland"].shape == (350, 450) and z["Lumen"].shape == (350, 450)
     assert z["type_Nuclei-TYPE"].dtype == np.uint8

@@ -108,3 +108,35 @@ def test_band_postprocess_and_gather_single_rank_equals_root_path(manager):
         assert a.shape == b.shape, t
         assert same_partition(a, b), t
         assert info_b[t]["n_truncated"] == 0 and info_b[t]["n_unresolved"] == 0
+
+
+def test_pipelined_band_upload_equals_resident_slab(manager):
+    """SlabUploader: a host-resident band uploaded in chunks on a copy stream underneath the inference gives the same canvases as the
+    band uploaded up front (many small chunks here; 448 -> 144 so that windows reach well below their output rows)."""
+    from cerberus_amd.wsi import SlabUploader
+
+    H, W = 1300, 1000
+    host = np.random.RandomState(4).randint(0, 256, (H, W, 3)).astype(np.uint8)
+    for win, out, batch in ((448, 144, 5), (256, 256, 7)):
+        a = WSIRunner(manager.net, (H, W), win, out, batch_size=batch)
+        a.infer_band(torch.from_numpy(host).cuda(), 0)
+        ref = {k: v.clone() for k, v in a.canv.items()}
+        b = WSIRunner(manager.net, (H, W), win, out, batch_size=batch)
+        up = SlabUploader(host, 0, H, chunk_bytes=90 * W * 3)
+        assert up.chunk == 90
+        b.infer_band(up.slab, 0, ready=up.upload_until)
+        torch.cuda.synchronize()
+        assert up.next_row == H
+        for k in ref:
+            assert torch.equal(ref[k], b.canv[k]), (win, k)
+    # a band in the middle of the slide (rank 1 of 3): rows are relative to the slab
+    r = WSIRunner(manager.net, (H, W), 256, 256, batch_size=4, rank=1, world_size=3)
+    y0, y1 = r.slab_rows()
+    r.infer_band(torch.from_numpy(host[y0:y1]).cuda(), y0)
+    ref = {k: v.clone() for k, v in r.canv.items()}
+    r2 = WSIRunner(manager.net, (H, W), 256, 256, batch_size=4, rank=1, world_size=3)
+    up = SlabUploader(host, y0, y1, chunk_bytes=64 * W * 3)
+    r2.infer_band(up.slab, y0, ready=up.upload_until)
+    torch.cuda.synchronize()
+    for k in ref:
+        assert torch.equal(ref[k], r2.canv[k]), k
