@@ -187,46 +187,64 @@ class InferManager(object):
         """img: HxWx3 uint8 RGB (numpy).  Returns dict with device tensors:
         'raw': per-head stitched canvases cropped to the source image, 'inst': {Tissue: int32 label map},
         'type': {Tissue: uint8 map or None}, 'pclass': float32 map or None, 'info': per-tissue postproc info."""
+        return self.infer_images([img], patch_input_shape, patch_output_shape, batch_size, postproc_list)[0]
+
+    def infer_images(self, imgs, patch_input_shape, patch_output_shape, batch_size=32, postproc_list=("gland", "lumen", "nuclei", "patch-class")):
+        """Several images through SHARED batches (the reference caches a group of files and runs one DataLoader over all their
+        patches, infer/tile.py:300-420; a folder of 256 x 256 tiles would otherwise run at batch 1).  The canvases of the group are
+        row blocks of one buffer per head (width = the widest canvas), so that a batch mixing patches of different images still
+        scatters with one row stride; every image is then post-processed on its own window of that buffer.  A single image gives
+        exactly what it gave alone (same offsets, same kernels)."""
         net = self.net
         dev = torch.device("cuda", torch.cuda.current_device())
-        padded, info, src_pos = _prepare_patching(img, patch_input_shape, patch_output_shape, 0)
-        uniq = info[: info.shape[0] // 2]  # second half duplicates the first (see module docstring)
-        hw = np.max(info[:, 1, 1], axis=0).tolist()
-        Hc, Wc = int(hw[0]), int(hw[1])
-        pad_dev = torch.from_numpy(np.ascontiguousarray(padded)).to(dev)
+        win, osz = int(patch_input_shape), int(patch_output_shape)
+        preps, row0, wmax = [], [0], 0
+        for img in imgs:
+            padded, info, src_pos = _prepare_patching(img, patch_input_shape, patch_output_shape, 0)
+            uniq = info[: info.shape[0] // 2]  # second half duplicates the first (see module docstring)
+            hw = np.max(info[:, 1, 1], axis=0).tolist()
+            preps.append((padded, uniq, src_pos, int(hw[0]), int(hw[1])))
+            row0.append(row0[-1] + int(hw[0]))
+            wmax = max(wmax, int(hw[1]))
         canv = OrderedDict()
         for name, hname, och, key in net._decoders:
             if hname == "INST":
-                canv[key] = torch.zeros((Hc, Wc, 2), dtype=torch.float32, device=dev)
+                canv[key] = torch.zeros((row0[-1], wmax, 2), dtype=torch.float32, device=dev)
             elif hname == "TYPE":
-                canv[key] = torch.zeros((Hc, Wc), dtype=torch.uint8, device=dev)
+                canv[key] = torch.zeros((row0[-1], wmax), dtype=torch.uint8, device=dev)
             else:
-                canv[key] = torch.zeros((Hc, Wc), dtype=torch.float32, device=dev)
+                canv[key] = torch.zeros((row0[-1], wmax), dtype=torch.float32, device=dev)
         outs = [canv[d[3]] for d in net._decoders]
-        win, osz = int(patch_input_shape), int(patch_output_shape)
-        for b0 in range(0, uniq.shape[0], batch_size):
-            chunk = uniq[b0:b0 + batch_size]
-            tiles = torch.stack([pad_dev[int(i[0, 0, 0]):int(i[0, 0, 0]) + win, int(i[0, 0, 1]):int(i[0, 0, 1]) + win] for i in chunk])
-            off = torch.tensor([int(i[1, 0, 0]) * Wc + int(i[1, 0, 1]) for i in chunk], dtype=torch.int64, device=dev)
-            net._run(tiles, osz, osz, outs, None, tile_off=off, row_stride=Wc, type_is_u8=True)
-        y0, x0 = src_pos
-        sh, sw = img.shape[:2]
-        raw = OrderedDict((k, v[y0:y0 + sh, x0:x0 + sw]) for k, v in canv.items())
-        inst, types, pp_info = OrderedDict(), OrderedDict(), OrderedDict()
-        pclass = None
-        for tissue in postproc_list:
-            tissue = tissue.capitalize()
-            code = self.decoder_dict.get(tissue + "-INST") if getattr(self, "decoder_dict", None) else "IP-ERODED-CONTOUR-3"
-            if tissue + "-INST" in raw:
-                if code not in POSTPROC_CODES:
-                    raise NotImplementedError("post-proc code %r: only IP-ERODED-CONTOUR-* (PostProcInstErodedContourMap) is on the HIP path" % code)
-                inst[tissue], pp_info[tissue] = postproc_device(raw[tissue + "-INST"], tissue)
-                types[tissue] = raw.get(tissue + "-TYPE")
-            elif tissue == "Patch-class":
-                pclass = raw.get("Patch-Class")
-        if "Lumen" in inst and "Gland" in inst:
-            mask_lumen_by_gland(inst["Lumen"], inst["Gland"])
-        return {"raw": raw, "inst": inst, "type": types, "pclass": pclass, "info": pp_info}
+        tiles_all, off_all = [], []
+        for k, (padded, uniq, _, _, _) in enumerate(preps):
+            pad_dev = torch.from_numpy(np.ascontiguousarray(padded)).to(dev)
+            tiles_all += [pad_dev[int(i[0, 0, 0]):int(i[0, 0, 0]) + win, int(i[0, 0, 1]):int(i[0, 0, 1]) + win] for i in uniq]
+            off_all += [(row0[k] + int(i[1, 0, 0])) * wmax + int(i[1, 0, 1]) for i in uniq]
+        off_dev = torch.tensor(off_all, dtype=torch.int64, device=dev)
+        for b0 in range(0, len(tiles_all), batch_size):
+            tiles = torch.stack(tiles_all[b0:b0 + batch_size])
+            net._run(tiles, osz, osz, outs, None, tile_off=off_dev[b0:b0 + batch_size], row_stride=wmax, type_is_u8=True)
+        results = []
+        for k, img in enumerate(imgs):
+            y0, x0 = preps[k][2]
+            sh, sw = img.shape[:2]
+            raw = OrderedDict((key, v[row0[k] + y0:row0[k] + y0 + sh, x0:x0 + sw]) for key, v in canv.items())
+            inst, types, pp_info = OrderedDict(), OrderedDict(), OrderedDict()
+            pclass = None
+            for tissue in postproc_list:
+                tissue = tissue.capitalize()
+                code = self.decoder_dict.get(tissue + "-INST") if getattr(self, "decoder_dict", None) else "IP-ERODED-CONTOUR-3"
+                if tissue + "-INST" in raw:
+                    if code not in POSTPROC_CODES:
+                        raise NotImplementedError("post-proc code %r: only IP-ERODED-CONTOUR-* (PostProcInstErodedContourMap) is on the HIP path" % code)
+                    inst[tissue], pp_info[tissue] = postproc_device(raw[tissue + "-INST"], tissue)
+                    types[tissue] = raw.get(tissue + "-TYPE")
+                elif tissue == "Patch-class":
+                    pclass = raw.get("Patch-Class")
+            if "Lumen" in inst and "Gland" in inst:
+                mask_lumen_by_gland(inst["Lumen"], inst["Gland"])
+            results.append({"raw": raw, "inst": inst, "type": types, "pclass": pclass, "info": pp_info})
+        return results
 
     # ---- reference CLI behaviour --------------------------------------------------------------------------------
     def process_file_list(self, run_args):
@@ -245,9 +263,25 @@ class InferManager(object):
             if any(not os.path.exists("%s/%s_mat/%s.mat" % (self.output_dir, t, base)) for t in self.postproc_list):
                 todo.append(fp)
         assert len(todo) > 0, "Not Detected Any Files From Path"
-        for fp in todo:
-            img = np.array(Image.open(fp).convert("RGB"))
-            res = self.infer_image(img, self.patch_input_shape, self.patch_output_shape, self.batch_size, self.postproc_list)
+        # groups of files share batches (infer/tile.py:300-420 caches several files per DataLoader pass): a group is closed once it
+        # holds 8 batches' worth of patches or 64 Mpx of padded pixels
+        win, osz = int(self.patch_input_shape), int(self.patch_output_shape)
+
+        def grouped_results():  # lazily: one group of decoded files and its canvases alive at a time
+            cur, n_patch, n_px = [], 0, 0
+            for idx, fp in enumerate(todo):
+                img = np.array(Image.open(fp).convert("RGB"))
+                cur.append((fp, img))
+                n_patch += int(math.ceil(img.shape[0] / osz)) * int(math.ceil(img.shape[1] / osz))
+                n_px += (img.shape[0] + win) * (img.shape[1] + win)
+                if n_patch >= 8 * int(self.batch_size) or n_px >= (64 << 20) or idx == len(todo) - 1:
+                    res_list = self.infer_images([im for _, im in cur], self.patch_input_shape, self.patch_output_shape, self.batch_size,
+                                                 self.postproc_list)
+                    for (f, im), r in zip(cur, res_list):
+                        yield f, im, r
+                    cur, n_patch, n_px = [], 0, 0
+
+        for fp, img, res in grouped_results():
             base = pathlib.Path(fp).stem
             prev_type = None
 

@@ -140,3 +140,19 @@ def test_pipelined_band_upload_equals_resident_slab(manager):
     torch.cuda.synchronize()
     for k in ref:
         assert torch.equal(ref[k], r2.canv[k]), k
+
+
+def test_images_sharing_batches_equal_images_alone(manager):
+    """infer_images: several files of different sizes through shared batches (one canvas buffer per head, row blocks per image) give,
+    image by image, bit-identical maps and labels to infer_image on its own -- and a folder of 256^2 tiles no longer runs at batch 1."""
+    rs = np.random.RandomState(12)
+    imgs = [rs.randint(0, 256, hw + (3,)).astype(np.uint8) for hw in ((256, 256), (300, 421), (256, 256), (97, 530), (512, 256))]
+    for win, out in ((256, 256), (448, 144)):
+        together = manager.infer_images(imgs, win, out, batch_size=6)
+        for img, res in zip(imgs, together):
+            alone = manager.infer_image(img, win, out, batch_size=6)
+            for k in alone["raw"]:
+                assert torch.equal(alone["raw"][k], res["raw"][k]), (win, k)
+            for t in alone["inst"]:
+                assert torch.equal(alone["inst"][t], res["inst"][t]), (win, t)
+            assert torch.equal(alone["pclass"], res["pclass"])
