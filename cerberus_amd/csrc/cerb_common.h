@@ -14,6 +14,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // so that one lane owns one pixel and 4 consecutive couts per accumulator quad -> float4 NHWC stores,
 // and the accumulators are directly the B operand of a following 1x1 GEMM (head fusion).
 // ---------------------------------------------------------------------------------------------
+// hipFuncSetAttribute is per device: remember it per device, not per process (a host process may drive several handles)
+static inline bool cerb_attr_needed(bool (&done)[64]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    if (done[dev]) return false;
+    done[dev] = true;
+    return true;
+}
+
 struct ConvParams {
     const float* in;     // NHWC fp32 [G][N][H][W][Cin]  (MODE 1: the skip tensor)
     const float* prev;   // MODE 1 only: [G][N][H/2][W/2][Cin], bilinearly upsampled x2 and added to `in`

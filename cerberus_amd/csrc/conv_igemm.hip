@@ -457,11 +457,10 @@ static hipError_t launch_cfg(ConvParams p, hipStream_t st) {
     p.tiles_y = (p.Ho + TH - 1) / TH;
     const long long items = (long long)p.groups * p.N * p.tiles_x * p.tiles_y * (p.Cout / 64);
     auto kern = conv_igemm_kernel<KS, STRIDE, TH, TW, CB, MODE>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[64] = {};
+    if (cerb_attr_needed(attr_done)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     // persistent grid: every workgroup resident at once (2 per CU when LDS allows), each walks a contiguous item range
     const int blocks_per_cu = (C::LDS_BYTES * 2 <= 160 * 1024) ? 2 : 1;

@@ -463,11 +463,10 @@ static hipError_t launch_wino(ConvParams p, hipStream_t st) {
     }
     const long long items = (long long)p.groups * p.N * p.tiles_x * p.tiles_y * (p.Cout / 64);
     auto kern = conv_wino_kernel<HAS_RES>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[64] = {};
+    if (cerb_attr_needed(attr_done)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     long long grid = 512;  // persistent: two workgroups per CU
     if (grid > items) grid = items;

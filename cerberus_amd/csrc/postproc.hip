@@ -1116,6 +1116,15 @@ static void ellipse_spans(int k, Spans* s) {  // cv2.getStructuringElement(MORPH
     }
 }
 
+// hipFuncSetAttribute is per device: remember it per device, not per process (a host process may drive several handles)
+static inline bool cerb_attr_needed(bool (&done)[64]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    if (done[dev]) return false;
+    done[dev] = true;
+    return true;
+}
+
 struct SideStreams {
     hipStream_t s[3];
     hipEvent_t fork, join[3];
@@ -1215,12 +1224,11 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
         auto k_big = ws_flood_window_kernel<WS_BIGWIN_CAP, WS_BIGHEAP_CAP, 1>;
         constexpr int lds_small = 2 * (WS_LDS_CAP * 10 + WS_WIN_CAP * 8), lds_big = WS_BIGHEAP_CAP * 10 + WS_BIGWIN_CAP * 8;
         constexpr int lds_tiny = 4 * (WS_TINY_CAP * 10 + WS_TINY_WIN * 8);
-        static bool attr_done = false;
-        if (!attr_done) {
+        static bool attr_done[64] = {};
+        if (cerb_attr_needed(attr_done)) {
             PP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_small), hipFuncAttributeMaxDynamicSharedMemorySize, lds_small));
             PP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tiny), hipFuncAttributeMaxDynamicSharedMemorySize, lds_tiny));
             PP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_big), hipFuncAttributeMaxDynamicSharedMemorySize, lds_big));
-            attr_done = true;
         }
         // The tiers touch disjoint components and each one ends with the tail of its longest flood: fork them onto side streams
         // (created once per device) so that the tails overlap instead of adding up; `st` resumes when all of them are done.
