@@ -64,8 +64,20 @@ struct Item {
 }  // namespace
 
 #ifdef WPROF
-// developer instrumentation (scripts/dev_wprof.sh): cycles per phase, summed over wave 0 of every workgroup
+// developer instrumentation (scripts/dev_wprof.sh, dev_wclock.py, dev_wlog.py): cycles per phase summed over wave 0 of every
+// workgroup, the same span in 100 MHz real-time ticks, and a log of every workgroup's start / end tick
 __device__ unsigned long long g_wprof[8];
+__device__ unsigned long long g_wlog[4 * 32768];  // per workgroup: start tick, end tick (100 MHz), (H << 32 | Cin), blockIdx
+__device__ unsigned int g_wlog_n;
+extern "C" int cerb_dev_wlog(unsigned long long* out, unsigned* n, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wlog), sizeof(g_wlog)) != hipSuccess) return 1;
+    if (n && hipMemcpyFromSymbol(n, HIP_SYMBOL(g_wlog_n), 4) != hipSuccess) return 1;
+    if (reset) {
+        unsigned z = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_wlog_n), &z, 4) != hipSuccess) return 1;
+    }
+    return 0;
+}
 extern "C" int cerb_dev_wprof(unsigned long long* out, int reset) {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wprof), sizeof(g_wprof)) != hipSuccess) return 1;
     if (reset) {
@@ -86,6 +98,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef WPROF
     const unsigned long long t_kernel = WPROF_T();
+    const unsigned long long t_real = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz counter: shader clock = cycles / ticks * 100 MHz
 #endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -445,6 +458,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
         atomicAdd(&g_wprof[6], t_first - t_kernel);
         atomicAdd(&g_wprof[3], WPROF_T() - t_kernel);
         atomicAdd(&g_wprof[4], 1ull);
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&g_wprof[7], t_end - t_real);
+        const unsigned slot = atomicAdd(&g_wlog_n, 1u);
+        if (slot < 32768u) {
+            g_wlog[4 * slot + 0] = t_real;
+            g_wlog[4 * slot + 1] = t_end;
+            g_wlog[4 * slot + 2] = ((unsigned long long)p.H << 32) | (unsigned)p.Cin;
+            g_wlog[4 * slot + 3] = blockIdx.x;
+        }
     }
 #endif
 }
