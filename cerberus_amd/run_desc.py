@@ -3,7 +3,7 @@ from collections import OrderedDict
 
 import torch
 
-from .net_desc import HEAD_NAME_MAP
+from .net_desc import HEAD_NAME_MAP  # noqa: F401  (re-exported: the reference keeps head_name_map next to infer_step, run_desc.py:466-473)
 
 
 def infer_step(img_list, model, output_shape, head_name_list):

@@ -1,7 +1,6 @@
 """Overlay rendering of the tile CLI (reference misc/viz_utils.py:187-214 `visualize_instances_dict_orig`,
 called at infer/tile.py:251-257).  Pure host code: contours come from the GPU (cerb_inst_contour_*), drawing is PIL
 (`cv2.drawContours` is not available in this image; line rasterisation may differ from OpenCV's by a pixel -- cosmetic)."""
-from collections import OrderedDict
 
 import numpy as np
 
