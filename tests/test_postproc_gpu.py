@@ -254,3 +254,43 @@ def test_sharded_postproc_flags_instances_taller_than_the_margin():
     assert all(i["n_truncated"] == 0 and i["n_unresolved"] == 0 for i in infos), infos
     ref, _ = postproc_device(full, "Gland", 1.0)
     assert n_total == 2 and sp.same_partition(ref.cpu().numpy(), sp.assemble(outs).cpu().numpy())
+
+
+def test_slide_scale_map_invariants_and_tiling_consistency():
+    """A 8192 x 8192 structured map (57 k nuclei; too large for the oracle to finish in test time) through properties that do not
+    depend on its size: ids are within 1..n (the markers' ids), every labelled pixel lies in the mask's support, and -- since
+    the watershed is independent per mask component -- every component that lies wholly inside a 2048 x 2048 crop is partitioned
+    exactly as when that crop is post-processed on its own (a checksum-of-tiles property: the crop result IS compared with the C
+    oracle, the slide-scale result with the crop)."""
+    from cerberus_amd.postproc import inst_table_device
+
+    H = W = 8192
+    m = synth.nuclei_maps(H, W, 7, 1000.0, noise=0.02)
+    dev = torch.from_numpy(m).cuda()
+    lab, info = postproc_device(dev, "Nuclei")
+    n = int(info["n_inst"])
+    assert n > 50000 and int(lab.max()) <= n and int(info["n_ambiguous"]) == 0
+    tab = inst_table_device(lab, None, n).cpu().numpy()
+    alive = tab[:, 0] > 0
+    assert alive.mean() > 0.95  # markers with no mask pixel left (erosion) disappear; the rest keep their id
+    assert int(lab.min()) == 0 and int(tab[alive, 0].sum()) == int((lab > 0).sum())  # every labelled pixel belongs to an id in 1..n
+    assert int(((lab > 0) & ~(dev.sum(-1) > 0.5)).sum()) == 0  # labels only inside inner + contour > 0.5
+    # tiling consistency on one crop: components fully inside the crop (not touching its edge ring) keep their partition
+    y0, x0, S = 3000, 4100, 2048
+    crop = np.ascontiguousarray(m[y0:y0 + S, x0:x0 + S])
+    exp = pr.proc(crop, "Nuclei").astype(np.int32)  # the C oracle on the crop
+    got_crop, _ = postproc_device(torch.from_numpy(crop).cuda(), "Nuclei")
+    assert np.array_equal(got_crop.cpu().numpy(), exp)
+    big = lab[y0:y0 + S, x0:x0 + S].cpu().numpy()
+    from scipy import ndimage
+
+    msk = (crop.sum(-1) > 0.5)
+    comp, _ = ndimage.label(msk)  # a superset of the eroded mask's components: safe for the "touches the ring" test
+    ring = np.zeros_like(msk)
+    ring[:3], ring[-3:], ring[:, :3], ring[:, -3:] = True, True, True, True
+    bad = np.unique(comp[ring & msk])
+    inner = msk & ~np.isin(comp, bad)
+    a, b = big[inner], exp[inner]
+    assert inner.sum() > 100000 and np.array_equal(a > 0, b > 0)
+    pairs = np.unique(np.stack([a[a > 0], b[a > 0]], axis=1), axis=0)
+    assert len(np.unique(pairs[:, 0])) == len(pairs) == len(np.unique(pairs[:, 1]))  # a bijection between the two labellings
