@@ -1,0 +1,209 @@
+// train_kernels.hip -- first pieces of the training step (BASELINE.json configs[4]; models/run_desc.py:25-230 of the reference).
+// NOT a training step yet: what is here is the per-head loss of train_step with its gradient on the logits, HBM-bound
+// elementwise / reduction work (one read of the logits per pass):
+//   cross entropy (models/utils/loss_utils.py:6-21) x pixel weight map, mean over the pixels of a sample, samples without the
+//   target masked out:   sum_n flag_n * mean_hw(ce * w) / (sum_n flag_n + 1e-8)                  (models/run_desc.py:147-156)
+//   TYPE heads: w = class weight of the target class, 0 on background (:118-124), plus the Dice term over the positive classes with
+//   mask = target > 0, smooth 1e-3, summed over classes and NOT flag-masked (:137-146, loss_utils.py:60-75)
+//   Patch-Class: the reference's `[N] * [N,1,1]` broadcast makes every sample's loss the mean over all samples (:126-128,152-154)
+// Three launches: per-block partial sums (fixed order -> bitwise reproducible), one-block finalise (double accumulation; loss value
+// and the coefficients of the gradient), gradient.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/cerberus_hip.h"
+
+int cerb_set_error(const std::string& m);
+
+namespace {
+constexpr int MAXC = 16;   // classes per head (reference: 3, 7, 9)
+constexpr int PIX_PER_BLOCK = 1024;
+
+struct LossParams {
+    const float* logits;
+    long long sn, sc, sy, sx;  // element strides of logits / dlogits
+    const float* target;       // [N][H][W] class ids as float
+    const float* has_target;   // [N]
+    const float* class_weight; // [C] or nullptr
+    int N, H, W, C;
+    float ce_w, dice_w, head_w;
+    int pc_mode;
+    float* dlogits;
+    float* partial;            // [blocks][1 + 3 * MAXC]: sum(ce * w), then I_c, L_c, R_c
+    double* coef;              // [N] ce factor per sample, then [MAXC] dLoss/dI_c, [MAXC] dLoss/dL_c, [1] loss
+    float* loss_out;
+    int blocks_per_sample;
+};
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+    return r;  // valid in thread 0
+}
+
+// softmax statistics of one pixel; returns the pixel's weight
+__device__ __forceinline__ float pixel_softmax(const LossParams& p, int n, int y, int x, float* prob, int* t_out, float* ce_out) {
+    const float* l = p.logits + n * p.sn + y * p.sy + x * p.sx;
+    float v[MAXC], m = -3.402823466e38f;
+    for (int c = 0; c < p.C; ++c) {
+        v[c] = l[c * p.sc];
+        m = fmaxf(m, v[c]);
+    }
+    float se = 0.f;
+    for (int c = 0; c < p.C; ++c) {
+        prob[c] = expf(v[c] - m);
+        se += prob[c];
+    }
+    const float inv = 1.f / se;
+    for (int c = 0; c < p.C; ++c) prob[c] *= inv;
+    const int t = (int)p.target[((long long)n * p.H + y) * p.W + x];
+    *t_out = t;
+    *ce_out = (m + logf(se)) - v[t];
+    if (!p.class_weight) return 1.f;
+    return t > 0 ? p.class_weight[t] : 0.f;  // get_class_wmap: listed classes get their weight, background keeps its own value 0
+}
+
+__global__ __launch_bounds__(256) void loss_partial_kernel(LossParams p) {
+    __shared__ float sh[4];
+    const int n = blockIdx.x / p.blocks_per_sample, b = blockIdx.x % p.blocks_per_sample;
+    const int hw = p.H * p.W;
+    float ce_sum = 0.f, I[MAXC], L[MAXC], R[MAXC];
+    for (int c = 0; c < MAXC; ++c) I[c] = L[c] = R[c] = 0.f;
+    for (int i = b * PIX_PER_BLOCK + threadIdx.x; i < min(hw, (b + 1) * PIX_PER_BLOCK); i += blockDim.x) {
+        float prob[MAXC], ce;
+        int t;
+        const float w = pixel_softmax(p, n, i / p.W, i % p.W, prob, &t, &ce);
+        ce_sum += ce * w;
+        if (p.dice_w != 0.f && t > 0) {  // mask = target > 0
+            for (int c = 1; c < p.C; ++c) {
+                L[c] += prob[c];
+                if (c == t) {
+                    I[c] += prob[c];
+                    R[c] += 1.f;
+                }
+            }
+        }
+    }
+    float* out = p.partial + (long long)blockIdx.x * (1 + 3 * MAXC);
+    float r = block_sum(ce_sum, sh);
+    if (threadIdx.x == 0) out[0] = r;
+    if (p.dice_w != 0.f)
+        for (int c = 1; c < p.C; ++c) {
+            const float a = block_sum(I[c], sh), bb = block_sum(L[c], sh), cc = block_sum(R[c], sh);
+            if (threadIdx.x == 0) {
+                out[1 + c] = a;
+                out[1 + MAXC + c] = bb;
+                out[1 + 2 * MAXC + c] = cc;
+            }
+        }
+}
+
+__global__ void loss_finalize_kernel(LossParams p) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int stride = 1 + 3 * MAXC;
+    const double hw = (double)p.H * p.W;
+    double flag_sum = 0.0;
+    for (int n = 0; n < p.N; ++n) flag_sum += p.has_target[n];
+    const double denom = flag_sum + 1.0e-8;
+    double ce_term = 0.0;
+    if (!p.pc_mode) {
+        for (int n = 0; n < p.N; ++n) {
+            double s = 0.0;
+            for (int b = 0; b < p.blocks_per_sample; ++b) s += p.partial[(long long)(n * p.blocks_per_sample + b) * stride];
+            ce_term += p.has_target[n] * (s / hw);
+            p.coef[n] = (double)p.ce_w * p.head_w * p.has_target[n] / (denom * hw);
+        }
+        ce_term /= denom;
+    } else {  // every sample's loss is the mean over all samples; H = W = 1
+        double s = 0.0;
+        for (int n = 0; n < p.N; ++n) s += p.partial[(long long)n * stride];
+        ce_term = (s / p.N) * flag_sum / denom;
+        for (int n = 0; n < p.N; ++n) p.coef[n] = (double)p.ce_w * p.head_w * flag_sum / (denom * p.N);
+    }
+    double dice = 0.0;
+    if (p.dice_w != 0.f)
+        for (int c = 1; c < p.C; ++c) {
+            double I = 0.0, L = 0.0, R = 0.0;
+            for (int b = 0; b < p.N * p.blocks_per_sample; ++b) {
+                I += p.partial[(long long)b * stride + 1 + c];
+                L += p.partial[(long long)b * stride + 1 + MAXC + c];
+                R += p.partial[(long long)b * stride + 1 + 2 * MAXC + c];
+            }
+            const double D = L + R + 1.0e-3;
+            dice += 1.0 - (2.0 * I + 1.0e-3) / D;
+            p.coef[p.N + c] = (double)p.dice_w * p.head_w * (-2.0 / D);                         // d/dI_c
+            p.coef[p.N + MAXC + c] = (double)p.dice_w * p.head_w * ((2.0 * I + 1.0e-3) / (D * D));  // d/dL_c
+        }
+    const double loss = ((double)p.ce_w * ce_term + (double)p.dice_w * dice) * p.head_w;
+    p.coef[p.N + 2 * MAXC] = loss;
+    if (p.loss_out) *p.loss_out = (float)loss;
+}
+
+__global__ __launch_bounds__(256) void loss_grad_kernel(LossParams p) {
+    const long long total = (long long)p.N * p.H * p.W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % p.W);
+        const long long r = i / p.W;
+        const int y = (int)(r % p.H), n = (int)(r / p.H);
+        float prob[MAXC], ce;
+        int t;
+        const float w = pixel_softmax(p, n, y, x, prob, &t, &ce);
+        const float f = (float)p.coef[n] * w;
+        float g[MAXC];
+        for (int c = 0; c < p.C; ++c) g[c] = f * (prob[c] - (c == t ? 1.f : 0.f));
+        if (p.dice_w != 0.f && t > 0) {  // q_c = dLoss/dp_c on masked pixels, chained through the softmax Jacobian
+            float q[MAXC], dot = 0.f;
+            q[0] = 0.f;
+            for (int c = 1; c < p.C; ++c) {
+                q[c] = (float)p.coef[p.N + MAXC + c] + (c == t ? (float)p.coef[p.N + c] : 0.f);
+                dot += q[c] * prob[c];
+            }
+            for (int c = 0; c < p.C; ++c) g[c] += prob[c] * (q[c] - dot);
+        }
+        float* d = p.dlogits + n * p.sn + y * p.sy + x * p.sx;
+        for (int c = 0; c < p.C; ++c) d[c * p.sc] = g[c];
+    }
+}
+}  // namespace
+
+extern "C" size_t cerb_head_loss_workspace_bytes(int n, int h, int w) {
+    const long long bps = ((long long)h * w + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK;
+    return (size_t)(n * bps) * (1 + 3 * MAXC) * 4 + (size_t)(n + 2 * MAXC + 1) * 8 + 512;
+}
+
+extern "C" int cerb_head_loss(const float* logits, long long stride_n, long long stride_c, long long stride_y, long long stride_x, const float* target,
+                              const float* has_target, int N, int H, int W, int C, const float* class_weight, float ce_weight, float dice_weight,
+                              float head_weight, int patch_class_mode, float* loss_out, float* dlogits, void* ws, size_t ws_bytes, void* hip_stream) {
+    if (!logits || !target || !has_target || !ws || N <= 0 || H <= 0 || W <= 0 || C < 2 || C > MAXC) return cerb_set_error("cerb_head_loss: bad arguments");
+    if (patch_class_mode && (H != 1 || W != 1)) return cerb_set_error("cerb_head_loss: Patch-Class logits are [N][C][1][1]");
+    if (ws_bytes < cerb_head_loss_workspace_bytes(N, H, W)) return cerb_set_error("cerb_head_loss: workspace too small");
+    hipStream_t st = (hipStream_t)hip_stream;
+    LossParams p;
+    p.logits = logits; p.sn = stride_n; p.sc = stride_c; p.sy = stride_y; p.sx = stride_x;
+    p.target = target; p.has_target = has_target; p.class_weight = class_weight;
+    p.N = N; p.H = H; p.W = W; p.C = C;
+    p.ce_w = ce_weight; p.dice_w = dice_weight; p.head_w = head_weight; p.pc_mode = patch_class_mode;
+    p.dlogits = dlogits; p.loss_out = loss_out;
+    p.blocks_per_sample = (int)(((long long)H * W + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK);
+    const size_t part_bytes = (size_t)N * p.blocks_per_sample * (1 + 3 * MAXC) * 4;
+    p.partial = (float*)ws;
+    p.coef = (double*)((char*)ws + ((part_bytes + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(N * p.blocks_per_sample), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, p);
+    if (dlogits) {
+        long long blocks = ((long long)N * H * W + 255) / 256;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(loss_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cerb_set_error(std::string("cerb_head_loss: ") + hipGetErrorString(e));
+    return 0;
+}

@@ -189,6 +189,24 @@ int cerb_relabel(const int32_t* labels, long long lab_row_stride, const int32_t*
                  long long out_row_stride, void* hip_stream);
 
 /* ---- device timing helper: HIP events on the given stream (bench.py; torch.cuda.Event only sees torch's stream) */
+/* ---- training step, first piece (BASELINE.json configs[4]; NOT a training step yet) --------------------------------------------
+ * cerb_head_loss: the per-head loss of the reference's train_step (models/run_desc.py:88-170) and its gradient on the logits.
+ *   logits / dlogits : device float, element strides (n, c, y, x) -- NCHW as the reference's forward returns them, or NHWC
+ *   target           : device float [N][H][W] class ids (the reference keeps targets in float32, :57-62)
+ *   has_target       : device float [N], 1 where the sample carries this head's annotation (dummy_target protocol, :96-97)
+ *   class_weight     : device float [C] or NULL.  Given (TYPE heads): pixel weight = class_weight[target], 0 on background
+ *                      (get_class_wmap, :18-22,118-124) and the Dice term is masked by target > 0
+ *   ce_weight, dice_weight, head_weight : paramset.yml loss_info ("ce" / "dice" weights inside the head, the head's own weight)
+ *   patch_class_mode : 1 for the [N][C][1][1] Patch-Class head, which inherits the reference's [N] x [N,1,1] broadcast (:126-154)
+ *   loss_out         : device float[1], the value train_step reports for the head; dlogits may be NULL (value only)
+ *   ws               : device workspace of cerb_head_loss_workspace_bytes(N, H, W)
+ * Sums are taken in a fixed order (per-block partials, one-block double-precision finalise): bitwise reproducible. */
+size_t cerb_head_loss_workspace_bytes(int n, int h, int w);
+int cerb_head_loss(const float* logits, long long stride_n, long long stride_c, long long stride_y, long long stride_x,
+                   const float* target, const float* has_target, int n, int h, int w, int c, const float* class_weight,
+                   float ce_weight, float dice_weight, float head_weight, int patch_class_mode, float* loss_out,
+                   float* dlogits, void* ws, size_t ws_bytes, void* hip_stream);
+
 int cerb_event_create(void** ev);
 int cerb_event_record(void* ev, void* hip_stream);
 int cerb_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms); /* synchronises on ev_stop */
