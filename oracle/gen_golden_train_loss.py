@@ -90,6 +90,13 @@ def run_case(prefix, nuclei_type_weight, store):
         for clf, mod in hd.items():
             mod.register_forward_hook(hook(dec.split("#")[0] + "-" + clf))
     model.decoder_head["Patch-Class"].register_forward_hook(hook("Patch-Class"))
+    drop = {}
+
+    def drop_hook(mod, inp, out):  # nn.Dropout(p=0.3) of the Patch-Class branch (models/net_desc.py:70): keep mask of this step
+        drop["mask"] = (out != 0).detach().numpy() | (inp[0] == 0).detach().numpy()
+
+    model.decoder_head["Patch-Class"].dropout.register_forward_hook(drop_hook)
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
     run_info = ({"net": {"desc": net, "optimizer": opt, "extra_info": {"loss": loss_kwargs}}}, None)
     res = train_step(dict(batch), run_info)
     store.update({"N": N, "H": H, "heads": np.array(list(heads.keys())), "n_classes": np.array(list(heads.values())),
@@ -110,6 +117,27 @@ def run_case(prefix, nuclei_type_weight, store):
         print("%s%-12s logits %-18s loss %.6f  |dlogits| max %.3e" % (prefix, h, tuple(lg.shape), store[prefix + "loss/" + h],
                                                                       np.abs(g).max()))
     print(prefix, "overall", store[prefix + "overall_loss"])
+    if prefix == "paramset/":  # the whole step, for the round that builds the backward pass: gradients, Adam update, BN statistics
+        store["step/dropout_mask"] = drop["mask"]
+        names, gstat, pstat = [], [], []
+        for k, prm in model.named_parameters():
+            g = prm.grad if prm.grad is not None else torch.zeros_like(prm)
+            g64, p64 = g.double().flatten(), prm.detach().double().flatten()
+            names.append(k)
+            gstat.append([g64.sum().item(), g64.abs().sum().item(), g64[0].item(), g64[g64.numel() // 2].item(), g64[-1].item()])
+            d64 = (prm.detach().double().flatten() - before[k].double().flatten())
+            pstat.append([p64.sum().item(), d64.abs().sum().item(), d64[0].item(), d64[d64.numel() // 2].item(), d64[-1].item()])
+        store["step/param_names"] = np.array(names)
+        store["step/grad_stats"] = np.array(gstat)     # per parameter: sum, abs-sum, first / middle / last element of the gradient
+        store["step/update_stats"] = np.array(pstat)   # per parameter: sum after the step, abs-sum / first / middle / last of (after - before)
+        bn_names, bn_stat = [], []
+        for k, v in model.state_dict().items():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                bn_names.append(k)
+                bn_stat.append([v.double().sum().item(), (v.double() - before[k].double()).abs().sum().item(), v.double().flatten()[0].item()])
+        store["step/bn_names"] = np.array(bn_names)
+        store["step/bn_stats"] = np.array(bn_stat)
+        print("captured step statistics for %d parameters, %d BN buffers; dropout keeps %d of %d" % (len(names), len(bn_names), drop["mask"].sum(), drop["mask"].size))
     store[prefix + "loss_weight"] = np.array([loss_kwargs["loss_info"][h]["weight"] for h in heads], np.float64)
 
 
