@@ -29,8 +29,18 @@ struct StemParams {
     const float* bias;
     float* out;
     int N, H, W, tiles_x, tiles_y;
+    int relu;
 };
 hipError_t cerb_launch_stem(StemParams p, hipStream_t st);
+// train-mode pieces (train_kernels.hip)
+size_t cerb_bn_workspace_bytes(int groups, long long rows, int C);
+hipError_t cerb_launch_bn_stats(const float* x, long long group_stride, long long rows, int C, int groups, float eps, float* mean, float* rstd,
+                                float* var_unbiased, void* ws, hipStream_t st);
+hipError_t cerb_launch_bn_apply(float* x, const float* resid, long long group_stride, long long rows, int C, int groups, const float* mean,
+                                const float* rstd, const float* gamma, const float* beta, int relu, hipStream_t st);
+hipError_t cerb_launch_pointwise(const float* in, const float* w, const float* bias, float* out, long long rows, int cin, int cout, const float* in_scale,
+                                 hipStream_t st);
+hipError_t cerb_launch_crop_gap(const float* x, int N, int H, int W, int C, int y0, int ch, int x0, int cw, float* out, hipStream_t st);
 hipError_t cerb_launch_maxpool(const float* in, float* out, int N, int H, int W, int C, hipStream_t st);
 hipError_t cerb_launch_head(const HeadParams& p, hipStream_t st);
 struct PatchClassParams {
@@ -124,6 +134,13 @@ struct cerb_net {
     std::vector<float*> head_w1, head_b1, head_w2, head_b2;  // per dense decoder
     float *pc_bn1s = nullptr, *pc_bn1b = nullptr, *pc_w1t = nullptr, *pc_b1 = nullptr, *pc_w2t = nullptr, *pc_b2 = nullptr;
     std::vector<void*> dev_allocs;
+    // train-mode packing (cerb_net_set_fold_bn(net, 0) before finalize): raw conv weights, BatchNorm affine parameters kept apart
+    int fold_bn = 1;
+    struct BnDev { float *gamma = nullptr, *beta = nullptr; int C = 0, groups = 1; };
+    std::map<std::string, BnDev> bn;  // by conv name ("stem", "backbone.layer1.0.conv1", "dec.<u>.<j>", "head.<k>", "pc.bn1", "pc.bn2")
+    std::vector<float*> head_rw1, head_rb1, head_rw2, head_rb2;  // raw head weights, row-major [cout][cin]
+    float *pc_rw1 = nullptr, *pc_rb1 = nullptr, *pc_rw2 = nullptr, *pc_rb2 = nullptr;
+    DevBuf t_mean, t_rstd, t_ws, t_hid, t_gap, t_pc1, t_idn;
     // workspace
     DevBuf x0, pool, x[5], ta, tb, cm, dmid, dsum, dout[4];
     // optional per-launch timing (HIP events on the caller's stream)
@@ -137,6 +154,7 @@ struct cerb_net {
         for (auto& r : prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         for (void* p : dev_allocs) (void)hipFree(p);
         x0.release(); pool.release(); ta.release(); tb.release(); cm.release(); dmid.release(); dsum.release();
+        t_mean.release(); t_rstd.release(); t_ws.release(); t_hid.release(); t_gap.release(); t_pc1.release(); t_idn.release();
         for (auto& b : x) b.release();
         for (auto& b : dout) b.release();
     }
@@ -327,6 +345,22 @@ static void pack_wino3(const float* U, int cout, int cin, std::vector<uint16_t>*
                                     }
 }
 
+static int store_bn(cerb_net* net, const std::string& name, const std::vector<std::string>& bnkeys, int ch) {
+    std::vector<float> ga, be;
+    for (const std::string& k : bnkeys) {
+        const HostTensor *w, *b;
+        if (get(net, k + ".weight", {ch}, &w) || get(net, k + ".bias", {ch}, &b)) return 1;
+        ga.insert(ga.end(), w->data.begin(), w->data.end());
+        be.insert(be.end(), b->data.begin(), b->data.end());
+    }
+    cerb_net::BnDev d;
+    d.C = ch;
+    d.groups = (int)bnkeys.size();
+    if (upload(net, ga, &d.gamma) || upload(net, be, &d.beta)) return 1;
+    net->bn[name] = d;
+    return 0;
+}
+
 static int make_conv(cerb_net* net, const std::string& name, const std::vector<std::string>& wkeys,
                      const std::vector<std::string>& bkeys, const std::vector<std::string>& bnkeys, int cout, int cin, int ks,
                      int stride) {
@@ -339,7 +373,7 @@ static int make_conv(cerb_net* net, const std::string& name, const std::vector<s
         const HostTensor* w;
         if (get(net, wkeys[g], {cout, cin, ks, ks}, &w)) return 1;
         Fold f;
-        bool have_bn = !bnkeys.empty();
+        bool have_bn = !bnkeys.empty() && net->fold_bn;
         if (have_bn && bn_fold(net, bnkeys[g], cout, &f)) return 1;
         pack_conv(w->data.data(), have_bn ? f.scale.data() : nullptr, cout, cin, ks, CB, &wp);
         if (wino) pack_wino(w->data.data(), have_bn ? f.scale.data() : nullptr, cout, cin, &wwino, &hu);
@@ -351,6 +385,7 @@ static int make_conv(cerb_net* net, const std::string& name, const std::vector<s
             bp.push_back(v);
         }
     }
+    if (!net->fold_bn && !bnkeys.empty() && store_bn(net, name, bnkeys, cout)) return 1;
     PackedConv pc;
     pc.cin = cin; pc.cout = cout; pc.ks = ks; pc.stride = stride; pc.groups = (int)wkeys.size();
     if (upload(net, wp, &pc.w) || upload(net, bp, &pc.b)) return 1;
@@ -372,6 +407,11 @@ extern "C" int cerb_net_finalize(cerb_net* net) {
         if (get(net, "backbone.conv1.weight", {64, 3, 7, 7}, &w)) return 1;
         Fold f;
         if (bn_fold(net, "backbone.bn1", 64, &f)) return 1;
+        if (!net->fold_bn) {
+            f.scale.assign(64, 1.f);
+            f.shift.assign(64, 0.f);
+            if (store_bn(net, "stem", {"backbone.bn1"}, 64)) return 1;
+        }
         std::vector<float> wp(7 * 12 * 2 * 64, 0.f);
         for (int ky = 0; ky < 7; ++ky)
             for (int t = 0; t < 12; ++t)
@@ -448,6 +488,12 @@ extern "C" int cerb_net_finalize(cerb_net* net) {
                         w2p[(blk * 64 + lane) * 4 + r] = (o < d.out_ch) ? w2->data[(size_t)o * 96 + hid] : 0.f;
                     }
             for (int c = 0; c < d.out_ch; ++c) b2p[c] = b2->data[c];
+            if (!net->fold_bn) {
+                float *r1, *rb1, *r2, *rb2;
+                if (upload(net, w1->data, &r1) || upload(net, b1->data, &rb1) || upload(net, w2->data, &r2) || upload(net, b2->data, &rb2)) return 1;
+                net->head_rw1.push_back(r1); net->head_rb1.push_back(rb1); net->head_rw2.push_back(r2); net->head_rb2.push_back(rb2);
+                if (store_bn(net, "head." + std::to_string(net->head_rw1.size() - 1), {p + ".0.block.0.bn"}, 96)) return 1;
+            }
             float *dw1, *db1, *dw2, *db2;
             if (upload(net, w1p, &dw1) || upload(net, b1p, &db1) || upload(net, w2p, &dw2) || upload(net, b2p, &db2)) return 1;
             net->head_w1.push_back(dw1); net->head_b1.push_back(db1); net->head_w2.push_back(dw2); net->head_b2.push_back(db2);
@@ -462,6 +508,11 @@ extern "C" int cerb_net_finalize(cerb_net* net) {
         if (bn_fold(net, p + ".bn1", 512, &f1) || bn_fold(net, p + ".bn2", 256, &f2) || get(net, p + ".conv1.weight", {256, 512, 1, 1}, &w1) ||
             get(net, p + ".conv1.bias", {256}, &b1) || get(net, p + ".conv2.weight", {oc, 256, 1, 1}, &w2) || get(net, p + ".conv2.bias", {oc}, &b2))
             return 1;
+        if (!net->fold_bn) {
+            if (upload(net, w1->data, &net->pc_rw1) || upload(net, b1->data, &net->pc_rb1) || upload(net, w2->data, &net->pc_rw2) ||
+                upload(net, b2->data, &net->pc_rb2) || store_bn(net, "pc.bn1", {p + ".bn1"}, 512) || store_bn(net, "pc.bn2", {p + ".bn2"}, 256))
+                return 1;
+        }
         std::vector<float> w1t(512 * 256), b1f(256), w2t(256 * 16, 0.f), b2f(16, 0.f);
         for (int o = 0; o < 256; ++o) {
             for (int c = 0; c < 512; ++c) w1t[(size_t)c * 256 + o] = w1->data[(size_t)o * 512 + c] * f2.scale[o];
@@ -594,7 +645,7 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
     if (macs) *macs += (double)N * H * W * 64.0 * 147.0;
     if (!dry) {
         StemParams sp;
-        sp.tiles = io->tiles; sp.wpack = net->stem_w; sp.bias = net->stem_b; sp.out = net->x0.p; sp.N = N; sp.H = H; sp.W = W;
+        sp.tiles = io->tiles; sp.wpack = net->stem_w; sp.bias = net->stem_b; sp.out = net->x0.p; sp.N = N; sp.H = H; sp.W = W; sp.relu = 1;
         sp.tiles_x = sp.tiles_y = 0;
         if (prof_begin(net, "stem", "stem_conv7x7", 2.0 * N * H * W * 64.0 * 147.0, st)) return 1;
         HIP_OK(cerb_launch_stem(sp, st));
@@ -745,10 +796,153 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Train-mode forward (models/run_desc.py:79-86: model.train(); pred_dict = model(img_list, train_dec_list)): every BatchNorm uses the
+// statistics of the batch, so the convolutions run with their raw weights (net packed with cerb_net_set_fold_bn(net, 0)) and each is
+// followed by cerb_launch_bn_stats / cerb_launch_bn_apply.  Returns the full-resolution logits of every head.  First version of
+// the forward half of BASELINE configs[4]: nothing is kept for a backward pass yet and the running statistics are not updated.
+static int bn_train(cerb_net* net, const std::string& name, float* x, const float* resid, long long group_stride, long long rows, int relu,
+                    hipStream_t st) {
+    auto it = net->bn.find(name);
+    if (it == net->bn.end()) return fail("internal: no BatchNorm parameters for " + name);
+    const cerb_net::BnDev& b = it->second;
+    if (net->t_mean.ensure((size_t)b.groups * b.C * 4, 0) || net->t_rstd.ensure((size_t)b.groups * b.C * 4, 0) ||
+        net->t_ws.ensure(cerb_bn_workspace_bytes(b.groups, rows, b.C), 0))
+        return fail("workspace allocation failed");
+    HIP_OK(cerb_launch_bn_stats(x, group_stride, rows, b.C, b.groups, 1e-5f, net->t_mean.p, net->t_rstd.p, nullptr, net->t_ws.p, st));
+    HIP_OK(cerb_launch_bn_apply(x, resid, group_stride, rows, b.C, b.groups, net->t_mean.p, net->t_rstd.p, b.gamma, b.beta, relu, st));
+    return 0;
+}
+
+extern "C" int cerb_net_forward_train(cerb_net* net, const cerb_train_io* io, void* hip_stream) {
+    if (!net || !io || !io->tiles || !io->logits) return fail("cerb_net_forward_train: null argument");
+    if (!net->finalized) return fail("cerb_net_forward_train: call cerb_net_finalize first");
+    if (net->fold_bn) return fail("cerb_net_forward_train: the network was packed for inference (BatchNorm folded); call cerb_net_set_fold_bn(net, 0) before cerb_net_finalize");
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int N = io->n, H = io->h, W = io->w;
+    if (N <= 0 || H <= 0 || W <= 0 || (H % 16) || (W % 16)) return fail("cerb_net_forward_train: tile H,W must be positive multiples of 16");
+    const int hs[5] = {H, H / 2, H / 4, H / 8, H / 16}, ws[5] = {W, W / 2, W / 4, W / 8, W / 16};
+    const size_t D = net->dense_idx.size();
+    const size_t guard = cerb_conv_guard_bytes(W);
+    if (net->x0.ensure((size_t)N * H * W * 64 * 4, guard) || net->pool.ensure((size_t)N * hs[1] * ws[1] * 64 * 4, guard) ||
+        net->ta.ensure((size_t)N * hs[1] * ws[1] * 64 * 4, guard) || net->tb.ensure((size_t)N * hs[1] * ws[1] * 64 * 4, guard) ||
+        net->cm.ensure((size_t)N * hs[4] * ws[4] * 256 * 4, guard))
+        return fail("workspace allocation failed");
+    for (int i = 1; i < 5; ++i)
+        if (net->x[i].ensure((size_t)N * hs[i] * ws[i] * kFilters[i] * 4, guard)) return fail("workspace allocation failed");
+    const int oc[4] = {128, 64, 64, 64};
+    if (D) {
+        if (net->dmid.ensure(D * (size_t)N * H * W * 64 * 4, guard) || net->dsum.ensure(D * (size_t)N * H * W * 64 * 4, guard)) return fail("workspace allocation failed");
+        for (int u = 0; u < 4; ++u)
+            if (net->dout[u].ensure(D * (size_t)N * hs[3 - u] * ws[3 - u] * oc[u] * 4, guard)) return fail("workspace allocation failed");
+    }
+    const int saved_algo = net->conv_algo;
+    if (net->conv_algo == 2) net->conv_algo = 1;
+    // ---- encoder: conv -> BN(batch) -> ReLU -----------------------------------------------------------------------------------
+    {
+        StemParams sp;
+        sp.tiles = io->tiles; sp.wpack = net->stem_w; sp.bias = net->stem_b; sp.out = net->x0.p; sp.N = N; sp.H = H; sp.W = W; sp.relu = 0;
+        sp.tiles_x = sp.tiles_y = 0;
+        HIP_OK(cerb_launch_stem(sp, st));
+        if (bn_train(net, "stem", net->x0.p, nullptr, 0, (long long)N * H * W, 1, st)) return 1;
+        HIP_OK(cerb_launch_maxpool(net->x0.p, net->pool.p, N, H, W, 64, st));
+    }
+    float* cur = net->pool.p;
+    int inpl = 64;
+    for (int li = 0; li < 4; ++li) {
+        const int planes = kFilters[li + 1];
+        const int Hi = (li == 0) ? hs[1] : hs[li], Wi = (li == 0) ? ws[1] : ws[li];
+        for (int b = 0; b < kLayers[li]; ++b) {
+            const std::string p = "backbone.layer" + std::to_string(li + 1) + "." + std::to_string(b);
+            const int stride = (b == 0 && li > 0) ? 2 : 1;
+            const int hin = (b == 0) ? Hi : hs[li + 1], win = (b == 0) ? Wi : ws[li + 1];
+            const long long rows_out = (long long)N * hs[li + 1] * ws[li + 1];
+            float* t1 = net->ta.p;
+            float* outb = ((kLayers[li] - 1 - b) % 2 == 0) ? net->x[li + 1].p : net->tb.p;
+            const float* idt = cur;
+            if (run_conv(net, p + ".conv1", cur, nullptr, nullptr, t1, N, hin, win, 0, 0, 0, 0, st, nullptr)) return 1;
+            if (bn_train(net, p + ".conv1", t1, nullptr, 0, rows_out, 1, st)) return 1;
+            if (stride != 1 || inpl != planes) {
+                // the identity branch needs its own buffer here: in layer1.0 there is none, later the pool buffer is free but smaller maps fit
+                if (net->t_idn.ensure((size_t)rows_out * planes * 4, guard)) return fail("workspace allocation failed");
+                if (run_conv(net, p + ".downsample", cur, nullptr, nullptr, net->t_idn.p, N, hin, win, 0, 0, 0, 0, st, nullptr)) return 1;
+                if (bn_train(net, p + ".downsample", net->t_idn.p, nullptr, 0, rows_out, 0, st)) return 1;
+                idt = net->t_idn.p;
+            }
+            if (run_conv(net, p + ".conv2", t1, nullptr, nullptr, outb, N, hs[li + 1], ws[li + 1], 0, 0, 0, 0, st, nullptr)) return 1;
+            if (bn_train(net, p + ".conv2", outb, idt, 0, rows_out, 1, st)) return 1;  // relu(bn2(conv2) + identity)
+            cur = outb;
+            inpl = planes;
+        }
+    }
+    if (run_conv(net, "conv_map", net->x[4].p, nullptr, nullptr, net->cm.p, N, hs[4], ws[4], 0, 0, 0, 0, st, nullptr)) return 1;
+    // ---- Patch-Class: crop -> GAP -> BN -> ReLU -> dropout -> 1x1 -> BN -> ReLU -> 1x1 (models/net_desc.py:64-76,169-180) -----------------
+    if (net->pc_idx >= 0 && io->logits[net->pc_idx]) {
+        const int ocp = net->dec[net->pc_idx].out_ch;
+        int y0 = 0, x0 = 0, ch = hs[4], cw = ws[4];
+        if (hs[4] != 9 && ws[4] != 9) {  // cropping_center as a Python slice (negative start wraps, stop clipped): see patch_class_kernel
+            auto py_slice = [](int len, int& start, int& count) {
+                const int h0 = (int)((len - 9) * 0.5);
+                const int a0 = h0 < 0 ? std::max(len + h0, 0) : std::min(h0, len);
+                const int a1 = std::min(h0 + 9, len);
+                start = a0;
+                count = std::max(a1 - a0, 0);
+            };
+            py_slice(hs[4], y0, ch);
+            py_slice(ws[4], x0, cw);
+        }
+        if (ch <= 0 || cw <= 0) return fail("cerb_net_forward_train: empty Patch-Class crop");
+        if (net->t_gap.ensure((size_t)N * 512 * 4, 0) || net->t_pc1.ensure((size_t)N * 256 * 4, 0)) return fail("workspace allocation failed");
+        HIP_OK(cerb_launch_crop_gap(net->x[4].p, N, hs[4], ws[4], 512, y0, ch, x0, cw, net->t_gap.p, st));
+        if (bn_train(net, "pc.bn1", net->t_gap.p, nullptr, 0, N, 1, st)) return 1;
+        HIP_OK(cerb_launch_pointwise(net->t_gap.p, net->pc_rw1, net->pc_rb1, net->t_pc1.p, N, 512, 256, io->dropout_scale, st));
+        if (bn_train(net, "pc.bn2", net->t_pc1.p, nullptr, 0, N, 1, st)) return 1;
+        HIP_OK(cerb_launch_pointwise(net->t_pc1.p, net->pc_rw2, net->pc_rb2, io->logits[net->pc_idx], N, 256, ocp, nullptr, st));
+    }
+    // ---- dense decoders (grouped) and heads ---------------------------------------------------------------------------------------
+    if (D) {
+        const float* skips[4] = {net->x[3].p, net->x[2].p, net->x[1].p, net->x0.p};
+        const float* prev = net->cm.p;
+        long long prev_gs = 0;
+        for (int u = 0; u < 4; ++u) {
+            const int hh = hs[3 - u], ww = ws[3 - u];
+            const std::string n0 = "dec." + std::to_string(u) + ".0", n1 = "dec." + std::to_string(u) + ".1";
+            const int cmid = net->conv[n0].cout, cin0 = net->conv[n0].cin;
+            const long long rows = (long long)N * hh * ww;
+            HIP_OK(cerb_launch_upsample2_add(skips[u], prev, net->dsum.p, (int)D, N, hh, ww, cin0, prev_gs, nullptr, st));
+            if (run_conv(net, n0, net->dsum.p, nullptr, nullptr, net->dmid.p, N, hh, ww, 0, 0, rows * cin0, 0, st, nullptr)) return 1;
+            if (bn_train(net, n0, net->dmid.p, nullptr, rows * cmid, rows, 1, st)) return 1;
+            if (run_conv(net, n1, net->dmid.p, nullptr, nullptr, net->dout[u].p, N, hh, ww, 0, 0, rows * cmid, 0, st, nullptr)) return 1;
+            if (bn_train(net, n1, net->dout[u].p, nullptr, rows * oc[u], rows, 1, st)) return 1;
+            prev = net->dout[u].p;
+            prev_gs = rows * oc[u];
+        }
+        const long long rows = (long long)N * H * W;
+        if (net->t_hid.ensure((size_t)rows * 96 * 4, 0)) return fail("workspace allocation failed");
+        for (size_t k = 0; k < D; ++k) {
+            const int di = net->dense_idx[k];
+            if (!io->logits[di]) continue;
+            HIP_OK(cerb_launch_pointwise(net->dout[3].p + k * (size_t)rows * 64, net->head_rw1[k], net->head_rb1[k], net->t_hid.p, rows, 64, 96, nullptr, st));
+            if (bn_train(net, "head." + std::to_string(k), net->t_hid.p, nullptr, 0, rows, 1, st)) return 1;
+            HIP_OK(cerb_launch_pointwise(net->t_hid.p, net->head_rw2[k], net->head_rb2[k], io->logits[di], rows, 96, net->dec[di].out_ch, nullptr, st));
+        }
+    }
+    net->conv_algo = saved_algo;
+    return 0;
+}
+
+extern "C" int cerb_net_set_fold_bn(cerb_net* net, int fold) {
+    if (!net) return fail("cerb_net_set_fold_bn: null handle");
+    if (net->finalized) return fail("cerb_net_set_fold_bn: must be called before cerb_net_finalize");
+    net->fold_bn = fold ? 1 : 0;
+    return 0;
+}
+
 extern "C" int cerb_net_forward(cerb_net* net, const cerb_forward_io* io, void* hip_stream) {
     if (!net || !io) return fail("cerb_net_forward: null argument");
     if (!net->finalized) return fail("cerb_net_forward: call cerb_net_finalize first");
     if (!io->tiles) return fail("cerb_net_forward: null tiles pointer");
+    if (!net->fold_bn) return fail("cerb_net_forward: the network was packed for training (cerb_net_set_fold_bn(net, 0)); use cerb_net_forward_train");
     net->prof_n = 0;
     return forward_impl(net, io, (hipStream_t)hip_stream, nullptr);
 }

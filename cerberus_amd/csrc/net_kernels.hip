@@ -19,6 +19,7 @@ struct StemParams {
     const float* bias;           // [64]
     float* out;                  // [N][H][W][64]
     int N, H, W, tiles_x, tiles_y;
+    int relu;                    // 1: inference (BN folded into wpack / bias, ReLU fused); 0: train mode (raw conv, BN and ReLU follow)
 };
 
 __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemParams p) {
@@ -81,10 +82,11 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemParams p) {
                     const int co = s * 32 + rq * 8 + h * 4;
                     f32x4 v = {acc[s][q][rq * 4 + 0], acc[s][q][rq * 4 + 1], acc[s][q][rq * 4 + 2], acc[s][q][rq * 4 + 3]};
                     v = v + *reinterpret_cast<const f32x4*>(p.bias + co);
-                    v[0] = fmaxf(v[0], 0.f);
-                    v[1] = fmaxf(v[1], 0.f);
-                    v[2] = fmaxf(v[2], 0.f);
-                    v[3] = fmaxf(v[3], 0.f);
+                    const float floor_ = p.relu ? 0.f : -3.402823466e38f;
+                    v[0] = fmaxf(v[0], floor_);
+                    v[1] = fmaxf(v[1], floor_);
+                    v[2] = fmaxf(v[2], floor_);
+                    v[3] = fmaxf(v[3], floor_);
                     *reinterpret_cast<f32x4*>(o + co) = v;
                 }
         }

@@ -207,3 +207,171 @@ extern "C" int cerb_head_loss(const float* logits, long long stride_n, long long
     if (e != hipSuccess) return cerb_set_error(std::string("cerb_head_loss: ") + hipGetErrorString(e));
     return 0;
 }
+
+// =================================================================================================================
+// Train-mode forward pieces (models/run_desc.py:79-86 `model.train()` forward): BatchNorm with BATCH statistics cannot be folded
+// into the convolutions, so every conv runs with its raw weights (the inference kernels, packed without the fold) and is followed by
+//   cerb_launch_bn_stats : per (group, channel) mean and biased variance over the N*H*W rows of an NHWC tensor -- per-block partial
+//                          sums in double, one finalising block per group (fixed order: reproducible)
+//   cerb_launch_bn_apply : y = (x - mean) * gamma / sqrt(var + eps) + beta (+ residual) (ReLU), in place, float4
+// plus the small dense pieces that the fused inference head / Patch-Class kernels cannot serve in train mode:
+//   cerb_launch_pointwise: out[r][co] = bias[co] + sum_ci in[r][ci] * W[co][ci]   (1x1 convs 64->96, 96->C, 512->256, 256->9)
+//   cerb_launch_crop_gap : centre crop (Python-slice semantics of cropping_center) + global average pool of the bottom features
+// First version: correctness and reproducibility; these are HBM-bound passes that a later round fuses into the conv epilogues.
+// =================================================================================================================
+namespace {
+constexpr int BN_ROWS_PER_BLOCK = 2048;
+
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, long long group_stride, long long rows, int C, int blocks_per_group,
+                                                         double* __restrict__ partial) {
+    extern __shared__ double shd[];  // [256][2] per float4 lane component handled below
+    const int g = blockIdx.x / blocks_per_group, b = blockIdx.x % blocks_per_group;
+    const int c4n = C >> 2, tid = threadIdx.x;
+    const int c4 = tid % c4n, rl = tid / c4n, nrl = 256 / c4n;  // threads with rl >= nrl idle (C / 4 need not divide 256)
+    const long long r0 = (long long)b * BN_ROWS_PER_BLOCK, r1 = min(rows, r0 + BN_ROWS_PER_BLOCK);
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (rl < nrl)
+        for (long long r = r0 + rl; r < r1; r += nrl) {
+            const float4 v = *reinterpret_cast<const float4*>(x + g * group_stride + r * C + 4 * c4);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+        }
+    // reduce over the row lanes of each channel quad through LDS, fixed order
+    for (int e = 0; e < 4; ++e) {
+        __syncthreads();
+        shd[tid * 2] = s[e];
+        shd[tid * 2 + 1] = q[e];
+        __syncthreads();
+        if (rl == 0) {
+            double ss = 0, qq = 0;
+            for (int k = 0; k < nrl; ++k) {
+                ss += shd[(k * c4n + c4) * 2];
+                qq += shd[(k * c4n + c4) * 2 + 1];
+            }
+            double* o = partial + ((long long)blockIdx.x * C + 4 * c4 + e) * 2;
+            o[0] = ss;
+            o[1] = qq;
+        }
+    }
+}
+__global__ void bn_finalize_kernel(const double* __restrict__ partial, long long rows, int C, int blocks_per_group, float eps, float* __restrict__ mean,
+                                   float* __restrict__ rstd, float* __restrict__ var_unbiased) {
+    const int g = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s = 0, q = 0;
+        for (int b = 0; b < blocks_per_group; ++b) {
+            const double* p = partial + ((long long)(g * blocks_per_group + b) * C + c) * 2;
+            s += p[0];
+            q += p[1];
+        }
+        const double m = s / (double)rows;
+        double v = q / (double)rows - m * m;
+        if (v < 0) v = 0;
+        mean[g * C + c] = (float)m;
+        rstd[g * C + c] = (float)(1.0 / sqrt(v + (double)eps));
+        if (var_unbiased) var_unbiased[g * C + c] = (float)(rows > 1 ? v * (double)rows / (double)(rows - 1) : v);
+    }
+}
+__global__ __launch_bounds__(256) void bn_apply_kernel(float* __restrict__ x, const float* __restrict__ resid, long long group_stride, long long rows, int C,
+                                                       int groups, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int relu) {
+    const int c4n = C >> 2;
+    const long long per_group = rows * c4n, total = per_group * groups;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i / per_group);
+        const long long j = i - (long long)g * per_group;
+        const int c = 4 * (int)(j % c4n);
+        float4* p = reinterpret_cast<float4*>(x + g * group_stride + (j / c4n) * C + c);
+        float4 v = *p;
+        const float* m = mean + g * C + c;
+        const float* rs = rstd + g * C + c;
+        const float* ga = gamma + g * C + c;
+        const float* be = beta + g * C + c;
+        v.x = (v.x - m[0]) * (rs[0] * ga[0]) + be[0];
+        v.y = (v.y - m[1]) * (rs[1] * ga[1]) + be[1];
+        v.z = (v.z - m[2]) * (rs[2] * ga[2]) + be[2];
+        v.w = (v.w - m[3]) * (rs[3] * ga[3]) + be[3];
+        if (resid) {
+            const float4 r = *reinterpret_cast<const float4*>(resid + g * group_stride + (j / c4n) * C + c);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        *p = v;
+    }
+}
+// out[r][co] = bias[co] + sum_ci in[r][ci] * W[co][ci]; thread = (row, 4 couts); weights read through the caches
+__global__ __launch_bounds__(256) void pointwise_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ out, long long rows, int cin, int cout, const float* __restrict__ in_scale) {
+    const int cq = (cout + 3) >> 2;
+    const long long total = rows * cq;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / cq;
+        const int co = 4 * (int)(i % cq);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* x = in + r * cin;
+        for (int ci = 0; ci < cin; ci += 4) {
+            float4 v = *reinterpret_cast<const float4*>(x + ci);
+            if (in_scale) {  // dropout mask * 1 / (1 - p), per (row, channel)
+                const float4 s = *reinterpret_cast<const float4*>(in_scale + r * cin + ci);
+                v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+            }
+            for (int e = 0; e < 4; ++e)
+                if (co + e < cout) {
+                    const float4 ww = *reinterpret_cast<const float4*>(w + (long long)(co + e) * cin + ci);
+                    acc[e] = fmaf(v.x, ww.x, acc[e]);
+                    acc[e] = fmaf(v.y, ww.y, acc[e]);
+                    acc[e] = fmaf(v.z, ww.z, acc[e]);
+                    acc[e] = fmaf(v.w, ww.w, acc[e]);
+                }
+        }
+        for (int e = 0; e < 4; ++e)
+            if (co + e < cout) out[r * cout + co + e] = acc[e] + (bias ? bias[co + e] : 0.f);
+    }
+}
+__global__ void crop_gap_kernel(const float* __restrict__ x, int N, int H, int W, int C, int y0, int ch, int x0, int cw, float* __restrict__ out) {
+    const int total = N * C;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int n = i / C, c = i % C;
+        float s = 0.f;  // torch's adaptive_avg_pool2d sums the window in order and divides once
+        for (int y = y0; y < y0 + ch; ++y)
+            for (int xx = x0; xx < x0 + cw; ++xx) s += x[(((long long)n * H + y) * W + xx) * C + c];
+        out[i] = s / (float)(ch * cw);
+    }
+}
+}  // namespace
+
+size_t cerb_bn_workspace_bytes(int groups, long long rows, int C) {
+    const long long bpg = (rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK;
+    return (size_t)groups * bpg * C * 2 * 8 + 256;
+}
+hipError_t cerb_launch_bn_stats(const float* x, long long group_stride, long long rows, int C, int groups, float eps, float* mean, float* rstd,
+                                float* var_unbiased, void* ws, hipStream_t st) {
+    if (C % 4 || C / 4 > 256) return hipErrorInvalidValue;  // a block covers all channel quads of a row; spare threads idle (C = 96: 24 quads x 10 row lanes)
+    const int bpg = (int)((rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK);
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(groups * bpg), dim3(256), 256 * 2 * sizeof(double), st, x, group_stride, rows, C, bpg, (double*)ws);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(groups), dim3(256), 0, st, (const double*)ws, rows, C, bpg, eps, mean, rstd, var_unbiased);
+    return hipGetLastError();
+}
+hipError_t cerb_launch_bn_apply(float* x, const float* resid, long long group_stride, long long rows, int C, int groups, const float* mean,
+                                const float* rstd, const float* gamma, const float* beta, int relu, hipStream_t st) {
+    long long blocks = (rows * (C / 4) * groups + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, resid, group_stride, rows, C, groups, mean, rstd, gamma, beta, relu);
+    return hipGetLastError();
+}
+hipError_t cerb_launch_pointwise(const float* in, const float* w, const float* bias, float* out, long long rows, int cin, int cout, const float* in_scale,
+                                 hipStream_t st) {
+    if (cin % 4) return hipErrorInvalidValue;
+    long long blocks = (rows * ((cout + 3) / 4) + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pointwise_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, w, bias, out, rows, cin, cout, in_scale);
+    return hipGetLastError();
+}
+hipError_t cerb_launch_crop_gap(const float* x, int N, int H, int W, int C, int y0, int ch, int x0, int cw, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(crop_gap_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, x, N, H, W, C, y0, ch, x0, cw, out);
+    return hipGetLastError();
+}

@@ -99,16 +99,6 @@ class NetDesc(torch.nn.Module):
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
     # ---- nn.Module conveniences ----------------------------------------------------------------------------
-    def train(self, mode=True):
-        if mode:
-            raise NotImplementedError("cerberus_amd.NetDesc is inference-only (training is SURVEY.md par.8f 'next')")
-        self.training = False
-        return self
-
-    def eval(self):
-        self.training = False
-        return self
-
     def _release(self):
         if self._handle is not None:
             _lib.lib().cerb_net_destroy(self._handle)
@@ -134,6 +124,8 @@ class NetDesc(torch.nn.Module):
         h = C.c_void_p()
         _lib.check(L.cerb_net_create(names, heads, och, n, C.byref(h)))
         try:
+            if getattr(self, "_train_packing", False):
+                _lib.check(L.cerb_net_set_fold_bn(h, 0))
             for k, v in self._sd.items():
                 if v.dtype != torch.float32:
                     continue
@@ -146,6 +138,48 @@ class NetDesc(torch.nn.Module):
             raise
         self._handle = h
         return h
+
+    def train(self, mode=True):
+        """nn.Module.train(): a network whose handle has not been created yet is packed for training on first use (raw conv weights,
+        BatchNorm with batch statistics; include/cerberus_hip.h cerb_net_set_fold_bn) and then serves forward_train only.  eval()
+        on such a handle -- or train() on an inference handle -- needs a fresh NetDesc: the two packings are different device data."""
+        if self._handle is not None and bool(mode) != bool(getattr(self, "_train_packing", False)):
+            raise _lib.CerberusHipError("this network is already packed for %s; create another NetDesc for the other mode"
+                                        % ("training" if getattr(self, "_train_packing", False) else "inference"))
+        self._train_packing = bool(mode)
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def forward_train(self, tiles_u8, dropout_keep=None):
+        """The reference's forward in model.train() mode (models/run_desc.py:79-86; BatchNorm with the batch's statistics).
+        tiles_u8: CUDA uint8 [N, H, W, 3]; dropout_keep: CUDA bool / float [N, 512] keep mask of the Patch-Class dropout (p = 0.3), or
+        None for no dropout.  -> OrderedDict head key -> logits, dense heads as [N, H, W, C] (channels last), Patch-Class [N, C]."""
+        self.train(True)
+        h = self._ensure_handle()
+        assert tiles_u8.is_cuda and tiles_u8.dtype == torch.uint8 and tiles_u8.dim() == 4 and tiles_u8.shape[3] == 3
+        tiles_u8 = tiles_u8.contiguous()
+        n, hh, ww, _ = [int(v) for v in tiles_u8.shape]
+        res, bufs = OrderedDict(), []
+        for name, hname, och, key in self._decoders:
+            t = torch.empty((n, och) if name == "Patch-Class" else (n, hh, ww, och), dtype=torch.float32, device=tiles_u8.device)
+            res[key] = t
+            bufs.append(t)
+        io = _lib.TrainIO()
+        io.tiles = tiles_u8.data_ptr()
+        io.n, io.h, io.w = n, hh, ww
+        scale = None
+        if dropout_keep is not None:
+            scale = (dropout_keep.to(tiles_u8.device).reshape(n, 512).float() / (1.0 - 0.3)).contiguous()
+            io.dropout_scale = scale.data_ptr()
+        arr = (C.c_void_p * len(bufs))(*[t.data_ptr() for t in bufs])
+        io.logits = arr
+        stream = torch.cuda.current_stream(tiles_u8.device).cuda_stream
+        with torch.cuda.device(tiles_u8.device):
+            _lib.check(_lib.lib().cerb_net_forward_train(h, C.byref(io), C.c_void_p(stream)))
+        return res
 
     def flops(self, n, h, w):
         return float(_lib.lib().cerb_net_flops(self._ensure_handle(), n, h, w))

@@ -189,6 +189,25 @@ int cerb_relabel(const int32_t* labels, long long lab_row_stride, const int32_t*
                  long long out_row_stride, void* hip_stream);
 
 /* ---- device timing helper: HIP events on the given stream (bench.py; torch.cuda.Event only sees torch's stream) */
+/* ---- train-mode forward (BASELINE.json configs[4], forward half; models/run_desc.py:79-86) ---------------------------------------
+ * cerb_net_set_fold_bn(net, 0), called BEFORE cerb_net_finalize, packs the network for training: raw convolution weights, the
+ * BatchNorm affine parameters kept apart.  Such a network only serves cerb_net_forward_train (and an inference-packed one only
+ * cerb_net_forward).  cerb_net_forward_train runs the reference's forward in `model.train()` mode: every BatchNorm normalises with
+ * the statistics of the batch (biased variance, eps 1e-5), dropout of the Patch-Class branch takes its keep mask from the caller.
+ *   tiles         : device uint8 [n][h][w][3]
+ *   dropout_scale : device float [n][512] = keep / (1 - 0.3) of nn.Dropout(p=0.3) (models/net_desc.py:70), or NULL (no dropout)
+ *   logits        : per decoder (cerb_net_create order) a device float buffer or NULL: dense heads [n][h][w][out_ch] (NHWC, full
+ *                   resolution), Patch-Class [n][out_ch]
+ * Not yet: activations are not kept for a backward pass, running statistics are not updated. */
+typedef struct cerb_train_io {
+    const uint8_t* tiles;
+    int n, h, w;
+    const float* dropout_scale;
+    float* const* logits;
+} cerb_train_io;
+int cerb_net_set_fold_bn(cerb_net* net, int fold);
+int cerb_net_forward_train(cerb_net* net, const cerb_train_io* io, void* hip_stream);
+
 /* ---- training step, first piece (BASELINE.json configs[4]; NOT a training step yet) --------------------------------------------
  * cerb_head_loss: the per-head loss of the reference's train_step (models/run_desc.py:88-170) and its gradient on the logits.
  *   logits / dlogits : device float, element strides (n, c, y, x) -- NCHW as the reference's forward returns them, or NHWC

@@ -99,7 +99,7 @@ def run_case(prefix, nuclei_type_weight, store):
     before = {k: v.detach().clone() for k, v in model.state_dict().items()}
     run_info = ({"net": {"desc": net, "optimizer": opt, "extra_info": {"loss": loss_kwargs}}}, None)
     res = train_step(dict(batch), run_info)
-    store.update({"N": N, "H": H, "heads": np.array(list(heads.keys())), "n_classes": np.array(list(heads.values())),
+    store.update({"N": N, "H": H, "img": batch["img"].numpy(), "weight_seed": 0, "heads": np.array(list(heads.keys())), "n_classes": np.array(list(heads.values())),
                   "has_target": np.array([[x is not None for x in row] for row in has])})
     store[prefix + "overall_loss"] = np.float64(res["EMA"]["overall_loss"])
     for h in heads:

@@ -58,3 +58,44 @@ def test_head_loss_is_bitwise_reproducible_and_matches_the_oracle_on_larger_maps
     exp, g = train_ref.head_loss("Nuclei-TYPE", lg, tgt[..., None], flag, opts)
     assert abs(float(a[0]) - exp) <= 1e-5 * abs(exp)
     assert np.abs(a[1].cpu().numpy() - g).max() <= 2e-5 * np.abs(g).max()
+
+
+def test_train_mode_forward_vs_reference_train_step(gold):
+    """cerb_net_forward_train (BatchNorm with the batch's statistics, raw conv weights, the Patch-Class dropout mask of that step) against
+    the logits the reference's network produced inside its own train_step (forward hooks, oracle/gen_golden_train_loss.py), and the
+    losses computed from OUR logits against the losses train_step reported."""
+    from cerberus_amd.net_desc import create_model
+    from cerberus_amd.weights import default_model_kwargs, make_state_dict
+
+    kw = default_model_kwargs()
+    m = create_model(**kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(int(gold["weight_seed"])).items()}, strict=True)
+    m.train()
+    tiles = torch.from_numpy(gold["img"]).cuda()
+    keep = torch.from_numpy(gold["step/dropout_mask"].reshape(int(gold["N"]), 512)).cuda()
+    out = m.forward_train(tiles, keep)
+    total = 0.0
+    for j, h in enumerate(gold["heads"]):
+        h = str(h)
+        ref = gold["logits/" + h]                      # NCHW
+        got = out[h].cpu().numpy()
+        got = got.reshape(ref.shape) if h == "Patch-Class" else got.transpose(0, 3, 1, 2)
+        err = np.abs(got - ref).max()
+        assert err <= 2e-4 * max(1.0, np.abs(ref).max()), (h, err, np.abs(ref).max())
+        lg = out[h].reshape(int(gold["N"]), -1, 1, 1) if h == "Patch-Class" else out[h]
+        loss, _ = head_loss(h, lg, torch.from_numpy(gold["target/" + h][..., 0]).cuda(),
+                            torch.from_numpy(gold["has_target"][:, j].astype(np.float32)).cuda(), channels_last=(h != "Patch-Class"))
+        exp = float(gold["paramset/loss/" + h])
+        assert abs(float(loss) - exp) <= 1e-4 * max(1.0, abs(exp)), (h, float(loss), exp)  # north_star's bar on the loss
+        total += float(loss)
+    assert abs(total - float(gold["paramset/overall_loss"])) <= 1e-4 * float(gold["paramset/overall_loss"])
+    # an inference-packed network refuses the train-mode entry point and vice versa
+    from cerberus_amd._lib import CerberusHipError
+
+    with pytest.raises(CerberusHipError):
+        m.infer_tiles(tiles, 64)
+    e = create_model(**kw)
+    e.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(0).items()}, strict=True)
+    e.infer_tiles(tiles, 64)
+    with pytest.raises(CerberusHipError):
+        e.train()

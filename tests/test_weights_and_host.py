@@ -65,9 +65,8 @@ def test_unsupported_backbone_and_train_mode():
         create_model(**kw)
     m = create_model(**default_model_kwargs(["Nuclei"]))
     assert isinstance(m, NetDesc) and isinstance(m, torch.nn.Module)
-    with pytest.raises(NotImplementedError):
-        m.train()
-    assert m.eval() is m
+    # train() selects the training packing of a handle that does not exist yet (forward half of the training step); eval() the default
+    assert m.train() is m and m.training and m.eval() is m and not m.training
 
 
 def test_no_gpu_fails_loudly():
