@@ -41,6 +41,16 @@ hipError_t cerb_launch_bn_apply(float* x, const float* resid, long long group_st
 hipError_t cerb_launch_pointwise(const float* in, const float* w, const float* bias, float* out, long long rows, int cin, int cout, const float* in_scale,
                                  hipStream_t st);
 hipError_t cerb_launch_crop_gap(const float* x, int N, int H, int W, int C, int y0, int ch, int x0, int cw, float* out, hipStream_t st);
+hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, float* dy, float* dresid, long long group_stride, long long rows, int C, int groups,
+                              const float* mean, const float* rstd, const float* gamma, float* dgamma, float* dbeta, int relu, void* ws, hipStream_t st);
+hipError_t cerb_launch_conv_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int G, int N, int H, int W, int Cin, int Cout,
+                                int ks, int stride, long long x_gs, hipStream_t st);
+hipError_t cerb_launch_stem_wgrad(const unsigned char* tiles, const float* dy, float* dw, int N, int H, int W, hipStream_t st);
+hipError_t cerb_launch_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, hipStream_t st);
+hipError_t cerb_launch_upadd_bwd(const float* dout, float* dskip, float* dprev, int G, int N, int H, int W, int C, long long prev_gs, int shared_prev, hipStream_t st);
+hipError_t cerb_launch_pointwise_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long long rows, int cin, int cout,
+                                     const float* in_scale, hipStream_t st);
+hipError_t cerb_launch_crop_gap_bwd(const float* dg, float* dx, int N, int H, int W, int C, int y0, int ch, int x0, int cw, hipStream_t st);
 hipError_t cerb_launch_maxpool(const float* in, float* out, int N, int H, int W, int C, hipStream_t st);
 hipError_t cerb_launch_head(const HeadParams& p, hipStream_t st);
 struct PatchClassParams {
@@ -141,6 +151,13 @@ struct cerb_net {
     std::vector<float*> head_rw1, head_rb1, head_rw2, head_rb2;  // raw head weights, row-major [cout][cin]
     float *pc_rw1 = nullptr, *pc_rb1 = nullptr, *pc_rw2 = nullptr, *pc_rb2 = nullptr;
     DevBuf t_mean, t_rstd, t_ws, t_hid, t_gap, t_pc1, t_idn;
+    // backward pass (cerb_net_train_grads): raw weights in state-dict layout, per conv name, groups concatenated; the tape's buffers
+    struct RawW { float* w = nullptr; float* b = nullptr; std::vector<std::string> wkeys, bkeys, bnkeys; };
+    std::map<std::string, RawW> raw;
+    std::vector<DevBuf> tape;
+    size_t tape_pos = 0;
+    std::map<std::string, std::pair<float*, long long>> grads;  // state-dict key -> (device gradient, numel) of the last cerb_net_train_grads
+    std::map<std::string, std::vector<std::string>> bn_keys;   // conv / bn name -> state-dict prefixes of its BatchNorm, one per group
     // workspace
     DevBuf x0, pool, x[5], ta, tb, cm, dmid, dsum, dout[4];
     // optional per-launch timing (HIP events on the caller's stream)
@@ -155,6 +172,7 @@ struct cerb_net {
         for (void* p : dev_allocs) (void)hipFree(p);
         x0.release(); pool.release(); ta.release(); tb.release(); cm.release(); dmid.release(); dsum.release();
         t_mean.release(); t_rstd.release(); t_ws.release(); t_hid.release(); t_gap.release(); t_pc1.release(); t_idn.release();
+        for (auto& b : tape) b.release();
         for (auto& b : x) b.release();
         for (auto& b : dout) b.release();
     }
@@ -358,6 +376,7 @@ static int store_bn(cerb_net* net, const std::string& name, const std::vector<st
     d.groups = (int)bnkeys.size();
     if (upload(net, ga, &d.gamma) || upload(net, be, &d.beta)) return 1;
     net->bn[name] = d;
+    net->bn_keys[name] = bnkeys;
     return 0;
 }
 
@@ -386,6 +405,23 @@ static int make_conv(cerb_net* net, const std::string& name, const std::vector<s
         }
     }
     if (!net->fold_bn && !bnkeys.empty() && store_bn(net, name, bnkeys, cout)) return 1;
+    if (!net->fold_bn) {  // raw copies for the backward kernels (state-dict layout [G][cout][cin][ks][ks]) and the key names of the gradients
+        std::vector<float> rw, rb;
+        for (size_t g = 0; g < wkeys.size(); ++g) {
+            const HostTensor* w;
+            if (get(net, wkeys[g], {cout, cin, ks, ks}, &w)) return 1;
+            rw.insert(rw.end(), w->data.begin(), w->data.end());
+            if (!bkeys.empty()) {
+                const HostTensor* b;
+                if (get(net, bkeys[g], {cout}, &b)) return 1;
+                rb.insert(rb.end(), b->data.begin(), b->data.end());
+            }
+        }
+        cerb_net::RawW r;
+        r.wkeys = wkeys; r.bkeys = bkeys; r.bnkeys = bnkeys;
+        if (upload(net, rw, &r.w) || (!rb.empty() && upload(net, rb, &r.b))) return 1;
+        net->raw[name] = r;
+    }
     PackedConv pc;
     pc.cin = cin; pc.cout = cout; pc.ks = ks; pc.stride = stride; pc.groups = (int)wkeys.size();
     if (upload(net, wp, &pc.w) || upload(net, bp, &pc.b)) return 1;
@@ -928,6 +964,336 @@ extern "C" int cerb_net_forward_train(cerb_net* net, const cerb_train_io* io, vo
         }
     }
     net->conv_algo = saved_algo;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One training step's gradients (models/run_desc.py:79-170: train-mode forward, the six head losses, all_loss.backward()).
+// FIRST VERSION: the forward runs on the production kernels, the backward on plain gather kernels (train_kernels.hip) -- correct
+// and reproducible, not fast.  The forward is recorded on a tape (every op keeps its input and output), the backward walks it in
+// reverse; gradients accumulate with += into zeroed buffers, so tensors with several consumers (skips, residual identities, the
+// shared conv_map output) need no special casing.  Gradients are published per state-dict key (cerb_net_grad_lookup).
+struct TapeOp {
+    int type = 0;  // 0 stem, 1 conv, 2 bn, 3 maxpool, 4 upadd, 5 pointwise, 6 crop+gap
+    std::string name;
+    int a = -1, b = -1, o = -1;        // tensor ids: input, second input (residual / prev), output
+    int N = 0, H = 0, W = 0, Cin = 0, Cout = 0, ks = 0, stride = 1, G = 1, relu = 0;
+    long long a_gs = 0, o_gs = 0, b_gs = 0, rows = 0;
+    int stat = -1;                     // bn: tensor id holding [mean | rstd]
+    const float *w = nullptr, *bias = nullptr, *scale = nullptr;
+    int y0 = 0, ch = 0, x0 = 0, cw = 0;
+    std::string wkey, bkey;            // pointwise: state-dict keys of its weight / bias
+};
+
+extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io, void* hip_stream) {
+    if (!net || !io || !io->tiles || !io->target || !io->has_target || !io->loss_out) return fail("cerb_net_train_grads: null argument");
+    if (!net->finalized || net->fold_bn) return fail("cerb_net_train_grads: needs a network packed with cerb_net_set_fold_bn(net, 0)");
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int N = io->n, H = io->h, W = io->w;
+    if (N <= 0 || H <= 0 || W <= 0 || (H % 16) || (W % 16)) return fail("cerb_net_train_grads: tile H,W must be positive multiples of 16");
+    const int hs[5] = {H, H / 2, H / 4, H / 8, H / 16}, ws[5] = {W, W / 2, W / 4, W / 8, W / 16};
+    const size_t D = net->dense_idx.size();
+    const size_t guard = cerb_conv_guard_bytes(W);
+    net->tape_pos = 0;
+    std::vector<float*> val, grd;
+    std::vector<size_t> cnt;
+    auto take = [&](size_t nfloat, bool zero) -> float* {  // next buffer of the tape arena (kept across steps)
+        if (net->tape_pos == net->tape.size()) net->tape.emplace_back();
+        DevBuf& b = net->tape[net->tape_pos++];
+        if (b.ensure(nfloat * 4, guard)) return nullptr;
+        if (zero && hipMemsetAsync(b.p, 0, nfloat * 4, st) != hipSuccess) return nullptr;
+        return b.p;
+    };
+    auto newT = [&](size_t nfloat) {
+        val.push_back(take(nfloat, false));
+        grd.push_back(nullptr);
+        cnt.push_back(nfloat);
+        return (int)val.size() - 1;
+    };
+    auto G_ = [&](int t) -> float* {  // gradient buffer of tensor t, created zeroed on first use
+        if (!grd[t]) grd[t] = take(cnt[t], true);
+        return grd[t];
+    };
+    std::vector<TapeOp> tape;
+    net->grads.clear();
+    auto pub = [&](const std::string& key, size_t n) -> float* {  // a published parameter gradient
+        float* p = take(n, true);
+        net->grads[key] = std::make_pair(p, (long long)n);
+        return p;
+    };
+    const int saved_algo = net->conv_algo;
+    if (net->conv_algo == 2) net->conv_algo = 1;
+    // ---------------------------------------------------------------- forward, recorded ----------------------------------------
+    auto conv = [&](const std::string& name, int a, int n_, int h_, int w_, long long a_gs) -> int {
+        const PackedConv& c = net->conv[name];
+        const int ho = c.stride == 2 ? h_ / 2 : h_, wo = c.stride == 2 ? w_ / 2 : w_;
+        const int o = newT((size_t)c.groups * n_ * ho * wo * c.cout);
+        if (!val[o] || run_conv(net, name, val[a], nullptr, nullptr, val[o], n_, h_, w_, 0, 0, a_gs, 0, st, nullptr)) return -1;
+        TapeOp op;
+        op.type = 1; op.name = name; op.a = a; op.o = o; op.N = n_; op.H = h_; op.W = w_; op.Cin = c.cin; op.Cout = c.cout; op.ks = c.ks; op.stride = c.stride;
+        op.G = c.groups; op.a_gs = a_gs;
+        tape.push_back(op);
+        return o;
+    };
+    auto bn = [&](const std::string& name, int y, int resid, long long rows, int relu) -> int {
+        const cerb_net::BnDev& b = net->bn[name];
+        const int z = newT(cnt[y]), stt = newT((size_t)2 * b.groups * b.C);
+        if (!val[z] || !val[stt] || net->t_ws.ensure(cerb_bn_workspace_bytes(b.groups, rows, b.C), 0)) return -1;
+        float* mean = val[stt];
+        float* rstd = val[stt] + (size_t)b.groups * b.C;
+        const long long gs = b.groups > 1 ? rows * b.C : 0;
+        if (cerb_launch_bn_stats(val[y], gs, rows, b.C, b.groups, 1e-5f, mean, rstd, nullptr, net->t_ws.p, st) != hipSuccess) return -1;
+        if (hipMemcpyAsync(val[z], val[y], cnt[y] * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
+        if (cerb_launch_bn_apply(val[z], resid >= 0 ? val[resid] : nullptr, gs, rows, b.C, b.groups, mean, rstd, b.gamma, b.beta, relu, st) != hipSuccess) return -1;
+        TapeOp op;
+        op.type = 2; op.name = name; op.a = y; op.b = resid; op.o = z; op.stat = stt; op.rows = rows; op.Cout = b.C; op.G = b.groups; op.relu = relu; op.a_gs = gs;
+        tape.push_back(op);
+        return z;
+    };
+#define TCHK(x) do { if ((x) < 0) { net->conv_algo = saved_algo; return fail(std::string("cerb_net_train_grads: ") + #x + " failed"); } } while (0)
+    const int t_stem = newT((size_t)N * H * W * 64);
+    {
+        StemParams sp;
+        sp.tiles = io->tiles; sp.wpack = net->stem_w; sp.bias = net->stem_b; sp.out = val[t_stem]; sp.N = N; sp.H = H; sp.W = W; sp.relu = 0;
+        sp.tiles_x = sp.tiles_y = 0;
+        HIP_OK(cerb_launch_stem(sp, st));
+        TapeOp op;
+        op.type = 0; op.o = t_stem; op.N = N; op.H = H; op.W = W;
+        tape.push_back(op);
+    }
+    const int x0 = bn("stem", t_stem, -1, (long long)N * H * W, 1);
+    TCHK(x0);
+    const int pool = newT((size_t)N * hs[1] * ws[1] * 64);
+    HIP_OK(cerb_launch_maxpool(val[x0], val[pool], N, H, W, 64, st));
+    {
+        TapeOp op;
+        op.type = 3; op.a = x0; op.o = pool; op.N = N; op.H = H; op.W = W; op.Cout = 64;
+        tape.push_back(op);
+    }
+    int cur = pool, inpl = 64, xs[5] = {x0, -1, -1, -1, -1};
+    for (int li = 0; li < 4; ++li) {
+        const int planes = kFilters[li + 1];
+        const int Hi = (li == 0) ? hs[1] : hs[li], Wi = (li == 0) ? ws[1] : ws[li];
+        for (int b = 0; b < kLayers[li]; ++b) {
+            const std::string p = "backbone.layer" + std::to_string(li + 1) + "." + std::to_string(b);
+            const int stride = (b == 0 && li > 0) ? 2 : 1;
+            const int hin = (b == 0) ? Hi : hs[li + 1], win = (b == 0) ? Wi : ws[li + 1];
+            const long long rows_out = (long long)N * hs[li + 1] * ws[li + 1];
+            int idt = cur;
+            const int c1 = conv(p + ".conv1", cur, N, hin, win, 0);
+            TCHK(c1);
+            const int z1 = bn(p + ".conv1", c1, -1, rows_out, 1);
+            TCHK(z1);
+            if (stride != 1 || inpl != planes) {
+                const int d = conv(p + ".downsample", cur, N, hin, win, 0);
+                TCHK(d);
+                idt = bn(p + ".downsample", d, -1, rows_out, 0);
+                TCHK(idt);
+            }
+            const int c2 = conv(p + ".conv2", z1, N, hs[li + 1], ws[li + 1], 0);
+            TCHK(c2);
+            cur = bn(p + ".conv2", c2, idt, rows_out, 1);
+            TCHK(cur);
+            inpl = planes;
+        }
+        xs[li + 1] = cur;
+    }
+    const int cm = conv("conv_map", xs[4], N, hs[4], ws[4], 0);
+    TCHK(cm);
+    std::vector<int> logit_t(net->dec.size(), -1);
+    // Patch-Class
+    if (net->pc_idx >= 0) {
+        const int ocp = net->dec[net->pc_idx].out_ch;
+        int y0 = 0, x0c = 0, ch = hs[4], cw = ws[4];
+        if (hs[4] != 9 && ws[4] != 9) {
+            auto py_slice = [](int len, int& start, int& count) {
+                const int h0 = (int)((len - 9) * 0.5);
+                const int a0 = h0 < 0 ? std::max(len + h0, 0) : std::min(h0, len);
+                const int a1 = std::min(h0 + 9, len);
+                start = a0;
+                count = std::max(a1 - a0, 0);
+            };
+            py_slice(hs[4], y0, ch);
+            py_slice(ws[4], x0c, cw);
+        }
+        const int gap = newT((size_t)N * 512);
+        HIP_OK(cerb_launch_crop_gap(val[xs[4]], N, hs[4], ws[4], 512, y0, ch, x0c, cw, val[gap], st));
+        {
+            TapeOp op;
+            op.type = 6; op.a = xs[4]; op.o = gap; op.N = N; op.H = hs[4]; op.W = ws[4]; op.Cout = 512; op.y0 = y0; op.ch = ch; op.x0 = x0c; op.cw = cw;
+            tape.push_back(op);
+        }
+        const int g1 = bn("pc.bn1", gap, -1, N, 1);
+        TCHK(g1);
+        auto pw = [&](int a, const float* w, const float* bias, long long rows, int cin, int cout, const float* scale, const std::string& wk, const std::string& bk) {
+            const int o = newT((size_t)rows * cout);
+            if (!val[o] || cerb_launch_pointwise(val[a], w, bias, val[o], rows, cin, cout, scale, st) != hipSuccess) return -1;
+            TapeOp op;
+            op.type = 5; op.a = a; op.o = o; op.rows = rows; op.Cin = cin; op.Cout = cout; op.w = w; op.bias = bias; op.scale = scale; op.wkey = wk; op.bkey = bk;
+            tape.push_back(op);
+            return o;
+        };
+        const std::string pp = "decoder_head.Patch-Class";
+        const int h1 = pw(g1, net->pc_rw1, net->pc_rb1, N, 512, 256, io->dropout_scale, pp + ".conv1.weight", pp + ".conv1.bias");
+        TCHK(h1);
+        const int h2 = bn("pc.bn2", h1, -1, N, 1);
+        TCHK(h2);
+        logit_t[net->pc_idx] = pw(h2, net->pc_rw2, net->pc_rb2, N, 256, ocp, nullptr, pp + ".conv2.weight", pp + ".conv2.bias");
+        TCHK(logit_t[net->pc_idx]);
+    }
+    if (D) {
+        const int skips[4] = {xs[3], xs[2], xs[1], xs[0]};
+        const int oc[4] = {128, 64, 64, 64};
+        int prev = cm;
+        long long prev_gs = 0;
+        for (int u = 0; u < 4; ++u) {
+            const int hh = hs[3 - u], ww = ws[3 - u];
+            const std::string n0 = "dec." + std::to_string(u) + ".0", n1 = "dec." + std::to_string(u) + ".1";
+            const int cin0 = net->conv[n0].cin;
+            const long long rows = (long long)N * hh * ww;
+            const int dsum = newT((size_t)D * rows * cin0);
+            HIP_OK(cerb_launch_upsample2_add(val[skips[u]], val[prev], val[dsum], (int)D, N, hh, ww, cin0, prev_gs, nullptr, st));
+            {
+                TapeOp op;
+                op.type = 4; op.a = skips[u]; op.b = prev; op.o = dsum; op.N = N; op.H = hh; op.W = ww; op.Cout = cin0; op.G = (int)D; op.b_gs = prev_gs;
+                tape.push_back(op);
+            }
+            const int c0 = conv(n0, dsum, N, hh, ww, rows * cin0);
+            TCHK(c0);
+            const int z0 = bn(n0, c0, -1, rows, 1);
+            TCHK(z0);
+            const int c1 = conv(n1, z0, N, hh, ww, rows * net->conv[n0].cout);
+            TCHK(c1);
+            prev = bn(n1, c1, -1, rows, 1);
+            TCHK(prev);
+            prev_gs = rows * oc[u];
+        }
+        const long long rows = (long long)N * H * W;
+        for (size_t k = 0; k < D; ++k) {
+            const int di = net->dense_idx[k];
+            const DecoderCfg& d = net->dec[di];
+            const std::string p = "output_head." + d.name + "." + d.head + ".x";
+            // the head reads decoder k's slice of the grouped tensor: a view (tensor id with its own grad slice) is the slice itself
+            const int hid = newT((size_t)rows * 96);
+            HIP_OK(cerb_launch_pointwise(val[prev] + k * (size_t)rows * 64, net->head_rw1[k], net->head_rb1[k], val[hid], rows, 64, 96, nullptr, st));
+            {
+                TapeOp op;
+                op.type = 5; op.a = prev; op.o = hid; op.rows = rows; op.Cin = 64; op.Cout = 96; op.w = net->head_rw1[k]; op.bias = net->head_rb1[k];
+                op.a_gs = (long long)k * rows * 64;  // offset of the slice inside tensor a
+                op.wkey = p + ".0.block.0.conv.weight"; op.bkey = p + ".0.block.0.conv.bias";
+                tape.push_back(op);
+            }
+            const int hz = bn("head." + std::to_string(k), hid, -1, rows, 1);
+            TCHK(hz);
+            const int lg = newT((size_t)rows * d.out_ch);
+            HIP_OK(cerb_launch_pointwise(val[hz], net->head_rw2[k], net->head_rb2[k], val[lg], rows, 96, d.out_ch, nullptr, st));
+            {
+                TapeOp op;
+                op.type = 5; op.a = hz; op.o = lg; op.rows = rows; op.Cin = 96; op.Cout = d.out_ch; op.w = net->head_rw2[k]; op.bias = net->head_rb2[k];
+                op.wkey = p + ".1.conv.weight"; op.bkey = p + ".1.conv.bias";
+                tape.push_back(op);
+            }
+            logit_t[di] = lg;
+        }
+    }
+    // ---------------------------------------------------------------- losses: d(overall) / d(logits) ------------------------------
+    for (size_t di = 0; di < net->dec.size(); ++di) {
+        const int lg = logit_t[di];
+        if (lg < 0 || !io->target[di]) continue;
+        const DecoderCfg& d = net->dec[di];
+        const bool pc = (int)di == net->pc_idx;
+        const int hh = pc ? 1 : H, ww = pc ? 1 : W, C = d.out_ch;
+        if (net->t_hid.ensure(cerb_head_loss_workspace_bytes(N, hh, ww), 0)) return fail("workspace allocation failed");
+        // NHWC logits: strides (n, c, y, x) = (h w C, 1, w C, C)
+        if (cerb_head_loss(val[lg], (long long)hh * ww * C, 1, (long long)ww * C, C, io->target[di], io->has_target[di], N, hh, ww, C,
+                           io->class_weight ? io->class_weight[di] : nullptr, io->ce_w[di], io->dice_w[di], io->head_w[di], pc ? 1 : 0, io->loss_out + di, G_(lg),
+                           net->t_hid.p, cerb_head_loss_workspace_bytes(N, hh, ww), st))
+            return 1;
+        if (io->logits && io->logits[di]) HIP_OK(hipMemcpyAsync(io->logits[di], val[lg], cnt[lg] * 4, hipMemcpyDeviceToDevice, st));
+    }
+    // ---------------------------------------------------------------- backward ------------------------------------------------------
+    for (int i = (int)tape.size() - 1; i >= 0; --i) {
+        const TapeOp& op = tape[i];
+        if (!grd[op.o]) continue;  // nothing flowed into this output (a head without target)
+        float* go = grd[op.o];
+        switch (op.type) {
+            case 0: {  // stem: weight gradient only
+                HIP_OK(cerb_launch_stem_wgrad(io->tiles, go, pub("backbone.conv1.weight", 64 * 147), N, H, W, st));
+                break;
+            }
+            case 1: {
+                const cerb_net::RawW& r = net->raw[op.name];
+                const size_t wn = (size_t)op.Cout * op.Cin * op.ks * op.ks;
+                float* dw = take(wn * op.G, true);
+                float* db = r.b ? take((size_t)op.Cout * op.G, true) : nullptr;
+                if (!dw) return fail("workspace allocation failed");
+                const bool need_dx = !(op.name == "__none__");
+                HIP_OK(cerb_launch_conv_bwd(val[op.a], go, r.w, need_dx ? G_(op.a) : nullptr, dw, db, op.G, op.N, op.H, op.W, op.Cin, op.Cout, op.ks, op.stride,
+                                            op.a_gs, st));
+                for (int g = 0; g < op.G; ++g) {
+                    net->grads[r.wkeys[g]] = std::make_pair(dw + g * wn, (long long)wn);
+                    if (db) net->grads[r.bkeys[g]] = std::make_pair(db + (size_t)g * op.Cout, (long long)op.Cout);
+                }
+                break;
+            }
+            case 2: {
+                const cerb_net::BnDev& b = net->bn[op.name];
+                float* dgb = take((size_t)2 * op.G * op.Cout, true);
+                if (!dgb || net->t_ws.ensure(cerb_bn_workspace_bytes(op.G, op.rows, op.Cout), 0)) return fail("workspace allocation failed");
+                float* dgamma = dgb;
+                float* dbeta = dgb + (size_t)op.G * op.Cout;
+                HIP_OK(cerb_launch_bn_bwd(go, val[op.o], val[op.a], G_(op.a), op.b >= 0 ? G_(op.b) : nullptr, op.a_gs, op.rows, op.Cout, op.G, val[op.stat],
+                                          val[op.stat] + (size_t)op.G * op.Cout, b.gamma, dgamma, dbeta, op.relu, net->t_ws.p, st));
+                const std::vector<std::string>& keys = net->bn_keys[op.name];
+                for (int g = 0; g < op.G; ++g) {
+                    net->grads[keys[g] + ".weight"] = std::make_pair(dgamma + (size_t)g * op.Cout, (long long)op.Cout);
+                    net->grads[keys[g] + ".bias"] = std::make_pair(dbeta + (size_t)g * op.Cout, (long long)op.Cout);
+                }
+                break;
+            }
+            case 3:
+                HIP_OK(cerb_launch_maxpool_bwd(val[op.a], go, G_(op.a), op.N, op.H, op.W, op.Cout, st));
+                break;
+            case 4: {
+                // The reference runs a decoder that is not in train_decoder_list under torch.set_grad_enabled(False) (models/net_desc.py:182), but
+                // its conv layers switch autograd back on inside themselves (models/utils/conv_layers.py:44-53): gradients then live only
+                // INSIDE each block and stop at the skip + upsample sum.  With train_step's substring test (run_desc.py:70-74) that is the
+                // fate of the "#TYPE" decoders ("Gland#TYPE" is not a substring of "Gland-TYPE"): cut their slices here.
+                const long long per_group = (long long)op.N * op.H * op.W * op.Cout;
+                if (io->decoder_trained)
+                    for (int k = 0; k < op.G; ++k)
+                        if (!io->decoder_trained[net->dense_idx[k]]) HIP_OK(hipMemsetAsync(go + k * per_group, 0, per_group * 4, st));
+                HIP_OK(cerb_launch_upadd_bwd(go, G_(op.a), G_(op.b), op.G, op.N, op.H, op.W, op.Cout, op.b_gs, op.b_gs == 0 ? 1 : 0, st));
+                break;
+            }
+            case 5: {
+                float* dw = pub(op.wkey, (size_t)op.Cin * op.Cout);
+                float* db = pub(op.bkey, (size_t)op.Cout);
+                if (!dw || !db) return fail("workspace allocation failed");
+                HIP_OK(cerb_launch_pointwise_bwd(val[op.a] + op.a_gs, go, op.w, G_(op.a) + op.a_gs, dw, db, op.rows, op.Cin, op.Cout, op.scale, st));
+                break;
+            }
+            case 6:
+                HIP_OK(cerb_launch_crop_gap_bwd(go, G_(op.a), op.N, op.H, op.W, op.Cout, op.y0, op.ch, op.x0, op.cw, st));
+                break;
+        }
+    }
+#undef TCHK
+    net->conv_algo = saved_algo;
+    return 0;
+}
+
+extern "C" int cerb_copy_d2d(void* dst, const void* src, size_t bytes, void* hip_stream) {
+    if (!dst || !src) return fail("cerb_copy_d2d: null pointer");
+    HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
+    return 0;
+}
+extern "C" int cerb_net_grad_lookup(cerb_net* net, const char* key, float** dev_ptr, long long* numel) {
+    if (!net || !key || !dev_ptr || !numel) return fail("cerb_net_grad_lookup: null argument");
+    auto it = net->grads.find(key);
+    if (it == net->grads.end()) return fail(std::string("cerb_net_grad_lookup: no gradient for ") + key);
+    *dev_ptr = it->second.first;
+    *numel = it->second.second;
     return 0;
 }
 

@@ -375,3 +375,378 @@ hipError_t cerb_launch_crop_gap(const float* x, int N, int H, int W, int C, int 
     hipLaunchKernelGGL(crop_gap_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, x, N, H, W, C, y0, ch, x0, cw, out);
     return hipGetLastError();
 }
+
+// =================================================================================================================
+// Backward pieces, FIRST VERSION (correctness against the reference's gradients; plain gather kernels, no MFMA yet -- the data
+// gradient of the 3x3 stride-1 convs is the forward Winograd kernel on rotated weights and the weight gradient a split-K MFMA GEMM in
+// the design).  Every kernel is a deterministic gather (no float atomics): bitwise reproducible.
+// Layouts: activations NHWC [G][N][H][W][C]; weights as in the state dict [G][Cout][Cin][ks][ks].
+// =================================================================================================================
+namespace {
+// ---- BatchNorm backward: dz (+ReLU mask from z) -> per-channel sum(dz), sum(dz * xhat); dy = gamma * rstd * (dz - mean(dz) - xhat * mean(dz * xhat))
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ y,
+                                                             long long group_stride, long long rows, int C, int blocks_per_group,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd, int relu,
+                                                             double* __restrict__ partial) {
+    extern __shared__ double shd[];
+    const int g = blockIdx.x / blocks_per_group, b = blockIdx.x % blocks_per_group;
+    const int tid = threadIdx.x, c = tid % C, rl = tid / C, nrl = 256 / C;  // C <= 256 here: one channel per thread (wider: loop below)
+    const long long r0 = (long long)b * BN_ROWS_PER_BLOCK, r1 = min(rows, r0 + BN_ROWS_PER_BLOCK);
+    for (int cc = c; cc < C; cc += 256) {  // C > 256 (512-channel layers): a thread walks several channels, rl = 0 only
+        double s = 0, q = 0;
+        if (rl < max(nrl, 1)) {
+            const float m = mean[g * C + cc], rs = rstd[g * C + cc];
+            for (long long r = r0 + rl; r < r1; r += max(nrl, 1)) {
+                const long long i = g * group_stride + r * C + cc;
+                float d = dz[i];
+                if (relu && !(z[i] > 0.f)) d = 0.f;
+                s += d;
+                q += (double)d * ((y[i] - m) * rs);
+            }
+        }
+        __syncthreads();
+        shd[tid * 2] = s;
+        shd[tid * 2 + 1] = q;
+        __syncthreads();
+        if (rl == 0) {
+            double ss = 0, qq = 0;
+            for (int k = 0; k < max(nrl, 1); ++k) {
+                const int t = k * C + (C <= 256 ? cc : tid);
+                if (C <= 256 || k == 0) {
+                    ss += shd[t * 2];
+                    qq += shd[t * 2 + 1];
+                }
+            }
+            double* o = partial + ((long long)blockIdx.x * C + cc) * 2;
+            o[0] = ss;
+            o[1] = qq;
+        }
+    }
+}
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int C, int blocks_per_group, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int g = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s = 0, q = 0;
+        for (int b = 0; b < blocks_per_group; ++b) {
+            const double* p = partial + ((long long)(g * blocks_per_group + b) * C + c) * 2;
+            s += p[0];
+            q += p[1];
+        }
+        dbeta[g * C + c] = (float)s;
+        dgamma[g * C + c] = (float)q;
+    }
+}
+// dy = gamma * rstd * (dzm - dbeta / M - xhat * dgamma / M); dresid += dzm (dzm = ReLU-masked dz)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ y,
+                                                           float* __restrict__ dy, float* __restrict__ dresid, long long group_stride, long long rows, int C,
+                                                           int groups, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                                           const float* __restrict__ dbeta, int relu) {
+    const long long per_group = rows * C, total = per_group * groups;
+    const float invM = 1.f / (float)rows;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i / per_group);
+        const long long j = i - (long long)g * per_group;
+        const int c = (int)(j % C);
+        const long long a = g * group_stride + j;
+        float d = dz[a];
+        if (relu && !(z[a] > 0.f)) d = 0.f;
+        if (dresid) dresid[a] += d;
+        const int gc = g * C + c;
+        const float xh = (y[a] - mean[gc]) * rstd[gc];
+        dy[a] += gamma[gc] * rstd[gc] * (d - dbeta[gc] * invM - xh * dgamma[gc] * invM);
+    }
+}
+// ---- convolution backward, gather form (any ks / stride / pad = ks / 2; groups = independent convs stacked along G) ------------------
+__global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int G, int N, int H,
+                                                         int W, int Cin, int Ho, int Wo, int Cout, int ks, int stride, long long x_gs) {
+    const int pad = ks / 2;
+    const long long per_g = (long long)N * H * W * Cin, total = per_g * G;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i / per_g);
+        long long r = i - (long long)g * per_g;
+        const int ci = (int)(r % Cin);
+        r /= Cin;
+        const int ix = (int)(r % W);
+        r /= W;
+        const int iy = (int)(r % H), n = (int)(r / H);
+        float acc = 0.f;
+        for (int ky = 0; ky < ks; ++ky) {
+            const int ty = iy + pad - ky;
+            if (ty < 0 || ty % stride) continue;
+            const int oy = ty / stride;
+            if (oy >= Ho) continue;
+            for (int kx = 0; kx < ks; ++kx) {
+                const int tx = ix + pad - kx;
+                if (tx < 0 || tx % stride) continue;
+                const int ox = tx / stride;
+                if (ox >= Wo) continue;
+                const float* d = dy + (((long long)(g * N + n) * Ho + oy) * Wo + ox) * Cout;
+                const float* ww = w + ((long long)g * Cout * Cin + ci) * ks * ks + ky * ks + kx;
+                for (int co = 0; co < Cout; ++co) acc = fmaf(d[co], ww[(long long)co * Cin * ks * ks], acc);
+            }
+        }
+        dx[g * x_gs + (i - (long long)g * per_g)] += acc;
+    }
+}
+// dW[g][co][ci][ky][kx] = sum over pixels; one block per (g, co, ci), threads = taps x pixel lanes, fixed-order reduction
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, int N, int H, int W,
+                                                         int Cin, int Ho, int Wo, int Cout, int ks, int stride, long long x_gs) {
+    __shared__ double sh[256];
+    const int pad = ks / 2, T = ks * ks;
+    const long long b = blockIdx.x;
+    const int ci = (int)(b % Cin), co = (int)((b / Cin) % Cout), g = (int)(b / ((long long)Cin * Cout));
+    const long long npix = (long long)N * Ho * Wo;
+    for (int t = 0; t < T; ++t) {
+        const int ky = t / ks, kx = t % ks;
+        double s = 0;
+        for (long long p = threadIdx.x; p < npix; p += 256) {
+            const int ox = (int)(p % Wo);
+            const long long r = p / Wo;
+            const int oy = (int)(r % Ho), n = (int)(r / Ho);
+            const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+            s += (double)dy[((long long)g * npix + p) * Cout + co] * x[g * x_gs + (((long long)n * H + iy) * W + ix) * Cin + ci];
+        }
+        __syncthreads();
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0;
+            for (int k = 0; k < 256; ++k) tot += sh[k];
+            dw[(((long long)g * Cout + co) * Cin + ci) * T + t] = (float)tot;
+        }
+    }
+}
+// per-channel sum over rows (conv bias gradient, pointwise bias gradient)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d, long long group_stride, long long rows, int C, float* __restrict__ out) {
+    __shared__ double sh[256];
+    const int c = blockIdx.x % C, g = blockIdx.x / C;
+    double s = 0;
+    for (long long r = threadIdx.x; r < rows; r += 256) s += d[g * group_stride + r * C + c];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int k = 0; k < 256; ++k) t += sh[k];
+        out[g * C + c] = (float)t;
+    }
+}
+// stem: dW[co][c][ky][kx] = sum dy[n][y][x][co] * tiles[n][y+ky-3][x+kx-3][c] / 255
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const unsigned char* __restrict__ tiles, const float* __restrict__ dy, float* __restrict__ dw, int N, int H,
+                                                         int W) {
+    __shared__ double sh[256];
+    const int b = blockIdx.x;  // ((co * 3 + c) * 7 + ky) * 7 + kx
+    const int kx = b % 7, ky = (b / 7) % 7, c = (b / 49) % 3, co = b / 147;
+    const long long npix = (long long)N * H * W;
+    double s = 0;
+    for (long long p = threadIdx.x; p < npix; p += 256) {
+        const int x = (int)(p % W);
+        const long long r = p / W;
+        const int y = (int)(r % H), n = (int)(r / H);
+        const int iy = y + ky - 3, ix = x + kx - 3;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        s += (double)dy[p * 64 + co] * ((float)tiles[(((long long)n * H + iy) * W + ix) * 3 + c] / 255.0f);
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int k = 0; k < 256; ++k) t += sh[k];
+        dw[b] = (float)t;
+    }
+}
+// max-pool 3x3 stride 2 pad 1: an input pixel collects the gradient of every window whose FIRST maximum (row-major scan, as
+// torch.nn.functional.max_pool2d records it) it is
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W,
+                                                          int C, int Ho, int Wo) {
+    const long long total = (long long)N * H * W * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int ix = (int)(r % W);
+        r /= W;
+        const int iy = (int)(r % H), n = (int)(r / H);
+        float acc = 0.f;
+        for (int oy = (iy + 1 - 2 + 1) / 2; oy <= (iy + 1) / 2; ++oy) {      // windows with oy*2-1 <= iy <= oy*2+1
+            if (oy < 0 || oy >= Ho) continue;
+            for (int ox = (ix + 1 - 2 + 1) / 2; ox <= (ix + 1) / 2; ++ox) {
+                if (ox < 0 || ox >= Wo) continue;
+                float best = -INFINITY;
+                int by = -1, bx = -1;
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int y = oy * 2 - 1 + ky;
+                    if (y < 0 || y >= H) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int xx = ox * 2 - 1 + kx;
+                        if (xx < 0 || xx >= W) continue;
+                        const float v = x[(((long long)n * H + y) * W + xx) * C + c];
+                        if (v > best || by < 0) {
+                            if (v > best || by < 0) {
+                                best = v;
+                                by = y;
+                                bx = xx;
+                            }
+                        }
+                    }
+                }
+                if (by == iy && bx == ix) acc += dy[(((long long)n * Ho + oy) * Wo + ox) * C + c];
+            }
+        }
+        dx[i] += acc;
+    }
+}
+// out_g = skip + up2(prev_g):  dskip += sum_g dout_g;  dprev_g = transpose of the bilinear x2 (align_corners = False) applied to dout_g
+__global__ __launch_bounds__(256) void upadd_bwd_skip_kernel(const float* __restrict__ dout, float* __restrict__ dskip, int G, long long per_group) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < per_group; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int g = 0; g < G; ++g) s += dout[g * per_group + i];
+        dskip[i] += s;
+    }
+}
+__device__ __forceinline__ void up2_taps(int o, int n_src, int& i0, int& i1, float& w0, float& w1) {  // output index o -> sources and weights
+    const int bm = (o + 1) / 2 - 1;  // o = 2 bm + 1 or 2 bm + 2
+    i0 = max(bm, 0);
+    i1 = min(bm + 1, n_src - 1);
+    if (o == 2 * bm + 1) { w0 = 0.75f; w1 = 0.25f; } else { w0 = 0.25f; w1 = 0.75f; }
+}
+__global__ __launch_bounds__(256) void upadd_bwd_prev_kernel(const float* __restrict__ dout, float* __restrict__ dprev, int G, int N, int H, int W, int C,
+                                                             long long prev_gs, int shared_prev) {
+    const int Hp = H / 2, Wp = W / 2;
+    const long long per_g = (long long)N * Hp * Wp * C, total = shared_prev ? per_g : per_g * G;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int g = shared_prev ? 0 : (int)(i / per_g);
+        long long r = i - (long long)g * per_g;
+        const int c = (int)(r % C);
+        r /= C;
+        const int pn = (int)(r % Wp);
+        r /= Wp;
+        const int pm = (int)(r % Hp), n = (int)(r / Hp);
+        float acc = 0.f;
+        for (int gg = shared_prev ? 0 : g; gg < (shared_prev ? G : g + 1); ++gg)
+            for (int y = max(2 * pm - 2, 0); y <= min(2 * pm + 2, H - 1); ++y) {
+                int a0, a1;
+                float u0, u1;
+                up2_taps(y, Hp, a0, a1, u0, u1);
+                const float wy = (a0 == pm ? u0 : 0.f) + (a1 == pm ? u1 : 0.f);
+                if (wy == 0.f) continue;
+                for (int x = max(2 * pn - 2, 0); x <= min(2 * pn + 2, W - 1); ++x) {
+                    int b0, b1;
+                    float v0, v1;
+                    up2_taps(x, Wp, b0, b1, v0, v1);
+                    const float wx = (b0 == pn ? v0 : 0.f) + (b1 == pn ? v1 : 0.f);
+                    if (wx == 0.f) continue;
+                    acc += wy * wx * dout[((((long long)gg * N + n) * H + y) * W + x) * C + c];
+                }
+            }
+        dprev[(shared_prev ? 0 : g * prev_gs) + (i - (long long)g * per_g)] += acc;
+    }
+}
+// pointwise (1x1) backward: dx[r][ci] += scale * sum_co dy[r][co] W[co][ci];  dW[co][ci] = sum_r dy[r][co] x[r][ci] scale
+__global__ __launch_bounds__(256) void pointwise_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, long long rows, int cin,
+                                                              int cout, const float* __restrict__ in_scale) {
+    const long long total = rows * cin;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / cin;
+        const int ci = (int)(i % cin);
+        float acc = 0.f;
+        for (int co = 0; co < cout; ++co) acc = fmaf(dy[r * cout + co], w[(long long)co * cin + ci], acc);
+        dx[i] += in_scale ? acc * in_scale[i] : acc;
+    }
+}
+__global__ __launch_bounds__(256) void pointwise_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, long long rows, int cin,
+                                                              int cout, const float* __restrict__ in_scale) {
+    __shared__ double sh[256];
+    const int ci = blockIdx.x % cin, co = blockIdx.x / cin;
+    double s = 0;
+    for (long long r = threadIdx.x; r < rows; r += 256) {
+        float xv = x[r * cin + ci];
+        if (in_scale) xv *= in_scale[r * cin + ci];
+        s += (double)dy[r * cout + co] * xv;
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int k = 0; k < 256; ++k) t += sh[k];
+        dw[(long long)co * cin + ci] = (float)t;
+    }
+}
+__global__ void crop_gap_bwd_kernel(const float* __restrict__ dg, float* __restrict__ dx, int N, int H, int W, int C, int y0, int ch, int x0, int cw) {
+    const long long total = (long long)N * ch * cw * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int x = (int)(r % cw);
+        r /= cw;
+        const int y = (int)(r % ch), n = (int)(r / ch);
+        dx[(((long long)n * H + y0 + y) * W + x0 + x) * C + c] += dg[n * C + c] / (float)(ch * cw);
+    }
+}
+// Adam (torch.optim.Adam, no weight decay / amsgrad; models/opt.py:47-58): one launch per parameter tensor in this first version
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n, float lr, float b1,
+                            float b2, float eps, float bc1, float bc2) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = v[i] = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        p[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+static unsigned gridfor(long long n) {
+    long long b = (n + 255) / 256;
+    if (b > 256 * 32) b = 256 * 32;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+}  // namespace
+
+hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, float* dy, float* dresid, long long group_stride, long long rows, int C, int groups,
+                              const float* mean, const float* rstd, const float* gamma, float* dgamma, float* dbeta, int relu, void* ws, hipStream_t st) {
+    const int bpg = (int)((rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(groups * bpg), dim3(256), 256 * 2 * sizeof(double), st, dz, z, y, group_stride, rows, C, bpg, mean, rstd, relu,
+                       (double*)ws);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(groups), dim3(256), 0, st, (const double*)ws, C, bpg, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gridfor(rows * C * groups)), dim3(256), 0, st, dz, z, y, dy, dresid, group_stride, rows, C, groups, mean, rstd,
+                       gamma, dgamma, dbeta, relu);
+    return hipGetLastError();
+}
+hipError_t cerb_launch_conv_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int G, int N, int H, int W, int Cin, int Cout,
+                                int ks, int stride, long long x_gs, hipStream_t st) {
+    const int Ho = stride == 2 ? H / 2 : H, Wo = stride == 2 ? W / 2 : W;
+    if (dx) hipLaunchKernelGGL(conv_dgrad_kernel, dim3(gridfor((long long)G * N * H * W * Cin)), dim3(256), 0, st, dy, w, dx, G, N, H, W, Cin, Ho, Wo, Cout, ks, stride, x_gs);
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)((long long)G * Cout * Cin)), dim3(256), 0, st, x, dy, dw, N, H, W, Cin, Ho, Wo, Cout, ks, stride, x_gs);
+    if (db) hipLaunchKernelGGL(colsum_kernel, dim3(G * Cout), dim3(256), 0, st, dy, (long long)N * Ho * Wo * Cout, (long long)N * Ho * Wo, Cout, db);
+    return hipGetLastError();
+}
+hipError_t cerb_launch_stem_wgrad(const unsigned char* tiles, const float* dy, float* dw, int N, int H, int W, hipStream_t st) {
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(64 * 147), dim3(256), 0, st, tiles, dy, dw, N, H, W);
+    return hipGetLastError();
+}
+hipError_t cerb_launch_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, hipStream_t st) {
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(gridfor((long long)N * H * W * C)), dim3(256), 0, st, x, dy, dx, N, H, W, C, H / 2, W / 2);
+    return hipGetLastError();
+}
+hipError_t cerb_launch_upadd_bwd(const float* dout, float* dskip, float* dprev, int G, int N, int H, int W, int C, long long prev_gs, int shared_prev, hipStream_t st) {
+    hipLaunchKernelGGL(upadd_bwd_skip_kernel, dim3(gridfor((long long)N * H * W * C)), dim3(256), 0, st, dout, dskip, G, (long long)N * H * W * C);
+    hipLaunchKernelGGL(upadd_bwd_prev_kernel, dim3(gridfor((long long)N * (H / 2) * (W / 2) * C * (shared_prev ? 1 : G))), dim3(256), 0, st, dout, dprev, G, N, H, W, C,
+                       prev_gs, shared_prev);
+    return hipGetLastError();
+}
+hipError_t cerb_launch_pointwise_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long long rows, int cin, int cout,
+                                     const float* in_scale, hipStream_t st) {
+    if (dx) hipLaunchKernelGGL(pointwise_dgrad_kernel, dim3(gridfor(rows * cin)), dim3(256), 0, st, dy, w, dx, rows, cin, cout, in_scale);
+    hipLaunchKernelGGL(pointwise_wgrad_kernel, dim3(cin * cout), dim3(256), 0, st, x, dy, dw, rows, cin, cout, in_scale);
+    if (db) hipLaunchKernelGGL(colsum_kernel, dim3(cout), dim3(256), 0, st, dy, 0ll, rows, cout, db);
+    return hipGetLastError();
+}
+hipError_t cerb_launch_crop_gap_bwd(const float* dg, float* dx, int N, int H, int W, int C, int y0, int ch, int x0, int cw, hipStream_t st) {
+    hipLaunchKernelGGL(crop_gap_bwd_kernel, dim3(gridfor((long long)N * ch * cw * C)), dim3(256), 0, st, dg, dx, N, H, W, C, y0, ch, x0, cw);
+    return hipGetLastError();
+}
+hipError_t cerb_launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step, hipStream_t st) {
+    const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(gridfor(n)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2);
+    return hipGetLastError();
+}

@@ -181,6 +181,70 @@ class NetDesc(torch.nn.Module):
             _lib.check(_lib.lib().cerb_net_forward_train(h, C.byref(io), C.c_void_p(stream)))
         return res
 
+    def train_grads(self, tiles_u8, targets, has_target, loss_opts, dropout_keep=None):
+        """One step of the reference's train_step up to all_loss.backward() (models/run_desc.py:79-170): train-mode forward, the head
+        losses, the backward pass.  targets: head key -> CUDA float [N, H, W] class ids ([N] for Patch-Class); has_target: head key ->
+        CUDA float [N]; loss_opts: the reference's loss_kwargs (cerberus_amd.losses.PARAMSET_LOSS).
+        -> (losses: head key -> float as train_step reports them, grads: state-dict key -> CUDA float tensor shaped like the parameter).
+        First version: the backward pass runs on plain gather kernels (correct and reproducible, not tuned)."""
+        self.train(True)
+        h = self._ensure_handle()
+        L = _lib.lib()
+        tiles_u8 = tiles_u8.contiguous()
+        n, hh, ww, _ = [int(v) for v in tiles_u8.shape]
+        nd = len(self._decoders)
+        dev = tiles_u8.device
+        keep = []
+        tg, fl, cw = (C.c_void_p * nd)(), (C.c_void_p * nd)(), (C.c_void_p * nd)()
+        ce, dc, hw = (C.c_float * nd)(), (C.c_float * nd)(), (C.c_float * nd)()
+        for i, (name, hname, och, key) in enumerate(self._decoders):
+            if key not in targets:
+                continue
+            t = targets[key].to(dev).float().contiguous()
+            f = has_target[key].to(dev).float().contiguous()
+            keep += [t, f]
+            tg[i], fl[i] = t.data_ptr(), f.data_ptr()
+            info = loss_opts["loss_info"][key]
+            ce[i], dc[i], hw[i] = float(info["loss"].get("ce", 0)), float(info["loss"].get("dice", 0)), float(info["weight"])
+            if key in loss_opts.get("class_weight", {}):
+                w = torch.arange(och, dtype=torch.float32)
+                for k, v in loss_opts["class_weight"][key].items():
+                    w[int(k)] = float(v)
+                w = w.to(dev)
+                keep.append(w)
+                cw[i] = w.data_ptr()
+        loss = torch.zeros(nd, dtype=torch.float32, device=dev)
+        io = _lib.TrainStepIO()
+        io.tiles = tiles_u8.data_ptr()
+        io.n, io.h, io.w = n, hh, ww
+        if dropout_keep is not None:
+            scale = (dropout_keep.to(dev).reshape(n, 512).float() / (1.0 - 0.3)).contiguous()
+            keep.append(scale)
+            io.dropout_scale = scale.data_ptr()
+        io.target, io.has_target, io.class_weight, io.ce_w, io.dice_w, io.head_w = tg, fl, cw, ce, dc, hw
+        io.loss_out = loss.data_ptr()
+        # train_step's rule (models/run_desc.py:64-74): a decoder trains when its NAME is a substring of a target name that at least one
+        # sample carries -- "Gland#TYPE" is not a substring of "Gland-TYPE", so the #TYPE decoders only ever train inside their blocks
+        present = [k for k in targets if bool((has_target[k] > 0).any())]
+        trained = (C.c_int * nd)(*[int(any(name in t for t in present)) for name, _, _, _ in self._decoders])
+        io.decoder_trained = trained
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(L.cerb_net_train_grads(h, C.byref(io), C.c_void_p(stream)))
+            grads = OrderedDict()
+            for k, v in self._sd.items():
+                if v.dtype != torch.float32 or k.endswith("running_mean") or k.endswith("running_var") or k.startswith("backbone.fc."):
+                    continue
+                ptr, numel = C.c_void_p(), C.c_longlong()
+                _lib.check(L.cerb_net_grad_lookup(h, k.encode(), C.byref(ptr), C.byref(numel)))
+                assert numel.value == v.numel(), (k, numel.value, v.numel())
+                g = torch.empty(v.shape, dtype=torch.float32, device=dev)
+                _lib.check(L.cerb_copy_d2d(g.data_ptr(), ptr, 4 * v.numel(), C.c_void_p(stream)))
+                grads[k] = g
+        torch.cuda.synchronize(dev)
+        losses = OrderedDict((key, float(loss[i])) for i, (_, _, _, key) in enumerate(self._decoders) if key in targets)
+        return losses, grads
+
     def flops(self, n, h, w):
         return float(_lib.lib().cerb_net_flops(self._ensure_handle(), n, h, w))
 

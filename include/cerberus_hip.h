@@ -208,6 +208,35 @@ typedef struct cerb_train_io {
 int cerb_net_set_fold_bn(cerb_net* net, int fold);
 int cerb_net_forward_train(cerb_net* net, const cerb_train_io* io, void* hip_stream);
 
+/* cerb_net_train_grads: train-mode forward + the head losses + the backward pass of one step (models/run_desc.py:79-170 up to
+ * all_loss.backward()), for a network packed with cerb_net_set_fold_bn(net, 0).  FIRST VERSION: the backward runs on plain gather
+ * kernels -- correct against the reference's gradients and bitwise reproducible, not tuned.  Arrays are per decoder in
+ * cerb_net_create order; a decoder whose target pointer is NULL contributes no loss.
+ *   target[d]       : device float [n][h][w] class ids (Patch-Class: [n])          has_target[d] : device float [n]
+ *   class_weight[d] : device float [out_ch] or NULL (see cerb_head_loss)           ce_w / dice_w / head_w : host floats
+ *   loss_out        : device float [n_decoders], the value train_step reports per head (0 where no target was given)
+ *   logits          : optional, as in cerb_train_io
+ * Gradients are then read per state-dict key with cerb_net_grad_lookup (device pointer valid until the next call). */
+typedef struct cerb_train_step_io {
+    const uint8_t* tiles;
+    int n, h, w;
+    const float* dropout_scale;
+    const float* const* target;
+    const float* const* has_target;
+    const float* const* class_weight;
+    const float* ce_w;
+    const float* dice_w;
+    const float* head_w;
+    float* loss_out;
+    float* const* logits;
+    const int* decoder_trained;  /* host int per decoder or NULL (= all): 0 reproduces a decoder outside train_decoder_list, whose
+                                    gradients stay inside each of its blocks (models/net_desc.py:182 + conv_layers.py:44-53) */
+} cerb_train_step_io;
+int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io, void* hip_stream);
+int cerb_net_grad_lookup(cerb_net* net, const char* key, float** dev_ptr, long long* numel);
+/* device-to-device copy on a stream (lets a host language without a HIP binding move a looked-up gradient into its own buffer) */
+int cerb_copy_d2d(void* dst, const void* src, size_t bytes, void* hip_stream);
+
 /* ---- training step, first piece (BASELINE.json configs[4]; NOT a training step yet) --------------------------------------------
  * cerb_head_loss: the per-head loss of the reference's train_step (models/run_desc.py:88-170) and its gradient on the logits.
  *   logits / dlogits : device float, element strides (n, c, y, x) -- NCHW as the reference's forward returns them, or NHWC

@@ -99,3 +99,48 @@ def test_train_mode_forward_vs_reference_train_step(gold):
     e.infer_tiles(tiles, 64)
     with pytest.raises(CerberusHipError):
         e.train()
+
+
+def test_backward_pass_vs_reference_train_step(gold):
+    """cerb_net_train_grads: the gradient of EVERY parameter (309 tensors) after train-mode forward + losses + backward against what
+    `all_loss.backward()` left in the reference's own train_step -- per tensor the sum, the absolute sum and three sampled elements
+    (oracle/gen_golden_train_loss.py stores those statistics instead of 113 MB of gradients)."""
+    from cerberus_amd.net_desc import create_model
+    from cerberus_amd.weights import default_model_kwargs, make_state_dict
+
+    m = create_model(**default_model_kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(int(gold["weight_seed"])).items()}, strict=True)
+    tiles = torch.from_numpy(gold["img"]).cuda()
+    keep = torch.from_numpy(gold["step/dropout_mask"].reshape(int(gold["N"]), 512)).cuda()
+    targets, flags = {}, {}
+    for j, h in enumerate(gold["heads"]):
+        h = str(h)
+        t = gold["target/" + h][..., 0]
+        targets[h] = torch.from_numpy(t.reshape(t.shape[0]) if h == "Patch-Class" else t).cuda()
+        flags[h] = torch.from_numpy(gold["has_target"][:, j].astype(np.float32)).cuda()
+    losses, grads = m.train_grads(tiles, targets, flags, PARAMSET_LOSS, keep)
+    for h in targets:
+        exp = float(gold["paramset/loss/" + h])
+        assert abs(losses[h] - exp) <= 1e-4 * max(1.0, abs(exp)), (h, losses[h], exp)
+    names = [str(x) for x in gold["step/param_names"]]
+    stats = gold["step/grad_stats"]
+    assert set(n for n in names if not n.startswith("backbone.fc.")) == set(grads.keys())  # fc exists but is never called: no gradient
+    worst = 0.0
+    for k, (s_sum, s_abs, e0, em, e1) in zip(names, stats):
+        if k.startswith("backbone.fc."):
+            assert s_abs == 0.0
+            continue
+        g = grads[k].double().flatten().cpu().numpy()
+        # yardsticks: the tensor's absolute sum, with a floor for gradients that are mathematically zero -- the bias of a conv in front
+        # of a BatchNorm -- where both sides hold rounding noise (1e-6 .. 1e-7 in the reference, less here)
+        floor_ = 1e-3 * g.size ** 0.5
+        ref_abs = max(s_abs, floor_)
+        per_el = ref_abs / g.size
+        err = max(abs(g.sum() - s_sum) / ref_abs, abs(np.abs(g).sum() - s_abs) / ref_abs, abs(g[0] - e0) / (50 * per_el + abs(e0)),
+                  abs(g[g.size // 2] - em) / (50 * per_el + abs(em)), abs(g[-1] - e1) / (50 * per_el + abs(e1)))
+        worst = max(worst, err)
+        assert err < 2e-3, (k, err, g.sum(), s_sum, np.abs(g).sum(), s_abs, g[0], e0)
+    # the reference's train_decoder_list quirk: the #TYPE decoders get gradients only inside their last block and head
+    assert float(grads["decoder_head.Gland#TYPE.0.block.0.conv.weight"].abs().sum()) == 0.0
+    assert float(grads["decoder_head.Gland#TYPE.3.block.0.conv.weight"].abs().sum()) > 0.0
+    print("worst relative gradient-statistic error over %d tensors: %.2e" % (len(names), worst))
