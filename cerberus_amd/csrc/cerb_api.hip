@@ -51,6 +51,7 @@ hipError_t cerb_launch_upadd_bwd(const float* dout, float* dskip, float* dprev, 
 hipError_t cerb_launch_pointwise_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long long rows, int cin, int cout,
                                      const float* in_scale, hipStream_t st);
 hipError_t cerb_launch_crop_gap_bwd(const float* dg, float* dx, int N, int H, int W, int C, int y0, int ch, int x0, int cw, hipStream_t st);
+hipError_t cerb_launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step, hipStream_t st);
 hipError_t cerb_launch_maxpool(const float* in, float* out, int N, int H, int W, int C, hipStream_t st);
 hipError_t cerb_launch_head(const HeadParams& p, hipStream_t st);
 struct PatchClassParams {
@@ -1042,7 +1043,15 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         float* mean = val[stt];
         float* rstd = val[stt] + (size_t)b.groups * b.C;
         const long long gs = b.groups > 1 ? rows * b.C : 0;
-        if (cerb_launch_bn_stats(val[y], gs, rows, b.C, b.groups, 1e-5f, mean, rstd, nullptr, net->t_ws.p, st) != hipSuccess) return -1;
+        float* var_u = take((size_t)b.groups * b.C, false);  // unbiased batch variance: what the running_var update uses
+        if (!var_u || cerb_launch_bn_stats(val[y], gs, rows, b.C, b.groups, 1e-5f, mean, rstd, var_u, net->t_ws.p, st) != hipSuccess) return -1;
+        {
+            const std::vector<std::string>& keys = net->bn_keys[name];
+            for (int g = 0; g < b.groups; ++g) {
+                net->grads[keys[g] + ".batch_mean"] = std::make_pair(mean + (size_t)g * b.C, (long long)b.C);
+                net->grads[keys[g] + ".batch_var"] = std::make_pair(var_u + (size_t)g * b.C, (long long)b.C);
+            }
+        }
         if (hipMemcpyAsync(val[z], val[y], cnt[y] * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
         if (cerb_launch_bn_apply(val[z], resid >= 0 ? val[resid] : nullptr, gs, rows, b.C, b.groups, mean, rstd, b.gamma, b.beta, relu, st) != hipSuccess) return -1;
         TapeOp op;
@@ -1283,6 +1292,12 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
     return 0;
 }
 
+extern "C" int cerb_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long numel, float lr, float beta1, float beta2,
+                              float eps, int step, void* hip_stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || numel < 0 || step < 1) return fail("cerb_adam_step: bad arguments");
+    HIP_OK(cerb_launch_adam(param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, step, (hipStream_t)hip_stream));
+    return 0;
+}
 extern "C" int cerb_copy_d2d(void* dst, const void* src, size_t bytes, void* hip_stream) {
     if (!dst || !src) return fail("cerb_copy_d2d: null pointer");
     HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));

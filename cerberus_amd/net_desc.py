@@ -185,7 +185,8 @@ class NetDesc(torch.nn.Module):
         """One step of the reference's train_step up to all_loss.backward() (models/run_desc.py:79-170): train-mode forward, the head
         losses, the backward pass.  targets: head key -> CUDA float [N, H, W] class ids ([N] for Patch-Class); has_target: head key ->
         CUDA float [N]; loss_opts: the reference's loss_kwargs (cerberus_amd.losses.PARAMSET_LOSS).
-        -> (losses: head key -> float as train_step reports them, grads: state-dict key -> CUDA float tensor shaped like the parameter).
+        -> (losses: head key -> float as train_step reports them, grads: state-dict key -> CUDA float tensor shaped like the parameter;
+        under the keys of the BatchNorm buffers (running_mean / running_var) it holds the step's batch mean / unbiased batch variance).
         First version: the backward pass runs on plain gather kernels (correct and reproducible, not tuned)."""
         self.train(True)
         h = self._ensure_handle()
@@ -233,10 +234,15 @@ class NetDesc(torch.nn.Module):
             _lib.check(L.cerb_net_train_grads(h, C.byref(io), C.c_void_p(stream)))
             grads = OrderedDict()
             for k, v in self._sd.items():
-                if v.dtype != torch.float32 or k.endswith("running_mean") or k.endswith("running_var") or k.startswith("backbone.fc."):
+                if v.dtype != torch.float32 or k.startswith("backbone.fc."):
                     continue
+                lk = k
+                if k.endswith("running_mean"):  # the batch statistics behind the running-statistics update, under the buffer's own key
+                    lk = k[: -len("running_mean")] + "batch_mean"
+                elif k.endswith("running_var"):
+                    lk = k[: -len("running_var")] + "batch_var"
                 ptr, numel = C.c_void_p(), C.c_longlong()
-                _lib.check(L.cerb_net_grad_lookup(h, k.encode(), C.byref(ptr), C.byref(numel)))
+                _lib.check(L.cerb_net_grad_lookup(h, lk.encode(), C.byref(ptr), C.byref(numel)))
                 assert numel.value == v.numel(), (k, numel.value, v.numel())
                 g = torch.empty(v.shape, dtype=torch.float32, device=dev)
                 _lib.check(L.cerb_copy_d2d(g.data_ptr(), ptr, 4 * v.numel(), C.c_void_p(stream)))
@@ -244,6 +250,13 @@ class NetDesc(torch.nn.Module):
         torch.cuda.synchronize(dev)
         losses = OrderedDict((key, float(loss[i])) for i, (_, _, _, key) in enumerate(self._decoders) if key in targets)
         return losses, grads
+
+    def load_updated_parameters(self, dev_params):
+        """After an optimiser step: take the updated parameters (key -> CUDA tensor) into the state dict and drop the device handle, which
+        is re-packed on the next use (first version: the packing runs on the host)."""
+        for k, v in dev_params.items():
+            self._sd[k] = v.detach().cpu().clone()
+        self._release()
 
     def flops(self, n, h, w):
         return float(_lib.lib().cerb_net_flops(self._ensure_handle(), n, h, w))

@@ -1,0 +1,103 @@
+"""Mirror of the reference's train_step (models/run_desc.py:25-230) on the GPU: train-mode forward, the six head losses, the backward
+pass, Adam (models/opt.py:47-58) and the BatchNorm running statistics -- BASELINE configs[4].  FIRST VERSION: every piece is checked
+against the reference's own train_step (tests/test_train_loss_gpu.py), none of the backward kernels is tuned, and the updated weights
+are re-packed by rebuilding the device handle (cerb_net_finalize on the host) -- seconds per step, see DESIGN.md par.9.
+
+Multi-GPU: one process per GPU, `allreduce_grads` averages the gradients over ranks in buckets (backend "nccl" = RCCL over xGMI,
+113.5 MB per step) between the backward pass and the optimiser -- the DistributedDataParallel arithmetic of a reference that only
+has DataParallel (infer/base.py:46; it ships no training launcher)."""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class Adam(object):
+    """torch.optim.Adam's state and arithmetic (no weight decay, no amsgrad) over a state dict of CUDA tensors."""
+
+    def __init__(self, lr=1.0e-3, betas=(0.9, 0.999), eps=1.0e-8):
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.step_count = 0
+        self.state = {}
+
+    def step(self, params, grads):
+        """params / grads: key -> CUDA float tensor (contiguous); params are updated in place."""
+        L = _lib.lib()
+        self.step_count += 1
+        for k, g in grads.items():
+            p = params[k]
+            if k not in self.state:
+                self.state[k] = (torch.zeros_like(p), torch.zeros_like(p))
+            m, v = self.state[k]
+            st = torch.cuda.current_stream(p.device).cuda_stream
+            with torch.cuda.device(p.device):
+                _lib.check(L.cerb_adam_step(p.data_ptr(), g.contiguous().data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), self.lr, self.betas[0], self.betas[1],
+                                            self.eps, self.step_count, C.c_void_p(st)))
+
+
+def allreduce_grads(grads, dist, world_size, bucket_bytes=32 << 20):
+    """Average gradients over ranks in flat buckets (a ring all-reduce over xGMI is bound per link: few large messages beat 300 small
+    ones).  grads: key -> tensor (any device); in place.  dist: torch.distributed or None."""
+    if dist is None or world_size == 1:
+        return
+    keys, bucket, size = list(grads.keys()), [], 0
+
+    def flush():
+        if not bucket:
+            return
+        flat = torch.cat([grads[k].reshape(-1) for k in bucket])
+        dist.all_reduce(flat)
+        flat /= world_size
+        o = 0
+        for k in bucket:
+            n = grads[k].numel()
+            grads[k].copy_(flat[o:o + n].view_as(grads[k]))
+            o += n
+
+    for k in keys:
+        bucket.append(k)
+        size += grads[k].numel() * 4
+        if size >= bucket_bytes:
+            flush()
+            bucket, size = [], 0
+    flush()
+
+
+def train_step(batch_data, run_info, dist=None, world_size=1, dropout_keep=None):
+    """batch_data: {'img': uint8 [N, H, W, 3], 'dummy_target': object array [N, B] of head names / None, '<head>': [N, H, W, 1] class
+    ids, ...}; run_info: ({'net': {'desc': NetDesc, 'optimizer': cerberus_amd.train.Adam, 'extra_info': {'loss': loss_kwargs}}}, state)
+    -- the reference's protocol (models/run_desc.py:25-60).  Returns {'EMA': {'<head>_loss': ..., 'overall_loss': ...}}."""
+    run_info, _ = run_info
+    model, opt = run_info["net"]["desc"], run_info["net"]["optimizer"]
+    loss_opts = run_info["net"]["extra_info"]["loss"]
+    batch = dict(batch_data)
+    img = batch.pop("img")
+    has = batch.pop("dummy_target")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    targets, flags = OrderedDict(), OrderedDict()
+    for k, v in batch.items():
+        if "#WEIGHT-MAP" in k:
+            raise NotImplementedError("per-pixel weight maps (%s) are not on the HIP path yet" % k)
+        t = torch.as_tensor(v).float()
+        targets[k] = (t.reshape(t.shape[0]) if k == "Patch-Class" else t.reshape(t.shape[0], t.shape[1], t.shape[2])).to(dev)
+        flags[k] = torch.from_numpy(np.any(np.asarray(has) == k, axis=-1).astype(np.float32)).to(dev)
+    if dropout_keep is None and "Patch-Class" in targets:  # nn.Dropout(p=0.3) of the Patch-Class branch (models/net_desc.py:70)
+        dropout_keep = torch.rand((img.shape[0], 512), device=dev) >= 0.3
+    losses, grads = model.train_grads(torch.as_tensor(img).to(dev), targets, flags, loss_opts, dropout_keep)
+    buf_keys = [k for k in grads if k.endswith("running_mean") or k.endswith("running_var")]
+    stats = OrderedDict((k, grads.pop(k)) for k in buf_keys)
+    allreduce_grads(grads, dist, world_size)
+    # parameters live in the model's state dict (host); the optimiser works on device copies that persist across steps
+    if not hasattr(model, "_dev_params"):
+        model._dev_params = OrderedDict((k, v.to(dev).clone()) for k, v in model._sd.items() if v.dtype == torch.float32)
+    opt.step(model._dev_params, grads)
+    for k, s in stats.items():  # running = 0.9 running + 0.1 batch (torch BatchNorm momentum 0.1; the variance is the unbiased one)
+        model._dev_params[k].mul_(0.9).add_(s.reshape(model._dev_params[k].shape), alpha=0.1)
+    torch.cuda.synchronize(dev)
+    model.load_updated_parameters(model._dev_params)
+    ema = OrderedDict(("%s_loss" % k, v) for k, v in losses.items())
+    ema["overall_loss"] = float(sum(losses.values()))
+    return {"EMA": ema}

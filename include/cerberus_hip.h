@@ -234,6 +234,11 @@ typedef struct cerb_train_step_io {
 } cerb_train_step_io;
 int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io, void* hip_stream);
 int cerb_net_grad_lookup(cerb_net* net, const char* key, float** dev_ptr, long long* numel);
+/* The same lookup also serves the batch statistics of every BatchNorm of the step under "<bn prefix>.batch_mean" and
+ * "<bn prefix>.batch_var" (unbiased), from which the caller updates running_mean / running_var (momentum 0.1).
+ * cerb_adam_step: torch.optim.Adam (no weight decay / amsgrad; models/opt.py:47-58) on one parameter tensor, in place; `step` counts from 1. */
+int cerb_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long numel, float lr, float beta1,
+                   float beta2, float eps, int step, void* hip_stream);
 /* device-to-device copy on a stream (lets a host language without a HIP binding move a looked-up gradient into its own buffer) */
 int cerb_copy_d2d(void* dst, const void* src, size_t bytes, void* hip_stream);
 

@@ -299,3 +299,42 @@ def test_dat_writer_is_readable_by_joblib_and_uuids_are_version_4(tmp_path):
     assert list(back["Nuclei"].keys()) == list(obj["Nuclei"].keys()) and back["proc_dimensions"].tolist() == [7, 9]
     d = back["Nuclei"][ids[7]]
     assert d["box"].tolist() == [7, 8, 9, 10] and d["contour"].dtype == np.int32 and d["type"] == 3
+
+
+def _allreduce_worker(rank, world, port, ret):
+    import torch.distributed as dist
+
+    from cerberus_amd.train import allreduce_grads
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rs = np.random.RandomState(0)
+    shapes = [(64, 3, 7, 7), (64,), (128, 64, 3, 3), (9,), (256, 512, 1, 1), (1,)]
+    base = [rs.randn(*s).astype(np.float32) for s in shapes]
+    grads = {"p%d" % i: torch.from_numpy(b * (rank + 1)) for i, b in enumerate(base)}  # rank r holds (r + 1) * base
+    allreduce_grads(grads, dist, world, bucket_bytes=40000)  # several buckets, one of them closed by a single large tensor
+    mean_factor = sum(range(1, world + 1)) / world
+    ok = all(np.allclose(grads["p%d" % i].numpy(), b * mean_factor, rtol=1e-6, atol=1e-7) and tuple(grads["p%d" % i].shape) == shapes[i]
+             for i, b in enumerate(base))
+    if rank == 0:
+        ret.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bucketed_gradient_allreduce_gloo(world):
+    """cerberus_amd.train.allreduce_grads (the data-parallel step of BASELINE configs[4]: gradients averaged over ranks in flat buckets;
+    RCCL on the GPU box, gloo here)."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_allreduce_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=10) is True
