@@ -122,6 +122,7 @@ struct PackedConv {
     int cin = 0, cout = 0, ks = 0, stride = 1, groups = 1;
     float* w = nullptr;     // device
     float* wino = nullptr;  // device, 3x3 stride-1 only: Winograd F(2x2,3x3) transformed weights (conv_wino.hip)
+    float* wino_dgrad = nullptr;  // train packing only: the same for the DATA GRADIENT -- the conv with rotated, transposed weights
     void* wino3 = nullptr;  // device, same weights split into three bf16 planes (conv_wino3.hip, conv_algo 2), packed lazily
     std::vector<float> host_u;  // fp32 transformed weights kept on the host until conv_algo 2 is first used
     float* b = nullptr;     // device
@@ -157,6 +158,7 @@ struct cerb_net {
     std::map<std::string, RawW> raw;
     std::vector<DevBuf> tape;
     size_t tape_pos = 0;
+    float* zero_bias = nullptr;  // 512 zeros: the bias operand of the data-gradient convs
     std::map<std::string, std::pair<float*, long long>> grads;  // state-dict key -> (device gradient, numel) of the last cerb_net_train_grads
     std::map<std::string, std::vector<std::string>> bn_keys;   // conv / bn name -> state-dict prefixes of its BatchNorm, one per group
     // workspace
@@ -423,8 +425,22 @@ static int make_conv(cerb_net* net, const std::string& name, const std::vector<s
         if (upload(net, rw, &r.w) || (!rb.empty() && upload(net, rb, &r.b))) return 1;
         net->raw[name] = r;
     }
+    std::vector<float> wdg;
+    if (!net->fold_bn && wino && cin % 64 == 0 && cout % 32 == 0) {
+        // dx = conv(dy, W') with W'[ci][co][ky][kx] = W[co][ci][2 - ky][2 - kx]: the data gradient of a 3x3 stride-1 pad-1 conv is the same conv
+        std::vector<float> wr((size_t)cin * cout * 9);
+        for (size_t g = 0; g < wkeys.size(); ++g) {
+            const HostTensor* w;
+            if (get(net, wkeys[g], {cout, cin, ks, ks}, &w)) return 1;
+            for (int co = 0; co < cout; ++co)
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int t = 0; t < 9; ++t) wr[((size_t)ci * cout + co) * 9 + (8 - t)] = w->data[((size_t)co * cin + ci) * 9 + t];
+            pack_wino(wr.data(), nullptr, cin, cout, &wdg, nullptr);
+        }
+    }
     PackedConv pc;
     pc.cin = cin; pc.cout = cout; pc.ks = ks; pc.stride = stride; pc.groups = (int)wkeys.size();
+    if (!wdg.empty() && upload(net, wdg, &pc.wino_dgrad)) return 1;
     if (upload(net, wp, &pc.w) || upload(net, bp, &pc.b)) return 1;
     if (wino && upload(net, wwino, &pc.wino)) return 1;
     pc.host_u.swap(hu);
@@ -562,6 +578,10 @@ extern "C" int cerb_net_finalize(cerb_net* net) {
         if (upload(net, f1.scale, &net->pc_bn1s) || upload(net, f1.shift, &net->pc_bn1b) || upload(net, w1t, &net->pc_w1t) ||
             upload(net, b1f, &net->pc_b1) || upload(net, w2t, &net->pc_w2t) || upload(net, b2f, &net->pc_b2))
             return 1;
+    }
+    if (!net->fold_bn) {
+        std::vector<float> z(512, 0.f);
+        if (upload(net, z, &net->zero_bias)) return 1;
     }
     net->host.clear();
     net->finalized = true;
@@ -1236,8 +1256,26 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 float* dw = take(wn * op.G, true);
                 float* db = r.b ? take((size_t)op.Cout * op.G, true) : nullptr;
                 if (!dw) return fail("workspace allocation failed");
-                const bool need_dx = !(op.name == "__none__");
-                HIP_OK(cerb_launch_conv_bwd(val[op.a], go, r.w, need_dx ? G_(op.a) : nullptr, dw, db, op.G, op.N, op.H, op.W, op.Cin, op.Cout, op.ks, op.stride,
+                const PackedConv& pcv = net->conv[op.name];
+                bool dx_done = false;
+                if (pcv.wino_dgrad && net->conv_algo) {
+                    // data gradient on the forward Winograd kernel: in = dy, weights rotated + transposed, the gradient already held by the
+                    // input (other consumers) rides in as the residual and is written back in place
+                    float* dx = G_(op.a);
+                    ConvParams p;
+                    memset(&p, 0, sizeof(p));
+                    p.in = go; p.wpack = pcv.wino_dgrad; p.bias = net->zero_bias; p.resid = dx; p.out = dx;
+                    p.N = op.N; p.H = op.H; p.W = op.W; p.Cin = op.Cout; p.Cout = op.Cin; p.Ho = op.H; p.Wo = op.W; p.relu = 0; p.groups = op.G;
+                    p.in_gs = (long long)op.N * op.H * op.W * op.Cout;
+                    p.w_gs = (long long)op.Cout * op.Cin * 16;
+                    p.bias_gs = 0;
+                    p.resid_gs = op.a_gs;
+                    p.out_gs = op.a_gs;
+                    if (op.G == 1) p.resid_gs = p.out_gs = 0;
+                    HIP_OK(cerb_launch_wino(p, st));
+                    dx_done = true;
+                }
+                HIP_OK(cerb_launch_conv_bwd(val[op.a], go, r.w, dx_done ? nullptr : G_(op.a), dw, db, op.G, op.N, op.H, op.W, op.Cin, op.Cout, op.ks, op.stride,
                                             op.a_gs, st));
                 for (int g = 0; g < op.G; ++g) {
                     net->grads[r.wkeys[g]] = std::make_pair(dw + g * wn, (long long)wn);

@@ -124,7 +124,8 @@ def test_backward_pass_vs_reference_train_step(gold):
         assert abs(losses[h] - exp) <= 1e-4 * max(1.0, abs(exp)), (h, losses[h], exp)
     names = [str(x) for x in gold["step/param_names"]]
     stats = gold["step/grad_stats"]
-    assert set(n for n in names if not n.startswith("backbone.fc.")) == set(grads.keys())  # fc exists but is never called: no gradient
+    # fc exists but is never called: no gradient; under the BatchNorm buffers' keys train_grads returns the step's batch statistics
+    assert set(n for n in names if not n.startswith("backbone.fc.")) == set(k for k in grads if not k.endswith(("running_mean", "running_var")))
     worst = 0.0
     for k, (s_sum, s_abs, e0, em, e1) in zip(names, stats):
         if k.startswith("backbone.fc."):
