@@ -52,6 +52,8 @@ hipError_t cerb_launch_pointwise_bwd(const float* x, const float* dy, const floa
                                      const float* in_scale, hipStream_t st);
 hipError_t cerb_launch_crop_gap_bwd(const float* dg, float* dx, int N, int H, int W, int C, int y0, int ch, int x0, int cw, hipStream_t st);
 hipError_t cerb_launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step, hipStream_t st);
+size_t cerb_wgrad3x3_workspace_bytes(int G, int N, int H, int W, int Cin, int Cout, int* slices_out);
+hipError_t cerb_launch_wgrad3x3(const float* x, const float* dy, float* dw, int G, int N, int H, int W, int Cin, int Cout, long long x_gs, void* ws, hipStream_t st);
 hipError_t cerb_launch_maxpool(const float* in, float* out, int N, int H, int W, int C, hipStream_t st);
 hipError_t cerb_launch_head(const HeadParams& p, hipStream_t st);
 struct PatchClassParams {
@@ -1275,8 +1277,14 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     HIP_OK(cerb_launch_wino(p, st));
                     dx_done = true;
                 }
-                HIP_OK(cerb_launch_conv_bwd(val[op.a], go, r.w, dx_done ? nullptr : G_(op.a), dw, db, op.G, op.N, op.H, op.W, op.Cin, op.Cout, op.ks, op.stride,
-                                            op.a_gs, st));
+                bool dw_done = false;
+                if (op.ks == 3 && op.stride == 1 && op.Cin % 64 == 0 && op.Cout % 64 == 0 && net->conv_algo) {  // weight gradient on the matrix cores
+                    if (net->t_ws.ensure(cerb_wgrad3x3_workspace_bytes(op.G, op.N, op.H, op.W, op.Cin, op.Cout, nullptr), 0)) return fail("workspace allocation failed");
+                    HIP_OK(cerb_launch_wgrad3x3(val[op.a], go, dw, op.G, op.N, op.H, op.W, op.Cin, op.Cout, op.a_gs, net->t_ws.p, st));
+                    dw_done = true;
+                }
+                HIP_OK(cerb_launch_conv_bwd(val[op.a], go, r.w, dx_done ? nullptr : G_(op.a), dw_done ? nullptr : dw, db, op.G, op.N, op.H, op.W, op.Cin, op.Cout,
+                                            op.ks, op.stride, op.a_gs, st));
                 for (int g = 0; g < op.G; ++g) {
                     net->grads[r.wkeys[g]] = std::make_pair(dw + g * wn, (long long)wn);
                     if (db) net->grads[r.bkeys[g]] = std::make_pair(db + (size_t)g * op.Cout, (long long)op.Cout);

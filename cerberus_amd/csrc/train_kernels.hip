@@ -716,7 +716,7 @@ hipError_t cerb_launch_conv_bwd(const float* x, const float* dy, const float* w,
                                 int ks, int stride, long long x_gs, hipStream_t st) {
     const int Ho = stride == 2 ? H / 2 : H, Wo = stride == 2 ? W / 2 : W;
     if (dx) hipLaunchKernelGGL(conv_dgrad_kernel, dim3(gridfor((long long)G * N * H * W * Cin)), dim3(256), 0, st, dy, w, dx, G, N, H, W, Cin, Ho, Wo, Cout, ks, stride, x_gs);
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)((long long)G * Cout * Cin)), dim3(256), 0, st, x, dy, dw, N, H, W, Cin, Ho, Wo, Cout, ks, stride, x_gs);
+    if (dw) hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)((long long)G * Cout * Cin)), dim3(256), 0, st, x, dy, dw, N, H, W, Cin, Ho, Wo, Cout, ks, stride, x_gs);
     if (db) hipLaunchKernelGGL(colsum_kernel, dim3(G * Cout), dim3(256), 0, st, dy, (long long)N * Ho * Wo * Cout, (long long)N * Ho * Wo, Cout, db);
     return hipGetLastError();
 }
