@@ -52,8 +52,9 @@ hipError_t cerb_launch_pointwise_bwd(const float* x, const float* dy, const floa
                                      const float* in_scale, hipStream_t st);
 hipError_t cerb_launch_crop_gap_bwd(const float* dg, float* dx, int N, int H, int W, int C, int y0, int ch, int x0, int cw, hipStream_t st);
 hipError_t cerb_launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step, hipStream_t st);
-size_t cerb_wgrad3x3_workspace_bytes(int G, int N, int H, int W, int Cin, int Cout, int* slices_out);
-hipError_t cerb_launch_wgrad3x3(const float* x, const float* dy, float* dw, int G, int N, int H, int W, int Cin, int Cout, long long x_gs, void* ws, hipStream_t st);
+size_t cerb_wgrad_workspace_bytes(int G, int N, int Ho, int Wo, int Cin, int Cout, int ks, int* slices_out);
+hipError_t cerb_launch_wgrad(const float* x, const float* dy, float* dw, int G, int N, int H, int W, int Cin, int Cout, int ks, int stride, long long x_gs, void* ws,
+                             hipStream_t st);
 hipError_t cerb_launch_maxpool(const float* in, float* out, int N, int H, int W, int C, hipStream_t st);
 hipError_t cerb_launch_head(const HeadParams& p, hipStream_t st);
 struct PatchClassParams {
@@ -1278,9 +1279,10 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     dx_done = true;
                 }
                 bool dw_done = false;
-                if (op.ks == 3 && op.stride == 1 && op.Cin % 64 == 0 && op.Cout % 64 == 0 && net->conv_algo) {  // weight gradient on the matrix cores
-                    if (net->t_ws.ensure(cerb_wgrad3x3_workspace_bytes(op.G, op.N, op.H, op.W, op.Cin, op.Cout, nullptr), 0)) return fail("workspace allocation failed");
-                    HIP_OK(cerb_launch_wgrad3x3(val[op.a], go, dw, op.G, op.N, op.H, op.W, op.Cin, op.Cout, op.a_gs, net->t_ws.p, st));
+                if ((op.ks == 3 || op.ks == 1) && net->conv_algo) {  // weight gradient on the matrix cores
+                    const int ho = op.stride == 2 ? op.H / 2 : op.H, wo = op.stride == 2 ? op.W / 2 : op.W;
+                    if (net->t_ws.ensure(cerb_wgrad_workspace_bytes(op.G, op.N, ho, wo, op.Cin, op.Cout, op.ks, nullptr), 0)) return fail("workspace allocation failed");
+                    HIP_OK(cerb_launch_wgrad(val[op.a], go, dw, op.G, op.N, op.H, op.W, op.Cin, op.Cout, op.ks, op.stride, op.a_gs, net->t_ws.p, st));
                     dw_done = true;
                 }
                 HIP_OK(cerb_launch_conv_bwd(val[op.a], go, r.w, dx_done ? nullptr : G_(op.a), dw_done ? nullptr : dw, db, op.G, op.N, op.H, op.W, op.Cin, op.Cout,
@@ -1325,7 +1327,13 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 float* dw = pub(op.wkey, (size_t)op.Cin * op.Cout);
                 float* db = pub(op.bkey, (size_t)op.Cout);
                 if (!dw || !db) return fail("workspace allocation failed");
-                HIP_OK(cerb_launch_pointwise_bwd(val[op.a] + op.a_gs, go, op.w, G_(op.a) + op.a_gs, dw, db, op.rows, op.Cin, op.Cout, op.scale, st));
+                bool pw_dw = false;
+                if (op.Cin % 4 == 0 && op.Cout % 4 == 0 && !op.scale && op.rows >= 4096 && op.rows < (1ll << 31) && net->conv_algo) {
+                    if (net->t_ws.ensure(cerb_wgrad_workspace_bytes(1, 1, 1, (int)op.rows, op.Cin, op.Cout, 1, nullptr), 0)) return fail("workspace allocation failed");
+                    HIP_OK(cerb_launch_wgrad(val[op.a] + op.a_gs, go, dw, 1, 1, 1, (int)op.rows, op.Cin, op.Cout, 1, 1, 0, net->t_ws.p, st));
+                    pw_dw = true;
+                }
+                HIP_OK(cerb_launch_pointwise_bwd(val[op.a] + op.a_gs, go, op.w, G_(op.a) + op.a_gs, pw_dw ? nullptr : dw, db, op.rows, op.Cin, op.Cout, op.scale, st));
                 break;
             }
             case 6:
