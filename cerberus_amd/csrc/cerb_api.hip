@@ -53,6 +53,9 @@ hipError_t cerb_launch_pointwise_bwd(const float* x, const float* dy, const floa
 hipError_t cerb_launch_crop_gap_bwd(const float* dg, float* dx, int N, int H, int W, int C, int y0, int ch, int x0, int cw, hipStream_t st);
 hipError_t cerb_launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step, hipStream_t st);
 size_t cerb_wgrad_workspace_bytes(int G, int N, int Ho, int Wo, int Cin, int Cout, int ks, int* slices_out);
+size_t cerb_stem_wgrad_workspace_bytes();
+hipError_t cerb_launch_stem_wgrad_mfma(const unsigned char* tiles, const float* dy, float* dw, int N, int H, int W, void* ws, hipStream_t st);
+hipError_t cerb_launch_colsum(const float* d, long long group_stride, long long rows, int C, int G, float* out, void* ws, hipStream_t st);
 hipError_t cerb_launch_wgrad(const float* x, const float* dy, float* dw, int G, int N, int H, int W, int Cin, int Cout, int ks, int stride, long long x_gs, void* ws,
                              hipStream_t st);
 hipError_t cerb_launch_maxpool(const float* in, float* out, int N, int H, int W, int C, hipStream_t st);
@@ -1250,7 +1253,8 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         float* go = grd[op.o];
         switch (op.type) {
             case 0: {  // stem: weight gradient only
-                HIP_OK(cerb_launch_stem_wgrad(io->tiles, go, pub("backbone.conv1.weight", 64 * 147), N, H, W, st));
+                if (net->t_ws.ensure(cerb_stem_wgrad_workspace_bytes(), 0)) return fail("workspace allocation failed");
+                HIP_OK(cerb_launch_stem_wgrad_mfma(io->tiles, go, pub("backbone.conv1.weight", 64 * 147), N, H, W, net->t_ws.p, st));
                 break;
             }
             case 1: {
@@ -1285,7 +1289,12 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     HIP_OK(cerb_launch_wgrad(val[op.a], go, dw, op.G, op.N, op.H, op.W, op.Cin, op.Cout, op.ks, op.stride, op.a_gs, net->t_ws.p, st));
                     dw_done = true;
                 }
-                HIP_OK(cerb_launch_conv_bwd(val[op.a], go, r.w, dx_done ? nullptr : G_(op.a), dw_done ? nullptr : dw, db, op.G, op.N, op.H, op.W, op.Cin, op.Cout,
+                if (db) {
+                    const long long orow = (long long)op.N * (op.stride == 2 ? op.H / 2 : op.H) * (op.stride == 2 ? op.W / 2 : op.W);
+                    if (net->t_ws.ensure((size_t)op.G * 2048 * op.Cout * 4 + 256, 0)) return fail("workspace allocation failed");
+                    HIP_OK(cerb_launch_colsum(go, orow * op.Cout, orow, op.Cout, op.G, db, net->t_ws.p, st));
+                }
+                HIP_OK(cerb_launch_conv_bwd(val[op.a], go, r.w, dx_done ? nullptr : G_(op.a), dw_done ? nullptr : dw, nullptr, op.G, op.N, op.H, op.W, op.Cin, op.Cout,
                                             op.ks, op.stride, op.a_gs, st));
                 for (int g = 0; g < op.G; ++g) {
                     net->grads[r.wkeys[g]] = std::make_pair(dw + g * wn, (long long)wn);
@@ -1333,7 +1342,9 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     HIP_OK(cerb_launch_wgrad(val[op.a] + op.a_gs, go, dw, 1, 1, 1, (int)op.rows, op.Cin, op.Cout, 1, 1, 0, net->t_ws.p, st));
                     pw_dw = true;
                 }
-                HIP_OK(cerb_launch_pointwise_bwd(val[op.a] + op.a_gs, go, op.w, G_(op.a) + op.a_gs, pw_dw ? nullptr : dw, db, op.rows, op.Cin, op.Cout, op.scale, st));
+                if (net->t_ws.ensure((size_t)2048 * op.Cout * 4 + 256, 0)) return fail("workspace allocation failed");
+                HIP_OK(cerb_launch_colsum(go, 0, op.rows, op.Cout, 1, db, net->t_ws.p, st));
+                HIP_OK(cerb_launch_pointwise_bwd(val[op.a] + op.a_gs, go, op.w, G_(op.a) + op.a_gs, pw_dw ? nullptr : dw, nullptr, op.rows, op.Cin, op.Cout, op.scale, st));
                 break;
             }
             case 6:

@@ -148,3 +148,125 @@ hipError_t cerb_launch_wgrad(const float* x, const float* dy, float* dw, int G, 
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, dw, G, Cin, Cout, ks * ks, slices);
     return hipGetLastError();
 }
+
+// =================================================================================================================
+// Stem (7x7, 3 -> 64 channels, stride 1, pad 3; uint8 tiles / 255): dW[co][c][ky][kx] = sum dy[n][y][x][co] * tile[n][y+ky-3][x+kx-3][c] / 255.
+// GEMM 64 x 147 over the pixels: the 147 columns are five 32-wide tiles (the last one padded), a wave = (co half, two or three of
+// the column tiles); per row segment the 7 x 38 x 3 input strip sits in LDS as floats and the B operand is gathered from it.
+// =================================================================================================================
+namespace {
+constexpr int SROWS = 7, SPX = SEG + 6;
+struct StemWgradParams {
+    const unsigned char* tiles;
+    const float* dy;
+    float* part;  // [slices][5 column tiles][64 co][32]
+    int N, H, W, slices, segs_per_row;
+};
+}  // namespace
+__global__ __launch_bounds__(256, 2) void stem_wgrad_mfma_kernel(StemWgradParams p) {
+    __shared__ __attribute__((aligned(16))) float dyl[DY_FLOATS];
+    __shared__ float xs[SROWS * SPX * 3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ch = wave & 1, jt0 = wave >> 1, j = lane & 31, k = lane >> 5;
+    // this lane's column in each of the wave's tiles: jj = 32 * jt + j -> (c, ky, kx) -> offset in the strip (pixel part added per pair)
+    int off[3];
+    bool live[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int jt = jt0 + 2 * u, jj = 32 * jt + j;
+        live[u] = jt < 5 && jj < 147;
+        const int c = jj / 49, ky = (jj % 49) / 7, kx = jj % 7;
+        off[u] = live[u] ? (ky * SPX + kx) * 3 + c : 0;
+    }
+    f32x16 acc[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+    const long long nseg = (long long)p.N * p.H * p.segs_per_row;
+    for (long long s = blockIdx.x; s < nseg; s += p.slices) {
+        const int sx = (int)(s % p.segs_per_row);
+        const long long ry = s / p.segs_per_row;
+        const int y = (int)(ry % p.H), n = (int)(ry / p.H), x0 = sx * SEG;
+        __syncthreads();
+        for (int i = tid; i < DY_FLOATS / 4; i += 256) {
+            const int px = i >> 4, c4 = i & 15;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (x0 + px < p.W) v = *reinterpret_cast<const f32x4*>(p.dy + (((long long)n * p.H + y) * p.W + x0 + px) * 64 + 4 * c4);
+            *reinterpret_cast<f32x4*>(dyl + px * 64 + 4 * c4) = v;
+        }
+        for (int i = tid; i < SROWS * SPX * 3; i += 256) {
+            const int c = i % 3, q = (i / 3) % SPX, r = i / (3 * SPX);
+            const int yy = y + r - 3, xx = x0 + q - 3;
+            float v = 0.f;
+            if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) v = (float)p.tiles[(((long long)n * p.H + yy) * p.W + xx) * 3 + c] / 255.0f;
+            xs[i] = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int pp = 0; pp < SEG / 2; ++pp) {
+            const float a = dyl[(2 * pp + k) * 64 + 32 * ch + j];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                if (jt0 + 2 * u < 5) {  // wave-uniform
+                    const float b = live[u] ? xs[off[u] + (2 * pp + k) * 3] : 0.f;
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[u], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float* o = p.part + (long long)blockIdx.x * 5 * 64 * 32;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int jt = jt0 + 2 * u;
+        if (jt >= 5) continue;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[(jt * 64 + 32 * ch + rq * 8 + k * 4 + e) * 32 + j] = acc[u][rq * 4 + e];
+    }
+}
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int slices) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 64 * 147; i += gridDim.x * blockDim.x) {
+        const int co = i / 147, jj = i % 147, jt = jj >> 5, j = jj & 31;
+        float s = 0.f;
+        for (int sl = 0; sl < slices; ++sl) s += part[((long long)sl * 5 * 64 + jt * 64 + co) * 32 + j];
+        dw[i] = s;  // [co][c][ky][kx] with jj = c * 49 + ky * 7 + kx
+    }
+}
+size_t cerb_stem_wgrad_workspace_bytes() { return (size_t)1536 * 5 * 64 * 32 * 4; }
+hipError_t cerb_launch_stem_wgrad_mfma(const unsigned char* tiles, const float* dy, float* dw, int N, int H, int W, void* ws, hipStream_t st) {
+    StemWgradParams p;
+    p.tiles = tiles; p.dy = dy; p.part = (float*)ws; p.N = N; p.H = H; p.W = W;
+    p.segs_per_row = (W + SEG - 1) / SEG;
+    const long long nseg = (long long)N * H * p.segs_per_row;
+    p.slices = (int)(nseg < 1536 ? nseg : 1536);
+    hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3((unsigned)p.slices), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(37), dim3(256), 0, st, (const float*)ws, dw, p.slices);
+    return hipGetLastError();
+}
+
+// per-channel sums over the rows of [G][rows][C] (bias gradients): coalesced partial sums per row slab, then a fixed-order finalise
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ d, long long group_stride, long long rows, int C, int slabs, float* __restrict__ part) {
+    const int g = blockIdx.x / slabs, sl = blockIdx.x % slabs;
+    const long long per = (rows + slabs - 1) / slabs, r0 = sl * per, r1 = min(rows, r0 + per);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s = 0;
+        for (long long r = r0; r < r1; ++r) s += d[g * group_stride + r * C + c];
+        part[((long long)g * slabs + sl) * C + c] = (float)s;
+    }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int C, int slabs, float* __restrict__ out) {
+    const int g = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s = 0;
+        for (int sl = 0; sl < slabs; ++sl) s += part[((long long)g * slabs + sl) * C + c];
+        out[g * C + c] = (float)s;
+    }
+}
+hipError_t cerb_launch_colsum(const float* d, long long group_stride, long long rows, int C, int G, float* out, void* ws, hipStream_t st) {
+    int slabs = (int)(rows < 2048 ? 1 : (rows / 512 > 2048 ? 2048 : rows / 512));
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(G * slabs), dim3(256), 0, st, d, group_stride, rows, C, slabs, (float*)ws);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(G), dim3(256), 0, st, (const float*)ws, C, slabs, out);
+    return hipGetLastError();
+}
