@@ -54,6 +54,9 @@ hipError_t cerb_launch_crop_gap_bwd(const float* dg, float* dx, int N, int H, in
 hipError_t cerb_launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step, hipStream_t st);
 size_t cerb_wgrad_workspace_bytes(int G, int N, int Ho, int Wo, int Cin, int Cout, int ks, int* slices_out);
 size_t cerb_stem_wgrad_workspace_bytes();
+hipError_t cerb_launch_dilate2(const float* dy, float* d, long long n, int H, int W, int C, hipStream_t st);
+size_t cerb_pw_wgrad_small_workspace_bytes(long long rows, int cin, int cout);
+hipError_t cerb_launch_pw_wgrad_small(const float* x, const float* dy, float* dw, long long rows, int cin, int cout, void* ws, hipStream_t st);
 hipError_t cerb_launch_stem_wgrad_mfma(const unsigned char* tiles, const float* dy, float* dw, int N, int H, int W, void* ws, hipStream_t st);
 hipError_t cerb_launch_colsum(const float* d, long long group_stride, long long rows, int C, int G, float* out, void* ws, hipStream_t st);
 hipError_t cerb_launch_wgrad(const float* x, const float* dy, float* dw, int G, int N, int H, int W, int Cin, int Cout, int ks, int stride, long long x_gs, void* ws,
@@ -158,7 +161,7 @@ struct cerb_net {
     std::map<std::string, BnDev> bn;  // by conv name ("stem", "backbone.layer1.0.conv1", "dec.<u>.<j>", "head.<k>", "pc.bn1", "pc.bn2")
     std::vector<float*> head_rw1, head_rb1, head_rw2, head_rb2;  // raw head weights, row-major [cout][cin]
     float *pc_rw1 = nullptr, *pc_rb1 = nullptr, *pc_rw2 = nullptr, *pc_rb2 = nullptr;
-    DevBuf t_mean, t_rstd, t_ws, t_hid, t_gap, t_pc1, t_idn;
+    DevBuf t_mean, t_rstd, t_ws, t_hid, t_gap, t_pc1, t_idn, t_dil;
     // backward pass (cerb_net_train_grads): raw weights in state-dict layout, per conv name, groups concatenated; the tape's buffers
     struct RawW { float* w = nullptr; float* b = nullptr; std::vector<std::string> wkeys, bkeys, bnkeys; };
     std::map<std::string, RawW> raw;
@@ -180,7 +183,7 @@ struct cerb_net {
         for (auto& r : prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         for (void* p : dev_allocs) (void)hipFree(p);
         x0.release(); pool.release(); ta.release(); tb.release(); cm.release(); dmid.release(); dsum.release();
-        t_mean.release(); t_rstd.release(); t_ws.release(); t_hid.release(); t_gap.release(); t_pc1.release(); t_idn.release();
+        t_mean.release(); t_rstd.release(); t_ws.release(); t_hid.release(); t_gap.release(); t_pc1.release(); t_idn.release(); t_dil.release();
         for (auto& b : tape) b.release();
         for (auto& b : x) b.release();
         for (auto& b : dout) b.release();
@@ -432,8 +435,9 @@ static int make_conv(cerb_net* net, const std::string& name, const std::vector<s
         net->raw[name] = r;
     }
     std::vector<float> wdg;
-    if (!net->fold_bn && wino && cin % 64 == 0 && cout % 32 == 0) {
-        // dx = conv(dy, W') with W'[ci][co][ky][kx] = W[co][ci][2 - ky][2 - kx]: the data gradient of a 3x3 stride-1 pad-1 conv is the same conv
+    if (!net->fold_bn && ks == 3 && cin % 32 == 0 && cin % 64 == 0 && cout % 32 == 0) {
+        // dx = conv(dy, W') with W'[ci][co][ky][kx] = W[co][ci][2 - ky][2 - kx]: the data gradient of a 3x3 stride-1 pad-1 conv is the same conv;
+        // of a stride-2 one, the same conv over dy spread onto the even positions of a zero map
         std::vector<float> wr((size_t)cin * cout * 9);
         for (size_t g = 0; g < wkeys.size(); ++g) {
             const HostTensor* w;
@@ -1265,10 +1269,16 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 if (!dw) return fail("workspace allocation failed");
                 const PackedConv& pcv = net->conv[op.name];
                 bool dx_done = false;
-                if (pcv.wino_dgrad && net->conv_algo) {
+                if (pcv.wino_dgrad && net->conv_algo && (op.stride == 1 || (op.H % 2 == 0 && op.W % 2 == 0))) {
                     // data gradient on the forward Winograd kernel: in = dy, weights rotated + transposed, the gradient already held by the
                     // input (other consumers) rides in as the residual and is written back in place
                     float* dx = G_(op.a);
+                    if (op.stride == 2) {  // y = 2 yo - 1 + ky  <=>  dx = conv_s1(D, W'), D[2 yo][2 xo] = dy[yo][xo], zero elsewhere
+                        const long long dn = (long long)op.G * op.N * op.H * op.W * op.Cout;
+                        if (net->t_dil.ensure((size_t)dn * 4, cerb_conv_guard_bytes(W))) return fail("workspace allocation failed");
+                        HIP_OK(cerb_launch_dilate2(go, net->t_dil.p, (long long)op.G * op.N, op.H, op.W, op.Cout, st));
+                        go = net->t_dil.p;
+                    }
                     ConvParams p;
                     memset(&p, 0, sizeof(p));
                     p.in = go; p.wpack = pcv.wino_dgrad; p.bias = net->zero_bias; p.resid = dx; p.out = dx;
@@ -1281,6 +1291,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     if (op.G == 1) p.resid_gs = p.out_gs = 0;
                     HIP_OK(cerb_launch_wino(p, st));
                     dx_done = true;
+                    go = grd[op.o];
                 }
                 bool dw_done = false;
                 if ((op.ks == 3 || op.ks == 1) && net->conv_algo) {  // weight gradient on the matrix cores
@@ -1340,6 +1351,11 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 if (op.Cin % 4 == 0 && op.Cout % 4 == 0 && !op.scale && op.rows >= 4096 && op.rows < (1ll << 31) && net->conv_algo) {
                     if (net->t_ws.ensure(cerb_wgrad_workspace_bytes(1, 1, 1, (int)op.rows, op.Cin, op.Cout, 1, nullptr), 0)) return fail("workspace allocation failed");
                     HIP_OK(cerb_launch_wgrad(val[op.a] + op.a_gs, go, dw, 1, 1, 1, (int)op.rows, op.Cin, op.Cout, 1, 1, 0, net->t_ws.p, st));
+                    pw_dw = true;
+                }
+                if (!pw_dw && op.Cout <= 8 && !op.scale && op.rows >= 4096) {  // the heads' 96 -> 3 / 7
+                    if (net->t_ws.ensure(cerb_pw_wgrad_small_workspace_bytes(op.rows, op.Cin, op.Cout), 0)) return fail("workspace allocation failed");
+                    HIP_OK(cerb_launch_pw_wgrad_small(val[op.a] + op.a_gs, go, dw, op.rows, op.Cin, op.Cout, net->t_ws.p, st));
                     pw_dw = true;
                 }
                 if (net->t_ws.ensure((size_t)2048 * op.Cout * 4 + 256, 0)) return fail("workspace allocation failed");

@@ -270,3 +270,66 @@ hipError_t cerb_launch_colsum(const float* d, long long group_stride, long long 
     hipLaunchKernelGGL(colsum_final_kernel, dim3(G), dim3(256), 0, st, (const float*)ws, C, slabs, out);
     return hipGetLastError();
 }
+
+// Pointwise layer as a streaming GEMM on the matrix pipe: out[r][n] (+)= bias[n] + sum_k a[r][k] B[k][n], K and NC multiples of 32 / 8 (the heads' 64 -> 96
+// forward and its 96 -> 64 data gradient).  One wave = 32 rows x NC: v_mfma_f32_32x32x2_f32 with A = the rows (lane = row, half-wave = k parity block), so
+// each lane fetches its row as float4s and the k order is permuted to match (k = 8 j + 4 h + e; a sum does not care); B sits in LDS in that order, one
+// ds_read_b128 per four MFMAs.  Stores put 32 consecutive floats of one row per half-wave.
+template <int K, int NC, bool ACCUM>
+__global__ __launch_bounds__(256) void pw_mfma_kernel(const float* __restrict__ a, const float* __restrict__ w, int w_trans, const float* __restrict__ bias,
+                                                      float* __restrict__ out, long long rows) {
+    __shared__ __attribute__((aligned(16))) float Bs[K * NC];
+    for (int i = threadIdx.x; i < K * NC; i += 256) {
+        const int e = i & 3, n = (i >> 2) % NC, jh = (i >> 2) / NC;  // Bs[jh][n][e], jh = 2 j + h
+        const int k = 4 * jh + e;                                    // = 8 j + 4 h + e
+        Bs[i] = w_trans ? w[n * K + k] : w[k * NC + n];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, n0 = lane & 31;
+    const long long ntiles = (rows + 31) >> 5;
+    float bv[NC / 32];
+#pragma unroll
+    for (int nb = 0; nb < NC / 32; ++nb) bv[nb] = bias ? bias[nb * 32 + n0] : 0.f;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+        const long long row = min(tile * 32 + n0, rows - 1);
+        f32x4 av[K / 8];
+#pragma unroll
+        for (int j = 0; j < K / 8; ++j) av[j] = *reinterpret_cast<const f32x4*>(a + row * K + 8 * j + 4 * h);
+        f32x16 acc[NC / 32];
+#pragma unroll
+        for (int nb = 0; nb < NC / 32; ++nb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[nb][v] = 0.f;
+#pragma unroll
+        for (int j = 0; j < K / 8; ++j)
+#pragma unroll
+            for (int nb = 0; nb < NC / 32; ++nb) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(Bs + (((2 * j + h) * NC) + nb * 32 + n0) * 4);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].x, b.x, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].y, b.y, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].z, b.z, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].w, b.w, acc[nb], 0, 0, 0);
+            }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const long long r = tile * 32 + 8 * (v >> 2) + 4 * h + (v & 3);
+            if (r < rows) {
+#pragma unroll
+                for (int nb = 0; nb < NC / 32; ++nb) {
+                    float* p = out + r * NC + nb * 32 + n0;
+                    const float val = acc[nb][v] + bv[nb];
+                    *p = ACCUM ? *p + val : val;
+                }
+            }
+        }
+    }
+}
+// returns hipErrorNotSupported for shapes the kernel is not built for (the caller keeps its scalar path)
+hipError_t cerb_launch_pw_mfma(const float* a, const float* w, int w_trans, const float* bias, float* out, long long rows, int K, int NC, int accumulate, hipStream_t st) {
+    const long long ntiles = (rows + 31) / 32;
+    const unsigned blocks = (unsigned)(ntiles / 4 < 1 ? 1 : (ntiles / 4 > 2048 ? 2048 : ntiles / 4));
+    if (K == 64 && NC == 96 && !accumulate) hipLaunchKernelGGL((pw_mfma_kernel<64, 96, false>), dim3(blocks), dim3(256), 0, st, a, w, w_trans, bias, out, rows);
+    else if (K == 96 && NC == 64 && accumulate) hipLaunchKernelGGL((pw_mfma_kernel<96, 64, true>), dim3(blocks), dim3(256), 0, st, a, w, w_trans, bias, out, rows);
+    else return hipErrorNotSupported;
+    return hipGetLastError();
+}

@@ -17,6 +17,7 @@
 
 int cerb_set_error(const std::string& m);
 
+hipError_t cerb_launch_pw_mfma(const float* a, const float* w, int w_trans, const float* bias, float* out, long long rows, int K, int NC, int accumulate, hipStream_t st);
 namespace {
 constexpr int MAXC = 16;   // classes per head (reference: 3, 7, 9)
 constexpr int PIX_PER_BLOCK = 1024;
@@ -365,6 +366,7 @@ hipError_t cerb_launch_bn_apply(float* x, const float* resid, long long group_st
 hipError_t cerb_launch_pointwise(const float* in, const float* w, const float* bias, float* out, long long rows, int cin, int cout, const float* in_scale,
                                  hipStream_t st) {
     if (cin % 4) return hipErrorInvalidValue;
+    if (!in_scale && rows >= 4096 && cerb_launch_pw_mfma(in, w, 1, bias, out, rows, cin, cout, 0, st) == hipSuccess) return hipSuccess;
     long long blocks = (rows * ((cout + 3) / 4) + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     if (blocks < 1) blocks = 1;
@@ -390,34 +392,42 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              double* __restrict__ partial) {
     extern __shared__ double shd[];
     const int g = blockIdx.x / blocks_per_group, b = blockIdx.x % blocks_per_group;
-    const int tid = threadIdx.x, c = tid % C, rl = tid / C, nrl = 256 / C;  // C <= 256 here: one channel per thread (wider: loop below)
+    const int c4n = C >> 2, tid = threadIdx.x;
+    const int c4 = tid % c4n, rl = tid / c4n, nrl = 256 / c4n;  // thread = (channel quad, row lane); spare threads idle
     const long long r0 = (long long)b * BN_ROWS_PER_BLOCK, r1 = min(rows, r0 + BN_ROWS_PER_BLOCK);
-    for (int cc = c; cc < C; cc += 256) {  // C > 256 (512-channel layers): a thread walks several channels, rl = 0 only
-        double s = 0, q = 0;
-        if (rl < max(nrl, 1)) {
-            const float m = mean[g * C + cc], rs = rstd[g * C + cc];
-            for (long long r = r0 + rl; r < r1; r += max(nrl, 1)) {
-                const long long i = g * group_stride + r * C + cc;
-                float d = dz[i];
-                if (relu && !(z[i] > 0.f)) d = 0.f;
-                s += d;
-                q += (double)d * ((y[i] - m) * rs);
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (rl < nrl) {
+        const float4 m = *reinterpret_cast<const float4*>(mean + g * C + 4 * c4), rs = *reinterpret_cast<const float4*>(rstd + g * C + 4 * c4);
+        for (long long r = r0 + rl; r < r1; r += nrl) {
+            const long long i = g * group_stride + r * C + 4 * c4;
+            float4 d = *reinterpret_cast<const float4*>(dz + i);
+            const float4 yy = *reinterpret_cast<const float4*>(y + i);
+            if (relu) {
+                const float4 zz = *reinterpret_cast<const float4*>(z + i);
+                if (!(zz.x > 0.f)) d.x = 0.f;
+                if (!(zz.y > 0.f)) d.y = 0.f;
+                if (!(zz.z > 0.f)) d.z = 0.f;
+                if (!(zz.w > 0.f)) d.w = 0.f;
             }
+            s[0] += d.x; s[1] += d.y; s[2] += d.z; s[3] += d.w;
+            q[0] += (double)d.x * ((yy.x - m.x) * rs.x);
+            q[1] += (double)d.y * ((yy.y - m.y) * rs.y);
+            q[2] += (double)d.z * ((yy.z - m.z) * rs.z);
+            q[3] += (double)d.w * ((yy.w - m.w) * rs.w);
         }
+    }
+    for (int e = 0; e < 4; ++e) {
         __syncthreads();
-        shd[tid * 2] = s;
-        shd[tid * 2 + 1] = q;
+        shd[tid * 2] = s[e];
+        shd[tid * 2 + 1] = q[e];
         __syncthreads();
         if (rl == 0) {
             double ss = 0, qq = 0;
-            for (int k = 0; k < max(nrl, 1); ++k) {
-                const int t = k * C + (C <= 256 ? cc : tid);
-                if (C <= 256 || k == 0) {
-                    ss += shd[t * 2];
-                    qq += shd[t * 2 + 1];
-                }
+            for (int k = 0; k < nrl; ++k) {
+                ss += shd[(k * c4n + c4) * 2];
+                qq += shd[(k * c4n + c4) * 2 + 1];
             }
-            double* o = partial + ((long long)blockIdx.x * C + cc) * 2;
+            double* o = partial + ((long long)blockIdx.x * C + 4 * c4 + e) * 2;
             o[0] = ss;
             o[1] = qq;
         }
@@ -672,6 +682,51 @@ __global__ __launch_bounds__(256) void pointwise_wgrad_kernel(const float* __res
         dw[(long long)co * cin + ci] = (float)t;
     }
 }
+// weight gradient of a pointwise layer with FEW outputs (the heads' 96 -> 3 / 7): thread = input channel, the dy row is a broadcast;
+// per-slab partials, added in slab order by the second kernel
+__global__ __launch_bounds__(128) void pw_wgrad_small_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                                    long long rows, int cin, int cout, long long rows_per_block) {
+    const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int ci = threadIdx.x; ci < cin; ci += 128) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        long long r = r0;
+        for (; r + 4 <= r1; r += 4) {  // four rows in flight: the loop is latency-bound otherwise
+            const float x0 = x[r * cin + ci], x1 = x[(r + 1) * cin + ci], x2 = x[(r + 2) * cin + ci], x3 = x[(r + 3) * cin + ci];
+            for (int c = 0; c < cout; ++c) {
+                acc[c] = fmaf(dy[r * cout + c], x0, acc[c]);
+                acc[c] = fmaf(dy[(r + 1) * cout + c], x1, acc[c]);
+                acc[c] = fmaf(dy[(r + 2) * cout + c], x2, acc[c]);
+                acc[c] = fmaf(dy[(r + 3) * cout + c], x3, acc[c]);
+            }
+        }
+        for (; r < r1; ++r) {
+            const float xv = x[r * cin + ci];
+            for (int c = 0; c < cout; ++c) acc[c] = fmaf(dy[r * cout + c], xv, acc[c]);
+        }
+        for (int c = 0; c < cout; ++c) part[((long long)blockIdx.x * cout + c) * cin + ci] = acc[c];
+    }
+}
+__global__ void pw_wgrad_small_final_kernel(const float* __restrict__ part, float* __restrict__ dw, int n, int blocks) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double s = 0;
+        for (int b = 0; b < blocks; ++b) s += part[(long long)b * n + i];
+        dw[i] = (float)s;
+    }
+}
+// D[n][2 yo][2 xo][:] = dy[n][yo][xo][:], zero elsewhere (H, W even): turns the data gradient of a stride-2 conv into a stride-1 conv
+__global__ __launch_bounds__(256) void dilate2_kernel(const float* __restrict__ dy, float* __restrict__ d, long long n, int H, int W, int C4) {
+    const long long total = n * H * W * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long r = i / C4;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const long long b = r / H;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!((x | y) & 1)) v = reinterpret_cast<const float4*>(dy)[((b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * C4 + c];
+        reinterpret_cast<float4*>(d)[i] = v;
+    }
+}
 __global__ void crop_gap_bwd_kernel(const float* __restrict__ dg, float* __restrict__ dx, int N, int H, int W, int C, int y0, int ch, int x0, int cw) {
     const long long total = (long long)N * ch * cw * C;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -736,9 +791,23 @@ hipError_t cerb_launch_upadd_bwd(const float* dout, float* dskip, float* dprev, 
 }
 hipError_t cerb_launch_pointwise_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long long rows, int cin, int cout,
                                      const float* in_scale, hipStream_t st) {
+    if (dx && !in_scale && rows >= 4096 && cerb_launch_pw_mfma(dy, w, 0, nullptr, dx, rows, cout, cin, 1, st) == hipSuccess) dx = nullptr;
     if (dx) hipLaunchKernelGGL(pointwise_dgrad_kernel, dim3(gridfor(rows * cin)), dim3(256), 0, st, dy, w, dx, rows, cin, cout, in_scale);
     if (dw) hipLaunchKernelGGL(pointwise_wgrad_kernel, dim3(cin * cout), dim3(256), 0, st, x, dy, dw, rows, cin, cout, in_scale);
     if (db) hipLaunchKernelGGL(colsum_kernel, dim3(cout), dim3(256), 0, st, dy, 0ll, rows, cout, db);
+    return hipGetLastError();
+}
+size_t cerb_pw_wgrad_small_workspace_bytes(long long rows, int cin, int cout) { return (size_t)((rows + 511) / 512) * cin * cout * 4 + 256; }
+hipError_t cerb_launch_pw_wgrad_small(const float* x, const float* dy, float* dw, long long rows, int cin, int cout, void* ws, hipStream_t st) {
+    if (cout > 8) return hipErrorInvalidValue;
+    const int blocks = (int)((rows + 511) / 512);
+    hipLaunchKernelGGL(pw_wgrad_small_partial_kernel, dim3(blocks), dim3(128), 0, st, x, dy, (float*)ws, rows, cin, cout, 512ll);
+    hipLaunchKernelGGL(pw_wgrad_small_final_kernel, dim3((cin * cout + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, cin * cout, blocks);
+    return hipGetLastError();
+}
+hipError_t cerb_launch_dilate2(const float* dy, float* d, long long n, int H, int W, int C, hipStream_t st) {
+    if (C % 4 || H % 2 || W % 2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(dilate2_kernel, dim3(gridfor(n * H * W * (C / 4))), dim3(256), 0, st, dy, d, n, H, W, C / 4);
     return hipGetLastError();
 }
 hipError_t cerb_launch_crop_gap_bwd(const float* dg, float* dx, int N, int H, int W, int C, int y0, int ch, int x0, int cw, hipStream_t st) {
