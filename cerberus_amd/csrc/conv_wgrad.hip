@@ -248,26 +248,62 @@ hipError_t cerb_launch_stem_wgrad_mfma(const unsigned char* tiles, const float* 
 
 // per-channel sums over the rows of [G][rows][C] (bias gradients): coalesced partial sums per row slab, then a fixed-order finalise
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ d, long long group_stride, long long rows, int C, int slabs, float* __restrict__ part) {
+    __shared__ double sh[256];
     const int g = blockIdx.x / slabs, sl = blockIdx.x % slabs;
     const long long per = (rows + slabs - 1) / slabs, r0 = sl * per, r1 = min(rows, r0 + per);
-    for (int c = threadIdx.x; c < C; c += 256) {
+    const float* dg = d + g * group_stride;
+    for (int c0 = 0; c0 < C; c0 += 256) {  // thread = (channel, row lane): all 256 threads load, the row lanes are added in lane order
+        const int cw = min(256, C - c0), nrl = 256 / cw, c = c0 + (int)threadIdx.x % cw, rl = (int)threadIdx.x / cw;
         double s = 0;
-        for (long long r = r0; r < r1; ++r) s += d[g * group_stride + r * C + c];
-        part[((long long)g * slabs + sl) * C + c] = (float)s;
+        if (rl < nrl) {
+            long long r = r0 + rl;
+            for (; r + 3ll * nrl < r1; r += 4ll * nrl) {
+                const float v0 = dg[r * C + c], v1 = dg[(r + nrl) * C + c], v2 = dg[(r + 2ll * nrl) * C + c], v3 = dg[(r + 3ll * nrl) * C + c];
+                s += v0; s += v1; s += v2; s += v3;
+            }
+            for (; r < r1; r += nrl) s += dg[r * C + c];
+        }
+        __syncthreads();
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        if (rl == 0) {
+            double t = 0;
+            for (int k = 0; k < nrl; ++k) t += sh[k * cw + (threadIdx.x % cw)];
+            part[((long long)g * slabs + sl) * C + c] = (float)t;
+        }
     }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int C, int slabs, float* __restrict__ out) {
-    const int g = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double s = 0;
-        for (int sl = 0; sl < slabs; ++sl) s += part[((long long)g * slabs + sl) * C + c];
-        out[g * C + c] = (float)s;
+// out[g][i] = sum_b part[g][b][i] in a fixed order: 64 outputs x 16 slab chunks per block, chunks combined in chunk order
+__global__ __launch_bounds__(1024) void slab_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int blocks) {
+    __shared__ double sh[16][64];
+    const int lane = threadIdx.x & 63, ch = threadIdx.x >> 6, i = blockIdx.x * 64 + lane;
+    const float* pg = part + (long long)blockIdx.y * blocks * n;
+    const int per = (blocks + 15) / 16, b0 = ch * per, b1 = min(blocks, b0 + per);
+    double s = 0;
+    if (i < n) {
+        int b = b0;
+        for (; b + 4 <= b1; b += 4) {
+            const float v0 = pg[(long long)b * n + i], v1 = pg[(long long)(b + 1) * n + i], v2 = pg[(long long)(b + 2) * n + i], v3 = pg[(long long)(b + 3) * n + i];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; b < b1; ++b) s += pg[(long long)b * n + i];
     }
+    sh[ch][lane] = s;
+    __syncthreads();
+    if (ch == 0 && i < n) {
+        double t = 0;
+        for (int k = 0; k < 16; ++k) t += sh[k][lane];
+        out[(long long)blockIdx.y * n + i] = (float)t;
+    }
+}
+hipError_t cerb_launch_slab_sum(const float* part, float* out, int n, int blocks, int groups, hipStream_t st) {
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((n + 63) / 64, groups), dim3(1024), 0, st, part, out, n, blocks);
+    return hipGetLastError();
 }
 hipError_t cerb_launch_colsum(const float* d, long long group_stride, long long rows, int C, int G, float* out, void* ws, hipStream_t st) {
     int slabs = (int)(rows < 2048 ? 1 : (rows / 512 > 2048 ? 2048 : rows / 512));
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(G * slabs), dim3(256), 0, st, d, group_stride, rows, C, slabs, (float*)ws);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(G), dim3(256), 0, st, (const float*)ws, C, slabs, out);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((C + 63) / 64, G), dim3(1024), 0, st, (const float*)ws, out, C, slabs);
     return hipGetLastError();
 }
 

@@ -18,6 +18,7 @@
 int cerb_set_error(const std::string& m);
 
 hipError_t cerb_launch_pw_mfma(const float* a, const float* w, int w_trans, const float* bias, float* out, long long rows, int K, int NC, int accumulate, hipStream_t st);
+hipError_t cerb_launch_slab_sum(const float* part, float* out, int n, int blocks, int groups, hipStream_t st);
 namespace {
 constexpr int MAXC = 16;   // classes per head (reference: 3, 7, 9)
 constexpr int PIX_PER_BLOCK = 1024;
@@ -255,23 +256,42 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
         }
     }
 }
-__global__ void bn_finalize_kernel(const double* __restrict__ partial, long long rows, int C, int blocks_per_group, float eps, float* __restrict__ mean,
-                                   float* __restrict__ rstd, float* __restrict__ var_unbiased) {
-    const int g = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double s = 0, q = 0;
-        for (int b = 0; b < blocks_per_group; ++b) {
-            const double* p = partial + ((long long)(g * blocks_per_group + b) * C + c) * 2;
-            s += p[0];
-            q += p[1];
+// (sum, sum of squares) partials of one channel added over the row blocks in a fixed order: 64 channels x 16 block chunks per workgroup of 1024
+__device__ __forceinline__ bool bn_sum_partials(const double* __restrict__ partial, int C, int blocks_per_group, int* c_out, double* s_out, double* q_out) {
+    __shared__ double sh[2][16][64];
+    const int lane = threadIdx.x & 63, ch = threadIdx.x >> 6, c = blockIdx.x * 64 + lane, g = blockIdx.y;
+    const int per = (blocks_per_group + 15) / 16, b0 = ch * per, b1 = min(blocks_per_group, b0 + per);
+    double s = 0, q = 0;
+    if (c < C)
+        for (int b = b0; b < b1; ++b) {
+            const double2 v = *reinterpret_cast<const double2*>(partial + ((long long)(g * blocks_per_group + b) * C + c) * 2);
+            s += v.x;
+            q += v.y;
         }
-        const double m = s / (double)rows;
-        double v = q / (double)rows - m * m;
-        if (v < 0) v = 0;
-        mean[g * C + c] = (float)m;
-        rstd[g * C + c] = (float)(1.0 / sqrt(v + (double)eps));
-        if (var_unbiased) var_unbiased[g * C + c] = (float)(rows > 1 ? v * (double)rows / (double)(rows - 1) : v);
+    sh[0][ch][lane] = s;
+    sh[1][ch][lane] = q;
+    __syncthreads();
+    if (ch != 0 || c >= C) return false;
+    s = q = 0;
+    for (int k = 0; k < 16; ++k) {
+        s += sh[0][k][lane];
+        q += sh[1][k][lane];
     }
+    *c_out = c; *s_out = s; *q_out = q;
+    return true;
+}
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ partial, long long rows, int C, int blocks_per_group, float eps,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ var_unbiased) {
+    int c;
+    double s, q;
+    if (!bn_sum_partials(partial, C, blocks_per_group, &c, &s, &q)) return;
+    const int g = blockIdx.y;
+    const double m = s / (double)rows;
+    double v = q / (double)rows - m * m;
+    if (v < 0) v = 0;
+    mean[g * C + c] = (float)m;
+    rstd[g * C + c] = (float)(1.0 / sqrt(v + (double)eps));
+    if (var_unbiased) var_unbiased[g * C + c] = (float)(rows > 1 ? v * (double)rows / (double)(rows - 1) : v);
 }
 __global__ __launch_bounds__(256) void bn_apply_kernel(float* __restrict__ x, const float* __restrict__ resid, long long group_stride, long long rows, int C,
                                                        int groups, const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -352,7 +372,7 @@ hipError_t cerb_launch_bn_stats(const float* x, long long group_stride, long lon
     if (C % 4 || C / 4 > 256) return hipErrorInvalidValue;  // a block covers all channel quads of a row; spare threads idle (C = 96: 24 quads x 10 row lanes)
     const int bpg = (int)((rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK);
     hipLaunchKernelGGL(bn_partial_kernel, dim3(groups * bpg), dim3(256), 256 * 2 * sizeof(double), st, x, group_stride, rows, C, bpg, (double*)ws);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(groups), dim3(256), 0, st, (const double*)ws, rows, C, bpg, eps, mean, rstd, var_unbiased);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, (const double*)ws, rows, C, bpg, eps, mean, rstd, var_unbiased);
     return hipGetLastError();
 }
 hipError_t cerb_launch_bn_apply(float* x, const float* resid, long long group_stride, long long rows, int C, int groups, const float* mean,
@@ -433,18 +453,13 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         }
     }
 }
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int C, int blocks_per_group, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int g = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double s = 0, q = 0;
-        for (int b = 0; b < blocks_per_group; ++b) {
-            const double* p = partial + ((long long)(g * blocks_per_group + b) * C + c) * 2;
-            s += p[0];
-            q += p[1];
-        }
-        dbeta[g * C + c] = (float)s;
-        dgamma[g * C + c] = (float)q;
-    }
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int C, int blocks_per_group, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta) {
+    int c;
+    double s, q;
+    if (!bn_sum_partials(partial, C, blocks_per_group, &c, &s, &q)) return;
+    dbeta[blockIdx.y * C + c] = (float)s;
+    dgamma[blockIdx.y * C + c] = (float)q;
 }
 // dy = gamma * rstd * (dzm - dbeta / M - xhat * dgamma / M); dresid += dzm (dzm = ReLU-masked dz)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ y,
@@ -706,13 +721,6 @@ __global__ __launch_bounds__(128) void pw_wgrad_small_partial_kernel(const float
         for (int c = 0; c < cout; ++c) part[((long long)blockIdx.x * cout + c) * cin + ci] = acc[c];
     }
 }
-__global__ void pw_wgrad_small_final_kernel(const float* __restrict__ part, float* __restrict__ dw, int n, int blocks) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        double s = 0;
-        for (int b = 0; b < blocks; ++b) s += part[(long long)b * n + i];
-        dw[i] = (float)s;
-    }
-}
 // D[n][2 yo][2 xo][:] = dy[n][yo][xo][:], zero elsewhere (H, W even): turns the data gradient of a stride-2 conv into a stride-1 conv
 __global__ __launch_bounds__(256) void dilate2_kernel(const float* __restrict__ dy, float* __restrict__ d, long long n, int H, int W, int C4) {
     const long long total = n * H * W * C4;
@@ -762,7 +770,7 @@ hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, f
     const int bpg = (int)((rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(groups * bpg), dim3(256), 256 * 2 * sizeof(double), st, dz, z, y, group_stride, rows, C, bpg, mean, rstd, relu,
                        (double*)ws);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(groups), dim3(256), 0, st, (const double*)ws, C, bpg, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, (const double*)ws, C, bpg, dgamma, dbeta);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gridfor(rows * C * groups)), dim3(256), 0, st, dz, z, y, dy, dresid, group_stride, rows, C, groups, mean, rstd,
                        gamma, dgamma, dbeta, relu);
     return hipGetLastError();
@@ -802,7 +810,7 @@ hipError_t cerb_launch_pw_wgrad_small(const float* x, const float* dy, float* dw
     if (cout > 8) return hipErrorInvalidValue;
     const int blocks = (int)((rows + 511) / 512);
     hipLaunchKernelGGL(pw_wgrad_small_partial_kernel, dim3(blocks), dim3(128), 0, st, x, dy, (float*)ws, rows, cin, cout, 512ll);
-    hipLaunchKernelGGL(pw_wgrad_small_final_kernel, dim3((cin * cout + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, cin * cout, blocks);
+    (void)cerb_launch_slab_sum((const float*)ws, dw, cin * cout, blocks, 1, st);
     return hipGetLastError();
 }
 hipError_t cerb_launch_dilate2(const float* dy, float* d, long long n, int H, int W, int C, hipStream_t st) {
