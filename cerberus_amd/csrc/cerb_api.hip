@@ -54,6 +54,8 @@ hipError_t cerb_launch_crop_gap_bwd(const float* dg, float* dx, int N, int H, in
 hipError_t cerb_launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step, hipStream_t st);
 size_t cerb_wgrad_workspace_bytes(int G, int N, int Ho, int Wo, int Cin, int Cout, int ks, int* slices_out);
 size_t cerb_stem_wgrad_workspace_bytes();
+hipError_t cerb_launch_pack_conv(const float* w_raw, float* out, int cout, int cin, int ks, int chunk, hipStream_t st);
+hipError_t cerb_launch_pack_wino(const float* w_raw, float* out, int cout, int cin, int dgrad, hipStream_t st);
 hipError_t cerb_launch_dilate2(const float* dy, float* d, long long n, int H, int W, int C, hipStream_t st);
 size_t cerb_pw_wgrad_small_workspace_bytes(long long rows, int cin, int cout);
 hipError_t cerb_launch_pw_wgrad_small(const float* x, const float* dy, float* dw, long long rows, int cin, int cout, void* ws, hipStream_t st);
@@ -155,6 +157,9 @@ struct cerb_net {
     std::vector<float*> head_w1, head_b1, head_w2, head_b2;  // per dense decoder
     float *pc_bn1s = nullptr, *pc_bn1b = nullptr, *pc_w1t = nullptr, *pc_b1 = nullptr, *pc_w2t = nullptr, *pc_b2 = nullptr;
     std::vector<void*> dev_allocs;
+    std::vector<size_t> dev_alloc_bytes;  // sizes of dev_allocs: a reload (cerb_net_begin_reload) hands the same buffers out again, in order
+    size_t n_finalize_allocs = 0, reuse_cursor = 0;
+    bool reusing = false;
     // train-mode packing (cerb_net_set_fold_bn(net, 0) before finalize): raw conv weights, BatchNorm affine parameters kept apart
     int fold_bn = 1;
     struct BnDev { float *gamma = nullptr, *beta = nullptr; int C = 0, groups = 1; };
@@ -190,12 +195,25 @@ struct cerb_net {
     }
 };
 
-static int upload(cerb_net* net, const std::vector<float>& v, float** out) {
-    float* d = nullptr;
-    HIP_OK(hipMalloc(&d, v.size() * sizeof(float)));
+static int alloc_dev(cerb_net* net, size_t bytes, void** out) {
+    if (net->reusing) {
+        if (net->reuse_cursor >= net->n_finalize_allocs || net->dev_alloc_bytes[net->reuse_cursor] != bytes)
+            return fail("reload: the tensors do not have the shapes the handle was finalized with");
+        *out = net->dev_allocs[net->reuse_cursor++];
+        return 0;
+    }
+    void* d = nullptr;
+    HIP_OK(hipMalloc(&d, bytes));
     net->dev_allocs.push_back(d);
-    HIP_OK(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    net->dev_alloc_bytes.push_back(bytes);
     *out = d;
+    return 0;
+}
+static int upload(cerb_net* net, const std::vector<float>& v, float** out) {
+    void* d = nullptr;
+    if (alloc_dev(net, v.size() * sizeof(float), &d)) return 1;
+    HIP_OK(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = reinterpret_cast<float*>(d);
     return 0;
 }
 
@@ -406,8 +424,10 @@ static int make_conv(cerb_net* net, const std::string& name, const std::vector<s
         Fold f;
         bool have_bn = !bnkeys.empty() && net->fold_bn;
         if (have_bn && bn_fold(net, bnkeys[g], cout, &f)) return 1;
-        pack_conv(w->data.data(), have_bn ? f.scale.data() : nullptr, cout, cin, ks, CB, &wp);
-        if (wino) pack_wino(w->data.data(), have_bn ? f.scale.data() : nullptr, cout, cin, &wwino, &hu);
+        if (net->fold_bn) {  // handles packed for training lay their weights out on the device (below)
+            pack_conv(w->data.data(), have_bn ? f.scale.data() : nullptr, cout, cin, ks, CB, &wp);
+            if (wino) pack_wino(w->data.data(), have_bn ? f.scale.data() : nullptr, cout, cin, &wwino, &hu);
+        }
         const HostTensor* b = nullptr;
         if (!bkeys.empty() && get(net, bkeys[g], {cout}, &b)) return 1;
         for (int c = 0; c < cout; ++c) {
@@ -434,26 +454,31 @@ static int make_conv(cerb_net* net, const std::string& name, const std::vector<s
         if (upload(net, rw, &r.w) || (!rb.empty() && upload(net, rb, &r.b))) return 1;
         net->raw[name] = r;
     }
-    std::vector<float> wdg;
-    if (!net->fold_bn && ks == 3 && cin % 32 == 0 && cin % 64 == 0 && cout % 32 == 0) {
-        // dx = conv(dy, W') with W'[ci][co][ky][kx] = W[co][ci][2 - ky][2 - kx]: the data gradient of a 3x3 stride-1 pad-1 conv is the same conv;
-        // of a stride-2 one, the same conv over dy spread onto the even positions of a zero map
-        std::vector<float> wr((size_t)cin * cout * 9);
-        for (size_t g = 0; g < wkeys.size(); ++g) {
-            const HostTensor* w;
-            if (get(net, wkeys[g], {cout, cin, ks, ks}, &w)) return 1;
-            for (int co = 0; co < cout; ++co)
-                for (int ci = 0; ci < cin; ++ci)
-                    for (int t = 0; t < 9; ++t) wr[((size_t)ci * cout + co) * 9 + (8 - t)] = w->data[((size_t)co * cin + ci) * 9 + t];
-            pack_wino(wr.data(), nullptr, cin, cout, &wdg, nullptr);
-        }
-    }
     PackedConv pc;
     pc.cin = cin; pc.cout = cout; pc.ks = ks; pc.stride = stride; pc.groups = (int)wkeys.size();
-    if (!wdg.empty() && upload(net, wdg, &pc.wino_dgrad)) return 1;
-    if (upload(net, wp, &pc.w) || upload(net, bp, &pc.b)) return 1;
-    if (wino && upload(net, wwino, &pc.wino)) return 1;
-    pc.host_u.swap(hu);
+    if (upload(net, bp, &pc.b)) return 1;
+    if (net->fold_bn) {
+        if (upload(net, wp, &pc.w)) return 1;
+        if (wino && upload(net, wwino, &pc.wino)) return 1;
+        pc.host_u.swap(hu);
+    } else {
+        // packed on the device from the raw copy (pack_kernels.hip): nothing but the state-dict tensors crosses PCIe after an optimiser step.
+        // Data gradient of a 3x3 pad-1 conv: dx = conv(dy, W') with W'[ci][co][ky][kx] = W[co][ci][2 - ky][2 - kx] -- the same Winograd conv
+        // (stride 2: over dy spread onto the even positions of a zero map)
+        const float* rawd = net->raw[name].w;
+        const size_t G = wkeys.size(), nw = (size_t)cout * cin * ks * ks, nu = (size_t)cout * cin * 16;
+        const bool dgrad = ks == 3 && cin % 64 == 0 && cout % 32 == 0;
+        void *dwp = nullptr, *dwi = nullptr, *ddg = nullptr;
+        if (alloc_dev(net, G * nw * 4, &dwp) || (wino && alloc_dev(net, G * nu * 4, &dwi)) || (dgrad && alloc_dev(net, G * nu * 4, &ddg))) return 1;
+        pc.w = reinterpret_cast<float*>(dwp);
+        pc.wino = reinterpret_cast<float*>(dwi);
+        pc.wino_dgrad = reinterpret_cast<float*>(ddg);
+        for (size_t g = 0; g < G; ++g) {
+            HIP_OK(cerb_launch_pack_conv(rawd + g * nw, pc.w + g * nw, cout, cin, ks, CB, 0));
+            if (wino) HIP_OK(cerb_launch_pack_wino(rawd + g * nw, pc.wino + g * nu, cout, cin, 0, 0));
+            if (dgrad) HIP_OK(cerb_launch_pack_wino(rawd + g * nw, pc.wino_dgrad + g * nu, cin, cout, 1, 0));
+        }
+    }
     net->conv[name] = pc;
     return 0;
 }
@@ -593,6 +618,10 @@ extern "C" int cerb_net_finalize(cerb_net* net) {
         std::vector<float> z(512, 0.f);
         if (upload(net, z, &net->zero_bias)) return 1;
     }
+    if (!net->fold_bn) HIP_OK(hipDeviceSynchronize());  // the packing kernels ran on the null stream
+    if (net->reusing && net->reuse_cursor != net->n_finalize_allocs) return fail("reload: fewer tensors than the handle was finalized with");
+    if (!net->reusing) net->n_finalize_allocs = net->dev_allocs.size();
+    net->reusing = false;
     net->host.clear();
     net->finalized = true;
     return 0;
@@ -651,6 +680,7 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
             void* d = nullptr;
             HIP_OK(hipMalloc(&d, w3.size() * 2));
             net->dev_allocs.push_back(d);
+            net->dev_alloc_bytes.push_back(w3.size() * 2);
             HIP_OK(hipMemcpy(d, w3.data(), w3.size() * 2, hipMemcpyHostToDevice));
             cm.wino3 = d;
         }
@@ -1393,6 +1423,26 @@ extern "C" int cerb_net_grad_lookup(cerb_net* net, const char* key, float** dev_
     return 0;
 }
 
+extern "C" int cerb_net_begin_reload(cerb_net* net) {
+    if (!net) return fail("cerb_net_begin_reload: null handle");
+    HIP_OK(hipDeviceSynchronize());
+    while (net->dev_allocs.size() > net->n_finalize_allocs) {  // buffers made after finalize (lazy packings); the others are handed out again
+        (void)hipFree(net->dev_allocs.back());
+        net->dev_allocs.pop_back();
+        net->dev_alloc_bytes.pop_back();
+    }
+    net->reusing = true;
+    net->reuse_cursor = 0;
+    net->conv.clear();
+    net->bn.clear();
+    net->raw.clear();
+    net->grads.clear();
+    net->head_w1.clear(); net->head_b1.clear(); net->head_w2.clear(); net->head_b2.clear();
+    net->head_rw1.clear(); net->head_rb1.clear(); net->head_rw2.clear(); net->head_rb2.clear();
+    net->host.clear();
+    net->finalized = false;
+    return 0;
+}
 extern "C" int cerb_net_set_fold_bn(cerb_net* net, int fold) {
     if (!net) return fail("cerb_net_set_fold_bn: null handle");
     if (net->finalized) return fail("cerb_net_set_fold_bn: must be called before cerb_net_finalize");

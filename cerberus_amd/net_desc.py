@@ -126,18 +126,22 @@ class NetDesc(torch.nn.Module):
         try:
             if getattr(self, "_train_packing", False):
                 _lib.check(L.cerb_net_set_fold_bn(h, 0))
-            for k, v in self._sd.items():
-                if v.dtype != torch.float32:
-                    continue
-                a = np.ascontiguousarray(v.numpy())
-                shp = (C.c_int64 * a.ndim)(*a.shape)
-                _lib.check(L.cerb_net_load_tensor(h, k.encode(), a.ctypes.data_as(C.c_void_p), shp, a.ndim))
-            _lib.check(L.cerb_net_finalize(h))
+            self._load_and_finalize(h)
         except Exception:
             L.cerb_net_destroy(h)
             raise
         self._handle = h
         return h
+
+    def _load_and_finalize(self, h):
+        L = _lib.lib()
+        for k, v in self._sd.items():
+            if v.dtype != torch.float32:
+                continue
+            a = np.ascontiguousarray(v.numpy())
+            shp = (C.c_int64 * a.ndim)(*a.shape)
+            _lib.check(L.cerb_net_load_tensor(h, k.encode(), a.ctypes.data_as(C.c_void_p), shp, a.ndim))
+        _lib.check(L.cerb_net_finalize(h))
 
     def train(self, mode=True):
         """nn.Module.train(): a network whose handle has not been created yet is packed for training on first use (raw conv weights,
@@ -251,12 +255,24 @@ class NetDesc(torch.nn.Module):
         losses = OrderedDict((key, float(loss[i])) for i, (_, _, _, key) in enumerate(self._decoders) if key in targets)
         return losses, grads
 
-    def load_updated_parameters(self, dev_params):
-        """After an optimiser step: take the updated parameters (key -> CUDA tensor) into the state dict and drop the device handle, which
-        is re-packed on the next use (first version: the packing runs on the host)."""
-        for k, v in dev_params.items():
-            self._sd[k] = v.detach().cpu().clone()
-        self._release()
+    def load_updated_parameters(self, dev_params, flat=None, layout=None):
+        """After an optimiser step: take the updated parameters (key -> CUDA tensor) into the state dict and re-pack the weights of the device handle in
+        place (conv weights are laid out by device kernels from the raw copies; activation workspaces and the training tape are kept)."""
+        if flat is not None:  # dev_params are views of one flat buffer, layout = [(key, offset, numel, shape)]: one device -> host copy
+            host = flat.detach().cpu()
+            for k, o, n, shp in layout:
+                self._sd[k] = host[o:o + n].view(shp)
+        else:
+            for k, v in dev_params.items():
+                self._sd[k] = v.detach().cpu().clone()
+        if self._handle is None:
+            return
+        try:  # keep the handle (workspaces, tape); only the packed weights are rebuilt
+            _lib.check(_lib.lib().cerb_net_begin_reload(self._handle))
+            self._load_and_finalize(self._handle)
+        except Exception:
+            self._release()
+            raise
 
     def flops(self, n, h, w):
         return float(_lib.lib().cerb_net_flops(self._ensure_handle(), n, h, w))

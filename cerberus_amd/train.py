@@ -1,7 +1,7 @@
 """Mirror of the reference's train_step (models/run_desc.py:25-230) on the GPU: train-mode forward, the six head losses, the backward
-pass, Adam (models/opt.py:47-58) and the BatchNorm running statistics -- BASELINE configs[4].  FIRST VERSION: every piece is checked
-against the reference's own train_step (tests/test_train_loss_gpu.py), none of the backward kernels is tuned, and the updated weights
-are re-packed by rebuilding the device handle (cerb_net_finalize on the host) -- seconds per step, see DESIGN.md par.9.
+pass, Adam (models/opt.py:47-58) and the BatchNorm running statistics -- BASELINE configs[4].  Every piece is checked against
+the reference's own train_step (tests/test_train_loss_gpu.py).  After the optimiser the updated parameters go back into the state dict
+in one transfer and the handle re-packs its conv weights on the device (cerb_net_begin_reload).
 
 Multi-GPU: one process per GPU, `allreduce_grads` averages the gradients over ranks in buckets (backend "nccl" = RCCL over xGMI,
 113.5 MB per step) between the backward pass and the optimiser -- the DistributedDataParallel arithmetic of a reference that only
@@ -91,13 +91,22 @@ def train_step(batch_data, run_info, dist=None, world_size=1, dropout_keep=None)
     stats = OrderedDict((k, grads.pop(k)) for k in buf_keys)
     allreduce_grads(grads, dist, world_size)
     # parameters live in the model's state dict (host); the optimiser works on device copies that persist across steps
-    if not hasattr(model, "_dev_params"):
-        model._dev_params = OrderedDict((k, v.to(dev).clone()) for k, v in model._sd.items() if v.dtype == torch.float32)
+    if not hasattr(model, "_dev_params"):  # views into ONE flat device buffer: the copy back to the state dict is a single transfer
+        layout, off = [], 0
+        for k, v in model._sd.items():
+            if v.dtype == torch.float32:
+                layout.append((k, off, v.numel(), tuple(v.shape)))
+                off += (v.numel() + 63) // 64 * 64
+        model._dev_flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        model._dev_layout = layout
+        model._dev_params = OrderedDict((k, model._dev_flat[o:o + n].view(shp)) for k, o, n, shp in layout)
+        for k, t in model._dev_params.items():
+            t.copy_(model._sd[k])
     opt.step(model._dev_params, grads)
     for k, s in stats.items():  # running = 0.9 running + 0.1 batch (torch BatchNorm momentum 0.1; the variance is the unbiased one)
         model._dev_params[k].mul_(0.9).add_(s.reshape(model._dev_params[k].shape), alpha=0.1)
     torch.cuda.synchronize(dev)
-    model.load_updated_parameters(model._dev_params)
+    model.load_updated_parameters(model._dev_params, model._dev_flat, model._dev_layout)
     ema = OrderedDict(("%s_loss" % k, v) for k, v in losses.items())
     ema["overall_loss"] = float(sum(losses.values()))
     return {"EMA": ema}

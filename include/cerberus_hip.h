@@ -206,6 +206,9 @@ typedef struct cerb_train_io {
     float* const* logits;
 } cerb_train_io;
 int cerb_net_set_fold_bn(cerb_net* net, int fold);
+/* After an optimiser step: drop the packed weights of a finalized handle (activation workspaces, the training tape and the mode stay), so
+ * that cerb_net_load_tensor of EVERY tensor + cerb_net_finalize install the updated parameters (models/run_desc.py:165 optimizer.step()). */
+int cerb_net_begin_reload(cerb_net* net);
 int cerb_net_forward_train(cerb_net* net, const cerb_train_io* io, void* hip_stream);
 
 /* cerb_net_train_grads: train-mode forward + the head losses + the backward pass of one step (models/run_desc.py:79-170 up to

@@ -21,3 +21,12 @@ for n, hw in [(2, 64), (4, 128), (4, 256), (16, 448)][: int(sys.argv[1]) if len(
         t0 = time.time(); m.forward_train(tiles); torch.cuda.synchronize(); t2 = time.time() - t0
     print("batch %2d x %3d^2: gradient step %.3f s (train-mode forward alone %.3f s), overall loss %.4f, peak memory %.1f GB" % (
         n, hw, t1, t2, sum(losses.values()), torch.cuda.max_memory_allocated() / 1e9), flush=True)
+    from cerberus_amd.train import Adam, train_step
+    if not hasattr(m, "_opt"): m._opt = Adam(lr=1.0e-4, betas=(0.9, 0.999))
+    batch = {"img": tiles.cpu(), "dummy_target": np.array([list(heads)] * n, dtype=object)}
+    for h in heads: batch[h] = tg[h].cpu().reshape((n,) if h == "Patch-Class" else (n, hw, hw, 1))
+    for rep in range(3):  # whole step as the reference's engine calls it: host batch in, losses out, Adam + BN statistics + weight re-pack
+        torch.cuda.synchronize(); t0 = time.time()
+        res = train_step(batch, ({"net": {"desc": m, "optimizer": m._opt, "extra_info": {"loss": PARAMSET_LOSS}}}, None))
+        torch.cuda.synchronize(); t3 = time.time() - t0
+    print("    whole train_step (host batch in, Adam, running statistics, weight re-pack): %.3f s, overall loss %.4f" % (t3, res["EMA"]["overall_loss"]), flush=True)
