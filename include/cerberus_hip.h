@@ -212,8 +212,9 @@ int cerb_net_begin_reload(cerb_net* net);
 int cerb_net_forward_train(cerb_net* net, const cerb_train_io* io, void* hip_stream);
 
 /* cerb_net_train_grads: train-mode forward + the head losses + the backward pass of one step (models/run_desc.py:79-170 up to
- * all_loss.backward()), for a network packed with cerb_net_set_fold_bn(net, 0).  FIRST VERSION: the backward runs on plain gather
- * kernels -- correct against the reference's gradients and bitwise reproducible, not tuned.  Arrays are per decoder in
+ * all_loss.backward()), for a network packed with cerb_net_set_fold_bn(net, 0).  Weight gradients, the 3x3 data gradients and
+ * the heads' pointwise layers run on the matrix cores, every reduction adds its partials in a fixed order (bitwise reproducible, no float
+ * atomics).  Arrays are per decoder in
  * cerb_net_create order; a decoder whose target pointer is NULL contributes no loss.
  *   target[d]       : device float [n][h][w] class ids (Patch-Class: [n])          has_target[d] : device float [n]
  *   class_weight[d] : device float [out_ch] or NULL (see cerb_head_loss)           ce_w / dice_w / head_w : host floats
