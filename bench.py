@@ -65,12 +65,94 @@ def cpu_baseline(sd, kw, n_tiles=8, iters=2):
     }
 
 
+TRAIN_BATCH, TRAIN_TILE = 16, 448  # BASELINE.json configs[4]: batch 16; 448 x 448 is the reference's training patch (paramset.yml)
+
+
+def train_leg(args, model, dev, dist, world, rank):
+    """--mode train: K whole training steps (train-mode forward, six losses, backward, bucketed gradient all-reduce over the ranks, Adam,
+    BatchNorm running statistics, on-device weight re-pack) on a synthetic batch resident in HBM; every rank has its own batch (weak)."""
+    import numpy as np
+
+    from cerberus_amd.losses import PARAMSET_LOSS
+    from cerberus_amd.train import Adam, train_step
+
+    model.train()
+    heads = {"Lumen-INST": 3, "Gland-INST": 3, "Nuclei-INST": 3, "Nuclei-TYPE": 7, "Gland-TYPE": 3, "Patch-Class": 9}
+    n, hw = TRAIN_BATCH, TRAIN_TILE
+    g = torch.Generator(device=dev).manual_seed(2000 + rank)
+    batch = {"img": torch.randint(0, 256, (n, hw, hw, 3), dtype=torch.uint8, device=dev, generator=g),
+             "dummy_target": np.array([list(heads)] * n, dtype=object)}
+    for h, c in heads.items():
+        if h == "Patch-Class":
+            batch[h] = torch.randint(0, c, (n,), device=dev, generator=g).float()
+        else:  # sparse foreground, as annotation masks are
+            fg = torch.rand((n, hw, hw, 1), device=dev, generator=g) < 0.3
+            batch[h] = (fg * torch.randint(1, c, (n, hw, hw, 1), device=dev, generator=g)).float()
+    opt = Adam(lr=1.0e-4, betas=(0.9, 0.999))
+    info = ({"net": {"desc": model, "optimizer": opt, "extra_info": {"loss": PARAMSET_LOSS}}}, None)
+
+    def step():
+        return train_step(batch, info, dist=dist, world_size=world)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        fwd_flops = model.flops(n, hw, hw)
+        print(json.dumps({
+            "metric": "training tiles/sec (multi-task step, all 6 losses)",
+            "value": round(world * args.steps * n / dt, 3),
+            "unit": "tiles/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "Multi-task training step (train-mode forward + 6 losses + backward + Adam + BN running statistics + weight re-pack), "
+                            "batch=%d %dx%dx3 uint8 tiles per GPU, fp32 (BASELINE.json configs[4])" % (n, hw, hw),
+                "batch_tiles": n,
+                "tile": hw,
+                "Mpx_s": round(world * args.steps * n * hw * hw / dt / 1e6, 3),
+                "approx_tflops_3x_forward": round(3.0 * fwd_flops / (dt / args.steps) / 1e12 * world, 2),
+                "parallelism": "data-parallel x%d, bucketed gradient all-reduce (%s)" % (world, args.backend if world > 1 else "none at 1 GPU"),
+                "last_overall_loss": round(float(res["EMA"]["overall_loss"]), 4),
+            },
+            "roofline": None,
+            "cpu_baseline": None,
+        }), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help='"infer" (default): the headline, BASELINE.json configs[1]; "train": the multi-task training step of configs[4]')
     ap.add_argument("--backend", default="nccl", help='torch.distributed backend ("nccl" = RCCL over xGMI; "gloo" only for plumbing tests)')
     args = ap.parse_args()
 
@@ -98,6 +180,8 @@ def main():
     sd = {k: torch.from_numpy(v) for k, v in make_state_dict(0).items()}
     model = create_model(**kw)
     model.load_state_dict(sd, strict=True)
+    if args.mode == "train":
+        return train_leg(args, model, dev, dist, world, rank)
 
     # synthetic slide strip resident in HBM: this rank's batches (seeded per rank), and its output canvas
     g = torch.Generator(device=dev).manual_seed(1000 + rank)

@@ -138,3 +138,26 @@ def test_bench_contract_single_and_two_ranks(tmp_path):
     # two ranks time-share one GPU here: each step takes about twice as long and the aggregate stays about the same
     assert abs(two["value"] - 2 * 32 * 256 * 256 / (two["ms_per_step"] * 1e-3) / 1e6) / two["value"] < 0.01
     assert 0.6 < two["value"] / one["value"] < 1.25
+
+
+def test_bench_train_mode_single_and_two_ranks():
+    """bench.py --mode train: whole training steps of BASELINE configs[4] (batch 16 x 448^2 per rank); with two ranks (gloo, both on this
+    box's one GPU) the gradients are averaged in buckets between the backward pass and Adam, and rank 0 reports the whole job."""
+    import json
+
+    def run(cmd):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+
+    one = run([sys.executable, "bench.py", "--mode", "train", "--steps", "2", "--warmup", "1"])
+    assert one["unit"] == "tiles/s" and one["n_gpus"] == 1 and one["dtype"] == "f32" and one["scaling"] == "weak"
+    assert abs(one["value"] - 16 / (one["ms_per_step"] * 1e-3)) / one["value"] < 0.01
+    assert 0 < one["config"]["last_overall_loss"] < 100
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+               "bench.py", "--mode", "train", "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo"])
+    assert two["n_gpus"] == 2 and abs(two["value"] - 2 * 16 / (two["ms_per_step"] * 1e-3)) / two["value"] < 0.01
+    assert 0 < two["config"]["last_overall_loss"] < 100
