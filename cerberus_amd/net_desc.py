@@ -30,6 +30,13 @@ HEAD_NAME_MAP = {  # reference models/run_desc.py:466-473
 }
 
 
+class _DeviceArray(object):
+    """A float32 device buffer owned by the library, exposed to torch without a copy (__cuda_array_interface__)."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (int(ptr), False), "version": 2, "strides": None}
+
+
 class NetDesc(torch.nn.Module):
     """U-Net style network with a shared ResNet34 encoder and per-task decoders (reference net_desc.py:16-103)."""
 
@@ -185,13 +192,13 @@ class NetDesc(torch.nn.Module):
             _lib.check(_lib.lib().cerb_net_forward_train(h, C.byref(io), C.c_void_p(stream)))
         return res
 
-    def train_grads(self, tiles_u8, targets, has_target, loss_opts, dropout_keep=None):
+    def train_grads(self, tiles_u8, targets, has_target, loss_opts, dropout_keep=None, views=False):
         """One step of the reference's train_step up to all_loss.backward() (models/run_desc.py:79-170): train-mode forward, the head
         losses, the backward pass.  targets: head key -> CUDA float [N, H, W] class ids ([N] for Patch-Class); has_target: head key ->
         CUDA float [N]; loss_opts: the reference's loss_kwargs (cerberus_amd.losses.PARAMSET_LOSS).
         -> (losses: head key -> float as train_step reports them, grads: state-dict key -> CUDA float tensor shaped like the parameter;
         under the keys of the BatchNorm buffers (running_mean / running_var) it holds the step's batch mean / unbiased batch variance).
-        First version: the backward pass runs on plain gather kernels (correct and reproducible, not tuned)."""
+        views=True returns tensors over the handle's own gradient memory instead of copies: valid until the next call on this network."""
         self.train(True)
         h = self._ensure_handle()
         L = _lib.lib()
@@ -248,8 +255,11 @@ class NetDesc(torch.nn.Module):
                 ptr, numel = C.c_void_p(), C.c_longlong()
                 _lib.check(L.cerb_net_grad_lookup(h, lk.encode(), C.byref(ptr), C.byref(numel)))
                 assert numel.value == v.numel(), (k, numel.value, v.numel())
-                g = torch.empty(v.shape, dtype=torch.float32, device=dev)
-                _lib.check(L.cerb_copy_d2d(g.data_ptr(), ptr, 4 * v.numel(), C.c_void_p(stream)))
+                if views:  # zero-copy: a tensor over the handle's own gradient memory
+                    g = torch.as_tensor(_DeviceArray(ptr.value, tuple(v.shape)), device=dev)
+                else:
+                    g = torch.empty(v.shape, dtype=torch.float32, device=dev)
+                    _lib.check(L.cerb_copy_d2d(g.data_ptr(), ptr, 4 * v.numel(), C.c_void_p(stream)))
                 grads[k] = g
         torch.cuda.synchronize(dev)
         losses = OrderedDict((key, float(loss[i])) for i, (_, _, _, key) in enumerate(self._decoders) if key in targets)

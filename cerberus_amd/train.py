@@ -91,7 +91,7 @@ def train_step(batch_data, run_info, dist=None, world_size=1, dropout_keep=None)
         flags[k] = torch.from_numpy(np.any(np.asarray(has) == k, axis=-1).astype(np.float32)).to(dev)
     if dropout_keep is None and "Patch-Class" in targets:  # nn.Dropout(p=0.3) of the Patch-Class branch (models/net_desc.py:70)
         dropout_keep = torch.rand((img.shape[0], 512), device=dev) >= 0.3
-    losses, grads = model.train_grads(torch.as_tensor(img).to(dev), targets, flags, loss_opts, dropout_keep)
+    losses, grads = model.train_grads(torch.as_tensor(img).to(dev), targets, flags, loss_opts, dropout_keep, views=True)
     buf_keys = [k for k in grads if k.endswith("running_mean") or k.endswith("running_var")]
     stats = OrderedDict((k, grads.pop(k)) for k in buf_keys)
     allreduce_grads(grads, dist, world_size)
