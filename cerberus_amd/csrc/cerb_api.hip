@@ -1274,8 +1274,8 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         const int hh = pc ? 1 : H, ww = pc ? 1 : W, C = d.out_ch;
         if (net->t_hid.ensure(cerb_head_loss_workspace_bytes(N, hh, ww), 0)) return fail("workspace allocation failed");
         // NHWC logits: strides (n, c, y, x) = (h w C, 1, w C, C)
-        if (cerb_head_loss(val[lg], (long long)hh * ww * C, 1, (long long)ww * C, C, io->target[di], io->has_target[di], N, hh, ww, C,
-                           io->class_weight ? io->class_weight[di] : nullptr, io->ce_w[di], io->dice_w[di], io->head_w[di], pc ? 1 : 0, io->loss_out + di, G_(lg),
+        if (cerb_head_loss_wmap(val[lg], (long long)hh * ww * C, 1, (long long)ww * C, C, io->target[di], io->has_target[di], N, hh, ww, C,
+                           io->class_weight ? io->class_weight[di] : nullptr, io->pixel_weight ? io->pixel_weight[di] : nullptr, io->ce_w[di], io->dice_w[di], io->head_w[di], pc ? 1 : 0, io->loss_out + di, G_(lg),
                            net->t_hid.p, cerb_head_loss_workspace_bytes(N, hh, ww), st))
             return 1;
         if (io->logits && io->logits[di]) HIP_OK(hipMemcpyAsync(io->logits[di], val[lg], cnt[lg] * 4, hipMemcpyDeviceToDevice, st));

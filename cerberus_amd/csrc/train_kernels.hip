@@ -29,6 +29,7 @@ struct LossParams {
     const float* target;       // [N][H][W] class ids as float
     const float* has_target;   // [N]
     const float* class_weight; // [C] or nullptr
+    const float* pixel_weight; // [N][H][W] or nullptr (the '#WEIGHT-MAP' target of the head; ignored when class_weight is given)
     int N, H, W, C;
     float ce_w, dice_w, head_w;
     int pc_mode;
@@ -69,7 +70,7 @@ __device__ __forceinline__ float pixel_softmax(const LossParams& p, int n, int y
     const int t = (int)p.target[((long long)n * p.H + y) * p.W + x];
     *t_out = t;
     *ce_out = (m + logf(se)) - v[t];
-    if (!p.class_weight) return 1.f;
+    if (!p.class_weight) return p.pixel_weight ? p.pixel_weight[((long long)n * p.H + y) * p.W + x] : 1.f;
     return t > 0 ? p.class_weight[t] : 0.f;  // get_class_wmap: listed classes get their weight, background keeps its own value 0
 }
 
@@ -181,16 +182,27 @@ extern "C" size_t cerb_head_loss_workspace_bytes(int n, int h, int w) {
     return (size_t)(n * bps) * (1 + 3 * MAXC) * 4 + (size_t)(n + 2 * MAXC + 1) * 8 + 512;
 }
 
+extern "C" int cerb_head_loss_wmap(const float* logits, long long stride_n, long long stride_c, long long stride_y, long long stride_x, const float* target,
+                                   const float* has_target, int N, int H, int W, int C, const float* class_weight, const float* pixel_weight, float ce_weight,
+                                   float dice_weight, float head_weight, int patch_class_mode, float* loss_out, float* dlogits, void* ws, size_t ws_bytes,
+                                   void* hip_stream);
 extern "C" int cerb_head_loss(const float* logits, long long stride_n, long long stride_c, long long stride_y, long long stride_x, const float* target,
                               const float* has_target, int N, int H, int W, int C, const float* class_weight, float ce_weight, float dice_weight,
                               float head_weight, int patch_class_mode, float* loss_out, float* dlogits, void* ws, size_t ws_bytes, void* hip_stream) {
+    return cerb_head_loss_wmap(logits, stride_n, stride_c, stride_y, stride_x, target, has_target, N, H, W, C, class_weight, nullptr, ce_weight, dice_weight,
+                               head_weight, patch_class_mode, loss_out, dlogits, ws, ws_bytes, hip_stream);
+}
+extern "C" int cerb_head_loss_wmap(const float* logits, long long stride_n, long long stride_c, long long stride_y, long long stride_x, const float* target,
+                                   const float* has_target, int N, int H, int W, int C, const float* class_weight, const float* pixel_weight, float ce_weight,
+                                   float dice_weight, float head_weight, int patch_class_mode, float* loss_out, float* dlogits, void* ws, size_t ws_bytes,
+                                   void* hip_stream) {
     if (!logits || !target || !has_target || !ws || N <= 0 || H <= 0 || W <= 0 || C < 2 || C > MAXC) return cerb_set_error("cerb_head_loss: bad arguments");
     if (patch_class_mode && (H != 1 || W != 1)) return cerb_set_error("cerb_head_loss: Patch-Class logits are [N][C][1][1]");
     if (ws_bytes < cerb_head_loss_workspace_bytes(N, H, W)) return cerb_set_error("cerb_head_loss: workspace too small");
     hipStream_t st = (hipStream_t)hip_stream;
     LossParams p;
     p.logits = logits; p.sn = stride_n; p.sc = stride_c; p.sy = stride_y; p.sx = stride_x;
-    p.target = target; p.has_target = has_target; p.class_weight = class_weight;
+    p.target = target; p.has_target = has_target; p.class_weight = class_weight; p.pixel_weight = patch_class_mode ? nullptr : pixel_weight;
     p.N = N; p.H = H; p.W = W; p.C = C;
     p.ce_w = ce_weight; p.dice_w = dice_weight; p.head_w = head_weight; p.pc_mode = patch_class_mode;
     p.dlogits = dlogits; p.loss_out = loss_out;

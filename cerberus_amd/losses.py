@@ -14,9 +14,10 @@ PARAMSET_LOSS = {  # the reference's models/paramset.yml:13-31 (configuration da
 }
 
 
-def head_loss(head_name, logits, target, has_target, loss_opts=PARAMSET_LOSS, channels_last=False, with_grad=True):
+def head_loss(head_name, logits, target, has_target, loss_opts=PARAMSET_LOSS, channels_last=False, with_grad=True, pixel_weight=None):
     """logits: CUDA float32 [N, C, H, W] (or [N, H, W, C] with channels_last); target: CUDA float32 [N, H, W] class ids;
-    has_target: CUDA float32 [N].  -> (loss: 0-d CUDA float32, dlogits like logits or None)"""
+    has_target: CUDA float32 [N]; pixel_weight: the head's '#WEIGHT-MAP' target, CUDA float32 [N, H, W], or None (ones).
+    -> (loss: 0-d CUDA float32, dlogits like logits or None)"""
     if not torch.cuda.is_available():
         raise _lib.CerberusHipError("cerberus_amd needs a ROCm GPU; there is no CPU fallback")
     L = _lib.lib()
@@ -36,13 +37,14 @@ def head_loss(head_name, logits, target, has_target, loss_opts=PARAMSET_LOSS, ch
         for k, v in loss_opts["class_weight"][head_name].items():
             cw[int(k)] = float(v)
         cw = cw.to(logits.device)
+    pw = None if pixel_weight is None else pixel_weight.reshape(n, h, w).contiguous().float()
     dl = torch.empty_like(logits) if with_grad else None
     loss = torch.zeros((), dtype=torch.float32, device=logits.device)
     ws = torch.empty(int(L.cerb_head_loss_workspace_bytes(n, h, w)), dtype=torch.uint8, device=logits.device)
     st = torch.cuda.current_stream(logits.device).cuda_stream
     with torch.cuda.device(logits.device):
-        _lib.check(L.cerb_head_loss(logits.data_ptr(), sn, sc, sy, sx, target.data_ptr(), has_target.data_ptr(), n, h, w, c,
-                                    None if cw is None else cw.data_ptr(), float(info["loss"].get("ce", 0)), float(info["loss"].get("dice", 0)),
-                                    float(info["weight"]), int(head_name == "Patch-Class"), loss.data_ptr(), None if dl is None else dl.data_ptr(),
-                                    ws.data_ptr(), ws.numel(), C.c_void_p(st)))
+        _lib.check(L.cerb_head_loss_wmap(logits.data_ptr(), sn, sc, sy, sx, target.data_ptr(), has_target.data_ptr(), n, h, w, c,
+                                         None if cw is None else cw.data_ptr(), None if pw is None else pw.data_ptr(), float(info["loss"].get("ce", 0)),
+                                         float(info["loss"].get("dice", 0)), float(info["weight"]), int(head_name == "Patch-Class"), loss.data_ptr(),
+                                         None if dl is None else dl.data_ptr(), ws.data_ptr(), ws.numel(), C.c_void_p(st)))
     return loss, dl

@@ -192,12 +192,13 @@ class NetDesc(torch.nn.Module):
             _lib.check(_lib.lib().cerb_net_forward_train(h, C.byref(io), C.c_void_p(stream)))
         return res
 
-    def train_grads(self, tiles_u8, targets, has_target, loss_opts, dropout_keep=None, views=False):
+    def train_grads(self, tiles_u8, targets, has_target, loss_opts, dropout_keep=None, views=False, pixel_weights=None):
         """One step of the reference's train_step up to all_loss.backward() (models/run_desc.py:79-170): train-mode forward, the head
         losses, the backward pass.  targets: head key -> CUDA float [N, H, W] class ids ([N] for Patch-Class); has_target: head key ->
         CUDA float [N]; loss_opts: the reference's loss_kwargs (cerberus_amd.losses.PARAMSET_LOSS).
         -> (losses: head key -> float as train_step reports them, grads: state-dict key -> CUDA float tensor shaped like the parameter;
         under the keys of the BatchNorm buffers (running_mean / running_var) it holds the step's batch mean / unbiased batch variance).
+        pixel_weights: head key -> CUDA float [N, H, W], the head's '#WEIGHT-MAP' target (models/run_desc.py:111-117), optional.
         views=True returns tensors over the handle's own gradient memory instead of copies: valid until the next call on this network."""
         self.train(True)
         h = self._ensure_handle()
@@ -207,7 +208,7 @@ class NetDesc(torch.nn.Module):
         nd = len(self._decoders)
         dev = tiles_u8.device
         keep = []
-        tg, fl, cw = (C.c_void_p * nd)(), (C.c_void_p * nd)(), (C.c_void_p * nd)()
+        tg, fl, cw, pwm = (C.c_void_p * nd)(), (C.c_void_p * nd)(), (C.c_void_p * nd)(), (C.c_void_p * nd)()
         ce, dc, hw = (C.c_float * nd)(), (C.c_float * nd)(), (C.c_float * nd)()
         for i, (name, hname, och, key) in enumerate(self._decoders):
             if key not in targets:
@@ -215,6 +216,10 @@ class NetDesc(torch.nn.Module):
             t = targets[key].to(dev).float().contiguous()
             f = has_target[key].to(dev).float().contiguous()
             keep += [t, f]
+            if pixel_weights and key in pixel_weights and key != "Patch-Class":
+                pw_t = pixel_weights[key].to(dev).float().reshape(t.shape).contiguous()
+                keep.append(pw_t)
+                pwm[i] = pw_t.data_ptr()
             tg[i], fl[i] = t.data_ptr(), f.data_ptr()
             info = loss_opts["loss_info"][key]
             ce[i], dc[i], hw[i] = float(info["loss"].get("ce", 0)), float(info["loss"].get("dice", 0)), float(info["weight"])
@@ -240,6 +245,7 @@ class NetDesc(torch.nn.Module):
         present = [k for k in targets if bool((has_target[k] > 0).any())]
         trained = (C.c_int * nd)(*[int(any(name in t for t in present)) for name, _, _, _ in self._decoders])
         io.decoder_trained = trained
+        io.pixel_weight = pwm
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             _lib.check(L.cerb_net_train_grads(h, C.byref(io), C.c_void_p(stream)))

@@ -83,15 +83,18 @@ def train_step(batch_data, run_info, dist=None, world_size=1, dropout_keep=None)
     has = batch.pop("dummy_target")
     dev = torch.device("cuda", torch.cuda.current_device())
     targets, flags = OrderedDict(), OrderedDict()
+    wmaps = OrderedDict()
     for k, v in batch.items():
-        if "#WEIGHT-MAP" in k:
-            raise NotImplementedError("per-pixel weight maps (%s) are not on the HIP path yet" % k)
+        if k.endswith("#WEIGHT-MAP"):  # models/run_desc.py:111-117: "<head>#WEIGHT-MAP" multiplies that head's per-pixel cross-entropy
+            t = torch.as_tensor(v).float()
+            wmaps[k[: -len("#WEIGHT-MAP")]] = t.reshape(t.shape[0], t.shape[1], t.shape[2]).to(dev)
+            continue
         t = torch.as_tensor(v).float()
         targets[k] = (t.reshape(t.shape[0]) if k == "Patch-Class" else t.reshape(t.shape[0], t.shape[1], t.shape[2])).to(dev)
         flags[k] = torch.from_numpy(np.any(np.asarray(has) == k, axis=-1).astype(np.float32)).to(dev)
     if dropout_keep is None and "Patch-Class" in targets:  # nn.Dropout(p=0.3) of the Patch-Class branch (models/net_desc.py:70)
         dropout_keep = torch.rand((img.shape[0], 512), device=dev) >= 0.3
-    losses, grads = model.train_grads(torch.as_tensor(img).to(dev), targets, flags, loss_opts, dropout_keep, views=True)
+    losses, grads = model.train_grads(torch.as_tensor(img).to(dev), targets, flags, loss_opts, dropout_keep, views=True, pixel_weights=wmaps)
     buf_keys = [k for k in grads if k.endswith("running_mean") or k.endswith("running_var")]
     stats = OrderedDict((k, grads.pop(k)) for k in buf_keys)
     allreduce_grads(grads, dist, world_size)

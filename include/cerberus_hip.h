@@ -235,6 +235,8 @@ typedef struct cerb_train_step_io {
     float* const* logits;
     const int* decoder_trained;  /* host int per decoder or NULL (= all): 0 reproduces a decoder outside train_decoder_list, whose
                                     gradients stay inside each of its blocks (models/net_desc.py:182 + conv_layers.py:44-53) */
+    const float* const* pixel_weight; /* NULL, or per decoder NULL / device float [n][h][w]: the head's "#WEIGHT-MAP" target
+                                         (models/run_desc.py:111-117), see cerb_head_loss_wmap */
 } cerb_train_step_io;
 int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io, void* hip_stream);
 int cerb_net_grad_lookup(cerb_net* net, const char* key, float** dev_ptr, long long* numel);
@@ -263,6 +265,14 @@ int cerb_head_loss(const float* logits, long long stride_n, long long stride_c, 
                    const float* target, const float* has_target, int n, int h, int w, int c, const float* class_weight,
                    float ce_weight, float dice_weight, float head_weight, int patch_class_mode, float* loss_out,
                    float* dlogits, void* ws, size_t ws_bytes, void* hip_stream);
+
+/* The same with the head's per-pixel weight map (loader/targets.py "#WEIGHT-MAP" channel; models/run_desc.py:111-117,150): the pixel's
+ * cross-entropy is multiplied by pixel_weight[n][y][x] (device float [N][H][W] or NULL = ones).  As in the reference, class weights
+ * (TYPE heads) REPLACE the map, and the Patch-Class head has none. */
+int cerb_head_loss_wmap(const float* logits, long long stride_n, long long stride_c, long long stride_y, long long stride_x,
+                        const float* target, const float* has_target, int n, int h, int w, int c, const float* class_weight,
+                        const float* pixel_weight, float ce_weight, float dice_weight, float head_weight, int patch_class_mode,
+                        float* loss_out, float* dlogits, void* ws, size_t ws_bytes, void* hip_stream);
 
 int cerb_event_create(void** ev);
 int cerb_event_record(void* ev, void* hip_stream);

@@ -46,7 +46,7 @@ from models.run_desc import train_step  # noqa: E402  (reference)
 from cerberus_amd.weights import default_model_kwargs, make_state_dict  # noqa: E402
 
 
-def run_case(prefix, nuclei_type_weight, store):
+def run_case(prefix, nuclei_type_weight, store, weight_maps=False):
     torch.manual_seed(0)
     torch.set_num_threads(8)
     rs = np.random.RandomState(11)
@@ -70,6 +70,11 @@ def run_case(prefix, nuclei_type_weight, store):
             t[:, :8] = 0
         targets[h] = t.astype(np.float32)
         batch[h] = torch.from_numpy(targets[h])
+    wmap_heads = ("Gland-INST", "Nuclei-INST") if weight_maps else ()
+    for h in wmap_heads:  # loader/targets.py:55-57: 1 + w0 exp(-d^2 / 2) outside the instances, 1 inside -- here any positive map serves
+        wm = (1.0 + 4.0 * rs.rand(N, H, H, 1) * (targets[h] == 0)).astype(np.float32)
+        batch[h + "#WEIGHT-MAP"] = torch.from_numpy(wm)
+        store["wmap/weight_map/" + h] = wm
     # which sample carries which target: sample 1 has no gland annotation, sample 2 no nuclei types (dummy targets there)
     has = np.full((N, len(heads)), None, dtype=object)
     for j, h in enumerate(heads):
@@ -108,7 +113,13 @@ def run_case(prefix, nuclei_type_weight, store):
             assert np.array_equal(store["logits/" + h], lg.detach().numpy())
         store["logits/" + h] = lg.detach().numpy()                          # NCHW, as the reference's forward returns them
         g = lg.grad.numpy() if lg.grad is not None else np.zeros_like(lg.detach().numpy())
-        if prefix == "paramset/" or h == "Nuclei-TYPE":                     # the other heads' gradients do not depend on the case
+        if prefix == "wmap/":  # only the heads with a weight map differ from the paramset case
+            if h in wmap_heads:
+                store[prefix + "dlogits/" + h] = g
+                assert not np.array_equal(store["paramset/dlogits/" + h], g)
+            else:
+                assert np.array_equal(store["paramset/dlogits/" + h], g), h
+        elif prefix == "paramset/" or h == "Nuclei-TYPE":                   # the other heads' gradients do not depend on the case
             store[prefix + "dlogits/" + h] = g
         else:
             assert np.array_equal(store["paramset/dlogits/" + h], g)
@@ -145,6 +156,7 @@ def main():
     store = {}
     run_case("paramset/", None, store)
     run_case("typew1/", 1.0, store)
+    run_case("wmap/", None, store, weight_maps=True)
     path = os.path.join(ROOT, "tests", "golden", "train_loss.npz")
     np.savez_compressed(path, **store)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")

@@ -19,12 +19,15 @@ PARAMSET_LOSS = {  # models/paramset.yml:13-31
 }
 
 
-def head_loss(head_name, logits_nchw, target_nhw1, has_target, loss_opts=PARAMSET_LOSS, n_classes=None):
-    """-> (loss value as train_step reports it = weighted head loss, d(that)/d(logits) as float32 NCHW numpy)"""
+def head_loss(head_name, logits_nchw, target_nhw1, has_target, loss_opts=PARAMSET_LOSS, n_classes=None, weight_map_nhw1=None):
+    """weight_map_nhw1: the head's '#WEIGHT-MAP' target (models/run_desc.py:111-117) or None.
+    -> (loss value as train_step reports it = weighted head loss, d(that)/d(logits) as float32 NCHW numpy)"""
     pred = torch.tensor(np.asarray(logits_nchw), dtype=torch.float32, requires_grad=True)
     true = torch.tensor(np.asarray(target_nhw1), dtype=torch.float32).permute(0, 3, 1, 2).contiguous()  # NCHW like :60-62
     flag = torch.tensor(np.asarray(has_target).astype(np.float32))
     wmap = torch.ones_like(true)
+    if weight_map_nhw1 is not None:
+        wmap = torch.tensor(np.asarray(weight_map_nhw1), dtype=torch.float32).permute(0, 3, 1, 2).contiguous()
     binary = None
     if head_name in ("Nuclei-TYPE", "Gland-TYPE"):
         binary = (true > 0).float()

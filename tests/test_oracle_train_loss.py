@@ -16,7 +16,7 @@ def gold():
     return np.load(os.path.join(ROOT, "tests", "golden", "train_loss.npz"))
 
 
-@pytest.mark.parametrize("case", ["paramset/", "typew1/"])
+@pytest.mark.parametrize("case", ["paramset/", "typew1/", "wmap/"])
 def test_head_losses_and_logit_gradients_match_the_reference_train_step(gold, case):
     opts = copy.deepcopy(train_ref.PARAMSET_LOSS)
     if case == "typew1/":
@@ -25,7 +25,8 @@ def test_head_losses_and_logit_gradients_match_the_reference_train_step(gold, ca
     for j, h in enumerate(gold["heads"]):
         h = str(h)
         assert gold[case + "loss_weight"][j] == opts["loss_info"][h]["weight"]
-        loss, grad = train_ref.head_loss(h, gold["logits/" + h], gold["target/" + h], gold["has_target"][:, j], opts)
+        wm = gold["wmap/weight_map/" + h] if case == "wmap/" and "wmap/weight_map/" + h in gold.files else None  # "<head>#WEIGHT-MAP" targets
+        loss, grad = train_ref.head_loss(h, gold["logits/" + h], gold["target/" + h], gold["has_target"][:, j], opts, weight_map_nhw1=wm)
         exp = float(gold[case + "loss/" + h])
         assert abs(loss - exp) <= 2e-6 * max(1.0, abs(exp)), (h, loss, exp)
         gkey = case + "dlogits/" + h if case + "dlogits/" + h in gold.files else "paramset/dlogits/" + h

@@ -18,7 +18,7 @@ def gold():
     return np.load(os.path.join(ROOT, "tests", "golden", "train_loss.npz"))
 
 
-@pytest.mark.parametrize("case", ["paramset/", "typew1/"])
+@pytest.mark.parametrize("case", ["paramset/", "typew1/", "wmap/"])
 @pytest.mark.parametrize("channels_last", [False, True])
 def test_head_loss_and_gradient_vs_reference_train_step(gold, case, channels_last):
     opts = copy.deepcopy(PARAMSET_LOSS)
@@ -32,7 +32,10 @@ def test_head_loss_and_gradient_vs_reference_train_step(gold, case, channels_las
             lg = lg.permute(0, 2, 3, 1).contiguous()
         tgt = torch.from_numpy(gold["target/" + h][..., 0]).cuda()
         flag = torch.from_numpy(gold["has_target"][:, j].astype(np.float32)).cuda()
-        loss, dl = head_loss(h, lg, tgt, flag, opts, channels_last=channels_last)
+        wm = None
+        if case == "wmap/" and "wmap/weight_map/" + h in gold.files:  # the head's "#WEIGHT-MAP" target of the reference's batch
+            wm = torch.from_numpy(gold["wmap/weight_map/" + h][..., 0]).cuda()
+        loss, dl = head_loss(h, lg, tgt, flag, opts, channels_last=channels_last, pixel_weight=wm)
         exp = float(gold[case + "loss/" + h])
         assert abs(float(loss) - exp) <= 1e-4 * max(1.0, abs(exp)), (h, float(loss), exp)  # the bar of north_star: 1e-4
         assert abs(float(loss) - exp) <= 5e-6 * max(1.0, abs(exp)), (h, float(loss), exp)  # what it actually reaches
@@ -193,3 +196,30 @@ def test_whole_train_step_vs_reference(gold):
     # a second step runs on the re-packed weights
     res2 = train_step(batch, ({"net": {"desc": m, "optimizer": opt, "extra_info": {"loss": PARAMSET_LOSS}}}, None), dropout_keep=keep)
     assert np.isfinite(res2["EMA"]["overall_loss"]) and res2["EMA"]["overall_loss"] != res["EMA"]["overall_loss"]
+
+
+def test_train_step_with_weight_maps_reports_the_reference_losses(gold):
+    """The reference's batch protocol with "<head>#WEIGHT-MAP" entries (loader/targets.py, models/run_desc.py:111-117) through
+    cerberus_amd.train.train_step: every reported loss against the reference's own train_step on the same batch."""
+    from cerberus_amd.net_desc import create_model
+    from cerberus_amd.train import Adam, train_step
+    from cerberus_amd.weights import default_model_kwargs, make_state_dict
+
+    m = create_model(**default_model_kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(int(gold["weight_seed"])).items()}, strict=True)
+    heads = [str(h) for h in gold["heads"]]
+    has = np.full(gold["has_target"].shape, None, dtype=object)
+    for j, h in enumerate(heads):
+        has[gold["has_target"][:, j], j] = h
+    batch = {"img": torch.from_numpy(gold["img"]), "dummy_target": has}
+    for h in heads:
+        batch[h] = torch.from_numpy(gold["target/" + h])
+        if "wmap/weight_map/" + h in gold.files:
+            batch[h + "#WEIGHT-MAP"] = torch.from_numpy(gold["wmap/weight_map/" + h])
+    keep = torch.from_numpy(gold["step/dropout_mask"].reshape(int(gold["N"]), 512)).cuda()
+    res = train_step(batch, ({"net": {"desc": m, "optimizer": Adam(lr=1.0e-3), "extra_info": {"loss": PARAMSET_LOSS}}}, None), dropout_keep=keep)
+    for h in heads:
+        exp = float(gold["wmap/loss/" + h])
+        assert abs(res["EMA"][h + "_loss"] - exp) <= 1e-4 * max(1.0, abs(exp)), (h, res["EMA"][h + "_loss"], exp)
+    assert abs(res["EMA"]["overall_loss"] - float(gold["wmap/overall_loss"])) <= 2e-4
+    assert abs(float(gold["wmap/overall_loss"]) - float(gold["paramset/overall_loss"])) > 0.1  # the maps matter
