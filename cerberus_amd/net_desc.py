@@ -54,6 +54,10 @@ class NetDesc(torch.nn.Module):
         if encoder_backbone_name != "resnet34":
             # the other backbones are out of scope of the MI355X path
             raise NotImplementedError("cerberus_amd implements encoder_backbone_name='resnet34' only, got %r" % (encoder_backbone_name,))
+        self._init_kwargs = dict(encoder_backbone_name=encoder_backbone_name, backbone_imagenet_pretrained=backbone_imagenet_pretrained,
+                                 fullnet_custom_pretrained=fullnet_custom_pretrained, decoder_kwargs=decoder_kwargs, considered_tasks=list(considered_tasks),
+                                 subtype_gland=subtype_gland, subtype_nuclei=subtype_nuclei)
+        self._param_version = 0  # bumped whenever the parameters change (load_state_dict, optimiser step)
         self.encoder_backbone_name = encoder_backbone_name
         self.net_code = encoder_backbone_name[:3]
         self.considered_tasks = list(considered_tasks)
@@ -102,7 +106,17 @@ class NetDesc(torch.nn.Module):
         if errors:
             raise RuntimeError("Error(s) in loading state_dict for NetDesc:\n\t" + "\n\t".join(errors))
         self._sd = new_sd
-        self._release()
+        self._param_version += 1
+        for stale in ("_dev_params", "_dev_flat", "_dev_layout"):  # the optimiser's device copies (cerberus_amd.train) follow the state dict
+            if hasattr(self, stale):
+                delattr(self, stale)
+        if self._handle is not None:  # same architecture, new values: re-pack in place (workspaces stay)
+            try:
+                _lib.check(_lib.lib().cerb_net_begin_reload(self._handle))
+                self._load_and_finalize(self._handle)
+            except Exception:
+                self._release()
+                raise
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
     # ---- nn.Module conveniences ----------------------------------------------------------------------------
@@ -274,6 +288,7 @@ class NetDesc(torch.nn.Module):
     def load_updated_parameters(self, dev_params, flat=None, layout=None):
         """After an optimiser step: take the updated parameters (key -> CUDA tensor) into the state dict and re-pack the weights of the device handle in
         place (conv weights are laid out by device kernels from the raw copies; activation workspaces and the training tape are kept)."""
+        self._param_version += 1
         if flat is not None:  # dev_params are views of one flat buffer, layout = [(key, offset, numel, shape)]: one device -> host copy
             host = flat.detach().cpu()
             for k, o, n, shp in layout:

@@ -118,3 +118,52 @@ def train_step(batch_data, run_info, dist=None, world_size=1, dropout_keep=None)
     ema = OrderedDict(("%s_loss" % k, v) for k, v in losses.items())
     ema["overall_loss"] = float(sum(losses.values()))
     return {"EMA": ema}
+
+
+def _eval_twin(model):
+    """valid_step runs the network in eval mode (running statistics folded into the convolutions): a handle packed for training
+    cannot serve that, so a model in training mode gets an inference twin that is refreshed whenever the parameters have changed."""
+    if not getattr(model, "_train_packing", False):
+        return model
+    from .net_desc import NetDesc  # noqa: F401  (type of the twin)
+
+    version = getattr(model, "_param_version", 0)
+    twin = getattr(model, "_valid_twin", None)
+    if twin is None or model._valid_twin_version != version:
+        if twin is None:
+            twin = model.__class__(**model._init_kwargs)
+        twin.load_state_dict(model.state_dict(), strict=True)
+        model._valid_twin, model._valid_twin_version = twin, version
+    return twin
+
+
+def valid_step(batch_data, run_info):
+    """The reference's valid_step (models/run_desc.py:332-436): eval-mode forward of the whole batch at full size and the per-head
+    read-outs -- '*-INST' softmax channels 1: , '*-TYPE' argmax, 'Patch-Class' argmax spread over the tile -- returned on the host as
+    {'raw': {'img', 'true', 'pred', 'dummy', 'channel_info'}}.  Read-outs come from the inference kernels (cerb_net_forward with the
+    output window = the tile).  Quirks kept: torch.squeeze on every array, and when a sample carries a Patch-Class target the dense
+    heads' 'true' maps pass through F.interpolate in NHWC order, which turns [N, H, W, 1] into [N, H, H, W] (:418-421)."""
+    run_info, _ = run_info
+    model = run_info["net"]["desc"]
+    batch = dict(batch_data)
+    img = torch.as_tensor(batch.pop("img"))
+    has = np.asarray(batch.pop("dummy_target"))
+    tgt_names = list(np.unique(has[has != None]))  # noqa: E711  (object array, as in the reference)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n, h, w = int(img.shape[0]), int(img.shape[1]), int(img.shape[2])
+    tiles = img.to(dev).float().to(torch.uint8).contiguous()  # the reference computes on float32 of the input and hands back .byte()
+    pred_dev = _eval_twin(model).infer_tiles(tiles, [h, w])
+    pc_in_targets = "Patch-Class" in tgt_names
+    pred, true = {}, {}
+    for key, p in pred_dev.items():
+        pred[key] = np.squeeze(p.cpu().numpy())
+        t = torch.as_tensor(batch[key]).float().numpy()  # NHWC, one channel
+        if key == "Patch-Class":
+            t = np.broadcast_to(t.reshape(n, 1, 1), (n, h, w))
+        elif pc_in_targets:  # F.interpolate(nearest, size = tile) over NHWC read as NCHW: [N, H, W, 1] -> [N, H, H, W], last axis repeated
+            t = np.broadcast_to(t[:, :, :, 0][:, :, :, None], (n, t.shape[1], t.shape[2], w))
+            if t.shape[2] != h:
+                t = t[:, :, (np.arange(h) * t.shape[2] // h), :]
+        true[key] = np.squeeze(np.array(t, dtype=np.float32))
+    info = OrderedDict((name, {hname: och}) for name, hname, och, _ in model._decoders)
+    return {"raw": {"img": tiles.cpu().numpy(), "true": true, "pred": pred, "dummy": has, "channel_info": info}}

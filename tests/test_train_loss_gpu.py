@@ -223,3 +223,40 @@ def test_train_step_with_weight_maps_reports_the_reference_losses(gold):
         assert abs(res["EMA"][h + "_loss"] - exp) <= 1e-4 * max(1.0, abs(exp)), (h, res["EMA"][h + "_loss"], exp)
     assert abs(res["EMA"]["overall_loss"] - float(gold["wmap/overall_loss"])) <= 2e-4
     assert abs(float(gold["wmap/overall_loss"]) - float(gold["paramset/overall_loss"])) > 0.1  # the maps matter
+
+
+@pytest.mark.parametrize("case", ["pc/", "nopc/"])
+def test_valid_step_vs_reference(case):
+    """cerberus_amd.train.valid_step against the reference's own valid_step (tests/golden/valid_step.npz, oracle/gen_golden_valid_step.py):
+    per-head predictions (probabilities to 1e-4, class maps equal except where the two best logits tie within float noise) and the 'true'
+    arrays with the reference's shapes, including the [N, H, H, W] one that F.interpolate makes of NHWC targets when Patch-Class is present."""
+    from cerberus_amd.net_desc import create_model
+    from cerberus_amd.train import valid_step
+    from cerberus_amd.weights import default_model_kwargs, make_state_dict
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "valid_step.npz"))
+    heads = [str(h) for h in g["heads"]]
+    has = np.full(g[case + "has_target"].shape, None, dtype=object)
+    for j, h in enumerate(heads):
+        has[g[case + "has_target"][:, j], j] = h
+    batch = {"img": torch.from_numpy(g[case + "img"]), "dummy_target": has}
+    for h in heads:
+        batch[h] = torch.from_numpy(g[case + "target/" + h])
+    for mode in ("eval", "train"):  # a model in training mode validates through its inference twin
+        m = create_model(**default_model_kwargs())
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(int(g["weight_seed"])).items()}, strict=True)
+        if mode == "train":
+            m.train()
+            m.forward_train(torch.from_numpy(g[case + "img"]).cuda())
+        raw = valid_step(dict(batch), ({"net": {"desc": m}}, None))["raw"]
+        assert np.array_equal(raw["img"], g[case + "img"]) and raw["dummy"] is not None
+        assert list(raw["channel_info"].keys()) == list(m.decoder_info_list.keys())
+        for h in heads:
+            exp, got = g[case + "pred/" + h], raw["pred"][h]
+            assert got.shape == exp.shape, (h, got.shape, exp.shape)
+            if h.endswith("INST"):
+                assert got.dtype == np.float32 and np.abs(got - exp).max() <= 1e-4, (h, np.abs(got - exp).max())
+            else:
+                assert (got != exp).mean() <= 1e-3, (h, (got != exp).mean())
+            te, tg = g[case + "true/" + h], raw["true"][h]
+            assert tg.shape == te.shape and np.array_equal(tg, te), (h, tg.shape, te.shape)
