@@ -38,6 +38,22 @@ class Adam(object):
                                             self.eps, self.step_count, C.c_void_p(st)))
 
 
+class StepLR(object):
+    """torch.optim.lr_scheduler.StepLR over cerberus_amd.train.Adam (models/opt.py:55-58: StepLR(opt, 75000), gamma 0.1):
+    after `step()` number e the rate is base_lr * gamma ** (e // step_size)."""
+
+    def __init__(self, optimizer, step_size, gamma=0.1):
+        self.optimizer, self.step_size, self.gamma = optimizer, int(step_size), float(gamma)
+        self.base_lr, self.last_epoch = optimizer.lr, 0
+
+    def step(self):
+        self.last_epoch += 1
+        self.optimizer.lr = self.base_lr * self.gamma ** (self.last_epoch // self.step_size)
+
+    def get_last_lr(self):
+        return [self.optimizer.lr]
+
+
 def allreduce_grads(grads, dist, world_size, bucket_bytes=32 << 20):
     """Average gradients over ranks in flat buckets (a ring all-reduce over xGMI is bound per link: few large messages beat 300 small
     ones).  grads: key -> tensor (any device); in place.  dist: torch.distributed or None."""

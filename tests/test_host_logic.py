@@ -338,3 +338,21 @@ def test_bucketed_gradient_allreduce_gloo(world):
         p.join(120)
         assert p.exitcode == 0
     assert ret.get(timeout=10) is True
+
+
+def test_steplr_follows_torch():
+    """cerberus_amd.train.StepLR (models/opt.py:55-58 binds torch's StepLR to the optimiser) against torch.optim.lr_scheduler.StepLR."""
+    import torch
+
+    from cerberus_amd.train import Adam, StepLR
+
+    prm = [torch.nn.Parameter(torch.zeros(1))]
+    topt = torch.optim.Adam(prm, lr=1.0e-3, betas=(0.9, 0.999))
+    tsch = torch.optim.lr_scheduler.StepLR(topt, 7)
+    opt = Adam(lr=1.0e-3)
+    sch = StepLR(opt, 7)
+    for _ in range(30):
+        topt.step()
+        tsch.step()
+        sch.step()
+        assert abs(sch.get_last_lr()[0] - tsch.get_last_lr()[0]) <= 1e-12 * tsch.get_last_lr()[0] + 1e-18
