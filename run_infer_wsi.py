@@ -57,12 +57,20 @@ def main(argv=None):
     from cerberus_amd.wsi import SlabUploader, WSIRunner, build_wsi_inst_info, synth_slide, write_dat
 
     dist = None
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if os.environ.get("CERB_DIST_BACKEND", "nccl") == "gloo":  # host-staged collectives (cerberus_amd/hostdist.py)
+            from cerberus_amd.hostdist import HostStagedDist
+
+            local = local % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local)
+            dist.init_process_group("gloo")
+            dist = HostStagedDist(dist)
+        else:  # "nccl" = RCCL over xGMI, one process per GPU
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     out_dir = args["--output_dir"]
     os.makedirs(out_dir, exist_ok=True)
 

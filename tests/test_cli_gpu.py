@@ -161,3 +161,48 @@ def test_bench_train_mode_single_and_two_ranks():
                "bench.py", "--mode", "train", "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo"])
     assert two["n_gpus"] == 2 and abs(two["value"] - 2 * 16 / (two["ms_per_step"] * 1e-3)) / two["value"] < 0.01
     assert 0 < two["config"]["last_overall_loss"] < 100
+
+
+def test_run_infer_wsi_cli_two_ranks_equals_one_rank(tmp_path):
+    """run_infer_wsi.py end to end under torch.distributed.run with two ranks (both on this box's GPU, CERB_DIST_BACKEND=gloo = the
+    host-staged collectives of cerberus_amd/hostdist.py) against the single-process run of the same slide.
+    With a tissue mask the bands are gathered to the root, which labels them: every output is identical.  Without one the bands are
+    labelled where they are (halo exchange, slide-global ids, label bands gathered): the stitched class maps are identical; the label
+    maps of this random-weight network are slide-sized blobs, beyond the halo the band protocol resolves (tests/test_host_logic.py and
+    tests/tools/dev_fuzz_drivers.py check that protocol on structured maps), so only their presence and shape are checked here."""
+    import joblib
+    from PIL import Image
+
+    spec, msk = tmp_path / "slides", tmp_path / "masks"
+    spec.mkdir()
+    msk.mkdir()
+    (spec / "s1.txt").write_text("synthetic:1500x1100:9")
+    m = np.zeros((150, 110), np.uint8)
+    m[10:140, 8:70] = 255
+    Image.fromarray(np.stack([m] * 3, -1)).save(str(msk / "s1.png"))
+    base = ["--input_dir=%s" % spec, "--wsi_file_ext=.txt", "--batch_size=6", "--patch_input_shape=256", "--patch_output_shape=256", "--save_label_maps"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CERB_DIST_BACKEND="gloo")
+    port = 29547
+    for tag, extra in (("mask", ["--msk_dir=%s" % msk]), ("nomask", [])):
+        one, two = tmp_path / (tag + "1"), tmp_path / (tag + "2")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--output_dir=%s" % one] + base + extra, capture_output=True, text=True,
+                           timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                            str(port), os.path.join(ROOT, "run_infer_wsi.py"), "--output_dir=%s" % two] + base + extra, capture_output=True, text=True,
+                           timeout=900, cwd=ROOT, env=env)
+        port += 1
+        assert r.returncode == 0, r.stderr[-3000:]
+        za, zb = np.load(str(one / "s1.npz")), np.load(str(two / "s1.npz"))
+        assert set(za.files) == set(zb.files)
+        for k in za.files:
+            assert za[k].shape == zb[k].shape, k
+            if tag == "mask" or k not in ("Nuclei", "Gland", "Lumen"):
+                assert np.array_equal(za[k], zb[k]), (tag, k)
+        da, db = joblib.load(str(one / "dat" / "s1.dat")), joblib.load(str(two / "dat" / "s1.dat"))
+        assert set(da.keys()) == set(db.keys())
+        if tag == "mask":
+            for t in ("Nuclei", "Gland", "Lumen"):
+                ca = sorted(tuple(np.round(d["centroid"], 3)) for d in da.get(t, {}).values())
+                cb = sorted(tuple(np.round(d["centroid"], 3)) for d in db.get(t, {}).values())
+                assert ca == cb, t

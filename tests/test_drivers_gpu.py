@@ -156,3 +156,75 @@ def test_images_sharing_batches_equal_images_alone(manager):
             for t in alone["inst"]:
                 assert torch.equal(alone["inst"][t], res["inst"][t]), (win, t)
             assert torch.equal(alone["pclass"], res["pclass"])
+
+
+def _gpu_shard_worker(rank, world, port, tissue, ret):
+    import os
+
+    import torch.distributed as dist
+
+    from cerberus_amd import shard_postproc as sp
+    from cerberus_amd import synth_maps as synth
+    from cerberus_amd.hostdist import HostStagedDist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H, W = 1536, 1024
+    m = synth.nuclei_maps(H, W, 31, 600.0, noise=0.02) if tissue == "Nuclei" else synth.blob_maps(H, W, 9, 60, 8.0, 30.0, rim=3.0, sharp=1.0, noise=0.02, holes=0.3)
+    bounds = [0, 700, H] if world == 2 else [0, 500, 1010, H]
+    band = torch.from_numpy(m[bounds[rank]:bounds[rank + 1]].copy()).cuda()
+    out, n_total, info = sp.run_distributed(band, bounds[rank], tissue, 192, 24, HostStagedDist(dist), 1.0 if tissue == "Nuclei" else 0.5)
+    ret.put((rank, out.cpu().numpy(), int(n_total), {k: int(v) for k, v in info.items() if k in ("n_truncated", "n_unresolved")}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,tissue", [(2, "Nuclei"), (3, "Gland")])
+def test_sharded_postproc_on_device_with_staged_collectives(world, tissue):
+    """shard_postproc.run_distributed with the DEVICE label / table / relabel kernels in every rank (the ranks share this box's GPU;
+    halo strips, counts and crossing-instance tables travel through cerberus_amd.hostdist) against the whole-map post-processing."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from cerberus_amd import synth_maps as synth
+    from cerberus_amd.postproc import postproc_device
+    from cerberus_amd.shard_postproc import same_partition
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_shard_worker, args=(r, world, port, tissue, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue
+    import time
+
+    got, t_end = [], time.time() + 300
+    while len(got) < world:
+        try:
+            got.append(ret.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() > t_end:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise AssertionError("a rank died or timed out: exit codes %s" % [p.exitcode for p in procs])
+    got.sort(key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    H, W = 1536, 1024
+    m = synth.nuclei_maps(H, W, 31, 600.0, noise=0.02) if tissue == "Nuclei" else synth.blob_maps(H, W, 9, 60, 8.0, 30.0, rim=3.0, sharp=1.0, noise=0.02, holes=0.3)
+    ref, info = postproc_device(torch.from_numpy(m).cuda(), tissue, 1.0 if tissue == "Nuclei" else 0.5)
+    ref = ref.cpu().numpy()
+    lab = np.concatenate([g[1] for g in got], axis=0)
+    assert all(g[3]["n_truncated"] == 0 and g[3]["n_unresolved"] == 0 for g in got), [g[3] for g in got]
+    n_ref = int(ref.max())
+    assert n_ref > 20 and got[0][2] == n_ref and lab.shape == ref.shape
+    assert same_partition(ref, lab)
