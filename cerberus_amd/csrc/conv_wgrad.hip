@@ -29,7 +29,11 @@ struct WgradParams {
 template <int KS, int STRIDE>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
     constexpr int T = KS * KS, PAD = KS / 2, XQ = (SEG - 1) * STRIDE + KS, X_FLOATS = KS * XQ * 64;
-    __shared__ __attribute__((aligned(16))) float lds[DY_FLOATS + X_FLOATS];
+    // PIPE: the next segment's operands are fetched into registers underneath this segment's MFMAs and dropped into the other LDS buffer
+    // (3x3 stride 2 would need 52 more registers for that: it keeps the single-buffer loop)
+    constexpr bool PIPE = STRIDE == 1;
+    constexpr int NBUF = PIPE ? 2 : 1, ND = DY_FLOATS / 4 / 256, NX = (X_FLOATS / 4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float lds[NBUF * (DY_FLOATS + X_FLOATS)];
     float* dyl = lds;
     float* xl = lds + DY_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -47,40 +51,99 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    for (long long s = slice; s < nseg; s += p.slices) {
-        const int sx = (int)(s % p.segs_per_row);
-        const long long ry = s / p.segs_per_row;
-        const int y = (int)(ry % p.Ho), n = (int)(ry / p.Ho);
-        const int x0 = sx * SEG;
-        __syncthreads();  // the previous segment's MFMAs have read their operands
-        // ---- stage dy: 32 px x 64 co ------------------------------------------------------------------------------------------------
-        for (int i = tid; i < DY_FLOATS / 4; i += 256) {
-            const int px = i >> 4, c4 = i & 15;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (x0 + px < p.Wo && 4 * c4 < co_valid) v = *reinterpret_cast<const f32x4*>(dyg + (((long long)n * p.Ho + y) * p.Wo + x0 + px) * p.Cout + 4 * c4);
-            *reinterpret_cast<f32x4*>(dyl + px * 64 + 4 * c4) = v;
-        }
-        // ---- stage x: the KS input rows and (SEG - 1) * STRIDE + KS input pixels the segment's taps read, 64 ci --------------------------------
-        for (int i = tid; i < X_FLOATS / 4; i += 256) {
-            const int c4 = i & 15, q = (i >> 4) % XQ, r = (i >> 4) / XQ;
-            const int yy = y * STRIDE + r - PAD, xx = x0 * STRIDE + q - PAD;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && 4 * c4 < ci_valid)
-                v = *reinterpret_cast<const f32x4*>(xg + (((long long)n * p.H + yy) * p.W + xx) * p.Cin + 4 * c4);
-            *reinterpret_cast<f32x4*>(xl + (r * XQ + q) * 64 + 4 * c4) = v;
+    if constexpr (PIPE) {
+        f32x4 rd[ND], rx[NX];
+        auto fetch = [&](long long s) {
+            const int sx = (int)(s % p.segs_per_row);
+            const long long ry = s / p.segs_per_row;
+            const int y = (int)(ry % p.Ho), n = (int)(ry / p.Ho);
+            const int x0 = sx * SEG;
+#pragma unroll
+            for (int u = 0; u < ND; ++u) {
+                const int i = tid + 256 * u, px = i >> 4, c4 = i & 15;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (x0 + px < p.Wo && 4 * c4 < co_valid) v = *reinterpret_cast<const f32x4*>(dyg + (((long long)n * p.Ho + y) * p.Wo + x0 + px) * p.Cout + 4 * c4);
+                rd[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < NX; ++u) {
+                const int i = tid + 256 * u, c4 = i & 15, q = (i >> 4) % XQ, r = (i >> 4) / XQ;
+                const int yy = y * STRIDE + r - PAD, xx = x0 * STRIDE + q - PAD;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (i < X_FLOATS / 4 && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && 4 * c4 < ci_valid)
+                    v = *reinterpret_cast<const f32x4*>(xg + (((long long)n * p.H + yy) * p.W + xx) * p.Cin + 4 * c4);
+                rx[u] = v;
+            }
+        };
+        auto drop = [&](int buf) {
+            float* d = lds + buf * (DY_FLOATS + X_FLOATS);
+#pragma unroll
+            for (int u = 0; u < ND; ++u) *reinterpret_cast<f32x4*>(d + 4 * (tid + 256 * u)) = rd[u];  // dyl[px * 64 + 4 c4], i = px * 16 + c4
+#pragma unroll
+            for (int u = 0; u < NX; ++u)
+                if (tid + 256 * u < X_FLOATS / 4) *reinterpret_cast<f32x4*>(d + DY_FLOATS + 4 * (tid + 256 * u)) = rx[u];  // xl[(r * XQ + q) * 64 + 4 c4]
+        };
+        long long s = slice;
+        int buf = 0;
+        if (s < nseg) {
+            fetch(s);
+            drop(0);
         }
         __syncthreads();
-        // ---- 16 pixel pairs x 9 taps ------------------------------------------------------------------------------------------------------
+        for (; s < nseg; s += p.slices) {
+            const bool more = s + p.slices < nseg;
+            if (more) fetch(s + p.slices);
+            const float* dl = lds + buf * (DY_FLOATS + X_FLOATS);
+            const float* xq = dl + DY_FLOATS;
 #pragma unroll 4
-        for (int pp = 0; pp < SEG / 2; ++pp) {
-            const float a = dyl[(2 * pp + k) * 64 + 32 * ch + j];
+            for (int pp = 0; pp < SEG / 2; ++pp) {
+                const float a = dl[(2 * pp + k) * 64 + 32 * ch + j];
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const float b = xl[((t / KS) * XQ + (2 * pp + k) * STRIDE + (t % KS)) * 64 + 32 * ih + j];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                for (int t = 0; t < T; ++t) {
+                    const float b = xq[((t / KS) * XQ + (2 * pp + k) * STRIDE + (t % KS)) * 64 + 32 * ih + j];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                }
+            }
+            if (more) drop(buf ^ 1);
+            __syncthreads();  // the other buffer is complete; this one has been read by every wave
+            buf ^= 1;
+        }
+    } else {
+    for (long long s = slice; s < nseg; s += p.slices) {
+            const int sx = (int)(s % p.segs_per_row);
+            const long long ry = s / p.segs_per_row;
+            const int y = (int)(ry % p.Ho), n = (int)(ry / p.Ho);
+            const int x0 = sx * SEG;
+            __syncthreads();  // the previous segment's MFMAs have read their operands
+            // ---- stage dy: 32 px x 64 co ------------------------------------------------------------------------------------------------
+            for (int i = tid; i < DY_FLOATS / 4; i += 256) {
+                const int px = i >> 4, c4 = i & 15;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (x0 + px < p.Wo && 4 * c4 < co_valid) v = *reinterpret_cast<const f32x4*>(dyg + (((long long)n * p.Ho + y) * p.Wo + x0 + px) * p.Cout + 4 * c4);
+                *reinterpret_cast<f32x4*>(dyl + px * 64 + 4 * c4) = v;
+            }
+            // ---- stage x: the KS input rows and (SEG - 1) * STRIDE + KS input pixels the segment's taps read, 64 ci --------------------------------
+            for (int i = tid; i < X_FLOATS / 4; i += 256) {
+                const int c4 = i & 15, q = (i >> 4) % XQ, r = (i >> 4) / XQ;
+                const int yy = y * STRIDE + r - PAD, xx = x0 * STRIDE + q - PAD;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && 4 * c4 < ci_valid)
+                    v = *reinterpret_cast<const f32x4*>(xg + (((long long)n * p.H + yy) * p.W + xx) * p.Cin + 4 * c4);
+                *reinterpret_cast<f32x4*>(xl + (r * XQ + q) * 64 + 4 * c4) = v;
+            }
+            __syncthreads();
+            // ---- 16 pixel pairs x 9 taps ------------------------------------------------------------------------------------------------------
+    #pragma unroll 4
+            for (int pp = 0; pp < SEG / 2; ++pp) {
+                const float a = dyl[(2 * pp + k) * 64 + 32 * ch + j];
+    #pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const float b = xl[((t / KS) * XQ + (2 * pp + k) * STRIDE + (t % KS)) * 64 + 32 * ih + j];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                }
             }
         }
-    }
+}
     // ---- this slice's partial tile: part[slice][tile][tap][co 64][ci 64]; MFMA D layout: row = rq*8 + (lane>>5)*4 + e, column = lane & 31 ----
     float* o = p.part + ((long long)slice * tiles + tile) * T * 4096;
 #pragma unroll
