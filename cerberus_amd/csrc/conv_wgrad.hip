@@ -374,26 +374,41 @@ hipError_t cerb_launch_colsum(const float* d, long long group_stride, long long 
 // forward and its 96 -> 64 data gradient).  One wave = 32 rows x NC: v_mfma_f32_32x32x2_f32 with A = the rows (lane = row, half-wave = k parity block), so
 // each lane fetches its row as float4s and the k order is permuted to match (k = 8 j + 4 h + e; a sum does not care); B sits in LDS in that order, one
 // ds_read_b128 per four MFMAs.  Stores put 32 consecutive floats of one row per half-wave.
-template <int K, int NC, bool ACCUM>
+template <int K, int NC, bool ACCUM, bool EXACT>
 __global__ __launch_bounds__(256) void pw_mfma_kernel(const float* __restrict__ a, const float* __restrict__ w, int w_trans, const float* __restrict__ bias,
-                                                      float* __restrict__ out, long long rows) {
+                                                      float* __restrict__ out, long long rows, int k_rt, int nc_rt) {
+    const int k_real = EXACT ? K : k_rt, nc_real = EXACT ? NC : nc_rt;  // EXACT: the shape is the template's, all strides are constants
+    // K, NC: the padded GEMM (multiples of 8 / 32); k_real <= K columns of `a` and nc_real <= NC outputs exist (the heads' 96 -> 3 / 7 layer and
+    // its data gradient run here with zero padding: the layer is HBM-bound, the padded MFMAs are free)
     __shared__ __attribute__((aligned(16))) float Bs[K * NC];
     for (int i = threadIdx.x; i < K * NC; i += 256) {
         const int e = i & 3, n = (i >> 2) % NC, jh = (i >> 2) / NC;  // Bs[jh][n][e], jh = 2 j + h
         const int k = 4 * jh + e;                                    // = 8 j + 4 h + e
-        Bs[i] = w_trans ? w[n * K + k] : w[k * NC + n];
+        Bs[i] = (k < k_real && n < nc_real) ? (w_trans ? w[n * k_real + k] : w[k * nc_real + n]) : 0.f;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, n0 = lane & 31;
     const long long ntiles = (rows + 31) >> 5;
+    const bool vec = EXACT || (k_real & 3) == 0;  // float4 fetches need 16-byte aligned rows
     float bv[NC / 32];
 #pragma unroll
-    for (int nb = 0; nb < NC / 32; ++nb) bv[nb] = bias ? bias[nb * 32 + n0] : 0.f;
+    for (int nb = 0; nb < NC / 32; ++nb) bv[nb] = (bias && nb * 32 + n0 < nc_real) ? bias[nb * 32 + n0] : 0.f;
     for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
         const long long row = min(tile * 32 + n0, rows - 1);
         f32x4 av[K / 8];
 #pragma unroll
-        for (int j = 0; j < K / 8; ++j) av[j] = *reinterpret_cast<const f32x4*>(a + row * K + 8 * j + 4 * h);
+        for (int j = 0; j < K / 8; ++j) {
+            const int k0 = 8 * j + 4 * h;
+            if (vec) {
+                av[j] = k0 < k_real ? *reinterpret_cast<const f32x4*>(a + row * k_real + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                const float* ar = a + row * k_real + k0;
+                av[j].x = k0 < k_real ? ar[0] : 0.f;
+                av[j].y = k0 + 1 < k_real ? ar[1] : 0.f;
+                av[j].z = k0 + 2 < k_real ? ar[2] : 0.f;
+                av[j].w = k0 + 3 < k_real ? ar[3] : 0.f;
+            }
+        }
         f32x16 acc[NC / 32];
 #pragma unroll
         for (int nb = 0; nb < NC / 32; ++nb)
@@ -414,11 +429,12 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(const float* __restrict__ 
             const long long r = tile * 32 + 8 * (v >> 2) + 4 * h + (v & 3);
             if (r < rows) {
 #pragma unroll
-                for (int nb = 0; nb < NC / 32; ++nb) {
-                    float* p = out + r * NC + nb * 32 + n0;
-                    const float val = acc[nb][v] + bv[nb];
-                    *p = ACCUM ? *p + val : val;
-                }
+                for (int nb = 0; nb < NC / 32; ++nb)
+                    if (nb * 32 + n0 < nc_real) {
+                        float* p = out + r * nc_real + nb * 32 + n0;
+                        const float val = acc[nb][v] + bv[nb];
+                        *p = ACCUM ? *p + val : val;
+                    }
             }
         }
     }
@@ -427,8 +443,9 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(const float* __restrict__ 
 hipError_t cerb_launch_pw_mfma(const float* a, const float* w, int w_trans, const float* bias, float* out, long long rows, int K, int NC, int accumulate, hipStream_t st) {
     const long long ntiles = (rows + 31) / 32;
     const unsigned blocks = (unsigned)(ntiles / 4 < 1 ? 1 : (ntiles / 4 > 2048 ? 2048 : ntiles / 4));
-    if (K == 64 && NC == 96 && !accumulate) hipLaunchKernelGGL((pw_mfma_kernel<64, 96, false>), dim3(blocks), dim3(256), 0, st, a, w, w_trans, bias, out, rows);
-    else if (K == 96 && NC == 64 && accumulate) hipLaunchKernelGGL((pw_mfma_kernel<96, 64, true>), dim3(blocks), dim3(256), 0, st, a, w, w_trans, bias, out, rows);
+    if (K == 64 && NC == 96 && !accumulate) hipLaunchKernelGGL((pw_mfma_kernel<64, 96, false, true>), dim3(blocks), dim3(256), 0, st, a, w, w_trans, bias, out, rows, K, NC);
+    else if (K == 96 && NC == 64 && accumulate) hipLaunchKernelGGL((pw_mfma_kernel<96, 64, true, true>), dim3(blocks), dim3(256), 0, st, a, w, w_trans, bias, out, rows, K, NC);
+    else if (K == 96 && NC <= 32 && !accumulate) hipLaunchKernelGGL((pw_mfma_kernel<96, 32, false, false>), dim3(blocks), dim3(256), 0, st, a, w, w_trans, bias, out, rows, K, NC);
     else return hipErrorNotSupported;
     return hipGetLastError();
 }
