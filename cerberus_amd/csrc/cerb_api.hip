@@ -54,6 +54,9 @@ hipError_t cerb_launch_crop_gap_bwd(const float* dg, float* dx, int N, int H, in
 hipError_t cerb_launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step, hipStream_t st);
 size_t cerb_wgrad_workspace_bytes(int G, int N, int Ho, int Wo, int Cin, int Cout, int ks, int* slices_out);
 size_t cerb_stem_wgrad_workspace_bytes();
+hipError_t cerb_launch_pack_stem(const float* w_raw, float* out, hipStream_t st);
+hipError_t cerb_launch_adam_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* n, float lr, float b1,
+                                  float b2, float eps, int step, hipStream_t st);
 hipError_t cerb_launch_pack_conv(const float* w_raw, float* out, int cout, int cin, int ks, int chunk, hipStream_t st);
 hipError_t cerb_launch_pack_wino(const float* w_raw, float* out, int cout, int cin, int dgrad, hipStream_t st);
 hipError_t cerb_launch_dilate2(const float* dy, float* d, long long n, int H, int W, int C, hipStream_t st);
@@ -170,6 +173,10 @@ struct cerb_net {
     // backward pass (cerb_net_train_grads): raw weights in state-dict layout, per conv name, groups concatenated; the tape's buffers
     struct RawW { float* w = nullptr; float* b = nullptr; std::vector<std::string> wkeys, bkeys, bnkeys; };
     std::map<std::string, RawW> raw;
+    // handles packed for training: where each state-dict tensor lives verbatim on the device (cerb_net_update_params copies into these)
+    struct ParamSlot { float* dst; long long n; };
+    std::map<std::string, std::vector<ParamSlot>> param_slots;
+    float* stem_raw = nullptr;  // [64][3][7][7]
     std::vector<DevBuf> tape;
     size_t tape_pos = 0;
     float* zero_bias = nullptr;  // 512 zeros: the bias operand of the data-gradient convs
@@ -405,6 +412,10 @@ static int store_bn(cerb_net* net, const std::string& name, const std::vector<st
     d.C = ch;
     d.groups = (int)bnkeys.size();
     if (upload(net, ga, &d.gamma) || upload(net, be, &d.beta)) return 1;
+    for (size_t g = 0; g < bnkeys.size(); ++g) {
+        net->param_slots[bnkeys[g] + ".weight"].push_back({d.gamma + g * ch, ch});
+        net->param_slots[bnkeys[g] + ".bias"].push_back({d.beta + g * ch, ch});
+    }
     net->bn[name] = d;
     net->bn_keys[name] = bnkeys;
     return 0;
@@ -452,11 +463,18 @@ static int make_conv(cerb_net* net, const std::string& name, const std::vector<s
         cerb_net::RawW r;
         r.wkeys = wkeys; r.bkeys = bkeys; r.bnkeys = bnkeys;
         if (upload(net, rw, &r.w) || (!rb.empty() && upload(net, rb, &r.b))) return 1;
+        for (size_t g = 0; g < wkeys.size(); ++g) {
+            const long long nwg = (long long)cout * cin * ks * ks;
+            net->param_slots[wkeys[g]].push_back({r.w + g * nwg, nwg});
+            if (r.b) net->param_slots[bkeys[g]].push_back({r.b + g * cout, cout});
+        }
         net->raw[name] = r;
     }
     PackedConv pc;
     pc.cin = cin; pc.cout = cout; pc.ks = ks; pc.stride = stride; pc.groups = (int)wkeys.size();
     if (upload(net, bp, &pc.b)) return 1;
+    if (!net->fold_bn)
+        for (size_t g = 0; g < bkeys.size(); ++g) net->param_slots[bkeys[g]].push_back({pc.b + g * cout, cout});
     if (net->fold_bn) {
         if (upload(net, wp, &pc.w)) return 1;
         if (wino && upload(net, wwino, &pc.wino)) return 1;
@@ -514,6 +532,10 @@ extern "C" int cerb_net_finalize(cerb_net* net) {
                         wp[((ky * 12 + t) * 2 + s) * 64 + lane] = v;
                     }
         if (upload(net, wp, &net->stem_w) || upload(net, f.shift, &net->stem_b)) return 1;
+        if (!net->fold_bn) {
+            if (upload(net, w->data, &net->stem_raw)) return 1;
+            net->param_slots["backbone.conv1.weight"].push_back({net->stem_raw, 64 * 147});
+        }
     }
     // ---- residual trunk ---------------------------------------------------------------------------------------
     int inpl = 64;
@@ -580,6 +602,10 @@ extern "C" int cerb_net_finalize(cerb_net* net) {
                 float *r1, *rb1, *r2, *rb2;
                 if (upload(net, w1->data, &r1) || upload(net, b1->data, &rb1) || upload(net, w2->data, &r2) || upload(net, b2->data, &rb2)) return 1;
                 net->head_rw1.push_back(r1); net->head_rb1.push_back(rb1); net->head_rw2.push_back(r2); net->head_rb2.push_back(rb2);
+                net->param_slots[p + ".0.block.0.conv.weight"].push_back({r1, 96 * 64});
+                net->param_slots[p + ".0.block.0.conv.bias"].push_back({rb1, 96});
+                net->param_slots[p + ".1.conv.weight"].push_back({r2, (long long)d.out_ch * 96});
+                net->param_slots[p + ".1.conv.bias"].push_back({rb2, d.out_ch});
                 if (store_bn(net, "head." + std::to_string(net->head_rw1.size() - 1), {p + ".0.block.0.bn"}, 96)) return 1;
             }
             float *dw1, *db1, *dw2, *db2;
@@ -600,6 +626,10 @@ extern "C" int cerb_net_finalize(cerb_net* net) {
             if (upload(net, w1->data, &net->pc_rw1) || upload(net, b1->data, &net->pc_rb1) || upload(net, w2->data, &net->pc_rw2) ||
                 upload(net, b2->data, &net->pc_rb2) || store_bn(net, "pc.bn1", {p + ".bn1"}, 512) || store_bn(net, "pc.bn2", {p + ".bn2"}, 256))
                 return 1;
+            net->param_slots[p + ".conv1.weight"].push_back({net->pc_rw1, 256 * 512});
+            net->param_slots[p + ".conv1.bias"].push_back({net->pc_rb1, 256});
+            net->param_slots[p + ".conv2.weight"].push_back({net->pc_rw2, (long long)oc * 256});
+            net->param_slots[p + ".conv2.bias"].push_back({net->pc_rb2, oc});
         }
         std::vector<float> w1t(512 * 256), b1f(256), w2t(256 * 16, 0.f), b2f(16, 0.f);
         for (int o = 0; o < 256; ++o) {
@@ -1409,6 +1439,14 @@ extern "C" int cerb_adam_step(float* param, const float* grad, float* exp_avg, f
     HIP_OK(cerb_launch_adam(param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, step, (hipStream_t)hip_stream));
     return 0;
 }
+extern "C" int cerb_adam_step_multi(int count, float* const* param, const float* const* grad, float* const* exp_avg, float* const* exp_avg_sq,
+                                    const long long* numel, float lr, float beta1, float beta2, float eps, int step, void* hip_stream) {
+    if (count < 0 || (count && (!param || !grad || !exp_avg || !exp_avg_sq || !numel)) || step < 1) return fail("cerb_adam_step_multi: bad arguments");
+    for (int i = 0; i < count; ++i)
+        if (!param[i] || !grad[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] < 0) return fail("cerb_adam_step_multi: null tensor in the list");
+    HIP_OK(cerb_launch_adam_multi(count, param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, step, (hipStream_t)hip_stream));
+    return 0;
+}
 extern "C" int cerb_copy_d2d(void* dst, const void* src, size_t bytes, void* hip_stream) {
     if (!dst || !src) return fail("cerb_copy_d2d: null pointer");
     HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
@@ -1433,6 +1471,7 @@ extern "C" int cerb_net_begin_reload(cerb_net* net) {
     }
     net->reusing = true;
     net->reuse_cursor = 0;
+    net->param_slots.clear();
     net->conv.clear();
     net->bn.clear();
     net->raw.clear();
@@ -1441,6 +1480,29 @@ extern "C" int cerb_net_begin_reload(cerb_net* net) {
     net->head_rw1.clear(); net->head_rb1.clear(); net->head_rw2.clear(); net->head_rb2.clear();
     net->host.clear();
     net->finalized = false;
+    return 0;
+}
+extern "C" int cerb_net_update_params(cerb_net* net, int count, const char* const* keys, const float* const* dev_src, void* hip_stream) {
+    if (!net || count < 0 || (count && (!keys || !dev_src))) return fail("cerb_net_update_params: bad arguments");
+    if (!net->finalized || net->fold_bn) return fail("cerb_net_update_params: needs a finalized handle packed for training (cerb_net_set_fold_bn(net, 0))");
+    hipStream_t st = (hipStream_t)hip_stream;
+    for (int i = 0; i < count; ++i) {
+        auto it = net->param_slots.find(keys[i]);
+        if (it == net->param_slots.end()) continue;  // running statistics, num_batches_tracked, backbone.fc.*: nothing on the device reads them
+        if (!dev_src[i]) return fail(std::string("cerb_net_update_params: null source for ") + keys[i]);
+        for (const cerb_net::ParamSlot& sl : it->second) HIP_OK(hipMemcpyAsync(sl.dst, dev_src[i], (size_t)sl.n * 4, hipMemcpyDeviceToDevice, st));
+    }
+    HIP_OK(cerb_launch_pack_stem(net->stem_raw, net->stem_w, st));
+    for (auto& kv : net->conv) {
+        const PackedConv& pc = kv.second;
+        const float* rawd = net->raw[kv.first].w;
+        const size_t nw = (size_t)pc.cout * pc.cin * pc.ks * pc.ks, nu = (size_t)pc.cout * pc.cin * 16;
+        for (int g = 0; g < pc.groups; ++g) {
+            HIP_OK(cerb_launch_pack_conv(rawd + g * nw, pc.w + g * nw, pc.cout, pc.cin, pc.ks, cerb_conv_chunk(pc.ks, pc.stride), st));
+            if (pc.wino) HIP_OK(cerb_launch_pack_wino(rawd + g * nw, pc.wino + g * nu, pc.cout, pc.cin, 0, st));
+            if (pc.wino_dgrad) HIP_OK(cerb_launch_pack_wino(rawd + g * nw, pc.wino_dgrad + g * nu, pc.cin, pc.cout, 1, st));
+        }
+    }
     return 0;
 }
 extern "C" int cerb_net_set_fold_bn(cerb_net* net, int fold) {

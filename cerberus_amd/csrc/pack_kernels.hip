@@ -51,6 +51,14 @@ __global__ __launch_bounds__(256) void pack_wino_kernel(const float* __restrict_
         out[i] = (float)(tx[0] * Gb[0] + tx[1] * Gb[1] + tx[2] * Gb[2]);
     }
 }
+// stem 7x7 (cerb_api.hip: cerb_net_finalize): wp[ky 7][t 12][s 2][lane 64] = W[32 s + (lane & 31)][c][ky][kx] with kk = 2 t + (lane >> 5) = 3 kx + c < 21
+__global__ void pack_stem_kernel(const float* __restrict__ w, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 7 * 12 * 2 * 64) return;
+    const int lane = i & 63, s = (i >> 6) & 1, t = (i >> 7) % 12, ky = (i >> 7) / 12;
+    const int co = s * 32 + (lane & 31), kk = 2 * t + (lane >> 5);
+    out[i] = kk < 21 ? w[((co * 3 + kk % 3) * 7 + ky) * 7 + kk / 3] : 0.f;
+}
 unsigned pack_grid(long long n) {
     long long b = (n + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -64,5 +72,9 @@ hipError_t cerb_launch_pack_conv(const float* w_raw, float* out, int cout, int c
 // (cout, cin) are those of the conv the packed filter serves: for dgrad = 1 the transposed pair of the raw tensor
 hipError_t cerb_launch_pack_wino(const float* w_raw, float* out, int cout, int cin, int dgrad, hipStream_t st) {
     hipLaunchKernelGGL(pack_wino_kernel, dim3(pack_grid((long long)cout * cin * 16)), dim3(256), 0, st, w_raw, out, cout, cin, dgrad);
+    return hipGetLastError();
+}
+hipError_t cerb_launch_pack_stem(const float* w_raw, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(pack_stem_kernel, dim3((7 * 12 * 2 * 64 + 255) / 256), dim3(256), 0, st, w_raw, out);
     return hipGetLastError();
 }

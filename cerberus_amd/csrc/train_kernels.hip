@@ -9,6 +9,9 @@
 // Three launches: per-block partial sums (fixed order -> bitwise reproducible), one-block finalise (double accumulation; loss value
 // and the coefficients of the gradient), gradient.
 #include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
 #include <stdint.h>
 
 #include <string>
@@ -769,6 +772,28 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         p[i] -= (lr / bc1) * (mi / denom);
     }
 }
+// the same update over MANY tensors in one launch: a block takes one 16384-element chunk of one tensor (table built by the launcher)
+struct AdamTensor {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    long long n;
+};
+constexpr int ADAM_CHUNK = 16384;
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTensor* __restrict__ tensors, const int2* __restrict__ chunks, float lr, float b1, float b2,
+                                                         float eps, float bc1, float bc2) {
+    const int2 c = chunks[blockIdx.x];
+    const AdamTensor t = tensors[c.x];
+    const long long lo = (long long)c.y * ADAM_CHUNK, hi = min(t.n, lo + ADAM_CHUNK);
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        const float gi = t.g[i];
+        const float mi = t.m[i] = b1 * t.m[i] + (1.f - b1) * gi;
+        const float vi = t.v[i] = b2 * t.v[i] + (1.f - b2) * gi * gi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        t.p[i] -= (lr / bc1) * (mi / denom);
+    }
+}
 static unsigned gridfor(long long n) {
     long long b = (n + 255) / 256;
     if (b > 256 * 32) b = 256 * 32;
@@ -832,6 +857,37 @@ hipError_t cerb_launch_dilate2(const float* dy, float* d, long long n, int H, in
 }
 hipError_t cerb_launch_crop_gap_bwd(const float* dg, float* dx, int N, int H, int W, int C, int y0, int ch, int x0, int cw, hipStream_t st) {
     hipLaunchKernelGGL(crop_gap_bwd_kernel, dim3(gridfor((long long)N * ch * cw * C)), dim3(256), 0, st, dg, dx, N, H, W, C, y0, ch, x0, cw);
+    return hipGetLastError();
+}
+// tables live in one device buffer that grows on demand and is reused by later steps (single optimiser stream assumed, as torch's own)
+hipError_t cerb_launch_adam_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* n, float lr, float b1,
+                                  float b2, float eps, int step, hipStream_t st) {
+    static void* dev_tab = nullptr;
+    static size_t dev_bytes = 0;
+    static std::vector<char> host;
+    std::vector<AdamTensor> tt(count);
+    std::vector<int2> ch;
+    for (int i = 0; i < count; ++i) {
+        tt[i] = AdamTensor{p[i], g[i], m[i], v[i], n[i]};
+        for (long long c = 0; c * ADAM_CHUNK < n[i]; ++c) ch.push_back(make_int2(i, (int)c));
+    }
+    if (ch.empty()) return hipSuccess;
+    const size_t tb = (tt.size() * sizeof(AdamTensor) + 255) & ~(size_t)255, need = tb + ch.size() * sizeof(int2);
+    hipError_t e;
+    if (need > dev_bytes) {
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+        if (dev_tab) (void)hipFree(dev_tab);
+        if ((e = hipMalloc(&dev_tab, need * 2)) != hipSuccess) return e;
+        dev_bytes = need * 2;
+    }
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;  // the previous step's launch has consumed the table
+    host.resize(need);
+    memcpy(host.data(), tt.data(), tt.size() * sizeof(AdamTensor));
+    memcpy(host.data() + tb, ch.data(), ch.size() * sizeof(int2));
+    if ((e = hipMemcpyAsync(dev_tab, host.data(), need, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+    const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)ch.size()), dim3(256), 0, st, (const AdamTensor*)dev_tab, (const int2*)((const char*)dev_tab + tb), lr, b1,
+                       b2, eps, bc1, bc2);
     return hipGetLastError();
 }
 hipError_t cerb_launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step, hipStream_t st) {

@@ -81,6 +81,7 @@ class NetDesc(torch.nn.Module):
 
     # ---- state dict (reference key names) -----------------------------------------------------------------
     def state_dict(self, *args, **kwargs):
+        self._sync_state_dict()
         return OrderedDict((k, v.clone()) for k, v in self._sd.items())
 
     def load_state_dict(self, state_dict, strict=True):
@@ -92,6 +93,7 @@ class NetDesc(torch.nn.Module):
             errors.append("Missing key(s) in state_dict: " + ", ".join('"%s"' % k for k in missing) + ".")
         if strict and unexpected:
             errors.append("Unexpected key(s) in state_dict: " + ", ".join('"%s"' % k for k in unexpected) + ".")
+        self._sync_state_dict()
         new_sd = OrderedDict(self._sd)
         for k, shp in expected.items():
             if k not in state_dict:
@@ -156,6 +158,7 @@ class NetDesc(torch.nn.Module):
 
     def _load_and_finalize(self, h):
         L = _lib.lib()
+        self._sync_state_dict()
         for k, v in self._sd.items():
             if v.dtype != torch.float32:
                 continue
@@ -286,24 +289,48 @@ class NetDesc(torch.nn.Module):
         return losses, grads
 
     def load_updated_parameters(self, dev_params, flat=None, layout=None):
-        """After an optimiser step: take the updated parameters (key -> CUDA tensor) into the state dict and re-pack the weights of the device handle in
-        place (conv weights are laid out by device kernels from the raw copies; activation workspaces and the training tape are kept)."""
+        """After an optimiser step: install the updated parameters (key -> CUDA tensor).  A live handle packed for training takes them
+        device to device (cerb_net_update_params: copies into its raw tensors + the packing kernels) and the host state dict is brought
+        up to date lazily, when somebody asks for it; otherwise they go through the host and the handle re-packs in place.
+        flat / layout: dev_params as views of one buffer, layout = [(key, offset, numel, shape)] -- one transfer instead of one per key."""
         self._param_version += 1
-        if flat is not None:  # dev_params are views of one flat buffer, layout = [(key, offset, numel, shape)]: one device -> host copy
+        if self._handle is not None and getattr(self, "_train_packing", False):
+            keys = [k for k in dev_params if dev_params[k].dtype == torch.float32]
+            n = len(keys)
+            ck, cp = (C.c_char_p * n)(*[k.encode() for k in keys]), (C.c_void_p * n)()
+            for i, k in enumerate(keys):
+                assert dev_params[k].is_contiguous() and dev_params[k].is_cuda, k
+                cp[i] = dev_params[k].data_ptr()
+            dev = dev_params[keys[0]].device
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().cerb_net_update_params(self._handle, n, ck, cp, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            self._sd_pending = (dev_params, flat, layout)  # the host copy follows on demand (state_dict, a new handle)
+            return
+        self._sd_pending = (dev_params, flat, layout)
+        self._sync_state_dict()
+        if self._handle is None:
+            return
+        try:  # keep the handle (workspaces); only the packed weights are rebuilt
+            _lib.check(_lib.lib().cerb_net_begin_reload(self._handle))
+            self._load_and_finalize(self._handle)
+        except Exception:
+            self._release()
+            raise
+
+    def _sync_state_dict(self):
+        """Bring the host state dict up to date with the optimiser's device copies (see load_updated_parameters)."""
+        pend = getattr(self, "_sd_pending", None)
+        if pend is None:
+            return
+        self._sd_pending = None
+        dev_params, flat, layout = pend
+        if flat is not None:
             host = flat.detach().cpu()
             for k, o, n, shp in layout:
                 self._sd[k] = host[o:o + n].view(shp)
         else:
             for k, v in dev_params.items():
                 self._sd[k] = v.detach().cpu().clone()
-        if self._handle is None:
-            return
-        try:  # keep the handle (workspaces, tape); only the packed weights are rebuilt
-            _lib.check(_lib.lib().cerb_net_begin_reload(self._handle))
-            self._load_and_finalize(self._handle)
-        except Exception:
-            self._release()
-            raise
 
     def flops(self, n, h, w):
         return float(_lib.lib().cerb_net_flops(self._ensure_handle(), n, h, w))

@@ -24,18 +24,33 @@ class Adam(object):
         self.state = {}
 
     def step(self, params, grads):
-        """params / grads: key -> CUDA float tensor (contiguous); params are updated in place."""
+        """params / grads: key -> CUDA float tensor (contiguous); params are updated in place.  One launch for all tensors."""
         L = _lib.lib()
         self.step_count += 1
-        for k, g in grads.items():
+        keys = list(grads.keys())
+        if not keys:
+            return
+        dev = params[keys[0]].device
+        fresh = [k for k in keys if k not in self.state]
+        if fresh:  # moments of the new tensors as views of two flat buffers (one allocation, one memset each)
+            sizes = [(params[k].numel() + 63) // 64 * 64 for k in fresh]
+            fm, fv = torch.zeros(sum(sizes), dtype=torch.float32, device=dev), torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+            o = 0
+            for k, sz in zip(fresh, sizes):
+                n = params[k].numel()
+                self.state[k] = (fm[o:o + n].view(params[k].shape), fv[o:o + n].view(params[k].shape))
+                o += sz
+        n = len(keys)
+        gs = [grads[k].contiguous() for k in keys]
+        pp, gg, mm, vv = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+        nn = (C.c_longlong * n)()
+        for i, k in enumerate(keys):
             p = params[k]
-            if k not in self.state:
-                self.state[k] = (torch.zeros_like(p), torch.zeros_like(p))
-            m, v = self.state[k]
-            st = torch.cuda.current_stream(p.device).cuda_stream
-            with torch.cuda.device(p.device):
-                _lib.check(L.cerb_adam_step(p.data_ptr(), g.contiguous().data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), self.lr, self.betas[0], self.betas[1],
-                                            self.eps, self.step_count, C.c_void_p(st)))
+            assert p.is_contiguous() and p.dtype == torch.float32 and gs[i].numel() == p.numel(), k
+            pp[i], gg[i], mm[i], vv[i], nn[i] = p.data_ptr(), gs[i].data_ptr(), self.state[k][0].data_ptr(), self.state[k][1].data_ptr(), p.numel()
+        st = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(L.cerb_adam_step_multi(n, pp, gg, mm, vv, nn, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, C.c_void_p(st)))
 
 
 class StepLR(object):
@@ -115,6 +130,8 @@ def train_step(batch_data, run_info, dist=None, world_size=1, dropout_keep=None)
     stats = OrderedDict((k, grads.pop(k)) for k in buf_keys)
     allreduce_grads(grads, dist, world_size)
     # parameters live in the model's state dict (host); the optimiser works on device copies that persist across steps
+    if not hasattr(model, "_dev_params"):
+        model._sync_state_dict()
     if not hasattr(model, "_dev_params"):  # views into ONE flat device buffer: the copy back to the state dict is a single transfer
         layout, off = [], 0
         for k, v in model._sd.items():
@@ -127,8 +144,10 @@ def train_step(batch_data, run_info, dist=None, world_size=1, dropout_keep=None)
         for k, t in model._dev_params.items():
             t.copy_(model._sd[k])
     opt.step(model._dev_params, grads)
-    for k, s in stats.items():  # running = 0.9 running + 0.1 batch (torch BatchNorm momentum 0.1; the variance is the unbiased one)
-        model._dev_params[k].mul_(0.9).add_(s.reshape(model._dev_params[k].shape), alpha=0.1)
+    if stats:  # running = 0.9 running + 0.1 batch (torch BatchNorm momentum 0.1; the variance is the unbiased one), all buffers per launch
+        run = [model._dev_params[k] for k in stats]
+        torch._foreach_mul_(run, 0.9)
+        torch._foreach_add_(run, [s.reshape(r.shape) for s, r in zip(stats.values(), run)], alpha=0.1)
     torch.cuda.synchronize(dev)
     model.load_updated_parameters(model._dev_params, model._dev_flat, model._dev_layout)
     ema = OrderedDict(("%s_loss" % k, v) for k, v in losses.items())

@@ -209,6 +209,10 @@ int cerb_net_set_fold_bn(cerb_net* net, int fold);
 /* After an optimiser step: drop the packed weights of a finalized handle (activation workspaces, the training tape and the mode stay), so
  * that cerb_net_load_tensor of EVERY tensor + cerb_net_finalize install the updated parameters (models/run_desc.py:165 optimizer.step()). */
 int cerb_net_begin_reload(cerb_net* net);
+/* The optimiser's step without a host round trip (handles packed for training): copies each listed state-dict tensor from `dev_src[i]`
+ * (device, float32, state-dict layout) into the handle's own copies and re-packs the conv weights with device kernels on `hip_stream`.
+ * Keys the train-mode device path does not read (running statistics, num_batches_tracked, backbone.fc.*) are accepted and ignored. */
+int cerb_net_update_params(cerb_net* net, int count, const char* const* keys, const float* const* dev_src, void* hip_stream);
 int cerb_net_forward_train(cerb_net* net, const cerb_train_io* io, void* hip_stream);
 
 /* cerb_net_train_grads: train-mode forward + the head losses + the backward pass of one step (models/run_desc.py:79-170 up to
@@ -245,6 +249,10 @@ int cerb_net_grad_lookup(cerb_net* net, const char* key, float** dev_ptr, long l
  * cerb_adam_step: torch.optim.Adam (no weight decay / amsgrad; models/opt.py:47-58) on one parameter tensor, in place; `step` counts from 1. */
 int cerb_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long numel, float lr, float beta1,
                    float beta2, float eps, int step, void* hip_stream);
+/* The same update over `count` tensors in ONE launch (host arrays of device pointers and element counts): the 307 parameter tensors of
+ * the six-head network per step. */
+int cerb_adam_step_multi(int count, float* const* param, const float* const* grad, float* const* exp_avg, float* const* exp_avg_sq,
+                         const long long* numel, float lr, float beta1, float beta2, float eps, int step, void* hip_stream);
 /* device-to-device copy on a stream (lets a host language without a HIP binding move a looked-up gradient into its own buffer) */
 int cerb_copy_d2d(void* dst, const void* src, size_t bytes, void* hip_stream);
 

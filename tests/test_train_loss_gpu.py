@@ -260,3 +260,38 @@ def test_valid_step_vs_reference(case):
                 assert (got != exp).mean() <= 1e-3, (h, (got != exp).mean())
             te, tg = g[case + "true/" + h], raw["true"][h]
             assert tg.shape == te.shape and np.array_equal(tg, te), (h, tg.shape, te.shape)
+
+
+def test_device_side_parameter_update_equals_a_rebuilt_handle(gold):
+    """Three optimiser steps with the handle updated device to device (cerb_net_update_params: every tensor the train-mode kernels read
+    + the packing kernels) against the same steps with the handle thrown away and rebuilt from the host state dict after each one:
+    identical losses at every step and an identical final state dict -- a tensor missed by the device path would leave stale weights."""
+    from cerberus_amd.net_desc import create_model
+    from cerberus_amd.train import Adam, train_step
+    from cerberus_amd.weights import default_model_kwargs, make_state_dict
+
+    heads = [str(h) for h in gold["heads"]]
+    has = np.full(gold["has_target"].shape, None, dtype=object)
+    for j, h in enumerate(heads):
+        has[gold["has_target"][:, j], j] = h
+    batch = {"img": torch.from_numpy(gold["img"]), "dummy_target": has}
+    for h in heads:
+        batch[h] = torch.from_numpy(gold["target/" + h])
+    keep = torch.from_numpy(gold["step/dropout_mask"].reshape(int(gold["N"]), 512)).cuda()
+    runs = []
+    for rebuild in (False, True):
+        m = create_model(**default_model_kwargs())
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(int(gold["weight_seed"])).items()}, strict=True)
+        opt = Adam(lr=1.0e-3, betas=(0.9, 0.999))
+        losses = []
+        for _ in range(3):
+            res = train_step(dict(batch), ({"net": {"desc": m, "optimizer": opt, "extra_info": {"loss": PARAMSET_LOSS}}}, None), dropout_keep=keep)
+            losses.append([res["EMA"][h + "_loss"] for h in heads])
+            if rebuild:
+                m._sync_state_dict()
+                m._release()  # the next step creates a fresh handle from the host state dict
+        runs.append((losses, m.state_dict()))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert runs[0][0][0] != runs[0][0][2]  # the parameters did move
+    for k, v in runs[0][1].items():
+        assert torch.equal(v, runs[1][1][k]), k
