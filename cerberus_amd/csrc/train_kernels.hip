@@ -112,8 +112,23 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(LossParams p) {
         }
 }
 
-__global__ void loss_finalize_kernel(LossParams p) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// one wave: every lane adds a strided share of the partials in double, lane 0 adds the 64 lane sums in lane order (fixed order: reproducible)
+__device__ __forceinline__ double lane_ordered_sum(double v, double* sh) {
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 64; ++k) t += sh[k];
+        sh[64] = t;
+    }
+    __syncthreads();
+    const double t = sh[64];
+    __syncthreads();
+    return t;
+}
+__global__ __launch_bounds__(64) void loss_finalize_kernel(LossParams p) {
+    __shared__ double sh[65];
+    const int lane = threadIdx.x;
     const int stride = 1 + 3 * MAXC;
     const double hw = (double)p.H * p.W;
     double flag_sum = 0.0;
@@ -123,34 +138,43 @@ __global__ void loss_finalize_kernel(LossParams p) {
     if (!p.pc_mode) {
         for (int n = 0; n < p.N; ++n) {
             double s = 0.0;
-            for (int b = 0; b < p.blocks_per_sample; ++b) s += p.partial[(long long)(n * p.blocks_per_sample + b) * stride];
+            for (int b = lane; b < p.blocks_per_sample; b += 64) s += p.partial[(long long)(n * p.blocks_per_sample + b) * stride];
+            s = lane_ordered_sum(s, sh);
             ce_term += p.has_target[n] * (s / hw);
-            p.coef[n] = (double)p.ce_w * p.head_w * p.has_target[n] / (denom * hw);
+            if (lane == 0) p.coef[n] = (double)p.ce_w * p.head_w * p.has_target[n] / (denom * hw);
         }
         ce_term /= denom;
     } else {  // every sample's loss is the mean over all samples; H = W = 1
         double s = 0.0;
         for (int n = 0; n < p.N; ++n) s += p.partial[(long long)n * stride];
         ce_term = (s / p.N) * flag_sum / denom;
-        for (int n = 0; n < p.N; ++n) p.coef[n] = (double)p.ce_w * p.head_w * flag_sum / (denom * p.N);
+        if (lane == 0)
+            for (int n = 0; n < p.N; ++n) p.coef[n] = (double)p.ce_w * p.head_w * flag_sum / (denom * p.N);
     }
     double dice = 0.0;
     if (p.dice_w != 0.f)
         for (int c = 1; c < p.C; ++c) {
             double I = 0.0, L = 0.0, R = 0.0;
-            for (int b = 0; b < p.N * p.blocks_per_sample; ++b) {
+            for (int b = lane; b < p.N * p.blocks_per_sample; b += 64) {
                 I += p.partial[(long long)b * stride + 1 + c];
                 L += p.partial[(long long)b * stride + 1 + MAXC + c];
                 R += p.partial[(long long)b * stride + 1 + 2 * MAXC + c];
             }
+            I = lane_ordered_sum(I, sh);
+            L = lane_ordered_sum(L, sh);
+            R = lane_ordered_sum(R, sh);
             const double D = L + R + 1.0e-3;
             dice += 1.0 - (2.0 * I + 1.0e-3) / D;
-            p.coef[p.N + c] = (double)p.dice_w * p.head_w * (-2.0 / D);                         // d/dI_c
-            p.coef[p.N + MAXC + c] = (double)p.dice_w * p.head_w * ((2.0 * I + 1.0e-3) / (D * D));  // d/dL_c
+            if (lane == 0) {
+                p.coef[p.N + c] = (double)p.dice_w * p.head_w * (-2.0 / D);                         // d/dI_c
+                p.coef[p.N + MAXC + c] = (double)p.dice_w * p.head_w * ((2.0 * I + 1.0e-3) / (D * D));  // d/dL_c
+            }
         }
     const double loss = ((double)p.ce_w * ce_term + (double)p.dice_w * dice) * p.head_w;
-    p.coef[p.N + 2 * MAXC] = loss;
-    if (p.loss_out) *p.loss_out = (float)loss;
+    if (lane == 0) {
+        p.coef[p.N + 2 * MAXC] = loss;
+        if (p.loss_out) *p.loss_out = (float)loss;
+    }
 }
 
 __global__ __launch_bounds__(256) void loss_grad_kernel(LossParams p) {
