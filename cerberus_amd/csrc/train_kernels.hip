@@ -500,25 +500,48 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const double* __r
     dbeta[blockIdx.y * C + c] = (float)s;
     dgamma[blockIdx.y * C + c] = (float)q;
 }
-// dy = gamma * rstd * (dzm - dbeta / M - xhat * dgamma / M); dresid += dzm (dzm = ReLU-masked dz)
+// dy (+)= gamma * rstd * (dzm - dbeta / M - xhat * dgamma / M); dresid += dzm (dzm = ReLU-masked dz).  Thread = four channels of a row;
+// ASSIGN: dy holds nothing yet (this BatchNorm is its first and only writer): no read of it, and no zero fill before the launch
+template <bool ASSIGN>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ y,
                                                            float* __restrict__ dy, float* __restrict__ dresid, long long group_stride, long long rows, int C,
                                                            int groups, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, int relu) {
-    const long long per_group = rows * C, total = per_group * groups;
+    const int c4n = C >> 2;
+    const long long per_group = rows * c4n, total = per_group * groups;
     const float invM = 1.f / (float)rows;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int g = (int)(i / per_group);
         const long long j = i - (long long)g * per_group;
-        const int c = (int)(j % C);
-        const long long a = g * group_stride + j;
-        float d = dz[a];
-        if (relu && !(z[a] > 0.f)) d = 0.f;
-        if (dresid) dresid[a] += d;
+        const int c = 4 * (int)(j % c4n);
+        const long long a = g * group_stride + (j / c4n) * C + c;
+        float4 d = *reinterpret_cast<const float4*>(dz + a);
+        if (relu) {
+            const float4 m = *reinterpret_cast<const float4*>(z + a);
+            if (!(m.x > 0.f)) d.x = 0.f;
+            if (!(m.y > 0.f)) d.y = 0.f;
+            if (!(m.z > 0.f)) d.z = 0.f;
+            if (!(m.w > 0.f)) d.w = 0.f;
+        }
+        if (dresid) {
+            float4 r = *reinterpret_cast<float4*>(dresid + a);
+            r.x += d.x; r.y += d.y; r.z += d.z; r.w += d.w;
+            *reinterpret_cast<float4*>(dresid + a) = r;
+        }
         const int gc = g * C + c;
-        const float xh = (y[a] - mean[gc]) * rstd[gc];
-        dy[a] += gamma[gc] * rstd[gc] * (d - dbeta[gc] * invM - xh * dgamma[gc] * invM);
+        const float4 yv = *reinterpret_cast<const float4*>(y + a), mu = *reinterpret_cast<const float4*>(mean + gc), rs = *reinterpret_cast<const float4*>(rstd + gc),
+                     ga = *reinterpret_cast<const float4*>(gamma + gc), dg = *reinterpret_cast<const float4*>(dgamma + gc), db = *reinterpret_cast<const float4*>(dbeta + gc);
+        float4 o;
+        o.x = ga.x * rs.x * (d.x - db.x * invM - ((yv.x - mu.x) * rs.x) * dg.x * invM);
+        o.y = ga.y * rs.y * (d.y - db.y * invM - ((yv.y - mu.y) * rs.y) * dg.y * invM);
+        o.z = ga.z * rs.z * (d.z - db.z * invM - ((yv.z - mu.z) * rs.z) * dg.z * invM);
+        o.w = ga.w * rs.w * (d.w - db.w * invM - ((yv.w - mu.w) * rs.w) * dg.w * invM);
+        if (!ASSIGN) {
+            const float4 p = *reinterpret_cast<const float4*>(dy + a);
+            o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+        }
+        *reinterpret_cast<float4*>(dy + a) = o;
     }
 }
 // ---- convolution backward, gather form (any ks / stride / pad = ks / 2; groups = independent convs stacked along G) ------------------
@@ -827,13 +850,15 @@ static unsigned gridfor(long long n) {
 }  // namespace
 
 hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, float* dy, float* dresid, long long group_stride, long long rows, int C, int groups,
-                              const float* mean, const float* rstd, const float* gamma, float* dgamma, float* dbeta, int relu, void* ws, hipStream_t st) {
+                              const float* mean, const float* rstd, const float* gamma, float* dgamma, float* dbeta, int relu, int dy_assign, void* ws, hipStream_t st) {
     const int bpg = (int)((rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(groups * bpg), dim3(256), 256 * 2 * sizeof(double), st, dz, z, y, group_stride, rows, C, bpg, mean, rstd, relu,
                        (double*)ws);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, (const double*)ws, C, bpg, dgamma, dbeta);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gridfor(rows * C * groups)), dim3(256), 0, st, dz, z, y, dy, dresid, group_stride, rows, C, groups, mean, rstd,
-                       gamma, dgamma, dbeta, relu);
+    if (dy_assign) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gridfor(rows * (C / 4) * groups)), dim3(256), 0, st, dz, z, y, dy, dresid, group_stride, rows, C,
+                                      groups, mean, rstd, gamma, dgamma, dbeta, relu);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(gridfor(rows * (C / 4) * groups)), dim3(256), 0, st, dz, z, y, dy, dresid, group_stride, rows, C, groups,
+                            mean, rstd, gamma, dgamma, dbeta, relu);
     return hipGetLastError();
 }
 hipError_t cerb_launch_conv_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int G, int N, int H, int W, int Cin, int Cout,
