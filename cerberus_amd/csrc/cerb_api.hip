@@ -1332,6 +1332,9 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 if (pcv.wino_dgrad && net->conv_algo && (op.stride == 1 || (op.H % 2 == 0 && op.W % 2 == 0))) {
                     // data gradient on the forward Winograd kernel: in = dy, weights rotated + transposed, the gradient already held by the
                     // input (other consumers) rides in as the residual and is written back in place
+                    const long long in_n = (long long)op.N * op.H * op.W * op.Cin;
+                    const bool fresh = !grd[op.a] && cnt[op.a] == (size_t)op.G * in_n && (op.G == 1 || op.a_gs == in_n);  // first writer: no residual, no zero fill
+                    if (fresh && !(grd[op.a] = take(cnt[op.a], false))) return fail("workspace allocation failed");
                     float* dx = G_(op.a);
                     if (op.stride == 2) {  // y = 2 yo - 1 + ky  <=>  dx = conv_s1(D, W'), D[2 yo][2 xo] = dy[yo][xo], zero elsewhere
                         const long long dn = (long long)op.G * op.N * op.H * op.W * op.Cout;
@@ -1341,7 +1344,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     }
                     ConvParams p;
                     memset(&p, 0, sizeof(p));
-                    p.in = go; p.wpack = pcv.wino_dgrad; p.bias = net->zero_bias; p.resid = dx; p.out = dx;
+                    p.in = go; p.wpack = pcv.wino_dgrad; p.bias = net->zero_bias; p.resid = fresh ? nullptr : dx; p.out = dx;
                     p.N = op.N; p.H = op.H; p.W = op.W; p.Cin = op.Cout; p.Cout = op.Cin; p.Ho = op.H; p.Wo = op.W; p.relu = 0; p.groups = op.G;
                     p.in_gs = (long long)op.N * op.H * op.W * op.Cout;
                     p.w_gs = (long long)op.Cout * op.Cin * 16;
