@@ -36,7 +36,7 @@ hipError_t cerb_launch_stem(StemParams p, hipStream_t st);
 size_t cerb_bn_workspace_bytes(int groups, long long rows, int C);
 hipError_t cerb_launch_bn_stats(const float* x, long long group_stride, long long rows, int C, int groups, float eps, float* mean, float* rstd,
                                 float* var_unbiased, void* ws, hipStream_t st);
-hipError_t cerb_launch_bn_apply(float* x, const float* resid, long long group_stride, long long rows, int C, int groups, const float* mean,
+hipError_t cerb_launch_bn_apply(float* x, const float* src, const float* resid, long long group_stride, long long rows, int C, int groups, const float* mean,
                                 const float* rstd, const float* gamma, const float* beta, int relu, hipStream_t st);
 hipError_t cerb_launch_pointwise(const float* in, const float* w, const float* bias, float* out, long long rows, int cin, int cout, const float* in_scale,
                                  hipStream_t st);
@@ -937,7 +937,7 @@ static int bn_train(cerb_net* net, const std::string& name, float* x, const floa
         net->t_ws.ensure(cerb_bn_workspace_bytes(b.groups, rows, b.C), 0))
         return fail("workspace allocation failed");
     HIP_OK(cerb_launch_bn_stats(x, group_stride, rows, b.C, b.groups, 1e-5f, net->t_mean.p, net->t_rstd.p, nullptr, net->t_ws.p, st));
-    HIP_OK(cerb_launch_bn_apply(x, resid, group_stride, rows, b.C, b.groups, net->t_mean.p, net->t_rstd.p, b.gamma, b.beta, relu, st));
+    HIP_OK(cerb_launch_bn_apply(x, nullptr, resid, group_stride, rows, b.C, b.groups, net->t_mean.p, net->t_rstd.p, b.gamma, b.beta, relu, st));
     return 0;
 }
 
@@ -1142,8 +1142,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 net->grads[keys[g] + ".batch_var"] = std::make_pair(var_u + (size_t)g * b.C, (long long)b.C);
             }
         }
-        if (hipMemcpyAsync(val[z], val[y], cnt[y] * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
-        if (cerb_launch_bn_apply(val[z], resid >= 0 ? val[resid] : nullptr, gs, rows, b.C, b.groups, mean, rstd, b.gamma, b.beta, relu, st) != hipSuccess) return -1;
+        if (cerb_launch_bn_apply(val[z], val[y], resid >= 0 ? val[resid] : nullptr, gs, rows, b.C, b.groups, mean, rstd, b.gamma, b.beta, relu, st) != hipSuccess) return -1;
         TapeOp op;
         op.type = 2; op.name = name; op.a = y; op.b = resid; op.o = z; op.stat = stt; op.rows = rows; op.Cout = b.C; op.G = b.groups; op.relu = relu; op.a_gs = gs;
         tape.push_back(op);

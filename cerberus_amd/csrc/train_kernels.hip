@@ -254,7 +254,7 @@ extern "C" int cerb_head_loss_wmap(const float* logits, long long stride_n, long
 // into the convolutions, so every conv runs with its raw weights (the inference kernels, packed without the fold) and is followed by
 //   cerb_launch_bn_stats : per (group, channel) mean and biased variance over the N*H*W rows of an NHWC tensor -- per-block partial
 //                          sums in double, one finalising block per group (fixed order: reproducible)
-//   cerb_launch_bn_apply : y = (x - mean) * gamma / sqrt(var + eps) + beta (+ residual) (ReLU), in place, float4
+//   cerb_launch_bn_apply : y = (x - mean) * gamma / sqrt(var + eps) + beta (+ residual) (ReLU), in place or from `src` into x, float4
 // plus the small dense pieces that the fused inference head / Patch-Class kernels cannot serve in train mode:
 //   cerb_launch_pointwise: out[r][co] = bias[co] + sum_ci in[r][ci] * W[co][ci]   (1x1 convs 64->96, 96->C, 512->256, 256->9)
 //   cerb_launch_crop_gap : centre crop (Python-slice semantics of cropping_center) + global average pool of the bottom features
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restr
     rstd[g * C + c] = (float)(1.0 / sqrt(v + (double)eps));
     if (var_unbiased) var_unbiased[g * C + c] = (float)(rows > 1 ? v * (double)rows / (double)(rows - 1) : v);
 }
-__global__ __launch_bounds__(256) void bn_apply_kernel(float* __restrict__ x, const float* __restrict__ resid, long long group_stride, long long rows, int C,
+__global__ __launch_bounds__(256) void bn_apply_kernel(float* x, const float* src, const float* __restrict__ resid, long long group_stride, long long rows, int C,
                                                        int groups, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int relu) {
     const int c4n = C >> 2;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(float* __restrict__ x, co
         const long long j = i - (long long)g * per_group;
         const int c = 4 * (int)(j % c4n);
         float4* p = reinterpret_cast<float4*>(x + g * group_stride + (j / c4n) * C + c);
-        float4 v = *p;
+        float4 v = *reinterpret_cast<const float4*>(src + g * group_stride + (j / c4n) * C + c);  // src == x: in place
         const float* m = mean + g * C + c;
         const float* rs = rstd + g * C + c;
         const float* ga = gamma + g * C + c;
@@ -414,12 +414,12 @@ hipError_t cerb_launch_bn_stats(const float* x, long long group_stride, long lon
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, (const double*)ws, rows, C, bpg, eps, mean, rstd, var_unbiased);
     return hipGetLastError();
 }
-hipError_t cerb_launch_bn_apply(float* x, const float* resid, long long group_stride, long long rows, int C, int groups, const float* mean,
+hipError_t cerb_launch_bn_apply(float* x, const float* src, const float* resid, long long group_stride, long long rows, int C, int groups, const float* mean,
                                 const float* rstd, const float* gamma, const float* beta, int relu, hipStream_t st) {
     long long blocks = (rows * (C / 4) * groups + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, resid, group_stride, rows, C, groups, mean, rstd, gamma, beta, relu);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, src ? src : x, resid, group_stride, rows, C, groups, mean, rstd, gamma, beta, relu);
     return hipGetLastError();
 }
 hipError_t cerb_launch_pointwise(const float* in, const float* w, const float* bias, float* out, long long rows, int cin, int cout, const float* in_scale,
