@@ -46,7 +46,7 @@ hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, f
 hipError_t cerb_launch_conv_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int G, int N, int H, int W, int Cin, int Cout,
                                 int ks, int stride, long long x_gs, hipStream_t st);
 hipError_t cerb_launch_stem_wgrad(const unsigned char* tiles, const float* dy, float* dw, int N, int H, int W, hipStream_t st);
-hipError_t cerb_launch_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, hipStream_t st);
+hipError_t cerb_launch_maxpool_bwd(const float* x, const float* ypool, const float* dy, float* dx, int N, int H, int W, int C, hipStream_t st);
 hipError_t cerb_launch_upadd_bwd(const float* dout, float* dskip, float* dprev, int G, int N, int H, int W, int C, long long prev_gs, int shared_prev, hipStream_t st);
 hipError_t cerb_launch_pointwise_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long long rows, int cin, int cout,
                                      const float* in_scale, hipStream_t st);
@@ -1394,7 +1394,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 break;
             }
             case 3:
-                HIP_OK(cerb_launch_maxpool_bwd(val[op.a], go, G_(op.a), op.N, op.H, op.W, op.Cout, st));
+                HIP_OK(cerb_launch_maxpool_bwd(val[op.a], val[op.o], go, G_(op.a), op.N, op.H, op.W, op.Cout, st));
                 break;
             case 4: {
                 // The reference runs a decoder that is not in train_decoder_list under torch.set_grad_enabled(False) (models/net_desc.py:182), but

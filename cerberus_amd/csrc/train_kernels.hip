@@ -645,8 +645,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const unsigned char* __
 }
 // max-pool 3x3 stride 2 pad 1: an input pixel collects the gradient of every window whose FIRST maximum (row-major scan, as
 // torch.nn.functional.max_pool2d records it) it is
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W,
-                                                          int C, int Ho, int Wo) {
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ypool, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
     const long long total = (long long)N * H * W * C;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
@@ -654,30 +654,30 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
         const int ix = (int)(r % W);
         r /= W;
         const int iy = (int)(r % H), n = (int)(r / H);
+        const float xv = x[i];
         float acc = 0.f;
         for (int oy = (iy + 1 - 2 + 1) / 2; oy <= (iy + 1) / 2; ++oy) {      // windows with oy*2-1 <= iy <= oy*2+1
             if (oy < 0 || oy >= Ho) continue;
             for (int ox = (ix + 1 - 2 + 1) / 2; ox <= (ix + 1) / 2; ++ox) {
                 if (ox < 0 || ox >= Wo) continue;
-                float best = -INFINITY;
-                int by = -1, bx = -1;
-                for (int ky = 0; ky < 3; ++ky) {
+                // the pooled value is the window's maximum: most (pixel, window) pairs end here; a pixel that holds it is the FIRST maximum
+                // when no window element before it in the row-major scan holds it too
+                if (xv != ypool[(((long long)n * Ho + oy) * Wo + ox) * C + c]) continue;
+                bool first = true;
+                for (int ky = 0; ky < 3 && first; ++ky) {
                     const int y = oy * 2 - 1 + ky;
-                    if (y < 0 || y >= H) continue;
+                    if (y < 0 || y >= H || y > iy) continue;
                     for (int kx = 0; kx < 3; ++kx) {
                         const int xx = ox * 2 - 1 + kx;
                         if (xx < 0 || xx >= W) continue;
-                        const float v = x[(((long long)n * H + y) * W + xx) * C + c];
-                        if (v > best || by < 0) {
-                            if (v > best || by < 0) {
-                                best = v;
-                                by = y;
-                                bx = xx;
-                            }
+                        if (y == iy && xx >= ix) break;
+                        if (x[(((long long)n * H + y) * W + xx) * C + c] == xv) {
+                            first = false;
+                            break;
                         }
                     }
                 }
-                if (by == iy && bx == ix) acc += dy[(((long long)n * Ho + oy) * Wo + ox) * C + c];
+                if (first) acc += dy[(((long long)n * Ho + oy) * Wo + ox) * C + c];
             }
         }
         dx[i] += acc;
@@ -873,8 +873,8 @@ hipError_t cerb_launch_stem_wgrad(const unsigned char* tiles, const float* dy, f
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(64 * 147), dim3(256), 0, st, tiles, dy, dw, N, H, W);
     return hipGetLastError();
 }
-hipError_t cerb_launch_maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, hipStream_t st) {
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(gridfor((long long)N * H * W * C)), dim3(256), 0, st, x, dy, dx, N, H, W, C, H / 2, W / 2);
+hipError_t cerb_launch_maxpool_bwd(const float* x, const float* ypool, const float* dy, float* dx, int N, int H, int W, int C, hipStream_t st) {
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(gridfor((long long)N * H * W * C)), dim3(256), 0, st, x, ypool, dy, dx, N, H, W, C, H / 2, W / 2);
     return hipGetLastError();
 }
 hipError_t cerb_launch_upadd_bwd(const float* dout, float* dskip, float* dprev, int G, int N, int H, int W, int C, long long prev_gs, int shared_prev, hipStream_t st) {
