@@ -49,7 +49,7 @@ hipError_t cerb_launch_stem_wgrad(const unsigned char* tiles, const float* dy, f
 hipError_t cerb_launch_maxpool_bwd(const float* x, const float* ypool, const float* dy, float* dx, int N, int H, int W, int C, hipStream_t st);
 hipError_t cerb_launch_upadd_bwd(const float* dout, float* dskip, float* dprev, int G, int N, int H, int W, int C, long long prev_gs, int shared_prev, hipStream_t st);
 hipError_t cerb_launch_pointwise_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long long rows, int cin, int cout,
-                                     const float* in_scale, hipStream_t st);
+                                     const float* in_scale, int dx_assign, hipStream_t st);
 hipError_t cerb_launch_crop_gap_bwd(const float* dg, float* dx, int N, int H, int W, int C, int y0, int ch, int x0, int cw, hipStream_t st);
 hipError_t cerb_launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step, hipStream_t st);
 size_t cerb_wgrad_workspace_bytes(int G, int N, int Ho, int Wo, int Cin, int Cout, int ks, int* slices_out);
@@ -1425,7 +1425,11 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 }
                 if (net->t_ws.ensure((size_t)2048 * op.Cout * 4 + 256, 0)) return fail("workspace allocation failed");
                 HIP_OK(cerb_launch_colsum(go, 0, op.rows, op.Cout, 1, db, net->t_ws.p, st));
-                HIP_OK(cerb_launch_pointwise_bwd(val[op.a] + op.a_gs, go, op.w, G_(op.a) + op.a_gs, pw_dw ? nullptr : dw, nullptr, op.rows, op.Cin, op.Cout, op.scale, st));
+                // a hidden map read by this layer alone gets its gradient assigned (no zero fill, no read-modify-write)
+                const bool fresh = !grd[op.a] && op.a_gs == 0 && cnt[op.a] == (size_t)op.rows * op.Cin;
+                if (fresh && !(grd[op.a] = take(cnt[op.a], false))) return fail("workspace allocation failed");
+                HIP_OK(cerb_launch_pointwise_bwd(val[op.a] + op.a_gs, go, op.w, G_(op.a) + op.a_gs, pw_dw ? nullptr : dw, nullptr, op.rows, op.Cin, op.Cout, op.scale,
+                                                 fresh ? 1 : 0, st));
                 break;
             }
             case 6:

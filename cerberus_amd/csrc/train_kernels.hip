@@ -731,14 +731,15 @@ __global__ __launch_bounds__(256) void upadd_bwd_prev_kernel(const float* __rest
 }
 // pointwise (1x1) backward: dx[r][ci] += scale * sum_co dy[r][co] W[co][ci];  dW[co][ci] = sum_r dy[r][co] x[r][ci] scale
 __global__ __launch_bounds__(256) void pointwise_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, long long rows, int cin,
-                                                              int cout, const float* __restrict__ in_scale) {
+                                                              int cout, const float* __restrict__ in_scale, int assign) {
     const long long total = rows * cin;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long r = i / cin;
         const int ci = (int)(i % cin);
         float acc = 0.f;
         for (int co = 0; co < cout; ++co) acc = fmaf(dy[r * cout + co], w[(long long)co * cin + ci], acc);
-        dx[i] += in_scale ? acc * in_scale[i] : acc;
+        const float v = in_scale ? acc * in_scale[i] : acc;
+        dx[i] = assign ? v : dx[i] + v;  // assign: dx has no other writer and holds nothing yet
     }
 }
 __global__ __launch_bounds__(256) void pointwise_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, long long rows, int cin,
@@ -884,9 +885,9 @@ hipError_t cerb_launch_upadd_bwd(const float* dout, float* dskip, float* dprev, 
     return hipGetLastError();
 }
 hipError_t cerb_launch_pointwise_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long long rows, int cin, int cout,
-                                     const float* in_scale, hipStream_t st) {
-    if (dx && !in_scale && rows >= 4096 && cerb_launch_pw_mfma(dy, w, 0, nullptr, dx, rows, cout, cin, 1, st) == hipSuccess) dx = nullptr;
-    if (dx) hipLaunchKernelGGL(pointwise_dgrad_kernel, dim3(gridfor(rows * cin)), dim3(256), 0, st, dy, w, dx, rows, cin, cout, in_scale);
+                                     const float* in_scale, int dx_assign, hipStream_t st) {
+    if (dx && !in_scale && !dx_assign && rows >= 4096 && cerb_launch_pw_mfma(dy, w, 0, nullptr, dx, rows, cout, cin, 1, st) == hipSuccess) dx = nullptr;
+    if (dx) hipLaunchKernelGGL(pointwise_dgrad_kernel, dim3(gridfor(rows * cin)), dim3(256), 0, st, dy, w, dx, rows, cin, cout, in_scale, dx_assign);
     if (dw) hipLaunchKernelGGL(pointwise_wgrad_kernel, dim3(cin * cout), dim3(256), 0, st, x, dy, dw, rows, cin, cout, in_scale);
     if (db) hipLaunchKernelGGL(colsum_kernel, dim3(cout), dim3(256), 0, st, dy, 0ll, rows, cout, db);
     return hipGetLastError();
