@@ -157,17 +157,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
             }
 }
 
-// dW[g][cb*64 + co][cib*64 + ci][tap] = sum over slices, in slice order
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int G, int Cin, int Cout, int T, int slices) {
+// dW[g][cb*64 + co][cib*64 + ci][tap] = sum over slices: 64 outputs x 16 slice chunks per workgroup, a chunk's slices added in order, then the
+// chunks in chunk order (fixed order: reproducible)
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int G, int Cin, int Cout, int T, int slices) {
+    __shared__ float sh[16][64];
     const int ncb = (Cout + 63) >> 6, ncib = (Cin + 63) >> 6, tiles = G * ncb * ncib;
     const long long total = (long long)tiles * T * 4096;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int ci = (int)(i & 63), co = (int)((i >> 6) & 63), t = (int)((i >> 12) % T), tile = (int)(i / ((long long)T * 4096));
-        const int cib = tile % ncib, cb = (tile / ncib) % ncb, g = tile / (ncib * ncb);
-        if (cb * 64 + co >= Cout || cib * 64 + ci >= Cin) continue;
+    const int lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
+    const int per = (slices + 15) / 16, s0 = ch * per, s1 = min(slices, s0 + per);
+    for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64) {
+        const long long i = base + lane;  // total is a multiple of 64
         float s = 0.f;
-        for (int sl = 0; sl < slices; ++sl) s += part[(long long)sl * total + i];
-        dw[(((long long)g * Cout + cb * 64 + co) * Cin + cib * 64 + ci) * T + t] = s;
+        int sl = s0;
+        for (; sl + 4 <= s1; sl += 4) {
+            const float v0 = part[(long long)sl * total + i], v1 = part[(long long)(sl + 1) * total + i], v2 = part[(long long)(sl + 2) * total + i],
+                        v3 = part[(long long)(sl + 3) * total + i];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; sl < s1; ++sl) s += part[(long long)sl * total + i];
+        __syncthreads();
+        sh[ch][lane] = s;
+        __syncthreads();
+        if (ch == 0) {
+            float t = 0.f;
+            for (int k = 0; k < 16; ++k) t += sh[k][lane];
+            const int ci = (int)(i & 63), co = (int)((i >> 6) & 63), tp = (int)((i >> 12) % T), tile = (int)(i / ((long long)T * 4096));
+            const int cib = tile % ncib, cb = (tile / ncib) % ncb, g = tile / (ncib * ncb);
+            if (cb * 64 + co < Cout && cib * 64 + ci < Cin) dw[(((long long)g * Cout + cb * 64 + co) * Cin + cib * 64 + ci) * T + tp] = t;
+        }
     }
 }
 
@@ -206,9 +223,9 @@ hipError_t cerb_launch_wgrad(const float* x, const float* dy, float* dw, int G, 
     else if (ks == 3) hipLaunchKernelGGL((wgrad_kernel<3, 2>), grid, dim3(256), 0, st, p);
     else if (stride == 1) hipLaunchKernelGGL((wgrad_kernel<1, 1>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((wgrad_kernel<1, 2>), grid, dim3(256), 0, st, p);
-    long long blocks = ((long long)tiles * ks * ks * 4096 + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, dw, G, Cin, Cout, ks * ks, slices);
+    long long blocks = (long long)tiles * ks * ks * 4096 / 64;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, (const float*)ws, dw, G, Cin, Cout, ks * ks, slices);
     return hipGetLastError();
 }
 
