@@ -699,17 +699,18 @@ __device__ __forceinline__ void up2_taps(int o, int n_src, int& i0, int& i1, flo
 }
 __global__ __launch_bounds__(256) void upadd_bwd_prev_kernel(const float* __restrict__ dout, float* __restrict__ dprev, int G, int N, int H, int W, int C,
                                                              long long prev_gs, int shared_prev) {
-    const int Hp = H / 2, Wp = W / 2;
-    const long long per_g = (long long)N * Hp * Wp * C, total = shared_prev ? per_g : per_g * G;
+    // thread = four channels of a source pixel; the (at most 4 x 4) output pixels it feeds are added in raster order, groups outermost
+    const int Hp = H / 2, Wp = W / 2, C4 = C >> 2;
+    const long long per_g = (long long)N * Hp * Wp * C4, total = shared_prev ? per_g : per_g * G;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int g = shared_prev ? 0 : (int)(i / per_g);
         long long r = i - (long long)g * per_g;
-        const int c = (int)(r % C);
-        r /= C;
+        const int c = 4 * (int)(r % C4);
+        r /= C4;
         const int pn = (int)(r % Wp);
         r /= Wp;
         const int pm = (int)(r % Hp), n = (int)(r / Hp);
-        float acc = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int gg = shared_prev ? 0 : g; gg < (shared_prev ? G : g + 1); ++gg)
             for (int y = max(2 * pm - 2, 0); y <= min(2 * pm + 2, H - 1); ++y) {
                 int a0, a1;
@@ -723,10 +724,15 @@ __global__ __launch_bounds__(256) void upadd_bwd_prev_kernel(const float* __rest
                     up2_taps(x, Wp, b0, b1, v0, v1);
                     const float wx = (b0 == pn ? v0 : 0.f) + (b1 == pn ? v1 : 0.f);
                     if (wx == 0.f) continue;
-                    acc += wy * wx * dout[((((long long)gg * N + n) * H + y) * W + x) * C + c];
+                    const float4 d = *reinterpret_cast<const float4*>(dout + ((((long long)gg * N + n) * H + y) * W + x) * C + c);
+                    const float wgt = wy * wx;
+                    acc.x += wgt * d.x; acc.y += wgt * d.y; acc.z += wgt * d.z; acc.w += wgt * d.w;
                 }
             }
-        dprev[(shared_prev ? 0 : g * prev_gs) + (i - (long long)g * per_g)] += acc;
+        float4* o = reinterpret_cast<float4*>(dprev + (shared_prev ? 0 : g * prev_gs) + (((long long)n * Hp + pm) * Wp + pn) * C + c);
+        float4 pv = *o;
+        pv.x += acc.x; pv.y += acc.y; pv.z += acc.z; pv.w += acc.w;
+        *o = pv;
     }
 }
 // pointwise (1x1) backward: dx[r][ci] += scale * sum_co dy[r][co] W[co][ci];  dW[co][ci] = sum_r dy[r][co] x[r][ci] scale
@@ -880,7 +886,7 @@ hipError_t cerb_launch_maxpool_bwd(const float* x, const float* ypool, const flo
 }
 hipError_t cerb_launch_upadd_bwd(const float* dout, float* dskip, float* dprev, int G, int N, int H, int W, int C, long long prev_gs, int shared_prev, hipStream_t st) {
     hipLaunchKernelGGL(upadd_bwd_skip_kernel, dim3(gridfor((long long)N * H * W * C)), dim3(256), 0, st, dout, dskip, G, (long long)N * H * W * C);
-    hipLaunchKernelGGL(upadd_bwd_prev_kernel, dim3(gridfor((long long)N * (H / 2) * (W / 2) * C * (shared_prev ? 1 : G))), dim3(256), 0, st, dout, dprev, G, N, H, W, C,
+    hipLaunchKernelGGL(upadd_bwd_prev_kernel, dim3(gridfor((long long)N * (H / 2) * (W / 2) * (C / 4) * (shared_prev ? 1 : G))), dim3(256), 0, st, dout, dprev, G, N, H, W, C,
                        prev_gs, shared_prev);
     return hipGetLastError();
 }
