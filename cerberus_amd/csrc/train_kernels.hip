@@ -735,6 +735,24 @@ __global__ __launch_bounds__(256) void upadd_bwd_prev_kernel(const float* __rest
         *o = pv;
     }
 }
+// data gradient of a 1x1 stride-2 conv (the residual downsample branches): only the even input positions receive anything --
+// dx[n][2 yo][2 xo][ci] += sum_co dy[n][yo][xo][co] W[co][ci]; thread = (output pixel, ci), the dy row is a broadcast
+__global__ __launch_bounds__(256) void conv1x1s2_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int N, int H, int W,
+                                                              int Cin, int Cout) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)N * Ho * Wo * Cin;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        long long r = i / Cin;
+        const int xo = (int)(r % Wo);
+        const long long r2 = r / Wo;
+        const int yo = (int)(r2 % Ho), n = (int)(r2 / Ho);
+        const float* d = dy + r * Cout;
+        float acc = 0.f;
+        for (int co = 0; co < Cout; ++co) acc = fmaf(d[co], w[(long long)co * Cin + ci], acc);
+        dx[(((long long)n * H + 2 * yo) * W + 2 * xo) * Cin + ci] += acc;
+    }
+}
 // pointwise (1x1) backward: dx[r][ci] += scale * sum_co dy[r][co] W[co][ci];  dW[co][ci] = sum_r dy[r][co] x[r][ci] scale
 __global__ __launch_bounds__(256) void pointwise_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, long long rows, int cin,
                                                               int cout, const float* __restrict__ in_scale, int assign) {
@@ -871,7 +889,9 @@ hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, f
 hipError_t cerb_launch_conv_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int G, int N, int H, int W, int Cin, int Cout,
                                 int ks, int stride, long long x_gs, hipStream_t st) {
     const int Ho = stride == 2 ? H / 2 : H, Wo = stride == 2 ? W / 2 : W;
-    if (dx) hipLaunchKernelGGL(conv_dgrad_kernel, dim3(gridfor((long long)G * N * H * W * Cin)), dim3(256), 0, st, dy, w, dx, G, N, H, W, Cin, Ho, Wo, Cout, ks, stride, x_gs);
+    if (dx && ks == 1 && stride == 2 && G == 1 && H % 2 == 0 && W % 2 == 0)
+        hipLaunchKernelGGL(conv1x1s2_dgrad_kernel, dim3(gridfor((long long)N * Ho * Wo * Cin)), dim3(256), 0, st, dy, w, dx, N, H, W, Cin, Cout);
+    else if (dx) hipLaunchKernelGGL(conv_dgrad_kernel, dim3(gridfor((long long)G * N * H * W * Cin)), dim3(256), 0, st, dy, w, dx, G, N, H, W, Cin, Ho, Wo, Cout, ks, stride, x_gs);
     if (dw) hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)((long long)G * Cout * Cin)), dim3(256), 0, st, x, dy, dw, N, H, W, Cin, Ho, Wo, Cout, ks, stride, x_gs);
     if (db) hipLaunchKernelGGL(colsum_kernel, dim3(G * Cout), dim3(256), 0, st, dy, (long long)N * Ho * Wo * Cout, (long long)N * Ho * Wo, Cout, db);
     return hipGetLastError();
