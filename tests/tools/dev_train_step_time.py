@@ -1,4 +1,4 @@
-"""Developer probe: wall time of one gradient step (train-mode forward + losses + backward) at growing sizes, first-version kernels."""
+"""Developer probe: wall time of one gradient step (train-mode forward + losses + backward) and of a whole train_step at growing sizes."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
