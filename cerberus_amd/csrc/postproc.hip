@@ -16,12 +16,16 @@
 //     are compared with one wave-wide argmin.  Ages are assigned in skimage's neighbour order (up, left, right,
 //     down), so equal-priority plateaus are split exactly as the reference splits them.  The only freedom skimage
 //     leaves to its binary heap's internal layout -- the order between SEED pixels with bit-identical priority --
-//     is resolved by raster index here and reported through n_ambiguous (DESIGN.md "watershed ties").
+//     is resolved by raster index here; the floods PROVE per component whether that order can reach the label map
+//     ("uncertain age" propagation, see ws_flood_kernel) and count the components where it can in n_ambiguous.
+//     When the count is not zero the map is re-flooded by ws_exact_kernel: a literal emulation of skimage's ONE
+//     global binary heap (all markers pushed in raster order, strict-less sift-up / sift-down) -- slow, exact.
 //   * gland / lumen: per instance crop (bounding box + conditional padding) -> elliptical dilation clipped to the
 //     crop -> fill holes inside the crop -> paste with "later id wins" (atomicMax).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstdlib>
@@ -282,6 +286,12 @@ __device__ __forceinline__ u32 order_key(float v) {  // monotone map float -> ui
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+// "Uncertain age" flag of a queue entry (top bit of its pixel / window index): the entry's position among entries of EQUAL
+// priority value is not determined by (value, age) alone -- it is a seed (all seeds enter with age 0 and skimage's heap layout
+// orders equal ones), or it was pushed by an entry popped inside such a tie (its age then inherits the tie's order).
+#define WS_UNC32 0x80000000u
+#define WS_UNC16 0x8000u
+
 // out[p] = mask ? marker : 0 ; per mask component: count of pixels that can ever enter the queue (upper bound of the
 // heap size = component area) is already known (area).  Seeds = labelled pixels with an unlabelled in-mask neighbour.
 __global__ void ws_init_out_kernel(const uint8_t* __restrict__ mask, const int* __restrict__ marker, int* __restrict__ out, int n) {
@@ -316,7 +326,7 @@ __global__ void ws_seed_kernel(const float* __restrict__ inst, long long row_str
         const int slot = hoff[root] + atomicAdd(&hcnt[root], 1);
         const float v = -inst[y * row_stride + (long long)x * pix_stride];  // watershed(-inst_inner_raw, ...)
         hkey[slot] = ((u64)order_key(v) << 32);  // age 0
-        hidx[slot] = (u32)p;
+        hidx[slot] = (u32)p | WS_UNC32;          // every seed's pop position among equal-valued seeds is skimage's heap layout's choice
     }
 }
 // bounding box of every kept mask component, keyed by its root pixel (only outline pixels issue atomics)
@@ -348,9 +358,6 @@ __global__ void ws_bbox_kernel(const int* __restrict__ L, const uint8_t* __restr
 //   global tier : everything else                                                        -> heap in global memory (back of wl)
 //   big-window  : bounding box fits WS_BIGWIN_CAP pixels and (seeds + unlabelled mask pixels) <= WS_BIGHEAP_CAP: one wave per
 //                 workgroup with ~150 KB of LDS                                                                  (wl3)
-#ifndef WS_FLAT_QUEUE
-#define WS_FLAT_QUEUE 1
-#endif
 #define WS_LDS_CAP 1024
 #define WS_WIN_CAP 2304
 #define WS_TINY_CAP 512    // tiny-window tier: pairs / small clusters; 13 KB of LDS per wave -> 12 waves per CU instead of 4
@@ -386,10 +393,6 @@ __global__ void ws_fill_single_kernel(const uint8_t* __restrict__ mask, const in
     }
 }
 
-struct HeapRef {
-    u64* key;
-    u32* idx;
-};
 __device__ __forceinline__ bool hless(u64 k1, u32 i1, u64 k2, u32 i2) { return k1 < k2 || (k1 == k2 && i1 < i2); }
 
 // wave-wide min of a u32: 4 DPP row rotations (min inside each 16-lane row), then the 4 row results via readlane.
@@ -463,6 +466,35 @@ __device__ __forceinline__ void heap_push(volatile u64* hk, volatile u32* hi, in
 // One wavefront per mask component.  Exact sequential priority flood (skimage _watershed_cy.watershed_raveled,
 // compactness 0, no watershed line): pop min (value, age); for neighbours in order up, left, right, down: if in mask
 // and unlabelled -> label it NOW with the popped pixel's label, age += 1, push.
+//
+// Tie rule (all flood kernels; validated on the CPU against the oracle's literal heap by tests/tools/dev_tie_rule_fuzz.py).
+// (value, age) is a total order except between age-0 seeds of equal value, where skimage's global heap layout decides and this
+// kernel takes raster order instead.  That choice reaches the label map only through
+//   (a) a DIRECT conflict: the popped entry X labels a pixel q that also touches an equal-valued pixel of ANOTHER label
+//       (whichever of the two pops first claims q), or
+//   (b) the AGES of the pixels X pushes, which inherit X's position inside its tie and matter again only where such
+//       children tie in value among themselves -- so pushed entries carry the "uncertain age" flag of WS_UNC32 and rule (a) is
+//       applied to them in turn, and
+//   (c) a child that is smaller than the tied value itself: it pops before the rest of the tie, which the bookkeeping of
+//       (b) assumes cannot happen (conservatively counted as ambiguous).
+// X is "inside a tie" when it carries the flag and the entry popped before it or the one popped after it has X's value.
+// A component where none of (a)/(c) fires is labelled identically under every tie order, skimage's included.
+__device__ __forceinline__ bool ws_conflict_global(const float* __restrict__ inst, long long row_stride, int pix_stride, const int* out, long long q,
+                                                   long long p, int lab, u32 v, int H, int W) {
+    const int qy = (int)(q / W), qx = (int)(q % W);
+    bool hit = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int wy = qy + (j == 0 ? -1 : j == 3 ? 1 : 0), wx = qx + (j == 1 ? -1 : j == 2 ? 1 : 0);
+        if (wy < 0 || wy >= H || wx < 0 || wx >= W) continue;
+        const long long w = (long long)wy * W + wx;
+        if (w == p) continue;
+        const int ow = __hip_atomic_load(&out[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ow != 0 && ow != lab && order_key(-inst[wy * row_stride + (long long)wx * pix_stride]) == v) hit = true;
+    }
+    return hit;
+}
+
 __global__ __launch_bounds__(256) void ws_flood_kernel(const float* __restrict__ inst, long long row_stride, int pix_stride,
                                                        const uint8_t* __restrict__ mask, int* out, const int* __restrict__ wl,
                                                        const int* __restrict__ wl_n, const int* __restrict__ hoff, const int* __restrict__ hcnt,
@@ -482,12 +514,12 @@ __global__ __launch_bounds__(256) void ws_flood_kernel(const float* __restrict__
             heap_sift_down(hk, hi, n, i, k, x);
         }
         u32 age = 0;
-        bool have_prev_seed = false, ambiguous = false;
-        u32 prev_seed_val = 0;
-        int prev_seed_lab = 0;
+        bool have_prev = false, ambiguous = false;
+        u32 prev_val = 0;
         while (n > 0) {
             const u64 k = hk[0];
-            const u32 p = hi[0];
+            const u32 pu = hi[0];
+            const u32 p = pu & ~WS_UNC32;
             --n;
             if (n > 0) {
                 const u64 lk = hk[n];
@@ -495,16 +527,12 @@ __global__ __launch_bounds__(256) void ws_flood_kernel(const float* __restrict__
                 heap_sift_down(hk, hi, n, 0, lk, li);
             }
             const int lab = __hip_atomic_load(&out[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((u32)k == 0u) {
-                // A seed (age 0).  skimage's pop order between seeds with bit-identical priority depends on its binary
-                // heap's layout; that order can only change the result when the tied seeds carry DIFFERENT labels
-                // (same-label ties only permute ages inside one label's own front) -- see DESIGN.md "watershed ties".
-                const u32 v = (u32)(k >> 32);
-                if (have_prev_seed && v == prev_seed_val && lab != prev_seed_lab) ambiguous = true;
-                have_prev_seed = true;
-                prev_seed_val = v;
-                prev_seed_lab = lab;
-            }
+            const u32 v = (u32)(k >> 32);
+            bool tied = have_prev && prev_val == v;
+            if (!tied && n > 0) tied = (u32)(hk[0] >> 32) == v;  // the new minimum
+            const bool unc = (pu & WS_UNC32) && tied;
+            have_prev = true;
+            prev_val = v;
             const int y = (int)(p / (u32)W), x = (int)(p % (u32)W);
             // lanes 0..3 look at the four neighbours in skimage's order: up, left, right, down
             long long q = -1;
@@ -513,25 +541,26 @@ __global__ __launch_bounds__(256) void ws_flood_kernel(const float* __restrict__
             if (lane == 2 && x < W - 1) q = (long long)p + 1;
             if (lane == 3 && y < H - 1) q = (long long)p + W;
             bool elig = false;
-            float v = 0.f;
+            u32 vq = 0;
             if (q >= 0 && mask[q]) {
                 elig = __hip_atomic_load(&out[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
                 if (elig) {
                     __hip_atomic_store(&out[q], lab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const int qy = (int)(q / W), qx = (int)(q % W);
-                    v = -inst[qy * row_stride + (long long)qx * pix_stride];
+                    vq = order_key(-inst[qy * row_stride + (long long)qx * pix_stride]);
                 }
             }
+            if (unc && elig && (vq < v || ws_conflict_global(inst, row_stride, pix_stride, out, q, p, lab, v, H, W))) ambiguous = true;
             const u64 em = __ballot(elig);
             for (int t = 0; t < 4; ++t) {
                 if (!((em >> t) & 1)) continue;
                 ++age;
-                const u32 qk = order_key(__shfl(v, t));
-                const u32 qi = (u32)__shfl((int)q, t);
+                const u32 qk = (u32)__shfl((int)vq, t);
+                const u32 qi = (u32)__shfl((int)q, t) | (unc ? WS_UNC32 : 0u);
                 heap_push(hk, hi, &n, ((u64)qk << 32) | age, qi);
             }
         }
-        if (ambiguous && lane == 0) atomicAdd(n_ambiguous, 1);
+        if (__any(ambiguous) && lane == 0) atomicAdd(n_ambiguous, 1);
     }
 }
 
@@ -582,23 +611,21 @@ __global__ __launch_bounds__(WAVES * 64) void ws_flood_window_kernel(const float
             if (seed) {
                 const int slot = n + __popcll(m & ((1ull << lane) - 1));
                 hk[slot] = (u64)vl[i] << 32;  // age 0
-                hi[slot] = (unsigned short)i;
+                hi[slot] = (unsigned short)(i | WS_UNC16);
             }
             n += __popcll(m);
         }
-#if WS_FLAT_QUEUE
         // ---- flood with an UNORDERED queue: the frontier of a nucleus cluster is a few dozen to a few hundred entries, so the
         // minimum is found by one strided scan (each lane keeps the best of its entries) + one wave-wide argmin, the popped slot is
         // refilled with the last entry and the (up to four) pushes are plain appends done by lanes 0..3 in parallel.  Same total
-        // order as the heap ((value, age), then window index), hence the same pops.
+        // order as the heap ((value, age), then window index), hence the same pops.  Tie rule: see ws_flood_kernel.
         u32 age = 0;
-        bool have_prev_seed = false, ambiguous = false;
-        u32 prev_seed_val = 0;
-        int prev_seed_lab = 0;
+        bool have_prev = false, ambiguous = false;
+        u32 prev_val = 0;
         while (n > 0) {
             u64 bk = ~0ull;
             u32 bi = ~0u;
-            int bpos = -1;
+            int bpos = -1, bc = 0;  // bc: how many of this lane's entries carry the lane's smallest VALUE
             {
                 // four strided entries per lane and trip: the LDS reads of a trip are independent, so their latencies overlap
                 // (plain pointers for that; the empty asm keeps the compiler from carrying queue contents across pops)
@@ -617,10 +644,14 @@ __global__ __launch_bounds__(WAVES * 64) void ws_flood_window_kernel(const float
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        if (c + 64 * u < n && (bpos < 0 || hless(ck[u], ci[u], bk, bi))) {
-                            bk = ck[u];
-                            bi = ci[u];
-                            bpos = c + 64 * u;
+                        if (c + 64 * u < n) {
+                            const u32 cv = (u32)(ck[u] >> 32), bv = (u32)(bk >> 32);
+                            bc = (bpos < 0 || cv < bv) ? 1 : bc + (cv == bv);
+                            if (bpos < 0 || hless(ck[u], ci[u], bk, bi)) {
+                                bk = ck[u];
+                                bi = ci[u];
+                                bpos = c + 64 * u;
+                            }
                         }
                 }
                 asm volatile("" ::: "memory");
@@ -629,19 +660,20 @@ __global__ __launch_bounds__(WAVES * 64) void ws_flood_window_kernel(const float
             u32 wi_u;
             const int wl_ = wave_argmin(bk, bi, bpos >= 0, &k, &wi_u);
             const int pos = __shfl(bpos, wl_);
-            const int wi = (int)wi_u;
+            const int wi = (int)(wi_u & ~WS_UNC16);
             const int lab = st[wi];
+            const u32 v = (u32)(k >> 32);
+            // another queue entry with the popped value?  (two lanes hold one, or one lane holds two)
+            const bool mine = bpos >= 0 && (u32)(bk >> 32) == v;
+            const u64 holders = __ballot(mine);
+            const bool tied = (have_prev && prev_val == v) || __popcll(holders) >= 2 || __ballot(mine && bc >= 2) != 0;
+            const bool unc = (wi_u & WS_UNC16) && tied;
+            have_prev = true;
+            prev_val = v;
             --n;
             if (lane == 0 && pos != n) {
                 hk[pos] = hk[n];
                 hi[pos] = hi[n];
-            }
-            if ((u32)k == 0u) {  // seed: see ws_flood_kernel
-                const u32 v = (u32)(k >> 32);
-                if (have_prev_seed && v == prev_seed_val && lab != prev_seed_lab) ambiguous = true;
-                have_prev_seed = true;
-                prev_seed_val = v;
-                prev_seed_lab = lab;
             }
             // lanes 0..3: up, left, right, down (skimage's neighbour order); the ring of -1 makes bounds checks unnecessary
             const int nq = wi + (lane == 0 ? -ww : lane == 1 ? -1 : lane == 2 ? 1 : ww);
@@ -650,127 +682,31 @@ __global__ __launch_bounds__(WAVES * 64) void ws_flood_window_kernel(const float
             const u64 em = __ballot(elig);
             if (elig) {
                 const int before = __popcll(em & ((1ull << lane) - 1));
+                const u32 vq = vl[nq];
                 st[nq] = lab;
-                hk[n + before] = ((u64)vl[nq] << 32) | (u64)(age + 1 + before);
-                hi[n + before] = (unsigned short)nq;
+                hk[n + before] = ((u64)vq << 32) | (u64)(age + 1 + before);
+                hi[n + before] = (unsigned short)(nq | (unc ? WS_UNC16 : 0u));
+                if (unc) {
+                    if (vq < v) ambiguous = true;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int wq = nq + (j == 0 ? -ww : j == 1 ? -1 : j == 2 ? 1 : ww);
+                        if (wq == wi) continue;
+                        const int sw = st[wq];
+                        if (sw > 0 && sw != lab && vl[wq] == v) ambiguous = true;
+                    }
+                }
             }
             const int np = __popcll(em);
             n += np;
             age += np;
         }
-#else
-        // ---- heapify (Floyd) ----------------------------------------------------------------------------------------------
-        for (int i = (n - 2) >> 6; i >= 0 && n > 1; --i) {
-            const u64 k = hk[i];
-            const u32 x = hi[i];
-            int pos = i;
-            for (;;) {
-                const int c0 = 64 * pos + 1;
-                if (c0 >= n) break;
-                const int c = c0 + lane;
-                const bool valid = c < n;
-                const u64 ck = valid ? hk[c] : 0;
-                const u32 ci = valid ? hi[c] : 0;
-                u64 mk;
-                u32 mi;
-                const int ml = wave_argmin(ck, ci, valid, &mk, &mi);
-                if (!hless(mk, mi, k, x)) break;
-                if (lane == 0) {
-                    hk[pos] = mk;
-                    hi[pos] = (unsigned short)mi;
-                }
-                pos = c0 + ml;
-            }
-            if (lane == 0) {
-                hk[pos] = k;
-                hi[pos] = (unsigned short)x;
-            }
-        }
-        // ---- flood ------------------------------------------------------------------------------------------------------------
-        u32 age = 0;
-        bool have_prev_seed = false, ambiguous = false;
-        u32 prev_seed_val = 0;
-        int prev_seed_lab = 0;
-        while (n > 0) {
-            const u64 k = hk[0];
-            const int wi = hi[0];
-            const int lab = st[wi];
-            --n;
-            if (n > 0) {
-                const u64 lk = hk[n];
-                const u32 li = hi[n];
-                int pos = 0;
-                for (;;) {
-                    const int c0 = 64 * pos + 1;
-                    if (c0 >= n) break;
-                    const int c = c0 + lane;
-                    const bool valid = c < n;
-                    const u64 ck = valid ? hk[c] : 0;
-                    const u32 ci = valid ? hi[c] : 0;
-                    u64 mk;
-                    u32 mi;
-                    const int ml = wave_argmin(ck, ci, valid, &mk, &mi);
-                    if (!hless(mk, mi, lk, li)) break;
-                    if (lane == 0) {
-                        hk[pos] = mk;
-                        hi[pos] = (unsigned short)mi;
-                    }
-                    pos = c0 + ml;
-                }
-                if (lane == 0) {
-                    hk[pos] = lk;
-                    hi[pos] = (unsigned short)li;
-                }
-            }
-            if ((u32)k == 0u) {  // seed: see ws_flood_kernel
-                const u32 v = (u32)(k >> 32);
-                if (have_prev_seed && v == prev_seed_val && lab != prev_seed_lab) ambiguous = true;
-                have_prev_seed = true;
-                prev_seed_val = v;
-                prev_seed_lab = lab;
-            }
-            // lanes 0..3: up, left, right, down (skimage's neighbour order); the ring of -1 makes bounds checks unnecessary
-            const int nq = wi + (lane == 0 ? -ww : lane == 1 ? -1 : lane == 2 ? 1 : ww);
-            bool elig = false;
-            u32 v = 0;
-            if (lane < 4) {
-                elig = st[nq] == 0;
-                if (elig) {
-                    st[nq] = lab;
-                    v = vl[nq];
-                }
-            }
-            const u64 em = __ballot(elig);
-            for (int t = 0; t < 4; ++t) {
-                if (!((em >> t) & 1)) continue;
-                ++age;
-                const u64 nk = ((u64)__shfl(v, t) << 32) | age;
-                const u32 nx = (u32)__shfl(nq, t);
-                int jn = n++;
-                while (jn > 0) {
-                    const int par = (jn - 1) >> 6;
-                    const u64 pk = hk[par];
-                    const u32 pi = hi[par];
-                    if (!hless(nk, nx, pk, pi)) break;
-                    if (lane == 0) {
-                        hk[jn] = pk;
-                        hi[jn] = (unsigned short)pi;
-                    }
-                    jn = par;
-                }
-                if (lane == 0) {
-                    hk[jn] = nk;
-                    hi[jn] = (unsigned short)nx;
-                }
-            }
-        }
-#endif
         // ---- write back -----------------------------------------------------------------------------------------------------
         for (int i = lane; i < wn; i += 64) {
             const int s = st[i];
             if (s > 0) out[(long long)(b.y1 - 1 + i / ww) * W + (b.x1 - 1 + i % ww)] = s;
         }
-        if (ambiguous && lane == 0) atomicAdd(n_ambiguous, 1);
+        if (__any(ambiguous) && lane == 0) atomicAdd(n_ambiguous, 1);
     }
 }
 
@@ -798,7 +734,7 @@ __global__ __launch_bounds__(256) void ws_flood_lds_kernel(const float* __restri
             const u32 px = hidx[base + i];
             hk[i] = hkey[base + i];
             hi[i] = px;
-            hl[i] = out[px];
+            hl[i] = out[px & ~WS_UNC32];
         }
         // heapify (Floyd) -- (key, idx) order; the label rides along
         for (int i = (n - 2) >> 6; i >= 0 && n > 1; --i) {
@@ -831,12 +767,12 @@ __global__ __launch_bounds__(256) void ws_flood_lds_kernel(const float* __restri
             }
         }
         u32 age = 0;
-        bool have_prev_seed = false, ambiguous = false;
-        u32 prev_seed_val = 0;
-        int prev_seed_lab = 0;
+        bool have_prev = false, ambiguous = false;
+        u32 prev_val = 0;
         while (n > 0) {
             const u64 k = hk[0];
-            const u32 p = hi[0];
+            const u32 pu = hi[0];
+            const u32 p = pu & ~WS_UNC32;
             const int lab = hl[0];
             --n;
             if (n > 0) {  // move the last entry to the root and sift it down
@@ -869,13 +805,13 @@ __global__ __launch_bounds__(256) void ws_flood_lds_kernel(const float* __restri
                     hl[pos] = ll;
                 }
             }
-            if ((u32)k == 0u) {  // seed: see ws_flood_kernel
-                const u32 v = (u32)(k >> 32);
-                if (have_prev_seed && v == prev_seed_val && lab != prev_seed_lab) ambiguous = true;
-                have_prev_seed = true;
-                prev_seed_val = v;
-                prev_seed_lab = lab;
-            }
+            // tie rule: see ws_flood_kernel
+            const u32 v = (u32)(k >> 32);
+            bool tied = have_prev && prev_val == v;
+            if (!tied && n > 0) tied = (u32)(hk[0] >> 32) == v;
+            const bool unc = (pu & WS_UNC32) && tied;
+            have_prev = true;
+            prev_val = v;
             const int y = (int)(p / (u32)W), x = (int)(p % (u32)W);
             long long q = -1;
             if (lane == 0 && y > 0) q = (long long)p - W;
@@ -883,22 +819,23 @@ __global__ __launch_bounds__(256) void ws_flood_lds_kernel(const float* __restri
             if (lane == 2 && x < W - 1) q = (long long)p + 1;
             if (lane == 3 && y < H - 1) q = (long long)p + W;
             bool elig = false;
-            float v = 0.f;
+            u32 vq = 0;
             if (q >= 0) {
                 // one round trip: mask, current label and priority of the neighbour
                 const uint8_t mq = mask[q];
                 const int oq = __hip_atomic_load(&out[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int qy = (int)(q / W), qx = (int)(q % W);
-                v = -inst[qy * row_stride + (long long)qx * pix_stride];
+                vq = order_key(-inst[qy * row_stride + (long long)qx * pix_stride]);
                 elig = mq && oq == 0;
                 if (elig) __hip_atomic_store(&out[q], lab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (unc && elig && (vq < v || ws_conflict_global(inst, row_stride, pix_stride, out, q, p, lab, v, H, W))) ambiguous = true;
             const u64 em = __ballot(elig);
             for (int t = 0; t < 4; ++t) {
                 if (!((em >> t) & 1)) continue;
                 ++age;
-                const u64 nk = ((u64)order_key(__shfl(v, t)) << 32) | age;
-                const u32 nx = (u32)__shfl((int)q, t);
+                const u64 nk = ((u64)(u32)__shfl((int)vq, t) << 32) | age;
+                const u32 nx = (u32)__shfl((int)q, t) | (unc ? WS_UNC32 : 0u);
                 int jn = n++;
                 while (jn > 0) {
                     const int par = (jn - 1) >> 6;
@@ -920,7 +857,217 @@ __global__ __launch_bounds__(256) void ws_flood_lds_kernel(const float* __restri
                 }
             }
         }
-        if (ambiguous && lane == 0) atomicAdd(n_ambiguous, 1);
+        if (__any(ambiguous) && lane == 0) atomicAdd(n_ambiguous, 1);
+    }
+}
+
+// =================================================================================================================
+// Exact tie order: literal emulation of skimage's global heap (runs only when a flood flagged an ambiguous component)
+// =================================================================================================================
+// skimage.segmentation.watershed keeps ONE binary heap for the whole image (_watershed_cy.pyx + _shared/heap_general.pxi;
+// restated and pinned against the real library in oracle/postproc_ref.c::ref_watershed): every marker pixel is pushed in
+// raster order with age 0, `smaller` is strict on (value, age), heappush sifts up while the new entry is smaller than its
+// parent, heappop moves the LAST entry to the root and sifts it down preferring the left child on equal keys.  The order in
+// which equal-valued markers leave that heap is a function of its whole push / pop history, so it cannot be evaluated per
+// component: one wavefront replays the history.  The replay is literal (same array layout, same comparisons) but each heap
+// operation is wave-cooperative: a pop gathers the six levels below the hole with one load per lane pair (126 descendants),
+// walks them in registers (readlane) and repeats; a push gathers all <= 31 ancestors of the new leaf at once, and -- the path
+// being sorted -- shifts the ancestors that are larger down by one in a single scatter.  Heap positions [0, 8191) (13 levels)
+// live in LDS, deeper ones in global memory; the four neighbour probes of a pop are issued before its sift-down.
+#define EX_LDS 8191
+struct ExHeap {
+    volatile u64* sk;
+    volatile u32* si;
+    u64* gk;
+    u32* gi;
+};
+__device__ __forceinline__ void ex_load(const ExHeap& h, long long pos, u64& k, u32& i) {
+    if (pos < EX_LDS) {
+        k = h.sk[pos];
+        i = h.si[pos];
+    } else {
+        k = __hip_atomic_load(&h.gk[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        i = __hip_atomic_load(&h.gi[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void ex_store(const ExHeap& h, long long pos, u64 k, u32 i) {
+    if (pos < EX_LDS) {
+        h.sk[pos] = k;
+        h.si[pos] = i;
+    } else {
+        __hip_atomic_store(&h.gk[pos], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&h.gi[pos], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ u32 ex_uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 ex_uni64(u64 v) { return ((u64)ex_uni((u32)(v >> 32)) << 32) | ex_uni((u32)v); }
+__device__ __forceinline__ u64 ex_lane64(u64 v, int l) {
+    return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, l);
+}
+// position of local node j (0 = the hole, children 2j+1 / 2j+2) of the subtree rooted at heap position i
+__device__ __forceinline__ long long ex_pos(long long i, int j) {
+    const int d = 31 - __clz(j + 1);
+    return ((i + 1) << d) - 1 + (j + 1 - (1 << d));
+}
+// heappop's tail: entry x (the former last entry) enters at the root of a heap of n entries and sifts down
+__device__ __forceinline__ void ex_sift_down(const ExHeap& h, int n, u64 xk, u32 xi) {
+    const int lane = threadIdx.x & 63;
+    long long i = 0;
+    for (;;) {
+        u64 ka = 0, kb = 0;
+        u32 ia = 0, ib = 0;
+        if (lane >= 1) {
+            const long long pa = ex_pos(i, lane);
+            if (pa < n) ex_load(h, pa, ka, ia);
+        }
+        if (lane <= 62) {
+            const long long pb = ex_pos(i, lane + 64);
+            if (pb < n) ex_load(h, pb, kb, ib);
+        }
+        int cur = 0;
+        bool placed = false;
+#pragma unroll 1
+        for (int step = 0; step < 6; ++step) {
+            const int l = 2 * cur + 1, r = l + 1;
+            const long long pl = ex_pos(i, l);
+            if (pl >= n) {
+                placed = true;
+                break;
+            }
+            const u64 kl = l < 64 ? ex_lane64(ka, l) : ex_lane64(kb, l - 64);
+            int s = cur;
+            u64 ks = xk;
+            if (kl < xk) {  // smaller(l, i)
+                s = l;
+                ks = kl;
+            }
+            if (pl + 1 < n) {
+                const u64 kr = r < 64 ? ex_lane64(ka, r) : ex_lane64(kb, r - 64);
+                if (kr < ks) s = r;  // smaller(r, smallest)
+            }
+            if (s == cur) {
+                placed = true;
+                break;
+            }
+            if (lane == (s & 63)) ex_store(h, ex_pos(i, cur), s < 64 ? ka : kb, s < 64 ? ia : ib);  // child moves up into the hole
+            cur = s;
+        }
+        const long long pc = ex_pos(i, cur);
+        if (placed) {
+            if (lane == 0) ex_store(h, pc, xk, xi);
+            return;
+        }
+        i = pc;
+    }
+}
+// heappush: new entry y at leaf position n (n = heap size before the push)
+__device__ __forceinline__ void ex_push(const ExHeap& h, int n, u64 yk, u32 yi) {
+    const int lane = threadIdx.x & 63;
+    const long long np1 = (long long)n + 1;
+    const long long qa = lane < 32 ? (np1 >> (lane + 1)) : 0;  // lane t: the ancestor t+1 levels above the leaf
+    u64 ak = 0;
+    u32 ai = 0;
+    if (qa >= 1) ex_load(h, qa - 1, ak, ai);
+    const u64 up = __ballot(qa >= 1 && yk < ak);                // smaller(child, parent): strict
+    const int m = __ffsll((long long)~up) - 1;                  // the path is sorted: the larger ancestors are lanes 0 .. m-1
+    if (lane < m) ex_store(h, (np1 >> lane) - 1, ak, ai);       // each moves one step down the path (lane 0's lands on the leaf)
+    if (lane == 0) ex_store(h, (np1 >> m) - 1, yk, yi);
+}
+
+__global__ void ws_exact_reset_kernel(const uint8_t* __restrict__ mrk, const uint8_t* __restrict__ mask, int* __restrict__ out, int n,
+                                      const int* __restrict__ flag) {
+    if (*flag == 0) return;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
+        if (!(mrk[p] && mask[p])) out[p] = 0;  // back to markers * mask: a marker pixel keeps its label through every flood
+}
+
+__global__ __launch_bounds__(64) void ws_exact_kernel(const float* __restrict__ inst, long long row_stride, int pix_stride,
+                                                      const uint8_t* __restrict__ mask, int* out, u64* hkey, u32* hidx, int H, int W,
+                                                      const int* __restrict__ flag) {
+    if (*flag == 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_ex[];
+    ExHeap h;
+    h.sk = reinterpret_cast<volatile u64*>(s_ex);
+    h.si = reinterpret_cast<volatile u32*>(s_ex + (size_t)EX_LDS * 8 + 8);
+    h.gk = hkey;
+    h.gi = hidx;
+    const int lane = threadIdx.x & 63;
+    const long long N = (long long)H * W;
+    int n = 0;
+    // ---- all marker pixels, raster order, age 0 (8 chunks of 64 pixels in flight) ----------------------------------------
+    for (long long base = 0; base < N; base += 512) {
+        int o[8];
+        u32 kv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long p = base + u * 64 + lane;
+            o[u] = p < N ? out[p] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long p = base + u * 64 + lane;
+            kv[u] = 0;
+            if (o[u]) {
+                const int y = (int)(p / W), x = (int)(p % W);
+                kv[u] = order_key(-inst[y * row_stride + (long long)x * pix_stride]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            u64 m = __ballot(o[u] != 0);
+            while (m) {
+                const int j = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const u32 key = (u32)__builtin_amdgcn_readlane((int)kv[u], j);
+                ex_push(h, n, (u64)key << 32, (u32)(base + u * 64 + j));
+                ++n;
+            }
+        }
+    }
+    // ---- the flood -----------------------------------------------------------------------------------------------------------
+    u32 age = 0;
+    while (n > 0) {
+        u64 rk;
+        u32 ri;
+        ex_load(h, 0, rk, ri);
+        const u32 p = ex_uni(ri);
+        const int y = (int)(p / (u32)W), x = (int)(p % (u32)W);
+        // neighbour probes first: they only depend on the popped pixel
+        const int lab = __hip_atomic_load(&out[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long long q = -1;
+        if (lane == 0 && y > 0) q = (long long)p - W;
+        if (lane == 1 && x > 0) q = (long long)p - 1;
+        if (lane == 2 && x < W - 1) q = (long long)p + 1;
+        if (lane == 3 && y < H - 1) q = (long long)p + W;
+        uint8_t mq = 0;
+        int oq = 1;
+        float vq = 0.f;
+        if (q >= 0) {
+            mq = mask[q];
+            oq = __hip_atomic_load(&out[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int qy = (int)(q / W), qx = (int)(q % W);
+            vq = -inst[qy * row_stride + (long long)qx * pix_stride];
+        }
+        --n;
+        if (n > 0) {
+            u64 xk;
+            u32 xi;
+            ex_load(h, n, xk, xi);
+            ex_sift_down(h, n, ex_uni64(xk), ex_uni(xi));
+        }
+        const bool elig = q >= 0 && mq && oq == 0;
+        if (elig) __hip_atomic_store(&out[q], lab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u32 kq = order_key(vq);
+        const u64 em = __ballot(elig);
+#pragma unroll 1
+        for (int t = 0; t < 4; ++t) {
+            if (!((em >> t) & 1)) continue;
+            ++age;
+            const u32 qk = (u32)__builtin_amdgcn_readlane((int)kq, t);
+            const u32 qi = (u32)__builtin_amdgcn_readlane((int)(u32)q, t);
+            ex_push(h, n, ((u64)qk << 32) | age, qi);
+            ++n;
+        }
     }
 }
 
@@ -1148,6 +1295,12 @@ static SideStreams* side_streams() {  // one set per device, created on first us
     return per_dev[dev];
 }
 
+// Literal skimage tie order for maps whose floods flag an ambiguous component (default on).  The WSI band driver turns it off:
+// the reference floods 4096^2 tiles there (infer/wsi.py:143-149), so the tie order of its heap is a property of ITS tiling.
+static std::atomic<int> g_exact_ties{1};
+extern "C" void cerb_pp_set_exact_ties(int on) { g_exact_ties.store(on ? 1 : 0); }
+extern "C" int cerb_pp_get_exact_ties(void) { return g_exact_ties.load(); }
+
 extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long row_stride, int pix_stride, int32_t* labels_out,
                                     int32_t* n_inst_out, int32_t* n_ambiguous_out, void* ws, size_t ws_bytes, void* hip_stream) {
     hipStream_t st = (hipStream_t)hip_stream;
@@ -1252,6 +1405,18 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
         }
     }
     KCHECK();
+    if (g_exact_ties.load()) {
+        // Components whose result depends on skimage's heap-layout order between equal-valued markers were counted in small[3]:
+        // when there is one, the whole map is re-flooded through the literal emulation of that heap (both kernels return at once
+        // when the count is zero -- no host round trip decides this).
+        constexpr int lds_exact = EX_LDS * 8 + 8 + EX_LDS * 4 + 4;
+        static bool attr_done2[64] = {};
+        if (cerb_attr_needed(attr_done2))
+            PP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_exact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_exact));
+        hipLaunchKernelGGL(ws_exact_reset_kernel, dim3(g), dim3(256), 0, st, mrk, msk, labels_out, n, small + 3);
+        hipLaunchKernelGGL(ws_exact_kernel, dim3(1), dim3(64), lds_exact, st, inst, row_stride, pix_stride, msk, labels_out, hkey, hidx, H, W, small + 3);
+        KCHECK();
+    }
     if (n_ambiguous_out) PP_OK(hipMemcpyAsync(n_ambiguous_out, small + 3, 4, hipMemcpyDeviceToDevice, st));
     return 0;
 }

@@ -29,10 +29,15 @@ def _workspace(device, h, w):
     return t
 
 
-def postproc_device(inst, tissue_mode, ds_factor=1.0, out=None):
+def postproc_device(inst, tissue_mode, ds_factor=1.0, out=None, exact_ties=True):
     """inst: CUDA float32 tensor (H,W,2) or a strided (H,W,>=2) window of a canvas (channel 0 inner, 1 contour).
     Returns (labels int32 CUDA (H,W), info) with info = {'n_inst': 0-d CUDA int32 (-1: empty nuclei map),
-    'n_ambiguous': 0-d CUDA int32 (nuclei only)}.  Nothing is synchronised for nuclei."""
+    'n_ambiguous': 0-d CUDA int32 (nuclei only)}.  Nothing is synchronised for nuclei.
+
+    exact_ties (nuclei): when the floods count a region whose labels depend on the order in which skimage's heap releases
+    equal-valued markers (n_ambiguous > 0), re-flood the map through the on-device replay of that heap so that the result is
+    skimage's (loader/postproc.py:378) in every case.  The WSI band drivers pass False: the reference floods 4096^2 tiles there
+    (infer/wsi.py:143-149), so its tie order belongs to its tiling and a slide-sized replay would buy nothing."""
     if not torch.cuda.is_available():
         raise _lib.CerberusHipError("cerberus_amd needs a ROCm GPU; there is no CPU fallback")
     L = _lib.lib()
@@ -48,6 +53,7 @@ def postproc_device(inst, tissue_mode, ds_factor=1.0, out=None):
     t = tissue_mode.upper()
     with torch.cuda.device(dev):
         if t == "NUCLEI":
+            L.cerb_pp_set_exact_ties(1 if exact_ties else 0)
             _lib.check(L.cerb_postproc_nuclei(inst.data_ptr(), h, w, inst.stride(0), inst.stride(1), labels.data_ptr(), meta.data_ptr(),
                                               meta.data_ptr() + 4, ws.data_ptr(), ws.numel(), C.c_void_p(stream)))
         elif t in ("GLAND", "LUMEN"):

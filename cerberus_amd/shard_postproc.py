@@ -31,7 +31,7 @@ import torch
 def _device_label_fn(window, tissue, ds_factor):
     from .postproc import postproc_device
 
-    lab, info = postproc_device(window, tissue, ds_factor)
+    lab, info = postproc_device(window, tissue, ds_factor, exact_ties=False)  # WSI bands: see postproc_device
     n = int(info["n_inst"].item())
     return lab, max(n, 0)
 

@@ -56,3 +56,40 @@ def gland_maps(H, W, seed, n=None, **kw):
     kw.setdefault("rim", 4.0)
     kw.setdefault("sharp", 1.0)
     return blob_maps(H, W, seed, n, 25.0, 150.0, **kw)
+
+
+def softmax_nuclei_maps(H, W, seed, density_per_mpx=600.0, gain=4.0, logit_noise=0.5, rim=2.0, rmin=4.0, rmax=9.0):
+    """(H,W,2) float32 inner / contour maps computed the way a trained head produces them: a float32 softmax over three logits
+    (background, inner, contour).  With gain >= ~3 the nucleus cores saturate to EXACTLY 1.0f (logit gap > 17) while rim pixels
+    keep generic, pairwise distinct floats -- the tie pattern of a confident network (SURVEY par.7 "Hard parts")."""
+    n = max(1, int(round(density_per_mpx * H * W / 1e6)))
+    rs = np.random.RandomState(seed)
+    d = np.full((H, W), -40.0, np.float32)
+    for _ in range(n):
+        r = rs.uniform(rmin, rmax)
+        cy, cx = rs.uniform(0, H), rs.uniform(0, W)
+        ax, th = rs.uniform(0.7, 1.3), rs.uniform(0, np.pi)
+        ext = int(np.ceil(r * 1.45 + 14.0))
+        y0, y1 = max(0, int(cy) - ext), min(H, int(cy) + ext + 1)
+        x0, x1 = max(0, int(cx) - ext), min(W, int(cx) + ext + 1)
+        if y0 >= y1 or x0 >= x1:
+            continue
+        yy, xx = np.mgrid[y0:y1, x0:x1].astype(np.float32)
+        dy, dx = yy - np.float32(cy), xx - np.float32(cx)
+        u = (np.cos(th) * dx + np.sin(th) * dy) * ax
+        v = (-np.sin(th) * dx + np.cos(th) * dy) / ax
+        f = (r - np.sqrt(u * u + v * v)).astype(np.float32)
+        # touching nuclei keep a contour ridge between them: union of blobs by max, ridge where the two largest are close
+        d[y0:y1, x0:x1] = np.maximum(d[y0:y1, x0:x1], f)
+    g = np.float32(gain)
+    z_in = g * (d - np.float32(rim))
+    z_ct = g * (np.float32(rim) - np.abs(d - np.float32(0.5 * rim))) - np.float32(1.0)
+    z_bg = -g * d
+    if logit_noise > 0:
+        z_in = z_in + rs.normal(0, logit_noise, d.shape).astype(np.float32)
+        z_ct = z_ct + rs.normal(0, logit_noise, d.shape).astype(np.float32)
+    z = np.stack([z_bg, z_in, z_ct], axis=-1).astype(np.float32)
+    z = z - z.max(axis=-1, keepdims=True)
+    e = np.exp(z, dtype=np.float32)
+    p = e / e.sum(axis=-1, keepdims=True, dtype=np.float32)
+    return np.ascontiguousarray(p[..., 1:3].astype(np.float32))

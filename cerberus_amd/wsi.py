@@ -215,7 +215,7 @@ class WSIRunner(object):
         (infer/wsi.py:786-804); otherwise tile-mode semantics at full resolution (infer/tile.py:168-191)."""
         inst, info = OrderedDict(), OrderedDict()
         if "Nuclei-INST" in canv:
-            inst["Nuclei"], info["Nuclei"] = postproc_device(canv["Nuclei-INST"], "Nuclei")
+            inst["Nuclei"], info["Nuclei"] = postproc_device(canv["Nuclei-INST"], "Nuclei", exact_ties=False)
         for t in ("Gland", "Lumen"):
             key = t + "-INST"
             if key not in canv:

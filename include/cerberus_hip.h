@@ -105,15 +105,20 @@ int cerb_net_profile_get(cerb_net* net, int idx, char* name, int name_cap, char*
  * labels_out : device int32 [H][W]; ids as the reference assigns them (raster order of first pixel).
  * n_inst_out : device int32[1]; number of instances (nuclei: number of watershed markers; -1 when the map has no
  *        foreground at all, the branch in which the reference returns an all-zero float64 map, postproc.py:379-380).
- *        n_ambiguous_out : device int32[1] (nuclei only): number of
- *        watershed regions whose result depends on skimage's heap-internal order between seed pixels with
- *        bit-identical priority (see DESIGN.md "watershed ties"); 0 means the label map is provably identical.
+ *        n_ambiguous_out : device int32[1] (nuclei only): number of watershed regions whose result depends on the order
+ *        in which skimage's global binary heap releases marker pixels of bit-identical priority
+ *        (skimage.segmentation.watershed, loader/postproc.py:378; DESIGN.md "watershed ties").  0: the parallel floods'
+ *        label map is provably what skimage produces.  > 0: with cerb_pp_set_exact_ties(1) (the default) the map has been
+ *        re-flooded on the device by a literal replay of that heap and is skimage's result as well; with (0) those regions
+ *        keep the raster-order tie break.
  * ws / ws_bytes : caller-allocated device workspace of at least cerb_pp_workspace_bytes(H, W).
  * Streams: everything is ordered on `hip_stream`.  cerb_postproc_nuclei forks its independent flood tiers onto three internal
  * side streams per device (created on first use, joined back into `hip_stream` with events before it returns) -- the only
  * process-level state of the library; like the reference's run_step / post_process it is meant to be driven from one host
  * thread per GPU (SURVEY par.8b). */
 size_t cerb_pp_workspace_bytes(int h, int w);
+void cerb_pp_set_exact_ties(int on); /* process-wide; default 1 */
+int cerb_pp_get_exact_ties(void);
 int cerb_postproc_nuclei(const float* inst, int h, int w, long long row_stride, int pix_stride, int32_t* labels_out,
                          int32_t* n_inst_out, int32_t* n_ambiguous_out, void* ws, size_t ws_bytes, void* hip_stream);
 int cerb_postproc_gland(const float* inst, int h, int w, long long row_stride, int pix_stride, float ds_factor,

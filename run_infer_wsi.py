@@ -136,7 +136,7 @@ def main(argv=None):
                 from cerberus_amd.tissue import postprocess_regions
 
                 regions = TissueRegions(torch.from_numpy(mask).cuda())
-                inst = {"Nuclei": postproc_device(maps["Nuclei-INST"], "Nuclei")[0]} if "Nuclei-INST" in maps else {}
+                inst = {"Nuclei": postproc_device(maps["Nuclei-INST"], "Nuclei", exact_ties=False)[0]} if "Nuclei-INST" in maps else {}
                 records = postprocess_regions(maps, (H, W), regions)
             elif rank == 0:
                 inst, _ = WSIRunner.postprocess(maps, wsi_mode=True)
