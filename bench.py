@@ -3,11 +3,21 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch of 32 synthetic 256x256x3 uint8 tiles (BASELINE.json
-configs[1]: full Cerberus, ResNet34 + 6 heads, fp32): forward of all heads, fused softmax / crop / argmax, outputs
-scattered straight into this rank's device-resident canvas.  Inputs are resident in HBM before the timed region.
-Multi-GPU: tiles shard embarrassingly -> one process per GPU, every rank runs its own batches, no
-data-path collective; weak scaling.  Rank 0 prints ONE JSON line.
+Default (`--mode wsi`): the whole `run_infer_wsi.py` job on ONE synthetic 40000 x 40000 x 3 slide (BASELINE.json north_star /
+configs[2-3]; 24,649 tiles of 256 x 256) resident in HBM, sharded over the N ranks by contiguous bands of patch rows (STRONG
+scaling: the slide is fixed, every rank owns 1/N of it):
+    timed region = K steps, step k = stripe k of this rank's band: on-device patch gather -> forward of all six heads -> fused
+                   softmax / crop / argmax -> scatter into the band's canvases (cerberus_amd.wsi.WSIRunner.infer_patches),
+                 + the slide's tail: halo exchange with the neighbouring ranks (RCCL send/recv over xGMI), on-GPU labelling of the
+                   band (nuclei at full resolution, gland / lumen at x0.5, lumen-in-gland masking), instance tables, slide-global
+                   ids (two all-gathers), and the gather of the int32 label bands + class maps onto rank 0 (RCCL gather)
+                   (cerberus_amd.shard_postproc.postprocess_bands_and_gather -- the function run_infer_wsi.py calls).
+A random-weight network paints slide-sized blobs, so the labelling leg reads seeded STRUCTURED probability maps of the slide's
+size instead (600 nuclei / Mpx of radius 4-9 px, glands of 25-150 px; SURVEY.md par.8d cfg 3): same kernels, same band
+protocol, realistic instance counts (~1 M nuclei).  `value` = slide pixels / wall time of that whole region (max over ranks);
+`config.inference_Mpx_s` is the same slide over the K inference steps alone.
+`--mode batch`: the inner loop alone on 32 resident tiles (BASELINE.json configs[1]); `--mode train`: configs[4].
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -145,48 +155,83 @@ def train_leg(args, model, dev, dist, world, rank):
         dist.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
-                    help='"infer" (default): the headline, BASELINE.json configs[1]; "train": the multi-task training step of configs[4]')
-    ap.add_argument("--backend", default="nccl", help='torch.distributed backend ("nccl" = RCCL over xGMI; "gloo" only for plumbing tests)')
-    args = ap.parse_args()
+# ---- kernel-family table of one batch step (per-launch HIP events on the launch stream, cerb_net_profile_*) ----------------------
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md
+XGMI_LINK_GBS = 153.0   # per peer link, SURVEY.md par.8e
+_SYMBOL = {"conv_wino<f2x2,8x16>": "void conv_wino_kernel<false>(ConvParams)",
+           "conv_wino<f2x2,8x16,res>": "void conv_wino_kernel<true>(ConvParams)"}
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        local_rank = local_rank % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+def _family_bytes(kern, n):
+    """Algorithmic HBM bytes of one batch step for the families that are bandwidth bound (fp32 NHWC, batch n of 256^2 tiles)."""
+    if kern == "upsample2_add":  # per level: read prev (5 decoders) + skip (once), write 5 sums; levels 32^2x256, 64^2x128, 128^2x64, 256^2x64
+        tot = 0
+        for hw, c in ((32, 256), (64, 128), (128, 64), (256, 64)):
+            out = n * hw * hw * c * 4
+            tot += 5 * out // 4 + out + 5 * out
+        return tot
+    if kern == "maxpool3x3s2":
+        return n * 256 * 256 * 64 * 4 + n * 128 * 128 * 64 * 4
+    return None
 
-    from cerberus_amd.net_desc import create_model
-    from cerberus_amd.weights import default_model_kwargs, make_state_dict
 
-    kw = default_model_kwargs()
-    sd = {k: torch.from_numpy(v) for k, v in make_state_dict(0).items()}
-    model = create_model(**kw)
-    model.load_state_dict(sd, strict=True)
-    if args.mode == "train":
-        return train_leg(args, model, dev, dist, world, rank)
+def kernel_table(model, step, n_tiles):
+    model.profile(True)
+    step()
+    torch.cuda.synchronize()
+    recs = model.profile_records()
+    model.profile(False)
+    fam = {}
+    for name, kern, fl, ms in recs:
+        f = fam.setdefault(kern, [0.0, 0.0, 0])
+        f[0] += fl
+        f[1] += ms
+        f[2] += 1
+    total_ms = sum(v[1] for v in fam.values())
+    rows = []
+    for kern, (fl, ms, cnt) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+        row = {"kernel": kern, "launches": cnt, "ms_per_step": round(ms, 4), "share": round(ms / total_ms, 4)}
+        by = _family_bytes(kern, n_tiles)
+        if by is not None:
+            gbs = by / (ms * 1e-3) / 1e9
+            row.update(bound="hbm", achieved=round(gbs, 1), unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), algorithmic_bytes=by)
+        elif fl > 0:
+            alg = fl / (ms * 1e-3) / 1e12
+            ex = alg * (16.0 / 36.0 if kern.startswith("conv_wino") else 1.0)  # F(2x2,3x3) executes 16 of the 36 multiplies
+            row.update(bound="mfma", achieved=round(ex, 2), unit="TFLOP/s", frac=round(ex / PEAK_F32_MFMA_TFLOPS, 4), algorithmic_tflops=round(alg, 2))
+        rows.append(row)
+    dom = rows[0]
+    fl, ms, cnt = fam[dom["kernel"]]
+    traffic = None
+    for cand in ("r02_bench_pmc_hbm.json", "r01_bench_pmc_hbm.json"):
+        pth = os.path.join(ROOT, "profiles", cand)
+        sym = _SYMBOL.get(dom["kernel"])
+        if sym and os.path.exists(pth):
+            traffic = json.load(open(pth)).get(sym, {}).get("hbm_bytes_per_launch")
+            traffic_src = cand
+            break
+    # `achieved` / `frac`: the MFMA FLOPs the kernel EXECUTES per second against the dense fp32 MFMA peak (the share of the matrix
+    # pipe it fills).  The algorithmic (direct-convolution, SURVEY par.8d) rate is 36/16 of that for the Winograd kernel and is
+    # carried beside it: it can exceed the peak because F(2x2,3x3) skips 5/9 of the multiplies.
+    roofline = {
+        "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": dom["frac"], "algorithmic_tflops": dom.get("algorithmic_tflops"),
+        "algorithmic_frac": round(dom.get("algorithmic_tflops", 0.0) / PEAK_F32_MFMA_TFLOPS, 4),
+        "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC passes, profiles/%s)" % (traffic_src if traffic else "-"),
+        "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3), "launches_per_step": cnt, "avg_launch_ms": round(ms / cnt, 4),
+        "kernel_share_of_step": dom["share"],
+        "whole_step": {"ms_sum_of_kernels": round(total_ms, 3),
+                       "executed_mfma_frac": round(sum(r["achieved"] * r["ms_per_step"] for r in rows if r.get("bound") == "mfma")
+                                                   / total_ms / PEAK_F32_MFMA_TFLOPS, 4)},
+    }
+    return roofline, rows
 
-    # synthetic slide strip resident in HBM: this rank's batches (seeded per rank), and its output canvas
+
+def batch_loop(model, dev, rank, steps, warmup, dist, backend):
+    """configs[1]: 32 resident tiles, forward + fused output wrapper + scatter into a 4 x 8-tile canvas.  Returns (dt, step, n_tiles)."""
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     tiles = torch.randint(0, 256, (BATCH, TILE, TILE, 3), dtype=torch.uint8, device=dev, generator=g)
-    gy, gx = 4, 8  # canvas of 4 x 8 tiles
+    gy, gx = 4, 8
     Wc = gx * TILE
     canvas = {
         "Lumen": torch.zeros((gy * TILE, Wc, 2), dtype=torch.float32, device=dev),
@@ -202,136 +247,259 @@ def main():
     def step():
         model._run(tiles, TILE, TILE, outs, None, tile_off=off, row_stride=Wc, type_is_u8=True)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
+    dt = _timed(lambda: [step() for _ in range(steps)], dev, dist, backend)
+    return dt, step, BATCH
+
+
+def _timed(fn, dev, dist, backend):
+    """barrier + synchronize on both sides, max over ranks"""
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    fn()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    return dt
 
-    # ---- roofline leg: per-launch HIP-event timing of ONE more step (outside the timed region) -------------
-    model.profile(True)
-    step()
-    torch.cuda.synchronize()
-    recs = model.profile_records()
-    model.profile(False)
-    fam = {}
-    for name, kern, fl, ms in recs:
-        f = fam.setdefault(kern, [0.0, 0.0, 0])
-        f[0] += fl
-        f[1] += ms
-        f[2] += 1
-    dom = max(fam.items(), key=lambda kv: kv[1][1])
-    dom_name, (dom_fl, dom_ms, dom_cnt) = dom
-    achieved = dom_fl / (dom_ms * 1e-3) / 1e12
-    total_ms = sum(r[3] for r in recs)
-    # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    # separate runs of this same command; gfx950 read-side x2 correction applied by scripts/rocprof_summary.py)
-    traffic = None
-    sym = {"conv_wino<f2x2,8x16>": "void conv_wino_kernel<false>(ConvParams)",
-           "conv_wino<f2x2,8x16,res>": "void conv_wino_kernel<true>(ConvParams)",
-           "conv_igemm<ks3,s1,mode0,8x32>": "void conv_igemm_kernel<3, 1, 8, 32, 32, 0>(ConvParams)",
-           "conv_igemm<ks3,s1,mode1,8x32>": "void conv_igemm_kernel<3, 1, 8, 32, 32, 1>(ConvParams)"}.get(dom_name)
-    pmc_path = os.path.join(ROOT, "profiles", "r01_bench_pmc_hbm.json")
-    if sym and os.path.exists(pmc_path):
-        traffic = json.load(open(pmc_path)).get(sym, {}).get("hbm_bytes_per_launch")
-    # `achieved` is ALGORITHMIC work (direct-convolution FLOPs, SURVEY par.8d) per second.  The Winograd F(2x2,3x3) kernel
-    # executes 16 multiplies per 2x2 output patch and input channel instead of 36, so its matrix pipe runs 4/9 of those FLOPs:
-    # `frac` can exceed 1; `executed_frac` is the share of the fp32 MFMA roof the kernel's own instructions fill.
-    exec_ratio = 16.0 / 36.0 if dom_name.startswith("conv_wino") else 1.0
-    roofline = {
-        "bound": "mfma",
-        "kernel": dom_name,
-        "achieved": round(achieved, 2),
-        "peak": PEAK_F32_MFMA_TFLOPS,
-        "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-        "executed_mfma_tflops": round(achieved * exec_ratio, 2),
-        "executed_frac": round(achieved * exec_ratio / PEAK_F32_MFMA_TFLOPS, 4),
-        "traffic": traffic,
-        "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_bench_pmc_hbm.json)",
-        "flop_per_launch": round(dom_fl / dom_cnt / 1e9, 3),
-        "launches": dom_cnt,
-        "avg_launch_ms": round(dom_ms / dom_cnt, 4),
-        "kernel_share_of_step": round(dom_ms / total_ms, 4),
-    }
 
-    # ---- post-processing leg (reported beside the headline; P1-P5 of SURVEY.md par.8a): on-GPU label maps from a seeded
-    # structured probability map (600 nuclei / Mpx, radius 4-9 px; glands 14-60 px) and from this step's own canvas -------
-    postproc = None
-    if rank == 0:
-        from cerberus_amd.postproc import postproc_device
-        from cerberus_amd import synth_maps as synth  # structured synthetic INPUT generator (numpy)
+def structured_band(dev, y0, rows, W, period=4096):
+    """Seeded structured probability maps for canvas rows [y0, y0 + rows) x [0, W): a `period`^2 tile of each kind (numpy generator,
+    cerberus_amd/synth_maps.py) repeated over the slide in absolute coordinates, so every rank sees the same slide."""
+    from cerberus_amd import synth_maps as synth
 
-        PH = 2048
-        maps = {
-            "Nuclei": torch.from_numpy(synth.nuclei_maps(PH, PH, 7, 600.0, noise=0.02)).to(dev),
-            "Gland": torch.from_numpy(synth.blob_maps(PH, PH, 9, 120, 14.0, 60.0, rim=4.0, sharp=1.0, noise=0.02, holes=0.3)).to(dev),
-        }
-        maps["Lumen"] = maps["Gland"]
-        postproc = {"map": "%dx%d structured synthetic" % (PH, PH), "unit": "Mpx/s", "algorithmic_bytes_per_px": 12}
-        for t in ("Nuclei", "Gland", "Lumen"):
-            postproc_device(maps[t], t)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                lab, info = postproc_device(maps[t], t)
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / 3 * 1e3
-            postproc[t] = {"ms": round(ms, 3), "Mpx_s": round(PH * PH / ms / 1e3, 1), "n_inst": int(info["n_inst"].item()),
-                           "hbm_frac_of_8TBs": round(12.0 * PH * PH / (ms * 1e-3) / 8e12, 5)}
-        # the three label maps of this step's own 1024 x 2048 canvas (random-weight network => degenerate maps)
-        torch.cuda.synchronize()
+    yi = (torch.arange(y0, y0 + rows, device=dev) % period)
+    xi = (torch.arange(0, W, device=dev) % period)
+    out = {}
+    nuc = torch.from_numpy(synth.nuclei_maps(period, period, 7, 600.0, noise=0.02)).to(dev)
+    out["Nuclei-INST"] = nuc.index_select(0, yi).index_select(1, xi)
+    del nuc
+    gl = torch.from_numpy(synth.gland_maps(period, period, 9, noise=0.02, holes=0.3)).to(dev)
+    out["Gland-INST"] = gl.index_select(0, yi).index_select(1, xi)
+    del gl
+    lu = torch.from_numpy(synth.blob_maps(period, period, 11, 260, 8.0, 40.0, rim=2.0, sharp=1.0, noise=0.02)).to(dev)
+    out["Lumen-INST"] = lu.index_select(0, yi).index_select(1, xi)
+    return out
+
+
+def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
+    from collections import OrderedDict
+
+    from cerberus_amd.shard_postproc import postprocess_bands_and_gather
+    from cerberus_amd.wsi import WSIRunner, band_partition, synth_slide
+
+    free = torch.cuda.mem_get_info(dev)[0]
+    side = args.slide
+    if side <= 0:  # 40000^2 needs ~130 GB on one GPU (slide, 36 B/px canvases, structured maps, labels, banded workspace)
+        side = 40000 if free > (140e9 if world == 1 else 270e9 / world + 8e9) else 20000
+    H = W = side
+    K = args.steps
+    run = WSIRunner(model, (H, W), TILE, TILE, BATCH, rank, world)
+    y0, y1 = run.slab_rows()
+    slab = synth_slide(y1 - y0, W, y0=y0, seed=3)
+    valid = max(0, min(run.band_h, H - run.r0 * TILE))
+    struct = structured_band(dev, run.r0 * TILE, valid, W)
+    # stripes: this rank's patches in K contiguous pieces, cut at batch boundaries
+    nb = -(-run.n_patches // BATCH)
+    cuts = [min(run.n_patches, c * BATCH) for c in band_partition(nb, K)]
+    max_band_px = int(args.max_band_mpx * 1e6)
+    # warm-up: W stripes' worth of batches + one small labelling call per tissue (allocations, code objects, RCCL channels)
+    for k in range(min(args.warmup, K)):
+        run.infer_patches(slab, y0, cuts[k], min(cuts[k] + 2 * BATCH, cuts[k + 1]))
+    from cerberus_amd.postproc import _workspace, postproc_device
+
+    hw = min(valid * W, max_band_px) + 2 * 1100 * W if world == 1 else (valid + 1100) * W
+    side_ws = int(hw ** 0.5) + 1
+    _workspace(dev, side_ws, side_ws)  # the labelling workspace of the largest call, allocated outside the timed region
+    for t in ("Nuclei", "Gland", "Lumen"):
+        postproc_device(struct[t + "-INST"][:512, :512], t, exact_ties=False)
+    if dist is not None:  # first RCCL send/recv + gather open their channels outside the timed region
+        x = torch.zeros(1024, device=dev)
+        lst = [torch.zeros_like(x) for _ in range(world)] if rank == 0 else None
+        dist.gather(x, lst, dst=0)
+        ops = []
+        if rank > 0:
+            ops += [dist.P2POp(dist.isend, x, rank - 1), dist.P2POp(dist.irecv, torch.zeros_like(x), rank - 1)]
+        if rank < world - 1:
+            ops += [dist.P2POp(dist.isend, x, rank + 1), dist.P2POp(dist.irecv, torch.zeros_like(x), rank + 1)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+    prof = {}
+    phase = {}
+    res = {}
+
+    def job():
         t0 = time.perf_counter()
-        for t in ("Nuclei", "Gland", "Lumen"):
-            postproc_device(canvas[t], t)
+        for k in range(K):
+            run.infer_patches(slab, y0, cuts[k], cuts[k + 1])
         torch.cuda.synchronize()
-        postproc["own_canvas_all_tissues_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
-        postproc["own_canvas_note"] = "random-weight network => degenerate maps (canvas-sized components): the flood's serial worst case"
+        phase["inference_s"] = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        canv = OrderedDict(struct)
+        inst, info, small = postprocess_bands_and_gather(run, H, W, rank, world, dist, canv=canv, max_band_px=max_band_px, prof=prof)
+        torch.cuda.synchronize()
+        phase["tail_s"] = time.perf_counter() - t1
+        res.update(inst=inst, info=info)
 
-    if rank == 0:
-        px = world * args.steps * BATCH * TILE * TILE
-        flops_step = model.flops(BATCH, TILE, TILE)
-        line = {
-            "metric": "Mpx/sec WSI tiled inference (all heads)",
-            "value": round(px / dt / 1e6, 3),
-            "unit": "Mpx/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": "Full Cerberus (ResNet34 encoder + 6 decoder heads) batch=32 256x256x3 uint8 tiles, fp32, all heads + fused "
-                            "softmax/crop/argmax scattered into a device-resident canvas (BASELINE.json configs[1])",
-                "batch_tiles": BATCH,
-                "tile": TILE,
-                "gflop_per_tile": round(flops_step / BATCH / 1e9, 3),
-                "whole_step_tflops": round(flops_step / (dt / args.steps) / 1e12 * world, 2),
-                "parallelism": "tile-sharded x%d, no data-path collective" % world,
-            },
-            "roofline": roofline,
-            "postproc": postproc,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sd, kw)
-        print(json.dumps(line), flush=True)
+    dt = _timed(job, dev, dist, args.backend)
+    if dist is not None:  # slowest rank's phases
+        for key in ("inference_s", "tail_s"):
+            t = torch.tensor([phase[key]], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            phase[key] = float(t.item())
+    info = res["info"]
+    n_inst = {t: int(i.get("n_total", 0)) for t, i in info.items()}
+    checks = {t: {"n_truncated": int(i.get("n_truncated", 0)), "n_unresolved": int(i.get("n_unresolved", 0)), "local_bands": int(i.get("local_bands", 1))}
+              for t, i in info.items()}
+    res.clear()
+    # secondary: the inner loop alone (configs[1]) + the per-kernel table of one batch step
+    bdt, bstep, bn = batch_loop(model, dev, rank, 20, 3, None, args.backend)
+    roofline, rows = kernel_table(model, bstep, bn)
+    if rank != 0:
+        return
+    px = H * W
+    n_tiles = run.geo.rows * run.geo.cols
+    flops_tile = model.flops(1, TILE, TILE)
+    pp = {}
+    for t in ("Nuclei", "Gland", "Lumen"):
+        e = prof.get("label_" + t)
+        if e:
+            pp[t] = {"s": round(e["s"], 4), "n_inst": n_inst.get(t), "band_px": (valid * W) if t == "Nuclei" else (valid // 2) * (W // 2)}
+            pp[t]["Gpx_s"] = round(pp[t]["band_px"] / e["s"] / 1e9, 3)
+            pp[t]["hbm_frac_of_8TBs_at_12B_px"] = round(12.0 * pp[t]["band_px"] / e["s"] / 8e12, 5)
+            pp[t].update(checks.get(t, {}))
+    mg = None
+    if dist is not None:
+        mg = {"peak_GB_s_per_xgmi_link": XGMI_LINK_GBS, "rank": 0}
+        for key in ("halo_exchange", "root_gather"):
+            e = prof.get(key)
+            if e:
+                mg[key] = {"bytes_into_rank0": e["bytes"], "s": round(e["s"], 5), "GB_s": round(e["bytes"] / max(e["s"], 1e-9) / 1e9, 2)}
+        if "root_gather" in mg:
+            mg["root_gather"]["GB_s_per_link"] = round(mg["root_gather"]["GB_s"] / max(1, world - 1), 2)
+    line = {
+        "metric": "Mpx/sec WSI tiled inference (all heads)",
+        "value": round(px / dt / 1e6, 3),
+        "unit": "Mpx/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / K * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "Synthetic %dx%dx3 uint8 WSI resident in HBM (BASELINE.json north_star / configs[%d]), sliding window 256-in / 256-out = %d tiles, "
+                        "full Cerberus (ResNet34 + 6 heads, fp32) with on-device patch gather + canvas scatter, then on-GPU post-processing of "
+                        "slide-sized structured maps (nuclei watershed at x1, gland / lumen at x0.5, instance tables, global ids) and the label "
+                        "stitch on rank 0; a step = 1/%d of every rank's band, the tail is inside the timed region" % (H, W, 3 if side >= 40000 else 2, n_tiles, K),
+            "slide": [H, W],
+            "tiles": n_tiles,
+            "batch_tiles": BATCH,
+            "inference_s": round(phase["inference_s"], 3),
+            "inference_Mpx_s": round(px / phase["inference_s"] / 1e6, 3),
+            "postproc_and_stitch_s": round(phase["tail_s"], 3),
+            "whole_job_s": round(dt, 3),
+            "inference_algorithmic_tflops_per_gpu": round(n_tiles * flops_tile / phase["inference_s"] / 1e12 / world, 2),
+            "gflop_per_tile": round(flops_tile / 1e9, 3),
+            "parallelism": "band-sharded x%d (contiguous patch rows), no collective during inference; halo send/recv + 2 all-gathers + 1 gather per "
+                           "label map in the tail (%s)" % (world, args.backend if world > 1 else "single GPU"),
+        },
+        "roofline": roofline,
+        "kernels": rows,
+        "postproc": pp,
+        "multi_gpu": mg,
+        "batch_step": {"workload": "configs[1]: batch=32 256x256 tiles, inner loop only", "ms_per_step": round(bdt / 20 * 1e3, 3),
+                       "Mpx_s": round(20 * BATCH * TILE * TILE / bdt / 1e6, 2)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(sd, kw)
+    print(json.dumps(line), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="wsi", choices=["wsi", "batch", "infer", "train"],
+                    help='"wsi" (default): the headline, whole-slide job of north_star / configs[2-3]; "batch" (= "infer"): configs[1] inner loop; '
+                         '"train": the multi-task training step of configs[4]')
+    ap.add_argument("--slide", type=int, default=0, help="slide side in pixels (default: 40000, or 20000 when HBM is short)")
+    ap.add_argument("--max-band-mpx", type=float, default=220.0, help="largest labelling call on one GPU, in Mpx (96 B/px of workspace)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and take the collective code path even at world size 1 (RCCL accepts one rank): "
+                         "the nccl test of tests/test_cli_gpu.py")
+    ap.add_argument("--backend", default="nccl", help='torch.distributed backend ("nccl" = RCCL over xGMI; "gloo" only for plumbing tests)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1 or args.force_dist:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            from cerberus_amd.hostdist import HostStagedDist
+
+            dist.init_process_group(args.backend)
+            dist = HostStagedDist(dist)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from cerberus_amd.net_desc import create_model
+    from cerberus_amd.weights import default_model_kwargs, make_state_dict
+
+    kw = default_model_kwargs()
+    sd = {k: torch.from_numpy(v) for k, v in make_state_dict(0).items()}
+    model = create_model(**kw)
+    model.load_state_dict(sd, strict=True)
+    if args.mode == "train":
+        return train_leg(args, model, dev, dist, world, rank)
+    if args.mode == "wsi":
+        wsi_leg(args, model, dev, dist, world, rank, sd, kw)
+    else:
+        dt, step, n = batch_loop(model, dev, rank, args.steps, args.warmup, dist, args.backend)
+        roofline, rows = kernel_table(model, step, n)
+        if rank == 0:
+            flops_step = model.flops(BATCH, TILE, TILE)
+            line = {
+                "metric": "Mpx/sec WSI tiled inference (all heads)", "value": round(world * args.steps * BATCH * TILE * TILE / dt / 1e6, 3), "unit": "Mpx/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "Full Cerberus (ResNet34 encoder + 6 decoder heads) batch=32 256x256x3 uint8 tiles, fp32, all heads + fused "
+                                       "softmax/crop/argmax scattered into a device-resident canvas (BASELINE.json configs[1]; inner loop of the slide job)",
+                           "batch_tiles": BATCH, "tile": TILE, "gflop_per_tile": round(flops_step / BATCH / 1e9, 3),
+                           "whole_step_tflops": round(flops_step / (dt / args.steps) / 1e12 * world, 2),
+                           "parallelism": "tile-sharded x%d, no data-path collective" % world},
+                "roofline": roofline, "kernels": rows,
+            }
+            if world == 1 and not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(sd, kw)
+            print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

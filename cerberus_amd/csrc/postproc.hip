@@ -881,13 +881,15 @@ struct ExHeap {
     u64* gk;
     u32* gi;
 };
+// Only this one wave ever touches the heap, so no agent-scope coherence is needed: workgroup-scope accesses stay in the CU's own
+// L1 / the XCD's L2 (an agent-scope load has to miss both L2-non-coherent levels on a multi-XCD part: ~2 us per dependent access).
 __device__ __forceinline__ void ex_load(const ExHeap& h, long long pos, u64& k, u32& i) {
     if (pos < EX_LDS) {
         k = h.sk[pos];
         i = h.si[pos];
     } else {
-        k = __hip_atomic_load(&h.gk[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        i = __hip_atomic_load(&h.gi[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        k = __hip_atomic_load(&h.gk[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        i = __hip_atomic_load(&h.gi[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 __device__ __forceinline__ void ex_store(const ExHeap& h, long long pos, u64 k, u32 i) {
@@ -895,8 +897,8 @@ __device__ __forceinline__ void ex_store(const ExHeap& h, long long pos, u64 k, 
         h.sk[pos] = k;
         h.si[pos] = i;
     } else {
-        __hip_atomic_store(&h.gk[pos], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&h.gi[pos], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&h.gk[pos], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&h.gi[pos], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 __device__ __forceinline__ u32 ex_uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
@@ -1032,8 +1034,13 @@ __global__ __launch_bounds__(64) void ws_exact_kernel(const float* __restrict__ 
         ex_load(h, 0, rk, ri);
         const u32 p = ex_uni(ri);
         const int y = (int)(p / (u32)W), x = (int)(p % (u32)W);
-        // neighbour probes first: they only depend on the popped pixel
-        const int lab = __hip_atomic_load(&out[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // everything that only depends on the popped pixel / the heap size is requested first: the label, the four neighbour
+        // probes and the last entry (which heappop moves to the root)
+        const int lab = __hip_atomic_load(&out[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        --n;
+        u64 xk = 0;
+        u32 xi = 0;
+        if (n > 0) ex_load(h, n, xk, xi);
         long long q = -1;
         if (lane == 0 && y > 0) q = (long long)p - W;
         if (lane == 1 && x > 0) q = (long long)p - 1;
@@ -1044,19 +1051,13 @@ __global__ __launch_bounds__(64) void ws_exact_kernel(const float* __restrict__ 
         float vq = 0.f;
         if (q >= 0) {
             mq = mask[q];
-            oq = __hip_atomic_load(&out[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            oq = __hip_atomic_load(&out[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const int qy = (int)(q / W), qx = (int)(q % W);
             vq = -inst[qy * row_stride + (long long)qx * pix_stride];
         }
-        --n;
-        if (n > 0) {
-            u64 xk;
-            u32 xi;
-            ex_load(h, n, xk, xi);
-            ex_sift_down(h, n, ex_uni64(xk), ex_uni(xi));
-        }
+        if (n > 0) ex_sift_down(h, n, ex_uni64(xk), ex_uni(xi));
         const bool elig = q >= 0 && mq && oq == 0;
-        if (elig) __hip_atomic_store(&out[q], lab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (elig) __hip_atomic_store(&out[q], lab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const u32 kq = order_key(vq);
         const u64 em = __ballot(elig);
 #pragma unroll 1

@@ -167,8 +167,31 @@ def run_local(bands, tissue, margin, guard, ds_factor=1.0, label_fn=_device_labe
     return outs, int(offs[-1]), infos
 
 
+def _tick(prof, key, nbytes, t0):
+    """prof: None, or a dict collecting (bytes moved INTO this rank or out of it, seconds) per phase -- bench.py's xGMI figures."""
+    if prof is None:
+        return
+    import time
+
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    e = prof.setdefault(key, {"bytes": 0, "s": 0.0})
+    e["bytes"] += int(nbytes)
+    e["s"] += time.perf_counter() - t0
+
+
+def _tock(prof):
+    if prof is None:
+        return 0.0
+    import time
+
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    return time.perf_counter()
+
+
 def run_distributed(band, y0_global, tissue, margin, guard, dist, ds_factor=1.0, label_fn=_device_label_fn,
-                    table_fn=_device_table_fn, relabel_fn=_device_relabel_fn):
+                    table_fn=_device_table_fn, relabel_fn=_device_relabel_fn, prof=None):
     """One rank of the real thing.  `dist` = torch.distributed (initialised).  Returns (band labels with global ids,
     total instance count over all ranks, info dict)."""
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -181,10 +204,15 @@ def run_distributed(band, y0_global, tissue, margin, guard, dist, ds_factor=1.0,
         ops += [dist.P2POp(dist.isend, up, rank - 1), dist.P2POp(dist.irecv, above, rank - 1)]
     if rank < world - 1:
         ops += [dist.P2POp(dist.isend, down, rank + 1), dist.P2POp(dist.irecv, below, rank + 1)]
+    t0 = _tock(prof)
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+    _tick(prof, "halo_exchange", sum(t.numel() * t.element_size() for t in (above, below) if t is not None), t0)
+    t0 = _tock(prof)
     n_owned = st.label(above, below, label_fn, table_fn)
+    _tick(prof, "label_" + tissue, 0, t0)
+    t0 = _tock(prof)
     dev = band.device
     cnt = torch.tensor([n_owned], dtype=torch.int64, device=dev)
     allc = [torch.zeros_like(cnt) for _ in range(world)]
@@ -206,6 +234,7 @@ def run_distributed(band, y0_global, tissue, margin, guard, dist, ds_factor=1.0,
     pubs = [allp[r][: lens[r]].cpu().numpy() for r in range(rank)]
     out, info = st.resolve(pubs, relabel_fn)
     info["n_total"] = int(offs[-1])
+    _tick(prof, "ids_" + tissue, 0, t0)
     return out, int(offs[-1]), info
 
 
@@ -223,10 +252,21 @@ def same_partition(a, b):
     return len(np.unique(pairs[:, 0])) == len(pairs) and len(np.unique(pairs[:, 1])) == len(pairs)
 
 
-def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guard=48):
+def local_band_count(rows, cols, max_band_px):
+    """How many row bands a (rows x cols) canvas is labelled in on ONE GPU so that no labelling call exceeds max_band_px pixels
+    (workspace = 96 B / px, and H*W < 2^31 per call): 1 when it fits."""
+    if not max_band_px or rows * cols <= max_band_px:
+        return 1
+    return int(-(-rows * cols // int(max_band_px)))
+
+
+def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guard=48, max_band_px=None, prof=None):
     """Per-rank replacement of WSIRunner.postprocess for band canvases: label maps of THIS rank's band with slide-global
     ids, nothing gathered.  canv: the band canvases of this rank (full-resolution rows of equal count on every rank except
-    the last).  Gland / lumen run at x0.5 in wsi_mode (infer/wsi.py:786-804); their margin / guard are halved accordingly."""
+    the last).  Gland / lumen run at x0.5 in wsi_mode (infer/wsi.py:786-804); their margin / guard are halved accordingly.
+    max_band_px (world == 1 only): a canvas larger than this is labelled as several row bands one after the other through the
+    same halo / ownership / id protocol the ranks use (`run_local`) -- the one-GPU streaming path for slides whose 96 B / px
+    labelling workspace would not fit, or that exceed the 2^31-pixel limit of one call."""
     from .postproc import mask_lumen_by_gland
     from .wsi import downsample2_inst
 
@@ -234,7 +274,7 @@ def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guar
     rows = int(next(iter(canv.values())).shape[0])
     cnt = torch.tensor([rows], dtype=torch.int64, device=next(iter(canv.values())).device)
     allr = [torch.zeros_like(cnt) for _ in range(world)]
-    if world > 1:
+    if dist is not None:
         dist.all_gather(allr, cnt)
     else:
         allr = [cnt]
@@ -246,11 +286,18 @@ def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guar
         half = wsi_mode and t != "Nuclei"
         band = downsample2_inst(canv[key]) if half else canv[key]
         m, g, yy, ds = (margin // 2, guard // 2, y0 // 2, 0.5) if half else (margin, guard, y0, 1.0)
-        if world > 1:
-            inst[t], _, info[t] = run_distributed(band, yy, t, m, g, dist, ds)
+        if dist is not None:  # also at world == 1 when the caller initialised a process group (bench.py --force-dist, the nccl test)
+            inst[t], _, info[t] = run_distributed(band, yy, t, m, g, dist, ds, prof=prof)
         else:
-            outs, n, infos = run_local([band], t, m, g, ds)
-            inst[t], info[t] = outs[0], dict(infos[0], n_total=n)
+            t0 = _tock(prof)
+            nb = local_band_count(int(band.shape[0]), int(band.shape[1]), max_band_px)
+            nb = max(1, min(nb, int(band.shape[0]) // max(1, 2 * m)))  # every local band at least two margins tall
+            cuts = [int(round(i * band.shape[0] / nb)) for i in range(nb + 1)]
+            outs, n, infos = run_local([band[cuts[i]:cuts[i + 1]] for i in range(nb)], t, m, g, ds)
+            inst[t] = outs[0] if nb == 1 else assemble(outs)
+            info[t] = {"n_owned": n, "n_total": n, "n_truncated": sum(i["n_truncated"] for i in infos),
+                       "n_unresolved": sum(i["n_unresolved"] for i in infos), "local_bands": nb}
+            _tick(prof, "label_" + t, 0, t0)
     if "Lumen" in inst and "Gland" in inst:
         mask_lumen_by_gland(inst["Lumen"], inst["Gland"])
     return inst, info
@@ -258,8 +305,8 @@ def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guar
 
 def _gather_rows(lab, rows_per_rank, cols, dist, rank, world):
     """Concatenate per-rank label bands (rows_per_rank[r] valid rows each) on the root; None elsewhere."""
-    if world == 1:
-        return lab[: rows_per_rank[0], :cols].contiguous()
+    if dist is None:
+        return lab[: rows_per_rank[0], :cols]
     hmax = max(rows_per_rank)
     pad = torch.zeros((hmax, cols), dtype=lab.dtype, device=lab.device)
     pad[: lab.shape[0], : min(cols, lab.shape[1])] = lab[:, :cols]
@@ -270,23 +317,35 @@ def _gather_rows(lab, rows_per_rank, cols, dist, rank, world):
     return torch.cat([lst[i][: rows_per_rank[i]] for i in range(world)], dim=0)
 
 
-def postprocess_bands_and_gather(run, H, W, rank, world, dist, margin=512, guard=48):
-    """The multi-GPU tail of a slide: band-local label maps with slide-global ids, then only the int32 label bands and the
+def postprocess_bands_and_gather(run, H, W, rank, world, dist, margin=512, guard=48, canv=None, max_band_px=None, prof=None):
+    """The tail of a slide on 1..N GPUs: band-local label maps with slide-global ids, then only the int32 label bands and the
     uint8 / float class canvases travel to the root (12 + 3 B/px instead of the 36 B/px of raw probability canvases).
-    `run` is this rank's WSIRunner after infer_band.  Returns (inst, info, small) -- inst / small are None off the root."""
+    `run` is this rank's WSIRunner after infer_band.  Returns (inst, info, small) -- inst / small are None off the root.
+    canv: label these band canvases instead of run.canv (bench.py's structured probability maps); max_band_px: see
+    sharded_postprocess; prof: dict collecting bytes / seconds of the halo exchange and the root gather."""
     from .wsi import gather_bands, half_size
 
     geo = run.geo
+    src = run.canv if canv is None else canv
     valid = max(0, min(run.band_h, H - run.r0 * geo.out))
-    band = OrderedDict((k, v[:valid, :W]) for k, v in run.canv.items())
-    inst_b, info = sharded_postprocess(band, rank, world, dist, wsi_mode=True, margin=margin, guard=guard)
+    band = OrderedDict((k, v[:valid, :W]) for k, v in src.items())
+    inst_b, info = sharded_postprocess(band, rank, world, dist, wsi_mode=True, margin=margin, guard=guard, max_band_px=max_band_px, prof=prof)
     bounds = geo.bounds(world)
     rows = [max(0, min((bounds[i + 1] - bounds[i]) * geo.out, H - bounds[i] * geo.out)) for i in range(world)]
     inst = OrderedDict() if rank == 0 else None
+    t0 = _tock(prof)
+    moved = 0
     for t, lab in inst_b.items():
         half = t != "Nuclei"
-        g = _gather_rows(lab, [half_size(r) for r in rows] if half else rows, half_size(W) if half else W, dist, rank, world)
+        rr = [half_size(r) for r in rows] if half else rows
+        cc = half_size(W) if half else W
+        g = _gather_rows(lab, rr, cc, dist, rank, world)
+        moved += (world - 1) * max(rr) * cc * 4  # what the root receives (every rank pads to the tallest band)
         if rank == 0:
             inst[t] = g
-    small = gather_bands(OrderedDict((k, v) for k, v in run.canv.items() if not k.endswith("INST")), geo, rank, world, dist)
+    small_src = OrderedDict((k, v) for k, v in run.canv.items() if not k.endswith("INST"))
+    small = gather_bands(small_src, geo, rank, world, dist)
+    moved += (world - 1) * sum(v.numel() * v.element_size() for v in small_src.values())
+    if dist is not None:
+        _tick(prof, "root_gather", moved, t0)
     return inst, info, small

@@ -138,7 +138,7 @@ def gather_bands(canv, geo, rank, world, dist=None):
     Every rank pads its band to the tallest band so one `dist.gather` per head suffices (backend "nccl" = RCCL over
     xGMI on the GPU box, "gloo" in the CPU tests)."""
     bounds = geo.bounds(world)
-    if world == 1 or dist is None:
+    if dist is None:
         return OrderedDict((k, v[: geo.H, : geo.W]) for k, v in canv.items())
     max_rows = max(bounds[i + 1] - bounds[i] for i in range(world)) * geo.out
     full = OrderedDict() if rank == 0 else None
@@ -193,16 +193,21 @@ class WSIRunner(object):
         Runs every patch of the band; outputs land in self.canv.  Returns the number of patches.
         ready: optional callable(n_rows) that makes the first n_rows rows of `slab` valid for work queued on the current stream
         (SlabUploader.upload_until: the band is then uploaded chunk by chunk underneath the inference of the rows above)."""
+        return self.infer_patches(slab, slab_y0, 0, self.n_patches, ready)
+
+    def infer_patches(self, slab, slab_y0, p0, p1, ready=None):
+        """Patches [p0, p1) of this band's row-major patch list (bench.py times a slide as K such stripes)."""
         g = self.geo
         assert slab.shape[1] == g.W
+        p0, p1 = max(0, int(p0)), min(self.n_patches, int(p1))
         tl_y_host = self._tl_y.cpu().numpy() if ready is not None else None
-        for b0 in range(0, self.n_patches, self.batch):
-            b1 = min(self.n_patches, b0 + self.batch)
+        for b0 in range(p0, p1, self.batch):
+            b1 = min(p1, b0 + self.batch)
             if ready is not None:  # mirror padding only ever folds back to rows above the window's last in-slide row
                 ready(min(int(tl_y_host[b0:b1].max()) + g.win, g.H) - slab_y0)
             tiles = gather_patches(slab, slab_y0, g.H, self._tl_y[b0:b1], self._tl_x[b0:b1], g.win)
             self.net._run(tiles, g.out, g.out, self._outs, None, tile_off=self._off[b0:b1], row_stride=self.canvas_w, type_is_u8=True)
-        return self.n_patches
+        return p1 - p0
 
     def gather_to_root(self, dist=None):
         """Stitch the per-head band canvases on rank 0 (one gather per head over RCCL / xGMI).  Returns the full
