@@ -32,6 +32,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 BATCH, TILE = 32, 256
+MARGIN = 1024  # halo rows exchanged between neighbouring bands (full resolution): above the tallest gland cluster of the structured maps
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
@@ -284,7 +285,7 @@ def structured_band(dev, y0, rows, W, period=4096):
     nuc = torch.from_numpy(synth.nuclei_maps(period, period, 7, 600.0, noise=0.02)).to(dev)
     out["Nuclei-INST"] = nuc.index_select(0, yi).index_select(1, xi)
     del nuc
-    gl = torch.from_numpy(synth.gland_maps(period, period, 9, noise=0.02, holes=0.3)).to(dev)
+    gl = torch.from_numpy(synth.gland_maps(period, period, 9, n=90, noise=0.02, holes=0.3)).to(dev)  # ~13 % gland area
     out["Gland-INST"] = gl.index_select(0, yi).index_select(1, xi)
     del gl
     lu = torch.from_numpy(synth.blob_maps(period, period, 11, 260, 8.0, 40.0, rim=2.0, sharp=1.0, noise=0.02)).to(dev)
@@ -318,7 +319,7 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
         run.infer_patches(slab, y0, cuts[k], min(cuts[k] + 2 * BATCH, cuts[k + 1]))
     from cerberus_amd.postproc import _workspace, postproc_device
 
-    hw = min(valid * W, max_band_px) + 2 * 1100 * W if world == 1 else (valid + 1100) * W
+    hw = min(valid * W, max_band_px) + 2 * (MARGIN + 64) * W if world == 1 else (valid + 2 * MARGIN + 64) * W
     side_ws = int(hw ** 0.5) + 1
     _workspace(dev, side_ws, side_ws)  # the labelling workspace of the largest call, allocated outside the timed region
     for t in ("Nuclei", "Gland", "Lumen"):
@@ -347,7 +348,8 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
         phase["inference_s"] = time.perf_counter() - t0
         t1 = time.perf_counter()
         canv = OrderedDict(struct)
-        inst, info, small = postprocess_bands_and_gather(run, H, W, rank, world, dist, canv=canv, max_band_px=max_band_px, prof=prof)
+        inst, info, small = postprocess_bands_and_gather(run, H, W, rank, world, dist, margin=MARGIN, guard=48, canv=canv, max_band_px=max_band_px,
+                                                         prof=prof)
         torch.cuda.synchronize()
         phase["tail_s"] = time.perf_counter() - t1
         res.update(inst=inst, info=info)
