@@ -7,7 +7,8 @@ import sys
 # (flag, takes a value, default, help)
 _COMMON = [
     ("--gpu", True, "0", "GPU id(s), exported as HIP_VISIBLE_DEVICES when not launched under torch.distributed.run"),
-    ("--model", True, None, "directory holding settings.yml + weights.tar; omitted: seeded synthetic checkpoint"),
+    ("--model", True, None, "directory holding settings.yml + weights.tar (required unless --synthetic)"),
+    ("--synthetic", False, False, "(not in the reference) run on the package's seeded synthetic test weights instead of a checkpoint"),
     ("--nr_inference_workers", True, "0", "accepted for compatibility: tiles are gathered on the device, there is no loader pool"),
     ("--nr_post_proc_workers", True, "0", "accepted for compatibility: post-processing runs on the GPU in the main process"),
 ]
@@ -46,6 +47,12 @@ def usage(prog, options):
         left = flag + ("=<value>" if has_val else "")
         lines.append("  %-30s %s%s" % (left, text, "" if default in (None, False) else "  [default: %s]" % default))
     return "\n".join(lines)
+
+
+def require_model(args):
+    """A forgotten --model must not produce plausible-looking label maps from synthetic weights."""
+    if not args.get("--model") and not args.get("--synthetic"):
+        sys.exit("--model=<dir with settings.yml + weights.tar> is required (or --synthetic for the seeded test weights)")
 
 
 def parse(prog, options, argv=None, version=None):

@@ -865,7 +865,7 @@ __global__ __launch_bounds__(256) void ws_flood_lds_kernel(const float* __restri
 // Exact tie order: literal emulation of skimage's global heap (runs only when a flood flagged an ambiguous component)
 // =================================================================================================================
 // skimage.segmentation.watershed keeps ONE binary heap for the whole image (_watershed_cy.pyx + _shared/heap_general.pxi;
-// restated and pinned against the real library in oracle/postproc_ref.c::ref_watershed): every marker pixel is pushed in
+// the checker's C restatement of it is pinned against the real library): every marker pixel is pushed in
 // raster order with age 0, `smaller` is strict on (value, age), heappush sifts up while the new entry is smaller than its
 // parent, heappop moves the LAST entry to the root and sifts it down preferring the left child on equal keys.  The order in
 // which equal-valued markers leave that heap is a function of its whole push / pop history, so it cannot be evaluated per

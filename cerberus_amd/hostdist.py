@@ -55,6 +55,11 @@ class HostStagedDist(object):
             for a, b in zip(gather_list, hl):
                 a.copy_(b)
 
+    def broadcast(self, tensor, src=0):
+        h = _host(tensor).contiguous()
+        self._d.broadcast(h, src=src)
+        tensor.copy_(h)
+
     def all_reduce(self, tensor, op=None):
         h = _host(tensor).contiguous()
         self._d.all_reduce(h) if op is None else self._d.all_reduce(h, op=op)

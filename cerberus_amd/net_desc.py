@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .weights import DEFAULT_DECODER_KWARGS, make_state_dict, state_dict_schema
+from .weights import reference_init_state_dict, DEFAULT_DECODER_KWARGS, make_state_dict, state_dict_schema
 
 HEAD_NAME_MAP = {  # reference models/run_desc.py:466-473
     "Gland": "Gland-INST",
@@ -74,8 +74,12 @@ class NetDesc(torch.nn.Module):
             key = name if name == "Patch-Class" else name.split("#")[0] + "-" + hname
             self._decoders.append((name, hname, int(och), key))
         self._schema = state_dict_schema(self.decoder_info_list, self.considered_tasks)
-        # deterministic seeded initialisation (the reference draws kaiming-normal weights here, net_desc.py:89-101)
-        self._sd = OrderedDict((k, torch.from_numpy(v)) for k, v in make_state_dict(0, self.decoder_info_list, self.considered_tasks).items())
+        if backbone_imagenet_pretrained:
+            # the reference pulls torchvision's ImageNet ResNet34 here (models/backbone/__init__.py:67); no such file travels with this package
+            raise NotImplementedError("backbone_imagenet_pretrained=True: load the backbone.* keys with load_state_dict(..., strict=False) instead")
+        # the reference's initial state (weights_init_cnn, net_desc.py:89-103): kaiming-normal convs, identity BatchNorm.  The seeded
+        # non-saturating TEST weights of cerberus_amd.weights.make_state_dict are never installed implicitly.
+        self._sd = OrderedDict((k, torch.from_numpy(v)) for k, v in reference_init_state_dict(self.decoder_info_list, self.considered_tasks).items())
         self._handle = None
         self.training = False
 

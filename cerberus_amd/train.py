@@ -108,6 +108,11 @@ def train_step(batch_data, run_info, dist=None, world_size=1, dropout_keep=None)
     -- the reference's protocol (models/run_desc.py:25-60).  Returns {'EMA': {'<head>_loss': ..., 'overall_loss': ...}}."""
     run_info, _ = run_info
     model, opt = run_info["net"]["desc"], run_info["net"]["optimizer"]
+    if getattr(model, "subtype_gland", False) or getattr(model, "subtype_nuclei", False):
+        # the reference freezes the backbone, conv_map, Patch-Class, every INST decoder and the unselected TYPE decoder here and puts
+        # their BatchNorm layers in eval mode (models/run_desc.py:83-84, net_desc.py:105-140); this step trains and renormalises
+        # EVERYTHING, so running it in a sub-typing configuration would silently train the wrong network
+        raise NotImplementedError("train_step: subtype_gland / subtype_nuclei (frozen-backbone sub-typing fine-tune) is not implemented")
     loss_opts = run_info["net"]["extra_info"]["loss"]
     batch = dict(batch_data)
     img = batch.pop("img")
@@ -148,6 +153,11 @@ def train_step(batch_data, run_info, dist=None, world_size=1, dropout_keep=None)
         run = [model._dev_params[k] for k in stats]
         torch._foreach_mul_(run, 0.9)
         torch._foreach_add_(run, [s.reshape(r.shape) for s, r in zip(stats.values(), run)], alpha=0.1)
+        for k in stats:  # BatchNorm2d.num_batches_tracked += 1 per training forward (the checkpoint's int64 buffers)
+            if k.endswith("running_mean"):
+                nk = k[: -len("running_mean")] + "num_batches_tracked"
+                if nk in model._sd:
+                    model._sd[nk] = model._sd[nk] + 1
     torch.cuda.synchronize(dev)
     model.load_updated_parameters(model._dev_params, model._dev_flat, model._dev_layout)
     ema = OrderedDict(("%s_loss" % k, v) for k, v in losses.items())

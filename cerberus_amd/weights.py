@@ -156,6 +156,45 @@ def make_state_dict(seed=0, decoder_kwargs=None, considered_tasks=None):
     return sd
 
 
+def reference_init_state_dict(decoder_kwargs=None, considered_tasks=None, generator=None):
+    """What the reference's NetDesc.__init__ leaves in a freshly built model (models/net_desc.py:89-103 `weights_init_cnn`,
+    models/backbone/resnet.py:215-220): conv weights kaiming-normal (fan_out, relu), conv / linear biases at torch's defaults,
+    BatchNorm weight 1 / bias 0 / running_mean 0 / running_var 1 / num_batches_tracked 0.  Drawn from torch's global generator (or
+    `generator`), so `torch.manual_seed` governs it as it governs the reference; the streams are not bit-identical (module order)."""
+    import math
+
+    import torch
+
+    sd = OrderedDict()
+    fan_in_of = {}
+    for key, shape, kind in state_dict_schema(decoder_kwargs, considered_tasks):
+        if kind in ("conv", "conv_out"):
+            fan_out = int(shape[0] * np.prod(shape[2:]))
+            fan_in_of[key.rsplit(".", 1)[0]] = int(np.prod(shape[1:]))
+            w = torch.randn(tuple(shape), generator=generator) * math.sqrt(2.0 / fan_out)
+        elif kind == "fc":  # backbone.fc (never called): nn.Linear default
+            fan_in_of[key.rsplit(".", 1)[0]] = int(shape[1])
+            b = 1.0 / math.sqrt(shape[1])
+            w = (torch.rand(tuple(shape), generator=generator) * 2 - 1) * b
+        elif kind == "bias":
+            if key.startswith("backbone.fc"):
+                w = torch.zeros(tuple(shape))
+            else:
+                b = 1.0 / math.sqrt(max(1, fan_in_of.get(key.rsplit(".", 1)[0], 1)))
+                w = (torch.rand(tuple(shape), generator=generator) * 2 - 1) * b
+        elif kind in ("bn_w", "bn_w_res", "bn_v"):
+            w = torch.ones(tuple(shape))
+        elif kind in ("bn_b", "bn_m"):
+            w = torch.zeros(tuple(shape))
+        elif kind == "bn_n":
+            sd[key] = np.array(0, dtype=np.int64)
+            continue
+        else:  # pragma: no cover
+            raise ValueError(kind)
+        sd[key] = np.ascontiguousarray(w.numpy(), dtype=np.float32)
+    return sd
+
+
 def state_dict_sha256(sd):
     import hashlib
 

@@ -161,6 +161,10 @@ class WSIRunner(object):
         self.geo = SlideGeometry(slide_hw, patch_input_shape, patch_output_shape, patch_sel)
         self.batch = int(batch_size)
         self.rank, self.world = int(rank), int(world_size)
+        if self.geo.rows < self.world:
+            # every rank evaluates the same condition, so all of them stop here together (an empty band would leave its rank out of
+            # the halo exchange and the gathers, and the others waiting for it)
+            raise ValueError("slide of %d patch rows cannot be sharded over %d ranks: use at most %d" % (self.geo.rows, self.world, self.geo.rows))
         self.r0, self.r1 = self.geo.band(self.rank, self.world)
         self.dev = torch.device("cuda", torch.cuda.current_device())
         g = self.geo

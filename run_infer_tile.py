@@ -1,15 +1,16 @@
 """Tile-mode inference driver (the role of the reference's run_infer_tile.py): every .png / .jpg under --input_dir through
 the MI355X-native InferManager -- HIP forward, on-GPU post-processing, instance table -- writing <tissue>_mat/<name>.mat,
 pclass_mat/<name>.mat and overlay/<name>.jpg.  Flag names and defaults are the reference's (cerberus_amd/cli.py);
-<model>/settings.yml + weights.tar are read as the reference reads them (run_infer_tile.py:47-49 there); without --model a
-seeded synthetic checkpoint is used (this image has no network to fetch weights)."""
+<model>/settings.yml + weights.tar are read as the reference reads them (run_infer_tile.py:47-49 there); --synthetic
+selects the package's seeded test weights instead (this image has no network to fetch a checkpoint)."""
 import os
 
-from cerberus_amd.cli import TILE_OPTIONS, parse
+from cerberus_amd.cli import TILE_OPTIONS, parse, require_model
 
 
 def main(argv=None):
     args = parse("run_infer_tile.py", TILE_OPTIONS, argv, version="CoBi Gland Inference")
+    require_model(args)
     if args["--gpu"]:
         os.environ["HIP_VISIBLE_DEVICES"] = args["--gpu"]
     os.makedirs(args["--output_dir"], exist_ok=True)

@@ -16,7 +16,10 @@ import time
 
 import numpy as np
 
-from cerberus_amd.cli import WSI_OPTIONS, parse
+from cerberus_amd.cli import WSI_OPTIONS, parse, require_model
+
+
+ONE_CALL_PX = 400 * 1000 * 1000  # largest map labelled in one call on one GPU (38 GB of workspace); larger slides are banded
 
 
 def _basename(path, ext):
@@ -47,6 +50,7 @@ def _open_slide(path):
 
 def main(argv=None):
     args = parse("run_infer_wsi.py", WSI_OPTIONS, argv, version="CoBi Gland Inference")
+    require_model(args)
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     if args["--gpu"] and world == 1:
         os.environ["HIP_VISIBLE_DEVICES"] = args["--gpu"]
@@ -97,7 +101,12 @@ def main(argv=None):
     for path in slides:
         base = _basename(path, ext)
         dat_path = os.path.join(out_dir, "dat", base + ".dat")
-        if os.path.exists(dat_path):  # a finished slide is skipped on re-runs
+        done = os.path.exists(dat_path)  # a finished slide is skipped on re-runs (infer/wsi.py:969-978)
+        if dist is not None:  # rank 0's view decides for everybody: ranks that disagreed (laggy / unshared file system) would deadlock
+            flag = torch.tensor([1 if done else 0], dtype=torch.int64, device="cuda")
+            dist.broadcast(flag, src=0)
+            done = bool(int(flag.item()))
+        if done:
             continue
         t0 = time.perf_counter()
         host, H, W, seed = _open_slide(path)
@@ -125,10 +134,12 @@ def main(argv=None):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         records = None
-        if world > 1 and mask is None:  # band-local labelling with slide-global ids; only int32 label bands and the class maps travel to the root
+        if mask is None and (world > 1 or H * W > ONE_CALL_PX):
+            # band-local labelling with slide-global ids; only int32 label bands and the class maps travel to the root.  On ONE GPU a
+            # slide too large for a single labelling call (96 B / px of workspace, 2^31 px) streams through the same protocol band by band
             from cerberus_amd.shard_postproc import postprocess_bands_and_gather
 
-            inst, _, maps = postprocess_bands_and_gather(run, H, W, rank, world, dist)
+            inst, _, maps = postprocess_bands_and_gather(run, H, W, rank, world, dist, max_band_px=ONE_CALL_PX if world == 1 else None)
         else:  # with a mask gland / lumen are labelled per tissue region (infer/wsi.py:730-835), on the root
             maps = run.gather_to_root(dist)
             if rank == 0 and mask is not None:
@@ -160,7 +171,7 @@ def main(argv=None):
                     inst["topleft_region%d" % i] = torch.tensor(rec["topleft"])
             np.savez_compressed(os.path.join(out_dir, base + ".npz"), **{k: v.cpu().numpy() for k, v in inst.items()},
                                 **{"type_" + k: v.cpu().numpy() for k, v in maps.items() if k.endswith("TYPE")},
-                                pclass=maps.get("Patch-Class").cpu().numpy()[::4, ::4])
+                                **({"pclass": maps["Patch-Class"].cpu().numpy()[::4, ::4]} if "Patch-Class" in maps else {}))
         t3 = time.perf_counter()
         os.makedirs(os.path.dirname(dat_path), exist_ok=True)
         nuc_only = {k: v for k, v in inst.items() if k == "Nuclei"} if records is not None else inst

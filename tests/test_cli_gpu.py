@@ -20,7 +20,7 @@ def test_run_infer_tile_cli(tmp_path):
     rs = np.random.RandomState(3)
     for name, hw in (("a", (300, 421)), ("b", (256, 256))):
         Image.fromarray(rs.randint(0, 256, hw + (3,)).astype(np.uint8)).save(str(inp / (name + ".png")))
-    cmd = [sys.executable, os.path.join(ROOT, "run_infer_tile.py"), "--input_dir=%s" % inp, "--output_dir=%s" % out, "--batch_size=8",
+    cmd = [sys.executable, os.path.join(ROOT, "run_infer_tile.py"), "--synthetic", "--input_dir=%s" % inp, "--output_dir=%s" % out, "--batch_size=8",
            "--patch_input_shape=256", "--patch_output_shape=256"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -43,7 +43,7 @@ def test_run_infer_wsi_cli_synthetic(tmp_path):
     spec.mkdir()
     (spec / "s1.txt").write_text("synthetic:700x900:5")
     out = tmp_path / "out"
-    cmd = [sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--input_dir=%s" % spec, "--wsi_file_ext=.txt", "--output_dir=%s" % out,
+    cmd = [sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--synthetic", "--input_dir=%s" % spec, "--wsi_file_ext=.txt", "--output_dir=%s" % out,
            "--batch_size=6", "--patch_input_shape=448", "--patch_output_shape=144", "--save_label_maps"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -90,7 +90,7 @@ def test_run_infer_wsi_cli_with_tissue_mask(tmp_path):
     m[5:45, 4:50] = 255
     m[60:95, 20:70] = 255
     Image.fromarray(np.stack([m] * 3, -1)).save(str(msk / "s1.png"))
-    cmd = [sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--input_dir=%s" % spec, "--msk_dir=%s" % msk, "--wsi_file_ext=.txt",
+    cmd = [sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--synthetic", "--input_dir=%s" % spec, "--msk_dir=%s" % msk, "--wsi_file_ext=.txt",
            "--output_dir=%s" % out, "--batch_size=6", "--patch_input_shape=256", "--patch_output_shape=256", "--save_label_maps", "--save_mask"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -215,7 +215,7 @@ def test_run_infer_wsi_cli_two_ranks_equals_one_rank(tmp_path):
     m = np.zeros((150, 110), np.uint8)
     m[10:140, 8:70] = 255
     Image.fromarray(np.stack([m] * 3, -1)).save(str(msk / "s1.png"))
-    base = ["--input_dir=%s" % spec, "--wsi_file_ext=.txt", "--batch_size=6", "--patch_input_shape=256", "--patch_output_shape=256", "--save_label_maps"]
+    base = ["--synthetic", "--input_dir=%s" % spec, "--wsi_file_ext=.txt", "--batch_size=6", "--patch_input_shape=256", "--patch_output_shape=256", "--save_label_maps"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", CERB_DIST_BACKEND="gloo")
     port = 29547
     for tag, extra in (("mask", ["--msk_dir=%s" % msk]), ("nomask", [])):
