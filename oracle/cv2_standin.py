@@ -64,8 +64,8 @@ def erode(src, kernel, iterations=1):
 # with OpenCV's documented conventions: 8-connected foreground; Freeman codes 0..7 = E, NE, N, NW, W, SW, S, SE (y down);
 # raster scan finds outer-border start pixels; top-level contours are returned most-recently-found first, so [0][0] is the
 # outer border of the component whose start pixel comes LAST in raster order; CHAIN_APPROX_SIMPLE keeps the points at which
-# the chain code changes.  Not modelled: a piece nested in a hole of another piece (not top-level under RETR_TREE).
-# PARITY UNPINNED against the real library.
+# the chain code changes.  find_contours_tree below is the whole algorithm (holes, hierarchy); _trace_outer is the outer-border
+# walk alone.  PARITY UNPINNED against the real library; external pins: tests/golden/cv2_documented.json.
 RETR_TREE, CHAIN_APPROX_SIMPLE, CHAIN_APPROX_NONE = 3, 2, 1
 _CODE = [(1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1), (0, 1), (1, 1)]  # (dx, dy)
 
@@ -103,18 +103,135 @@ def _trace_outer(mask, x0, y0, method):
         s = (s + 4) & 7
 
 
+def find_contours_tree(mask, method=CHAIN_APPROX_SIMPLE):
+    """Suzuki & Abe's Algorithm 1 in full (outer AND hole borders, parent bookkeeping through LNBD, border marking), flattened
+    the way cv::findContours(RETR_TREE) flattens its tree: OpenCV links every finished border at the FRONT of its parent's child
+    list (cvInsertNodeIntoTree in the 4.x legacy implementation behind opencv-python 4.6.0.66) and walks the tree in pre-order
+    (cvTreeToNodeSeq), so siblings come newest-first and element 0 is the top-level outer border whose start pixel comes LAST in
+    the raster scan -- a piece lying inside a hole of another piece is a grand-child and never element 0.
+    Returns (contours, hierarchy): contours[k] int32 (K, 1, 2) of (x, y), hierarchy int32 (1, n, 4) = [next, prev, first_child, parent].
+    Foreground is 8-connected (outer borders), holes 4-connected, as in OpenCV."""
+    m = np.asarray(mask)
+    h, w = m.shape
+    f = np.zeros((h + 2, w + 2), np.int32)
+    f[1:-1, 1:-1] = (m != 0)
+    # neighbour k of (i, j) in CLOCKWISE order starting east (row i down): E, SE, S, SW, W, NW, N, NE
+    cw = [(0, 1), (1, 1), (1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1)]
+    idx_of = {d: k for k, d in enumerate(cw)}
+    borders = {1: dict(hole=True, parent=0, pts=None)}  # the frame
+    order = []
+    nbd = 1
+    for i in range(1, h + 1):
+        lnbd = 1
+        for j in range(1, w + 1):
+            v = f[i, j]
+            if v == 0:
+                continue
+            is_outer = v == 1 and f[i, j - 1] == 0
+            is_hole = (not is_outer) and v >= 1 and f[i, j + 1] == 0
+            if is_outer or is_hole:
+                nbd += 1
+                i2, j2 = (i, j - 1) if is_outer else (i, j + 1)
+                if is_hole and v > 1:
+                    lnbd = v
+                bp = borders[lnbd]
+                parent = (bp["parent"] if not bp["hole"] else lnbd) if is_outer else (lnbd if not bp["hole"] else bp["parent"])
+                if is_hole and not bp["hole"]:
+                    parent = lnbd
+                elif is_hole and bp["hole"]:
+                    parent = bp["parent"]
+                # (3.1) clockwise around (i, j) from (i2, j2): first non-zero pixel
+                k0 = idx_of[(i2 - i, j2 - j)]
+                i1 = j1 = None
+                for t in range(8):
+                    di, dj = cw[(k0 + t) % 8]
+                    if f[i + di, j + dj] != 0:
+                        i1, j1 = i + di, j + dj
+                        break
+                pts = []
+                if i1 is None:
+                    f[i, j] = -nbd
+                    pts = [(j - 1, i - 1)]
+                else:
+                    i2, j2, i3, j3 = i1, j1, i, j
+                    prev_dir = None
+                    while True:
+                        # (3.3) counter-clockwise around (i3, j3) starting after (i2, j2)
+                        k0 = idx_of[(i2 - i3, j2 - j3)]
+                        east_zero = False
+                        for t in range(1, 9):
+                            k = (k0 - t) % 8
+                            di, dj = cw[k]
+                            if f[i3 + di, j3 + dj] != 0:
+                                i4, j4 = i3 + di, j3 + dj
+                                break
+                            if k == 0:
+                                east_zero = True  # (i3, j3 + 1) is a 0-pixel examined in this step
+                        if east_zero:
+                            f[i3, j3] = -nbd
+                        elif f[i3, j3] == 1:
+                            f[i3, j3] = nbd
+                        step = (i4 - i3, j4 - j3)
+                        if method == CHAIN_APPROX_NONE or step != prev_dir:
+                            pts.append((j3 - 1, i3 - 1))
+                            prev_dir = step
+                        if (i4, j4) == (i, j) and (i3, j3) == (i1, j1):
+                            break
+                        i2, j2, i3, j3 = i3, j3, i4, j4
+                    borders[nbd] = dict(hole=is_hole, parent=parent, pts=pts)
+                    order.append(nbd)
+                    if f[i, j] != 1:
+                        lnbd = abs(f[i, j])
+                    continue
+                borders[nbd] = dict(hole=is_hole, parent=parent, pts=pts)
+                order.append(nbd)
+            if f[i, j] != 1:
+                lnbd = abs(f[i, j])
+    # flatten: children newest-first, pre-order
+    kids = {}
+    for b in order:
+        kids.setdefault(borders[b]["parent"], []).insert(0, b)
+    flat = []
+
+    def walk(p):
+        for c in kids.get(p, []):
+            flat.append(c)
+            walk(c)
+
+    walk(1)
+    pos = {b: k for k, b in enumerate(flat)}
+    hier = np.full((1, len(flat), 4), -1, np.int32)
+    for p, cs in kids.items():
+        for a_, b_ in zip(cs[:-1], cs[1:]):
+            hier[0, pos[a_], 0] = pos[b_]
+            hier[0, pos[b_], 1] = pos[a_]
+        if p != 1 and cs:
+            hier[0, pos[p], 2] = pos[cs[0]]
+        for c in cs:
+            hier[0, pos[c], 3] = pos[p] if p != 1 else -1
+    return [np.array(borders[b]["pts"], dtype=np.int32).reshape(-1, 1, 2) for b in flat], hier
+
+
 def findContours(mask, mode=RETR_TREE, method=CHAIN_APPROX_SIMPLE):
-    """Returns ([first_contour], None) with first_contour int32 (K, 1, 2) of (x, y) -- only element [0][0] is reproduced."""
+    """(contours, hierarchy) of cv2.findContours(mask, RETR_TREE, method) -- see find_contours_tree."""
+    assert mode == RETR_TREE
+    contours, hier = find_contours_tree(mask, method)
+    return contours, (hier if len(contours) else None)
+
+
+def findContours_first_piece(mask, method=CHAIN_APPROX_SIMPLE):
+    """The shortcut the device kernels take (cerb_inst_contour_start): outer border of the 8-connected piece whose first pixel
+    comes last in the raster scan.  Equals findContours(...)[0][0] whenever no piece lies inside a hole of another piece --
+    always true for the label maps post_process emits (tests/test_oracle_postproc.py)."""
     from scipy import ndimage
 
     mask = np.asarray(mask)
     lab, n = ndimage.label(mask != 0, structure=np.ones((3, 3), int))
     if n == 0:
-        return [], None
+        return None
     starts = ndimage.minimum(np.arange(mask.size).reshape(mask.shape), lab, index=np.arange(1, n + 1))
     last = int(np.max(starts))
-    pts = _trace_outer(mask, last % mask.shape[1], last // mask.shape[1], method)
-    return [np.array(pts, dtype=np.int32).reshape(-1, 1, 2)], None
+    return np.array(_trace_outer(mask, last % mask.shape[1], last // mask.shape[1], method), dtype=np.int32).reshape(-1, 1, 2)
 
 
 def _round_half_even(v):

@@ -1,5 +1,6 @@
 """Pins the C oracle of the post-processing path (oracle/postproc_ref.c) to the golden vectors produced by the
 reference's own loader/postproc.py run against the real scikit-image / scipy (oracle/gen_golden_postproc.py)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -56,3 +57,75 @@ def test_ellipse_structuring_elements():
     assert d5.sum() == 1 + 5 + 5 + 5 + 1
     e = pr.erode_cross3(np.ones((4, 5), np.uint8))
     assert e.all()  # the border never wins the min (cv2 default borderValue)
+
+
+# ---- external pins of the OpenCV pieces (OpenCV itself is absent from the image) -------------------------------------------
+def _cv2_doc(golden_dir):
+    import json
+
+    return json.load(open(os.path.join(golden_dir, "cv2_documented.json")))
+
+
+def test_cv2_documented_structuring_elements(golden_dir):
+    from oracle import cv2_standin as cv2
+
+    doc = _cv2_doc(golden_dir)
+    for k, key in ((5, "getStructuringElement_MORPH_ELLIPSE_5x5"), (3, "getStructuringElement_MORPH_ELLIPSE_3x3")):
+        want = np.array(doc[key]["value"], np.uint8)
+        assert np.array_equal(cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (k, k)), want)
+        # the C oracle's row spans (what the gland / lumen dilation uses) describe the same element
+        j1, j2 = (C.c_int * 64)(), (C.c_int * 64)()
+        pr.lib().ref_ellipse_spans(k, j1, j2)
+        got = np.zeros((k, k), np.uint8)
+        for i in range(k):
+            got[i, j1[i]:j2[i]] = 1
+        assert np.array_equal(got, want)
+
+
+def test_cv2_documented_contours_and_resize(golden_dir):
+    from oracle import cv2_standin as cv2
+
+    doc = _cv2_doc(golden_dir)
+    d = doc["findContours_filled_rectangle"]
+    m = np.zeros(d["mask_shape"], np.uint8)
+    m[d["rect_rows"][0]:d["rect_rows"][1], d["rect_cols"][0]:d["rect_cols"][1]] = 1
+    cs, hier = cv2.findContours(m, cv2.RETR_TREE, cv2.CHAIN_APPROX_SIMPLE)
+    assert len(cs) == 1 and cs[0].reshape(-1, 2).tolist() == d["contour_xy"] and hier.tolist() == [[[-1, -1, -1, -1]]]
+    d = doc["findContours_RETR_TREE_nesting"]
+    m = np.zeros((20, 20), np.uint8)
+    m[1:12, 1:12] = 1
+    m[3:10, 3:10] = 0
+    m[5:8, 5:8] = 1
+    m[15:18, 2:6] = 1
+    cs, hier = cv2.findContours(m, cv2.RETR_TREE, cv2.CHAIN_APPROX_SIMPLE)
+    assert hier[0].tolist() == d["hierarchy"]
+    assert [c.reshape(-1, 2)[0].tolist() for c in cs] == d["first_points_xy"]
+    # element [0][0] (all loader/postproc.py:29-33 reads) is the top-level border found last -- here the blob, NOT the island
+    # whose start pixel is... earlier; move the island's piece below the ring's start row and it still is not element 0:
+    m2 = m.copy()
+    m2[15:18, 2:6] = 0
+    assert cv2.findContours(m2, cv2.RETR_TREE, cv2.CHAIN_APPROX_SIMPLE)[0][0].reshape(-1, 2)[0].tolist() == [1, 1]
+    assert cv2.findContours_first_piece(m2).reshape(-1, 2)[0].tolist() == [5, 5]  # the shortcut differs exactly in this case
+    d = doc["resize_INTER_LINEAR_fx_0p5"]
+    row = np.array([d["row"]], np.float32)
+    assert cv2.resize(row, (0, 0), fx=0.5, fy=1.0, interpolation=cv2.INTER_LINEAR)[0].tolist() == d["value"]
+
+
+def test_contour_shortcut_equals_full_hierarchy_on_postproc_label_maps(golden_dir):
+    """The device kernels follow the border of the piece found last in the raster scan (cerb_inst_contour_start); the full
+    RETR_TREE hierarchy puts a different border first only when a piece of an instance lies inside a hole of another piece of the
+    SAME instance.  post_process cannot emit that (watershed regions are 4-connected; gland / lumen instances are hole-filled
+    before later ids overwrite them and an overwriting instance has no holes): checked on every instance of every golden map."""
+    from oracle import cv2_standin as cv2
+
+    g = np.load(os.path.join(golden_dir, "pp_cases.npz"))
+    n_inst = 0
+    for name in [str(n) for n in g["names"]]:
+        lab = g["out/" + name].astype(np.int32)
+        for iid in np.unique(lab)[1:]:
+            ys, xs = np.nonzero(lab == iid)
+            crop = (lab[ys.min():ys.max() + 1, xs.min():xs.max() + 1] == iid).astype(np.uint8)
+            full = cv2.findContours(crop, cv2.RETR_TREE, cv2.CHAIN_APPROX_SIMPLE)[0][0]
+            assert np.array_equal(full, cv2.findContours_first_piece(crop)), (name, int(iid))
+            n_inst += 1
+    assert n_inst > 500
