@@ -138,6 +138,22 @@ def run_case(prefix, nuclei_type_weight, store, weight_maps=False):
             gstat.append([g64.sum().item(), g64.abs().sum().item(), g64[0].item(), g64[g64.numel() // 2].item(), g64[-1].item()])
             d64 = (prm.detach().double().flatten() - before[k].double().flatten())
             pstat.append([p64.sum().item(), d64.abs().sum().item(), d64[0].item(), d64[d64.numel() // 2].item(), d64[-1].item()])
+        # FULL gradient tensors (fp32) for at least one layer per backward kernel family, compared element by element on the GPU:
+        #   3x3 stride-1 weight gradient + Winograd data gradient upstream of it (backbone, decoder), 3x3 stride 2, 1x1 stride 2,
+        #   plain 1x1 (conv_map), the 7x7 stem, the heads' two pointwise layers, BatchNorm gamma / beta, conv biases, Patch-Class
+        full = ["backbone.conv1.weight", "backbone.bn1.weight", "backbone.bn1.bias", "backbone.layer1.0.conv1.weight", "backbone.layer1.0.bn1.weight",
+                "backbone.layer1.0.bn1.bias", "backbone.layer1.2.conv2.weight", "backbone.layer2.0.conv1.weight", "backbone.layer2.0.downsample.0.weight",
+                "backbone.layer2.0.downsample.1.weight", "backbone.layer3.0.conv1.weight", "backbone.layer4.0.downsample.0.weight", "conv_map.weight",
+                "decoder_head.Nuclei.0.block.0.conv.weight", "decoder_head.Nuclei.3.block.0.conv.weight", "decoder_head.Nuclei.3.block.1.conv.weight",
+                "decoder_head.Nuclei.3.block.1.conv.bias", "decoder_head.Nuclei.3.block.1.bn.weight", "decoder_head.Nuclei.3.block.1.bn.bias",
+                "decoder_head.Lumen.2.block.0.conv.weight", "decoder_head.Gland#TYPE.3.block.1.conv.weight", "output_head.Nuclei.INST.x.0.block.0.conv.weight",
+                "output_head.Nuclei.INST.x.0.block.0.bn.weight", "output_head.Nuclei.INST.x.1.conv.weight", "output_head.Nuclei.INST.x.1.conv.bias",
+                "output_head.Gland#TYPE.TYPE.x.1.conv.weight", "decoder_head.Patch-Class.conv1.weight", "decoder_head.Patch-Class.conv2.weight",
+                "decoder_head.Patch-Class.bn1.weight"]
+        prm = dict(model.named_parameters())
+        for k in full:
+            store["step/grad_full/" + k] = prm[k].grad.detach().numpy().astype(np.float32)
+        store["step/grad_full_names"] = np.array(full)
         store["step/param_names"] = np.array(names)
         store["step/grad_stats"] = np.array(gstat)     # per parameter: sum, abs-sum, first / middle / last element of the gradient
         store["step/update_stats"] = np.array(pstat)   # per parameter: sum after the step, abs-sum / first / middle / last of (after - before)

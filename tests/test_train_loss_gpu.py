@@ -148,6 +148,24 @@ def test_backward_pass_vs_reference_train_step(gold):
     assert float(grads["decoder_head.Gland#TYPE.0.block.0.conv.weight"].abs().sum()) == 0.0
     assert float(grads["decoder_head.Gland#TYPE.3.block.0.conv.weight"].abs().sum()) > 0.0
     print("worst relative gradient-statistic error over %d tensors: %.2e" % (len(names), worst))
+    # FULL tensors, element by element, for one layer or more of every backward kernel family (3x3 weight gradient downstream of the
+    # Winograd data gradient, 3x3 stride 2, 1x1 stride 2, plain 1x1, the 7x7 stem, the heads' pointwise layers, BatchNorm gamma / beta,
+    # conv biases, Patch-Class): a permutation or a sign error inside a tensor cannot hide behind matching sums here
+    full_names = [str(x) for x in gold["step/grad_full_names"]]
+    assert len(full_names) >= 25
+    worst_full = 0.0
+    for k in full_names:
+        ref = gold["step/grad_full/" + k].astype(np.float64)
+        got = grads[k].double().cpu().numpy().reshape(ref.shape)
+        scale = max(float(np.abs(ref).max()), 1e-30)
+        if float(np.abs(ref).sum()) <= 1e-3 * ref.size ** 0.5:  # mathematically zero (bias in front of a BatchNorm): rounding noise both sides
+            assert float(np.abs(got).max()) < 1e-4, k
+            continue
+        err = float(np.abs(got - ref).max()) / scale
+        cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref)))
+        worst_full = max(worst_full, err)
+        assert err < 2e-3 and cos > 0.999999, (k, err, cos)
+    print("worst element-wise gradient error (relative to the tensor's largest element) over %d full tensors: %.2e" % (len(full_names), worst_full))
 
 
 def test_whole_train_step_vs_reference(gold):
