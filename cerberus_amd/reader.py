@@ -1,0 +1,400 @@
+"""Slide readers behind the interface the reference drives (tiatoolbox's `WSIReader`, infer/wsi.py:521-531):
+
+    reader = WSIReader.open(input_img=path)
+    w, h   = reader.slide_dimensions(resolution=0.5, units="mpp")      # XY, as tiatoolbox returns it
+    mpp    = reader.info.mpp                                            # scan resolution, microns per pixel (x, y) or None
+    rgb    = reader.read_bounds((x0, y0, x1, y1), resolution, units)   # uint8 [h, w, 3]; bounds in the REQUESTED resolution's pixels
+    rows   = reader.rows(resolution, units)                            # lazy (H, W, 3) row source for wsi.SlabUploader
+
+tiatoolbox / OpenSlide are not in this image, so the back ends are this package's own:
+  * ArrayReader      -- `.npy` (memory-mapped), PNG / JPG (PIL) and in-memory arrays: one level, no resolution metadata unless given;
+  * SyntheticReader  -- `.txt` holding `synthetic:<H>x<W>:<seed>`: pixels are generated on the device (wsi.synth_slide);
+  * TiffReader       -- baseline / BigTIFF, striped or TILED, pyramid pages, compression none / deflate (+ horizontal predictor) /
+                        JPEG tiles (decoded by PIL, JPEGTables spliced in), resolution from XResolution / ResolutionUnit or an
+                        Aperio `MPP = ...` description: generic tiled TIFFs and `.svs` files whose tiles are JPEG.  JPEG 2000 tiles
+                        (Aperio 33003 / 33005) and LZW are refused with a clear message.
+Resampling: the pyramid level with the largest downsample not above the request is read and reduced by a box (area) filter --
+exact pixel means for integer factors, PIL's BOX filter otherwise (tiatoolbox uses cv2 INTER_AREA there; unpinned, both libraries
+are absent).  Everything here is host I/O; pixels reach the GPU through wsi.SlabUploader chunk by chunk under the inference.
+"""
+import io
+import os
+import struct
+import zlib
+
+import numpy as np
+
+
+class SlideInfo(object):
+    def __init__(self, path, dims_wh, mpp=None, level_dimensions=None, level_downsamples=None):
+        self.file_path = path
+        self.slide_dimensions = (int(dims_wh[0]), int(dims_wh[1]))  # XY at baseline
+        self.mpp = None if mpp is None else np.array([float(mpp[0]), float(mpp[1])], np.float64)
+        self.level_dimensions = list(level_dimensions or [self.slide_dimensions])
+        self.level_downsamples = list(level_downsamples or [1.0])
+        self.level_count = len(self.level_dimensions)
+
+
+class _Rows(object):
+    """(H, W, 3) row source: rows[a:b] -> uint8 [b - a, W, 3] at the reader's requested resolution."""
+
+    def __init__(self, reader, resolution, units):
+        self.reader, self.resolution, self.units = reader, resolution, units
+        w, h = reader.slide_dimensions(resolution, units)
+        self.shape = (int(h), int(w), 3)
+        self.dtype = np.dtype(np.uint8)
+
+    def __getitem__(self, key):
+        rows = key[0] if isinstance(key, tuple) else key
+        if not isinstance(rows, slice):
+            raise TypeError("row slices only")
+        a, b, step = rows.indices(self.shape[0])
+        assert step == 1
+        out = self.reader.read_bounds((0, a, self.shape[1], b), self.resolution, self.units)
+        return out if not isinstance(key, tuple) else out[(slice(None),) + tuple(key[1:])]
+
+
+class WSIReader(object):
+    info = None
+
+    @staticmethod
+    def open(input_img, mpp=None, power=None):
+        if isinstance(input_img, np.ndarray):
+            return ArrayReader(input_img, mpp=mpp)
+        path = str(input_img)
+        ext = os.path.splitext(path)[1].lower()
+        if ext == ".npy":
+            return ArrayReader(np.load(path, mmap_mode="r"), path=path, mpp=mpp)
+        if ext == ".txt":
+            return SyntheticReader(path, mpp=mpp)
+        if ext in (".tif", ".tiff", ".svs"):
+            return TiffReader(path, mpp=mpp)
+        from PIL import Image
+
+        return ArrayReader(np.array(Image.open(path).convert("RGB")), path=path, mpp=mpp)
+
+    # ---- resolution arithmetic (tiatoolbox semantics: "mpp", "baseline" = scale w.r.t. level 0, "level") ---------------------
+    def _scale(self, resolution, units):
+        """baseline pixels per requested pixel's inverse: requested = baseline * scale"""
+        if units == "baseline":
+            return float(np.atleast_1d(resolution)[0])
+        if units == "level":
+            return 1.0 / float(self.info.level_downsamples[int(resolution)])
+        if units == "mpp":
+            if self.info.mpp is None:
+                return 1.0  # no scan resolution recorded (arrays, synthetic slides): the pixels ARE the processing resolution
+            res = np.atleast_1d(np.asarray(resolution, np.float64))
+            return float(self.info.mpp[0] / res[0])
+        raise ValueError("units must be 'mpp', 'baseline' or 'level' (objective power needs metadata these readers do not carry), got %r" % (units,))
+
+    def slide_dimensions(self, resolution, units):
+        s = self._scale(resolution, units)
+        w, h = self.info.slide_dimensions
+        return np.array([int(round(w * s)), int(round(h * s))], np.int64)
+
+    def rows(self, resolution=1.0, units="baseline"):
+        return _Rows(self, resolution, units)
+
+    def read_bounds(self, bounds, resolution=1.0, units="baseline"):
+        """bounds = (x0, y0, x1, y1) in pixels of the REQUESTED resolution; returns uint8 [y1 - y0, x1 - x0, 3]."""
+        x0, y0, x1, y1 = [int(v) for v in bounds]
+        s = self._scale(resolution, units)
+        if abs(s - 1.0) < 1e-9:
+            return self._read_level(0, x0, y0, x1, y1)
+        # level whose downsample is the largest one not above 1 / s
+        want = 1.0 / s
+        lvl = 0
+        for i, d in enumerate(self.info.level_downsamples):
+            if d <= want * (1 + 1e-6):
+                lvl = i
+        d = self.info.level_downsamples[lvl]
+        rel = want / d  # remaining reduction from that level (>= 1), or < 1 when upsampling from level 0
+        lw, lh = self.info.level_dimensions[lvl]
+        k = int(round(rel))
+        if rel >= 1 and abs(rel - k) < 1e-9:  # integer factor: exact box means
+            sx0, sy0 = x0 * k, y0 * k
+            sx1, sy1 = min(x1 * k, lw), min(y1 * k, lh)
+            src = self._read_level(lvl, sx0, sy0, sx1, sy1).astype(np.float32)
+            hh, ww = y1 - y0, x1 - x0
+            pad = np.zeros((hh * k, ww * k, 3), np.float32)
+            pad[: src.shape[0], : src.shape[1]] = src
+            if src.shape[0] < hh * k:  # the slide ends inside the last output row / column: replicate the edge
+                pad[src.shape[0]:, : src.shape[1]] = src[-1:]
+            if src.shape[1] < ww * k:
+                pad[:, src.shape[1]:] = pad[:, src.shape[1] - 1: src.shape[1]]
+            return np.clip(np.rint(pad.reshape(hh, k, ww, k, 3).mean(axis=(1, 3))), 0, 255).astype(np.uint8)
+        from PIL import Image
+
+        sx0, sy0 = int(np.floor(x0 * rel)), int(np.floor(y0 * rel))
+        sx1, sy1 = min(int(np.ceil(x1 * rel)), lw), min(int(np.ceil(y1 * rel)), lh)
+        src = Image.fromarray(self._read_level(lvl, sx0, sy0, sx1, sy1))
+        return np.array(src.resize((x1 - x0, y1 - y0), Image.BOX if rel >= 1 else Image.BILINEAR))
+
+    def _read_level(self, level, x0, y0, x1, y1):
+        raise NotImplementedError
+
+
+class ArrayReader(WSIReader):
+    def __init__(self, arr, path=None, mpp=None):
+        assert arr.ndim == 3 and arr.shape[2] >= 3 and arr.dtype == np.uint8, "slides are uint8 [H, W, 3] arrays"
+        self.arr = arr
+        self.info = SlideInfo(path, (arr.shape[1], arr.shape[0]), mpp)
+
+    def _read_level(self, level, x0, y0, x1, y1):
+        return np.ascontiguousarray(self.arr[y0:y1, x0:x1, :3])
+
+    def rows(self, resolution=1.0, units="baseline"):
+        if abs(self._scale(resolution, units) - 1.0) < 1e-9 and self.arr.shape[2] == 3:
+            return self.arr  # the array itself (np.memmap for .npy files: SlabUploader reads it chunk by chunk)
+        return _Rows(self, resolution, units)
+
+
+class SyntheticReader(WSIReader):
+    """`synthetic:<H>x<W>:<seed>`: there are no host pixels; run_infer_wsi.py generates the band on the device."""
+
+    def __init__(self, path, mpp=None):
+        _, dims, seed = open(path).read().strip().split(":")
+        h, w = [int(v) for v in dims.split("x")]
+        self.seed = int(seed)
+        self.info = SlideInfo(path, (w, h), mpp)
+
+    def _read_level(self, level, x0, y0, x1, y1):
+        from .wsi import synth_slide
+
+        return synth_slide(y1 - y0, self.info.slide_dimensions[0], y0=y0, seed=self.seed)[:, x0:x1].cpu().numpy()
+
+
+# ---- TIFF ------------------------------------------------------------------------------------------------------------------
+_TYPES = {1: ("B", 1), 2: ("c", 1), 3: ("H", 2), 4: ("I", 4), 5: ("II", 8), 6: ("b", 1), 7: ("B", 1), 8: ("h", 2), 9: ("i", 4), 10: ("ii", 8),
+          11: ("f", 4), 12: ("d", 8), 13: ("I", 4), 16: ("Q", 8), 17: ("q", 8), 18: ("Q", 8)}
+
+
+class _Page(object):
+    pass
+
+
+class TiffReader(WSIReader):
+    def __init__(self, path, mpp=None):
+        self.path = path
+        self.fh = open(path, "rb")
+        head = self.fh.read(16)
+        self.bo = "<" if head[:2] == b"II" else ">"
+        magic = struct.unpack(self.bo + "H", head[2:4])[0]
+        if magic == 42:
+            self.big, off = False, struct.unpack(self.bo + "I", head[4:8])[0]
+        elif magic == 43:
+            self.big, off = True, struct.unpack(self.bo + "Q", head[8:16])[0]
+        else:
+            raise ValueError("%s: not a TIFF file" % path)
+        pages = []
+        while off:
+            page, off = self._read_ifd(off)
+            pages.append(page)
+        # pyramid = the full-resolution page plus every REDUCED page of the same aspect (labels / macros of .svs files drop out)
+        base = pages[0]
+        levels = [base]
+        for p in pages[1:]:
+            ds_x, ds_y = base.w / p.w, base.h / p.h
+            if p.w < base.w and abs(ds_x - ds_y) / ds_x < 0.02 and p.samples >= 3 and (p.subfile & 1 or p.tiled):
+                levels.append(p)
+        levels.sort(key=lambda p: -p.w)
+        self.levels = levels
+        file_mpp = base.mpp
+        self.info = SlideInfo(path, (base.w, base.h), mpp if mpp is not None else file_mpp, [(p.w, p.h) for p in levels],
+                              [base.w / p.w for p in levels])
+
+    def _read_ifd(self, off):
+        bo, fh = self.bo, self.fh
+        fh.seek(off)
+        n = struct.unpack(bo + ("Q" if self.big else "H"), fh.read(8 if self.big else 2))[0]
+        esz = 20 if self.big else 12
+        raw = fh.read(n * esz + (8 if self.big else 4))
+        tags = {}
+        for i in range(n):
+            e = raw[i * esz:(i + 1) * esz]
+            tag, typ = struct.unpack(bo + "HH", e[:4])
+            cnt = struct.unpack(bo + ("Q" if self.big else "I"), e[4:12] if self.big else e[4:8])[0]
+            val = e[12:20] if self.big else e[8:12]
+            if typ not in _TYPES:
+                continue
+            fmt, size = _TYPES[typ]
+            nbytes = cnt * size
+            if nbytes > len(val):
+                pos = struct.unpack(bo + ("Q" if self.big else "I"), val)[0]
+                fh.seek(pos)
+                data = fh.read(nbytes)
+            else:
+                data = val[:nbytes]
+            if typ == 2:
+                tags[tag] = data.split(b"\x00")[0].decode("latin1")
+            elif typ == 7:
+                tags[tag] = data
+            elif typ in (5, 10):
+                v = struct.unpack(bo + fmt[0] * (2 * cnt), data)
+                tags[tag] = [v[2 * k] / v[2 * k + 1] if v[2 * k + 1] else 0.0 for k in range(cnt)]
+            else:
+                tags[tag] = list(struct.unpack(bo + fmt * cnt, data))
+        nxt = struct.unpack(bo + ("Q" if self.big else "I"), raw[n * esz:])[0]
+        p = _Page()
+        p.w, p.h = tags[256][0], tags[257][0]
+        p.samples = tags.get(277, [1])[0]
+        p.bits = tags.get(258, [8])[0]
+        p.compression = tags.get(259, [1])[0]
+        p.photometric = tags.get(262, [2])[0]
+        p.planar = tags.get(284, [1])[0]
+        p.predictor = tags.get(317, [1])[0]
+        p.subfile = tags.get(254, [0])[0]
+        p.jpeg_tables = tags.get(347)
+        p.tiled = 322 in tags
+        if p.tiled:
+            p.tw, p.th = tags[322][0], tags[323][0]
+            p.offsets, p.counts = tags[324], tags[325]
+        else:
+            p.tw, p.th = p.w, tags.get(278, [p.h])[0]
+            p.offsets, p.counts = tags[273], tags[279]
+        p.mpp = None
+        desc = tags.get(270, "")
+        if isinstance(desc, str) and "MPP" in desc:  # Aperio: "...|MPP = 0.2520|..."
+            try:
+                v = float(desc.split("MPP")[1].split("=")[1].split("|")[0])
+                p.mpp = (v, v)
+            except (IndexError, ValueError):
+                pass
+        if p.mpp is None and 282 in tags and 283 in tags and tags.get(296, [2])[0] in (2, 3) and tags[282][0] > 0 and tags[283][0] > 0:
+            per_um = 25400.0 if tags.get(296, [2])[0] == 2 else 10000.0  # pixels per inch / per centimetre
+            if tags[282][0] > 100:  # 72 / 96 dpi are display defaults, not scan resolutions
+                p.mpp = (per_um / tags[282][0], per_um / tags[283][0])
+        if p.bits != 8 or p.planar != 1:
+            raise NotImplementedError("%s: only 8-bit chunky RGB(A) pages are supported" % self.path)
+        return p, nxt
+
+    def _decode(self, p, idx, rows, cols):
+        self.fh.seek(p.offsets[idx])
+        data = self.fh.read(p.counts[idx])
+        c = p.compression
+        if c == 1:
+            buf = np.frombuffer(data, np.uint8)
+        elif c in (8, 32946):
+            buf = np.frombuffer(zlib.decompress(data), np.uint8)
+        elif c == 7:
+            from PIL import Image
+
+            if p.jpeg_tables:  # abbreviated streams: tables (minus EOI) + tile (minus SOI)
+                data = p.jpeg_tables[:-2] + data[2:]
+            im = Image.open(io.BytesIO(data))
+            if p.photometric == 2 and im.mode == "YCbCr":
+                im.draft("RGB", im.size)
+            arr = np.array(im.convert("RGB"))
+            return arr[:rows, :cols]
+        elif c in (33003, 33005):
+            raise NotImplementedError("%s: JPEG 2000 tiles (Aperio compression %d) need a JP2K decoder that is not in this image" % (self.path, c))
+        elif c == 5:
+            raise NotImplementedError("%s: LZW-compressed TIFF is not supported (re-save with deflate or as tiles of JPEG)" % self.path)
+        else:
+            raise NotImplementedError("%s: TIFF compression %d is not supported" % (self.path, c))
+        arr = buf[: rows * cols * p.samples].reshape(rows, cols, p.samples)
+        if p.predictor == 2:
+            arr = np.cumsum(arr, axis=1, dtype=np.uint8)
+        return arr[:, :, :3]
+
+    def _read_level(self, level, x0, y0, x1, y1):
+        p = self.levels[level]
+        x0, y0, x1, y1 = max(0, x0), max(0, y0), min(p.w, x1), min(p.h, y1)
+        out = np.zeros((max(0, y1 - y0), max(0, x1 - x0), 3), np.uint8)
+        across = -(-p.w // p.tw)
+        for ty in range(y0 // p.th, -(-y1 // p.th)):
+            for tx in range(x0 // p.tw, -(-x1 // p.tw)):
+                # tiles are stored whole (padded); strips are cropped to the image on the last rows
+                rows = p.th if p.tiled else min(p.th, p.h - ty * p.th)
+                cols = p.tw if p.tiled else p.w
+                tile = self._decode(p, ty * across + tx, rows, cols)
+                gy0, gx0 = ty * p.th, tx * p.tw
+                a0, a1 = max(y0, gy0), min(y1, gy0 + tile.shape[0])
+                b0, b1 = max(x0, gx0), min(x1, gx0 + tile.shape[1])
+                if a1 > a0 and b1 > b0:
+                    out[a0 - y0:a1 - y0, b0 - x0:b1 - x0] = tile[a0 - gy0:a1 - gy0, b0 - gx0:b1 - gx0]
+        return out
+
+
+def write_tiled_tiff(path, levels, tile=256, mpp=None, compress=True, description=None):
+    """Minimal pyramidal tiled TIFF writer (deflate or raw tiles) -- for tests and for converting arrays; levels[0] is full
+    resolution, the others are reduced pages (NewSubfileType 1)."""
+    bo = "<"
+    with open(path, "wb") as fh:
+        fh.write(b"II" + struct.pack(bo + "HI", 42, 0))
+        prev_next_pos = 4
+        for li, img in enumerate(levels):
+            img = np.ascontiguousarray(img[:, :, :3], np.uint8)
+            h, w = img.shape[:2]
+            offs, cnts = [], []
+            for ty in range(-(-h // tile)):
+                for tx in range(-(-w // tile)):
+                    t = np.zeros((tile, tile, 3), np.uint8)
+                    blk = img[ty * tile:(ty + 1) * tile, tx * tile:(tx + 1) * tile]
+                    t[: blk.shape[0], : blk.shape[1]] = blk
+                    data = zlib.compress(t.tobytes(), 6) if compress else t.tobytes()
+                    offs.append(fh.tell())
+                    cnts.append(len(data))
+                    fh.write(data)
+                    if fh.tell() & 1:
+                        fh.write(b"\0")
+            entries = []
+
+            def put(tag, typ, vals):
+                entries.append((tag, typ, vals))
+
+            put(254, 4, [1 if li else 0])
+            put(256, 4, [w])
+            put(257, 4, [h])
+            put(258, 3, [8, 8, 8])
+            put(259, 3, [8 if compress else 1])
+            put(262, 3, [2])
+            if description and li == 0:
+                put(270, 2, description.encode("latin1") + b"\0")
+            put(277, 3, [3])
+            if mpp is not None:
+                scale = levels[0].shape[1] / w
+                put(282, 5, [(int(round(1e4 / (mpp * scale) * 1000)), 1000)])
+                put(283, 5, [(int(round(1e4 / (mpp * scale) * 1000)), 1000)])
+            put(284, 3, [1])
+            if mpp is not None:
+                put(296, 3, [3])
+            put(322, 4, [tile])
+            put(323, 4, [tile])
+            put(324, 4, offs)
+            put(325, 4, cnts)
+            entries.sort(key=lambda e: e[0])
+            # out-of-line values first
+            blobs = {}
+            for tag, typ, vals in entries:
+                if typ == 2:
+                    raw = vals
+                elif typ == 5:
+                    raw = b"".join(struct.pack(bo + "II", a, b) for a, b in vals)
+                else:
+                    raw = struct.pack(bo + {3: "H", 4: "I"}[typ] * len(vals), *vals)
+                if len(raw) > 4:
+                    if fh.tell() & 1:
+                        fh.write(b"\0")
+                    blobs[tag] = fh.tell()
+                    fh.write(raw)
+            if fh.tell() & 1:
+                fh.write(b"\0")
+            ifd_pos = fh.tell()
+            fh.write(struct.pack(bo + "H", len(entries)))
+            for tag, typ, vals in entries:
+                if typ == 2:
+                    raw, cnt = vals, len(vals)
+                elif typ == 5:
+                    raw, cnt = b"".join(struct.pack(bo + "II", a, b) for a, b in vals), len(vals)
+                else:
+                    raw, cnt = struct.pack(bo + {3: "H", 4: "I"}[typ] * len(vals), *vals), len(vals)
+                fh.write(struct.pack(bo + "HHI", tag, typ, cnt))
+                fh.write(struct.pack(bo + "I", blobs[tag]) if len(raw) > 4 else raw.ljust(4, b"\0"))
+            next_pos = fh.tell()
+            fh.write(struct.pack(bo + "I", 0))
+            end = fh.tell()
+            fh.seek(prev_next_pos)
+            fh.write(struct.pack(bo + "I", ifd_pos))
+            fh.seek(end)
+            prev_next_pos = next_pos

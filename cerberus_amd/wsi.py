@@ -253,7 +253,7 @@ def _uuid4_hex(n):
     return [hx[i:i + 32] for i in range(0, 32 * n, 32)]
 
 
-def build_wsi_inst_info(inst, canv, slide_hw, proc_mag, ds_factor=0.5, region_records=None):
+def build_wsi_inst_info(inst, canv, slide_hw, proc_mag, ds_factor=0.5, region_records=None, base_mag=None, base_hw=None):
     """The dictionary the reference dumps as dat/<slide>.dat (infer/wsi.py:805-853): per tissue {uuid4 hex -> {'box':
     [x1, y1, x2, y2], 'centroid', 'contour', 'type', 'type_prob'}} plus resolution metadata.  Gland / lumen label maps are
     at x`ds_factor` and their coordinates are scaled back (get_inst_info_dict(..., ds_factor)); nuclei are at full
@@ -284,9 +284,11 @@ def build_wsi_inst_info(inst, canv, slide_hw, proc_mag, ds_factor=0.5, region_re
         info = get_inst_info_dict(lab.contiguous(), tmap, ds_factor if half else 1.0, flat_box=True)
         out[tissue] = OrderedDict(zip(_uuid4_hex(len(info)), info.values()))
     out["proc_resolution"] = {"resolution": float(proc_mag), "units": "mpp"}
-    out["base_resolution"] = {"resolution": float(proc_mag), "units": "mpp"}  # arrays / synthetic slides carry no pyramid
+    # scan resolution / baseline size as the reader reports them (infer/wsi.py:529-531); arrays and synthetic slides carry none
+    out["base_resolution"] = {"resolution": float(proc_mag if base_mag is None else base_mag), "units": "mpp"}
     out["proc_dimensions"] = np.array([int(slide_hw[0]), int(slide_hw[1])])  # YX
-    out["base_dimensions"] = np.array([int(slide_hw[0]), int(slide_hw[1])])
+    bh, bw = slide_hw if base_hw is None else base_hw
+    out["base_dimensions"] = np.array([int(bh), int(bw)])
     return out
 
 

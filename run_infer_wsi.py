@@ -1,6 +1,7 @@
-"""Slide-mode inference driver (the role of the reference's run_infer_wsi.py).  A slide is a `.npy` uint8 [H, W, 3] array, a
-PNG / JPG image, or a `.txt` file holding `synthetic:<H>x<W>:<seed>` (slide-file decoding through tiatoolbox / OpenSlide is out
-of scope).  The slide band of this rank lives in HBM; patches are gathered, inferred and scattered on the device, the band is
+"""Slide-mode inference driver (the role of the reference's run_infer_wsi.py).  Slides open through cerberus_amd.reader.WSIReader
+(the interface of tiatoolbox's reader, infer/wsi.py:521-531): tiled / pyramidal TIFF and JPEG-tiled `.svs`, `.npy` uint8 [H, W, 3]
+arrays, PNG / JPG images, or a `.txt` file holding `synthetic:<H>x<W>:<seed>`; pixels are read at `--wsi_proc_mag` microns per
+pixel when the file records its scan resolution.  The slide band of this rank lives in HBM; patches are gathered, inferred and scattered on the device, the band is
 labelled on the device, and only the instance dictionary is written -- `dat/<slide>.dat` in the reference's joblib format
 (infer/wsi.py:844-853 there).  Flag names and defaults are the reference's (cerberus_amd/cli.py); the tiling / cache flags it
 parses and then overrides with constants are accepted and ignored.  `--msk_dir` tissue masks are honoured: patches without
@@ -33,19 +34,16 @@ def _write_then_rename(write, obj, path):
     os.replace(tmp, path)
 
 
-def _open_slide(path):
-    """-> (host array or None, H, W, seed): None means a synthetic slide generated on the device from `seed`."""
-    if path.endswith(".npy"):
-        host = np.load(path, mmap_mode="r")
-        return host, int(host.shape[0]), int(host.shape[1]), 0
-    if path.endswith(".txt"):
-        _, dims, seed = open(path).read().strip().split(":")
-        h, w = [int(v) for v in dims.split("x")]
-        return None, h, w, int(seed)
-    from PIL import Image
+def _open_slide(path, proc_mpp):
+    """-> (row source or None, H, W, seed, reader): rows of the slide at the processing resolution (`--wsi_proc_mag` microns per
+    pixel, infer/wsi.py:521-527) through cerberus_amd.reader.WSIReader; None means a synthetic slide generated on the device."""
+    from cerberus_amd.reader import SyntheticReader, WSIReader
 
-    host = np.array(Image.open(path).convert("RGB"))
-    return host, int(host.shape[0]), int(host.shape[1]), 0
+    reader = WSIReader.open(input_img=path)
+    w, h = [int(v) for v in reader.slide_dimensions(resolution=proc_mpp, units="mpp")]
+    if isinstance(reader, SyntheticReader):
+        return None, h, w, reader.seed, reader
+    return reader.rows(proc_mpp, "mpp"), h, w, 0, reader
 
 
 def main(argv=None):
@@ -109,7 +107,7 @@ def main(argv=None):
         if done:
             continue
         t0 = time.perf_counter()
-        host, H, W, seed = _open_slide(path)
+        host, H, W, seed, reader = _open_slide(path, float(args["--wsi_proc_mag"]))
         mask, sel, regions = None, None, None
         if msk_dir:
             from cerberus_amd.tissue import TissueRegions, load_mask, select_patches
@@ -126,11 +124,11 @@ def main(argv=None):
         y0, y1 = run.slab_rows()  # this rank's band + context halo
         if host is None:
             run.infer_band(synth_slide(y1 - y0, W, y0=y0, seed=seed), y0)
-        elif isinstance(host, np.memmap):  # a slide on disk: read + upload chunk by chunk on a copy stream underneath the inference of
-            up = SlabUploader(host, y0, y1)  # the rows above (an array already in RAM goes up in one 50 GB/s copy: nothing to hide)
-            run.infer_band(up.slab, y0, ready=up.upload_until)
-        else:
+        elif isinstance(host, np.ndarray) and not isinstance(host, np.memmap):  # already in RAM: one 50 GB/s copy, nothing to hide
             run.infer_band(torch.from_numpy(np.ascontiguousarray(host[y0:y1])).cuda(), y0)
+        else:  # a slide on disk (memory-mapped array, tiled TIFF / .svs pyramid): read / decode + upload chunk by chunk on a copy
+            up = SlabUploader(host, y0, y1)  # stream underneath the inference of the rows above
+            run.infer_band(up.slab, y0, ready=up.upload_until)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         records = None
@@ -175,7 +173,9 @@ def main(argv=None):
         t3 = time.perf_counter()
         os.makedirs(os.path.dirname(dat_path), exist_ok=True)
         nuc_only = {k: v for k, v in inst.items() if k == "Nuclei"} if records is not None else inst
-        info = build_wsi_inst_info(nuc_only, maps, (H, W), float(args["--wsi_proc_mag"]), region_records=records)
+        bw, bh = reader.info.slide_dimensions
+        info = build_wsi_inst_info(nuc_only, maps, (H, W), float(args["--wsi_proc_mag"]), region_records=records,
+                                   base_mag=None if reader.info.mpp is None else float(reader.info.mpp[0]), base_hw=(bh, bw))
         # serialising ~1e6 per-instance dictionaries is host-only work: it overlaps the next slide's inference (written to a temporary
         # name and renamed, so a finished dat/<slide>.dat is always complete -- the resume-by-skip above relies on that)
         if writer is not None:

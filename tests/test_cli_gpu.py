@@ -241,3 +241,37 @@ def test_run_infer_wsi_cli_two_ranks_equals_one_rank(tmp_path):
                 ca = sorted(tuple(np.round(d["centroid"], 3)) for d in da.get(t, {}).values())
                 cb = sorted(tuple(np.round(d["centroid"], 3)) for d in db.get(t, {}).values())
                 assert ca == cb, t
+
+
+def test_run_infer_wsi_reads_pyramidal_tiff_at_proc_mag(tmp_path):
+    """A tiled pyramidal TIFF scanned at 0.25 um/px processed at --wsi_proc_mag=0.5 (infer/wsi.py:521-527) is read from its x2 level
+    through cerberus_amd.reader + SlabUploader and gives exactly what the same pixels give as a .npy array; the dat records the scan
+    resolution and baseline size the reader reports."""
+    import joblib
+
+    from cerberus_amd.reader import write_tiled_tiff
+
+    rs = np.random.RandomState(4)
+    base = rs.randint(0, 256, (1100, 1500, 3)).astype(np.uint8)
+    l1 = np.clip(np.rint(base.astype(np.float32).reshape(550, 2, 750, 2, 3).mean(axis=(1, 3))), 0, 255).astype(np.uint8)
+    a, b = tmp_path / "tif", tmp_path / "npy"
+    a.mkdir()
+    b.mkdir()
+    write_tiled_tiff(str(a / "s1.tif"), [base, l1], tile=256, mpp=0.25)
+    np.save(str(b / "s1.npy"), l1)
+    outs = []
+    for d, ext in ((a, ".tif"), (b, ".npy")):
+        out = tmp_path / ("out" + ext[1:])
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--synthetic", "--input_dir=%s" % d, "--wsi_file_ext=%s" % ext,
+                            "--output_dir=%s" % out, "--batch_size=6", "--patch_input_shape=256", "--patch_output_shape=256", "--wsi_proc_mag=0.5",
+                            "--save_label_maps"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(out)
+    za, zb = np.load(str(outs[0] / "s1.npz")), np.load(str(outs[1] / "s1.npz"))
+    assert set(za.files) == set(zb.files)
+    for k in za.files:
+        assert np.array_equal(za[k], zb[k]), k
+    da, db = joblib.load(str(outs[0] / "dat" / "s1.dat")), joblib.load(str(outs[1] / "dat" / "s1.dat"))
+    assert da["proc_dimensions"].tolist() == [550, 750] and da["base_dimensions"].tolist() == [1100, 1500]
+    assert abs(da["base_resolution"]["resolution"] - 0.25) < 1e-3 and da["proc_resolution"]["resolution"] == 0.5
+    assert db["base_dimensions"].tolist() == [550, 750]
