@@ -37,7 +37,10 @@ constexpr int PS = CB + 4;               // LDS stride of one tile's channel vec
 constexpr int V_FLOATS = 16 * NT * PS;   // 18432 floats = 72 KiB -> two workgroups per CU
 constexpr int LDS_BYTES = V_FLOATS * 4;
 constexpr int NQ = 16;                   // steps per chunk for one wave: 4 positions x 4 eight-channel groups
-constexpr int WD = 2;                    // weight prefetch distance in steps
+#ifndef WINO_WD
+#define WINO_WD 2
+#endif
+constexpr int WD = WINO_WD;              // weight prefetch distance in steps
 constexpr int NPRE = 4;                  // extra weight steps of the NEXT item requested before an item's output stores
 constexpr int CHUNK_W_BYTES = 16 * 4 * 2 * 1024;  // packed weights of one (cout block, chunk): 128 KiB
 constexpr int WAVE_W_BYTES = 4 * 4 * 2 * 1024;    // one wave's share of it
@@ -172,16 +175,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
     const unsigned wlane = (unsigned)lane * 16u;
     const int rowb = p.W * p.Cin * 4, pixb = p.Cin * 4;
     // output stage: thread = (column pp of the 16-pixel-wide item, cout quad cq) for all 8 rows -> a wave's store covers 1 KiB
-    const int cq = tid & 15, pp = tid >> 4;
-    const unsigned ooff = (unsigned)((pp * p.Cout + 4 * cq) * 4);
+    // (cq, pp, the store offset and the T-exchange positions are recomputed inside the output stage: five lane invariants less
+    // to keep in registers through the MFMA phase)
     // T exchange (floats): wave a writes into ITS OWN quarter of the V region (only wave a ever reads V[xi = (a, *)], so no
     // barrier is needed between its last MFMA and its T stores): block (jj, s, rq) at a*VW + (jj*8 + s*4+rq) * TB, lane (j, h)
     // at h*TH + j*4.  The 16-byte skews make both the per-wave writes (16 lanes = 16 tiles) and the remapped reads (16 lanes =
     // 16 cout quads) hit distinct banks.
     constexpr int TB = 264, TH = 132, VW = 4 * NT * PS;
     static_assert(16 * TB <= VW, "a wave's T blocks must fit in its quarter of V");
-    const int tw = a * VW + h * TH + j * 4;
-    const int tr = ((pp & 1) * 8 + (cq >> 1)) * TB + (cq & 1) * TH + (pp >> 1) * 4;  // + aa*VW + k*32
 
     f32x4 d[4][4];  // raw patch of the NEXT chunk while the matrix pipe works, transformed in place at the chunk boundary
     auto issue = [&](__amdgpu_buffer_rsrc_t r, int chunk_off, int k) { d[k >> 2][k & 3] = buf_load(r, ioff, chunk_off + (k >> 2) * rowb + (k & 3) * pixb); };
@@ -252,9 +253,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
         transform_cols(2);
     }
     __amdgpu_buffer_rsrc_t rw = make_rsrc(w_base(w));
-    // weight stream window: the operands of step q live in slot q & 3 (three slots are live at a time; four names so that the
+    // weight stream window: the operands of step q live in slot q & 7 (WD + 1 slots are live at a time; eight names so that the
     // slot of a step is the same in every chunk -- 16 steps per chunk -- and the unrolled body needs no register moves)
-    f32x4 wq[4][2];
+    static_assert(WD >= 1 && WD <= 7, "the slot ring has eight names");
+    f32x4 wq[8][2];
 #pragma unroll
     for (int dd = 0; dd < WD; ++dd)
 #pragma unroll
@@ -327,7 +329,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
             const __amdgpu_buffer_rsrc_t rw_over = last_ch ? rw_nx : rw;
             const int wover_off = last_ch ? 0 : (ch + 1) * CHUNK_W_BYTES;
 
+#ifdef WINO_BB1
+            f32x4 bb[1];  // B operand of the current step; the next one is read right behind the step's MFMAs (they hold their operands)
+#define WINO_BBI(q) 0
+#else
             f32x4 bb[2];  // B operand of step q in bb[q & 1]
+#define WINO_BBI(q) ((q) & 1)
+#endif
             bb[0] = *reinterpret_cast<const f32x4*>(lds + vr);
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
@@ -337,13 +345,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
                     if (FIRST && q < NPRE) {
                         // steps WD .. WD+NPRE-1 of an item's first chunk were requested before the previous item's stores (wpre)
                     } else if (q + WD < NQ) {
-                        wq[(q + WD) & 3][0] = buf_load(rw, wlane, wcur_off + ((q + WD) * 2 + 0) * 1024);
-                        wq[(q + WD) & 3][1] = buf_load(rw, wlane, wcur_off + ((q + WD) * 2 + 1) * 1024);
+                        wq[(q + WD) & 7][0] = buf_load(rw, wlane, wcur_off + ((q + WD) * 2 + 0) * 1024);
+                        wq[(q + WD) & 7][1] = buf_load(rw, wlane, wcur_off + ((q + WD) * 2 + 1) * 1024);
                     } else {
-                        wq[(q + WD) & 3][0] = buf_load(rw_over, wlane, wover_off + ((q + WD - NQ) * 2 + 0) * 1024);
-                        wq[(q + WD) & 3][1] = buf_load(rw_over, wlane, wover_off + ((q + WD - NQ) * 2 + 1) * 1024);
+                        wq[(q + WD) & 7][0] = buf_load(rw_over, wlane, wover_off + ((q + WD - NQ) * 2 + 0) * 1024);
+                        wq[(q + WD) & 7][1] = buf_load(rw_over, wlane, wover_off + ((q + WD - NQ) * 2 + 1) * 1024);
                     }
+#ifndef WINO_BB1
                     if (q + 1 < NQ) bb[(q + 1) & 1] = *reinterpret_cast<const f32x4*>(lds + vr + ((q + 1) >> 2) * NT * PS + ((q + 1) & 3) * 8);
+#endif
                     if (q < 8) {  // next chunk's patch: two loads per step, all in flight half a chunk before the transform
                         issue(r_stage, stage_off, 2 * q);
                         issue(r_stage, stage_off, 2 * q + 1);
@@ -358,8 +368,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     const bool pre = FIRST && q >= WD && q < WD + NPRE;  // compile-time after unrolling
-                    const f32x4 a0 = pre ? wpre[pre ? q - WD : 0][0] : wq[q & 3][0], a1 = pre ? wpre[pre ? q - WD : 0][1] : wq[q & 3][1];
-                    const f32x4 bq = bb[q & 1];
+                    const f32x4 a0 = pre ? wpre[pre ? q - WD : 0][0] : wq[q & 7][0], a1 = pre ? wpre[pre ? q - WD : 0][1] : wq[q & 7][1];
+                    const f32x4 bq = bb[WINO_BBI(q)];
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) {
                         if (FIRST && G == 0 && tt == 0 && b != 1) {
@@ -371,6 +381,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
                             acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[tt], bq[tt], acc[b][1], 0, 0, 0);
                         }
                     }
+#ifdef WINO_BB1
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (q + 1 < NQ) bb[0] = *reinterpret_cast<const f32x4*>(lds + vr + ((q + 1) >> 2) * NT * PS + ((q + 1) & 3) * 8);
+#endif
                 }
             }
             WPROF_ACC(1, t_m);
@@ -381,6 +395,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
         // ---- output transform ---------------------------------------------------------------------------------------------------
         const unsigned long long t_e = WPROF_T();
         {
+            int tid_o = tid;
+            asm volatile("" : "+v"(tid_o));  // keeps the compiler from hoisting these out of the item loop
+            const int cq = tid_o & 15, pp = tid_o >> 4;
+            const unsigned ooff = (unsigned)((pp * p.Cout + 4 * cq) * 4);
+            const int tw = a * VW + ((tid_o >> 5) & 1) * TH + (tid_o & 31) * 4;
+            const int tr = ((pp & 1) * 8 + (cq >> 1)) * TB + (cq & 1) * TH + (pp >> 1) * 4;  // + aa*VW + k*32
             // over b, in registers: T[0] = M0 + M1 + M2, T[1] = M1 - M2 - M3
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
