@@ -68,6 +68,7 @@ hipError_t cerb_launch_wgrad(const float* x, const float* dy, float* dw, int G, 
                              hipStream_t st);
 hipError_t cerb_launch_maxpool(const float* in, float* out, int N, int H, int W, int C, hipStream_t st);
 hipError_t cerb_launch_head(const HeadParams& p, hipStream_t st);
+hipError_t cerb_launch_head_group(const HeadParams* heads, int n_heads, hipStream_t st);
 struct PatchClassParams {
     const float* x4;
     const float* bn1_s;
@@ -187,6 +188,7 @@ struct cerb_net {
     // optional per-launch timing (HIP events on the caller's stream)
     bool profiling = false;
     int crop_roi = 1;   // cerb_net_set_crop_roi: decoders / heads only compute what the centre crop keeps (conv_algo 1)
+    int head_algo = 1;  // cerb_net_set_head_algo: 1 = all dense heads in one grouped launch (default), 0 = one launch per head
     int conv_algo = 1;  // cerb_net_set_conv_algo: 1 = Winograd F(2x2,3x3) for 3x3 stride-1 convs (default), 0 = direct implicit GEMM
     struct ProfRec { std::string name, kernel; double flops; hipEvent_t e0, e1; };
     std::vector<ProfRec> prof;
@@ -885,6 +887,9 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
             prev = dry ? nullptr : net->dout[u].p;
             prev_gs = (long long)N * hh * ww * oc[u];
         }
+        HeadParams hps[8];
+        int n_hp = 0;
+        double head_flops = 0.0;
         for (size_t k = 0; k < D; ++k) {
             const int di = net->dense_idx[k];
             const DecoderCfg& d = net->dec[di];
@@ -908,8 +913,19 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
             }
             hp.tile_off = io->tile_off; hp.tile_stride = tile_stride; hp.row_stride = row_stride;
             const double head_px = hp.roi ? (double)out_h * (((hp.crop_x0 + out_w + 15) / 16 - hp.crop_x0 / 16) * 16.0) : (double)H * W;
-            if (prof_begin(net, "head." + d.name, "head", 2.0 * N * head_px * (64.0 * 96 + 96.0 * d.out_ch), st)) return 1;
-            HIP_OK(cerb_launch_head(hp, st));
+            const double fl = 2.0 * N * head_px * (64.0 * 96 + 96.0 * d.out_ch);
+            if (net->head_algo == 0) {  // one launch per head (round-1 kernel, kept for A/B: cerb_net_set_head_algo)
+                if (prof_begin(net, "head." + d.name, "head", fl, st)) return 1;
+                HIP_OK(cerb_launch_head(hp, st));
+                if (prof_end(net, st)) return 1;
+            } else if (n_hp < 8) {
+                hps[n_hp++] = hp;
+                head_flops += fl;
+            }
+        }
+        if (n_hp > 0) {  // all dense heads of the batch in ONE grouped launch (models/utils/net_layers.py:31-38 x5)
+            if (prof_begin(net, "heads", "head_group", head_flops, st)) return 1;
+            HIP_OK(cerb_launch_head_group(hps, n_hp, st));
             if (prof_end(net, st)) return 1;
         }
     }
@@ -1550,6 +1566,13 @@ extern "C" int cerb_net_set_conv_algo(cerb_net* net, int algo) {
     if (!net) return fail("cerb_net_set_conv_algo: null handle");
     if (algo < 0 || algo > 2) return fail("cerb_net_set_conv_algo: algo must be 0 (direct), 1 (Winograd fp32) or 2 (Winograd, bf16x3 products)");
     net->conv_algo = algo;
+    return 0;
+}
+
+extern "C" int cerb_net_set_head_algo(cerb_net* net, int algo) {
+    if (!net) return fail("cerb_net_set_head_algo: null handle");
+    if (algo < 0 || algo > 1) return fail("cerb_net_set_head_algo: algo must be 0 (one launch per head) or 1 (grouped launch)");
+    net->head_algo = algo;
     return 0;
 }
 

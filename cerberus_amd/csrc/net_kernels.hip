@@ -438,6 +438,208 @@ hipError_t cerb_launch_head(const HeadParams& p_in, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Grouped output heads: ONE launch for all dense heads of a batch (blockIdx.y = head), same arithmetic as head_kernel, re-balanced
+// for latency: round 1 measured head_kernel at ~60 % of the matrix pipe with 242 VGPRs (two waves per SIMD) and the feature
+// prefetch only one 16-channel group (3072 MFMA cycles) ahead of an HBM read.  Here
+//   * W1 / W2 / biases of the workgroup's head live in LDS (31 KB, filled once per workgroup) instead of streaming through VGPRs,
+//   * a task is 32 pixels (two 16-pixel blocks): acc1 is 48 registers instead of 96, so THREE workgroups fit a CU, and the whole
+//     feature vector of the NEXT task (32 registers) is requested one task = 7680 MFMA cycles ahead,
+//   * every wave walks HEAD_G_TPW consecutive tasks.
+// Lane roles and the K permutations are those of head_kernel (lane = (px = l & 15, ks = l >> 4)).
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef HEAD_G_TPW
+#define HEAD_G_TPW 8
+#endif
+struct HeadGroupParams {
+    HeadParams h[8];
+    int n_heads;
+};
+__global__ __launch_bounds__(256, 3) void head_group_kernel(HeadGroupParams gp) {
+    __shared__ __attribute__((aligned(16))) float s_w1[6 * 4 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float s_w2[6 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float s_b1[96];
+    __shared__ __attribute__((aligned(16))) float s_b2[32];
+    const HeadParams& p = gp.h[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, px = lane & 15, ks = lane >> 4;
+    {
+        const f32x4h* w1g = reinterpret_cast<const f32x4h*>(p.w1p);
+        const f32x4h* w2g = reinterpret_cast<const f32x4h*>(p.w2p);
+        for (int i = tid; i < 6 * 4 * 64; i += 256) reinterpret_cast<f32x4h*>(s_w1)[i] = w1g[i];
+        for (int i = tid; i < 6 * 64; i += 256) reinterpret_cast<f32x4h*>(s_w2)[i] = w2g[i];
+        if (tid < 96) s_b1[tid] = p.b1[tid];
+        if (tid < 32) s_b2[tid] = p.b2[tid];
+    }
+    __syncthreads();
+    const f32x4h* w1v = reinterpret_cast<const f32x4h*>(s_w1) + lane;
+    const f32x4h* w2v = reinterpret_cast<const f32x4h*>(s_w2) + lane;
+    const unsigned nblk = (unsigned)p.N * (unsigned)p.rows * (unsigned)p.nxb;  // 16-pixel blocks (launcher: < 2^31)
+    const unsigned ntask = (nblk + 1u) >> 1;
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned task = ((unsigned)blockIdx.x * 4u + wave) * (unsigned)HEAD_G_TPW;
+    if (task >= ntask) return;
+    const unsigned task_end = min(task + (unsigned)HEAD_G_TPW, ntask);
+    struct BPos {
+        int n, row, xb;
+    };
+    auto decode = [&](unsigned b) {  // wave-uniform
+        BPos r;
+        const unsigned bc = min(b, nblk);  // blocks past the end decode to n == N: clamped for the loads, dropped at the store
+        const unsigned q = bc / (unsigned)p.nxb;
+        r.xb = (int)(bc - q * (unsigned)p.nxb);
+        r.n = (int)(q / (unsigned)p.rows);
+        r.row = (int)(q - (unsigned)r.n * (unsigned)p.rows);
+        return r;
+    };
+    auto ptr_of = [&](const BPos& b) {
+        const int n = min(b.n, p.N - 1), x = min(p.xa0 + 16 * b.xb + px, p.W - 1);
+        return p.feat + (((long long)n * p.H + p.row0 + b.row) * p.W + x) * 64 + 4 * ks;
+    };
+    f32x4h xn[4][2];
+    auto request = [&](unsigned t) {
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const float* fp = ptr_of(decode(2u * t + (unsigned)pb));
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xn[g][pb] = *reinterpret_cast<const f32x4h*>(fp + 16 * g);
+        }
+    };
+    request(task);
+#pragma unroll 1
+    for (; task < task_end; ++task) {
+        f32x4h x[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) x[g][pb] = xn[g][pb];
+        if (task + 1 < task_end) request(task + 1);  // a whole task ahead of its use
+        f32x4h acc1[6][2];
+#pragma unroll
+        for (int blk = 0; blk < 6; ++blk) {
+            const f32x4h bb = *reinterpret_cast<const f32x4h*>(s_b1 + blk * 16 + ks * 4);
+            acc1[blk][0] = bb;
+            acc1[blk][1] = bb;
+        }
+        {
+            // W1 operands come from LDS one (g, blk) step ahead; the scheduling barriers keep hipcc from hoisting all 24 reads
+            // (96 registers) to the top of the task
+            f32x4h a_cur = w1v[0];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int blk = 0; blk < 6; ++blk) {
+                    const int nx = g * 6 + blk + 1;
+                    f32x4h a_nxt = a_cur;
+                    if (nx < 24) a_nxt = w1v[((nx % 6) * 4 + nx / 6) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int pb = 0; pb < 2; ++pb)
+                            acc1[blk][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t], x[g][pb][t], acc1[blk][pb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    a_cur = a_nxt;
+                }
+        }
+#pragma unroll
+        for (int blk = 0; blk < 6; ++blk)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc1[blk][pb][r] = fmaxf(acc1[blk][pb][r], 0.f);
+        f32x4h acc2[2];
+        {
+            const f32x4h b2 = *reinterpret_cast<const f32x4h*>(s_b2 + 4 * ks);
+            acc2[0] = b2;
+            acc2[1] = b2;
+        }
+#pragma unroll
+        for (int blk = 0; blk < 6; ++blk) {
+            const f32x4h a = w2v[blk * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) acc2[pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], acc1[blk][pb][r], acc2[pb], 0, 0, 0);
+        }
+        // lane groups ks = 0, 1 finish pixel blocks 0, 1: the pixel's 8 logits sit in lanes px (rows 0..3) and 16 + px (rows 4..7)
+        float lg[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a0 = __shfl(acc2[0][e], px), a1 = __shfl(acc2[0][e], 16 + px);
+            const float c0 = __shfl(acc2[1][e], px), c1 = __shfl(acc2[1][e], 16 + px);
+            lg[e] = (ks & 1) ? c0 : a0;
+            lg[4 + e] = (ks & 1) ? c1 : a1;
+        }
+        if (ks >= 2) continue;
+        const BPos bp = decode(2u * task + (unsigned)ks);
+        const int n = bp.n, y_ = bp.row + p.row0, x_ = p.xa0 + 16 * bp.xb + px;
+        if (2u * task + (unsigned)ks >= nblk || x_ >= p.W) continue;
+        if (p.logits) {
+            const long long P = ((long long)n * p.H + y_) * p.W + x_;
+            for (int e = 0; e < p.out_ch; ++e) p.logits[P * p.out_ch + e] = lg[e];
+        }
+        float mx = lg[0];
+#pragma unroll
+        for (int e = 1; e < 8; ++e)
+            if (e < p.out_ch) mx = fmaxf(mx, lg[e]);
+        float ex[8], sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ex[e] = (e < p.out_ch) ? expf(lg[e] - mx) : 0.f;
+            sum += ex[e];
+        }
+        const int cy = y_ - p.crop_y0, cx = x_ - p.crop_x0;
+        if (cy < 0 || cy >= p.out_h || cx < 0 || cx >= p.out_w) continue;
+        const long long dst = (p.tile_off ? p.tile_off[n] : (long long)n * p.tile_stride) + (long long)cy * p.row_stride + cx;
+        if (p.kind == 0) {
+            float2 o;
+            o.x = ex[1] / sum;
+            o.y = ex[2] / sum;
+            *reinterpret_cast<float2*>(p.out_inst + dst * 2) = o;
+        } else {
+            int best = 0;
+            float bv = ex[0] / sum;
+#pragma unroll
+            for (int e = 1; e < 8; ++e) {
+                const float pe = ex[e] / sum;
+                if (e < p.out_ch && pe > bv) {
+                    bv = pe;
+                    best = e;
+                }
+            }
+            if (p.out_type_i64) p.out_type_i64[dst] = best;
+            if (p.out_type_u8) p.out_type_u8[dst] = (unsigned char)best;
+        }
+    }
+}
+
+hipError_t cerb_launch_head_group(const HeadParams* heads, int n_heads, hipStream_t st) {
+    if (n_heads < 1 || n_heads > 8) return hipErrorInvalidValue;
+
+    HeadGroupParams gp = {};
+    gp.n_heads = n_heads;
+    unsigned max_blocks = 0;
+    for (int i = 0; i < n_heads; ++i) {
+        HeadParams p = heads[i];
+        if (p.W % 16) return hipErrorInvalidValue;
+        p.rows = p.H; p.row0 = 0; p.xa0 = 0; p.nxb = p.W / 16;
+        if (p.roi && !p.logits && p.out_h > 0 && p.out_w > 0) {  // only the 16-aligned cover of the crop window
+            p.rows = p.out_h; p.row0 = p.crop_y0;
+            p.xa0 = p.crop_x0 & ~15;
+            p.nxb = (p.crop_x0 + p.out_w - p.xa0 + 15) / 16;
+        }
+        const long long nblk = (long long)p.N * p.rows * p.nxb;
+        if (nblk >= (1ll << 31)) return hipErrorInvalidValue;
+        const long long ntask = (nblk + 1) / 2;
+        const long long blocks = (ntask + 4 * HEAD_G_TPW - 1) / (4 * HEAD_G_TPW);
+        if (blocks > max_blocks) max_blocks = (unsigned)blocks;
+        gp.h[i] = p;
+    }
+    hipLaunchKernelGGL(head_group_kernel, dim3(max_blocks, (unsigned)n_heads), dim3(256), 0, st, gp);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 struct PatchClassParams {
     const float* x4;      // [N][Hf][Wf][512] (pre-conv_map bottom features, net_desc.py:152)
     const float* bn1_s;   // [512] scale

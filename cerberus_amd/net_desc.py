@@ -339,6 +339,10 @@ class NetDesc(torch.nn.Module):
     def flops(self, n, h, w):
         return float(_lib.lib().cerb_net_flops(self._ensure_handle(), n, h, w))
 
+    def set_head_algo(self, algo):
+        """1 = all dense heads in one grouped launch (default), 0 = one launch per head (include/cerberus_hip.h)."""
+        _lib.check(_lib.lib().cerb_net_set_head_algo(self._ensure_handle(), int(algo)))
+
     def set_conv_algo(self, algo):
         """0 = direct implicit GEMM, 1 = Winograd F(2x2,3x3) (default), 2 = experimental Winograd with bf16x3-split products
         (see include/cerberus_hip.h) for the 3x3 stride-1 convolutions."""

@@ -80,6 +80,9 @@ int cerb_net_forward(cerb_net* net, const cerb_forward_io* io, void* hip_stream)
  * (conv_wino3.hip; fp32 accumulate, errors indistinguishable from algorithm 1 in the tests).  It leaves the fp32 matrix
  * instruction, so it is never the default and never what bench.py's headline measures (BASELINE.json configs[1]: fp32). */
 int cerb_net_set_conv_algo(cerb_net* net, int algo);
+/* Output heads (models/utils/net_layers.py:31-38): 1 (default) = every dense head of the batch in ONE grouped launch with the head's
+ * weights resident in LDS (head_group_kernel), 0 = one launch per head (round-1 head_kernel); identical arithmetic, for A/B. */
+int cerb_net_set_head_algo(cerb_net* net, int algo);
 /* Centre-crop regions of interest (default 1 = on).  infer_step keeps only the centre out_h x out_w window of every head
  * (models/run_desc.py:452-491 cropping_center; the reference's default geometry 448 -> 144 keeps 10 % of the pixels it computes).
  * With the switch on and conv_algo 1, every decoder level computes only the part of its maps that the kept window depends on
