@@ -450,11 +450,14 @@ hipError_t cerb_launch_head(const HeadParams& p_in, hipStream_t st) {
 #ifndef HEAD_G_TPW
 #define HEAD_G_TPW 8
 #endif
+#ifndef HEAD_G_OCC
+#define HEAD_G_OCC 3
+#endif
 struct HeadGroupParams {
     HeadParams h[8];
     int n_heads;
 };
-__global__ __launch_bounds__(256, 3) void head_group_kernel(HeadGroupParams gp) {
+__global__ __launch_bounds__(256, HEAD_G_OCC) void head_group_kernel(HeadGroupParams gp) {
     __shared__ __attribute__((aligned(16))) float s_w1[6 * 4 * 64 * 4];
     __shared__ __attribute__((aligned(16))) float s_w2[6 * 64 * 4];
     __shared__ __attribute__((aligned(16))) float s_b1[96];
