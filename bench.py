@@ -300,6 +300,10 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
     from cerberus_amd.wsi import WSIRunner, band_partition, synth_slide
 
     free = torch.cuda.mem_get_info(dev)[0]
+    if dist is not None:  # one decision for all ranks: the smallest free HBM among them
+        t = torch.tensor([float(free)], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        free = float(t.item())
     side = args.slide
     if side <= 0:  # 40000^2 needs ~130 GB on one GPU (slide, 36 B/px canvases, structured maps, labels, banded workspace)
         side = 40000 if free > (140e9 if world == 1 else 270e9 / world + 8e9) else 20000

@@ -170,7 +170,17 @@ def run_case(prefix, nuclei_type_weight, store, weight_maps=False):
 
 def main():
     store = {}
+    # fp32 noise yardstick for the element-wise gradient comparison: the reference's OWN step through torch's two CPU convolution
+    # back ends (oneDNN / native) -- same arithmetic, different summation order
+    torch.backends.mkldnn.enabled = False
+    alt = {}
+    run_case("paramset/", None, alt)
+    torch.backends.mkldnn.enabled = True
     run_case("paramset/", None, store)
+    for k in [str(x) for x in store["step/grad_full_names"]]:
+        a, b = store["step/grad_full/" + k].astype(np.float64), alt["step/grad_full/" + k].astype(np.float64)
+        store["step/grad_full_noise/" + k] = np.float64(np.abs(a - b).max() / max(np.abs(a).max(), 1e-30))
+    return_after = store
     run_case("typew1/", 1.0, store)
     run_case("wmap/", None, store, weight_maps=True)
     path = os.path.join(ROOT, "tests", "golden", "train_loss.npz")
