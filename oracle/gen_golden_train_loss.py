@@ -146,7 +146,9 @@ def run_case(prefix, nuclei_type_weight, store, weight_maps=False):
                 "backbone.layer2.0.downsample.1.weight", "backbone.layer3.0.conv1.weight", "backbone.layer4.0.downsample.0.weight", "conv_map.weight",
                 "decoder_head.Nuclei.0.block.0.conv.weight", "decoder_head.Nuclei.3.block.0.conv.weight", "decoder_head.Nuclei.3.block.1.conv.weight",
                 "decoder_head.Nuclei.3.block.1.conv.bias", "decoder_head.Nuclei.3.block.1.bn.weight", "decoder_head.Nuclei.3.block.1.bn.bias",
-                "decoder_head.Lumen.2.block.0.conv.weight", "decoder_head.Gland#TYPE.3.block.1.conv.weight", "output_head.Nuclei.INST.x.0.block.0.conv.weight",
+                "decoder_head.Lumen.2.block.0.conv.weight", "decoder_head.Gland#TYPE.3.block.1.conv.weight", "decoder_head.Gland#TYPE.3.block.1.bn.weight",
+                "decoder_head.Gland#TYPE.3.block.1.bn.bias", "decoder_head.Gland#TYPE.3.block.0.conv.weight", "decoder_head.Nuclei#TYPE.3.block.1.conv.weight",
+                "decoder_head.Gland.3.block.1.conv.weight", "output_head.Gland#TYPE.TYPE.x.0.block.0.conv.weight", "output_head.Nuclei.INST.x.0.block.0.conv.weight",
                 "output_head.Nuclei.INST.x.0.block.0.bn.weight", "output_head.Nuclei.INST.x.1.conv.weight", "output_head.Nuclei.INST.x.1.conv.bias",
                 "output_head.Gland#TYPE.TYPE.x.1.conv.weight", "decoder_head.Patch-Class.conv1.weight", "decoder_head.Patch-Class.conv2.weight",
                 "decoder_head.Patch-Class.bn1.weight"]

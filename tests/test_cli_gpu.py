@@ -142,7 +142,7 @@ def test_bench_contract_single_and_two_ranks(tmp_path):
     assert abs(one["value"] - 3072 * 3072 / (one["ms_per_step"] * 1e-3 * 3) / 1e6) / one["value"] < 0.01
     assert one["config"]["inference_Mpx_s"] > one["value"] and one["config"]["whole_job_s"] >= one["config"]["inference_s"]
     kern = {r["kernel"]: r for r in one["kernels"]}
-    assert "head" in kern and abs(sum(r["share"] for r in one["kernels"]) - 1.0) < 0.01
+    assert "head_group" in kern and abs(sum(r["share"] for r in one["kernels"]) - 1.0) < 0.01
     for t in ("Nuclei", "Gland", "Lumen"):
         assert one["postproc"][t]["n_inst"] > 10 and one["postproc"][t]["n_truncated"] == 0, one["postproc"]
     two = _bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
