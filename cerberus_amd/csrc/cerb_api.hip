@@ -21,6 +21,7 @@ hipError_t cerb_launch_conv(const ConvParams& p, int ks, int stride, int mode, h
 hipError_t cerb_launch_wino(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino3(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino16(ConvParams p, hipStream_t st);
+hipError_t cerb_launch_wino16d(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_upsample2_add(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C,
                                      long long prev_gs, const int* roi, hipStream_t st);
 extern "C" int cerb_conv_chunk(int ks, int stride);
@@ -141,6 +142,7 @@ struct PackedConv {
     float* wino_dgrad = nullptr;  // train packing only: the same for the DATA GRADIENT -- the conv with rotated, transposed weights
     void* wino3 = nullptr;  // device, same weights split into three bf16 planes (conv_wino3.hip, conv_algo 2), packed lazily
     float* wino16 = nullptr;  // device, the transformed weights in conv_wino16.hip's per-wave layout (conv_algo 3), packed lazily
+    float* wino16d = nullptr; // device, conv_wino16d.hip's layout (conv_algo 4: 16-channel chunks), packed lazily
     std::vector<float> host_u;  // fp32 transformed weights kept on the host until conv_algo 2 is first used
     float* b = nullptr;     // device
 };
@@ -380,6 +382,25 @@ static void pack_wino16(const float* U, int cout, int cin, std::vector<float>* o
                             const int co = cb * 64 + 16 * a + (lane & 15);
                             const int ci = ch * 32 + 16 * (q & 1) + 4 * (lane >> 4) + t;
                             o[idx++] = U[((size_t)co * cin + ci) * 16 + (q >> 1)];
+                        }
+}
+
+// conv_wino16d.hip layout: [cb][16-channel chunk][wave a][position xi][lane][t]  ->  U[xi] of W[cb*64 + 16 a + (lane & 15)][chunk*16 + 4 (lane >> 4) + t]
+static void pack_wino16d(const float* U, int cout, int cin, std::vector<float>* out) {
+    const int nchunk = cin / 16, ncb = cout / 64;
+    const size_t base = out->size();
+    out->resize(base + (size_t)cout * cin * 16);
+    float* o = out->data() + base;
+    size_t idx = 0;
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int a = 0; a < 4; ++a)
+                for (int xi = 0; xi < 16; ++xi)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int t = 0; t < 4; ++t) {
+                            const int co = cb * 64 + 16 * a + (lane & 15);
+                            const int ci = ch * 16 + 4 * (lane >> 4) + t;
+                            o[idx++] = U[((size_t)co * cin + ci) * 16 + xi];
                         }
 }
 
@@ -744,19 +765,22 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
         if (prof_end(net, st)) return 1;
         return 0;
     }
-    if (net->conv_algo == 3 && c.wino && mode == 0 && !it->second.host_u.empty()) {
+    if ((net->conv_algo == 3 || net->conv_algo == 4) && c.wino && mode == 0 && !it->second.host_u.empty()) {
         PackedConv& cm = it->second;
-        if (!cm.wino16) {  // first use: re-lay the transformed weights out per wave (16 output channels x all 16 positions) and upload
+        const bool dbl = net->conv_algo == 4;
+        float*& slot = dbl ? cm.wino16d : cm.wino16;
+        if (!slot) {  // first use: re-lay the transformed weights out per wave (16 output channels x all 16 positions) and upload
             std::vector<float> w16;
-            for (int g = 0; g < cm.groups; ++g) pack_wino16(cm.host_u.data() + (size_t)g * cm.cout * cm.cin * 16, cm.cout, cm.cin, &w16);
+            for (int g = 0; g < cm.groups; ++g)
+                (dbl ? pack_wino16d : pack_wino16)(cm.host_u.data() + (size_t)g * cm.cout * cm.cin * 16, cm.cout, cm.cin, &w16);
             void* d = nullptr;
             HIP_OK(hipMalloc(&d, w16.size() * 4));
             net->dev_allocs.push_back(d);
             net->dev_alloc_bytes.push_back(w16.size() * 4);
             HIP_OK(hipMemcpy(d, w16.data(), w16.size() * 4, hipMemcpyHostToDevice));
-            cm.wino16 = (float*)d;
+            slot = (float*)d;
         }
-        p.wpack = cm.wino16;
+        p.wpack = slot;
         p.w_gs = (long long)c.cout * c.cin * 16;
         double fl_done = fl;
         if (roi && roi[1] > roi[0] && roi[3] > roi[2]) {
@@ -764,8 +788,8 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
             const double ty = (roi[1] + 7) / 8 - roi[0] / 8, tx = (roi[3] + 15) / 16 - roi[2] / 16;
             fl_done = fl * (ty * 8.0 * tx * 16.0) / ((double)p.Ho * p.Wo);
         }
-        if (prof_begin(net, name, resid ? "conv_wino16<f2x2,8x16,res>" : "conv_wino16<f2x2,8x16>", fl_done, st)) return 1;
-        HIP_OK(cerb_launch_wino16(p, st));
+        if (prof_begin(net, name, std::string(dbl ? "conv_wino16d" : "conv_wino16") + (resid ? "<f2x2,8x16,res>" : "<f2x2,8x16>"), fl_done, st)) return 1;
+        HIP_OK(dbl ? cerb_launch_wino16d(p, st) : cerb_launch_wino16(p, st));
         if (prof_end(net, st)) return 1;
         return 0;
     }
@@ -897,7 +921,7 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
                 if (io->logits[k]) return true;
             return false;
         }();
-        const bool use_roi = !dry && net->crop_roi && (net->conv_algo == 1 || net->conv_algo == 3) && !any_logits && (out_h < H || out_w < W);
+        const bool use_roi = !dry && net->crop_roi && (net->conv_algo == 1 || net->conv_algo >= 3) && !any_logits && (out_h < H || out_w < W);
         if (use_roi) {
             int y0 = (int)((H - out_h) * 0.5), x0 = (int)((W - out_w) * 0.5), y1 = y0 + out_h, x1 = x0 + out_w;
             for (int u = 3; u >= 0; --u) {
@@ -1610,8 +1634,8 @@ extern "C" int cerb_net_set_crop_roi(cerb_net* net, int enable) {
 }
 extern "C" int cerb_net_set_conv_algo(cerb_net* net, int algo) {
     if (!net) return fail("cerb_net_set_conv_algo: null handle");
-    if (algo < 0 || algo > 3)
-        return fail("cerb_net_set_conv_algo: algo must be 0 (direct), 1 (Winograd fp32), 2 (Winograd, bf16x3 products) or 3 (Winograd fp32, 16-channel waves)");
+    if (algo < 0 || algo > 4)
+        return fail("cerb_net_set_conv_algo: algo must be 0 (direct), 1 (Winograd fp32), 2 (Winograd, bf16x3 products), 3 (Winograd fp32, 16-channel waves) or 4 (3 with double-buffered 16-channel chunks)");
     net->conv_algo = algo;
     return 0;
 }

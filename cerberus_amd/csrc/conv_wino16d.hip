@@ -1,25 +1,14 @@
-// conv_wino16.hip -- 3x3 stride-1 convolution (+ folded BN bias, residual, ReLU) as Winograd F(2x2, 3x3) on the gfx950 fp32
-// matrix cores, second work decomposition (cerb_net_set_conv_algo(3); conv_wino.hip is algorithm 1).  Same layers, same math:
-//   reference models/utils/conv_layers.py:24-60 (_ConvLayer: Conv2d 3x3 pad 1 -> BatchNorm2d -> ReLU, eval mode) and
-//   reference models/backbone/resnet.py:81-97 (BasicBlock conv3x3 + bn (+ identity) + relu)
-//
-// Why a second decomposition.  In conv_wino.hip wave a owns row a of the 4x4 transformed patch for all 64 output channels, so the
-// output transform Y = A^T M A needs the four waves to exchange their partial sums through LDS behind a barrier -- round 1's cycle
-// counters put 20 % of a wave's time in that output stage.  Here wave a owns ALL 16 positions for 16 of the item's 64 output
-// channels, on v_mfma_f32_16x16x4_f32 (same FLOP rate as the 32x32x2 form):
-//   * item = 8 x 16 output pixels (32 Winograd tiles = two 16-column MFMA blocks) x 64 output channels, as in conv_wino.hip;
-//   * accumulators: 16 positions x 2 tile blocks x 4 registers = 128 VGPRs -- lane (m = l & 15, ks = l >> 4) holds, for every
-//     position, output channels 16 a + 4 ks .. + 3 of tile 16 tb + m: the whole 4x4 of M for its (tile, channel quad), so
-//     Y = A^T M A is 24 float4 additions per tile block IN REGISTERS: no LDS exchange, no exchange barrier, and the waves of a
-//     workgroup only meet at the two chunk-boundary barriers;
-//   * a step = (position, 16-channel group): one 16-byte weight load (A operand of 4 k-steps: k-slot ks at sub-step t <-> channel
-//     16 G + 4 ks + t), two ds_read_b128 of V (B operands of the two tile blocks, same permutation), 8 MFMAs = 256 cycles; 32 steps
-//     per 32-channel chunk.  Every wave reads the whole V tile (4x the LDS read traffic of conv_wino.hip, ~25 % of the LDS peak);
-//   * the weight stream is 4 registers per step instead of 8, so the same register budget holds a prefetch distance of W16_WD = 6
-//     steps (1536 cycles with the pipe to itself; conv_wino.hip: 1024);
-//   * input transform, V layout [xi][tile][36], persistent XCD-aware item ranges, edge masking, the bias through position (1,1),
-//     the requests for the next item's first steps before this item's stores (in-order vmcnt), the s_nop behind SGPR-soffset
-//     stores: all as in conv_wino.hip.
+// conv_wino16d.hip -- 3x3 stride-1 convolution (+ folded BN bias, residual, ReLU) as Winograd F(2x2, 3x3) on the gfx950 fp32
+// matrix cores, third work decomposition (cerb_net_set_conv_algo(4)): conv_wino16.hip's wave ownership (a wave owns ALL 16
+// positions of 16 output channels on v_mfma_f32_16x16x4_f32, output transform in registers, no exchange through LDS) with
+//   * 16-channel chunks and a DOUBLE-BUFFERED V tile (2 x 40 KiB = the 80 KiB a workgroup may use at two per CU): a thread writes its
+//     transformed patch of chunk c+1 into the other buffer at the end of chunk c's MFMA phase, so a chunk boundary is ONE barrier
+//     instead of barrier - 16 LDS writes - barrier;
+//   * thread = (tile, channel PAIR): the raw patch is 16 float2 = 32 registers instead of 64, which pays for a weight prefetch
+//     distance of 7 steps (1792 cycles with the pipe to itself) without spills -- the in-order vmcnt queue no longer makes a weight
+//     wait for an HBM patch load issued just before it;
+//   * a step = one position (16 channels): one 16-byte weight load, two ds_read_b128, 8 MFMAs; 16 steps per chunk.
+// Reference layers: models/utils/conv_layers.py:24-60 (_ConvLayer) and models/backbone/resnet.py:81-97 (BasicBlock).
 #include <type_traits>
 
 #include "cerb_common.h"
@@ -28,13 +17,13 @@ namespace {
 constexpr int WTY = 4, WTX = 8;
 constexpr int NT = WTY * WTX;                // 32 tiles per item
 constexpr int OTH = 2 * WTY, OTW = 2 * WTX;  // 8 x 16 output pixels
-constexpr int CB = 32;                       // input channels per LDS pass
+constexpr int CB = 16;                       // input channels per LDS pass
 constexpr int PS = CB + 4;                   // LDS stride of one tile's channel vector (floats)
-constexpr int V_FLOATS = 16 * NT * PS;       // 72 KiB -> two workgroups per CU
-constexpr int LDS_BYTES = V_FLOATS * 4;
-constexpr int NS = 32;                       // steps per chunk: 16 positions x 2 sixteen-channel groups
+constexpr int V_FLOATS = 16 * NT * PS;       // one V buffer: 40 KiB
+constexpr int LDS_BYTES = 2 * V_FLOATS * 4;  // double-buffered: 80 KiB -> two workgroups per CU use the whole LDS
+constexpr int NS = 16;                       // steps per chunk: the 16 positions
 #ifndef W16_WD
-#define W16_WD 6
+#define W16_WD 7
 #endif
 constexpr int WD = W16_WD;                   // weight prefetch distance in steps (ring of 8 names)
 #ifndef W16_NPRE
@@ -45,8 +34,8 @@ constexpr int NPRE = W16_NPRE;               // steps of the NEXT item requested
 #define W16_PL 1
 #endif
 constexpr int PL = W16_PL;                   // patch loads issued per step (over the first 16 / PL steps of a chunk)
-constexpr int CHUNK_W_BYTES = 16 * 2 * 4 * 1024;  // packed weights of one (cout block, chunk): 128 KiB
-constexpr int WAVE_W_BYTES = 16 * 2 * 1024;       // one wave's share: 32 steps x 1 KiB
+constexpr int CHUNK_W_BYTES = 16 * 4 * 1024;  // packed weights of one (cout block, 16-channel chunk): 64 KiB
+constexpr int WAVE_W_BYTES = 16 * 1024;       // one wave's share: 16 steps x 1 KiB
 static_assert(WD >= 1 && WD <= 7, "the slot ring has eight names");
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
@@ -62,13 +51,19 @@ __device__ __forceinline__ void buf_store(f32x4 v, __amdgpu_buffer_rsrc_t r, uns
     __builtin_amdgcn_sched_barrier(0);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, soff, 0));
+}
+
 struct Item {
     int g, cb, n, oy0, ox0, tx, ty;
 };
 }  // namespace
 
 template <bool HAS_RES>
-__global__ __launch_bounds__(256, 2) void conv_wino16_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, 2) void conv_wino16d_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -130,18 +125,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino16_kernel(ConvParams p) {
     };
 
     // ---- lane invariants ---------------------------------------------------------------------------------------------------
-    const int t = tid >> 3, c = tid & 7, tty = t >> 3, ttx = t & 7;  // input transform: thread = (tile t, channel quad c)
-    const unsigned ioff = (unsigned)((((2 * tty) * p.W + 2 * ttx) * p.Cin + 4 * c) * 4);
-    const int vw = t * PS + 4 * c;    // V write position (floats); position xi adds xi*NT*PS
-    const int vr = m * PS + 4 * ks;   // V read position for xi = 0, tb = 0, G = 0; (xi, tb, G) adds xi*NT*PS + tb*16*PS + 16 G
+    const int t = tid >> 3, c = tid & 7, tty = t >> 3, ttx = t & 7;  // input transform: thread = (tile t, channel pair c)
+    const unsigned ioff = (unsigned)((((2 * tty) * p.W + 2 * ttx) * p.Cin + 2 * c) * 4);
+    const int vw = t * PS + 2 * c;    // V write position (floats); position xi adds xi*NT*PS
+    const int vr = m * PS + 4 * ks;   // V read position for xi = 0, tb = 0; (xi, tb) adds xi*NT*PS + tb*16*PS
     const unsigned wlane = (unsigned)lane * 16u;
     const int rowb = p.W * p.Cin * 4, pixb = p.Cin * 4;
 
-    f32x4 d[4][4];  // raw patch of the NEXT chunk, transformed in place in the shadow of the matrix pipe
-    auto issue = [&](__amdgpu_buffer_rsrc_t r, int chunk_off, int k) { d[k >> 2][k & 3] = buf_load(r, ioff, chunk_off + (k >> 2) * rowb + (k & 3) * pixb); };
+    f32x2 d[4][4];  // raw patch of the NEXT chunk (two channels), transformed in place in the shadow of the matrix pipe
+    auto issue = [&](__amdgpu_buffer_rsrc_t r, int chunk_off, int k) { d[k >> 2][k & 3] = buf_load2(r, ioff, chunk_off + (k >> 2) * rowb + (k & 3) * pixb); };
     const bool lane_top = (tty == 0), lane_bot = (tty == WTY - 1), lane_left = (ttx == 0), lane_right = (ttx == WTX - 1);
     auto mask_edges = [&](int bits) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x2 z = {0.f, 0.f};
         if (bits & 3) {
             const bool zt = (bits & 1) && lane_top, zb = (bits & 2) && lane_bot;
 #pragma unroll
@@ -160,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino16_kernel(ConvParams p) {
         }
     };
     auto mask_border = [&](const Item& w) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x2 z = {0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -170,10 +165,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino16_kernel(ConvParams p) {
                 d[r][q] = ok ? d[r][q] : z;
             }
     };
-    auto bt4 = [&](f32x4& x0, f32x4& x1, f32x4& x2, f32x4& x3) {  // (x0, x1, x2, x3) -> (x0 - x2, x1 + x2, x2 - x1, x1 - x3)
+    auto bt4 = [&](f32x2& x0, f32x2& x1, f32x2& x2, f32x2& x3) {  // (x0, x1, x2, x3) -> (x0 - x2, x1 + x2, x2 - x1, x1 - x3)
         x0 = x0 - x2;
         x3 = x1 - x3;
-        const f32x4 o1 = x1;
+        const f32x2 o1 = x1;
         x1 = x1 + x2;
         x2 = x2 - o1;
     };
@@ -185,9 +180,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino16_kernel(ConvParams p) {
 #pragma unroll
         for (int q = q0; q < q0 + 2; ++q) bt4(d[0][q], d[1][q], d[2][q], d[3][q]);
     };
-    auto write_v = [&]() {
+    auto write_v = [&](int buf) {
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) *reinterpret_cast<f32x4*>(lds + xi * NT * PS + vw) = d[xi >> 2][xi & 3];
+        for (int xi = 0; xi < 16; ++xi) *reinterpret_cast<f32x2*>(lds + buf * V_FLOATS + xi * NT * PS + vw) = d[xi >> 2][xi & 3];
     };
 
     // ---- prologue ------------------------------------------------------------------------------------------------------------
@@ -197,13 +192,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino16_kernel(ConvParams p) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) issue(r0, 0, k);
     }
-    if (!hangs_over(w)) {
-        mask_edges(edge_bits(w));
-        transform_rows(0);
-        transform_rows(2);
-        transform_cols(0);
-        transform_cols(2);
-    }
+    if (hangs_over(w)) mask_border(w);
+    else mask_edges(edge_bits(w));
+    transform_rows(0);
+    transform_rows(2);
+    transform_cols(0);
+    transform_cols(2);
+    write_v(0);
+    int vbuf = 0;  // the buffer the CURRENT chunk reads; the next chunk's patch goes to vbuf ^ 1
+    __syncthreads();
     __amdgpu_buffer_rsrc_t rw = make_rsrc(w_base(w));
     f32x4 wq[8];  // weight ring: the operand of step q lives in slot q & 7
 #pragma unroll
@@ -232,17 +229,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino16_kernel(ConvParams p) {
 
         auto chunk = [&](auto first_tag, int ch) {
             constexpr bool FIRST = decltype(first_tag)::value;
-            if (mask_cur) {  // item hanging over the image: per-pixel mask of the raw patch, then transform
-                mask_border(w);
-                transform_rows(0);
-                transform_rows(2);
-                transform_cols(0);
-                transform_cols(2);
-            }
-            __syncthreads();  // every wave finished reading the previous chunk's V
-            write_v();
-            __syncthreads();
-
             const bool last_ch = (ch == nchunk - 1);
             const Item wp_ = last_ch ? wnx : w;
             const bool mask_nx = last_ch ? mask_next : mask_cur;
@@ -252,13 +238,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino16_kernel(ConvParams p) {
             const int wcur_off = ch * CHUNK_W_BYTES;
             const __amdgpu_buffer_rsrc_t rw_over = last_ch ? rw_nx : rw;
             const int wover_off = last_ch ? 0 : (ch + 1) * CHUNK_W_BYTES;
+            const float* vsrc = lds + vbuf * V_FLOATS + vr;
 
             f32x4 bb[2][2];  // B operands (tile blocks 0, 1) of step q in bb[q & 1]
-            bb[0][0] = *reinterpret_cast<const f32x4*>(lds + vr);
-            bb[0][1] = *reinterpret_cast<const f32x4*>(lds + vr + 16 * PS);
+            bb[0][0] = *reinterpret_cast<const f32x4*>(vsrc);
+            bb[0][1] = *reinterpret_cast<const f32x4*>(vsrc + 16 * PS);
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
-                const int xi = q >> 1;
+                const int xi = q;
                 if (FIRST && q < NPRE) {
                     // steps WD .. WD+NPRE-1 of an item's first chunk were requested before the previous item's stores (wpre)
                 } else if (q + WD < NS) {
@@ -267,26 +254,28 @@ __global__ __launch_bounds__(256, 2) void conv_wino16_kernel(ConvParams p) {
                     wq[(q + WD) & 7] = buf_load(rw_over, wlane, wover_off + (q + WD - NS) * 1024);
                 }
                 if (q + 1 < NS) {
-                    const int vo = vr + ((q + 1) >> 1) * NT * PS + ((q + 1) & 1) * 16;
-                    bb[(q + 1) & 1][0] = *reinterpret_cast<const f32x4*>(lds + vo);
-                    bb[(q + 1) & 1][1] = *reinterpret_cast<const f32x4*>(lds + vo + 16 * PS);
+                    bb[(q + 1) & 1][0] = *reinterpret_cast<const f32x4*>(vsrc + (q + 1) * NT * PS);
+                    bb[(q + 1) & 1][1] = *reinterpret_cast<const f32x4*>(vsrc + (q + 1) * NT * PS + 16 * PS);
                 }
                 if (q * PL < 16) {  // next chunk's patch: PL loads per step from the start of the chunk
 #pragma unroll
                     for (int u = 0; u < PL; ++u) issue(r_stage, stage_off, q * PL + u);
                 }
-                if (!mask_nx) {
-                    if (q == 22 && edge_nx) mask_edges(edge_nx);
-                    if (q == 24 || q == 26) transform_rows(q - 24);
-                    if (q == 28 || q == 30) transform_cols(q - 28);
+                // the next chunk's patch landed: mask, B^T d B and the V writes into the OTHER buffer run in the shadow of the pipe
+                if (q == 10) {
+                    if (mask_nx) mask_border(wp_);
+                    else if (edge_nx) mask_edges(edge_nx);
                 }
+                if (q == 11 || q == 12) transform_rows((q - 11) * 2);
+                if (q == 13 || q == 14) transform_cols((q - 13) * 2);
+                if (q == 15) write_v(vbuf ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
                 const bool pre = FIRST && q >= WD && q < WD + NPRE;  // compile-time after unrolling
                 const f32x4 av = pre ? wpre[pre ? q - WD : 0] : wq[q & 7];
                 const f32x4 b0 = bb[q & 1][0], b1 = bb[q & 1][1];
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
-                    if (FIRST && (q & 1) == 0 && tt == 0 && xi != 5) {
+                    if (FIRST && tt == 0 && xi != 5) {
                         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                         acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt], b0[tt], z, 0, 0, 0);
                         acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt], b1[tt], z, 0, 0, 0);
@@ -296,6 +285,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino16_kernel(ConvParams p) {
                     }
                 }
             }
+            __syncthreads();  // everybody has read this chunk's V and written the next one's
+            vbuf ^= 1;
         };
         chunk(std::true_type{}, 0);
         for (int ch = 1; ch < nchunk; ++ch) chunk(std::false_type{}, ch);
@@ -375,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino16_kernel(ConvParams p) {
 }
 
 template <bool HAS_RES>
-static hipError_t launch_wino16(ConvParams p, hipStream_t st) {
+static hipError_t launch_wino16d(ConvParams p, hipStream_t st) {
     p.tiles_x = (p.Wo + OTW - 1) / OTW;
     p.tiles_y = (p.Ho + OTH - 1) / OTH;
     p.ty_off = p.tx_off = 0;
@@ -386,7 +377,7 @@ static hipError_t launch_wino16(ConvParams p, hipStream_t st) {
         p.tiles_x = (p.roi_x1 + OTW - 1) / OTW - p.tx_off;
     }
     const long long items = (long long)p.groups * p.N * p.tiles_x * p.tiles_y * (p.Cout / 64);
-    auto kern = conv_wino16_kernel<HAS_RES>;
+    auto kern = conv_wino16d_kernel<HAS_RES>;
     static bool attr_done[64] = {};
     if (cerb_attr_needed(attr_done)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -398,7 +389,7 @@ static hipError_t launch_wino16(ConvParams p, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t cerb_launch_wino16(ConvParams p, hipStream_t st) {
+hipError_t cerb_launch_wino16d(ConvParams p, hipStream_t st) {
     if (p.Cin % CB || p.Cout % 64) return hipErrorInvalidValue;
-    return p.resid ? launch_wino16<true>(p, st) : launch_wino16<false>(p, st);
+    return p.resid ? launch_wino16d<true>(p, st) : launch_wino16d<false>(p, st);
 }

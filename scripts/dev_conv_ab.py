@@ -10,7 +10,7 @@ from cerberus_amd.weights import default_model_kwargs, make_state_dict
 dev = torch.device("cuda", 0)
 m = create_model(**default_model_kwargs())
 m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(0).items()}, strict=True)
-for algo in [int(a) for a in (sys.argv[1:] or ["1", "3", "1", "3"])]:
+for algo in [int(a) for a in (sys.argv[1:] or ["1", "3", "4", "1", "3", "4"])]:
     m._ensure_handle()
     m.set_conv_algo(algo)
     dt, step, n = bench.batch_loop(m, dev, 0, 30, 5, None, "nccl")

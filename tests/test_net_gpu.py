@@ -269,7 +269,7 @@ def test_small_feature_maps_patch_class_crop(full_model, hw):
     assert (lg - rl).abs().max().item() < 2e-4
 
 
-@pytest.mark.parametrize("algo", [1, 0, 3])
+@pytest.mark.parametrize("algo", [1, 0, 3, 4])
 def test_forward_is_bitwise_reproducible(full_model, algo):
     """Races and un-padded hardware hazards show up as run-to-run differences long before they show up as large errors (the
     gfx950 buffer_store hazard of DESIGN par.4.1 did): the same batch through the same handle must give identical bits."""
@@ -291,8 +291,9 @@ def test_forward_is_bitwise_reproducible(full_model, algo):
         m.set_conv_algo(1)
 
 
+@pytest.mark.parametrize("algo", [3, 4])
 @pytest.mark.parametrize("tag", ["cfg2_all", "g448_all", "small96_all"])
-def test_wino16_algo_vs_reference_golden(golden_dir, tag):
+def test_wino16_algo_vs_reference_golden(golden_dir, tag, algo):
     """cerb_net_set_conv_algo(3): the second Winograd decomposition (conv_wino16.hip: a wave owns all 16 positions of 16 output
     channels on v_mfma_f32_16x16x4_f32, output transform in registers) against the reference's golden vectors -- plain, residual,
     grouped, cropped (region-of-interest items) and odd-sized (items hanging over the image) launches -- and against algorithm 1:
@@ -303,7 +304,7 @@ def test_wino16_algo_vs_reference_golden(golden_dir, tag):
     n, hw, osz = int(g["n"]), int(g["hw"]), int(g["out_shape"])
     tiles = np.random.RandomState(int(g["tile_seed"])).randint(0, 256, (n, hw, hw, 3)).astype(np.uint8)
     wino = infer_step(torch.from_numpy(tiles), m, osz, tasks)
-    m.set_conv_algo(3)
+    m.set_conv_algo(algo)
     try:
         out = infer_step(torch.from_numpy(tiles), m, osz, tasks)
         m.profile(True)
