@@ -31,9 +31,18 @@ constexpr int WD = W16_WD;                   // weight prefetch distance in step
 #endif
 constexpr int NPRE = W16_NPRE;               // steps of the NEXT item requested before an item's output stores
 #ifndef W16_PL
-#define W16_PL 1
+#define W16_PL 4
 #endif
+#ifndef W16_WB
+#define W16_WB 4
+#endif
+constexpr int WB = W16_WB;                   // weight burst size in steps (divides 8)
+#ifndef W16_TQ
+#define W16_TQ 10
+#endif
+constexpr int TQ = W16_TQ;                   // step at which the next chunk's patch is masked; transformed at TQ+1 .. TQ+4; written at 15
 constexpr int PL = W16_PL;                   // patch loads issued per step (over the first 16 / PL steps of a chunk)
+static_assert(16 / PL <= TQ && TQ + 4 < 15, "the patch must be requested before its transform starts");
 constexpr int CHUNK_W_BYTES = 16 * 4 * 1024;  // packed weights of one (cout block, 16-channel chunk): 64 KiB
 constexpr int WAVE_W_BYTES = 16 * 1024;       // one wave's share: 16 steps x 1 KiB
 static_assert(WD >= 1 && WD <= 7, "the slot ring has eight names");
@@ -202,12 +211,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino16d_kernel(ConvParams p) {
     int vbuf = 0;  // the buffer the CURRENT chunk reads; the next chunk's patch goes to vbuf ^ 1
     __syncthreads();
     __amdgpu_buffer_rsrc_t rw = make_rsrc(w_base(w));
-    f32x4 wq[8];  // weight ring: the operand of step q lives in slot q & 7
+    // Weight stream in BURSTS: every WB steps the operands of steps q + 8 .. q + 8 + WB - 1 are requested at once, and the patch
+    // loads of the next chunk go out right behind the step-0 burst.  vmcnt retires in order, so a load only delays the waits of
+    // loads issued AFTER it: with WB = 4 the HBM-latency patch loads have until the step-4 burst is needed (step 12 = 3072
+    // matrix-pipe cycles later) instead of one rolling prefetch distance (7 steps = 1792 cycles; the measured cost of the patch
+    // loads there was 14 % of the kernel, W16_ABL_NOPATCH).
+    f32x4 wq[16];  // the operand of step q lives in slot q
 #pragma unroll
-    for (int dd = 0; dd < WD; ++dd) wq[dd] = buf_load(rw, wlane, dd * 1024);
-    f32x4 wpre[NPRE];  // steps WD .. WD+NPRE-1 of an item's first chunk, requested before the previous item's stores
-#pragma unroll
-    for (int dd = 0; dd < NPRE; ++dd) wpre[dd] = buf_load(rw, wlane, (WD + dd) * 1024);
+    for (int dd = 0; dd < 8; ++dd) wq[dd] = buf_load(rw, wlane, dd * 1024);
     // folded-BN bias through position (1,1) (A^T[i][1] A[1][j] = 1 for all four outputs): its accumulators start at the bias
     f32x4 bnext;
     auto load_bias = [&](const Item& wi) {
@@ -246,32 +257,41 @@ __global__ __launch_bounds__(256, 2) void conv_wino16d_kernel(ConvParams p) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
                 const int xi = q;
-                if (FIRST && q < NPRE) {
-                    // steps WD .. WD+NPRE-1 of an item's first chunk were requested before the previous item's stores (wpre)
-                } else if (q + WD < NS) {
-                    wq[(q + WD) & 7] = buf_load(rw, wlane, wcur_off + (q + WD) * 1024);
-                } else {
-                    wq[(q + WD) & 7] = buf_load(rw_over, wlane, wover_off + (q + WD - NS) * 1024);
+#ifndef W16_ABL_NOWLOAD
+                if (q % WB == 0) {  // burst: the operands of steps q + 8 .. q + 8 + WB - 1 (of this chunk, or of the next one)
+#pragma unroll
+                    for (int dd = q + 8; dd < q + 8 + WB; ++dd) {
+                        if (dd < NS) wq[dd] = buf_load(rw, wlane, wcur_off + dd * 1024);
+                        else wq[dd - NS] = buf_load(rw_over, wlane, wover_off + (dd - NS) * 1024);
+                    }
                 }
+#endif
+#ifndef W16_ABL_NOLDS
                 if (q + 1 < NS) {
                     bb[(q + 1) & 1][0] = *reinterpret_cast<const f32x4*>(vsrc + (q + 1) * NT * PS);
                     bb[(q + 1) & 1][1] = *reinterpret_cast<const f32x4*>(vsrc + (q + 1) * NT * PS + 16 * PS);
                 }
+#else
+                if (q + 1 < NS) { bb[(q + 1) & 1][0] = bb[q & 1][0]; bb[(q + 1) & 1][1] = bb[q & 1][1]; }
+#endif
+#ifndef W16_ABL_NOPATCH
                 if (q * PL < 16) {  // next chunk's patch: PL loads per step from the start of the chunk
 #pragma unroll
                     for (int u = 0; u < PL; ++u) issue(r_stage, stage_off, q * PL + u);
                 }
+#endif
                 // the next chunk's patch landed: mask, B^T d B and the V writes into the OTHER buffer run in the shadow of the pipe
-                if (q == 10) {
+                if (q == TQ) {
                     if (mask_nx) mask_border(wp_);
                     else if (edge_nx) mask_edges(edge_nx);
                 }
-                if (q == 11 || q == 12) transform_rows((q - 11) * 2);
-                if (q == 13 || q == 14) transform_cols((q - 13) * 2);
+                if (q == TQ + 1 || q == TQ + 2) transform_rows((q - TQ - 1) * 2);  // one half per step: a two-step version of the same
+                if (q == TQ + 3 || q == TQ + 4) transform_cols((q - TQ - 3) * 2);  // work cost 10 % (the VALU burst holds back the MFMAs)
+#ifndef W16_ABL_NOVWRITE
                 if (q == 15) write_v(vbuf ^ 1);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
-                const bool pre = FIRST && q >= WD && q < WD + NPRE;  // compile-time after unrolling
-                const f32x4 av = pre ? wpre[pre ? q - WD : 0] : wq[q & 7];
+                const f32x4 av = wq[q];
                 const f32x4 b0 = bb[q & 1][0], b1 = bb[q & 1][1];
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
@@ -285,7 +305,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino16d_kernel(ConvParams p) {
                     }
                 }
             }
+#ifndef W16_ABL_NOBAR
             __syncthreads();  // everybody has read this chunk's V and written the next one's
+#endif
             vbuf ^= 1;
         };
         chunk(std::true_type{}, 0);
@@ -307,9 +329,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino16d_kernel(ConvParams p) {
                 y[tb][1][0] = T1[0] + T1[1] + T1[2];
                 y[tb][1][1] = T1[1] - T1[2] - T1[3];
             }
-            // acc is dead: request what the next item's first steps need before this item's stores enter the vmcnt queue
-#pragma unroll
-            for (int dd = 0; dd < NPRE; ++dd) wpre[dd] = buf_load(rw_nx, wlane, (WD + dd) * 1024);
+            // the next item's first eight steps were requested at step 8 of this item's last chunk; its bias goes out here, before
+            // this item's stores enter the in-order vmcnt queue
             load_bias(wnx);
             const long long origin = (((long long)w.n * p.Ho + w.oy0) * p.Wo + w.ox0) * p.Cout + w.cb * 64 + 16 * a;  // floats, uniform
             const unsigned span = (unsigned)(OTH * p.Wo * p.Cout * 4);
@@ -355,7 +376,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino16d_kernel(ConvParams p) {
                         o[1] = fmaxf(o[1], floor_);
                         o[2] = fmaxf(o[2], floor_);
                         o[3] = fmaxf(o[3], floor_);
+#ifndef W16_ABL_NOSTORE
                         buf_store(o, r_out, vo[tb][i][jj], (4 * tb + i) * orow + jj * opix);
+#else
+                        if (o[0] == 1.2345e-30f) buf_store(o, r_out, vo[tb][i][jj], (4 * tb + i) * orow + jj * opix);
+#endif
                     }
         }
         if (!more_items) break;
