@@ -78,7 +78,10 @@ int cerb_net_forward(cerb_net* net, const cerb_forward_io* io, void* hip_stream)
  * Both meet the 1e-4 bar; the switch exists for A/B measurement and for the parity tests of the direct path.
  * 2 = experimental: algorithm 1 with every fp32 product emulated by six bf16 MFMAs on a three-way bf16 split of both operands
  * (conv_wino3.hip; fp32 accumulate, errors indistinguishable from algorithm 1 in the tests).  It leaves the fp32 matrix
- * instruction, so it is never the default and never what bench.py's headline measures (BASELINE.json configs[1]: fp32). */
+ * instruction, so it is never the default and never what bench.py's headline measures (BASELINE.json configs[1]: fp32).
+ * 3, 4 = the same exact-fp32 Winograd with another work decomposition (conv_wino16.hip: a wave owns all 16 positions of 16 output
+ * channels, output transform in registers; conv_wino16d.hip: that with double-buffered 16-channel chunks).  Parity-tested like 1; kept
+ * for A/B measurement, not faster than 1. */
 int cerb_net_set_conv_algo(cerb_net* net, int algo);
 /* Output heads (models/utils/net_layers.py:31-38): 1 (default) = every dense head of the batch in ONE grouped launch with the head's
  * weights resident in LDS (head_group_kernel), 0 = one launch per head (round-1 head_kernel); identical arithmetic, for A/B. */
