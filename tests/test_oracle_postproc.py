@@ -129,3 +129,42 @@ def test_contour_shortcut_equals_full_hierarchy_on_postproc_label_maps(golden_di
             assert np.array_equal(full, cv2.findContours_first_piece(crop)), (name, int(iid))
             n_inst += 1
     assert n_inst > 500
+
+
+# ---- W2: the reference's tiled nuclei post-processing against the untiled labelling ------------------------------------------------
+@pytest.mark.parametrize("seed,dens,hw,tile,margin", [(5, 300.0, (700, 900), 256, 32), (6, 600.0, (640, 1000), 320, 32), (7, 150.0, (1100, 1300), 512, 64)])
+def test_reference_tile_scheme_keeps_a_subset_of_the_untiled_instances(seed, dens, hw, tile, margin):
+    """infer/wsi.py:81-268 + 642-682 (4096^2 tiles, 64-px margins, vertical / horizontal strips, cross sections; here scaled down so that
+    a small map has many seams) restated in oracle/wsi_tiles_ref.py, on structured maps:
+      * every instance the reference's scheme keeps is an instance of the UNTILED labelling with the identical bounding box, none twice
+        -- the scheme is an approximation of the whole-map result, which is what cerberus_amd/shard_postproc.py computes exactly
+        (tests/test_postproc_gpu.py::test_sharded_postproc_equals_whole_map);
+      * what it loses are instances lying wholly inside a margin zone whose box TOUCHES the edge line of the strip that should have
+        re-found them (shapely's closed-interval `query` / `contains`): a few per cent of the instances at this seam density, ~0.1 % at
+        the real 4096 / 64 geometry.  The band scheme keeps those."""
+    from oracle import synth, wsi_tiles_ref as wt
+
+    m = synth.nuclei_maps(hw[0], hw[1], seed, dens, noise=0.02)
+    ref = wt.reference_tiled_nuclei(m, tile_shape=tile, margin=margin, patch_output_shape=16)
+    whole = wt.whole_map_nuclei(m)
+    assert len(ref) == len(set(ref)) and len(whole) == len(set(whole)) and len(whole) > 150
+    lost = sorted(set(whole) - set(ref))
+    assert not (set(ref) - set(whole)), sorted(set(ref) - set(whole))[:5]
+    assert len(lost) <= 0.05 * len(whole), (len(lost), len(whole))
+    for x0, y0, x1, y1 in lost:  # each lost instance sits within one margin of an internal tile boundary
+        near_x = min(abs(e - k * tile) for k in range(1, hw[1] // tile + 1) for e in (x0, x1))
+        near_y = min(abs(e - k * tile) for k in range(1, hw[0] // tile + 1) for e in (y0, y1))
+        assert min(near_x, near_y) <= margin, (x0, y0, x1, y1)
+
+
+def test_reference_tile_info_sets():
+    from oracle import wsi_tiles_ref as wt
+
+    info = wt.get_tile_info((1000, 700), [256, 256], 32, [16, 16])
+    assert [len(b) for b, _ in info] == [12, 9, 8, 6]  # 4 x 3 grid; strips astride the 3 x 3 inner vertical / 4 x 2 horizontal edges; 3 x 2 crosses
+    grid, flags = info[0]
+    assert flags[0].tolist() == [0, 1, 0, 1] and flags[5].tolist() == [1, 1, 1, 1] and flags[11].tolist() == [1, 0, 1, 0]
+    assert info[1][0][0].tolist() == [256 - 32, 0, 256 + 32, 256] and info[1][1][0].tolist() == [0, 1, 0, 0]
+    assert info[3][0][0].tolist() == [256 - 64, 256 - 64, 256 + 64, 256 + 64]
+    small = wt.get_tile_info((200, 100), [256, 256], 32, [16, 16])
+    assert len(small) == 1 and small[0][1].tolist() == [[0, 0, 0, 0]]
