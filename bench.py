@@ -123,6 +123,36 @@ def train_leg(args, model, dev, dist, world, rank):
         t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # roofline leg: per-launch HIP events of ONE more step (cerb_net_profile_*): forward / data-gradient convolutions, the weight-gradient
+    # kernels (executed MFMA FLOPs against the fp32 MFMA peak) and the BatchNorm passes (algorithmic bytes against the HBM peak)
+    roofline, fam_rows = None, None
+    try:
+        model.profile(True)
+        step()
+        torch.cuda.synchronize()
+        recs = model.profile_records()
+        model.profile(False)
+        fam = {}
+        for _, kern, work, ms in recs:
+            f = fam.setdefault(kern, [0.0, 0.0, 0])
+            f[0] += work
+            f[1] += ms
+            f[2] += 1
+        fam_rows = []
+        for kern, (work, ms, cnt) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+            row = {"kernel": kern, "launches": cnt, "ms_per_step": round(ms, 3)}
+            if kern.startswith("bn_"):
+                row.update(bound="hbm", achieved=round(work / (ms * 1e-3) / 1e9, 1), unit="GB/s", frac=round(work / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            elif work > 0:
+                ex = work / (ms * 1e-3) / 1e12 * (16.0 / 36.0 if kern.startswith("conv_wino") else 1.0)
+                row.update(bound="mfma", achieved=round(ex, 2), unit="TFLOP/s", frac=round(ex / PEAK_F32_MFMA_TFLOPS, 4))
+            fam_rows.append(row)
+        dom = next((r for r in fam_rows if r["kernel"].startswith("wgrad")), fam_rows[0])
+        roofline = dict(dom, peak=PEAK_F32_MFMA_TFLOPS if dom.get("bound") == "mfma" else HBM_PEAK_GBS, traffic=None,
+                        note="dominant backward family; `kernels` lists all profiled families of the step (the 7x7 stem, the pointwise / stride-2 1x1 "
+                             "data gradients, losses, Adam and re-pack are not individually timed)")
+    except Exception as e:  # the profile leg never fails the benchmark line
+        roofline = {"error": str(e)[:200]}
     if rank == 0:
         fwd_flops = model.flops(n, hw, hw)
         print(json.dumps({
@@ -148,7 +178,8 @@ def train_leg(args, model, dev, dist, world, rank):
                 "parallelism": "data-parallel x%d, bucketed gradient all-reduce (%s)" % (world, args.backend if world > 1 else "none at 1 GPU"),
                 "last_overall_loss": round(float(res["EMA"]["overall_loss"]), 4),
             },
-            "roofline": None,
+            "roofline": roofline,
+            "kernels": fam_rows,
             "cpu_baseline": None,
         }), flush=True)
     if dist is not None:

@@ -1172,6 +1172,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
     const size_t D = net->dense_idx.size();
     const size_t guard = cerb_conv_guard_bytes(W);
     net->tape_pos = 0;
+    net->prof_n = 0;  // per-launch records of this step (cerb_net_profile_*): the forward convs through run_conv, plus the backward families below
     std::vector<float*> val, grd;
     std::vector<size_t> cnt;
     auto take = [&](size_t nfloat, bool zero) -> float* {  // next buffer of the tape arena (kept across steps)
@@ -1220,6 +1221,8 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         float* rstd = val[stt] + (size_t)b.groups * b.C;
         const long long gs = b.groups > 1 ? rows * b.C : 0;
         float* var_u = take((size_t)b.groups * b.C, false);  // unbiased batch variance: what the running_var update uses
+        // `flops` field = algorithmic bytes of the two forward BatchNorm passes (statistics: read y; apply: read y (+ residual), write z)
+        if (prof_begin(net, name + ".bn_fwd", "bn_fwd", (double)b.groups * rows * b.C * 4.0 * (3.0 + (resid >= 0 ? 1.0 : 0.0)), st)) return -1;
         if (!var_u || cerb_launch_bn_stats(val[y], gs, rows, b.C, b.groups, 1e-5f, mean, rstd, var_u, net->t_ws.p, st) != hipSuccess) return -1;
         {
             const std::vector<std::string>& keys = net->bn_keys[name];
@@ -1229,6 +1232,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
             }
         }
         if (cerb_launch_bn_apply(val[z], val[y], resid >= 0 ? val[resid] : nullptr, gs, rows, b.C, b.groups, mean, rstd, b.gamma, b.beta, relu, st) != hipSuccess) return -1;
+        if (prof_end(net, st)) return -1;
         TapeOp op;
         op.type = 2; op.name = name; op.a = y; op.b = resid; op.o = z; op.stat = stt; op.rows = rows; op.Cout = b.C; op.G = b.groups; op.relu = relu; op.a_gs = gs;
         tape.push_back(op);
@@ -1445,7 +1449,11 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 if ((op.ks == 3 || op.ks == 1) && net->conv_algo) {  // weight gradient on the matrix cores
                     const int ho = op.stride == 2 ? op.H / 2 : op.H, wo = op.stride == 2 ? op.W / 2 : op.W;
                     if (net->t_ws.ensure(cerb_wgrad_workspace_bytes(op.G, op.N, ho, wo, op.Cin, op.Cout, op.ks, nullptr), 0)) return fail("workspace allocation failed");
+                    // `flops` field: executed MFMA FLOPs of the weight gradient (2 x outputs x taps x Cin x Cout)
+                    if (prof_begin(net, op.name + ".wgrad", "wgrad<ks" + std::to_string(op.ks) + ",s" + std::to_string(op.stride) + ">",
+                                   2.0 * op.G * op.N * ho * wo * (double)op.Cin * op.Cout * op.ks * op.ks, st)) return 1;
                     HIP_OK(cerb_launch_wgrad(val[op.a], go, dw, op.G, op.N, op.H, op.W, op.Cin, op.Cout, op.ks, op.stride, op.a_gs, net->t_ws.p, st));
+                    if (prof_end(net, st)) return 1;
                     dw_done = true;
                 }
                 if (db) {
@@ -1470,8 +1478,12 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 // the conv output's gradient has this BatchNorm as its first writer almost always: then the kernel assigns and the buffer needs no zero fill
                 const bool fresh = !grd[op.a] && cnt[op.a] == (size_t)op.G * op.rows * op.Cout && (op.G == 1 || op.a_gs == op.rows * op.Cout);
                 if (fresh && !(grd[op.a] = take(cnt[op.a], false))) return fail("workspace allocation failed");
+                // `flops` field of an HBM-bound family: its algorithmic BYTES (reads dz, z, y twice -- reduction pass + apply pass --, writes dy
+                // (+ the residual branch's gradient)), fp32
+                if (prof_begin(net, op.name + ".bn_bwd", "bn_bwd", (double)op.G * op.rows * op.Cout * 4.0 * (5.0 + (op.b >= 0 ? 2.0 : 0.0)), st)) return 1;
                 HIP_OK(cerb_launch_bn_bwd(go, val[op.o], val[op.a], G_(op.a), op.b >= 0 ? G_(op.b) : nullptr, op.a_gs, op.rows, op.Cout, op.G, val[op.stat],
                                           val[op.stat] + (size_t)op.G * op.Cout, b.gamma, dgamma, dbeta, op.relu, fresh ? 1 : 0, net->t_ws.p, st));
+                if (prof_end(net, st)) return 1;
                 const std::vector<std::string>& keys = net->bn_keys[op.name];
                 for (int g = 0; g < op.G; ++g) {
                     net->grads[keys[g] + ".weight"] = std::make_pair(dgamma + (size_t)g * op.Cout, (long long)op.Cout);
