@@ -44,7 +44,7 @@ hipError_t cerb_launch_pointwise(const float* in, const float* w, const float* b
                                  hipStream_t st);
 hipError_t cerb_launch_crop_gap(const float* x, int N, int H, int W, int C, int y0, int ch, int x0, int cw, float* out, hipStream_t st);
 hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, float* dy, float* dresid, long long group_stride, long long rows, int C, int groups,
-                              const float* mean, const float* rstd, const float* gamma, float* dgamma, float* dbeta, int relu, int dy_assign, void* ws, hipStream_t st);
+                              const float* mean, const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, int relu, int dy_assign, void* ws, hipStream_t st);
 hipError_t cerb_launch_conv_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int G, int N, int H, int W, int Cin, int Cout,
                                 int ks, int stride, long long x_gs, hipStream_t st);
 hipError_t cerb_launch_stem_wgrad(const unsigned char* tiles, const float* dy, float* dw, int N, int H, int W, hipStream_t st);
@@ -1482,7 +1482,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 // (+ the residual branch's gradient)), fp32
                 if (prof_begin(net, op.name + ".bn_bwd", "bn_bwd", (double)op.G * op.rows * op.Cout * 4.0 * (5.0 + (op.b >= 0 ? 2.0 : 0.0)), st)) return 1;
                 HIP_OK(cerb_launch_bn_bwd(go, val[op.o], val[op.a], G_(op.a), op.b >= 0 ? G_(op.b) : nullptr, op.a_gs, op.rows, op.Cout, op.G, val[op.stat],
-                                          val[op.stat] + (size_t)op.G * op.Cout, b.gamma, dgamma, dbeta, op.relu, fresh ? 1 : 0, net->t_ws.p, st));
+                                          val[op.stat] + (size_t)op.G * op.Cout, b.gamma, b.beta, dgamma, dbeta, op.relu, fresh ? 1 : 0, net->t_ws.p, st));
                 if (prof_end(net, st)) return 1;
                 const std::vector<std::string>& keys = net->bn_keys[op.name];
                 for (int g = 0; g < op.G; ++g) {

@@ -332,6 +332,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restr
     rstd[g * C + c] = (float)(1.0 / sqrt(v + (double)eps));
     if (var_unbiased) var_unbiased[g * C + c] = (float)(rows > 1 ? v * (double)rows / (double)(rows - 1) : v);
 }
+// z = gamma * (y - mean) * rstd + beta, ONE expression shared by the forward (bn_apply_kernel) and by the backward kernels, which
+// recompute z's sign from y instead of reading z back (the ReLU mask costs 4 bytes per element otherwise): identical bits by construction
+__device__ __forceinline__ float bn_out(float y, float m, float rs, float ga, float be) { return __fmaf_rn(y - m, rs * ga, be); }
+
 __global__ __launch_bounds__(256) void bn_apply_kernel(float* x, const float* src, const float* __restrict__ resid, long long group_stride, long long rows, int C,
                                                        int groups, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int relu) {
@@ -347,10 +351,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(float* x, const float* sr
         const float* rs = rstd + g * C + c;
         const float* ga = gamma + g * C + c;
         const float* be = beta + g * C + c;
-        v.x = (v.x - m[0]) * (rs[0] * ga[0]) + be[0];
-        v.y = (v.y - m[1]) * (rs[1] * ga[1]) + be[1];
-        v.z = (v.z - m[2]) * (rs[2] * ga[2]) + be[2];
-        v.w = (v.w - m[3]) * (rs[3] * ga[3]) + be[3];
+        v.x = bn_out(v.x, m[0], rs[0], ga[0], be[0]);
+        v.y = bn_out(v.y, m[1], rs[1], ga[1], be[1]);
+        v.z = bn_out(v.z, m[2], rs[2], ga[2], be[2]);
+        v.w = bn_out(v.w, m[3], rs[3], ga[3], be[3]);
         if (resid) {
             const float4 r = *reinterpret_cast<const float4*>(resid + g * group_stride + (j / c4n) * C + c);
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -448,7 +452,7 @@ namespace {
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ y,
                                                              long long group_stride, long long rows, int C, int blocks_per_group,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd, int relu,
-                                                             double* __restrict__ partial) {
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, double* __restrict__ partial) {
     extern __shared__ double shd[];
     const int g = blockIdx.x / blocks_per_group, b = blockIdx.x % blocks_per_group;
     const int c4n = C >> 2, tid = threadIdx.x;
@@ -457,12 +461,24 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     if (rl < nrl) {
         const float4 m = *reinterpret_cast<const float4*>(mean + g * C + 4 * c4), rs = *reinterpret_cast<const float4*>(rstd + g * C + 4 * c4);
+        float4 ga = {0.f, 0.f, 0.f, 0.f}, be = ga;
+        if (relu == 2) {  // no residual: the mask is the sign of bn_out(y), recomputed instead of read
+            ga = *reinterpret_cast<const float4*>(gamma + g * C + 4 * c4);
+            be = *reinterpret_cast<const float4*>(beta + g * C + 4 * c4);
+        }
         for (long long r = r0 + rl; r < r1; r += nrl) {
             const long long i = g * group_stride + r * C + 4 * c4;
             float4 d = *reinterpret_cast<const float4*>(dz + i);
             const float4 yy = *reinterpret_cast<const float4*>(y + i);
             if (relu) {
-                const float4 zz = *reinterpret_cast<const float4*>(z + i);
+                float4 zz;
+                if (relu == 2) {
+                    zz.x = bn_out(yy.x, m.x, rs.x, ga.x, be.x);
+                    zz.y = bn_out(yy.y, m.y, rs.y, ga.y, be.y);
+                    zz.z = bn_out(yy.z, m.z, rs.z, ga.z, be.z);
+                    zz.w = bn_out(yy.w, m.w, rs.w, ga.w, be.w);
+                } else
+                    zz = *reinterpret_cast<const float4*>(z + i);
                 if (!(zz.x > 0.f)) d.x = 0.f;
                 if (!(zz.y > 0.f)) d.y = 0.f;
                 if (!(zz.z > 0.f)) d.z = 0.f;
@@ -506,8 +522,8 @@ template <bool ASSIGN>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ y,
                                                            float* __restrict__ dy, float* __restrict__ dresid, long long group_stride, long long rows, int C,
                                                            int groups, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                           const float* __restrict__ gamma, const float* __restrict__ dgamma,
-                                                           const float* __restrict__ dbeta, int relu) {
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu) {
     const int c4n = C >> 2;
     const long long per_group = rows * c4n, total = per_group * groups;
     const float invM = 1.f / (float)rows;
@@ -517,8 +533,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const int c = 4 * (int)(j % c4n);
         const long long a = g * group_stride + (j / c4n) * C + c;
         float4 d = *reinterpret_cast<const float4*>(dz + a);
+        const int gc = g * C + c;
+        const float4 yv = *reinterpret_cast<const float4*>(y + a), mu = *reinterpret_cast<const float4*>(mean + gc), rs = *reinterpret_cast<const float4*>(rstd + gc),
+                     ga = *reinterpret_cast<const float4*>(gamma + gc), dg = *reinterpret_cast<const float4*>(dgamma + gc), db = *reinterpret_cast<const float4*>(dbeta + gc);
         if (relu) {
-            const float4 m = *reinterpret_cast<const float4*>(z + a);
+            float4 m;
+            if (relu == 2) {
+                const float4 be = *reinterpret_cast<const float4*>(beta + gc);
+                m.x = bn_out(yv.x, mu.x, rs.x, ga.x, be.x);
+                m.y = bn_out(yv.y, mu.y, rs.y, ga.y, be.y);
+                m.z = bn_out(yv.z, mu.z, rs.z, ga.z, be.z);
+                m.w = bn_out(yv.w, mu.w, rs.w, ga.w, be.w);
+            } else
+                m = *reinterpret_cast<const float4*>(z + a);
             if (!(m.x > 0.f)) d.x = 0.f;
             if (!(m.y > 0.f)) d.y = 0.f;
             if (!(m.z > 0.f)) d.z = 0.f;
@@ -529,9 +556,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             r.x += d.x; r.y += d.y; r.z += d.z; r.w += d.w;
             *reinterpret_cast<float4*>(dresid + a) = r;
         }
-        const int gc = g * C + c;
-        const float4 yv = *reinterpret_cast<const float4*>(y + a), mu = *reinterpret_cast<const float4*>(mean + gc), rs = *reinterpret_cast<const float4*>(rstd + gc),
-                     ga = *reinterpret_cast<const float4*>(gamma + gc), dg = *reinterpret_cast<const float4*>(dgamma + gc), db = *reinterpret_cast<const float4*>(dbeta + gc);
         float4 o;
         o.x = ga.x * rs.x * (d.x - db.x * invM - ((yv.x - mu.x) * rs.x) * dg.x * invM);
         o.y = ga.y * rs.y * (d.y - db.y * invM - ((yv.y - mu.y) * rs.y) * dg.y * invM);
@@ -875,15 +899,19 @@ static unsigned gridfor(long long n) {
 }  // namespace
 
 hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, float* dy, float* dresid, long long group_stride, long long rows, int C, int groups,
-                              const float* mean, const float* rstd, const float* gamma, float* dgamma, float* dbeta, int relu, int dy_assign, void* ws, hipStream_t st) {
+                              const float* mean, const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, int relu, int dy_assign,
+                              void* ws, hipStream_t st) {
     const int bpg = (int)((rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK);
+    // a ReLU behind a BatchNorm WITHOUT a residual: z > 0 <=> bn_out(y) > 0, recomputed from the y both passes read anyway (relu = 2):
+    // 5 instead of 7 tensor passes over the activation
+    if (relu && !dresid && beta) relu = 2;
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(groups * bpg), dim3(256), 256 * 2 * sizeof(double), st, dz, z, y, group_stride, rows, C, bpg, mean, rstd, relu,
-                       (double*)ws);
+                       gamma, beta, (double*)ws);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, (const double*)ws, C, bpg, dgamma, dbeta);
     if (dy_assign) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gridfor(rows * (C / 4) * groups)), dim3(256), 0, st, dz, z, y, dy, dresid, group_stride, rows, C,
-                                      groups, mean, rstd, gamma, dgamma, dbeta, relu);
+                                      groups, mean, rstd, gamma, beta, dgamma, dbeta, relu);
     else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(gridfor(rows * (C / 4) * groups)), dim3(256), 0, st, dz, z, y, dy, dresid, group_stride, rows, C, groups,
-                            mean, rstd, gamma, dgamma, dbeta, relu);
+                            mean, rstd, gamma, beta, dgamma, dbeta, relu);
     return hipGetLastError();
 }
 hipError_t cerb_launch_conv_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int G, int N, int H, int W, int Cin, int Cout,
