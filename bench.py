@@ -328,7 +328,7 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
     from collections import OrderedDict
 
     from cerberus_amd.shard_postproc import postprocess_bands_and_gather
-    from cerberus_amd.wsi import WSIRunner, band_partition, synth_slide
+    from cerberus_amd.wsi import WSIRunner, band_partition, check_shardable, synth_slide
 
     free = torch.cuda.mem_get_info(dev)[0]
     if dist is not None:  # one decision for all ranks: the smallest free HBM among them
@@ -340,6 +340,7 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
         side = 40000 if free > (140e9 if world == 1 else 270e9 / world + 8e9) else 20000
     H = W = side
     K = args.steps
+    check_shardable((H, W), TILE, world)
     run = WSIRunner(model, (H, W), TILE, TILE, BATCH, rank, world)
     y0, y1 = run.slab_rows()
     slab = synth_slide(y1 - y0, W, y0=y0, seed=3)

@@ -153,18 +153,23 @@ def gather_bands(canv, geo, rank, world, dist=None):
     return full
 
 
+def check_shardable(slide_hw, patch_output_shape, world_size):
+    """A rank without a patch row would stay out of the halo exchange and the gathers while the others wait for it: every rank
+    evaluates this same condition before the first collective of a slide, so all of them stop together."""
+    rows = math.ceil(int(slide_hw[0]) / int(patch_output_shape))
+    if rows < int(world_size):
+        raise ValueError("slide of %d patch rows cannot be sharded over %d ranks: use at most %d" % (rows, world_size, rows))
+
+
 class WSIRunner(object):
-    """One per process / GPU."""
+    """One per process / GPU.  (Single-process simulations of more ranks than patch rows get empty bands; distributed drivers call
+    check_shardable first.)"""
 
     def __init__(self, net, slide_hw, patch_input_shape=256, patch_output_shape=256, batch_size=32, rank=0, world_size=1, patch_sel=None):
         self.net = net
         self.geo = SlideGeometry(slide_hw, patch_input_shape, patch_output_shape, patch_sel)
         self.batch = int(batch_size)
         self.rank, self.world = int(rank), int(world_size)
-        if self.geo.rows < self.world:
-            # every rank evaluates the same condition, so all of them stop here together (an empty band would leave its rank out of
-            # the halo exchange and the gathers, and the others waiting for it)
-            raise ValueError("slide of %d patch rows cannot be sharded over %d ranks: use at most %d" % (self.geo.rows, self.world, self.geo.rows))
         self.r0, self.r1 = self.geo.band(self.rank, self.world)
         self.dev = torch.device("cuda", torch.cuda.current_device())
         g = self.geo

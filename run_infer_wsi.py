@@ -56,7 +56,7 @@ def main(argv=None):
 
     from cerberus_amd.tile import InferManager
     from cerberus_amd.weights import DEFAULT_REQ_TARGET_CODE, default_model_kwargs
-    from cerberus_amd.wsi import SlabUploader, WSIRunner, build_wsi_inst_info, synth_slide, write_dat
+    from cerberus_amd.wsi import SlabUploader, WSIRunner, build_wsi_inst_info, check_shardable, synth_slide, write_dat
 
     dist = None
     torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
@@ -120,6 +120,7 @@ def main(argv=None):
 
                 os.makedirs(os.path.join(out_dir, "mask"), exist_ok=True)
                 Image.fromarray(mask * 255).save(os.path.join(out_dir, "mask", base + ".png"))
+        check_shardable((H, W), out, world)
         run = WSIRunner(manager.net, (H, W), win, out, batch, rank, world, patch_sel=sel)
         y0, y1 = run.slab_rows()  # this rank's band + context halo
         if host is None:
