@@ -76,10 +76,43 @@ def cpu_baseline(sd, kw, n_tiles=8, iters=2):
     }
 
 
+def cpu_baseline_train(sd, kw):
+    """The training step on the host cores: oracle/train_step_ref.py (torch-autograd restatement of the reference's train_step) on a
+    BOUNDED sample -- 2 tiles of 448 x 448 (BatchNorm in training mode needs more than one sample), one warm-up step + one timed."""
+    from oracle import train_step_ref
+
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = min(avail, 16)
+    torch.set_num_threads(cores)
+    heads = {"Lumen-INST": 3, "Gland-INST": 3, "Nuclei-INST": 3, "Nuclei-TYPE": 7, "Gland-TYPE": 3, "Patch-Class": 9}
+    rs = np.random.RandomState(5)
+    n, hw = 2, TRAIN_TILE
+    img = rs.randint(0, 256, (n, hw, hw, 3)).astype(np.uint8)
+    tg = {h: (rs.randint(0, c, (n, 1, 1, 1)) if h == "Patch-Class" else (rs.rand(n, hw, hw, 1) < 0.3) * rs.randint(1, c, (n, hw, hw, 1))).astype(np.float32)
+          for h, c in heads.items()}
+    has = np.ones((n, len(heads)), bool)
+    step = train_step_ref.make_step({k: v.numpy() for k, v in sd.items()}, kw["decoder_kwargs"], kw["considered_tasks"])
+    t0 = time.perf_counter()
+    step(img, tg, has)
+    dt = time.perf_counter() - t0
+    timed = "first"
+    if dt < 15.0:
+        t0 = time.perf_counter()
+        step(img, tg, has)
+        dt = time.perf_counter() - t0
+        timed = "second"
+    return {"value": round(n / dt, 4), "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": "%s of two whole training steps (train-mode forward, six losses, autograd backward, Adam) on %d tiles of %dx%d, torch-CPU fp32, %d threads (host has %d)"
+                      % (timed, n, hw, hw, cores, avail)}
+
+
 TRAIN_BATCH, TRAIN_TILE = 16, 448  # BASELINE.json configs[4]: batch 16; 448 x 448 is the reference's training patch (paramset.yml)
 
 
-def train_leg(args, model, dev, dist, world, rank):
+def train_leg(args, model, dev, dist, world, rank, sd=None, kw=None):
     """--mode train: K whole training steps (train-mode forward, six losses, backward, bucketed gradient all-reduce over the ranks, Adam,
     BatchNorm running statistics, on-device weight re-pack) on a synthetic batch resident in HBM; every rank has its own batch (weak)."""
     import numpy as np
@@ -180,7 +213,7 @@ def train_leg(args, model, dev, dist, world, rank):
             },
             "roofline": roofline,
             "kernels": fam_rows,
-            "cpu_baseline": None,
+            "cpu_baseline": cpu_baseline_train(sd, kw) if (world == 1 and sd is not None and not args.no_cpu_baseline) else None,
         }), flush=True)
     if dist is not None:
         dist.barrier()
@@ -516,7 +549,7 @@ def main():
     model = create_model(**kw)
     model.load_state_dict(sd, strict=True)
     if args.mode == "train":
-        return train_leg(args, model, dev, dist, world, rank)
+        return train_leg(args, model, dev, dist, world, rank, sd, kw)
     if args.mode == "wsi":
         wsi_leg(args, model, dev, dist, world, rank, sd, kw)
     else:

@@ -39,10 +39,13 @@ def _t(sd, k):
     return v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))
 
 
+_TRAINING = False  # net_forward(training=True): BatchNorm on batch statistics (running buffers updated in place), autograd on
+
+
 def _bn(sd, p, x):
     return F.batch_norm(
         x, _t(sd, p + ".running_mean"), _t(sd, p + ".running_var"), _t(sd, p + ".weight"), _t(sd, p + ".bias"),
-        training=False, eps=BN_EPS,
+        training=_TRAINING, momentum=0.1, eps=BN_EPS,
     )
 
 
@@ -77,9 +80,12 @@ def backbone_forward(sd, x):
     return feats  # [x0, x1, x2, x3, x4]
 
 
-def net_forward(sd, imgs_nchw, decoder_kwargs, considered_tasks, return_feats=False):
-    """NetDesc.forward (net_desc.py:144-200). imgs: float NCHW in 0..255."""
-    with torch.no_grad():
+def net_forward(sd, imgs_nchw, decoder_kwargs, considered_tasks, return_feats=False, training=False):
+    """NetDesc.forward (net_desc.py:144-200). imgs: float NCHW in 0..255.  training=True: model.train() semantics (batch-statistics
+    BatchNorm, Dropout(0.3) in the Patch-Class branch, autograd enabled) -- the forward half of oracle/train_step_ref.py."""
+    global _TRAINING
+    _TRAINING = bool(training)
+    with torch.set_grad_enabled(bool(training)):
         imgs = imgs_nchw / 255.0
         feat_list = backbone_forward(sd, imgs)
         bottom = feat_list[-1]
@@ -97,6 +103,7 @@ def net_forward(sd, imgs_nchw, decoder_kwargs, considered_tasks, return_feats=Fa
                 v = F.adaptive_avg_pool2d(bf, (1, 1))
                 p = "decoder_head.Patch-Class"
                 v = F.relu(_bn(sd, p + ".bn1", v))
+                v = F.dropout(v, 0.3, training=_TRAINING)  # net_desc.py:70
                 v = F.conv2d(v, _t(sd, p + ".conv1.weight"), _t(sd, p + ".conv1.bias"))
                 v = F.relu(_bn(sd, p + ".bn2", v))
                 v = F.conv2d(v, _t(sd, p + ".conv2.weight"), _t(sd, p + ".conv2.bias"))
@@ -117,6 +124,7 @@ def net_forward(sd, imgs_nchw, decoder_kwargs, considered_tasks, return_feats=Fa
                 h = F.relu(_bn(sd, p + ".0.block.0.bn", h))
                 h = F.conv2d(h, _t(sd, p + ".1.conv.weight"), _t(sd, p + ".1.conv.bias"))
                 out[name.split("#")[0] + "-" + clf] = h
+    _TRAINING = False
     if return_feats:
         return out, feat_list, bottom
     return out

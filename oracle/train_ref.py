@@ -23,6 +23,13 @@ def head_loss(head_name, logits_nchw, target_nhw1, has_target, loss_opts=PARAMSE
     """weight_map_nhw1: the head's '#WEIGHT-MAP' target (models/run_desc.py:111-117) or None.
     -> (loss value as train_step reports it = weighted head loss, d(that)/d(logits) as float32 NCHW numpy)"""
     pred = torch.tensor(np.asarray(logits_nchw), dtype=torch.float32, requires_grad=True)
+    total = head_loss_tensor(head_name, pred, target_nhw1, has_target, loss_opts, n_classes, weight_map_nhw1)
+    total.backward()
+    return float(total.item()), pred.grad.numpy()
+
+
+def head_loss_tensor(head_name, pred, target_nhw1, has_target, loss_opts=PARAMSET_LOSS, n_classes=None, weight_map_nhw1=None):
+    """The weighted head loss as a tensor attached to `pred` (logits NCHW, possibly the output of a network under autograd)."""
     true = torch.tensor(np.asarray(target_nhw1), dtype=torch.float32).permute(0, 3, 1, 2).contiguous()  # NCHW like :60-62
     flag = torch.tensor(np.asarray(has_target).astype(np.float32))
     wmap = torch.ones_like(true)
@@ -53,6 +60,4 @@ def head_loss(head_name, logits_nchw, target_nhw1, has_target, loss_opts=PARAMSE
             ce = torch.mean(ce, dim=(1, 2))
             term = torch.sum(ce * flag) / (torch.sum(flag) + 1.0e-8)
         total = total + term * w
-    total = total * loss_opts["loss_info"][head_name]["weight"]
-    total.backward()
-    return float(total.item()), pred.grad.numpy()
+    return total * loss_opts["loss_info"][head_name]["weight"]

@@ -190,6 +190,10 @@ def test_bench_train_mode_single_and_two_ranks():
 
     one = run([sys.executable, "bench.py", "--mode", "train", "--steps", "2", "--warmup", "1"])
     assert one["unit"] == "tiles/s" and one["n_gpus"] == 1 and one["dtype"] == "f32" and one["scaling"] == "weak"
+    rf, cb = one["roofline"], one["cpu_baseline"]
+    assert rf["kernel"].startswith("wgrad") and rf["bound"] == "mfma" and 0.3 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 0.01
+    assert any(r["kernel"] == "bn_bwd" and r["bound"] == "hbm" and 0.1 < r["frac"] < 1.0 for r in one["kernels"])
+    assert cb["kind"] == "port" and cb["unit"] == "tiles/s" and 0 < cb["value"] < one["value"]
     assert abs(one["value"] - 16 / (one["ms_per_step"] * 1e-3)) / one["value"] < 0.01
     assert 0 < one["config"]["last_overall_loss"] < 100
     two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
