@@ -33,6 +33,7 @@ import torch  # noqa: E402
 
 BATCH, TILE = 32, 256
 MARGIN = 1024  # halo rows exchanged between neighbouring bands (full resolution): above the tallest gland cluster of the structured maps
+MARGINS = {"Nuclei": 128, "Gland": MARGIN, "Lumen": 512}  # per tissue: nuclei are < 30 px (the reference's own tile margin is 64)
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
@@ -417,7 +418,7 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
         phase["inference_s"] = time.perf_counter() - t0
         t1 = time.perf_counter()
         canv = OrderedDict(struct)
-        inst, info, small = postprocess_bands_and_gather(run, H, W, rank, world, dist, margin=MARGIN, guard=48, canv=canv, max_band_px=max_band_px,
+        inst, info, small = postprocess_bands_and_gather(run, H, W, rank, world, dist, margin=MARGINS, guard=48, canv=canv, max_band_px=max_band_px,
                                                          prof=prof)
         torch.cuda.synchronize()
         phase["tail_s"] = time.perf_counter() - t1

@@ -53,7 +53,10 @@ __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, unsigned vof
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
 }
 __device__ __forceinline__ void buf_store(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, soff, 0);
+#ifndef WINO_STORE_AUX
+#define WINO_STORE_AUX 0
+#endif
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, soff, WINO_STORE_AUX);
     // gfx950 hazard hipcc (ROCm 7.2) does not pad: buffer_store_dwordx4 whose soffset is an SGPR, followed directly by a VALU
     // write of its data VGPRs, stores corrupted data (the compiler only inserts wait states for the immediate-soffset form).
     // Found as run-to-run differing outputs; two wait states pinned behind the store cure it (scripts/dev_wrace.sh).

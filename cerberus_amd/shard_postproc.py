@@ -262,7 +262,8 @@ def local_band_count(rows, cols, max_band_px):
 
 def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guard=48, max_band_px=None, prof=None):
     """Per-rank replacement of WSIRunner.postprocess for band canvases: label maps of THIS rank's band with slide-global
-    ids, nothing gathered.  canv: the band canvases of this rank (full-resolution rows of equal count on every rank except
+    ids, nothing gathered.  margin: halo rows at full resolution, an int or {tissue: rows, "default": rows} (the reference's
+    own nuclei margin is 64 px, infer/wsi.py:906-915; gland clusters need hundreds).  canv: the band canvases of this rank (full-resolution rows of equal count on every rank except
     the last).  Gland / lumen run at x0.5 in wsi_mode (infer/wsi.py:786-804); their margin / guard are halved accordingly.
     max_band_px (world == 1 only): a canvas larger than this is labelled as several row bands one after the other through the
     same halo / ownership / id protocol the ranks use (`run_local`) -- the one-GPU streaming path for slides whose 96 B / px
@@ -285,7 +286,8 @@ def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guar
             continue
         half = wsi_mode and t != "Nuclei"
         band = downsample2_inst(canv[key]) if half else canv[key]
-        m, g, yy, ds = (margin // 2, guard // 2, y0 // 2, 0.5) if half else (margin, guard, y0, 1.0)
+        mt = margin.get(t, margin.get("default", 512)) if isinstance(margin, dict) else margin  # per-tissue halo: nuclei need far less than glands
+        m, g, yy, ds = (mt // 2, guard // 2, y0 // 2, 0.5) if half else (mt, guard, y0, 1.0)
         if dist is not None:  # also at world == 1 when the caller initialised a process group (bench.py --force-dist, the nccl test)
             inst[t], _, info[t] = run_distributed(band, yy, t, m, g, dist, ds, prof=prof)
         else:
