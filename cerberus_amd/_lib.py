@@ -73,6 +73,12 @@ def lib():
             "libcerberus_hip.so not found at %s -- run `python -m cerberus_amd.build` (needs hipcc). "
             "There is no CPU fallback for the Cerberus HIP path." % LIB_PATH
         )
+    # PyTorch-ROCm ships its own copy of the HIP runtime.  Whichever libamdhip64 is loaded FIRST serves every later user of that
+    # soname; if this library came first it would bring /opt/rocm's runtime in beside torch's, and the second runtime in a process
+    # does not get the device ("no ROCm-capable device is detected" from hipMalloc while torch.cuda works).  Device memory, streams
+    # and torch.distributed are torch's here, so torch's runtime is the one to share: import it before the dlopen.
+    import torch  # noqa: F401
+
     L = C.CDLL(LIB_PATH)
     L.cerb_last_error.restype = C.c_char_p
     L.cerb_net_create.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
