@@ -263,7 +263,8 @@ def kernel_table(model, step, n_tiles):
             row.update(bound="hbm", achieved=round(gbs, 1), unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), algorithmic_bytes=by)
         elif fl > 0:
             alg = fl / (ms * 1e-3) / 1e12
-            ex = alg * (16.0 / 36.0 if kern.startswith("conv_wino") else 1.0)  # F(2x2,3x3) executes 16 of the 36 multiplies
+            # F(2x2,3x3) executes 16 of the 36 multiplies of 4 outputs, F(4x4,3x3) 36 of the 144 multiplies of 16 outputs
+            ex = alg * (0.25 if kern.startswith("conv_wino4") else 16.0 / 36.0 if kern.startswith("conv_wino") else 1.0)
             row.update(bound="mfma", achieved=round(ex, 2), unit="TFLOP/s", frac=round(ex / PEAK_F32_MFMA_TFLOPS, 4), algorithmic_tflops=round(alg, 2))
         rows.append(row)
     dom = rows[0]

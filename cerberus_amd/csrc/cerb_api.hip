@@ -22,6 +22,7 @@ hipError_t cerb_launch_wino(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino3(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino16(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino16d(ConvParams p, hipStream_t st);
+hipError_t cerb_launch_wino4(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_upsample2_add(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C,
                                      long long prev_gs, const int* roi, hipStream_t st);
 extern "C" int cerb_conv_chunk(int ks, int stride);
@@ -143,6 +144,8 @@ struct PackedConv {
     void* wino3 = nullptr;  // device, same weights split into three bf16 planes (conv_wino3.hip, conv_algo 2), packed lazily
     float* wino16 = nullptr;  // device, the transformed weights in conv_wino16.hip's per-wave layout (conv_algo 3), packed lazily
     float* wino16d = nullptr; // device, conv_wino16d.hip's layout (conv_algo 4: 16-channel chunks), packed lazily
+    float* wino4 = nullptr;   // device, F(4x4,3x3) transformed weights in conv_wino4.hip's layout (conv_algo 5), packed lazily from host_w
+    std::vector<float> host_w;  // BN-folded 3x3 weights [G][cout][cin][9] kept on the host for the lazily packed Winograd variants
     std::vector<float> host_u;  // fp32 transformed weights kept on the host until conv_algo 2 is first used
     float* b = nullptr;     // device
 };
@@ -404,6 +407,40 @@ static void pack_wino16d(const float* U, int cout, int cin, std::vector<float>* 
                         }
 }
 
+// Winograd F(4x4,3x3) filter transform U = G g G^T for the points (0, 1, -1, 2, -2, inf), in double, rounded once, in the layout
+// conv_wino4.hip streams: [cb][16-channel chunk][wave a][position xi = 6 ya + xb][lane][t]
+//   ->  U[xi] of W[cb*64 + 16 a + (lane & 15)][chunk*16 + 4 (lane >> 4) + t]
+static void pack_wino4(const float* w, int cout, int cin, std::vector<float>* out) {  // w: BN-folded [cout][cin][3][3]
+    static const double Gm[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                    {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
+    const int nchunk = cin / 16, ncb = cout / 64;
+    std::vector<float> U((size_t)cout * cin * 36);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            const float* g = w + ((size_t)co * cin + ci) * 9;
+            double t[6][3];
+            for (int a = 0; a < 6; ++a)
+                for (int x = 0; x < 3; ++x) t[a][x] = Gm[a][0] * (double)g[x] + Gm[a][1] * (double)g[3 + x] + Gm[a][2] * (double)g[6 + x];
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b)
+                    U[((size_t)co * cin + ci) * 36 + a * 6 + b] = (float)(t[a][0] * Gm[b][0] + t[a][1] * Gm[b][1] + t[a][2] * Gm[b][2]);
+        }
+    const size_t base = out->size();
+    out->resize(base + (size_t)cout * cin * 36);
+    float* o = out->data() + base;
+    size_t idx = 0;
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int a = 0; a < 4; ++a)
+                for (int xi = 0; xi < 36; ++xi)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int t = 0; t < 4; ++t) {
+                            const int co = cb * 64 + 16 * a + (lane & 15);
+                            const int ci = ch * 16 + 4 * (lane >> 4) + t;
+                            o[idx++] = U[((size_t)co * cin + ci) * 36 + xi];
+                        }
+}
+
 // conv_wino3.hip layout: [cb][chunk][a][b][K-step s2][plane][cout half s][lane][8 bf16]
 //   element i of lane (j, h) = plane(U[a][b] of W[cb*64 + 32 s + j][chunk*32 + 16 s2 + 8 h + i]),  planes = hi, mid, lo of the bf16x3 split
 static uint16_t bf16_rne(float x) {
@@ -471,7 +508,7 @@ static int make_conv(cerb_net* net, const std::string& name, const std::vector<s
     // one entry per group
     const int CB = cerb_conv_chunk(ks, stride);
     if (cout % 64 || cin % CB) return fail("conv " + name + ": unsupported channel counts");
-    std::vector<float> wp, bp, wwino, hu;
+    std::vector<float> wp, bp, wwino, hu, hw;
     const bool wino = (ks == 3 && stride == 1 && cin % 32 == 0);
     for (size_t g = 0; g < wkeys.size(); ++g) {
         const HostTensor* w;
@@ -481,7 +518,14 @@ static int make_conv(cerb_net* net, const std::string& name, const std::vector<s
         if (have_bn && bn_fold(net, bnkeys[g], cout, &f)) return 1;
         if (net->fold_bn) {  // handles packed for training lay their weights out on the device (below)
             pack_conv(w->data.data(), have_bn ? f.scale.data() : nullptr, cout, cin, ks, CB, &wp);
-            if (wino) pack_wino(w->data.data(), have_bn ? f.scale.data() : nullptr, cout, cin, &wwino, &hu);
+            if (wino) {
+                pack_wino(w->data.data(), have_bn ? f.scale.data() : nullptr, cout, cin, &wwino, &hu);
+                const size_t b0 = hw.size();
+                hw.insert(hw.end(), w->data.begin(), w->data.end());
+                if (have_bn)
+                    for (int co = 0; co < cout; ++co)
+                        for (size_t e = 0; e < (size_t)cin * 9; ++e) hw[b0 + (size_t)co * cin * 9 + e] *= f.scale[co];
+            }
         }
         const HostTensor* b = nullptr;
         if (!bkeys.empty() && get(net, bkeys[g], {cout}, &b)) return 1;
@@ -523,6 +567,7 @@ static int make_conv(cerb_net* net, const std::string& name, const std::vector<s
         if (upload(net, wp, &pc.w)) return 1;
         if (wino && upload(net, wwino, &pc.wino)) return 1;
         pc.host_u.swap(hu);
+        pc.host_w.swap(hw);
     } else {
         // packed on the device from the raw copy (pack_kernels.hip): nothing but the state-dict tensors crosses PCIe after an optimiser step.
         // Data gradient of a 3x3 pad-1 conv: dx = conv(dy, W') with W'[ci][co][ky][kx] = W[co][ci][2 - ky][2 - kx] -- the same Winograd conv
@@ -762,6 +807,31 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
         p.w_gs = (long long)c.cout * c.cin * 16 * 3 * 2;  // bytes per group
         if (prof_begin(net, name, resid ? "conv_wino3<bf16x3,8x16,res>" : "conv_wino3<bf16x3,8x16>", fl, st)) return 1;
         HIP_OK(cerb_launch_wino3(p, st));
+        if (prof_end(net, st)) return 1;
+        return 0;
+    }
+    if (net->conv_algo == 5 && c.wino && mode == 0 && !it->second.host_w.empty()) {
+        PackedConv& cm = it->second;
+        if (!cm.wino4) {  // first use: F(4x4,3x3) filter transform on the host, conv_wino4.hip's per-wave layout, upload
+            std::vector<float> w4;
+            for (int g = 0; g < cm.groups; ++g) pack_wino4(cm.host_w.data() + (size_t)g * cm.cout * cm.cin * 9, cm.cout, cm.cin, &w4);
+            void* d = nullptr;
+            HIP_OK(hipMalloc(&d, w4.size() * 4));
+            net->dev_allocs.push_back(d);
+            net->dev_alloc_bytes.push_back(w4.size() * 4);
+            HIP_OK(hipMemcpy(d, w4.data(), w4.size() * 4, hipMemcpyHostToDevice));
+            cm.wino4 = (float*)d;
+        }
+        p.wpack = cm.wino4;
+        p.w_gs = (long long)c.cout * c.cin * 36;
+        double fl_done = fl;
+        if (roi && roi[1] > roi[0] && roi[3] > roi[2]) {  // region of interest: report the work of the 16 x 16 blocks that run
+            p.roi_y0 = roi[0]; p.roi_y1 = roi[1]; p.roi_x0 = roi[2]; p.roi_x1 = roi[3];
+            const double ty = (roi[1] + 15) / 16 - roi[0] / 16, tx = (roi[3] + 15) / 16 - roi[2] / 16;
+            fl_done = fl * (ty * 16.0 * tx * 16.0) / ((double)p.Ho * p.Wo);
+        }
+        if (prof_begin(net, name, resid ? "conv_wino4<f4x4,16x16x2,res>" : "conv_wino4<f4x4,16x16x2>", fl_done, st)) return 1;
+        HIP_OK(cerb_launch_wino4(p, st));
         if (prof_end(net, st)) return 1;
         return 0;
     }
@@ -1646,8 +1716,8 @@ extern "C" int cerb_net_set_crop_roi(cerb_net* net, int enable) {
 }
 extern "C" int cerb_net_set_conv_algo(cerb_net* net, int algo) {
     if (!net) return fail("cerb_net_set_conv_algo: null handle");
-    if (algo < 0 || algo > 4)
-        return fail("cerb_net_set_conv_algo: algo must be 0 (direct), 1 (Winograd fp32), 2 (Winograd, bf16x3 products), 3 (Winograd fp32, 16-channel waves) or 4 (3 with double-buffered 16-channel chunks)");
+    if (algo < 0 || algo > 5)
+        return fail("cerb_net_set_conv_algo: algo must be 0 (direct), 1 (Winograd F(2x2) fp32), 2 (F(2x2), bf16x3 products), 3 (F(2x2), 16-channel waves), 4 (3 with double-buffered 16-channel chunks) or 5 (Winograd F(4x4) fp32)");
     net->conv_algo = algo;
     return 0;
 }

@@ -1,0 +1,438 @@
+// conv_wino4.hip -- 3x3 stride-1 convolution (+ folded BN bias, residual, ReLU) as Winograd F(4x4, 3x3) on the gfx950 fp32 matrix
+// cores (cerb_net_set_conv_algo(5)).  36 products per 4x4 output pixels and input channel instead of 64 for F(2x2) (144 direct): 1.78x
+// fewer matrix instructions than conv_wino.hip AND 1.78x less input-transform volume per output pixel (a 6x6 patch per 16 outputs
+// instead of a 4x4 patch per 4) -- the input path is what bounded the three F(2x2) kernels.  Products are exact fp32
+// FMAs; the transforms (points 0, +-1, +-2, inf) move the probability maps by < 4e-6 against an fp64 evaluation of the network
+// (tests/tools/dev_wino4_numerics.py), 1.5x the direct fp32 convolution's own distance.
+//
+//   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A        d 6x6 input patch, g 3x3 filter (BN folded), Y 4x4 outputs
+//
+// Work decomposition (conv_wino16d.hip's, grown to 36 positions):
+//   * item = two 16x16-pixel blocks (2 x 16 tiles of 4x4 outputs) x 64 output channels; persistent workgroups of 4 waves, ONE per CU;
+//   * a wave owns ALL 36 positions of 16 output channels for the 32 tiles on v_mfma_f32_16x16x4_f32: 36 x 2 x 4 = 288 accumulator
+//     registers -- one wave per SIMD, accumulators in the AccVGPR half of the 512-register file -- so every weight register feeds two
+//     matrix instructions (a 16-tile item would need 1 KiB of weights per wave per 128 cycles = the L2's whole bandwidth) and the
+//     output transform A^T M A is additions in registers: no exchange through LDS;
+//   * 16-channel chunks, V tile [36][32 tiles][16 ch] = 72 KiB, double-buffered (144 of the CU's 160 KiB): one barrier per chunk;
+//     16-byte slots of a tile's channel vector are XOR-swizzled by the tile index so that ds_read_b128 of 16 tiles x 4 k-slots and the
+//     8-byte transform writes are bank-conflict-free without padding;
+//   * thread = (tile, channel pair): the raw 6x6 patch is 36 float2 loaded straight from global memory (uniform offsets ride in the
+//     buffer instruction's scalar offset), transformed in place one 1-D pass per step in the shadow of the matrix pipe.
+// Reference layers: models/utils/conv_layers.py:24-60 (_ConvLayer) and models/backbone/resnet.py:81-97 (BasicBlock).
+#include <type_traits>
+
+#include "cerb_common.h"
+
+namespace {
+constexpr int NPOS = 36;
+constexpr int NT = 32;                        // tiles per item: two blocks of 4x4 tiles
+constexpr int BLK = 16;                       // a block is 16x16 output pixels
+constexpr int CB = 16;                        // input channels per LDS pass
+constexpr int V_FLOATS = NPOS * NT * CB;      // one V buffer: 72 KiB
+constexpr int LDS_BYTES = 2 * V_FLOATS * 4;   // double-buffered: 144 KiB
+constexpr int NS = NPOS;                      // steps per chunk: one position each (one 16-byte weight load, two ds_read_b128, 8 MFMAs)
+constexpr int RING = 12;                      // weight operand slots (NS % RING == 0: the slot of a step does not depend on the chunk)
+#ifndef W4_WD
+#define W4_WD 8
+#endif
+constexpr int WD = W4_WD;                     // weight prefetch distance in steps
+#ifndef W4_WB
+#define W4_WB 4
+#endif
+constexpr int WB = W4_WB;                     // weight burst size in steps
+#ifndef W4_PL
+#define W4_PL 3
+#endif
+constexpr int PL = W4_PL;                     // patch loads issued per step
+#ifndef W4_P0
+#define W4_P0 0
+#endif
+constexpr int P0 = W4_P0;                     // first step that issues patch loads
+#ifndef W4_TQ
+#define W4_TQ 18
+#endif
+constexpr int TQ = W4_TQ;                     // the next chunk's patch is masked at TQ, transformed at TQ+1 .. TQ+12, written at TQ+7 .. TQ+12
+static_assert(NS % RING == 0 && WD + WB <= RING && WD % WB == 0 && NS % WB == 0, "weight ring");
+static_assert(P0 + (36 + PL - 1) / PL <= TQ && TQ + 13 < NS, "the patch must be requested before its transform starts");
+constexpr int BIAS_XI = 7;                    // A^T[i][1] A[1][j] = 1 for all 16 outputs: the bias enters through position (1, 1)
+constexpr int CHUNK_W_BYTES = NPOS * 4 * 1024;  // packed weights of one (cout block, 16-channel chunk): 144 KiB
+constexpr int WAVE_W_BYTES = NPOS * 1024;       // one wave's share: 36 steps x 1 KiB
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, soff, 0);
+    asm volatile("s_nop 1");  // gfx950 store hazard, see conv_wino.hip buf_store / tests/test_isa_hazard.py
+    __builtin_amdgcn_sched_barrier(0);
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, soff, 0));
+}
+
+struct Blk {
+    int n, by, bx;  // image, block row / column inside the launch's block grid
+};
+struct Item {
+    int g, cb;
+    Blk b0, b1;  // (no array: a dynamically indexed member would keep the whole struct in scratch, i.e. in vector registers)
+    int nvalid;  // 2, or 1 when the launch has an odd number of blocks and this is the last pair (block 1 repeats block 0, stores dropped)
+};
+}  // namespace
+
+template <bool HAS_RES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino4_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int a = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's 16 output channels of the item's 64; input path: block a >> 1
+    const int m = lane & 15;                                 // MFMA row (cout) / column (tile within a block)
+    const int ks = lane >> 4;                                // k-slot
+
+    const int ncb = p.Cout >> 6;
+    const int nblk = p.N * p.tiles_y * p.tiles_x;  // blocks per group
+    const int npair = (nblk + 1) >> 1;
+    const int per_group = npair * ncb;
+    const int total = per_group * p.groups;
+    const int nchunk = p.Cin / CB;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int base_cnt = total / (int)gridDim.x, rem_cnt = total % (int)gridDim.x;
+    int item = lb * base_cnt + min(lb, rem_cnt);
+    const int item_end = item + base_cnt + (lb < rem_cnt ? 1 : 0);
+    if (item >= item_end) return;
+
+    auto decode_blk = [&](int id) {
+        Blk b;
+        b.bx = id % p.tiles_x;
+        const int r = id / p.tiles_x;
+        b.by = r % p.tiles_y;
+        b.n = r / p.tiles_y;
+        return b;
+    };
+    auto decode = [&](int it) {
+        Item w;
+        w.g = it / per_group;
+        const int L = it - w.g * per_group;
+        w.cb = L % ncb;
+        const int pr = L / ncb;
+        w.nvalid = (2 * pr + 1 < nblk) ? 2 : 1;
+        w.b0 = decode_blk(2 * pr);
+        w.b1 = w.nvalid == 2 ? decode_blk(2 * pr + 1) : w.b0;
+        return w;
+    };
+    auto oy0 = [&](const Blk& b) { return (b.by + p.ty_off) * BLK; };
+    auto ox0 = [&](const Blk& b) { return (b.bx + p.tx_off) * BLK; };
+    auto in_base = [&](int g, const Blk& b) {
+        return reinterpret_cast<const char*>(p.in + g * p.in_gs) + ((((long long)b.n * p.H + (oy0(b) - 1)) * p.W + (ox0(b) - 1)) * p.Cin) * 4;
+    };
+    auto w_base = [&](const Item& w) {
+        return reinterpret_cast<const char*>(p.wpack + w.g * p.w_gs) + (long long)w.cb * nchunk * CHUNK_W_BYTES + a * WAVE_W_BYTES;
+    };
+    auto hangs_over = [&](const Blk& b) { return oy0(b) + BLK > p.H || ox0(b) + BLK > p.W; };
+    auto edge_bits = [&](const Blk& b) {  // 1 top, 2 bottom, 4 left, 8 right
+        return (oy0(b) == 0 ? 1 : 0) | (oy0(b) + BLK == p.H ? 2 : 0) | (ox0(b) == 0 ? 4 : 0) | (ox0(b) + BLK == p.W ? 8 : 0);
+    };
+
+    // ---- lane invariants ---------------------------------------------------------------------------------------------------
+    // input transform: thread = (tile t of the item, channel pair c); tiles 0..15 are block 0 (waves 0, 1), 16..31 block 1 (waves 2, 3)
+    const int t = tid >> 3, c = tid & 7, tm = t & 15, tty = tm >> 2, ttx = tm & 3;
+    const bool second = (a >> 1) != 0;
+    auto mine = [&](const Item& wi) {
+        Blk b;
+        b.n = second ? wi.b1.n : wi.b0.n;
+        b.by = second ? wi.b1.by : wi.b0.by;
+        b.bx = second ? wi.b1.bx : wi.b0.bx;
+        return b;
+    };
+    const unsigned ioff = (unsigned)((((4 * tty) * p.W + 4 * ttx) * p.Cin + 2 * c) * 4);
+    const int vw = t * CB + (((c >> 1) ^ ((tm & 8) ? 3 : 0)) << 2) + 2 * (c & 1);  // V write position (floats); position xi adds xi*NT*CB
+    const int vr = m * CB + ((ks ^ ((m & 8) ? 3 : 0)) << 2);                       // V read position, block 0; block 1 adds 16*CB
+    const unsigned wlane = (unsigned)lane * 16u;
+    const int rowb = p.W * p.Cin * 4, pixb = p.Cin * 4;
+
+    f32x2 d[6][6];  // raw patch of the NEXT chunk (two channels), transformed in place in the shadow of the matrix pipe
+    auto issue = [&](__amdgpu_buffer_rsrc_t r, int chunk_off, int k) { d[k / 6][k % 6] = buf_load2(r, ioff, chunk_off + (k / 6) * rowb + (k % 6) * pixb); };
+    const bool lane_top = (tty == 0), lane_bot = (tty == 3), lane_left = (ttx == 0), lane_right = (ttx == 3);
+    auto mask_edges = [&](int bits) {
+        const f32x2 z = {0.f, 0.f};
+        if (bits & 3) {
+            const bool zt = (bits & 1) && lane_top, zb = (bits & 2) && lane_bot;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                d[0][q] = zt ? z : d[0][q];
+                d[5][q] = zb ? z : d[5][q];
+            }
+        }
+        if (bits & 12) {
+            const bool zl = (bits & 4) && lane_left, zr = (bits & 8) && lane_right;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                d[r][0] = zl ? z : d[r][0];
+                d[r][5] = zr ? z : d[r][5];
+            }
+        }
+    };
+    auto mask_border = [&](const Blk& b) {
+        const f32x2 z = {0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int gy = oy0(b) - 1 + 4 * tty + r, gx = ox0(b) - 1 + 4 * ttx + q;
+                const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                d[r][q] = ok ? d[r][q] : z;
+            }
+    };
+    // B^T x for the points (0, 1, -1, 2, -2, inf), in place: 12 packed operations
+    auto bt6 = [&](f32x2& x0, f32x2& x1, f32x2& x2, f32x2& x3, f32x2& x4, f32x2& x5) {
+        const f32x2 t0 = x4 - 4.f * x2, t1 = x3 - 4.f * x1;
+        const f32x2 u0 = x4 - x2, u1 = x3 - x1;
+        x0 = (4.f * x0 + x4) - 5.f * x2;
+        x5 = (4.f * x1 + x5) - 5.f * x3;
+        x1 = t0 + t1;
+        x2 = t0 - t1;
+        x3 = u0 + 2.f * u1;
+        x4 = u0 - 2.f * u1;
+    };
+    auto pass_v = [&](int q) { bt6(d[0][q], d[1][q], d[2][q], d[3][q], d[4][q], d[5][q]); };  // down column q
+    auto pass_h = [&](int r) { bt6(d[r][0], d[r][1], d[r][2], d[r][3], d[r][4], d[r][5]); };  // along row r
+    auto write_row = [&](int buf, int r) {
+#pragma unroll
+        for (int b = 0; b < 6; ++b) *reinterpret_cast<f32x2*>(lds + buf * V_FLOATS + (r * 6 + b) * NT * CB + vw) = d[r][b];
+    };
+
+    // ---- prologue ------------------------------------------------------------------------------------------------------------
+    Item w = decode(item);
+    {
+        const Blk b0_ = mine(w);
+        const __amdgpu_buffer_rsrc_t r0 = make_rsrc(in_base(w.g, b0_));
+#pragma unroll
+        for (int k = 0; k < 36; ++k) issue(r0, 0, k);
+        if (hangs_over(b0_)) mask_border(b0_);
+        else mask_edges(edge_bits(b0_));
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) pass_v(q);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        pass_h(r);
+        write_row(0, r);
+    }
+    int vbuf = 0;  // the buffer the CURRENT chunk reads; the next chunk's patch goes to vbuf ^ 1
+    __syncthreads();
+    __amdgpu_buffer_rsrc_t rw = make_rsrc(w_base(w));
+    // Weight stream in bursts (conv_wino16d.hip): every WB steps the operands of steps q + WD .. q + WD + WB - 1 are requested at once; the
+    // operand of step q lives in slot q % RING.  Steps past the chunk's 36 belong to the next chunk, or to the next item's first chunk.
+    f32x4 wq[RING];
+#pragma unroll
+    for (int dd = 0; dd < WD; ++dd) wq[dd] = buf_load(rw, wlane, dd * 1024);
+    f32x4 bnext;
+    auto load_bias = [&](const Item& wi) {
+        const float* bias = p.bias + wi.g * p.bias_gs + wi.cb * 64 + 16 * a;
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, 64, 0x00020000);
+        bnext = buf_load(rb, (unsigned)ks * 16u, 0);
+    };
+    load_bias(w);
+
+    for (;;) {
+        f32x4 acc[NPOS][2];
+        const bool more_items = item + 1 < item_end;
+        const Item wnx = more_items ? decode(item + 1) : w;
+        const __amdgpu_buffer_rsrc_t rw_nx = more_items ? make_rsrc(w_base(wnx)) : rw;
+        const Blk bcur = mine(w), bnx = mine(wnx);
+        const bool mask_cur = hangs_over(bcur), mask_next = hangs_over(bnx);
+        const int edge_next = edge_bits(bnx), edge_cur = edge_bits(bcur);
+        const char* in_cur = in_base(w.g, bcur);
+        const char* in_nx = in_base(wnx.g, bnx);
+        acc[BIAS_XI][0] = bnext;
+        acc[BIAS_XI][1] = bnext;
+
+        auto chunk = [&](auto first_tag, int ch) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const bool last_ch = (ch == nchunk - 1);
+            const Blk bp_ = last_ch ? bnx : bcur;
+            const bool mask_nx = last_ch ? mask_next : mask_cur;
+            const int edge_nx = last_ch ? edge_next : edge_cur;
+            const __amdgpu_buffer_rsrc_t r_stage = make_rsrc(last_ch ? in_nx : in_cur);
+            const int stage_off = (last_ch ? 0 : ch + 1) * (CB * 4);
+            const int wcur_off = ch * CHUNK_W_BYTES;
+            const __amdgpu_buffer_rsrc_t rw_over = last_ch ? rw_nx : rw;
+            const int wover_off = last_ch ? 0 : (ch + 1) * CHUNK_W_BYTES;
+            const float* vsrc = lds + vbuf * V_FLOATS + vr;
+            const int wbuf = vbuf ^ 1;
+
+            f32x4 bb[2][2];  // B operands (blocks 0, 1) of step q in bb[q & 1]
+            bb[0][0] = *reinterpret_cast<const f32x4*>(vsrc);
+            bb[0][1] = *reinterpret_cast<const f32x4*>(vsrc + 16 * CB);
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const int xi = q;
+#ifndef W4_ABL_NOWLOAD
+                if (q % WB == 0) {
+#pragma unroll
+                    for (int dd = q + WD; dd < q + WD + WB; ++dd) {
+                        if (dd < NS) wq[dd % RING] = buf_load(rw, wlane, wcur_off + dd * 1024);
+                        else wq[(dd - NS) % RING] = buf_load(rw_over, wlane, wover_off + (dd - NS) * 1024);
+                    }
+                }
+#endif
+                if (q + 1 < NS) {
+                    bb[(q + 1) & 1][0] = *reinterpret_cast<const f32x4*>(vsrc + (q + 1) * NT * CB);
+                    bb[(q + 1) & 1][1] = *reinterpret_cast<const f32x4*>(vsrc + (q + 1) * NT * CB + 16 * CB);
+                }
+#ifndef W4_ABL_NOPATCH
+                if (q >= P0 && (q - P0) * PL < 36) {  // next chunk's patch: PL loads per step
+#pragma unroll
+                    for (int u = 0; u < PL; ++u)
+                        if ((q - P0) * PL + u < 36) issue(r_stage, stage_off, (q - P0) * PL + u);
+                }
+#endif
+                // the next chunk's patch landed: mask, B^T d B (one 1-D pass per step) and the V writes into the OTHER buffer
+                if (q == TQ) {
+                    if (mask_nx) mask_border(bp_);
+                    else if (edge_nx) mask_edges(edge_nx);
+                }
+#ifndef W4_ABL_NOXF
+                if (q > TQ && q <= TQ + 6) pass_v(q - TQ - 1);
+                if (q > TQ + 6 && q <= TQ + 12) pass_h(q - TQ - 7);
+#endif
+#ifndef W4_ABL_NOVWRITE
+                if (q > TQ + 6 && q <= TQ + 12) write_row(wbuf, q - TQ - 7);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4 av = wq[q % RING];
+                const f32x4 b0 = bb[q & 1][0], b1 = bb[q & 1][1];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    if (FIRST && tt == 0 && xi != BIAS_XI) {
+                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt], b0[tt], z, 0, 0, 0);
+                        acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt], b1[tt], z, 0, 0, 0);
+                    } else {
+                        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt], b0[tt], acc[xi][0], 0, 0, 0);
+                        acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt], b1[tt], acc[xi][1], 0, 0, 0);
+                    }
+                }
+            }
+#ifndef W4_ABL_NOBAR
+            __syncthreads();  // everybody has read this chunk's V and written the next one's
+#endif
+            vbuf ^= 1;
+        };
+        chunk(std::true_type{}, 0);
+        for (int ch = 1; ch < nchunk; ++ch) chunk(std::false_type{}, ch);
+
+        // ---- output transform A^T M A, entirely in registers; lane (m, ks): tile m of each block, channels 4 ks .. + 3 of the wave's 16 -------
+        load_bias(wnx);  // before this item's stores enter the in-order vmcnt queue (the next item's first WD steps already went out)
+        {
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));  // recomputed per item: keeps these out of the MFMA phase's register budget
+            const int mo = lane_o & 15, kso = lane_o >> 4;
+            const int ry = 4 * (mo >> 2), rx = 4 * (mo & 3);  // pixel of output (0, 0) of the lane's tile inside its block
+            const unsigned ooff = (unsigned)(((ry * p.Wo + rx) * p.Cout + 4 * kso) * 4);
+            const int orow = p.Wo * p.Cout * 4, opix = p.Cout * 4;
+            const float floor_ = p.relu ? 0.f : -3.402823466e38f;
+            const unsigned span = (unsigned)(BLK * p.Wo * p.Cout * 4);
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                const Blk bo = tb ? w.b1 : w.b0;
+                const int by0 = oy0(bo), bx0 = ox0(bo);
+                const long long origin = (((long long)bo.n * p.Ho + by0) * p.Wo + bx0) * p.Cout + w.cb * 64 + 16 * a;  // floats, uniform
+                const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + w.g * p.out_gs + origin, 0, span, 0x00020000);
+                const bool partial = (by0 + BLK > p.Ho) || (bx0 + BLK > p.Wo);
+                const bool dead = (tb == 1 && w.nvalid == 1);
+                unsigned vo[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = !dead && (!partial || ((by0 + ry + i < p.Ho) && (bx0 + rx + j < p.Wo)));
+                        vo[i][j] = ok ? ooff : 0x80000000u;  // out-of-range offsets: the hardware drops the store / returns 0
+                    }
+                // vertical pass: T[i][b] = sum_a A^T[i][a] M[a][b]
+                f32x4 T[4][6];
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    const f32x4 m0 = acc[0 * 6 + b][tb], m1 = acc[1 * 6 + b][tb], m2 = acc[2 * 6 + b][tb], m3 = acc[3 * 6 + b][tb],
+                                m4 = acc[4 * 6 + b][tb], m5 = acc[5 * 6 + b][tb];
+                    const f32x4 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                    T[0][b] = m0 + s1 + s2;
+                    T[1][b] = d1 + 2.f * d2;
+                    T[2][b] = s1 + 4.f * s2;
+                    T[3][b] = (d1 + 8.f * d2) + m5;
+                }
+                f32x4 res[4][4];
+                if (HAS_RES) {
+                    const __amdgpu_buffer_rsrc_t r_res =
+                        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid + w.g * p.resid_gs + origin), 0, span, 0x00020000);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) res[i][j] = buf_load(r_res, vo[i][j], i * orow + j * opix);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 s1 = T[i][1] + T[i][2], d1 = T[i][1] - T[i][2], s2 = T[i][3] + T[i][4], d2 = T[i][3] - T[i][4];
+                    f32x4 y[4];
+                    y[0] = T[i][0] + s1 + s2;
+                    y[1] = d1 + 2.f * d2;
+                    y[2] = s1 + 4.f * s2;
+                    y[3] = (d1 + 8.f * d2) + T[i][5];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 o = HAS_RES ? y[j] + res[i][j] : y[j];
+                        o[0] = fmaxf(o[0], floor_);
+                        o[1] = fmaxf(o[1], floor_);
+                        o[2] = fmaxf(o[2], floor_);
+                        o[3] = fmaxf(o[3], floor_);
+#ifndef W4_ABL_NOSTORE
+                        buf_store(o, r_out, vo[i][j], i * orow + j * opix);
+#else
+                        if (o[0] == 1.2345e-30f) buf_store(o, r_out, vo[i][j], i * orow + j * opix);
+#endif
+                    }
+                }
+            }
+        }
+        if (!more_items) break;
+        ++item;
+        w = wnx;
+        rw = rw_nx;
+    }
+}
+
+template <bool HAS_RES>
+static hipError_t launch_wino4(ConvParams p, hipStream_t st) {
+    p.tiles_x = (p.Wo + BLK - 1) / BLK;  // blocks, not tiles
+    p.tiles_y = (p.Ho + BLK - 1) / BLK;
+    p.ty_off = p.tx_off = 0;
+    if (p.roi_y1 > p.roi_y0 && p.roi_x1 > p.roi_x0) {
+        p.ty_off = p.roi_y0 / BLK;
+        p.tx_off = p.roi_x0 / BLK;
+        p.tiles_y = (p.roi_y1 + BLK - 1) / BLK - p.ty_off;
+        p.tiles_x = (p.roi_x1 + BLK - 1) / BLK - p.tx_off;
+    }
+    const long long nblk = (long long)p.N * p.tiles_x * p.tiles_y;
+    const long long items = (long long)p.groups * ((nblk + 1) / 2) * (p.Cout / 64);
+    auto kern = conv_wino4_kernel<HAS_RES>;
+    static bool attr_done[64] = {};
+    if (cerb_attr_needed(attr_done)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
+    }
+    long long grid = 256;  // persistent: one workgroup per CU
+    if (grid > items) grid = items;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS_BYTES, st, p);
+    return hipGetLastError();
+}
+
+hipError_t cerb_launch_wino4(ConvParams p, hipStream_t st) {
+    if (p.Cin % CB || p.Cout % 64) return hipErrorInvalidValue;
+    return p.resid ? launch_wino4<true>(p, st) : launch_wino4<false>(p, st);
+}

@@ -269,7 +269,7 @@ def test_small_feature_maps_patch_class_crop(full_model, hw):
     assert (lg - rl).abs().max().item() < 2e-4
 
 
-@pytest.mark.parametrize("algo", [1, 0, 3, 4])
+@pytest.mark.parametrize("algo", [1, 0, 3, 4, 5])
 def test_forward_is_bitwise_reproducible(full_model, algo):
     """Races and un-padded hardware hazards show up as run-to-run differences long before they show up as large errors (the
     gfx950 buffer_store hazard of DESIGN par.4.1 did): the same batch through the same handle must give identical bits."""
@@ -289,6 +289,44 @@ def test_forward_is_bitwise_reproducible(full_model, algo):
                     assert torch.equal(ref[k], cur[k]), k
     finally:
         m.set_conv_algo(1)
+
+
+@pytest.mark.parametrize("tag", ["cfg2_all", "g448_all", "small96_all"])
+def test_wino4_algo_vs_reference_golden(golden_dir, tag):
+    """cerb_net_set_conv_algo(5): Winograd F(4x4,3x3) (conv_wino4.hip: 36 products per 16 outputs, transform points 0, +-1, +-2, inf)
+    against the reference's golden vectors at the same 1e-4 bar -- plain, residual, grouped, cropped (region-of-interest blocks),
+    odd-sized (blocks hanging over the image, odd block counts) launches -- and against algorithm 1 (F(2x2)): the two differ by the
+    transforms' rounding only, a few 1e-6 on the probability maps (tests/tools/dev_wino4_numerics.py)."""
+    g = np.load(os.path.join(golden_dir, "net_%s.npz" % tag))
+    tasks = [str(t) for t in g["tasks"]]
+    m, sd, kw = _model(tasks, int(g["weight_seed"]))
+    n, hw, osz = int(g["n"]), int(g["hw"]), int(g["out_shape"])
+    tiles = np.random.RandomState(int(g["tile_seed"])).randint(0, 256, (n, hw, hw, 3)).astype(np.uint8)
+    wino = infer_step(torch.from_numpy(tiles), m, osz, tasks)
+    m.set_conv_algo(5)
+    try:
+        out = infer_step(torch.from_numpy(tiles), m, osz, tasks)
+        m.profile(True)
+        m.infer_tiles(torch.from_numpy(tiles).cuda(), osz)
+        torch.cuda.synchronize()
+        kernels = {r[1] for r in m.profile_records()}
+        m.profile(False)
+    finally:
+        m.set_conv_algo(1)
+    assert any(k.startswith("conv_wino4") for k in kernels) and not any(k.startswith("conv_wino<") for k in kernels)
+    for k in out[0].keys():
+        a = np.stack([out[i][k] for i in range(n)])
+        b = np.stack([wino[i][k] for i in range(n)])
+        a4 = a[..., None] if a.ndim == 3 else a
+        key = "out_crops/" + k
+        ref = g[key] if key in g else g["out_full/" + k]
+        got = _crops(a4) if key in g else a4
+        if a.dtype == np.float32:
+            assert np.abs(got - ref).max() < PROB_TOL, k
+            assert np.abs(a - b).max() < 5e-5, k
+        else:
+            assert (got != ref).mean() < 1e-4, k
+            assert (a != b).mean() < 1e-4, k
 
 
 @pytest.mark.parametrize("algo", [3, 4])
