@@ -178,7 +178,7 @@ def train_leg(args, model, dev, dist, world, rank, sd=None, kw=None):
             if kern.startswith("bn_"):
                 row.update(bound="hbm", achieved=round(work / (ms * 1e-3) / 1e9, 1), unit="GB/s", frac=round(work / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
             elif work > 0:
-                ex = work / (ms * 1e-3) / 1e12 * (16.0 / 36.0 if kern.startswith("conv_wino") else 1.0)
+                ex = work / (ms * 1e-3) / 1e12 * (0.25 if kern.startswith("conv_wino4") else 16.0 / 36.0 if kern.startswith("conv_wino") else 1.0)
                 row.update(bound="mfma", achieved=round(ex, 2), unit="TFLOP/s", frac=round(ex / PEAK_F32_MFMA_TFLOPS, 4))
             fam_rows.append(row)
         dom = next((r for r in fam_rows if r["kernel"].startswith("wgrad")), fam_rows[0])
@@ -224,7 +224,9 @@ def train_leg(args, model, dev, dist, world, rank, sd=None, kw=None):
 # ---- kernel-family table of one batch step (per-launch HIP events on the launch stream, cerb_net_profile_*) ----------------------
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md
 XGMI_LINK_GBS = 153.0   # per peer link, SURVEY.md par.8e
-_SYMBOL = {"conv_wino<f2x2,8x16>": "void conv_wino_kernel<false>(ConvParams)",
+_SYMBOL = {"conv_wino4<f4x4,16x16x2>": "void conv_wino4_kernel<false>(ConvParams)",
+           "conv_wino4<f4x4,16x16x2,res>": "void conv_wino4_kernel<true>(ConvParams)",
+           "conv_wino<f2x2,8x16>": "void conv_wino_kernel<false>(ConvParams)",
            "conv_wino<f2x2,8x16,res>": "void conv_wino_kernel<true>(ConvParams)"}
 
 
@@ -278,8 +280,8 @@ def kernel_table(model, step, n_tiles):
             traffic_src = cand
             break
     # `achieved` / `frac`: the MFMA FLOPs the kernel EXECUTES per second against the dense fp32 MFMA peak (the share of the matrix
-    # pipe it fills).  The algorithmic (direct-convolution, SURVEY par.8d) rate is 36/16 of that for the Winograd kernel and is
-    # carried beside it: it can exceed the peak because F(2x2,3x3) skips 5/9 of the multiplies.
+    # pipe it fills).  The algorithmic (direct-convolution, SURVEY par.8d) rate is 4x that for the F(4x4,3x3) kernel (36/16 for
+    # F(2x2,3x3)) and is carried beside it: it can exceed the peak because Winograd skips 3/4 (5/9) of the multiplies.
     roofline = {
         "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": dom["frac"], "algorithmic_tflops": dom.get("algorithmic_tflops"),

@@ -196,7 +196,7 @@ struct cerb_net {
     bool profiling = false;
     int crop_roi = 1;   // cerb_net_set_crop_roi: decoders / heads only compute what the centre crop keeps (conv_algo 1)
     int head_algo = 1;  // cerb_net_set_head_algo: 1 = all dense heads in one grouped launch (default), 0 = one launch per head
-    int conv_algo = 1;  // cerb_net_set_conv_algo: 1 = Winograd F(2x2,3x3) for 3x3 stride-1 convs (default), 0 = direct implicit GEMM
+    int conv_algo = 6;  // cerb_net_set_conv_algo: 6 = Winograd F(4x4,3x3) / F(2x2,3x3) by launch size (default), 1 = F(2x2,3x3), 0 = direct implicit GEMM
     struct ProfRec { std::string name, kernel; double flops; hipEvent_t e0, e1; };
     std::vector<ProfRec> prof;
     size_t prof_n = 0;
@@ -810,7 +810,12 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
         if (prof_end(net, st)) return 1;
         return 0;
     }
-    if (net->conv_algo == 5 && c.wino && mode == 0 && !it->second.host_w.empty()) {
+    // conv_algo 6 (default): F(4x4,3x3) for maps of at least 32 x 32 pixels, F(2x2,3x3) below (the 16 x 16 level of a batch of 32
+    // 256-pixel tiles is 128 two-block items of conv_wino4 against 512 items of conv_wino: measured 0.21 ms against 0.146 ms).  The rule
+    // looks at the layer's geometry only -- never at the batch size or the region of interest -- so that a tile's values do not depend
+    // on what it is batched with (sharded == unsharded, cropped == full stay bitwise, tests/test_drivers_gpu.py, test_net_gpu.py).
+    const bool use_w4 = net->conv_algo == 5 || (net->conv_algo == 6 && (long long)p.Ho * p.Wo >= 1024);
+    if (use_w4 && c.wino && mode == 0 && !it->second.host_w.empty()) {
         PackedConv& cm = it->second;
         if (!cm.wino4) {  // first use: F(4x4,3x3) filter transform on the host, conv_wino4.hip's per-wave layout, upload
             std::vector<float> w4;
@@ -994,14 +999,20 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
         const bool use_roi = !dry && net->crop_roi && (net->conv_algo == 1 || net->conv_algo >= 3) && !any_logits && (out_h < H || out_w < W);
         if (use_roi) {
             int y0 = (int)((H - out_h) * 0.5), x0 = (int)((W - out_w) * 0.5), y1 = y0 + out_h, x1 = x0 + out_w;
+            // A Winograd tile mixes its WHOLE input patch into every output (the contributions of the pixels a 3x3 filter does not touch
+            // cancel only up to rounding), so each window is widened to whole 4x4 tiles (F(4x4); F(2x2)'s 2x2 tiles divide them) before
+            // the next one is derived from it: every tile that overlaps a window then reads nothing but valid producer pixels, and a
+            // tile's values do not depend on what the workspace held before (or on the batch it is computed with).
             for (int u = 3; u >= 0; --u) {
                 const int hh = hs[3 - u], ww = ws[3 - u];
-                auto grow = [&](int* r, int d) {
-                    r[0] = std::max(0, y0 - d); r[1] = std::min(hh, y1 + d); r[2] = std::max(0, x0 - d); r[3] = std::min(ww, x1 + d);
+                auto widen = [&](int* r, const int* in, int d) {  // in grown by d pixels, then out to multiples of 4, clamped to the map
+                    r[0] = std::max(0, (in[0] - d) & ~3); r[1] = std::min(hh, (in[1] + d + 3) & ~3);
+                    r[2] = std::max(0, (in[2] - d) & ~3); r[3] = std::min(ww, (in[3] + d + 3) & ~3);
                 };
-                grow(roi_out[u], 0);
-                grow(roi_mid[u], 1);
-                grow(roi_sum[u], 2);
+                const int win[4] = {y0, y1, x0, x1};
+                widen(roi_out[u], win, 0);
+                widen(roi_mid[u], roi_out[u], 1);
+                widen(roi_sum[u], roi_mid[u], 1);
                 // bilinear x2, align_corners = False: output o reads sources floor(o / 2 - 0.25) and the next one
                 y0 = std::max(0, roi_sum[u][0] / 2 - 1); y1 = std::min(hh / 2, (roi_sum[u][1] - 1) / 2 + 2);
                 x0 = std::max(0, roi_sum[u][2] / 2 - 1); x1 = std::min(ww / 2, (roi_sum[u][3] - 1) / 2 + 2);
@@ -1716,8 +1727,8 @@ extern "C" int cerb_net_set_crop_roi(cerb_net* net, int enable) {
 }
 extern "C" int cerb_net_set_conv_algo(cerb_net* net, int algo) {
     if (!net) return fail("cerb_net_set_conv_algo: null handle");
-    if (algo < 0 || algo > 5)
-        return fail("cerb_net_set_conv_algo: algo must be 0 (direct), 1 (Winograd F(2x2) fp32), 2 (F(2x2), bf16x3 products), 3 (F(2x2), 16-channel waves), 4 (3 with double-buffered 16-channel chunks) or 5 (Winograd F(4x4) fp32)");
+    if (algo < 0 || algo > 6)
+        return fail("cerb_net_set_conv_algo: algo must be 0 (direct), 1 (Winograd F(2x2) fp32), 2 (F(2x2), bf16x3 products), 3 (F(2x2), 16-channel waves), 4 (3 with double-buffered 16-channel chunks), 5 (Winograd F(4x4) fp32) or 6 (F(4x4) for maps of 32 x 32 pixels and more, else F(2x2): the default)");
     net->conv_algo = algo;
     return 0;
 }

@@ -30,8 +30,22 @@ constexpr int BLK = 16;                       // a block is 16x16 output pixels
 constexpr int CB = 16;                        // input channels per LDS pass
 constexpr int V_FLOATS = NPOS * NT * CB;      // one V buffer: 72 KiB
 constexpr int LDS_BYTES = 2 * V_FLOATS * 4;   // double-buffered: 144 KiB
+constexpr int OPX = 68;                       // output staging: floats per pixel (64 channels + 4: bank skew)
+static_assert(256 * OPX + 16 <= V_FLOATS, "a block's outputs are staged in one V buffer");
+#ifdef W4_PROF
+constexpr int PROF_BYTES = 16 * 40 * 8;
+#else
+constexpr int PROF_BYTES = 0;
+#endif
 constexpr int NS = NPOS;                      // steps per chunk: one position each (one 16-byte weight load, two ds_read_b128, 8 MFMAs)
-constexpr int RING = 12;                      // weight operand slots (NS % RING == 0: the slot of a step does not depend on the chunk)
+#ifndef W4_RING
+#define W4_RING 12
+#endif
+constexpr int RING = W4_RING;                 // weight operand slots (NS % RING == 0: the slot of a step does not depend on the chunk)
+#ifndef W4_PRE
+#define W4_PRE 8
+#endif
+constexpr int PRE = W4_PRE;                   // steps of the NEXT item whose weights are requested before an item's output stores
 #ifndef W4_WD
 #define W4_WD 8
 #endif
@@ -51,8 +65,11 @@ constexpr int P0 = W4_P0;                     // first step that issues patch lo
 #ifndef W4_TQ
 #define W4_TQ 18
 #endif
+#ifndef W4_STORE_AUX
+#define W4_STORE_AUX 0
+#endif
 constexpr int TQ = W4_TQ;                     // the next chunk's patch is masked at TQ, transformed at TQ+1 .. TQ+12, written at TQ+7 .. TQ+12
-static_assert(NS % RING == 0 && WD + WB <= RING && WD % WB == 0 && NS % WB == 0, "weight ring");
+static_assert(NS % RING == 0 && WD + WB <= RING && NS % WB == 0 && PRE >= WD && PRE <= RING, "weight ring");
 static_assert(P0 + (36 + PL - 1) / PL <= TQ && TQ + 13 < NS, "the patch must be requested before its transform starts");
 constexpr int BIAS_XI = 7;                    // A^T[i][1] A[1][j] = 1 for all 16 outputs: the bias enters through position (1, 1)
 constexpr int CHUNK_W_BYTES = NPOS * 4 * 1024;  // packed weights of one (cout block, 16-channel chunk): 144 KiB
@@ -66,7 +83,7 @@ __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, unsigned vof
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
 }
 __device__ __forceinline__ void buf_store(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, soff, W4_STORE_AUX);
     asm volatile("s_nop 1");  // gfx950 store hazard, see conv_wino.hip buf_store / tests/test_isa_hazard.py
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -75,6 +92,11 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, soff, 0));
 }
+
+#ifdef W4_PROF
+// developer instrumentation (scripts/dev_w4prof.py): wave 0 of workgroup W4_PROF stamps s_memtime at every step of its second item
+__device__ unsigned long long w4_prof_buf[16 * 40];
+#endif
 
 struct Blk {
     int n, by, bx;  // image, block row / column inside the launch's block grid
@@ -106,6 +128,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int item = lb * base_cnt + min(lb, rem_cnt);
     const int item_end = item + base_cnt + (lb < rem_cnt ? 1 : 0);
     if (item >= item_end) return;
+#ifdef W4_PROF
+    const int prof_item = item + 1;
+#endif
 
     auto decode_blk = [&](int id) {
         Blk b;
@@ -231,7 +256,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // operand of step q lives in slot q % RING.  Steps past the chunk's 36 belong to the next chunk, or to the next item's first chunk.
     f32x4 wq[RING];
 #pragma unroll
-    for (int dd = 0; dd < WD; ++dd) wq[dd] = buf_load(rw, wlane, dd * 1024);
+    for (int dd = 0; dd < PRE; ++dd) wq[dd] = buf_load(rw, wlane, dd * 1024);
     f32x4 bnext;
     auto load_bias = [&](const Item& wi) {
         const float* bias = p.bias + wi.g * p.bias_gs + wi.cb * 64 + 16 * a;
@@ -252,6 +277,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const char* in_nx = in_base(wnx.g, bnx);
         acc[BIAS_XI][0] = bnext;
         acc[BIAS_XI][1] = bnext;
+#ifdef W4_PROF
+        const bool prof_on = (blockIdx.x == W4_PROF) && a == 0 && (item == prof_item);
+#define W4_STAMP(k) do { if (prof_on && lane == 0) reinterpret_cast<unsigned long long*>(lds + 2 * V_FLOATS)[15 * 40 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define W4_STAMP(k) do { } while (0)
+#endif
 
         auto chunk = [&](auto first_tag, int ch) {
             constexpr bool FIRST = decltype(first_tag)::value;
@@ -259,8 +290,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const Blk bp_ = last_ch ? bnx : bcur;
             const bool mask_nx = last_ch ? mask_next : mask_cur;
             const int edge_nx = last_ch ? edge_next : edge_cur;
+#ifdef W4_ABL_PATCHHOT
+            const __amdgpu_buffer_rsrc_t r_stage = make_rsrc(reinterpret_cast<const char*>(p.in) + (blockIdx.x & 7) * 65536);  // cache-resident
+            const int stage_off = 0;
+#else
             const __amdgpu_buffer_rsrc_t r_stage = make_rsrc(last_ch ? in_nx : in_cur);
             const int stage_off = (last_ch ? 0 : ch + 1) * (CB * 4);
+#endif
             const int wcur_off = ch * CHUNK_W_BYTES;
             const __amdgpu_buffer_rsrc_t rw_over = last_ch ? rw_nx : rw;
             const int wover_off = last_ch ? 0 : (ch + 1) * CHUNK_W_BYTES;
@@ -273,10 +309,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
                 const int xi = q;
+#ifdef W4_PROF
+                if (prof_on && ch < 16 && lane == 0) reinterpret_cast<unsigned long long*>(lds + 2 * V_FLOATS)[ch * 40 + q] = __builtin_readcyclecounter();
+#endif
 #ifndef W4_ABL_NOWLOAD
                 if (q % WB == 0) {
 #pragma unroll
                     for (int dd = q + WD; dd < q + WD + WB; ++dd) {
+                        if (FIRST && dd < PRE) continue;  // requested before the previous item's stores (or in the prologue)
                         if (dd < NS) wq[dd % RING] = buf_load(rw, wlane, wcur_off + dd * 1024);
                         else wq[(dd - NS) % RING] = buf_load(rw_over, wlane, wover_off + (dd - NS) * 1024);
                     }
@@ -329,32 +369,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int ch = 1; ch < nchunk; ++ch) chunk(std::false_type{}, ch);
 
         // ---- output transform A^T M A, entirely in registers; lane (m, ks): tile m of each block, channels 4 ks .. + 3 of the wave's 16 -------
-        load_bias(wnx);  // before this item's stores enter the in-order vmcnt queue (the next item's first WD steps already went out)
+        // vmcnt retires in order across loads AND stores, and the stores' acknowledgements take microseconds: everything the next item
+        // needs during its first PRE steps is requested here, before this item's stores enter the queue (its steps 0 .. WD-1 went out
+        // during the last chunk).  The raw-patch registers are dead at this point, so the extra slots cost nothing in the steady state.
+        W4_STAMP(0);
+#pragma unroll
+        for (int dd = WD; dd < PRE; ++dd) wq[dd % RING] = buf_load(rw_nx, wlane, dd * 1024);
+        load_bias(wnx);
         {
+            // The wave's results are 64-byte pieces (16 channels) of pixels 4 apart: stored directly, one instruction touches 16 partial
+            // cache lines and takes ~300 cycles to issue, with the matrix pipe idle (measured: 8 k of an item's 80 k cycles).  The four
+            // waves therefore transpose each block through the V buffer the last chunk has finished with (64 KiB + skew of its 72):
+            // [pixel][64 channels], and store whole pixel rows -- 1 KiB contiguous (4 pixels x 256 bytes) per instruction.
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));  // recomputed per item: keeps these out of the MFMA phase's register budget
             const int mo = lane_o & 15, kso = lane_o >> 4;
-            const int ry = 4 * (mo >> 2), rx = 4 * (mo & 3);  // pixel of output (0, 0) of the lane's tile inside its block
-            const unsigned ooff = (unsigned)(((ry * p.Wo + rx) * p.Cout + 4 * kso) * 4);
+            float* stg = lds + (vbuf ^ 1) * V_FLOATS;
+            // write side: lane (tile mo, channel quad kso) owns pixels (4 ty + i, 4 tx + j); pixel stride 68 floats, 4 floats of skew per tile row
+            const int sw = ((64 * (mo >> 2) + 4 * (mo & 3)) * OPX + 4 * (mo >> 2) + 16 * a + 4 * kso);
+            // read side: wave a stores pixel rows 4 a .. 4 a + 3; lane = (pixel lane_o >> 4 of a group of four, 16-byte piece lane_o & 15)
+            const int sr = ((64 * a + (lane_o >> 4)) * OPX + 4 * a + 4 * (lane_o & 15));
             const int orow = p.Wo * p.Cout * 4, opix = p.Cout * 4;
+            const unsigned ooff = (unsigned)(((4 * a * p.Wo + (lane_o >> 4)) * p.Cout + 4 * (lane_o & 15)) * 4);
             const float floor_ = p.relu ? 0.f : -3.402823466e38f;
             const unsigned span = (unsigned)(BLK * p.Wo * p.Cout * 4);
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb) {
                 const Blk bo = tb ? w.b1 : w.b0;
                 const int by0 = oy0(bo), bx0 = ox0(bo);
-                const long long origin = (((long long)bo.n * p.Ho + by0) * p.Wo + bx0) * p.Cout + w.cb * 64 + 16 * a;  // floats, uniform
+                const long long origin = (((long long)bo.n * p.Ho + by0) * p.Wo + bx0) * p.Cout + w.cb * 64;  // floats, uniform
                 const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + w.g * p.out_gs + origin, 0, span, 0x00020000);
                 const bool partial = (by0 + BLK > p.Ho) || (bx0 + BLK > p.Wo);
                 const bool dead = (tb == 1 && w.nvalid == 1);
-                unsigned vo[4][4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool ok = !dead && (!partial || ((by0 + ry + i < p.Ho) && (bx0 + rx + j < p.Wo)));
-                        vo[i][j] = ok ? ooff : 0x80000000u;  // out-of-range offsets: the hardware drops the store / returns 0
-                    }
+                W4_STAMP(1 + 3 * tb);
                 // vertical pass: T[i][b] = sum_a A^T[i][a] M[a][b]
                 f32x4 T[4][6];
 #pragma unroll
@@ -367,39 +414,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     T[2][b] = s1 + 4.f * s2;
                     T[3][b] = (d1 + 8.f * d2) + m5;
                 }
-                f32x4 res[4][4];
+                W4_STAMP(2 + 3 * tb);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 s1 = T[i][1] + T[i][2], d1 = T[i][1] - T[i][2], s2 = T[i][3] + T[i][4], d2 = T[i][3] - T[i][4];
+                    *reinterpret_cast<f32x4*>(stg + sw + (16 * i + 0) * OPX) = T[i][0] + s1 + s2;
+                    *reinterpret_cast<f32x4*>(stg + sw + (16 * i + 1) * OPX) = d1 + 2.f * d2;
+                    *reinterpret_cast<f32x4*>(stg + sw + (16 * i + 2) * OPX) = s1 + 4.f * s2;
+                    *reinterpret_cast<f32x4*>(stg + sw + (16 * i + 3) * OPX) = (d1 + 8.f * d2) + T[i][5];
+                }
+                __syncthreads();
+                // 16 groups of four pixels per wave: row 4 a + (k >> 2), pixels 4 (k & 3) .. + 3
+                unsigned vo[4];
+#pragma unroll
+                for (int x4 = 0; x4 < 4; ++x4) {
+                    const bool ok = !dead && (!partial || (bx0 + 4 * x4 + (lane_o >> 4) < p.Wo));
+                    vo[x4] = ok ? ooff : 0x80000000u;  // out-of-range offsets: the hardware drops the store / returns 0
+                }
+                f32x4 res[16];
                 if (HAS_RES) {
                     const __amdgpu_buffer_rsrc_t r_res =
                         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid + w.g * p.resid_gs + origin), 0, span, 0x00020000);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) res[i][j] = buf_load(r_res, vo[i][j], i * orow + j * opix);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x4 s1 = T[i][1] + T[i][2], d1 = T[i][1] - T[i][2], s2 = T[i][3] + T[i][4], d2 = T[i][3] - T[i][4];
-                    f32x4 y[4];
-                    y[0] = T[i][0] + s1 + s2;
-                    y[1] = d1 + 2.f * d2;
-                    y[2] = s1 + 4.f * s2;
-                    y[3] = (d1 + 8.f * d2) + T[i][5];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        f32x4 o = HAS_RES ? y[j] + res[i][j] : y[j];
-                        o[0] = fmaxf(o[0], floor_);
-                        o[1] = fmaxf(o[1], floor_);
-                        o[2] = fmaxf(o[2], floor_);
-                        o[3] = fmaxf(o[3], floor_);
-#ifndef W4_ABL_NOSTORE
-                        buf_store(o, r_out, vo[i][j], i * orow + j * opix);
-#else
-                        if (o[0] == 1.2345e-30f) buf_store(o, r_out, vo[i][j], i * orow + j * opix);
-#endif
+                    for (int k = 0; k < 16; ++k) {
+                        const bool rowok = !partial || (by0 + 4 * a + (k >> 2) < p.Ho);
+                        res[k] = buf_load(r_res, rowok ? vo[k & 3] : 0x80000000u, (k >> 2) * orow + 4 * (k & 3) * opix);
                     }
                 }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    f32x4 o = *reinterpret_cast<const f32x4*>(stg + sr + (16 * (k >> 2) + 4 * (k & 3)) * OPX);
+                    if (HAS_RES) o = o + res[k];
+                    o[0] = fmaxf(o[0], floor_);
+                    o[1] = fmaxf(o[1], floor_);
+                    o[2] = fmaxf(o[2], floor_);
+                    o[3] = fmaxf(o[3], floor_);
+                    const bool rowok = !partial || (by0 + 4 * a + (k >> 2) < p.Ho);
+#ifndef W4_ABL_NOSTORE
+                    buf_store(o, r_out, rowok ? vo[k & 3] : 0x80000000u, (k >> 2) * orow + 4 * (k & 3) * opix);
+#else
+                    if (o[0] == 1.2345e-30f) buf_store(o, r_out, rowok ? vo[k & 3] : 0x80000000u, (k >> 2) * orow + 4 * (k & 3) * opix);
+#endif
+                }
+                __syncthreads();  // the staging buffer is rewritten by the next block, then by the next item's second chunk
             }
         }
+#ifdef W4_PROF
+        W4_STAMP(7);
+        if (prof_on) {
+            __builtin_amdgcn_s_waitcnt(0);
+            W4_STAMP(8);
+            if (lane == 0) reinterpret_cast<unsigned long long*>(lds + 2 * V_FLOATS)[(nchunk < 16 ? nchunk : 15) * 40 + 39] = __builtin_readcyclecounter();
+            __builtin_amdgcn_s_waitcnt(0);
+            for (int i = lane; i < 16 * 40; i += 64) w4_prof_buf[i] = reinterpret_cast<unsigned long long*>(lds + 2 * V_FLOATS)[i];
+        }
+#endif
         if (!more_items) break;
         ++item;
         w = wnx;
@@ -423,14 +492,18 @@ static hipError_t launch_wino4(ConvParams p, hipStream_t st) {
     auto kern = conv_wino4_kernel<HAS_RES>;
     static bool attr_done[64] = {};
     if (cerb_attr_needed(attr_done)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + PROF_BYTES);
         if (e != hipSuccess) return e;
     }
     long long grid = 256;  // persistent: one workgroup per CU
     if (grid > items) grid = items;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS_BYTES, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS_BYTES + PROF_BYTES, st, p);
     return hipGetLastError();
 }
+
+#ifdef W4_PROF
+extern "C" int cerb_w4_prof_read(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(w4_prof_buf), sizeof(unsigned long long) * 16 * 40); }
+#endif
 
 hipError_t cerb_launch_wino4(ConvParams p, hipStream_t st) {
     if (p.Cin % CB || p.Cout % 64) return hipErrorInvalidValue;

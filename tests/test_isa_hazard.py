@@ -14,7 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "cerberus_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-UNITS = ["conv_wino.hip", "conv_igemm.hip", "conv_wino3.hip", "conv_wino16.hip", "conv_wino16d.hip"]
+UNITS = ["conv_wino.hip", "conv_igemm.hip", "conv_wino3.hip", "conv_wino16.hip", "conv_wino16d.hip", "conv_wino4.hip"]
 
 STORE = re.compile(r"^\s*buffer_store_dwordx4\s+v\[(\d+):(\d+)\],\s*(\S+),\s*s\[\d+:\d+\],\s*(\S+)")
 VDST = re.compile(r"^\s*(v_\w+|ds_read\w*|ds_load\w*|buffer_load\w*|global_load\w*|flat_load\w*|scratch_load\w*)\s+(v\[(\d+):(\d+)\]|v(\d+))")
@@ -22,8 +22,9 @@ VDST = re.compile(r"^\s*(v_\w+|ds_read\w*|ds_load\w*|buffer_load\w*|global_load\
 
 def _asm(unit, tmp):
     out = os.path.join(tmp, unit.replace(".hip", ".s"))
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--offload-device-only", "-S", "-o", out, os.path.join(CSRC, unit)],
-                          stderr=subprocess.DEVNULL)
+    from cerberus_amd.build import EXTRA_FLAGS  # the per-unit flags of the real build
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--offload-device-only", "-S", "-o", out] + EXTRA_FLAGS.get(unit, [])
+                          + [os.path.join(CSRC, unit)], stderr=subprocess.DEVNULL)
     return [l for l in open(out).read().splitlines() if l.strip() and not l.strip().startswith((";", ".", "//")) and not l.strip().endswith(":")]
 
 
