@@ -224,7 +224,9 @@ def train_leg(args, model, dev, dist, world, rank, sd=None, kw=None):
 # ---- kernel-family table of one batch step (per-launch HIP events on the launch stream, cerb_net_profile_*) ----------------------
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md
 XGMI_LINK_GBS = 153.0   # per peer link, SURVEY.md par.8e
-_SYMBOL = {"conv_wino4<f4x4,16x16x2>": "void conv_wino4_kernel<false>(ConvParams)",
+_SYMBOL = {"conv_wino4b<f4x4,16x16>": "void conv_wino4b_kernel<false>(ConvParams)",
+           "conv_wino4b<f4x4,16x16,res>": "void conv_wino4b_kernel<true>(ConvParams)",
+           "conv_wino4<f4x4,16x16x2>": "void conv_wino4_kernel<false>(ConvParams)",
            "conv_wino4<f4x4,16x16x2,res>": "void conv_wino4_kernel<true>(ConvParams)",
            "conv_wino<f2x2,8x16>": "void conv_wino_kernel<false>(ConvParams)",
            "conv_wino<f2x2,8x16,res>": "void conv_wino_kernel<true>(ConvParams)"}

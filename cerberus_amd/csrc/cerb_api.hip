@@ -23,6 +23,7 @@ hipError_t cerb_launch_wino3(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino16(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino16d(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino4(ConvParams p, hipStream_t st);
+hipError_t cerb_launch_wino4b(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_upsample2_add(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C,
                                      long long prev_gs, const int* roi, hipStream_t st);
 extern "C" int cerb_conv_chunk(int ks, int stride);
@@ -144,6 +145,7 @@ struct PackedConv {
     void* wino3 = nullptr;  // device, same weights split into three bf16 planes (conv_wino3.hip, conv_algo 2), packed lazily
     float* wino16 = nullptr;  // device, the transformed weights in conv_wino16.hip's per-wave layout (conv_algo 3), packed lazily
     float* wino16d = nullptr; // device, conv_wino16d.hip's layout (conv_algo 4: 16-channel chunks), packed lazily
+    float* wino4b = nullptr;  // device, the same transform in conv_wino4b.hip's layout (32-channel chunks, conv_algo 7), packed lazily
     float* wino4 = nullptr;   // device, F(4x4,3x3) transformed weights in conv_wino4.hip's layout (conv_algo 5), packed lazily from host_w
     std::vector<float> host_w;  // BN-folded 3x3 weights [G][cout][cin][9] kept on the host for the lazily packed Winograd variants
     std::vector<float> host_u;  // fp32 transformed weights kept on the host until conv_algo 2 is first used
@@ -410,7 +412,9 @@ static void pack_wino16d(const float* U, int cout, int cin, std::vector<float>* 
 // Winograd F(4x4,3x3) filter transform U = G g G^T for the points (0, 1, -1, 2, -2, inf), in double, rounded once, in the layout
 // conv_wino4.hip streams: [cb][16-channel chunk][wave a][position xi = 6 ya + xb][lane][t]
 //   ->  U[xi] of W[cb*64 + 16 a + (lane & 15)][chunk*16 + 4 (lane >> 4) + t]
-static void pack_wino4(const float* w, int cout, int cin, std::vector<float>* out) {  // w: BN-folded [cout][cin][3][3]
+//   conv_wino4b.hip (chunk32 = true): [cb][32-channel chunk][wave a][xi][channel group G][lane][t]
+//   ->  U[xi] of W[cb*64 + 16 a + (lane & 15)][chunk*32 + 16 G + 4 (lane >> 4) + t]
+static void pack_wino4(const float* w, int cout, int cin, std::vector<float>* out, bool chunk32 = false) {  // w: BN-folded [cout][cin][3][3]
     static const double Gm[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                     {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
     const int nchunk = cin / 16, ncb = cout / 64;
@@ -429,6 +433,20 @@ static void pack_wino4(const float* w, int cout, int cin, std::vector<float>* ou
     out->resize(base + (size_t)cout * cin * 36);
     float* o = out->data() + base;
     size_t idx = 0;
+    if (chunk32) {
+        for (int cb = 0; cb < ncb; ++cb)
+            for (int ch = 0; ch < cin / 32; ++ch)
+                for (int a = 0; a < 4; ++a)
+                    for (int xi = 0; xi < 36; ++xi)
+                        for (int G = 0; G < 2; ++G)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int t = 0; t < 4; ++t) {
+                                    const int co = cb * 64 + 16 * a + (lane & 15);
+                                    const int ci = ch * 32 + 16 * G + 4 * (lane >> 4) + t;
+                                    o[idx++] = U[((size_t)co * cin + ci) * 36 + xi];
+                                }
+        return;
+    }
     for (int cb = 0; cb < ncb; ++cb)
         for (int ch = 0; ch < nchunk; ++ch)
             for (int a = 0; a < 4; ++a)
@@ -810,24 +828,29 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
         if (prof_end(net, st)) return 1;
         return 0;
     }
-    // conv_algo 6 (default): F(4x4,3x3) for maps of at least 32 x 32 pixels, F(2x2,3x3) below (the 16 x 16 level of a batch of 32
-    // 256-pixel tiles is 128 two-block items of conv_wino4 against 512 items of conv_wino: measured 0.21 ms against 0.146 ms).  The rule
-    // looks at the layer's geometry only -- never at the batch size or the region of interest -- so that a tile's values do not depend
-    // on what it is batched with (sharded == unsharded, cropped == full stay bitwise, tests/test_drivers_gpu.py, test_net_gpu.py).
-    const bool use_w4 = net->conv_algo == 5 || (net->conv_algo == 6 && (long long)p.Ho * p.Wo >= 1024);
+    // conv_algo 6 (default): F(4x4,3x3) for maps of at least 16 x 16 pixels -- conv_wino4b.hip (one-block items, 32-channel chunks) up to
+    // 64 x 64, conv_wino4.hip (two-block items, half the weight traffic) above; F(2x2,3x3) for smaller maps, where a 16 x 16 block would
+    // be mostly padding.  Measured per layer on a batch of 32 256-pixel tiles (scripts/dev_conv_layers.py): 16^2 x 512 ch 0.115 / 0.21 /
+    // 0.146 ms (4b / 4 / F(2x2)), 64^2 x 128 ch 0.131 / 0.138 / 0.158, 256^2 x 64 ch x 5 decoders 2.63 / 2.52 / 3.28.  The rule looks at
+    // the layer's geometry only -- never at the batch size or the region of interest -- so that a tile's values do not depend on what it
+    // is batched with (sharded == unsharded, cropped == full stay bitwise, tests/test_drivers_gpu.py, test_net_gpu.py).
+    const long long map_px = (long long)p.Ho * p.Wo;
+    const bool use_w4 = net->conv_algo == 5 || net->conv_algo == 7 || (net->conv_algo == 6 && map_px >= 256);
+    const bool w4b = (net->conv_algo == 7 || (net->conv_algo == 6 && map_px <= 4096)) && c.cin % 64 == 0;
     if (use_w4 && c.wino && mode == 0 && !it->second.host_w.empty()) {
         PackedConv& cm = it->second;
-        if (!cm.wino4) {  // first use: F(4x4,3x3) filter transform on the host, conv_wino4.hip's per-wave layout, upload
+        float*& slot4 = w4b ? cm.wino4b : cm.wino4;
+        if (!slot4) {  // first use: F(4x4,3x3) filter transform on the host, the kernel's per-wave layout, upload
             std::vector<float> w4;
-            for (int g = 0; g < cm.groups; ++g) pack_wino4(cm.host_w.data() + (size_t)g * cm.cout * cm.cin * 9, cm.cout, cm.cin, &w4);
+            for (int g = 0; g < cm.groups; ++g) pack_wino4(cm.host_w.data() + (size_t)g * cm.cout * cm.cin * 9, cm.cout, cm.cin, &w4, w4b);
             void* d = nullptr;
             HIP_OK(hipMalloc(&d, w4.size() * 4));
             net->dev_allocs.push_back(d);
             net->dev_alloc_bytes.push_back(w4.size() * 4);
             HIP_OK(hipMemcpy(d, w4.data(), w4.size() * 4, hipMemcpyHostToDevice));
-            cm.wino4 = (float*)d;
+            slot4 = (float*)d;
         }
-        p.wpack = cm.wino4;
+        p.wpack = slot4;
         p.w_gs = (long long)c.cout * c.cin * 36;
         double fl_done = fl;
         if (roi && roi[1] > roi[0] && roi[3] > roi[2]) {  // region of interest: report the work of the 16 x 16 blocks that run
@@ -835,8 +858,8 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
             const double ty = (roi[1] + 15) / 16 - roi[0] / 16, tx = (roi[3] + 15) / 16 - roi[2] / 16;
             fl_done = fl * (ty * 16.0 * tx * 16.0) / ((double)p.Ho * p.Wo);
         }
-        if (prof_begin(net, name, resid ? "conv_wino4<f4x4,16x16x2,res>" : "conv_wino4<f4x4,16x16x2>", fl_done, st)) return 1;
-        HIP_OK(cerb_launch_wino4(p, st));
+        if (prof_begin(net, name, w4b ? (resid ? "conv_wino4b<f4x4,16x16,res>" : "conv_wino4b<f4x4,16x16>") : (resid ? "conv_wino4<f4x4,16x16x2,res>" : "conv_wino4<f4x4,16x16x2>"), fl_done, st)) return 1;
+        HIP_OK(w4b ? cerb_launch_wino4b(p, st) : cerb_launch_wino4(p, st));
         if (prof_end(net, st)) return 1;
         return 0;
     }
@@ -1727,8 +1750,8 @@ extern "C" int cerb_net_set_crop_roi(cerb_net* net, int enable) {
 }
 extern "C" int cerb_net_set_conv_algo(cerb_net* net, int algo) {
     if (!net) return fail("cerb_net_set_conv_algo: null handle");
-    if (algo < 0 || algo > 6)
-        return fail("cerb_net_set_conv_algo: algo must be 0 (direct), 1 (Winograd F(2x2) fp32), 2 (F(2x2), bf16x3 products), 3 (F(2x2), 16-channel waves), 4 (3 with double-buffered 16-channel chunks), 5 (Winograd F(4x4) fp32) or 6 (F(4x4) for maps of 32 x 32 pixels and more, else F(2x2): the default)");
+    if (algo < 0 || algo > 7)
+        return fail("cerb_net_set_conv_algo: algo must be 0 (direct), 1 (Winograd F(2x2) fp32), 2 (F(2x2), bf16x3 products), 3 (F(2x2), 16-channel waves), 4 (3 with double-buffered 16-channel chunks), 5 (Winograd F(4x4) fp32), 7 (F(4x4), one-block items with 32-channel chunks) or 6 (F(4x4) for maps of 16 x 16 pixels and more -- 7's kernel up to 64 x 64, 5's above --, else F(2x2): the default)");
     net->conv_algo = algo;
     return 0;
 }

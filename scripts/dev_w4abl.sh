@@ -5,9 +5,9 @@ cd "$(dirname "$0")/.."
 IFS=';'
 for FL in ${CERB_VARIANTS:-""}; do
   unset IFS
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=1000000 -mllvm -amdgpu-mfma-vgpr-form $FL -c cerberus_amd/csrc/conv_wino4.hip -o cerberus_amd/csrc/conv_wino4.o || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=1000000 ${W4_FORM--mllvm -amdgpu-mfma-vgpr-form} $FL -c cerberus_amd/csrc/${W4_SRC:-conv_wino4}.hip -o cerberus_amd/csrc/${W4_SRC:-conv_wino4}.o || exit 1
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o cerberus_amd/libcerberus_hip.so cerberus_amd/csrc/*.o || exit 1
   echo "=== flags: [$FL]"
-  timeout 120 python -u scripts/dev_conv_ab.py 5 5 2>&1 | grep "conv_algo" | cut -c1-230
+  timeout 120 python -u scripts/dev_conv_ab.py ${W4_ALGO:-5} ${W4_ALGO:-5} 2>&1 | grep "conv_algo" | cut -c1-230
   IFS=';'
 done

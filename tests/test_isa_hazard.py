@@ -14,7 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "cerberus_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-UNITS = ["conv_wino.hip", "conv_igemm.hip", "conv_wino3.hip", "conv_wino16.hip", "conv_wino16d.hip", "conv_wino4.hip"]
+UNITS = ["conv_wino.hip", "conv_igemm.hip", "conv_wino3.hip", "conv_wino16.hip", "conv_wino16d.hip", "conv_wino4.hip", "conv_wino4b.hip"]
 
 STORE = re.compile(r"^\s*buffer_store_dwordx4\s+v\[(\d+):(\d+)\],\s*(\S+),\s*s\[\d+:\d+\],\s*(\S+)")
 VDST = re.compile(r"^\s*(v_\w+|ds_read\w*|ds_load\w*|buffer_load\w*|global_load\w*|flat_load\w*|scratch_load\w*)\s+(v\[(\d+):(\d+)\]|v(\d+))")

@@ -14,7 +14,7 @@ from oracle import net_ref
 
 pytestmark = pytest.mark.gpu
 PROB_TOL = 1e-4
-DEFAULT_ALGO = 6  # cerb_net_set_conv_algo: F(4x4,3x3) for maps >= 32 x 32, F(2x2,3x3) below
+DEFAULT_ALGO = 6  # cerb_net_set_conv_algo: F(4x4,3x3) for maps >= 16 x 16 (conv_wino4b up to 64 x 64, conv_wino4 above), F(2x2,3x3) below
 CROPS = [(0, 0), (96, 96), (192, 192)]
 CS = 64
 
@@ -270,7 +270,7 @@ def test_small_feature_maps_patch_class_crop(full_model, hw):
     assert (lg - rl).abs().max().item() < 2e-4
 
 
-@pytest.mark.parametrize("algo", [6, 1, 0, 3, 4, 5])
+@pytest.mark.parametrize("algo", [6, 1, 0, 3, 4, 5, 7])
 def test_forward_is_bitwise_reproducible(full_model, algo):
     """Races and un-padded hardware hazards show up as run-to-run differences long before they show up as large errors (the
     gfx950 buffer_store hazard of DESIGN par.4.1 did): the same batch through the same handle must give identical bits."""
@@ -292,10 +292,11 @@ def test_forward_is_bitwise_reproducible(full_model, algo):
         m.set_conv_algo(DEFAULT_ALGO)
 
 
+@pytest.mark.parametrize("algo", [5, 7])
 @pytest.mark.parametrize("tag", ["cfg2_all", "g448_all", "small96_all"])
-def test_wino4_algo_vs_reference_golden(golden_dir, tag):
-    """cerb_net_set_conv_algo(5): Winograd F(4x4,3x3) (conv_wino4.hip: 36 products per 16 outputs, transform points 0, +-1, +-2, inf)
-    against the reference's golden vectors at the same 1e-4 bar -- plain, residual, grouped, cropped (region-of-interest blocks),
+def test_wino4_algo_vs_reference_golden(golden_dir, tag, algo):
+    """cerb_net_set_conv_algo(5 / 7): Winograd F(4x4,3x3) (conv_wino4.hip / conv_wino4b.hip: 36 products per 16 outputs, transform points
+    0, +-1, +-2, inf) against the reference's golden vectors at the same 1e-4 bar -- plain, residual, grouped, cropped (region-of-interest blocks),
     odd-sized (blocks hanging over the image, odd block counts) launches -- and against algorithm 1 (F(2x2)): the two differ by the
     transforms' rounding only, a few 1e-6 on the probability maps (tests/tools/dev_wino4_numerics.py)."""
     g = np.load(os.path.join(golden_dir, "net_%s.npz" % tag))
@@ -305,7 +306,7 @@ def test_wino4_algo_vs_reference_golden(golden_dir, tag):
     tiles = np.random.RandomState(int(g["tile_seed"])).randint(0, 256, (n, hw, hw, 3)).astype(np.uint8)
     m.set_conv_algo(1)
     wino = infer_step(torch.from_numpy(tiles), m, osz, tasks)
-    m.set_conv_algo(5)
+    m.set_conv_algo(algo)
     try:
         out = infer_step(torch.from_numpy(tiles), m, osz, tasks)
         m.profile(True)
