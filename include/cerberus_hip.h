@@ -72,24 +72,29 @@ typedef struct cerb_forward_io {
 
 int cerb_net_forward(cerb_net* net, const cerb_forward_io* io, void* hip_stream);
 
-/* Algorithm of the 3x3 stride-1 convolutions (90 % of the FLOPs): 1 (default) = Winograd F(2x2,3x3) on the fp32 matrix
- * cores (conv_wino.hip; same fp32 products, different summation order, 2.25x fewer multiplies), 0 = direct implicit GEMM
- * (conv_igemm.hip).  cuDNN makes the same choice per layer for the reference (torch.backends.cudnn, models/run_desc.py:447).
- * Both meet the 1e-4 bar; the switch exists for A/B measurement and for the parity tests of the direct path.
- * 2 = experimental: algorithm 1 with every fp32 product emulated by six bf16 MFMAs on a three-way bf16 split of both operands
- * (conv_wino3.hip; fp32 accumulate, errors indistinguishable from algorithm 1 in the tests).  It leaves the fp32 matrix
- * instruction, so it is never the default and never what bench.py's headline measures (BASELINE.json configs[1]: fp32).
- * 3, 4 = the same exact-fp32 Winograd with another work decomposition (conv_wino16.hip: a wave owns all 16 positions of 16 output
- * channels, output transform in registers; conv_wino16d.hip: that with double-buffered 16-channel chunks).  Parity-tested like 1; kept
- * for A/B measurement, not faster than 1. */
+/* Algorithm of the 3x3 stride-1 convolutions (90 % of the FLOPs), all on the exact-fp32 matrix instructions unless stated:
+ *   6 (default) = Winograd F(4x4,3x3) for maps of 16 x 16 pixels and more -- conv_wino4b.hip up to 64 x 64, conv_wino4.hip above --
+ *                 and F(2x2,3x3) below; the choice looks at the layer's geometry only, never at the batch size or the region of
+ *                 interest, so a tile's values do not depend on what it is batched with;
+ *   5, 7        = F(4x4,3x3) everywhere, with conv_wino4.hip / conv_wino4b.hip (36 products per 4x4 outputs instead of 144; transform
+ *                 points 0, +-1, +-2, inf; probability maps within 4e-6 of the fp64 evaluation, tests/tools/dev_wino4_numerics.py);
+ *   1           = Winograd F(2x2,3x3) (conv_wino.hip, round 1's default; same fp32 products, 2.25x fewer multiplies than direct);
+ *   0           = direct implicit GEMM (conv_igemm.hip).
+ * cuDNN makes the same kind of choice per layer for the reference (torch.backends.cudnn, models/run_desc.py:447).  All meet the 1e-4
+ * bar; the switch exists for A/B measurement and for the parity tests of each path.
+ *   2           = experimental: algorithm 1 with every fp32 product emulated by six bf16 MFMAs on a three-way bf16 split of both
+ *                 operands (conv_wino3.hip; fp32 accumulate).  It leaves the fp32 matrix instruction, so it is never the default and
+ *                 never what bench.py's headline measures (BASELINE.json configs[1]: fp32).
+ *   3, 4        = F(2x2,3x3) with another work decomposition (conv_wino16.hip, conv_wino16d.hip), not faster than 1.
+ * The training step always uses the F(2x2) kernels. */
 int cerb_net_set_conv_algo(cerb_net* net, int algo);
 /* Output heads (models/utils/net_layers.py:31-38): 1 (default) = every dense head of the batch in ONE grouped launch with the head's
  * weights resident in LDS (head_group_kernel), 0 = one launch per head (round-1 head_kernel); identical arithmetic, for A/B. */
 int cerb_net_set_head_algo(cerb_net* net, int algo);
 /* Centre-crop regions of interest (default 1 = on).  infer_step keeps only the centre out_h x out_w window of every head
  * (models/run_desc.py:452-491 cropping_center; the reference's default geometry 448 -> 144 keeps 10 % of the pixels it computes).
- * With the switch on and conv_algo 1, every decoder level computes only the part of its maps that the kept window depends on
- * (3x3 conv: +1 pixel per layer, bilinear x2: +1 source pixel) and the heads only the window; the encoder still sees the whole
+ * With the switch on (any Winograd algorithm), every decoder level computes only the part of its maps that the kept window depends on
+ * (3x3 conv: +1 pixel per layer, then out to whole 4x4 Winograd tiles; bilinear x2: +1 source pixel) and the heads only the window; the encoder still sees the whole
  * tile.  Results inside the window are bit-identical to the full computation (tests/test_net_gpu.py).  Ignored (full
  * computation) when full-size logits are requested or out == in. */
 int cerb_net_set_crop_roi(cerb_net* net, int enable);
