@@ -8,7 +8,7 @@ m = create_model(**default_model_kwargs())
 m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(0).items()}, strict=True)
 m._ensure_handle()
 algos = [int(a) for a in sys.argv[1:]] or [1, 7]
-for win, osz, n in ((256, 256, 8), (448, 144, 3), (96, 96, 5)):
+for win, osz, n in ((256, 256, 8), (448, 144, 3), (96, 96, 5), (144, 144, 3), (176, 80, 5), (208, 208, 2), (304, 144, 3)):
     tiles = torch.from_numpy(np.random.RandomState(3).randint(0, 256, (n, win, win, 3)).astype(np.uint8)).cuda()
     ref = None
     for algo in algos:

@@ -427,3 +427,30 @@ def test_crop_region_of_interest_is_bit_identical_to_the_full_computation(full_m
             assert torch.equal(full[k], roi2[k]), k
     finally:
         m.set_crop_roi(True)
+
+
+@pytest.mark.parametrize("win,osz,n", [(144, 144, 3), (176, 80, 5), (304, 144, 3), (208, 208, 2)])
+def test_winograd_partial_tiles_and_odd_blocks_vs_direct(full_model, win, osz, n):
+    """Map sizes that are not multiples of the 4x4 Winograd tile (a 144-pixel tile has an 18 x 18 level, a 176-pixel one 22 x 22 / 11 x 11),
+    odd numbers of 16 x 16 blocks (conv_wino4's two-block items: the last pair repeats a block) and blocks hanging over the map, with
+    and without a centre crop: every F(4x4) path (5: conv_wino4, 7: conv_wino4b, 6: the default mix) agrees with the direct implicit
+    GEMM (conv_algo 0, no tiles at all) to 2e-5 on every probability map, is bitwise reproducible, and the TYPE maps differ on < 1e-4 of
+    the pixels."""
+    m, sd, kw = full_model
+    tiles = torch.from_numpy(np.random.RandomState(100 + win).randint(0, 256, (n, win, win, 3)).astype(np.uint8)).cuda()
+    try:
+        m.set_conv_algo(0)
+        ref = {k: v.clone() for k, v in m.infer_tiles(tiles, osz).items()}
+        for algo in (5, 7, 6):
+            m.set_conv_algo(algo)
+            a = {k: v.clone() for k, v in m.infer_tiles(tiles, osz).items()}
+            b = m.infer_tiles(tiles, osz)
+            torch.cuda.synchronize()
+            for k in ref:
+                assert torch.equal(a[k], b[k]), (algo, k)
+                if ref[k].dtype.is_floating_point:
+                    assert (a[k] - ref[k]).abs().max().item() < 2e-5, (algo, k)
+                else:
+                    assert (a[k] != ref[k]).float().mean().item() < 1e-4, (algo, k)
+    finally:
+        m.set_conv_algo(DEFAULT_ALGO)
