@@ -12,7 +12,7 @@ tiatoolbox / OpenSlide are not in this image, so the back ends are this package'
   * TiffReader       -- baseline / BigTIFF, striped or TILED, pyramid pages, compression none / deflate (+ horizontal predictor) /
                         JPEG tiles (decoded by PIL, JPEGTables spliced in), resolution from XResolution / ResolutionUnit or an
                         Aperio `MPP = ...` description: generic tiled TIFFs and `.svs` files whose tiles are JPEG.  JPEG 2000 tiles
-                        (Aperio 33003 / 33005) and LZW are refused with a clear message.
+                        (Aperio 33003 / 33005) is refused with a clear message; LZW and PackBits are decoded in pure Python (slow, for compatibility).
 Resampling: the pyramid level with the largest downsample not above the request is read and reduced by a box (area) filter --
 exact pixel means for integer factors, PIL's BOX filter otherwise (tiatoolbox uses cv2 INTER_AREA there; unpinned, both libraries
 are absent).  Everything here is host I/O; pixels reach the GPU through wsi.SlabUploader chunk by chunk under the inference.
@@ -289,7 +289,9 @@ class TiffReader(WSIReader):
         elif c in (33003, 33005):
             raise NotImplementedError("%s: JPEG 2000 tiles (Aperio compression %d) need a JP2K decoder that is not in this image" % (self.path, c))
         elif c == 5:
-            raise NotImplementedError("%s: LZW-compressed TIFF is not supported (re-save with deflate or as tiles of JPEG)" % self.path)
+            buf = np.frombuffer(_tiff_lzw_decode(data, rows * cols * p.samples), np.uint8)
+        elif c == 32773:
+            buf = np.frombuffer(_packbits_decode(data, rows * cols * p.samples), np.uint8)
         else:
             raise NotImplementedError("%s: TIFF compression %d is not supported" % (self.path, c))
         arr = buf[: rows * cols * p.samples].reshape(rows, cols, p.samples)
@@ -314,6 +316,60 @@ class TiffReader(WSIReader):
                 if a1 > a0 and b1 > b0:
                     out[a0 - y0:a1 - y0, b0 - x0:b1 - x0] = tile[a0 - gy0:a1 - gy0, b0 - gx0:b1 - gx0]
         return out
+
+
+def _tiff_lzw_decode(data, expected):
+    """TIFF 6.0 section 13 LZW: MSB-first codes of 9..12 bits, ClearCode 256, EndOfInformation 257, the code width grows one code EARLY
+    (when the table reaches 511 / 1023 / 2047 entries).  Pure Python (a 256 x 256 RGB tile takes ~50 ms): a compatibility path for slides
+    that were not written for speed -- the decoded rows still upload under the inference (wsi.py::SlabUploader)."""
+    out = bytearray()
+    table = [bytes((i,)) for i in range(256)] + [b"", b""]
+    nbits, bitbuf, bitcnt, prev = 9, 0, 0, None
+    for byte in data:
+        bitbuf = (bitbuf << 8) | byte
+        bitcnt += 8
+        while bitcnt >= nbits:
+            code = (bitbuf >> (bitcnt - nbits)) & ((1 << nbits) - 1)
+            bitcnt -= nbits
+            if code == 256:
+                table = table[:258]
+                nbits, prev = 9, None
+                continue
+            if code == 257:
+                return bytes(out[:expected])
+            if prev is None:
+                entry = table[code]
+            else:
+                if code < len(table):
+                    entry = table[code]
+                elif code == len(table):
+                    entry = prev + prev[:1]
+                else:
+                    raise ValueError("corrupt LZW stream in a TIFF strip / tile")
+                table.append(prev + entry[:1])
+            out += entry
+            prev = entry
+            n = len(table)
+            nbits = 12 if n >= 2047 else 11 if n >= 1023 else 10 if n >= 511 else 9
+            if len(out) >= expected:
+                return bytes(out[:expected])
+    return bytes(out[:expected])
+
+
+def _packbits_decode(data, expected):
+    """TIFF 6.0 section 9 PackBits."""
+    out = bytearray()
+    i, n = 0, len(data)
+    while i < n and len(out) < expected:
+        h = data[i]
+        i += 1
+        if h < 128:
+            out += data[i:i + h + 1]
+            i += h + 1
+        elif h > 128:
+            out += data[i:i + 1] * (257 - h)
+            i += 1
+    return bytes(out[:expected])
 
 
 def write_tiled_tiff(path, levels, tile=256, mpp=None, compress=True, description=None):

@@ -48,9 +48,9 @@ def test_tiled_pyramid_tiff_roundtrip_and_resolutions(tmp_path):
     assert np.array_equal(np.array(im), levels[1])
 
 
-@pytest.mark.parametrize("compression", [None, "tiff_adobe_deflate", "jpeg"])
+@pytest.mark.parametrize("compression", [None, "tiff_adobe_deflate", "jpeg", "tiff_lzw", "packbits"])
 def test_reads_tiffs_written_by_pil(tmp_path, compression):
-    """independent encoder: files written by PIL (strips; raw, deflate, JPEG) through this package's reader"""
+    """independent encoder: files written by PIL's libtiff (strips; raw, deflate, JPEG, LZW, PackBits) through this package's reader"""
     from PIL import Image
 
     base = _pyramid(300, 420, 5)[0]
