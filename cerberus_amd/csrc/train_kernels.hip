@@ -346,46 +346,33 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restr
 // recompute z's sign from y instead of reading z back (the ReLU mask costs 4 bytes per element otherwise): identical bits by construction
 __device__ __forceinline__ float bn_out(float y, float m, float rs, float ga, float be) { return __fmaf_rn(y - m, rs * ga, be); }
 
-constexpr int BN_EW_ROWS = 512;  // rows of one workgroup of the element-wise BatchNorm passes
-// thread = (channel quad, row lane) as in bn_partial_kernel: the channel's four parameters are loaded once per thread instead of once per
-// element, no 64-bit division per element, two rows in flight (the grid-stride version ran at 0.45 of the HBM peak)
 __global__ __launch_bounds__(256) void bn_apply_kernel(float* x, const float* src, const float* __restrict__ resid, long long group_stride, long long rows, int C,
-                                                       int blocks_per_group, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       int groups, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int relu) {
-    const int g = blockIdx.x / blocks_per_group, b = blockIdx.x % blocks_per_group;
-    const int c4n = C >> 2, tid = threadIdx.x;
-    const int c4 = tid % c4n, rl = tid / c4n, nrl = 256 / c4n;
-    if (rl >= nrl) return;
-    const long long r0 = (long long)b * BN_EW_ROWS, r1 = min(rows, r0 + BN_EW_ROWS);
-    const int gc = g * C + 4 * c4;
-    const float4 m = *reinterpret_cast<const float4*>(mean + gc), rs = *reinterpret_cast<const float4*>(rstd + gc),
-                 ga = *reinterpret_cast<const float4*>(gamma + gc), be = *reinterpret_cast<const float4*>(beta + gc);
-    const long long base = g * group_stride + 4 * c4;
-    auto one = [&](float4 v, const float4& r) {
-        v.x = bn_out(v.x, m.x, rs.x, ga.x, be.x);
-        v.y = bn_out(v.y, m.y, rs.y, ga.y, be.y);
-        v.z = bn_out(v.z, m.z, rs.z, ga.z, be.z);
-        v.w = bn_out(v.w, m.w, rs.w, ga.w, be.w);
+    const int c4n = C >> 2;
+    const long long per_group = rows * c4n, total = per_group * groups;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i / per_group);
+        const long long j = i - (long long)g * per_group;
+        const int c = 4 * (int)(j % c4n);
+        float4* p = reinterpret_cast<float4*>(x + g * group_stride + (j / c4n) * C + c);
+        float4 v = *reinterpret_cast<const float4*>(src + g * group_stride + (j / c4n) * C + c);  // src == x: in place
+        const float* m = mean + g * C + c;
+        const float* rs = rstd + g * C + c;
+        const float* ga = gamma + g * C + c;
+        const float* be = beta + g * C + c;
+        v.x = bn_out(v.x, m[0], rs[0], ga[0], be[0]);
+        v.y = bn_out(v.y, m[1], rs[1], ga[1], be[1]);
+        v.z = bn_out(v.z, m[2], rs[2], ga[2], be[2]);
+        v.w = bn_out(v.w, m[3], rs[3], ga[3], be[3]);
         if (resid) {
+            const float4 r = *reinterpret_cast<const float4*>(resid + g * group_stride + (j / c4n) * C + c);
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
         if (relu) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        return v;
-    };
-    const float4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    long long r = r0 + rl;
-    for (; r + nrl < r1; r += 2 * nrl) {
-        const long long i0 = base + r * C, i1 = base + (r + nrl) * C;
-        const float4 v0 = *reinterpret_cast<const float4*>(src + i0), v1 = *reinterpret_cast<const float4*>(src + i1);  // src == x: in place
-        const float4 q0 = resid ? *reinterpret_cast<const float4*>(resid + i0) : zero4, q1 = resid ? *reinterpret_cast<const float4*>(resid + i1) : zero4;
-        *reinterpret_cast<float4*>(x + i0) = one(v0, q0);
-        *reinterpret_cast<float4*>(x + i1) = one(v1, q1);
-    }
-    for (; r < r1; r += nrl) {
-        const long long i = base + r * C;
-        *reinterpret_cast<float4*>(x + i) = one(*reinterpret_cast<const float4*>(src + i), resid ? *reinterpret_cast<const float4*>(resid + i) : zero4);
+        *p = v;
     }
 }
 // out[r][co] = bias[co] + sum_ci in[r][ci] * W[co][ci]; thread = (row, 4 couts); weights read through the caches
@@ -443,9 +430,10 @@ hipError_t cerb_launch_bn_stats(const float* x, long long group_stride, long lon
 }
 hipError_t cerb_launch_bn_apply(float* x, const float* src, const float* resid, long long group_stride, long long rows, int C, int groups, const float* mean,
                                 const float* rstd, const float* gamma, const float* beta, int relu, hipStream_t st) {
-    if (C % 4 || C > 1024) return hipErrorInvalidValue;
-    const int bpg = (int)((rows + BN_EW_ROWS - 1) / BN_EW_ROWS);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)(groups * bpg)), dim3(256), 0, st, x, src ? src : x, resid, group_stride, rows, C, bpg, mean, rstd, gamma, beta, relu);
+    long long blocks = (rows * (C / 4) * groups + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, src ? src : x, resid, group_stride, rows, C, groups, mean, rstd, gamma, beta, relu);
     return hipGetLastError();
 }
 hipError_t cerb_launch_pointwise(const float* in, const float* w, const float* bias, float* out, long long rows, int cin, int cout, const float* in_scale,
@@ -559,38 +547,38 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const double* __r
 template <bool ASSIGN>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ y,
                                                            float* __restrict__ dy, float* __restrict__ dresid, long long group_stride, long long rows, int C,
-                                                           int blocks_per_group, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           int groups, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu) {
-    const int g = blockIdx.x / blocks_per_group, b = blockIdx.x % blocks_per_group;
-    const int c4n = C >> 2, tid = threadIdx.x;
-    const int c4 = tid % c4n, rl = tid / c4n, nrl = 256 / c4n;  // thread = (channel quad, row lane): parameters loaded once per thread
-    if (rl >= nrl) return;
-    const long long r0 = (long long)b * BN_EW_ROWS, r1 = min(rows, r0 + BN_EW_ROWS);
+    const int c4n = C >> 2;
+    const long long per_group = rows * c4n, total = per_group * groups;
     const float invM = 1.f / (float)rows;
-    const int gc = g * C + 4 * c4;
-    const float4 mu = *reinterpret_cast<const float4*>(mean + gc), rs = *reinterpret_cast<const float4*>(rstd + gc), ga = *reinterpret_cast<const float4*>(gamma + gc),
-                 dg = *reinterpret_cast<const float4*>(dgamma + gc), db = *reinterpret_cast<const float4*>(dbeta + gc);
-    float4 be = {0.f, 0.f, 0.f, 0.f};
-    if (relu == 2) be = *reinterpret_cast<const float4*>(beta + gc);
-    const long long base = g * group_stride + 4 * c4;
-    const float4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto one = [&](long long a, float4 d, const float4& yv, const float4& zr, const float4& prev, const float4& rr) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i / per_group);
+        const long long j = i - (long long)g * per_group;
+        const int c = 4 * (int)(j % c4n);
+        const long long a = g * group_stride + (j / c4n) * C + c;
+        float4 d = *reinterpret_cast<const float4*>(dz + a);
+        const int gc = g * C + c;
+        const float4 yv = *reinterpret_cast<const float4*>(y + a), mu = *reinterpret_cast<const float4*>(mean + gc), rs = *reinterpret_cast<const float4*>(rstd + gc),
+                     ga = *reinterpret_cast<const float4*>(gamma + gc), dg = *reinterpret_cast<const float4*>(dgamma + gc), db = *reinterpret_cast<const float4*>(dbeta + gc);
         if (relu) {
-            float4 m = zr;
+            float4 m;
             if (relu == 2) {
+                const float4 be = *reinterpret_cast<const float4*>(beta + gc);
                 m.x = bn_out(yv.x, mu.x, rs.x, ga.x, be.x);
                 m.y = bn_out(yv.y, mu.y, rs.y, ga.y, be.y);
                 m.z = bn_out(yv.z, mu.z, rs.z, ga.z, be.z);
                 m.w = bn_out(yv.w, mu.w, rs.w, ga.w, be.w);
-            }
+            } else
+                m = *reinterpret_cast<const float4*>(z + a);
             if (!(m.x > 0.f)) d.x = 0.f;
             if (!(m.y > 0.f)) d.y = 0.f;
             if (!(m.z > 0.f)) d.z = 0.f;
             if (!(m.w > 0.f)) d.w = 0.f;
         }
         if (dresid) {
-            float4 r = rr;
+            float4 r = *reinterpret_cast<float4*>(dresid + a);
             r.x += d.x; r.y += d.y; r.z += d.z; r.w += d.w;
             *reinterpret_cast<float4*>(dresid + a) = r;
         }
@@ -600,24 +588,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         o.z = ga.z * rs.z * (d.z - db.z * invM - ((yv.z - mu.z) * rs.z) * dg.z * invM);
         o.w = ga.w * rs.w * (d.w - db.w * invM - ((yv.w - mu.w) * rs.w) * dg.w * invM);
         if (!ASSIGN) {
-            o.x += prev.x; o.y += prev.y; o.z += prev.z; o.w += prev.w;
+            const float4 p = *reinterpret_cast<const float4*>(dy + a);
+            o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
         }
         *reinterpret_cast<float4*>(dy + a) = o;
-    };
-    auto ld = [&](const float* p, long long a, bool on) { return on ? *reinterpret_cast<const float4*>(p + a) : zero4; };
-    long long r = r0 + rl;
-    for (; r + nrl < r1; r += 2 * nrl) {  // two rows in flight
-        const long long a0 = base + r * C, a1 = base + (r + nrl) * C;
-        const float4 d0 = ld(dz, a0, true), d1 = ld(dz, a1, true), y0 = ld(y, a0, true), y1 = ld(y, a1, true);
-        const float4 z0 = ld(z, a0, relu == 1), z1 = ld(z, a1, relu == 1);
-        const float4 p0 = ld(dy, a0, !ASSIGN), p1 = ld(dy, a1, !ASSIGN);
-        const float4 q0 = ld(dresid, a0, dresid != nullptr), q1 = ld(dresid, a1, dresid != nullptr);
-        one(a0, d0, y0, z0, p0, q0);
-        one(a1, d1, y1, z1, p1, q1);
-    }
-    for (; r < r1; r += nrl) {
-        const long long a = base + r * C;
-        one(a, ld(dz, a, true), ld(y, a, true), ld(z, a, relu == 1), ld(dy, a, !ASSIGN), ld(dresid, a, dresid != nullptr));
     }
 }
 // ---- convolution backward, gather form (any ks / stride / pad = ks / 2; groups = independent convs stacked along G) ------------------
@@ -960,10 +934,9 @@ hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, f
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(groups * bpg), dim3(256), 256 * 2 * sizeof(double), st, dz, z, y, group_stride, rows, C, bpg, mean, rstd, relu,
                        gamma, beta, (double*)ws);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, (const double*)ws, C, bpg, dgamma, dbeta);
-    const int ebpg = (int)((rows + BN_EW_ROWS - 1) / BN_EW_ROWS);
-    if (dy_assign) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)(groups * ebpg)), dim3(256), 0, st, dz, z, y, dy, dresid, group_stride, rows, C,
-                                      ebpg, mean, rstd, gamma, beta, dgamma, dbeta, relu);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3((unsigned)(groups * ebpg)), dim3(256), 0, st, dz, z, y, dy, dresid, group_stride, rows, C, ebpg,
+    if (dy_assign) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gridfor(rows * (C / 4) * groups)), dim3(256), 0, st, dz, z, y, dy, dresid, group_stride, rows, C,
+                                      groups, mean, rstd, gamma, beta, dgamma, dbeta, relu);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(gridfor(rows * (C / 4) * groups)), dim3(256), 0, st, dz, z, y, dy, dresid, group_stride, rows, C, groups,
                             mean, rstd, gamma, beta, dgamma, dbeta, relu);
     return hipGetLastError();
 }
