@@ -63,6 +63,7 @@ hipError_t cerb_launch_adam_multi(int count, float* const* p, const float* const
                                   float b2, float eps, int step, hipStream_t st);
 hipError_t cerb_launch_pack_conv(const float* w_raw, float* out, int cout, int cin, int ks, int chunk, hipStream_t st);
 hipError_t cerb_launch_pack_wino(const float* w_raw, float* out, int cout, int cin, int dgrad, hipStream_t st);
+hipError_t cerb_launch_pack_wino4(const float* w_raw, float* out, int cout, int cin, int dgrad, int chunk32, hipStream_t st);
 hipError_t cerb_launch_dilate2(const float* dy, float* d, long long n, int H, int W, int C, hipStream_t st);
 size_t cerb_pw_wgrad_small_workspace_bytes(long long rows, int cin, int cout);
 hipError_t cerb_launch_pw_wgrad_small(const float* x, const float* dy, float* dw, long long rows, int cin, int cout, void* ws, hipStream_t st);
@@ -145,6 +146,8 @@ struct PackedConv {
     void* wino3 = nullptr;  // device, same weights split into three bf16 planes (conv_wino3.hip, conv_algo 2), packed lazily
     float* wino16 = nullptr;  // device, the transformed weights in conv_wino16.hip's per-wave layout (conv_algo 3), packed lazily
     float* wino16d = nullptr; // device, conv_wino16d.hip's layout (conv_algo 4: 16-channel chunks), packed lazily
+    float* wino4_t[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // train packing only: [layout 4 / 4b][forward / data gradient], packed on the
+                                                                      // device at first use and again after every optimiser step
     float* wino4b = nullptr;  // device, the same transform in conv_wino4b.hip's layout (32-channel chunks, conv_algo 7), packed lazily
     float* wino4 = nullptr;   // device, F(4x4,3x3) transformed weights in conv_wino4.hip's layout (conv_algo 5), packed lazily from host_w
     std::vector<float> host_w;  // BN-folded 3x3 weights [G][cout][cin][9] kept on the host for the lazily packed Winograd variants
@@ -785,6 +788,26 @@ static int prof_end(cerb_net* net, hipStream_t st) {
     return 0;
 }
 
+// Train packing: the F(4x4,3x3) weights of one conv ([layout 4 / 4b][forward / data gradient]) are transformed on the device from the raw
+// state-dict copy at first use; cerb_net_update_params repeats it for the slots that exist.
+static int train_wino4_slot(cerb_net* net, const std::string& name, PackedConv& cm, int w4b, int dgrad, hipStream_t st, float** out) {
+    float*& slot = cm.wino4_t[w4b][dgrad];
+    if (!slot) {
+        auto rit = net->raw.find(name);
+        if (rit == net->raw.end()) return fail("conv " + name + ": no raw weights for the F(4x4) transform");
+        const size_t nw = (size_t)cm.cout * cm.cin * 9, nu = (size_t)cm.cout * cm.cin * 36;
+        void* d = nullptr;
+        HIP_OK(hipMalloc(&d, (size_t)cm.groups * nu * 4));
+        net->dev_allocs.push_back(d);
+        net->dev_alloc_bytes.push_back((size_t)cm.groups * nu * 4);
+        slot = (float*)d;
+        for (int g = 0; g < cm.groups; ++g)
+            HIP_OK(cerb_launch_pack_wino4(rit->second.w + g * nw, slot + g * nu, dgrad ? cm.cin : cm.cout, dgrad ? cm.cout : cm.cin, dgrad, w4b, st));
+    }
+    *out = slot;
+    return 0;
+}
+
 static int run_conv(cerb_net* net, const std::string& name, const float* in, const float* prev, const float* resid, float* out, int N,
                     int H, int W, int relu, int mode, long long in_gs, long long prev_gs, hipStream_t st, double* macs,
                     const int* roi = nullptr) {
@@ -837,9 +860,11 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
     const long long map_px = (long long)p.Ho * p.Wo;
     const bool use_w4 = net->conv_algo == 5 || net->conv_algo == 7 || (net->conv_algo == 6 && map_px >= 256);
     const bool w4b = (net->conv_algo == 7 || (net->conv_algo == 6 && map_px <= 4096)) && c.cin % 64 == 0;
-    if (use_w4 && c.wino && mode == 0 && !it->second.host_w.empty()) {
+    if (use_w4 && c.wino && mode == 0 && (!it->second.host_w.empty() || !net->fold_bn)) {
         PackedConv& cm = it->second;
-        float*& slot4 = w4b ? cm.wino4b : cm.wino4;
+        float* train_slot = nullptr;
+        if (!net->fold_bn && train_wino4_slot(net, name, cm, w4b ? 1 : 0, 0, st, &train_slot)) return 1;
+        float*& slot4 = !net->fold_bn ? train_slot : (w4b ? cm.wino4b : cm.wino4);
         if (!slot4) {  // first use: F(4x4,3x3) filter transform on the host, the kernel's per-wave layout, upload
             std::vector<float> w4;
             for (int g = 0; g < cm.groups; ++g) pack_wino4(cm.host_w.data() + (size_t)g * cm.cout * cm.cin * 9, cm.cout, cm.cin, &w4, w4b);
@@ -1154,7 +1179,7 @@ extern "C" int cerb_net_forward_train(cerb_net* net, const cerb_train_io* io, vo
             if (net->dout[u].ensure(D * (size_t)N * hs[3 - u] * ws[3 - u] * oc[u] * 4, guard)) return fail("workspace allocation failed");
     }
     const int saved_algo = net->conv_algo;
-    if (net->conv_algo >= 2) net->conv_algo = 1;
+    if (net->conv_algo >= 2 && net->conv_algo <= 4) net->conv_algo = 1;  // the experimental F(2x2) variants have no train packing
     // ---- encoder: conv -> BN(batch) -> ReLU -----------------------------------------------------------------------------------
     {
         StemParams sp;
@@ -1304,7 +1329,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         return p;
     };
     const int saved_algo = net->conv_algo;
-    if (net->conv_algo == 2) net->conv_algo = 1;
+    if (net->conv_algo >= 2 && net->conv_algo <= 4) net->conv_algo = 1;
     // ---------------------------------------------------------------- forward, recorded ----------------------------------------
     auto conv = [&](const std::string& name, int a, int n_, int h_, int w_, long long a_gs) -> int {
         const PackedConv& c = net->conv[name];
@@ -1545,7 +1570,18 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     p.resid_gs = op.a_gs;
                     p.out_gs = op.a_gs;
                     if (op.G == 1) p.resid_gs = p.out_gs = 0;
-                    HIP_OK(cerb_launch_wino(p, st));
+                    // the same per-geometry choice as the forward convolutions (run_conv): F(4x4,3x3) for maps of 16 x 16 and more
+                    const long long map_px = (long long)op.H * op.W;
+                    const bool d_w4 = saved_algo == 5 || saved_algo == 7 || (saved_algo == 6 && map_px >= 256);
+                    const bool d_w4b = (saved_algo == 7 || (saved_algo == 6 && map_px <= 4096)) && op.Cout % 64 == 0;
+                    if (d_w4 && op.Cout % 16 == 0 && op.Cin % 64 == 0) {
+                        float* w4 = nullptr;
+                        if (train_wino4_slot(net, op.name, net->conv[op.name], d_w4b ? 1 : 0, 1, st, &w4)) return 1;
+                        p.wpack = w4;
+                        p.w_gs = (long long)op.Cout * op.Cin * 36;
+                        HIP_OK(d_w4b ? cerb_launch_wino4b(p, st) : cerb_launch_wino4(p, st));
+                    } else
+                        HIP_OK(cerb_launch_wino(p, st));
                     dx_done = true;
                     go = grd[op.o];
                 }
@@ -1712,6 +1748,11 @@ extern "C" int cerb_net_update_params(cerb_net* net, int count, const char* cons
             HIP_OK(cerb_launch_pack_conv(rawd + g * nw, pc.w + g * nw, pc.cout, pc.cin, pc.ks, cerb_conv_chunk(pc.ks, pc.stride), st));
             if (pc.wino) HIP_OK(cerb_launch_pack_wino(rawd + g * nw, pc.wino + g * nu, pc.cout, pc.cin, 0, st));
             if (pc.wino_dgrad) HIP_OK(cerb_launch_pack_wino(rawd + g * nw, pc.wino_dgrad + g * nu, pc.cin, pc.cout, 1, st));
+            const size_t nu4 = (size_t)pc.cout * pc.cin * 36;
+            for (int l = 0; l < 2; ++l)
+                for (int dg = 0; dg < 2; ++dg)
+                    if (pc.wino4_t[l][dg])
+                        HIP_OK(cerb_launch_pack_wino4(rawd + g * nw, pc.wino4_t[l][dg] + g * nu4, dg ? pc.cin : pc.cout, dg ? pc.cout : pc.cin, dg, l, st));
         }
     }
     return 0;

@@ -51,6 +51,37 @@ __global__ __launch_bounds__(256) void pack_wino_kernel(const float* __restrict_
         out[i] = (float)(tx[0] * Gb[0] + tx[1] * Gb[1] + tx[2] * Gb[2]);
     }
 }
+// Winograd F(4x4,3x3) filter transform (points 0, 1, -1, 2, -2, inf; the host packer is cerb_api.hip: pack_wino4) in the layouts of
+// conv_wino4.hip  [cb][16-channel chunk][wave a][xi][lane][t]      (chunk32 = 0)  and
+// conv_wino4b.hip [cb][32-channel chunk][wave a][xi][G][lane][t]   (chunk32 = 1); `cout` / `cin` are the convolution's own (for the data
+// gradient: the forward layer's cin / cout, filter W'[ci][co][tap] = W[co][ci][8 - tap])
+__global__ __launch_bounds__(256) void pack_wino4_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int dgrad, int chunk32) {
+#pragma clang fp contract(off)
+    const double Gm[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                             {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
+    const long long total = (long long)cout * cin * 36;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int t = (int)(r & 3); r >>= 2;
+        const int lane = (int)(r & 63); r >>= 6;
+        int G = 0;
+        if (chunk32) { G = (int)(r & 1); r >>= 1; }
+        const int xi = (int)(r % 36); r /= 36;
+        const int a = (int)(r & 3); r >>= 2;
+        const int nchunk = chunk32 ? cin / 32 : cin / 16;
+        const int ch = (int)(r % nchunk);
+        const int cb = (int)(r / nchunk);
+        const int co = cb * 64 + 16 * a + (lane & 15);
+        const int ci = chunk32 ? ch * 32 + 16 * G + 4 * (lane >> 4) + t : ch * 16 + 4 * (lane >> 4) + t;
+        double g[3][3];
+        for (int k = 0; k < 9; ++k)
+            g[k / 3][k % 3] = dgrad ? (double)w[((long long)ci * cout + co) * 9 + (8 - k)] : (double)w[((long long)co * cin + ci) * 9 + k];
+        const int ya = xi / 6, xb = xi % 6;
+        double tx[3];
+        for (int x = 0; x < 3; ++x) tx[x] = Gm[ya][0] * g[0][x] + Gm[ya][1] * g[1][x] + Gm[ya][2] * g[2][x];
+        out[i] = (float)(tx[0] * Gm[xb][0] + tx[1] * Gm[xb][1] + tx[2] * Gm[xb][2]);
+    }
+}
 // stem 7x7 (cerb_api.hip: cerb_net_finalize): wp[ky 7][t 12][s 2][lane 64] = W[32 s + (lane & 31)][c][ky][kx] with kk = 2 t + (lane >> 5) = 3 kx + c < 21
 __global__ void pack_stem_kernel(const float* __restrict__ w, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -70,6 +101,10 @@ hipError_t cerb_launch_pack_conv(const float* w_raw, float* out, int cout, int c
     return hipGetLastError();
 }
 // (cout, cin) are those of the conv the packed filter serves: for dgrad = 1 the transposed pair of the raw tensor
+hipError_t cerb_launch_pack_wino4(const float* w_raw, float* out, int cout, int cin, int dgrad, int chunk32, hipStream_t st) {
+    hipLaunchKernelGGL(pack_wino4_kernel, dim3(pack_grid((long long)cout * cin * 36)), dim3(256), 0, st, w_raw, out, cout, cin, dgrad, chunk32);
+    return hipGetLastError();
+}
 hipError_t cerb_launch_pack_wino(const float* w_raw, float* out, int cout, int cin, int dgrad, hipStream_t st) {
     hipLaunchKernelGGL(pack_wino_kernel, dim3(pack_grid((long long)cout * cin * 16)), dim3(256), 0, st, w_raw, out, cout, cin, dgrad);
     return hipGetLastError();

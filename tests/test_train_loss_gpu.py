@@ -217,7 +217,9 @@ def test_whole_train_step_vs_reference(gold):
         # first step of Adam: |update| = lr for every element whose gradient is not tiny; a sign flip of a near-zero gradient costs 2 lr
         flips = abs(np.abs(d).sum() - d_abs) / max(d_abs, 1e-12)
         assert flips < 2e-2, (k, np.abs(d).sum(), d_abs)
-        assert abs(new[k].double().sum().item() - p_sum) <= 2e-2 * d_abs + 1e-6 * abs(p_sum), (k, new[k].double().sum().item(), p_sum, d_abs)
+        # + 4.2e-3: two sign flips (2 lr each) in a small tensor -- between the F(2x2) and the F(4x4) convolutions of this package the
+        # elements whose first step changes sign all have gradients below 2e-3 of the tensor's largest (tests/tools/dev_train_flip.py)
+        assert abs(new[k].double().sum().item() - p_sum) <= 2e-2 * d_abs + 4.2e-3 + 1e-6 * abs(p_sum), (k, new[k].double().sum().item(), p_sum, d_abs)
     assert n_cmp > 250
     for k, (b_sum, b_dabs, b0) in zip([str(x) for x in gold["step/bn_names"]], gold["step/bn_stats"]):
         got = new[k].double()
