@@ -101,6 +101,22 @@ static int scan_exclusive(const int* in, int* out, int n, int* tmp, hipStream_t 
     return 0;
 }
 
+// (row, column) of a linear pixel index p < 2^31 without the 64-bit integer division a per-pixel `p / W`, `p % W` costs (~100 VALU
+// instructions): one fp64 multiply by a per-thread reciprocal, exact after a one-step fix-up.
+__device__ __forceinline__ void pix_yx(long long p, int W, double invW, int& y, int& x) {
+    int q = (int)((double)p * invW);
+    int r = (int)(p - (long long)q * W);
+    if (r < 0) {
+        --q;
+        r += W;
+    } else if (r >= W) {
+        ++q;
+        r -= W;
+    }
+    y = q;
+    x = r;
+}
+
 // =================================================================================================================
 // Union-find connected components (4-connectivity) on an implicit grid
 // =================================================================================================================
@@ -136,10 +152,13 @@ __device__ __forceinline__ void uf_union(int* L, int a, int b) {
 // union per run and row pair instead of two per pixel.
 __global__ void ccl_init_kernel(const uint8_t* __restrict__ fg, uint8_t val, int* __restrict__ L, int n, int W) {
     const int lane = threadIdx.x & 63;
+    const double invW = 1.0 / (double)W;
     for (long long p0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) - lane; p0 < n; p0 += (long long)gridDim.x * blockDim.x) {
         const long long p = p0 + lane;
         const bool f = p < n && fg[p] == val;
-        const bool link = f && lane > 0 && (p % W) != 0 && fg[p - 1] == val;  // joined to the previous lane's pixel
+        int y_, x_;
+        pix_yx(p < n ? p : 0, W, invW, y_, x_);
+        const bool link = f && lane > 0 && x_ != 0 && fg[p - 1] == val;  // joined to the previous lane's pixel
         const u64 starts = __ballot(f && !link);
         if (f) {
             const u64 below = starts & ((2ull << lane) - 1);  // run starts at or below this lane
@@ -150,9 +169,11 @@ __global__ void ccl_init_kernel(const uint8_t* __restrict__ fg, uint8_t val, int
 }
 __global__ void ccl_merge_kernel(const uint8_t* __restrict__ fg, uint8_t val, int* L, int H, int W) {
     const long long n = (long long)H * W;
+    const double invW = 1.0 / (double)W;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
         if (fg[p] != val) continue;
-        const int x = (int)(p % W);
+        int y_, x;
+        pix_yx(p, W, invW, y_, x);
         const bool left = x > 0 && fg[p - 1] == val;
         const bool chunk_start = (p & 63) == 0 || !left;  // first pixel of its run inside the 64-pixel chunk
         if (left && (p & 63) == 0) uf_union(L, (int)p, (int)p - 1);  // run continues across the chunk boundary
@@ -224,8 +245,10 @@ __global__ void nuc_threshold_kernel(const float* __restrict__ inst, long long r
                                      uint8_t* __restrict__ msk0, uint8_t* __restrict__ mrk0, int* __restrict__ any) {
     const long long n = (long long)H * W;
     int local = 0;
+    const double invW = 1.0 / (double)W;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(p / W), x = (int)(p % W);
+        int y, x;
+        pix_yx(p, W, invW, y, x);
         const float* s = inst + y * row_stride + (long long)x * pix_stride;
         const float inner = s[0], cnt = s[1];
         const float raw = inner + cnt;  // float32 add, as numpy (postproc.py:360)
@@ -239,8 +262,10 @@ __global__ void nuc_threshold_kernel(const float* __restrict__ inst, long long r
 // cv2.erode with the 3x3 MORPH_ELLIPSE (= cross); the constant border never wins the min
 __global__ void erode_cross_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W) {
     const long long n = (long long)H * W;
+    const double invW = 1.0 / (double)W;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(p / W), x = (int)(p % W);
+        int y, x;
+        pix_yx(p, W, invW, y, x);
         uint8_t v = src[p];
         if (y > 0) v &= src[p - W];
         if (y < H - 1) v &= src[p + W];
@@ -308,12 +333,14 @@ __global__ void ws_seed_kernel(const float* __restrict__ inst, long long row_str
                                u64* __restrict__ hkey, u32* __restrict__ hidx, int H, int W, int* __restrict__ unl, int* __restrict__ lmin,
                                int* __restrict__ lmax) {
     const long long n = (long long)H * W;
+    const double invW = 1.0 / (double)W;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
         if (!out[p]) {
             if (mask[p]) atomicAdd(&unl[L[p]], 1);  // floodable pixel of its component
             continue;
         }
-        const int y = (int)(p / W), x = (int)(p % W);
+        int y, x;
+        pix_yx(p, W, invW, y, x);
         bool active = false;
         if (y > 0 && mask[p - W] && !out[p - W]) active = true;
         if (x > 0 && mask[p - 1] && !out[p - 1]) active = true;
@@ -340,9 +367,11 @@ __global__ void ws_bbox_init_kernel(const int* __restrict__ L, const uint8_t* __
 }
 __global__ void ws_bbox_kernel(const int* __restrict__ L, const uint8_t* __restrict__ mask, CBox* bb, int H, int W) {
     const long long n = (long long)H * W;
+    const double invW = 1.0 / (double)W;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
         if (!mask[p]) continue;
-        const int y = (int)(p / W), x = (int)(p % W);
+        int y, x;
+        pix_yx(p, W, invW, y, x);
         if (y > 0 && y < H - 1 && x > 0 && x < W - 1 && mask[p - W] && mask[p + W] && mask[p - 1] && mask[p + 1]) continue;
         CBox* b = bb + L[p];
         const volatile CBox* vb = b;  // monotone extremes: skip the atomic when a plain read already covers the pixel
@@ -995,6 +1024,7 @@ __global__ __launch_bounds__(64) void ws_exact_kernel(const float* __restrict__ 
     h.gi = hidx;
     const int lane = threadIdx.x & 63;
     const long long N = (long long)H * W;
+    const double invW = 1.0 / (double)W;
     int n = 0;
     // ---- all marker pixels, raster order, age 0 (8 chunks of 64 pixels in flight) ----------------------------------------
     for (long long base = 0; base < N; base += 512) {
@@ -1010,7 +1040,8 @@ __global__ __launch_bounds__(64) void ws_exact_kernel(const float* __restrict__ 
             const long long p = base + u * 64 + lane;
             kv[u] = 0;
             if (o[u]) {
-                const int y = (int)(p / W), x = (int)(p % W);
+                int y, x;
+                pix_yx(p, W, invW, y, x);
                 kv[u] = order_key(-inst[y * row_stride + (long long)x * pix_stride]);
             }
         }
@@ -1078,8 +1109,10 @@ __global__ __launch_bounds__(64) void ws_exact_kernel(const float* __restrict__ 
 __global__ void gl_threshold_kernel(const float* __restrict__ inst, long long row_stride, int pix_stride, int H, int W, float thr,
                                     uint8_t* __restrict__ fg) {
     const long long n = (long long)H * W;
+    const double invW = 1.0 / (double)W;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(p / W), x = (int)(p % W);
+        int y, x;
+        pix_yx(p, W, invW, y, x);
         const float* s = inst + y * row_stride + (long long)x * pix_stride;
         const float c = s[1] > 0.5f ? 1.f : 0.f;  // inst_cnt binarised (postproc.py:280-282)
         fg[p] = (s[0] - c) > thr;
@@ -1098,10 +1131,12 @@ __global__ void box_init_kernel(Box* b, int n, int H, int W) {
 }
 __global__ void box_accum_kernel(const int* __restrict__ lab, Box* b, int H, int W) {
     const long long n = (long long)H * W;
+    const double invW = 1.0 / (double)W;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
         const int l = lab[p];
         if (!l) continue;
-        const int y = (int)(p / W), x = (int)(p % W);
+        int y, x;
+        pix_yx(p, W, invW, y, x);
         // only pixels on the instance outline can be bounding-box extremes (keeps the atomics off the interior)
         if (y > 0 && y < H - 1 && x > 0 && x < W - 1 && lab[p - W] == l && lab[p + W] == l && lab[p - 1] == l && lab[p + 1] == l) continue;
         // the extremes only ever move outwards, so a (possibly stale) plain read that already covers this pixel makes the atomic
@@ -1573,8 +1608,10 @@ __global__ void cc8_init_kernel(const int* __restrict__ lab, long long ls, int H
 }
 __global__ void cc8_merge_kernel(const int* __restrict__ lab, long long ls, int H, int W, int* L) {
     const long long n = (long long)H * W;
+    const double invW = 1.0 / (double)W;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(p / W), x = (int)(p % W);
+        int y, x;
+        pix_yx(p, W, invW, y, x);
         const int id = lab[y * ls + x];
         if (id <= 0) continue;
         if (x > 0 && lab[y * ls + x - 1] == id) uf_union(L, (int)p, (int)p - 1);
