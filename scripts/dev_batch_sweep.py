@@ -5,7 +5,7 @@ import torch
 from cerberus_amd.net_desc import create_model
 from cerberus_amd.weights import default_model_kwargs
 m = create_model(**default_model_kwargs())
-for nb in (1, 2, 4, 8, 16, 32, 64):
+for nb in (1, 2, 4, 8, 16, 32, 48, 64, 96, 128):
     t = torch.randint(0, 256, (nb, 256, 256, 3), dtype=torch.uint8, device="cuda")
     for _ in range(3): m.infer_tiles(t, 256)
     torch.cuda.synchronize(); t0 = time.perf_counter()
