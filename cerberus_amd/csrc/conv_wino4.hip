@@ -70,7 +70,11 @@ constexpr int P0 = W4_P0;                     // first step that issues patch lo
 #endif
 constexpr int TQ = W4_TQ;                     // the next chunk's patch is masked at TQ, transformed at TQ+1 .. TQ+12, written at TQ+7 .. TQ+12
 static_assert(NS % RING == 0 && WD + WB <= RING && NS % WB == 0 && PRE >= WD && PRE <= RING, "weight ring");
+#ifdef W4_ABL_HALFPATCH
+static_assert(P0 + (W4_ABL_HALFPATCH + PL - 1) / PL <= TQ && TQ + 13 < NS, "ablation: the loads that are issued must precede the transform");
+#else
 static_assert(P0 + (36 + PL - 1) / PL <= TQ && TQ + 13 < NS, "the patch must be requested before its transform starts");
+#endif
 constexpr int BIAS_XI = 7;                    // A^T[i][1] A[1][j] = 1 for all 16 outputs: the bias enters through position (1, 1)
 constexpr int CHUNK_W_BYTES = NPOS * 4 * 1024;  // packed weights of one (cout block, 16-channel chunk): 144 KiB
 constexpr int WAVE_W_BYTES = NPOS * 1024;       // one wave's share: 36 steps x 1 KiB
@@ -327,10 +331,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     bb[(q + 1) & 1][1] = *reinterpret_cast<const f32x4*>(vsrc + (q + 1) * NT * CB + 16 * CB);
                 }
 #ifndef W4_ABL_NOPATCH
-                if (q >= P0 && (q - P0) * PL < 36) {  // next chunk's patch: PL loads per step
+                if (q >= P0 && (q - P0) * PL < 36 && q <= TQ) {  // next chunk's patch: PL loads per step
 #pragma unroll
                     for (int u = 0; u < PL; ++u)
+#ifdef W4_ABL_HALFPATCH
+                        if ((q - P0) * PL + u < W4_ABL_HALFPATCH) issue(r_stage, stage_off, (q - P0) * PL + u);
+#else
                         if ((q - P0) * PL + u < 36) issue(r_stage, stage_off, (q - P0) * PL + u);
+#endif
                 }
 #endif
                 // the next chunk's patch landed: mask, B^T d B (one 1-D pass per step) and the V writes into the OTHER buffer
