@@ -65,6 +65,9 @@ constexpr int P0 = W4_P0;                     // first step that issues patch lo
 #ifndef W4_TQ
 #define W4_TQ 18
 #endif
+#ifndef W4_PATCH_AUX
+#define W4_PATCH_AUX 0
+#endif
 #ifndef W4_STORE_AUX
 #define W4_STORE_AUX 0
 #endif
@@ -94,7 +97,7 @@ __device__ __forceinline__ void buf_store(f32x4 v, __amdgpu_buffer_rsrc_t r, uns
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
-    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, soff, 0));
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, soff, W4_PATCH_AUX));
 }
 
 #ifdef W4_PROF
@@ -130,10 +133,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
     const int base_cnt = total / (int)gridDim.x, rem_cnt = total % (int)gridDim.x;
     int item = lb * base_cnt + min(lb, rem_cnt);
+#ifndef W4_CONTIGUOUS  // workgroup lb takes items lb, lb + G, ...: neighbouring blocks (shared halo lines, the cout blocks of one patch) run at the
+                       // same time on one XCD and meet in its L2 (-1 % / -3 % against contiguous item ranges per workgroup)
+    const int ISTEP = (int)gridDim.x;
+    item = lb;
+    const int item_end = total;
+#else
+    const int ISTEP = 1;
     const int item_end = item + base_cnt + (lb < rem_cnt ? 1 : 0);
+#endif
     if (item >= item_end) return;
 #ifdef W4_PROF
-    const int prof_item = item + 1;
+    const int prof_item = item + ISTEP;
 #endif
 
     auto decode_blk = [&](int id) {
@@ -271,8 +282,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     for (;;) {
         f32x4 acc[NPOS][2];
-        const bool more_items = item + 1 < item_end;
-        const Item wnx = more_items ? decode(item + 1) : w;
+        const bool more_items = item + ISTEP < item_end;
+        const Item wnx = more_items ? decode(item + ISTEP) : w;
         const __amdgpu_buffer_rsrc_t rw_nx = more_items ? make_rsrc(w_base(wnx)) : rw;
         const Blk bcur = mine(w), bnx = mine(wnx);
         const bool mask_cur = hangs_over(bcur), mask_next = hangs_over(bnx);
@@ -478,7 +489,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
 #endif
         if (!more_items) break;
-        ++item;
+        item += ISTEP;
         w = wnx;
         rw = rw_nx;
     }

@@ -88,10 +88,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
     const int base_cnt = total / (int)gridDim.x, rem_cnt = total % (int)gridDim.x;
     int item = lb * base_cnt + min(lb, rem_cnt);
+#ifndef W4B_CONTIGUOUS  // workgroup lb takes items lb, lb + G, ...: neighbours meet in the XCD's L2 (conv_wino4.hip; -2.6 %)
+    const int ISTEP = (int)gridDim.x;
+    item = lb;
+    const int item_end = total;
+#else
+    const int ISTEP = 1;
     const int item_end = item + base_cnt + (lb < rem_cnt ? 1 : 0);
+#endif
     if (item >= item_end) return;
 #ifdef W4_PROF
-    const int prof_item = item + 1;
+    const int prof_item = item + ISTEP;
 #endif
 
     auto decode = [&](int it) {
@@ -217,8 +224,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     for (;;) {
         f32x4 acc[NPOS];
-        const bool more_items = item + 1 < item_end;
-        const Item wnx = more_items ? decode(item + 1) : w;
+        const bool more_items = item + ISTEP < item_end;
+        const Item wnx = more_items ? decode(item + ISTEP) : w;
         const __amdgpu_buffer_rsrc_t rw_nx = more_items ? make_rsrc(w_base(wnx)) : rw;
         const bool mask_cur = hangs_over(w), mask_next = hangs_over(wnx);
         const int edge_next = edge_bits(wnx), edge_cur = edge_bits(w);
@@ -403,7 +410,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
 #endif
         if (!more_items) break;
-        ++item;
+        item += ISTEP;
         w = wnx;
         rw = rw_nx;
     }
