@@ -28,7 +28,7 @@ constexpr int OPX = 68;                       // output staging: floats per pixe
 static_assert(256 * OPX + 16 <= V_FLOATS, "a block's outputs are staged in one V buffer");
 constexpr int RP = 9;                         // weight ring, in positions (two 16-byte operands each); 36 % RP == 0
 #ifndef W4B_WDP
-#define W4B_WDP 6
+#define W4B_WDP 4
 #endif
 constexpr int WDP = W4B_WDP;                  // weight prefetch distance in positions (256 matrix-pipe cycles each)
 static_assert(NPOS % RP == 0 && WDP + 2 <= RP && WDP % 2 == 0, "weight ring");
@@ -45,8 +45,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
 }
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#ifndef W4B_WAUX
+#define W4B_WAUX 0
+#endif
 __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, W4B_WAUX));
 }
 __device__ __forceinline__ void buf_store(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, soff, 0);
