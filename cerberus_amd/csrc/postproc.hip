@@ -176,12 +176,18 @@ __global__ void ccl_merge_kernel(const uint8_t* __restrict__ fg, uint8_t val, in
         pix_yx(p, W, invW, y_, x);
         const bool left = x > 0 && fg[p - 1] == val;
         const bool chunk_start = (p & 63) == 0 || !left;  // first pixel of its run inside the 64-pixel chunk
+#ifndef PP_ABL_NOUNION
         if (left && (p & 63) == 0) uf_union(L, (int)p, (int)p - 1);  // run continues across the chunk boundary
+#endif
         if (p >= W && fg[p - W] == val) {
             // one union per (upper run, lower run) pair: at the first column where they overlap either the lower run starts
             // here, or the upper run does (its left neighbour is background)
             const bool up_starts = !(x > 0 && fg[p - W - 1] == val);
+#ifndef PP_ABL_NOUNION
             if (chunk_start || up_starts) uf_union(L, (int)p, (int)(p - W));
+#else
+            if ((chunk_start || up_starts) && L[p] == -12345) L[p] = 0;
+#endif
         }
     }
 }
@@ -197,10 +203,113 @@ static unsigned grid_for(long long n) {
     if (b < 1) b = 1;
     return (unsigned)b;
 }
+// Tile-local labelling (round 2): a workgroup labels a 64 x 32-pixel tile with its union-find in LDS (an LDS atomic is ~20x cheaper than
+// the L2 round trips of a global uf_union, and a run-pair union of the global merge pass cost 2-3 us of serial latency), writes every
+// pixel's tile root as a GLOBAL index, and only the pixel pairs across tile borders (1/32 of the rows, 1/64 of the columns) go through
+// the global union-find.  Roots stay "smallest raster index of the component", so the labels are the ones ccl_init / ccl_merge gave.
+constexpr int CT_W = 64, CT_H = 32;
+__device__ __forceinline__ int lds_find(volatile int* L, int x) {
+    int p = L[x];
+    while (p != x) {
+        x = p;
+        p = L[x];
+    }
+    return x;
+}
+__device__ __forceinline__ void lds_union(int* L, int a, int b) {
+    bool done;
+    do {
+        a = lds_find(L, a);
+        b = lds_find(L, b);
+        if (a < b) {
+            const int old = atomicMin(&L[b], a);
+            done = (old == b);
+            b = old;
+        } else if (b < a) {
+            const int old = atomicMin(&L[a], b);
+            done = (old == a);
+            a = old;
+        } else
+            done = true;
+    } while (!done);
+}
+__global__ __launch_bounds__(256) void ccl_tile_kernel(const uint8_t* __restrict__ fg, uint8_t val, int* __restrict__ L, int H, int W, int tiles_x, int n_tiles) {
+    __shared__ int sl[CT_H * CT_W];
+    __shared__ u64 smask[CT_H];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int tx0 = (tile % tiles_x) * CT_W, ty0 = (tile / tiles_x) * CT_H;
+        const int x = tx0 + lane;
+        // rows wave*8 .. +7: every pixel points at the first pixel of its horizontal run inside the tile (ballot, no atomics)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave * 8 + i, y = ty0 + r;
+            const bool f = x < W && y < H && fg[(long long)y * W + x] == val;
+            const u64 m = __ballot(f);
+            const u64 starts = m & ~(m << 1);
+            sl[r * CT_W + lane] = f ? r * CT_W + 63 - __clzll((long long)(starts & ((2ull << lane) - 1))) : -1;
+            if (lane == 0) smask[r] = m;
+        }
+        __syncthreads();
+        // one union per pair of vertically adjacent runs: at the first column where they overlap
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave * 8 + i;
+            if (r == 0) continue;
+            const u64 m = smask[r], up = smask[r - 1];
+            const u64 both = m & up;
+            const u64 first = both & (~(m << 1) | ~(up << 1));  // the lower run starts here, or the upper one does
+            if ((first >> lane) & 1) lds_union(sl, r * CT_W + lane, (r - 1) * CT_W + lane);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave * 8 + i, y = ty0 + r;
+            if (x < W && y < H) {
+                const int l = sl[r * CT_W + lane];
+                int g = -1;
+                if (l >= 0) {
+                    const int root = lds_find(sl, l);
+                    g = (ty0 + (root >> 6)) * W + tx0 + (root & 63);
+                }
+                L[(long long)y * W + x] = g;
+            }
+        }
+        __syncthreads();
+    }
+}
+// unions across tile borders: vertical seams (x a multiple of 64: the run continues), horizontal seams (y a multiple of 32: one union per
+// pair of tile-clipped runs, at the first column where they overlap)
+__global__ void ccl_seam_kernel(const uint8_t* __restrict__ fg, uint8_t val, int* L, int H, int W, int tiles_x, int tiles_y) {
+    const long long nv = (long long)(tiles_x - 1) * H, nh = (long long)(tiles_y - 1) * W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nv + nh; i += (long long)gridDim.x * blockDim.x) {
+        if (i < nv) {
+            const int y = (int)(i % H), x = ((int)(i / H) + 1) * CT_W;
+            const long long p = (long long)y * W + x;
+            if (fg[p] == val && fg[p - 1] == val) uf_union(L, (int)p, (int)p - 1);
+        } else {
+            const long long j = i - nv;
+            const int x = (int)(j % W), y = ((int)(j / W) + 1) * CT_H;
+            const long long p = (long long)y * W + x;
+            if (fg[p] != val || fg[p - W] != val) continue;
+            const bool edge = (x % CT_W) == 0;
+            const bool low_starts = edge || fg[p - 1] != val, up_starts = edge || fg[p - W - 1] != val;
+            if (low_starts || up_starts) uf_union(L, (int)p, (int)(p - W));
+        }
+    }
+}
 static int ccl_run(const uint8_t* fg, uint8_t val, int* L, int H, int W, hipStream_t st) {
     const int n = H * W;
+#ifdef PP_CCL_GLOBAL  // round 1's labelling: run-based init + one global union per run pair
     hipLaunchKernelGGL(ccl_init_kernel, dim3(grid_for(n)), dim3(256), 0, st, fg, val, L, n, W);
     hipLaunchKernelGGL(ccl_merge_kernel, dim3(grid_for(n)), dim3(256), 0, st, fg, val, L, H, W);
+#else
+    const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H;
+    const int n_tiles = tiles_x * tiles_y;
+    hipLaunchKernelGGL(ccl_tile_kernel, dim3(n_tiles < 256 * 16 ? n_tiles : 256 * 16), dim3(256), 0, st, fg, val, L, H, W, tiles_x, n_tiles);
+    const long long seams = (long long)(tiles_x - 1) * H + (long long)(tiles_y - 1) * W;
+    if (seams > 0) hipLaunchKernelGGL(ccl_seam_kernel, dim3(grid_for(seams)), dim3(256), 0, st, fg, val, L, H, W, tiles_x, tiles_y);
+#endif
     hipLaunchKernelGGL(ccl_flatten_kernel, dim3(grid_for(n)), dim3(256), 0, st, L, n);
     KCHECK();
     return 0;
