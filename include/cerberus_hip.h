@@ -86,7 +86,7 @@ int cerb_net_forward(cerb_net* net, const cerb_forward_io* io, void* hip_stream)
  *                 operands (conv_wino3.hip; fp32 accumulate).  It leaves the fp32 matrix instruction, so it is never the default and
  *                 never what bench.py's headline measures (BASELINE.json configs[1]: fp32).
  *   3, 4        = F(2x2,3x3) with another work decomposition (conv_wino16.hip, conv_wino16d.hip), not faster than 1.
- * The training step always uses the F(2x2) kernels. */
+ * The training step follows the same rule for its forward and data-gradient convolutions (filter transform on the device). */
 int cerb_net_set_conv_algo(cerb_net* net, int algo);
 /* Output heads (models/utils/net_layers.py:31-38): 1 (default) = every dense head of the batch in ONE grouped launch with the head's
  * weights resident in LDS (head_group_kernel), 0 = one launch per head (round-1 head_kernel); identical arithmetic, for A/B. */
