@@ -229,8 +229,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 d[r][q] = ok ? d[r][q] : z;
             }
     };
-    // B^T x for the points (0, 1, -1, 2, -2, inf), in place: 12 packed operations
-    auto bt6 = [&](f32x2& x0, f32x2& x1, f32x2& x2, f32x2& x3, f32x2& x4, f32x2& x5) {
+    // B^T x for the points (0, 1, -1, 2, -2, inf), in place: 12 packed operations.  Written as v_pk_fma_f32 / v_pk_add_f32 by hand: hipcc
+    // (ROCm 7.2) scalarises vector subtractions and multiplies by negative literals (116 v_fma_f32 + 44 v_add_f32 + 64 packed instructions
+    // per chunk instead of 144 packed ones), and every VALU instruction of this wave is a matrix-pipe cycle lost (one wave per SIMD).
+    f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, k5 = {5.f, 5.f};
+    asm volatile("" : "+v"(k2), "+v"(k4), "+v"(k5));
+    auto bt6 = [&](f32x2& x0, f32x2& x1, f32x2& x2, f32x2& x3, f32x2& x4, f32x2& x5) __attribute__((always_inline)) {
+#ifdef W4_C_XF
         const f32x2 t0 = x4 - 4.f * x2, t1 = x3 - 4.f * x1;
         const f32x2 u0 = x4 - x2, u1 = x3 - x1;
         x0 = (4.f * x0 + x4) - 5.f * x2;
@@ -239,6 +244,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         x2 = t0 - t1;
         x3 = u0 + 2.f * u1;
         x4 = u0 - 2.f * u1;
+#else
+        f32x2 t0, t1, u0, u1;
+        asm("v_pk_fma_f32 %6, %2, %11, %4 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"   // t0 = x4 - 4 x2
+            "v_pk_fma_f32 %7, %1, %11, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"   // t1 = x3 - 4 x1
+            "v_pk_add_f32 %8, %4, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"            // u0 = x4 - x2
+            "v_pk_add_f32 %9, %3, %1 neg_lo:[0,1] neg_hi:[0,1]\n\t"            // u1 = x3 - x1
+            "v_pk_fma_f32 %0, %0, %11, %4\n\t"                                  // x0 = 4 x0 + x4
+            "v_pk_fma_f32 %5, %1, %11, %5\n\t"                                  // x5 = 4 x1 + x5
+            "v_pk_fma_f32 %0, %2, %12, %0 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"   // x0 -= 5 x2
+            "v_pk_fma_f32 %5, %3, %12, %5 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"   // x5 -= 5 x3
+            "v_pk_add_f32 %1, %6, %7\n\t"                                       // x1 = t0 + t1
+            "v_pk_add_f32 %2, %6, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"            // x2 = t0 - t1
+            "v_pk_fma_f32 %3, %9, %10, %8\n\t"                                  // x3 = u0 + 2 u1
+            "v_pk_fma_f32 %4, %9, %10, %8 neg_lo:[1,0,0] neg_hi:[1,0,0]"         // x4 = u0 - 2 u1
+            : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "=&v"(t0), "=&v"(t1), "=&v"(u0), "=&v"(u1)
+            : "v"(k2), "v"(k4), "v"(k5));
+#endif
     };
     auto pass_v = [&](int q) { bt6(d[0][q], d[1][q], d[2][q], d[3][q], d[4][q], d[5][q]); };  // down column q
     auto pass_h = [&](int r) { bt6(d[r][0], d[r][1], d[r][2], d[r][3], d[r][4], d[r][5]); };  // along row r

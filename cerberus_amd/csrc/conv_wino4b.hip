@@ -26,7 +26,10 @@ constexpr int V_FLOATS = NPOS * NT * CB;      // one V buffer: 72 KiB
 constexpr int LDS_BYTES = 2 * V_FLOATS * 4;   // double-buffered: 144 KiB
 constexpr int OPX = 68;                       // output staging: floats per pixel (64 channels + 4: bank skew)
 static_assert(256 * OPX + 16 <= V_FLOATS, "a block's outputs are staged in one V buffer");
-constexpr int RP = 9;                         // weight ring, in positions (two 16-byte operands each); 36 % RP == 0
+#ifndef W4B_RP
+#define W4B_RP 9
+#endif
+constexpr int RP = W4B_RP;                    // weight ring, in positions (two 16-byte operands each); 36 % RP == 0
 #ifndef W4B_WDP
 #define W4B_WDP 4
 #endif
@@ -43,6 +46,11 @@ constexpr int CHUNK_W_BYTES = 4 * WAVE_W_BYTES;   // packed weights of one (cout
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+// the input patch: 2 GiB of range, so that a lane offset of 0x80000000 is out of range and the hardware returns zeros (zero padding of the
+// image border without a single VALU instruction)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_lim(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef W4B_WAUX
@@ -139,26 +147,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int rowb = p.W * p.Cin * 4, pixb = p.Cin * 4;
 
     f32x2 d[2][6][6];  // raw patches (two channels) of the chunks with even / odd index: one is being loaded while the other is transformed
-    auto issue = [&](int P, __amdgpu_buffer_rsrc_t r, int chunk_off, int k) __attribute__((always_inline)) { d[P][k / 6][k % 6] = buf_load2(r, ioff, chunk_off + (k / 6) * rowb + (k % 6) * pixb); };
     const bool lane_left = (ttx == 0), lane_right = (ttx == 3);
-    auto mask_edges = [&](int P, int bits) __attribute__((always_inline)) {
-        const f32x2 z = {0.f, 0.f};
-        if (bits & 3) {
-            const bool zt = (bits & 1) && a == 0, zb = (bits & 2) && a == 3;  // wave-uniform: a wave is one tile row
+    // Zero padding at the image border by ADDRESS: the lane offset of a patch element that lies outside the image is out of the buffer's
+    // range.  Nine offsets (patch row first / inner / last x column first / inner / last) are derived from the block's edge bits once per
+    // chunk; the former in-register masking cost ~100 VALU instructions per chunk (selects + the copies that merged its two code paths),
+    // each of them matrix-pipe time at one wave per SIMD.  Blocks hanging over the image keep the per-pixel mask (mask_border).
+    struct EdgeOff { unsigned o[3][3]; };
+    auto edge_offsets = [&](int bits) __attribute__((always_inline)) {
+        EdgeOff e;
+        const bool zt = (bits & 1) && a == 0, zb = (bits & 2) && a == 3;  // wave-uniform: a wave is one tile row
+        const bool zl = (bits & 4) && lane_left, zr = (bits & 8) && lane_right;
+        const unsigned col[3] = {zl ? 0x80000000u : ioff, ioff, zr ? 0x80000000u : ioff};
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                d[P][0][q] = zt ? z : d[P][0][q];
-                d[P][5][q] = zb ? z : d[P][5][q];
-            }
+        for (int qc = 0; qc < 3; ++qc) {
+            e.o[0][qc] = zt ? 0x80000000u : col[qc];
+            e.o[1][qc] = col[qc];
+            e.o[2][qc] = zb ? 0x80000000u : col[qc];
         }
-        if (bits & 12) {
-            const bool zl = (bits & 4) && lane_left, zr = (bits & 8) && lane_right;
+        // pinned in registers: left alone, hipcc re-derives the select in front of every load
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                d[P][r][0] = zl ? z : d[P][r][0];
-                d[P][r][5] = zr ? z : d[P][r][5];
-            }
-        }
+        for (int rc = 0; rc < 3; ++rc)
+#pragma unroll
+            for (int qc = 0; qc < 3; ++qc) asm volatile("" : "+v"(e.o[rc][qc]));
+        return e;
+    };
+    auto issue = [&](int P, __amdgpu_buffer_rsrc_t r, const EdgeOff& e, int chunk_off, int k) __attribute__((always_inline)) {
+        const int rr = k / 6, qq = k % 6;
+        d[P][rr][qq] = buf_load2(r, e.o[rr == 0 ? 0 : rr == 5 ? 2 : 1][qq == 0 ? 0 : qq == 5 ? 2 : 1], chunk_off + rr * rowb + qq * pixb);
     };
     auto mask_border = [&](int P, const Item& b) __attribute__((always_inline)) {
         const f32x2 z = {0.f, 0.f};
@@ -171,8 +186,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 d[P][r][q] = ok ? d[P][r][q] : z;
             }
     };
-    // B^T x for the points (0, 1, -1, 2, -2, inf), in place: 12 packed operations
-    auto bt6 = [&](f32x2& x0, f32x2& x1, f32x2& x2, f32x2& x3, f32x2& x4, f32x2& x5) {
+    // B^T x for the points (0, 1, -1, 2, -2, inf), in place: 12 packed operations.  Written as v_pk_fma_f32 / v_pk_add_f32 by hand: hipcc
+    // (ROCm 7.2) scalarises vector subtractions and multiplies by negative literals (116 v_fma_f32 + 44 v_add_f32 + 64 packed instructions
+    // per chunk instead of 144 packed ones), and every VALU instruction of this wave is a matrix-pipe cycle lost (one wave per SIMD).
+    f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, k5 = {5.f, 5.f};
+    asm volatile("" : "+v"(k2), "+v"(k4), "+v"(k5));
+    auto bt6 = [&](f32x2& x0, f32x2& x1, f32x2& x2, f32x2& x3, f32x2& x4, f32x2& x5) __attribute__((always_inline)) {
+#ifdef W4_C_XF
         const f32x2 t0 = x4 - 4.f * x2, t1 = x3 - 4.f * x1;
         const f32x2 u0 = x4 - x2, u1 = x3 - x1;
         x0 = (4.f * x0 + x4) - 5.f * x2;
@@ -181,24 +201,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         x2 = t0 - t1;
         x3 = u0 + 2.f * u1;
         x4 = u0 - 2.f * u1;
+#else
+        f32x2 t0, t1, u0, u1;
+        asm("v_pk_fma_f32 %6, %2, %11, %4 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"   // t0 = x4 - 4 x2
+            "v_pk_fma_f32 %7, %1, %11, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"   // t1 = x3 - 4 x1
+            "v_pk_add_f32 %8, %4, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"            // u0 = x4 - x2
+            "v_pk_add_f32 %9, %3, %1 neg_lo:[0,1] neg_hi:[0,1]\n\t"            // u1 = x3 - x1
+            "v_pk_fma_f32 %0, %0, %11, %4\n\t"                                  // x0 = 4 x0 + x4
+            "v_pk_fma_f32 %5, %1, %11, %5\n\t"                                  // x5 = 4 x1 + x5
+            "v_pk_fma_f32 %0, %2, %12, %0 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"   // x0 -= 5 x2
+            "v_pk_fma_f32 %5, %3, %12, %5 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"   // x5 -= 5 x3
+            "v_pk_add_f32 %1, %6, %7\n\t"                                       // x1 = t0 + t1
+            "v_pk_add_f32 %2, %6, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"            // x2 = t0 - t1
+            "v_pk_fma_f32 %3, %9, %10, %8\n\t"                                  // x3 = u0 + 2 u1
+            "v_pk_fma_f32 %4, %9, %10, %8 neg_lo:[1,0,0] neg_hi:[1,0,0]"         // x4 = u0 - 2 u1
+            : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "=&v"(t0), "=&v"(t1), "=&v"(u0), "=&v"(u1)
+            : "v"(k2), "v"(k4), "v"(k5));
+#endif
     };
     auto pass_v = [&](int P, int q) __attribute__((always_inline)) { bt6(d[P][0][q], d[P][1][q], d[P][2][q], d[P][3][q], d[P][4][q], d[P][5][q]); };  // down column q
     auto pass_h = [&](int P, int r) __attribute__((always_inline)) { bt6(d[P][r][0], d[P][r][1], d[P][r][2], d[P][r][3], d[P][r][4], d[P][r][5]); };  // along row r
+#ifdef W4B_ABL_NOVW
+    f32x2 abl_sink = {0.f, 0.f};
+#endif
     auto write_row = [&](int P, int r) __attribute__((always_inline)) {  // patch of parity P -> V buffer P
+#ifdef W4B_ABL_NOVW
+#pragma unroll
+        for (int b = 0; b < 6; ++b) abl_sink += d[P][r][b];
+        if (abl_sink[0] == 1.2345e-30f) lds[vw] = abl_sink[1];
+#else
 #pragma unroll
         for (int b = 0; b < 6; ++b) *reinterpret_cast<f32x2*>(lds + P * V_FLOATS + (r * 6 + b) * NT * CB + vw) = d[P][r][b];
+#endif
     };
 
     // ---- prologue: chunk 0 of the first item into V buffer 0, chunk 1's patch requested ------------------------------------------
     Item w = decode(item);
     {
-        const __amdgpu_buffer_rsrc_t r0 = make_rsrc(in_base(w));
+        const __amdgpu_buffer_rsrc_t r0 = make_rsrc_lim(in_base(w));
+        const EdgeOff e0 = edge_offsets(hangs_over(w) ? 0 : edge_bits(w));
 #pragma unroll
-        for (int k = 0; k < 36; ++k) issue(0, r0, 0, k);
+        for (int k = 0; k < 36; ++k) issue(0, r0, e0, 0, k);
 #pragma unroll
-        for (int k = 0; k < 36; ++k) issue(1, r0, CB * 4, k);
+        for (int k = 0; k < 36; ++k) issue(1, r0, e0, CB * 4, k);
         if (hangs_over(w)) mask_border(0, w);
-        else mask_edges(0, edge_bits(w));
     }
 #pragma unroll
     for (int q = 0; q < 6; ++q) pass_v(0, q);
@@ -250,9 +296,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const bool a_next = (ch + 1 >= nchunk);           // the chunk being transformed belongs to the next item
             const bool b_next = (ch + 2 >= nchunk);           // the chunk being requested belongs to the next item
             const bool mask_a = a_next ? mask_next : mask_cur;
-            const int edge_a = a_next ? edge_next : edge_cur;
-            const __amdgpu_buffer_rsrc_t r_stage = make_rsrc(b_next ? in_nx : in_cur);
+#ifdef W4B_ABL_PATCHHOT
+            const __amdgpu_buffer_rsrc_t r_stage = make_rsrc_lim(reinterpret_cast<const char*>(p.in) + (blockIdx.x & 7) * 65536);  // cache-resident
+            const int stage_off = 0;
+#else
+            const __amdgpu_buffer_rsrc_t r_stage = make_rsrc_lim(b_next ? in_nx : in_cur);
+            const EdgeOff eB = edge_offsets((b_next ? mask_next : mask_cur) ? 0 : (b_next ? edge_next : edge_cur));
             const int stage_off = (b_next ? ch + 2 - nchunk : ch + 2) * (CB * 4);
+#endif
             const int wcur_off = ch * CHUNK_W_BYTES;
             const bool last_ch = (ch == nchunk - 1);
             const __amdgpu_buffer_rsrc_t rw_over = last_ch ? rw_nx : rw;
@@ -291,19 +342,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
                 }
 #ifndef W4B_ABL_NOPATCH
-                issue(P, r_stage, stage_off, 2 * s);
-                issue(P, r_stage, stage_off, 2 * s + 1);
+                issue(P, r_stage, eB, stage_off, 2 * s);
+#ifndef W4B_ABL_HALFLOADS
+                issue(P, r_stage, eB, stage_off, 2 * s + 1);
+#endif
 #endif
                 // the patch of chunk ch + 1 landed long ago: mask, B^T d B (one 1-D pass per step) and the V writes into the OTHER buffer
                 if (s == TQ) {
                     if (mask_a) mask_border(Q, a_next ? wnx : w);
-                    else if (edge_a) mask_edges(Q, edge_a);
                 }
+#ifndef W4B_ABL_NOXF
+#ifndef W4B_ABL_XFLITE
                 if (s > TQ && s <= TQ + 6) pass_v(Q, s - TQ - 1);
+#endif
                 if (s > TQ + 6 && s <= TQ + 12) {
+#ifndef W4B_ABL_XFLITE
                     pass_h(Q, s - TQ - 7);
+#endif
                     write_row(Q, s - TQ - 7);
                 }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int G = 0; G < 2; ++G)
