@@ -18,7 +18,7 @@ for i in range(n_cases):
     h, w = 16 * int(rs.randint(1, 26)), 16 * int(rs.randint(1, 26))
     n = int(rs.randint(1, 4))
     out = [int(rs.randint(2, h + 1)), int(rs.randint(2, w + 1))] if rs.randint(2) else [h, w]  # a side of 1 trips the reference's own squeeze (run_desc.py:484-487)
-    algo = int(rs.randint(2))
+    algo = [0, 1, 5, 6, 7, 6, 7, 5][int(rs.randint(8))]  # direct, F(2x2), and the three F(4x4) choices
     m.set_conv_algo(algo)
     tiles = rs.randint(0, 256, (n, h, w, 3)).astype(np.uint8)
     got = infer_step(torch.from_numpy(tiles), m, out, kw["considered_tasks"])
