@@ -85,6 +85,10 @@ constexpr int WAVE_W_BYTES = NPOS * 1024;       // one wave's share: 36 steps x 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
 }
+// the input patch: 2 GiB of range, so that a lane offset of 0x80000000 is out of range and the hardware returns zeros (conv_wino4b.hip)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_lim(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
@@ -197,28 +201,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int rowb = p.W * p.Cin * 4, pixb = p.Cin * 4;
 
     f32x2 d[6][6];  // raw patch of the NEXT chunk (two channels), transformed in place in the shadow of the matrix pipe
-    auto issue = [&](__amdgpu_buffer_rsrc_t r, int chunk_off, int k) { d[k / 6][k % 6] = buf_load2(r, ioff, chunk_off + (k / 6) * rowb + (k % 6) * pixb); };
     const bool lane_top = (tty == 0), lane_bot = (tty == 3), lane_left = (ttx == 0), lane_right = (ttx == 3);
-    auto mask_edges = [&](int bits) {
-        const f32x2 z = {0.f, 0.f};
-        if (bits & 3) {
-            const bool zt = (bits & 1) && lane_top, zb = (bits & 2) && lane_bot;
+    // zero padding at the image border by ADDRESS (conv_wino4b.hip): nine lane offsets per chunk instead of ~100 VALU instructions of masking
+    struct EdgeOff { unsigned o[3][3]; };
+    auto edge_offsets = [&](int bits) __attribute__((always_inline)) {
+        EdgeOff e;
+        const bool zt = (bits & 1) && lane_top, zb = (bits & 2) && lane_bot, zl = (bits & 4) && lane_left, zr = (bits & 8) && lane_right;
+        const unsigned col[3] = {zl ? 0x80000000u : ioff, ioff, zr ? 0x80000000u : ioff};
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                d[0][q] = zt ? z : d[0][q];
-                d[5][q] = zb ? z : d[5][q];
-            }
+        for (int qc = 0; qc < 3; ++qc) {
+            e.o[0][qc] = zt ? 0x80000000u : col[qc];
+            e.o[1][qc] = col[qc];
+            e.o[2][qc] = zb ? 0x80000000u : col[qc];
         }
-        if (bits & 12) {
-            const bool zl = (bits & 4) && lane_left, zr = (bits & 8) && lane_right;
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                d[r][0] = zl ? z : d[r][0];
-                d[r][5] = zr ? z : d[r][5];
-            }
-        }
+        for (int rc = 0; rc < 3; ++rc)
+#pragma unroll
+            for (int qc = 0; qc < 3; ++qc) asm volatile("" : "+v"(e.o[rc][qc]));
+        return e;
     };
-    auto mask_border = [&](const Blk& b) {
+    auto issue = [&](__amdgpu_buffer_rsrc_t r, const EdgeOff& e, int chunk_off, int k) __attribute__((always_inline)) {
+        const int rr = k / 6, qq = k % 6;
+        d[rr][qq] = buf_load2(r, e.o[rr == 0 ? 0 : rr == 5 ? 2 : 1][qq == 0 ? 0 : qq == 5 ? 2 : 1], chunk_off + rr * rowb + qq * pixb);
+    };
+    auto mask_border = [&](const Blk& b) __attribute__((always_inline)) {
         const f32x2 z = {0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 6; ++r)
@@ -273,11 +279,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     Item w = decode(item);
     {
         const Blk b0_ = mine(w);
-        const __amdgpu_buffer_rsrc_t r0 = make_rsrc(in_base(w.g, b0_));
+        const __amdgpu_buffer_rsrc_t r0 = make_rsrc_lim(in_base(w.g, b0_));
+        const EdgeOff e0 = edge_offsets(hangs_over(b0_) ? 0 : edge_bits(b0_));
 #pragma unroll
-        for (int k = 0; k < 36; ++k) issue(r0, 0, k);
+        for (int k = 0; k < 36; ++k) issue(r0, e0, 0, k);
         if (hangs_over(b0_)) mask_border(b0_);
-        else mask_edges(edge_bits(b0_));
     }
 #pragma unroll
     for (int q = 0; q < 6; ++q) pass_v(q);
@@ -321,19 +327,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_STAMP(k) do { } while (0)
 #endif
 
-        auto chunk = [&](auto first_tag, int ch) {
+        auto chunk = [&](auto first_tag, int ch) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
             const bool last_ch = (ch == nchunk - 1);
             const Blk bp_ = last_ch ? bnx : bcur;
             const bool mask_nx = last_ch ? mask_next : mask_cur;
             const int edge_nx = last_ch ? edge_next : edge_cur;
 #ifdef W4_ABL_PATCHHOT
-            const __amdgpu_buffer_rsrc_t r_stage = make_rsrc(reinterpret_cast<const char*>(p.in) + (blockIdx.x & 7) * 65536);  // cache-resident
+            const __amdgpu_buffer_rsrc_t r_stage = make_rsrc_lim(reinterpret_cast<const char*>(p.in) + (blockIdx.x & 7) * 65536);  // cache-resident
             const int stage_off = 0;
 #else
-            const __amdgpu_buffer_rsrc_t r_stage = make_rsrc(last_ch ? in_nx : in_cur);
+            const __amdgpu_buffer_rsrc_t r_stage = make_rsrc_lim(last_ch ? in_nx : in_cur);
             const int stage_off = (last_ch ? 0 : ch + 1) * (CB * 4);
 #endif
+            const EdgeOff eN = edge_offsets(mask_nx ? 0 : edge_nx);
             const int wcur_off = ch * CHUNK_W_BYTES;
             const __amdgpu_buffer_rsrc_t rw_over = last_ch ? rw_nx : rw;
             const int wover_off = last_ch ? 0 : (ch + 1) * CHUNK_W_BYTES;
@@ -368,16 +375,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                     for (int u = 0; u < PL; ++u)
 #ifdef W4_ABL_HALFPATCH
-                        if ((q - P0) * PL + u < W4_ABL_HALFPATCH) issue(r_stage, stage_off, (q - P0) * PL + u);
+                        if ((q - P0) * PL + u < W4_ABL_HALFPATCH) issue(r_stage, eN, stage_off, (q - P0) * PL + u);
 #else
-                        if ((q - P0) * PL + u < 36) issue(r_stage, stage_off, (q - P0) * PL + u);
+                        if ((q - P0) * PL + u < 36) issue(r_stage, eN, stage_off, (q - P0) * PL + u);
 #endif
                 }
 #endif
                 // the next chunk's patch landed: mask, B^T d B (one 1-D pass per step) and the V writes into the OTHER buffer
                 if (q == TQ) {
                     if (mask_nx) mask_border(bp_);
-                    else if (edge_nx) mask_edges(edge_nx);
                 }
 #ifndef W4_ABL_NOXF
                 if (q > TQ && q <= TQ + 6) pass_v(q - TQ - 1);
