@@ -65,3 +65,23 @@ def test_sgpr_soffset_stores_are_padded(unit, tmp_path):
         assert wait >= 2, "%s: data registers v[%d:%d] of `%s` are rewritten after %d wait state(s)" % (unit, lo, hi, l.strip(), wait)
     if unit != "conv_wino3.hip":
         assert n_sgpr_stores >= 8, "expected the output stage's SGPR-soffset stores in %s (found %d): has the kernel changed shape?" % (unit, n_sgpr_stores)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc not available")
+@pytest.mark.parametrize("unit", ["conv_wino4.hip", "conv_wino4b.hip"])
+def test_f4x4_kernels_keep_their_arrays_in_registers(unit, tmp_path):
+    """The F(4x4) kernels hold 144 / 288 accumulators, the raw patch and the weight ring in (Acc)VGPRs.  Twice during round 2 hipcc put
+    them in scratch without a word: below the full unroll of the 36-step chunk (the pragma-unroll budget of cerberus_amd/build.py) and when
+    it stopped inlining a lambda that takes the patch by reference (3.4x slower, same results).  Guard: no scratch, no out-of-line
+    lambda, no call, and the fully unrolled chunk (>= 1152 matrix instructions per translation unit)."""
+    from cerberus_amd.build import EXTRA_FLAGS
+
+    out = os.path.join(str(tmp_path), unit.replace(".hip", ".s"))
+    res = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--offload-device-only", "-S", "-o", out, "-Rpass-analysis=kernel-resource-usage"]
+                         + EXTRA_FLAGS.get(unit, []) + [os.path.join(CSRC, unit)], stderr=subprocess.PIPE, universal_newlines=True, check=True)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", res.stderr)]
+    assert scratch and max(scratch) == 0, scratch
+    asm = open(out).read()
+    assert not re.search(r"^_ZZ", asm, re.M), "a lambda was compiled out of line"
+    assert "s_swappc_b64" not in asm and "scratch_" not in asm
+    assert asm.count("v_mfma_f32_16x16x4") >= 1152
