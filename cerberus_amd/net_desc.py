@@ -344,8 +344,9 @@ class NetDesc(torch.nn.Module):
         _lib.check(_lib.lib().cerb_net_set_head_algo(self._ensure_handle(), int(algo)))
 
     def set_conv_algo(self, algo):
-        """0 = direct implicit GEMM, 1 = Winograd F(2x2,3x3) (default), 2 = experimental Winograd with bf16x3-split products
-        (see include/cerberus_hip.h) for the 3x3 stride-1 convolutions."""
+        """Algorithm of the 3x3 stride-1 convolutions (include/cerberus_hip.h): 6 = Winograd F(4x4,3x3) for maps of 16 x 16 pixels and more,
+        F(2x2,3x3) below (default); 5 / 7 = F(4x4) everywhere with conv_wino4 / conv_wino4b; 1 = F(2x2); 0 = direct implicit GEMM;
+        2, 3, 4 = experimental F(2x2) variants."""
         _lib.check(_lib.lib().cerb_net_set_conv_algo(self._ensure_handle(), int(algo)))
 
     def set_crop_roi(self, enable=True):
