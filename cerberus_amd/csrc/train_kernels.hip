@@ -697,40 +697,59 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const unsigned char* __
 // torch.nn.functional.max_pool2d records it) it is
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ypool, const float* __restrict__ dy,
                                                           float* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
-    const long long total = (long long)N * H * W * C;
+    // thread = four channels of an input pixel (C is a multiple of 4): one index decode, 16-byte accesses; per channel the rule is unchanged
+    const int C4 = C >> 2;
+    const long long total = (long long)N * H * W * C4;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        long long r = i / C;
+        const int c = 4 * (int)(i % C4);
+        long long r = i / C4;
         const int ix = (int)(r % W);
         r /= W;
         const int iy = (int)(r % H), n = (int)(r / H);
-        const float xv = x[i];
-        float acc = 0.f;
+        const long long xi = (((long long)n * H + iy) * W + ix) * C + c;
+        const float4 xv4 = *reinterpret_cast<const float4*>(x + xi);
+        const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int oy = (iy + 1 - 2 + 1) / 2; oy <= (iy + 1) / 2; ++oy) {      // windows with oy*2-1 <= iy <= oy*2+1
             if (oy < 0 || oy >= Ho) continue;
             for (int ox = (ix + 1 - 2 + 1) / 2; ox <= (ix + 1) / 2; ++ox) {
                 if (ox < 0 || ox >= Wo) continue;
+                const long long oi = (((long long)n * Ho + oy) * Wo + ox) * C + c;
+                const float4 yp4 = *reinterpret_cast<const float4*>(ypool + oi);
+                const float yp[4] = {yp4.x, yp4.y, yp4.z, yp4.w};
                 // the pooled value is the window's maximum: most (pixel, window) pairs end here; a pixel that holds it is the FIRST maximum
                 // when no window element before it in the row-major scan holds it too
-                if (xv != ypool[(((long long)n * Ho + oy) * Wo + ox) * C + c]) continue;
-                bool first = true;
-                for (int ky = 0; ky < 3 && first; ++ky) {
+                bool cand[4], any = false;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    cand[e] = (xv[e] == yp[e]);
+                    any |= cand[e];
+                }
+                if (!any) continue;
+                for (int ky = 0; ky < 3; ++ky) {
                     const int y = oy * 2 - 1 + ky;
                     if (y < 0 || y >= H || y > iy) continue;
                     for (int kx = 0; kx < 3; ++kx) {
                         const int xx = ox * 2 - 1 + kx;
                         if (xx < 0 || xx >= W) continue;
                         if (y == iy && xx >= ix) break;
-                        if (x[(((long long)n * H + y) * W + xx) * C + c] == xv) {
-                            first = false;
-                            break;
-                        }
+                        const float4 o4 = *reinterpret_cast<const float4*>(x + (((long long)n * H + y) * W + xx) * C + c);
+                        if (o4.x == xv[0]) cand[0] = false;
+                        if (o4.y == xv[1]) cand[1] = false;
+                        if (o4.z == xv[2]) cand[2] = false;
+                        if (o4.w == xv[3]) cand[3] = false;
                     }
                 }
-                if (first) acc += dy[(((long long)n * Ho + oy) * Wo + ox) * C + c];
+                const float4 g4 = *reinterpret_cast<const float4*>(dy + oi);
+                if (cand[0]) acc[0] += g4.x;
+                if (cand[1]) acc[1] += g4.y;
+                if (cand[2]) acc[2] += g4.z;
+                if (cand[3]) acc[3] += g4.w;
             }
         }
-        dx[i] += acc;
+        float4 d = *reinterpret_cast<float4*>(dx + xi);
+        d.x += acc[0]; d.y += acc[1]; d.z += acc[2]; d.w += acc[3];
+        *reinterpret_cast<float4*>(dx + xi) = d;
     }
 }
 // out_g = skip + up2(prev_g):  dskip += sum_g dout_g;  dprev_g = transpose of the bilinear x2 (align_corners = False) applied to dout_g
@@ -955,7 +974,7 @@ hipError_t cerb_launch_stem_wgrad(const unsigned char* tiles, const float* dy, f
     return hipGetLastError();
 }
 hipError_t cerb_launch_maxpool_bwd(const float* x, const float* ypool, const float* dy, float* dx, int N, int H, int W, int C, hipStream_t st) {
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(gridfor((long long)N * H * W * C)), dim3(256), 0, st, x, ypool, dy, dx, N, H, W, C, H / 2, W / 2);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(gridfor((long long)N * H * W * (C / 4))), dim3(256), 0, st, x, ypool, dy, dx, N, H, W, C, H / 2, W / 2);
     return hipGetLastError();
 }
 hipError_t cerb_launch_upadd_bwd(const float* dout, float* dskip, float* dprev, int G, int N, int H, int W, int C, long long prev_gs, int shared_prev, hipStream_t st) {
