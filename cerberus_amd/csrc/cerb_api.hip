@@ -146,6 +146,9 @@ struct PackedConv {
     void* wino3 = nullptr;  // device, same weights split into three bf16 planes (conv_wino3.hip, conv_algo 2), packed lazily
     float* wino16 = nullptr;  // device, the transformed weights in conv_wino16.hip's per-wave layout (conv_algo 3), packed lazily
     float* wino16d = nullptr; // device, conv_wino16d.hip's layout (conv_algo 4: 16-channel chunks), packed lazily
+    // train packing: the F(2x2) copies are re-packed after an optimiser step only if a kernel has read them since the handle was made (a
+    // network whose maps all take the F(4x4) kernels never does); a copy that was skipped is stale and is re-packed on first use
+    bool wino_used = false, wino_dgrad_used = false, wino_stale = false, wino_dgrad_stale = false;
     float* wino4_t[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // train packing only: [layout 4 / 4b][forward / data gradient], packed on the
                                                                       // device at first use and again after every optimiser step
     float* wino4b = nullptr;  // device, the same transform in conv_wino4b.hip's layout (32-channel chunks, conv_algo 7), packed lazily
@@ -788,6 +791,21 @@ static int prof_end(cerb_net* net, hipStream_t st) {
     return 0;
 }
 
+static int train_wino2_fresh(cerb_net* net, const std::string& name, PackedConv& cm, int dgrad, hipStream_t st) {
+    if (net->fold_bn) return 0;
+    bool& used = dgrad ? cm.wino_dgrad_used : cm.wino_used;
+    bool& stale = dgrad ? cm.wino_dgrad_stale : cm.wino_stale;
+    used = true;
+    if (!stale) return 0;
+    auto rit = net->raw.find(name);
+    if (rit == net->raw.end()) return fail("conv " + name + ": no raw weights to re-pack");
+    const size_t nw = (size_t)cm.cout * cm.cin * 9, nu = (size_t)cm.cout * cm.cin * 16;
+    for (int g = 0; g < cm.groups; ++g)
+        HIP_OK(cerb_launch_pack_wino(rit->second.w + g * nw, (dgrad ? cm.wino_dgrad : cm.wino) + g * nu, dgrad ? cm.cin : cm.cout, dgrad ? cm.cout : cm.cin, dgrad, st));
+    stale = false;
+    return 0;
+}
+
 // Train packing: the F(4x4,3x3) weights of one conv ([layout 4 / 4b][forward / data gradient]) are transformed on the device from the raw
 // state-dict copy at first use; cerb_net_update_params repeats it for the slots that exist.
 static int train_wino4_slot(cerb_net* net, const std::string& name, PackedConv& cm, int w4b, int dgrad, hipStream_t st, float** out) {
@@ -917,6 +935,7 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
         return 0;
     }
     if (net->conv_algo && c.wino && mode == 0) {
+        if (train_wino2_fresh(net, name, it->second, 0, st)) return 1;
         p.wpack = c.wino;
         p.w_gs = (long long)c.cout * c.cin * 16;
         double fl_done = fl;
@@ -1583,8 +1602,10 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                         p.wpack = w4;
                         p.w_gs = (long long)op.Cout * op.Cin * 36;
                         HIP_OK(d_w4b ? cerb_launch_wino4b(p, st) : cerb_launch_wino4(p, st));
-                    } else
+                    } else {
+                        if (train_wino2_fresh(net, op.name, net->conv[op.name], 1, st)) return 1;
                         HIP_OK(cerb_launch_wino(p, st));
+                    }
                     dx_done = true;
                     go = grd[op.o];
                 }
@@ -1744,13 +1765,15 @@ extern "C" int cerb_net_update_params(cerb_net* net, int count, const char* cons
     }
     HIP_OK(cerb_launch_pack_stem(net->stem_raw, net->stem_w, st));
     for (auto& kv : net->conv) {
-        const PackedConv& pc = kv.second;
+        PackedConv& pc = kv.second;
         const float* rawd = net->raw[kv.first].w;
+        if (pc.wino && !pc.wino_used) pc.wino_stale = true;
+        if (pc.wino_dgrad && !pc.wino_dgrad_used) pc.wino_dgrad_stale = true;
         const size_t nw = (size_t)pc.cout * pc.cin * pc.ks * pc.ks, nu = (size_t)pc.cout * pc.cin * 16;
         for (int g = 0; g < pc.groups; ++g) {
             HIP_OK(cerb_launch_pack_conv(rawd + g * nw, pc.w + g * nw, pc.cout, pc.cin, pc.ks, cerb_conv_chunk(pc.ks, pc.stride), st));
-            if (pc.wino) HIP_OK(cerb_launch_pack_wino(rawd + g * nw, pc.wino + g * nu, pc.cout, pc.cin, 0, st));
-            if (pc.wino_dgrad) HIP_OK(cerb_launch_pack_wino(rawd + g * nw, pc.wino_dgrad + g * nu, pc.cin, pc.cout, 1, st));
+            if (pc.wino && pc.wino_used) HIP_OK(cerb_launch_pack_wino(rawd + g * nw, pc.wino + g * nu, pc.cout, pc.cin, 0, st));
+            if (pc.wino_dgrad && pc.wino_dgrad_used) HIP_OK(cerb_launch_pack_wino(rawd + g * nw, pc.wino_dgrad + g * nu, pc.cin, pc.cout, 1, st));
             const size_t nu4 = (size_t)pc.cout * pc.cin * 36;
             for (int l = 0; l < 2; ++l)
                 for (int dg = 0; dg < 2; ++dg)
