@@ -63,7 +63,7 @@ hipError_t cerb_launch_adam_multi(int count, float* const* p, const float* const
                                   float b2, float eps, int step, hipStream_t st);
 hipError_t cerb_launch_pack_conv(const float* w_raw, float* out, int cout, int cin, int ks, int chunk, hipStream_t st);
 hipError_t cerb_launch_pack_wino(const float* w_raw, float* out, int cout, int cin, int dgrad, hipStream_t st);
-hipError_t cerb_launch_pack_wino4(const float* w_raw, float* out, int cout, int cin, int dgrad, int chunk32, hipStream_t st);
+hipError_t cerb_launch_pack_wino4(const float* w_raw, float* out, int cout, int cin, int dgrad, int chunk32, int groups, hipStream_t st);
 hipError_t cerb_launch_dilate2(const float* dy, float* d, long long n, int H, int W, int C, hipStream_t st);
 size_t cerb_pw_wgrad_small_workspace_bytes(long long rows, int cin, int cout);
 hipError_t cerb_launch_pw_wgrad_small(const float* x, const float* dy, float* dw, long long rows, int cin, int cout, void* ws, hipStream_t st);
@@ -819,8 +819,8 @@ static int train_wino4_slot(cerb_net* net, const std::string& name, PackedConv& 
         net->dev_allocs.push_back(d);
         net->dev_alloc_bytes.push_back((size_t)cm.groups * nu * 4);
         slot = (float*)d;
-        for (int g = 0; g < cm.groups; ++g)
-            HIP_OK(cerb_launch_pack_wino4(rit->second.w + g * nw, slot + g * nu, dgrad ? cm.cin : cm.cout, dgrad ? cm.cout : cm.cin, dgrad, w4b, st));
+        (void)nw;
+        HIP_OK(cerb_launch_pack_wino4(rit->second.w, slot, dgrad ? cm.cin : cm.cout, dgrad ? cm.cout : cm.cin, dgrad, w4b, cm.groups, st));
     }
     *out = slot;
     return 0;
@@ -1774,12 +1774,11 @@ extern "C" int cerb_net_update_params(cerb_net* net, int count, const char* cons
             HIP_OK(cerb_launch_pack_conv(rawd + g * nw, pc.w + g * nw, pc.cout, pc.cin, pc.ks, cerb_conv_chunk(pc.ks, pc.stride), st));
             if (pc.wino && pc.wino_used) HIP_OK(cerb_launch_pack_wino(rawd + g * nw, pc.wino + g * nu, pc.cout, pc.cin, 0, st));
             if (pc.wino_dgrad && pc.wino_dgrad_used) HIP_OK(cerb_launch_pack_wino(rawd + g * nw, pc.wino_dgrad + g * nu, pc.cin, pc.cout, 1, st));
-            const size_t nu4 = (size_t)pc.cout * pc.cin * 36;
-            for (int l = 0; l < 2; ++l)
-                for (int dg = 0; dg < 2; ++dg)
-                    if (pc.wino4_t[l][dg])
-                        HIP_OK(cerb_launch_pack_wino4(rawd + g * nw, pc.wino4_t[l][dg] + g * nu4, dg ? pc.cin : pc.cout, dg ? pc.cout : pc.cin, dg, l, st));
         }
+        for (int l = 0; l < 2; ++l)  // the F(4x4) layouts in use: all groups of the conv in one launch
+            for (int dg = 0; dg < 2; ++dg)
+                if (pc.wino4_t[l][dg])
+                    HIP_OK(cerb_launch_pack_wino4(rawd, pc.wino4_t[l][dg], dg ? pc.cin : pc.cout, dg ? pc.cout : pc.cin, dg, l, pc.groups, st));
     }
     return 0;
 }

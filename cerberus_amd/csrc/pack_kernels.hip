@@ -57,6 +57,8 @@ __global__ __launch_bounds__(256) void pack_wino_kernel(const float* __restrict_
 // gradient: the forward layer's cin / cout, filter W'[ci][co][tap] = W[co][ci][8 - tap])
 __global__ __launch_bounds__(256) void pack_wino4_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int dgrad, int chunk32) {
 #pragma clang fp contract(off)
+    w += (size_t)blockIdx.y * cout * cin * 9;    // one launch packs all the groups of a conv (blockIdx.y)
+    out += (size_t)blockIdx.y * cout * cin * 36;
     const double Gm[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                              {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
     const long long total = (long long)cout * cin * 36;
@@ -101,8 +103,8 @@ hipError_t cerb_launch_pack_conv(const float* w_raw, float* out, int cout, int c
     return hipGetLastError();
 }
 // (cout, cin) are those of the conv the packed filter serves: for dgrad = 1 the transposed pair of the raw tensor
-hipError_t cerb_launch_pack_wino4(const float* w_raw, float* out, int cout, int cin, int dgrad, int chunk32, hipStream_t st) {
-    hipLaunchKernelGGL(pack_wino4_kernel, dim3(pack_grid((long long)cout * cin * 36)), dim3(256), 0, st, w_raw, out, cout, cin, dgrad, chunk32);
+hipError_t cerb_launch_pack_wino4(const float* w_raw, float* out, int cout, int cin, int dgrad, int chunk32, int groups, hipStream_t st) {
+    hipLaunchKernelGGL(pack_wino4_kernel, dim3(pack_grid((long long)cout * cin * 36), groups), dim3(256), 0, st, w_raw, out, cout, cin, dgrad, chunk32);
     return hipGetLastError();
 }
 hipError_t cerb_launch_pack_wino(const float* w_raw, float* out, int cout, int cin, int dgrad, hipStream_t st) {
