@@ -351,6 +351,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(float* x, const float* sr
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int relu) {
     const int c4n = C >> 2;
     const long long per_group = rows * c4n, total = per_group * groups;
+    #pragma unroll 2
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int g = (int)(i / per_group);
         const long long j = i - (long long)g * per_group;
@@ -553,6 +554,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const int c4n = C >> 2;
     const long long per_group = rows * c4n, total = per_group * groups;
     const float invM = 1.f / (float)rows;
+    #pragma unroll 2
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int g = (int)(i / per_group);
         const long long j = i - (long long)g * per_group;
