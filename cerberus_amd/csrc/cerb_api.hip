@@ -19,9 +19,6 @@
 // launchers implemented in the kernel translation units
 hipError_t cerb_launch_conv(const ConvParams& p, int ks, int stride, int mode, hipStream_t st);
 hipError_t cerb_launch_wino(ConvParams p, hipStream_t st);
-hipError_t cerb_launch_wino3(ConvParams p, hipStream_t st);
-hipError_t cerb_launch_wino16(ConvParams p, hipStream_t st);
-hipError_t cerb_launch_wino16d(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino4(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino4b(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_upsample2_add(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C,
@@ -143,9 +140,6 @@ struct PackedConv {
     float* w = nullptr;     // device
     float* wino = nullptr;  // device, 3x3 stride-1 only: Winograd F(2x2,3x3) transformed weights (conv_wino.hip)
     float* wino_dgrad = nullptr;  // train packing only: the same for the DATA GRADIENT -- the conv with rotated, transposed weights
-    void* wino3 = nullptr;  // device, same weights split into three bf16 planes (conv_wino3.hip, conv_algo 2), packed lazily
-    float* wino16 = nullptr;  // device, the transformed weights in conv_wino16.hip's per-wave layout (conv_algo 3), packed lazily
-    float* wino16d = nullptr; // device, conv_wino16d.hip's layout (conv_algo 4: 16-channel chunks), packed lazily
     // train packing: the F(2x2) copies are re-packed after an optimiser step only if a kernel has read them since the handle was made (a
     // network whose maps all take the F(4x4) kernels never does); a copy that was skipped is stale and is re-packed on first use
     bool wino_used = false, wino_dgrad_used = false, wino_stale = false, wino_dgrad_stale = false;
@@ -154,7 +148,6 @@ struct PackedConv {
     float* wino4b = nullptr;  // device, the same transform in conv_wino4b.hip's layout (32-channel chunks, conv_algo 7), packed lazily
     float* wino4 = nullptr;   // device, F(4x4,3x3) transformed weights in conv_wino4.hip's layout (conv_algo 5), packed lazily from host_w
     std::vector<float> host_w;  // BN-folded 3x3 weights [G][cout][cin][9] kept on the host for the lazily packed Winograd variants
-    std::vector<float> host_u;  // fp32 transformed weights kept on the host until conv_algo 2 is first used
     float* b = nullptr;     // device
 };
 
@@ -343,7 +336,7 @@ static void pack_conv(const float* w, const float* scale, int cout, int cin, int
 
 // Winograd F(2x2,3x3) filter transform U = G g G^T (in double, rounded once) in the layout conv_wino.hip streams:
 //   [cb][chunk][a][b][G][s][lane][t]  ->  U[a][b] of W[cb*64 + s*32 + (lane&31)][chunk*32 + G*8 + 4*(lane>>5) + t]
-static void pack_wino(const float* w, const float* scale, int cout, int cin, std::vector<float>* out, std::vector<float>* u_out) {
+static void pack_wino(const float* w, const float* scale, int cout, int cin, std::vector<float>* out) {
     static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     const int nchunk = cin / 32, ncb = cout / 64;
     const size_t base = out->size();
@@ -361,7 +354,6 @@ static void pack_wino(const float* w, const float* scale, int cout, int cin, std
                 for (int b = 0; b < 4; ++b)
                     U[((size_t)co * cin + ci) * 16 + a * 4 + b] = (float)(t[a][0] * Gm[b][0] + t[a][1] * Gm[b][1] + t[a][2] * Gm[b][2]);
         }
-    if (u_out) u_out->insert(u_out->end(), U.begin(), U.end());
     size_t idx = 0;
     for (int cb = 0; cb < ncb; ++cb)
         for (int ch = 0; ch < nchunk; ++ch)
@@ -375,44 +367,6 @@ static void pack_wino(const float* w, const float* scale, int cout, int cin, std
                                     const int ci = ch * 32 + G * 8 + 4 * (lane >> 5) + t;
                                     o[idx++] = U[((size_t)co * cin + ci) * 16 + a * 4 + b];
                                 }
-}
-
-// conv_wino16.hip layout: [cb][chunk][wave a][step q = 2 xi + G][lane][t]  ->  U[xi] of W[cb*64 + 16 a + (lane & 15)][chunk*32 + 16 G + 4 (lane >> 4) + t]
-static void pack_wino16(const float* U, int cout, int cin, std::vector<float>* out) {  // U: [cout][cin][16] from pack_wino's transform
-    const int nchunk = cin / 32, ncb = cout / 64;
-    const size_t base = out->size();
-    out->resize(base + (size_t)cout * cin * 16);
-    float* o = out->data() + base;
-    size_t idx = 0;
-    for (int cb = 0; cb < ncb; ++cb)
-        for (int ch = 0; ch < nchunk; ++ch)
-            for (int a = 0; a < 4; ++a)
-                for (int q = 0; q < 32; ++q)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int t = 0; t < 4; ++t) {
-                            const int co = cb * 64 + 16 * a + (lane & 15);
-                            const int ci = ch * 32 + 16 * (q & 1) + 4 * (lane >> 4) + t;
-                            o[idx++] = U[((size_t)co * cin + ci) * 16 + (q >> 1)];
-                        }
-}
-
-// conv_wino16d.hip layout: [cb][16-channel chunk][wave a][position xi][lane][t]  ->  U[xi] of W[cb*64 + 16 a + (lane & 15)][chunk*16 + 4 (lane >> 4) + t]
-static void pack_wino16d(const float* U, int cout, int cin, std::vector<float>* out) {
-    const int nchunk = cin / 16, ncb = cout / 64;
-    const size_t base = out->size();
-    out->resize(base + (size_t)cout * cin * 16);
-    float* o = out->data() + base;
-    size_t idx = 0;
-    for (int cb = 0; cb < ncb; ++cb)
-        for (int ch = 0; ch < nchunk; ++ch)
-            for (int a = 0; a < 4; ++a)
-                for (int xi = 0; xi < 16; ++xi)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int t = 0; t < 4; ++t) {
-                            const int co = cb * 64 + 16 * a + (lane & 15);
-                            const int ci = ch * 16 + 4 * (lane >> 4) + t;
-                            o[idx++] = U[((size_t)co * cin + ci) * 16 + xi];
-                        }
 }
 
 // Winograd F(4x4,3x3) filter transform U = G g G^T for the points (0, 1, -1, 2, -2, inf), in double, rounded once, in the layout
@@ -465,46 +419,6 @@ static void pack_wino4(const float* w, int cout, int cin, std::vector<float>* ou
                         }
 }
 
-// conv_wino3.hip layout: [cb][chunk][a][b][K-step s2][plane][cout half s][lane][8 bf16]
-//   element i of lane (j, h) = plane(U[a][b] of W[cb*64 + 32 s + j][chunk*32 + 16 s2 + 8 h + i]),  planes = hi, mid, lo of the bf16x3 split
-static uint16_t bf16_rne(float x) {
-    uint32_t u;
-    memcpy(&u, &x, 4);
-    const uint32_t r = u + 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(r >> 16);
-}
-static float bf16_to_f(uint16_t v) {
-    const uint32_t u = (uint32_t)v << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-static void pack_wino3(const float* U, int cout, int cin, std::vector<uint16_t>* out) {  // U: [cout][cin][16] from pack_wino's transform
-    const int nchunk = cin / 32, ncb = cout / 64;
-    const size_t base = out->size();
-    out->resize(base + (size_t)cout * cin * 16 * 3);
-    uint16_t* o = out->data() + base;
-    size_t idx = 0;
-    for (int cb = 0; cb < ncb; ++cb)
-        for (int ch = 0; ch < nchunk; ++ch)
-            for (int a = 0; a < 4; ++a)
-                for (int b = 0; b < 4; ++b)
-                    for (int s2 = 0; s2 < 2; ++s2)
-                        for (int pl = 0; pl < 3; ++pl)
-                            for (int s = 0; s < 2; ++s)
-                                for (int lane = 0; lane < 64; ++lane)
-                                    for (int i = 0; i < 8; ++i) {
-                                        const int co = cb * 64 + s * 32 + (lane & 31);
-                                        const int ci = ch * 32 + s2 * 16 + 8 * (lane >> 5) + i;
-                                        const float x = U[((size_t)co * cin + ci) * 16 + a * 4 + b];
-                                        const uint16_t hi = bf16_rne(x);
-                                        const float r1 = x - bf16_to_f(hi);
-                                        const uint16_t mid = bf16_rne(r1);
-                                        const uint16_t lo = bf16_rne(r1 - bf16_to_f(mid));
-                                        o[idx++] = pl == 0 ? hi : pl == 1 ? mid : lo;
-                                    }
-}
-
 static int store_bn(cerb_net* net, const std::string& name, const std::vector<std::string>& bnkeys, int ch) {
     std::vector<float> ga, be;
     for (const std::string& k : bnkeys) {
@@ -532,7 +446,7 @@ static int make_conv(cerb_net* net, const std::string& name, const std::vector<s
     // one entry per group
     const int CB = cerb_conv_chunk(ks, stride);
     if (cout % 64 || cin % CB) return fail("conv " + name + ": unsupported channel counts");
-    std::vector<float> wp, bp, wwino, hu, hw;
+    std::vector<float> wp, bp, wwino, hw;
     const bool wino = (ks == 3 && stride == 1 && cin % 32 == 0);
     for (size_t g = 0; g < wkeys.size(); ++g) {
         const HostTensor* w;
@@ -543,7 +457,7 @@ static int make_conv(cerb_net* net, const std::string& name, const std::vector<s
         if (net->fold_bn) {  // handles packed for training lay their weights out on the device (below)
             pack_conv(w->data.data(), have_bn ? f.scale.data() : nullptr, cout, cin, ks, CB, &wp);
             if (wino) {
-                pack_wino(w->data.data(), have_bn ? f.scale.data() : nullptr, cout, cin, &wwino, &hu);
+                pack_wino(w->data.data(), have_bn ? f.scale.data() : nullptr, cout, cin, &wwino);
                 const size_t b0 = hw.size();
                 hw.insert(hw.end(), w->data.begin(), w->data.end());
                 if (have_bn)
@@ -590,7 +504,6 @@ static int make_conv(cerb_net* net, const std::string& name, const std::vector<s
     if (net->fold_bn) {
         if (upload(net, wp, &pc.w)) return 1;
         if (wino && upload(net, wwino, &pc.wino)) return 1;
-        pc.host_u.swap(hu);
         pc.host_w.swap(hw);
     } else {
         // packed on the device from the raw copy (pack_kernels.hip): nothing but the state-dict tensors crosses PCIe after an optimiser step.
@@ -850,25 +763,6 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
         if (!out) return 0;
     }
     const double fl = 2.0 * (double)c.groups * N * p.Ho * p.Wo * (double)c.cout * c.cin * c.ks * c.ks;
-    if (net->conv_algo == 2 && c.wino && mode == 0) {
-        PackedConv& cm = it->second;
-        if (!cm.wino3) {  // first use: split the transformed weights into bf16 planes and upload
-            std::vector<uint16_t> w3;
-            for (int g = 0; g < cm.groups; ++g) pack_wino3(cm.host_u.data() + (size_t)g * cm.cout * cm.cin * 16, cm.cout, cm.cin, &w3);
-            void* d = nullptr;
-            HIP_OK(hipMalloc(&d, w3.size() * 2));
-            net->dev_allocs.push_back(d);
-            net->dev_alloc_bytes.push_back(w3.size() * 2);
-            HIP_OK(hipMemcpy(d, w3.data(), w3.size() * 2, hipMemcpyHostToDevice));
-            cm.wino3 = d;
-        }
-        p.wpack = reinterpret_cast<const float*>(cm.wino3);
-        p.w_gs = (long long)c.cout * c.cin * 16 * 3 * 2;  // bytes per group
-        if (prof_begin(net, name, resid ? "conv_wino3<bf16x3,8x16,res>" : "conv_wino3<bf16x3,8x16>", fl, st)) return 1;
-        HIP_OK(cerb_launch_wino3(p, st));
-        if (prof_end(net, st)) return 1;
-        return 0;
-    }
     // conv_algo 6 (default): F(4x4,3x3) for maps of at least 16 x 16 pixels -- conv_wino4b.hip (one-block items, 32-channel chunks) up to
     // 64 x 64, conv_wino4.hip (two-block items, half the weight traffic) above; F(2x2,3x3) for smaller maps, where a 16 x 16 block would
     // be mostly padding.  Measured per layer on a batch of 32 256-pixel tiles (scripts/dev_conv_layers.py): 16^2 x 512 ch 0.115 / 0.21 /
@@ -903,34 +797,6 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
         }
         if (prof_begin(net, name, w4b ? (resid ? "conv_wino4b<f4x4,16x16,res>" : "conv_wino4b<f4x4,16x16>") : (resid ? "conv_wino4<f4x4,16x16x2,res>" : "conv_wino4<f4x4,16x16x2>"), fl_done, st)) return 1;
         HIP_OK(w4b ? cerb_launch_wino4b(p, st) : cerb_launch_wino4(p, st));
-        if (prof_end(net, st)) return 1;
-        return 0;
-    }
-    if ((net->conv_algo == 3 || net->conv_algo == 4) && c.wino && mode == 0 && !it->second.host_u.empty()) {
-        PackedConv& cm = it->second;
-        const bool dbl = net->conv_algo == 4;
-        float*& slot = dbl ? cm.wino16d : cm.wino16;
-        if (!slot) {  // first use: re-lay the transformed weights out per wave (16 output channels x all 16 positions) and upload
-            std::vector<float> w16;
-            for (int g = 0; g < cm.groups; ++g)
-                (dbl ? pack_wino16d : pack_wino16)(cm.host_u.data() + (size_t)g * cm.cout * cm.cin * 16, cm.cout, cm.cin, &w16);
-            void* d = nullptr;
-            HIP_OK(hipMalloc(&d, w16.size() * 4));
-            net->dev_allocs.push_back(d);
-            net->dev_alloc_bytes.push_back(w16.size() * 4);
-            HIP_OK(hipMemcpy(d, w16.data(), w16.size() * 4, hipMemcpyHostToDevice));
-            slot = (float*)d;
-        }
-        p.wpack = slot;
-        p.w_gs = (long long)c.cout * c.cin * 16;
-        double fl_done = fl;
-        if (roi && roi[1] > roi[0] && roi[3] > roi[2]) {
-            p.roi_y0 = roi[0]; p.roi_y1 = roi[1]; p.roi_x0 = roi[2]; p.roi_x1 = roi[3];
-            const double ty = (roi[1] + 7) / 8 - roi[0] / 8, tx = (roi[3] + 15) / 16 - roi[2] / 16;
-            fl_done = fl * (ty * 8.0 * tx * 16.0) / ((double)p.Ho * p.Wo);
-        }
-        if (prof_begin(net, name, std::string(dbl ? "conv_wino16d" : "conv_wino16") + (resid ? "<f2x2,8x16,res>" : "<f2x2,8x16>"), fl_done, st)) return 1;
-        HIP_OK(dbl ? cerb_launch_wino16d(p, st) : cerb_launch_wino16(p, st));
         if (prof_end(net, st)) return 1;
         return 0;
     }
@@ -1063,7 +929,7 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
                 if (io->logits[k]) return true;
             return false;
         }();
-        const bool use_roi = !dry && net->crop_roi && (net->conv_algo == 1 || net->conv_algo >= 3) && !any_logits && (out_h < H || out_w < W);
+        const bool use_roi = !dry && net->crop_roi && (net->conv_algo == 1 || net->conv_algo >= 5) && !any_logits && (out_h < H || out_w < W);
         if (use_roi) {
             int y0 = (int)((H - out_h) * 0.5), x0 = (int)((W - out_w) * 0.5), y1 = y0 + out_h, x1 = x0 + out_w;
             // A Winograd tile mixes its WHOLE input patch into every output (the contributions of the pixels a 3x3 filter does not touch
@@ -1136,7 +1002,14 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
                 if (prof_begin(net, "head." + d.name, "head", fl, st)) return 1;
                 HIP_OK(cerb_launch_head(hp, st));
                 if (prof_end(net, st)) return 1;
-            } else if (n_hp < 8) {
+            } else {
+                if (n_hp == 8) {  // a grouped launch carries at most 8 heads: more dense decoders go out in chunks of 8
+                    if (prof_begin(net, "heads", "head_group", head_flops, st)) return 1;
+                    HIP_OK(cerb_launch_head_group(hps, n_hp, st));
+                    if (prof_end(net, st)) return 1;
+                    n_hp = 0;
+                    head_flops = 0.0;
+                }
                 hps[n_hp++] = hp;
                 head_flops += fl;
             }
@@ -1198,7 +1071,6 @@ extern "C" int cerb_net_forward_train(cerb_net* net, const cerb_train_io* io, vo
             if (net->dout[u].ensure(D * (size_t)N * hs[3 - u] * ws[3 - u] * oc[u] * 4, guard)) return fail("workspace allocation failed");
     }
     const int saved_algo = net->conv_algo;
-    if (net->conv_algo >= 2 && net->conv_algo <= 4) net->conv_algo = 1;  // the experimental F(2x2) variants have no train packing
     // ---- encoder: conv -> BN(batch) -> ReLU -----------------------------------------------------------------------------------
     {
         StemParams sp;
@@ -1348,7 +1220,6 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         return p;
     };
     const int saved_algo = net->conv_algo;
-    if (net->conv_algo >= 2 && net->conv_algo <= 4) net->conv_algo = 1;
     // ---------------------------------------------------------------- forward, recorded ----------------------------------------
     auto conv = [&](const std::string& name, int a, int n_, int h_, int w_, long long a_gs) -> int {
         const PackedConv& c = net->conv[name];
@@ -1816,8 +1687,8 @@ extern "C" int cerb_net_set_crop_roi(cerb_net* net, int enable) {
 }
 extern "C" int cerb_net_set_conv_algo(cerb_net* net, int algo) {
     if (!net) return fail("cerb_net_set_conv_algo: null handle");
-    if (algo < 0 || algo > 7)
-        return fail("cerb_net_set_conv_algo: algo must be 0 (direct), 1 (Winograd F(2x2) fp32), 2 (F(2x2), bf16x3 products), 3 (F(2x2), 16-channel waves), 4 (3 with double-buffered 16-channel chunks), 5 (Winograd F(4x4) fp32), 7 (F(4x4), one-block items with 32-channel chunks) or 6 (F(4x4) for maps of 16 x 16 pixels and more -- 7's kernel up to 64 x 64, 5's above --, else F(2x2): the default)");
+    if (algo < 0 || algo > 7 || (algo >= 2 && algo <= 4))
+        return fail("cerb_net_set_conv_algo: algo must be 0 (direct), 1 (Winograd F(2x2) fp32), 5 (Winograd F(4x4) fp32), 7 (F(4x4), one-block items with 32-channel chunks) or 6 (F(4x4) for maps of 16 x 16 pixels and more -- 7's kernel up to 64 x 64, 5's above --, else F(2x2): the default); 2-4 were experiments (scripts/experiments/)");
     net->conv_algo = algo;
     return 0;
 }

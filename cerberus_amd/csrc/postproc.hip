@@ -1458,14 +1458,12 @@ static SideStreams* side_streams() {  // one set per device, created on first us
     return per_dev[dev];
 }
 
-// Literal skimage tie order for maps whose floods flag an ambiguous component (default on).  The WSI band driver turns it off:
-// the reference floods 4096^2 tiles there (infer/wsi.py:143-149), so the tie order of its heap is a property of ITS tiling.
-static std::atomic<int> g_exact_ties{1};
-extern "C" void cerb_pp_set_exact_ties(int on) { g_exact_ties.store(on ? 1 : 0); }
-extern "C" int cerb_pp_get_exact_ties(void) { return g_exact_ties.load(); }
-
+// exact_ties: literal skimage tie order for maps whose floods flag an ambiguous component -- a per-call argument (round 2 kept it in a
+// process-wide flag that two host threads could race on).  The WSI band driver passes 0: the reference floods 4096^2 tiles there
+// (infer/wsi.py:143-149), so the tie order of its heap is a property of ITS tiling.
 extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long row_stride, int pix_stride, int32_t* labels_out,
-                                    int32_t* n_inst_out, int32_t* n_ambiguous_out, void* ws, size_t ws_bytes, void* hip_stream) {
+                                    int32_t* n_inst_out, int32_t* n_ambiguous_out, int exact_ties, void* ws, size_t ws_bytes,
+                                    void* hip_stream) {
     hipStream_t st = (hipStream_t)hip_stream;
     if (!inst || !labels_out || !ws || H <= 0 || W <= 0) return cerb_set_error("cerb_postproc_nuclei: bad arguments");
     if (ws_bytes < cerb_pp_workspace_bytes(H, W)) return cerb_set_error("cerb_postproc_nuclei: workspace too small");
@@ -1568,7 +1566,7 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
         }
     }
     KCHECK();
-    if (g_exact_ties.load()) {
+    if (exact_ties) {
         // Components whose result depends on skimage's heap-layout order between equal-valued markers were counted in small[3]:
         // when there is one, the whole map is re-flooded through the literal emulation of that heap (both kernels return at once
         // when the count is zero -- no host round trip decides this).

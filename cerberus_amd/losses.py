@@ -1,5 +1,5 @@
-"""Per-head training loss of the reference's train_step on the GPU (cerb_head_loss; models/run_desc.py:88-170 there) -- the first
-piece of BASELINE configs[4].  Not a training step: there is no backward pass of the network in this package yet."""
+"""Per-head training loss of the reference's train_step on the GPU (cerb_head_loss; models/run_desc.py:88-170 there) -- the loss
+piece of BASELINE configs[4]; the backward pass and the optimiser step that consume its gradients are in cerberus_amd/train.py."""
 import ctypes as C
 
 import torch

@@ -53,9 +53,8 @@ def postproc_device(inst, tissue_mode, ds_factor=1.0, out=None, exact_ties=True)
     t = tissue_mode.upper()
     with torch.cuda.device(dev):
         if t == "NUCLEI":
-            L.cerb_pp_set_exact_ties(1 if exact_ties else 0)
             _lib.check(L.cerb_postproc_nuclei(inst.data_ptr(), h, w, inst.stride(0), inst.stride(1), labels.data_ptr(), meta.data_ptr(),
-                                              meta.data_ptr() + 4, ws.data_ptr(), ws.numel(), C.c_void_p(stream)))
+                                              meta.data_ptr() + 4, 1 if exact_ties else 0, ws.data_ptr(), ws.numel(), C.c_void_p(stream)))
         elif t in ("GLAND", "LUMEN"):
             fn = L.cerb_postproc_gland if t == "GLAND" else L.cerb_postproc_lumen
             _lib.check(fn(inst.data_ptr(), h, w, inst.stride(0), inst.stride(1), C.c_float(ds_factor), labels.data_ptr(), meta.data_ptr(),

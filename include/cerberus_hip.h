@@ -82,10 +82,8 @@ int cerb_net_forward(cerb_net* net, const cerb_forward_io* io, void* hip_stream)
  *   0           = direct implicit GEMM (conv_igemm.hip).
  * cuDNN makes the same kind of choice per layer for the reference (torch.backends.cudnn, models/run_desc.py:447).  All meet the 1e-4
  * bar; the switch exists for A/B measurement and for the parity tests of each path.
- *   2           = experimental: algorithm 1 with every fp32 product emulated by six bf16 MFMAs on a three-way bf16 split of both
- *                 operands (conv_wino3.hip; fp32 accumulate).  It leaves the fp32 matrix instruction, so it is never the default and
- *                 never what bench.py's headline measures (BASELINE.json configs[1]: fp32).
- *   3, 4        = F(2x2,3x3) with another work decomposition (conv_wino16.hip, conv_wino16d.hip), not faster than 1.
+ * (Three F(2x2) variants that lost their A/B -- bf16x3-split products and two other work decompositions -- live in scripts/experiments/,
+ * outside the product library.)
  * The training step follows the same rule for its forward and data-gradient convolutions (filter transform on the device). */
 int cerb_net_set_conv_algo(cerb_net* net, int algo);
 /* Output heads (models/utils/net_layers.py:31-38): 1 (default) = every dense head of the batch in ONE grouped launch with the head's
@@ -119,8 +117,8 @@ int cerb_net_profile_get(cerb_net* net, int idx, char* name, int name_cap, char*
  *        n_ambiguous_out : device int32[1] (nuclei only): number of watershed regions whose result depends on the order
  *        in which skimage's global binary heap releases marker pixels of bit-identical priority
  *        (skimage.segmentation.watershed, loader/postproc.py:378; DESIGN.md "watershed ties").  0: the parallel floods'
- *        label map is provably what skimage produces.  > 0: with cerb_pp_set_exact_ties(1) (the default) the map has been
- *        re-flooded on the device by a literal replay of that heap and is skimage's result as well; with (0) those regions
+ *        label map is provably what skimage produces.  > 0: with exact_ties != 0 the map has been
+ *        re-flooded on the device by a literal replay of that heap and is skimage's result as well; with exact_ties == 0 those regions
  *        keep the raster-order tie break.
  * ws / ws_bytes : caller-allocated device workspace of at least cerb_pp_workspace_bytes(H, W).
  * Streams: everything is ordered on `hip_stream`.  cerb_postproc_nuclei forks its independent flood tiers onto three internal
@@ -128,10 +126,8 @@ int cerb_net_profile_get(cerb_net* net, int idx, char* name, int name_cap, char*
  * process-level state of the library; like the reference's run_step / post_process it is meant to be driven from one host
  * thread per GPU (SURVEY par.8b). */
 size_t cerb_pp_workspace_bytes(int h, int w);
-void cerb_pp_set_exact_ties(int on); /* process-wide; default 1 */
-int cerb_pp_get_exact_ties(void);
 int cerb_postproc_nuclei(const float* inst, int h, int w, long long row_stride, int pix_stride, int32_t* labels_out,
-                         int32_t* n_inst_out, int32_t* n_ambiguous_out, void* ws, size_t ws_bytes, void* hip_stream);
+                         int32_t* n_inst_out, int32_t* n_ambiguous_out, int exact_ties, void* ws, size_t ws_bytes, void* hip_stream);
 int cerb_postproc_gland(const float* inst, int h, int w, long long row_stride, int pix_stride, float ds_factor,
                         int32_t* labels_out, int32_t* n_inst_out, void* ws, size_t ws_bytes, void* hip_stream);
 int cerb_postproc_lumen(const float* inst, int h, int w, long long row_stride, int pix_stride, float ds_factor,
@@ -214,7 +210,8 @@ int cerb_relabel(const int32_t* labels, long long lab_row_stride, const int32_t*
  *   dropout_scale : device float [n][512] = keep / (1 - 0.3) of nn.Dropout(p=0.3) (models/net_desc.py:70), or NULL (no dropout)
  *   logits        : per decoder (cerb_net_create order) a device float buffer or NULL: dense heads [n][h][w][out_ch] (NHWC, full
  *                   resolution), Patch-Class [n][out_ch]
- * Not yet: activations are not kept for a backward pass, running statistics are not updated. */
+ * cerb_net_forward_train is the forward half alone; cerb_net_train_grads (below) records the activations on a tape and runs the backward
+ * pass and returns the batch statistics from which the Python train_step updates the running ones. */
 typedef struct cerb_train_io {
     const uint8_t* tiles;
     int n, h, w;
@@ -272,7 +269,7 @@ int cerb_adam_step_multi(int count, float* const* param, const float* const* gra
 /* device-to-device copy on a stream (lets a host language without a HIP binding move a looked-up gradient into its own buffer) */
 int cerb_copy_d2d(void* dst, const void* src, size_t bytes, void* hip_stream);
 
-/* ---- training step, first piece (BASELINE.json configs[4]; NOT a training step yet) --------------------------------------------
+/* ---- training step: per-head losses (BASELINE.json configs[4]; the whole step is cerberus_amd/train.py::train_step) --------------
  * cerb_head_loss: the per-head loss of the reference's train_step (models/run_desc.py:88-170) and its gradient on the logits.
  *   logits / dlogits : device float, element strides (n, c, y, x) -- NCHW as the reference's forward returns them, or NHWC
  *   target           : device float [N][H][W] class ids (the reference keeps targets in float32, :57-62)

@@ -1,4 +1,4 @@
-"""A/B of the 3x3 convolution algorithms (cerb_net_set_conv_algo 1 = conv_wino, 3 = conv_wino16) inside the configs[1] batch step (GPU)."""
+"""A/B of the 3x3 convolution algorithms (cerb_net_set_conv_algo 1 = conv_wino F(2x2), 5 / 7 / 6 = F(4x4)) inside the configs[1] batch step (GPU)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

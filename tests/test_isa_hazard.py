@@ -14,7 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "cerberus_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-UNITS = ["conv_wino.hip", "conv_igemm.hip", "conv_wino3.hip", "conv_wino16.hip", "conv_wino16d.hip", "conv_wino4.hip", "conv_wino4b.hip"]
+UNITS = ["conv_wino.hip", "conv_igemm.hip", "conv_wino4.hip", "conv_wino4b.hip"]
 
 STORE = re.compile(r"^\s*buffer_store_dwordx4\s+v\[(\d+):(\d+)\],\s*(\S+),\s*s\[\d+:\d+\],\s*(\S+)")
 VDST = re.compile(r"^\s*(v_\w+|ds_read\w*|ds_load\w*|buffer_load\w*|global_load\w*|flat_load\w*|scratch_load\w*)\s+(v\[(\d+):(\d+)\]|v(\d+))")
@@ -63,8 +63,7 @@ def test_sgpr_soffset_stores_are_padded(unit, tmp_path):
             if wait >= 2:
                 break
         assert wait >= 2, "%s: data registers v[%d:%d] of `%s` are rewritten after %d wait state(s)" % (unit, lo, hi, l.strip(), wait)
-    if unit != "conv_wino3.hip":
-        assert n_sgpr_stores >= 8, "expected the output stage's SGPR-soffset stores in %s (found %d): has the kernel changed shape?" % (unit, n_sgpr_stores)
+    assert n_sgpr_stores >= 8, "expected the output stage's SGPR-soffset stores in %s (found %d): has the kernel changed shape?" % (unit, n_sgpr_stores)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc not available")
