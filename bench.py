@@ -534,6 +534,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and take the collective code path even at world size 1 (RCCL accepts one rank): "
                          "the nccl test of tests/test_cli_gpu.py")
+    ap.add_argument("--planar", type=int, default=1, help="last decoder level in the tile-planar layout (1, default: conv_wino4p.hip) or NHWC (0: conv_wino4.hip, round 2's path) -- A/B")
     ap.add_argument("--backend", default="nccl", help='torch.distributed backend ("nccl" = RCCL over xGMI; "gloo" only for plumbing tests)')
     args = ap.parse_args()
 
@@ -567,6 +568,8 @@ def main():
     sd = {k: torch.from_numpy(v) for k, v in make_state_dict(0).items()}
     model = create_model(**kw)
     model.load_state_dict(sd, strict=True)
+    if not args.planar:
+        model.set_planar(False)
     if args.mode == "train":
         return train_leg(args, model, dev, dist, world, rank, sd, kw)
     if args.mode == "wsi":

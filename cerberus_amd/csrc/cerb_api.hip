@@ -21,6 +21,9 @@ hipError_t cerb_launch_conv(const ConvParams& p, int ks, int stride, int mode, h
 hipError_t cerb_launch_wino(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino4(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino4b(ConvParams p, hipStream_t st);
+hipError_t cerb_launch_wino4p(ConvParams p, hipStream_t st);
+hipError_t cerb_launch_upsample2_add_planar(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C, long long prev_gs,
+                                            long long out_gs, const int* roi, hipStream_t st);
 hipError_t cerb_launch_upsample2_add(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C,
                                      long long prev_gs, const int* roi, hipStream_t st);
 extern "C" int cerb_conv_chunk(int ks, int stride);
@@ -135,6 +138,30 @@ struct DevBuf {
     }
 };
 
+// A tile-planar tensor (cerb_common.h: cerb_planar_offset) of `groups` x up to cap_n images.  Its guard ring and the pixels of edge blocks
+// beyond the image must read as zero and no kernel ever writes them, so the buffer is zeroed when it is made and again whenever the
+// map geometry (and with it the position of those bytes) changes; a smaller batch keeps the image slots where they are.
+struct PlanarBuf {
+    DevBuf b;
+    int h = 0, w = 0, c = 0, groups = 0;
+    long long cap_n = 0;
+    long long per_image() const { return cerb_planar_elems(1, h, w, c); }
+    long long gs() const { return cap_n * per_image(); }  // elements between groups
+    int ensure(int G, int N, int H, int W, int C, hipStream_t st) {
+        if (H == h && W == w && C == c && G == groups && N <= cap_n) return 0;
+        const size_t need = (size_t)G * (size_t)N * (size_t)cerb_planar_elems(1, H, W, C) * 4;
+        if (need > b.bytes) {
+            if (b.ensure(need, 0)) return 1;  // zeroed by DevBuf
+        } else if (hipMemsetAsync(b.raw, 0, b.bytes + 2 * b.guard, st) != hipSuccess) {
+            return 1;
+        }
+        h = H; w = W; c = C; groups = G;
+        cap_n = (long long)(b.bytes / ((size_t)G * (size_t)cerb_planar_elems(1, H, W, C) * 4));
+        return 0;
+    }
+    void release() { b.release(); h = w = c = groups = 0; cap_n = 0; }
+};
+
 struct PackedConv {
     int cin = 0, cout = 0, ks = 0, stride = 1, groups = 1;
     float* w = nullptr;     // device
@@ -193,6 +220,8 @@ struct cerb_net {
     std::map<std::string, std::vector<std::string>> bn_keys;   // conv / bn name -> state-dict prefixes of its BatchNorm, one per group
     // workspace
     DevBuf x0, pool, x[5], ta, tb, cm, dmid, dsum, dout[4];
+    PlanarBuf psum, pmid, pout;  // the last decoder level's private tensors in the tile-planar layout (conv_wino4p.hip), cerb_net_set_planar
+    int planar = 1;              // cerb_net_set_planar: 1 (default) = that level runs upsample2_add_planar -> conv_wino4p x2 -> heads reading planar features
     // optional per-launch timing (HIP events on the caller's stream)
     bool profiling = false;
     int crop_roi = 1;   // cerb_net_set_crop_roi: decoders / heads only compute what the centre crop keeps (conv_algo 1)
@@ -204,7 +233,7 @@ struct cerb_net {
     ~cerb_net() {
         for (auto& r : prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         for (void* p : dev_allocs) (void)hipFree(p);
-        x0.release(); pool.release(); ta.release(); tb.release(); cm.release(); dmid.release(); dsum.release();
+        x0.release(); pool.release(); ta.release(); tb.release(); cm.release(); dmid.release(); dsum.release(); psum.release(); pmid.release(); pout.release();
         t_mean.release(); t_rstd.release(); t_ws.release(); t_hid.release(); t_gap.release(); t_pc1.release(); t_idn.release(); t_dil.release();
         for (auto& b : tape) b.release();
         for (auto& b : x) b.release();
@@ -741,7 +770,7 @@ static int train_wino4_slot(cerb_net* net, const std::string& name, PackedConv& 
 
 static int run_conv(cerb_net* net, const std::string& name, const float* in, const float* prev, const float* resid, float* out, int N,
                     int H, int W, int relu, int mode, long long in_gs, long long prev_gs, hipStream_t st, double* macs,
-                    const int* roi = nullptr) {
+                    const int* roi = nullptr, long long planar_out_gs = 0) {  // planar_out_gs > 0: in / out are tile-planar (conv_wino4p.hip)
     auto it = net->conv.find(name);
     if (it == net->conv.end()) return fail("internal: conv " + name + " not packed");
     const PackedConv& c = it->second;
@@ -771,7 +800,9 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
     // is batched with (sharded == unsharded, cropped == full stay bitwise, tests/test_drivers_gpu.py, test_net_gpu.py).
     const long long map_px = (long long)p.Ho * p.Wo;
     const bool use_w4 = net->conv_algo == 5 || net->conv_algo == 7 || (net->conv_algo == 6 && map_px >= 256);
-    const bool w4b = (net->conv_algo == 7 || (net->conv_algo == 6 && map_px <= 4096)) && c.cin % 64 == 0;
+    const bool planar = planar_out_gs > 0;
+    const bool w4b = !planar && (net->conv_algo == 7 || (net->conv_algo == 6 && map_px <= 4096)) && c.cin % 64 == 0;
+    if (planar && !(use_w4 && c.wino && mode == 0 && net->fold_bn && !resid)) return fail("internal: conv " + name + " cannot take the planar path");
     if (use_w4 && c.wino && mode == 0 && (!it->second.host_w.empty() || !net->fold_bn)) {
         PackedConv& cm = it->second;
         float* train_slot = nullptr;
@@ -795,8 +826,13 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
             const double ty = (roi[1] + 15) / 16 - roi[0] / 16, tx = (roi[3] + 15) / 16 - roi[2] / 16;
             fl_done = fl * (ty * 16.0 * tx * 16.0) / ((double)p.Ho * p.Wo);
         }
-        if (prof_begin(net, name, w4b ? (resid ? "conv_wino4b<f4x4,16x16,res>" : "conv_wino4b<f4x4,16x16>") : (resid ? "conv_wino4<f4x4,16x16x2,res>" : "conv_wino4<f4x4,16x16x2>"), fl_done, st)) return 1;
-        HIP_OK(w4b ? cerb_launch_wino4b(p, st) : cerb_launch_wino4(p, st));
+        if (planar) {
+            p.out_gs = planar_out_gs;
+            p.pl_byp = cerb_planar_blocks(p.Ho);
+            p.pl_bxp = cerb_planar_blocks(p.Wo);
+        }
+        if (prof_begin(net, name, planar ? "conv_wino4p<f4x4,16x16x2,planar>" : w4b ? (resid ? "conv_wino4b<f4x4,16x16,res>" : "conv_wino4b<f4x4,16x16>") : (resid ? "conv_wino4<f4x4,16x16x2,res>" : "conv_wino4<f4x4,16x16x2>"), fl_done, st)) return 1;
+        HIP_OK(planar ? cerb_launch_wino4p(p, st) : w4b ? cerb_launch_wino4b(p, st) : cerb_launch_wino4(p, st));
         if (prof_end(net, st)) return 1;
         return 0;
     }
@@ -951,11 +987,30 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
                 x0 = std::max(0, roi_sum[u][2] / 2 - 1); x1 = std::min(ww / 2, (roi_sum[u][3] - 1) / 2 + 2);
             }
         }
+        bool feat_planar = false;
         for (int u = 0; u < 4; ++u) {
             const int hh = hs[3 - u], ww = ws[3 - u];
             const std::string n0 = "dec." + std::to_string(u) + ".0", n1 = "dec." + std::to_string(u) + ".1";
             const int cmid = net->conv[n0].cout;
             const int cin0 = net->conv[n0].cin;
+            // The last level (40 % of the network's FLOPs) keeps its three private tensors -- skip + upsample, the first conv's output, the
+            // features the heads read -- in the tile-planar layout: conv_wino4p.hip stores 1-KiB rows straight from its registers and reads
+            // whole lines, nothing masks an edge.  Same arithmetic in the same order: bit-identical to the NHWC path (cerb_net_set_planar(0)).
+            const bool lvl_planar = !dry && u == 3 && net->planar && net->fold_bn && net->conv_algo == 6 && net->head_algo == 1 && net->conv[n0].wino &&
+                                    (long long)hh * ww > 4096 && cin0 == 64 && cmid == 64 && net->conv[n1].cout == 64;
+            if (lvl_planar) {
+                if (net->psum.ensure((int)D, N, hh, ww, 64, st) || net->pmid.ensure((int)D, N, hh, ww, 64, st) || net->pout.ensure((int)D, N, hh, ww, 64, st))
+                    return fail("workspace allocation failed");
+                if (prof_begin(net, n0 + ".up", "upsample2_add_planar", 0.0, st)) return 1;
+                HIP_OK(cerb_launch_upsample2_add_planar(skips[u], prev, net->psum.b.p, (int)D, N, hh, ww, cin0, prev_gs, net->psum.gs(), use_roi ? roi_sum[u] : nullptr, st));
+                if (prof_end(net, st)) return 1;
+                if (run_conv(net, n0, net->psum.b.p, nullptr, nullptr, net->pmid.b.p, N, hh, ww, 1, 0, net->psum.gs(), 0, st, macs, use_roi ? roi_mid[u] : nullptr, net->pmid.gs()))
+                    return 1;
+                if (run_conv(net, n1, net->pmid.b.p, nullptr, nullptr, net->pout.b.p, N, hh, ww, 1, 0, net->pmid.gs(), 0, st, macs, use_roi ? roi_out[u] : nullptr, net->pout.gs()))
+                    return 1;
+                feat_planar = true;
+                continue;
+            }
             if (net->conv_algo && net->conv[n0].wino && !dry) {
                 // skip + upsample2x(prev) as one HBM pass, then the Winograd conv over the materialised sum
                 if (prof_begin(net, n0 + ".up", "upsample2_add", 0.0, st)) return 1;
@@ -983,7 +1038,10 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
             if (dry || !(want || wantl)) continue;
             HeadParams hp;
             memset(&hp, 0, sizeof(hp));
-            hp.feat = net->dout[3].p + k * (size_t)N * H * W * 64;
+            hp.feat = feat_planar ? net->pout.b.p + k * net->pout.gs() : net->dout[3].p + k * (size_t)N * H * W * 64;
+            hp.feat_planar = feat_planar ? 1 : 0;
+            hp.pl_byp = cerb_planar_blocks(H);
+            hp.pl_bxp = cerb_planar_blocks(W);
             hp.w1p = net->head_w1[k]; hp.b1 = net->head_b1[k]; hp.w2p = net->head_w2[k]; hp.b2 = net->head_b2[k];
             hp.N = N; hp.H = H; hp.W = W; hp.out_ch = d.out_ch; hp.kind = d.kind;
             hp.crop_y0 = (int)((H - out_h) * 0.5); hp.crop_x0 = (int)((W - out_w) * 0.5);  // cropping_center, misc/utils.py:94-104
@@ -1690,6 +1748,12 @@ extern "C" int cerb_net_set_conv_algo(cerb_net* net, int algo) {
     if (algo < 0 || algo > 7 || (algo >= 2 && algo <= 4))
         return fail("cerb_net_set_conv_algo: algo must be 0 (direct), 1 (Winograd F(2x2) fp32), 5 (Winograd F(4x4) fp32), 7 (F(4x4), one-block items with 32-channel chunks) or 6 (F(4x4) for maps of 16 x 16 pixels and more -- 7's kernel up to 64 x 64, 5's above --, else F(2x2): the default); 2-4 were experiments (scripts/experiments/)");
     net->conv_algo = algo;
+    return 0;
+}
+
+extern "C" int cerb_net_set_planar(cerb_net* net, int enable) {
+    if (!net) return fail("cerb_net_set_planar: null handle");
+    net->planar = enable ? 1 : 0;
     return 0;
 }
 

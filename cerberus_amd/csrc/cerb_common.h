@@ -40,7 +40,23 @@ struct ConvParams {
     int ty_off, tx_off;
     int groups;
     long long in_gs, prev_gs, w_gs, bias_gs, resid_gs, out_gs;  // per-group strides in elements
+    // conv_wino4p.hip only: `in` / `out` are tile-planar tensors (planar_elems below); blocks per image column / row incl. the guard ring
+    int pl_byp, pl_bxp;
 };
+
+// Tile-planar layout of the decoder's private tensors (conv_wino4p.hip; producer upsample2_add_planar, consumers conv_wino4p and the heads):
+//   [group][image n][block row by + 1][block column bx + 1][16-channel plane cc][i = y & 3][j = x & 3][tile m = 4 ((y >> 2) & 3) + ((x >> 2) & 3)][16 ch]
+// a block is 16 x 16 pixels; one 16-channel plane of a block is 16 KiB whose 1-KiB rows hold ONE pixel position (i, j) of all 16 4x4 tiles:
+// exactly what one store instruction of a Winograd wave produces (lane = (tile, channel quad)) and what one patch load of the consumer reads.
+// Every image carries a ring of guard blocks (row / column 0 and BY + 1 / BX + 1) that stay zero, and pixels of edge blocks beyond the image
+// stay zero as well (nobody writes them): the 3x3 convolution's zero padding is DATA, no kernel masks an edge.
+static inline int cerb_planar_blocks(int px) { return (px + 15) / 16 + 2; }
+static inline long long cerb_planar_elems(int n, int h, int w, int c) {
+    return (long long)n * cerb_planar_blocks(h) * cerb_planar_blocks(w) * (c / 16) * 4096;
+}
+__host__ __device__ __forceinline__ long long cerb_planar_offset(int n, int y, int x, int cc, int byp, int bxp, int ncc) {  // floats; channel 0 of plane cc
+    return ((((long long)n * byp + (y >> 4) + 1) * bxp + (x >> 4) + 1) * ncc + cc) * 4096 + ((((y & 3) << 2) + (x & 3)) * 16 + (((y >> 2) & 3) << 2) + ((x >> 2) & 3)) * 16;
+}
 
 // Fused output head (head.hip): 1x1 64->96 (+BN+ReLU) -> 1x1 96->out_ch -> softmax -> INST probs / TYPE argmax
 struct HeadParams {
@@ -62,6 +78,8 @@ struct HeadParams {
     const long long* tile_off;   // optional per-tile element offset (in pixels) into the destination canvas
     long long tile_stride;       // pixels between consecutive tiles when tile_off == nullptr
     long long row_stride;        // pixels between consecutive output rows
+    int feat_planar;             // head_group_kernel only: `feat` is a tile-planar tensor (cerb_planar_offset) with pl_byp x pl_bxp blocks per image
+    int pl_byp, pl_bxp;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

@@ -1,0 +1,445 @@
+// conv_wino4p.hip -- conv_wino4.hip's Winograd F(4x4,3x3) convolution (+ folded BN bias, ReLU) on the TILE-PLANAR layout of the decoder's
+// private tensors (cerb_common.h: cerb_planar_offset).  Same arithmetic, same accumulation order, same transforms as conv_wino4.hip --
+// results are bit-identical -- with the three things round 2's cycle accounting charged to the NHWC layout removed:
+//   * output stage: a wave's results for one pixel position (i, j) of its 16 tiles x 16 channels ARE a contiguous 1-KiB row of the
+//     planar block, so the 32 stores of an item leave straight from the registers -- no transposition through LDS, no barriers
+//     (conv_wino4: 32 ds_write_b128 + 32 ds_read_b128 + 4 barriers per item, ~10 k of 70 k cycles);
+//   * input path: a patch load of a wave reads 64-byte pieces that pair up into whole 128-byte lines of ONE chunk's plane (NHWC: half
+//     lines whose other halves are fetched again a chunk later -- the 1.66x read amplification of round 2's PMC counters), and the
+//     nine lane offsets of the 6x6 patch are kernel invariants;
+//   * zero padding is data (guard ring + never-written edge pixels): no edge selects, no hang-over masks, no per-item edge bits.
+// The accumulators are pinned by hand: 32 of the 36 positions live in the 256 AccVGPRs, 4 in VGPRs, through inline-asm matrix
+// instructions with "a" / "v" constraints -- hipcc's own split (-amdgpu-mfma-vgpr-form) rotated 8 positions per chunk through
+// v_accvgpr_read / s_nop 9 / v_accvgpr_write on the matrix pipe's lanes.
+// Reference layers: models/utils/conv_layers.py:24-60 (_ConvLayer) inside models/net_desc.py:182-198 (the decoder loop).
+#include <type_traits>
+
+#include "cerb_common.h"
+
+namespace {
+constexpr int NPOS = 36;
+constexpr int NT = 32;                        // tiles per item: two blocks of 4x4 tiles
+constexpr int BLK = 16;                       // a block is 16x16 output pixels
+constexpr int CB = 16;                        // input channels per LDS pass = one plane
+constexpr int V_FLOATS = NPOS * NT * CB;      // one V buffer: 72 KiB
+constexpr int LDS_BYTES = 2 * V_FLOATS * 4;   // double-buffered: 144 KiB
+constexpr int PLANE_BYTES = 16 * 16 * 16 * 4; // one 16-channel plane of a block
+constexpr int NS = NPOS;                      // steps per chunk: one position each (one 16-byte weight load, two ds_read_b128, 8 MFMAs)
+constexpr int NPOS_A = 32;                    // positions whose accumulators live in AccVGPRs (32 x 2 blocks x 4 = 256); the rest in VGPRs
+// Schedule of a chunk (36 steps of 8 matrix instructions = 256 cycles each).  vmcnt retires IN ORDER across all of a wave's loads and
+// stores, so a patch load that misses to HBM holds back the wait of every weight load issued after it: the first weight burst issued after
+// a patch load is needed WD + WB - (steps since the previous burst) steps later, and that distance -- not the distance to the patch's own
+// transform -- is the latency the input path can hide.  Round 2's schedule (bursts of 4 every 4 steps, 8 ahead, three patch loads in every
+// one of the first 12 steps) left 9 steps = 0.9 us; here the weight stream runs in bursts of WB = 6, WD = 12 steps ahead, and the patch
+// loads go out in the PLN steps right behind a burst, column by column (the order the transform consumes them): 16 steps = 1.75 us.
+#ifndef P4_RING
+#define P4_RING 18
+#endif
+constexpr int RING = P4_RING;                 // weight operand slots (NS % RING == 0: the slot of a step does not depend on the chunk)
+#ifndef P4_WD
+#define P4_WD 12
+#endif
+constexpr int WD = P4_WD;                     // weight prefetch distance in steps
+#ifndef P4_PRE
+#define P4_PRE P4_WD
+#endif
+constexpr int PRE = P4_PRE;                   // steps of the NEXT item whose weights are requested before an item's output stores
+#ifndef P4_WB
+#define P4_WB 6
+#endif
+constexpr int WB = P4_WB;                     // weight burst size in steps
+#ifndef P4_PL
+#define P4_PL 4
+#endif
+constexpr int PL = P4_PL;                     // patch loads issued per step ...
+#ifndef P4_PLN
+#define P4_PLN 3
+#endif
+constexpr int PLN = P4_PLN;                   // ... in the first PLN steps behind every weight burst
+#ifndef P4_TQ
+#define P4_TQ 22
+#endif
+constexpr int TQ = P4_TQ;                     // the next chunk's patch is transformed at TQ+1 .. TQ+12, written at TQ+7 .. TQ+12
+constexpr int patch_slot(int q) { return (q % WB) < PLN ? (q / WB) * PLN + (q % WB) : -1; }  // which group of PL loads step q issues
+constexpr int last_patch_step() {
+    int l = -1;
+    for (int q = 0; q < NS; ++q)
+        if (patch_slot(q) >= 0 && patch_slot(q) * PL < 36) l = q;
+    return l;
+}
+static_assert(NS % RING == 0 && WD + WB <= RING && NS % WB == 0 && PRE == WD && PRE <= RING, "weight ring");
+static_assert(PLN <= WB && ((NS / WB) * PLN) * PL >= 36 && last_patch_step() < TQ && TQ + 13 < NS, "the patch must be requested before its transform starts");
+constexpr int BIAS_XI = 7;                    // A^T[i][1] A[1][j] = 1 for all 16 outputs: the bias enters through position (1, 1)
+constexpr int CHUNK_W_BYTES = NPOS * 4 * 1024;  // packed weights of one (cout block, 16-channel chunk): 144 KiB
+constexpr int WAVE_W_BYTES = NPOS * 1024;       // one wave's share: 36 steps x 1 KiB
+
+template <int I>
+using IC = std::integral_constant<int, I>;
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(IC<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, soff, 0);
+    asm volatile("s_nop 1");  // gfx950 store hazard, see conv_wino.hip buf_store / tests/test_isa_hazard.py
+    __builtin_amdgcn_sched_barrier(0);
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, soff, 0));
+}
+
+// The matrix instruction, with the accumulator's register file chosen by the caller.  hipcc does not model what is inside the string:
+// the operands' s_waitcnt are still its own (they are ordinary register uses), the wait states are ours -- an accumulate chain needs
+// none; the first reader of a finished accumulator waits through wait_mfma_results() below.
+// One step = the 8 matrix instructions of one position (4 k-slots x 2 blocks) in ONE statement: hipcc pads every asm boundary whose
+// neighbour touches the statement's outputs with a wait state, which eight single-instruction statements paid four times per step.
+template <bool AGPR, bool ZERO>
+__device__ __forceinline__ void mfma_step(f32x4& c0, f32x4& c1, const f32x4& av, const f32x4& b0, const f32x4& b1) {
+#define P4_STEP_BODY(FIRST0, FIRST1)                               \
+    "v_mfma_f32_16x16x4_f32 %0, %2, %6, " FIRST0 "\n\t"             \
+    "v_mfma_f32_16x16x4_f32 %1, %2, %10, " FIRST1 "\n\t"            \
+    "v_mfma_f32_16x16x4_f32 %0, %3, %7, %0\n\t"                     \
+    "v_mfma_f32_16x16x4_f32 %1, %3, %11, %1\n\t"                    \
+    "v_mfma_f32_16x16x4_f32 %0, %4, %8, %0\n\t"                     \
+    "v_mfma_f32_16x16x4_f32 %1, %4, %12, %1\n\t"                    \
+    "v_mfma_f32_16x16x4_f32 %0, %5, %9, %0\n\t"                     \
+    "v_mfma_f32_16x16x4_f32 %1, %5, %13, %1"
+#define P4_STEP_IN "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(b0[0]), "v"(b0[1]), "v"(b0[2]), "v"(b0[3]), "v"(b1[0]), "v"(b1[1]), "v"(b1[2]), "v"(b1[3])
+    if constexpr (ZERO) {
+        if constexpr (AGPR) asm volatile(P4_STEP_BODY("0", "0") : "=&a"(c0), "=&a"(c1) : P4_STEP_IN);
+        else asm volatile(P4_STEP_BODY("0", "0") : "=&v"(c0), "=&v"(c1) : P4_STEP_IN);
+    } else {
+        if constexpr (AGPR) asm volatile(P4_STEP_BODY("%0", "%1") : "+a"(c0), "+a"(c1) : P4_STEP_IN);
+        else asm volatile(P4_STEP_BODY("%0", "%1") : "+v"(c0), "+v"(c1) : P4_STEP_IN);
+    }
+#undef P4_STEP_BODY
+#undef P4_STEP_IN
+}
+__device__ __forceinline__ void wait_mfma_results() { asm volatile("s_nop 15\n\ts_nop 3"); }  // 8-pass MFMA D -> VALU reader: 12 states and more
+
+struct Blk {
+    int n, by, bx;  // image, block row / column inside the launch's block grid
+};
+struct Item {
+    int g, cb;
+    Blk b0, b1;  // (no array: a dynamically indexed member would keep the whole struct in scratch, i.e. in vector registers)
+    int nvalid;  // 2, or 1 when the launch has an odd number of blocks and this is the last pair (block 1 repeats block 0, stores skipped)
+};
+}  // namespace
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino4p_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int a = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's 16 output channels of the item's 64 (= one output plane); input path: block a >> 1
+    const int m = lane & 15;                                 // MFMA row (cout) / column (tile within a block)
+    const int ks = lane >> 4;                                // k-slot
+
+    const int ncb = p.Cout >> 6;
+    const int nblk = p.N * p.tiles_y * p.tiles_x;  // blocks per group
+    const int npair = (nblk + 1) >> 1;
+    const int per_group = npair * ncb;
+    const int total = per_group * p.groups;
+    const int nchunk = p.Cin / CB;   // = input planes per block
+    const int nplane_o = p.Cout / CB;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    // workgroup lb takes items lb, lb + G, ...: neighbouring blocks (shared halo lines) run at the same time on one XCD and meet in its L2
+    const int ISTEP = (int)gridDim.x;
+    int item = lb;
+    const int item_end = total;
+    if (item >= item_end) return;
+
+    auto decode_blk = [&](int id) {
+        Blk b;
+        b.bx = id % p.tiles_x;
+        const int r = id / p.tiles_x;
+        b.by = r % p.tiles_y;
+        b.n = r / p.tiles_y;
+        return b;
+    };
+    auto decode = [&](int it) {
+        Item w;
+        w.g = it / per_group;
+        const int L = it - w.g * per_group;
+        w.cb = L % ncb;
+        const int pr = L / ncb;
+        w.nvalid = (2 * pr + 1 < nblk) ? 2 : 1;
+        w.b0 = decode_blk(2 * pr);
+        w.b1 = w.nvalid == 2 ? decode_blk(2 * pr + 1) : w.b0;
+        return w;
+    };
+    // the block's TOP-LEFT neighbour in the guard-ringed block grid (stored index of block (by, bx) is (by + 1, bx + 1)): every patch offset is >= 0
+    auto in_base = [&](int g, const Blk& b) {
+        return reinterpret_cast<const char*>(p.in + g * p.in_gs) +
+               (((long long)b.n * p.pl_byp + (b.by + p.ty_off)) * p.pl_bxp + (b.bx + p.tx_off)) * (long long)nchunk * PLANE_BYTES;
+    };
+    auto w_base = [&](const Item& w) {
+        return reinterpret_cast<const char*>(p.wpack + w.g * p.w_gs) + (long long)w.cb * nchunk * CHUNK_W_BYTES + a * WAVE_W_BYTES;
+    };
+
+    // ---- lane invariants ---------------------------------------------------------------------------------------------------
+    // input transform: thread = (tile t of the item, channel pair c); tiles 0..15 are block 0 (waves 0, 1), 16..31 block 1 (waves 2, 3)
+    const int t = tid >> 3, c = tid & 7, tm = t & 15, tty = tm >> 2, ttx = tm & 3;
+    const bool second = (a >> 1) != 0;
+    auto mine = [&](const Item& wi) {
+        Blk b;
+        b.n = second ? wi.b1.n : wi.b0.n;
+        b.by = second ? wi.b1.by : wi.b0.by;
+        b.bx = second ? wi.b1.bx : wi.b0.bx;
+        return b;
+    };
+    // patch element (r, q) = pixel (4 tty + r - 1, 4 ttx + q - 1) of the block: row class 0 (r = 0: pixel row 3 of the tile above, in the block
+    // above when tty = 0), 1 (r = 1..4: the tile's own rows), 2 (r = 5: row 0 of the tile below); columns alike.  Nine lane offsets, for good.
+    unsigned poff[3][3];
+    {
+        const unsigned rowblk = (unsigned)p.pl_bxp * (unsigned)nchunk * PLANE_BYTES, colblk = (unsigned)nchunk * PLANE_BYTES;
+#pragma unroll
+        for (int rc = 0; rc < 3; ++rc)
+#pragma unroll
+            for (int qc = 0; qc < 3; ++qc) {
+                const int dby = (rc == 0 && tty == 0) ? 0 : (rc == 2 && tty == 3) ? 2 : 1;
+                const int dbx = (qc == 0 && ttx == 0) ? 0 : (qc == 2 && ttx == 3) ? 2 : 1;
+                const int ty2 = rc == 0 ? ((tty + 3) & 3) : rc == 2 ? ((tty + 1) & 3) : tty;
+                const int tx2 = qc == 0 ? ((ttx + 3) & 3) : qc == 2 ? ((ttx + 1) & 3) : ttx;
+                poff[rc][qc] = (unsigned)dby * rowblk + (unsigned)dbx * colblk + (unsigned)((4 * ty2 + tx2) * 64 + c * 8);
+                asm volatile("" : "+v"(poff[rc][qc]));
+            }
+    }
+    const int vw = t * CB + (((c >> 1) ^ ((tm & 8) ? 3 : 0)) << 2) + 2 * (c & 1);  // V write position (floats); position xi adds xi*NT*CB
+    const int vr = m * CB + ((ks ^ ((m & 8) ? 3 : 0)) << 2);                       // V read position, block 0; block 1 adds 16*CB
+    const unsigned wlane = (unsigned)lane * 16u;
+
+    f32x2 d[6][6];  // raw patch of the NEXT chunk (two channels), transformed in place in the shadow of the matrix pipe
+    auto issue = [&](__amdgpu_buffer_rsrc_t r, int chunk_off, int k) __attribute__((always_inline)) {
+        const int qq = k / 6, rr = k % 6;  // column by column: pass_v(q) needs column q first
+        const int ii = rr == 0 ? 3 : rr == 5 ? 0 : rr - 1, jj = qq == 0 ? 3 : qq == 5 ? 0 : qq - 1;
+        d[rr][qq] = buf_load2(r, poff[rr == 0 ? 0 : rr == 5 ? 2 : 1][qq == 0 ? 0 : qq == 5 ? 2 : 1], chunk_off + (ii * 4 + jj) * 1024);
+    };
+    // B^T x for the points (0, 1, -1, 2, -2, inf), in place: 12 packed operations (conv_wino4.hip: written by hand, hipcc scalarises them)
+    f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, k5 = {5.f, 5.f};
+    asm volatile("" : "+v"(k2), "+v"(k4), "+v"(k5));
+    auto bt6 = [&](f32x2& x0, f32x2& x1, f32x2& x2, f32x2& x3, f32x2& x4, f32x2& x5) __attribute__((always_inline)) {
+        f32x2 t0, t1, u0, u1;
+        asm("v_pk_fma_f32 %6, %2, %11, %4 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"   // t0 = x4 - 4 x2
+            "v_pk_fma_f32 %7, %1, %11, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"   // t1 = x3 - 4 x1
+            "v_pk_add_f32 %8, %4, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"            // u0 = x4 - x2
+            "v_pk_add_f32 %9, %3, %1 neg_lo:[0,1] neg_hi:[0,1]\n\t"            // u1 = x3 - x1
+            "v_pk_fma_f32 %0, %0, %11, %4\n\t"                                  // x0 = 4 x0 + x4
+            "v_pk_fma_f32 %5, %1, %11, %5\n\t"                                  // x5 = 4 x1 + x5
+            "v_pk_fma_f32 %0, %2, %12, %0 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"   // x0 -= 5 x2
+            "v_pk_fma_f32 %5, %3, %12, %5 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"   // x5 -= 5 x3
+            "v_pk_add_f32 %1, %6, %7\n\t"                                       // x1 = t0 + t1
+            "v_pk_add_f32 %2, %6, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"            // x2 = t0 - t1
+            "v_pk_fma_f32 %3, %9, %10, %8\n\t"                                  // x3 = u0 + 2 u1
+            "v_pk_fma_f32 %4, %9, %10, %8 neg_lo:[1,0,0] neg_hi:[1,0,0]"         // x4 = u0 - 2 u1
+            : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "=&v"(t0), "=&v"(t1), "=&v"(u0), "=&v"(u1)
+            : "v"(k2), "v"(k4), "v"(k5));
+    };
+    auto pass_v = [&](int q) __attribute__((always_inline)) { bt6(d[0][q], d[1][q], d[2][q], d[3][q], d[4][q], d[5][q]); };  // down column q
+    auto pass_h = [&](int r) __attribute__((always_inline)) { bt6(d[r][0], d[r][1], d[r][2], d[r][3], d[r][4], d[r][5]); };  // along row r
+    auto write_row = [&](int buf, int r) __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < 6; ++b) *reinterpret_cast<f32x2*>(lds + buf * V_FLOATS + (r * 6 + b) * NT * CB + vw) = d[r][b];
+    };
+
+    // ---- prologue ------------------------------------------------------------------------------------------------------------
+    Item w = decode(item);
+    {
+        const __amdgpu_buffer_rsrc_t r0 = make_rsrc(in_base(w.g, mine(w)));
+#pragma unroll
+        for (int k = 0; k < 36; ++k) issue(r0, 0, k);
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) pass_v(q);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        pass_h(r);
+        write_row(0, r);
+    }
+    int vbuf = 0;  // the buffer the CURRENT chunk reads; the next chunk's patch goes to vbuf ^ 1
+    __syncthreads();
+    __amdgpu_buffer_rsrc_t rw = make_rsrc(w_base(w));
+    // Weight stream in bursts: every WB steps the operands of steps q + WD .. q + WD + WB - 1 are requested at once; the operand of step q
+    // lives in slot q % RING.  Steps past the chunk's 36 belong to the next chunk, or to the next item's first chunk.
+    f32x4 wq[RING];
+#pragma unroll
+    for (int dd = 0; dd < PRE; ++dd) wq[dd] = buf_load(rw, wlane, dd * 1024);
+    f32x4 bnext;
+    auto load_bias = [&](const Item& wi) {
+        const float* bias = p.bias + wi.g * p.bias_gs + wi.cb * 64 + 16 * a;
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, 64, 0x00020000);
+        bnext = buf_load(rb, (unsigned)ks * 16u, 0);
+    };
+    load_bias(w);
+    const unsigned olane = (unsigned)(m * 64 + ks * 16);  // output: lane (tile m, channel quad ks) inside a 1-KiB pixel-position row
+
+    for (;;) {
+        f32x4 acc[NPOS][2];
+        const bool more_items = item + ISTEP < item_end;
+        const Item wnx = more_items ? decode(item + ISTEP) : w;
+        const __amdgpu_buffer_rsrc_t rw_nx = more_items ? make_rsrc(w_base(wnx)) : rw;
+        const char* in_cur = in_base(w.g, mine(w));
+        const char* in_nx = in_base(wnx.g, mine(wnx));
+        acc[BIAS_XI][0] = bnext;
+        acc[BIAS_XI][1] = bnext;
+
+        auto chunk = [&](auto first_tag, int ch) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const bool last_ch = (ch == nchunk - 1);
+            const __amdgpu_buffer_rsrc_t r_stage = make_rsrc(last_ch ? in_nx : in_cur);
+            const int stage_off = (last_ch ? 0 : ch + 1) * PLANE_BYTES;
+            const int wcur_off = ch * CHUNK_W_BYTES;
+            const __amdgpu_buffer_rsrc_t rw_over = last_ch ? rw_nx : rw;
+            const int wover_off = last_ch ? 0 : (ch + 1) * CHUNK_W_BYTES;
+            const float* vsrc = lds + vbuf * V_FLOATS + vr;
+            const int wbuf = vbuf ^ 1;
+
+            f32x4 bb[2][2];  // B operands (blocks 0, 1) of step q in bb[q & 1]
+            bb[0][0] = *reinterpret_cast<const f32x4*>(vsrc);
+            bb[0][1] = *reinterpret_cast<const f32x4*>(vsrc + 16 * CB);
+            static_for<0, NS>([&](auto Q) __attribute__((always_inline)) {
+                constexpr int q = decltype(Q)::value;
+                constexpr int xi = q;
+                constexpr bool AG = xi < NPOS_A;
+                if constexpr (q % WB == 0) {
+#pragma unroll
+                    for (int dd = q + WD; dd < q + WD + WB; ++dd) {
+                        if (FIRST && dd < PRE) continue;  // requested before the previous item's stores (or in the prologue)
+                        if (dd < NS) wq[dd % RING] = buf_load(rw, wlane, wcur_off + dd * 1024);
+                        else wq[(dd - NS) % RING] = buf_load(rw_over, wlane, wover_off + (dd - NS) * 1024);
+                    }
+                }
+                if constexpr (q + 1 < NS) {
+                    bb[(q + 1) & 1][0] = *reinterpret_cast<const f32x4*>(vsrc + (q + 1) * NT * CB);
+                    bb[(q + 1) & 1][1] = *reinterpret_cast<const f32x4*>(vsrc + (q + 1) * NT * CB + 16 * CB);
+                }
+                if constexpr (patch_slot(q) >= 0 && patch_slot(q) * PL < 36) {  // next chunk's patch: PL loads in each of the PLN steps behind a weight burst
+#pragma unroll
+                    for (int u = 0; u < PL; ++u)
+                        if (patch_slot(q) * PL + u < 36) {
+#ifdef P4_ABL_PATCHHOT
+                            issue(make_rsrc(reinterpret_cast<const char*>(p.in) + (blockIdx.x & 7) * (1 << 20)), 0, patch_slot(q) * PL + u);  // cache-resident
+#elif !defined(P4_ABL_NOPATCH)
+                            issue(r_stage, stage_off, patch_slot(q) * PL + u);
+#endif
+                        }
+                }
+                // the next chunk's patch landed: B^T d B (one 1-D pass per step) and the V writes into the OTHER buffer
+                if constexpr (q > TQ && q <= TQ + 6) pass_v(q - TQ - 1);
+                if constexpr (q > TQ + 6 && q <= TQ + 12) {
+                    pass_h(q - TQ - 7);
+                    write_row(wbuf, q - TQ - 7);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4 av = wq[q % RING];
+                const f32x4 b0 = bb[q & 1][0], b1 = bb[q & 1][1];
+                mfma_step<AG, FIRST && xi != BIAS_XI>(acc[xi][0], acc[xi][1], av, b0, b1);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            __syncthreads();  // everybody has read this chunk's V and written the next one's
+            vbuf ^= 1;
+        };
+        chunk(std::true_type{}, 0);
+        for (int ch = 1; ch < nchunk; ++ch) chunk(std::false_type{}, ch);
+
+        // ---- output transform A^T M A, entirely in registers; lane (m, ks): tile m of each block, channels 4 ks .. + 3 of the wave's 16 -------
+        // vmcnt retires in order across loads AND stores: everything the next item needs during its first PRE steps is requested here, before
+        // this item's stores enter the queue (its steps 0 .. WD-1 went out during the last chunk).
+#pragma unroll
+        for (int dd = WD; dd < PRE; ++dd) wq[dd % RING] = buf_load(rw_nx, wlane, dd * 1024);
+        load_bias(wnx);
+        wait_mfma_results();
+        {
+            const float floor_ = p.relu ? 0.f : -3.402823466e38f;
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                const Blk bo = tb ? w.b1 : w.b0;
+                if (tb == 1 && w.nvalid == 1) continue;  // the pair's second block repeats the first: nothing to store
+                const int by_abs = bo.by + p.ty_off, bx_abs = bo.bx + p.tx_off;
+                const long long origin = p.out_gs * w.g + ((((long long)bo.n * p.pl_byp + by_abs + 1) * p.pl_bxp + bx_abs + 1) * nplane_o + w.cb * 4 + a) * (long long)(PLANE_BYTES / 4);
+                const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + origin, 0, PLANE_BYTES, 0x00020000);
+                const bool partial = (by_abs * BLK + BLK > p.Ho) || (bx_abs * BLK + BLK > p.Wo);
+                // vertical pass: T[i][b] = sum_a A^T[i][a] M[a][b]
+                f32x4 T[4][6];
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    const f32x4 m0 = acc[0 * 6 + b][tb], m1 = acc[1 * 6 + b][tb], m2 = acc[2 * 6 + b][tb], m3 = acc[3 * 6 + b][tb],
+                                m4 = acc[4 * 6 + b][tb], m5 = acc[5 * 6 + b][tb];
+                    const f32x4 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                    T[0][b] = m0 + s1 + s2;
+                    T[1][b] = d1 + 2.f * d2;
+                    T[2][b] = s1 + 4.f * s2;
+                    T[3][b] = (d1 + 8.f * d2) + m5;
+                }
+                const int rem_y = p.Ho - by_abs * BLK - 4 * (m >> 2), rem_x = p.Wo - bx_abs * BLK - 4 * (m & 3);  // partial blocks: rows / columns of this lane's tile inside the image
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 s1 = T[i][1] + T[i][2], d1 = T[i][1] - T[i][2], s2 = T[i][3] + T[i][4], d2 = T[i][3] - T[i][4];
+                    f32x4 y[4];
+                    y[0] = T[i][0] + s1 + s2;
+                    y[1] = d1 + 2.f * d2;
+                    y[2] = s1 + 4.f * s2;
+                    y[3] = (d1 + 8.f * d2) + T[i][5];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 o = y[j];
+                        o[0] = fmaxf(o[0], floor_);
+                        o[1] = fmaxf(o[1], floor_);
+                        o[2] = fmaxf(o[2], floor_);
+                        o[3] = fmaxf(o[3], floor_);
+                        // pixels of an edge block beyond the image are never written: they stay zero (the next convolution's padding)
+                        const unsigned vo = (!partial || (i < rem_y && j < rem_x)) ? olane : 0x80000000u;
+#ifndef P4_ABL_NOSTORE
+                        buf_store(o, r_out, vo, (i * 4 + j) * 1024);
+#else
+                        if (o[0] == 1.2345e-30f) buf_store(o, r_out, vo, (i * 4 + j) * 1024);
+#endif
+                    }
+                }
+            }
+        }
+        if (!more_items) break;
+        item += ISTEP;
+        w = wnx;
+        rw = rw_nx;
+    }
+}
+
+hipError_t cerb_launch_wino4p(ConvParams p, hipStream_t st) {
+    if (p.Cin % CB || p.Cout % 64 || p.resid || p.pl_byp < 3 || p.pl_bxp < 3 || p.H != p.Ho || p.W != p.Wo) return hipErrorInvalidValue;
+    p.tiles_x = (p.Wo + BLK - 1) / BLK;  // blocks, not tiles
+    p.tiles_y = (p.Ho + BLK - 1) / BLK;
+    p.ty_off = p.tx_off = 0;
+    if (p.roi_y1 > p.roi_y0 && p.roi_x1 > p.roi_x0) {
+        p.ty_off = p.roi_y0 / BLK;
+        p.tx_off = p.roi_x0 / BLK;
+        p.tiles_y = (p.roi_y1 + BLK - 1) / BLK - p.ty_off;
+        p.tiles_x = (p.roi_x1 + BLK - 1) / BLK - p.tx_off;
+    }
+    if (p.pl_byp != (p.Ho + BLK - 1) / BLK + 2 || p.pl_bxp != (p.Wo + BLK - 1) / BLK + 2) return hipErrorInvalidValue;
+    const long long nblk = (long long)p.N * p.tiles_x * p.tiles_y;
+    const long long items = (long long)p.groups * ((nblk + 1) / 2) * (p.Cout / 64);
+    auto kern = conv_wino4p_kernel;
+    static bool attr_done[64] = {};
+    if (cerb_attr_needed(attr_done)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
+    }
+    long long grid = 256;  // persistent: one workgroup per CU
+    if (grid > items) grid = items;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS_BYTES, st, p);
+    return hipGetLastError();
+}

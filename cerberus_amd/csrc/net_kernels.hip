@@ -147,6 +147,14 @@ hipError_t cerb_launch_maxpool(const float* in, float* out, int N, int H, int W,
 // block x 4 channels: rows 2m+1, 2m+2 and columns 2n+1, 2n+2 blend exactly prev rows m, m+1 / columns n, n+1 with weights
 // {0.75, 0.25}; m = -1 and m = Hp-1 are the clamped edge blocks (one of their two rows lies outside the image).
 // ---------------------------------------------------------------------------------------------------------------
+// a x + b y with the rounding spelled out -- fma(a, x, b * y) -- so that upsample2_add_kernel and upsample2_add_planar_kernel (two
+// different instruction streams for the same blend) cannot be contracted differently by the compiler: their values are bit-identical.
+__device__ __forceinline__ f32x4 blend2(float a, const f32x4& x, float b, const f32x4& y) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(a, x[e], b * y[e]);
+    return r;
+}
 __global__ void upsample2_add_kernel(const float* __restrict__ skip, const float* __restrict__ prev, float* __restrict__ out, int groups,
                                      int N, int H, int W, int C, long long prev_gs, int bm_lo, int bm_cnt, int bn_lo, int bn_cnt) {
     // 2x2 output blocks (bm, bn), bm in [-1, H/2): the launcher restricts them to [bm_lo, bm_lo + bm_cnt) x [bn_lo, bn_lo + bn_cnt)
@@ -181,10 +189,10 @@ __global__ void upsample2_add_kernel(const float* __restrict__ skip, const float
             const f32x4 p01 = *reinterpret_cast<const f32x4*>(pg + ((long long)m0 * Wp + n1) * C);
             const f32x4 p10 = *reinterpret_cast<const f32x4*>(pg + ((long long)m1 * Wp + n0) * C);
             const f32x4 p11 = *reinterpret_cast<const f32x4*>(pg + ((long long)m1 * Wp + n1) * C);
-            const f32x4 top_l = 0.75f * p00 + 0.25f * p01, top_r = 0.25f * p00 + 0.75f * p01;
-            const f32x4 bot_l = 0.75f * p10 + 0.25f * p11, bot_r = 0.25f * p10 + 0.75f * p11;
-            const f32x4 u[2][2] = {{0.75f * top_l + 0.25f * bot_l, 0.75f * top_r + 0.25f * bot_r},
-                                   {0.25f * top_l + 0.75f * bot_l, 0.25f * top_r + 0.75f * bot_r}};
+            const f32x4 top_l = blend2(0.75f, p00, 0.25f, p01), top_r = blend2(0.25f, p00, 0.75f, p01);
+            const f32x4 bot_l = blend2(0.75f, p10, 0.25f, p11), bot_r = blend2(0.25f, p10, 0.75f, p11);
+            const f32x4 u[2][2] = {{blend2(0.75f, top_l, 0.25f, bot_l), blend2(0.75f, top_r, 0.25f, bot_r)},
+                                   {blend2(0.25f, top_l, 0.75f, bot_l), blend2(0.25f, top_r, 0.75f, bot_r)}};
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -212,6 +220,81 @@ hipError_t cerb_launch_upsample2_add(const float* skip, const float* prev, float
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(upsample2_add_kernel, dim3((unsigned)blocks), dim3(256), 0, st, skip, prev, out, groups, N, H, W, C, prev_gs, bm_lo, bm_cnt, bn_lo,
                        bn_cnt);
+    return hipGetLastError();
+}
+
+// skip + upsample2x(prev) written in the TILE-PLANAR layout (cerb_common.h) that conv_wino4p.hip reads: thread = (block, 16-channel plane =
+// wave, 4x4 tile m, channel quad) keeps the tile's 16 skip quads and the 4 x 4 source pixels of `prev` its 16 outputs blend, and every
+// store instruction of a wave is one contiguous 1-KiB row (pixel position (i, j) of the 16 tiles).  Same expressions, same order as
+// upsample2_add_kernel: the values are bit-identical.  Pixels of edge blocks beyond the image are not written (they stay zero).
+__global__ __launch_bounds__(256) void upsample2_add_planar_kernel(const float* __restrict__ skip, const float* __restrict__ prev, float* __restrict__ out,
+                                                                   int groups, int N, int H, int W, long long prev_gs, long long out_gs, int byp, int bxp,
+                                                                   int by_lo, int by_cnt, int bx_lo, int bx_cnt) {
+    constexpr int C = 64, NCC = 4;
+    const int Hp = H >> 1, Wp = W >> 1;
+    const int lane = threadIdx.x & 63, cc = threadIdx.x >> 6, m = lane >> 2, cq = lane & 3, ty = m >> 2, tx = m & 3;
+    const int nblk = N * by_cnt * bx_cnt;
+    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int bx = blk % bx_cnt + bx_lo;
+        const int r_ = blk / bx_cnt;
+        const int by = r_ % by_cnt + by_lo, n = r_ / by_cnt;
+        const int y0 = 16 * by + 4 * ty, x0 = 16 * bx + 4 * tx;
+        if (y0 >= H || x0 >= W) continue;  // the whole tile lies beyond the image (H, W are multiples of 4: a tile is inside or outside)
+        const int ch = cc * 16 + cq * 4;
+        f32x4 sk[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sk[i][j] = *reinterpret_cast<const f32x4*>(skip + (((long long)n * H + y0 + i) * W + x0 + j) * C + ch);
+        // source rows 2Y - 1 .. 2Y + 2 of tile row Y = y0 / 4 (clamped like the index clamp of align_corners = False), columns alike
+        int rr[4], qq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            rr[k] = min(max((y0 >> 1) - 1 + k, 0), Hp - 1);
+            qq[k] = min(max((x0 >> 1) - 1 + k, 0), Wp - 1);
+        }
+        float* ob = out + ((((long long)n * byp + by + 1) * bxp + bx + 1) * NCC + cc) * 4096 + lane * 4;
+        for (int g = 0; g < groups; ++g) {
+            const float* pg = prev + g * prev_gs + (long long)n * Hp * Wp * C + ch;
+            f32x4 h[4][4];  // h[source row k][output column j]
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float* pr = pg + (long long)rr[k] * Wp * C;
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(pr + (long long)qq[0] * C), p1 = *reinterpret_cast<const f32x4*>(pr + (long long)qq[1] * C),
+                            p2 = *reinterpret_cast<const f32x4*>(pr + (long long)qq[2] * C), p3 = *reinterpret_cast<const f32x4*>(pr + (long long)qq[3] * C);
+                h[k][0] = blend2(0.25f, p0, 0.75f, p1);
+                h[k][1] = blend2(0.75f, p1, 0.25f, p2);
+                h[k][2] = blend2(0.25f, p1, 0.75f, p2);
+                h[k][3] = blend2(0.75f, p2, 0.25f, p3);
+            }
+            float* og = ob + g * out_gs;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 u0 = blend2(0.25f, h[0][j], 0.75f, h[1][j]), u1 = blend2(0.75f, h[1][j], 0.25f, h[2][j]), u2 = blend2(0.25f, h[1][j], 0.75f, h[2][j]),
+                            u3 = blend2(0.75f, h[2][j], 0.25f, h[3][j]);
+                __builtin_nontemporal_store(sk[0][j] + u0, reinterpret_cast<f32x4*>(og + (0 * 4 + j) * 256));
+                __builtin_nontemporal_store(sk[1][j] + u1, reinterpret_cast<f32x4*>(og + (1 * 4 + j) * 256));
+                __builtin_nontemporal_store(sk[2][j] + u2, reinterpret_cast<f32x4*>(og + (2 * 4 + j) * 256));
+                __builtin_nontemporal_store(sk[3][j] + u3, reinterpret_cast<f32x4*>(og + (3 * 4 + j) * 256));
+            }
+        }
+    }
+}
+
+// roi = {y0, y1, x0, x1} in output pixels (nullptr or empty = the whole map): the 16 x 16 blocks overlapping it are written whole
+hipError_t cerb_launch_upsample2_add_planar(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C, long long prev_gs,
+                                            long long out_gs, const int* roi, hipStream_t st) {
+    if (C != 64 || (H & 3) || (W & 3)) return hipErrorInvalidValue;
+    int by_lo = 0, by_hi = (H + 15) / 16, bx_lo = 0, bx_hi = (W + 15) / 16;
+    if (roi && roi[1] > roi[0] && roi[3] > roi[2]) {
+        by_lo = roi[0] / 16; by_hi = (roi[1] + 15) / 16;
+        bx_lo = roi[2] / 16; bx_hi = (roi[3] + 15) / 16;
+    }
+    const long long nblk = (long long)N * (by_hi - by_lo) * (bx_hi - bx_lo);
+    if (nblk <= 0 || nblk >= (1ll << 31)) return hipErrorInvalidValue;
+    long long blocks = nblk < 256 * 16 ? nblk : 256 * 16;
+    hipLaunchKernelGGL(upsample2_add_planar_kernel, dim3((unsigned)blocks), dim3(256), 0, st, skip, prev, out, groups, N, H, W, prev_gs, out_gs,
+                       cerb_planar_blocks(H), cerb_planar_blocks(W), by_lo, by_hi - by_lo, bx_lo, bx_hi - bx_lo);
     return hipGetLastError();
 }
 
@@ -493,9 +576,13 @@ __global__ __launch_bounds__(256, HEAD_G_OCC) void head_group_kernel(HeadGroupPa
         r.row = (int)(q - (unsigned)r.n * (unsigned)p.rows);
         return r;
     };
+    // NHWC: a pixel's 64 channels are contiguous (group stride 16 floats); tile-planar (conv_wino4p.hip's output): a pixel's 16-channel groups
+    // are one plane = 4096 floats apart, and the 16 pixels of a row segment are four runs of 256 bytes
+    const int gstride = p.feat_planar ? 4096 : 16;
     auto ptr_of = [&](const BPos& b) {
-        const int n = min(b.n, p.N - 1), x = min(p.xa0 + 16 * b.xb + px, p.W - 1);
-        return p.feat + (((long long)n * p.H + p.row0 + b.row) * p.W + x) * 64 + 4 * ks;
+        const int n = min(b.n, p.N - 1), x = min(p.xa0 + 16 * b.xb + px, p.W - 1), y = p.row0 + b.row;
+        if (p.feat_planar) return p.feat + cerb_planar_offset(n, y, x, 0, p.pl_byp, p.pl_bxp, 4) + 4 * ks;
+        return p.feat + (((long long)n * p.H + y) * p.W + x) * 64 + 4 * ks;
     };
     f32x4h xn[4][2];
     auto request = [&](unsigned t) {
@@ -503,7 +590,7 @@ __global__ __launch_bounds__(256, HEAD_G_OCC) void head_group_kernel(HeadGroupPa
         for (int pb = 0; pb < 2; ++pb) {
             const float* fp = ptr_of(decode(2u * t + (unsigned)pb));
 #pragma unroll
-            for (int g = 0; g < 4; ++g) xn[g][pb] = *reinterpret_cast<const f32x4h*>(fp + 16 * g);
+            for (int g = 0; g < 4; ++g) xn[g][pb] = *reinterpret_cast<const f32x4h*>(fp + gstride * g);
         }
     };
     request(task);

@@ -345,9 +345,12 @@ class NetDesc(torch.nn.Module):
 
     def set_conv_algo(self, algo):
         """Algorithm of the 3x3 stride-1 convolutions (include/cerberus_hip.h): 6 = Winograd F(4x4,3x3) for maps of 16 x 16 pixels and more,
-        F(2x2,3x3) below (default); 5 / 7 = F(4x4) everywhere with conv_wino4 / conv_wino4b; 1 = F(2x2); 0 = direct implicit GEMM;
-        2, 3, 4 = experimental F(2x2) variants."""
+        F(2x2,3x3) below (default); 5 / 7 = F(4x4) everywhere with conv_wino4 / conv_wino4b; 1 = F(2x2); 0 = direct implicit GEMM."""
         _lib.check(_lib.lib().cerb_net_set_conv_algo(self._ensure_handle(), int(algo)))
+
+    def set_planar(self, enable=True):
+        """Last decoder level in the tile-planar layout (conv_wino4p.hip; default on) or NHWC (conv_wino4.hip): bit-identical outputs."""
+        _lib.check(_lib.lib().cerb_net_set_planar(self._ensure_handle(), int(bool(enable))))
 
     def set_crop_roi(self, enable=True):
         """Compute only what the centre crop keeps in the decoders / heads (default on; include/cerberus_hip.h)."""

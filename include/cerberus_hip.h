@@ -86,6 +86,12 @@ int cerb_net_forward(cerb_net* net, const cerb_forward_io* io, void* hip_stream)
  * outside the product library.)
  * The training step follows the same rule for its forward and data-gradient convolutions (filter transform on the device). */
 int cerb_net_set_conv_algo(cerb_net* net, int algo);
+/* Layout of the LAST decoder level's private tensors (skip + upsample, first conv output, head features; models/net_desc.py:182-198):
+ *   1 (default) = tile-planar (cerb_common.h: cerb_planar_offset) through upsample2_add_planar -> conv_wino4p.hip x2 -> heads: a Winograd
+ *                 wave's stores are contiguous 1-KiB rows and its patch loads whole lines, zero padding is data;
+ *   0           = NHWC through conv_wino4.hip (round 2's path).
+ * Same arithmetic in the same order: the outputs are bit-identical (tests/test_net_gpu.py).  Applies with conv_algo 6 and head_algo 1. */
+int cerb_net_set_planar(cerb_net* net, int enable);
 /* Output heads (models/utils/net_layers.py:31-38): 1 (default) = every dense head of the batch in ONE grouped launch with the head's
  * weights resident in LDS (head_group_kernel), 0 = one launch per head (round-1 head_kernel); identical arithmetic, for A/B. */
 int cerb_net_set_head_algo(cerb_net* net, int algo);

@@ -219,6 +219,17 @@ def findContours(mask, mode=RETR_TREE, method=CHAIN_APPROX_SIMPLE):
     return contours, (hier if len(contours) else None)
 
 
+def moments(array, binaryImage=False):
+    """cv2.moments of a single-channel image as loader/postproc.py:27 consumes it (m00, m10, m01 only): raw spatial moments
+    m_pq = sum_{x,y} x^p y^q I(x, y) in double precision (OpenCV's documented definition; the mask is 0 / 1, so no rounding is
+    involved below 2^53).  Restated, PARITY UNPINNED against the library."""
+    a = np.asarray(array)
+    assert a.ndim == 2
+    v = (a != 0).astype(np.float64) if binaryImage else a.astype(np.float64)
+    ys, xs = np.mgrid[0:a.shape[0], 0:a.shape[1]]
+    return {"m00": float(v.sum()), "m10": float((v * xs).sum()), "m01": float((v * ys).sum())}
+
+
 def findContours_first_piece(mask, method=CHAIN_APPROX_SIMPLE):
     """The shortcut the device kernels take (cerb_inst_contour_start): outer border of the 8-connected piece whose first pixel
     comes last in the raster scan.  Equals findContours(...)[0][0] whenever no piece lies inside a hole of another piece --

@@ -47,7 +47,7 @@ torch.Tensor.to = _to
 from models.net_desc import create_model  # noqa: E402  (reference)
 from models.run_desc import infer_step as ref_infer_step  # noqa: E402  (reference)
 
-from cerberus_amd.weights import default_model_kwargs, make_state_dict, state_dict_sha256  # noqa: E402
+from cerberus_amd.weights import default_model_kwargs, make_state_dict, reference_init_state_dict, state_dict_sha256  # noqa: E402
 from oracle import net_ref  # noqa: E402
 
 torch.manual_seed(0)
@@ -62,9 +62,15 @@ def crops(a, axes=(1, 2)):
     return np.stack([a[:, y:y + CS, x:x + CS] for (y, x) in CROPS], axis=1)
 
 
-def run_case(tag, tile_seed, n, hw, out_shape, tasks, weight_seed=0):
+def run_case(tag, tile_seed, n, hw, out_shape, tasks, weight_seed=0, family="seeded"):
+    """family "seeded": cerberus_amd.weights.make_state_dict (non-saturating); "refinit": the distribution the reference's own constructor
+    leaves in a fresh model (weights_init_cnn, models/net_desc.py:89-103: kaiming-normal convs, identity BatchNorm) drawn from a seeded
+    torch generator (cerberus_amd.weights.reference_init_state_dict) so that the GPU box can rebuild the same tensors."""
     kw = default_model_kwargs(tasks)
-    sd_np = make_state_dict(weight_seed, kw["decoder_kwargs"], kw["considered_tasks"])
+    if family == "refinit":
+        sd_np = reference_init_state_dict(kw["decoder_kwargs"], kw["considered_tasks"], generator=torch.Generator().manual_seed(weight_seed))
+    else:
+        sd_np = make_state_dict(weight_seed, kw["decoder_kwargs"], kw["considered_tasks"])
     sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
     model = create_model(**kw)
     model.load_state_dict(sd, strict=True)  # pins the key schema too
@@ -79,12 +85,36 @@ def run_case(tag, tile_seed, n, hw, out_shape, tasks, weight_seed=0):
     # oracle vs reference (same machine, same torch) -- must agree to rounding
     orc_logits = net_ref.net_forward(sd, x, kw["decoder_kwargs"], kw["considered_tasks"])
     orc_out = net_ref.infer_step(sd, tiles, out_shape, kw["considered_tasks"], kw["decoder_kwargs"])
-    store = {"tile_seed": tile_seed, "weight_seed": weight_seed, "n": n, "hw": hw, "out_shape": out_shape,
+    store = {"tile_seed": tile_seed, "weight_seed": weight_seed, "weight_family": family, "n": n, "hw": hw, "out_shape": out_shape,
              "tasks": np.array(tasks), "weights_sha256": state_dict_sha256(sd_np)}
+    # The reference's OWN rounding noise: the same model and tiles evaluated in float64 (model.double()), read out like infer_step does
+    # (softmax, channels 1..2 of INST heads, argmax of TYPE heads).  noise/<head> = max |p_fp32 - p_fp64| over the whole tensor: two faithful
+    # fp32 evaluations of this network cannot be expected to agree more closely than this.  margin/<head>: top-1 minus top-2 softmax
+    # probability of the float32 reference per pixel (crops) -- where it is tiny an argmax may legitimately flip.
+    import copy
+
+    m64 = copy.deepcopy(model).double()
+    with torch.no_grad():
+        lg64 = m64(x.double())
+    for k, v in ref_logits.items():
+        p32 = torch.softmax(v.double(), 1)
+        p64 = torch.softmax(lg64[k], 1)
+        store["noise/" + k] = np.float64((p32 - p64).abs().max().item())
+        store["logit_noise_rel/" + k] = np.float64(((v.double() - lg64[k]).abs().max() / lg64[k].abs().max()).item())
+        store["logit_absmax/" + k] = np.float64(lg64[k].abs().max().item())
+        top = torch.topk(torch.softmax(v, 1), 2, dim=1).values
+        mg = (top[:, 0] - top[:, 1]).numpy()[..., None]  # (N, H, W, 1)
+        if k != "Patch-Class" and mg.shape[1] > out_shape:  # the kept window of infer_step (cropping_center)
+            o = (mg.shape[1] - out_shape) // 2
+            mg = mg[:, o:o + out_shape, o:o + out_shape]
+        if k != "Patch-Class":
+            store["margin/" + k] = crops(mg) if mg.shape[1] >= 256 else mg
+        print("%-12s %-12s reference fp32-vs-fp64: probabilities %.3e, logits %.3e relative (|logit| max %.1f)" %
+              (tag, k, store["noise/" + k], store["logit_noise_rel/" + k], store["logit_absmax/" + k]))
     for k, v in ref_logits.items():
         d = (orc_logits[k] - v).abs().max().item()
         print("%-12s logits %-18s absmax %.4f  oracle-vs-ref maxdiff %.3e" % (tag, tuple(v.shape), v.abs().max().item(), d))
-        assert d < 2e-4, (k, d)
+        assert d < 2e-4 * max(1.0, v.abs().max().item() / 10.0), (k, d)
         a = v.permute(0, 2, 3, 1).contiguous().numpy()
         if a.shape[1] >= 256:
             store["logits_crops/" + k] = crops(a)
@@ -102,7 +132,7 @@ def run_case(tag, tile_seed, n, hw, out_shape, tasks, weight_seed=0):
             assert o.shape == v.shape and o.dtype == v.dtype, (k, o.shape, v.shape, o.dtype, v.dtype)
             if v.dtype == np.float32:
                 d = np.abs(o - v).max()
-                assert d < 1e-5, (k, d)
+                assert d < max(1e-5, 2.0 * float(store["noise/" + k])), (k, d)
             else:
                 mism = (o != v).mean()
                 assert mism < 1e-3, (k, mism)
@@ -140,3 +170,8 @@ if __name__ == "__main__":
     run_case("g448_all", tile_seed=2, n=1, hw=448, out_shape=144, tasks=all_tasks)
     # bottom feature map smaller than 9 x 9 (6 x 6): cropping_center's negative-start slice in the Patch-Class branch
     run_case("small96_all", tile_seed=3, n=2, hw=96, out_shape=96, tasks=all_tasks)
+    # a second draw of the same recipe
+    run_case("seed1_all", tile_seed=4, n=2, hw=256, out_shape=256, tasks=all_tasks, weight_seed=1)
+    # the reference's default initialisation: logits in the hundreds / thousands, saturated probabilities -- every fp32 evaluation is far
+    # from the fp64 one here (noise/<head> in the fixture); the regime DESIGN.md par.4.0 calls the stress case
+    run_case("refinit_all", tile_seed=5, n=2, hw=256, out_shape=256, tasks=all_tasks, weight_seed=0, family="refinit")

@@ -107,8 +107,9 @@ class PostProcInstErodedContourMap(object):
         return inst_map, type_map
 
 
-def inst_info_ref(inst_map, type_map=None):
-    """ORACLE restatement of get_inst_info_dict (loader/postproc.py:12-75): box from get_bounding_box (misc/utils.py:82-91),
+def inst_info_ref(inst_map, type_map=None, ds_factor=1.0):
+    """ORACLE restatement of get_inst_info_dict (loader/postproc.py:12-98; pinned against the reference's own function on the golden label
+    maps by oracle/gen_golden_instinfo.py -> tests/golden/inst_info.npz, OpenCV's two calls through the stand-in): box from get_bounding_box (misc/utils.py:82-91),
     centroid = cv2.moments m10/m00, m01/m00 of the cropped binary mask (= mean x, mean y), contour =
     findContours(crop, RETR_TREE, CHAIN_APPROX_SIMPLE)[0][0] shifted by the box origin with the `< 3 points -> skip` filter
     (postproc.py:26-41; OpenCV is absent here, so findContours is oracle/cv2_standin.py's Suzuki-Abe restatement -- parity
@@ -143,4 +144,8 @@ def inst_info_ref(inst_map, type_map=None):
             d["type"] = int(it)
             d["type_prob"] = float(dict(lst)[it] / (m.sum() + 1.0e-6))
         info[int(inst_id)] = d
+    if ds_factor != 1.0:  # loader/postproc.py:78-96: back to the resolution the slide is annotated at
+        for k in list(info.keys()):
+            for f in ("box", "centroid", "contour"):
+                info[k][f] = np.round(info[k][f] / ds_factor).astype("int")
     return info

@@ -9,7 +9,7 @@ import torch
 
 from cerberus_amd.net_desc import create_model
 from cerberus_amd.run_desc import infer_step
-from cerberus_amd.weights import default_model_kwargs, make_state_dict
+from cerberus_amd.weights import default_model_kwargs, make_state_dict, reference_init_state_dict
 from oracle import net_ref
 
 pytestmark = pytest.mark.gpu
@@ -23,12 +23,78 @@ def _crops(a):
     return np.stack([a[:, y:y + CS, x:x + CS] for (y, x) in CROPS], axis=1)
 
 
-def _model(tasks, seed=0):
+def _model(tasks, seed=0, family="seeded"):
+    """family "seeded": cerberus_amd.weights.make_state_dict; "refinit": the reference's default initialisation (weights_init_cnn,
+    models/net_desc.py:89-103) from a seeded generator -- exactly what oracle/gen_golden_net.py loaded into the reference."""
     kw = default_model_kwargs(tasks)
-    sd = {k: torch.from_numpy(v) for k, v in make_state_dict(seed, kw["decoder_kwargs"], kw["considered_tasks"]).items()}
+    if family == "refinit":
+        sd_np = reference_init_state_dict(kw["decoder_kwargs"], kw["considered_tasks"], generator=torch.Generator().manual_seed(seed))
+    else:
+        sd_np = make_state_dict(seed, kw["decoder_kwargs"], kw["considered_tasks"])
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
     m = create_model(**kw)
     m.load_state_dict(sd, strict=True)
     return m, sd, kw
+
+
+def _golden_model(g):
+    tasks = [str(t) for t in g["tasks"]]
+    fam = str(g["weight_family"]) if "weight_family" in g else "seeded"
+    m, sd, kw = _model(tasks, int(g["weight_seed"]), fam)
+    from cerberus_amd.weights import state_dict_sha256
+    assert state_dict_sha256({k: v.numpy() for k, v in sd.items()}) == str(g["weights_sha256"]), "the fixture's weights were not rebuilt bit for bit"
+    return m, sd, kw, tasks
+
+
+# The bars (north_star: "within 1e-4 on float probability maps ... bit-exact on integer maps given identical seeds"):
+#   * probabilities: 1e-4 absolute -- OR, where the reference's own float32 evaluation is further than that from its float64 evaluation
+#     (noise/<head> in the fixture, measured by oracle/gen_golden_net.py with model.double(): up to 4.6e-4 under the reference's default
+#     initialisation, whose logits run into the thousands), 3x that noise: two faithful fp32 evaluations of one network cannot be asked to
+#     agree more closely than each agrees with the exact result.  The relative logit error is checked at 1e-5 beside it.
+#   * integer (argmax) maps: EVERY mismatching pixel must sit where the reference's own top-1 / top-2 softmax margin (margin/<head>) is
+#     below twice the probability bar of that head -- i.e. only genuine rounding-order ties may flip; a systematic argmax error fails.
+def _prob_bar(g, head):
+    noise = float(g["noise/" + head]) if ("noise/" + head) in g else 0.0
+    return max(PROB_TOL, 3.0 * noise)
+
+
+def _margin_bar(noise):
+    return max(2e-5, 6.0 * noise)
+
+
+def _check_type_map(g, head, got, ref):
+    bad = got != ref
+    if not bad.any():
+        return
+    assert ("margin/" + head) in g, "fixture without margins: " + head
+    mg = g["margin/" + head]
+    assert mg.shape == bad.shape, (mg.shape, bad.shape)
+    noise = float(g["noise/" + head]) if ("noise/" + head) in g else 0.0
+    worst = float(mg[bad].max())
+    assert worst < _margin_bar(noise), "%s: an argmax differs where the reference's top-2 margin is %.3e (bar %.1e), %d pixels differ" % (head, worst, _margin_bar(noise), int(bad.sum()))
+
+
+def _oracle_type_margins(sd, tiles, out_shape, kw):
+    """top-1 minus top-2 softmax probability of the oracle's own logits inside the kept window, per TYPE head: (N, h, w)."""
+    x = torch.from_numpy(tiles).float().permute(0, 3, 1, 2).contiguous()
+    lg = net_ref.net_forward(sd, x, kw["decoder_kwargs"], kw["considered_tasks"])
+    oh, ow = (out_shape, out_shape) if np.isscalar(out_shape) else out_shape
+    res = {}
+    for k, v in lg.items():
+        if not k.endswith("TYPE"):
+            continue
+        top = torch.topk(torch.softmax(v, 1), 2, dim=1).values
+        mg = (top[:, 0] - top[:, 1]).numpy()
+        y0, x0 = int((mg.shape[1] - oh) * 0.5), int((mg.shape[2] - ow) * 0.5)
+        res[k] = mg[:, y0:y0 + oh, x0:x0 + ow]
+    return res
+
+
+def _assert_type_equal_up_to_ties(a, b, margin, k):
+    bad = a != b
+    if bad.any():
+        worst = float(margin[bad].max())
+        assert worst < _margin_bar(0.0), "%s: an argmax differs where the oracle's top-2 margin is %.3e, %d pixels differ" % (k, worst, int(bad.sum()))
 
 
 @pytest.fixture(scope="module")
@@ -59,11 +125,14 @@ def test_encoder_and_logits_vs_oracle(full_model):
         assert (v.cpu() - ref[k]).abs().max().item() < 2e-4, k
 
 
-@pytest.mark.parametrize("tag", ["cfg1_nuclei", "cfg2_all", "g448_all", "small96_all"])
+@pytest.mark.parametrize("tag", ["cfg1_nuclei", "cfg2_all", "g448_all", "small96_all", "seed1_all", "refinit_all"])
 def test_infer_step_vs_reference_golden(golden_dir, tag):
+    """The default path (F(4x4) Winograd, planar last level, grouped heads) against what the REFERENCE's own NetDesc / infer_step produced
+    for the same seeded weights and tiles: two draws of the non-saturating recipe, four geometries, and the reference's DEFAULT
+    initialisation (refinit_all: saturated probabilities, logits in the thousands -- the regime in which the reference's own fp32 result
+    is 2e-5 .. 4.6e-4 from its fp64 result, so the bar there is 3x that noise; see _prob_bar)."""
     g = np.load(os.path.join(golden_dir, "net_%s.npz" % tag))
-    tasks = [str(t) for t in g["tasks"]]
-    m, sd, kw = _model(tasks, int(g["weight_seed"]))
+    m, sd, kw, tasks = _golden_model(g)
     n, hw, osz = int(g["n"]), int(g["hw"]), int(g["out_shape"])
     tiles = np.random.RandomState(int(g["tile_seed"])).randint(0, 256, (n, hw, hw, 3)).astype(np.uint8)
     out = infer_step(torch.from_numpy(tiles), m, osz, tasks)
@@ -78,15 +147,19 @@ def test_infer_step_vs_reference_golden(golden_dir, tag):
         ref = g[key] if key in g else g["out_full/" + k]
         got = _crops(a4) if key in g else a4
         if a.dtype == np.float32:
-            assert np.abs(got - ref).max() < PROB_TOL, k
+            err = np.abs(got - ref).max()
+            assert err < _prob_bar(g, k), (k, err, _prob_bar(g, k))
+        elif k != "Patch-Class":
+            _check_type_map(g, k, got, ref)
         else:
-            assert (got != ref).mean() < 1e-4, k
+            assert np.array_equal(got, ref), k
     for k, v in lg.items():
         a = v.permute(0, 2, 3, 1).contiguous().cpu().numpy()
         key = "logits_crops/" + k
         ref = g[key] if key in g else g["logits_full/" + k]
         got = _crops(a) if key in g else a
-        assert np.abs(got - ref).max() < 3e-4, k
+        scale = max(1.0, float(g["logit_absmax/" + k]) if ("logit_absmax/" + k) in g else 1.0)
+        assert np.abs(got - ref).max() < 3e-4 * max(1.0, scale / 30.0), (k, np.abs(got - ref).max(), scale)
 
 
 def test_infer_step_full_tensor_vs_oracle(full_model):
@@ -94,6 +167,7 @@ def test_infer_step_full_tensor_vs_oracle(full_model):
     tiles = np.random.RandomState(5).randint(0, 256, (3, 256, 256, 3)).astype(np.uint8)
     got = infer_step(torch.from_numpy(tiles), m, 256, kw["considered_tasks"])
     ref = net_ref.infer_step(sd, tiles, 256, kw["considered_tasks"], kw["decoder_kwargs"])
+    mgs = _oracle_type_margins(sd, tiles, 256, kw)
     for i in range(3):
         assert list(got[i].keys()) == list(ref[i].keys())
         for k in ref[i]:
@@ -101,8 +175,10 @@ def test_infer_step_full_tensor_vs_oracle(full_model):
             assert a.shape == b.shape and a.dtype == b.dtype, k
             if a.dtype == np.float32:
                 assert np.abs(a - b).max() < PROB_TOL, k
+            elif k in mgs:
+                _assert_type_equal_up_to_ties(a, b, mgs[k][i], k)
             else:
-                assert (a != b).mean() < 1e-4, k
+                assert np.array_equal(a, b), k
 
 
 def test_ragged_batch_sizes_and_crop(full_model):
@@ -111,13 +187,16 @@ def test_ragged_batch_sizes_and_crop(full_model):
     tiles = np.random.RandomState(6).randint(0, 256, (1, 304, 304, 3)).astype(np.uint8)
     got = infer_step(torch.from_numpy(tiles), m, [144, 160], kw["considered_tasks"])
     ref = net_ref.infer_step(sd, tiles, [144, 160], kw["considered_tasks"], kw["decoder_kwargs"])
+    mgs = _oracle_type_margins(sd, tiles, [144, 160], kw)
     for k in ref[0]:
         a, b = got[0][k], ref[0][k]
         assert a.shape == b.shape and a.dtype == b.dtype, k
         if a.dtype == np.float32:
             assert np.abs(a - b).max() < PROB_TOL, k
+        elif k in mgs:
+            _assert_type_equal_up_to_ties(a, b, mgs[k][0], k)
         else:
-            assert (a != b).mean() < 1e-4, k
+            assert np.array_equal(a, b), k
 
 
 def test_linearity_property_of_identical_tiles(full_model):
@@ -383,3 +462,36 @@ def test_winograd_partial_tiles_and_odd_blocks_vs_direct(full_model, win, osz, n
                     assert (a[k] != ref[k]).float().mean().item() < 1e-4, (algo, k)
     finally:
         m.set_conv_algo(DEFAULT_ALGO)
+
+
+@pytest.mark.parametrize("win,osz,n", [(256, 256, 3), (448, 144, 2), (272, 272, 2), (304, 144, 3), (96, 96, 5), (208, 80, 2)])
+def test_planar_last_level_is_bit_identical_to_nhwc(full_model, win, osz, n):
+    """cerb_net_set_planar(1) (default): the last decoder level in the tile-planar layout (upsample2_add_planar -> conv_wino4p x2 -> heads
+    reading planar features) against cerb_net_set_planar(0) (round 2's NHWC path through conv_wino4): same arithmetic in the same order,
+    so every head's output must be BITWISE equal -- whole tiles, centre crops (region-of-interest launches), odd block counts, a 96-pixel
+    tile whose last level falls back to NHWC, and a different batch in between (stale planar workspaces).  Also checks that the planar
+    kernels are the ones that ran."""
+    m, sd, kw = full_model
+    rs = np.random.RandomState(500 + win + osz)
+    tiles = torch.from_numpy(rs.randint(0, 256, (n, win, win, 3)).astype(np.uint8)).cuda()
+    other = torch.from_numpy(rs.randint(0, 256, (n + 1, win, win, 3)).astype(np.uint8)).cuda()
+    try:
+        m.set_planar(False)
+        ref = {k: v.clone() for k, v in m.infer_tiles(tiles, osz).items()}
+        m.set_planar(True)
+        m.infer_tiles(other, osz)  # leaves another batch's values in every planar buffer
+        m.profile(True)
+        got = {k: v.clone() for k, v in m.infer_tiles(tiles, osz).items()}
+        torch.cuda.synchronize()
+        kernels = [r[1] for r in m.profile_records()]
+        m.profile(False)
+        again = m.infer_tiles(tiles, osz)
+        torch.cuda.synchronize()
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), (k, (got[k].float() - ref[k].float()).abs().max().item())
+            assert torch.equal(again[k], ref[k]), k
+    finally:
+        m.profile(False)
+        m.set_planar(True)
+    if win * win > 4096 * 4:  # last level above 64 x 64: the planar kernels carry it
+        assert sum(k.startswith("conv_wino4p") for k in kernels) == 2 and "upsample2_add_planar" in kernels, kernels

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from cerberus_amd.weights import default_model_kwargs, make_state_dict
+from cerberus_amd.weights import default_model_kwargs, make_state_dict, reference_init_state_dict, state_dict_sha256
 from oracle import net_ref
 
 CROPS = [(0, 0), (96, 96), (192, 192)]
@@ -17,25 +17,33 @@ def _crops(a):
     return np.stack([a[:, y:y + CS, x:x + CS] for (y, x) in CROPS], axis=1)
 
 
-@pytest.mark.parametrize("tag", ["cfg1_nuclei", "cfg2_all", "g448_all", "small96_all"])
+@pytest.mark.parametrize("tag", ["cfg1_nuclei", "cfg2_all", "g448_all", "small96_all", "seed1_all", "refinit_all"])
 def test_oracle_matches_reference_fixtures(golden_dir, tag):
+    """Two draws of the seeded non-saturating recipe and the reference's default initialisation (refinit_all: logits in the thousands,
+    so the tolerances scale with the logit magnitude and with the reference's own fp32-vs-fp64 noise recorded in the fixture)."""
     g = np.load(os.path.join(golden_dir, "net_%s.npz" % tag))
     tasks = [str(t) for t in g["tasks"]]
     kw = default_model_kwargs(tasks)
-    sd = {k: torch.from_numpy(v) for k, v in make_state_dict(int(g["weight_seed"]), kw["decoder_kwargs"], tasks).items()}
+    if str(g["weight_family"]) == "refinit":
+        sd_np = reference_init_state_dict(kw["decoder_kwargs"], tasks, generator=torch.Generator().manual_seed(int(g["weight_seed"])))
+    else:
+        sd_np = make_state_dict(int(g["weight_seed"]), kw["decoder_kwargs"], tasks)
+    assert state_dict_sha256(sd_np) == str(g["weights_sha256"])
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
     n, hw, osz = int(g["n"]), int(g["hw"]), int(g["out_shape"])
     tiles = np.random.RandomState(int(g["tile_seed"])).randint(0, 256, (n, hw, hw, 3)).astype(np.uint8)
     x = torch.from_numpy(tiles).float().permute(0, 3, 1, 2).contiguous()
     logits, feats, bottom = net_ref.net_forward(sd, x, kw["decoder_kwargs"], tasks, return_feats=True)
     for i, f in enumerate(feats[:4] + [bottom]):
-        assert abs(f.double().mean().item() - float(g["feat_mean/x%d" % i])) < 1e-5
+        assert abs(f.double().mean().item() - float(g["feat_mean/x%d" % i])) < 1e-5 * max(1.0, float(g["feat_absmean/x%d" % i]))
     for k, v in logits.items():
         a = v.permute(0, 2, 3, 1).contiguous().numpy()
         key = "logits_crops/" + k
         ref = g[key] if key in g else g["logits_full/" + k]
         got = _crops(a) if key in g else a
-        assert np.abs(got - ref).max() < 2e-4, k
-        assert abs(a.astype(np.float64).mean() - float(g["logits_mean/" + k])) < 1e-5
+        scale = max(1.0, float(g["logit_absmax/" + k]) / 10.0)
+        assert np.abs(got - ref).max() < 2e-4 * scale, k
+        assert abs(a.astype(np.float64).mean() - float(g["logits_mean/" + k])) < 1e-5 * scale
     out = net_ref.infer_step(sd, tiles, osz, tasks, kw["decoder_kwargs"])
     for k in out[0].keys():
         a = np.stack([out[i][k] for i in range(n)])
@@ -44,7 +52,11 @@ def test_oracle_matches_reference_fixtures(golden_dir, tag):
         key = "out_crops/" + k
         ref = g[key] if key in g else g["out_full/" + k]
         got = _crops(a4) if key in g else a4
+        noise = float(g["noise/" + k])
         if a.dtype == np.float32:
-            assert np.abs(got - ref).max() < 1e-5, k
+            assert np.abs(got - ref).max() < max(1e-5, 3.0 * noise), k
+        elif ("margin/" + k) in g:  # an argmax may differ from the reference's only where its own top-2 margin is rounding-sized
+            bad = got != ref
+            assert not bad.any() or float(g["margin/" + k][bad].max()) < max(2e-5, 6.0 * noise), k
         else:
-            assert (got != ref).mean() < 1e-3, k
+            assert np.array_equal(got, ref), k

@@ -168,3 +168,17 @@ def test_reference_tile_info_sets():
     assert info[3][0][0].tolist() == [256 - 64, 256 - 64, 256 + 64, 256 + 64]
     small = wt.get_tile_info((200, 100), [256, 256], 32, [16, 16])
     assert len(small) == 1 and small[0][1].tolist() == [[0, 0, 0, 0]]
+
+
+def test_instance_dictionary_oracle_vs_reference_fixture(golden_dir):
+    """oracle/postproc_ref.py::inst_info_ref against what the REFERENCE's get_inst_info_dict (loader/postproc.py:12-98) returned for the
+    golden label maps (tests/golden/inst_info.npz, oracle/gen_golden_instinfo.py): boxes, the < 3-point skip, majority type with the
+    background rule and the stable tie order, type_prob, key order, ds_factor rounding.  cv2.moments / findContours went through the
+    stand-in on both sides (OpenCV is installed nowhere here): those two stay unpinned."""
+    from oracle import instinfo_fixture as fx
+
+    n = 0
+    for tag, lab, typ, ds, with_type, ref in fx.cases(golden_dir):
+        fx.check(pr.inst_info_ref(lab, typ if with_type else None, ds_factor=ds), ref, with_type, tag)
+        n += 1
+    assert n >= 20

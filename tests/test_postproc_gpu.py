@@ -122,7 +122,8 @@ def test_idempotent_and_deterministic():
 
 
 def test_instance_table_vs_oracle():
-    """cerb_inst_table / get_inst_info_dict (box, centroid, majority type) vs the numpy restatement of loader/postproc.py:12-75."""
+    """cerb_inst_table / get_inst_info_dict (box, centroid, majority type) vs the numpy restatement of loader/postproc.py:12-98 (itself
+    pinned to the reference's function by tests/golden/inst_info.npz) on a larger map than the fixtures hold."""
     from cerberus_amd.postproc import get_inst_info_dict
 
     m = synth.blob_maps(700, 900, 71, 60, 10.0, 45.0, rim=4.0, sharp=1.0, noise=0.02, border_bias=True)
@@ -142,6 +143,21 @@ def test_instance_table_vs_oracle():
     assert np.array_equal(half[k0]["box"], np.round(got[k0]["box"] / 0.5).astype(int)) and "type" not in half[k0]
     assert np.array_equal(half[k0]["contour"], np.round(got[k0]["contour"] / 0.5).astype(int))
     assert get_inst_info_dict(torch.zeros((8, 8), dtype=torch.int32, device="cuda")) == {}
+
+
+def test_instance_dictionary_vs_reference_fixture(golden_dir):
+    """cerberus_amd.postproc.get_inst_info_dict (cerb_inst_table + cerb_inst_contour_* on the GPU) against the dictionaries the REFERENCE's
+    own get_inst_info_dict returned for the golden label maps (tests/golden/inst_info.npz): key order, boxes, centroids, contours, the
+    < 3-point skip, type votes incl. exact ties and background majorities, type_prob, ds_factor 1 and 0.5, with and without a type map."""
+    from cerberus_amd.postproc import get_inst_info_dict
+    from oracle import instinfo_fixture as fx
+
+    n = 0
+    for tag, lab, typ, ds, with_type, ref in fx.cases(golden_dir):
+        got = get_inst_info_dict(torch.from_numpy(lab).cuda(), torch.from_numpy(typ).cuda() if with_type else None, ds_factor=ds)
+        fx.check(got, ref, with_type, tag)
+        n += 1
+    assert n >= 20
 
 
 def test_inst_table_first_pixel_and_relabel():
