@@ -26,18 +26,24 @@ constexpr int LDS_BYTES = 2 * V_FLOATS * 4;   // double-buffered: 144 KiB
 constexpr int PLANE_BYTES = 16 * 16 * 16 * 4; // one 16-channel plane of a block
 constexpr int NS = NPOS;                      // steps per chunk: one position each (one 16-byte weight load, two ds_read_b128, 8 MFMAs)
 constexpr int NPOS_A = 32;                    // positions whose accumulators live in AccVGPRs (32 x 2 blocks x 4 = 256); the rest in VGPRs
-// Schedule of a chunk (36 steps of 8 matrix instructions = 256 cycles each).  vmcnt retires IN ORDER across all of a wave's loads and
-// stores, so a patch load that misses to HBM holds back the wait of every weight load issued after it: the first weight burst issued after
-// a patch load is needed WD + WB - (steps since the previous burst) steps later, and that distance -- not the distance to the patch's own
-// transform -- is the latency the input path can hide.  Round 2's schedule (bursts of 4 every 4 steps, 8 ahead, three patch loads in every
-// one of the first 12 steps) left 9 steps = 0.9 us; here the weight stream runs in bursts of WB = 6, WD = 12 steps ahead, and the patch
-// loads go out in the PLN steps right behind a burst, column by column (the order the transform consumes them): 16 steps = 1.75 us.
+// Schedule of a chunk (36 steps of 8 matrix instructions = 256 cycles each).  What round 3's counters showed (profiles/r03_*): the CU's
+// vector L1 stalls IN ORDER whenever a request hits a line whose miss is still in flight (TCP_PENDING_STALL_CYCLES = 57 % of the kernel with
+// the 6x6 patches loaded tile by tile: 20 of a thread's 36 patch pixels are interior pixels of its neighbours' tiles, requested a step or two
+// earlier by other lanes / the other wave of the block and still on their way from HBM), and behind a stalled L1 the TA FIFOs fill and the wave
+// cannot even ISSUE its next weight load (SQ_VMEM_TA_*_FIFO_FULL 8 %).  So the patch is requested in two groups that are far apart in time:
+//   * the 16 INTERIOR pixels (rows / columns 1..4 = the tile's own 4x4 pixels: no other lane of this CU asks for them) as early as their
+//     registers allow -- row r of the patch that has just been transformed is free after its V write at step TQ+7+r, so the interior of the
+//     chunk AFTER NEXT goes out at steps TQ+8+r, four loads per step;
+//   * the 20 HALO pixels (interior pixels of the neighbouring tiles, requested by their owners in the previous chunk) at steps HQ .. HQ+9 of
+//     the chunk before their transform: by then the owners' misses have landed, so a halo load is an L1 / L2 hit and never waits on a
+//     pending line.  Halo pixels in OTHER blocks' tiles are first touches for this CU (no pending line either).
+// The weight stream is one 1-KiB load per step, WD steps ahead (smooth: bursts of 4..6 overflowed the TA FIFOs).
 #ifndef P4_RING
-#define P4_RING 18
+#define P4_RING 12
 #endif
 constexpr int RING = P4_RING;                 // weight operand slots (NS % RING == 0: the slot of a step does not depend on the chunk)
 #ifndef P4_WD
-#define P4_WD 12
+#define P4_WD 8
 #endif
 constexpr int WD = P4_WD;                     // weight prefetch distance in steps
 #ifndef P4_PRE
@@ -45,33 +51,36 @@ constexpr int WD = P4_WD;                     // weight prefetch distance in ste
 #endif
 constexpr int PRE = P4_PRE;                   // steps of the NEXT item whose weights are requested before an item's output stores
 #ifndef P4_WB
-#define P4_WB 6
+#define P4_WB 1
 #endif
 constexpr int WB = P4_WB;                     // weight burst size in steps
-#ifndef P4_PL
-#define P4_PL 4
-#endif
-constexpr int PL = P4_PL;                     // patch loads issued per step ...
-#ifndef P4_PLN
-#define P4_PLN 3
-#endif
-constexpr int PLN = P4_PLN;                   // ... in the first PLN steps behind every weight burst
 #ifndef P4_TQ
 #define P4_TQ 22
 #endif
 constexpr int TQ = P4_TQ;                     // the next chunk's patch is transformed at TQ+1 .. TQ+12, written at TQ+7 .. TQ+12
-constexpr int patch_slot(int q) { return (q % WB) < PLN ? (q / WB) * PLN + (q % WB) : -1; }  // which group of PL loads step q issues
-constexpr int last_patch_step() {
-    int l = -1;
-    for (int q = 0; q < NS; ++q)
-        if (patch_slot(q) >= 0 && patch_slot(q) * PL < 36) l = q;
-    return l;
-}
+#ifndef P4_HQ
+#define P4_HQ 8
+#endif
+constexpr int HQ = P4_HQ;                     // halo loads of the next chunk's patch: two per step at steps HQ .. HQ+9
+// halo pixels in the order the vertical pass consumes their columns: column 0 (6), the top / bottom pixels of columns 1..4 (8), column 5 (6)
+constexpr int halo_r(int k) { return k < 6 ? k : k < 14 ? ((k - 6) & 1 ? 5 : 0) : k - 14; }
+constexpr int halo_q(int k) { return k < 6 ? 0 : k < 14 ? 1 + (k - 6) / 2 : 5; }
 static_assert(NS % RING == 0 && WD + WB <= RING && NS % WB == 0 && PRE == WD && PRE <= RING, "weight ring");
-static_assert(PLN <= WB && ((NS / WB) * PLN) * PL >= 36 && last_patch_step() < TQ && TQ + 13 < NS, "the patch must be requested before its transform starts");
+static_assert(HQ + 10 <= TQ && TQ + 13 < NS && TQ + 8 + 4 <= NS, "the halo must be requested before the transform starts, the interior after its registers are free");
 constexpr int BIAS_XI = 7;                    // A^T[i][1] A[1][j] = 1 for all 16 outputs: the bias enters through position (1, 1)
 constexpr int CHUNK_W_BYTES = NPOS * 4 * 1024;  // packed weights of one (cout block, 16-channel chunk): 144 KiB
 constexpr int WAVE_W_BYTES = NPOS * 1024;       // one wave's share: 36 steps x 1 KiB
+
+#ifdef P4_PROF
+// developer instrumentation (scripts/dev_w4pprof.py): wave P4_PROF_WAVE of workgroup P4_PROF stamps the cycle counter at every step of its third item
+constexpr int PROF_BYTES = 16 * 40 * 8;
+__device__ unsigned long long p4_prof_buf[16 * 40];
+#ifndef P4_PROF_WAVE
+#define P4_PROF_WAVE 0
+#endif
+#else
+constexpr int PROF_BYTES = 0;
+#endif
 
 template <int I>
 using IC = std::integral_constant<int, I>;
@@ -87,8 +96,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
 }
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#ifndef P4_WAUX
+#define P4_WAUX 0
+#endif
+#ifndef P4_PAUX
+#define P4_PAUX 0
+#endif
 __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, P4_WAUX));
 }
 __device__ __forceinline__ void buf_store(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, soff, 0);
@@ -98,7 +113,7 @@ __device__ __forceinline__ void buf_store(f32x4 v, __amdgpu_buffer_rsrc_t r, uns
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
-    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, soff, 0));
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, soff, P4_PAUX));
 }
 
 // The matrix instruction, with the accumulator's register file chosen by the caller.  hipcc does not model what is inside the string:
@@ -129,6 +144,14 @@ __device__ __forceinline__ void mfma_step(f32x4& c0, f32x4& c1, const f32x4& av,
 #undef P4_STEP_IN
 }
 __device__ __forceinline__ void wait_mfma_results() { asm volatile("s_nop 15\n\ts_nop 3"); }  // 8-pass MFMA D -> VALU reader: 12 states and more
+
+// the hardware lane id, computed where it is used (volatile: not hoisted out of the item loop): a lane-invariant kept in a register across the
+// chunk loop was spilled, and its scratch reload sits in the same in-order vmcnt queue as every load the wave has in flight
+__device__ __forceinline__ int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 
 struct Blk {
     int n, by, bx;  // image, block row / column inside the launch's block grid
@@ -161,6 +184,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int item = lb;
     const int item_end = total;
     if (item >= item_end) return;
+#ifdef P4_PROF
+    const int prof_item = item + 2 * ISTEP;
+#endif
 
     auto decode_blk = [&](int id) {
         Blk b;
@@ -223,8 +249,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned wlane = (unsigned)lane * 16u;
 
     f32x2 d[6][6];  // raw patch of the NEXT chunk (two channels), transformed in place in the shadow of the matrix pipe
-    auto issue = [&](__amdgpu_buffer_rsrc_t r, int chunk_off, int k) __attribute__((always_inline)) {
-        const int qq = k / 6, rr = k % 6;  // column by column: pass_v(q) needs column q first
+    auto issue = [&](__amdgpu_buffer_rsrc_t r, int chunk_off, int rr, int qq) __attribute__((always_inline)) {
         const int ii = rr == 0 ? 3 : rr == 5 ? 0 : rr - 1, jj = qq == 0 ? 3 : qq == 5 ? 0 : qq - 1;
         d[rr][qq] = buf_load2(r, poff[rr == 0 ? 0 : rr == 5 ? 2 : 1][qq == 0 ? 0 : qq == 5 ? 2 : 1], chunk_off + (ii * 4 + jj) * 1024);
     };
@@ -260,7 +285,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     {
         const __amdgpu_buffer_rsrc_t r0 = make_rsrc(in_base(w.g, mine(w)));
 #pragma unroll
-        for (int k = 0; k < 36; ++k) issue(r0, 0, k);
+        for (int k = 0; k < 36; ++k) issue(r0, 0, k / 6, k % 6);
     }
 #pragma unroll
     for (int q = 0; q < 6; ++q) pass_v(q);
@@ -268,6 +293,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int r = 0; r < 6; ++r) {
         pass_h(r);
         write_row(0, r);
+    }
+    {   // the interior of the SECOND chunk's patch (in the steady state the previous chunk requests it)
+        const bool one = (nchunk == 1);
+        const Item w1 = (one && item + ISTEP < item_end) ? decode(item + ISTEP) : w;
+        const __amdgpu_buffer_rsrc_t r1 = make_rsrc(in_base(w1.g, mine(w1)));
+#pragma unroll
+        for (int k = 0; k < 16; ++k) issue(r1, one ? 0 : PLANE_BYTES, 1 + k / 4, 1 + k % 4);
     }
     int vbuf = 0;  // the buffer the CURRENT chunk reads; the next chunk's patch goes to vbuf ^ 1
     __syncthreads();
@@ -281,10 +313,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto load_bias = [&](const Item& wi) {
         const float* bias = p.bias + wi.g * p.bias_gs + wi.cb * 64 + 16 * a;
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, 64, 0x00020000);
-        bnext = buf_load(rb, (unsigned)ks * 16u, 0);
+        bnext = buf_load(rb, (unsigned)(fresh_lane() >> 4) * 16u, 0);
     };
     load_bias(w);
-    const unsigned olane = (unsigned)(m * 64 + ks * 16);  // output: lane (tile m, channel quad ks) inside a 1-KiB pixel-position row
 
     for (;;) {
         f32x4 acc[NPOS][2];
@@ -293,14 +324,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const __amdgpu_buffer_rsrc_t rw_nx = more_items ? make_rsrc(w_base(wnx)) : rw;
         const char* in_cur = in_base(w.g, mine(w));
         const char* in_nx = in_base(wnx.g, mine(wnx));
+        // the item that holds the chunk after next when it lies beyond this item: the next item -- or, for a one-chunk convolution, the one after
+        const bool more2 = item + 2 * ISTEP < item_end;
+        const Item wn2 = (nchunk == 1 && more2) ? decode(item + 2 * ISTEP) : wnx;
+        const char* in_n2 = in_base(wn2.g, mine(wn2));
+        auto in_nx2 = [&](int over) { return (nchunk == 1 && over >= 1) ? in_n2 : in_nx; };
         acc[BIAS_XI][0] = bnext;
         acc[BIAS_XI][1] = bnext;
+#ifdef P4_PROF
+        const bool prof_on = (blockIdx.x == P4_PROF) && a == P4_PROF_WAVE && (item == prof_item);
+#define P4_STAMP(row, col) do { if (prof_on && lane == 0) reinterpret_cast<unsigned long long*>(lds + 2 * V_FLOATS)[(row) * 40 + (col)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define P4_STAMP(row, col) do { } while (0)
+#endif
 
         auto chunk = [&](auto first_tag, int ch) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
             const bool last_ch = (ch == nchunk - 1);
-            const __amdgpu_buffer_rsrc_t r_stage = make_rsrc(last_ch ? in_nx : in_cur);
+            const __amdgpu_buffer_rsrc_t r_stage = make_rsrc(last_ch ? in_nx : in_cur);   // the next chunk's patch (halo loads)
             const int stage_off = (last_ch ? 0 : ch + 1) * PLANE_BYTES;
+            const bool wrap2 = ch + 2 >= nchunk;                                           // the patch of the chunk after next (interior loads)
+            const __amdgpu_buffer_rsrc_t r_stage2 = make_rsrc(wrap2 ? in_nx2(ch + 2 - nchunk) : in_cur);
+            const int stage_off2 = (wrap2 ? (ch + 2 - nchunk) % nchunk : ch + 2) * PLANE_BYTES;
             const int wcur_off = ch * CHUNK_W_BYTES;
             const __amdgpu_buffer_rsrc_t rw_over = last_ch ? rw_nx : rw;
             const int wover_off = last_ch ? 0 : (ch + 1) * CHUNK_W_BYTES;
@@ -314,6 +359,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 constexpr int q = decltype(Q)::value;
                 constexpr int xi = q;
                 constexpr bool AG = xi < NPOS_A;
+#ifdef P4_PROF
+                if (ch < 15) P4_STAMP(ch, q);
+#endif
+#ifndef P4_ABL_NOWLOAD
                 if constexpr (q % WB == 0) {
 #pragma unroll
                     for (int dd = q + WD; dd < q + WD + WB; ++dd) {
@@ -322,34 +371,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         else wq[(dd - NS) % RING] = buf_load(rw_over, wlane, wover_off + (dd - NS) * 1024);
                     }
                 }
+#endif
                 if constexpr (q + 1 < NS) {
                     bb[(q + 1) & 1][0] = *reinterpret_cast<const f32x4*>(vsrc + (q + 1) * NT * CB);
                     bb[(q + 1) & 1][1] = *reinterpret_cast<const f32x4*>(vsrc + (q + 1) * NT * CB + 16 * CB);
                 }
-                if constexpr (patch_slot(q) >= 0 && patch_slot(q) * PL < 36) {  // next chunk's patch: PL loads in each of the PLN steps behind a weight burst
-#pragma unroll
-                    for (int u = 0; u < PL; ++u)
-                        if (patch_slot(q) * PL + u < 36) {
-#ifdef P4_ABL_PATCHHOT
-                            issue(make_rsrc(reinterpret_cast<const char*>(p.in) + (blockIdx.x & 7) * (1 << 20)), 0, patch_slot(q) * PL + u);  // cache-resident
-#elif !defined(P4_ABL_NOPATCH)
-                            issue(r_stage, stage_off, patch_slot(q) * PL + u);
+#ifndef P4_ABL_NOPATCH
+                if constexpr (q >= HQ && q < HQ + 10) {  // halo of the next chunk's patch, two pixels per step
+                    issue(r_stage, stage_off, halo_r(2 * (q - HQ)), halo_q(2 * (q - HQ)));
+                    issue(r_stage, stage_off, halo_r(2 * (q - HQ) + 1), halo_q(2 * (q - HQ) + 1));
+                }
 #endif
-                        }
-                }
                 // the next chunk's patch landed: B^T d B (one 1-D pass per step) and the V writes into the OTHER buffer
+#ifndef P4_ABL_NOXF
                 if constexpr (q > TQ && q <= TQ + 6) pass_v(q - TQ - 1);
-                if constexpr (q > TQ + 6 && q <= TQ + 12) {
-                    pass_h(q - TQ - 7);
-                    write_row(wbuf, q - TQ - 7);
+                if constexpr (q > TQ + 6 && q <= TQ + 12) pass_h(q - TQ - 7);
+#endif
+#ifndef P4_ABL_NOVWRITE
+                if constexpr (q > TQ + 6 && q <= TQ + 12) write_row(wbuf, q - TQ - 7);
+#endif
+#ifndef P4_ABL_NOPATCH
+                if constexpr (q >= TQ + 9 && q <= TQ + 12) {  // row q - TQ - 8 was written a step ago: its registers take the interior of the chunk after next
+#pragma unroll
+                    for (int u = 1; u <= 4; ++u) issue(r_stage2, stage_off2, q - TQ - 8, u);
                 }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 const f32x4 av = wq[q % RING];
                 const f32x4 b0 = bb[q & 1][0], b1 = bb[q & 1][1];
                 mfma_step<AG, FIRST && xi != BIAS_XI>(acc[xi][0], acc[xi][1], av, b0, b1);
                 __builtin_amdgcn_sched_barrier(0);
             });
+#ifndef P4_ABL_NOBAR
             __syncthreads();  // everybody has read this chunk's V and written the next one's
+#endif
             vbuf ^= 1;
         };
         chunk(std::true_type{}, 0);
@@ -361,9 +416,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int dd = WD; dd < PRE; ++dd) wq[dd % RING] = buf_load(rw_nx, wlane, dd * 1024);
         load_bias(wnx);
+        P4_STAMP(15, 0);
         wait_mfma_results();
+#ifdef P4_ABL_NOOUT
+        if (acc[0][0][0] == 1.2345e-30f)
+#endif
         {
             const float floor_ = p.relu ? 0.f : -3.402823466e38f;
+            // the lane's place in a 1-KiB pixel-position row, recomputed per item from the hardware lane id: a value kept in a register across the
+            // chunk loop instead was spilled, and its scratch reload -- in the same in-order vmcnt queue as everything else -- drained the queue here
+            const int lane_o = fresh_lane();
+            const int m_o = lane_o & 15;
+            const unsigned olane = (unsigned)(m_o * 64 + (lane_o >> 4) * 16);  // lane (tile m, channel quad ks)
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb) {
                 const Blk bo = tb ? w.b1 : w.b0;
@@ -384,7 +448,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     T[2][b] = s1 + 4.f * s2;
                     T[3][b] = (d1 + 8.f * d2) + m5;
                 }
-                const int rem_y = p.Ho - by_abs * BLK - 4 * (m >> 2), rem_x = p.Wo - bx_abs * BLK - 4 * (m & 3);  // partial blocks: rows / columns of this lane's tile inside the image
+                const int rem_y = p.Ho - by_abs * BLK - 4 * (m_o >> 2), rem_x = p.Wo - bx_abs * BLK - 4 * (m_o & 3);  // partial blocks: rows / columns of this lane's tile inside the image
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const f32x4 s1 = T[i][1] + T[i][2], d1 = T[i][1] - T[i][2], s2 = T[i][3] + T[i][4], d2 = T[i][3] - T[i][4];
@@ -411,6 +475,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }
         }
+#ifdef P4_PROF
+        P4_STAMP(15, 1);
+        if (prof_on) {
+            __builtin_amdgcn_s_waitcnt(0);
+            P4_STAMP(15, 2);
+            __builtin_amdgcn_s_waitcnt(0);
+            for (int i = lane; i < 16 * 40; i += 64) p4_prof_buf[i] = reinterpret_cast<unsigned long long*>(lds + 2 * V_FLOATS)[i];
+        }
+#endif
         if (!more_items) break;
         item += ISTEP;
         w = wnx;
@@ -435,11 +508,15 @@ hipError_t cerb_launch_wino4p(ConvParams p, hipStream_t st) {
     auto kern = conv_wino4p_kernel;
     static bool attr_done[64] = {};
     if (cerb_attr_needed(attr_done)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + PROF_BYTES);
         if (e != hipSuccess) return e;
     }
     long long grid = 256;  // persistent: one workgroup per CU
     if (grid > items) grid = items;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS_BYTES, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS_BYTES + PROF_BYTES, st, p);
     return hipGetLastError();
 }
+
+#ifdef P4_PROF
+extern "C" int cerb_w4p_prof_read(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(p4_prof_buf), sizeof(unsigned long long) * 16 * 40); }
+#endif

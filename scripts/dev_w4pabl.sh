@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 IFS=';'
 for FL in ${CERB_VARIANTS:-""}; do
   unset IFS
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=1000000 $FL -c cerberus_amd/csrc/conv_wino4p.hip -o cerberus_amd/csrc/conv_wino4p.o || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=1000000 $FL -c cerberus_amd/csrc/conv_wino4p.hip -o cerberus_amd/csrc/conv_wino4p.o 2>/tmp/cc.err || { echo "=== flags: [$FL] DOES NOT COMPILE"; IFS=";"; continue; }
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o cerberus_amd/libcerberus_hip.so cerberus_amd/csrc/*.o || exit 1
   echo "=== flags: [$FL]"
   timeout 120 python bench.py --mode batch --steps 20 --warmup 3 --no-cpu-baseline > /tmp/w4pabl.json 2>/tmp/w4pabl.err || { tail -5 /tmp/w4pabl.err; IFS=';'; continue; }
