@@ -258,7 +258,7 @@ def _uuid4_hex(n):
     return [hx[i:i + 32] for i in range(0, 32 * n, 32)]
 
 
-def build_wsi_inst_info(inst, canv, slide_hw, proc_mag, ds_factor=0.5, region_records=None, base_mag=None, base_hw=None):
+def build_wsi_inst_info(inst, canv, slide_hw, proc_mag, ds_factor=0.5, region_records=None, base_mag=None, base_hw=None, prebuilt=None):
     """The dictionary the reference dumps as dat/<slide>.dat (infer/wsi.py:805-853): per tissue {uuid4 hex -> {'box':
     [x1, y1, x2, y2], 'centroid', 'contour', 'type', 'type_prob'}} plus resolution metadata.  Gland / lumen label maps are
     at x`ds_factor` and their coordinates are scaled back (get_inst_info_dict(..., ds_factor)); nuclei are at full
@@ -266,7 +266,8 @@ def build_wsi_inst_info(inst, canv, slide_hw, proc_mag, ds_factor=0.5, region_re
     Deviation: the class map handed to the half-resolution tissues is the strided sub-sample of the uint8 class canvas; the
     reference bilinearly resizes class ids together with the probabilities (cv2.resize, infer/wsi.py:786-788).
     region_records: cerberus_amd.tissue.postprocess_regions(...) when the slide has a tissue mask -- the gland / lumen entries then
-    come from the per-region dictionaries (already in slide coordinates) and `inst` only supplies the nuclei."""
+    come from the per-region dictionaries (already in slide coordinates) and `inst` only supplies the nuclei.
+    prebuilt: {tissue: ready dictionary} that replaces the entry computed from `inst[tissue]` (`--reference_tiling`)."""
     import uuid
 
     from .postproc import get_inst_info_dict
@@ -278,8 +279,10 @@ def build_wsi_inst_info(inst, canv, slide_hw, proc_mag, ds_factor=0.5, region_re
                 dst = out.setdefault(tissue, OrderedDict())
                 for v in d.values():
                     dst[uuid.uuid4().hex] = v
+    for tissue, d in (prebuilt or {}).items():  # dictionaries made elsewhere (cerberus_amd/ref_tiling.py: the reference's tiled nuclei)
+        out[tissue] = d
     for tissue, lab in inst.items():
-        if region_records is not None and tissue != "Nuclei":
+        if (region_records is not None and tissue != "Nuclei") or (prebuilt and tissue in prebuilt):
             continue
         tkey = tissue + "-TYPE"
         half = tuple(lab.shape) != tuple(int(v) for v in slide_hw)

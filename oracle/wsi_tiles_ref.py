@@ -83,15 +83,16 @@ def _inst_boxes(lab):
     return out
 
 
-def process_tile(inst_canvas, tile_bounds, tile_flag, tile_mode, ref_boxes, margin):
-    """infer/wsi.py:81-268.  ref_boxes: {uid: box} accumulated so far.  -> (new {local key: slide box}, [uids to remove from ref_boxes])"""
+def process_tile(inst_canvas, tile_bounds, tile_flag, tile_mode, ref_boxes, margin, labeller=None):
+    """infer/wsi.py:81-268.  ref_boxes: {uid: box} accumulated so far.  -> (new {local key: slide box}, [uids to remove from ref_boxes]).
+    labeller(crop [h, w, 2]) -> label map: the C oracle by default; the GPU tests pass the HIP kernel here."""
     H, W = inst_canvas.shape[:2]
     tl, br = np.array(tile_bounds[:2]), np.array(tile_bounds[2:])
     w, h = (br - tl).tolist()
     crop = inst_canvas[max(tl[1], 0):br[1], max(tl[0], 0):br[0]]
     if crop.size == 0:
         return {}, []
-    lab = pr.proc(np.ascontiguousarray(crop), "Nuclei").astype(np.int64)
+    lab = (labeller(np.ascontiguousarray(crop)) if labeller is not None else pr.proc(np.ascontiguousarray(crop), "Nuclei")).astype(np.int64)
     boxes = _inst_boxes(lab)
     if not boxes:
         return {}, []
@@ -125,14 +126,14 @@ def process_tile(inst_canvas, tile_bounds, tile_flag, tile_mode, ref_boxes, marg
     return new, remove_in_orig
 
 
-def reference_tiled_nuclei(inst_canvas, tile_shape=4096, margin=64, patch_output_shape=144):
+def reference_tiled_nuclei(inst_canvas, tile_shape=4096, margin=64, patch_output_shape=144, labeller=None):
     """The whole nuclei loop of infer/wsi.py:642-682 on one (H, W, 2) probability canvas -> sorted list of kept instance boxes."""
     H, W = inst_canvas.shape[:2]
     acc, uid = {}, 0
     for mode, (bounds, flags) in enumerate(get_tile_info((W, H), [tile_shape, tile_shape], margin, [patch_output_shape, patch_output_shape])):
         results = []
         for tb, tf in zip(bounds, flags):  # all tiles of a set see the dictionary as it was BEFORE the set (futures are merged after)
-            results.append(process_tile(inst_canvas, tb, tf, mode, acc, margin))
+            results.append(process_tile(inst_canvas, tb, tf, mode, acc, margin, labeller))
         for new, rem in results:
             for b in new.values():
                 acc[uid] = b

@@ -75,6 +75,8 @@ def main(argv=None):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     out_dir = args["--output_dir"]
     os.makedirs(out_dir, exist_ok=True)
+    if args["--reference_tiling"] and world > 1:
+        raise SystemExit("--reference_tiling walks the whole slide's canvases on one GPU (the reference's tile sets cross band borders): run it without torch.distributed.run")
 
     checkpoint, decoders, model_args = None, dict(DEFAULT_REQ_TARGET_CODE), default_model_kwargs()
     if args["--model"]:
@@ -175,8 +177,18 @@ def main(argv=None):
         os.makedirs(os.path.dirname(dat_path), exist_ok=True)
         nuc_only = {k: v for k, v in inst.items() if k == "Nuclei"} if records is not None else inst
         bw, bh = reader.info.slide_dimensions
+        prebuilt = None
+        ref_src = maps if "Nuclei-INST" in maps else run.canv  # (a slide above ONE_CALL_PX leaves only the class maps in `maps`: the canvases are the runner's)
+        if args["--reference_tiling"] and "Nuclei-INST" in ref_src:
+            # the reference's own tile sets and margin rules (infer/wsi.py:81-268, 642-684) over the stitched canvases, each tile labelled on
+            # the GPU with skimage's tie order: its instance set exactly, seam losses included
+            from cerberus_amd.ref_tiling import reference_tiled_nuclei
+
+            tmap = ref_src.get("Nuclei-TYPE")
+            prebuilt = {"Nuclei": reference_tiled_nuclei(ref_src["Nuclei-INST"][:H, :W], None if tmap is None else tmap[:H, :W], tile_shape=4096, margin=64,
+                                                         patch_output_shape=out)}
         info = build_wsi_inst_info(nuc_only, maps, (H, W), float(args["--wsi_proc_mag"]), region_records=records,
-                                   base_mag=None if reader.info.mpp is None else float(reader.info.mpp[0]), base_hw=(bh, bw))
+                                   base_mag=None if reader.info.mpp is None else float(reader.info.mpp[0]), base_hw=(bh, bw), prebuilt=prebuilt)
         # serialising ~1e6 per-instance dictionaries is host-only work: it overlaps the next slide's inference (written to a temporary
         # name and renamed, so a finished dat/<slide>.dat is always complete -- the resume-by-skip above relies on that)
         if writer is not None:

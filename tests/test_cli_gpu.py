@@ -74,6 +74,32 @@ def test_run_infer_wsi_cli_synthetic(tmp_path):
             assert len(uid) == 32 and d["box"].shape == (4,) and d["contour"].ndim == 2 and d["contour"].shape[1] == 2 and (("type" in d) == (t != "Lumen"))
 
 
+def test_run_infer_wsi_cli_reference_tiling(tmp_path):
+    """`--reference_tiling`: the nuclei dictionary comes from the reference's tile sets and margin rules (cerberus_amd/ref_tiling.py) instead of
+    band ownership.  A 700 x 900 slide fits one 4032-pixel tile, where the scheme has no seam: the dictionary must then hold exactly the
+    instances of the default run (same boxes, types and contours), under fresh uuids; gland / lumen entries are untouched."""
+    import joblib
+
+    spec = tmp_path / "slides"
+    spec.mkdir()
+    (spec / "s1.txt").write_text("synthetic:700x900:5")
+    base = [sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--synthetic", "--input_dir=%s" % spec, "--wsi_file_ext=.txt", "--batch_size=6",
+            "--patch_input_shape=448", "--patch_output_shape=144"]
+    outs = []
+    for tag, extra in (("a", []), ("b", ["--reference_tiling"])):
+        out = tmp_path / tag
+        r = subprocess.run(base + ["--output_dir=%s" % out] + extra, capture_output=True, text=True, timeout=300, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(joblib.load(str(out / "dat" / "s1.dat")))
+    a, b = outs
+
+    def key(d):
+        return (tuple(int(v) for v in d["box"]), int(d.get("type", -1)), tuple(np.asarray(d["contour"]).ravel().tolist()))
+
+    assert sorted(key(d) for d in a["Nuclei"].values()) == sorted(key(d) for d in b["Nuclei"].values())
+    assert len(a["Gland"]) == len(b["Gland"]) and len(a["Lumen"]) == len(b["Lumen"])
+
+
 def test_run_infer_wsi_cli_with_tissue_mask(tmp_path):
     """--msk_dir: slides without a mask are skipped, patches without tissue never run (their canvas pixels stay 0), the tissue
     map and the dictionary are written (infer/wsi.py:533-569, 688-853)."""

@@ -356,3 +356,18 @@ def test_steplr_follows_torch():
         tsch.step()
         sch.step()
         assert abs(sch.get_last_lr()[0] - tsch.get_last_lr()[0]) <= 1e-12 * tsch.get_last_lr()[0] + 1e-18
+
+
+def test_reference_tile_sets_product_vs_oracle():
+    """cerberus_amd/ref_tiling.py::get_tile_info (the tile sets behind `--reference_tiling`: grid, vertical / horizontal strips, cross
+    sections with their removal flags) against the oracle's restatement of tiatoolbox's `_get_tile_info`, incl. slides that fit one tile,
+    non-square tiles and tile shapes that are not multiples of the output patch."""
+    from cerberus_amd import ref_tiling as rt
+    from oracle import wsi_tiles_ref as wt
+
+    for wh, tile, m, pos in [((1000, 700), [256, 256], 32, [16, 16]), ((9000, 8200), [4096, 4096], 64, [144, 144]), ((200, 100), [256, 256], 32, [16, 16]),
+                             ((40000, 40000), [4096, 4096], 64, [144, 144]), ((513, 1025), [256, 300], 16, [16, 20]), ((4096, 4097), [4096, 4096], 64, [144, 144])]:
+        a, b = rt.get_tile_info(wh, tile, m, pos), wt.get_tile_info(wh, tile, m, pos)
+        assert len(a) == len(b)
+        for (ba, fa), (bb, fb) in zip(a, b):
+            assert np.array_equal(ba, bb) and np.array_equal(fa, fb), (wh, tile)

@@ -338,3 +338,74 @@ def test_slide_scale_map_invariants_and_tiling_consistency():
     assert inner.sum() > 100000 and np.array_equal(a > 0, b > 0)
     pairs = np.unique(np.stack([a[a > 0], b[a > 0]], axis=1), axis=0)
     assert len(np.unique(pairs[:, 0])) == len(pairs) == len(np.unique(pairs[:, 1]))  # a bijection between the two labellings
+
+
+# ---- W2: the reference's tiled nuclei post-processing (infer/wsi.py:81-268, 642-684) on the GPU ------------------------------------------
+@pytest.mark.parametrize("seed,dens,hw,tile,margin", [(5, 300.0, (700, 900), 256, 32), (6, 600.0, (640, 1000), 320, 32), (7, 150.0, (1100, 1300), 512, 64)])
+def test_reference_tiling_on_device_equals_the_oracle_scheme(seed, dens, hw, tile, margin):
+    """cerberus_amd/ref_tiling.py (`run_infer_wsi.py --reference_tiling`: the reference's four tile sets and margin rules, every tile labelled
+    by cerb_postproc_nuclei, boxes from cerb_inst_table) against oracle/wsi_tiles_ref.py (the same scheme restated on the CPU with the C
+    oracle as the labeller), scaled down so that a small map has many seams:
+      (i)   the oracle's scheme run with the HIP kernel as its per-tile labeller keeps exactly the instances it keeps with the C oracle;
+      (ii)  the product module returns exactly that instance set (boxes in slide coordinates), none twice;
+      (iii) every one of them is an instance of the band scheme's result (sharded_postprocess == the whole-map labelling) with the identical
+            box -- the reference's set is a subset; what it loses lies within one margin of an inner tile edge."""
+    # (instances are identified by their boxes; get_inst_info_dict drops contours of fewer than 3 points like the reference does, which a
+    # nucleus of >= 10 pixels -- remove_small_objects, loader/postproc.py:355 -- only has as a 1-pixel-wide line: none in these maps)
+    from cerberus_amd import ref_tiling as rt
+    from oracle import wsi_tiles_ref as wt
+
+    m = synth.nuclei_maps(hw[0], hw[1], seed, dens, noise=0.02)
+    dev = torch.from_numpy(m).cuda()
+
+    def hip_labeller(crop):
+        return postproc_device(torch.from_numpy(crop).cuda(), "Nuclei")[0].cpu().numpy()
+
+    ref_c = wt.reference_tiled_nuclei(m, tile_shape=tile, margin=margin, patch_output_shape=16)
+    ref_hip = wt.reference_tiled_nuclei(m, tile_shape=tile, margin=margin, patch_output_shape=16, labeller=hip_labeller)
+    assert ref_hip == ref_c and len(ref_c) > 100                                                              # (i)
+    got = rt.reference_tiled_nuclei(dev, None, tile_shape=tile, margin=margin, patch_output_shape=16)
+    boxes = sorted(tuple(int(v) for v in d["box"]) for d in got.values())
+    assert boxes == ref_c and len(set(boxes)) == len(boxes)                                                   # (ii)
+    for d in list(got.values())[:50]:  # dictionaries are in slide coordinates: the centroid lies inside its box, the contour on / inside it
+        x0, y0, x1, y1 = [int(v) for v in d["box"]]
+        assert x0 <= d["centroid"][0] < x1 and y0 <= d["centroid"][1] < y1
+        c = np.asarray(d["contour"])
+        assert c[:, 0].min() >= x0 and c[:, 0].max() < x1 and c[:, 1].min() >= y0 and c[:, 1].max() < y1
+    lab, _ = postproc_device(dev, "Nuclei", exact_ties=False)  # the whole-map labelling == the band scheme (test_sharded_postproc_equals_whole_map)
+    whole = set(tuple(int(v) for v in b) for b in wt._inst_boxes(lab.cpu().numpy().astype(np.int64)).values())
+    lost = whole - set(boxes)
+    assert not (set(boxes) - whole) and len(lost) <= 0.05 * len(whole), (len(lost), len(whole))              # (iii)
+    for x0, y0, x1, y1 in lost:
+        near_x = min(abs(e - k * tile) for k in range(1, hw[1] // tile + 1) for e in (x0, x1))
+        near_y = min(abs(e - k * tile) for k in range(1, hw[0] // tile + 1) for e in (y0, y1))
+        assert min(near_x, near_y) <= margin, (x0, y0, x1, y1)
+
+
+def test_reference_tiling_at_the_reference_geometry_loss_rate():
+    """4096-pixel tiles, 64-pixel margins (infer/wsi.py:299-302) on a 9000 x 8600 structured map (a 3 x 3 tile grid with every strip / cross
+    section kind): the reference's scheme on the GPU keeps a subset of the band scheme's instances with identical boxes and loses well
+    under 1 % of them (printed: the number DESIGN.md quotes), all within one margin of an inner tile edge."""
+    from cerberus_amd import ref_tiling as rt
+    from cerberus_amd.postproc import inst_table_device
+
+    H, W, tile, margin = 8600, 9000, 4096, 64
+    eff = (tile // 144) * 144  # tiles hold whole output patches: 28 x 144 = 4032 pixels (infer/wsi.py:299-302 through _get_tile_info)
+    t = torch.from_numpy(synth.nuclei_maps(2048, 2048, 31, 600.0, noise=0.02)).cuda()
+    dev = t.repeat(-(-H // 2048), -(-W // 2048), 1)[:H, :W].contiguous()
+    got = rt.reference_tiled_nuclei(dev, None, tile_shape=tile, margin=margin, patch_output_shape=144)
+    boxes = [tuple(int(v) for v in d["box"]) for d in got.values()]
+    assert len(set(boxes)) == len(boxes)
+    lab, _ = postproc_device(dev, "Nuclei", exact_ties=False)  # == the band scheme's result
+    tab = inst_table_device(lab).cpu().numpy()
+    tab = tab[tab[:, 0] > 0]
+    whole = set((int(r[5]), int(r[3]), int(r[6]), int(r[4])) for r in tab)  # cerb_inst_table: rows 3..6 = y1, y2, x1, x2 -> (x1, y1, x2, y2)
+    lost = whole - set(boxes)
+    assert not (set(boxes) - whole)
+    rate = len(lost) / max(1, len(whole))
+    print("reference tiling 4096 / 64 on %d x %d: %d of %d band-scheme instances lost (%.3f %%)" % (H, W, len(lost), len(whole), 100.0 * rate))
+    assert len(whole) > 40000 and rate < 0.01
+    for x0, y0, x1, y1 in lost:
+        near_x = min(abs(e - k * eff) for k in (1, 2) for e in (x0, x1))
+        near_y = min(abs(e - k * eff) for k in (1, 2) for e in (y0, y1))
+        assert min(near_x, near_y) <= margin, (x0, y0, x1, y1)
