@@ -159,6 +159,9 @@ def test_bench_contract_single_and_two_ranks(tmp_path):
     one = _bench([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--slide", "3072"])
     for k in CONTRACT_KEYS:
         assert k in one, k
+    ts = one["train_step"]  # BASELINE configs[4] rides along in the default line: batch 16 x 448^2, three timed steps
+    assert "error" not in ts and ts["ms_per_step"] > 0 and abs(ts["tiles_s"] - 16 / (ts["ms_per_step"] * 1e-3)) / ts["tiles_s"] < 0.01, ts
+    assert ts["roofline"]["kernel"].startswith("wgrad") and 0.3 < ts["roofline"]["frac"] <= 1.0
     assert one["n_gpus"] == 1 and one["steps"] == 3 and one["unit"] == "Mpx/s" and one["scaling"] == "strong" and one["vs_baseline"] is None
     assert one["config"]["slide"] == [3072, 3072] and one["config"]["tiles"] == 144
     rf = one["roofline"]
@@ -182,12 +185,40 @@ def test_bench_contract_single_and_two_ranks(tmp_path):
     assert two["multi_gpu"]["halo_exchange"]["bytes_into_rank0"] > 0 and two["multi_gpu"]["root_gather"]["bytes_into_rank0"] > 0
 
 
+def test_bench_contract_eight_ranks_time_sharing_one_gpu():
+    """The driver's 8-GPU launch line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py --gpus 8`) with the
+    host-staged gloo backend, all eight ranks on this box's single GPU: one 8192^2 slide sharded into eight bands of four patch rows,
+    band-local labelling with halo exchange, two all-gathers for the slide-global ids, label / class-map gather onto rank 0.  The eight-rank
+    job must find exactly the instances one rank finds, with no instance cut by a band window (n_truncated == 0): the only evidence for
+    BASELINE.json configs[3] this pool can give until a multi-GPU node runs it over RCCL."""
+    env8 = dict(os.environ, MASTER_ADDR="127.0.0.1", CERB_WSI_BATCH="16")  # eight handles share one GPU's HBM: small batches
+    import json
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env8)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+
+    one = run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-train-leg", "--slide", "8192"])
+    eight = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29541",
+                 "bench.py", "--gpus", "8", "--steps", "4", "--warmup", "1", "--backend", "gloo", "--slide", "8192"])
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "strong" and eight["config"]["tiles"] == 1024 and "cpu_baseline" not in eight and "train_step" not in eight
+    assert abs(eight["value"] - 8192 * 8192 / (eight["ms_per_step"] * 1e-3 * 4) / 1e6) / eight["value"] < 0.01
+    for t in ("Nuclei", "Gland", "Lumen"):
+        assert eight["postproc"][t]["n_inst"] == one["postproc"][t]["n_inst"] > 10, (t, one["postproc"][t], eight["postproc"][t])
+        assert eight["postproc"][t]["n_truncated"] == 0 and eight["postproc"][t]["n_unresolved"] == 0, eight["postproc"][t]
+    mg = eight["multi_gpu"]
+    assert mg["halo_exchange"]["bytes_into_rank0"] > 0 and mg["root_gather"]["bytes_into_rank0"] > 0
+
+
 def test_bench_nccl_branch_at_world_one():
     """The RCCL code path on the hardware there is: `init_process_group("nccl", device_id=...)`, the warm-up gather, run_distributed's
     all-gathers and the label / class-map gathers on CUDA tensors all execute with ONE rank (RCCL accepts a single-rank communicator),
     and the result equals the plain single-process run."""
-    ref = _bench([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--slide", "2048"])
-    one = _bench([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--slide", "2048", "--force-dist", "--backend", "nccl"])
+    ref = _bench([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-train-leg", "--slide", "2048"])
+    one = _bench([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-train-leg", "--slide", "2048", "--force-dist", "--backend", "nccl"])
     assert one["n_gpus"] == 1 and one["multi_gpu"] is not None and "root_gather" in one["multi_gpu"]
     for t in ("Nuclei", "Gland", "Lumen"):
         assert one["postproc"][t]["n_inst"] == ref["postproc"][t]["n_inst"]

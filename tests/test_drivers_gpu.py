@@ -228,3 +228,87 @@ def test_sharded_postproc_on_device_with_staged_collectives(world, tissue):
     n_ref = int(ref.max())
     assert n_ref > 20 and got[0][2] == n_ref and lab.shape == ref.shape
     assert same_partition(ref, lab)
+
+
+def _gpu_gather_worker(rank, world, port, ret):
+    import os
+
+    import torch.distributed as dist
+
+    from cerberus_amd.hostdist import HostStagedDist
+    from cerberus_amd.wsi import SlideGeometry, gather_bands
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hd = HostStagedDist(dist)
+    geo = SlideGeometry((1000, 640), 256, 128)  # 8 patch rows of 128 px, the last one ragged (1000 = 7 * 128 + 104)
+    b = geo.bounds(world)
+    rows = (b[rank + 1] - b[rank]) * geo.out
+    g = torch.Generator().manual_seed(77)
+    full_inst = torch.rand((geo.rows * geo.out, geo.cols * geo.out, 2), generator=g)
+    full_type = torch.randint(0, 7, (geo.rows * geo.out, geo.cols * geo.out), generator=g, dtype=torch.uint8)
+    y0 = b[rank] * geo.out
+    canv = {"Nuclei-INST": full_inst[y0:y0 + rows].cuda(), "Nuclei-TYPE": full_type[y0:y0 + rows].cuda()}
+    # the halo exchange of shard_postproc.run_distributed, spelled out: 64 rows to each neighbour, received into CUDA buffers
+    up, down = canv["Nuclei-INST"][:64].contiguous(), canv["Nuclei-INST"][-64:].contiguous()
+    above = torch.empty_like(up) if rank > 0 else None
+    below = torch.empty_like(down) if rank < world - 1 else None
+    ops = []
+    if rank > 0:
+        ops += [hd.P2POp(hd.isend, up, rank - 1), hd.P2POp(hd.irecv, above, rank - 1)]
+    if rank < world - 1:
+        ops += [hd.P2POp(hd.isend, down, rank + 1), hd.P2POp(hd.irecv, below, rank + 1)]
+    for req in hd.batch_isend_irecv(ops):
+        req.wait()
+    halo_ok = True
+    if above is not None:
+        halo_ok &= bool(torch.equal(above.cpu(), full_inst[y0 - 64:y0]))
+    if below is not None:
+        halo_ok &= bool(torch.equal(below.cpu(), full_inst[y0 + rows:y0 + rows + 64]))
+    full = gather_bands(canv, geo, rank, world, hd)
+    ok = None
+    if rank == 0:
+        ok = bool(full["Nuclei-INST"].is_cuda and torch.equal(full["Nuclei-INST"].cpu(), full_inst[:1000, :640]) and
+                  torch.equal(full["Nuclei-TYPE"].cpu(), full_type[:1000, :640]))
+    ret.put((rank, halo_ok, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_bands_and_halo_exchange_of_cuda_tensors_through_hostdist(world):
+    """wsi.gather_bands (one dist.gather per head, bands padded to the tallest, ragged last patch row cropped on the root) and the
+    batched send / recv of the band halos, with CUDA tensors on both sides, through cerberus_amd.hostdist -- the calls "nccl" (RCCL over
+    xGMI) moves device to device on a multi-GPU node; here the ranks share this box's GPU and the bytes are staged through the host."""
+    import queue
+    import socket
+    import time
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_gather_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, t_end = [], time.time() + 300
+    while len(got) < world:
+        try:
+            got.append(ret.get(timeout=2))
+        except queue.Empty:
+            if [p.exitcode for p in procs if p.exitcode not in (None, 0)] or time.time() > t_end:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise AssertionError("a rank died or timed out: exit codes %s" % [p.exitcode for p in procs])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    assert all(g[1] for g in got), got
+    assert got[0][2] is True
