@@ -35,6 +35,35 @@ class SlideInfo(object):
         self.level_count = len(self.level_dimensions)
 
 
+def _resample_axis(src, axis, o0, o1, rel, s0, size):
+    """Output pixels o0 .. o1-1 of a global resampling grid along `axis`: src holds the source pixels s0 .. s0 + n - 1 of a level that is
+    `size` pixels long.  rel >= 1: area mean over [o * rel, (o + 1) * rel) clipped to the level (fractional end pixels weighted by their overlap);
+    rel < 1: linear interpolation at (o + 0.5) * rel - 0.5 with edge replication."""
+    src = np.moveaxis(src, axis, 0)
+    n = src.shape[0]
+    o = np.arange(o0, o1, dtype=np.float64)
+    out = np.zeros((len(o),) + src.shape[1:], np.float32)
+    if rel >= 1:
+        lo, hi = o * rel, np.minimum((o + 1) * rel, float(size))
+        first = np.floor(lo).astype(np.int64)
+        wsum = np.zeros(len(o), np.float64)
+        for t in range(int(np.ceil(rel)) + 1):
+            idx = first + t
+            wgt = np.clip(np.minimum(hi, idx + 1.0) - np.maximum(lo, idx.astype(np.float64)), 0.0, 1.0)
+            ok = (idx - s0 >= 0) & (idx - s0 < n)
+            wgt = np.where(ok, wgt, 0.0)
+            out += src[np.clip(idx - s0, 0, n - 1)] * wgt.astype(np.float32).reshape((-1,) + (1,) * (src.ndim - 1))
+            wsum += wgt
+        out /= np.maximum(wsum, 1e-12).astype(np.float32).reshape((-1,) + (1,) * (src.ndim - 1))
+    else:
+        c = np.clip((o + 0.5) * rel - 0.5, 0.0, size - 1.0)
+        i0 = np.floor(c).astype(np.int64)
+        i1 = np.minimum(i0 + 1, size - 1)
+        f = (c - i0).astype(np.float32).reshape((-1,) + (1,) * (src.ndim - 1))
+        out = src[np.clip(i0 - s0, 0, n - 1)] * (1.0 - f) + src[np.clip(i1 - s0, 0, n - 1)] * f
+    return np.moveaxis(out, 0, axis)
+
+
 class _Rows(object):
     """(H, W, 3) row source: rows[a:b] -> uint8 [b - a, W, 3] at the reader's requested resolution."""
 
@@ -123,12 +152,16 @@ class WSIReader(object):
             if src.shape[1] < ww * k:
                 pad[:, src.shape[1]:] = pad[:, src.shape[1] - 1: src.shape[1]]
             return np.clip(np.rint(pad.reshape(hh, k, ww, k, 3).mean(axis=(1, 3))), 0, 255).astype(np.uint8)
-        from PIL import Image
-
-        sx0, sy0 = int(np.floor(x0 * rel)), int(np.floor(y0 * rel))
-        sx1, sy1 = min(int(np.ceil(x1 * rel)), lw), min(int(np.ceil(y1 * rel)), lh)
-        src = Image.fromarray(self._read_level(lvl, sx0, sy0, sx1, sy1))
-        return np.array(src.resize((x1 - x0, y1 - y0), Image.BOX if rel >= 1 else Image.BILINEAR))
+        # non-integer factor: resample on ONE global grid -- output pixel o covers the source interval [o * rel, (o + 1) * rel) of the level (exact
+        # area means; bilinear at (o + 0.5) * rel - 0.5 when enlarging) -- so that the pixels do not depend on how a caller cuts the slide into row
+        # chunks or rank bands (a per-window resize would shift scale and phase with every window)
+        pad = 1 if rel < 1 else 0
+        sx0, sy0 = max(int(np.floor(x0 * rel)) - pad, 0), max(int(np.floor(y0 * rel)) - pad, 0)
+        sx1, sy1 = min(int(np.ceil(x1 * rel)) + pad, lw), min(int(np.ceil(y1 * rel)) + pad, lh)
+        src = self._read_level(lvl, sx0, sy0, sx1, sy1).astype(np.float32)
+        tmp = _resample_axis(src, 0, y0, y1, rel, sy0, lh)
+        out = _resample_axis(tmp, 1, x0, x1, rel, sx0, lw)
+        return np.clip(np.rint(out), 0, 255).astype(np.uint8)
 
     def _read_level(self, level, x0, y0, x1, y1):
         raise NotImplementedError
@@ -281,10 +314,12 @@ class TiffReader(WSIReader):
 
             if p.jpeg_tables:  # abbreviated streams: tables (minus EOI) + tile (minus SOI)
                 data = p.jpeg_tables[:-2] + data[2:]
-            im = Image.open(io.BytesIO(data))
-            if p.photometric == 2 and im.mode == "YCbCr":
-                im.draft("RGB", im.size)
-            arr = np.array(im.convert("RGB"))
+            if p.photometric == 2:
+                # PhotometricInterpretation = RGB (most Aperio .svs): the components ARE R, G, B, but the stream carries neither a JFIF nor
+                # an Adobe marker, and libjpeg then guesses YCbCr for component ids 1, 2, 3 and converts.  An Adobe APP14 segment with
+                # transform = 0 right behind SOI states "no colour transform" (libjpeg honours it before any guess).
+                data = data[:2] + b"\xff\xee\x00\x0eAdobe\x00\x64\x00\x00\x00\x00\x00" + data[2:]
+            arr = np.array(Image.open(io.BytesIO(data)).convert("RGB"))
             return arr[:rows, :cols]
         elif c in (33003, 33005):
             raise NotImplementedError("%s: JPEG 2000 tiles (Aperio compression %d) need a JP2K decoder that is not in this image" % (self.path, c))
@@ -372,9 +407,10 @@ def _packbits_decode(data, expected):
     return bytes(out[:expected])
 
 
-def write_tiled_tiff(path, levels, tile=256, mpp=None, compress=True, description=None):
+def write_tiled_tiff(path, levels, tile=256, mpp=None, compress=True, description=None, encode=None):
     """Minimal pyramidal tiled TIFF writer (deflate or raw tiles) -- for tests and for converting arrays; levels[0] is full
-    resolution, the others are reduced pages (NewSubfileType 1)."""
+    resolution, the others are reduced pages (NewSubfileType 1).  encode = (function tile [t, t, 3] uint8 -> bytes, TIFF compression
+    code) replaces the built-in tile encoders (the tests write Aperio-style JPEG tiles through it)."""
     bo = "<"
     with open(path, "wb") as fh:
         fh.write(b"II" + struct.pack(bo + "HI", 42, 0))
@@ -388,7 +424,7 @@ def write_tiled_tiff(path, levels, tile=256, mpp=None, compress=True, descriptio
                     t = np.zeros((tile, tile, 3), np.uint8)
                     blk = img[ty * tile:(ty + 1) * tile, tx * tile:(tx + 1) * tile]
                     t[: blk.shape[0], : blk.shape[1]] = blk
-                    data = zlib.compress(t.tobytes(), 6) if compress else t.tobytes()
+                    data = encode[0](t) if encode else zlib.compress(t.tobytes(), 6) if compress else t.tobytes()
                     offs.append(fh.tell())
                     cnts.append(len(data))
                     fh.write(data)
@@ -403,7 +439,7 @@ def write_tiled_tiff(path, levels, tile=256, mpp=None, compress=True, descriptio
             put(256, 4, [w])
             put(257, 4, [h])
             put(258, 3, [8, 8, 8])
-            put(259, 3, [8 if compress else 1])
+            put(259, 3, [encode[1] if encode else 8 if compress else 1])
             put(262, 3, [2])
             if description and li == 0:
                 put(270, 2, description.encode("latin1") + b"\0")

@@ -252,12 +252,20 @@ def same_partition(a, b):
     return len(np.unique(pairs[:, 0])) == len(pairs) and len(np.unique(pairs[:, 1])) == len(pairs)
 
 
-def local_band_count(rows, cols, max_band_px):
-    """How many row bands a (rows x cols) canvas is labelled in on ONE GPU so that no labelling call exceeds max_band_px pixels
-    (workspace = 96 B / px, and H*W < 2^31 per call): 1 when it fits."""
+def local_band_count(rows, cols, max_band_px, margin=0):
+    """How many row bands a (rows x cols) canvas is labelled in on ONE GPU so that no labelling CALL exceeds max_band_px pixels (workspace =
+    96 B / px, and H*W < 2^31 per call): 1 when it fits.  A local band is labelled together with `margin` halo rows on each side, so the
+    rows it may own are max_band_px / cols - 2 * margin; every band is at least two margins tall (an instance crossing a cut must end inside
+    the neighbour's halo).  A canvas so wide that even such a band exceeds the limit cannot be banded by rows: that is an error here, not a
+    failure inside the C call."""
     if not max_band_px or rows * cols <= max_band_px:
         return 1
-    return int(-(-rows * cols // int(max_band_px)))
+    own = int(max_band_px) // max(1, cols) - 2 * int(margin)
+    if own < max(1, 2 * int(margin)):
+        raise ValueError("a %d-pixel-wide map cannot be labelled in row bands of at most %d pixels with a %d-row halo on each side: a band of two "
+                         "margins plus its halos already has %d pixels (raise max_band_px or lower the margin)"
+                         % (cols, int(max_band_px), int(margin), 4 * int(margin) * cols))
+    return int(-(-rows // own))
 
 
 def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guard=48, max_band_px=None, prof=None):
@@ -292,8 +300,7 @@ def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guar
             inst[t], _, info[t] = run_distributed(band, yy, t, m, g, dist, ds, prof=prof)
         else:
             t0 = _tock(prof)
-            nb = local_band_count(int(band.shape[0]), int(band.shape[1]), max_band_px)
-            nb = max(1, min(nb, int(band.shape[0]) // max(1, 2 * m)))  # every local band at least two margins tall
+            nb = local_band_count(int(band.shape[0]), int(band.shape[1]), max_band_px, m)  # (half-resolution maps: their own pixel count, halved margin)
             cuts = [int(round(i * band.shape[0] / nb)) for i in range(nb + 1)]
             outs, n, infos = run_local([band[cuts[i]:cuts[i + 1]] for i in range(nb)], t, m, g, ds)
             inst[t] = outs[0] if nb == 1 else assemble(outs)

@@ -371,3 +371,18 @@ def test_reference_tile_sets_product_vs_oracle():
         assert len(a) == len(b)
         for (ba, fa), (bb, fb) in zip(a, b):
             assert np.array_equal(ba, bb) and np.array_equal(fa, fb), (wh, tile)
+
+
+def test_local_band_count_accounts_for_the_halo_rows():
+    """One labelling call sees a local band PLUS a margin of halo rows on each side: the band count is sized from max_band_px / cols - 2 margin
+    rows per band, and a map too wide for even a two-margin band raises instead of failing inside the C call."""
+    from cerberus_amd.shard_postproc import local_band_count
+
+    assert local_band_count(1000, 1000, None) == 1 and local_band_count(1000, 1000, 2_000_000, 64) == 1
+    nb = local_band_count(40000, 40000, 220_000_000, 128)
+    rows = -(-40000 // nb)
+    assert (rows + 2 * 128) * 40000 <= 220_000_000 and nb == 8
+    nb = local_band_count(3000, 100000, 120_000_000, 128)  # wide and short: 1200 rows per call, 256 of them halo
+    assert (-(-3000 // nb) + 256) * 100000 <= 120_000_000
+    with pytest.raises(ValueError):
+        local_band_count(3000, 100000, 40_000_000, 128)  # 400 rows per call cannot hold a 256-row band with its two 128-row halos

@@ -88,3 +88,58 @@ def test_array_and_synthetic_specs(tmp_path):
     assert r3.info.slide_dimensions == (1100, 1500) and r3.seed == 9
     with pytest.raises(ValueError):
         r.slide_dimensions(20, "power")
+
+
+def test_jpeg_tiles_with_rgb_photometric_and_plain_component_ids(tmp_path):
+    """Aperio-style JPEG tiles: PhotometricInterpretation = RGB, component ids 1, 2, 3, no JFIF / Adobe marker -- the components are R, G, B
+    and must come out unconverted (libjpeg alone would guess YCbCr and convert; libtiff-written files hide this because libtiff names
+    its components 'R', 'G', 'B')."""
+    import io
+
+    from PIL import Image
+
+    yy, xx = np.mgrid[0:200, 0:330]
+    base = np.stack([xx * 255 // 330, yy * 255 // 200, (xx + yy) * 255 // 530], -1).astype(np.uint8)
+
+    def enc(t):  # encode the R, G, B planes as they are: PIL writes a 'YCbCr' image's components untouched (ids 1, 2, 3); drop its JFIF APP0
+        buf = io.BytesIO()
+        Image.merge("YCbCr", [Image.fromarray(t[..., i]) for i in range(3)]).save(buf, format="JPEG", quality=95, subsampling=0)
+        b = buf.getvalue()
+        assert b[2:4] == b"\xff\xe0"
+        n = (b[4] << 8) | b[5]
+        b = b[:2] + b[4 + n:]
+        assert b"JFIF" not in b[:64] and b"Adobe" not in b[:64]
+        return b
+
+    path = str(tmp_path / "aperio_like.tif")
+    write_tiled_tiff(path, [base], tile=128, mpp=0.25, encode=(enc, 7))
+    r = WSIReader.open(path)
+    assert r.levels[0].photometric == 2 and r.levels[0].compression == 7
+    got = r.read_bounds((0, 0, 330, 200), 1.0, "baseline")
+    assert np.abs(got.astype(int) - base.astype(int)).mean() < 2.0, np.abs(got.astype(int) - base.astype(int)).mean()
+
+
+def test_non_integer_reduction_does_not_depend_on_the_row_chunks(tmp_path):
+    """mpp 0.252 -> 0.5 (a factor of 1.984 from level 0: Aperio's scan resolution against the reference's default processing resolution):
+    the rows a SlabUploader reads chunk by chunk, or two ranks read as bands, are the rows of ONE read of the whole slide -- the resampling
+    grid is global -- and they are area means of the level's pixels."""
+    levels = _pyramid(523, 389, 11)[:1]
+    path = str(tmp_path / "s.tif")
+    write_tiled_tiff(path, levels, tile=128, mpp=0.252)
+    r = WSIReader.open(path)
+    w, h = [int(v) for v in r.slide_dimensions(0.5, "mpp")]
+    whole = r.read_bounds((0, 0, w, h), 0.5, "mpp")
+    assert whole.shape == (h, w, 3)
+    rows = r.rows(0.5, "mpp")
+    for a, b in ((0, 37), (37, 100), (100, 101), (101, h)):
+        assert np.array_equal(rows[a:b], whole[a:b]), (a, b)
+    assert np.array_equal(r.read_bounds((13, 50, 140, 77), 0.5, "mpp"), whole[50:77, 13:140])
+    # a constant image stays constant, a linear ramp keeps its slope: area means on the right grid
+    rel = 0.5 / 0.252
+    ramp = levels[0][..., 0].astype(np.float64)  # x * 255 // w
+    exp = np.array([ramp[:, int(np.floor(o * rel)):int(np.ceil((o + 1) * rel))].mean() for o in range(5, 60)])
+    assert np.abs(whole[:, 5:60, 0].mean(axis=0) - exp).max() < 1.5
+    # enlarging (0.252 -> 0.2) goes through the same global grid
+    w2, h2 = [int(v) for v in r.slide_dimensions(0.2, "mpp")]
+    big = r.read_bounds((0, 0, w2, h2), 0.2, "mpp")
+    assert np.array_equal(r.read_bounds((0, 211, w2, 305), 0.2, "mpp"), big[211:305])
