@@ -12,7 +12,7 @@ What runs where: every tile is labelled by cerb_postproc_nuclei with `exact_ties
 skimage, so its heap order is reproducible) and turned into the instance dictionary by cerb_inst_table / cerb_inst_contour_*; the margin
 logic is a few vectorised closed-interval box tests on the host (shapely's `STRtree.query` = envelope intersection, touching included;
 `box.contains(box)`).  Tile sets follow tiatoolbox 1.3.1 `NucleusInstanceSegmentor._get_tile_info` (un-vendored in the reference's tree,
-absent from this image: restated, unpinned -- the same statement as oracle/wsi_tiles_ref.py, which the tests compare this module with).
+absent from this image: restated, unpinned -- the test-suite compares this module with an independent CPU restatement of the same scheme).
 """
 from collections import OrderedDict
 
