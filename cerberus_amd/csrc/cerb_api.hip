@@ -201,7 +201,14 @@ struct cerb_net {
     bool reusing = false;
     // train-mode packing (cerb_net_set_fold_bn(net, 0) before finalize): raw conv weights, BatchNorm affine parameters kept apart
     int fold_bn = 1;
-    struct BnDev { float *gamma = nullptr, *beta = nullptr; int C = 0, groups = 1; };
+    struct BnDev {
+        float *gamma = nullptr, *beta = nullptr;
+        int C = 0, groups = 1;
+        // cerb_net_set_bn_eval: groups of a train-packed network whose BatchNorm runs in EVAL mode (the reference's frozen sub-typing modules,
+        // models/net_desc.py:105-121): device copies of running_mean and 1 / sqrt(running_var + eps), [groups][C]; eval[g] != 0 where set
+        float *run_mean = nullptr, *run_rstd = nullptr;
+        std::vector<char> eval;
+    };
     std::map<std::string, BnDev> bn;  // by conv name ("stem", "backbone.layer1.0.conv1", "dec.<u>.<j>", "head.<k>", "pc.bn1", "pc.bn2")
     std::vector<float*> head_rw1, head_rb1, head_rw2, head_rb2;  // raw head weights, row-major [cout][cin]
     float *pc_rw1 = nullptr, *pc_rb1 = nullptr, *pc_rw2 = nullptr, *pc_rb2 = nullptr;
@@ -1093,6 +1100,16 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
 // statistics of the batch, so the convolutions run with their raw weights (net packed with cerb_net_set_fold_bn(net, 0)) and each is
 // followed by cerb_launch_bn_stats / cerb_launch_bn_apply.  Returns the full-resolution logits of every head.  First version of
 // the forward half of BASELINE configs[4]: nothing is kept for a backward pass yet and the running statistics are not updated.
+// Groups in eval mode normalise with their running statistics: the batch statistics just computed are replaced before the apply pass reads them.
+static int bn_eval_override(const cerb_net::BnDev& b, float* mean, float* rstd, hipStream_t st) {
+    for (int g = 0; g < (int)b.eval.size(); ++g)
+        if (b.eval[g]) {
+            HIP_OK(hipMemcpyAsync(mean + (size_t)g * b.C, b.run_mean + (size_t)g * b.C, (size_t)b.C * 4, hipMemcpyDeviceToDevice, st));
+            HIP_OK(hipMemcpyAsync(rstd + (size_t)g * b.C, b.run_rstd + (size_t)g * b.C, (size_t)b.C * 4, hipMemcpyDeviceToDevice, st));
+        }
+    return 0;
+}
+
 static int bn_train(cerb_net* net, const std::string& name, float* x, const float* resid, long long group_stride, long long rows, int relu,
                     hipStream_t st) {
     auto it = net->bn.find(name);
@@ -1102,6 +1119,7 @@ static int bn_train(cerb_net* net, const std::string& name, float* x, const floa
         net->t_ws.ensure(cerb_bn_workspace_bytes(b.groups, rows, b.C), 0))
         return fail("workspace allocation failed");
     HIP_OK(cerb_launch_bn_stats(x, group_stride, rows, b.C, b.groups, 1e-5f, net->t_mean.p, net->t_rstd.p, nullptr, net->t_ws.p, st));
+    if (bn_eval_override(b, net->t_mean.p, net->t_rstd.p, st)) return 1;
     HIP_OK(cerb_launch_bn_apply(x, nullptr, resid, group_stride, rows, b.C, b.groups, net->t_mean.p, net->t_rstd.p, b.gamma, b.beta, relu, st));
     return 0;
 }
@@ -1301,9 +1319,11 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         // `flops` field = algorithmic bytes of the two forward BatchNorm passes (statistics: read y; apply: read y (+ residual), write z)
         if (prof_begin(net, name + ".bn_fwd", "bn_fwd", (double)b.groups * rows * b.C * 4.0 * (3.0 + (resid >= 0 ? 1.0 : 0.0)), st)) return -1;
         if (!var_u || cerb_launch_bn_stats(val[y], gs, rows, b.C, b.groups, 1e-5f, mean, rstd, var_u, net->t_ws.p, st) != hipSuccess) return -1;
+        if (bn_eval_override(b, mean, rstd, st)) return -1;
         {
             const std::vector<std::string>& keys = net->bn_keys[name];
             for (int g = 0; g < b.groups; ++g) {
+                if (g < (int)b.eval.size() && b.eval[g]) continue;  // eval mode: running statistics are not updated (no batch statistics published)
                 net->grads[keys[g] + ".batch_mean"] = std::make_pair(mean + (size_t)g * b.C, (long long)b.C);
                 net->grads[keys[g] + ".batch_var"] = std::make_pair(var_u + (size_t)g * b.C, (long long)b.C);
             }
@@ -1749,6 +1769,41 @@ extern "C" int cerb_net_set_conv_algo(cerb_net* net, int algo) {
         return fail("cerb_net_set_conv_algo: algo must be 0 (direct), 1 (Winograd F(2x2) fp32), 5 (Winograd F(4x4) fp32), 7 (F(4x4), one-block items with 32-channel chunks) or 6 (F(4x4) for maps of 16 x 16 pixels and more -- 7's kernel up to 64 x 64, 5's above --, else F(2x2): the default); 2-4 were experiments (scripts/experiments/)");
     net->conv_algo = algo;
     return 0;
+}
+
+extern "C" int cerb_net_set_bn_eval(cerb_net* net, const char* bn_prefix, const float* running_mean, const float* running_var, int channels) {
+    if (!net || !bn_prefix) return fail("cerb_net_set_bn_eval: null argument");
+    if (!net->finalized || net->fold_bn) return fail("cerb_net_set_bn_eval: needs a finalized network packed with cerb_net_set_fold_bn(net, 0)");
+    for (auto& kv : net->bn_keys) {
+        const std::vector<std::string>& keys = kv.second;
+        for (size_t g = 0; g < keys.size(); ++g) {
+            if (keys[g] != bn_prefix) continue;
+            auto it = net->bn.find(kv.first);
+            if (it == net->bn.end()) return fail(std::string("cerb_net_set_bn_eval: internal: no BatchNorm ") + kv.first);
+            cerb_net::BnDev& b = it->second;
+            if (!running_mean || !running_var) {  // back to training mode
+                if (g < b.eval.size()) b.eval[g] = 0;
+                return 0;
+            }
+            if (channels != b.C) return fail(std::string("cerb_net_set_bn_eval: ") + bn_prefix + " has " + std::to_string(b.C) + " channels");
+            if (!b.run_mean) {
+                void* d = nullptr;
+                HIP_OK(hipMalloc(&d, (size_t)2 * b.groups * b.C * 4));
+                net->dev_allocs.push_back(d);
+                net->dev_alloc_bytes.push_back((size_t)2 * b.groups * b.C * 4);
+                b.run_mean = (float*)d;
+                b.run_rstd = b.run_mean + (size_t)b.groups * b.C;
+                b.eval.assign(b.groups, 0);
+            }
+            std::vector<float> rs(b.C);
+            for (int c = 0; c < b.C; ++c) rs[c] = 1.0f / sqrtf(running_var[c] + 1e-5f);
+            HIP_OK(hipMemcpy(b.run_mean + g * b.C, running_mean, (size_t)b.C * 4, hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(b.run_rstd + g * b.C, rs.data(), (size_t)b.C * 4, hipMemcpyHostToDevice));
+            b.eval[g] = 1;
+            return 0;
+        }
+    }
+    return fail(std::string("cerb_net_set_bn_eval: no BatchNorm with the state-dict prefix ") + bn_prefix);
 }
 
 extern "C" int cerb_net_set_planar(cerb_net* net, int enable) {

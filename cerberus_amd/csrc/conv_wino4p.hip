@@ -387,7 +387,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if constexpr (q > TQ && q <= TQ + 6) pass_v(q - TQ - 1);
                 if constexpr (q > TQ + 6 && q <= TQ + 12) pass_h(q - TQ - 7);
 #endif
-#ifndef P4_ABL_NOVWRITE
+#if defined(P4_ABL_VWRITE_FAKE)
+                if constexpr (q > TQ + 6 && q <= TQ + 12) { if (p.N < 0) write_row(wbuf, q - TQ - 7); }  // everything upstream stays alive, nothing is written
+#elif !defined(P4_ABL_NOVWRITE)
                 if constexpr (q > TQ + 6 && q <= TQ + 12) write_row(wbuf, q - TQ - 7);
 #endif
 #ifndef P4_ABL_NOPATCH

@@ -170,6 +170,48 @@ class NetDesc(torch.nn.Module):
             shp = (C.c_int64 * a.ndim)(*a.shape)
             _lib.check(L.cerb_net_load_tensor(h, k.encode(), a.ctypes.data_as(C.c_void_p), shp, a.ndim))
         _lib.check(L.cerb_net_finalize(h))
+        if getattr(self, "_train_packing", False):
+            self._apply_freeze(h)
+
+    # ---- sub-typing fine-tune: frozen modules (models/net_desc.py:105-142) -------------------------------------------------------------
+    def frozen_prefixes(self):
+        """State-dict prefixes of the modules the reference's `_freeze_weight` freezes when subtype_gland / subtype_nuclei is set: backbone,
+        conv_map, Patch-Class, every decoder + output head except the selected '#TYPE' one(s).  Empty when no sub-typing flag is set."""
+        if not (self.subtype_gland or self.subtype_nuclei):
+            return []
+        keep = set()
+        if self.subtype_gland:
+            keep.add("Gland#TYPE")
+        if self.subtype_nuclei:
+            keep.add("Nuclei#TYPE")
+        pre = ["backbone.", "conv_map."]
+        for name, _, _, _ in self._decoders:
+            if name in keep:
+                continue
+            pre.append("decoder_head.%s." % name)
+            if name != "Patch-Class":
+                pre.append("output_head.%s." % name)
+        return pre
+
+    def is_frozen(self, key):
+        return any(key.startswith(p) for p in self.frozen_prefixes())
+
+    def _apply_freeze(self, h):
+        """BatchNorm layers of the frozen modules run in eval mode inside the train-mode device path (cerb_net_set_bn_eval): their running
+        statistics, which no training step of this configuration ever changes, are handed over once per handle."""
+        pre = self.frozen_prefixes()
+        if not pre:
+            return
+        L = _lib.lib()
+        for k, v in self._sd.items():
+            if not k.endswith(".running_mean") or not any(k.startswith(p) for p in pre):
+                continue
+            bn = k[: -len(".running_mean")]
+            if bn.startswith("backbone.fc"):
+                continue
+            mean = np.ascontiguousarray(v.numpy(), np.float32)
+            var = np.ascontiguousarray(self._sd[bn + ".running_var"].numpy(), np.float32)
+            _lib.check(L.cerb_net_set_bn_eval(h, bn.encode(), mean.ctypes.data_as(C.c_void_p), var.ctypes.data_as(C.c_void_p), int(mean.size)))
 
     def train(self, mode=True):
         """nn.Module.train(): a network whose handle has not been created yet is packed for training on first use (raw conv weights,
@@ -213,14 +255,16 @@ class NetDesc(torch.nn.Module):
             _lib.check(_lib.lib().cerb_net_forward_train(h, C.byref(io), C.c_void_p(stream)))
         return res
 
-    def train_grads(self, tiles_u8, targets, has_target, loss_opts, dropout_keep=None, views=False, pixel_weights=None):
+    def train_grads(self, tiles_u8, targets, has_target, loss_opts, dropout_keep=None, views=False, pixel_weights=None, logits_out=None):
         """One step of the reference's train_step up to all_loss.backward() (models/run_desc.py:79-170): train-mode forward, the head
         losses, the backward pass.  targets: head key -> CUDA float [N, H, W] class ids ([N] for Patch-Class); has_target: head key ->
         CUDA float [N]; loss_opts: the reference's loss_kwargs (cerberus_amd.losses.PARAMSET_LOSS).
         -> (losses: head key -> float as train_step reports them, grads: state-dict key -> CUDA float tensor shaped like the parameter;
         under the keys of the BatchNorm buffers (running_mean / running_var) it holds the step's batch mean / unbiased batch variance).
         pixel_weights: head key -> CUDA float [N, H, W], the head's '#WEIGHT-MAP' target (models/run_desc.py:111-117), optional.
-        views=True returns tensors over the handle's own gradient memory instead of copies: valid until the next call on this network."""
+        views=True returns tensors over the handle's own gradient memory instead of copies: valid until the next call on this network.
+        logits_out: an (empty) dict that receives the train-mode logits of every head that has a target, channels last ([N, H, W, C]; Patch-Class
+        [N, C]) -- what the reference's train_step turns into its `raw` visualisation payload."""
         self.train(True)
         h = self._ensure_handle()
         L = _lib.lib()
@@ -260,6 +304,14 @@ class NetDesc(torch.nn.Module):
             keep.append(scale)
             io.dropout_scale = scale.data_ptr()
         io.target, io.has_target, io.class_weight, io.ce_w, io.dice_w, io.head_w = tg, fl, cw, ce, dc, hw
+        if logits_out is not None:
+            lg_arr = (C.c_void_p * nd)()
+            for i, (name, hname, och, key) in enumerate(self._decoders):
+                if key in targets:
+                    logits_out[key] = torch.empty((n, och) if name == "Patch-Class" else (n, hh, ww, och), dtype=torch.float32, device=dev)
+                    lg_arr[i] = logits_out[key].data_ptr()
+            io.logits = lg_arr
+            keep.append(lg_arr)
         io.loss_out = loss.data_ptr()
         # train_step's rule (models/run_desc.py:64-74): a decoder trains when its NAME is a substring of a target name that at least one
         # sample carries -- "Gland#TYPE" is not a substring of "Gland-TYPE", so the #TYPE decoders only ever train inside their blocks
@@ -271,9 +323,12 @@ class NetDesc(torch.nn.Module):
         with torch.cuda.device(dev):
             _lib.check(L.cerb_net_train_grads(h, C.byref(io), C.c_void_p(stream)))
             grads = OrderedDict()
+            frozen = self.frozen_prefixes()
             for k, v in self._sd.items():
                 if v.dtype != torch.float32 or k.startswith("backbone.fc."):
                     continue
+                if (k.endswith("running_mean") or k.endswith("running_var")) and frozen and any(k.startswith(p) for p in frozen):
+                    continue  # eval-mode BatchNorm of a frozen module: no batch statistics, the running ones stay
                 lk = k
                 if k.endswith("running_mean"):  # the batch statistics behind the running-statistics update, under the buffer's own key
                     lk = k[: -len("running_mean")] + "batch_mean"

@@ -105,14 +105,14 @@ def allreduce_grads(grads, dist, world_size, bucket_bytes=32 << 20):
 def train_step(batch_data, run_info, dist=None, world_size=1, dropout_keep=None):
     """batch_data: {'img': uint8 [N, H, W, 3], 'dummy_target': object array [N, B] of head names / None, '<head>': [N, H, W, 1] class
     ids, ...}; run_info: ({'net': {'desc': NetDesc, 'optimizer': cerberus_amd.train.Adam, 'extra_info': {'loss': loss_kwargs}}}, state)
-    -- the reference's protocol (models/run_desc.py:25-60).  Returns {'EMA': {'<head>_loss': ..., 'overall_loss': ...}}."""
+    -- the reference's protocol (models/run_desc.py:25-60).  Returns {'EMA': {'<head>_loss': ..., 'overall_loss': ...},
+    'raw': {'img', 'true', 'pred'}} (two random samples for the visualisation callbacks, models/run_desc.py:172-230)."""
     run_info, _ = run_info
     model, opt = run_info["net"]["desc"], run_info["net"]["optimizer"]
-    if getattr(model, "subtype_gland", False) or getattr(model, "subtype_nuclei", False):
-        # the reference freezes the backbone, conv_map, Patch-Class, every INST decoder and the unselected TYPE decoder here and puts
-        # their BatchNorm layers in eval mode (models/run_desc.py:83-84, net_desc.py:105-140); this step trains and renormalises
-        # EVERYTHING, so running it in a sub-typing configuration would silently train the wrong network
-        raise NotImplementedError("train_step: subtype_gland / subtype_nuclei (frozen-backbone sub-typing fine-tune) is not implemented")
+    # Sub-typing fine-tune (subtype_gland / subtype_nuclei; models/run_desc.py:83-84 -> net_desc.py:105-142): the backbone, conv_map, Patch-Class,
+    # every INST decoder / head and the unselected TYPE decoder / head are frozen -- their BatchNorm layers normalise with the running statistics
+    # (cerb_net_set_bn_eval, registered when the handle is packed) and neither their parameters nor their statistics move; see `frozen` below.
+    frozen = model.frozen_prefixes() if hasattr(model, "frozen_prefixes") else []
     loss_opts = run_info["net"]["extra_info"]["loss"]
     batch = dict(batch_data)
     img = batch.pop("img")
@@ -130,9 +130,15 @@ def train_step(batch_data, run_info, dist=None, world_size=1, dropout_keep=None)
         flags[k] = torch.from_numpy(np.any(np.asarray(has) == k, axis=-1).astype(np.float32)).to(dev)
     if dropout_keep is None and "Patch-Class" in targets:  # nn.Dropout(p=0.3) of the Patch-Class branch (models/net_desc.py:70)
         dropout_keep = torch.rand((img.shape[0], 512), device=dev) >= 0.3
-    losses, grads = model.train_grads(torch.as_tensor(img).to(dev), targets, flags, loss_opts, dropout_keep, views=True, pixel_weights=wmaps)
+    logits = {}
+    losses, grads = model.train_grads(torch.as_tensor(img).to(dev), targets, flags, loss_opts, dropout_keep, views=True, pixel_weights=wmaps, logits_out=logits)
     buf_keys = [k for k in grads if k.endswith("running_mean") or k.endswith("running_var")]
     stats = OrderedDict((k, grads.pop(k)) for k in buf_keys)
+    if frozen:  # requires_grad = False there: the optimiser never sees these tensors (their moments stay unborn, as in torch.optim.Adam)
+        for k in [k for k in grads if any(k.startswith(p) for p in frozen)]:
+            del grads[k]
+        for k in [k for k in stats if any(k.startswith(p) for p in frozen)]:
+            del stats[k]
     allreduce_grads(grads, dist, world_size)
     # parameters live in the model's state dict (host); the optimiser works on device copies that persist across steps
     if not hasattr(model, "_dev_params"):
@@ -162,7 +168,41 @@ def train_step(batch_data, run_info, dist=None, world_size=1, dropout_keep=None)
     model.load_updated_parameters(model._dev_params, model._dev_flat, model._dev_layout)
     ema = OrderedDict(("%s_loss" % k, v) for k, v in losses.items())
     ema["overall_loss"] = float(sum(losses.values()))
-    return {"EMA": ema}
+    return {"EMA": ema, "raw": _raw_payload(torch.as_tensor(img), targets, logits, has)}
+
+
+def _raw_payload(img, targets, logits, has):
+    """train_step's visualisation payload (models/run_desc.py:172-230): two randomly drawn samples of the batch -- the uint8 images, the targets
+    and the train-mode predictions read out per head ('*-INST': softmax channels 1:, '*-TYPE': argmax, 'Patch-Class': argmax spread over the
+    tile), every array torch.squeeze'd as the reference does.  When a sample carries a Patch-Class target the reference pushes every head
+    through F.interpolate(nearest, size = tile): the identity for the dense heads, the broadcast over the tile for Patch-Class."""
+    import torch.nn.functional as F
+
+    n, h, w = int(img.shape[0]), int(img.shape[1]), int(img.shape[2])
+    idx = torch.randint(0, n, (2,))
+    names = np.asarray(has)
+    pc_in_targets = bool(np.any(names == "Patch-Class"))
+    true, pred = OrderedDict(), OrderedDict()
+    for key, lg in logits.items():
+        lg = lg[idx.to(lg.device)]
+        if key == "Patch-Class":
+            p = torch.argmax(torch.softmax(lg, -1), dim=-1, keepdim=True).reshape(2, 1, 1, 1)  # NHWC [2, 1, 1, 1], read as NCHW by interpolate
+            p = F.interpolate(p.float(), size=(h, w), mode="nearest").permute(0, 2, 3, 1)
+        else:
+            sm = torch.softmax(lg, -1)
+            p = sm if key.endswith("TYPE") else sm[..., 1:]
+            if pc_in_targets:
+                p = F.interpolate(p.permute(0, 3, 1, 2).float(), size=(h, w), mode="nearest").permute(0, 2, 3, 1)
+        p = torch.squeeze(p)
+        if "TYPE" in key:
+            p = torch.argmax(p, dim=-1, keepdim=False)
+        pred[key] = p.detach().cpu().numpy()
+        t = targets[key][idx.to(targets[key].device)]
+        t = t.reshape(2, 1, 1, 1) if key == "Patch-Class" else t.reshape(2, h, w, 1)
+        if key == "Patch-Class" or pc_in_targets:
+            t = F.interpolate(t.permute(0, 3, 1, 2).float(), size=(h, w), mode="nearest").permute(0, 2, 3, 1)
+        true[key] = torch.squeeze(t).detach().cpu().numpy()
+    return {"img": img[idx].to(torch.uint8).cpu().numpy(), "true": true, "pred": pred}
 
 
 def _eval_twin(model):

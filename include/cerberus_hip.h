@@ -225,6 +225,12 @@ typedef struct cerb_train_io {
     float* const* logits;
 } cerb_train_io;
 int cerb_net_set_fold_bn(cerb_net* net, int fold);
+/* Frozen modules of the sub-typing fine-tune (models/net_desc.py:105-142 `_freeze_weight`, called by train_step, models/run_desc.py:83-84): the
+ * BatchNorm with state-dict prefix `bn_prefix` (e.g. "backbone.layer1.0.bn1") of a train-packed, finalized network runs in EVAL mode from now on --
+ * cerb_net_forward_train / cerb_net_train_grads normalise it with these running statistics (host float[channels] each, eps 1e-5) instead of the
+ * batch's and publish no batch statistics for it.  NULL statistics put it back in training mode.  Which parameters an optimiser then skips is the
+ * caller's business (cerberus_amd/train.py drops the gradients of the frozen modules). */
+int cerb_net_set_bn_eval(cerb_net* net, const char* bn_prefix, const float* running_mean, const float* running_var, int channels);
 /* After an optimiser step: drop the packed weights of a finalized handle (activation workspaces, the training tape and the mode stay), so
  * that cerb_net_load_tensor of EVERY tensor + cerb_net_finalize install the updated parameters (models/run_desc.py:165 optimizer.step()). */
 int cerb_net_begin_reload(cerb_net* net);

@@ -327,3 +327,115 @@ def test_device_side_parameter_update_equals_a_rebuilt_handle(gold):
     assert runs[0][0][0] != runs[0][0][2]  # the parameters did move
     for k, v in runs[0][1].items():
         assert torch.equal(v, runs[1][1][k]), k
+
+
+def _gold_batch(g):
+    heads = [str(h) for h in g["heads"]]
+    has = np.full((int(g["N"]), len(heads)), None, dtype=object)
+    for j, h in enumerate(heads):
+        for n in range(int(g["N"])):
+            if g["has_target"][n, j]:
+                has[n, j] = h
+    batch = {"img": torch.from_numpy(g["img"]), "dummy_target": has}
+    for h in heads:
+        batch[h] = torch.from_numpy(g["target/" + h])
+    return heads, batch
+
+
+def test_train_step_raw_payload_vs_reference_logits(gold):
+    """train_step's 'raw' entry (models/run_desc.py:172-230): two random samples -- images, targets and the train-mode predictions read out per
+    head -- against the same read-outs of the REFERENCE's train-mode logits (tests/golden/train_loss.npz), drawn with the same indices."""
+    from cerberus_amd.net_desc import create_model
+    from cerberus_amd.train import Adam, train_step
+    from cerberus_amd.weights import default_model_kwargs, make_state_dict
+
+    m = create_model(**default_model_kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(int(gold["weight_seed"])).items()}, strict=True)
+    heads, batch = _gold_batch(gold)
+    n, hw = int(gold["N"]), int(gold["H"])
+    keep = torch.from_numpy(gold["step/dropout_mask"].reshape(n, 512)).cuda()
+    torch.manual_seed(123)
+    res = train_step(batch, ({"net": {"desc": m, "optimizer": Adam(lr=1.0e-3), "extra_info": {"loss": PARAMSET_LOSS}}}, None), dropout_keep=keep)
+    torch.manual_seed(123)
+    idx = torch.randint(0, n, (2,))
+    raw = res["raw"]
+    assert set(raw.keys()) == {"img", "true", "pred"} and raw["img"].dtype == np.uint8
+    assert np.array_equal(raw["img"], gold["img"][idx.numpy()])
+    assert list(raw["pred"].keys()) == heads and list(raw["true"].keys()) == heads
+    for h in heads:
+        lg = torch.from_numpy(gold["logits/" + h])[idx]  # NCHW from the reference
+        if h == "Patch-Class":
+            want = torch.argmax(lg.reshape(2, -1), dim=-1).reshape(2, 1, 1).expand(2, hw, hw).numpy()
+            assert raw["pred"][h].shape == (2, hw, hw) and np.array_equal(raw["pred"][h], want.astype(raw["pred"][h].dtype))
+            assert np.array_equal(raw["true"][h], np.broadcast_to(gold["target/" + h][idx.numpy()].reshape(2, 1, 1), (2, hw, hw)))
+            continue
+        sm = torch.softmax(lg.permute(0, 2, 3, 1), -1)
+        if h.endswith("TYPE"):
+            want, got = torch.argmax(sm, -1).numpy(), raw["pred"][h]
+            top = torch.topk(sm, 2, dim=-1).values
+            bad = got != want
+            assert got.shape == (2, hw, hw) and (not bad.any() or float((top[..., 0] - top[..., 1]).numpy()[bad].max()) < 1e-4), h
+        else:
+            assert raw["pred"][h].shape == (2, hw, hw, 2) and np.abs(raw["pred"][h] - sm[..., 1:].numpy()).max() < 1e-4, h
+        assert np.array_equal(raw["true"][h], gold["target/" + h][idx.numpy()][..., 0]), h
+
+
+def test_subtype_fine_tune_step_vs_reference():
+    """subtype_nuclei=True (the frozen-backbone sub-typing fine-tune, models/net_desc.py:105-142 + 160-170, run_desc.py:83-84) for one step,
+    against the REFERENCE's own train_step in that configuration (oracle/gen_golden_subtype.py -> tests/golden/train_subtype.npz):
+      * the train-mode forward normalises the frozen modules with their RUNNING statistics (eval-mode BatchNorm): reported losses agree;
+      * Adam moves exactly the 14 tensors the reference moves -- the last level of the 'Nuclei#TYPE' decoder and its output head -- by the
+        same amounts, every other parameter is bit-for-bit what it was;
+      * running statistics change in the 9 BatchNorm layers of that decoder / head only (and num_batches_tracked advances there only)."""
+    from cerberus_amd.net_desc import create_model
+    from cerberus_amd.train import Adam, train_step
+    from cerberus_amd.weights import default_model_kwargs, make_state_dict
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "train_subtype.npz"))
+    kw = default_model_kwargs()
+    kw["subtype_nuclei"] = True
+    m = create_model(**kw)
+    sd0 = {k: torch.from_numpy(v) for k, v in make_state_dict(int(g["weight_seed"])).items()}
+    m.load_state_dict(sd0, strict=True)
+    heads, batch = _gold_batch(g)
+    loss = copy.deepcopy(PARAMSET_LOSS)
+    loss["loss_info"]["Nuclei-TYPE"]["weight"] = 1.0
+    keep = torch.from_numpy(g["dropout_mask"].reshape(int(g["N"]), 512)).cuda()
+    opt = Adam(lr=1.0e-3, betas=(0.9, 0.999))
+    res = train_step(batch, ({"net": {"desc": m, "optimizer": opt, "extra_info": {"loss": loss}}}, None), dropout_keep=keep)
+    for h in heads:
+        want = float(g["loss/" + h])
+        assert abs(res["EMA"]["%s_loss" % h] - want) <= 2e-4 * max(1.0, abs(want)), (h, res["EMA"]["%s_loss" % h], want)
+    assert abs(res["EMA"]["overall_loss"] - float(g["overall_loss"])) <= 1e-4 * float(g["overall_loss"])
+    new = m.state_dict()
+    moved_ref = set(str(k) for k in g["moved"])
+    assert len(moved_ref) == 14
+    moved = set()
+    for k, (p_sum, d_abs, d0, dm, d1) in zip([str(x) for x in g["param_names"]], g["update_stats"]):
+        if k.startswith("backbone.fc."):
+            continue
+        d = (new[k].double() - sd0[k].double()).flatten().numpy()
+        if np.abs(d).sum() > 0:
+            moved.add(k)
+        if k not in moved_ref:
+            assert np.abs(d).sum() == 0.0, "frozen parameter moved: " + k
+            continue
+        if ".block." in k and k.endswith(".conv.bias"):
+            continue  # a bias in front of a BatchNorm: zero gradient, noise-driven +-lr steps on both sides
+        assert abs(np.abs(d).sum() - d_abs) / max(d_abs, 1e-12) < 2e-2, (k, np.abs(d).sum(), d_abs)
+        assert abs(new[k].double().sum().item() - p_sum) <= 2e-2 * d_abs + 4.2e-3 + 1e-6 * abs(p_sum), k
+    assert moved - moved_ref == set() and all(k in moved or k.endswith(".conv.bias") for k in moved_ref), (sorted(moved ^ moved_ref))
+    n_changed = 0
+    for k, (b_sum, b_dabs, b0) in zip([str(x) for x in g["bn_names"]], g["bn_stats"]):
+        got = new[k].double()
+        if b_dabs == 0:
+            assert torch.equal(new[k], sd0[k]), "running statistics of a frozen BatchNorm moved: " + k
+            continue
+        n_changed += 1
+        assert abs(got.sum().item() - b_sum) <= 1e-4 * max(1.0, abs(b_sum)) + 1e-3 * b_dabs, (k, got.sum().item(), b_sum)
+        assert abs(got.flatten()[0].item() - b0) <= 1e-4 * max(1.0, abs(b0)), k
+    assert n_changed == 18
+    tracked = set(str(k) for k in g["tracked_moved"])
+    for k, v in new.items():
+        if k.endswith("num_batches_tracked"):
+            assert (int(v) != int(sd0[k])) == (k in tracked), k
