@@ -153,6 +153,15 @@ __device__ __forceinline__ int fresh_lane() {
     return l;
 }
 
+// a - b as two v_pk_add_f32 with negated second operands (hipcc emits four scalar v_sub_f32 for a float4 difference); the same IEEE result
+__device__ __forceinline__ f32x4 sub4(const f32x4& x, const f32x4& y) {
+    f32x2 lo, hi;
+    const f32x2 xl = {x[0], x[1]}, xh = {x[2], x[3]}, yl = {y[0], y[1]}, yh = {y[2], y[3]};
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(xl), "v"(yl));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(xh), "v"(yh));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
 struct Blk {
     int n, by, bx;  // image, block row / column inside the launch's block grid
 };
@@ -209,6 +218,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     // the block's TOP-LEFT neighbour in the guard-ringed block grid (stored index of block (by, bx) is (by + 1, bx + 1)): every patch offset is >= 0
     auto in_base = [&](int g, const Blk& b) {
+#ifdef P4_ABL_PATCHL2   // ablation: every patch comes from the same few blocks (cache resident): the cost of the patch loads' HBM latency
+        return reinterpret_cast<const char*>(p.in) + (((long long)(b.by & 1)) * p.pl_bxp + (b.bx & 3)) * (long long)nchunk * PLANE_BYTES;
+#endif
         return reinterpret_cast<const char*>(p.in + g * p.in_gs) +
                (((long long)b.n * p.pl_byp + (b.by + p.ty_off)) * p.pl_bxp + (b.bx + p.tx_off)) * (long long)nchunk * PLANE_BYTES;
     };
@@ -424,7 +436,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (acc[0][0][0] == 1.2345e-30f)
 #endif
         {
-            const float floor_ = p.relu ? 0.f : -3.402823466e38f;
+            // the ReLU floor as a SCALAR made here, per item: hipcc had put this kernel invariant in a vector register at kernel start, spilled it,
+            // and reloaded it in the middle of the output stage -- behind an s_waitcnt vmcnt(0) that drained every load and every store in flight
+            int relu_s = p.relu;
+            asm volatile("" : "+s"(relu_s));
+            const float floor_ = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(relu_s ? 0 : (int)0xff7fffff));
             // the lane's place in a 1-KiB pixel-position row, recomputed per item from the hardware lane id: a value kept in a register across the
             // chunk loop instead was spilled, and its scratch reload -- in the same in-order vmcnt queue as everything else -- drained the queue here
             const int lane_o = fresh_lane();
@@ -444,7 +460,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int b = 0; b < 6; ++b) {
                     const f32x4 m0 = acc[0 * 6 + b][tb], m1 = acc[1 * 6 + b][tb], m2 = acc[2 * 6 + b][tb], m3 = acc[3 * 6 + b][tb],
                                 m4 = acc[4 * 6 + b][tb], m5 = acc[5 * 6 + b][tb];
-                    const f32x4 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                    const f32x4 s1 = m1 + m2, d1 = sub4(m1, m2), s2 = m3 + m4, d2 = sub4(m3, m4);
                     T[0][b] = m0 + s1 + s2;
                     T[1][b] = d1 + 2.f * d2;
                     T[2][b] = s1 + 4.f * s2;
@@ -453,7 +469,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const int rem_y = p.Ho - by_abs * BLK - 4 * (m_o >> 2), rem_x = p.Wo - bx_abs * BLK - 4 * (m_o & 3);  // partial blocks: rows / columns of this lane's tile inside the image
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const f32x4 s1 = T[i][1] + T[i][2], d1 = T[i][1] - T[i][2], s2 = T[i][3] + T[i][4], d2 = T[i][3] - T[i][4];
+                    const f32x4 s1 = T[i][1] + T[i][2], d1 = sub4(T[i][1], T[i][2]), s2 = T[i][3] + T[i][4], d2 = sub4(T[i][3], T[i][4]);
                     f32x4 y[4];
                     y[0] = T[i][0] + s1 + s2;
                     y[1] = d1 + 2.f * d2;
@@ -467,7 +483,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         o[2] = fmaxf(o[2], floor_);
                         o[3] = fmaxf(o[3], floor_);
                         // pixels of an edge block beyond the image are never written: they stay zero (the next convolution's padding)
+#ifdef P4_ABL_STOREOOB   // ablation: every store is issued and dropped by the descriptor's bounds check
+                        const unsigned vo = 0x80000000u | olane;
+#else
                         const unsigned vo = (!partial || (i < rem_y && j < rem_x)) ? olane : 0x80000000u;
+#endif
 #ifndef P4_ABL_NOSTORE
                         buf_store(o, r_out, vo, (i * 4 + j) * 1024);
 #else
