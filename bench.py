@@ -249,7 +249,8 @@ def train_leg(args, model, dev, dist, world, rank, sd=None, kw=None):
 # ---- kernel-family table of one batch step (per-launch HIP events on the launch stream, cerb_net_profile_*) ----------------------
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md
 XGMI_LINK_GBS = 153.0   # per peer link, SURVEY.md par.8e
-_SYMBOL = {"conv_wino4p<f4x4,16x16x2,planar>": "conv_wino4p_kernel(ConvParams)",
+_SYMBOL = {"conv_wino4p<f4x4,16x16x2,planar>": "void conv_wino4p_kernel<1>(ConvParams)",
+           "conv_wino4p<f4x4,16x16x2,planar,half-res>": "void conv_wino4p_kernel<0>(ConvParams)",
            "conv_wino4b<f4x4,16x16>": "void conv_wino4b_kernel<false>(ConvParams)",
            "conv_wino4b<f4x4,16x16,res>": "void conv_wino4b_kernel<true>(ConvParams)",
            "conv_wino4<f4x4,16x16x2>": "void conv_wino4_kernel<false>(ConvParams)",
@@ -267,9 +268,12 @@ def _family_bytes(kern, n, launches=4):
             out = n * hw * hw * c * 4
             tot += 5 * out // 4 + out + 5 * out
         return tot
-    if kern == "upsample2_add_planar":
-        out = n * 256 * 256 * 64 * 4
-        return 5 * out // 4 + out + 5 * out
+    if kern == "upsample2_add_planar":  # the last level, and the level below it when both run tile-planar (2 launches)
+        tot = 0
+        for hw, c in levels[4 - launches:]:
+            out = n * hw * hw * c * 4
+            tot += 5 * out // 4 + out + 5 * out
+        return tot
     if kern == "maxpool3x3s2":
         return n * 256 * 256 * 64 * 4 + n * 128 * 128 * 64 * 4
     return None

@@ -23,7 +23,7 @@ hipError_t cerb_launch_wino4(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino4b(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino4p(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_upsample2_add_planar(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C, long long prev_gs,
-                                            long long out_gs, const int* roi, hipStream_t st);
+                                            long long out_gs, const int* roi, int prev_planar, hipStream_t st);
 hipError_t cerb_launch_upsample2_add(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C,
                                      long long prev_gs, const int* roi, hipStream_t st);
 extern "C" int cerb_conv_chunk(int ks, int stride);
@@ -228,6 +228,8 @@ struct cerb_net {
     // workspace
     DevBuf x0, pool, x[5], ta, tb, cm, dmid, dsum, dout[4];
     PlanarBuf psum, pmid, pout;  // the last decoder level's private tensors in the tile-planar layout (conv_wino4p.hip), cerb_net_set_planar
+    bool planar_half = false;       // set by the decoder loop around the half-resolution level's run_conv calls (names the kernel symbol)
+    PlanarBuf psum2, pmid2, pout2;  // the same for the level below it (64 channels at half the resolution) when its maps are large enough
     int planar = 1;              // cerb_net_set_planar: 1 (default) = that level runs upsample2_add_planar -> conv_wino4p x2 -> heads reading planar features
     // optional per-launch timing (HIP events on the caller's stream)
     bool profiling = false;
@@ -240,7 +242,7 @@ struct cerb_net {
     ~cerb_net() {
         for (auto& r : prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         for (void* p : dev_allocs) (void)hipFree(p);
-        x0.release(); pool.release(); ta.release(); tb.release(); cm.release(); dmid.release(); dsum.release(); psum.release(); pmid.release(); pout.release();
+        x0.release(); pool.release(); ta.release(); tb.release(); cm.release(); dmid.release(); dsum.release(); psum.release(); pmid.release(); pout.release(); psum2.release(); pmid2.release(); pout2.release();
         t_mean.release(); t_rstd.release(); t_ws.release(); t_hid.release(); t_gap.release(); t_pc1.release(); t_idn.release(); t_dil.release();
         for (auto& b : tape) b.release();
         for (auto& b : x) b.release();
@@ -835,10 +837,11 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
         }
         if (planar) {
             p.out_gs = planar_out_gs;
+            p.level_tag = net->planar_half ? 0 : 1;
             p.pl_byp = cerb_planar_blocks(p.Ho);
             p.pl_bxp = cerb_planar_blocks(p.Wo);
         }
-        if (prof_begin(net, name, planar ? "conv_wino4p<f4x4,16x16x2,planar>" : w4b ? (resid ? "conv_wino4b<f4x4,16x16,res>" : "conv_wino4b<f4x4,16x16>") : (resid ? "conv_wino4<f4x4,16x16x2,res>" : "conv_wino4<f4x4,16x16x2>"), fl_done, st)) return 1;
+        if (prof_begin(net, name, planar ? (p.level_tag ? "conv_wino4p<f4x4,16x16x2,planar>" : "conv_wino4p<f4x4,16x16x2,planar,half-res>") : w4b ? (resid ? "conv_wino4b<f4x4,16x16,res>" : "conv_wino4b<f4x4,16x16>") : (resid ? "conv_wino4<f4x4,16x16x2,res>" : "conv_wino4<f4x4,16x16x2>"), fl_done, st)) return 1;
         HIP_OK(planar ? cerb_launch_wino4p(p, st) : w4b ? cerb_launch_wino4b(p, st) : cerb_launch_wino4(p, st));
         if (prof_end(net, st)) return 1;
         return 0;
@@ -994,7 +997,7 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
                 x0 = std::max(0, roi_sum[u][2] / 2 - 1); x1 = std::min(ww / 2, (roi_sum[u][3] - 1) / 2 + 2);
             }
         }
-        bool feat_planar = false;
+        bool feat_planar = false, prev_planar = false;
         for (int u = 0; u < 4; ++u) {
             const int hh = hs[3 - u], ww = ws[3 - u];
             const std::string n0 = "dec." + std::to_string(u) + ".0", n1 = "dec." + std::to_string(u) + ".1";
@@ -1003,21 +1006,29 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
             // The last level (40 % of the network's FLOPs) keeps its three private tensors -- skip + upsample, the first conv's output, the
             // features the heads read -- in the tile-planar layout: conv_wino4p.hip stores 1-KiB rows straight from its registers and reads
             // whole lines, nothing masks an edge.  Same arithmetic in the same order: bit-identical to the NHWC path (cerb_net_set_planar(0)).
-            const bool lvl_planar = !dry && u == 3 && net->planar && net->fold_bn && net->conv_algo == 6 && net->head_algo == 1 && net->conv[n0].wino &&
-                                    (long long)hh * ww > 4096 && cin0 == 64 && cmid == 64 && net->conv[n1].cout == 64;
+            // The level below (same 64 channels at half the resolution) does the same when its maps are above conv_wino4b's range, and hands
+            // its output to the last level's up-sampling in that layout.
+            const bool lvl_planar = !dry && u >= 2 && net->planar && net->fold_bn && net->conv_algo == 6 && net->head_algo == 1 && net->conv[n0].wino &&
+                                    (long long)hh * ww > 4096 && cin0 == 64 && cmid == 64 && net->conv[n1].cout == 64 && (u == 3 || prev_gs > 0);
             if (lvl_planar) {
-                if (net->psum.ensure((int)D, N, hh, ww, 64, st) || net->pmid.ensure((int)D, N, hh, ww, 64, st) || net->pout.ensure((int)D, N, hh, ww, 64, st))
+                PlanarBuf &bs = u == 3 ? net->psum : net->psum2, &bm = u == 3 ? net->pmid : net->pmid2, &bo = u == 3 ? net->pout : net->pout2;
+                if (bs.ensure((int)D, N, hh, ww, 64, st) || bm.ensure((int)D, N, hh, ww, 64, st) || bo.ensure((int)D, N, hh, ww, 64, st))
                     return fail("workspace allocation failed");
                 if (prof_begin(net, n0 + ".up", "upsample2_add_planar", 0.0, st)) return 1;
-                HIP_OK(cerb_launch_upsample2_add_planar(skips[u], prev, net->psum.b.p, (int)D, N, hh, ww, cin0, prev_gs, net->psum.gs(), use_roi ? roi_sum[u] : nullptr, st));
+                HIP_OK(cerb_launch_upsample2_add_planar(skips[u], prev, bs.b.p, (int)D, N, hh, ww, cin0, prev_gs, bs.gs(), use_roi ? roi_sum[u] : nullptr, prev_planar ? 1 : 0, st));
                 if (prof_end(net, st)) return 1;
-                if (run_conv(net, n0, net->psum.b.p, nullptr, nullptr, net->pmid.b.p, N, hh, ww, 1, 0, net->psum.gs(), 0, st, macs, use_roi ? roi_mid[u] : nullptr, net->pmid.gs()))
+                net->planar_half = (u != 3);
+                if (run_conv(net, n0, bs.b.p, nullptr, nullptr, bm.b.p, N, hh, ww, 1, 0, bs.gs(), 0, st, macs, use_roi ? roi_mid[u] : nullptr, bm.gs()))
                     return 1;
-                if (run_conv(net, n1, net->pmid.b.p, nullptr, nullptr, net->pout.b.p, N, hh, ww, 1, 0, net->pmid.gs(), 0, st, macs, use_roi ? roi_out[u] : nullptr, net->pout.gs()))
+                if (run_conv(net, n1, bm.b.p, nullptr, nullptr, bo.b.p, N, hh, ww, 1, 0, bm.gs(), 0, st, macs, use_roi ? roi_out[u] : nullptr, bo.gs()))
                     return 1;
-                feat_planar = true;
+                if (u == 3) feat_planar = true;
+                prev = bo.b.p;
+                prev_gs = bo.gs();
+                prev_planar = true;
                 continue;
             }
+            if (prev_planar) return fail("internal: a tile-planar decoder level feeds an NHWC one");
             if (net->conv_algo && net->conv[n0].wino && !dry) {
                 // skip + upsample2x(prev) as one HBM pass, then the Winograd conv over the materialised sum
                 if (prof_begin(net, n0 + ".up", "upsample2_add", 0.0, st)) return 1;

@@ -42,6 +42,7 @@ struct ConvParams {
     long long in_gs, prev_gs, w_gs, bias_gs, resid_gs, out_gs;  // per-group strides in elements
     // conv_wino4p.hip only: `in` / `out` are tile-planar tensors (planar_elems below); blocks per image column / row incl. the guard ring
     int pl_byp, pl_bxp;
+    int level_tag;        // conv_wino4p.hip: 1 = last decoder level, 0 = the level below it -- picks the kernel SYMBOL only (profiler statistics per launch size)
 };
 
 // Tile-planar layout of the decoder's private tensors (conv_wino4p.hip; producer upsample2_add_planar, consumers conv_wino4p and the heads):
@@ -50,7 +51,7 @@ struct ConvParams {
 // exactly what one store instruction of a Winograd wave produces (lane = (tile, channel quad)) and what one patch load of the consumer reads.
 // Every image carries a ring of guard blocks (row / column 0 and BY + 1 / BX + 1) that stay zero, and pixels of edge blocks beyond the image
 // stay zero as well (nobody writes them): the 3x3 convolution's zero padding is DATA, no kernel masks an edge.
-static inline int cerb_planar_blocks(int px) { return (px + 15) / 16 + 2; }
+__host__ __device__ static inline int cerb_planar_blocks(int px) { return (px + 15) / 16 + 2; }
 static inline long long cerb_planar_elems(int n, int h, int w, int c) {
     return (long long)n * cerb_planar_blocks(h) * cerb_planar_blocks(w) * (c / 16) * 4096;
 }

@@ -172,6 +172,9 @@ struct Item {
 };
 }  // namespace
 
+// LEVEL only names the symbol: the launches of the last decoder level (<1>) and of the level below it (<0>, a quarter of the work each) show
+// up as two kernels in a profiler's per-symbol statistics instead of one average over two launch sizes.
+template <int LEVEL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino4p_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -527,9 +530,9 @@ hipError_t cerb_launch_wino4p(ConvParams p, hipStream_t st) {
     if (p.pl_byp != (p.Ho + BLK - 1) / BLK + 2 || p.pl_bxp != (p.Wo + BLK - 1) / BLK + 2) return hipErrorInvalidValue;
     const long long nblk = (long long)p.N * p.tiles_x * p.tiles_y;
     const long long items = (long long)p.groups * ((nblk + 1) / 2) * (p.Cout / 64);
-    auto kern = conv_wino4p_kernel;
-    static bool attr_done[64] = {};
-    if (cerb_attr_needed(attr_done)) {
+    auto kern = p.level_tag ? conv_wino4p_kernel<1> : conv_wino4p_kernel<0>;
+    static bool attr_done[2][64] = {};
+    if (cerb_attr_needed(attr_done[p.level_tag ? 1 : 0])) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + PROF_BYTES);
         if (e != hipSuccess) return e;
     }

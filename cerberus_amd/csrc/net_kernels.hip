@@ -227,6 +227,7 @@ hipError_t cerb_launch_upsample2_add(const float* skip, const float* prev, float
 // wave, 4x4 tile m, channel quad) keeps the tile's 16 skip quads and the 4 x 4 source pixels of `prev` its 16 outputs blend, and every
 // store instruction of a wave is one contiguous 1-KiB row (pixel position (i, j) of the 16 tiles).  Same expressions, same order as
 // upsample2_add_kernel: the values are bit-identical.  Pixels of edge blocks beyond the image are not written (they stay zero).
+template <bool PREV_PLANAR>  // `prev` (half resolution) is NHWC, or tile-planar itself (the level below also runs on conv_wino4p.hip)
 __global__ __launch_bounds__(256) void upsample2_add_planar_kernel(const float* __restrict__ skip, const float* __restrict__ prev, float* __restrict__ out,
                                                                    int groups, int N, int H, int W, long long prev_gs, long long out_gs, int byp, int bxp,
                                                                    int by_lo, int by_cnt, int bx_lo, int bx_cnt) {
@@ -254,14 +255,27 @@ __global__ __launch_bounds__(256) void upsample2_add_planar_kernel(const float* 
             qq[k] = min(max((x0 >> 1) - 1 + k, 0), Wp - 1);
         }
         float* ob = out + ((((long long)n * byp + by + 1) * bxp + bx + 1) * NCC + cc) * 4096 + lane * 4;
+        long long pcol[4];  // PREV_PLANAR: the four source columns' offsets inside a block row (block column, tile column, pixel column)
+        if constexpr (PREV_PLANAR) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pcol[k] = (long long)((qq[k] >> 4) + 1) * NCC * 4096 + ((qq[k] & 3) * 16 + ((qq[k] >> 2) & 3)) * 16;
+        }
+        const int pbyp = cerb_planar_blocks(Hp), pbxp = cerb_planar_blocks(Wp);
         for (int g = 0; g < groups; ++g) {
-            const float* pg = prev + g * prev_gs + (long long)n * Hp * Wp * C + ch;
+            const float* pg = PREV_PLANAR ? prev + g * prev_gs + (long long)cc * 4096 + cq * 4 : prev + g * prev_gs + (long long)n * Hp * Wp * C + ch;
             f32x4 h[4][4];  // h[source row k][output column j]
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float* pr = pg + (long long)rr[k] * Wp * C;
-                const f32x4 p0 = *reinterpret_cast<const f32x4*>(pr + (long long)qq[0] * C), p1 = *reinterpret_cast<const f32x4*>(pr + (long long)qq[1] * C),
-                            p2 = *reinterpret_cast<const f32x4*>(pr + (long long)qq[2] * C), p3 = *reinterpret_cast<const f32x4*>(pr + (long long)qq[3] * C);
+                f32x4 p0, p1, p2, p3;
+                if constexpr (PREV_PLANAR) {  // cerb_planar_offset(n, rr[k], qq[.], cc, ...) split into its row and column parts
+                    const float* pr = pg + (((long long)n * pbyp + (rr[k] >> 4) + 1) * pbxp) * NCC * 4096 + (((rr[k] & 3) << 2) * 16 + (((rr[k] >> 2) & 3) << 2)) * 16;
+                    p0 = *reinterpret_cast<const f32x4*>(pr + pcol[0]); p1 = *reinterpret_cast<const f32x4*>(pr + pcol[1]);
+                    p2 = *reinterpret_cast<const f32x4*>(pr + pcol[2]); p3 = *reinterpret_cast<const f32x4*>(pr + pcol[3]);
+                } else {
+                    const float* pr = pg + (long long)rr[k] * Wp * C;
+                    p0 = *reinterpret_cast<const f32x4*>(pr + (long long)qq[0] * C); p1 = *reinterpret_cast<const f32x4*>(pr + (long long)qq[1] * C);
+                    p2 = *reinterpret_cast<const f32x4*>(pr + (long long)qq[2] * C); p3 = *reinterpret_cast<const f32x4*>(pr + (long long)qq[3] * C);
+                }
                 h[k][0] = blend2(0.25f, p0, 0.75f, p1);
                 h[k][1] = blend2(0.75f, p1, 0.25f, p2);
                 h[k][2] = blend2(0.25f, p1, 0.75f, p2);
@@ -283,7 +297,7 @@ __global__ __launch_bounds__(256) void upsample2_add_planar_kernel(const float* 
 
 // roi = {y0, y1, x0, x1} in output pixels (nullptr or empty = the whole map): the 16 x 16 blocks overlapping it are written whole
 hipError_t cerb_launch_upsample2_add_planar(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C, long long prev_gs,
-                                            long long out_gs, const int* roi, hipStream_t st) {
+                                            long long out_gs, const int* roi, int prev_planar, hipStream_t st) {
     if (C != 64 || (H & 3) || (W & 3)) return hipErrorInvalidValue;
     int by_lo = 0, by_hi = (H + 15) / 16, bx_lo = 0, bx_hi = (W + 15) / 16;
     if (roi && roi[1] > roi[0] && roi[3] > roi[2]) {
@@ -293,7 +307,8 @@ hipError_t cerb_launch_upsample2_add_planar(const float* skip, const float* prev
     const long long nblk = (long long)N * (by_hi - by_lo) * (bx_hi - bx_lo);
     if (nblk <= 0 || nblk >= (1ll << 31)) return hipErrorInvalidValue;
     long long blocks = nblk < 256 * 16 ? nblk : 256 * 16;
-    hipLaunchKernelGGL(upsample2_add_planar_kernel, dim3((unsigned)blocks), dim3(256), 0, st, skip, prev, out, groups, N, H, W, prev_gs, out_gs,
+    auto kern = prev_planar ? upsample2_add_planar_kernel<true> : upsample2_add_planar_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, skip, prev, out, groups, N, H, W, prev_gs, out_gs,
                        cerb_planar_blocks(H), cerb_planar_blocks(W), by_lo, by_hi - by_lo, bx_lo, bx_hi - bx_lo);
     return hipGetLastError();
 }

@@ -16,7 +16,7 @@ timeout -k 5 200 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f -- python bench.p
 timeout -k 5 200 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w -- python bench.py --mode batch --no-cpu-baseline --steps 5 --warmup 1 > $OUT/write.log 2>&1
 python scripts/rocprof_summary.py pmc "$(find $OUT/fetch -name '*.db' | head -1)" "$(find $OUT/write -name '*.db' | head -1)" $OUT/pmc_hbm.json
 rm -rf $OUT/stats $OUT/bstats $OUT/fetch $OUT/write
-scripts/dev_pmc_any.sh "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY;SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_LDS;TCP_PENDING_STALL_CYCLES TCP_GATE_EN1 TCP_TCC_READ_REQ_sum;TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "conv_wino4p|head_group" > $OUT/sq_counters.txt 2>&1
+scripts/dev_pmc_any.sh "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY;SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_LDS;TCP_PENDING_STALL_CYCLES TCP_GATE_EN1 TCP_TCC_READ_REQ_sum;TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "conv_wino4p|head_group|upsample2_add_planar" > $OUT/sq_counters.txt 2>&1
 head -8 $OUT/batch32_kernel_stats.txt
 tail -1 $OUT/bench_under_rocprof.json | cut -c1-300
 cat $OUT/sq_counters.txt | head -60
