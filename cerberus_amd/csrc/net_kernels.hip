@@ -286,10 +286,17 @@ __global__ __launch_bounds__(256) void upsample2_add_planar_kernel(const float* 
             for (int j = 0; j < 4; ++j) {
                 const f32x4 u0 = blend2(0.25f, h[0][j], 0.75f, h[1][j]), u1 = blend2(0.75f, h[1][j], 0.25f, h[2][j]), u2 = blend2(0.25f, h[1][j], 0.75f, h[2][j]),
                             u3 = blend2(0.75f, h[2][j], 0.25f, h[3][j]);
+#ifndef UPP_PLAIN_STORE
                 __builtin_nontemporal_store(sk[0][j] + u0, reinterpret_cast<f32x4*>(og + (0 * 4 + j) * 256));
                 __builtin_nontemporal_store(sk[1][j] + u1, reinterpret_cast<f32x4*>(og + (1 * 4 + j) * 256));
                 __builtin_nontemporal_store(sk[2][j] + u2, reinterpret_cast<f32x4*>(og + (2 * 4 + j) * 256));
                 __builtin_nontemporal_store(sk[3][j] + u3, reinterpret_cast<f32x4*>(og + (3 * 4 + j) * 256));
+#else
+                *reinterpret_cast<f32x4*>(og + (0 * 4 + j) * 256) = sk[0][j] + u0;
+                *reinterpret_cast<f32x4*>(og + (1 * 4 + j) * 256) = sk[1][j] + u1;
+                *reinterpret_cast<f32x4*>(og + (2 * 4 + j) * 256) = sk[2][j] + u2;
+                *reinterpret_cast<f32x4*>(og + (3 * 4 + j) * 256) = sk[3][j] + u3;
+#endif
             }
         }
     }
@@ -306,7 +313,10 @@ hipError_t cerb_launch_upsample2_add_planar(const float* skip, const float* prev
     }
     const long long nblk = (long long)N * (by_hi - by_lo) * (bx_hi - bx_lo);
     if (nblk <= 0 || nblk >= (1ll << 31)) return hipErrorInvalidValue;
-    long long blocks = nblk < 256 * 16 ? nblk : 256 * 16;
+#ifndef UPP_GRID
+#define UPP_GRID 16
+#endif
+    long long blocks = nblk < 256 * UPP_GRID ? nblk : 256 * UPP_GRID;
     auto kern = prev_planar ? upsample2_add_planar_kernel<true> : upsample2_add_planar_kernel<false>;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, skip, prev, out, groups, N, H, W, prev_gs, out_gs,
                        cerb_planar_blocks(H), cerb_planar_blocks(W), by_lo, by_hi - by_lo, bx_lo, bx_hi - bx_lo);
