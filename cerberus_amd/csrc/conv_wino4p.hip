@@ -266,6 +266,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     f32x2 d[6][6];  // raw patch of the NEXT chunk (two channels), transformed in place in the shadow of the matrix pipe
     auto issue = [&](__amdgpu_buffer_rsrc_t r, int chunk_off, int rr, int qq) __attribute__((always_inline)) {
         const int ii = rr == 0 ? 3 : rr == 5 ? 0 : rr - 1, jj = qq == 0 ? 3 : qq == 5 ? 0 : qq - 1;
+#ifdef P4_ABL_NOCORNER   // ablation: the four corner pixels of the patch (the loads whose lanes reach into up to four different blocks) are not requested
+        if ((rr == 0 || rr == 5) && (qq == 0 || qq == 5)) return;
+#endif
+#ifdef P4_ABL_NOEDGE     // ablation: no halo pixel at all, the interior only
+        if (rr == 0 || rr == 5 || qq == 0 || qq == 5) return;
+#endif
+#ifdef P4_ABL_HALOOWN   // ablation: every halo pixel is read from the lane's OWN tile (same instruction count, no lane leaves the block or its tile's row)
+        d[rr][qq] = buf_load2(r, poff[1][1], chunk_off + (ii * 4 + jj) * 1024);
+        return;
+#endif
+#ifdef P4_ABL_CORNEROWN
+        if ((rr == 0 || rr == 5) && (qq == 0 || qq == 5)) { d[rr][qq] = buf_load2(r, poff[1][1], chunk_off + (ii * 4 + jj) * 1024); return; }
+#endif
         d[rr][qq] = buf_load2(r, poff[rr == 0 ? 0 : rr == 5 ? 2 : 1][qq == 0 ? 0 : qq == 5 ? 2 : 1], chunk_off + (ii * 4 + jj) * 1024);
     };
     // B^T x for the points (0, 1, -1, 2, -2, inf), in place: 12 packed operations (conv_wino4.hip: written by hand, hipcc scalarises them)
