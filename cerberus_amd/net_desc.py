@@ -404,7 +404,7 @@ class NetDesc(torch.nn.Module):
         _lib.check(_lib.lib().cerb_net_set_conv_algo(self._ensure_handle(), int(algo)))
 
     def set_planar(self, enable=True):
-        """Last decoder level in the tile-planar layout (conv_wino4p.hip; default on) or NHWC (conv_wino4.hip): bit-identical outputs."""
+        """The two last decoder levels in the tile-planar layout (conv_wino4p.hip; default on) or NHWC (conv_wino4.hip): bit-identical outputs."""
         _lib.check(_lib.lib().cerb_net_set_planar(self._ensure_handle(), int(bool(enable))))
 
     def set_crop_roi(self, enable=True):

@@ -86,7 +86,8 @@ int cerb_net_forward(cerb_net* net, const cerb_forward_io* io, void* hip_stream)
  * outside the product library.)
  * The training step follows the same rule for its forward and data-gradient convolutions (filter transform on the device). */
 int cerb_net_set_conv_algo(cerb_net* net, int algo);
-/* Layout of the LAST decoder level's private tensors (skip + upsample, first conv output, head features; models/net_desc.py:182-198):
+/* Layout of the private tensors (skip + upsample, first conv output, level output / head features; models/net_desc.py:182-198) of the LAST
+ * decoder level and of the level below it (both 64 channels; a level takes part when its maps are above 64 x 64 pixels):
  *   1 (default) = tile-planar (cerb_common.h: cerb_planar_offset) through upsample2_add_planar -> conv_wino4p.hip x2 -> heads: a Winograd
  *                 wave's stores are contiguous 1-KiB rows and its patch loads whole lines, zero padding is data;
  *   0           = NHWC through conv_wino4.hip (round 2's path).
