@@ -54,8 +54,12 @@ __device__ __forceinline__ f32x4 splat4(float x) {
 template <int KS, int STRIDE, int TH, int TW, int CB, int MODE>
 struct ConvCfg {
     static constexpr int PAD = KS / 2;
-    static constexpr int IH = (TH - 1) * STRIDE + KS;
-    static constexpr int IW = (TW - 1) * STRIDE + KS;
+    // A strided 1x1 convolution only ever reads the pixels its outputs sit on: it stages THOSE (every STRIDE-th pixel of every STRIDE-th row, a
+    // TH x TW tile) instead of the whole (TH-1)*STRIDE+1 window -- a quarter of the loads and of the LDS tile at stride 2.
+    static constexpr int GSTEP = (KS == 1) ? STRIDE : 1;  // global pixels between neighbouring staged pixels
+    static constexpr int LSTEP = (KS == 1) ? 1 : STRIDE;  // staged pixels between neighbouring output pixels
+    static constexpr int IH = (KS == 1) ? TH : (TH - 1) * STRIDE + KS;
+    static constexpr int IW = (KS == 1) ? TW : (TW - 1) * STRIDE + KS;
     static constexpr int PS = CB + 4;  // LDS pixel stride in floats (16-lane ds_read_b128 groups hit distinct 16-B slots)
     static constexpr int NG = CB / 8;  // 8-channel groups per chunk
     static constexpr int T = KS * KS;  // taps
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     };
     auto touches_border = [&](const Item& w) {  // some halo / tile element lies outside the image -> masked LDS write
         const int y0 = w.oy0 * STRIDE - C::PAD, x0 = w.ox0 * STRIDE - C::PAD;
-        return y0 < 0 || x0 < 0 || y0 + C::IH > p.H || x0 + C::IW > p.W;
+        return y0 < 0 || x0 < 0 || y0 + (C::IH - 1) * C::GSTEP + 1 > p.H || x0 + (C::IW - 1) * C::GSTEP + 1 > p.W;
     };
 
     // ---- per-lane invariants, computed ONCE ------------------------------------------------------------------------------
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
         for (int s = 0; s < C::ITER; ++s) {
             const int f = min(tid + s * 256, C::NF - 1);  // the tail of the last slice re-reads the last element (never written)
             const int pix = f / C::PARTS, part = f % C::PARTS;
-            soff[s] = (unsigned)((((pix / C::IW) * p.W + (pix % C::IW)) * p.Cin + part * 4) * 4);
+            soff[s] = (unsigned)((((pix / C::IW) * C::GSTEP * p.W + (pix % C::IW) * C::GSTEP) * p.Cin + part * 4) * 4);
         }
         ldsw0 = (tid / C::PARTS) * C::PS + (tid % C::PARTS) * 4;  // slice s: + s*PPS*PS
     }
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     for (int q = 0; q < 2; ++q) {
         const int pl = (wave * 2 + q) * 32 + j;
         const int py = pl / TW, px = pl % TW;
-        ldsb[q] = ((py * STRIDE) * C::IW + px * STRIDE) * C::PS + 4 * h;
+        ldsb[q] = ((py * C::LSTEP) * C::IW + px * C::LSTEP) * C::PS + 4 * h;
         ooff[q] = (unsigned)(((py * p.Wo + px) * p.Cout + 4 * h) * 4);
     }
     float* aux = lds + C::MAIN_FLOATS;
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
         } else {
 #pragma unroll
             for (int s = 0; s < C::ITER; ++s) {
-                const int gy = w.oy0 * STRIDE - C::PAD + slice_iy(s), gx = w.ox0 * STRIDE - C::PAD + slice_ix(s);
+                const int gy = w.oy0 * STRIDE - C::PAD + slice_iy(s) * C::GSTEP, gx = w.ox0 * STRIDE - C::PAD + slice_ix(s) * C::GSTEP;
                 const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 if (slice_live(s)) *reinterpret_cast<f32x4*>(slice_ptr(s)) = ok ? v[s] : z;
