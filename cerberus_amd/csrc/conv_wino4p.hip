@@ -143,6 +143,26 @@ __device__ __forceinline__ void mfma_step(f32x4& c0, f32x4& c1, const f32x4& av,
 #undef P4_STEP_BODY
 #undef P4_STEP_IN
 }
+// P4_ILV experiment: one k-slot of a step (two matrix instructions) as its own statement, so that the step's memory instructions can sit
+// BETWEEN the pairs, in the shadow of a running matrix instruction, instead of in front of all eight.
+//   0 (default): eight matrix instructions in one statement, everything else before them
+//   1: weight load / operand reads / patch loads between the pairs;   3: and the V writes of the row transformed a step earlier
+// Measured A-B-C-A-C on one box (scripts/dev_ilvab.sh): 4.27-4.38 ms (0) against 4.31-4.35 ms (3) for the two launches -- inside the
+// run-to-run spread; the same rearrangement of conv_wino4b.hip's 16-instruction step: 2.71-2.74 against 2.71-2.72.  Where the instructions
+// of a step sit relative to its matrix instructions is not what the wave waits for.
+#ifndef P4_ILV
+#define P4_ILV 0
+#endif
+template <bool AGPR, bool ZERO>
+__device__ __forceinline__ void mfma_pair(f32x4& c0, f32x4& c1, float a, float b0, float b1) {
+    if constexpr (ZERO) {
+        if constexpr (AGPR) asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %3, 0\n\tv_mfma_f32_16x16x4_f32 %1, %2, %4, 0" : "=&a"(c0), "=&a"(c1) : "v"(a), "v"(b0), "v"(b1));
+        else asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %3, 0\n\tv_mfma_f32_16x16x4_f32 %1, %2, %4, 0" : "=&v"(c0), "=&v"(c1) : "v"(a), "v"(b0), "v"(b1));
+    } else {
+        if constexpr (AGPR) asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %3, %0\n\tv_mfma_f32_16x16x4_f32 %1, %2, %4, %1" : "+a"(c0), "+a"(c1) : "v"(a), "v"(b0), "v"(b1));
+        else asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %3, %0\n\tv_mfma_f32_16x16x4_f32 %1, %2, %4, %1" : "+v"(c0), "+v"(c1) : "v"(a), "v"(b0), "v"(b1));
+    }
+}
 __device__ __forceinline__ void wait_mfma_results() { asm volatile("s_nop 15\n\ts_nop 3"); }  // 8-pass MFMA D -> VALU reader: 12 states and more
 
 // the hardware lane id, computed where it is used (volatile: not hoisted out of the item loop): a lane-invariant kept in a register across the
@@ -390,6 +410,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef P4_PROF
                 if (ch < 15) P4_STAMP(ch, q);
 #endif
+#if P4_ILV
+                {   // the step's memory instructions between the pairs of its matrix instructions
+                    const f32x4 av = wq[q % RING];
+                    const f32x4 b0 = bb[q & 1][0], b1 = bb[q & 1][1];
+                    constexpr bool ZR = FIRST && xi != BIAS_XI;
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_pair<AG, ZR>(acc[xi][0], acc[xi][1], av[0], b0[0], b1[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+#ifndef P4_ABL_NOWLOAD
+                if constexpr (q % WB == 0) {
+#pragma unroll
+                    for (int dd = q + WD; dd < q + WD + WB; ++dd) {
+                        if (FIRST && dd < PRE) continue;  // requested before the previous item's stores (or in the prologue)
+                        if (dd < NS) wq[dd % RING] = buf_load(rw, wlane, wcur_off + dd * 1024);
+                        else wq[(dd - NS) % RING] = buf_load(rw_over, wlane, wover_off + (dd - NS) * 1024);
+                    }
+                }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_pair<AG, false>(acc[xi][0], acc[xi][1], av[1], b0[1], b1[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                if constexpr (q + 1 < NS) {
+                    bb[(q + 1) & 1][0] = *reinterpret_cast<const f32x4*>(vsrc + (q + 1) * NT * CB);
+                    bb[(q + 1) & 1][1] = *reinterpret_cast<const f32x4*>(vsrc + (q + 1) * NT * CB + 16 * CB);
+                }
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_pair<AG, false>(acc[xi][0], acc[xi][1], av[2], b0[2], b1[2]);
+                    __builtin_amdgcn_sched_barrier(0);
+#if P4_ILV == 3   // the V writes of the row transformed a step ago, too (its registers take the interior loads right after)
+                if constexpr (q > TQ + 7 && q <= TQ + 13) write_row(wbuf, q - TQ - 8);
+#endif
+#ifndef P4_ABL_NOPATCH
+                if constexpr (q >= HQ && q < HQ + 10) {  // halo of the next chunk's patch, two pixels per step
+                    issue(r_stage, stage_off, halo_r(2 * (q - HQ)), halo_q(2 * (q - HQ)));
+                    issue(r_stage, stage_off, halo_r(2 * (q - HQ) + 1), halo_q(2 * (q - HQ) + 1));
+                }
+#endif
+#ifndef P4_ABL_NOPATCH
+                if constexpr (q >= TQ + 9 && q <= TQ + 12) {  // row q - TQ - 8 was written a step ago: its registers take the interior of the chunk after next
+#pragma unroll
+                    for (int u = 1; u <= 4; ++u) issue(r_stage2, stage_off2, q - TQ - 8, u);
+                }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_pair<AG, false>(acc[xi][0], acc[xi][1], av[3], b0[3], b1[3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                // the next chunk's patch landed: B^T d B (one 1-D pass per step) and the V writes into the OTHER buffer
+#ifndef P4_ABL_NOXF
+                if constexpr (q > TQ && q <= TQ + 6) pass_v(q - TQ - 1);
+                if constexpr (q > TQ + 6 && q <= TQ + 12) pass_h(q - TQ - 7);
+#endif
+#if defined(P4_ABL_VWRITE_FAKE)
+                if constexpr (q > TQ + 6 && q <= TQ + 12) { if (p.N < 0) write_row(wbuf, q - TQ - 7); }  // everything upstream stays alive, nothing is written
+#elif !defined(P4_ABL_NOVWRITE)
+                if constexpr (P4_ILV != 3 && q > TQ + 6 && q <= TQ + 12) write_row(wbuf, q - TQ - 7);
+#endif
+                }
+#else
 #ifndef P4_ABL_NOWLOAD
                 if constexpr (q % WB == 0) {
 #pragma unroll
@@ -430,6 +508,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const f32x4 av = wq[q % RING];
                 const f32x4 b0 = bb[q & 1][0], b1 = bb[q & 1][1];
                 mfma_step<AG, FIRST && xi != BIAS_XI>(acc[xi][0], acc[xi][1], av, b0, b1);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             });
 #ifndef P4_ABL_NOBAR
