@@ -464,7 +464,7 @@ def test_winograd_partial_tiles_and_odd_blocks_vs_direct(full_model, win, osz, n
         m.set_conv_algo(DEFAULT_ALGO)
 
 
-@pytest.mark.parametrize("win,osz,n", [(256, 256, 3), (448, 144, 2), (272, 272, 2), (304, 144, 3), (96, 96, 5), (208, 80, 2)])
+@pytest.mark.parametrize("win,osz,n", [(256, 256, 3), (448, 144, 2), (272, 272, 2), (304, 144, 3), (96, 96, 5), (208, 80, 2), (256, 256, 40)])  # 40 tiles: planar tensors beyond 4 GiB
 def test_planar_last_level_is_bit_identical_to_nhwc(full_model, win, osz, n):
     """cerb_net_set_planar(1) (default): the last decoder level in the tile-planar layout (upsample2_add_planar -> conv_wino4p x2 -> heads
     reading planar features) against cerb_net_set_planar(0) (round 2's NHWC path through conv_wino4): same arithmetic in the same order,
