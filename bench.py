@@ -239,6 +239,7 @@ def train_leg(args, model, dev, dist, world, rank, sd=None, kw=None):
             },
             "roofline": roofline,
             "kernels": fam_rows,
+            "multi_gpu": dict(args.identity),
             "cpu_baseline": cpu_baseline_train(sd, kw) if (world == 1 and sd is not None and not args.no_cpu_baseline) else None,
         }), flush=True)
     if dist is not None:
@@ -437,14 +438,10 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
         x = torch.zeros(1024, device=dev)
         lst = [torch.zeros_like(x) for _ in range(world)] if rank == 0 else None
         dist.gather(x, lst, dst=0)
-        ops = []
-        if rank > 0:
-            ops += [dist.P2POp(dist.isend, x, rank - 1), dist.P2POp(dist.irecv, torch.zeros_like(x), rank - 1)]
-        if rank < world - 1:
-            ops += [dist.P2POp(dist.isend, x, rank + 1), dist.P2POp(dist.irecv, torch.zeros_like(x), rank + 1)]
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        from cerberus_amd.shard_postproc import halo_exchange
+
+        with args.watch.phase("warm-up halo exchange (opens the neighbour channels)"):
+            halo_exchange(dist, rank, world, x, x.clone(), torch.zeros_like(x) if rank > 0 else None, torch.zeros_like(x) if rank < world - 1 else None)
     # ... and one untimed full-size tail: the first labelling of a slide-sized map pays for the allocator's first touch of the label /
     # table buffers (hipMalloc of several GB: 1.1 s against 0.34 s for every later slide of a run_infer_wsi.py session); like the W warm-up
     # stripes it computes everything again in the timed region -- nothing is cached but the memory blocks
@@ -463,7 +460,7 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
         t1 = time.perf_counter()
         canv = OrderedDict(struct)
         inst, info, small = postprocess_bands_and_gather(run, H, W, rank, world, dist, margin=MARGINS, guard=48, canv=canv, max_band_px=max_band_px,
-                                                         prof=prof)
+                                                         prof=prof, watch=args.watch)
         torch.cuda.synchronize()
         phase["tail_s"] = time.perf_counter() - t1
         res.update(inst=inst, info=info)
@@ -502,9 +499,9 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
             pp[t]["Gpx_s"] = round(pp[t]["band_px"] / e["s"] / 1e9, 3)
             pp[t]["hbm_frac_of_8TBs_at_12B_px"] = round(12.0 * pp[t]["band_px"] / e["s"] / 8e12, 5)
             pp[t].update(checks.get(t, {}))
-    mg = None
+    mg = dict(args.identity)
     if dist is not None:
-        mg = {"peak_GB_s_per_xgmi_link": XGMI_LINK_GBS, "rank": 0}
+        mg.update({"peak_GB_s_per_xgmi_link": XGMI_LINK_GBS, "rank": 0})
         for key in ("halo_exchange", "root_gather"):
             e = prof.get(key)
             if e:
@@ -588,30 +585,37 @@ def main():
                          "the nccl test of tests/test_cli_gpu.py")
     ap.add_argument("--planar", type=int, default=1, help="last decoder level in the tile-planar layout (1, default: conv_wino4p.hip) or NHWC (0: conv_wino4.hip, round 2's path) -- A/B")
     ap.add_argument("--backend", default="nccl", help='torch.distributed backend ("nccl" = RCCL over xGMI; "gloo" only for plumbing tests)')
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="with --backend gloo only: let the N self-spawned ranks time-share fewer than N devices (plumbing tests on a one-GPU box); "
+                         "RCCL needs one device per rank and never oversubscribes")
     args = ap.parse_args()
 
+    # `--gpus N` without a launcher: re-execute N ranks (one per device, rendezvous on 127.0.0.1) -- or exit non-zero when N devices are not
+    # there.  Under torch.distributed.run WORLD_SIZE must agree with --gpus.  A line with n_gpus < --gpus is never printed.
+    from cerberus_amd import launch
+
+    launch.ensure_world(args.gpus, args.backend, oversubscribe=args.oversubscribe)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:  # (ensure_world has already refused; kept as the last line of defence)
+        sys.exit("error: --gpus %d but world size %d" % (args.gpus, world))
     dist = None
+    args.watch = launch.null_watch()
     if world > 1 or args.force_dist:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        local_rank = local_rank % max(1, torch.cuda.device_count())
+        n_dev = max(1, torch.cuda.device_count())
+        if args.backend == "nccl" and world > n_dev:
+            sys.exit("error: %d ranks but %d visible GPU(s): RCCL needs one device per rank" % (world, n_dev))
+        local_rank = local_rank % n_dev
         torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            from cerberus_amd.hostdist import HostStagedDist
-
-            dist.init_process_group(args.backend)
-            dist = HostStagedDist(dist)
+        dist = launch.init_dist(args.backend, local_rank)
+        args.watch = launch.PhaseWatch(rank)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    with args.watch.phase("rank identity all-gather (first collective on the communicator)"):
+        args.identity = launch.rank_identity(dist, dev, args.backend)
+    if dist is not None and args.identity["world"] != world:
+        sys.exit("error: the communicator spans %d ranks, the launcher said %d" % (args.identity["world"], world))
 
     from cerberus_amd.net_desc import create_model
     from cerberus_amd.weights import default_model_kwargs, make_state_dict
@@ -640,7 +644,7 @@ def main():
                            "batch_tiles": BATCH, "tile": TILE, "gflop_per_tile": round(flops_step / BATCH / 1e9, 3),
                            "whole_step_tflops": round(flops_step / (dt / args.steps) / 1e12 * world, 2),
                            "parallelism": "tile-sharded x%d, no data-path collective" % world},
-                "roofline": roofline, "kernels": rows,
+                "roofline": roofline, "kernels": rows, "multi_gpu": dict(args.identity),
             }
             if world == 1 and not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(sd, kw)

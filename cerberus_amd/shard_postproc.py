@@ -191,29 +191,50 @@ def _tock(prof):
 
 
 def run_distributed(band, y0_global, tissue, margin, guard, dist, ds_factor=1.0, label_fn=_device_label_fn,
-                    table_fn=_device_table_fn, relabel_fn=_device_relabel_fn, prof=None):
+                    table_fn=_device_table_fn, relabel_fn=_device_relabel_fn, prof=None, watch=None):
     """One rank of the real thing.  `dist` = torch.distributed (initialised).  Returns (band labels with global ids,
-    total instance count over all ranks, info dict)."""
+    total instance count over all ranks, info dict).  watch: a launch.PhaseWatch -- a collective that does not return ends the rank with
+    the name of the phase it was in."""
+    from .launch import null_watch
+
+    watch = watch or null_watch()
     rank, world = dist.get_rank(), dist.get_world_size()
     st = BandState(rank, world, band, y0_global, margin, guard, tissue, ds_factor)
     up, down = st.strips()
     above = torch.empty_like(up) if rank > 0 else None
     below = torch.empty_like(down) if rank < world - 1 else None
-    ops = []
-    if rank > 0:
-        ops += [dist.P2POp(dist.isend, up, rank - 1), dist.P2POp(dist.irecv, above, rank - 1)]
-    if rank < world - 1:
-        ops += [dist.P2POp(dist.isend, down, rank + 1), dist.P2POp(dist.irecv, below, rank + 1)]
     t0 = _tock(prof)
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+    with watch.phase("halo exchange (%s)" % tissue):
+        halo_exchange(dist, rank, world, up, down, above, below)
     _tick(prof, "halo_exchange", sum(t.numel() * t.element_size() for t in (above, below) if t is not None), t0)
     t0 = _tock(prof)
-    n_owned = st.label(above, below, label_fn, table_fn)
+    with watch.phase("band labelling (%s)" % tissue):
+        n_owned = st.label(above, below, label_fn, table_fn)
     _tick(prof, "label_" + tissue, 0, t0)
     t0 = _tock(prof)
-    dev = band.device
+    with watch.phase("instance-count / border-id all-gathers (%s)" % tissue):
+        out, total, info = _publish_and_resolve(st, n_owned, band.device, dist, rank, world, relabel_fn)
+    _tick(prof, "ids_" + tissue, 0, t0)
+    return out, total, info
+
+
+def halo_exchange(dist, rank, world, up, down, above, below):
+    """Neighbour strips over point-to-point links, in two rounds of disjoint PAIRS: round 0 pairs (0,1), (2,3), ..., round 1 pairs (1,2),
+    (3,4), ...  In a round a rank talks to at most one peer and posts its send and its receive in one group, so no rank ever posts a send
+    whose matching receive sits behind another blocking operation -- the pattern cannot deadlock whatever the backend's ordering rules
+    (RCCL groups, gloo's per-pair queues), and adjacent pairs use different xGMI links at the same time."""
+    for rnd in (0, 1):
+        ops = []
+        if rank % 2 == rnd and rank < world - 1:      # lower rank of the pair (rank, rank + 1)
+            ops = [dist.P2POp(dist.isend, down, rank + 1), dist.P2POp(dist.irecv, below, rank + 1)]
+        elif rank % 2 != rnd and rank > 0:            # upper rank of the pair (rank - 1, rank)
+            ops = [dist.P2POp(dist.irecv, above, rank - 1), dist.P2POp(dist.isend, up, rank - 1)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+
+def _publish_and_resolve(st, n_owned, dev, dist, rank, world, relabel_fn):
     cnt = torch.tensor([n_owned], dtype=torch.int64, device=dev)
     allc = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(allc, cnt)
@@ -234,7 +255,6 @@ def run_distributed(band, y0_global, tissue, margin, guard, dist, ds_factor=1.0,
     pubs = [allp[r][: lens[r]].cpu().numpy() for r in range(rank)]
     out, info = st.resolve(pubs, relabel_fn)
     info["n_total"] = int(offs[-1])
-    _tick(prof, "ids_" + tissue, 0, t0)
     return out, int(offs[-1]), info
 
 
@@ -255,8 +275,10 @@ def same_partition(a, b):
 def local_band_count(rows, cols, max_band_px, margin=0):
     """How many row bands a (rows x cols) canvas is labelled in on ONE GPU so that no labelling CALL exceeds max_band_px pixels (workspace =
     96 B / px, and H*W < 2^31 per call): 1 when it fits.  A local band is labelled together with `margin` halo rows on each side, so the
-    rows it may own are max_band_px / cols - 2 * margin; every band is at least two margins tall (an instance crossing a cut must end inside
-    the neighbour's halo).  A canvas so wide that even such a band exceeds the limit cannot be banded by rows: that is an error here, not a
+    rows it may own are `own` = max_band_px / cols - 2 * margin, required to be at least two margins; the canvas is then cut into
+    nb = ceil(rows / own) bands of equal height (+- 1 row), each therefore taller than own / 2 >= ONE margin -- the invariant the protocol
+    needs (an instance crossing a cut ends inside the neighbour's halo and cannot reach that neighbour's other cut; BandState asserts
+    band >= margin).  A canvas so wide that even such a band exceeds the limit cannot be banded by rows: that is an error here, not a
     failure inside the C call."""
     if not max_band_px or rows * cols <= max_band_px:
         return 1
@@ -265,10 +287,12 @@ def local_band_count(rows, cols, max_band_px, margin=0):
         raise ValueError("a %d-pixel-wide map cannot be labelled in row bands of at most %d pixels with a %d-row halo on each side: a band of two "
                          "margins plus its halos already has %d pixels (raise max_band_px or lower the margin)"
                          % (cols, int(max_band_px), int(margin), 4 * int(margin) * cols))
-    return int(-(-rows // own))
+    nb = int(-(-rows // own))
+    assert rows // nb >= int(margin), "internal: a local band shorter than its margin"
+    return nb
 
 
-def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guard=48, max_band_px=None, prof=None):
+def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guard=48, max_band_px=None, prof=None, watch=None):
     """Per-rank replacement of WSIRunner.postprocess for band canvases: label maps of THIS rank's band with slide-global
     ids, nothing gathered.  margin: halo rows at full resolution, an int or {tissue: rows, "default": rows} (the reference's
     own nuclei margin is 64 px, infer/wsi.py:906-915; gland clusters need hundreds).  canv: the band canvases of this rank (full-resolution rows of equal count on every rank except
@@ -284,7 +308,10 @@ def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guar
     cnt = torch.tensor([rows], dtype=torch.int64, device=next(iter(canv.values())).device)
     allr = [torch.zeros_like(cnt) for _ in range(world)]
     if dist is not None:
-        dist.all_gather(allr, cnt)
+        from .launch import null_watch
+
+        with (watch or null_watch()).phase("band-height all-gather"):
+            dist.all_gather(allr, cnt)
     else:
         allr = [cnt]
     y0 = int(sum(int(x.item()) for x in allr[:rank]))
@@ -297,7 +324,7 @@ def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guar
         mt = margin.get(t, margin.get("default", 512)) if isinstance(margin, dict) else margin  # per-tissue halo: nuclei need far less than glands
         m, g, yy, ds = (mt // 2, guard // 2, y0 // 2, 0.5) if half else (mt, guard, y0, 1.0)
         if dist is not None:  # also at world == 1 when the caller initialised a process group (bench.py --force-dist, the nccl test)
-            inst[t], _, info[t] = run_distributed(band, yy, t, m, g, dist, ds, prof=prof)
+            inst[t], _, info[t] = run_distributed(band, yy, t, m, g, dist, ds, prof=prof, watch=watch)
         else:
             t0 = _tock(prof)
             nb = local_band_count(int(band.shape[0]), int(band.shape[1]), max_band_px, m)  # (half-resolution maps: their own pixel count, halved margin)
@@ -326,7 +353,7 @@ def _gather_rows(lab, rows_per_rank, cols, dist, rank, world):
     return torch.cat([lst[i][: rows_per_rank[i]] for i in range(world)], dim=0)
 
 
-def postprocess_bands_and_gather(run, H, W, rank, world, dist, margin=512, guard=48, canv=None, max_band_px=None, prof=None):
+def postprocess_bands_and_gather(run, H, W, rank, world, dist, margin=512, guard=48, canv=None, max_band_px=None, prof=None, watch=None):
     """The tail of a slide on 1..N GPUs: band-local label maps with slide-global ids, then only the int32 label bands and the
     uint8 / float class canvases travel to the root (12 + 3 B/px instead of the 36 B/px of raw probability canvases).
     `run` is this rank's WSIRunner after infer_band.  Returns (inst, info, small) -- inst / small are None off the root.
@@ -338,22 +365,27 @@ def postprocess_bands_and_gather(run, H, W, rank, world, dist, margin=512, guard
     src = run.canv if canv is None else canv
     valid = max(0, min(run.band_h, H - run.r0 * geo.out))
     band = OrderedDict((k, v[:valid, :W]) for k, v in src.items())
-    inst_b, info = sharded_postprocess(band, rank, world, dist, wsi_mode=True, margin=margin, guard=guard, max_band_px=max_band_px, prof=prof)
+    inst_b, info = sharded_postprocess(band, rank, world, dist, wsi_mode=True, margin=margin, guard=guard, max_band_px=max_band_px, prof=prof, watch=watch)
     bounds = geo.bounds(world)
     rows = [max(0, min((bounds[i + 1] - bounds[i]) * geo.out, H - bounds[i] * geo.out)) for i in range(world)]
     inst = OrderedDict() if rank == 0 else None
     t0 = _tock(prof)
     moved = 0
+    from .launch import null_watch
+
+    watch = watch or null_watch()
     for t, lab in inst_b.items():
         half = t != "Nuclei"
         rr = [half_size(r) for r in rows] if half else rows
         cc = half_size(W) if half else W
-        g = _gather_rows(lab, rr, cc, dist, rank, world)
+        with watch.phase("label-band gather to rank 0 (%s)" % t):
+            g = _gather_rows(lab, rr, cc, dist, rank, world)
         moved += (world - 1) * max(rr) * cc * 4  # what the root receives (every rank pads to the tallest band)
         if rank == 0:
             inst[t] = g
     small_src = OrderedDict((k, v) for k, v in run.canv.items() if not k.endswith("INST"))
-    small = gather_bands(small_src, geo, rank, world, dist)
+    with watch.phase("class-canvas gather to rank 0"):
+        small = gather_bands(small_src, geo, rank, world, dist)
     moved += (world - 1) * sum(v.numel() * v.element_size() for v in small_src.values())
     if dist is not None:
         _tick(prof, "root_gather", moved, t0)
