@@ -6,7 +6,8 @@ import sys
 
 # (flag, takes a value, default, help)
 _COMMON = [
-    ("--gpu", True, "0", "GPU id(s), exported as HIP_VISIBLE_DEVICES when not launched under torch.distributed.run"),
+    ("--gpu", True, "0", "GPU id(s), exported as HIP_VISIBLE_DEVICES when not launched under torch.distributed.run; several ids (`0,1,2`) = one rank per "
+                          "device, self-spawned (cerberus_amd/launch.py): slide bands / the tile file list are sharded over them"),
     ("--model", True, None, "directory holding settings.yml + weights.tar (required unless --synthetic)"),
     ("--synthetic", False, False, "(not in the reference) run on the package's seeded synthetic test weights instead of a checkpoint"),
     ("--nr_inference_workers", True, "0", "accepted for compatibility: tiles are gathered on the device, there is no loader pool"),
@@ -27,7 +28,7 @@ WSI_OPTIONS = _COMMON + [
     ("--wsi_proc_mag", True, "0.5", "microns per pixel recorded in the instance dictionary"),
     ("--wsi_file_ext", True, ".svs", "slide extension: .npy arrays, .png/.jpg images or .txt `synthetic:<H>x<W>:<seed>` specs"),
     ("--cache_path", True, "cache/", "accepted and ignored: there is no memmap cache"),
-    ("--logging_dir", True, "logging/", "accepted and ignored"),
+    ("--logging_dir", True, "logging/", "one <slide>_<date>_std.log per slide and run with its phase timings (rank 0)"),
     ("--input_dir", True, None, "directory of slides (not searched recursively)"),
     ("--msk_dir", True, None, "directory of tissue masks <slide>.png (any resolution); when given, only slides that have a mask are processed"),
     ("--output_dir", True, "output/", "where dat/<slide>.dat, tissue/<slide>.mat (and <slide>.npz with --save_label_maps) are written"),

@@ -270,6 +270,13 @@ class InferManager(object):
             if any(not os.path.exists("%s/%s_mat/%s.mat" % (self.output_dir, t, base)) for t in self.postproc_list):
                 todo.append(fp)
         assert len(todo) > 0, "Not Detected Any Files From Path"
+        # several GPUs (run_infer_tile.py --gpu=0,1,...): the reference splits every batch over the devices (DataParallel, infer/base.py:46);
+        # files are independent, so here rank r of w takes files r, r + w, ... of the sorted list -- no collective, no shared canvas; a tile's
+        # values do not depend on what it is batched with, so the outputs are those of the one-GPU run
+        rank, world = int(getattr(self, "rank", 0)), int(getattr(self, "world_size", 1))
+        todo = todo[rank::world]
+        if not todo:
+            return
         # groups of files share batches (infer/tile.py:300-420 caches several files per DataLoader pass): a group is closed once it
         # holds 8 batches' worth of patches or 64 Mpx of padded pixels
         win, osz = int(self.patch_input_shape), int(self.patch_output_shape)

@@ -4,6 +4,7 @@ pclass_mat/<name>.mat and overlay/<name>.jpg.  Flag names and defaults are the r
 <model>/settings.yml + weights.tar are read as the reference reads them (run_infer_tile.py:47-49 there); --synthetic
 selects the package's seeded test weights instead (this image has no network to fetch a checkpoint)."""
 import os
+import sys
 
 from cerberus_amd.cli import TILE_OPTIONS, parse, require_model
 
@@ -11,9 +12,25 @@ from cerberus_amd.cli import TILE_OPTIONS, parse, require_model
 def main(argv=None):
     args = parse("run_infer_tile.py", TILE_OPTIONS, argv, version="CoBi Gland Inference")
     require_model(args)
-    if args["--gpu"]:
+    if args["--gpu"] and "WORLD_SIZE" not in os.environ:
+        # `--gpu=0,1`: the reference drives both devices from one process (DataParallel, infer/base.py:46-47); here one rank per listed device,
+        # self-spawned (cerberus_amd/launch.py), each taking every w-th file -- or a non-zero exit when the devices are not there
         os.environ["HIP_VISIBLE_DEVICES"] = args["--gpu"]
+        ids = [g for g in args["--gpu"].split(",") if g.strip() != ""]
+        if len(ids) > 1:
+            from cerberus_amd import launch
+
+            launch.ensure_world(len(ids), "gloo" if os.environ.get("CERB_OVERSUBSCRIBE") else "nccl",
+                                argv=[os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv), oversubscribe=bool(os.environ.get("CERB_OVERSUBSCRIBE")))
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     os.makedirs(args["--output_dir"], exist_ok=True)
+    if world > 1:
+        import torch
+
+        n_dev = max(1, torch.cuda.device_count())
+        if world > n_dev and not os.environ.get("CERB_OVERSUBSCRIBE"):
+            raise SystemExit("%d ranks but %d visible GPU(s)" % (world, n_dev))
+        torch.cuda.set_device(local % n_dev)
     from cerberus_amd.tile import InferManager
     from cerberus_amd.weights import DEFAULT_REQ_TARGET_CODE, default_model_kwargs
 
@@ -36,6 +53,8 @@ def main(argv=None):
         "nr_inference_workers": int(args["--nr_inference_workers"]),
         "nr_post_proc_workers": int(args["--nr_post_proc_workers"]),
         "postproc_list": ["gland", "lumen", "nuclei", "patch-class"],
+        "rank": rank,
+        "world_size": world,
     })
 
 

@@ -12,6 +12,7 @@ Multi-GPU: launch under `python -m torch.distributed.run --nproc-per-node N run_
 contiguous band per rank, inference needs no collective, post-processing is band-local (cerberus_amd/shard_postproc.py)."""
 import glob
 import os
+import sys
 import threading
 import time
 
@@ -34,6 +35,31 @@ def _write_then_rename(write, obj, path):
     os.replace(tmp, path)
 
 
+def _slide_logger(log_dir, base):
+    """`<logging_dir>/<slide>_<dd-mm-YYYY_HH:MM:SS>_std.log` with the reference's record format (infer/wsi.py:957-967): phase timings of
+    one slide.  A dedicated logger (the reference attaches the file to the root logger and clears it after the slide)."""
+    import logging
+    from datetime import datetime
+
+    if not log_dir:
+        return None
+    os.makedirs(log_dir, exist_ok=True)
+    lg = logging.getLogger("cerberus_amd.wsi.%s" % base)
+    lg.handlers.clear()
+    lg.propagate = False
+    fh = logging.FileHandler(filename=os.path.join(log_dir, "%s_%s_std.log" % (base, datetime.now().strftime("%d-%m-%Y_%H:%M:%S"))), mode="w")
+    fh.setFormatter(logging.Formatter("%(asctime)s - %(name)s - %(levelname)s - %(message)s"))
+    lg.addHandler(fh)
+    lg.setLevel(logging.DEBUG)
+    return lg
+
+
+def _close_logger(lg):
+    for h in list(lg.handlers):
+        h.close()
+    lg.handlers.clear()
+
+
 def _open_slide(path, proc_mpp):
     """-> (row source or None, H, W, seed, reader): rows of the slide at the processing resolution (`--wsi_proc_mag` microns per
     pixel, infer/wsi.py:521-527) through cerberus_amd.reader.WSIReader; None means a synthetic slide generated on the device."""
@@ -49,30 +75,38 @@ def _open_slide(path, proc_mpp):
 def main(argv=None):
     args = parse("run_infer_wsi.py", WSI_OPTIONS, argv, version="CoBi Gland Inference")
     require_model(args)
-    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
-    if args["--gpu"] and world == 1:
+    from cerberus_amd import launch
+
+    backend = os.environ.get("CERB_DIST_BACKEND", "nccl")
+    if args["--gpu"] and "WORLD_SIZE" not in os.environ:
+        # the reference's `--gpu=0,1` drives both devices from one process (DataParallel, infer/base.py:46-47); here every listed device gets
+        # its own rank: the driver re-executes itself once per id (cerberus_amd/launch.py) -- or refuses when the devices are not there
         os.environ["HIP_VISIBLE_DEVICES"] = args["--gpu"]
+        ids = [g for g in args["--gpu"].split(",") if g.strip() != ""]
+        if len(ids) > 1:
+            launch.ensure_world(len(ids), backend, argv=[os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv),
+                                oversubscribe=bool(os.environ.get("CERB_OVERSUBSCRIBE")))
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     import torch
 
     from cerberus_amd.tile import InferManager
     from cerberus_amd.weights import DEFAULT_REQ_TARGET_CODE, default_model_kwargs
     from cerberus_amd.wsi import SlabUploader, WSIRunner, build_wsi_inst_info, check_shardable, synth_slide, write_dat
 
-    dist = None
-    torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("CERB_DIST_BACKEND", "nccl") == "gloo":  # host-staged collectives (cerberus_amd/hostdist.py)
-            from cerberus_amd.hostdist import HostStagedDist
-
-            local = local % max(1, torch.cuda.device_count())
-            torch.cuda.set_device(local)
-            dist.init_process_group("gloo")
-            dist = HostStagedDist(dist)
-        else:  # "nccl" = RCCL over xGMI, one process per GPU
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dist, watch = None, launch.null_watch()
+    n_dev = max(1, torch.cuda.device_count())
+    if world > 1 and backend == "nccl" and world > n_dev:
+        raise SystemExit("%d ranks but %d visible GPU(s): RCCL needs one device per rank" % (world, n_dev))
+    local = local % n_dev
+    torch.cuda.set_device(local)
+    if world > 1:  # "nccl" = RCCL over xGMI, one process per GPU; "gloo" = host-staged collectives (cerberus_amd/hostdist.py)
+        dist = launch.init_dist(backend, local)
+        watch = launch.PhaseWatch(rank)
+        with watch.phase("rank identity all-gather (first collective on the communicator)"):
+            ident = launch.rank_identity(dist, torch.device("cuda", local), backend)
+        if rank == 0:
+            print("ranks: %d over %s on %d distinct device(s): %s" % (ident["world"], ident["backend"], ident["distinct_devices"],
+                                                                     ", ".join("%d:cuda%d[%s]" % (r["rank"], r["device"], (r["uuid"] or "")[:13]) for r in ident["ranks"])))
     out_dir = args["--output_dir"]
     os.makedirs(out_dir, exist_ok=True)
     if args["--reference_tiling"] and world > 1:
@@ -98,16 +132,24 @@ def main(argv=None):
     print("Number of WSIs in list:", len(slides))
     win, out, batch = int(args["--patch_input_shape"]), int(args["--patch_output_shape"]), int(args["--batch_size"])
     writer = None
+    log_dir = args["--logging_dir"]
     for path in slides:
         base = _basename(path, ext)
         dat_path = os.path.join(out_dir, "dat", base + ".dat")
         done = os.path.exists(dat_path)  # a finished slide is skipped on re-runs (infer/wsi.py:969-978)
         if dist is not None:  # rank 0's view decides for everybody: ranks that disagreed (laggy / unshared file system) would deadlock
             flag = torch.tensor([1 if done else 0], dtype=torch.int64, device="cuda")
-            dist.broadcast(flag, src=0)
+            with watch.phase("skip-flag broadcast (%s)" % base):
+                dist.broadcast(flag, src=0)
             done = bool(int(flag.item()))
+        log = _slide_logger(log_dir, base) if rank == 0 else None  # one log file per slide and run (infer/wsi.py:957-980)
         if done:
+            if log:
+                log.warning("Skip %s- already processed!" % base)
+                _close_logger(log)
             continue
+        if log:
+            log.info("Processing %s ..." % base)
         t0 = time.perf_counter()
         host, H, W, seed, reader = _open_slide(path, float(args["--wsi_proc_mag"]))
         mask, sel, regions = None, None, None
@@ -125,6 +167,9 @@ def main(argv=None):
         check_shardable((H, W), out, world)
         run = WSIRunner(manager.net, (H, W), win, out, batch, rank, world, patch_sel=sel)
         y0, y1 = run.slab_rows()  # this rank's band + context halo
+        t_prep = time.perf_counter()
+        if log:
+            log.info("Preparing Input Output Placement: {0}".format(t_prep - t0))
         if host is None:
             run.infer_band(synth_slide(y1 - y0, W, y0=y0, seed=seed), y0)
         elif isinstance(host, np.ndarray) and not isinstance(host, np.memmap):  # already in RAM: one 50 GB/s copy, nothing to hide
@@ -134,15 +179,22 @@ def main(argv=None):
             run.infer_band(up.slab, y0, ready=up.upload_until)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        if dist is not None:
+            with watch.phase("end-of-inference barrier (%s)" % base):
+                dist.barrier()
+        if log:
+            log.info("Inference Time: {0}".format(t1 - t_prep))
         records = None
+        pprof = {}
         if mask is None and (world > 1 or H * W > ONE_CALL_PX):
             # band-local labelling with slide-global ids; only int32 label bands and the class maps travel to the root.  On ONE GPU a
             # slide too large for a single labelling call (96 B / px of workspace, 2^31 px) streams through the same protocol band by band
             from cerberus_amd.shard_postproc import postprocess_bands_and_gather
 
-            inst, _, maps = postprocess_bands_and_gather(run, H, W, rank, world, dist, max_band_px=ONE_CALL_PX if world == 1 else None)
+            inst, _, maps = postprocess_bands_and_gather(run, H, W, rank, world, dist, max_band_px=ONE_CALL_PX if world == 1 else None, prof=pprof, watch=watch)
         else:  # with a mask gland / lumen are labelled per tissue region (infer/wsi.py:730-835), on the root
-            maps = run.gather_to_root(dist)
+            with watch.phase("canvas gather to rank 0 (%s)" % base):
+                maps = run.gather_to_root(dist)
             if rank == 0 and mask is not None:
                 from cerberus_amd.postproc import postproc_device
                 from cerberus_amd.tissue import postprocess_regions
@@ -156,6 +208,15 @@ def main(argv=None):
         t2 = time.perf_counter()
         if rank != 0:
             continue
+        # the reference times nuclei, the tissue map and gland + lumen as separate phases (infer/wsi.py:684, 719, 856); here the three tissues
+        # are labelled in one call: the per-tissue split comes from the labelling calls' own clocks when the band protocol ran
+        t_nuc = pprof.get("label_Nuclei", {}).get("s")
+        t_gl = sum(pprof.get(k, {}).get("s", 0.0) for k in ("label_Gland", "label_Lumen")) if t_nuc is not None else None
+        if log:
+            if t_nuc is not None:
+                log.info("Nuclei Post Proc Time: {0}".format(t_nuc))
+            else:
+                log.info("Nuclei, Gland & Lumen Labelling Time: {0}".format(t2 - t1))
         if "Patch-Class" in maps:  # tissue-region map (infer/wsi.py:688-716)
             import scipy.io as sio
 
@@ -164,6 +225,8 @@ def main(argv=None):
             os.makedirs(os.path.join(out_dir, "tissue"), exist_ok=True)
             pmap = pclass_tissue_map(maps["Patch-Class"], None if regions is None else regions.mask)
             sio.savemat(os.path.join(out_dir, "tissue", base + ".mat"), {"pclass": pmap.cpu().numpy()})
+        if log:
+            log.info("Tissue Region Post Proc Time: {0}".format(time.perf_counter() - t2))
         if args["--save_label_maps"]:  # the reference keeps only the instance dictionary; the maps are for tests / inspection
             if records is not None:  # per-region maps live on their own half-resolution grids
                 for i, rec in enumerate(records):
@@ -198,6 +261,13 @@ def main(argv=None):
         t4 = time.perf_counter()
         print("%s: Inference Time: %.3f  Post Proc Time: %.3f  Instance Table Time: %.3f  (%.1f Mpx/s inference)" % (
             base, t1 - t0, t2 - t1, t4 - t3, H * W / (t1 - t0) / 1e6))
+        if log:
+            # gland + lumen labelling (when timed apart) + contours + the instance dictionary: the reference's last phase ends at joblib.dump
+            log.info("Gland & Lumen Post Proc Time: {0}".format((t_gl or 0.0) + (t4 - t3)))
+            log.info("Instance Dictionary Time: {0} (dat/%s.dat is serialised on a writer thread underneath the next slide)".format(t4 - t3) % base)
+            log.info("Overall Time: {0}".format(t4 - t0))
+            log.info("Finish")
+            _close_logger(log)
     if writer is not None:
         writer.join()
     if dist is not None:

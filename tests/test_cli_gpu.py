@@ -337,3 +337,93 @@ def test_run_infer_wsi_reads_pyramidal_tiff_at_proc_mag(tmp_path):
     assert da["proc_dimensions"].tolist() == [550, 750] and da["base_dimensions"].tolist() == [1100, 1500]
     assert abs(da["base_resolution"]["resolution"] - 0.25) < 1e-3 and da["proc_resolution"]["resolution"] == 0.5
     assert db["base_dimensions"].tolist() == [550, 750]
+
+
+def test_bench_gpus_two_self_spawned_without_a_launcher():
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run: the script re-executes itself as two ranks (cerberus_amd/launch.py; gloo with
+    --oversubscribe because this box has one GPU and RCCL refuses two ranks on a device) and the line says n_gpus 2 with both ranks listed --
+    round 3's bench ignored --gpus and printed a one-GPU line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    import json
+
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--oversubscribe", "--slide", "3072", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    two = json.loads(lines[0])
+    mg = two["multi_gpu"]
+    assert two["n_gpus"] == 2 and mg["world"] == 2 and [x["rank"] for x in mg["ranks"]] == [0, 1] and mg["backend"].startswith("gloo")
+    assert len(set(x["pid"] for x in mg["ranks"])) == 2 and all(x["uuid"] for x in mg["ranks"])
+    assert mg["halo_exchange"]["bytes_into_rank0"] > 0
+    # RCCL never oversubscribes: asking for 2 ranks on a 1-GPU box over nccl is refused, not degraded
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--slide", "3072"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+        assert r.returncode == 2 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    one = _bench([sys.executable, "bench.py", "--mode", "batch", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert one["multi_gpu"]["world"] == 1 and one["multi_gpu"]["ranks"][0]["uuid"]
+
+
+def test_run_infer_tile_two_devices_self_spawned_equals_one(tmp_path):
+    """`run_infer_tile.py --gpu=0,1` (infer/base.py:46: the reference uses every listed GPU): two self-spawned ranks share the file list
+    (here both on this box's GPU) and write exactly the files of the one-rank run."""
+    import scipy.io as sio
+    from PIL import Image
+
+    inp = tmp_path / "in"
+    inp.mkdir()
+    rs = np.random.RandomState(5)
+    for name, hw in (("a", (300, 421)), ("b", (256, 256)), ("c", (500, 260))):
+        Image.fromarray(rs.randint(0, 256, hw + (3,)).astype(np.uint8)).save(str(inp / (name + ".png")))
+    outs = []
+    for tag, gpu, env in (("one", "0", dict(os.environ)), ("two", "0,1", dict(os.environ, CERB_OVERSUBSCRIBE="1"))):
+        out = tmp_path / tag
+        cmd = [sys.executable, os.path.join(ROOT, "run_infer_tile.py"), "--synthetic", "--gpu=%s" % gpu, "--input_dir=%s" % inp, "--output_dir=%s" % out,
+               "--batch_size=8", "--patch_input_shape=256", "--patch_output_shape=256"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env={k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(out)
+    for name in ("a", "b", "c"):
+        for t in ("gland", "lumen", "nuclei"):
+            ma, mb = sio.loadmat(str(outs[0] / ("%s_mat" % t) / (name + ".mat"))), sio.loadmat(str(outs[1] / ("%s_mat" % t) / (name + ".mat")))
+            assert np.array_equal(ma["inst_map"], mb["inst_map"]), (name, t)
+        assert np.array_equal(sio.loadmat(str(outs[0] / "pclass_mat" / (name + ".mat")))["pclass"], sio.loadmat(str(outs[1] / "pclass_mat" / (name + ".mat")))["pclass"])
+
+
+def test_run_infer_wsi_writes_a_log_per_slide_and_self_spawns(tmp_path):
+    """--logging_dir: one `<slide>_<date>_std.log` per slide with the reference's phase lines (infer/wsi.py:583, 624, 684, 719, 856, 957-980);
+    `--gpu=0,1` without a launcher = two self-spawned ranks (host-staged gloo on this one-GPU box) writing the same class maps."""
+    import glob
+
+    spec = tmp_path / "slides"
+    spec.mkdir()
+    (spec / "s1.txt").write_text("synthetic:1500x1100:9")
+    base = ["--synthetic", "--input_dir=%s" % spec, "--wsi_file_ext=.txt", "--batch_size=6", "--patch_input_shape=256", "--patch_output_shape=256", "--save_label_maps"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    one, two = tmp_path / "one", tmp_path / "two"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--output_dir=%s" % one, "--logging_dir=%s" % (tmp_path / "log1")] + base,
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    logs = glob.glob(str(tmp_path / "log1" / "s1_*_std.log"))
+    assert len(logs) == 1
+    text = open(logs[0]).read()
+    for phrase in ("Processing s1 ...", "Preparing Input Output Placement:", "Inference Time:", "Tissue Region Post Proc Time:", "Gland & Lumen Post Proc Time:",
+                   "Overall Time:", "Finish"):
+        assert phrase in text, phrase
+    assert " - INFO - " in text
+    # second run: the slide is skipped and the log says so
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--output_dir=%s" % one, "--logging_dir=%s" % (tmp_path / "log1b")] + base,
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0 and "already processed" in open(glob.glob(str(tmp_path / "log1b" / "s1_*_std.log"))[0]).read()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--gpu=0,1", "--output_dir=%s" % two, "--logging_dir=%s" % (tmp_path / "log2")] + base,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(env, CERB_DIST_BACKEND="gloo", CERB_OVERSUBSCRIBE="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "ranks: 2 over gloo" in r.stdout
+    za, zb = np.load(str(one / "s1.npz")), np.load(str(two / "s1.npz"))
+    for k in za.files:
+        if k not in ("Nuclei", "Gland", "Lumen"):
+            assert np.array_equal(za[k], zb[k]), k
+    text = open(glob.glob(str(tmp_path / "log2" / "s1_*_std.log"))[0]).read()
+    assert "Nuclei Post Proc Time:" in text  # the band protocol times the tissues apart
