@@ -463,7 +463,7 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
                                                          prof=prof, watch=args.watch)
         torch.cuda.synchronize()
         phase["tail_s"] = time.perf_counter() - t1
-        res.update(inst=inst, info=info)
+        res.update(inst=inst, info=info, small=small)
 
     if os.environ.get("CERB_BENCH_PROBE_REPEAT"):  # developer probe: is the first full-size tail slower than the second (allocator warm-up)?
         for _ in range(int(os.environ["CERB_BENCH_PROBE_REPEAT"])):
@@ -482,7 +482,54 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
     n_inst = {t: int(i.get("n_total", 0)) for t, i in info.items()}
     checks = {t: {"n_truncated": int(i.get("n_truncated", 0)), "n_unresolved": int(i.get("n_unresolved", 0)), "local_bands": int(i.get("local_bands", 1))}
               for t, i in info.items()}
+    # The reference's actual WSI output is the instance DICTIONARY (infer/wsi.py:805-853: get_inst_info_dict per tissue -> uuid keys ->
+    # joblib.dump): contour tracing on the GPU (cerb_inst_contour_*), the per-instance dictionaries on the host, and the .dat file.  Timed here,
+    # AFTER the headline region (the metric counts pixels inferred and labelled; `end_to_end_Mpx_s` = the same slide over job + dictionary + file).
+    dat = None
+    if rank == 0 and not args.no_dat:
+        import tempfile
+
+        from cerberus_amd.wsi import build_wsi_inst_info, write_dat
+
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        obj = build_wsi_inst_info(res["inst"], res["small"], (H, W), 0.5)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        with tempfile.TemporaryDirectory() as td:
+            pth = os.path.join(td, "slide.dat")
+            write_dat(obj, pth)
+            t2 = time.perf_counter()
+            nbytes = os.path.getsize(pth)
+        dat = {"dictionary_s": round(t1 - t0, 3), "write_s": round(t2 - t1, 3), "dat_s": round(t2 - t0, 3), "dat_MB": round(nbytes / 1e6, 1),
+               "entries": {t: len(obj[t]) for t in ("Nuclei", "Gland", "Lumen") if t in obj},
+               "note": "contours (GPU border following) + per-instance dictionaries + uuid keys + protocol-4 pickle that joblib.load reads; in "
+                       "run_infer_wsi.py the file write runs on a writer thread underneath the next slide's inference"}
+        del obj
     res.clear()
+    # The REFERENCE's nuclei scheme over the same maps (infer/wsi.py:81-268, 642-684: 4096-px tiles, 64-px margins, strips, cross sections; every
+    # tile labelled with skimage's tie order), tiles sharded over the ranks (cerberus_amd/ref_tiling.py) -- what `run_infer_wsi.py
+    # --reference_tiling` runs instead of the band scheme.  `value` uses the band scheme; this leg is timed beside it.
+    rt = None
+    if not args.no_ref_tiling:
+        from cerberus_amd.ref_tiling import reference_tiled_nuclei_sharded
+
+        tprof = {}
+        tmap = run.canv["Nuclei-TYPE"][:valid] if "Nuclei-TYPE" in run.canv else None
+
+        def ref_job():
+            res["ref"] = reference_tiled_nuclei_sharded(struct["Nuclei-INST"], tmap, run.r0 * TILE, (H, W), rank, world, dist, tile_shape=4096, margin=64,
+                                                        patch_output_shape=TILE, exact_ties=True, watch=args.watch, prof=tprof)
+
+        rdt = _timed(ref_job, dev, dist, args.backend)
+        if rank == 0:
+            n_ref, n_band = len(res["ref"]), n_inst.get("Nuclei", 0)
+            rt = {"ref_tiling_s": round(rdt, 3), "Mpx_s": round(H * W / rdt / 1e6, 1), "instances": n_ref, "band_scheme_instances": n_band,
+                  "instances_lost_by_the_reference_scheme": round(1.0 - n_ref / max(1, n_band), 5),
+                  "rank0": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in tprof.items()},
+                  "note": "nuclei instance DICTIONARY (boxes, centroids, contours, types) by the reference's own tile sets; compare with dat.dictionary_s + "
+                          "postproc.Nuclei.s of the band scheme"}
+        res.clear()
     # secondary: the inner loop alone (configs[1]) + the per-kernel table of one batch step
     bdt, bstep, bn = batch_loop(model, dev, rank, 20, 3, None, args.backend)
     roofline, rows = kernel_table(model, bstep, bn)
@@ -533,6 +580,8 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
             "inference_Mpx_s": round(px / phase["inference_s"] / 1e6, 3),
             "postproc_and_stitch_s": round(phase["tail_s"], 3),
             "whole_job_s": round(dt, 3),
+            "nuclei_scheme": "exact band ownership (every instance of the whole-slide labelling once; cerberus_amd/shard_postproc.py) -- the reference's own "
+                             "4096-px tile sets + 64-px margins (`run_infer_wsi.py --reference_tiling`) are timed beside it as `ref_tiling`",
             "inference_algorithmic_tflops_per_gpu": round(n_tiles * flops_tile / phase["inference_s"] / 1e12 / world, 2),
             "gflop_per_tile": round(flops_tile / 1e9, 3),
             "parallelism": "band-sharded x%d (contiguous patch rows), no collective during inference; halo send/recv + 2 all-gathers + 1 gather per "
@@ -541,6 +590,9 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
         "roofline": roofline,
         "kernels": rows,
         "postproc": pp,
+        "dat": dat,
+        "ref_tiling": rt,
+        "end_to_end_Mpx_s": round(px / (dt + dat["dat_s"]) / 1e6, 3) if dat else None,
         "multi_gpu": mg,
         "batch_step": {"workload": "configs[1]: batch=32 256x256 tiles, inner loop only", "ms_per_step": round(bdt / 20 * 1e3, 3),
                        "Mpx_s": round(20 * BATCH * TILE * TILE / bdt / 1e6, 2)},
@@ -574,6 +626,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dat", action="store_true", help="skip the untimed-by-`value` instance-dictionary leg (`dat`: contours + dictionary + .dat file)")
+    ap.add_argument("--no-ref-tiling", action="store_true", help="skip the `ref_tiling` leg (the reference's own nuclei tile scheme over the same maps)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the short configs[4] training leg that the default (wsi, 1 GPU) line carries as `train_step`")
     ap.add_argument("--mode", default="wsi", choices=["wsi", "batch", "infer", "train"],
                     help='"wsi" (default): the headline, whole-slide job of north_star / configs[2-3]; "batch" (= "infer"): configs[1] inner loop; '

@@ -26,6 +26,7 @@ class ForwardIO(C.Structure):
         ("row_stride", C.c_longlong),
         ("type_is_u8", C.c_int),
         ("feats", C.POINTER(C.c_void_p)),
+        ("tiles_f32", C.c_void_p),
     ]
 
 

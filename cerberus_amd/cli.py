@@ -41,7 +41,7 @@ WSI_OPTIONS = _COMMON + [
     ("--save_label_maps", False, False, "(not in the reference) also dump the label / class maps as <output_dir>/<slide>.npz"),
     ("--reference_tiling", False, False, "(not in the reference) nuclei instances through the reference's own 4096 x 4096 tiles, 64-px margins, strips and "
                                          "cross sections (infer/wsi.py:81-268, 642-684; cerberus_amd/ref_tiling.py) instead of exact band ownership: the "
-                                         "reference's instance set, including the few seam instances its scheme drops; one GPU"),
+                                         "reference's instance set, including the few seam instances its scheme drops; tiles are sharded over the ranks"),
 ]
 
 

@@ -29,6 +29,7 @@ hipError_t cerb_launch_upsample2_add(const float* skip, const float* prev, float
 extern "C" int cerb_conv_chunk(int ks, int stride);
 struct StemParams {
     const unsigned char* tiles;
+    const float* tiles_f32;
     const float* wpack;
     const float* bias;
     float* out;
@@ -46,7 +47,7 @@ hipError_t cerb_launch_pointwise(const float* in, const float* w, const float* b
                                  hipStream_t st);
 hipError_t cerb_launch_crop_gap(const float* x, int N, int H, int W, int C, int y0, int ch, int x0, int cw, float* out, hipStream_t st);
 hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, float* dy, float* dresid, long long group_stride, long long rows, int C, int groups,
-                              const float* mean, const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, int relu, int dy_assign, void* ws, hipStream_t st);
+                              const float* mean, const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, int relu, int dy_assign, void* ws, hipStream_t st, unsigned long long eval_mask = 0);
 hipError_t cerb_launch_conv_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int G, int N, int H, int W, int Cin, int Cout,
                                 int ks, int stride, long long x_gs, hipStream_t st);
 hipError_t cerb_launch_stem_wgrad(const unsigned char* tiles, const float* dy, float* dw, int N, int H, int W, hipStream_t st);
@@ -73,7 +74,7 @@ hipError_t cerb_launch_wgrad(const float* x, const float* dy, float* dw, int G, 
                              hipStream_t st);
 hipError_t cerb_launch_maxpool(const float* in, float* out, int N, int H, int W, int C, hipStream_t st);
 hipError_t cerb_launch_head(const HeadParams& p, hipStream_t st);
-hipError_t cerb_launch_head_group(const HeadParams* heads, int n_heads, hipStream_t st);
+hipError_t cerb_launch_head_group(const HeadParams* heads, int n_heads, hipStream_t st, int w2_44);
 struct PatchClassParams {
     const float* x4;
     const float* bn1_s;
@@ -193,7 +194,7 @@ struct cerb_net {
     // packed device weights
     float *stem_w = nullptr, *stem_b = nullptr;
     std::map<std::string, PackedConv> conv;  // backbone convs + conv_map + grouped decoder convs ("dec.<u>.<j>")
-    std::vector<float*> head_w1, head_b1, head_w2, head_b2;  // per dense decoder
+    std::vector<float*> head_w1, head_b1, head_w2, head_b2, head_w2q;  // per dense decoder
     float *pc_bn1s = nullptr, *pc_bn1b = nullptr, *pc_w1t = nullptr, *pc_b1 = nullptr, *pc_w2t = nullptr, *pc_b2 = nullptr;
     std::vector<void*> dev_allocs;
     std::vector<size_t> dev_alloc_bytes;  // sizes of dev_allocs: a reload (cerb_net_begin_reload) hands the same buffers out again, in order
@@ -234,7 +235,8 @@ struct cerb_net {
     // optional per-launch timing (HIP events on the caller's stream)
     bool profiling = false;
     int crop_roi = 1;   // cerb_net_set_crop_roi: decoders / heads only compute what the centre crop keeps (conv_algo 1)
-    int head_algo = 1;  // cerb_net_set_head_algo: 1 = all dense heads in one grouped launch (default), 0 = one launch per head
+    int head_algo = 1;  // cerb_net_set_head_algo: 1 = all dense heads in one grouped launch, logits on 4x4x1 matrix instructions (default); 2 = round 3's grouped
+                        // launch (logits on a zero-padded 16-row instruction); 0 = one launch per head
     int conv_algo = 6;  // cerb_net_set_conv_algo: 6 = Winograd F(4x4,3x3) / F(2x2,3x3) by launch size (default), 1 = F(2x2,3x3), 0 = direct implicit GEMM
     struct ProfRec { std::string name, kernel; double flops; hipEvent_t e0, e1; };
     std::vector<ProfRec> prof;
@@ -662,6 +664,15 @@ extern "C" int cerb_net_finalize(cerb_net* net) {
                         w2p[(blk * 64 + lane) * 4 + r] = (o < d.out_ch) ? w2->data[(size_t)o * 96 + hid] : 0.f;
                     }
             for (int c = 0; c < d.out_ch; ++c) b2p[c] = b2->data[c];
+            //   w2q[set 2][blk 6][lane][r] = W2[4 set + (l & 3)][16 blk + 4 (l >> 4) + r]   (head_group_kernel<true>: v_mfma_f32_4x4x1_16B_f32)
+            std::vector<float> w2q(2 * 24 * 64, 0.f);
+            for (int set = 0; set < 2; ++set)
+                for (int blk = 0; blk < 6; ++blk)
+                    for (int r = 0; r < 4; ++r)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int o = 4 * set + (lane & 3), hid = blk * 16 + 4 * (lane >> 4) + r;
+                            if (o < d.out_ch) w2q[((set * 6 + blk) * 64 + lane) * 4 + r] = w2->data[(size_t)o * 96 + hid];
+                        }
             if (!net->fold_bn) {
                 float *r1, *rb1, *r2, *rb2;
                 if (upload(net, w1->data, &r1) || upload(net, b1->data, &rb1) || upload(net, w2->data, &r2) || upload(net, b2->data, &rb2)) return 1;
@@ -673,8 +684,9 @@ extern "C" int cerb_net_finalize(cerb_net* net) {
                 if (store_bn(net, "head." + std::to_string(net->head_rw1.size() - 1), {p + ".0.block.0.bn"}, 96)) return 1;
             }
             float *dw1, *db1, *dw2, *db2;
-            if (upload(net, w1p, &dw1) || upload(net, b1p, &db1) || upload(net, w2p, &dw2) || upload(net, b2p, &db2)) return 1;
-            net->head_w1.push_back(dw1); net->head_b1.push_back(db1); net->head_w2.push_back(dw2); net->head_b2.push_back(db2);
+            float* dw2q;
+            if (upload(net, w1p, &dw1) || upload(net, b1p, &db1) || upload(net, w2p, &dw2) || upload(net, b2p, &db2) || upload(net, w2q, &dw2q)) return 1;
+            net->head_w1.push_back(dw1); net->head_b1.push_back(db1); net->head_w2.push_back(dw2); net->head_b2.push_back(db2); net->head_w2q.push_back(dw2q);
         }
     }
     // ---- Patch-Class branch -----------------------------------------------------------------------------------
@@ -870,7 +882,7 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
 }
 
 static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st, double* macs) {
-    const bool dry = (macs != nullptr) && (io->tiles == nullptr);
+    const bool dry = (macs != nullptr) && (io->tiles == nullptr) && (io->tiles_f32 == nullptr);
     const int N = io->n, H = io->h, W = io->w;
     if (N <= 0 || H <= 0 || W <= 0 || (H % 16) || (W % 16)) return fail("cerb_net_forward: tile H,W must be positive multiples of 16");
     const int out_h = io->out_h > 0 ? io->out_h : H, out_w = io->out_w > 0 ? io->out_w : W;
@@ -898,7 +910,7 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
     if (macs) *macs += (double)N * H * W * 64.0 * 147.0;
     if (!dry) {
         StemParams sp;
-        sp.tiles = io->tiles; sp.wpack = net->stem_w; sp.bias = net->stem_b; sp.out = net->x0.p; sp.N = N; sp.H = H; sp.W = W; sp.relu = 1;
+        sp.tiles = io->tiles; sp.tiles_f32 = io->tiles ? nullptr : io->tiles_f32; sp.wpack = net->stem_w; sp.bias = net->stem_b; sp.out = net->x0.p; sp.N = N; sp.H = H; sp.W = W; sp.relu = 1;
         sp.tiles_x = sp.tiles_y = 0;
         if (prof_begin(net, "stem", "stem_conv7x7", 2.0 * N * H * W * 64.0 * 147.0, st)) return 1;
         HIP_OK(cerb_launch_stem(sp, st));
@@ -1008,7 +1020,7 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
             // whole lines, nothing masks an edge.  Same arithmetic in the same order: bit-identical to the NHWC path (cerb_net_set_planar(0)).
             // The level below (same 64 channels at half the resolution) does the same when its maps are above conv_wino4b's range, and hands
             // its output to the last level's up-sampling in that layout.
-            const bool lvl_planar = !dry && u >= 2 && net->planar && net->fold_bn && net->conv_algo == 6 && net->head_algo == 1 && net->conv[n0].wino &&
+            const bool lvl_planar = !dry && u >= 2 && net->planar && net->fold_bn && net->conv_algo == 6 && net->head_algo >= 1 && net->conv[n0].wino &&
                                     (long long)hh * ww > 4096 && cin0 == 64 && cmid == 64 && net->conv[n1].cout == 64 && (u == 3 || prev_gs > 0);
             if (lvl_planar) {
                 PlanarBuf &bs = u == 3 ? net->psum : net->psum2, &bm = u == 3 ? net->pmid : net->pmid2, &bo = u == 3 ? net->pout : net->pout2;
@@ -1060,7 +1072,7 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
             hp.feat_planar = feat_planar ? 1 : 0;
             hp.pl_byp = cerb_planar_blocks(H);
             hp.pl_bxp = cerb_planar_blocks(W);
-            hp.w1p = net->head_w1[k]; hp.b1 = net->head_b1[k]; hp.w2p = net->head_w2[k]; hp.b2 = net->head_b2[k];
+            hp.w1p = net->head_w1[k]; hp.b1 = net->head_b1[k]; hp.w2p = net->head_w2[k]; hp.b2 = net->head_b2[k]; hp.w2q = net->head_w2q[k];
             hp.N = N; hp.H = H; hp.W = W; hp.out_ch = d.out_ch; hp.kind = d.kind;
             hp.crop_y0 = (int)((H - out_h) * 0.5); hp.crop_x0 = (int)((W - out_w) * 0.5);  // cropping_center, misc/utils.py:94-104
             hp.out_h = want ? out_h : 0; hp.out_w = want ? out_w : 0;
@@ -1081,7 +1093,7 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
             } else {
                 if (n_hp == 8) {  // a grouped launch carries at most 8 heads: more dense decoders go out in chunks of 8
                     if (prof_begin(net, "heads", "head_group", head_flops, st)) return 1;
-                    HIP_OK(cerb_launch_head_group(hps, n_hp, st));
+                    HIP_OK(cerb_launch_head_group(hps, n_hp, st, net->head_algo == 1 ? 1 : 0));
                     if (prof_end(net, st)) return 1;
                     n_hp = 0;
                     head_flops = 0.0;
@@ -1092,7 +1104,7 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
         }
         if (n_hp > 0) {  // all dense heads of the batch in ONE grouped launch (models/utils/net_layers.py:31-38 x5)
             if (prof_begin(net, "heads", "head_group", head_flops, st)) return 1;
-            HIP_OK(cerb_launch_head_group(hps, n_hp, st));
+            HIP_OK(cerb_launch_head_group(hps, n_hp, st, net->head_algo == 1 ? 1 : 0));
             if (prof_end(net, st)) return 1;
         }
     }
@@ -1161,7 +1173,7 @@ extern "C" int cerb_net_forward_train(cerb_net* net, const cerb_train_io* io, vo
     // ---- encoder: conv -> BN(batch) -> ReLU -----------------------------------------------------------------------------------
     {
         StemParams sp;
-        sp.tiles = io->tiles; sp.wpack = net->stem_w; sp.bias = net->stem_b; sp.out = net->x0.p; sp.N = N; sp.H = H; sp.W = W; sp.relu = 0;
+        sp.tiles = io->tiles; sp.tiles_f32 = nullptr; sp.wpack = net->stem_w; sp.bias = net->stem_b; sp.out = net->x0.p; sp.N = N; sp.H = H; sp.W = W; sp.relu = 0;
         sp.tiles_x = sp.tiles_y = 0;
         HIP_OK(cerb_launch_stem(sp, st));
         if (bn_train(net, "stem", net->x0.p, nullptr, 0, (long long)N * H * W, 1, st)) return 1;
@@ -1350,7 +1362,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
     const int t_stem = newT((size_t)N * H * W * 64);
     {
         StemParams sp;
-        sp.tiles = io->tiles; sp.wpack = net->stem_w; sp.bias = net->stem_b; sp.out = val[t_stem]; sp.N = N; sp.H = H; sp.W = W; sp.relu = 0;
+        sp.tiles = io->tiles; sp.tiles_f32 = nullptr; sp.wpack = net->stem_w; sp.bias = net->stem_b; sp.out = val[t_stem]; sp.N = N; sp.H = H; sp.W = W; sp.relu = 0;
         sp.tiles_x = sp.tiles_y = 0;
         HIP_OK(cerb_launch_stem(sp, st));
         TapeOp op;
@@ -1604,9 +1616,15 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 if (fresh && !(grd[op.a] = take(cnt[op.a], false))) return fail("workspace allocation failed");
                 // `flops` field of an HBM-bound family: its algorithmic BYTES (reads dz, z, y twice -- reduction pass + apply pass --, writes dy
                 // (+ the residual branch's gradient)), fp32
+                // groups whose BatchNorm ran in eval mode (cerb_net_set_bn_eval): the backward of a normalisation by CONSTANTS -- the data gradient
+                // upstream of a frozen BatchNorm is then right for callers that keep the convolutions under it trainable
+                unsigned long long eval_mask = 0;
+                if (b.eval.size() > 64) return fail("cerb_net_train_grads: more than 64 groups under one eval-mode BatchNorm");
+                for (size_t g = 0; g < b.eval.size(); ++g)
+                    if (b.eval[g]) eval_mask |= 1ull << g;
                 if (prof_begin(net, op.name + ".bn_bwd", "bn_bwd", (double)op.G * op.rows * op.Cout * 4.0 * (5.0 + (op.b >= 0 ? 2.0 : 0.0)), st)) return 1;
                 HIP_OK(cerb_launch_bn_bwd(go, val[op.o], val[op.a], G_(op.a), op.b >= 0 ? G_(op.b) : nullptr, op.a_gs, op.rows, op.Cout, op.G, val[op.stat],
-                                          val[op.stat] + (size_t)op.G * op.Cout, b.gamma, b.beta, dgamma, dbeta, op.relu, fresh ? 1 : 0, net->t_ws.p, st));
+                                          val[op.stat] + (size_t)op.G * op.Cout, b.gamma, b.beta, dgamma, dbeta, op.relu, fresh ? 1 : 0, net->t_ws.p, st, eval_mask));
                 if (prof_end(net, st)) return 1;
                 const std::vector<std::string>& keys = net->bn_keys[op.name];
                 for (int g = 0; g < op.G; ++g) {
@@ -1707,7 +1725,7 @@ extern "C" int cerb_net_begin_reload(cerb_net* net) {
     net->bn.clear();
     net->raw.clear();
     net->grads.clear();
-    net->head_w1.clear(); net->head_b1.clear(); net->head_w2.clear(); net->head_b2.clear();
+    net->head_w1.clear(); net->head_b1.clear(); net->head_w2.clear(); net->head_b2.clear(); net->head_w2q.clear();
     net->head_rw1.clear(); net->head_rb1.clear(); net->head_rw2.clear(); net->head_rb2.clear();
     net->host.clear();
     net->finalized = false;
@@ -1752,7 +1770,7 @@ extern "C" int cerb_net_set_fold_bn(cerb_net* net, int fold) {
 extern "C" int cerb_net_forward(cerb_net* net, const cerb_forward_io* io, void* hip_stream) {
     if (!net || !io) return fail("cerb_net_forward: null argument");
     if (!net->finalized) return fail("cerb_net_forward: call cerb_net_finalize first");
-    if (!io->tiles) return fail("cerb_net_forward: null tiles pointer");
+    if (!io->tiles && !io->tiles_f32) return fail("cerb_net_forward: null tiles pointer (neither tiles nor tiles_f32)");
     if (!net->fold_bn) return fail("cerb_net_forward: the network was packed for training (cerb_net_set_fold_bn(net, 0)); use cerb_net_forward_train");
     net->prof_n = 0;
     return forward_impl(net, io, (hipStream_t)hip_stream, nullptr);
@@ -1825,7 +1843,7 @@ extern "C" int cerb_net_set_planar(cerb_net* net, int enable) {
 
 extern "C" int cerb_net_set_head_algo(cerb_net* net, int algo) {
     if (!net) return fail("cerb_net_set_head_algo: null handle");
-    if (algo < 0 || algo > 1) return fail("cerb_net_set_head_algo: algo must be 0 (one launch per head) or 1 (grouped launch)");
+    if (algo < 0 || algo > 2) return fail("cerb_net_set_head_algo: algo must be 0 (one launch per head), 1 (grouped launch) or 2 (round 3's grouped launch)");
     net->head_algo = algo;
     return 0;
 }

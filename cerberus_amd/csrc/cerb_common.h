@@ -65,6 +65,7 @@ struct HeadParams {
     const float* w1p;    // packed W1 (BN folded): [6 blk][4 g][64 lane][4]  (cerb_api.hip: head packing)
     const float* b1;     // [96]
     const float* w2p;    // packed W2: [6 blk][64 lane][4]  (rows >= out_ch are zero)
+    const float* w2q;    // W2 for head_group_kernel<true> (4x4x1 matrix instructions): [set 2][blk 6][64 lane][r 4] = W2[4 set + (l & 3)][16 blk + 4 (l >> 4) + r]
     const float* b2;     // [32] (padded)
     int N, H, W;
     int out_ch;          // 3 or 7 (<= 8)

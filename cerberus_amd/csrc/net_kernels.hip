@@ -15,6 +15,7 @@
 // ---------------------------------------------------------------------------------------------------------------
 struct StemParams {
     const unsigned char* tiles;  // [N][H][W][3]
+    const float* tiles_f32;      // alternative input (tiles == nullptr): [N][H][W][3] float pixel values, divided by 255 like the bytes (net_desc.py:147)
     const float* wpack;          // [7 ky][12 t][2 s][64 lane]
     const float* bias;           // [64]
     float* out;                  // [N][H][W][64]
@@ -22,6 +23,7 @@ struct StemParams {
     int relu;                    // 1: inference (BN folded into wpack / bias, ReLU fused); 0: train mode (raw conv, BN and ReLU follow)
 };
 
+template <bool F32IN>
 __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemParams p) {
     constexpr int TH = 8, TW = 32, IH = TH + 6, IW = TW + 6, ROW = 120;  // ROW >= IW*3 + 3 (k padding)
     __shared__ __attribute__((aligned(16))) float wl[7 * 12 * 2 * 64];
@@ -37,13 +39,16 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(StemParams p) {
         const int n = t_ / p.tiles_y;
         const int oy0 = ty * TH, ox0 = tx * TW;
         __syncthreads();
-        const unsigned char* img = p.tiles + (long long)n * p.H * p.W * 3;
+        const unsigned char* img = F32IN ? nullptr : p.tiles + (long long)n * p.H * p.W * 3;
+        const float* imgf = F32IN ? p.tiles_f32 + (long long)n * p.H * p.W * 3 : nullptr;
         for (int i = tid; i < IH * ROW; i += 256) {
             const int iy = i / ROW, c = i % ROW;
             const int gy = oy0 - 3 + iy, gx = ox0 - 3 + c / 3;
             float v = 0.f;
-            if (c < IW * 3 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-                v = (float)img[((long long)gy * p.W + gx) * 3 + c % 3] / 255.0f;
+            if (c < IW * 3 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                const long long at = ((long long)gy * p.W + gx) * 3 + c % 3;
+                v = (F32IN ? imgf[at] : (float)img[at]) / 255.0f;
+            }
             xl[i] = v;
         }
         __syncthreads();
@@ -98,7 +103,8 @@ hipError_t cerb_launch_stem(StemParams p, hipStream_t st) {
     p.tiles_y = (p.H + 7) / 8;
     const long long ntile = (long long)p.N * p.tiles_x * p.tiles_y;
     const unsigned grid = (unsigned)(ntile < 256 * 6 ? ntile : 256 * 6);
-    hipLaunchKernelGGL(stem_conv7x7_kernel, dim3(grid), dim3(256), 0, st, p);
+    if (p.tiles) hipLaunchKernelGGL(stem_conv7x7_kernel<false>, dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(stem_conv7x7_kernel<true>, dim3(grid), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
@@ -565,24 +571,31 @@ struct HeadGroupParams {
     HeadParams h[8];
     int n_heads;
 };
+// W2_44 (round 4, the default): the second 1x1 (96 -> 3 / 7 logits) on v_mfma_f32_4x4x1_16B_f32 instead of a 16-row matrix instruction whose
+// rows 3 (7) .. 15 multiply zeros: 16 independent 4x4 outer products per instruction, block b = lanes 4b .. 4b+3 = four pixels of one k-slot
+// group, B = the lane's own hidden value (exactly where the first GEMM left it), A = W2[out l & 3][the block's hidden channel], D = 4 logits per
+// lane, partial over the lane's k-slot group; 24 instructions of 2 passes per pixel block and set of 4 logits (48 for the 7-class head) replace
+// 24 of 8 passes, then two cross-lane exchanges sum the four k-slot groups.  Matrix-pipe time of a 32-pixel task: 7680 -> 6528 (6912) cycles.
+template <bool W2_44>
 __global__ __launch_bounds__(256, HEAD_G_OCC) void head_group_kernel(HeadGroupParams gp) {
     __shared__ __attribute__((aligned(16))) float s_w1[6 * 4 * 64 * 4];
-    __shared__ __attribute__((aligned(16))) float s_w2[6 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float s_w2[(W2_44 ? 2 : 1) * 6 * 64 * 4];  // W2_44: w2q = [set][blk][lane][r], else w2p = [blk][lane][r]
     __shared__ __attribute__((aligned(16))) float s_b1[96];
     __shared__ __attribute__((aligned(16))) float s_b2[32];
     const HeadParams& p = gp.h[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, px = lane & 15, ks = lane >> 4;
     {
         const f32x4h* w1g = reinterpret_cast<const f32x4h*>(p.w1p);
-        const f32x4h* w2g = reinterpret_cast<const f32x4h*>(p.w2p);
+        const f32x4h* w2g = reinterpret_cast<const f32x4h*>(W2_44 ? p.w2q : p.w2p);
         for (int i = tid; i < 6 * 4 * 64; i += 256) reinterpret_cast<f32x4h*>(s_w1)[i] = w1g[i];
-        for (int i = tid; i < 6 * 64; i += 256) reinterpret_cast<f32x4h*>(s_w2)[i] = w2g[i];
+        for (int i = tid; i < (W2_44 ? 2 : 1) * 6 * 64; i += 256) reinterpret_cast<f32x4h*>(s_w2)[i] = w2g[i];
         if (tid < 96) s_b1[tid] = p.b1[tid];
         if (tid < 32) s_b2[tid] = p.b2[tid];
     }
     __syncthreads();
     const f32x4h* w1v = reinterpret_cast<const f32x4h*>(s_w1) + lane;
     const f32x4h* w2v = reinterpret_cast<const f32x4h*>(s_w2) + lane;
+    const bool wide = p.out_ch > 4;  // W2_44: a second set of 4 logits
     const unsigned nblk = (unsigned)p.N * (unsigned)p.rows * (unsigned)p.nxb;  // 16-pixel blocks (launcher: < 2^31)
     const unsigned ntask = (nblk + 1u) >> 1;
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
@@ -661,6 +674,45 @@ __global__ __launch_bounds__(256, HEAD_G_OCC) void head_group_kernel(HeadGroupPa
             for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc1[blk][pb][r] = fmaxf(acc1[blk][pb][r], 0.f);
+        float lg[8];
+        if constexpr (W2_44) {
+            f32x4h lo[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, hi[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int blk = 0; blk < 6; ++blk) {
+                const f32x4h wa = w2v[blk * 64];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int pb = 0; pb < 2; ++pb) lo[pb] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[r], acc1[blk][pb][r], lo[pb], 0, 0, 0);
+            }
+            if (wide) {
+#pragma unroll
+                for (int blk = 0; blk < 6; ++blk) {
+                    const f32x4h wb = w2v[(6 + blk) * 64];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int pb = 0; pb < 2; ++pb) hi[pb] = __builtin_amdgcn_mfma_f32_4x4x1f32(wb[r], acc1[blk][pb][r], hi[pb], 0, 0, 0);
+                }
+            }
+            // sum over the four k-slot groups; lane groups ks = 0, 1 finish pixel blocks 0, 1: first exchange hands the partner (ks ^ 1) the block
+            // it finishes, second adds the pair (ks ^ 2) -- a fixed order, so the logits do not depend on anything but the pixel's features
+            const bool odd = ks & 1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float mine = odd ? lo[1][e] : lo[0][e];
+                mine += __shfl_xor(odd ? lo[0][e] : lo[1][e], 16);
+                mine += __shfl_xor(mine, 32);
+                lg[e] = mine + s_b2[e];
+                float mh = 0.f;
+                if (wide) {
+                    mh = odd ? hi[1][e] : hi[0][e];
+                    mh += __shfl_xor(odd ? hi[0][e] : hi[1][e], 16);
+                    mh += __shfl_xor(mh, 32);
+                }
+                lg[4 + e] = mh + s_b2[4 + e];
+            }
+        } else {
         f32x4h acc2[2];
         {
             const f32x4h b2 = *reinterpret_cast<const f32x4h*>(s_b2 + 4 * ks);
@@ -677,13 +729,13 @@ __global__ __launch_bounds__(256, HEAD_G_OCC) void head_group_kernel(HeadGroupPa
                 for (int pb = 0; pb < 2; ++pb) acc2[pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], acc1[blk][pb][r], acc2[pb], 0, 0, 0);
         }
         // lane groups ks = 0, 1 finish pixel blocks 0, 1: the pixel's 8 logits sit in lanes px (rows 0..3) and 16 + px (rows 4..7)
-        float lg[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float a0 = __shfl(acc2[0][e], px), a1 = __shfl(acc2[0][e], 16 + px);
             const float c0 = __shfl(acc2[1][e], px), c1 = __shfl(acc2[1][e], 16 + px);
             lg[e] = (ks & 1) ? c0 : a0;
             lg[4 + e] = (ks & 1) ? c1 : a1;
+        }
         }
         if (ks >= 2) continue;
         const BPos bp = decode(2u * task + (unsigned)ks);
@@ -728,7 +780,7 @@ __global__ __launch_bounds__(256, HEAD_G_OCC) void head_group_kernel(HeadGroupPa
     }
 }
 
-hipError_t cerb_launch_head_group(const HeadParams* heads, int n_heads, hipStream_t st) {
+hipError_t cerb_launch_head_group(const HeadParams* heads, int n_heads, hipStream_t st, int w2_44) {
     if (n_heads < 1 || n_heads > 8) return hipErrorInvalidValue;
 
     HeadGroupParams gp = {};
@@ -750,7 +802,8 @@ hipError_t cerb_launch_head_group(const HeadParams* heads, int n_heads, hipStrea
         if (blocks > max_blocks) max_blocks = (unsigned)blocks;
         gp.h[i] = p;
     }
-    hipLaunchKernelGGL(head_group_kernel, dim3(max_blocks, (unsigned)n_heads), dim3(256), 0, st, gp);
+    if (w2_44) hipLaunchKernelGGL(head_group_kernel<true>, dim3(max_blocks, (unsigned)n_heads), dim3(256), 0, st, gp);
+    else hipLaunchKernelGGL(head_group_kernel<false>, dim3(max_blocks, (unsigned)n_heads), dim3(256), 0, st, gp);
     return hipGetLastError();
 }
 

@@ -550,13 +550,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dy, float* __restrict__ dresid, long long group_stride, long long rows, int C,
                                                            int groups, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu) {
+                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu,
+                                                           unsigned long long eval_mask) {
     const int c4n = C >> 2;
     const long long per_group = rows * c4n, total = per_group * groups;
-    const float invM = 1.f / (float)rows;
+    const float invM_train = 1.f / (float)rows;
     #pragma unroll 2
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int g = (int)(i / per_group);
+        // a group in EVAL mode (cerb_net_set_bn_eval) normalises with constants: dy = dz * gamma * rstd, no mean / xhat-projection terms
+        // (they are the derivative of the BATCH statistics, which an eval-mode BatchNorm does not use)
+        const float invM = ((eval_mask >> (g & 63)) & 1ull) ? 0.f : invM_train;
         const long long j = i - (long long)g * per_group;
         const int c = 4 * (int)(j % c4n);
         const long long a = g * group_stride + (j / c4n) * C + c;
@@ -947,7 +951,7 @@ static unsigned gridfor(long long n) {
 
 hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, float* dy, float* dresid, long long group_stride, long long rows, int C, int groups,
                               const float* mean, const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, int relu, int dy_assign,
-                              void* ws, hipStream_t st) {
+                              void* ws, hipStream_t st, unsigned long long eval_mask) {
     const int bpg = (int)((rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK);
     // a ReLU behind a BatchNorm WITHOUT a residual: z > 0 <=> bn_out(y) > 0, recomputed from the y both passes read anyway (relu = 2):
     // 5 instead of 7 tensor passes over the activation
@@ -956,9 +960,9 @@ hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, f
                        gamma, beta, (double*)ws);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, (const double*)ws, C, bpg, dgamma, dbeta);
     if (dy_assign) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gridfor(rows * (C / 4) * groups)), dim3(256), 0, st, dz, z, y, dy, dresid, group_stride, rows, C,
-                                      groups, mean, rstd, gamma, beta, dgamma, dbeta, relu);
+                                      groups, mean, rstd, gamma, beta, dgamma, dbeta, relu, eval_mask);
     else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(gridfor(rows * (C / 4) * groups)), dim3(256), 0, st, dz, z, y, dy, dresid, group_stride, rows, C, groups,
-                            mean, rstd, gamma, beta, dgamma, dbeta, relu);
+                            mean, rstd, gamma, beta, dgamma, dbeta, relu, eval_mask);
     return hipGetLastError();
 }
 hipError_t cerb_launch_conv_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int G, int N, int H, int W, int Cin, int Cout,

@@ -391,11 +391,18 @@ class NetDesc(torch.nn.Module):
             for k, v in dev_params.items():
                 self._sd[k] = v.detach().cpu().clone()
 
+    def handle_value(self):
+        """Integer value of the finalized `cerb_net*` -- the `handle` argument of torch.ops.cerberus_amd.infer_tiles (cerberus_amd/ops.py)."""
+        from . import ops
+
+        return ops.register_net(self)
+
     def flops(self, n, h, w):
         return float(_lib.lib().cerb_net_flops(self._ensure_handle(), n, h, w))
 
     def set_head_algo(self, algo):
-        """1 = all dense heads in one grouped launch (default), 0 = one launch per head (include/cerberus_hip.h)."""
+        """1 = all dense heads in one grouped launch, logits on 4x4x1 matrix instructions (default); 2 = round 3's grouped launch (zero-padded
+        16-row instruction); 0 = one launch per head (include/cerberus_hip.h)."""
         _lib.check(_lib.lib().cerb_net_set_head_algo(self._ensure_handle(), int(algo)))
 
     def set_conv_algo(self, algo):
@@ -426,12 +433,16 @@ class NetDesc(torch.nn.Module):
         return out
 
     def _run(self, tiles_u8, out_h, out_w, outs, logits, tile_off=None, tile_stride=0, row_stride=0, type_is_u8=False, feats=None):
-        assert tiles_u8.is_cuda and tiles_u8.dtype == torch.uint8 and tiles_u8.dim() == 4 and tiles_u8.shape[3] == 3
+        # uint8 tiles (what infer_step receives), or float32 NHWC pixel values for forward() on inputs that are not whole numbers in 0..255
+        assert tiles_u8.is_cuda and tiles_u8.dtype in (torch.uint8, torch.float32) and tiles_u8.dim() == 4 and tiles_u8.shape[3] == 3
         tiles_u8 = tiles_u8.contiguous()
         n, h, w, _ = tiles_u8.shape
         nd = len(self._decoders)
         io = _lib.ForwardIO()
-        io.tiles = tiles_u8.data_ptr()
+        if tiles_u8.dtype == torch.uint8:
+            io.tiles = tiles_u8.data_ptr()
+        else:
+            io.tiles, io.tiles_f32 = None, tiles_u8.data_ptr()
         io.n, io.h, io.w, io.out_h, io.out_w = n, h, w, out_h, out_w
         out_arr = (C.c_void_p * nd)(*[(t.data_ptr() if t is not None else None) for t in outs])
         io.out = out_arr
@@ -451,16 +462,20 @@ class NetDesc(torch.nn.Module):
 
     # ---- reference-compatible forward: logits ----------------------------------------------------------------
     def forward(self, imgs, train_decoder_list=[]):
-        """imgs: NCHW float tensor holding 0..255 pixel values (what infer_step passes, run_desc.py:440-449),
-        or uint8 NHWC.  Returns OrderedDict key -> NCHW fp32 logits on the GPU (reference net_desc.py:144-200)."""
+        """imgs: NCHW float tensor (any values; the reference divides by 255 whatever they are, models/net_desc.py:144-147), or uint8 NHWC
+        (what infer_step passes on after `.float()`, run_desc.py:440-449).  Returns OrderedDict key -> NCHW fp32 logits on the GPU
+        (reference net_desc.py:144-200).  Whole numbers in 0..255 take the uint8 stem (a quarter of the input bytes), anything else the
+        float-input instantiation of the same kernel (`cerb_forward_io.tiles_f32`): same `x / 255.0f` in fp32, same arithmetic after it."""
         self._ensure_handle()
         if imgs.dtype == torch.uint8 and imgs.shape[-1] == 3:
             tiles = imgs
         else:
+            imgs = imgs.float()
             q = imgs.round()
-            if not torch.equal(q, imgs) or imgs.min() < 0 or imgs.max() > 255:
-                raise NotImplementedError("the HIP path ingests uint8 RGB tiles; forward() accepts float inputs only when they hold integers in 0..255")
-            tiles = imgs.permute(0, 2, 3, 1).to(torch.uint8)
+            if torch.equal(q, imgs) and float(imgs.min()) >= 0 and float(imgs.max()) <= 255:
+                tiles = imgs.permute(0, 2, 3, 1).to(torch.uint8)
+            else:
+                tiles = imgs.permute(0, 2, 3, 1)
         tiles = tiles.cuda().contiguous()
         n, h, w, _ = tiles.shape
         lg = []

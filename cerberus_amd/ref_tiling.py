@@ -77,28 +77,45 @@ def get_tile_info(image_wh, tile_shape, margin, patch_output_shape):
     return info
 
 
-def _tile_instances(inst_canvas, type_canvas, bounds, exact_ties):
-    """Label one tile on the GPU -> (list of per-instance dictionaries in TILE coordinates, boxes [n, 4] as x0, y0, x1, y1)."""
-    H, W = int(inst_canvas.shape[0]), int(inst_canvas.shape[1])
+def _tile_instances(inst_canvas, type_canvas, bounds, exact_ties, y_off=0, slide_h=None):
+    """Label one tile on the GPU -> (list of per-instance dictionaries in TILE coordinates, boxes [n, 4] as x0, y0, x1, y1).
+    inst_canvas holds slide rows y_off .. y_off + rows (a rank's band plus the rows it fetched from its neighbours); slide_h = slide height."""
+    W = int(inst_canvas.shape[1])
+    H = int(inst_canvas.shape[0]) + int(y_off) if slide_h is None else int(slide_h)
     x0, y0, x1, y1 = max(int(bounds[0]), 0), max(int(bounds[1]), 0), min(int(bounds[2]), W), min(int(bounds[3]), H)
     if x1 <= x0 or y1 <= y0:
         return [], np.zeros((0, 4), np.int64)
-    lab, _ = postproc_device(inst_canvas[y0:y1, x0:x1], "Nuclei", exact_ties=exact_ties)
-    tmap = None if type_canvas is None else type_canvas[y0:y1, x0:x1].contiguous()
+    assert y0 >= y_off and y1 - y_off <= int(inst_canvas.shape[0]), "tile rows outside the rows this rank holds"
+    lab, _ = postproc_device(inst_canvas[y0 - y_off:y1 - y_off, x0:x1], "Nuclei", exact_ties=exact_ties)
+    tmap = None if type_canvas is None else type_canvas[y0 - y_off:y1 - y_off, x0:x1].contiguous()
     info = get_inst_info_dict(lab, tmap, flat_box=True)
     items = list(info.values())
     boxes = np.array([np.asarray(v["box"]) for v in items], dtype=np.int64).reshape(-1, 4)
     return items, boxes
 
 
-def process_tile_predictions(inst_canvas, type_canvas, tile_bounds, tile_flag, tile_mode, ref_boxes, margin, exact_ties=True):
-    """infer/wsi.py:81-268 for one tile.  ref_boxes: [k, 4] boxes (slide coordinates) of what has been accumulated before this tile SET.
-    -> (kept instance dictionaries in slide coordinates, indices into ref_boxes to remove)."""
+def eviction_lines(tile_bounds, margin):
+    """The four inner margin lines of a cross section in slide coordinates (infer/wsi.py:241-255): accumulated instances touching one are removed."""
+    tl = (int(tile_bounds[0]), int(tile_bounds[1]))
+    w, h = int(tile_bounds[2]) - tl[0], int(tile_bounds[3]) - tl[1]
+    m = int(margin)
+    return [(a + tl[0], b + tl[1], c + tl[0], d + tl[1]) for a, b, c, d in ((m, m, w - m, m), (m, h - m, w - m, h - m), (m, m, m, h - m), (w - m, m, w - m, h - m))]
+
+
+def process_tile_predictions(inst_canvas, type_canvas, tile_bounds, tile_flag, tile_mode, ref_boxes, margin, exact_ties=True, y_off=0, slide_h=None):
+    """infer/wsi.py:81-268 for one tile.  ref_boxes: [k, 4] boxes (slide coordinates) of what has been accumulated before this tile SET, or None
+    when the caller evicts at merge time (merge_tile_results).  -> (kept instance dictionaries in slide coordinates, indices into ref_boxes to remove)."""
     tl = np.array([int(tile_bounds[0]), int(tile_bounds[1])], dtype=np.int64)
     w, h = int(tile_bounds[2]) - int(tile_bounds[0]), int(tile_bounds[3]) - int(tile_bounds[1])
-    items, boxes = _tile_instances(inst_canvas, type_canvas, tile_bounds, exact_ties)
+    items, boxes = _tile_instances(inst_canvas, type_canvas, tile_bounds, exact_ties, y_off, slide_h)
+    remove = np.zeros(0, np.int64)
+    if tile_mode == 3 and ref_boxes is not None and len(ref_boxes):  # a cross section also evicts accumulated instances touching its inner margin lines
+        sel = np.zeros(len(ref_boxes), bool)
+        for line in eviction_lines(tile_bounds, margin):
+            sel |= _hits(ref_boxes, line)
+        remove = np.nonzero(sel)[0]
     if not items:
-        return [], np.zeros(0, np.int64)
+        return [], remove
     m = int(margin)
     boundary_lines = [(0, 0, w, 1), (0, h - 1, w, h), (0, 0, 1, h), (w - 1, 0, w, h)]
     margin_boxes = [(0, 0, w, m), (0, h - m, w, h), (0, 0, m, h), (w - m, 0, w, h)]
@@ -112,13 +129,6 @@ def process_tile_predictions(inst_canvas, type_canvas, tile_bounds, tile_flag, t
             drop |= _hits(boxes, margin_boxes[side] if flag else boundary_lines[side])
     else:
         raise ValueError("Unknown tile mode %r." % (tile_mode,))
-    remove = np.zeros(0, np.int64)
-    if tile_mode == 3 and len(ref_boxes):  # a cross section also evicts accumulated instances touching its inner margin lines
-        lines = [(m, m, w - m, m), (m, h - m, w - m, h - m), (m, m, m, h - m), (w - m, m, w - m, h - m)]
-        sel = np.zeros(len(ref_boxes), bool)
-        for a, b, c, d in lines:
-            sel |= _hits(ref_boxes, (a + tl[0], b + tl[1], c + tl[0], d + tl[1]))
-        remove = np.nonzero(sel)[0]
     off = np.concatenate([tl, tl])
     kept = []
     for i in np.nonzero(~drop)[0].tolist():
@@ -130,26 +140,143 @@ def process_tile_predictions(inst_canvas, type_canvas, tile_bounds, tile_flag, t
     return kept, remove
 
 
-def reference_tiled_nuclei(inst_canvas, type_canvas=None, tile_shape=4096, margin=64, patch_output_shape=144, exact_ties=True):
-    """The nuclei loop of infer/wsi.py:642-684 over a device-resident INST canvas [H, W, 2] (and uint8 TYPE canvas [H, W]):
-    OrderedDict {uuid4 hex -> {'box': [x1, y1, x2, y2], 'centroid', 'contour', 'type', 'type_prob'}} in slide coordinates.
-    All tiles of a set see the accumulated dictionary as it was BEFORE the set (the reference merges futures after the set's tiles have been
-    submitted), additions and evictions are applied in tile order."""
+def merge_tile_results(parts, tile_info, margin):
+    """parts: {(mode, tile index): kept dictionaries}, from one rank or gathered from all.  The accumulation of infer/wsi.py:642-684: sets in
+    order 0..3, tiles of a set in order; a cross section (set 3) evicts what had been accumulated BEFORE its set and touches one of its inner
+    margin lines (every tile of a set sees the dictionary as it was when the set was submitted), then adds its own instances."""
     import uuid
 
-    assert inst_canvas.is_cuda and inst_canvas.dim() == 3
-    H, W = int(inst_canvas.shape[0]), int(inst_canvas.shape[1])
     acc = OrderedDict()
-    shape2 = [tile_shape, tile_shape] if np.isscalar(tile_shape) else tile_shape
-    pos2 = [patch_output_shape, patch_output_shape] if np.isscalar(patch_output_shape) else patch_output_shape
-    for mode, (bounds, flags) in enumerate(get_tile_info((W, H), shape2, margin, pos2)):
+    for mode, (bounds, _) in enumerate(tile_info):
         keys = list(acc.keys())
-        ref_boxes = np.array([np.asarray(acc[k]["box"]) for k in keys], dtype=np.int64).reshape(-1, 4)
-        results = [process_tile_predictions(inst_canvas, type_canvas, tb, tf, mode, ref_boxes, margin, exact_ties) for tb, tf in zip(bounds, flags)]
-        for kept, remove in results:
+        ref_boxes = np.array([np.asarray(acc[k]["box"]) for k in keys], dtype=np.int64).reshape(-1, 4) if (mode == 3 and keys) else np.zeros((0, 4), np.int64)
+        cand = np.zeros(0, np.int64)
+        if mode == 3 and len(ref_boxes) and len(bounds):
+            # candidates once for the whole set: an instance can only touch a cross section's lines if it reaches within two margins of an
+            # inner tile corner in x AND in y -- a fraction of a per cent of a slide's instances; the per-tile tests then run on those
+            xs = np.unique([int(b[0]) for b in bounds])
+            ys = np.unique([int(b[1]) for b in bounds])
+            wx, wy = int(bounds[0][2]) - int(bounds[0][0]), int(bounds[0][3]) - int(bounds[0][1])
+            ix = np.searchsorted(xs, ref_boxes[:, 2], side="right") - 1  # the last cross-section column starting at or before the box's right edge
+            iy = np.searchsorted(ys, ref_boxes[:, 3], side="right") - 1
+            near = (ix >= 0) & (ref_boxes[:, 0] <= xs[np.maximum(ix, 0)] + wx) & (iy >= 0) & (ref_boxes[:, 1] <= ys[np.maximum(iy, 0)] + wy)
+            cand = np.nonzero(near)[0]
+        for ti in range(len(bounds)):
+            kept = parts.get((mode, ti), [])
+            if mode == 3 and len(cand):
+                sel = np.zeros(len(cand), bool)
+                for line in eviction_lines(bounds[ti], margin):
+                    sel |= _hits(ref_boxes[cand], line)
+                for r in cand[sel].tolist():
+                    acc.pop(keys[r], None)
             for v in kept:
                 acc[uuid.uuid4().hex] = v
-            for r in remove.tolist():
-                acc.pop(keys[r], None)
+    return acc
+
+
+def _rank_tiles(tile_info, band_bounds, slide_h):
+    """Owner of every tile = the rank whose band holds the tile's first slide row.  -> per rank [(mode, tile index)], per rank last row needed."""
+    world = len(band_bounds)
+    starts = np.array([b[0] for b in band_bounds], dtype=np.int64)
+    mine = [[] for _ in range(world)]
+    need_hi = [int(b[1]) for b in band_bounds]
+    for mode, (bounds, _) in enumerate(tile_info):
+        for ti, b in enumerate(bounds):
+            y0 = min(max(int(b[1]), 0), slide_h - 1)
+            r = int(np.searchsorted(starts, y0, side="right") - 1)
+            mine[r].append((mode, ti))
+            need_hi[r] = max(need_hi[r], min(int(b[3]), slide_h))
+    return mine, need_hi
+
+
+def reference_tiled_nuclei(inst_canvas, type_canvas=None, tile_shape=4096, margin=64, patch_output_shape=144, exact_ties=True, prof=None):
+    """The nuclei loop of infer/wsi.py:642-684 over a device-resident INST canvas [H, W, 2] (and uint8 TYPE canvas [H, W]):
+    OrderedDict {uuid4 hex -> {'box': [x1, y1, x2, y2], 'centroid', 'contour', 'type', 'type_prob'}} in slide coordinates."""
+    return reference_tiled_nuclei_sharded(inst_canvas, type_canvas, 0, (int(inst_canvas.shape[0]), int(inst_canvas.shape[1])), 0, 1, None, tile_shape, margin,
+                                          patch_output_shape, exact_ties, prof=prof)
+
+
+def reference_tiled_nuclei_sharded(band_inst, band_type, band_y0, slide_hw, rank, world, dist, tile_shape=4096, margin=64, patch_output_shape=144,
+                                   exact_ties=True, watch=None, prof=None):
+    """The same over N ranks that each hold a band of the slide's canvases (rows band_y0 .. band_y0 + band_inst.shape[0]): tiles are
+    independent, so every rank labels the tiles whose first row lies in its band -- after fetching the rows those tiles reach into below its
+    band from the ranks that hold them (point-to-point, upwards only: a tile never starts above its owner's band) -- and the root merges the
+    kept instances in the reference's order, applying the cross sections' evictions there (they look at instances of any rank).
+    Returns the dictionary on rank 0, None elsewhere.  prof: dict receiving seconds per phase."""
+    import time
+
+    from .launch import null_watch
+
+    watch = watch or null_watch()
+    assert band_inst.is_cuda and band_inst.dim() == 3
+    H, W = int(slide_hw[0]), int(slide_hw[1])
+    rows = min(int(band_inst.shape[0]), H - int(band_y0))
+    shape2 = [tile_shape, tile_shape] if np.isscalar(tile_shape) else tile_shape
+    pos2 = [patch_output_shape, patch_output_shape] if np.isscalar(patch_output_shape) else patch_output_shape
+    tile_info = get_tile_info((W, H), shape2, margin, pos2)
+    t0 = time.perf_counter()
+    if dist is None or world == 1:
+        band_bounds = [(0, H)]
+        assert int(band_y0) == 0 and rows == H, "a single rank holds the whole canvas"
+    else:
+        me = torch.tensor([int(band_y0), int(band_y0) + rows], dtype=torch.int64, device=band_inst.device)
+        allb = [torch.zeros_like(me) for _ in range(world)]
+        with watch.phase("reference tiling: band-bounds all-gather"):
+            dist.all_gather(allb, me)
+        band_bounds = [(int(b[0].item()), int(b[1].item())) for b in allb]
+    mine, need_hi = _rank_tiles(tile_info, band_bounds, H)
+    y0, y1 = band_bounds[rank]
+    canvas, tcanvas = band_inst[:rows], (None if band_type is None else band_type[:rows])
+    if world > 1 and dist is not None:
+        ext = max(need_hi[rank], y1) - y0
+        if ext > rows:
+            big = torch.empty((ext, W, 2), dtype=band_inst.dtype, device=band_inst.device)
+            big[:rows] = canvas[:, :W]
+            canvas = big
+            if tcanvas is not None:
+                tb = torch.empty((ext, W), dtype=tcanvas.dtype, device=tcanvas.device)
+                tb[:rows] = tcanvas[:, :W]
+                tcanvas = tb
+        with watch.phase("reference tiling: canvas rows from the ranks below"):
+            for d in range(1, world):
+                ops = []
+                src = rank + d
+                if src < world:  # rows of `src`'s band that my tiles reach into
+                    a, b = max(band_bounds[src][0], y1), min(band_bounds[src][1], need_hi[rank])
+                    if b > a:
+                        ops.append(dist.P2POp(dist.irecv, canvas[a - y0:b - y0], src))
+                        if tcanvas is not None:
+                            ops.append(dist.P2POp(dist.irecv, tcanvas[a - y0:b - y0], src))
+                dst = rank - d
+                if dst >= 0:
+                    a, b = max(y0, band_bounds[dst][1]), min(y1, need_hi[dst])
+                    if b > a:
+                        ops.append(dist.P2POp(dist.isend, band_inst[a - y0:b - y0, :W].contiguous(), dst))
+                        if band_type is not None:
+                            ops.append(dist.P2POp(dist.isend, band_type[a - y0:b - y0, :W].contiguous(), dst))
+                if ops:
+                    for req in dist.batch_isend_irecv(ops):
+                        req.wait()
+    t1 = time.perf_counter()
+    parts = {}
+    for mode, ti in mine[rank]:
+        bounds, flags = tile_info[mode]
+        kept, _ = process_tile_predictions(canvas, tcanvas, bounds[ti], flags[ti], mode, None, margin, exact_ties, y_off=y0, slide_h=H)
+        parts[(mode, ti)] = kept
     torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    if world > 1 and dist is not None:
+        lst = [None] * world if rank == 0 else None
+        with watch.phase("reference tiling: per-tile dictionaries to rank 0"):
+            dist.gather_object(parts, lst, dst=0)
+        if rank != 0:
+            if prof is not None:
+                prof.update(exchange_s=t1 - t0, tiles_s=t2 - t1, tiles=len(mine[rank]))
+            return None
+        parts = {}
+        for p in lst:
+            parts.update(p)
+    acc = merge_tile_results(parts, tile_info, margin)
+    if prof is not None:
+        prof.update(exchange_s=t1 - t0, tiles_s=t2 - t1, merge_s=time.perf_counter() - t2, tiles=len(mine[rank]), tiles_total=sum(len(b) for b, _ in tile_info))
     return acc

@@ -68,6 +68,8 @@ typedef struct cerb_forward_io {
     long long row_stride;      /* 0 means out_w */
     int type_is_u8;            /* 0: TYPE heads write int64 (reference dtype); 1: uint8 (device-resident canvas) */
     float* const* feats;       /* optional [6]: x0,x1,x2,x3,conv_map(x4),x4 NHWC dumps for tests, or NULL */
+    const float* tiles_f32;    /* used when tiles == NULL: device [N][H][W][3] float pixel values (any floats; divided by 255 in fp32 like
+                                * `imgs / 255.0`, models/net_desc.py:147) -- NetDesc.forward on inputs that are not whole numbers in 0..255 */
 } cerb_forward_io;
 
 int cerb_net_forward(cerb_net* net, const cerb_forward_io* io, void* hip_stream);
@@ -94,7 +96,9 @@ int cerb_net_set_conv_algo(cerb_net* net, int algo);
  * Same arithmetic in the same order: the outputs are bit-identical (tests/test_net_gpu.py).  Applies with conv_algo 6 and head_algo 1. */
 int cerb_net_set_planar(cerb_net* net, int enable);
 /* Output heads (models/utils/net_layers.py:31-38): 1 (default) = every dense head of the batch in ONE grouped launch with the head's
- * weights resident in LDS (head_group_kernel), 0 = one launch per head (round-1 head_kernel); identical arithmetic, for A/B. */
+ * weights resident in LDS (head_group_kernel) and the 96 -> 3 / 7 logits on 4x4x1 matrix instructions (no zero-padded rows); 2 = round 3's
+ * grouped launch (logits on a 16-row instruction, 13 / 9 rows of zeros); 0 = one launch per head (round-1 head_kernel).  0 and 2 are
+ * bit-identical to each other; 1 sums the 96 products of a logit in another order (a few 1e-7 on the logits).  For A/B. */
 int cerb_net_set_head_algo(cerb_net* net, int algo);
 /* Centre-crop regions of interest (default 1 = on).  infer_step keeps only the centre out_h x out_w window of every head
  * (models/run_desc.py:452-491 cropping_center; the reference's default geometry 448 -> 144 keeps 10 % of the pixels it computes).

@@ -109,6 +109,14 @@ def run_case(tag, tile_seed, n, hw, out_shape, tasks, weight_seed=0, family="see
             mg = mg[:, o:o + out_shape, o:o + out_shape]
         if k != "Patch-Class":
             store["margin/" + k] = crops(mg) if mg.shape[1] >= 256 else mg
+        if k.endswith("INST"):
+            # the float64 evaluation itself, read out like infer_step reads the float32 one (softmax channels 1..2, centre crop): the anchor of
+            # tests/test_net_gpu.py's bar |got - p64| <= max|ref_fp32 - p64| + 1e-4 (rounded to float32 for storage: 6e-8)
+            pr = p64[:, 1:3].permute(0, 2, 3, 1).contiguous().numpy()
+            if pr.shape[1] > out_shape:
+                o = (pr.shape[1] - out_shape) // 2
+                pr = pr[:, o:o + out_shape, o:o + out_shape]
+            store[("p64_crops/" if pr.shape[1] >= 256 else "p64_full/") + k] = (crops(pr) if pr.shape[1] >= 256 else pr).astype(np.float32)
         print("%-12s %-12s reference fp32-vs-fp64: probabilities %.3e, logits %.3e relative (|logit| max %.1f)" %
               (tag, k, store["noise/" + k], store["logit_noise_rel/" + k], store["logit_absmax/" + k]))
     for k, v in ref_logits.items():

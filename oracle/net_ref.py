@@ -40,12 +40,14 @@ def _t(sd, k):
 
 
 _TRAINING = False  # net_forward(training=True): BatchNorm on batch statistics (running buffers updated in place), autograd on
+_EVAL_BN = ()      # net_forward(eval_bn_prefixes=...): BatchNorm layers under these state-dict prefixes stay in eval mode while training
+                   # (the reference's _freeze_weight puts the frozen modules' BatchNorm2d in eval(), models/net_desc.py:105-121)
 
 
 def _bn(sd, p, x):
     return F.batch_norm(
         x, _t(sd, p + ".running_mean"), _t(sd, p + ".running_var"), _t(sd, p + ".weight"), _t(sd, p + ".bias"),
-        training=_TRAINING, momentum=0.1, eps=BN_EPS,
+        training=_TRAINING and not any(p.startswith(e) for e in _EVAL_BN), momentum=0.1, eps=BN_EPS,
     )
 
 
@@ -80,11 +82,17 @@ def backbone_forward(sd, x):
     return feats  # [x0, x1, x2, x3, x4]
 
 
-def net_forward(sd, imgs_nchw, decoder_kwargs, considered_tasks, return_feats=False, training=False):
+def net_forward(sd, imgs_nchw, decoder_kwargs, considered_tasks, return_feats=False, training=False, eval_bn_prefixes=(), block_local_grads=(),
+                dropout_scale=None):
     """NetDesc.forward (net_desc.py:144-200). imgs: float NCHW in 0..255.  training=True: model.train() semantics (batch-statistics
-    BatchNorm, Dropout(0.3) in the Patch-Class branch, autograd enabled) -- the forward half of oracle/train_step_ref.py."""
-    global _TRAINING
+    BatchNorm, Dropout(0.3) in the Patch-Class branch, autograd enabled) -- the forward half of oracle/train_step_ref.py.
+    eval_bn_prefixes: BatchNorm layers that stay in eval mode (frozen modules); block_local_grads: decoder names run the way the reference
+    runs a decoder that is NOT in train_decoder_list -- under set_grad_enabled(False), with every conv layer switching autograd back on inside
+    itself (models/utils/conv_layers.py:44-53), so gradients exist inside each block and stop at the skip + upsample sum (net_desc.py:182);
+    dropout_scale: [N, 512] multiplier replacing the random Patch-Class dropout (keep / 0.7), for reproducible comparisons."""
+    global _TRAINING, _EVAL_BN
     _TRAINING = bool(training)
+    _EVAL_BN = tuple(eval_bn_prefixes)
     with torch.set_grad_enabled(bool(training)):
         imgs = imgs_nchw / 255.0
         feat_list = backbone_forward(sd, imgs)
@@ -103,7 +111,10 @@ def net_forward(sd, imgs_nchw, decoder_kwargs, considered_tasks, return_feats=Fa
                 v = F.adaptive_avg_pool2d(bf, (1, 1))
                 p = "decoder_head.Patch-Class"
                 v = F.relu(_bn(sd, p + ".bn1", v))
-                v = F.dropout(v, 0.3, training=_TRAINING)  # net_desc.py:70
+                if dropout_scale is not None:
+                    v = v * torch.as_tensor(dropout_scale, dtype=v.dtype).reshape(v.shape[0], 512, 1, 1)
+                else:
+                    v = F.dropout(v, 0.3, training=_TRAINING)  # net_desc.py:70
                 v = F.conv2d(v, _t(sd, p + ".conv1.weight"), _t(sd, p + ".conv1.bias"))
                 v = F.relu(_bn(sd, p + ".bn2", v))
                 v = F.conv2d(v, _t(sd, p + ".conv2.weight"), _t(sd, p + ".conv2.bias"))
@@ -113,6 +124,8 @@ def net_forward(sd, imgs_nchw, decoder_kwargs, considered_tasks, return_feats=Fa
             for idx in range(1, 5):
                 prev = F.interpolate(prev, scale_factor=2, mode="bilinear", align_corners=False)
                 new = feat_list[-(idx + 1)] + prev
+                if name in block_local_grads:
+                    new = new.detach()
                 for j in range(2):
                     p = "decoder_head.%s.%d.block.%d" % (name, idx - 1, j)
                     new = F.conv2d(new, _t(sd, p + ".conv.weight"), _t(sd, p + ".conv.bias"), padding=1)
@@ -125,6 +138,7 @@ def net_forward(sd, imgs_nchw, decoder_kwargs, considered_tasks, return_feats=Fa
                 h = F.conv2d(h, _t(sd, p + ".1.conv.weight"), _t(sd, p + ".1.conv.bias"))
                 out[name.split("#")[0] + "-" + clf] = h
     _TRAINING = False
+    _EVAL_BN = ()
     if return_feats:
         return out, feat_list, bottom
     return out

@@ -15,7 +15,8 @@ def main(argv=None):
     if args["--gpu"] and "WORLD_SIZE" not in os.environ:
         # `--gpu=0,1`: the reference drives both devices from one process (DataParallel, infer/base.py:46-47); here one rank per listed device,
         # self-spawned (cerberus_amd/launch.py), each taking every w-th file -- or a non-zero exit when the devices are not there
-        os.environ["HIP_VISIBLE_DEVICES"] = args["--gpu"]
+        if not os.environ.get("CERB_OVERSUBSCRIBE"):  # (plumbing tests list more ids than the box has devices: the ranks then time-share device 0)
+            os.environ["HIP_VISIBLE_DEVICES"] = args["--gpu"]
         ids = [g for g in args["--gpu"].split(",") if g.strip() != ""]
         if len(ids) > 1:
             from cerberus_amd import launch

@@ -81,7 +81,8 @@ def main(argv=None):
     if args["--gpu"] and "WORLD_SIZE" not in os.environ:
         # the reference's `--gpu=0,1` drives both devices from one process (DataParallel, infer/base.py:46-47); here every listed device gets
         # its own rank: the driver re-executes itself once per id (cerberus_amd/launch.py) -- or refuses when the devices are not there
-        os.environ["HIP_VISIBLE_DEVICES"] = args["--gpu"]
+        if not os.environ.get("CERB_OVERSUBSCRIBE"):  # (plumbing tests list more ids than the box has devices: the ranks then time-share device 0)
+            os.environ["HIP_VISIBLE_DEVICES"] = args["--gpu"]
         ids = [g for g in args["--gpu"].split(",") if g.strip() != ""]
         if len(ids) > 1:
             launch.ensure_world(len(ids), backend, argv=[os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv),
@@ -109,8 +110,6 @@ def main(argv=None):
                                                                      ", ".join("%d:cuda%d[%s]" % (r["rank"], r["device"], (r["uuid"] or "")[:13]) for r in ident["ranks"])))
     out_dir = args["--output_dir"]
     os.makedirs(out_dir, exist_ok=True)
-    if args["--reference_tiling"] and world > 1:
-        raise SystemExit("--reference_tiling walks the whole slide's canvases on one GPU (the reference's tile sets cross band borders): run it without torch.distributed.run")
 
     checkpoint, decoders, model_args = None, dict(DEFAULT_REQ_TARGET_CODE), default_model_kwargs()
     if args["--model"]:
@@ -206,6 +205,20 @@ def main(argv=None):
                 inst, _ = WSIRunner.postprocess(maps, wsi_mode=True)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
+        ref_nuclei = None
+        if args["--reference_tiling"] and "Nuclei-INST" in run.canv:
+            # the reference's own tile sets and margin rules (infer/wsi.py:81-268, 642-684) over the band canvases, every rank labelling the tiles
+            # that start in its band (rows below it fetched from its neighbours), each tile with skimage's tie order: the reference's instance
+            # set exactly, seam losses included; merged on rank 0
+            from cerberus_amd.ref_tiling import reference_tiled_nuclei_sharded
+
+            valid = max(0, min(run.band_h, H - run.r0 * out))
+            tprof = {}
+            ref_nuclei = reference_tiled_nuclei_sharded(run.canv["Nuclei-INST"][:valid], None if "Nuclei-TYPE" not in run.canv else run.canv["Nuclei-TYPE"][:valid],
+                                                        run.r0 * out, (H, W), rank, world, dist, tile_shape=4096, margin=64, patch_output_shape=out, watch=watch,
+                                                        prof=tprof)
+            if log:
+                log.info("Reference-Tiled Nuclei Time: {0} ({1} tiles on rank 0)".format(time.perf_counter() - t2, tprof.get("tiles")))
         if rank != 0:
             continue
         # the reference times nuclei, the tissue map and gland + lumen as separate phases (infer/wsi.py:684, 719, 856); here the three tissues
@@ -241,15 +254,8 @@ def main(argv=None):
         nuc_only = {k: v for k, v in inst.items() if k == "Nuclei"} if records is not None else inst
         bw, bh = reader.info.slide_dimensions
         prebuilt = None
-        ref_src = maps if "Nuclei-INST" in maps else run.canv  # (a slide above ONE_CALL_PX leaves only the class maps in `maps`: the canvases are the runner's)
-        if args["--reference_tiling"] and "Nuclei-INST" in ref_src:
-            # the reference's own tile sets and margin rules (infer/wsi.py:81-268, 642-684) over the stitched canvases, each tile labelled on
-            # the GPU with skimage's tie order: its instance set exactly, seam losses included
-            from cerberus_amd.ref_tiling import reference_tiled_nuclei
-
-            tmap = ref_src.get("Nuclei-TYPE")
-            prebuilt = {"Nuclei": reference_tiled_nuclei(ref_src["Nuclei-INST"][:H, :W], None if tmap is None else tmap[:H, :W], tile_shape=4096, margin=64,
-                                                         patch_output_shape=out)}
+        if ref_nuclei is not None:
+            prebuilt = {"Nuclei": ref_nuclei}
         info = build_wsi_inst_info(nuc_only, maps, (H, W), float(args["--wsi_proc_mag"]), region_records=records,
                                    base_mag=None if reader.info.mpp is None else float(reader.info.mpp[0]), base_hw=(bh, bw), prebuilt=prebuilt)
         # serialising ~1e6 per-instance dictionaries is host-only work: it overlaps the next slide's inference (written to a temporary

@@ -125,6 +125,71 @@ def test_encoder_and_logits_vs_oracle(full_model):
         assert (v.cpu() - ref[k]).abs().max().item() < 2e-4, k
 
 
+def test_forward_accepts_any_float_input(full_model):
+    """NetDesc.forward on float NCHW values that are NOT whole numbers in 0..255 (models/net_desc.py:144-147 divides whatever it gets by 255):
+    the float-input instantiation of the stem against the oracle on the same floats -- fractional, negative and above 255 -- and, on
+    integer-valued floats, bit-identical to the uint8 path."""
+    m, sd, kw = full_model
+    rs = np.random.RandomState(12)
+    x = torch.from_numpy((rs.rand(2, 3, 96, 96) * 300.0 - 20.0).astype(np.float32))
+    ref = net_ref.net_forward(sd, x, kw["decoder_kwargs"], kw["considered_tasks"])
+    out = m(x.cuda())
+    assert list(out.keys()) == list(ref.keys())
+    for k, v in out.items():
+        assert v.shape == ref[k].shape
+        assert (v.cpu() - ref[k]).abs().max().item() < 2e-4, k
+    tiles = rs.randint(0, 256, (2, 96, 96, 3)).astype(np.uint8)
+    a = m(torch.from_numpy(tiles).cuda())                                          # uint8 NHWC
+    b = m(torch.from_numpy(tiles).float().permute(0, 3, 1, 2).contiguous())        # whole numbers as float NCHW: routed to the uint8 stem
+    xf = torch.from_numpy(tiles).float().permute(0, 3, 1, 2).contiguous().cuda()
+    xf[0, 0, 0, 0] += 0.5                                                          # one fractional value: the float stem; every other input equal
+    c = m(xf)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+        # one input value moved by 0.5 / 255: the float stem does the same arithmetic on all the others (a wrong channel order, a missing /255 or a
+        # transposed read would be O(1) here), and tile 1 does not see the change at all
+        assert (a[k] - c[k]).abs().max().item() < 1e-2 * max(1.0, a[k].abs().max().item()), k
+        assert torch.equal(a[k][1], c[k][1]), k
+
+
+def test_head_w2_on_4x4_matrix_instructions_vs_padded_16_row_instruction(full_model):
+    """cerb_net_set_head_algo(1) (default: 96 -> 3 / 7 logits on v_mfma_f32_4x4x1) against 2 (round 3: zero-padded 16 x 16 x 4) and 0 (one
+    launch per head): the same products summed in another order -- logits within 2e-6 of their scale, probabilities within 2e-6, argmax
+    maps equal wherever the top-2 margin is not rounding-sized; 0 and 2 stay bit-identical to each other."""
+    m, sd, kw = full_model
+    tiles = torch.from_numpy(np.random.RandomState(31).randint(0, 256, (3, 256, 256, 3)).astype(np.uint8)).cuda()
+    res, lgs = {}, {}
+    try:
+        for algo in (1, 2, 0):
+            m.set_head_algo(algo)
+            res[algo] = {k: v.clone() for k, v in m.infer_tiles(tiles, [200, 232]).items()}
+            lgs[algo] = {k: v.clone() for k, v in m(tiles).items()}
+    finally:
+        m.set_head_algo(1)
+    for k in res[1]:
+        assert torch.equal(res[2][k], res[0][k]), k
+        if res[1][k].dtype == torch.float32:
+            assert (res[1][k] - res[2][k]).abs().max().item() < 2e-6, k
+        else:
+            assert (res[1][k] != res[2][k]).float().mean().item() < 1e-4, k
+    for k in lgs[1]:
+        scale = max(1.0, lgs[2][k].abs().max().item())
+        assert (lgs[1][k] - lgs[2][k]).abs().max().item() < 2e-6 * scale, k
+
+
+# What the default path ACHIEVED against the reference's float32 outputs when these bars were last set (round 4, scripts/dev_parity_achieved.py on an
+# MI355X; max |got - ref_fp32| over the fixture's INST probabilities).  The test holds every later build to max(1e-4, 1.5 x) of it: a
+# regression from 2e-6 to 9e-5 would pass the 1e-4 bar of the north star but not this one.
+ACHIEVED_R04 = {
+    'cfg1_nuclei': {'Nuclei-INST': 2.95e-06},
+    'cfg2_all': {'Lumen-INST': 3.13e-06, 'Gland-INST': 1.91e-06, 'Nuclei-INST': 2.80e-06},
+    'g448_all': {'Lumen-INST': 3.61e-06, 'Gland-INST': 1.19e-07, 'Nuclei-INST': 1.49e-06},
+    'small96_all': {'Lumen-INST': 2.80e-06, 'Gland-INST': 1.49e-06, 'Nuclei-INST': 2.65e-06},
+    'seed1_all': {'Lumen-INST': 4.23e-06, 'Gland-INST': 3.31e-06, 'Nuclei-INST': 4.65e-06},
+    'refinit_all': {'Lumen-INST': 6.86e-04, 'Gland-INST': 6.62e-05, 'Nuclei-INST': 2.52e-04},
+}
+
+
 @pytest.mark.parametrize("tag", ["cfg1_nuclei", "cfg2_all", "g448_all", "small96_all", "seed1_all", "refinit_all"])
 def test_infer_step_vs_reference_golden(golden_dir, tag):
     """The default path (F(4x4) Winograd, planar last level, grouped heads) against what the REFERENCE's own NetDesc / infer_step produced
@@ -149,10 +214,26 @@ def test_infer_step_vs_reference_golden(golden_dir, tag):
         if a.dtype == np.float32:
             err = np.abs(got - ref).max()
             assert err < _prob_bar(g, k), (k, err, _prob_bar(g, k))
+            # the reference's own float64 evaluation is the anchor.  Non-saturating families: this path is at most 1e-4 further from it than the
+            # reference's float32 evaluation is (achieved: 1e-7 .. 4e-6 against 1e-7 .. 2e-6).  refinit_all (the reference's default
+            # initialisation: logits in the thousands, where ITS float32 result is 7e-5 .. 4.6e-4 from ITS float64 result): F(4x4,3x3) amplifies
+            # rounding ~3x more than a direct convolution there (measured round 4, scripts/dev_parity_achieved.py: |got - p64| 5.8e-4 / 6.0e-5 /
+            # 3.2e-4 for Lumen / Gland / Nuclei with F(4x4); 6.7e-4 / 4.2e-5 / 1.3e-4 direct; 4.6e-4 / 3.6e-5 / 1.1e-4 F(2x2); the reference
+            # itself 4.6e-4 / 2.4e-5 / 6.7e-5) -- bar: 3x the whole-tensor fp32-vs-fp64 noise of the reference, and the achieved-error record
+            p64 = g["p64_crops/" + k] if ("p64_crops/" + k) in g else g["p64_full/" + k]
+            e64, r64 = float(np.abs(got - p64).max()), float(np.abs(ref - p64).max())
+            if tag != "refinit_all":
+                assert e64 <= r64 + PROB_TOL, (k, e64, r64)
+            else:
+                assert e64 <= 3.0 * float(g["noise/" + k]) + PROB_TOL, (k, e64, float(g["noise/" + k]))
+            print("achieved %s %s: |got - ref32| %.3e  |got - ref64| %.3e  (|ref32 - ref64| %.3e)" % (tag, k, err, e64, r64))
+            if tag in ACHIEVED_R04:
+                assert err <= max(1.5 * ACHIEVED_R04[tag][k], 2e-6 if tag != "refinit_all" else 1e-4), (k, err, ACHIEVED_R04[tag][k])
         elif k != "Patch-Class":
             _check_type_map(g, k, got, ref)
         else:
             assert np.array_equal(got, ref), k
+    assert tag in ACHIEVED_R04, "no achieved-error record for " + tag
     for k, v in lg.items():
         a = v.permute(0, 2, 3, 1).contiguous().cpu().numpy()
         key = "logits_crops/" + k
@@ -259,8 +340,15 @@ def test_direct_conv_algo_vs_reference_golden(golden_dir, tag):
         ref = g[key] if key in g else g["out_full/" + k]
         got = _crops(a4) if key in g else a4
         if a.dtype == np.float32:
-            assert np.abs(got - ref).max() < PROB_TOL, k
-            assert np.abs(a - b).max() < 5e-5, k
+            p64 = g["p64_crops/" + k] if ("p64_crops/" + k) in g else g["p64_full/" + k]
+            assert np.abs(got - ref).max() < _prob_bar(g, k), k
+            if tag != "refinit_all":
+                assert float(np.abs(got - p64).max()) <= float(np.abs(ref - p64).max()) + PROB_TOL, k
+            else:
+                assert float(np.abs(got - p64).max()) <= 3.0 * float(g["noise/" + k]) + PROB_TOL, k
+            assert np.abs(a - b).max() < (5e-5 if tag != "refinit_all" else 2.0 * _prob_bar(g, k)), k
+        elif tag == "refinit_all" and k != "Patch-Class":
+            _check_type_map(g, k, got, ref)
         else:
             assert (got != ref).mean() < 1e-4, k
             assert (a != b).mean() < 1e-4, k
@@ -372,15 +460,14 @@ def test_forward_is_bitwise_reproducible(full_model, algo):
 
 
 @pytest.mark.parametrize("algo", [5, 7])
-@pytest.mark.parametrize("tag", ["cfg2_all", "g448_all", "small96_all"])
+@pytest.mark.parametrize("tag", ["cfg2_all", "g448_all", "small96_all", "refinit_all"])
 def test_wino4_algo_vs_reference_golden(golden_dir, tag, algo):
     """cerb_net_set_conv_algo(5 / 7): Winograd F(4x4,3x3) (conv_wino4.hip / conv_wino4b.hip: 36 products per 16 outputs, transform points
     0, +-1, +-2, inf) against the reference's golden vectors at the same 1e-4 bar -- plain, residual, grouped, cropped (region-of-interest blocks),
     odd-sized (blocks hanging over the image, odd block counts) launches -- and against algorithm 1 (F(2x2)): the two differ by the
     transforms' rounding only, a few 1e-6 on the probability maps (tests/tools/dev_wino4_numerics.py)."""
     g = np.load(os.path.join(golden_dir, "net_%s.npz" % tag))
-    tasks = [str(t) for t in g["tasks"]]
-    m, sd, kw = _model(tasks, int(g["weight_seed"]))
+    m, sd, kw, tasks = _golden_model(g)  # (refinit_all: the reference's default initialisation -- logits in the thousands, the stress case)
     n, hw, osz = int(g["n"]), int(g["hw"]), int(g["out_shape"])
     tiles = np.random.RandomState(int(g["tile_seed"])).randint(0, 256, (n, hw, hw, 3)).astype(np.uint8)
     m.set_conv_algo(1)
@@ -404,8 +491,15 @@ def test_wino4_algo_vs_reference_golden(golden_dir, tag, algo):
         ref = g[key] if key in g else g["out_full/" + k]
         got = _crops(a4) if key in g else a4
         if a.dtype == np.float32:
-            assert np.abs(got - ref).max() < PROB_TOL, k
-            assert np.abs(a - b).max() < 5e-5, k
+            p64 = g["p64_crops/" + k] if ("p64_crops/" + k) in g else g["p64_full/" + k]
+            assert np.abs(got - ref).max() < _prob_bar(g, k), k
+            if tag != "refinit_all":
+                assert float(np.abs(got - p64).max()) <= float(np.abs(ref - p64).max()) + PROB_TOL, k
+            else:
+                assert float(np.abs(got - p64).max()) <= 3.0 * float(g["noise/" + k]) + PROB_TOL, k
+            assert np.abs(a - b).max() < (5e-5 if tag != "refinit_all" else 2.0 * _prob_bar(g, k)), k
+        elif tag == "refinit_all" and k != "Patch-Class":
+            _check_type_map(g, k, got, ref)
         else:
             assert (got != ref).mean() < 1e-4, k
             assert (a != b).mean() < 1e-4, k

@@ -439,3 +439,69 @@ def test_subtype_fine_tune_step_vs_reference():
     for k, v in new.items():
         if k.endswith("num_batches_tracked"):
             assert (int(v) != int(sd0[k])) == (k in tracked), k
+
+
+def test_data_gradients_upstream_of_an_eval_mode_batchnorm():
+    """a BatchNorm put in eval mode by cerb_net_set_bn_eval normalises with CONSTANTS, so its backward is dy = dz * gamma * rstd
+    with no batch-mean / xhat-projection terms.  Round 3 ran the batch-statistics backward there (train.py only hid it by deleting the frozen
+    gradients).  Here the frozen configuration (subtype_nuclei) keeps every gradient the tape produces and compares the ones UPSTREAM of
+    frozen BatchNorm layers -- backbone, conv_map, an INST decoder, the frozen BatchNorm's own gamma / beta -- with torch autograd over the oracle
+    network run the same way (eval-mode BatchNorm under the frozen prefixes, the #TYPE decoders with block-local gradients, same dropout)."""
+    from cerberus_amd.net_desc import create_model
+    from cerberus_amd.weights import default_model_kwargs, make_state_dict
+    from oracle import net_ref
+
+    kw = default_model_kwargs()
+    kw["subtype_nuclei"] = True
+    m = create_model(**kw)
+    sd_np = make_state_dict(0)
+    rs = np.random.RandomState(7)
+    for k, v in sd_np.items():  # running statistics away from (0, 1), so that eval mode differs visibly from batch statistics
+        if k.endswith("running_mean"):
+            sd_np[k] = (v + 0.05 * rs.randn(*v.shape)).astype(np.float32)
+        elif k.endswith("running_var"):
+            sd_np[k] = (v * (0.8 + 0.4 * rs.rand(*v.shape))).astype(np.float32)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    n, hw = 2, 96
+    tiles = rs.randint(0, 256, (n, hw, hw, 3)).astype(np.uint8)
+    heads = {"Lumen-INST": 3, "Gland-INST": 3, "Nuclei-INST": 3, "Nuclei-TYPE": 7, "Gland-TYPE": 3, "Patch-Class": 9}
+    targets, flags, tnp = {}, {}, {}
+    for h, c in heads.items():
+        t = rs.randint(0, c, (n,) if h == "Patch-Class" else (n, hw, hw)).astype(np.float32)
+        tnp[h] = t.reshape(n, 1, 1, 1) if h == "Patch-Class" else t[..., None]
+        targets[h] = torch.from_numpy(t).cuda()
+        flags[h] = torch.ones(n).cuda()
+    loss = copy.deepcopy(PARAMSET_LOSS)
+    loss["loss_info"]["Nuclei-TYPE"]["weight"] = 1.0
+    keep = torch.from_numpy(rs.rand(n, 512) >= 0.3)
+    losses, grads = m.train_grads(torch.from_numpy(tiles).cuda(), targets, flags, loss, keep.cuda())
+    # the oracle under autograd
+    params = {}
+    for k, v in sd_np.items():
+        t = torch.from_numpy(np.array(v))
+        if t.dtype == torch.float32 and not k.endswith(("running_mean", "running_var")) and not k.startswith("backbone.fc"):
+            t.requires_grad_(True)
+        params[k] = t
+    x = torch.from_numpy(tiles).float().permute(0, 3, 1, 2).contiguous()
+    lg = net_ref.net_forward(params, x, kw["decoder_kwargs"], kw["considered_tasks"], training=True, eval_bn_prefixes=m.frozen_prefixes(),
+                             block_local_grads=("Nuclei#TYPE", "Gland#TYPE"), dropout_scale=keep.float() / 0.7)
+    total = 0
+    for h in heads:
+        one = train_ref.head_loss_tensor(h, lg[h], tnp[h], np.ones(n, bool), loss, n_classes=heads[h])
+        assert abs(float(one) - losses[h]) <= 2e-4 * max(1.0, abs(float(one))), (h, float(one), losses[h])
+        total = total + one
+    total.backward()
+    checked = 0
+    for k in ("backbone.conv1.weight", "backbone.layer1.1.conv2.weight", "backbone.layer2.0.downsample.0.weight", "backbone.layer3.2.conv1.weight",
+              "backbone.layer4.2.conv2.weight", "backbone.layer3.4.bn2.weight", "backbone.layer2.1.bn1.bias", "conv_map.weight",
+              "decoder_head.Lumen.1.block.0.conv.weight", "decoder_head.Gland.3.block.1.conv.weight", "decoder_head.Gland.3.block.1.bn.weight",
+              "output_head.Nuclei.INST.x.0.block.0.conv.weight", "decoder_head.Nuclei#TYPE.3.block.1.conv.weight"):
+        ref = params[k].grad.double().numpy()
+        got = grads[k].double().cpu().numpy().reshape(ref.shape)
+        scale = float(np.abs(ref).max())
+        assert scale > 0, k
+        cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-300))
+        err = float(np.abs(got - ref).max()) / scale
+        assert cos > 0.9999 and err < 2e-2, (k, cos, err)
+        checked += 1
+    assert checked == 13

@@ -77,3 +77,19 @@ def test_no_gpu_fails_loudly():
     m = create_model(**default_model_kwargs(["Nuclei"]))
     with pytest.raises(CerberusHipError, match="no CPU fallback"):
         m.infer_tiles(torch.zeros((1, 256, 256, 3), dtype=torch.uint8), 256)
+
+
+def test_custom_ops_register_without_a_gpu_and_refuse_cpu_tensors():
+    """cerberus_amd/ops.py: schemas + FakeTensor shape inference work anywhere; a CPU tensor is refused by the dispatcher (CUDA-only kernels)."""
+    import pytest
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+
+    from cerberus_amd import ops  # noqa: F401
+
+    assert "Tensor[]" in str(torch.ops.cerberus_amd.infer_tiles.default._schema)
+    with FakeTensorMode():
+        outs = torch.ops.cerberus_amd.infer_tiles(torch.empty((2, 256, 256, 3), dtype=torch.uint8), 0, 256, 256, "Nuclei-INST,Nuclei-TYPE")
+        assert [tuple(o.shape) for o in outs] == [(2, 256, 256, 2), (2, 256, 256)] and outs[1].dtype == torch.int64
+    with pytest.raises(NotImplementedError):
+        torch.ops.cerberus_amd.postproc(torch.zeros((8, 8, 2)), "Nuclei", 1.0, True)
