@@ -46,6 +46,8 @@ hipError_t cerb_launch_bn_apply(float* x, const float* src, const float* resid, 
 hipError_t cerb_launch_pointwise(const float* in, const float* w, const float* bias, float* out, long long rows, int cin, int cout, const float* in_scale,
                                  hipStream_t st);
 hipError_t cerb_launch_crop_gap(const float* x, int N, int H, int W, int C, int y0, int ch, int x0, int cw, float* out, hipStream_t st);
+hipError_t cerb_launch_copy_multi(int count, float* const* dst, const float* const* src, const long long* n, void** dev_tab, size_t* dev_bytes,
+                                  std::vector<char>* host_prev, hipStream_t st);
 hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, float* dy, float* dresid, long long group_stride, long long rows, int C, int groups,
                               const float* mean, const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, int relu, int dy_assign, void* ws, hipStream_t st, unsigned long long eval_mask = 0);
 hipError_t cerb_launch_conv_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int G, int N, int H, int W, int Cin, int Cout,
@@ -223,6 +225,9 @@ struct cerb_net {
     float* stem_raw = nullptr;  // [64][3][7][7]
     std::vector<DevBuf> tape;
     size_t tape_pos = 0;
+    void* copy_tab = nullptr;    // cerb_net_update_params: device table of the parameter copies (cerb_launch_copy_multi)
+    size_t copy_tab_bytes = 0;
+    std::vector<char> copy_tab_host;
     float* zero_bias = nullptr;  // 512 zeros: the bias operand of the data-gradient convs
     std::map<std::string, std::pair<float*, long long>> grads;  // state-dict key -> (device gradient, numel) of the last cerb_net_train_grads
     std::map<std::string, std::vector<std::string>> bn_keys;   // conv / bn name -> state-dict prefixes of its BatchNorm, one per group
@@ -244,6 +249,7 @@ struct cerb_net {
     ~cerb_net() {
         for (auto& r : prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         for (void* p : dev_allocs) (void)hipFree(p);
+        if (copy_tab) (void)hipFree(copy_tab);
         x0.release(); pool.release(); ta.release(); tb.release(); cm.release(); dmid.release(); dsum.release(); psum.release(); pmid.release(); pout.release(); psum2.release(); pmid2.release(); pout2.release();
         t_mean.release(); t_rstd.release(); t_ws.release(); t_hid.release(); t_gap.release(); t_pc1.release(); t_idn.release(); t_dil.release();
         for (auto& b : tape) b.release();
@@ -822,7 +828,11 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
     const long long map_px = (long long)p.Ho * p.Wo;
     const bool use_w4 = net->conv_algo == 5 || net->conv_algo == 7 || (net->conv_algo == 6 && map_px >= 256);
     const bool planar = planar_out_gs > 0;
-    const bool w4b = !planar && (net->conv_algo == 7 || (net->conv_algo == 6 && map_px <= 4096)) && c.cin % 64 == 0;
+    static const long long w4b_max_px = [] {  // developer A/B only (scripts/gpu_session_r04c.sh): where conv_wino4b hands over to conv_wino4
+        const char* e = getenv("CERB_W4B_MAX_PX");
+        return e ? atoll(e) : 4096ll;
+    }();
+    const bool w4b = !planar && (net->conv_algo == 7 || (net->conv_algo == 6 && map_px <= w4b_max_px)) && c.cin % 64 == 0;
     if (planar && !(use_w4 && c.wino && mode == 0 && net->fold_bn && !resid)) return fail("internal: conv " + name + " cannot take the planar path");
     if (use_w4 && c.wino && mode == 0 && (!it->second.host_w.empty() || !net->fold_bn)) {
         PackedConv& cm = it->second;
@@ -890,6 +900,15 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
     const int hs[5] = {H, H / 2, H / 4, H / 8, H / 16}, ws[5] = {W, W / 2, W / 4, W / 8, W / 16};
     const size_t D = net->dense_idx.size();
     const size_t guard = cerb_conv_guard_bytes(W);
+    // Which decoder levels keep their three private tensors in the tile-planar layout (conv_wino4p.hip): the two last levels (64 channels) when
+    // their maps are above conv_wino4b's range, on the default algorithms with folded BatchNorm.  One predicate for the allocation and the loop.
+    auto level_is_planar = [&](int u) {
+        if (dry || u < 2 || !net->planar || !net->fold_bn || net->conv_algo != 6 || net->head_algo < 1) return false;
+        const std::string n0 = "dec." + std::to_string(u) + ".0", n1 = "dec." + std::to_string(u) + ".1";
+        auto c0 = net->conv.find(n0), c1 = net->conv.find(n1);
+        if (c0 == net->conv.end() || c1 == net->conv.end() || !c0->second.wino) return false;
+        return (long long)hs[3 - u] * ws[3 - u] > 4096 && c0->second.cin == 64 && c0->second.cout == 64 && c1->second.cout == 64;
+    };
     if (!dry) {
         if (net->x0.ensure((size_t)N * H * W * 64 * 4, guard) || net->pool.ensure((size_t)N * hs[1] * ws[1] * 64 * 4, guard)) return fail("workspace allocation failed");
         for (int i = 1; i < 5; ++i)
@@ -898,12 +917,20 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
             net->cm.ensure((size_t)N * hs[4] * ws[4] * 256 * 4, guard))
             return fail("workspace allocation failed");
         if (D) {
-            // dmid holds the first conv of a level: sizes (per decoder) 32^2*256, 64^2*128, 128^2*64, 256^2*64 -> max is the last
-            if (net->dmid.ensure(D * (size_t)N * H * W * 64 * 4, guard)) return fail("workspace allocation failed");
-            if (net->conv_algo && net->dsum.ensure(D * (size_t)N * H * W * 64 * 4, guard)) return fail("workspace allocation failed");
-            const int oc[4] = {128, 64, 64, 64};
-            for (int u = 0; u < 4; ++u)
-                if (net->dout[u].ensure(D * (size_t)N * hs[3 - u] * ws[3 - u] * oc[u] * 4, guard)) return fail("workspace allocation failed");
+            // NHWC decoder workspace: dsum = skip + upsample, dmid = the first conv's output, dout[u] = the level's output -- sized by the
+            // largest level that actually RUNS NHWC: the levels that live in the tile-planar buffers (level_is_planar below) need none of them
+            // (round 3 allocated all three at the last level's size next to the planar tensors: ~8 GB of untouched HBM at 32 x 256^2)
+            const int oc[4] = {128, 64, 64, 64}, ic[4] = {256, 128, 64, 64};
+            size_t mid_px = 0, sum_px = 0;
+            for (int u = 0; u < 4; ++u) {
+                if (level_is_planar(u)) continue;
+                const size_t px = (size_t)hs[3 - u] * ws[3 - u];
+                mid_px = std::max(mid_px, px * (size_t)oc[u]);
+                sum_px = std::max(sum_px, px * (size_t)ic[u]);
+                if (net->dout[u].ensure(D * (size_t)N * px * oc[u] * 4, guard)) return fail("workspace allocation failed");
+            }
+            if (mid_px && net->dmid.ensure(D * (size_t)N * mid_px * 4, guard)) return fail("workspace allocation failed");
+            if (sum_px && net->conv_algo && net->dsum.ensure(D * (size_t)N * sum_px * 4, guard)) return fail("workspace allocation failed");
         }
     }
     // ---- encoder ----------------------------------------------------------------------------------------------
@@ -1020,8 +1047,7 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
             // whole lines, nothing masks an edge.  Same arithmetic in the same order: bit-identical to the NHWC path (cerb_net_set_planar(0)).
             // The level below (same 64 channels at half the resolution) does the same when its maps are above conv_wino4b's range, and hands
             // its output to the last level's up-sampling in that layout.
-            const bool lvl_planar = !dry && u >= 2 && net->planar && net->fold_bn && net->conv_algo == 6 && net->head_algo >= 1 && net->conv[n0].wino &&
-                                    (long long)hh * ww > 4096 && cin0 == 64 && cmid == 64 && net->conv[n1].cout == 64 && (u == 3 || prev_gs > 0);
+            const bool lvl_planar = level_is_planar(u) && (u == 3 || prev_gs > 0);
             if (lvl_planar) {
                 PlanarBuf &bs = u == 3 ? net->psum : net->psum2, &bm = u == 3 ? net->pmid : net->pmid2, &bo = u == 3 ? net->pout : net->pout2;
                 if (bs.ensure((int)D, N, hh, ww, 64, st) || bm.ensure((int)D, N, hh, ww, 64, st) || bo.ensure((int)D, N, hh, ww, 64, st))
@@ -1735,12 +1761,19 @@ extern "C" int cerb_net_update_params(cerb_net* net, int count, const char* cons
     if (!net || count < 0 || (count && (!keys || !dev_src))) return fail("cerb_net_update_params: bad arguments");
     if (!net->finalized || net->fold_bn) return fail("cerb_net_update_params: needs a finalized handle packed for training (cerb_net_set_fold_bn(net, 0))");
     hipStream_t st = (hipStream_t)hip_stream;
+    std::vector<float*> cd;
+    std::vector<const float*> cs;
+    std::vector<long long> cn;
     for (int i = 0; i < count; ++i) {
         auto it = net->param_slots.find(keys[i]);
         if (it == net->param_slots.end()) continue;  // running statistics, num_batches_tracked, backbone.fc.*: nothing on the device reads them
         if (!dev_src[i]) return fail(std::string("cerb_net_update_params: null source for ") + keys[i]);
-        for (const cerb_net::ParamSlot& sl : it->second) HIP_OK(hipMemcpyAsync(sl.dst, dev_src[i], (size_t)sl.n * 4, hipMemcpyDeviceToDevice, st));
+        for (const cerb_net::ParamSlot& sl : it->second) {
+            cd.push_back(sl.dst); cs.push_back(dev_src[i]); cn.push_back(sl.n);
+        }
     }
+    // every parameter tensor into its slot(s) in ONE launch (round 3: one hipMemcpyAsync per tensor, ~470 per optimiser step)
+    HIP_OK(cerb_launch_copy_multi((int)cd.size(), cd.data(), cs.data(), cn.data(), &net->copy_tab, &net->copy_tab_bytes, &net->copy_tab_host, st));
     HIP_OK(cerb_launch_pack_stem(net->stem_raw, net->stem_w, st));
     for (auto& kv : net->conv) {
         PackedConv& pc = kv.second;

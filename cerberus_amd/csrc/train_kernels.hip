@@ -10,6 +10,7 @@
 // and the coefficients of the gradient), gradient.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 #include <stdint.h>
@@ -346,35 +347,43 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restr
 // recompute z's sign from y instead of reading z back (the ReLU mask costs 4 bytes per element otherwise): identical bits by construction
 __device__ __forceinline__ float bn_out(float y, float m, float rs, float ga, float be) { return __fmaf_rn(y - m, rs * ga, be); }
 
+// Thread = (channel quad c4, row lane rl) like the statistics pass; a block walks rows rl + nrl * (blockIdx.x + k * gridDim.x): the channel quad
+// of a thread never changes, so the four per-channel vectors are loaded ONCE and an element costs one 64-bit multiply-add of address
+// arithmetic (round 3 decoded a flat index with two 64-bit divisions per element and re-read 16 parameter values for it: the pass ran at
+// 0.5 of the HBM peak on instruction issue).  Same expression per element (bn_out): identical bits.  blockIdx.y = group.
 __global__ __launch_bounds__(256) void bn_apply_kernel(float* x, const float* src, const float* __restrict__ resid, long long group_stride, long long rows, int C,
                                                        int groups, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int relu) {
-    const int c4n = C >> 2;
-    const long long per_group = rows * c4n, total = per_group * groups;
-    #pragma unroll 2
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int g = (int)(i / per_group);
-        const long long j = i - (long long)g * per_group;
-        const int c = 4 * (int)(j % c4n);
-        float4* p = reinterpret_cast<float4*>(x + g * group_stride + (j / c4n) * C + c);
-        float4 v = *reinterpret_cast<const float4*>(src + g * group_stride + (j / c4n) * C + c);  // src == x: in place
-        const float* m = mean + g * C + c;
-        const float* rs = rstd + g * C + c;
-        const float* ga = gamma + g * C + c;
-        const float* be = beta + g * C + c;
-        v.x = bn_out(v.x, m[0], rs[0], ga[0], be[0]);
-        v.y = bn_out(v.y, m[1], rs[1], ga[1], be[1]);
-        v.z = bn_out(v.z, m[2], rs[2], ga[2], be[2]);
-        v.w = bn_out(v.w, m[3], rs[3], ga[3], be[3]);
+    const int c4n = C >> 2, tid = threadIdx.x, g = blockIdx.y;
+    const int c4 = tid % c4n, rl = tid / c4n, nrl = 256 / c4n;
+    if (rl >= nrl) return;
+    const int gc = g * C + 4 * c4;
+    const float4 m = *reinterpret_cast<const float4*>(mean + gc), rs = *reinterpret_cast<const float4*>(rstd + gc),
+                 ga = *reinterpret_cast<const float4*>(gamma + gc), be = *reinterpret_cast<const float4*>(beta + gc);
+    const long long base = g * group_stride + 4 * c4;
+    const long long step = (long long)gridDim.x * nrl;
+    auto one = [&](long long r) {
+        const long long a = base + r * C;
+        float4 v = *reinterpret_cast<const float4*>(src + a);  // src == x: in place
+        v.x = bn_out(v.x, m.x, rs.x, ga.x, be.x);
+        v.y = bn_out(v.y, m.y, rs.y, ga.y, be.y);
+        v.z = bn_out(v.z, m.z, rs.z, ga.z, be.z);
+        v.w = bn_out(v.w, m.w, rs.w, ga.w, be.w);
         if (resid) {
-            const float4 r = *reinterpret_cast<const float4*>(resid + g * group_stride + (j / c4n) * C + c);
-            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            const float4 r4 = *reinterpret_cast<const float4*>(resid + a);
+            v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
         }
         if (relu) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        *p = v;
+        *reinterpret_cast<float4*>(x + a) = v;
+    };
+    long long r = (long long)blockIdx.x * nrl + rl;
+    for (; r + step < rows; r += 2 * step) {  // two independent rows in flight
+        one(r);
+        one(r + step);
     }
+    if (r < rows) one(r);
 }
 // out[r][co] = bias[co] + sum_ci in[r][ci] * W[co][ci]; thread = (row, 4 couts); weights read through the caches
 __global__ __launch_bounds__(256) void pointwise_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
@@ -431,10 +440,14 @@ hipError_t cerb_launch_bn_stats(const float* x, long long group_stride, long lon
 }
 hipError_t cerb_launch_bn_apply(float* x, const float* src, const float* resid, long long group_stride, long long rows, int C, int groups, const float* mean,
                                 const float* rstd, const float* gamma, const float* beta, int relu, hipStream_t st) {
-    long long blocks = (rows * (C / 4) * groups + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (C % 4 || C / 4 > 256) return hipErrorInvalidValue;
+    const int nrl = 256 / (C / 4);
+    long long blocks = (rows + nrl - 1) / nrl;
+    const long long cap = std::max(1ll, (256ll * 32) / std::max(1, groups));
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, src ? src : x, resid, group_stride, rows, C, groups, mean, rstd, gamma, beta, relu);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks, (unsigned)groups), dim3(256), 0, st, x, src ? src : x, resid, group_stride, rows, C, groups, mean, rstd, gamma,
+                       beta, relu);
     return hipGetLastError();
 }
 hipError_t cerb_launch_pointwise(const float* in, const float* w, const float* bias, float* out, long long rows, int cin, int cout, const float* in_scale,
@@ -552,26 +565,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu,
                                                            unsigned long long eval_mask) {
-    const int c4n = C >> 2;
-    const long long per_group = rows * c4n, total = per_group * groups;
-    const float invM_train = 1.f / (float)rows;
-    #pragma unroll 2
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int g = (int)(i / per_group);
-        // a group in EVAL mode (cerb_net_set_bn_eval) normalises with constants: dy = dz * gamma * rstd, no mean / xhat-projection terms
-        // (they are the derivative of the BATCH statistics, which an eval-mode BatchNorm does not use)
-        const float invM = ((eval_mask >> (g & 63)) & 1ull) ? 0.f : invM_train;
-        const long long j = i - (long long)g * per_group;
-        const int c = 4 * (int)(j % c4n);
-        const long long a = g * group_stride + (j / c4n) * C + c;
+    // thread = (channel quad, row lane), rows strided by the grid, blockIdx.y = group (see bn_apply_kernel): per-channel vectors loaded once
+    const int c4n = C >> 2, tid = threadIdx.x, g = blockIdx.y;
+    const int c4 = tid % c4n, rl = tid / c4n, nrl = 256 / c4n;
+    if (rl >= nrl) return;
+    // a group in EVAL mode (cerb_net_set_bn_eval) normalises with constants: dy = dz * gamma * rstd, no mean / xhat-projection terms
+    // (they are the derivative of the BATCH statistics, which an eval-mode BatchNorm does not use)
+    const float invM = ((eval_mask >> (g & 63)) & 1ull) ? 0.f : 1.f / (float)rows;
+    const int gc = g * C + 4 * c4;
+    const float4 mu = *reinterpret_cast<const float4*>(mean + gc), rs = *reinterpret_cast<const float4*>(rstd + gc),
+                 ga = *reinterpret_cast<const float4*>(gamma + gc), dg = *reinterpret_cast<const float4*>(dgamma + gc), db = *reinterpret_cast<const float4*>(dbeta + gc);
+    float4 be = {0.f, 0.f, 0.f, 0.f};
+    if (relu == 2) be = *reinterpret_cast<const float4*>(beta + gc);
+    const long long base = g * group_stride + 4 * c4;
+    const long long step = (long long)gridDim.x * nrl;
+    auto one = [&](long long r) {
+        const long long a = base + r * C;
         float4 d = *reinterpret_cast<const float4*>(dz + a);
-        const int gc = g * C + c;
-        const float4 yv = *reinterpret_cast<const float4*>(y + a), mu = *reinterpret_cast<const float4*>(mean + gc), rs = *reinterpret_cast<const float4*>(rstd + gc),
-                     ga = *reinterpret_cast<const float4*>(gamma + gc), dg = *reinterpret_cast<const float4*>(dgamma + gc), db = *reinterpret_cast<const float4*>(dbeta + gc);
+        const float4 yv = *reinterpret_cast<const float4*>(y + a);
         if (relu) {
             float4 m;
             if (relu == 2) {
-                const float4 be = *reinterpret_cast<const float4*>(beta + gc);
                 m.x = bn_out(yv.x, mu.x, rs.x, ga.x, be.x);
                 m.y = bn_out(yv.y, mu.y, rs.y, ga.y, be.y);
                 m.z = bn_out(yv.z, mu.z, rs.z, ga.z, be.z);
@@ -584,9 +598,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             if (!(m.w > 0.f)) d.w = 0.f;
         }
         if (dresid) {
-            float4 r = *reinterpret_cast<float4*>(dresid + a);
-            r.x += d.x; r.y += d.y; r.z += d.z; r.w += d.w;
-            *reinterpret_cast<float4*>(dresid + a) = r;
+            float4 r4 = *reinterpret_cast<float4*>(dresid + a);
+            r4.x += d.x; r4.y += d.y; r4.z += d.z; r4.w += d.w;
+            *reinterpret_cast<float4*>(dresid + a) = r4;
         }
         float4 o;
         o.x = ga.x * rs.x * (d.x - db.x * invM - ((yv.x - mu.x) * rs.x) * dg.x * invM);
@@ -598,7 +612,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
         }
         *reinterpret_cast<float4*>(dy + a) = o;
+    };
+    long long r = (long long)blockIdx.x * nrl + rl;
+    for (; r + step < rows; r += 2 * step) {
+        one(r);
+        one(r + step);
     }
+    if (r < rows) one(r);
 }
 // ---- convolution backward, gather form (any ks / stride / pad = ks / 2; groups = independent convs stacked along G) ------------------
 __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int G, int N, int H,
@@ -941,6 +961,19 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTensor* __res
         t.p[i] -= (lr / bc1) * (mi / denom);
     }
 }
+// ---- many small device-to-device copies in ONE launch (cerb_net_update_params: ~470 parameter tensors per optimiser step went out as 470 hipMemcpyAsync) ----
+struct CopyDesc {
+    float* dst;
+    const float* src;
+    long long n;
+};
+constexpr int COPY_CHUNK = 16384;
+__global__ __launch_bounds__(256) void copy_multi_kernel(const CopyDesc* __restrict__ descs, const int2* __restrict__ chunks) {
+    const int2 c = chunks[blockIdx.x];
+    const CopyDesc d = descs[c.x];
+    const long long lo = (long long)c.y * COPY_CHUNK, hi = min(d.n, lo + COPY_CHUNK);
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) d.dst[i] = d.src[i];
+}
 static unsigned gridfor(long long n) {
     long long b = (n + 255) / 256;
     if (b > 256 * 32) b = 256 * 32;
@@ -959,9 +992,15 @@ hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, f
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(groups * bpg), dim3(256), 256 * 2 * sizeof(double), st, dz, z, y, group_stride, rows, C, bpg, mean, rstd, relu,
                        gamma, beta, (double*)ws);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, (const double*)ws, C, bpg, dgamma, dbeta);
-    if (dy_assign) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gridfor(rows * (C / 4) * groups)), dim3(256), 0, st, dz, z, y, dy, dresid, group_stride, rows, C,
+    if (C % 4 || C / 4 > 256) return hipErrorInvalidValue;
+    const int nrl = 256 / (C / 4);
+    long long ablocks = (rows + nrl - 1) / nrl;
+    const long long cap = std::max(1ll, (256ll * 32) / std::max(1, groups));
+    if (ablocks > cap) ablocks = cap;
+    const dim3 agrid((unsigned)std::max(1ll, ablocks), (unsigned)groups);
+    if (dy_assign) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, agrid, dim3(256), 0, st, dz, z, y, dy, dresid, group_stride, rows, C,
                                       groups, mean, rstd, gamma, beta, dgamma, dbeta, relu, eval_mask);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(gridfor(rows * (C / 4) * groups)), dim3(256), 0, st, dz, z, y, dy, dresid, group_stride, rows, C, groups,
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, agrid, dim3(256), 0, st, dz, z, y, dy, dresid, group_stride, rows, C, groups,
                             mean, rstd, gamma, beta, dgamma, dbeta, relu, eval_mask);
     return hipGetLastError();
 }
@@ -1012,6 +1051,35 @@ hipError_t cerb_launch_dilate2(const float* dy, float* d, long long n, int H, in
 }
 hipError_t cerb_launch_crop_gap_bwd(const float* dg, float* dx, int N, int H, int W, int C, int y0, int ch, int x0, int cw, hipStream_t st) {
     hipLaunchKernelGGL(crop_gap_bwd_kernel, dim3(gridfor((long long)N * ch * cw * C)), dim3(256), 0, st, dg, dx, N, H, W, C, y0, ch, x0, cw);
+    return hipGetLastError();
+}
+// count copies dst[i] <- src[i] (n[i] floats) in one launch.  The descriptor table lives in *dev_tab (grown on demand) and is uploaded only when
+// it differs from the previous call's (host_prev): the optimiser's parameter views and the handle's slots are the same pointers every step.
+hipError_t cerb_launch_copy_multi(int count, float* const* dst, const float* const* src, const long long* n, void** dev_tab, size_t* dev_bytes,
+                                  std::vector<char>* host_prev, hipStream_t st) {
+    std::vector<CopyDesc> dd(count);
+    std::vector<int2> ch;
+    for (int i = 0; i < count; ++i) {
+        dd[i] = CopyDesc{dst[i], src[i], n[i]};
+        for (long long c = 0; c * COPY_CHUNK < n[i]; ++c) ch.push_back(make_int2(i, (int)c));
+    }
+    if (ch.empty()) return hipSuccess;
+    const size_t tb = (dd.size() * sizeof(CopyDesc) + 255) & ~(size_t)255, need = tb + ch.size() * sizeof(int2);
+    std::vector<char> host(need, 0);
+    memcpy(host.data(), dd.data(), dd.size() * sizeof(CopyDesc));
+    memcpy(host.data() + tb, ch.data(), ch.size() * sizeof(int2));
+    hipError_t e;
+    if (need > *dev_bytes || host != *host_prev) {
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;  // an earlier launch may still be reading the old table
+        if (need > *dev_bytes) {
+            if (*dev_tab) (void)hipFree(*dev_tab);
+            if ((e = hipMalloc(dev_tab, need * 2)) != hipSuccess) return e;
+            *dev_bytes = need * 2;
+        }
+        if ((e = hipMemcpy(*dev_tab, host.data(), need, hipMemcpyHostToDevice)) != hipSuccess) return e;
+        host_prev->swap(host);
+    }
+    hipLaunchKernelGGL(copy_multi_kernel, dim3((unsigned)ch.size()), dim3(256), 0, st, (const CopyDesc*)*dev_tab, (const int2*)((const char*)*dev_tab + tb));
     return hipGetLastError();
 }
 // tables live in one device buffer that grows on demand and is reused by later steps (single optimiser stream assumed, as torch's own)

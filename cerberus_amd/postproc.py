@@ -20,8 +20,9 @@ from . import _lib
 _ws_cache = {}
 
 
-def _workspace(device, h, w):
-    need = int(_lib.lib().cerb_pp_workspace_bytes(int(h), int(w)))
+def _workspace(device, h, w, nbytes=None):
+    """The labelling workspace of an h x w map (cerb_pp_workspace_bytes: 96 B / px), or -- nbytes given -- at least that many bytes of it."""
+    need = int(_lib.lib().cerb_pp_workspace_bytes(int(h), int(w))) if nbytes is None else int(nbytes)
     key = (device.index if device.index is not None else torch.cuda.current_device())
     t = _ws_cache.get(key)
     if t is None or t.numel() < need:
@@ -138,7 +139,8 @@ def inst_contours_device(inst_map, table):
     h, w = int(inst_map.shape[0]), int(inst_map.shape[1])
     stream = torch.cuda.current_stream(inst_map.device).cuda_stream
     counts = torch.empty(n, dtype=torch.int32, device=inst_map.device)
-    ws = _workspace(inst_map.device, h, w)
+    ws = _workspace(inst_map.device, h, w, nbytes=4 * h * w + 256)  # cerb_inst_contour_start: one int32 union-find label per pixel (not the 96 B / px
+    #                                                                   of a labelling call: a 40000^2 slide map needs 6.4 GB here, not 143 GiB)
     table = table.clone()  # column 7 becomes the start pixel of the border findContours lists first (several-piece instances)
     start = torch.empty(n, dtype=torch.int64, device=inst_map.device)
     with torch.cuda.device(inst_map.device):

@@ -35,6 +35,20 @@ class SlideInfo(object):
         self.level_count = len(self.level_dimensions)
 
 
+def _strip_jfif_app0(data):
+    """Remove APP0 ("JFIF" / "JFXX") segments that precede the first SOF / SOS of a JPEG stream; everything else is kept byte for byte."""
+    out, i, n = bytearray(data[:2]), 2, len(data)
+    while i + 4 <= n and data[i] == 0xFF:
+        m = data[i + 1]
+        if m in (0xC0, 0xC1, 0xC2, 0xDA) or m == 0xD9:  # frame header / scan / EOI: the rest is copied as it is
+            break
+        seg = (data[i + 2] << 8) | data[i + 3]
+        if m != 0xE0:
+            out += data[i:i + 2 + seg]
+        i += 2 + seg
+    return bytes(out) + data[i:]
+
+
 def _resample_axis(src, axis, o0, o1, rel, s0, size):
     """Output pixels o0 .. o1-1 of a global resampling grid along `axis`: src holds the source pixels s0 .. s0 + n - 1 of a level that is
     `size` pixels long.  rel >= 1: area mean over [o * rel, (o + 1) * rel) clipped to the level (fractional end pixels weighted by their overlap);
@@ -55,6 +69,9 @@ def _resample_axis(src, axis, o0, o1, rel, s0, size):
             out += src[np.clip(idx - s0, 0, n - 1)] * wgt.astype(np.float32).reshape((-1,) + (1,) * (src.ndim - 1))
             wsum += wgt
         out /= np.maximum(wsum, 1e-12).astype(np.float32).reshape((-1,) + (1,) * (src.ndim - 1))
+        beyond = wsum <= 0.0  # output pixels wholly past the level's end: replicate the last source pixel like the integer-factor path
+        if beyond.any():
+            out[beyond] = src[np.clip(size - 1 - s0, 0, n - 1)]
     else:
         c = np.clip((o + 0.5) * rel - 0.5, 0.0, size - 1.0)
         i0 = np.floor(c).astype(np.int64)
@@ -318,6 +335,9 @@ class TiffReader(WSIReader):
                 # PhotometricInterpretation = RGB (most Aperio .svs): the components ARE R, G, B, but the stream carries neither a JFIF nor
                 # an Adobe marker, and libjpeg then guesses YCbCr for component ids 1, 2, 3 and converts.  An Adobe APP14 segment with
                 # transform = 0 right behind SOI states "no colour transform" (libjpeg honours it before any guess).
+                # A JFIF APP0 segment takes precedence over the Adobe marker in libjpeg (JFIF means YCbCr for three components), so any APP0
+                # in front of the frame header is dropped first.
+                data = _strip_jfif_app0(data)
                 data = data[:2] + b"\xff\xee\x00\x0eAdobe\x00\x64\x00\x00\x00\x00\x00" + data[2:]
             arr = np.array(Image.open(io.BytesIO(data)).convert("RGB"))
             return arr[:rows, :cols]

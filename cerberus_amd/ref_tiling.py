@@ -77,11 +77,11 @@ def get_tile_info(image_wh, tile_shape, margin, patch_output_shape):
     return info
 
 
-def _tile_instances(inst_canvas, type_canvas, bounds, exact_ties, y_off=0, slide_h=None):
+def _tile_instances(inst_canvas, type_canvas, bounds, exact_ties, y_off=0, slide_hw=None):
     """Label one tile on the GPU -> (list of per-instance dictionaries in TILE coordinates, boxes [n, 4] as x0, y0, x1, y1).
-    inst_canvas holds slide rows y_off .. y_off + rows (a rank's band plus the rows it fetched from its neighbours); slide_h = slide height."""
-    W = int(inst_canvas.shape[1])
-    H = int(inst_canvas.shape[0]) + int(y_off) if slide_h is None else int(slide_h)
+    inst_canvas holds slide rows y_off .. y_off + rows (a rank's band plus the rows it fetched from its neighbours) and may be wider than the
+    slide (canvases are whole output patches wide); slide_hw = the slide's own height / width, the clip of every tile."""
+    H, W = (int(inst_canvas.shape[0]) + int(y_off), int(inst_canvas.shape[1])) if slide_hw is None else (int(slide_hw[0]), int(slide_hw[1]))
     x0, y0, x1, y1 = max(int(bounds[0]), 0), max(int(bounds[1]), 0), min(int(bounds[2]), W), min(int(bounds[3]), H)
     if x1 <= x0 or y1 <= y0:
         return [], np.zeros((0, 4), np.int64)
@@ -102,12 +102,12 @@ def eviction_lines(tile_bounds, margin):
     return [(a + tl[0], b + tl[1], c + tl[0], d + tl[1]) for a, b, c, d in ((m, m, w - m, m), (m, h - m, w - m, h - m), (m, m, m, h - m), (w - m, m, w - m, h - m))]
 
 
-def process_tile_predictions(inst_canvas, type_canvas, tile_bounds, tile_flag, tile_mode, ref_boxes, margin, exact_ties=True, y_off=0, slide_h=None):
+def process_tile_predictions(inst_canvas, type_canvas, tile_bounds, tile_flag, tile_mode, ref_boxes, margin, exact_ties=True, y_off=0, slide_hw=None):
     """infer/wsi.py:81-268 for one tile.  ref_boxes: [k, 4] boxes (slide coordinates) of what has been accumulated before this tile SET, or None
     when the caller evicts at merge time (merge_tile_results).  -> (kept instance dictionaries in slide coordinates, indices into ref_boxes to remove)."""
     tl = np.array([int(tile_bounds[0]), int(tile_bounds[1])], dtype=np.int64)
     w, h = int(tile_bounds[2]) - int(tile_bounds[0]), int(tile_bounds[3]) - int(tile_bounds[1])
-    items, boxes = _tile_instances(inst_canvas, type_canvas, tile_bounds, exact_ties, y_off, slide_h)
+    items, boxes = _tile_instances(inst_canvas, type_canvas, tile_bounds, exact_ties, y_off, slide_hw)
     remove = np.zeros(0, np.int64)
     if tile_mode == 3 and ref_boxes is not None and len(ref_boxes):  # a cross section also evicts accumulated instances touching its inner margin lines
         sel = np.zeros(len(ref_boxes), bool)
@@ -261,7 +261,7 @@ def reference_tiled_nuclei_sharded(band_inst, band_type, band_y0, slide_hw, rank
     parts = {}
     for mode, ti in mine[rank]:
         bounds, flags = tile_info[mode]
-        kept, _ = process_tile_predictions(canvas, tcanvas, bounds[ti], flags[ti], mode, None, margin, exact_ties, y_off=y0, slide_h=H)
+        kept, _ = process_tile_predictions(canvas, tcanvas, bounds[ti], flags[ti], mode, None, margin, exact_ties, y_off=y0, slide_hw=(H, W))
         parts[(mode, ti)] = kept
     torch.cuda.synchronize()
     t2 = time.perf_counter()

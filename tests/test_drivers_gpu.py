@@ -312,3 +312,84 @@ def test_gather_bands_and_halo_exchange_of_cuda_tensors_through_hostdist(world):
     got.sort(key=lambda t: t[0])
     assert all(g[1] for g in got), got
     assert got[0][2] is True
+
+
+# ---- the reference's nuclei tile scheme, sharded over ranks (cerberus_amd/ref_tiling.py, `run_infer_wsi.py --reference_tiling`) --------------
+def _ref_tiling_case():
+    from cerberus_amd import synth_maps as synth
+
+    H, W = 3000, 2500
+    t = synth.nuclei_maps(1024, 1024, 31, 700.0, noise=0.02)
+    m = np.tile(t, (3, 3, 1))[:H, :W].copy()
+    tmap = ((np.arange(H)[:, None] // 37 + np.arange(W)[None, :] // 53) % 6).astype(np.uint8)
+    return H, W, m, tmap
+
+
+def _ref_tiling_worker(rank, world, port, bounds, ret):
+    import torch.distributed as dist
+
+    from cerberus_amd import ref_tiling as rt
+    from cerberus_amd.hostdist import HostStagedDist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H, W, m, tmap = _ref_tiling_case()
+    band = torch.from_numpy(m[bounds[rank]:bounds[rank + 1]].copy()).cuda()
+    tband = torch.from_numpy(tmap[bounds[rank]:bounds[rank + 1]].copy()).cuda()
+    prof = {}
+    got = rt.reference_tiled_nuclei_sharded(band, tband, bounds[rank], (H, W), rank, world, HostStagedDist(dist), tile_shape=1024, margin=32,
+                                            patch_output_shape=16, prof=prof)
+    if rank == 0:
+        ret.put((0, sorted((tuple(int(v) for v in d["box"]), int(d["type"])) for d in got.values()), prof.get("tiles")))
+    else:
+        assert got is None
+        ret.put((rank, None, prof.get("tiles")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,bounds", [(2, [0, 1700, 3000]), (3, [0, 900, 2100, 3000]), (4, [0, 400, 800, 2000, 3000])])
+def test_reference_tiling_sharded_over_ranks_equals_one_rank(world, bounds):
+    """`--reference_tiling` band-sharded over ranks.  Every rank labels the tiles that START in its band (rows below it are
+    fetched from the ranks that hold them -- with 400-row bands and 1024-row tiles a rank reaches into the next TWO bands), rank 0 merges in
+    the reference's order and applies the cross sections' evictions: the instance set (boxes + majority types) is exactly the one-rank result,
+    whatever the band cuts (none of them tile-aligned)."""
+    import queue
+    import socket
+    import time
+
+    import torch.multiprocessing as mp
+
+    from cerberus_amd import ref_tiling as rt
+
+    H, W, m, tmap = _ref_tiling_case()
+    one = rt.reference_tiled_nuclei(torch.from_numpy(m).cuda(), torch.from_numpy(tmap).cuda(), tile_shape=1024, margin=32, patch_output_shape=16)
+    ref = sorted((tuple(int(v) for v in d["box"]), int(d["type"])) for d in one.values())
+    assert len(ref) > 3000 and len(set(b for b, _ in ref)) == len(ref)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_ref_tiling_worker, args=(r, world, port, bounds, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, t_end = [], time.time() + 600
+    while len(got) < world:
+        try:
+            got.append(ret.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() > t_end:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise AssertionError("a rank died or timed out: exit codes %s" % [p.exitcode for p in procs])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    assert got[0][1] == ref
+    assert sum(g[2] for g in got) == sum(len(b) for b, _ in rt.get_tile_info((W, H), [1024, 1024], 32, [16, 16])) and all(g[2] > 0 for g in got)

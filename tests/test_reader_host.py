@@ -143,3 +143,32 @@ def test_non_integer_reduction_does_not_depend_on_the_row_chunks(tmp_path):
     w2, h2 = [int(v) for v in r.slide_dimensions(0.2, "mpp")]
     big = r.read_bounds((0, 0, w2, h2), 0.2, "mpp")
     assert np.array_equal(r.read_bounds((0, 211, w2, 305), 0.2, "mpp"), big[211:305])
+
+
+def test_rgb_photometric_jpeg_tile_with_a_jfif_header_and_resampling_past_the_edge():
+    """(i) a JPEG tile of a PhotometricInterpretation = RGB page whose stream ALSO carries a JFIF APP0 segment -- libjpeg lets JFIF win over
+    the injected Adobe transform-0 marker and converts as YCbCr -- has its APP0 dropped before the Adobe marker goes in; (ii) a non-integer
+    down-sampling factor whose last output pixels lie wholly past the level's end replicates the edge pixel (it returned black)."""
+    import io
+
+    from PIL import Image
+
+    from cerberus_amd.reader import _resample_axis, _strip_jfif_app0
+
+    rgb = np.random.RandomState(3).randint(0, 256, (48, 64, 3)).astype(np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(rgb).save(buf, format="JPEG", quality=95, subsampling=0)
+    data = buf.getvalue()
+    assert b"JFIF" in data[:32]
+    plain = np.array(Image.open(io.BytesIO(data)).convert("RGB")).astype(int)
+    stripped = _strip_jfif_app0(data)
+    assert b"JFIF" not in stripped[:32] and stripped[:2] == data[:2]
+    assert np.array_equal(np.array(Image.open(io.BytesIO(stripped)).convert("RGB")).astype(int), plain)  # nothing but the APP0 segment changed
+    adobe = b"\xff\xee\x00\x0eAdobe\x00\x64\x00\x00\x00\x00\x00"
+    with_jfif = np.array(Image.open(io.BytesIO(data[:2] + adobe + data[2:])).convert("RGB")).astype(int)
+    without = np.array(Image.open(io.BytesIO(stripped[:2] + adobe + stripped[2:])).convert("RGB")).astype(int)
+    assert np.abs(without - plain).max() > 20   # transform 0 honoured: the components are taken as R, G, B (no YCbCr conversion)
+    assert np.abs(with_jfif - plain).max() <= 1  # ... which the JFIF segment would have prevented
+    src = np.arange(10, dtype=np.float32).reshape(10, 1)
+    out = _resample_axis(src, 0, 0, 5, 2.5, 0, 10).ravel()
+    assert abs(out[3] - 8.2) < 1e-5 and out[4] == 9.0
