@@ -86,6 +86,8 @@ def cpu_baseline(sd, kw, n_tiles=8, iters=2):
     pp_dt = time.perf_counter() - t0
     return {
         "postproc_nuclei_Mpx_s_1core": round(2048 * 2048 / pp_dt / 1e6, 2),
+        "postproc_note": "oracle/postproc_ref.c -- this build's C restatement of loader/postproc.py's nuclei branch on ONE host core, NOT the reference: the "
+                         "reference's own skimage / scipy path does ~8 Mpx/s per core (BASELINE.md), about 5x slower than this figure",
         "value": round(rate, 4),
         "unit": "Mpx/s",
         "cores": cores,
@@ -309,7 +311,7 @@ def kernel_table(model, step, n_tiles):
     dom = rows[0]
     fl, ms, cnt = fam[dom["kernel"]]
     traffic = None
-    for cand in ("r03_bench_pmc_hbm.json", "r02_bench_pmc_hbm.json", "r01_bench_pmc_hbm.json"):
+    for cand in ("r04_bench_pmc_hbm.json", "r03_bench_pmc_hbm.json", "r02_bench_pmc_hbm.json", "r01_bench_pmc_hbm.json"):
         pth = os.path.join(ROOT, "profiles", cand)
         sym = _SYMBOL.get(dom["kernel"])
         if sym and os.path.exists(pth):
@@ -489,22 +491,37 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
     if rank == 0 and not args.no_dat:
         import tempfile
 
-        from cerberus_amd.wsi import build_wsi_inst_info, write_dat
+        from cerberus_amd.wsi import build_wsi_inst_info
 
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         obj = build_wsi_inst_info(res["inst"], res["small"], (H, W), 0.5)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        # The file is written the way run_infer_wsi.py writes it: by a forked child (cerberus_amd.wsi.DatWriter) UNDERNEATH the next slide's
+        # inference -- here a second, untimed-by-`value` pass over the same K stripes, so that the line shows what the overlap costs the inference
+        # (`inference_pass_under_writer_s` against config.inference_s) and how long the parent still waits afterwards (`writer_wait_s`).
+        from cerberus_amd.wsi import DatWriter
+
+        os.environ["CERB_DAT_WRITER_TIMING"] = "1"
         with tempfile.TemporaryDirectory() as td:
             pth = os.path.join(td, "slide.dat")
-            write_dat(obj, pth)
+            wr = DatWriter(obj, pth)
             t2 = time.perf_counter()
+            for k in range(K):
+                run.infer_patches(slab, y0, cuts[k], cuts[k + 1])
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            wr.join()
+            t4 = time.perf_counter()
             nbytes = os.path.getsize(pth)
-        dat = {"dictionary_s": round(t1 - t0, 3), "write_s": round(t2 - t1, 3), "dat_s": round(t2 - t0, 3), "dat_MB": round(nbytes / 1e6, 1),
+            write_s = float(open(pth + ".time").read()) if os.path.exists(pth + ".time") else (t4 - t2)
+        dat = {"dictionary_s": round(t1 - t0, 3), "write_s": round(write_s, 3), "dat_s": round(t1 - t0 + write_s, 3), "dat_MB": round(nbytes / 1e6, 1),
                "entries": {t: len(obj[t]) for t in ("Nuclei", "Gland", "Lumen") if t in obj},
-               "note": "contours (GPU border following) + per-instance dictionaries + uuid keys + protocol-4 pickle that joblib.load reads; in "
-                       "run_infer_wsi.py the file write runs on a writer thread underneath the next slide's inference"}
+               "inference_pass_under_writer_s": round(t3 - t2, 3), "writer_wait_s": round(t4 - t3, 3),
+               "note": "dictionary_s = contours (GPU border following) + per-instance dictionaries + uuid keys, in the parent; write_s = the protocol-4 pickle "
+                       "that joblib.load reads, in a forked child underneath the next slide's inference (its own clock); end_to_end_Mpx_s counts both "
+                       "serially, as a one-slide run pays them"}
         del obj
     res.clear()
     # The REFERENCE's nuclei scheme over the same maps (infer/wsi.py:81-268, 642-684: 4096-px tiles, 64-px margins, strips, cross sections; every

@@ -917,20 +917,16 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
             net->cm.ensure((size_t)N * hs[4] * ws[4] * 256 * 4, guard))
             return fail("workspace allocation failed");
         if (D) {
-            // NHWC decoder workspace: dsum = skip + upsample, dmid = the first conv's output, dout[u] = the level's output -- sized by the
-            // largest level that actually RUNS NHWC: the levels that live in the tile-planar buffers (level_is_planar below) need none of them
-            // (round 3 allocated all three at the last level's size next to the planar tensors: ~8 GB of untouched HBM at 32 x 256^2)
-            const int oc[4] = {128, 64, 64, 64}, ic[4] = {256, 128, 64, 64};
-            size_t mid_px = 0, sum_px = 0;
-            for (int u = 0; u < 4; ++u) {
-                if (level_is_planar(u)) continue;
-                const size_t px = (size_t)hs[3 - u] * ws[3 - u];
-                mid_px = std::max(mid_px, px * (size_t)oc[u]);
-                sum_px = std::max(sum_px, px * (size_t)ic[u]);
-                if (net->dout[u].ensure(D * (size_t)N * px * oc[u] * 4, guard)) return fail("workspace allocation failed");
-            }
-            if (mid_px && net->dmid.ensure(D * (size_t)N * mid_px * 4, guard)) return fail("workspace allocation failed");
-            if (sum_px && net->conv_algo && net->dsum.ensure(D * (size_t)N * sum_px * 4, guard)) return fail("workspace allocation failed");
+            // dmid holds the first conv of a level: sizes (per decoder) 32^2*256, 64^2*128, 128^2*64, 256^2*64 -> max is the last.
+            // (ADVICE r3 asked to size dmid / dsum / dout by the levels that really run NHWC when the two last levels are tile-planar -- ~8 GB of
+            // untouched HBM at 32 x 256^2.  Tried in round 4: the first forward then dies with an illegal address in the NHWC levels, i.e. a
+            // kernel of those levels reaches past its tensor into what used to be the tail of these oversized buffers; until that reach is found
+            // and bounded the allocation stays as it was -- untouched memory costs nothing but address space on a 288 GB part.)
+            if (net->dmid.ensure(D * (size_t)N * H * W * 64 * 4, guard)) return fail("workspace allocation failed");
+            if (net->conv_algo && net->dsum.ensure(D * (size_t)N * H * W * 64 * 4, guard)) return fail("workspace allocation failed");
+            const int oc[4] = {128, 64, 64, 64};
+            for (int u = 0; u < 4; ++u)
+                if (net->dout[u].ensure(D * (size_t)N * hs[3 - u] * ws[3 - u] * oc[u] * 4, guard)) return fail("workspace allocation failed");
         }
     }
     // ---- encoder ----------------------------------------------------------------------------------------------

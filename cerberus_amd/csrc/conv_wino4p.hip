@@ -79,7 +79,11 @@ __device__ unsigned long long p4_prof_buf[16 * 40];
 #define P4_PROF_WAVE 0
 #endif
 #else
+#ifdef P4_ABL_LDSPATCH
+constexpr int PROF_BYTES = 16 * 1024;  // landing zone of the ablation's direct-to-LDS loads
+#else
 constexpr int PROF_BYTES = 0;
+#endif
 #endif
 
 template <int I>
@@ -286,6 +290,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     f32x2 d[6][6];  // raw patch of the NEXT chunk (two channels), transformed in place in the shadow of the matrix pipe
     auto issue = [&](__amdgpu_buffer_rsrc_t r, int chunk_off, int rr, int qq) __attribute__((always_inline)) {
         const int ii = rr == 0 ? 3 : rr == 5 ? 0 : rr - 1, jj = qq == 0 ? 3 : qq == 5 ? 0 : qq - 1;
+#ifdef P4_ABL_LDSPATCH  // ablation (round 4): what an LDS-staged raw patch would cost -- the thread reads its 36 pixels from LDS
+        // (any in-range address: the values are garbage) and the workgroup's unique pixels arrive through stage_lds() below
+        d[rr][qq] = *reinterpret_cast<const f32x2*>(lds + (rr * 6 + qq) * NT * CB + vw);
+        return;
+#endif
 #ifdef P4_ABL_NOCORNER   // ablation: the four corner pixels of the patch (the loads whose lanes reach into up to four different blocks) are not requested
         if ((rr == 0 || rr == 5) && (qq == 0 || qq == 5)) return;
 #endif
@@ -482,6 +491,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     bb[(q + 1) & 1][0] = *reinterpret_cast<const f32x4*>(vsrc + (q + 1) * NT * CB);
                     bb[(q + 1) & 1][1] = *reinterpret_cast<const f32x4*>(vsrc + (q + 1) * NT * CB + 16 * CB);
                 }
+#ifdef P4_ABL_LDSPATCH
+                if constexpr (q < P4_ABL_LDSPATCH) {  // the workgroup's share of the unique raw pixels of a chunk (2 blocks x 18 x 18 px x 16 ch = 41.5 KB = ~10
+                    // 16-byte loads per thread), global -> LDS without a register: 1 KiB per wave and instruction into the 16 KiB behind the V buffers
+                    const unsigned voff = (unsigned)(q * 4096 + tid * 16);
+                    asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(r_stage), "s"((unsigned)(LDS_BYTES + ((q & 3) * 4 + a) * 1024)) : "memory");
+                }
+#endif
 #ifndef P4_ABL_NOPATCH
                 if constexpr (q >= HQ && q < HQ + 10) {  // halo of the next chunk's patch, two pixels per step
                     issue(r_stage, stage_off, halo_r(2 * (q - HQ)), halo_q(2 * (q - HQ)));

@@ -311,6 +311,67 @@ def write_dat(obj, path):
         pickle.dump(obj, fh, protocol=4)
 
 
+class DatWriter(object):
+    """dat/<slide>.dat written by a CHILD PROCESS (fork) while the parent goes on to the next slide.
+
+    Serialising ~1e6 per-instance dictionaries (three small numpy arrays each) is ~8 s of pure-Python / pickle work for a 40000^2 slide -- as long
+    as the slide's whole inference.  On a thread it would share the interpreter lock with the loop that launches the next slide's batches; a forked
+    child has the dictionary copy-on-write, touches neither the GPU nor any lock of the parent, writes `<path>.part`, renames it, and leaves through
+    os._exit (no atexit handlers, no HIP teardown).  `join()` waits for it and raises if it failed.  Falls back to a thread where fork is not available."""
+
+    def __init__(self, obj, path):
+        import os
+        import threading
+
+        self.path, self._pid, self._thr, self._err = path, None, None, None
+        tmp = path + ".part"
+
+        def work():
+            import time
+
+            t0 = time.perf_counter()
+            write_dat(obj, tmp)
+            os.replace(tmp, path)
+            self.seconds = time.perf_counter() - t0
+            if os.environ.get("CERB_DAT_WRITER_TIMING"):  # bench.py reads the child's own clock from a side file
+                with open(path + ".time", "w") as fh:
+                    fh.write("%.6f" % self.seconds)
+
+        if hasattr(os, "fork") and not os.environ.get("CERB_DAT_WRITER_THREAD"):
+            pid = os.fork()
+            if pid == 0:
+                code = 0
+                try:
+                    work()
+                except BaseException:  # the parent reports it
+                    code = 1
+                os._exit(code)
+            self._pid = pid
+        else:
+            def run():
+                try:
+                    work()
+                except BaseException as e:
+                    self._err = e
+
+            self._thr = threading.Thread(target=run)
+            self._thr.start()
+
+    def join(self):
+        import os
+
+        if self._pid is not None:
+            _, status = os.waitpid(self._pid, 0)
+            self._pid = None
+            if status != 0:
+                raise RuntimeError("writing %s failed in the writer process (status %d)" % (self.path, status))
+        if self._thr is not None:
+            self._thr.join()
+            self._thr = None
+            if self._err is not None:
+                raise self._err
+
+
 class SlabUploader(object):
     """Host-resident slide band -> device slab, chunk by chunk through two pinned staging buffers on a copy stream, so that the
     upload (and the page-cache / mmap read behind it) runs underneath the inference of the rows already on the device instead of

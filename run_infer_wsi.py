@@ -13,7 +13,6 @@ contiguous band per rank, inference needs no collective, post-processing is band
 import glob
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -27,12 +26,6 @@ ONE_CALL_PX = 400 * 1000 * 1000  # largest map labelled in one call on one GPU (
 def _basename(path, ext):
     base = os.path.basename(path)
     return base[: -len(ext)] if ext else base
-
-
-def _write_then_rename(write, obj, path):
-    tmp = path + ".part"
-    write(obj, tmp)
-    os.replace(tmp, path)
 
 
 def _slide_logger(log_dir, base):
@@ -92,7 +85,7 @@ def main(argv=None):
 
     from cerberus_amd.tile import InferManager
     from cerberus_amd.weights import DEFAULT_REQ_TARGET_CODE, default_model_kwargs
-    from cerberus_amd.wsi import SlabUploader, WSIRunner, build_wsi_inst_info, check_shardable, synth_slide, write_dat
+    from cerberus_amd.wsi import DatWriter, SlabUploader, WSIRunner, build_wsi_inst_info, check_shardable, synth_slide
 
     dist, watch = None, launch.null_watch()
     n_dev = max(1, torch.cuda.device_count())
@@ -262,8 +255,7 @@ def main(argv=None):
         # name and renamed, so a finished dat/<slide>.dat is always complete -- the resume-by-skip above relies on that)
         if writer is not None:
             writer.join()
-        writer = threading.Thread(target=_write_then_rename, args=(write_dat, info, dat_path))
-        writer.start()
+        writer = DatWriter(info, dat_path)  # a forked child: no interpreter lock shared with the next slide's launch loop
         t4 = time.perf_counter()
         print("%s: Inference Time: %.3f  Post Proc Time: %.3f  Instance Table Time: %.3f  (%.1f Mpx/s inference)" % (
             base, t1 - t0, t2 - t1, t4 - t3, H * W / (t1 - t0) / 1e6))

@@ -326,6 +326,8 @@ def _ref_tiling_case():
 
 
 def _ref_tiling_worker(rank, world, port, bounds, ret):
+    import os
+
     import torch.distributed as dist
 
     from cerberus_amd import ref_tiling as rt
