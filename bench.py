@@ -254,6 +254,8 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md
 XGMI_LINK_GBS = 153.0   # per peer link, SURVEY.md par.8e
 _SYMBOL = {"conv_wino4p<f4x4,16x16x2,planar>": "void conv_wino4p_kernel<1>(ConvParams)",
            "conv_wino4p<f4x4,16x16x2,planar,half-res>": "void conv_wino4p_kernel<0>(ConvParams)",
+           "conv_wino4s<f4x4,16x16x2,planar,lds-patch>": "void conv_wino4s_kernel<1>(ConvParams)",
+           "conv_wino4s<f4x4,16x16x2,planar,lds-patch,half-res>": "void conv_wino4s_kernel<0>(ConvParams)",
            "conv_wino4b<f4x4,16x16>": "void conv_wino4b_kernel<false>(ConvParams)",
            "conv_wino4b<f4x4,16x16,res>": "void conv_wino4b_kernel<true>(ConvParams)",
            "conv_wino4<f4x4,16x16x2>": "void conv_wino4_kernel<false>(ConvParams)",
@@ -695,8 +697,8 @@ def main():
     sd = {k: torch.from_numpy(v) for k, v in make_state_dict(0).items()}
     model = create_model(**kw)
     model.load_state_dict(sd, strict=True)
-    if not args.planar:
-        model.set_planar(False)
+    if args.planar != 1:
+        model.set_planar(args.planar)
     if args.mode == "train":
         return train_leg(args, model, dev, dist, world, rank, sd, kw)
     if args.mode == "wsi":

@@ -22,6 +22,7 @@ hipError_t cerb_launch_wino(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino4(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino4b(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino4p(ConvParams p, hipStream_t st);
+hipError_t cerb_launch_wino4s(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_upsample2_add_planar(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C, long long prev_gs,
                                             long long out_gs, const int* roi, int prev_planar, hipStream_t st);
 hipError_t cerb_launch_upsample2_add(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C,
@@ -177,6 +178,7 @@ struct PackedConv {
                                                                       // device at first use and again after every optimiser step
     float* wino4b = nullptr;  // device, the same transform in conv_wino4b.hip's layout (32-channel chunks, conv_algo 7), packed lazily
     float* wino4 = nullptr;   // device, F(4x4,3x3) transformed weights in conv_wino4.hip's layout (conv_algo 5), packed lazily from host_w
+    float* wino4s = nullptr;  // device, the same transform in conv_wino4s.hip's layout (position pairs x channel halves), packed lazily
     std::vector<float> host_w;  // BN-folded 3x3 weights [G][cout][cin][9] kept on the host for the lazily packed Winograd variants
     float* b = nullptr;     // device
 };
@@ -420,7 +422,8 @@ static void pack_wino(const float* w, const float* scale, int cout, int cin, std
 //   ->  U[xi] of W[cb*64 + 16 a + (lane & 15)][chunk*16 + 4 (lane >> 4) + t]
 //   conv_wino4b.hip (chunk32 = true): [cb][32-channel chunk][wave a][xi][channel group G][lane][t]
 //   ->  U[xi] of W[cb*64 + 16 a + (lane & 15)][chunk*32 + 16 G + 4 (lane >> 4) + t]
-static void pack_wino4(const float* w, int cout, int cin, std::vector<float>* out, bool chunk32 = false) {  // w: BN-folded [cout][cin][3][3]
+static void pack_wino4(const float* w, int cout, int cin, std::vector<float>* out, int layout = 0) {  // w: BN-folded [cout][cin][3][3]; layout 0 = conv_wino4 / 4p, 1 = conv_wino4b, 2 = conv_wino4s
+    const bool chunk32 = layout == 1;
     static const double Gm[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                     {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
     const int nchunk = cin / 16, ncb = cout / 64;
@@ -450,6 +453,20 @@ static void pack_wino4(const float* w, int cout, int cin, std::vector<float>* ou
                                     const int co = cb * 64 + 16 * a + (lane & 15);
                                     const int ci = ch * 32 + 16 * G + 4 * (lane >> 4) + t;
                                     o[idx++] = U[((size_t)co * cin + ci) * 36 + xi];
+                                }
+        return;
+    }
+    if (layout == 2) {  // conv_wino4s.hip: one 1-KiB wave load = a PAIR of positions x the two matrix instructions (t = 2h, 2h + 1) of a channel half
+        for (int cb = 0; cb < ncb; ++cb)
+            for (int ch = 0; ch < nchunk; ++ch)
+                for (int a = 0; a < 4; ++a)
+                    for (int h = 0; h < 2; ++h)
+                        for (int s = 0; s < 18; ++s)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int e = 0; e < 4; ++e) {
+                                    const int co = cb * 64 + 16 * a + (lane & 15);
+                                    const int ci = ch * 16 + 4 * (lane >> 4) + 2 * h + (e & 1);
+                                    o[idx++] = U[((size_t)co * cin + ci) * 36 + 2 * s + (e >> 1)];
                                 }
         return;
     }
@@ -838,10 +855,11 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
         PackedConv& cm = it->second;
         float* train_slot = nullptr;
         if (!net->fold_bn && train_wino4_slot(net, name, cm, w4b ? 1 : 0, 0, st, &train_slot)) return 1;
-        float*& slot4 = !net->fold_bn ? train_slot : (w4b ? cm.wino4b : cm.wino4);
+        const bool w4s = planar && net->planar == 2;  // conv_wino4s.hip: raw patch staged through LDS (its own weight layout)
+        float*& slot4 = !net->fold_bn ? train_slot : (w4s ? cm.wino4s : w4b ? cm.wino4b : cm.wino4);
         if (!slot4) {  // first use: F(4x4,3x3) filter transform on the host, the kernel's per-wave layout, upload
             std::vector<float> w4;
-            for (int g = 0; g < cm.groups; ++g) pack_wino4(cm.host_w.data() + (size_t)g * cm.cout * cm.cin * 9, cm.cout, cm.cin, &w4, w4b);
+            for (int g = 0; g < cm.groups; ++g) pack_wino4(cm.host_w.data() + (size_t)g * cm.cout * cm.cin * 9, cm.cout, cm.cin, &w4, w4s ? 2 : w4b ? 1 : 0);
             void* d = nullptr;
             HIP_OK(hipMalloc(&d, w4.size() * 4));
             net->dev_allocs.push_back(d);
@@ -863,8 +881,9 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
             p.pl_byp = cerb_planar_blocks(p.Ho);
             p.pl_bxp = cerb_planar_blocks(p.Wo);
         }
-        if (prof_begin(net, name, planar ? (p.level_tag ? "conv_wino4p<f4x4,16x16x2,planar>" : "conv_wino4p<f4x4,16x16x2,planar,half-res>") : w4b ? (resid ? "conv_wino4b<f4x4,16x16,res>" : "conv_wino4b<f4x4,16x16>") : (resid ? "conv_wino4<f4x4,16x16x2,res>" : "conv_wino4<f4x4,16x16x2>"), fl_done, st)) return 1;
-        HIP_OK(planar ? cerb_launch_wino4p(p, st) : w4b ? cerb_launch_wino4b(p, st) : cerb_launch_wino4(p, st));
+        if (prof_begin(net, name, w4s ? (p.level_tag ? "conv_wino4s<f4x4,16x16x2,planar,lds-patch>" : "conv_wino4s<f4x4,16x16x2,planar,lds-patch,half-res>") :
+                                  planar ? (p.level_tag ? "conv_wino4p<f4x4,16x16x2,planar>" : "conv_wino4p<f4x4,16x16x2,planar,half-res>") : w4b ? (resid ? "conv_wino4b<f4x4,16x16,res>" : "conv_wino4b<f4x4,16x16>") : (resid ? "conv_wino4<f4x4,16x16x2,res>" : "conv_wino4<f4x4,16x16x2>"), fl_done, st)) return 1;
+        HIP_OK(w4s ? cerb_launch_wino4s(p, st) : planar ? cerb_launch_wino4p(p, st) : w4b ? cerb_launch_wino4b(p, st) : cerb_launch_wino4(p, st));
         if (prof_end(net, st)) return 1;
         return 0;
     }
@@ -1866,7 +1885,8 @@ extern "C" int cerb_net_set_bn_eval(cerb_net* net, const char* bn_prefix, const 
 
 extern "C" int cerb_net_set_planar(cerb_net* net, int enable) {
     if (!net) return fail("cerb_net_set_planar: null handle");
-    net->planar = enable ? 1 : 0;
+    if (enable < 0 || enable > 2) return fail("cerb_net_set_planar: 0 (NHWC), 1 (tile-planar, conv_wino4p.hip) or 2 (tile-planar with the raw patch staged through LDS, conv_wino4s.hip)");
+    net->planar = enable;
     return 0;
 }
 

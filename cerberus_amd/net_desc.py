@@ -411,8 +411,9 @@ class NetDesc(torch.nn.Module):
         _lib.check(_lib.lib().cerb_net_set_conv_algo(self._ensure_handle(), int(algo)))
 
     def set_planar(self, enable=True):
-        """The two last decoder levels in the tile-planar layout (conv_wino4p.hip; default on) or NHWC (conv_wino4.hip): bit-identical outputs."""
-        _lib.check(_lib.lib().cerb_net_set_planar(self._ensure_handle(), int(bool(enable))))
+        """The two last decoder levels: 1 / True = tile-planar layout (conv_wino4p.hip), 2 = tile-planar with the raw patch staged through LDS
+        (conv_wino4s.hip), 0 / False = NHWC (conv_wino4.hip).  Bit-identical outputs in all three."""
+        _lib.check(_lib.lib().cerb_net_set_planar(self._ensure_handle(), int(enable)))
 
     def set_crop_roi(self, enable=True):
         """Compute only what the centre crop keeps in the decoders / heads (default on; include/cerberus_hip.h)."""
