@@ -493,22 +493,21 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
     if rank == 0 and not args.no_dat:
         import tempfile
 
-        from cerberus_amd.wsi import build_wsi_inst_info
+        from cerberus_amd.wsi import DatWriter, collect_wsi_inst_arrays, wsi_meta
 
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        obj = build_wsi_inst_info(res["inst"], res["small"], (H, W), 0.5)
+        parts = collect_wsi_inst_arrays(res["inst"], res["small"], (H, W))  # GPU: instance tables + border following; arrays to the host
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        # The file is written the way run_infer_wsi.py writes it: by a forked child (cerberus_amd.wsi.DatWriter) UNDERNEATH the next slide's
-        # inference -- here a second, untimed-by-`value` pass over the same K stripes, so that the line shows what the overlap costs the inference
-        # (`inference_pass_under_writer_s` against config.inference_s) and how long the parent still waits afterwards (`writer_wait_s`).
-        from cerberus_amd.wsi import DatWriter
-
+        # The ~1e6 per-instance dictionaries, the uuid keys and the pickle are built the way run_infer_wsi.py builds them: by a separate, torch-free
+        # writer process (cerberus_amd.wsi.DatWriter.from_arrays) UNDERNEATH the next slide's inference -- here a second pass over the same K
+        # stripes, untimed by `value`, so that the line shows what the overlap costs the inference (`inference_pass_under_writer_s` against
+        # config.inference_s) and how long the parent still waits afterwards (`writer_wait_s`).
         os.environ["CERB_DAT_WRITER_TIMING"] = "1"
         with tempfile.TemporaryDirectory() as td:
             pth = os.path.join(td, "slide.dat")
-            wr = DatWriter(obj, pth)
+            wr = DatWriter.from_arrays(parts, wsi_meta((H, W), 0.5), pth)
             t2 = time.perf_counter()
             for k in range(K):
                 run.infer_patches(slab, y0, cuts[k], cuts[k + 1])
@@ -517,14 +516,16 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
             wr.join()
             t4 = time.perf_counter()
             nbytes = os.path.getsize(pth)
-            write_s = float(open(pth + ".time").read()) if os.path.exists(pth + ".time") else (t4 - t2)
-        dat = {"dictionary_s": round(t1 - t0, 3), "write_s": round(write_s, 3), "dat_s": round(t1 - t0 + write_s, 3), "dat_MB": round(nbytes / 1e6, 1),
-               "entries": {t: len(obj[t]) for t in ("Nuclei", "Gland", "Lumen") if t in obj},
+            build_s, write_s = [float(v) for v in open(pth + ".time").read().split()] if os.path.exists(pth + ".time") else (0.0, t4 - t2)
+        dat = {"tables_and_contours_s": round(t1 - t0, 3), "hand_over_s": round(t2 - t1, 3), "writer_build_s": round(build_s, 3), "writer_pickle_s": round(write_s, 3),
+               "dat_s": round(t2 - t0 + build_s + write_s, 3), "dat_MB": round(nbytes / 1e6, 1),
+               "entries": {p_[0]: int(((p_[1][:, 0] > 0) & (p_[2] >= 3)).sum()) for p_ in parts},
                "inference_pass_under_writer_s": round(t3 - t2, 3), "writer_wait_s": round(t4 - t3, 3),
-               "note": "dictionary_s = contours (GPU border following) + per-instance dictionaries + uuid keys, in the parent; write_s = the protocol-4 pickle "
-                       "that joblib.load reads, in a forked child underneath the next slide's inference (its own clock); end_to_end_Mpx_s counts both "
+               "note": "tables_and_contours_s = cerb_inst_table + cerb_inst_contour_* + copies to the host, hand_over_s = the arrays written for the writer "
+                       "process (both in the parent, between two slides); writer_build_s / writer_pickle_s = per-instance dictionaries + uuid keys / the "
+                       "protocol-4 pickle joblib.load reads, on the writer's own clock, underneath the next slide; end_to_end_Mpx_s counts all four "
                        "serially, as a one-slide run pays them"}
-        del obj
+        del parts
     res.clear()
     # The REFERENCE's nuclei scheme over the same maps (infer/wsi.py:81-268, 642-684: 4096-px tiles, 64-px margins, strips, cross sections; every
     # tile labelled with skimage's tie order), tiles sharded over the ranks (cerberus_amd/ref_tiling.py) -- what `run_infer_wsi.py

@@ -11,7 +11,7 @@
 //   * to make room for the raw buffer next to V in the CU's 160 KB, V holds 8 channels at a time: the matrix instructions t = 0, 1 of a
 //     16-channel chunk (channels {t, 4 + t, 8 + t, 12 + t}) read V_A in the first half, t = 2, 3 read V_B in the second; waves 0-1 transform the
 //     channels of V_A, waves 2-3 those of V_B (every lane busy: lane = (tile, k-slot), two channels each).  V_A(c+1) is written while V_B(c) is
-//     read, so V_A is single- and V_B double-buffered: 3 x 36.9 KB + 43 KB of raw patch = 153.6 KB.  Two barriers per chunk instead of one.
+//     read, so V_A is single- and V_B double-buffered: 3 x 36.9 KB + 43 KB of raw patch (+ 5 KB of offsets) = 159 KB.  Two barriers per chunk instead of one.
 // Each accumulator still receives t = 0, 1, 2, 3 of chunk 0, then of chunk 1, ...: the SAME products in the SAME order as conv_wino4p.hip and
 // conv_wino4.hip -- results are bit-identical (tests/test_net_gpu.py::test_planar_last_level_is_bit_identical_to_nhwc runs all three).
 // Weights are packed per PAIR of positions so that one 1-KiB load still feeds 8 matrix instructions (cerb_api.hip: pack_wino4 layout 2):
@@ -31,7 +31,8 @@ constexpr int VH_FLOATS = NPAIR * NT * 16;     // one V half: [pair][tile][k-slo
 constexpr int RAW_PIECES = 21 * 64;            // 16-byte pieces of one block's raw patch: 324 pixels x 4 channel quads = 1296, padded to 21 wave instructions
 constexpr int RAW_BLOCK_BYTES = RAW_PIECES * 16;  // 21,504
 constexpr int LDS_VA = 0, LDS_VB = VH_FLOATS * 4, LDS_RAW = 3 * VH_FLOATS * 4;   // byte offsets: V_A, V_B[2], raw patch (2 blocks)
-constexpr int LDS_BYTES = LDS_RAW + 2 * RAW_BLOCK_BYTES;                       // 110,592 + 43,008 = 153,600
+constexpr int LDS_TAB = LDS_RAW + 2 * RAW_BLOCK_BYTES;                         // [21 wave instructions of a block][64 lanes] global byte offsets of the raw pieces
+constexpr int LDS_BYTES = LDS_TAB + 23 * 64 * 4;                               // 110,592 + 43,008 + 5,888 = 159,488 (rows 21, 22: copies, read by nobody's DMA)
 constexpr int PLANE_BYTES = 16 * 16 * 16 * 4;
 constexpr int NS = 36;                         // steps per 16-channel chunk: 18 pair steps of half A, 18 of half B (8 matrix instructions each)
 constexpr int NPOS_A = 32;                     // positions whose accumulators live in AccVGPRs
@@ -189,23 +190,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // (image pixel (16 by + y - 1, 16 bx + x - 1)) sits in slot (18 y + x) ^ ((x >> 2) & 1): neighbouring tiles of a row start on slots of
     // opposite parity, so the 16 tiles of a patch read spread over both 64-byte halves of the LDS bank window.
     // Wave `a` issues wave instructions j = a, a + 4, ..., j < 42: block j / 21, pieces (j % 21) * 64 + lane.
-    unsigned doff[NDMA];
+    // The offsets are kernel invariants, but eleven registers kept alive across the whole item loop were spilled (each reload a scratch load followed
+    // by s_waitcnt vmcnt(0) in front of the DMA it feeds: 3.9 ms per launch instead of 2.1).  They live in an LDS table instead and are read back
+    // at the start of every chunk into registers that die within its first eleven steps -- while the patch registers are dead.
     {
         const unsigned rowblk = (unsigned)p.pl_bxp * (unsigned)nchunk * PLANE_BYTES, colblk = (unsigned)nchunk * PLANE_BYTES;
-#pragma unroll
-        for (int k = 0; k < NDMA; ++k) {
-            const int j = 4 * k + a;
-            int g = (j % 21) * 64 + lane;
+        unsigned* tab = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + LDS_TAB);
+        for (int e = tid; e < 23 * 64; e += 256) {
+            int g = e;
             if (g > 1295) g = 1295;  // the padding lanes of a block's last instruction fetch a valid piece into the padding of the buffer
             const int s = g >> 2, quad = g & 3;
             const int x0 = s % 18, pp = s ^ ((x0 >> 2) & 1), y = pp / 18, x = pp % 18;
             const int yy = y + 15, xx = x + 15;  // image pixel relative to the top-left neighbour block's origin
             const int dby = yy >> 4, dbx = xx >> 4, iy = yy & 15, ix = xx & 15;
-            doff[k] = (unsigned)dby * rowblk + (unsigned)dbx * colblk +
-                      (unsigned)(((((iy & 3) << 2) + (ix & 3)) * 16 + (((iy >> 2) & 3) << 2) + ((ix >> 2) & 3)) * 64 + quad * 16);
-            asm volatile("" : "+v"(doff[k]));
+            tab[e] = (unsigned)dby * rowblk + (unsigned)dbx * colblk +
+                     (unsigned)(((((iy & 3) << 2) + (ix & 3)) * 16 + (((iy >> 2) & 3) << 2) + ((ix >> 2) & 3)) * 64 + quad * 16);
         }
     }
+    // wave a's instruction k is j = 4 k + a of the 42; its table row is j % 21 = 4 k + a (k < 5, and k = 5 for wave 0), else 4 k + a - 21: a
+    // compile-time displacement from ONE lane address (+ one more for k = 5) -- eleven separately computed addresses were hoisted and spilled too
+    const char* tabA = reinterpret_cast<const char*>(lds) + LDS_TAB + a * 256 + lane * 4;
+    const int tab5_off = __builtin_amdgcn_readfirstlane(a ? -256 : 5 * 1024);
+    auto load_doff = [&](unsigned (&doff)[NDMA]) __attribute__((always_inline)) {
+        static_for<0, NDMA>([&](auto K) __attribute__((always_inline)) {
+            constexpr int k = decltype(K)::value;
+            if constexpr (k < 5) doff[k] = *reinterpret_cast<const unsigned*>(tabA + k * 1024);
+            else if constexpr (k == 5) {
+                unsigned addr5;  // computed where it is used (volatile: a hoisted copy was kept in a register across the item loop and spilled)
+                asm volatile("v_add_u32 %0, %1, %2" : "=v"(addr5) : "s"(tab5_off), "v"((unsigned)(size_t)tabA));
+                doff[k] = *reinterpret_cast<const unsigned __attribute__((address_space(3)))*>(addr5);
+            }
+            else doff[k] = *reinterpret_cast<const unsigned*>(tabA + k * 1024 - 21 * 256);
+        });
+    };
     // patch reads: thread (tile m of block a & 1, k-slot ks), channels 4 ks + 2 (a >> 1), + 1
     const int tty = m >> 2, ttx = m & 3, half = a >> 1;
     // slot of patch element (r, q) = (18 (4 tty + r) + 4 ttx + q) ^ ((ttx + (q >> 2)) & 1); the sum is even iff q is, so the XOR is +-1:
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // the raw patch of one 16-channel chunk: this wave's share of the 42 wave instructions
     // (a block's pieces fill exactly 21 KiB, so wave instruction j lands at LDS_RAW + 1024 j whichever block it belongs to; only k = 5 straddles:
     // j = 20 is block 0's last instruction, 21 .. 23 are block 1's first)
-    auto stage = [&](const __amdgpu_buffer_rsrc_t& r0, const __amdgpu_buffer_rsrc_t& r1, int chunk_off, auto K) __attribute__((always_inline)) {
+    auto stage = [&](const unsigned (&doff)[NDMA], const __amdgpu_buffer_rsrc_t& r0, const __amdgpu_buffer_rsrc_t& r1, int chunk_off, auto K) __attribute__((always_inline)) {
         constexpr int k = decltype(K)::value;
         const int j = 4 * k + a;
         if (k < 10 || a < 2) {  // j < 42
@@ -281,7 +298,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     Item w = decode(item);
     {
         const __amdgpu_buffer_rsrc_t r0 = make_rsrc(in_base(w.g, w.b0)), r1 = make_rsrc(in_base(w.g, w.b1));
-        static_for<0, NDMA>([&](auto K) __attribute__((always_inline)) { stage(r0, r1, 0, K); });
+        __syncthreads();  // the offset table
+        unsigned doff[NDMA];
+        load_doff(doff);
+        static_for<0, NDMA>([&](auto K) __attribute__((always_inline)) { stage(doff, r0, r1, 0, K); });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
@@ -332,6 +352,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float* vsrcB = lds + LDS_VB / 4 + vbb * VH_FLOATS + vr;
             const int wbuf = vbb ^ 1;
 
+            unsigned doff[NDMA];
+            load_doff(doff);
             f32x4 bb[2][2];
             bb[0][0] = *reinterpret_cast<const f32x4*>(vsrcA);
             bb[0][1] = *reinterpret_cast<const f32x4*>(vsrcA + 16 * 16);
@@ -356,13 +378,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
                 // first half: the NEXT chunk's raw patch, global -> LDS (everybody finished reading the raw buffer before the barrier that ended the
                 // previous chunk)
-                if constexpr (q < NDMA) stage(st0, st1, stage_off, Q);
+#ifndef S4_ABL_NODMA
+                if constexpr (q < NDMA) stage(doff, st0, st1, stage_off, Q);
+#endif
                 // second half: this wave's channels of the next chunk: read, B^T d B, V writes
+#ifndef S4_ABL_NOREAD
                 if constexpr (q >= RQ && q < RQ + 6) read_row(q - RQ);
+#endif
+#ifndef S4_ABL_NOXF
                 if constexpr (q >= RQ + 6 && q < RQ + 12) pass_v(q - RQ - 6);
+#endif
                 if constexpr (q >= RQ + 12 && q < RQ + 18) {
+#ifndef S4_ABL_NOXF
                     pass_h(q - RQ - 12);
+#endif
+#ifndef S4_ABL_NOVWRITE
                     write_row(wbuf, q - RQ - 12);
+#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const f32x4 av = wq[q % RING];
@@ -373,8 +405,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if constexpr (q == NPAIR - 1) {
                     // mid-chunk: the raw patch requested at steps 0 .. 10 must have landed (at most the 6 youngest loads -- weight operands of
                     // steps 12 .. 17 + WD -- may still be in flight: any count below 7 is safe whatever else the compiler queued), V_A is read
+#ifndef S4_ABL_NOWAIT
                     asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+#endif
+#ifndef S4_ABL_NOMIDBAR
                     __syncthreads();
+#endif
                 }
             });
             __syncthreads();  // everybody has read V_B of this chunk and written V_A / V_B of the next one

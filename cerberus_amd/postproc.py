@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .inst_info import info_from_table  # noqa: F401  (numpy-only module: the .dat writer process imports it without torch)
 
 _ws_cache = {}
 
@@ -174,48 +175,3 @@ def get_inst_info_dict(inst_map, type_map=None, ds_factor=1.0, flat_box=False):
     tab_dev = inst_table_device(inst_map, None if type_map is None else type_map.contiguous())
     cnts, pts, offs = inst_contours_device(inst_map, tab_dev)
     return info_from_table(tab_dev.cpu().numpy(), cnts, pts, offs, type_map is not None, ds_factor, flat_box)
-
-
-def info_from_table(tab, cnts, pts, offs, has_type, ds_factor=1.0, flat_box=False):
-    """Host side of get_inst_info_dict: the per-instance dictionaries from cerb_inst_table's rows and the compact contour list.
-    Everything numeric is computed for all instances at once; the per-instance values are row views of those arrays (a slide has
-    ~1e6 nuclei: array construction per instance would dominate the whole slide).  Rules kept from loader/postproc.py:34-35,55-75,
-    78-96 (flat_box: the slide dictionary's [x1, y1, x2, y2] form of infer/wsi.py:817-825 instead of [[y1, x1], [y2, x2]]):
-    drop contours with < 3 points; majority type, skipping background when a second class exists; type_prob =
-    votes / (area + 1e-6); with ds_factor != 1 box / centroid / contour are np.round(x / ds_factor).astype(int)."""
-    from collections import OrderedDict
-
-    n = tab.shape[0]
-    info = OrderedDict()
-    if n == 0:
-        return info
-    area = tab[:, 0]
-    keep = np.nonzero((area > 0) & (cnts >= 3))[0]
-    if keep.size == 0:
-        return info
-    a = np.maximum(area, 1).astype(np.float64)
-    box = np.stack([tab[:, [3, 5]], tab[:, [4, 6]]], axis=1)  # [[y1, x1], [y2, x2]]
-    cen = np.stack([tab[:, 1] / a, tab[:, 2] / a], axis=1)
-    if ds_factor != 1.0:
-        box = np.round(box / ds_factor).astype("int")
-        cen = np.round(cen / ds_factor).astype("int")
-        pts = np.round(pts / ds_factor).astype("int")
-    if flat_box:
-        box = box.reshape(n, 4)[:, [1, 0, 3, 2]]
-    if has_type:
-        votes = tab[:, 8:16]
-        # dominant class first, ties towards the smaller class id (np.unique order + stable sort of the reference)
-        order = np.argsort(-votes, axis=1, kind="stable")
-        t0, t1 = order[:, 0], order[:, 1]
-        second = np.take_along_axis(votes, t1[:, None], 1)[:, 0] > 0
-        typ = np.where((t0 == 0) & second, t1, t0)
-        prob = np.take_along_axis(votes, typ[:, None], 1)[:, 0] / (area + 1.0e-6)
-        typ_l, prob_l = typ.tolist(), prob.tolist()
-    starts, ends = offs.tolist(), (offs + cnts).tolist()
-    for i in keep.tolist():
-        d = {"box": box[i], "centroid": cen[i], "contour": pts[starts[i]:ends[i]]}
-        if has_type:
-            d["type"] = typ_l[i]
-            d["type_prob"] = prob_l[i]
-        info[i + 1] = d
-    return info

@@ -24,6 +24,8 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
+from .inst_info import _uuid4_hex, write_dat  # noqa: F401
+
 from . import _lib
 from .postproc import mask_lumen_by_gland, postproc_device
 
@@ -245,19 +247,6 @@ class WSIRunner(object):
         return inst, info
 
 
-def _uuid4_hex(n):
-    """n random uuid4().hex strings from one os.urandom call (a slide has ~1e6 instances; uuid.uuid4() costs a syscall each)."""
-    import os
-
-    if n == 0:
-        return []
-    raw = np.frombuffer(os.urandom(16 * n), np.uint8).reshape(n, 16).copy()
-    raw[:, 6] = (raw[:, 6] & 0x0F) | 0x40  # version 4
-    raw[:, 8] = (raw[:, 8] & 0x3F) | 0x80  # RFC 4122 variant
-    hx = raw.tobytes().hex()
-    return [hx[i:i + 32] for i in range(0, 32 * n, 32)]
-
-
 def build_wsi_inst_info(inst, canv, slide_hw, proc_mag, ds_factor=0.5, region_records=None, base_mag=None, base_hw=None, prebuilt=None):
     """The dictionary the reference dumps as dat/<slide>.dat (infer/wsi.py:805-853): per tissue {uuid4 hex -> {'box':
     [x1, y1, x2, y2], 'centroid', 'contour', 'type', 'type_prob'}} plus resolution metadata.  Gland / lumen label maps are
@@ -300,15 +289,36 @@ def build_wsi_inst_info(inst, canv, slide_hw, proc_mag, ds_factor=0.5, region_re
     return out
 
 
-def write_dat(obj, path):
-    """dat/<slide>.dat (infer/wsi.py:853 `joblib.dump(wsi_inst_info, ...)`).  Written as a plain protocol-4 pickle: `joblib.load`
-    -- what consumers of the reference's files call -- reads it back to the same objects, and for a dictionary of ~1e6 instances
-    with three small arrays each it is an order of magnitude faster to write (and twice as fast to load) than joblib's per-array
-    wrapper stream."""
-    import pickle
+def collect_wsi_inst_arrays(inst, canv, slide_hw, ds_factor=0.5, skip=()):
+    """The GPU half of build_wsi_inst_info: per tissue the instance table (cerb_inst_table) and the contour point lists (cerb_inst_contour_*),
+    copied to the host as arrays -- what cerberus_amd.inst_info.build_from_parts turns into the dictionary, in this process or in the writer's.
+    -> [(tissue, tab, cnts, pts, offs, has_type, ds_factor)]"""
+    from .postproc import inst_contours_device, inst_table_device
 
-    with open(path, "wb") as fh:
-        pickle.dump(obj, fh, protocol=4)
+    parts = []
+    for tissue, lab in inst.items():
+        if tissue in skip:
+            continue
+        half = tuple(lab.shape) != tuple(int(v) for v in slide_hw)
+        tmap = canv.get(tissue + "-TYPE")
+        if tmap is not None and half:
+            tmap = tmap[::2, ::2][: lab.shape[0], : lab.shape[1]].contiguous()
+        lab = lab.contiguous()
+        tab_dev = inst_table_device(lab, None if tmap is None else tmap.contiguous())
+        cnts, pts, offs = inst_contours_device(lab, tab_dev)
+        parts.append((tissue, tab_dev.cpu().numpy(), cnts, pts, offs, tmap is not None, ds_factor if half else 1.0))
+    return parts
+
+
+def wsi_meta(slide_hw, proc_mag, base_mag=None, base_hw=None):
+    """The resolution entries of dat/<slide>.dat (infer/wsi.py:847-851)."""
+    meta = OrderedDict()
+    meta["proc_resolution"] = {"resolution": float(proc_mag), "units": "mpp"}
+    meta["base_resolution"] = {"resolution": float(proc_mag if base_mag is None else base_mag), "units": "mpp"}
+    meta["proc_dimensions"] = np.array([int(slide_hw[0]), int(slide_hw[1])])  # YX
+    bh, bw = slide_hw if base_hw is None else base_hw
+    meta["base_dimensions"] = np.array([int(bh), int(bw)])
+    return meta
 
 
 class DatWriter(object):
@@ -357,9 +367,45 @@ class DatWriter(object):
             self._thr = threading.Thread(target=run)
             self._thr.start()
 
+    @classmethod
+    def from_arrays(cls, parts, meta, path, extra=None):
+        """The preferred form: the parent hands over ARRAYS (collect_wsi_inst_arrays) and a fresh, torch-free Python process
+        (`python -m cerberus_amd.inst_info`) builds the ~1e6 per-instance dictionaries, draws the uuid keys and pickles them.  Nothing of the
+        8-9 s a 40000^2 slide's dictionary costs stays in the process that launches the next slide's batches, and -- unlike the forked child
+        of __init__, whose copy-on-write image of a 120 GB process slowed the parent's next inference pass by a third -- nothing is shared.
+        extra: {key: ready dictionary} merged in (tissue-region records, `--reference_tiling` nuclei), pickled to a side file."""
+        import os
+        import pickle
+        import subprocess
+        import sys
+
+        from . import inst_info
+
+        self = cls.__new__(cls)
+        self.path, self._pid, self._thr, self._err = path, None, None, None
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        src = path + ".parts.npz"
+        inst_info.save_parts(src, parts, meta)
+        xtra = ""
+        if extra:
+            xtra = path + ".extra.pkl"
+            with open(xtra, "wb") as fh:
+                pickle.dump(extra, fh, protocol=4)
+        env = dict(os.environ)
+        env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + env.get("PYTHONPATH", "")
+        env.pop("HIP_VISIBLE_DEVICES", None)
+        self._proc = subprocess.Popen([sys.executable, "-m", "cerberus_amd.inst_info", src, path, xtra], env=env)
+        return self
+
     def join(self):
         import os
 
+        proc = getattr(self, "_proc", None)
+        if proc is not None:
+            rc = proc.wait()
+            self._proc = None
+            if rc != 0:
+                raise RuntimeError("writing %s failed in the writer process (exit code %d)" % (self.path, rc))
         if self._pid is not None:
             _, status = os.waitpid(self._pid, 0)
             self._pid = None

@@ -11,6 +11,7 @@ slide also gets `tissue/<slide>.mat` (infer/wsi.py:688-716).
 Multi-GPU: launch under `python -m torch.distributed.run --nproc-per-node N run_infer_wsi.py ...`; patch rows shard into one
 contiguous band per rank, inference needs no collective, post-processing is band-local (cerberus_amd/shard_postproc.py)."""
 import glob
+from collections import OrderedDict
 import os
 import sys
 import time
@@ -85,7 +86,7 @@ def main(argv=None):
 
     from cerberus_amd.tile import InferManager
     from cerberus_amd.weights import DEFAULT_REQ_TARGET_CODE, default_model_kwargs
-    from cerberus_amd.wsi import DatWriter, SlabUploader, WSIRunner, build_wsi_inst_info, check_shardable, synth_slide
+    from cerberus_amd.wsi import DatWriter, SlabUploader, WSIRunner, check_shardable, collect_wsi_inst_arrays, synth_slide, wsi_meta
 
     dist, watch = None, launch.null_watch()
     n_dev = max(1, torch.cuda.device_count())
@@ -249,13 +250,25 @@ def main(argv=None):
         prebuilt = None
         if ref_nuclei is not None:
             prebuilt = {"Nuclei": ref_nuclei}
-        info = build_wsi_inst_info(nuc_only, maps, (H, W), float(args["--wsi_proc_mag"]), region_records=records,
-                                   base_mag=None if reader.info.mpp is None else float(reader.info.mpp[0]), base_hw=(bh, bw), prebuilt=prebuilt)
-        # serialising ~1e6 per-instance dictionaries is host-only work: it overlaps the next slide's inference (written to a temporary
-        # name and renamed, so a finished dat/<slide>.dat is always complete -- the resume-by-skip above relies on that)
+        # The dictionary's GPU half (tables, contours) here; its ~1e6 per-instance Python objects, the uuid keys and the pickle in a separate,
+        # torch-free writer process underneath the next slide (cerberus_amd.wsi.DatWriter.from_arrays); a finished dat/<slide>.dat is always
+        # complete (written to a temporary name and renamed) -- the resume-by-skip above relies on that.
+        extra = OrderedDict()
+        if records is not None:  # tissue regions: per-region dictionaries are already built (slide coordinates)
+            import uuid
+
+            for rec in records:
+                for tissue, d in rec["info"].items():
+                    dst = extra.setdefault(tissue, OrderedDict())
+                    for v in d.values():
+                        dst[uuid.uuid4().hex] = v
+        for tissue, d in (prebuilt or {}).items():
+            extra[tissue] = d
+        parts = collect_wsi_inst_arrays(nuc_only, maps, (H, W), skip=tuple(extra.keys()))
+        meta = wsi_meta((H, W), float(args["--wsi_proc_mag"]), base_mag=None if reader.info.mpp is None else float(reader.info.mpp[0]), base_hw=(bh, bw))
         if writer is not None:
             writer.join()
-        writer = DatWriter(info, dat_path)  # a forked child: no interpreter lock shared with the next slide's launch loop
+        writer = DatWriter.from_arrays(parts, meta, dat_path, extra=extra)
         t4 = time.perf_counter()
         print("%s: Inference Time: %.3f  Post Proc Time: %.3f  Instance Table Time: %.3f  (%.1f Mpx/s inference)" % (
             base, t1 - t0, t2 - t1, t4 - t3, H * W / (t1 - t0) / 1e6))

@@ -386,3 +386,53 @@ def test_local_band_count_accounts_for_the_halo_rows():
     assert (-(-3000 // nb) + 256) * 100000 <= 120_000_000
     with pytest.raises(ValueError):
         local_band_count(3000, 100000, 40_000_000, 128)  # 400 rows per call cannot hold a 256-row band with its two 128-row halos
+
+
+def test_dat_writer_process_builds_the_dictionary_from_arrays(tmp_path):
+    """cerberus_amd.wsi.DatWriter.from_arrays: the per-instance tables travel to a torch-free writer process (`python -m cerberus_amd.inst_info`) as
+    arrays; it builds the dictionaries with the same info_from_table the in-process path uses, draws uuid keys, merges pre-built entries and the
+    resolution metadata, writes + renames.  The file holds exactly what build_from_parts gives here (up to the random keys)."""
+    import joblib
+
+    from cerberus_amd import inst_info
+    from cerberus_amd.wsi import DatWriter, wsi_meta
+
+    rs = np.random.RandomState(4)
+    parts = []
+    for tissue, n, has_type, ds in (("Nuclei", 300, True, 1.0), ("Gland", 7, False, 0.5)):
+        tab = np.zeros((n, 16), np.int64)
+        y1, x1 = rs.randint(0, 900, n), rs.randint(0, 900, n)
+        hh, ww = rs.randint(3, 40, n), rs.randint(3, 40, n)
+        tab[:, 0] = hh * ww
+        tab[:, 1], tab[:, 2] = (x1 + ww // 2) * tab[:, 0], (y1 + hh // 2) * tab[:, 0]
+        tab[:, 3], tab[:, 4], tab[:, 5], tab[:, 6] = y1, y1 + hh, x1, x1 + ww
+        tab[:, 7] = y1 * 1000 + x1
+        if has_type:
+            tab[np.arange(n), 8 + rs.randint(0, 6, n)] = tab[:, 0]
+        cnts = rs.randint(2, 9, n).astype(np.int32)  # some contours below 3 points: dropped (loader/postproc.py:34-35)
+        offs = (np.cumsum(cnts) - cnts).astype(np.int64)
+        pts = rs.randint(0, 940, (int(cnts.sum()), 2)).astype(np.int32)
+        parts.append((tissue, tab, cnts, pts, offs, has_type, ds))
+    meta = wsi_meta((1000, 1000), 0.5, base_mag=0.25, base_hw=(2000, 2000))
+    extra = {"Lumen": {"abc": {"box": np.array([1, 2, 3, 4]), "centroid": np.array([2, 3]), "contour": np.zeros((4, 2), np.int32)}}}
+    path = str(tmp_path / "dat" / "s1.dat")
+    DatWriter.from_arrays(parts, meta, path, extra=extra).join()
+    assert not os.path.exists(path + ".parts.npz") and not os.path.exists(path + ".extra.pkl") and not os.path.exists(path + ".part")
+    got = joblib.load(path)
+    want = inst_info.build_from_parts(parts, meta)
+    assert set(got.keys()) == {"Nuclei", "Gland", "Lumen", "proc_resolution", "base_resolution", "proc_dimensions", "base_dimensions"}
+    assert got["proc_resolution"] == {"resolution": 0.5, "units": "mpp"} and got["base_resolution"]["resolution"] == 0.25
+    assert list(got["base_dimensions"]) == [2000, 2000] and list(got["Lumen"].keys()) == ["abc"]
+
+    def key(d):
+        return (tuple(int(v) for v in d["box"]), tuple(np.asarray(d["contour"]).ravel().tolist()), int(d.get("type", -1)), round(float(d.get("type_prob", 0)), 6))
+
+    for t in ("Nuclei", "Gland"):
+        assert len(got[t]) == len(want[t]) > 0 and len(got[t]) < len([p for p in parts if p[0] == t][0][1])  # (< n: short contours dropped)
+        assert sorted(key(d) for d in got[t].values()) == sorted(key(d) for d in want[t].values())
+        assert all(len(k) == 32 for k in got[t])
+    # a failure in the writer process reaches join()
+    bad = DatWriter.from_arrays(parts, meta, str(tmp_path / "dat2" / "s.dat"), extra={"Lumen": {}})
+    os.remove(str(tmp_path / "dat2" / "s.dat") + ".extra.pkl")  # (races with the child's start-up: it has to import numpy first)
+    with pytest.raises(RuntimeError):
+        bad.join()

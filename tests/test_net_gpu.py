@@ -220,6 +220,8 @@ def test_infer_step_vs_reference_golden(golden_dir, tag):
             # rounding ~3x more than a direct convolution there (measured round 4, scripts/dev_parity_achieved.py: |got - p64| 5.8e-4 / 6.0e-5 /
             # 3.2e-4 for Lumen / Gland / Nuclei with F(4x4); 6.7e-4 / 4.2e-5 / 1.3e-4 direct; 4.6e-4 / 3.6e-5 / 1.1e-4 F(2x2); the reference
             # itself 4.6e-4 / 2.4e-5 / 6.7e-5) -- bar: 3x the whole-tensor fp32-vs-fp64 noise of the reference, and the achieved-error record
+            if not k.endswith("INST"):  # Patch-Class: class ids carried in a float map, compared above
+                continue
             p64 = g["p64_crops/" + k] if ("p64_crops/" + k) in g else g["p64_full/" + k]
             e64, r64 = float(np.abs(got - p64).max()), float(np.abs(ref - p64).max())
             if tag != "refinit_all":
@@ -340,13 +342,15 @@ def test_direct_conv_algo_vs_reference_golden(golden_dir, tag):
         ref = g[key] if key in g else g["out_full/" + k]
         got = _crops(a4) if key in g else a4
         if a.dtype == np.float32:
-            p64 = g["p64_crops/" + k] if ("p64_crops/" + k) in g else g["p64_full/" + k]
             assert np.abs(got - ref).max() < _prob_bar(g, k), k
+            assert np.abs(a - b).max() < (5e-5 if tag != "refinit_all" else 2.0 * _prob_bar(g, k)), k
+            if not k.endswith("INST"):
+                continue
+            p64 = g["p64_crops/" + k] if ("p64_crops/" + k) in g else g["p64_full/" + k]
             if tag != "refinit_all":
                 assert float(np.abs(got - p64).max()) <= float(np.abs(ref - p64).max()) + PROB_TOL, k
             else:
                 assert float(np.abs(got - p64).max()) <= 3.0 * float(g["noise/" + k]) + PROB_TOL, k
-            assert np.abs(a - b).max() < (5e-5 if tag != "refinit_all" else 2.0 * _prob_bar(g, k)), k
         elif tag == "refinit_all" and k != "Patch-Class":
             _check_type_map(g, k, got, ref)
         else:
@@ -491,13 +495,14 @@ def test_wino4_algo_vs_reference_golden(golden_dir, tag, algo):
         ref = g[key] if key in g else g["out_full/" + k]
         got = _crops(a4) if key in g else a4
         if a.dtype == np.float32:
-            p64 = g["p64_crops/" + k] if ("p64_crops/" + k) in g else g["p64_full/" + k]
             assert np.abs(got - ref).max() < _prob_bar(g, k), k
-            if tag != "refinit_all":
-                assert float(np.abs(got - p64).max()) <= float(np.abs(ref - p64).max()) + PROB_TOL, k
-            else:
-                assert float(np.abs(got - p64).max()) <= 3.0 * float(g["noise/" + k]) + PROB_TOL, k
             assert np.abs(a - b).max() < (5e-5 if tag != "refinit_all" else 2.0 * _prob_bar(g, k)), k
+            if k.endswith("INST"):  # (Patch-Class is a float map of class ids: no fp64 anchor)
+                p64 = g["p64_crops/" + k] if ("p64_crops/" + k) in g else g["p64_full/" + k]
+                if tag != "refinit_all":
+                    assert float(np.abs(got - p64).max()) <= float(np.abs(ref - p64).max()) + PROB_TOL, k
+                else:
+                    assert float(np.abs(got - p64).max()) <= 3.0 * float(g["noise/" + k]) + PROB_TOL, k
         elif tag == "refinit_all" and k != "Patch-Class":
             _check_type_map(g, k, got, ref)
         else:
@@ -590,3 +595,20 @@ def test_planar_last_level_is_bit_identical_to_nhwc(full_model, win, osz, n):
     if win * win > 4096 * 4:  # the two last levels are above 64 x 64: the planar kernels carry both
         want = 4
         assert sum(k.startswith("conv_wino4p") for k in kernels) == want and kernels.count("upsample2_add_planar") == want // 2, kernels
+    # cerb_net_set_planar(2): the same layout through conv_wino4s.hip (raw patch staged through LDS by direct-to-LDS loads, V in 8-channel halves):
+    # the same products in the same order again -- bit-identical to both
+    try:
+        m.set_planar(2)
+        m.infer_tiles(other, osz)
+        m.profile(True)
+        got2 = {k: v.clone() for k, v in m.infer_tiles(tiles, osz).items()}
+        torch.cuda.synchronize()
+        kernels2 = [r[1] for r in m.profile_records()]
+        m.profile(False)
+        for k in ref:
+            assert torch.equal(got2[k], ref[k]), (k, (got2[k].float() - ref[k].float()).abs().max().item())
+    finally:
+        m.profile(False)
+        m.set_planar(True)
+    if win * win > 4096 * 4:
+        assert sum(k.startswith("conv_wino4s") for k in kernels2) == 4 and not any(k.startswith("conv_wino4p") for k in kernels2), kernels2
