@@ -49,7 +49,7 @@ constexpr int PRE = WD;
 #define S4_RQ 18
 #endif
 constexpr int RQ = S4_RQ;                      // second half: patch reads at RQ .. RQ+5 (a row of 6 pixels per step), vertical passes RQ+6 .. +11, horizontal + V writes RQ+12 .. +17
-static_assert(NS % RING == 0 && WD + 1 <= RING && RQ >= NPAIR && RQ + 18 <= NS, "schedule");
+static_assert(NS % RING == 0 && WD + 1 <= RING && RQ >= NPAIR && RQ + 18 <= NS && PRE == WD, "schedule");
 constexpr int NDMA = 11;                       // direct-to-LDS loads per thread and chunk (waves 2, 3: ten)
 constexpr int BIAS_XI = 7;
 constexpr int CHUNK_W_BYTES = NPOS * 4 * 1024;
@@ -77,6 +77,24 @@ __device__ __forceinline__ void buf_store(f32x4 v, __amdgpu_buffer_rsrc_t r, uns
     __builtin_amdgcn_sched_barrier(0);
 }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// The weight stream as inline assembly, with every wait on it spelled out (S4_MANUAL_WAITS, default on).  With the builtin load the compiler
+// counts ITS loads only: for the operand of step q, requested WD steps earlier, it emits s_waitcnt vmcnt(WD) -- but the queue also holds the
+// direct-to-LDS loads below, which it cannot see, and vmcnt retires in order: vmcnt(WD) then also demands the patch loads of ~WD/2 steps ago,
+// i.e. HBM latency (~0.65 us) inside half the prefetch distance, on each of the eleven steps that carry one (the 0.3 ms / launch the
+// S4_ABL_NODMA ablation had priced, profiles/r04_w4s_ablations.txt).  With both kinds of load invisible the count is exact: wait_weights<q>().
+#ifndef S4_BUILTIN_WEIGHT_LOADS
+#define S4_MANUAL_WAITS 1
+#endif
+__device__ __forceinline__ f32x4 weight_load(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+#ifdef S4_MANUAL_WAITS
+    f32x4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(r), "s"(soff));
+    return v;
+#else
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+#endif
+}
 
 // global -> LDS without a register: 64 lanes x 16 bytes land at LDS byte address lds_base + 16 * lane (scripts/ubench/lds_dma_probe.hip); the
 // compiler does not see the instruction, so it neither tracks it in vmcnt nor knows it writes LDS -- every wait on it is spelled out below.
@@ -224,18 +242,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         });
     };
     // patch reads: thread (tile m of block a & 1, k-slot ks), channels 4 ks + 2 (a >> 1), + 1
-    const int tty = m >> 2, ttx = m & 3, half = a >> 1;
+    // (input-path lane roles: k-slot fastest -- lane = 4 tile + k-slot -- so that a quarter wave reads 4 tiles x 32 bytes spread over both 64-byte
+    // halves of the bank window and a pair write of the wave is one contiguous 1-KiB run)
+    const int tm = lane >> 2, tks = lane & 3;
+    const int tty = tm >> 2, ttx = tm & 3, half = a >> 1;
     // slot of patch element (r, q) = (18 (4 tty + r) + 4 ttx + q) ^ ((ttx + (q >> 2)) & 1); the sum is even iff q is, so the XOR is +-1:
     //   even q (0, 2, 4): + 1 when flipped, odd q (1, 3, 5): - 1;  flipped  <=>  (ttx odd) for q < 4, (ttx even) for q >= 4
     const int slot0 = 18 * 4 * tty + 4 * ttx;
-    const int rd_base = LDS_RAW + (a & 1) * RAW_BLOCK_BYTES + slot0 * 64 + ks * 16 + half * 8;  // bytes
+    const int rd_base = LDS_RAW + (a & 1) * RAW_BLOCK_BYTES + slot0 * 64 + tks * 16 + half * 8;  // bytes
     const int odd = ttx & 1;
     const int rd_lo = rd_base + (odd ? 64 : 0);    // q = 0, 2:  + 64 when ttx is odd
     const int rd_lo_m = rd_base - (odd ? 64 : 0);  // q = 1, 3:  - 64 when ttx is odd
     const int rd_hi = rd_base + (odd ? 0 : 64);    // q = 4:     + 64 when ttx is even (the pixel's 4-group is ttx + 1)
     const int rd_hi_m = rd_base - (odd ? 0 : 64);  // q = 5:     - 64 when ttx is even
-    // V write position (floats) inside a half buffer: position xi adds (xi >> 1) * NT * 16 + (xi & 1) * 2
-    const int vw = (((a & 1) * 16 + m) * 4 + ks) * 4;
+    // V write position (floats) inside a half buffer: pair s adds s * NT * 16
+    const int vw = (((a & 1) * 16 + tm) * 4 + tks) * 4;
     // V read position (floats), block 0; block 1 adds 16 * 16
     const int vr = (m * 4 + ks) * 4;
     const unsigned wlane = (unsigned)lane * 16u;
@@ -274,23 +295,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // V destination of this wave's half: V_A (waves 0, 1), or V_B[buf] (waves 2, 3)
     auto write_row = [&](int vb_buf, int r) __attribute__((always_inline)) {
         float* dst = lds + (half ? (LDS_VB / 4 + vb_buf * VH_FLOATS) : LDS_VA / 4) + vw;
+        // positions 6 r + 2 j and 6 r + 2 j + 1 are one pair (6 r is even): both go out as ONE 16-byte write, {pos 0: t0, t1; pos 1: t0, t1}
 #pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            const int xi = r * 6 + b;
-            *reinterpret_cast<f32x2*>(dst + (xi >> 1) * NT * 16 + (xi & 1) * 2) = d[r][b];
+        for (int j = 0; j < 3; ++j) {
+            const f32x4 v = {d[r][2 * j][0], d[r][2 * j][1], d[r][2 * j + 1][0], d[r][2 * j + 1][1]};
+            *reinterpret_cast<f32x4*>(dst + (3 * r + j) * NT * 16) = v;
         }
     };
     // the raw patch of one 16-channel chunk: this wave's share of the 42 wave instructions
     // (a block's pieces fill exactly 21 KiB, so wave instruction j lands at LDS_RAW + 1024 j whichever block it belongs to; only k = 5 straddles:
     // j = 20 is block 0's last instruction, 21 .. 23 are block 1's first)
-    auto stage = [&](const unsigned (&doff)[NDMA], const __amdgpu_buffer_rsrc_t& r0, const __amdgpu_buffer_rsrc_t& r1, int chunk_off, auto K) __attribute__((always_inline)) {
+    // r5 = the block wave instruction j = 20 + a belongs to (block 0 for wave 0, block 1 for the others), chosen by the caller as a VALUE: a branch
+    // here would put the two loads in different basic blocks, and the hand-counted waits below want one straight instruction stream
+    auto stage = [&](const unsigned (&doff)[NDMA], const __amdgpu_buffer_rsrc_t& r0, const __amdgpu_buffer_rsrc_t& r1, const __amdgpu_buffer_rsrc_t& r5, int chunk_off, auto K) __attribute__((always_inline)) {
         constexpr int k = decltype(K)::value;
         const int j = 4 * k + a;
         if (k < 10 || a < 2) {  // j < 42
             if constexpr (k < 5) dma16(r0, doff[k], chunk_off, (unsigned)(LDS_RAW + j * 1024));
             else if constexpr (k > 5) dma16(r1, doff[k], chunk_off, (unsigned)(LDS_RAW + j * 1024));
-            else if (a == 0) dma16(r0, doff[k], chunk_off, (unsigned)(LDS_RAW + j * 1024));
-            else dma16(r1, doff[k], chunk_off, (unsigned)(LDS_RAW + j * 1024));
+            else dma16(r5, doff[k], chunk_off, (unsigned)(LDS_RAW + j * 1024));
         }
     };
 
@@ -298,10 +321,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     Item w = decode(item);
     {
         const __amdgpu_buffer_rsrc_t r0 = make_rsrc(in_base(w.g, w.b0)), r1 = make_rsrc(in_base(w.g, w.b1));
+        const __amdgpu_buffer_rsrc_t r5 = make_rsrc(in_base(w.g, a == 0 ? w.b0 : w.b1));
         __syncthreads();  // the offset table
         unsigned doff[NDMA];
         load_doff(doff);
-        static_for<0, NDMA>([&](auto K) __attribute__((always_inline)) { stage(doff, r0, r1, 0, K); });
+        static_for<0, NDMA>([&](auto K) __attribute__((always_inline)) { stage(doff, r0, r1, r5, 0, K); });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
@@ -318,15 +342,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();
     __amdgpu_buffer_rsrc_t rw = make_rsrc(w_base(w));
     f32x4 wq[RING];
-#pragma unroll
-    for (int dd = 0; dd < PRE; ++dd) wq[dd] = buf_load(rw, wlane, dd * 1024);
     f32x4 bnext;
     auto load_bias = [&](const Item& wi) {
         const float* bias = p.bias + wi.g * p.bias_gs + wi.cb * 64 + 16 * a;
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, 64, 0x00020000);
+#ifdef S4_MANUAL_WAITS
+        // straight into AccVGPRs, where the value waits until the next item's step BIAS_XI / 2: given a VGPR destination the compiler parks the
+        // value in AccVGPRs itself -- with copies placed right behind the load, reading registers the data has not reached (tests/test_isa_hazard.py)
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=a"(bnext) : "v"((unsigned)(fresh_lane() >> 4) * 16u), "s"(rb));
+#else
         bnext = buf_load(rb, (unsigned)(fresh_lane() >> 4) * 16u, 0);
+#endif
     };
+    // the bias first: it is consumed at step BIAS_XI / 2 of the item's first chunk behind that step's weight wait, which only covers what is
+    // OLDER than the step's own operand (in the output stage below it is younger than the next item's first WD operands, but >= 16 stores follow it)
     load_bias(w);
+#pragma unroll
+    for (int dd = 0; dd < PRE; ++dd) wq[dd] = weight_load(rw, wlane, dd * 1024);
 
     for (;;) {
         f32x4 acc[NPOS][2];
@@ -337,13 +369,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const char* cur1 = in_base(w.g, w.b1);
         const char* nx0 = in_base(wnx.g, wnx.b0);
         const char* nx1 = in_base(wnx.g, wnx.b1);
+#ifndef S4_MANUAL_WAITS
         acc[BIAS_XI][0] = bnext;
         acc[BIAS_XI][1] = bnext;
+#endif
 
         auto chunk = [&](auto first_tag, int ch) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
             const bool last_ch = (ch == nchunk - 1);
             const __amdgpu_buffer_rsrc_t st0 = make_rsrc(last_ch ? nx0 : cur0), st1 = make_rsrc(last_ch ? nx1 : cur1);  // the next chunk's raw patch
+            const __amdgpu_buffer_rsrc_t st5 = make_rsrc(a == 0 ? (last_ch ? nx0 : cur0) : (last_ch ? nx1 : cur1));
             const int stage_off = (last_ch ? 0 : ch + 1) * PLANE_BYTES;
             const int wcur_off = ch * CHUNK_W_BYTES;
             const __amdgpu_buffer_rsrc_t rw_over = last_ch ? rw_nx : rw;
@@ -366,8 +401,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 {
                     constexpr int dd = q + WD;
                     if constexpr (!(FIRST && dd < PRE)) {
-                        if constexpr (dd < NS) wq[dd % RING] = buf_load(rw, wlane, wcur_off + dd * 1024);
-                        else wq[(dd - NS) % RING] = buf_load(rw_over, wlane, wover_off + (dd - NS) * 1024);
+                        if constexpr (dd < NS) wq[dd % RING] = weight_load(rw, wlane, wcur_off + dd * 1024);
+                        else wq[(dd - NS) % RING] = weight_load(rw_over, wlane, wover_off + (dd - NS) * 1024);
                     }
                 }
                 if constexpr (q + 1 < NS) {  // B operands of the next step
@@ -379,7 +414,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 // first half: the NEXT chunk's raw patch, global -> LDS (everybody finished reading the raw buffer before the barrier that ended the
                 // previous chunk)
 #ifndef S4_ABL_NODMA
-                if constexpr (q < NDMA) stage(doff, st0, st1, stage_off, Q);
+                if constexpr (q < NDMA) stage(doff, st0, st1, st5, stage_off, Q);
 #endif
                 // second half: this wave's channels of the next chunk: read, B^T d B, V writes
 #ifndef S4_ABL_NOREAD
@@ -397,6 +432,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef S4_MANUAL_WAITS
+                {
+                    // loads of THIS kernel's inline assembly younger than the operand of step q (requested at the top of step q - WD): the WD weight
+                    // loads of steps q - WD + 1 .. q, and the patch loads of steps max(0, q - WD) .. min(q, 9) (step 10's is issued by two waves
+                    // only and not counted).  A lower bound is all a wait needs: whatever else is queued (stores, the bias) only makes it stricter.
+                    constexpr int lo = q - WD > 0 ? q - WD : 0, hi = q < 9 ? q : 9;
+#ifndef S4_ABL_NODMA
+                    constexpr int nwait = WD + (hi >= lo ? hi - lo + 1 : 0);
+#else
+                    constexpr int nwait = WD;
+#endif
+                    static_assert(nwait < 64, "vmcnt is a 6-bit field");
+                    if constexpr (FIRST && q == BIAS_XI / 2) {
+                        // the item's bias enters position BIAS_XI here: everything but this item's own loads of steps 0 .. q must have landed
+                        constexpr int nb = nwait - WD + q + 1 < nwait ? nwait - WD + q + 1 : nwait;
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(nb));
+                        asm volatile("" : "+a"(bnext));  // a value made AFTER the wait: no copy of it can be scheduled above it
+                        acc[BIAS_XI][0] = bnext;
+                        acc[BIAS_XI][1] = bnext;
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(nwait));
+                    }
+                }
+#endif
                 const f32x4 av = wq[q % RING];
                 const f32x4 b0 = bb[q & 1][0], b1 = bb[q & 1][1];
                 constexpr bool Z = FIRST && hh == 0;
@@ -421,7 +480,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
         // ---- output transform A^T M A (conv_wino4p.hip) ---------------------------------------------------------------------------------
 #pragma unroll
-        for (int dd = WD; dd < PRE; ++dd) wq[dd % RING] = buf_load(rw_nx, wlane, dd * 1024);
+        for (int dd = WD; dd < PRE; ++dd) wq[dd % RING] = weight_load(rw_nx, wlane, dd * 1024);
         load_bias(wnx);
         wait_mfma_results();
         {

@@ -111,7 +111,10 @@ hipError_t cerb_launch_stem(StemParams p, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int C, int Ho, int Wo) {
     const long long total = (long long)N * Ho * Wo * (C / 4);
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    // Workgroup b runs on XCD b % 8, each with its own L2: give every XCD one CONTIGUOUS eighth of the output (whole images at the batch sizes
+    // in use), so that the input rows two neighbouring output rows share are fetched from HBM once, not once per XCD (r04 PMC: 2.5x the input).
+    const long long per_xcd = gridDim.x / 8, vb = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    for (long long i = vb * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % (C / 4));
         long long r = i / (C / 4);
         const int ox = (int)(r % Wo);
@@ -141,8 +144,8 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restr
 hipError_t cerb_launch_maxpool(const float* in, float* out, int N, int H, int W, int C, hipStream_t st) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)N * Ho * Wo * (C / 4);
-    long long blocks = (total + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    long long blocks = ((total + 255) / 256 + 7) / 8 * 8;  // a multiple of the 8 XCDs (the kernel's block -> output mapping relies on it)
+    if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, N, H, W, C, Ho, Wo);
     return hipGetLastError();
 }

@@ -84,3 +84,128 @@ def test_f4x4_kernels_keep_their_arrays_in_registers(unit, tmp_path):
     assert not re.search(r"^_ZZ", asm, re.M), "a lambda was compiled out of line"
     assert "s_swappc_b64" not in asm and "scratch_" not in asm
     assert asm.count("v_mfma_f32_16x16x4") >= 1152
+
+
+# ---- conv_wino4s.hip: loads the compiler cannot see ------------------------------------------------------------------------------------
+# The kernel issues its weight, bias and direct-to-LDS loads from inline assembly and spells out every s_waitcnt vmcnt itself (the compiler's
+# own count would also demand the invisible patch loads, conv_wino4s.hip `weight_load`).  The price: the compiler believes an asm load's
+# destination is valid the moment the statement has run, so a register copy it decides to place between the load and the hand-written wait
+# would read (or a re-use would overwrite) a register whose data is still in flight -- silently.  This scan replays the kernel's instruction
+# stream in text order with the hardware's in-order vmcnt queue and fails on any instruction that touches a register with a load pending.
+_VREG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
+_VMCNT = re.compile(r"s_waitcnt\b.*?vmcnt\((\d+)\)")
+
+
+def _regs(text):
+    out = set()
+    for m in _VREG.finditer(text):
+        if m.group(1):
+            out.update((m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1))
+        else:
+            out.add((m.group(4), int(m.group(5))))
+    return out
+
+
+def _step(queue, t):
+    """One instruction against the in-order queue of vector-memory operations in flight -> (new queue, registers it touches that are pending)."""
+    op = t.split()[0]
+    if op == "s_waitcnt":
+        m = _VMCNT.search(t)
+        if m:
+            keep = int(m.group(1))
+            queue = queue[len(queue) - keep:] if 0 < keep < len(queue) else (() if keep == 0 else queue)
+        return queue, set()
+    rest = t.split(None, 1)[1] if len(t.split(None, 1)) > 1 else ""
+    pending = set().union(*queue) if queue else set()
+    hit = _regs(rest) & pending
+    if op.startswith(("buffer_load", "global_load")):
+        queue = queue + ((frozenset() if " lds" in t else frozenset(_regs(rest.split(",")[0]))),)
+    elif op.startswith(("buffer_store", "global_store")):
+        queue = queue + (frozenset(),)
+    if len(queue) > 63:  # the counter saturates; nothing in these kernels gets near
+        queue = queue[-63:]
+    return queue, hit
+
+
+def scan_invisible_loads(lines):
+    """-> (violations, register loads seen, vmcnt waits seen).  `lines`: the text of ONE kernel (labels and instructions).  Walks the control-flow
+    graph (labels, s_branch / s_cbranch_*) with the queue as the state, every (block, queue) pair once."""
+    blocks, order, cur = {"<entry>": []}, ["<entry>"], "<entry>"
+    for l in lines:
+        t = l.split(";")[0].strip()
+        if not t:
+            continue
+        m = re.match(r"^(\.?\w+):$", t)
+        if m:
+            cur = m.group(1)
+            blocks[cur] = []
+            order.append(cur)
+        else:
+            blocks[cur].append(t)
+    nxt = {b: (order[i + 1] if i + 1 < len(order) else None) for i, b in enumerate(order)}
+    n_loads = sum(1 for b in blocks.values() for t in b if t.startswith(("buffer_load", "global_load")) and " lds" not in t)
+    n_waits = sum(1 for b in blocks.values() for t in b if _VMCNT.search(t))
+    bad, seen, work = {}, set(), [("<entry>", ())]
+    while work:
+        b, queue = work.pop()
+        if b is None or (b, queue) in seen:
+            continue
+        assert len(seen) < 200000, "state explosion in the vmcnt scan"
+        seen.add((b, queue))
+        fall = True
+        for k, t in enumerate(blocks[b]):
+            op = t.split()[0]
+            if op == "s_branch":
+                work.append((t.split()[1], queue))
+                fall = False
+                break
+            if op.startswith("s_cbranch"):
+                work.append((t.split()[1], queue))
+                continue
+            if op == "s_endpgm":
+                fall = False
+                break
+            queue, hit = _step(queue, t)
+            if hit:
+                bad.setdefault((b, k), (t, sorted(hit)[:4]))
+        if fall:
+            work.append((nxt[b], queue))
+    return [(k, v[0], v[1]) for k, v in sorted(bad.items())], n_loads, n_waits
+
+
+def _kernels(unit, tmp):
+    out = os.path.join(tmp, unit.replace(".hip", ".s"))
+    from cerberus_amd.build import EXTRA_FLAGS
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--offload-device-only", "-S", "-o", out] + EXTRA_FLAGS.get(unit, [])
+                          + [os.path.join(CSRC, unit)], stderr=subprocess.DEVNULL)
+    kernels, cur = {}, None
+    for l in open(out).read().splitlines():
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = []
+        elif cur is not None:
+            if l.strip().startswith(".Lfunc_end"):
+                cur = None
+            else:
+                t = l.split(";")[0].strip()
+                if t and not t.startswith("//") and not (t.startswith(".") and not t.endswith(":")):
+                    kernels[cur].append(t)
+    return kernels
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc not available")
+def test_wino4s_no_instruction_touches_a_register_with_a_load_in_flight(tmp_path):
+    ks = {k: v for k, v in _kernels("conv_wino4s.hip", str(tmp_path)).items() if "conv_wino4s_kernel" in k}
+    assert len(ks) == 2
+    for name, lines in ks.items():
+        bad, n_loads, n_waits = scan_invisible_loads(lines)
+        assert n_loads >= 72 and n_waits >= 72, "%s: expected the unrolled chunk bodies (%d loads, %d waits seen)" % (name, n_loads, n_waits)
+        assert not bad, "%s: %d instruction(s) touch a register whose load is still in flight, first: line %d `%s` %s" % (name, len(bad), bad[0][0], bad[0][1], bad[0][2])
+
+
+def test_invisible_load_scan_catches_a_planted_copy():
+    lines = ["buffer_load_dwordx4 v[4:7], v1, s[0:3], 0 offen", "buffer_load_dwordx4 v[8:11], v1, s[0:3], 0 offen", "s_waitcnt vmcnt(1)",
+             "v_mov_b32_e32 v20, v5", "v_mov_b32_e32 v21, v9", "s_waitcnt vmcnt(0)", "v_mov_b32_e32 v22, v9"]
+    bad, n_loads, n_waits = scan_invisible_loads(lines)
+    assert [b[1] for b in bad] == ["v_mov_b32_e32 v21, v9"] and n_loads == 2 and n_waits == 2
