@@ -78,14 +78,14 @@ __device__ __forceinline__ void buf_store(f32x4 v, __amdgpu_buffer_rsrc_t r, uns
 }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// The weight stream as inline assembly, with every wait on it spelled out (S4_MANUAL_WAITS, default on).  With the builtin load the compiler
-// counts ITS loads only: for the operand of step q, requested WD steps earlier, it emits s_waitcnt vmcnt(WD) -- but the queue also holds the
-// direct-to-LDS loads below, which it cannot see, and vmcnt retires in order: vmcnt(WD) then also demands the patch loads of ~WD/2 steps ago,
-// i.e. HBM latency (~0.65 us) inside half the prefetch distance, on each of the eleven steps that carry one (the 0.3 ms / launch the
-// S4_ABL_NODMA ablation had priced, profiles/r04_w4s_ablations.txt).  With both kinds of load invisible the count is exact: wait_weights<q>().
-#ifndef S4_BUILTIN_WEIGHT_LOADS
-#define S4_MANUAL_WAITS 1
-#endif
+// EXPERIMENT, off by default (-DS4_MANUAL_WAITS): the weight and bias loads as inline assembly with every wait on them spelled out.
+// Idea: with the builtin load the compiler counts ITS loads only -- for the operand of step q, requested WD steps earlier, it emits
+// s_waitcnt vmcnt(WD) -- but the queue also holds the direct-to-LDS loads below, which it cannot see, and vmcnt retires in order: vmcnt(WD) then
+// also demands the patch loads of ~WD/2 steps ago.  With both kinds of load invisible the count can be exact (wait below: WD + the patch loads
+// issued since).  Measured (profiles/r04_w4s_ablations.txt): 2.108 ms per launch against 2.155 with the compiler's waits -- the coupling is NOT
+// where the 0.28 ms of the patch loads go -- and the results were NOT bit-identical to conv_wino4p on the GPU although the instruction stream
+// passes the in-flight-register scan of tests/test_isa_hazard.py: either a direct-to-LDS load can retire behind a younger register load (the
+// counter is not in order across the two kinds) or the hand count has a hole.  Not shipped; kept for the record with the scan that guards it.
 __device__ __forceinline__ f32x4 weight_load(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
 #ifdef S4_MANUAL_WAITS
     f32x4 v;
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     // loads of steps q - WD + 1 .. q, and the patch loads of steps max(0, q - WD) .. min(q, 9) (step 10's is issued by two waves
                     // only and not counted).  A lower bound is all a wait needs: whatever else is queued (stores, the bias) only makes it stricter.
                     constexpr int lo = q - WD > 0 ? q - WD : 0, hi = q < 9 ? q : 9;
-#ifndef S4_ABL_NODMA
+#if !defined(S4_ABL_NODMA) && !defined(S4_WAIT_IGNORE_DMA)
                     constexpr int nwait = WD + (hi >= lo ? hi - lo + 1 : 0);
 #else
                     constexpr int nwait = WD;
@@ -481,8 +481,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // ---- output transform A^T M A (conv_wino4p.hip) ---------------------------------------------------------------------------------
 #pragma unroll
         for (int dd = WD; dd < PRE; ++dd) wq[dd % RING] = weight_load(rw_nx, wlane, dd * 1024);
+#ifndef S4_MANUAL_WAITS
         load_bias(wnx);
         wait_mfma_results();
+#else
+        // the asm bias load wants four AccVGPRs and all 256 hold accumulators: the compiler frees them by reading an accumulator out first -- which
+        // must not happen before the matrix pipe has drained (it does not know the asm matrix instructions' latency)
+        wait_mfma_results();
+        load_bias(wnx);
+#endif
         {
             int relu_s = p.relu;
             asm volatile("" : "+s"(relu_s));

@@ -197,6 +197,26 @@ __global__ void ccl_flatten_kernel(int* L, int n) {
         L[p] = uf_find(L, (int)p);
     }
 }
+// flatten + component areas in one pass over L: area[root] += the length of each RUN of equal roots inside the wave (64 consecutive pixels of a
+// row hold a few runs; the separate ccl_area_kernel pass re-read all of L for the same atomics).  `area` is zeroed by the caller.
+__global__ void ccl_flatten_area_kernel(int* L, int* __restrict__ area, int n) {
+    const int lane = threadIdx.x & 63;
+    for (long long base = (blockIdx.x * (long long)blockDim.x + threadIdx.x) - lane; base < n; base += (long long)gridDim.x * blockDim.x) {
+        const long long p = base + lane;
+        int r = -1;
+        if (p < n && L[p] >= 0) {
+            r = uf_find(L, (int)p);
+            L[p] = r;
+        }
+        const int prev = __shfl_up(r, 1);
+        const bool head = r >= 0 && (lane == 0 || prev != r);
+        const unsigned long long bounds = __ballot(head || r < 0);
+        if (head) {
+            const unsigned long long after = lane == 63 ? 0ull : (bounds >> (lane + 1));
+            atomicAdd(&area[r], after ? __ffsll((long long)after) : 64 - lane);
+        }
+    }
+}
 static unsigned grid_for(long long n) {
     long long b = (n + 255) / 256;
     if (b > 256 * 16) b = 256 * 16;
@@ -316,7 +336,7 @@ __global__ void ccl_seam_kernel(const uint8_t* __restrict__ fg, uint8_t val, int
         if (a >= 0 && ra != rb && !(lane > 0 && pa == ra && pb == rb)) uf_union(L, ra, rb);
     }
 }
-static int ccl_run(const uint8_t* fg, uint8_t val, int* L, int H, int W, hipStream_t st) {
+static int ccl_run(const uint8_t* fg, uint8_t val, int* L, int H, int W, hipStream_t st, int* area = nullptr) {
     const int n = H * W;
 #ifdef PP_CCL_GLOBAL  // round 1's labelling: run-based init + one global union per run pair
     hipLaunchKernelGGL(ccl_init_kernel, dim3(grid_for(n)), dim3(256), 0, st, fg, val, L, n, W);
@@ -328,7 +348,8 @@ static int ccl_run(const uint8_t* fg, uint8_t val, int* L, int H, int W, hipStre
     const long long seams = (long long)(tiles_x - 1) * H + (long long)(tiles_y - 1) * W;
     if (seams > 0) hipLaunchKernelGGL(ccl_seam_kernel, dim3(grid_for(seams)), dim3(256), 0, st, fg, val, L, H, W, tiles_x, tiles_y);
 #endif
-    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(grid_for(n)), dim3(256), 0, st, L, n);
+    if (area) hipLaunchKernelGGL(ccl_flatten_area_kernel, dim3(grid_for(n)), dim3(256), 0, st, L, area, n);
+    else hipLaunchKernelGGL(ccl_flatten_kernel, dim3(grid_for(n)), dim3(256), 0, st, L, n);
     KCHECK();
     return 0;
 }
@@ -385,6 +406,63 @@ __global__ void nuc_threshold_kernel(const float* __restrict__ inst, long long r
         local |= m;
     }
     if (__any(local) && (threadIdx.x & 63) == 0) atomicOr(any, 1);
+}
+// Four pixels per thread (W % 4 == 0, so a quad never straddles a row and the byte maps take one 32-bit store per thread instead of four
+// single-byte ones): the r04 profile had the one-pixel kernels at 2.7 TB/s of their 10 bytes per pixel.
+template <bool PACKED>
+__global__ void nuc_threshold4_kernel(const float* __restrict__ inst, long long row_stride, int pix_stride, int H, int W,
+                                      uint32_t* __restrict__ msk0, uint32_t* __restrict__ mrk0, int* __restrict__ any) {
+    const long long nq = (long long)H * W / 4;
+    const int qw = W / 4;
+    int local = 0;
+    const double invQ = 1.0 / (double)qw;
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < nq; q += (long long)gridDim.x * blockDim.x) {
+        int y, xq;
+        pix_yx(q, qw, invQ, y, xq);
+        const float* s = inst + y * row_stride + (long long)xq * 4 * pix_stride;
+        uint32_t m = 0, k = 0;
+        float px[8];
+        if (PACKED) {  // [H][W][2] floats, 16-byte aligned rows: the quad is two 16-byte loads
+            const float4 a = reinterpret_cast<const float4*>(s)[0], b = reinterpret_cast<const float4*>(s)[1];
+            px[0] = a.x; px[1] = a.y; px[2] = a.z; px[3] = a.w; px[4] = b.x; px[5] = b.y; px[6] = b.z; px[7] = b.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                px[2 * i] = s[(long long)i * pix_stride];
+                px[2 * i + 1] = s[(long long)i * pix_stride + 1];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float inner = px[2 * i], cnt = px[2 * i + 1];
+            const float raw = inner + cnt;  // float32 add, as numpy (postproc.py:360)
+            m |= (uint32_t)(raw > 0.5f) << (8 * i);
+            k |= (uint32_t)(inner > 0.5f) << (8 * i);
+        }
+        msk0[q] = m;
+        mrk0[q] = k;
+        local |= (int)m;
+    }
+    if (__any(local) && (threadIdx.x & 63) == 0) atomicOr(any, 1);
+}
+// the cross erosion on four 0/1 bytes at once: AND of the word with its row neighbours and with itself shifted one byte either way (the byte
+// that shifts in comes from the neighbouring word, or is 1 at the image border: the constant border never wins the min)
+__global__ void erode_cross4_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int H, int W) {
+    const long long nq = (long long)H * W / 4;
+    const int qw = W / 4;
+    const double invQ = 1.0 / (double)qw;
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < nq; q += (long long)gridDim.x * blockDim.x) {
+        int y, xq;
+        pix_yx(q, qw, invQ, y, xq);
+        const uint32_t c = src[q];
+        uint32_t v = c;
+        if (y > 0) v &= src[q - qw];
+        if (y < H - 1) v &= src[q + qw];
+        const uint32_t left = xq > 0 ? src[q - 1] >> 24 : 1u, right = xq < qw - 1 ? src[q + 1] << 24 : 0x01000000u;
+        v &= (c << 8) | left;
+        v &= (c >> 8) | right;
+        dst[q] = v;
+    }
 }
 // cv2.erode with the 3x3 MORPH_ELLIPSE (= cross); the constant border never wins the min
 __global__ void erode_cross_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W) {
@@ -461,11 +539,23 @@ __global__ void ws_seed_kernel(const float* __restrict__ inst, long long row_str
                                int* __restrict__ lmax) {
     const long long n = (long long)H * W;
     const double invW = 1.0 / (double)W;
-    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
-        if (!out[p]) {
-            if (mask[p]) atomicAdd(&unl[L[p]], 1);  // floodable pixel of its component
-            continue;
+    const int lane = threadIdx.x & 63;
+    // whole waves step together (no lane leaves the loop early): the count of floodable pixels is added once per RUN of equal roots inside the
+    // wave -- 64 consecutive pixels of a row hold a few runs, where one atomic per pixel had every ring pixel of a nucleus hit one address
+    for (long long base = (blockIdx.x * (long long)blockDim.x + threadIdx.x) - lane; base < n; base += (long long)gridDim.x * blockDim.x) {
+        const long long p = base + lane;
+        const bool valid = p < n;
+        const int o = valid ? out[p] : 0;
+        const int key = (valid && !o && mask[p]) ? L[p] : -1;  // root of a floodable pixel
+        const int prev = __shfl_up(key, 1);
+        const bool head = key >= 0 && (lane == 0 || prev != key);
+        const unsigned long long bounds = __ballot(head || key < 0);
+        if (head) {
+            const unsigned long long after = lane == 63 ? 0ull : (bounds >> (lane + 1));
+            const int run = after ? __ffsll((long long)after) : 64 - lane;
+            atomicAdd(&unl[key], run);
         }
+        if (!o) continue;
         int y, x;
         pix_yx(p, W, invW, y, x);
         bool active = false;
@@ -492,15 +582,20 @@ __global__ void ws_bbox_init_kernel(const int* __restrict__ L, const uint8_t* __
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
         if (L[p] == (int)p && mask[p]) bb[p] = CBox{H, -1, W, -1};
 }
-__global__ void ws_bbox_kernel(const int* __restrict__ L, const uint8_t* __restrict__ mask, CBox* bb, int H, int W) {
+// Only components that reach a priority flood need their box (ws_worklist_kernel: seeds of at least two labels, lmin < lmax; no seed at all
+// leaves lmin = 0x7f7f7f7f > lmax = 0): isolated nuclei -- the common case -- skip the outline test and the atomics.
+__global__ void ws_bbox_kernel(const int* __restrict__ L, const uint8_t* __restrict__ mask, CBox* bb, int H, int W, const int* __restrict__ lmin,
+                               const int* __restrict__ lmax) {
     const long long n = (long long)H * W;
     const double invW = 1.0 / (double)W;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
         if (!mask[p]) continue;
+        const int root = L[p];
+        if (lmin[root] >= lmax[root]) continue;
         int y, x;
         pix_yx(p, W, invW, y, x);
         if (y > 0 && y < H - 1 && x > 0 && x < W - 1 && mask[p - W] && mask[p + W] && mask[p - 1] && mask[p + 1]) continue;
-        CBox* b = bb + L[p];
+        CBox* b = bb + root;
         const volatile CBox* vb = b;  // monotone extremes: skip the atomic when a plain read already covers the pixel
         if (y < vb->y1) atomicMin(&b->y1, y);
         if (y > vb->y2) atomicMax(&b->y2, y);
@@ -1493,17 +1588,23 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
     const unsigned g = grid_for(n);
 
     PP_OK(hipMemsetAsync(small, 0, 256, st));
-    hipLaunchKernelGGL(nuc_threshold_kernel, dim3(g), dim3(256), 0, st, inst, row_stride, pix_stride, H, W, msk0, mrk, small);
     // (A) mask: erode -> label -> drop components < 8 px   (postproc.py:365-368)
-    hipLaunchKernelGGL(erode_cross_kernel, dim3(g), dim3(256), 0, st, msk0, msk, H, W);
-    if (ccl_run(msk, 1, LA, H, W, st)) return 1;
+    if (W % 4 == 0 && ((uintptr_t)msk0 | (uintptr_t)msk | (uintptr_t)mrk) % 4 == 0) {
+        const unsigned g4 = grid_for(n / 4);
+        const bool packed = pix_stride == 2 && row_stride % 4 == 0 && (uintptr_t)inst % 16 == 0;
+        hipLaunchKernelGGL(packed ? nuc_threshold4_kernel<true> : nuc_threshold4_kernel<false>, dim3(g4), dim3(256), 0, st, inst, row_stride, pix_stride, H, W,
+                           (uint32_t*)msk0, (uint32_t*)mrk, small);
+        hipLaunchKernelGGL(erode_cross4_kernel, dim3(g4), dim3(256), 0, st, (const uint32_t*)msk0, (uint32_t*)msk, H, W);
+    } else {
+        hipLaunchKernelGGL(nuc_threshold_kernel, dim3(g), dim3(256), 0, st, inst, row_stride, pix_stride, H, W, msk0, mrk, small);
+        hipLaunchKernelGGL(erode_cross_kernel, dim3(g), dim3(256), 0, st, msk0, msk, H, W);
+    }
     PP_OK(hipMemsetAsync(areaA, 0, (size_t)n * 4, st));
-    hipLaunchKernelGGL(ccl_area_kernel, dim3(g), dim3(256), 0, st, LA, areaA, n);
+    if (ccl_run(msk, 1, LA, H, W, st, areaA)) return 1;
     hipLaunchKernelGGL(apply_min_area_kernel, dim3(g), dim3(256), 0, st, msk, LA, areaA, 8, n);
     // (B) markers: inner > 0.5 -> label -> drop < 4 px -> fill holes -> label (postproc.py:370-377)
-    if (ccl_run(mrk, 1, LB, H, W, st)) return 1;
     PP_OK(hipMemsetAsync(areaB, 0, (size_t)n * 4, st));
-    hipLaunchKernelGGL(ccl_area_kernel, dim3(g), dim3(256), 0, st, LB, areaB, n);
+    if (ccl_run(mrk, 1, LB, H, W, st, areaB)) return 1;
     hipLaunchKernelGGL(apply_min_area_kernel, dim3(g), dim3(256), 0, st, mrk, LB, areaB, 4, n);
     if (ccl_run(mrk, 0, LB, H, W, st)) return 1;  // background of the marker image
     PP_OK(hipMemsetAsync(areaB, 0, (size_t)n * 4, st));
@@ -1528,7 +1629,7 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
     hipLaunchKernelGGL(ws_seed_kernel, dim3(g), dim3(256), 0, st, inst, row_stride, pix_stride, msk, labels_out, LA, hoff, hcnt, hkey, hidx, H, W, unl,
                        lmin, lmax);
     hipLaunchKernelGGL(ws_bbox_init_kernel, dim3(g), dim3(256), 0, st, LA, msk, cbox, H, W);
-    hipLaunchKernelGGL(ws_bbox_kernel, dim3(g), dim3(256), 0, st, LA, msk, cbox, H, W);
+    hipLaunchKernelGGL(ws_bbox_kernel, dim3(g), dim3(256), 0, st, LA, msk, cbox, H, W, lmin, lmax);
     int* counts = small + 8;  // [0] window tier, [1] LDS-heap tier, [2] global tier
     hipLaunchKernelGGL(ws_worklist_kernel, dim3(g), dim3(256), 0, st, hcnt, areaA, unl, cbox, lmin, lmax, wl, rank, wl3, wl4, counts, n);
     hipLaunchKernelGGL(ws_fill_single_kernel, dim3(g), dim3(256), 0, st, msk, LA, lmin, lmax, labels_out, n);
@@ -1614,9 +1715,8 @@ static int gland_lumen(const float* inst, int H, int W, long long row_stride, in
     const unsigned g = grid_for(n);
 
     hipLaunchKernelGGL(gl_threshold_kernel, dim3(g), dim3(256), 0, st, inst, row_stride, pix_stride, H, W, thr, fg);
-    if (ccl_run(fg, 1, L, H, W, st)) return 1;
     PP_OK(hipMemsetAsync(area, 0, (size_t)n * 4, st));
-    hipLaunchKernelGGL(ccl_area_kernel, dim3(g), dim3(256), 0, st, L, area, n);
+    if (ccl_run(fg, 1, L, H, W, st, area)) return 1;
     hipLaunchKernelGGL(ccl_keep_roots_kernel, dim3(g), dim3(256), 0, st, L, area, min_size, flag, n);
     if (scan_exclusive(flag, rank, n, scantmp, st)) return 1;
     hipLaunchKernelGGL(ccl_relabel_kernel, dim3(g), dim3(256), 0, st, L, flag, rank, lab, n);

@@ -2,6 +2,7 @@
 
   python scripts/rocprof_summary.py stats  <results.db>  <out.txt>
   python scripts/rocprof_summary.py pmc    <fetch.db> <write.db> <out.json>
+  python scripts/rocprof_summary.py timeline <results.db> <first-kernel substring> <out.txt>     (dispatches of the LAST call that starts with that kernel)
 
 PMC post-processing follows /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KiB, collected in
 separate passes; on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced stream, so reads are
@@ -51,8 +52,24 @@ def pmc(fetch_db, write_db, out):
     print("wrote", out)
 
 
+def timeline(db, first, out):
+    c = sqlite3.connect(db)
+    rows = list(c.execute("select name, start, end, queue_id from kernels order by start"))
+    idx = [i for i, r in enumerate(rows) if first in r[0]]
+    rows = rows[idx[-1]:]
+    t0 = rows[0][1]
+    with open(out, "w") as f:
+        f.write("# dispatches of the last call (rocprofv3 --kernel-trace): start offset, duration (ms), queue, kernel; wall %.3f ms, sum of durations %.3f ms\n"
+                % ((max(r[2] for r in rows) - t0) / 1e6, sum(r[2] - r[1] for r in rows) / 1e6))
+        for n, a, b, q in rows:
+            f.write("%8.3f %8.3f q%-3s %s\n" % ((a - t0) / 1e6, (b - a) / 1e6, q, n[:70]))
+    print("wrote", out)
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "timeline":
+        timeline(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])

@@ -87,11 +87,12 @@ def test_f4x4_kernels_keep_their_arrays_in_registers(unit, tmp_path):
 
 
 # ---- conv_wino4s.hip: loads the compiler cannot see ------------------------------------------------------------------------------------
-# The kernel issues its weight, bias and direct-to-LDS loads from inline assembly and spells out every s_waitcnt vmcnt itself (the compiler's
-# own count would also demand the invisible patch loads, conv_wino4s.hip `weight_load`).  The price: the compiler believes an asm load's
-# destination is valid the moment the statement has run, so a register copy it decides to place between the load and the hand-written wait
-# would read (or a re-use would overwrite) a register whose data is still in flight -- silently.  This scan replays the kernel's instruction
-# stream in text order with the hardware's in-order vmcnt queue and fails on any instruction that touches a register with a load pending.
+# The kernel issues its direct-to-LDS loads from inline assembly; its -DS4_MANUAL_WAITS experiment (off by default, see the source) does the same
+# with the weight and bias loads and spells out every s_waitcnt vmcnt itself.  The price of an invisible load: the compiler believes an asm
+# load's destination is valid the moment the statement has run, so a register copy it decides to place between the load and the hand-written
+# wait would read (or a re-use would overwrite) a register whose data is still in flight -- silently.  (It happened: given a VGPR destination
+# for the bias, hipcc parked the value in AccVGPRs with copies right behind the load.)  This scan walks the kernel's control-flow graph with the
+# hardware's in-order vmcnt queue as the state and fails on any instruction that touches a register with a load pending.
 _VREG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
 _VMCNT = re.compile(r"s_waitcnt\b.*?vmcnt\((\d+)\)")
 
@@ -173,10 +174,10 @@ def scan_invisible_loads(lines):
     return [(k, v[0], v[1]) for k, v in sorted(bad.items())], n_loads, n_waits
 
 
-def _kernels(unit, tmp):
+def _kernels(unit, tmp, extra=()):
     out = os.path.join(tmp, unit.replace(".hip", ".s"))
     from cerberus_amd.build import EXTRA_FLAGS
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--offload-device-only", "-S", "-o", out] + EXTRA_FLAGS.get(unit, [])
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--offload-device-only", "-S", "-o", out] + EXTRA_FLAGS.get(unit, []) + list(extra)
                           + [os.path.join(CSRC, unit)], stderr=subprocess.DEVNULL)
     kernels, cur = {}, None
     for l in open(out).read().splitlines():
@@ -195,12 +196,13 @@ def _kernels(unit, tmp):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc not available")
-def test_wino4s_no_instruction_touches_a_register_with_a_load_in_flight(tmp_path):
-    ks = {k: v for k, v in _kernels("conv_wino4s.hip", str(tmp_path)).items() if "conv_wino4s_kernel" in k}
+@pytest.mark.parametrize("extra", [(), ("-DS4_MANUAL_WAITS",)], ids=["default", "manual-waits"])
+def test_wino4s_no_instruction_touches_a_register_with_a_load_in_flight(tmp_path, extra):
+    ks = {k: v for k, v in _kernels("conv_wino4s.hip", str(tmp_path), extra).items() if "conv_wino4s_kernel" in k}
     assert len(ks) == 2
     for name, lines in ks.items():
         bad, n_loads, n_waits = scan_invisible_loads(lines)
-        assert n_loads >= 72 and n_waits >= 72, "%s: expected the unrolled chunk bodies (%d loads, %d waits seen)" % (name, n_loads, n_waits)
+        assert n_loads >= 72 and n_waits >= 60, "%s: expected the unrolled chunk bodies (%d loads, %d waits seen)" % (name, n_loads, n_waits)
         assert not bad, "%s: %d instruction(s) touch a register whose load is still in flight, first: line %d `%s` %s" % (name, len(bad), bad[0][0], bad[0][1], bad[0][2])
 
 
