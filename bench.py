@@ -522,8 +522,9 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
                "entries": {p_[0]: int(((p_[1][:, 0] > 0) & (p_[2] >= 3)).sum()) for p_ in parts},
                "inference_pass_under_writer_s": round(t3 - t2, 3), "writer_wait_s": round(t4 - t3, 3),
                "note": "tables_and_contours_s = cerb_inst_table + cerb_inst_contour_* + copies to the host, hand_over_s = the arrays written for the writer "
-                       "process (both in the parent, between two slides); writer_build_s / writer_pickle_s = per-instance dictionaries + uuid keys / the "
-                       "protocol-4 pickle joblib.load reads, on the writer's own clock, underneath the next slide; end_to_end_Mpx_s counts all four "
+                       "process (both in the parent, between two slides); writer_build_s / writer_pickle_s = reading them back / the protocol-4 pickle joblib.load "
+                       "reads, assembled as byte matrices without a Python object per instance (inst_info.write_dat_fast), on the writer's own clock, "
+                       "underneath the next slide; end_to_end_Mpx_s counts all four "
                        "serially, as a one-slide run pays them"}
         del parts
     res.clear()

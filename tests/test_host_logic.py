@@ -436,3 +436,76 @@ def test_dat_writer_process_builds_the_dictionary_from_arrays(tmp_path):
     os.remove(str(tmp_path / "dat2" / "s.dat") + ".extra.pkl")  # (races with the child's start-up: it has to import numpy first)
     with pytest.raises(RuntimeError):
         bad.join()
+
+
+def _same_object(a, b, path=""):
+    assert type(a) == type(b), (path, type(a), type(b))
+    if isinstance(a, dict):
+        assert len(a) == len(b), (path, len(a), len(b))
+        for (ka, va), (kb, vb) in zip(a.items(), b.items()):
+            if isinstance(ka, str) and len(ka) == 32 and isinstance(va, dict) and "box" in va:
+                assert isinstance(kb, str) and len(kb) == 32  # fresh uuid keys on both sides
+            else:
+                assert ka == kb, (path, ka, kb)
+            _same_object(va, vb, path + "/" + str(ka))
+    elif isinstance(a, np.ndarray):
+        assert a.dtype == b.dtype and a.shape == b.shape and (a == b).all(), (path, a, b)
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), path
+        for x, y in zip(a, b):
+            _same_object(x, y, path)
+    else:
+        assert a == b, (path, a, b)
+
+
+def test_write_dat_fast_writes_what_pickle_would(tmp_path):
+    """inst_info.write_dat_fast assembles the protocol-4 stream of the slide dictionary as byte matrices (no Python object per instance): the file
+    must unpickle -- with pickle AND joblib -- to exactly what write_dat(build_from_parts(...)) gives: same keys in the same order, equal values of
+    equal dtypes and Python types; and it names numpy.core (loadable by the reference's numpy 1.x), never numpy._core."""
+    import pickle
+    import time
+    import uuid
+    from collections import OrderedDict
+
+    import joblib
+
+    from cerberus_amd import inst_info as ii
+
+    rng = np.random.RandomState(0)
+
+    def part(name, n, has_type, ds, pdt):
+        cnts = rng.randint(0, 300 if name == "Gland" else 40, n).astype(np.int32)
+        offs = (np.cumsum(cnts) - cnts).astype(np.int64)
+        pts = rng.randint(0, 40000, (int(cnts.sum()), 2)).astype(pdt)
+        tab = np.zeros((n, 16), np.int64)
+        tab[:, 0] = rng.randint(0, 300, n)
+        tab[:, 1], tab[:, 2] = rng.randint(0, 10 ** 7, n), rng.randint(0, 10 ** 7, n)
+        tab[:, 3:7] = rng.randint(0, 40000, (n, 4))
+        tab[:, 8:16] = rng.randint(0, 50, (n, 8)) * (rng.rand(n, 8) > 0.5)
+        return (name, tab, cnts, pts, offs, has_type, ds)
+
+    parts = [part("Nuclei", 30000, True, 1.0, np.int64), part("Gland", 400, False, 2.0, np.int32), part("Lumen", 0, False, 1.0, np.int64)]
+    meta = OrderedDict([("proc_resolution", {"resolution": 0.5, "units": "mpp"}), ("proc_dimensions", np.array([40000, 40000]))])
+    extra = OrderedDict([("Tissue", OrderedDict([("r0", {"box": np.arange(4), "poly": [1, 2.5, "x", None, True, (3, 4)], "big": 2 ** 40})]))])
+    fast_path, slow_path = str(tmp_path / "fast.dat"), str(tmp_path / "slow.dat")
+    t0 = time.perf_counter()
+    ii.write_dat_fast(parts, meta, fast_path, extra)
+    t_fast = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    slow = ii.build_from_parts(parts, OrderedDict())
+    for k, v in extra.items():
+        slow[k] = v
+    slow.update(meta)
+    ii.write_dat(slow, slow_path)
+    t_slow = time.perf_counter() - t0
+    with open(fast_path, "rb") as fh:
+        raw = fh.read()
+    fast = pickle.loads(raw)
+    _same_object(slow, fast)
+    _same_object(slow, joblib.load(fast_path))
+    assert list(fast.keys()) == ["Nuclei", "Gland", "Lumen", "Tissue", "proc_resolution", "proc_dimensions"] and len(fast["Lumen"]) == 0
+    keys = list(fast["Nuclei"].keys())
+    assert len(set(keys)) == len(keys) > 20000 and all(uuid.UUID(hex=k).version == 4 for k in keys[:100])
+    assert b"numpy.core.multiarray" in raw and b"numpy._core" not in raw
+    assert type(fast["Nuclei"][keys[0]]["type"]) is int and type(fast["Nuclei"][keys[0]]["type_prob"]) is float
+    assert t_fast < t_slow, (t_fast, t_slow)  # ~10x here; the point of the exercise
