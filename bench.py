@@ -32,7 +32,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 BATCH, TILE = 32, 256
-WSI_BATCH = int(os.environ.get("CERB_WSI_BATCH", "96"))  # tiles per forward of the slide job (32: 130.3, 64: 131.1, 96: 134.6 Mpx/s on the 20000^2 slide)
+WSI_BATCH = int(os.environ.get("CERB_WSI_BATCH", "0"))  # tiles per forward of the slide job; 0 = 64 with two streams (152.4 Mpx/s; 96: 151.9, 48: 150.6), 96 with one (149.9)
 MARGIN = 1024  # halo rows exchanged between neighbouring bands (full resolution): above the tallest gland cluster of the structured maps
 MARGINS = {"Nuclei": 128, "Gland": MARGIN, "Lumen": 512}  # per tissue: nuclei are < 30 px (the reference's own tile margin is 64)
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
@@ -415,9 +415,11 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
         free = float(t.item())
     side = args.slide
     if side <= 0:  # 40000^2 needs ~130 GB on one GPU (slide, 36 B/px canvases, structured maps, labels, banded workspace)
-        side = 40000 if free > (140e9 if world == 1 else 270e9 / world + 8e9) else 20000
+        side = 40000 if free > (140e9 if world == 1 else 270e9 / world + 8e9) + (42e9 if args.streams == 2 else 0.0) else 20000  # (a twin handle's workspace at batch 64: ~40 GB)
     H = W = side
     K = args.steps
+    global WSI_BATCH
+    WSI_BATCH = WSI_BATCH or (64 if args.streams == 2 else 96)
     check_shardable((H, W), TILE, world)
     run = WSIRunner(model, (H, W), TILE, TILE, WSI_BATCH, rank, world)
     y0, y1 = run.slab_rows()
@@ -438,6 +440,18 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
     _workspace(dev, side_ws, side_ws)  # the labelling workspace of the largest call, allocated outside the timed region
     for t in ("Nuclei", "Gland", "Lumen"):
         postproc_device(struct[t + "-INST"][:512, :512], t, exact_ties=False)
+    if args.streams == 2:
+        # the second handle (NetDesc.twin) only when its workspace (~0.65 GB per tile of the batch) fits beside everything allocated so far AND what the
+        # tail / dat / ref_tiling legs still take; otherwise the job runs on one handle and says so in config.streams
+        torch.cuda.synchronize()
+        need = 0.7e9 * WSI_BATCH + 0.04e9 * (valid * W / 1e6) * 1e0 + 8e9
+        if torch.cuda.mem_get_info(dev)[0] > need:
+            run.twin = model.twin()
+            for k in range(min(max(args.warmup, 1), K)):
+                run.infer_patches(slab, y0, cuts[k], min(cuts[k] + 2 * WSI_BATCH, cuts[k + 1]))
+            torch.cuda.synchronize()
+        else:
+            args.streams = 1
     if dist is not None:  # first RCCL send/recv + gather open their channels outside the timed region
         x = torch.zeros(1024, device=dev)
         lst = [torch.zeros_like(x) for _ in range(world)] if rank == 0 else None
@@ -596,7 +610,7 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
                         "stitch on rank 0; a step = 1/%d of every rank's band, the tail is inside the timed region" % (H, W, 3 if side >= 40000 else 2, n_tiles, K),
             "slide": [H, W],
             "tiles": n_tiles,
-            "batch_tiles": WSI_BATCH,
+            "batch_tiles": WSI_BATCH, "streams": args.streams,
             "inference_s": round(phase["inference_s"], 3),
             "inference_Mpx_s": round(px / phase["inference_s"] / 1e6, 3),
             "postproc_and_stitch_s": round(phase["tail_s"], 3),
@@ -659,6 +673,8 @@ def main():
                     help="initialise the process group and take the collective code path even at world size 1 (RCCL accepts one rank): "
                          "the nccl test of tests/test_cli_gpu.py")
     ap.add_argument("--planar", type=int, default=1, help="last decoder level in the tile-planar layout (1, default: conv_wino4p.hip) or NHWC (0: conv_wino4.hip, round 2's path) -- A/B")
+    ap.add_argument("--streams", type=int, default=2, choices=[1, 2], help="slide job: 2 (default) = batches alternate between two handles on two streams "
+                                                                               "(NetDesc.twin: the ramps / tails / sub-chip launches of one batch overlap the other's), 1 = one handle")
     ap.add_argument("--backend", default="nccl", help='torch.distributed backend ("nccl" = RCCL over xGMI; "gloo" only for plumbing tests)')
     ap.add_argument("--oversubscribe", action="store_true",
                     help="with --backend gloo only: let the N self-spawned ranks time-share fewer than N devices (plumbing tests on a one-GPU box); "

@@ -129,6 +129,9 @@ struct DevBuf {
         release();
         if (hipMalloc(&raw, need + 2 * g) != hipSuccess) return 1;
         if (hipMemset(raw, 0, need + 2 * g) != hipSuccess) return 1;
+        // hipMemset runs on the NULL stream and may return before it is done; a caller on a non-blocking stream (two handles on two side streams,
+        // cerberus_amd/wsi.py) is not ordered against that stream at all -- its first kernels raced this fill.  Allocation is rare: wait here.
+        if (hipDeviceSynchronize() != hipSuccess) return 1;
         p = reinterpret_cast<float*>(raw + g);
         bytes = need;
         guard = g;

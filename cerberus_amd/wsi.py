@@ -167,8 +167,11 @@ class WSIRunner(object):
     """One per process / GPU.  (Single-process simulations of more ranks than patch rows get empty bands; distributed drivers call
     check_shardable first.)"""
 
-    def __init__(self, net, slide_hw, patch_input_shape=256, patch_output_shape=256, batch_size=32, rank=0, world_size=1, patch_sel=None):
+    def __init__(self, net, slide_hw, patch_input_shape=256, patch_output_shape=256, batch_size=32, rank=0, world_size=1, patch_sel=None, twin=None):
+        """twin: a second handle with the same parameters (NetDesc.twin()); batches then alternate between the two on two side streams."""
         self.net = net
+        self.twin = twin
+        self._side = None
         self.geo = SlideGeometry(slide_hw, patch_input_shape, patch_output_shape, patch_sel)
         self.batch = int(batch_size)
         self.rank, self.world = int(rank), int(world_size)
@@ -212,12 +215,34 @@ class WSIRunner(object):
         assert slab.shape[1] == g.W
         p0, p1 = max(0, int(p0)), min(self.n_patches, int(p1))
         tl_y_host = self._tl_y.cpu().numpy() if ready is not None else None
-        for b0 in range(p0, p1, self.batch):
+
+        def one(net, b0):
             b1 = min(p1, b0 + self.batch)
             if ready is not None:  # mirror padding only ever folds back to rows above the window's last in-slide row
                 ready(min(int(tl_y_host[b0:b1].max()) + g.win, g.H) - slab_y0)
             tiles = gather_patches(slab, slab_y0, g.H, self._tl_y[b0:b1], self._tl_x[b0:b1], g.win)
-            self.net._run(tiles, g.out, g.out, self._outs, None, tile_off=self._off[b0:b1], row_stride=self.canvas_w, type_is_u8=True)
+            net._run(tiles, g.out, g.out, self._outs, None, tile_off=self._off[b0:b1], row_stride=self.canvas_w, type_is_u8=True)
+
+        if self.twin is None or p1 - p0 <= self.batch:
+            for b0 in range(p0, p1, self.batch):
+                one(self.net, b0)
+            return p1 - p0
+        # two handles, two side streams: everything queued on the caller's stream so far happens before, everything after waits for both
+        if self._side is None:
+            self._side = [torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)]
+        cur = torch.cuda.current_stream(self.dev)
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        nets = (self.net, self.twin)
+        for s in self._side:
+            s.wait_event(fork)
+        for i, b0 in enumerate(range(p0, p1, self.batch)):
+            with torch.cuda.stream(self._side[i & 1]):
+                one(nets[i & 1], b0)
+        for s in self._side:
+            join = torch.cuda.Event()
+            join.record(s)
+            cur.wait_event(join)
         return p1 - p0
 
     def gather_to_root(self, dist=None):

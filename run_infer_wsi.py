@@ -114,6 +114,8 @@ def main(argv=None):
             settings = yaml.full_load(fh)
         decoders, model_args = settings["dataset_kwargs"]["req_target_code"], settings["model_kwargs"]
     manager = InferManager(checkpoint_path=checkpoint, decoder_dict=decoders, model_args=model_args)
+    # a second handle with the same weights: WSIRunner alternates batches between the two on two streams (+2 .. 3 %; CERB_WSI_STREAMS=1: one handle)
+    twin = manager.net.twin() if os.environ.get("CERB_WSI_STREAMS", "2") == "2" else None
 
     ext = args["--wsi_file_ext"]
     slides = sorted(glob.glob(os.path.join(args["--input_dir"], "*" + ext))) if args["--input_dir"] else []
@@ -158,7 +160,7 @@ def main(argv=None):
                 os.makedirs(os.path.join(out_dir, "mask"), exist_ok=True)
                 Image.fromarray(mask * 255).save(os.path.join(out_dir, "mask", base + ".png"))
         check_shardable((H, W), out, world)
-        run = WSIRunner(manager.net, (H, W), win, out, batch, rank, world, patch_sel=sel)
+        run = WSIRunner(manager.net, (H, W), win, out, batch, rank, world, patch_sel=sel, twin=twin)
         y0, y1 = run.slab_rows()  # this rank's band + context halo
         t_prep = time.perf_counter()
         if log:

@@ -91,6 +91,31 @@ def test_wsi_runner_equals_tile_manager_and_sharding(manager, win, out):
     assert np.array_equal(inst["Gland"].cpu().numpy(), pr.proc(np.ascontiguousarray(ds.astype(np.float32)), "Gland", 0.5).astype(np.int32))
 
 
+def test_wsi_runner_two_handles_on_two_streams_is_bitwise_the_one_handle_run(manager):
+    """WSIRunner(twin=NetDesc.twin()): batches alternate between two handles on two side streams (bench.py --streams 2, run_infer_wsi.py).  Same
+    kernels, same patches, disjoint canvas tiles: every canvas is bit-identical to the one-handle run, with work queued on the caller's stream
+    before (the slab) and after (a reduction over the canvases) ordered against the side streams; the twin carries the parent's switches."""
+    H, W = 1100, 1300
+    one = WSIRunner(manager.net, (H, W), 256, 256, batch_size=3)
+    slide = synth_slide(H, W, seed=11)
+    one.infer_band(slide, 0)
+    want = {k: v.clone() for k, v in one.canv.items()}
+    manager.net.set_planar(1)
+    twin = manager.net.twin()
+    assert twin is not manager.net and twin._switches["set_planar"] == 1 and twin.handle_value() != manager.net.handle_value()
+    two = WSIRunner(manager.net, (H, W), 256, 256, batch_size=3, twin=twin)
+    for rep in range(3):  # repeated: stream-ordering mistakes are timing dependent
+        for v in two.canv.values():
+            v.zero_()
+        slide2 = synth_slide(H, W, seed=11)  # produced on the caller's stream right before the fork
+        n = two.infer_band(slide2, 0)
+        sums = {k: v.double().sum().item() for k, v in two.canv.items()}  # consumed on the caller's stream right after the join
+        assert n == two.n_patches == 5 * 6
+        for k, v in two.canv.items():
+            assert torch.equal(v, want[k]), (rep, k)
+            assert sums[k] == want[k].double().sum().item(), (rep, k)
+
+
 def test_band_postprocess_and_gather_single_rank_equals_root_path(manager):
     """postprocess_bands_and_gather (the multi-GPU tail of run_infer_wsi.py) at world 1: same instances as the root-side
     WSIRunner.postprocess on a slide whose size is not a multiple of the patch (canvas rows / columns beyond the slide are cropped)."""
