@@ -71,6 +71,9 @@ hipError_t cerb_launch_pack_wino4(const float* w_raw, float* out, int cout, int 
 hipError_t cerb_launch_dilate2(const float* dy, float* d, long long n, int H, int W, int C, hipStream_t st);
 size_t cerb_pw_wgrad_small_workspace_bytes(long long rows, int cin, int cout);
 hipError_t cerb_launch_pw_wgrad_small(const float* x, const float* dy, float* dw, long long rows, int cin, int cout, void* ws, hipStream_t st);
+size_t cerb_pw_bwd_small_workspace_bytes(long long rows, int cin, int cout);
+hipError_t cerb_launch_pw_bwd_small(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long long rows, int cin, int cout,
+                                    int dx_assign, void* ws, hipStream_t st);
 hipError_t cerb_launch_stem_wgrad_mfma(const unsigned char* tiles, const float* dy, float* dw, int N, int H, int W, void* ws, hipStream_t st);
 hipError_t cerb_launch_colsum(const float* d, long long group_stride, long long rows, int C, int G, float* out, void* ws, hipStream_t st);
 hipError_t cerb_launch_wgrad(const float* x, const float* dy, float* dw, int G, int N, int H, int W, int Cin, int Cout, int ks, int stride, long long x_gs, void* ws,
@@ -251,6 +254,7 @@ struct cerb_net {
     struct ProfRec { std::string name, kernel; double flops; hipEvent_t e0, e1; };
     std::vector<ProfRec> prof;
     size_t prof_n = 0;
+    bool prof_open = false;  // a record is open (prof_begin without its prof_end yet)
     ~cerb_net() {
         for (auto& r : prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         for (void* p : dev_allocs) (void)hipFree(p);
@@ -771,12 +775,14 @@ static int prof_begin(cerb_net* net, const std::string& name, const std::string&
     cerb_net::ProfRec& r = net->prof[net->prof_n];
     r.name = name; r.kernel = kernel; r.flops = flops;
     HIP_OK(hipEventRecord(r.e0, st));
+    net->prof_open = true;
     return 0;
 }
 static int prof_end(cerb_net* net, hipStream_t st) {
     if (!net->profiling) return 0;
     HIP_OK(hipEventRecord(net->prof[net->prof_n].e1, st));
     net->prof_n++;
+    net->prof_open = false;
     return 0;
 }
 
@@ -1342,7 +1348,12 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         if (net->tape_pos == net->tape.size()) net->tape.emplace_back();
         DevBuf& b = net->tape[net->tape_pos++];
         if (b.ensure(nfloat * 4, guard)) return nullptr;
-        if (zero && hipMemsetAsync(b.p, 0, nfloat * 4, st) != hipSuccess) return nullptr;
+        if (zero) {  // its own profile record unless a family's record is open (then the fill is that family's)
+            const bool own = net->profiling && !net->prof_open;
+            if (own && prof_begin(net, "zero_fill", "zero_fill", nfloat * 4.0, st)) return nullptr;
+            if (hipMemsetAsync(b.p, 0, nfloat * 4, st) != hipSuccess) return nullptr;
+            if (own && prof_end(net, st)) return nullptr;
+        }
         return b.p;
     };
     auto newT = [&](size_t nfloat) {
@@ -1351,8 +1362,20 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         cnt.push_back(nfloat);
         return (int)val.size() - 1;
     };
+    // A grouped tensor whose gradient arrives slice by slice (the decoders' last maps: one 1x1 head per group reads its own slice): the buffer is
+    // made WITHOUT a zero fill, the first writer of a slice assigns, and the slices nobody wrote (decoders without a target) are zeroed just
+    // before the tensor's producer reads the gradient -- instead of 4 GB of fill plus a read-modify-write per slice.
+    std::map<int, unsigned long long> slice_written;  // tensor -> bit k = slice k holds a gradient
+    std::map<int, std::pair<int, size_t>> slice_geom;    // tensor -> (slices, floats per slice)
     auto G_ = [&](int t) -> float* {  // gradient buffer of tensor t, created zeroed on first use
         if (!grd[t]) grd[t] = take(cnt[t], true);
+        auto sw = slice_written.find(t);
+        if (sw != slice_written.end()) {  // a whole-tensor writer arrives while slices are still unwritten: they must read as zero from here on
+            const std::pair<int, size_t> ge = slice_geom[t];
+            for (int k = 0; k < ge.first; ++k)
+                if (!((sw->second >> k) & 1ull) && hipMemsetAsync(grd[t] + (size_t)k * ge.second, 0, ge.second * 4, st) != hipSuccess) return nullptr;
+            slice_written.erase(sw);
+        }
         return grd[t];
     };
     std::vector<TapeOp> tape;
@@ -1403,12 +1426,16 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         return z;
     };
 #define TCHK(x) do { if ((x) < 0) { net->conv_algo = saved_algo; return fail(std::string("cerb_net_train_grads: ") + #x + " failed"); } } while (0)
+// one per-launch profile record (cerb_net_profile_*) around a launch of the families that run_conv / bn / wgrad do not cover themselves, so that a
+// profiled step attributes ALL of its device time; `work` = FLOPs of a matrix-core family, algorithmic bytes of an HBM-bound one
+#define PROF(nm, kern, work, stmt) do { if (prof_begin(net, (nm), (kern), (work), st)) return 1; stmt; if (prof_end(net, st)) return 1; } while (0)
+#define PROFN(nm, kern, work, stmt) do { if (prof_begin(net, (nm), (kern), (work), st)) return -1; stmt; if (prof_end(net, st)) return -1; } while (0)
     const int t_stem = newT((size_t)N * H * W * 64);
     {
         StemParams sp;
         sp.tiles = io->tiles; sp.tiles_f32 = nullptr; sp.wpack = net->stem_w; sp.bias = net->stem_b; sp.out = val[t_stem]; sp.N = N; sp.H = H; sp.W = W; sp.relu = 0;
         sp.tiles_x = sp.tiles_y = 0;
-        HIP_OK(cerb_launch_stem(sp, st));
+        PROF("stem", "stem_conv7x7", 2.0 * N * H * W * 64.0 * 147.0, HIP_OK(cerb_launch_stem(sp, st)));
         TapeOp op;
         op.type = 0; op.o = t_stem; op.N = N; op.H = H; op.W = W;
         tape.push_back(op);
@@ -1416,7 +1443,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
     const int x0 = bn("stem", t_stem, -1, (long long)N * H * W, 1);
     TCHK(x0);
     const int pool = newT((size_t)N * hs[1] * ws[1] * 64);
-    HIP_OK(cerb_launch_maxpool(val[x0], val[pool], N, H, W, 64, st));
+    PROF("maxpool", "maxpool3x3s2", (double)N * H * W * 64 * 4.0 * 1.25, HIP_OK(cerb_launch_maxpool(val[x0], val[pool], N, H, W, 64, st)));
     {
         TapeOp op;
         op.type = 3; op.a = x0; op.o = pool; op.N = N; op.H = H; op.W = W; op.Cout = 64;
@@ -1469,7 +1496,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
             py_slice(ws[4], x0c, cw);
         }
         const int gap = newT((size_t)N * 512);
-        HIP_OK(cerb_launch_crop_gap(val[xs[4]], N, hs[4], ws[4], 512, y0, ch, x0c, cw, val[gap], st));
+        PROF("pc.crop_gap", "crop_gap", (double)N * ch * cw * 512 * 4.0, HIP_OK(cerb_launch_crop_gap(val[xs[4]], N, hs[4], ws[4], 512, y0, ch, x0c, cw, val[gap], st)));
         {
             TapeOp op;
             op.type = 6; op.a = xs[4]; op.o = gap; op.N = N; op.H = hs[4]; op.W = ws[4]; op.Cout = 512; op.y0 = y0; op.ch = ch; op.x0 = x0c; op.cw = cw;
@@ -1479,7 +1506,8 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         TCHK(g1);
         auto pw = [&](int a, const float* w, const float* bias, long long rows, int cin, int cout, const float* scale, const std::string& wk, const std::string& bk) {
             const int o = newT((size_t)rows * cout);
-            if (!val[o] || cerb_launch_pointwise(val[a], w, bias, val[o], rows, cin, cout, scale, st) != hipSuccess) return -1;
+            if (!val[o]) return -1;
+            PROFN(wk, "pointwise_fwd", 2.0 * rows * cin * cout, if (cerb_launch_pointwise(val[a], w, bias, val[o], rows, cin, cout, scale, st) != hipSuccess) return -1);
             TapeOp op;
             op.type = 5; op.a = a; op.o = o; op.rows = rows; op.Cin = cin; op.Cout = cout; op.w = w; op.bias = bias; op.scale = scale; op.wkey = wk; op.bkey = bk;
             tape.push_back(op);
@@ -1504,7 +1532,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
             const int cin0 = net->conv[n0].cin;
             const long long rows = (long long)N * hh * ww;
             const int dsum = newT((size_t)D * rows * cin0);
-            HIP_OK(cerb_launch_upsample2_add(val[skips[u]], val[prev], val[dsum], (int)D, N, hh, ww, cin0, prev_gs, nullptr, st));
+            PROF(n0 + ".up", "upsample2_add", (double)rows * cin0 * 4.0 * (1.0 + D * 1.25), HIP_OK(cerb_launch_upsample2_add(val[skips[u]], val[prev], val[dsum], (int)D, N, hh, ww, cin0, prev_gs, nullptr, st)));
             {
                 TapeOp op;
                 op.type = 4; op.a = skips[u]; op.b = prev; op.o = dsum; op.N = N; op.H = hh; op.W = ww; op.Cout = cin0; op.G = (int)D; op.b_gs = prev_gs;
@@ -1527,7 +1555,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
             const std::string p = "output_head." + d.name + "." + d.head + ".x";
             // the head reads decoder k's slice of the grouped tensor: a view (tensor id with its own grad slice) is the slice itself
             const int hid = newT((size_t)rows * 96);
-            HIP_OK(cerb_launch_pointwise(val[prev] + k * (size_t)rows * 64, net->head_rw1[k], net->head_rb1[k], val[hid], rows, 64, 96, nullptr, st));
+            PROF(p + ".0", "pointwise_fwd", 2.0 * rows * 64 * 96, HIP_OK(cerb_launch_pointwise(val[prev] + k * (size_t)rows * 64, net->head_rw1[k], net->head_rb1[k], val[hid], rows, 64, 96, nullptr, st)));
             {
                 TapeOp op;
                 op.type = 5; op.a = prev; op.o = hid; op.rows = rows; op.Cin = 64; op.Cout = 96; op.w = net->head_rw1[k]; op.bias = net->head_rb1[k];
@@ -1538,7 +1566,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
             const int hz = bn("head." + std::to_string(k), hid, -1, rows, 1);
             TCHK(hz);
             const int lg = newT((size_t)rows * d.out_ch);
-            HIP_OK(cerb_launch_pointwise(val[hz], net->head_rw2[k], net->head_rb2[k], val[lg], rows, 96, d.out_ch, nullptr, st));
+            PROF(p + ".1", "pointwise_fwd", 2.0 * rows * 96 * d.out_ch, HIP_OK(cerb_launch_pointwise(val[hz], net->head_rw2[k], net->head_rb2[k], val[lg], rows, 96, d.out_ch, nullptr, st)));
             {
                 TapeOp op;
                 op.type = 5; op.a = hz; op.o = lg; op.rows = rows; op.Cin = 96; op.Cout = d.out_ch; op.w = net->head_rw2[k]; op.bias = net->head_rb2[k];
@@ -1557,21 +1585,32 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         const int hh = pc ? 1 : H, ww = pc ? 1 : W, C = d.out_ch;
         if (net->t_hid.ensure(cerb_head_loss_workspace_bytes(N, hh, ww), 0)) return fail("workspace allocation failed");
         // NHWC logits: strides (n, c, y, x) = (h w C, 1, w C, C)
-        if (cerb_head_loss_wmap(val[lg], (long long)hh * ww * C, 1, (long long)ww * C, C, io->target[di], io->has_target[di], N, hh, ww, C,
-                           io->class_weight ? io->class_weight[di] : nullptr, io->pixel_weight ? io->pixel_weight[di] : nullptr, io->ce_w[di], io->dice_w[di], io->head_w[di], pc ? 1 : 0, io->loss_out + di, G_(lg),
-                           net->t_hid.p, cerb_head_loss_workspace_bytes(N, hh, ww), st))
-            return 1;
-        if (io->logits && io->logits[di]) HIP_OK(hipMemcpyAsync(io->logits[di], val[lg], cnt[lg] * 4, hipMemcpyDeviceToDevice, st));
+        float* glg = G_(lg);
+        PROF("loss." + d.name, "head_loss", (double)N * hh * ww * (C * 8.0 + 8.0),
+             if (cerb_head_loss_wmap(val[lg], (long long)hh * ww * C, 1, (long long)ww * C, C, io->target[di], io->has_target[di], N, hh, ww, C,
+                                     io->class_weight ? io->class_weight[di] : nullptr, io->pixel_weight ? io->pixel_weight[di] : nullptr, io->ce_w[di], io->dice_w[di],
+                                     io->head_w[di], pc ? 1 : 0, io->loss_out + di, glg, net->t_hid.p, cerb_head_loss_workspace_bytes(N, hh, ww), st)) return 1;
+             if (io->logits && io->logits[di]) HIP_OK(hipMemcpyAsync(io->logits[di], val[lg], cnt[lg] * 4, hipMemcpyDeviceToDevice, st)));
     }
     // ---------------------------------------------------------------- backward ------------------------------------------------------
     for (int i = (int)tape.size() - 1; i >= 0; --i) {
         const TapeOp& op = tape[i];
         if (!grd[op.o]) continue;  // nothing flowed into this output (a head without target)
         float* go = grd[op.o];
+        {
+            auto sw = slice_written.find(op.o);
+            if (sw != slice_written.end()) {  // the slices no head wrote read as zero
+                const std::pair<int, size_t> ge = slice_geom[op.o];
+                for (int k = 0; k < ge.first; ++k)
+                    if (!((sw->second >> k) & 1ull)) HIP_OK(hipMemsetAsync(go + (size_t)k * ge.second, 0, ge.second * 4, st));
+                slice_written.erase(sw);
+            }
+        }
         switch (op.type) {
             case 0: {  // stem: weight gradient only
                 if (net->t_ws.ensure(cerb_stem_wgrad_workspace_bytes(), 0)) return fail("workspace allocation failed");
-                HIP_OK(cerb_launch_stem_wgrad_mfma(io->tiles, go, pub("backbone.conv1.weight", 64 * 147), N, H, W, net->t_ws.p, st));
+                float* dws = pub("backbone.conv1.weight", 64 * 147);
+                PROF("stem.wgrad", "stem_wgrad", 2.0 * N * H * W * 64.0 * 147.0, HIP_OK(cerb_launch_stem_wgrad_mfma(io->tiles, go, dws, N, H, W, net->t_ws.p, st)));
                 break;
             }
             case 1: {
@@ -1592,6 +1631,13 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     const bool fresh = !grd[op.a] && cnt[op.a] == (size_t)op.G * in_n && (op.G == 1 || op.a_gs == in_n);  // first writer: no residual, no zero fill
                     if (fresh && !(grd[op.a] = take(cnt[op.a], false))) return fail("workspace allocation failed");
                     float* dx = G_(op.a);
+                    const long long map_px = (long long)op.H * op.W;
+                    const bool d_w4 = saved_algo == 5 || saved_algo == 7 || (saved_algo == 6 && map_px >= 256);
+                    const bool d_w4b = (saved_algo == 7 || (saved_algo == 6 && map_px <= 4096)) && op.Cout % 64 == 0;
+                    const bool d_f4 = d_w4 && op.Cout % 16 == 0 && op.Cin % 64 == 0;
+                    // the data gradient as its own family: the forward Winograd kernels on rotated weights (+ the stride-2 dilation pass)
+                    if (prof_begin(net, op.name + ".dgrad", std::string("dgrad:") + (d_f4 ? (d_w4b ? "conv_wino4b<f4x4,16x16>" : "conv_wino4<f4x4,16x16x2>") : "conv_wino<f2x2,8x16>"),
+                                   2.0 * op.G * op.N * op.H * op.W * (double)op.Cin * op.Cout * 9.0, st)) return 1;
                     if (op.stride == 2) {  // y = 2 yo - 1 + ky  <=>  dx = conv_s1(D, W'), D[2 yo][2 xo] = dy[yo][xo], zero elsewhere
                         const long long dn = (long long)op.G * op.N * op.H * op.W * op.Cout;
                         if (net->t_dil.ensure((size_t)dn * 4, cerb_conv_guard_bytes(W))) return fail("workspace allocation failed");
@@ -1609,10 +1655,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     p.out_gs = op.a_gs;
                     if (op.G == 1) p.resid_gs = p.out_gs = 0;
                     // the same per-geometry choice as the forward convolutions (run_conv): F(4x4,3x3) for maps of 16 x 16 and more
-                    const long long map_px = (long long)op.H * op.W;
-                    const bool d_w4 = saved_algo == 5 || saved_algo == 7 || (saved_algo == 6 && map_px >= 256);
-                    const bool d_w4b = (saved_algo == 7 || (saved_algo == 6 && map_px <= 4096)) && op.Cout % 64 == 0;
-                    if (d_w4 && op.Cout % 16 == 0 && op.Cin % 64 == 0) {
+                    if (d_f4) {
                         float* w4 = nullptr;
                         if (train_wino4_slot(net, op.name, net->conv[op.name], d_w4b ? 1 : 0, 1, st, &w4)) return 1;
                         p.wpack = w4;
@@ -1622,6 +1665,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                         if (train_wino2_fresh(net, op.name, net->conv[op.name], 1, st)) return 1;
                         HIP_OK(cerb_launch_wino(p, st));
                     }
+                    if (prof_end(net, st)) return 1;
                     dx_done = true;
                     go = grd[op.o];
                 }
@@ -1639,10 +1683,13 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 if (db) {
                     const long long orow = (long long)op.N * (op.stride == 2 ? op.H / 2 : op.H) * (op.stride == 2 ? op.W / 2 : op.W);
                     if (net->t_ws.ensure((size_t)op.G * 2048 * op.Cout * 4 + 256, 0)) return fail("workspace allocation failed");
-                    HIP_OK(cerb_launch_colsum(go, orow * op.Cout, orow, op.Cout, op.G, db, net->t_ws.p, st));
+                    PROF(op.name + ".dbias", "bias_colsum", (double)op.G * orow * op.Cout * 4.0, HIP_OK(cerb_launch_colsum(go, orow * op.Cout, orow, op.Cout, op.G, db, net->t_ws.p, st)));
                 }
-                HIP_OK(cerb_launch_conv_bwd(val[op.a], go, r.w, dx_done ? nullptr : G_(op.a), dw_done ? nullptr : dw, nullptr, op.G, op.N, op.H, op.W, op.Cin, op.Cout,
-                                            op.ks, op.stride, op.a_gs, st));
+                if (!dx_done || !dw_done) {
+                    float* dxg = dx_done ? nullptr : G_(op.a);
+                    PROF(op.name + ".bwd", "conv_bwd_direct", 2.0 * op.G * op.N * op.H * op.W * (double)op.Cin * op.Cout * op.ks * op.ks / (op.stride * op.stride) * ((dx_done ? 0 : 1) + (dw_done ? 0 : 1)),
+                         HIP_OK(cerb_launch_conv_bwd(val[op.a], go, r.w, dxg, dw_done ? nullptr : dw, nullptr, op.G, op.N, op.H, op.W, op.Cin, op.Cout, op.ks, op.stride, op.a_gs, st)));
+                }
                 for (int g = 0; g < op.G; ++g) {
                     net->grads[r.wkeys[g]] = std::make_pair(dw + g * wn, (long long)wn);
                     if (db) net->grads[r.bkeys[g]] = std::make_pair(db + (size_t)g * op.Cout, (long long)op.Cout);
@@ -1677,19 +1724,24 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 }
                 break;
             }
-            case 3:
-                HIP_OK(cerb_launch_maxpool_bwd(val[op.a], val[op.o], go, G_(op.a), op.N, op.H, op.W, op.Cout, st));
+            case 3: {
+                float* dxp = G_(op.a);
+                PROF("maxpool.bwd", "maxpool_bwd", (double)op.N * op.H * op.W * op.Cout * 4.0 * 2.5, HIP_OK(cerb_launch_maxpool_bwd(val[op.a], val[op.o], go, dxp, op.N, op.H, op.W, op.Cout, st)));
                 break;
+            }
             case 4: {
                 // The reference runs a decoder that is not in train_decoder_list under torch.set_grad_enabled(False) (models/net_desc.py:182), but
                 // its conv layers switch autograd back on inside themselves (models/utils/conv_layers.py:44-53): gradients then live only
                 // INSIDE each block and stop at the skip + upsample sum.  With train_step's substring test (run_desc.py:70-74) that is the
                 // fate of the "#TYPE" decoders ("Gland#TYPE" is not a substring of "Gland-TYPE"): cut their slices here.
                 const long long per_group = (long long)op.N * op.H * op.W * op.Cout;
-                if (io->decoder_trained)
-                    for (int k = 0; k < op.G; ++k)
-                        if (!io->decoder_trained[net->dense_idx[k]]) HIP_OK(hipMemsetAsync(go + k * per_group, 0, per_group * 4, st));
-                HIP_OK(cerb_launch_upadd_bwd(go, G_(op.a), G_(op.b), op.G, op.N, op.H, op.W, op.Cout, op.b_gs, op.b_gs == 0 ? 1 : 0, st));
+                float* ga = G_(op.a);
+                float* gb = G_(op.b);
+                PROF("upadd.bwd", "upadd_bwd", (double)op.G * per_group * 4.0 * 2.5,
+                     if (io->decoder_trained)
+                         for (int k = 0; k < op.G; ++k)
+                             if (!io->decoder_trained[net->dense_idx[k]]) HIP_OK(hipMemsetAsync(go + k * per_group, 0, per_group * 4, st));
+                     HIP_OK(cerb_launch_upadd_bwd(go, ga, gb, op.G, op.N, op.H, op.W, op.Cout, op.b_gs, op.b_gs == 0 ? 1 : 0, st)));
                 break;
             }
             case 5: {
@@ -1697,12 +1749,23 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 float* db = pub(op.bkey, (size_t)op.Cout);
                 if (!dw || !db) return fail("workspace allocation failed");
                 bool pw_dw = false;
+                if (prof_begin(net, op.wkey + ".bwd", "pointwise_bwd", 4.0 * op.rows * (double)op.Cin * op.Cout, st)) return 1;  // weight + data gradient + bias sums
                 if (op.Cin % 4 == 0 && op.Cout % 4 == 0 && !op.scale && op.rows >= 4096 && op.rows < (1ll << 31) && net->conv_algo) {
                     if (net->t_ws.ensure(cerb_wgrad_workspace_bytes(1, 1, 1, (int)op.rows, op.Cin, op.Cout, 1, nullptr), 0)) return fail("workspace allocation failed");
                     HIP_OK(cerb_launch_wgrad(val[op.a] + op.a_gs, go, dw, 1, 1, 1, (int)op.rows, op.Cin, op.Cout, 1, 1, 0, net->t_ws.p, st));
                     pw_dw = true;
                 }
-                if (!pw_dw && op.Cout <= 8 && !op.scale && op.rows >= 4096) {  // the heads' 96 -> 3 / 7
+                if (!pw_dw && op.Cout <= 8 && !op.scale && op.rows >= 4096 && net->conv_algo) {
+                    // the heads' 96 -> 3 / 7: weight gradient, bias sums and data gradient in one pass over the rows (cerb_launch_pw_bwd_small)
+                    const bool fresh1 = !grd[op.a] && op.a_gs == 0 && cnt[op.a] == (size_t)op.rows * op.Cin;
+                    if (fresh1 && !(grd[op.a] = take(cnt[op.a], false))) return fail("workspace allocation failed");
+                    float* dxs = G_(op.a) + op.a_gs;
+                    if (net->t_ws.ensure(cerb_pw_bwd_small_workspace_bytes(op.rows, op.Cin, op.Cout), 0)) return fail("workspace allocation failed");
+                    HIP_OK(cerb_launch_pw_bwd_small(val[op.a] + op.a_gs, go, op.w, dxs, dw, db, op.rows, op.Cin, op.Cout, fresh1 ? 1 : 0, net->t_ws.p, st));
+                    if (prof_end(net, st)) return 1;
+                    break;
+                }
+                if (!pw_dw && op.Cout <= 8 && !op.scale && op.rows >= 4096) {  // (conv_algo 0: the separate passes)
                     if (net->t_ws.ensure(cerb_pw_wgrad_small_workspace_bytes(op.rows, op.Cin, op.Cout), 0)) return fail("workspace allocation failed");
                     HIP_OK(cerb_launch_pw_wgrad_small(val[op.a] + op.a_gs, go, dw, op.rows, op.Cin, op.Cout, net->t_ws.p, st));
                     pw_dw = true;
@@ -1710,18 +1773,38 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 if (net->t_ws.ensure((size_t)2048 * op.Cout * 4 + 256, 0)) return fail("workspace allocation failed");
                 HIP_OK(cerb_launch_colsum(go, 0, op.rows, op.Cout, 1, db, net->t_ws.p, st));
                 // a hidden map read by this layer alone gets its gradient assigned (no zero fill, no read-modify-write)
-                const bool fresh = !grd[op.a] && op.a_gs == 0 && cnt[op.a] == (size_t)op.rows * op.Cin;
+                bool fresh = !grd[op.a] && op.a_gs == 0 && cnt[op.a] == (size_t)op.rows * op.Cin;
                 if (fresh && !(grd[op.a] = take(cnt[op.a], false))) return fail("workspace allocation failed");
-                HIP_OK(cerb_launch_pointwise_bwd(val[op.a] + op.a_gs, go, op.w, G_(op.a) + op.a_gs, pw_dw ? nullptr : dw, nullptr, op.rows, op.Cin, op.Cout, op.scale,
+                const size_t slice = (size_t)op.rows * op.Cin;
+                if (!fresh && cnt[op.a] > slice && cnt[op.a] % slice == 0 && cnt[op.a] / slice <= 64 && op.a_gs % (long long)slice == 0 &&
+                    (!grd[op.a] || slice_written.count(op.a))) {  // one slice of a grouped tensor that only such layers have written so far
+                    if (!grd[op.a]) {
+                        if (!(grd[op.a] = take(cnt[op.a], false))) return fail("workspace allocation failed");
+                        slice_written[op.a] = 0ull;
+                        slice_geom[op.a] = std::make_pair((int)(cnt[op.a] / slice), slice);
+                    }
+                    const int k = (int)(op.a_gs / (long long)slice);
+                    if (!((slice_written[op.a] >> k) & 1ull)) {
+                        fresh = true;
+                        slice_written[op.a] |= 1ull << k;
+                    }
+                }
+                float* dxp = (fresh && grd[op.a]) ? grd[op.a] : G_(op.a);  // (a slice's first writer must not trigger G_'s zeroing of the unwritten slices)
+                HIP_OK(cerb_launch_pointwise_bwd(val[op.a] + op.a_gs, go, op.w, dxp + op.a_gs, pw_dw ? nullptr : dw, nullptr, op.rows, op.Cin, op.Cout, op.scale,
                                                  fresh ? 1 : 0, st));
+                if (prof_end(net, st)) return 1;
                 break;
             }
-            case 6:
-                HIP_OK(cerb_launch_crop_gap_bwd(go, G_(op.a), op.N, op.H, op.W, op.Cout, op.y0, op.ch, op.x0, op.cw, st));
+            case 6: {
+                float* dxc = G_(op.a);
+                PROF("pc.crop_gap.bwd", "crop_gap_bwd", (double)op.N * op.H * op.W * op.Cout * 4.0, HIP_OK(cerb_launch_crop_gap_bwd(go, dxc, op.N, op.H, op.W, op.Cout, op.y0, op.ch, op.x0, op.cw, st)));
                 break;
+            }
         }
     }
 #undef TCHK
+#undef PROF
+#undef PROFN
     net->conv_algo = saved_algo;
     return 0;
 }

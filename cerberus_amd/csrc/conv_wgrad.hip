@@ -462,6 +462,7 @@ hipError_t cerb_launch_pw_mfma(const float* a, const float* w, int w_trans, cons
     const unsigned blocks = (unsigned)(ntiles / 4 < 1 ? 1 : (ntiles / 4 > 2048 ? 2048 : ntiles / 4));
     if (K == 64 && NC == 96 && !accumulate) hipLaunchKernelGGL((pw_mfma_kernel<64, 96, false, true>), dim3(blocks), dim3(256), 0, st, a, w, w_trans, bias, out, rows, K, NC);
     else if (K == 96 && NC == 64 && accumulate) hipLaunchKernelGGL((pw_mfma_kernel<96, 64, true, true>), dim3(blocks), dim3(256), 0, st, a, w, w_trans, bias, out, rows, K, NC);
+    else if (K == 96 && NC == 64 && !accumulate) hipLaunchKernelGGL((pw_mfma_kernel<96, 64, false, true>), dim3(blocks), dim3(256), 0, st, a, w, w_trans, bias, out, rows, K, NC);
     else if (K == 96 && NC <= 32 && !accumulate) hipLaunchKernelGGL((pw_mfma_kernel<96, 32, false, false>), dim3(blocks), dim3(256), 0, st, a, w, w_trans, bias, out, rows, K, NC);
     else return hipErrorNotSupported;
     return hipGetLastError();

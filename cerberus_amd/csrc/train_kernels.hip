@@ -903,6 +903,56 @@ __global__ __launch_bounds__(128) void pw_wgrad_small_partial_kernel(const float
         for (int c = 0; c < cout; ++c) part[((long long)blockIdx.x * cout + c) * cin + ci] = acc[c];
     }
 }
+// The whole backward of such a layer in ONE pass over its input (round 4: the per-family table of bench.py --mode train put the pointwise backward at
+// 17 ms of a 180 ms step, 0.16 of any roof -- three passes over the rows for the heads' 96 -> 3 / 7: weight gradient, data gradient, bias sums).
+// thread = input channel: it keeps its weight column (<= 8 values), reads x[r][ci] once, adds dy[r][c] x to its weight-gradient partials and
+// writes dx[r][ci] = sum_c dy[r][c] W[c][ci] (same fmaf order as pointwise_dgrad_kernel: bit-identical); thread 0 also sums dy for the bias.
+__global__ __launch_bounds__(128) void pw_bwd_small_fused_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
+                                                                float* __restrict__ dx, float* __restrict__ part, float* __restrict__ part_b, long long rows,
+                                                                int cin, int cout, long long rows_per_block, int assign) {
+    const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int ci = threadIdx.x; ci < cin; ci += 128) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, accb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, wc[8];
+        for (int c = 0; c < 8; ++c) wc[c] = c < cout ? w[(long long)c * cin + ci] : 0.f;
+        long long r = r0;
+        for (; r + 4 <= r1; r += 4) {  // four rows in flight
+            const float x0 = x[r * cin + ci], x1 = x[(r + 1) * cin + ci], x2 = x[(r + 2) * cin + ci], x3 = x[(r + 3) * cin + ci];
+            float p0 = assign ? 0.f : dx[r * cin + ci], p1 = assign ? 0.f : dx[(r + 1) * cin + ci], p2 = assign ? 0.f : dx[(r + 2) * cin + ci],
+                  p3 = assign ? 0.f : dx[(r + 3) * cin + ci];
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+            for (int c = 0; c < cout; ++c) {
+                const float d0 = dy[r * cout + c], d1 = dy[(r + 1) * cout + c], d2 = dy[(r + 2) * cout + c], d3 = dy[(r + 3) * cout + c];
+                acc[c] = fmaf(d0, x0, acc[c]);
+                acc[c] = fmaf(d1, x1, acc[c]);
+                acc[c] = fmaf(d2, x2, acc[c]);
+                acc[c] = fmaf(d3, x3, acc[c]);
+                g0 = fmaf(d0, wc[c], g0);
+                g1 = fmaf(d1, wc[c], g1);
+                g2 = fmaf(d2, wc[c], g2);
+                g3 = fmaf(d3, wc[c], g3);
+                if (ci == 0) accb[c] += (d0 + d1) + (d2 + d3);
+            }
+            dx[r * cin + ci] = p0 + g0;
+            dx[(r + 1) * cin + ci] = p1 + g1;
+            dx[(r + 2) * cin + ci] = p2 + g2;
+            dx[(r + 3) * cin + ci] = p3 + g3;
+        }
+        for (; r < r1; ++r) {
+            const float xv = x[r * cin + ci];
+            float g = 0.f;
+            for (int c = 0; c < cout; ++c) {
+                const float d = dy[r * cout + c];
+                acc[c] = fmaf(d, xv, acc[c]);
+                g = fmaf(d, wc[c], g);
+                if (ci == 0) accb[c] += d;
+            }
+            dx[r * cin + ci] = assign ? g : dx[r * cin + ci] + g;
+        }
+        for (int c = 0; c < cout; ++c) part[((long long)blockIdx.x * cout + c) * cin + ci] = acc[c];
+        if (ci == 0)
+            for (int c = 0; c < cout; ++c) part_b[(long long)blockIdx.x * cout + c] = accb[c];
+    }
+}
 // D[n][2 yo][2 xo][:] = dy[n][yo][xo][:], zero elsewhere (H, W even): turns the data gradient of a stride-2 conv into a stride-1 conv
 __global__ __launch_bounds__(256) void dilate2_kernel(const float* __restrict__ dy, float* __restrict__ d, long long n, int H, int W, int C4) {
     const long long total = n * H * W * C4;
@@ -1030,7 +1080,7 @@ hipError_t cerb_launch_upadd_bwd(const float* dout, float* dskip, float* dprev, 
 }
 hipError_t cerb_launch_pointwise_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long long rows, int cin, int cout,
                                      const float* in_scale, int dx_assign, hipStream_t st) {
-    if (dx && !in_scale && !dx_assign && rows >= 4096 && cerb_launch_pw_mfma(dy, w, 0, nullptr, dx, rows, cout, cin, 1, st) == hipSuccess) dx = nullptr;
+    if (dx && !in_scale && rows >= 4096 && cerb_launch_pw_mfma(dy, w, 0, nullptr, dx, rows, cout, cin, dx_assign ? 0 : 1, st) == hipSuccess) dx = nullptr;
     if (dx) hipLaunchKernelGGL(pointwise_dgrad_kernel, dim3(gridfor(rows * cin)), dim3(256), 0, st, dy, w, dx, rows, cin, cout, in_scale, dx_assign);
     if (dw) hipLaunchKernelGGL(pointwise_wgrad_kernel, dim3(cin * cout), dim3(256), 0, st, x, dy, dw, rows, cin, cout, in_scale);
     if (db) hipLaunchKernelGGL(colsum_kernel, dim3(cout), dim3(256), 0, st, dy, 0ll, rows, cout, db);
@@ -1042,6 +1092,19 @@ hipError_t cerb_launch_pw_wgrad_small(const float* x, const float* dy, float* dw
     const int blocks = (int)((rows + 511) / 512);
     hipLaunchKernelGGL(pw_wgrad_small_partial_kernel, dim3(blocks), dim3(128), 0, st, x, dy, (float*)ws, rows, cin, cout, 512ll);
     (void)cerb_launch_slab_sum((const float*)ws, dw, cin * cout, blocks, 1, st);
+    return hipGetLastError();
+}
+size_t cerb_pw_bwd_small_workspace_bytes(long long rows, int cin, int cout) { return (size_t)((rows + 511) / 512) * (cin + 1) * cout * 4 + 512; }
+// dx (assigned or accumulated), dw and db of a pointwise layer with <= 8 outputs, one pass over x / dy / dx; partials per 512-row slab added in slab order
+hipError_t cerb_launch_pw_bwd_small(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long long rows, int cin, int cout,
+                                    int dx_assign, void* ws, hipStream_t st) {
+    if (cout > 8 || !dx || !dw || !db) return hipErrorInvalidValue;
+    const int blocks = (int)((rows + 511) / 512);
+    float* part = (float*)ws;
+    float* part_b = part + (size_t)blocks * cin * cout;
+    hipLaunchKernelGGL(pw_bwd_small_fused_kernel, dim3(blocks), dim3(128), 0, st, x, dy, w, dx, part, part_b, rows, cin, cout, 512ll, dx_assign);
+    (void)cerb_launch_slab_sum(part, dw, cin * cout, blocks, 1, st);
+    (void)cerb_launch_slab_sum(part_b, db, cout, blocks, 1, st);
     return hipGetLastError();
 }
 hipError_t cerb_launch_dilate2(const float* dy, float* d, long long n, int H, int W, int C, hipStream_t st) {

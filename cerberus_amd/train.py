@@ -102,11 +102,21 @@ def allreduce_grads(grads, dist, world_size, bucket_bytes=32 << 20):
     flush()
 
 
-def train_step(batch_data, run_info, dist=None, world_size=1, dropout_keep=None):
+def train_step(batch_data, run_info, dist=None, world_size=1, dropout_keep=None, timings=None):
     """batch_data: {'img': uint8 [N, H, W, 3], 'dummy_target': object array [N, B] of head names / None, '<head>': [N, H, W, 1] class
     ids, ...}; run_info: ({'net': {'desc': NetDesc, 'optimizer': cerberus_amd.train.Adam, 'extra_info': {'loss': loss_kwargs}}}, state)
     -- the reference's protocol (models/run_desc.py:25-60).  Returns {'EMA': {'<head>_loss': ..., 'overall_loss': ...},
-    'raw': {'img', 'true', 'pred'}} (two random samples for the visualisation callbacks, models/run_desc.py:172-230)."""
+    'raw': {'img', 'true', 'pred'}} (two random samples for the visualisation callbacks, models/run_desc.py:172-230).
+    timings: optional dict that receives the DEVICE time (ms, stream events) of the step's phases outside cerb_net_train_grads' own per-launch
+    records -- 'batch_to_device', 'train_grads' (the whole call), 'allreduce', 'adam_and_running_stats', 'param_update_and_repack', 'raw_payload'."""
+    marks = []
+
+    def mark(name):
+        if timings is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append((name, e))
+
     run_info, _ = run_info
     model, opt = run_info["net"]["desc"], run_info["net"]["optimizer"]
     # Sub-typing fine-tune (subtype_gland / subtype_nuclei; models/run_desc.py:83-84 -> net_desc.py:105-142): the backbone, conv_map, Patch-Class,
@@ -118,6 +128,7 @@ def train_step(batch_data, run_info, dist=None, world_size=1, dropout_keep=None)
     img = batch.pop("img")
     has = batch.pop("dummy_target")
     dev = torch.device("cuda", torch.cuda.current_device())
+    mark("start")
     targets, flags = OrderedDict(), OrderedDict()
     wmaps = OrderedDict()
     for k, v in batch.items():
@@ -131,7 +142,10 @@ def train_step(batch_data, run_info, dist=None, world_size=1, dropout_keep=None)
     if dropout_keep is None and "Patch-Class" in targets:  # nn.Dropout(p=0.3) of the Patch-Class branch (models/net_desc.py:70)
         dropout_keep = torch.rand((img.shape[0], 512), device=dev) >= 0.3
     logits = {}
-    losses, grads = model.train_grads(torch.as_tensor(img).to(dev), targets, flags, loss_opts, dropout_keep, views=True, pixel_weights=wmaps, logits_out=logits)
+    img_dev = torch.as_tensor(img).to(dev)
+    mark("batch_to_device")
+    losses, grads = model.train_grads(img_dev, targets, flags, loss_opts, dropout_keep, views=True, pixel_weights=wmaps, logits_out=logits)
+    mark("train_grads")
     buf_keys = [k for k in grads if k.endswith("running_mean") or k.endswith("running_var")]
     stats = OrderedDict((k, grads.pop(k)) for k in buf_keys)
     if frozen:  # requires_grad = False there: the optimiser never sees these tensors (their moments stay unborn, as in torch.optim.Adam)
@@ -140,6 +154,7 @@ def train_step(batch_data, run_info, dist=None, world_size=1, dropout_keep=None)
         for k in [k for k in stats if any(k.startswith(p) for p in frozen)]:
             del stats[k]
     allreduce_grads(grads, dist, world_size)
+    mark("allreduce")
     # parameters live in the model's state dict (host); the optimiser works on device copies that persist across steps
     if not hasattr(model, "_dev_params"):
         model._sync_state_dict()
@@ -164,11 +179,19 @@ def train_step(batch_data, run_info, dist=None, world_size=1, dropout_keep=None)
                 nk = k[: -len("running_mean")] + "num_batches_tracked"
                 if nk in model._sd:
                     model._sd[nk] = model._sd[nk] + 1
+    mark("adam_and_running_stats")
     torch.cuda.synchronize(dev)
     model.load_updated_parameters(model._dev_params, model._dev_flat, model._dev_layout)
+    mark("param_update_and_repack")
     ema = OrderedDict(("%s_loss" % k, v) for k, v in losses.items())
     ema["overall_loss"] = float(sum(losses.values()))
-    return {"EMA": ema, "raw": _raw_payload(torch.as_tensor(img), targets, logits, has)}
+    out = {"EMA": ema, "raw": _raw_payload(torch.as_tensor(img), targets, logits, has)}
+    mark("raw_payload")
+    if timings is not None:
+        torch.cuda.synchronize(dev)
+        for (_, a), (name, b) in zip(marks[:-1], marks[1:]):
+            timings[name] = a.elapsed_time(b)
+    return out
 
 
 def _raw_payload(img, targets, logits, has):
