@@ -167,6 +167,81 @@ def run_local(bands, tissue, margin, guard, ds_factor=1.0, label_fn=_device_labe
     return outs, int(offs[-1]), infos
 
 
+class IncrementalLocalLabeller(object):
+    """run_local for ONE tissue on ONE GPU, fed while the rows further down are still being inferred: a local band is labelled (on a side stream)
+    as soon as its own rows and the halo rows below it are final, so that of the slide's tail only the last band, the id protocol and the
+    relabelling remain when the inference ends.  Same bands, same protocol, same results as run_local -- only earlier.
+        lab = IncrementalLocalLabeller(band, "Nuclei", margin, guard, max_band_px)
+        lab.feed(rows_final, events)     after some inference was queued: `events` complete => canvas rows [0, rows_final) are final
+        outs, n, infos = lab.finish()    on the caller's stream (waits for the side stream)"""
+
+    def __init__(self, band, tissue, margin, guard, max_band_px, ds_factor=1.0, label_fn=_device_label_fn, table_fn=_device_table_fn,
+                 relabel_fn=_device_relabel_fn):
+        rows, cols = int(band.shape[0]), int(band.shape[1])
+        self.nb = local_band_count(rows, cols, max_band_px, margin)
+        self.cuts = [int(round(i * rows / self.nb)) for i in range(self.nb + 1)]
+        self.margin = int(margin)
+        self.states = [BandState(r, self.nb, band[self.cuts[r]:self.cuts[r + 1]], self.cuts[r], margin, guard, tissue, ds_factor) for r in range(self.nb)]
+        self.counts = [None] * self.nb
+        self.done = 0
+        self.fns = (label_fn, table_fn, relabel_fn)
+        self.side = torch.cuda.Stream(band.device) if band.is_cuda else None
+        self.early = 0  # bands labelled before finish()
+
+    def rows_needed(self, r):
+        return self.cuts[r + 1] + (self.margin if r < self.nb - 1 else 0)
+
+    def _label(self, r):
+        above = self.states[r - 1].strips()[1] if r > 0 else None
+        below = self.states[r + 1].strips()[0] if r < self.nb - 1 else None
+        self.counts[r] = self.states[r].label(above, below, self.fns[0], self.fns[1])
+
+    def feed(self, rows_final, events=()):
+        while self.done < self.nb and self.rows_needed(self.done) <= rows_final:
+            if self.side is not None:
+                with torch.cuda.stream(self.side):
+                    for e in events:
+                        self.side.wait_event(e)
+                    self._label(self.done)
+            else:
+                self._label(self.done)
+            self.done += 1
+            self.early += 1
+
+    def finish(self):
+        if self.side is not None:
+            torch.cuda.current_stream(self.side.device).wait_stream(self.side)
+        for r in range(self.done, self.nb):
+            self._label(r)
+        self.done = self.nb
+        offs = np.concatenate([[0], np.cumsum(self.counts)])
+        pubs = [s.publish(int(offs[r])) for r, s in enumerate(self.states)]
+        outs, infos = [], []
+        for r, s in enumerate(self.states):
+            o, i = s.resolve(pubs[:r], self.fns[2])
+            outs.append(o)
+            infos.append(i)
+        return outs, int(offs[-1]), infos
+
+
+def make_incremental(band_canv, dist, wsi_mode=True, margin=512, guard=48, max_band_px=None, tissues=("Nuclei",)):
+    """{tissue: IncrementalLocalLabeller} for the full-resolution tissues of a one-GPU job whose canvas is labelled in several local bands (nothing to
+    overlap otherwise, and the multi-rank protocol labels one band per rank after its halo exchange).  band_canv: the canvases sharded_postprocess
+    will get (same rows, same columns).  The half-resolution tissues (gland, lumen: 0.04 s of a 40000^2 slide) stay in the tail."""
+    pre = OrderedDict()
+    if dist is not None or not max_band_px:
+        return pre
+    for t in tissues:
+        key = t + "-INST"
+        if key not in band_canv or (wsi_mode and t != "Nuclei"):
+            continue
+        band = band_canv[key]
+        mt = margin.get(t, margin.get("default", 512)) if isinstance(margin, dict) else margin
+        if local_band_count(int(band.shape[0]), int(band.shape[1]), max_band_px, mt) > 1:
+            pre[t] = IncrementalLocalLabeller(band, t, mt, guard, max_band_px)
+    return pre
+
+
 def _tick(prof, key, nbytes, t0):
     """prof: None, or a dict collecting (bytes moved INTO this rank or out of it, seconds) per phase -- bench.py's xGMI figures."""
     if prof is None:
@@ -292,7 +367,7 @@ def local_band_count(rows, cols, max_band_px, margin=0):
     return nb
 
 
-def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guard=48, max_band_px=None, prof=None, watch=None):
+def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guard=48, max_band_px=None, prof=None, watch=None, pre=None):
     """Per-rank replacement of WSIRunner.postprocess for band canvases: label maps of THIS rank's band with slide-global
     ids, nothing gathered.  margin: halo rows at full resolution, an int or {tissue: rows, "default": rows} (the reference's
     own nuclei margin is 64 px, infer/wsi.py:906-915; gland clusters need hundreds).  canv: the band canvases of this rank (full-resolution rows of equal count on every rank except
@@ -328,15 +403,28 @@ def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guar
         else:
             t0 = _tock(prof)
             nb = local_band_count(int(band.shape[0]), int(band.shape[1]), max_band_px, m)  # (half-resolution maps: their own pixel count, halved margin)
-            cuts = [int(round(i * band.shape[0] / nb)) for i in range(nb + 1)]
-            outs, n, infos = run_local([band[cuts[i]:cuts[i + 1]] for i in range(nb)], t, m, g, ds)
+            if pre and t in pre:  # bands already labelled underneath the inference (IncrementalLocalLabeller): finish the rest, same protocol
+                assert pre[t].nb == nb and pre[t].states[0].band.data_ptr() == band.data_ptr(), "the incremental labeller was built for another canvas"
+                outs, n, infos = pre[t].finish()
+            else:
+                cuts = [int(round(i * band.shape[0] / nb)) for i in range(nb + 1)]
+                outs, n, infos = run_local([band[cuts[i]:cuts[i + 1]] for i in range(nb)], t, m, g, ds)
             inst[t] = outs[0] if nb == 1 else assemble(outs)
             info[t] = {"n_owned": n, "n_total": n, "n_truncated": sum(i["n_truncated"] for i in infos),
                        "n_unresolved": sum(i["n_unresolved"] for i in infos), "local_bands": nb}
+            if pre and t in pre:
+                info[t]["bands_labelled_under_inference"] = pre[t].early
             _tick(prof, "label_" + t, 0, t0)
     if "Lumen" in inst and "Gland" in inst:
         mask_lumen_by_gland(inst["Lumen"], inst["Gland"])
     return inst, info
+
+
+def band_view(run, H, W, canv=None):
+    """The canvases postprocess_bands_and_gather labels: this rank's valid rows and the slide's columns of run.canv (or of `canv`)."""
+    src = run.canv if canv is None else canv
+    valid = max(0, min(run.band_h, H - run.r0 * run.geo.out))
+    return OrderedDict((k, v[:valid, :W]) for k, v in src.items())
 
 
 def _gather_rows(lab, rows_per_rank, cols, dist, rank, world):
@@ -353,10 +441,11 @@ def _gather_rows(lab, rows_per_rank, cols, dist, rank, world):
     return torch.cat([lst[i][: rows_per_rank[i]] for i in range(world)], dim=0)
 
 
-def postprocess_bands_and_gather(run, H, W, rank, world, dist, margin=512, guard=48, canv=None, max_band_px=None, prof=None, watch=None):
+def postprocess_bands_and_gather(run, H, W, rank, world, dist, margin=512, guard=48, canv=None, max_band_px=None, prof=None, watch=None, pre=None):
     """The tail of a slide on 1..N GPUs: band-local label maps with slide-global ids, then only the int32 label bands and the
     uint8 / float class canvases travel to the root (12 + 3 B/px instead of the 36 B/px of raw probability canvases).
     `run` is this rank's WSIRunner after infer_band.  Returns (inst, info, small) -- inst / small are None off the root.
+    pre: band_view(run, H, W, canv) labellers from make_incremental that were fed during the inference (one-GPU jobs).
     canv: label these band canvases instead of run.canv (bench.py's structured probability maps); max_band_px: see
     sharded_postprocess; prof: dict collecting bytes / seconds of the halo exchange and the root gather."""
     from .wsi import gather_bands, half_size
@@ -365,7 +454,7 @@ def postprocess_bands_and_gather(run, H, W, rank, world, dist, margin=512, guard
     src = run.canv if canv is None else canv
     valid = max(0, min(run.band_h, H - run.r0 * geo.out))
     band = OrderedDict((k, v[:valid, :W]) for k, v in src.items())
-    inst_b, info = sharded_postprocess(band, rank, world, dist, wsi_mode=True, margin=margin, guard=guard, max_band_px=max_band_px, prof=prof, watch=watch)
+    inst_b, info = sharded_postprocess(band, rank, world, dist, wsi_mode=True, margin=margin, guard=guard, max_band_px=max_band_px, prof=prof, watch=watch, pre=pre)
     bounds = geo.bounds(world)
     rows = [max(0, min((bounds[i + 1] - bounds[i]) * geo.out, H - bounds[i] * geo.out)) for i in range(world)]
     inst = OrderedDict() if rank == 0 else None

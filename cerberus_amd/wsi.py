@@ -202,15 +202,23 @@ class WSIRunner(object):
     def slab_rows(self):
         return self.geo.input_rows(self.r0, self.r1)
 
-    def infer_band(self, slab, slab_y0, ready=None):
+    def infer_band(self, slab, slab_y0, ready=None, progress=None):
         """slab: uint8 [rows, W, 3] holding absolute slide rows [slab_y0, slab_y0+rows) (this rank's band + halo).
         Runs every patch of the band; outputs land in self.canv.  Returns the number of patches.
         ready: optional callable(n_rows) that makes the first n_rows rows of `slab` valid for work queued on the current stream
         (SlabUploader.upload_until: the band is then uploaded chunk by chunk underneath the inference of the rows above)."""
-        return self.infer_patches(slab, slab_y0, 0, self.n_patches, ready)
+        return self.infer_patches(slab, slab_y0, 0, self.n_patches, ready, progress)
 
-    def infer_patches(self, slab, slab_y0, p0, p1, ready=None):
-        """Patches [p0, p1) of this band's row-major patch list (bench.py times a slide as K such stripes)."""
+    def rows_final(self, n_patches_done):
+        """Canvas rows of this band that are final once the first n patches of the row-major list have run (whole patch rows only)."""
+        if self.geo.patch_sel is not None:
+            return 0 if n_patches_done < self.n_patches else self.band_h  # (a tissue mask drops patches: no simple row count)
+        return min(self.band_h, (int(n_patches_done) // self.geo.cols) * self.geo.out)
+
+    def infer_patches(self, slab, slab_y0, p0, p1, ready=None, progress=None):
+        """Patches [p0, p1) of this band's row-major patch list (bench.py times a slide as K such stripes).
+        progress: optional callable(n_done, events) after every queued batch: the first n_done patches of the list are complete once `events`
+        (one per stream in use) are -- what shard_postproc.IncrementalLocalLabeller.feed wants."""
         g = self.geo
         assert slab.shape[1] == g.W
         p0, p1 = max(0, int(p0)), min(self.n_patches, int(p1))
@@ -223,9 +231,16 @@ class WSIRunner(object):
             tiles = gather_patches(slab, slab_y0, g.H, self._tl_y[b0:b1], self._tl_x[b0:b1], g.win)
             net._run(tiles, g.out, g.out, self._outs, None, tile_off=self._off[b0:b1], row_stride=self.canvas_w, type_is_u8=True)
 
+        def mark(stream):
+            e = torch.cuda.Event()
+            e.record(stream)
+            return e
+
         if self.twin is None or p1 - p0 <= self.batch:
             for b0 in range(p0, p1, self.batch):
                 one(self.net, b0)
+                if progress is not None:
+                    progress(min(p1, b0 + self.batch), [mark(torch.cuda.current_stream(self.dev))])
             return p1 - p0
         # two handles, two side streams: everything queued on the caller's stream so far happens before, everything after waits for both
         if self._side is None:
@@ -236,9 +251,13 @@ class WSIRunner(object):
         nets = (self.net, self.twin)
         for s in self._side:
             s.wait_event(fork)
+        last = [fork, fork]
         for i, b0 in enumerate(range(p0, p1, self.batch)):
             with torch.cuda.stream(self._side[i & 1]):
                 one(nets[i & 1], b0)
+            if progress is not None:
+                last[i & 1] = mark(self._side[i & 1])
+                progress(min(p1, b0 + self.batch), list(last))
         for s in self._side:
             join = torch.cuda.Event()
             join.record(s)

@@ -165,13 +165,33 @@ def main(argv=None):
         t_prep = time.perf_counter()
         if log:
             log.info("Preparing Input Output Placement: {0}".format(t_prep - t0))
+        # CERB_WSI_OVERLAP_TAIL=1 (one GPU, a slide labelled in several local bands): the nuclei bands are labelled on a side stream while the rows
+        # below are still being inferred (shard_postproc.IncrementalLocalLabeller); a band is started a few batches after its rows became final, so
+        # that the host's waits inside the labelling call have queued inference to hide behind.  Off by default: on resident data the labelling's
+        # kernels cost the saturated inference more than the tail they remove (bench.py --overlap-tail: 149.6 against 150.6 Mpx/s).
+        pre, progress = {}, None
+        if mask is None and world == 1 and H * W > ONE_CALL_PX and os.environ.get("CERB_WSI_OVERLAP_TAIL", "0") == "1":
+            from collections import deque
+
+            from cerberus_amd.shard_postproc import band_view, make_incremental
+
+            pre = make_incremental(band_view(run, H, W), dist, max_band_px=ONE_CALL_PX)
+            if pre:
+                pending = deque()
+
+                def progress(n_done, events, pending=pending, pre=pre, run=run):
+                    pending.append((run.rows_final(n_done), events))
+                    if len(pending) > 6:
+                        rows_final, evs = pending.popleft()
+                        for lab in pre.values():
+                            lab.feed(rows_final, evs)
         if host is None:
-            run.infer_band(synth_slide(y1 - y0, W, y0=y0, seed=seed), y0)
+            run.infer_band(synth_slide(y1 - y0, W, y0=y0, seed=seed), y0, progress=progress)
         elif isinstance(host, np.ndarray) and not isinstance(host, np.memmap):  # already in RAM: one 50 GB/s copy, nothing to hide
-            run.infer_band(torch.from_numpy(np.ascontiguousarray(host[y0:y1])).cuda(), y0)
+            run.infer_band(torch.from_numpy(np.ascontiguousarray(host[y0:y1])).cuda(), y0, progress=progress)
         else:  # a slide on disk (memory-mapped array, tiled TIFF / .svs pyramid): read / decode + upload chunk by chunk on a copy
             up = SlabUploader(host, y0, y1)  # stream underneath the inference of the rows above
-            run.infer_band(up.slab, y0, ready=up.upload_until)
+            run.infer_band(up.slab, y0, ready=up.upload_until, progress=progress)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         if dist is not None:
@@ -186,7 +206,7 @@ def main(argv=None):
             # slide too large for a single labelling call (96 B / px of workspace, 2^31 px) streams through the same protocol band by band
             from cerberus_amd.shard_postproc import postprocess_bands_and_gather
 
-            inst, _, maps = postprocess_bands_and_gather(run, H, W, rank, world, dist, max_band_px=ONE_CALL_PX if world == 1 else None, prof=pprof, watch=watch)
+            inst, _, maps = postprocess_bands_and_gather(run, H, W, rank, world, dist, max_band_px=ONE_CALL_PX if world == 1 else None, prof=pprof, watch=watch, pre=pre)
         else:  # with a mask gland / lumen are labelled per tissue region (infer/wsi.py:730-835), on the root
             with watch.phase("canvas gather to rank 0 (%s)" % base):
                 maps = run.gather_to_root(dist)

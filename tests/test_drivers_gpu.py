@@ -116,6 +116,40 @@ def test_wsi_runner_two_handles_on_two_streams_is_bitwise_the_one_handle_run(man
             assert sums[k] == want[k].double().sum().item(), (rep, k)
 
 
+def test_nuclei_bands_labelled_under_the_inference_equal_the_tail_only_run(manager):
+    """run_infer_wsi.py / bench.py on one GPU: WSIRunner.infer_band(progress=...) feeds shard_postproc.IncrementalLocalLabeller, which labels a local
+    nuclei band on a side stream as soon as its rows and the halo below are final -- while both inference streams go on writing the rows further
+    down.  The tail then finishes the remaining band(s) and the id protocol.  Label maps, counts and checks must equal the run that labels
+    everything after the inference, bit for bit (repeated: an ordering mistake between the three streams is timing dependent)."""
+    from cerberus_amd.shard_postproc import band_view, make_incremental, postprocess_bands_and_gather
+
+    H, W, margin = 1500, 1300, 64
+    max_px = (300 + 2 * margin) * W  # five local bands
+    slide = synth_slide(H, W, seed=21)
+    twin = manager.net.twin()
+    ref_run = WSIRunner(manager.net, (H, W), 256, 256, batch_size=4)
+    ref_run.infer_band(slide, 0)
+    want, want_info, _ = postprocess_bands_and_gather(ref_run, H, W, 0, 1, None, margin=margin, guard=16, max_band_px=max_px)
+    assert want_info["Nuclei"]["local_bands"] == 5
+    for rep in range(3):
+        run = WSIRunner(manager.net, (H, W), 256, 256, batch_size=4, twin=twin if rep else None)
+        pre = make_incremental(band_view(run, H, W), None, margin=margin, guard=16, max_band_px=max_px)
+        assert list(pre) == ["Nuclei"] and pre["Nuclei"].nb == 5
+        seen = []
+
+        def progress(n_done, events):
+            pre["Nuclei"].feed(run.rows_final(n_done), events)
+            seen.append(pre["Nuclei"].done)
+
+        run.infer_band(slide, 0, progress=progress)
+        got, info, _ = postprocess_bands_and_gather(run, H, W, 0, 1, None, margin=margin, guard=16, max_band_px=max_px, pre=pre)
+        assert seen[-1] >= 3 and seen == sorted(seen) and info["Nuclei"]["bands_labelled_under_inference"] == seen[-1]
+        for t in want:
+            assert torch.equal(got[t], want[t]), (rep, t)
+        for key in ("n_total", "n_truncated", "n_unresolved", "local_bands"):
+            assert info["Nuclei"][key] == want_info["Nuclei"][key], (rep, key)
+
+
 def test_band_postprocess_and_gather_single_rank_equals_root_path(manager):
     """postprocess_bands_and_gather (the multi-GPU tail of run_infer_wsi.py) at world 1: same instances as the root-side
     WSIRunner.postprocess on a slide whose size is not a multiple of the patch (canvas rows / columns beyond the slide are cropped)."""

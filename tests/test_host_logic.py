@@ -509,3 +509,31 @@ def test_write_dat_fast_writes_what_pickle_would(tmp_path):
     assert b"numpy.core.multiarray" in raw and b"numpy._core" not in raw
     assert type(fast["Nuclei"][keys[0]]["type"]) is int and type(fast["Nuclei"][keys[0]]["type_prob"]) is float
     assert t_fast < t_slow, (t_fast, t_slow)  # ~10x here; the point of the exercise
+
+
+def test_incremental_local_labeller_equals_run_local():
+    """shard_postproc.IncrementalLocalLabeller: the one-GPU local bands labelled one by one as the rows above become final (fed with growing row
+    counts, in uneven steps, with the oracle as labeller here) end in exactly run_local's label bands, instance count and per-band info; a band is
+    labelled only when its own rows AND the halo below are final, and finish() labels what is left."""
+    from cerberus_amd import shard_postproc as sp
+    from oracle import synth
+
+    H, W, margin, guard = 1040, 320, 96, 16
+    full = torch.from_numpy(synth.nuclei_maps(H, W, 3, 900.0, noise=0.02))
+    max_px = (1040 // 4 + 2 * margin) * W  # -> four local bands
+    fns = dict(label_fn=_oracle_label_fn, table_fn=_np_table, relabel_fn=lambda rows, m: np.asarray(m)[rows])
+    nb = sp.local_band_count(H, W, max_px, margin)
+    assert nb >= 3
+    cuts = [int(round(i * H / nb)) for i in range(nb + 1)]
+    want, n_want, info_want = sp.run_local([full[cuts[i]:cuts[i + 1]] for i in range(nb)], "Nuclei", margin, guard, 1.0, **fns)
+    lab = sp.IncrementalLocalLabeller(full, "Nuclei", margin, guard, max_px, **fns)
+    assert lab.nb == nb and lab.cuts == cuts
+    seen = []
+    for rows_final in (10, cuts[1], cuts[1] + margin - 1, cuts[1] + margin, cuts[2] + margin + 5, cuts[3] - 1):
+        lab.feed(rows_final)
+        seen.append(lab.done)
+    assert seen == [0, 0, 0, 1, 2, 2]  # a band waits for its halo rows below
+    got, n_got, info_got = lab.finish()
+    assert lab.early == 2 and lab.done == nb and n_got == n_want > 50 and info_got == info_want
+    for a, b in zip(got, want):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
