@@ -362,28 +362,34 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(float* x, const float* sr
                  ga = *reinterpret_cast<const float4*>(gamma + gc), be = *reinterpret_cast<const float4*>(beta + gc);
     const long long base = g * group_stride + 4 * c4;
     const long long step = (long long)gridDim.x * nrl;
-    auto one = [&](long long r) {
-        const long long a = base + r * C;
-        float4 v = *reinterpret_cast<const float4*>(src + a);  // src == x: in place
+    // FOUR rows per iteration with every load issued before the first store: the pass is in place (no __restrict__ on x / src), so the compiler
+    // cannot move a later row's loads above an earlier row's store by itself, and one row in flight per thread left the pass latency-bound
+    const float4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto finish = [&](long long r, float4 v, const float4& r4) {
         v.x = bn_out(v.x, m.x, rs.x, ga.x, be.x);
         v.y = bn_out(v.y, m.y, rs.y, ga.y, be.y);
         v.z = bn_out(v.z, m.z, rs.z, ga.z, be.z);
         v.w = bn_out(v.w, m.w, rs.w, ga.w, be.w);
         if (resid) {
-            const float4 r4 = *reinterpret_cast<const float4*>(resid + a);
             v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
         }
         if (relu) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        *reinterpret_cast<float4*>(x + a) = v;
+        *reinterpret_cast<float4*>(x + base + r * C) = v;
     };
     long long r = (long long)blockIdx.x * nrl + rl;
-    for (; r + step < rows; r += 2 * step) {  // two independent rows in flight
-        one(r);
-        one(r + step);
+    for (; r + 3 * step < rows; r += 4 * step) {
+        float4 v[4], q4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(src + base + (r + k * step) * C);  // src == x: in place
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q4[k] = resid ? *reinterpret_cast<const float4*>(resid + base + (r + k * step) * C) : zero4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) finish(r + k * step, v[k], q4[k]);
     }
-    if (r < rows) one(r);
+    for (; r < rows; r += step)
+        finish(r, *reinterpret_cast<const float4*>(src + base + r * C), resid ? *reinterpret_cast<const float4*>(resid + base + r * C) : zero4);
 }
 // out[r][co] = bias[co] + sum_ci in[r][ci] * W[co][ci]; thread = (row, 4 couts); weights read through the caches
 __global__ __launch_bounds__(256) void pointwise_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
@@ -513,7 +519,25 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         const float4 zero4 = {0.f, 0.f, 0.f, 0.f};
         const long long base = g * group_stride + 4 * c4;
         long long r = r0 + rl;
-        // two rows (four to six 16-byte loads) in flight per thread; sums still in row order: bit-identical to the one-row loop
+        // four rows (eight to twelve 16-byte loads) in flight per thread, then two; sums still in row order: bit-identical to the one-row loop
+        for (; r + 3 * nrl < r1; r += 4 * nrl) {
+            const long long i0 = base + r * C, i1 = base + (r + nrl) * C, i2 = base + (r + 2 * nrl) * C, i3 = base + (r + 3 * nrl) * C;
+            const float4 d0 = *reinterpret_cast<const float4*>(dz + i0), d1 = *reinterpret_cast<const float4*>(dz + i1),
+                         d2 = *reinterpret_cast<const float4*>(dz + i2), d3 = *reinterpret_cast<const float4*>(dz + i3);
+            const float4 y0 = *reinterpret_cast<const float4*>(y + i0), y1 = *reinterpret_cast<const float4*>(y + i1),
+                         y2 = *reinterpret_cast<const float4*>(y + i2), y3 = *reinterpret_cast<const float4*>(y + i3);
+            float4 z0 = zero4, z1 = zero4, z2 = zero4, z3 = zero4;
+            if (relu == 1) {
+                z0 = *reinterpret_cast<const float4*>(z + i0);
+                z1 = *reinterpret_cast<const float4*>(z + i1);
+                z2 = *reinterpret_cast<const float4*>(z + i2);
+                z3 = *reinterpret_cast<const float4*>(z + i3);
+            }
+            add(d0, y0, z0);
+            add(d1, y1, z1);
+            add(d2, y2, z2);
+            add(d3, y3, z3);
+        }
         for (; r + nrl < r1; r += 2 * nrl) {
             const long long i0 = base + r * C, i1 = base + (r + nrl) * C;
             const float4 d0 = *reinterpret_cast<const float4*>(dz + i0), d1 = *reinterpret_cast<const float4*>(dz + i1);
@@ -579,26 +603,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     if (relu == 2) be = *reinterpret_cast<const float4*>(beta + gc);
     const long long base = g * group_stride + 4 * c4;
     const long long step = (long long)gridDim.x * nrl;
-    auto one = [&](long long r) {
+    // four rows per iteration, every load before the first store (see bn_apply_kernel)
+    const float4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto finish = [&](long long r, float4 d, const float4& yv, const float4& zm, float4 r4, const float4& p) {
         const long long a = base + r * C;
-        float4 d = *reinterpret_cast<const float4*>(dz + a);
-        const float4 yv = *reinterpret_cast<const float4*>(y + a);
         if (relu) {
-            float4 m;
+            float4 m = zm;
             if (relu == 2) {
                 m.x = bn_out(yv.x, mu.x, rs.x, ga.x, be.x);
                 m.y = bn_out(yv.y, mu.y, rs.y, ga.y, be.y);
                 m.z = bn_out(yv.z, mu.z, rs.z, ga.z, be.z);
                 m.w = bn_out(yv.w, mu.w, rs.w, ga.w, be.w);
-            } else
-                m = *reinterpret_cast<const float4*>(z + a);
+            }
             if (!(m.x > 0.f)) d.x = 0.f;
             if (!(m.y > 0.f)) d.y = 0.f;
             if (!(m.z > 0.f)) d.z = 0.f;
             if (!(m.w > 0.f)) d.w = 0.f;
         }
         if (dresid) {
-            float4 r4 = *reinterpret_cast<float4*>(dresid + a);
             r4.x += d.x; r4.y += d.y; r4.z += d.z; r4.w += d.w;
             *reinterpret_cast<float4*>(dresid + a) = r4;
         }
@@ -608,17 +630,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         o.z = ga.z * rs.z * (d.z - db.z * invM - ((yv.z - mu.z) * rs.z) * dg.z * invM);
         o.w = ga.w * rs.w * (d.w - db.w * invM - ((yv.w - mu.w) * rs.w) * dg.w * invM);
         if (!ASSIGN) {
-            const float4 p = *reinterpret_cast<const float4*>(dy + a);
             o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
         }
         *reinterpret_cast<float4*>(dy + a) = o;
     };
+    auto ld = [&](const float* t, long long r) { return *reinterpret_cast<const float4*>(t + base + r * C); };
     long long r = (long long)blockIdx.x * nrl + rl;
-    for (; r + step < rows; r += 2 * step) {
-        one(r);
-        one(r + step);
+    for (; r + 3 * step < rows; r += 4 * step) {
+        float4 d[4], yv[4], zm[4], r4[4], p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            d[k] = ld(dz, r + k * step);
+            yv[k] = ld(y, r + k * step);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            zm[k] = relu == 1 ? ld(z, r + k * step) : zero4;
+            r4[k] = dresid ? ld(dresid, r + k * step) : zero4;
+            p[k] = ASSIGN ? zero4 : ld(dy, r + k * step);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) finish(r + k * step, d[k], yv[k], zm[k], r4[k], p[k]);
     }
-    if (r < rows) one(r);
+    for (; r < rows; r += step)
+        finish(r, ld(dz, r), ld(y, r), relu == 1 ? ld(z, r) : zero4, dresid ? ld(dresid, r) : zero4, ASSIGN ? zero4 : ld(dy, r));
 }
 // ---- convolution backward, gather form (any ks / stride / pad = ks / 2; groups = independent convs stacked along G) ------------------
 __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int G, int N, int H,
