@@ -50,13 +50,15 @@ static inline unsigned nblk(long long n, int per) { return (unsigned)((n + per -
 // Exclusive prefix sum over int32 (three-kernel, recursive on the block sums)
 // =================================================================================================================
 #define SCAN_ITEMS 1024  // per block: 256 threads x 4
+// ROOTS: the scanned value is "pixel j is a root of the union-find map `in`" (in[j] == j), computed here instead of by a flag pass of its own
+template <bool ROOTS>
 __global__ __launch_bounds__(256) void scan_block_kernel(const int* __restrict__ in, int* __restrict__ out, int* __restrict__ sums, int n) {
     __shared__ int wsum[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long base = (long long)blockIdx.x * SCAN_ITEMS + tid * 4;
     int v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (base + i < n) ? in[base + i] : 0;
+    for (int i = 0; i < 4; ++i) v[i] = (base + i < n) ? (ROOTS ? (in[base + i] == (int)(base + i) ? 1 : 0) : in[base + i]) : 0;
     const int tsum = v[0] + v[1] + v[2] + v[3];
     int inc = tsum;  // inclusive scan across the wave
 #pragma unroll
@@ -86,16 +88,24 @@ __global__ void scan_add_kernel(int* __restrict__ out, const int* __restrict__ s
     }
 }
 // tmp must hold at least n/1024 + n/1024^2 + ... + 4 ints.  total (sum of all elements) is written to *total_dev.
-static int scan_exclusive(const int* in, int* out, int n, int* tmp, hipStream_t st) {
+// block_offsets != nullptr: the last pass (adding every block's offset to its 1024 outputs: a read-modify-write of the whole array) is left to
+// the READERS -- scan[j] = out[j] + (*block_offsets)[j >> 10], with *block_offsets == nullptr when one block held everything.
+static int scan_exclusive(const int* in, int* out, int n, int* tmp, hipStream_t st, bool roots = false, const int** block_offsets = nullptr) {
     const int nb = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
+    auto kern = roots ? scan_block_kernel<true> : scan_block_kernel<false>;
+    if (block_offsets) *block_offsets = nullptr;
     if (nb <= 1) {
-        hipLaunchKernelGGL(scan_block_kernel, dim3(1), dim3(256), 0, st, in, out, (int*)nullptr, n);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(256), 0, st, in, out, (int*)nullptr, n);
         KCHECK();
         return 0;
     }
-    hipLaunchKernelGGL(scan_block_kernel, dim3(nb), dim3(256), 0, st, in, out, tmp, n);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, st, in, out, tmp, n);
     KCHECK();
     if (scan_exclusive(tmp, tmp, nb, tmp + ((nb + 3) & ~3), st)) return 1;
+    if (block_offsets) {
+        *block_offsets = tmp;
+        return 0;
+    }
     hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, st, out, tmp, n);
     KCHECK();
     return 0;
@@ -381,6 +391,21 @@ __global__ void ccl_relabel_kernel(const int* __restrict__ L, const int* __restr
         out[p] = (r >= 0 && flag[r]) ? rank[r] + 1 : 0;
     }
 }
+// the watershed's start map in one pass: out[p] = mask ? 1 + rank[root of p in the marker labelling] : 0 (rank = exclusive scan of "is a root");
+// replaces the flag pass, the relabel pass into a marker map and the mask pass over it
+// (boff: the scan's per-1024 block offsets, left unadded by scan_exclusive(..., &boff); nullptr = already complete)
+__global__ void nuc_marker_out_kernel(const int* __restrict__ L, const int* __restrict__ rank, const int* __restrict__ boff, const uint8_t* __restrict__ mask,
+                                      int* __restrict__ out, int n) {
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        const int r = L[p];
+        out[p] = (r >= 0 && mask[p]) ? rank[r] + (boff ? boff[r / SCAN_ITEMS] : 0) + 1 : 0;
+    }
+}
+__global__ void count_roots_from_scan_kernel(const int* __restrict__ L, const int* __restrict__ rank, const int* __restrict__ boff, int n, int* __restrict__ out,
+                                             const int* __restrict__ any) {
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        *out = (any && !*any) ? -1 : (n > 0 ? rank[n - 1] + (boff ? boff[(n - 1) / SCAN_ITEMS] : 0) + (L[n - 1] == n - 1 ? 1 : 0) : 0);
+}
 __global__ void count_from_scan_kernel(const int* __restrict__ flag, const int* __restrict__ rank, int n, int* __restrict__ out,
                                        const int* __restrict__ any) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *out = (any && !*any) ? -1 : (n > 0 ? rank[n - 1] + flag[n - 1] : 0);
@@ -618,11 +643,54 @@ __global__ void ws_bbox_kernel(const int* __restrict__ L, const uint8_t* __restr
 // A component all of whose seeds carry ONE label needs no priority flood: every unlabelled mask pixel of a 4-connected mask
 // component is reachable from a seed through unlabelled mask pixels, so the flood can only ever assign that label
 // (ws_fill_single_kernel).  Isolated nuclei -- the common case -- take this path; only touching clusters reach the heaps.
+// First kernel of the heap-offset scan with the per-root state set up on the way: the scanned value is the heap capacity of a kept mask component
+// (its area, at its root pixel; 0 elsewhere), and every kept root gets its counters / label extremes / box initialised HERE -- the per-root arrays are
+// indexed by root pixel and only ever read at kept roots, so the four whole-map fills, the capacity pass and the box-init pass are not needed.
+__global__ __launch_bounds__(256) void scan_block_cap_kernel(const int* __restrict__ L, const int* __restrict__ area, const uint8_t* __restrict__ mask,
+                                                            int* __restrict__ out, int* __restrict__ sums, int n, int* __restrict__ hcnt, int* __restrict__ unl,
+                                                            int* __restrict__ lmin, int* __restrict__ lmax, CBox* __restrict__ bb, int H, int W) {
+    __shared__ int wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long base = (long long)blockIdx.x * SCAN_ITEMS + tid * 4;
+    int v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long j = base + i;
+        v[i] = 0;
+        if (j < n && L[j] == (int)j && mask[j]) {
+            v[i] = area[j];
+            hcnt[j] = 0;
+            unl[j] = 0;
+            lmin[j] = 0x7f7f7f7f;
+            lmax[j] = 0;
+            bb[j] = CBox{H, -1, W, -1};
+        }
+    }
+    const int tsum = v[0] + v[1] + v[2] + v[3];
+    int inc = tsum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    int run = woff + inc - tsum;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+    if (tid == 255 && sums) sums[blockIdx.x] = woff + inc;
+}
 __global__ void ws_worklist_kernel(const int* __restrict__ hcnt, const int* __restrict__ area, const int* __restrict__ unl, const CBox* __restrict__ bb,
                                    const int* __restrict__ lmin, const int* __restrict__ lmax, int* __restrict__ wl, int* __restrict__ wl2,
-                                   int* __restrict__ wl3, int* __restrict__ wl4, int* __restrict__ counts, int n) {
+                                   int* __restrict__ wl3, int* __restrict__ wl4, int* __restrict__ counts, int n, const int* __restrict__ L,
+                                   const uint8_t* __restrict__ mask) {
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
-        if (hcnt[p] > 0 && lmin[p] != lmax[p]) {
+        if (L[p] == (int)p && mask[p] && hcnt[p] > 0 && lmin[p] != lmax[p]) {  // (the per-root arrays hold something at kept roots only)
             const CBox b = bb[p];
             const long long win = (long long)(b.y2 - b.y1 + 3) * (b.x2 - b.x1 + 3);
             const int need = hcnt[p] + unl[p];  // every queue entry is a seed or a pixel that was unlabelled at the start
@@ -1611,28 +1679,30 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
     hipLaunchKernelGGL(mark_border_kernel, dim3(nblk(2 * (H + W), 256)), dim3(256), 0, st, LB, areaB, H, W);
     hipLaunchKernelGGL(fill_holes_apply_kernel, dim3(g), dim3(256), 0, st, mrk, LB, areaB, n);
     if (ccl_run(mrk, 1, LB, H, W, st)) return 1;
-    hipLaunchKernelGGL(ccl_keep_roots_kernel, dim3(g), dim3(256), 0, st, LB, areaB /*unused: min_size 0*/, -2147483647 - 1, areaB, n);
-    if (scan_exclusive(areaB, rank, n, scantmp, st)) return 1;
-    hipLaunchKernelGGL(ccl_relabel_kernel, dim3(g), dim3(256), 0, st, LB, areaB, rank, marker, n);
-    if (n_inst_out) hipLaunchKernelGGL(count_from_scan_kernel, dim3(1), dim3(1), 0, st, areaB, rank, n, n_inst_out, small);
+    // marker ids = 1 + rank of the component's root among all roots (scipy's label order), written straight into the watershed's start map
+    const int* boff = nullptr;
+    if (scan_exclusive(LB, rank, n, scantmp, st, true, &boff)) return 1;
+    if (n_inst_out) hipLaunchKernelGGL(count_roots_from_scan_kernel, dim3(1), dim3(1), 0, st, LB, rank, boff, n, n_inst_out, small);
     // (C) watershed(-inner, marker, mask)   (postproc.py:378)
-    hipLaunchKernelGGL(ws_init_out_kernel, dim3(g), dim3(256), 0, st, msk, marker, labels_out, n);
-    hipLaunchKernelGGL(ws_cap_kernel, dim3(g), dim3(256), 0, st, LA, areaA, msk, hcnt, n);
-    if (scan_exclusive(hcnt, hoff, n, scantmp, st)) return 1;
-    PP_OK(hipMemsetAsync(hcnt, 0, (size_t)n * 4, st));
+    hipLaunchKernelGGL(nuc_marker_out_kernel, dim3(g), dim3(256), 0, st, LB, rank, boff, msk, labels_out, n);
     int* unl = areaB;  // free again: per-root count of unlabelled mask pixels
-    int* wl3 = marker; // free after ws_init_out_kernel: big-window tier list
-    PP_OK(hipMemsetAsync(unl, 0, (size_t)n * 4, st));
-    int* lmin = LB;    // free after ccl_relabel_kernel
-    PP_OK(hipMemsetAsync(lmin, 0x7f, (size_t)n * 4, st));
-    PP_OK(hipMemsetAsync(lmax, 0, (size_t)n * 4, st));
+    int* wl3 = marker; // big-window tier list
+    int* lmin = LB;    // free after nuc_marker_out_kernel
+    {   // heap offsets = exclusive scan of the kept components' areas at their roots; the same pass initialises the per-root state
+        const int nbk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
+        hipLaunchKernelGGL(scan_block_cap_kernel, dim3(nbk), dim3(256), 0, st, LA, areaA, msk, hoff, nbk > 1 ? scantmp : (int*)nullptr, n, hcnt, unl, lmin, lmax, cbox, H, W);
+        KCHECK();
+        if (nbk > 1) {
+            if (scan_exclusive(scantmp, scantmp, nbk, scantmp + ((nbk + 3) & ~3), st)) return 1;
+            hipLaunchKernelGGL(scan_add_kernel, dim3(nbk), dim3(256), 0, st, hoff, scantmp, n);
+            KCHECK();
+        }
+    }
     hipLaunchKernelGGL(ws_seed_kernel, dim3(g), dim3(256), 0, st, inst, row_stride, pix_stride, msk, labels_out, LA, hoff, hcnt, hkey, hidx, H, W, unl,
                        lmin, lmax);
-    hipLaunchKernelGGL(ws_bbox_init_kernel, dim3(g), dim3(256), 0, st, LA, msk, cbox, H, W);
     hipLaunchKernelGGL(ws_bbox_kernel, dim3(g), dim3(256), 0, st, LA, msk, cbox, H, W, lmin, lmax);
     int* counts = small + 8;  // [0] window tier, [1] LDS-heap tier, [2] global tier
-    hipLaunchKernelGGL(ws_worklist_kernel, dim3(g), dim3(256), 0, st, hcnt, areaA, unl, cbox, lmin, lmax, wl, rank, wl3, wl4, counts, n);
-    hipLaunchKernelGGL(ws_fill_single_kernel, dim3(g), dim3(256), 0, st, msk, LA, lmin, lmax, labels_out, n);
+    hipLaunchKernelGGL(ws_worklist_kernel, dim3(g), dim3(256), 0, st, hcnt, areaA, unl, cbox, lmin, lmax, wl, rank, wl3, wl4, counts, n, LA, msk);
     {
         auto k_tiny = ws_flood_window_kernel<WS_TINY_WIN, WS_TINY_CAP, 4>;
         auto k_small = ws_flood_window_kernel<WS_WIN_CAP, WS_LDS_CAP, 2>;
@@ -1649,14 +1719,31 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
         // (created once per device) so that the tails overlap instead of adding up; `st` resumes when all of them are done.
         SideStreams* ss = side_streams();
         if (!ss) return cerb_set_error("cerb_postproc_nuclei: side stream creation failed");
+        if (getenv("CERB_PP_DEBUG_COUNTS")) {  // developer probe: components per flood tier
+            int hc[8] = {};
+            PP_OK(hipStreamSynchronize(st));
+            PP_OK(hipMemcpy(hc, counts, sizeof(hc), hipMemcpyDeviceToHost));
+            fprintf(stderr, "flood tiers: small-window %d, lds-heap %d, global-heap %d, big-window %d, tiny-window %d\n", hc[0], hc[1], hc[2], hc[3], hc[4]);
+        }
+        static const bool serial_floods = getenv("CERB_PP_SERIAL_FLOODS") != nullptr;  // developer probe: the tiers one after the other on `st`
+        SideStreams serial_ss;
+        if (serial_floods) {
+            serial_ss = *ss;
+            serial_ss.s[0] = serial_ss.s[1] = serial_ss.s[2] = st;
+            ss = &serial_ss;
+        }
         PP_OK(hipEventRecord(ss->fork, st));
         for (int i = 0; i < 3; ++i) PP_OK(hipStreamWaitEvent(ss->s[i], ss->fork, 0));
         hipLaunchKernelGGL(k_tiny, dim3(256 * 3), dim3(256), lds_tiny, ss->s[0], inst, row_stride, pix_stride, msk, LA, labels_out, wl4, counts + 4, cbox,
                            H, W, small + 3);
         hipLaunchKernelGGL(k_small, dim3(256 * 2), dim3(128), lds_small, ss->s[1], inst, row_stride, pix_stride, msk, LA, labels_out, wl, counts + 0, cbox,
                            H, W, small + 3);
+        // (launching this tier FIRST -- its longest flood is the critical path -- measured worse: its 151-KB workgroups then keep the other tiers off
+        // every CU that holds one; behind them it starts where they have left)
         hipLaunchKernelGGL(k_big, dim3(256), dim3(64), lds_big, st, inst, row_stride, pix_stride, msk, LA, labels_out, wl3, counts + 3, cbox, H, W,
                            small + 3);
+        // the fill of the single-label components (isolated nuclei: no flood) touches other pixels than any flood: beside them, not before them
+        hipLaunchKernelGGL(ws_fill_single_kernel, dim3(g), dim3(256), 0, ss->s[2], msk, LA, lmin, lmax, labels_out, n);
         hipLaunchKernelGGL(ws_flood_lds_kernel, dim3(256 * 2), dim3(256), 0, ss->s[2], inst, row_stride, pix_stride, msk, labels_out, rank, counts + 1,
                            hoff, hcnt, hkey, hidx, H, W, small + 3);
         hipLaunchKernelGGL(ws_flood_kernel, dim3(256 * 4), dim3(256), 0, ss->s[2], inst, row_stride, pix_stride, msk, labels_out, wl, counts + 2, hoff,

@@ -66,8 +66,43 @@ def timeline(db, first, out):
     print("wrote", out)
 
 
+def busy(db, out):
+    """Device occupancy of the last second of a trace: union of the kernel intervals / wall, the overlap between queues, the largest gaps."""
+    c = sqlite3.connect(db)
+    rows = sorted(c.execute("select start, end, queue_id, name from kernels"))
+    t1 = max(r[1] for r in rows)
+    rows = [r for r in rows if r[0] >= t1 - 1.0e9]
+    t0 = rows[0][0]
+    wall = (t1 - t0) / 1e6
+    ev = sorted([(r[0], 1) for r in rows] + [(r[1], -1) for r in rows])
+    depth, last, by_depth = 0, t0, {}
+    for t, d in ev:
+        by_depth[depth] = by_depth.get(depth, 0) + (t - last)
+        depth += d
+        last = t
+    gaps, cur_end = [], rows[0][1]
+    for a, b, q, n in rows[1:]:
+        if a > cur_end:
+            gaps.append((a - cur_end, n))
+        cur_end = max(cur_end, b)
+    gaps.sort(reverse=True)
+    with open(out, "w") as f:
+        f.write("# last %.1f ms of the trace: time with k kernels in flight (ms): %s\n" % (wall, {k: round(v / 1e6, 2) for k, v in sorted(by_depth.items())}))
+        f.write("# idle (0 in flight) %.2f %% ; sum of kernel durations / wall = %.3f\n" % (100.0 * by_depth.get(0, 0) / (t1 - t0), sum(r[1] - r[0] for r in rows) / (t1 - t0)))
+        f.write("# largest gaps (us) and the kernel that ended them:\n")
+        for g, n in gaps[:12]:
+            f.write("%8.1f  %s\n" % (g / 1e3, n[:80]))
+        per = {}
+        for a, b, q, n in rows:
+            per[q] = per.get(q, 0) + (b - a)
+        f.write("# busy per queue (ms): %s\n" % {q: round(v / 1e6, 1) for q, v in per.items()})
+    print("wrote", out)
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "timeline":
+    if sys.argv[1] == "busy":
+        busy(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "timeline":
         timeline(sys.argv[2], sys.argv[3], sys.argv[4])
     elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
