@@ -496,13 +496,16 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
         pre = make_incremental(band_view(run, H, W, canv), dist, margin=MARGINS, guard=48, max_band_px=max_band_px) if args.overlap_tail else {}
         evs = []
         for k in range(K):
-            run.infer_patches(slab, y0, cuts[k], cuts[k + 1])
-            e = torch.cuda.Event()
-            e.record()
-            evs.append(e)
-            if pre and k >= 1:
-                for lab in pre.values():
-                    lab.feed(run.rows_final(cuts[k]), [evs[k - 1]])
+            # (no join of the two handles' streams between the stripes unless the overlapped labelling needs a per-stripe completion event)
+            run.infer_patches(slab, y0, cuts[k], cuts[k + 1], join=bool(pre))
+            if pre:
+                e = torch.cuda.Event()
+                e.record()
+                evs.append(e)
+                if k >= 1:
+                    for lab in pre.values():
+                        lab.feed(run.rows_final(cuts[k]), [evs[k - 1]])
+        run.join()
         torch.cuda.synchronize()
         phase["inference_s"] = time.perf_counter() - t0
         t1 = time.perf_counter()

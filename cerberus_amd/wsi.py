@@ -172,6 +172,7 @@ class WSIRunner(object):
         self.net = net
         self.twin = twin
         self._side = None
+        self._turn = 0
         self.geo = SlideGeometry(slide_hw, patch_input_shape, patch_output_shape, patch_sel)
         self.batch = int(batch_size)
         self.rank, self.world = int(rank), int(world_size)
@@ -215,10 +216,19 @@ class WSIRunner(object):
             return 0 if n_patches_done < self.n_patches else self.band_h  # (a tissue mask drops patches: no simple row count)
         return min(self.band_h, (int(n_patches_done) // self.geo.cols) * self.geo.out)
 
-    def infer_patches(self, slab, slab_y0, p0, p1, ready=None, progress=None):
+    def join(self):
+        """Make the caller's stream wait for the side streams (two-handle mode, after infer_patches(..., join=False))."""
+        if self._side is not None:
+            cur = torch.cuda.current_stream(self.dev)
+            for s in self._side:
+                cur.wait_stream(s)
+
+    def infer_patches(self, slab, slab_y0, p0, p1, ready=None, progress=None, join=True):
         """Patches [p0, p1) of this band's row-major patch list (bench.py times a slide as K such stripes).
         progress: optional callable(n_done, events) after every queued batch: the first n_done patches of the list are complete once `events`
-        (one per stream in use) are -- what shard_postproc.IncrementalLocalLabeller.feed wants."""
+        (one per stream in use) are -- what shard_postproc.IncrementalLocalLabeller.feed wants.
+        join=False (two-handle mode): the caller's stream does not wait for the side streams at the end -- a job cut into many short calls (bench.py's K
+        stripes, a few batches each on 8 GPUs) then keeps both streams full across the calls; call join() before anything reads the canvases."""
         g = self.geo
         assert slab.shape[1] == g.W
         p0, p1 = max(0, int(p0)), min(self.n_patches, int(p1))
@@ -236,7 +246,7 @@ class WSIRunner(object):
             e.record(stream)
             return e
 
-        if self.twin is None or p1 - p0 <= self.batch:
+        if self.twin is None or (p1 - p0 <= self.batch and join):
             for b0 in range(p0, p1, self.batch):
                 one(self.net, b0)
                 if progress is not None:
@@ -252,16 +262,16 @@ class WSIRunner(object):
         for s in self._side:
             s.wait_event(fork)
         last = [fork, fork]
-        for i, b0 in enumerate(range(p0, p1, self.batch)):
+        for b0 in range(p0, p1, self.batch):
+            i = self._turn  # the alternation goes on across calls
+            self._turn += 1
             with torch.cuda.stream(self._side[i & 1]):
                 one(nets[i & 1], b0)
             if progress is not None:
                 last[i & 1] = mark(self._side[i & 1])
                 progress(min(p1, b0 + self.batch), list(last))
-        for s in self._side:
-            join = torch.cuda.Event()
-            join.record(s)
-            cur.wait_event(join)
+        if join:
+            self.join()
         return p1 - p0
 
     def gather_to_root(self, dist=None):
