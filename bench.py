@@ -587,16 +587,17 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
 
         def ref_job():
             res["ref"] = reference_tiled_nuclei_sharded(struct["Nuclei-INST"], tmap, run.r0 * TILE, (H, W), rank, world, dist, tile_shape=4096, margin=64,
-                                                        patch_output_shape=TILE, exact_ties=True, watch=args.watch, prof=tprof)
+                                                        patch_output_shape=TILE, exact_ties=True, watch=args.watch, prof=tprof, as_part=True)
 
         rdt = _timed(ref_job, dev, dist, args.backend)
         if rank == 0:
-            n_ref, n_band = len(res["ref"]), n_inst.get("Nuclei", 0)
+            n_ref, n_band = int(len(res["ref"][1])), n_inst.get("Nuclei", 0)
             rt = {"ref_tiling_s": round(rdt, 3), "Mpx_s": round(H * W / rdt / 1e6, 1), "instances": n_ref, "band_scheme_instances": n_band,
                   "instances_lost_by_the_reference_scheme": round(1.0 - n_ref / max(1, n_band), 5),
                   "rank0": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in tprof.items()},
-                  "note": "nuclei instance DICTIONARY (boxes, centroids, contours, types) by the reference's own tile sets; compare with dat.dictionary_s + "
-                          "postproc.Nuclei.s of the band scheme"}
+                  "note": "nuclei instance tables + contours (the arrays the .dat writer takes: boxes, centroid sums, contour runs, type votes, tile origins) by "
+                          "the reference's own tile sets, no Python object per instance; compare with dat.tables_and_contours_s + postproc.Nuclei.s of the "
+                          "band scheme"}
         res.clear()
     # secondary: the inner loop alone (configs[1]) + the per-kernel table of one batch step
     bdt, bstep, bn = batch_loop(model, dev, rank, 20, 3, None, args.backend)

@@ -11,13 +11,15 @@ from collections import OrderedDict
 import numpy as np
 
 
-def info_from_table(tab, cnts, pts, offs, has_type, ds_factor=1.0, flat_box=False):
+def info_from_table(tab, cnts, pts, offs, has_type, ds_factor=1.0, flat_box=False, origin=None):
     """Host side of get_inst_info_dict: the per-instance dictionaries from cerb_inst_table's rows and the compact contour list.
     Everything numeric is computed for all instances at once; the per-instance values are row views of those arrays (a slide has
     ~1e6 nuclei: array construction per instance would dominate the whole slide).  Rules kept from loader/postproc.py:34-35,55-75,
     78-96 (flat_box: the slide dictionary's [x1, y1, x2, y2] form of infer/wsi.py:817-825 instead of [[y1, x1], [y2, x2]]):
     drop contours with < 3 points; majority type, skipping background when a second class exists; type_prob =
-    votes / (area + 1e-6); with ds_factor != 1 box / centroid / contour are np.round(x / ds_factor).astype(int)."""
+    votes / (area + 1e-6); with ds_factor != 1 box / centroid / contour are np.round(x / ds_factor).astype(int).
+    origin: optional int [n, 2] (x, y) added to every coordinate of instance i AFTER all of the above -- instances measured inside a tile
+    (cerberus_amd/ref_tiling.py) placed in the slide, with the arithmetic of `value + offset` on the finished values."""
     from collections import OrderedDict
 
     n = tab.shape[0]
@@ -37,6 +39,11 @@ def info_from_table(tab, cnts, pts, offs, has_type, ds_factor=1.0, flat_box=Fals
         pts = np.round(pts / ds_factor).astype("int")
     if flat_box:
         box = box.reshape(n, 4)[:, [1, 0, 3, 2]]
+    if origin is not None:
+        origin = np.asarray(origin, dtype=np.int64).reshape(n, 2)
+        box = box + (np.concatenate([origin, origin], axis=1) if flat_box else origin[:, None, ::-1])
+        cen = cen + origin
+        pts = pts + np.repeat(origin, np.asarray(cnts, dtype=np.int64), axis=0)[: len(pts)] if len(pts) == int(np.sum(cnts)) else _shift_points(pts, cnts, offs, origin)
     if has_type:
         votes = tab[:, 8:16]
         # dominant class first, ties towards the smaller class id (np.unique order + stable sort of the reference)
@@ -54,6 +61,14 @@ def info_from_table(tab, cnts, pts, offs, has_type, ds_factor=1.0, flat_box=Fals
             d["type_prob"] = prob_l[i]
         info[i + 1] = d
     return info
+
+
+def _shift_points(pts, cnts, offs, origin):
+    """pts + origin[i] for the points of instance i when the point list is not simply the concatenation of the instances' runs."""
+    out = np.array(pts, copy=True)
+    for i in np.nonzero(np.asarray(cnts) > 0)[0].tolist():
+        out[offs[i]:offs[i] + cnts[i]] += origin[i]
+    return out
 
 
 def _uuid4_hex(n):
@@ -213,7 +228,9 @@ def write_dat_fast(parts, meta, path, extra=None):
             return dts[key]
 
         prepared = []
-        for tissue, tab, cnts, pts, offs, has_type, ds_factor in parts:
+        for part in parts:
+            tissue, tab, cnts, pts, offs, has_type, ds_factor = part[:7]
+            origin = np.asarray(part[7], dtype=np.int64).reshape(-1, 2) if len(part) > 7 and part[7] is not None else None
             n = tab.shape[0]
             area = tab[:, 0] if n else np.zeros(0, np.int64)
             keep = np.nonzero((area > 0) & (cnts >= 3))[0] if n else np.zeros(0, np.int64)
@@ -227,10 +244,15 @@ def write_dat_fast(parts, meta, path, extra=None):
                 box = np.round(box / ds_factor).astype("int")
                 cen = np.round(cen / ds_factor).astype("int")
                 pts = np.round(pts / ds_factor).astype("int")
-            box = np.ascontiguousarray(box.reshape(n, 4)[:, [1, 0, 3, 2]][keep])
+            box = box.reshape(n, 4)[:, [1, 0, 3, 2]]
+            if origin is not None:
+                box = box + np.concatenate([origin, origin], axis=1)
+                cen = cen + origin
+            box = np.ascontiguousarray(box[keep])
             cen = np.ascontiguousarray(cen[keep])
-            pts = np.ascontiguousarray(pts)
+            pts = np.ascontiguousarray(pts.astype(np.int64) if origin is not None else pts)  # (points + int64 origin: int64, as numpy promotes in the object path)
             kc, ko = cnts[keep].astype(np.int64), offs[keep].astype(np.int64)
+            korg = origin[keep] if origin is not None else None
             dt_box, dt_cen, dt_pts = dtype_index(box.dtype), dtype_index(cen.dtype), dtype_index(pts.dtype)
             # ---- the contours, grouped by point count: fixed-size rows, each array memoised and popped
             cidx = np.zeros(keep.size, np.int64)
@@ -241,6 +263,8 @@ def write_dat_fast(parts, meta, path, extra=None):
                 rec = np.empty((rows.size, len(tmpl) + 6), np.uint8)
                 rec[:, :len(tmpl)] = _u8(tmpl)
                 gathered = pts[ko[rows][:, None] + np.arange(k)[None, :]]  # [rows, k, 2]
+                if korg is not None:
+                    gathered = gathered + korg[rows][:, None, :].astype(gathered.dtype)
                 rec[:, pay:pay + k * isz] = gathered.reshape(rows.size, -1).view(np.uint8).reshape(rows.size, k * isz)
                 base = memo.n
                 memo.n += rows.size
@@ -319,10 +343,11 @@ def write_dat_fast(parts, meta, path, extra=None):
 
 
 def build_from_parts(parts, meta):
-    """parts: [(tissue, tab, cnts, pts, offs, has_type, ds_factor)]; meta: the resolution entries.  -> the dictionary of infer/wsi.py:805-853."""
+    """parts: [(tissue, tab, cnts, pts, offs, has_type, ds_factor[, origin])]; meta: the resolution entries.  -> the dictionary of infer/wsi.py:805-853."""
     out = OrderedDict()
-    for tissue, tab, cnts, pts, offs, has_type, ds_factor in parts:
-        info = info_from_table(tab, cnts, pts, offs, bool(has_type), float(ds_factor), flat_box=True)
+    for part in parts:
+        tissue, tab, cnts, pts, offs, has_type, ds_factor = part[:7]
+        info = info_from_table(tab, cnts, pts, offs, bool(has_type), float(ds_factor), flat_box=True, origin=part[7] if len(part) > 7 else None)
         out[tissue] = OrderedDict(zip(_uuid4_hex(len(info)), info.values()))
     out.update(meta)
     return out
@@ -333,6 +358,8 @@ def save_parts(path, parts, meta):
     arrs = {"tissues": np.array([p[0] for p in parts]), "has_type": np.array([int(bool(p[5])) for p in parts]), "ds_factor": np.array([float(p[6]) for p in parts])}
     for i, p in enumerate(parts):
         arrs["tab%d" % i], arrs["cnts%d" % i], arrs["pts%d" % i], arrs["offs%d" % i] = p[1], p[2], p[3], p[4]
+        if len(p) > 7 and p[7] is not None:
+            arrs["origin%d" % i] = np.asarray(p[7], dtype=np.int64)
     for k, v in meta.items():
         arrs["meta/" + k] = np.asarray(v["resolution"] if isinstance(v, dict) else v)
         if isinstance(v, dict):
@@ -344,6 +371,7 @@ def save_parts(path, parts, meta):
 def load_parts(path):
     z = np.load(path, allow_pickle=False)
     parts = [(str(t), z["tab%d" % i], z["cnts%d" % i], z["pts%d" % i], z["offs%d" % i], bool(z["has_type"][i]), float(z["ds_factor"][i]))
+             + ((z["origin%d" % i],) if ("origin%d" % i) in z.files else ())
              for i, t in enumerate(z["tissues"])]
     meta = OrderedDict()
     for k in z.files:

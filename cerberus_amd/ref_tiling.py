@@ -94,6 +94,122 @@ def _tile_instances(inst_canvas, type_canvas, bounds, exact_ties, y_off=0, slide
     return items, boxes
 
 
+def _tile_arrays(inst_canvas, type_canvas, bounds, exact_ties, y_off=0, slide_hw=None):
+    """_tile_instances without a Python object per instance: the valid rows (area > 0, contour of >= 3 points: loader/postproc.py:34-35) of the tile's
+    instance table, their contour runs re-packed, boxes [n, 4] as x0, y0, x1, y1 -- all in TILE coordinates.  -> (tab, cnts, pts, offs, boxes, has_type)"""
+    from .postproc import inst_contours_device, inst_table_device
+
+    H, W = (int(inst_canvas.shape[0]) + int(y_off), int(inst_canvas.shape[1])) if slide_hw is None else (int(slide_hw[0]), int(slide_hw[1]))
+    x0, y0, x1, y1 = max(int(bounds[0]), 0), max(int(bounds[1]), 0), min(int(bounds[2]), W), min(int(bounds[3]), H)
+    empty = (np.zeros((0, 16), np.int64), np.zeros(0, np.int64), np.zeros((0, 2), np.int64), np.zeros(0, np.int64), np.zeros((0, 4), np.int64), type_canvas is not None)
+    if x1 <= x0 or y1 <= y0:
+        return empty
+    assert y0 >= y_off and y1 - y_off <= int(inst_canvas.shape[0]), "tile rows outside the rows this rank holds"
+    lab, _ = postproc_device(inst_canvas[y0 - y_off:y1 - y_off, x0:x1], "Nuclei", exact_ties=exact_ties)
+    tmap = None if type_canvas is None else type_canvas[y0 - y_off:y1 - y_off, x0:x1].contiguous()
+    lab = lab.contiguous()
+    tab_dev = inst_table_device(lab, tmap)
+    cnts, pts, offs = inst_contours_device(lab, tab_dev)
+    tab = tab_dev.cpu().numpy()
+    cnts, offs = np.asarray(cnts, dtype=np.int64), np.asarray(offs, dtype=np.int64)
+    valid = np.nonzero((tab[:, 0] > 0) & (cnts >= 3))[0] if len(tab) else np.zeros(0, np.int64)
+    if valid.size == 0:
+        return empty
+    tab, cnts, offs = tab[valid], cnts[valid], offs[valid]
+    idx = np.repeat(offs, cnts) + (np.arange(int(cnts.sum())) - np.repeat(np.cumsum(cnts) - cnts, cnts))  # the kept runs, packed
+    pts = np.asarray(pts)[idx]
+    offs = np.cumsum(cnts) - cnts
+    return tab, cnts, pts, offs, tab[:, [5, 3, 6, 4]].astype(np.int64), type_canvas is not None
+
+
+def process_tile_arrays(inst_canvas, type_canvas, tile_bounds, tile_flag, tile_mode, margin, exact_ties=True, y_off=0, slide_hw=None):
+    """process_tile_predictions on arrays: the kept instances of one tile as (tab, cnts, pts, origin [n, 2]) -- table rows and contour points in
+    TILE coordinates plus the tile's (x, y) origin per instance (cerberus_amd.inst_info places them) -- and their boxes in SLIDE coordinates."""
+    tl = np.array([int(tile_bounds[0]), int(tile_bounds[1])], dtype=np.int64)
+    w, h = int(tile_bounds[2]) - int(tile_bounds[0]), int(tile_bounds[3]) - int(tile_bounds[1])
+    tab, cnts, pts, offs, boxes, has_type = _tile_arrays(inst_canvas, type_canvas, tile_bounds, exact_ties, y_off, slide_hw)
+    if len(tab) == 0:
+        return {"tab": tab, "cnts": cnts, "pts": pts, "origin": np.zeros((0, 2), np.int64), "boxes": boxes, "has_type": has_type}
+    m = int(margin)
+    boundary_lines = [(0, 0, w, 1), (0, h - 1, w, h), (0, 0, 1, h), (w - 1, 0, w, h)]
+    margin_boxes = [(0, 0, w, m), (0, h - m, w, h), (0, 0, m, h), (w - m, 0, w, h)]
+    drop = np.zeros(len(tab), bool)
+    if tile_mode in (0, 3):
+        for side, zone in enumerate(margin_boxes):
+            if tile_flag[side] or tile_mode == 3:
+                drop |= _hits(boxes, zone) & _inside(boxes, zone)
+    elif tile_mode in (1, 2):
+        for side, flag in enumerate(tile_flag):
+            drop |= _hits(boxes, margin_boxes[side] if flag else boundary_lines[side])
+    else:
+        raise ValueError("Unknown tile mode %r." % (tile_mode,))
+    keep = np.nonzero(~drop)[0]
+    kc, ko = cnts[keep], offs[keep]
+    idx = np.repeat(ko, kc) + (np.arange(int(kc.sum())) - np.repeat(np.cumsum(kc) - kc, kc))
+    return {"tab": tab[keep], "cnts": kc, "pts": pts[idx], "origin": np.tile(tl, (len(keep), 1)), "boxes": boxes[keep] + np.concatenate([tl, tl]),
+            "has_type": has_type}
+
+
+def merge_tile_arrays(parts, tile_info, margin):
+    """merge_tile_results on arrays -> the ("Nuclei", tab, cnts, pts, offs, has_type, 1.0, origin) tuple cerberus_amd.inst_info builds the
+    dictionary (or the .dat stream) from: sets in order 0..3, tiles of a set in order, a cross section evicting what was accumulated before ITS SET
+    and touches one of its inner margin lines."""
+    chunks, alive, has_type = [], [], False
+    for mode, (bounds, _) in enumerate(tile_info):
+        n_before = len(chunks)
+        ref_boxes = np.concatenate([c["boxes"] for c in chunks], axis=0) if (mode == 3 and chunks) else np.zeros((0, 4), np.int64)
+        ref_alive = np.concatenate(alive) if (mode == 3 and alive) else np.zeros(0, bool)
+        evict = np.zeros(len(ref_boxes), bool)
+        cand = np.zeros(0, np.int64)
+        if mode == 3 and len(ref_boxes) and len(bounds):
+            xs = np.unique([int(b[0]) for b in bounds])
+            ys = np.unique([int(b[1]) for b in bounds])
+            wx, wy = int(bounds[0][2]) - int(bounds[0][0]), int(bounds[0][3]) - int(bounds[0][1])
+            ix = np.searchsorted(xs, ref_boxes[:, 2], side="right") - 1
+            iy = np.searchsorted(ys, ref_boxes[:, 3], side="right") - 1
+            near = (ix >= 0) & (ref_boxes[:, 0] <= xs[np.maximum(ix, 0)] + wx) & (iy >= 0) & (ref_boxes[:, 1] <= ys[np.maximum(iy, 0)] + wy)
+            cand = np.nonzero(near & ref_alive)[0]
+        for ti in range(len(bounds)):
+            c = parts.get((mode, ti))
+            if mode == 3 and len(cand):
+                sel = np.zeros(len(cand), bool)
+                for line in eviction_lines(bounds[ti], margin):
+                    sel |= _hits(ref_boxes[cand], line)
+                evict[cand[sel]] = True
+            if c is not None and len(c["tab"]):
+                chunks.append(c)
+                alive.append(np.ones(len(c["tab"]), bool))
+                has_type = has_type or bool(c["has_type"])
+        if mode == 3 and evict.any():
+            pos = 0
+            for j in range(n_before):
+                k = len(alive[j])
+                alive[j] &= ~evict[pos:pos + k]
+                pos += k
+    if not chunks:
+        return ("Nuclei", np.zeros((0, 16), np.int64), np.zeros(0, np.int64), np.zeros((0, 2), np.int64), np.zeros(0, np.int64), has_type, 1.0, np.zeros((0, 2), np.int64))
+    tabs, cntss, ptss, orgs = [], [], [], []
+    for c, a in zip(chunks, alive):
+        keep = np.nonzero(a)[0]
+        if keep.size == len(a):
+            tabs.append(c["tab"]); cntss.append(c["cnts"]); ptss.append(c["pts"]); orgs.append(c["origin"])
+            continue
+        kc = c["cnts"][keep]
+        ko = (np.cumsum(c["cnts"]) - c["cnts"])[keep]
+        idx = np.repeat(ko, kc) + (np.arange(int(kc.sum())) - np.repeat(np.cumsum(kc) - kc, kc))
+        tabs.append(c["tab"][keep]); cntss.append(kc); ptss.append(c["pts"][idx]); orgs.append(c["origin"][keep])
+    cnts = np.concatenate(cntss)
+    return ("Nuclei", np.concatenate(tabs), cnts, np.concatenate(ptss), np.cumsum(cnts) - cnts, has_type, 1.0, np.concatenate(orgs))
+
+
+def nuclei_dict_from_part(part):
+    """{uuid4 hex -> {'box': [x1, y1, x2, y2], 'centroid', 'contour', 'type', 'type_prob'}} of a merge_tile_arrays result (slide coordinates)."""
+    from .inst_info import _uuid4_hex, info_from_table
+
+    info = info_from_table(part[1], part[2], part[3], part[4], bool(part[5]), 1.0, flat_box=True, origin=part[7])
+    return OrderedDict(zip(_uuid4_hex(len(info)), info.values()))
+
+
 def eviction_lines(tile_bounds, margin):
     """The four inner margin lines of a cross section in slide coordinates (infer/wsi.py:241-255): accumulated instances touching one are removed."""
     tl = (int(tile_bounds[0]), int(tile_bounds[1]))
@@ -144,7 +260,7 @@ def merge_tile_results(parts, tile_info, margin):
     """parts: {(mode, tile index): kept dictionaries}, from one rank or gathered from all.  The accumulation of infer/wsi.py:642-684: sets in
     order 0..3, tiles of a set in order; a cross section (set 3) evicts what had been accumulated BEFORE its set and touches one of its inner
     margin lines (every tile of a set sees the dictionary as it was when the set was submitted), then adds its own instances."""
-    import uuid
+    from .inst_info import _uuid4_hex
 
     acc = OrderedDict()
     for mode, (bounds, _) in enumerate(tile_info):
@@ -169,8 +285,8 @@ def merge_tile_results(parts, tile_info, margin):
                     sel |= _hits(ref_boxes[cand], line)
                 for r in cand[sel].tolist():
                     acc.pop(keys[r], None)
-            for v in kept:
-                acc[uuid.uuid4().hex] = v
+            for k, v in zip(_uuid4_hex(len(kept)), kept):  # (one os.urandom call per tile: uuid.uuid4() per instance was 1.3 s of a slide's merge)
+                acc[k] = v
     return acc
 
 
@@ -189,20 +305,23 @@ def _rank_tiles(tile_info, band_bounds, slide_h):
     return mine, need_hi
 
 
-def reference_tiled_nuclei(inst_canvas, type_canvas=None, tile_shape=4096, margin=64, patch_output_shape=144, exact_ties=True, prof=None):
+def reference_tiled_nuclei(inst_canvas, type_canvas=None, tile_shape=4096, margin=64, patch_output_shape=144, exact_ties=True, prof=None, as_part=False):
     """The nuclei loop of infer/wsi.py:642-684 over a device-resident INST canvas [H, W, 2] (and uint8 TYPE canvas [H, W]):
     OrderedDict {uuid4 hex -> {'box': [x1, y1, x2, y2], 'centroid', 'contour', 'type', 'type_prob'}} in slide coordinates."""
     return reference_tiled_nuclei_sharded(inst_canvas, type_canvas, 0, (int(inst_canvas.shape[0]), int(inst_canvas.shape[1])), 0, 1, None, tile_shape, margin,
-                                          patch_output_shape, exact_ties, prof=prof)
+                                          patch_output_shape, exact_ties, prof=prof, as_part=as_part)
 
 
 def reference_tiled_nuclei_sharded(band_inst, band_type, band_y0, slide_hw, rank, world, dist, tile_shape=4096, margin=64, patch_output_shape=144,
-                                   exact_ties=True, watch=None, prof=None):
+                                   exact_ties=True, watch=None, prof=None, as_part=False):
     """The same over N ranks that each hold a band of the slide's canvases (rows band_y0 .. band_y0 + band_inst.shape[0]): tiles are
     independent, so every rank labels the tiles whose first row lies in its band -- after fetching the rows those tiles reach into below its
     band from the ranks that hold them (point-to-point, upwards only: a tile never starts above its owner's band) -- and the root merges the
     kept instances in the reference's order, applying the cross sections' evictions there (they look at instances of any rank).
-    Returns the dictionary on rank 0, None elsewhere.  prof: dict receiving seconds per phase."""
+    Returns the dictionary on rank 0, None elsewhere.  prof: dict receiving seconds per phase.
+    Tiles and merge work on ARRAYS (instance-table rows, contour runs, boxes): no Python object per instance until -- unless as_part -- the
+    dictionary is built once at the end; as_part=True returns the ("Nuclei", tab, cnts, pts, offs, has_type, 1.0, origin) tuple instead, which
+    cerberus_amd.inst_info turns into the `.dat` stream directly (write_dat_fast) or into the same dictionary (nuclei_dict_from_part)."""
     import time
 
     from .launch import null_watch
@@ -261,13 +380,12 @@ def reference_tiled_nuclei_sharded(band_inst, band_type, band_y0, slide_hw, rank
     parts = {}
     for mode, ti in mine[rank]:
         bounds, flags = tile_info[mode]
-        kept, _ = process_tile_predictions(canvas, tcanvas, bounds[ti], flags[ti], mode, None, margin, exact_ties, y_off=y0, slide_hw=(H, W))
-        parts[(mode, ti)] = kept
+        parts[(mode, ti)] = process_tile_arrays(canvas, tcanvas, bounds[ti], flags[ti], mode, margin, exact_ties, y_off=y0, slide_hw=(H, W))
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     if world > 1 and dist is not None:
         lst = [None] * world if rank == 0 else None
-        with watch.phase("reference tiling: per-tile dictionaries to rank 0"):
+        with watch.phase("reference tiling: per-tile instance arrays to rank 0"):
             dist.gather_object(parts, lst, dst=0)
         if rank != 0:
             if prof is not None:
@@ -276,7 +394,10 @@ def reference_tiled_nuclei_sharded(band_inst, band_type, band_y0, slide_hw, rank
         parts = {}
         for p in lst:
             parts.update(p)
-    acc = merge_tile_results(parts, tile_info, margin)
+    part = merge_tile_arrays(parts, tile_info, margin)
+    t3 = time.perf_counter()
+    acc = part if as_part else nuclei_dict_from_part(part)
     if prof is not None:
-        prof.update(exchange_s=t1 - t0, tiles_s=t2 - t1, merge_s=time.perf_counter() - t2, tiles=len(mine[rank]), tiles_total=sum(len(b) for b, _ in tile_info))
+        prof.update(exchange_s=t1 - t0, tiles_s=t2 - t1, merge_s=t3 - t2, dictionary_s=time.perf_counter() - t3, instances=int(len(part[1])),
+                    tiles=len(mine[rank]), tiles_total=sum(len(b) for b, _ in tile_info))
     return acc

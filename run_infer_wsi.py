@@ -232,7 +232,7 @@ def main(argv=None):
             tprof = {}
             ref_nuclei = reference_tiled_nuclei_sharded(run.canv["Nuclei-INST"][:valid], None if "Nuclei-TYPE" not in run.canv else run.canv["Nuclei-TYPE"][:valid],
                                                         run.r0 * out, (H, W), rank, world, dist, tile_shape=4096, margin=64, patch_output_shape=out, watch=watch,
-                                                        prof=tprof)
+                                                        prof=tprof, as_part=True)  # arrays: the writer process builds the entries
             if log:
                 log.info("Reference-Tiled Nuclei Time: {0} ({1} tiles on rank 0)".format(time.perf_counter() - t2, tprof.get("tiles")))
         if rank != 0:
@@ -270,8 +270,6 @@ def main(argv=None):
         nuc_only = {k: v for k, v in inst.items() if k == "Nuclei"} if records is not None else inst
         bw, bh = reader.info.slide_dimensions
         prebuilt = None
-        if ref_nuclei is not None:
-            prebuilt = {"Nuclei": ref_nuclei}
         # The dictionary's GPU half (tables, contours) here; its ~1e6 per-instance Python objects, the uuid keys and the pickle in a separate,
         # torch-free writer process underneath the next slide (cerberus_amd.wsi.DatWriter.from_arrays); a finished dat/<slide>.dat is always
         # complete (written to a temporary name and renamed) -- the resume-by-skip above relies on that.
@@ -286,7 +284,9 @@ def main(argv=None):
                         dst[uuid.uuid4().hex] = v
         for tissue, d in (prebuilt or {}).items():
             extra[tissue] = d
-        parts = collect_wsi_inst_arrays(nuc_only, maps, (H, W), skip=tuple(extra.keys()))
+        parts = collect_wsi_inst_arrays(nuc_only, maps, (H, W), skip=tuple(extra.keys()) + (("Nuclei",) if ref_nuclei is not None else ()))
+        if ref_nuclei is not None:  # the reference-tiled nuclei replace the band scheme's: same kind of arrays (+ per-instance tile origins)
+            parts.insert(0, ref_nuclei)
         meta = wsi_meta((H, W), float(args["--wsi_proc_mag"]), base_mag=None if reader.info.mpp is None else float(reader.info.mpp[0]), base_hw=(bh, bw))
         if writer is not None:
             writer.join()
