@@ -865,6 +865,70 @@ __global__ __launch_bounds__(256) void upadd_bwd_prev_kernel(const float* __rest
         *o = pv;
     }
 }
+// Both gradients of the decoder entry in ONE pass over dout (round 4: the two kernels above read it twice -- 4.9 ms of a 174 ms step at 0.38 of HBM):
+// thread = four channels of a SOURCE pixel (pm, pn) of the level below, all groups: the <= 4 x 4 output pixels it feeds give dprev (same loops, same
+// order as upadd_bwd_prev_kernel: identical bits), and the 2 x 2 of them it owns -- rows 2 pm, 2 pm + 1, columns 2 pn, 2 pn + 1 -- give dskip
+// (sum over the groups in group order, then added: as upadd_bwd_skip_kernel).
+__global__ __launch_bounds__(256) void upadd_bwd_fused_kernel(const float* __restrict__ dout, float* __restrict__ dskip, float* __restrict__ dprev, int G, int N,
+                                                              int H, int W, int C, long long prev_gs, int shared_prev) {
+    const int Hp = H / 2, Wp = W / 2, C4 = C >> 2;
+    const long long total = (long long)N * Hp * Wp * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int c = 4 * (int)(r % C4);
+        r /= C4;
+        const int pn = (int)(r % Wp);
+        r /= Wp;
+        const int pm = (int)(r % Hp), n = (int)(r / Hp);
+        float4 sk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sk[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int gg = 0; gg < G; ++gg) {
+            if (!shared_prev) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int y = max(2 * pm - 2, 0); y <= min(2 * pm + 2, H - 1); ++y) {
+                int a0, a1;
+                float u0, u1;
+                up2_taps(y, Hp, a0, a1, u0, u1);
+                const float wy = (a0 == pm ? u0 : 0.f) + (a1 == pm ? u1 : 0.f);
+                if (wy == 0.f) continue;
+                for (int x = max(2 * pn - 2, 0); x <= min(2 * pn + 2, W - 1); ++x) {
+                    int b0, b1;
+                    float v0, v1;
+                    up2_taps(x, Wp, b0, b1, v0, v1);
+                    const float wx = (b0 == pn ? v0 : 0.f) + (b1 == pn ? v1 : 0.f);
+                    if (wx == 0.f) continue;
+                    const float4 d = *reinterpret_cast<const float4*>(dout + ((((long long)gg * N + n) * H + y) * W + x) * C + c);
+                    const float wgt = wy * wx;
+                    acc.x += wgt * d.x; acc.y += wgt * d.y; acc.z += wgt * d.z; acc.w += wgt * d.w;
+                    if ((y >> 1) == pm && (x >> 1) == pn) {
+                        float4& t = sk[(y & 1) * 2 + (x & 1)];
+                        t.x += d.x; t.y += d.y; t.z += d.z; t.w += d.w;
+                    }
+                }
+            }
+            if (!shared_prev) {
+                float4* o = reinterpret_cast<float4*>(dprev + gg * prev_gs + (((long long)n * Hp + pm) * Wp + pn) * C + c);
+                float4 pv = *o;
+                pv.x += acc.x; pv.y += acc.y; pv.z += acc.z; pv.w += acc.w;
+                *o = pv;
+            }
+        }
+        if (shared_prev) {
+            float4* o = reinterpret_cast<float4*>(dprev + (((long long)n * Hp + pm) * Wp + pn) * C + c);
+            float4 pv = *o;
+            pv.x += acc.x; pv.y += acc.y; pv.z += acc.z; pv.w += acc.w;
+            *o = pv;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4* o = reinterpret_cast<float4*>(dskip + (((long long)n * H + 2 * pm + (k >> 1)) * W + 2 * pn + (k & 1)) * C + c);
+            float4 pv = *o;
+            pv.x += sk[k].x; pv.y += sk[k].y; pv.z += sk[k].z; pv.w += sk[k].w;
+            *o = pv;
+        }
+    }
+}
 // data gradient of a 1x1 stride-2 conv (the residual downsample branches): only the even input positions receive anything --
 // dx[n][2 yo][2 xo][ci] += sum_co dy[n][yo][xo][co] W[co][ci]; thread = (output pixel, ci), the dy row is a broadcast
 __global__ __launch_bounds__(256) void conv1x1s2_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int N, int H, int W,
@@ -1108,6 +1172,10 @@ hipError_t cerb_launch_maxpool_bwd(const float* x, const float* ypool, const flo
     return hipGetLastError();
 }
 hipError_t cerb_launch_upadd_bwd(const float* dout, float* dskip, float* dprev, int G, int N, int H, int W, int C, long long prev_gs, int shared_prev, hipStream_t st) {
+    if (C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && !getenv("CERB_UPADD_BWD_TWO_PASS")) {
+        hipLaunchKernelGGL(upadd_bwd_fused_kernel, dim3(gridfor((long long)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, st, dout, dskip, dprev, G, N, H, W, C, prev_gs, shared_prev);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(upadd_bwd_skip_kernel, dim3(gridfor((long long)N * H * W * C)), dim3(256), 0, st, dout, dskip, G, (long long)N * H * W * C);
     hipLaunchKernelGGL(upadd_bwd_prev_kernel, dim3(gridfor((long long)N * (H / 2) * (W / 2) * (C / 4) * (shared_prev ? 1 : G))), dim3(256), 0, st, dout, dprev, G, N, H, W, C,
                        prev_gs, shared_prev);
