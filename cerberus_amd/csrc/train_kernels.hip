@@ -947,6 +947,47 @@ __global__ __launch_bounds__(256) void conv1x1s2_dgrad_kernel(const float* __res
         dx[(((long long)n * H + 2 * yo) * W + 2 * xo) * Cin + ci] += acc;
     }
 }
+// Data gradient of a 1x1 convolution (stride 1 or 2) with EIGHT output pixels per workgroup pass: their dy rows are staged in LDS once (coalesced), a
+// thread = one input channel then reads four dy values of a row per ds_read_b128 (a broadcast) and four weight values (coalesced, independent) per
+// 32 multiply-adds.  The one-row kernels issued a 64-lane broadcast load of dy and a weight load per multiply-add, each behind the previous one's
+// wait: 0.6 ms per layer whatever its shape, 3 % of the vector pipe.  Per row the products are added in the same order: identical bits.
+__global__ __launch_bounds__(256) void conv1x1_dgrad8_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int N, int H, int W,
+                                                             int Cin, int Cout, int stride) {
+    extern __shared__ __attribute__((aligned(16))) float dyl[];  // [8][Cout]
+    const int Ho = H / stride, Wo = W / stride;
+    const long long rows = (long long)N * Ho * Wo, nrb = (rows + 7) / 8;
+    for (long long rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+        const long long r0 = rb * 8;
+        const int nr = (int)min(8ll, rows - r0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 8 * Cout; i += blockDim.x) dyl[i] = i < nr * Cout ? dy[r0 * Cout + i] : 0.f;
+        __syncthreads();
+        for (int ci = threadIdx.x; ci < Cin; ci += blockDim.x) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int co = 0; co < Cout; co += 4) {
+                const float w0 = w[(long long)co * Cin + ci], w1 = w[(long long)(co + 1) * Cin + ci], w2 = w[(long long)(co + 2) * Cin + ci],
+                            w3 = w[(long long)(co + 3) * Cin + ci];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 d = *reinterpret_cast<const float4*>(dyl + j * Cout + co);
+                    acc[j] = fmaf(d.x, w0, acc[j]);
+                    acc[j] = fmaf(d.y, w1, acc[j]);
+                    acc[j] = fmaf(d.z, w2, acc[j]);
+                    acc[j] = fmaf(d.w, w3, acc[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nr) {
+                    const long long r = r0 + j;
+                    const int xo = (int)(r % Wo);
+                    const long long r2 = r / Wo;
+                    const int yo = (int)(r2 % Ho), n = (int)(r2 / Ho);
+                    dx[(((long long)n * H + stride * yo) * W + stride * xo) * Cin + ci] += acc[j];
+                }
+        }
+    }
+}
 // pointwise (1x1) backward: dx[r][ci] += scale * sum_co dy[r][co] W[co][ci];  dW[co][ci] = sum_r dy[r][co] x[r][ci] scale
 __global__ __launch_bounds__(256) void pointwise_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, long long rows, int cin,
                                                               int cout, const float* __restrict__ in_scale, int assign) {
@@ -1156,7 +1197,11 @@ hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, f
 hipError_t cerb_launch_conv_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int G, int N, int H, int W, int Cin, int Cout,
                                 int ks, int stride, long long x_gs, hipStream_t st) {
     const int Ho = stride == 2 ? H / 2 : H, Wo = stride == 2 ? W / 2 : W;
-    if (dx && ks == 1 && stride == 2 && G == 1 && H % 2 == 0 && W % 2 == 0)
+    if (dx && ks == 1 && G == 1 && Cout % 4 == 0 && Cout * 32 <= 64 * 1024 && (stride == 1 || (stride == 2 && H % 2 == 0 && W % 2 == 0))) {
+        const long long nrb = ((long long)N * Ho * Wo + 7) / 8;
+        hipLaunchKernelGGL(conv1x1_dgrad8_kernel, dim3((unsigned)std::min<long long>(nrb, 256 * 32)), dim3(Cin >= 256 ? 256 : (Cin >= 128 ? 128 : 64)), (size_t)8 * Cout * sizeof(float), st, dy, w, dx, N, H, W, Cin,
+                           Cout, stride);
+    } else if (dx && ks == 1 && stride == 2 && G == 1 && H % 2 == 0 && W % 2 == 0)
         hipLaunchKernelGGL(conv1x1s2_dgrad_kernel, dim3(gridfor((long long)N * Ho * Wo * Cin)), dim3(256), 0, st, dy, w, dx, N, H, W, Cin, Cout);
     else if (dx) hipLaunchKernelGGL(conv_dgrad_kernel, dim3(gridfor((long long)G * N * H * W * Cin)), dim3(256), 0, st, dy, w, dx, G, N, H, W, Cin, Ho, Wo, Cout, ks, stride, x_gs);
     if (dw) hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)((long long)G * Cout * Cin)), dim3(256), 0, st, x, dy, dw, N, H, W, Cin, Ho, Wo, Cout, ks, stride, x_gs);

@@ -1,0 +1,12 @@
+cd "$(dirname "$0")/.."; export TMPDIR=/tmp; O=gpurun_out/r04ab; mkdir -p $O
+timeout -k 5 300 rocprofv3 --kernel-trace -d $O/ts -o t -- python bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline > $O/train.json 2> $O/t.log
+python - <<P
+import sqlite3, glob
+db=glob.glob("$O/ts/**/*.db", recursive=True)[0]
+c=sqlite3.connect(db)
+rows=list(c.execute("select name, start, end, grid_x, workgroup_x from kernels order by start"))
+for pat in ("conv1x1_dgrad8","conv_dgrad_kernel","maxpool_bwd"):
+    d=[(round((e-s)/1e3,1),g,w) for n,s,e,g,w in rows if pat in n]
+    print(pat, d[-4:])
+P
+rm -rf $O/ts
