@@ -77,7 +77,7 @@ hipError_t cerb_launch_pw_bwd_small(const float* x, const float* dy, const float
 hipError_t cerb_launch_stem_wgrad_mfma(const unsigned char* tiles, const float* dy, float* dw, int N, int H, int W, void* ws, hipStream_t st);
 hipError_t cerb_launch_colsum(const float* d, long long group_stride, long long rows, int C, int G, float* out, void* ws, hipStream_t st);
 hipError_t cerb_launch_wgrad(const float* x, const float* dy, float* dw, int G, int N, int H, int W, int Cin, int Cout, int ks, int stride, long long x_gs, void* ws,
-                             hipStream_t st);
+                             hipStream_t st, float* db = nullptr);
 hipError_t cerb_launch_maxpool(const float* in, float* out, int N, int H, int W, int C, hipStream_t st);
 hipError_t cerb_launch_head(const HeadParams& p, hipStream_t st);
 hipError_t cerb_launch_head_group(const HeadParams* heads, int n_heads, hipStream_t st, int w2_44);
@@ -1669,18 +1669,21 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     dx_done = true;
                     go = grd[op.o];
                 }
-                bool dw_done = false;
+                bool dw_done = false, db_done = false;
                 if ((op.ks == 3 || op.ks == 1) && net->conv_algo) {  // weight gradient on the matrix cores
                     const int ho = op.stride == 2 ? op.H / 2 : op.H, wo = op.stride == 2 ? op.W / 2 : op.W;
                     if (net->t_ws.ensure(cerb_wgrad_workspace_bytes(op.G, op.N, ho, wo, op.Cin, op.Cout, op.ks, nullptr), 0)) return fail("workspace allocation failed");
                     // `flops` field: executed MFMA FLOPs of the weight gradient (2 x outputs x taps x Cin x Cout)
                     if (prof_begin(net, op.name + ".wgrad", "wgrad<ks" + std::to_string(op.ks) + ",s" + std::to_string(op.stride) + ">",
                                    2.0 * op.G * op.N * ho * wo * (double)op.Cin * op.Cout * op.ks * op.ks, st)) return 1;
-                    HIP_OK(cerb_launch_wgrad(val[op.a], go, dw, op.G, op.N, op.H, op.W, op.Cin, op.Cout, op.ks, op.stride, op.a_gs, net->t_ws.p, st));
+                    // the bias gradient (sums of dy over the pixels) rides inside the same pass when the channel count allows
+                    const bool db_in_wgrad = db && op.Cout % 64 == 0;
+                    HIP_OK(cerb_launch_wgrad(val[op.a], go, dw, op.G, op.N, op.H, op.W, op.Cin, op.Cout, op.ks, op.stride, op.a_gs, net->t_ws.p, st, db_in_wgrad ? db : nullptr));
                     if (prof_end(net, st)) return 1;
                     dw_done = true;
+                    if (db_in_wgrad) db_done = true;
                 }
-                if (db) {
+                if (db && !db_done) {
                     const long long orow = (long long)op.N * (op.stride == 2 ? op.H / 2 : op.H) * (op.stride == 2 ? op.W / 2 : op.W);
                     if (net->t_ws.ensure((size_t)op.G * 2048 * op.Cout * 4 + 256, 0)) return fail("workspace allocation failed");
                     PROF(op.name + ".dbias", "bias_colsum", (double)op.G * orow * op.Cout * 4.0, HIP_OK(cerb_launch_colsum(go, orow * op.Cout, orow, op.Cout, op.G, db, net->t_ws.p, st)));

@@ -21,6 +21,7 @@ struct WgradParams {
     const float* x;
     const float* dy;
     float* part;   // [slices][tiles][taps][64 co][64 ci]
+    float* part_b; // optional [slices][G][ncb * 64]: per-slice sums of dy over the pixels (the bias gradient), written by the cib == 0 tiles
     int G, N, H, W, Ho, Wo, Cin, Cout, slices, segs_per_row;  // H, W: input map; Ho, Wo: output map; Cin / Cout: real channel counts (multiples of 4)
     long long x_gs, dy_gs;
 };
@@ -51,6 +52,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // the bias gradient rides along: lane (j, k) reads dy[pixel of parity k][co = 32 ch + j] as its A operand anyway -- one more add per nine
+    // matrix instructions instead of a pass of its own over dy (double, like the column-sum kernel it replaces)
+    double bsum = 0.0;
     if constexpr (PIPE) {
         f32x4 rd[ND], rx[NX];
         auto fetch = [&](long long s) {
@@ -95,15 +99,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
             if (more) fetch(s + p.slices);
             const float* dl = lds + buf * (DY_FLOATS + X_FLOATS);
             const float* xq = dl + DY_FLOATS;
+            float bseg = 0.f;  // the segment's 16 values in float, the segments in double
 #pragma unroll 4
             for (int pp = 0; pp < SEG / 2; ++pp) {
                 const float a = dl[(2 * pp + k) * 64 + 32 * ch + j];
+                bseg += a;
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     const float b = xq[((t / KS) * XQ + (2 * pp + k) * STRIDE + (t % KS)) * 64 + 32 * ih + j];
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
                 }
             }
+            bsum += (double)bseg;
             if (more) drop(buf ^ 1);
             __syncthreads();  // the other buffer is complete; this one has been read by every wave
             buf ^= 1;
@@ -133,17 +140,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
             }
             __syncthreads();
             // ---- 16 pixel pairs x 9 taps ------------------------------------------------------------------------------------------------------
+            float bseg = 0.f;
     #pragma unroll 4
             for (int pp = 0; pp < SEG / 2; ++pp) {
                 const float a = dyl[(2 * pp + k) * 64 + 32 * ch + j];
+                bseg += a;
     #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     const float b = xl[((t / KS) * XQ + (2 * pp + k) * STRIDE + (t % KS)) * 64 + 32 * ih + j];
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
                 }
             }
+            bsum += (double)bseg;
         }
 }
+    if (p.part_b && cib == 0 && ih == 0) {  // (both ci-halves' waves read the same dy: one of them reports)
+        const double other = __shfl_xor(bsum, 32);
+        if (k == 0) p.part_b[((long long)slice * p.G + g) * ncb * 64 + cb * 64 + 32 * ch + j] = (float)(bsum + other);
+    }
     // ---- this slice's partial tile: part[slice][tile][tap][co 64][ci 64]; MFMA D layout: row = rq*8 + (lane>>5)*4 + e, column = lane & 31 ----
     float* o = p.part + ((long long)slice * tiles + tile) * T * 4096;
 #pragma unroll
@@ -200,13 +214,16 @@ size_t cerb_wgrad_workspace_bytes(int G, int N, int Ho, int Wo, int Cin, int Cou
     if (slices < 1) slices = 1;
     if (slices > nseg) slices = nseg;
     if (slices_out) *slices_out = (int)slices;
-    return (size_t)slices * tiles * ks * ks * 4096 * 4;
+    return (size_t)slices * tiles * ks * ks * 4096 * 4 + (size_t)slices * G * ((Cout + 63) / 64) * 64 * 4;  // + the bias partials
 }
 
+__global__ void slab_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int blocks);
 // x: [G][N][H][W][Cin], dy: [G][N][Ho][Wo][Cout] with Ho = H / stride; dw: [G][Cout][Cin][ks][ks].  ks in {1, 3}, stride in {1, 2}; channel counts
 // multiples of 4.  Pointwise layers: N = H = 1, W = rows.
+// db != nullptr (Cout a multiple of 64): also db[G][Cout] = sum of dy over the pixels, collected inside the same pass.
 hipError_t cerb_launch_wgrad(const float* x, const float* dy, float* dw, int G, int N, int H, int W, int Cin, int Cout, int ks, int stride, long long x_gs, void* ws,
-                             hipStream_t st) {
+                             hipStream_t st, float* db) {
+    if (db && Cout % 64) return hipErrorInvalidValue;
     if (Cin % 4 || Cout % 4 || (ks != 1 && ks != 3) || (stride != 1 && stride != 2)) return hipErrorInvalidValue;
     WgradParams p;
     p.x = x; p.dy = dy; p.part = (float*)ws;
@@ -218,6 +235,7 @@ hipError_t cerb_launch_wgrad(const float* x, const float* dy, float* dw, int G, 
     wgrad_shape(G, N, p.Ho, p.Wo, Cin, Cout, &tiles, &nseg);
     (void)cerb_wgrad_workspace_bytes(G, N, p.Ho, p.Wo, Cin, Cout, ks, &slices);
     p.slices = slices;
+    p.part_b = db ? (float*)ws + (size_t)slices * tiles * ks * ks * 4096 : nullptr;
     const dim3 grid((unsigned)(tiles * slices));
     if (ks == 3 && stride == 1) hipLaunchKernelGGL((wgrad_kernel<3, 1>), grid, dim3(256), 0, st, p);
     else if (ks == 3) hipLaunchKernelGGL((wgrad_kernel<3, 2>), grid, dim3(256), 0, st, p);
@@ -226,6 +244,7 @@ hipError_t cerb_launch_wgrad(const float* x, const float* dy, float* dw, int G, 
     long long blocks = (long long)tiles * ks * ks * 4096 / 64;
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, (const float*)ws, dw, G, Cin, Cout, ks * ks, slices);
+    if (db) hipLaunchKernelGGL(slab_sum_kernel, dim3((G * Cout + 63) / 64, 1), dim3(1024), 0, st, (const float*)p.part_b, db, G * Cout, slices);
     return hipGetLastError();
 }
 
