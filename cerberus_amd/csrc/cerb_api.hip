@@ -1751,12 +1751,13 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 float* dw = pub(op.wkey, (size_t)op.Cin * op.Cout);
                 float* db = pub(op.bkey, (size_t)op.Cout);
                 if (!dw || !db) return fail("workspace allocation failed");
-                bool pw_dw = false;
+                bool pw_dw = false, pw_db = false;
                 if (prof_begin(net, op.wkey + ".bwd", "pointwise_bwd", 4.0 * op.rows * (double)op.Cin * op.Cout, st)) return 1;  // weight + data gradient + bias sums
                 if (op.Cin % 4 == 0 && op.Cout % 4 == 0 && !op.scale && op.rows >= 4096 && op.rows < (1ll << 31) && net->conv_algo) {
                     if (net->t_ws.ensure(cerb_wgrad_workspace_bytes(1, 1, 1, (int)op.rows, op.Cin, op.Cout, 1, nullptr), 0)) return fail("workspace allocation failed");
-                    HIP_OK(cerb_launch_wgrad(val[op.a] + op.a_gs, go, dw, 1, 1, 1, (int)op.rows, op.Cin, op.Cout, 1, 1, 0, net->t_ws.p, st));
+                    HIP_OK(cerb_launch_wgrad(val[op.a] + op.a_gs, go, dw, 1, 1, 1, (int)op.rows, op.Cin, op.Cout, 1, 1, 0, net->t_ws.p, st, db));  // (+ the bias sums)
                     pw_dw = true;
+                    pw_db = true;
                 }
                 if (!pw_dw && op.Cout <= 8 && !op.scale && op.rows >= 4096 && net->conv_algo) {
                     // the heads' 96 -> 3 / 7: weight gradient, bias sums and data gradient in one pass over the rows (cerb_launch_pw_bwd_small)
@@ -1773,8 +1774,10 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     HIP_OK(cerb_launch_pw_wgrad_small(val[op.a] + op.a_gs, go, dw, op.rows, op.Cin, op.Cout, net->t_ws.p, st));
                     pw_dw = true;
                 }
-                if (net->t_ws.ensure((size_t)2048 * op.Cout * 4 + 256, 0)) return fail("workspace allocation failed");
-                HIP_OK(cerb_launch_colsum(go, 0, op.rows, op.Cout, 1, db, net->t_ws.p, st));
+                if (!pw_db) {
+                    if (net->t_ws.ensure((size_t)2048 * op.Cout * 4 + 256, 0)) return fail("workspace allocation failed");
+                    HIP_OK(cerb_launch_colsum(go, 0, op.rows, op.Cout, 1, db, net->t_ws.p, st));
+                }
                 // a hidden map read by this layer alone gets its gradient assigned (no zero fill, no read-modify-write)
                 bool fresh = !grd[op.a] && op.a_gs == 0 && cnt[op.a] == (size_t)op.rows * op.Cin;
                 if (fresh && !(grd[op.a] = take(cnt[op.a], false))) return fail("workspace allocation failed");

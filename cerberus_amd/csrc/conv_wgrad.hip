@@ -218,12 +218,28 @@ size_t cerb_wgrad_workspace_bytes(int G, int N, int Ho, int Wo, int Cin, int Cou
 }
 
 __global__ void slab_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int blocks);
+// out[i] = sum_b part[b][i], i < n, rows of `stride` floats (a channel count padded to whole 64-blocks): same fixed order as slab_sum_kernel
+__global__ __launch_bounds__(1024) void slab_sum_strided_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int stride, int blocks) {
+    __shared__ double sh[16][64];
+    const int lane = threadIdx.x & 63, ch = threadIdx.x >> 6, i = blockIdx.x * 64 + lane;
+    const int per = (blocks + 15) / 16, b0 = ch * per, b1 = min(blocks, b0 + per);
+    double s = 0;
+    if (i < n)
+        for (int b = b0; b < b1; ++b) s += part[(long long)b * stride + i];
+    sh[ch][lane] = s;
+    __syncthreads();
+    if (ch == 0 && i < n) {
+        double t = 0;
+        for (int k = 0; k < 16; ++k) t += sh[k][lane];
+        out[i] = (float)t;
+    }
+}
 // x: [G][N][H][W][Cin], dy: [G][N][Ho][Wo][Cout] with Ho = H / stride; dw: [G][Cout][Cin][ks][ks].  ks in {1, 3}, stride in {1, 2}; channel counts
 // multiples of 4.  Pointwise layers: N = H = 1, W = rows.
 // db != nullptr (Cout a multiple of 64): also db[G][Cout] = sum of dy over the pixels, collected inside the same pass.
 hipError_t cerb_launch_wgrad(const float* x, const float* dy, float* dw, int G, int N, int H, int W, int Cin, int Cout, int ks, int stride, long long x_gs, void* ws,
                              hipStream_t st, float* db) {
-    if (db && Cout % 64) return hipErrorInvalidValue;
+    if (db && Cout % 64 && G != 1) return hipErrorInvalidValue;  // (padded channel blocks: only without groups -- the pointwise layers)
     if (Cin % 4 || Cout % 4 || (ks != 1 && ks != 3) || (stride != 1 && stride != 2)) return hipErrorInvalidValue;
     WgradParams p;
     p.x = x; p.dy = dy; p.part = (float*)ws;
@@ -244,7 +260,8 @@ hipError_t cerb_launch_wgrad(const float* x, const float* dy, float* dw, int G, 
     long long blocks = (long long)tiles * ks * ks * 4096 / 64;
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, (const float*)ws, dw, G, Cin, Cout, ks * ks, slices);
-    if (db) hipLaunchKernelGGL(slab_sum_kernel, dim3((G * Cout + 63) / 64, 1), dim3(1024), 0, st, (const float*)p.part_b, db, G * Cout, slices);
+    if (db && Cout % 64 == 0) hipLaunchKernelGGL(slab_sum_kernel, dim3((G * Cout + 63) / 64, 1), dim3(1024), 0, st, (const float*)p.part_b, db, G * Cout, slices);
+    else if (db) hipLaunchKernelGGL(slab_sum_strided_kernel, dim3((Cout + 63) / 64), dim3(1024), 0, st, (const float*)p.part_b, db, Cout, ((Cout + 63) / 64) * 64, slices);
     return hipGetLastError();
 }
 
