@@ -1633,7 +1633,11 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     float* dx = G_(op.a);
                     const long long map_px = (long long)op.H * op.W;
                     const bool d_w4 = saved_algo == 5 || saved_algo == 7 || (saved_algo == 6 && map_px >= 256);
-                    const bool d_w4b = (saved_algo == 7 || (saved_algo == 6 && map_px <= 4096)) && op.Cout % 64 == 0;
+                    static const long long d_w4b_max_px = [] {  // developer A/B only, as in run_conv
+                        const char* e = getenv("CERB_W4B_MAX_PX");
+                        return e ? atoll(e) : 4096ll;
+                    }();
+                    const bool d_w4b = (saved_algo == 7 || (saved_algo == 6 && map_px <= d_w4b_max_px)) && op.Cout % 64 == 0;
                     const bool d_f4 = d_w4 && op.Cout % 16 == 0 && op.Cin % 64 == 0;
                     // the data gradient as its own family: the forward Winograd kernels on rotated weights (+ the stride-2 dilation pass)
                     if (prof_begin(net, op.name + ".dgrad", std::string("dgrad:") + (d_f4 ? (d_w4b ? "conv_wino4b<f4x4,16x16>" : "conv_wino4<f4x4,16x16x2>") : "conv_wino<f2x2,8x16>"),
