@@ -44,8 +44,9 @@ hipError_t cerb_launch_bn_stats(const float* x, long long group_stride, long lon
                                 float* var_unbiased, void* ws, hipStream_t st);
 hipError_t cerb_launch_bn_apply(float* x, const float* src, const float* resid, long long group_stride, long long rows, int C, int groups, const float* mean,
                                 const float* rstd, const float* gamma, const float* beta, int relu, hipStream_t st);
+hipError_t cerb_launch_bn_finalize(const double* partial, int blocks, long long rows, int C, float eps, float* mean, float* rstd, float* var_unbiased, hipStream_t st);
 hipError_t cerb_launch_pointwise(const float* in, const float* w, const float* bias, float* out, long long rows, int cin, int cout, const float* in_scale,
-                                 hipStream_t st);
+                                 hipStream_t st, double* bn_part = nullptr, int* bn_blocks = nullptr);
 hipError_t cerb_launch_crop_gap(const float* x, int N, int H, int W, int C, int y0, int ch, int x0, int cw, float* out, hipStream_t st);
 hipError_t cerb_launch_copy_multi(int count, float* const* dst, const float* const* src, const long long* n, void** dev_tab, size_t* dev_bytes,
                                   std::vector<char>* host_prev, hipStream_t st);
@@ -1398,17 +1399,21 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         tape.push_back(op);
         return o;
     };
-    auto bn = [&](const std::string& name, int y, int resid, long long rows, int relu) -> int {
+    // pre_blocks > 0: the producer of y already left pre_blocks rows of statistics partials in net->t_ws (one group): no statistics pass over y
+    auto bn = [&](const std::string& name, int y, int resid, long long rows, int relu, int pre_blocks = 0) -> int {
         const cerb_net::BnDev& b = net->bn[name];
         const int z = newT(cnt[y]), stt = newT((size_t)2 * b.groups * b.C);
-        if (!val[z] || !val[stt] || net->t_ws.ensure(cerb_bn_workspace_bytes(b.groups, rows, b.C), 0)) return -1;
+        if (!val[z] || !val[stt] || (!pre_blocks && net->t_ws.ensure(cerb_bn_workspace_bytes(b.groups, rows, b.C), 0))) return -1;
         float* mean = val[stt];
         float* rstd = val[stt] + (size_t)b.groups * b.C;
         const long long gs = b.groups > 1 ? rows * b.C : 0;
         float* var_u = take((size_t)b.groups * b.C, false);  // unbiased batch variance: what the running_var update uses
         // `flops` field = algorithmic bytes of the two forward BatchNorm passes (statistics: read y; apply: read y (+ residual), write z)
         if (prof_begin(net, name + ".bn_fwd", "bn_fwd", (double)b.groups * rows * b.C * 4.0 * (3.0 + (resid >= 0 ? 1.0 : 0.0)), st)) return -1;
-        if (!var_u || cerb_launch_bn_stats(val[y], gs, rows, b.C, b.groups, 1e-5f, mean, rstd, var_u, net->t_ws.p, st) != hipSuccess) return -1;
+        if (!var_u) return -1;
+        if (pre_blocks > 0 && b.groups == 1) {
+            if (cerb_launch_bn_finalize((const double*)net->t_ws.p, pre_blocks, rows, b.C, 1e-5f, mean, rstd, var_u, st) != hipSuccess) return -1;
+        } else if (cerb_launch_bn_stats(val[y], gs, rows, b.C, b.groups, 1e-5f, mean, rstd, var_u, net->t_ws.p, st) != hipSuccess) return -1;
         if (bn_eval_override(b, mean, rstd, st)) return -1;
         {
             const std::vector<std::string>& keys = net->bn_keys[name];
@@ -1555,7 +1560,11 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
             const std::string p = "output_head." + d.name + "." + d.head + ".x";
             // the head reads decoder k's slice of the grouped tensor: a view (tensor id with its own grad slice) is the slice itself
             const int hid = newT((size_t)rows * 96);
-            PROF(p + ".0", "pointwise_fwd", 2.0 * rows * 64 * 96, HIP_OK(cerb_launch_pointwise(val[prev] + k * (size_t)rows * 64, net->head_rw1[k], net->head_rb1[k], val[hid], rows, 64, 96, nullptr, st)));
+            // the hidden map's BatchNorm statistics come out of the layer itself (per-wave partials in t_ws, sized for either way before the launch)
+            int pre_blocks = 0;
+            if (net->t_ws.ensure(std::max(cerb_bn_workspace_bytes(1, rows, 96), (size_t)8192 * 96 * 16), 0)) return fail("workspace allocation failed");
+            PROF(p + ".0", "pointwise_fwd", 2.0 * rows * 64 * 96, HIP_OK(cerb_launch_pointwise(val[prev] + k * (size_t)rows * 64, net->head_rw1[k], net->head_rb1[k], val[hid], rows, 64, 96, nullptr, st,
+                                                                                          net->conv_algo ? (double*)net->t_ws.p : nullptr, &pre_blocks)));
             {
                 TapeOp op;
                 op.type = 5; op.a = prev; op.o = hid; op.rows = rows; op.Cin = 64; op.Cout = 96; op.w = net->head_rw1[k]; op.bias = net->head_rb1[k];
@@ -1563,7 +1572,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 op.wkey = p + ".0.block.0.conv.weight"; op.bkey = p + ".0.block.0.conv.bias";
                 tape.push_back(op);
             }
-            const int hz = bn("head." + std::to_string(k), hid, -1, rows, 1);
+            const int hz = bn("head." + std::to_string(k), hid, -1, rows, 1, pre_blocks);
             TCHK(hz);
             const int lg = newT((size_t)rows * d.out_ch);
             PROF(p + ".1", "pointwise_fwd", 2.0 * rows * 96 * d.out_ch, HIP_OK(cerb_launch_pointwise(val[hz], net->head_rw2[k], net->head_rb2[k], val[lg], rows, 96, d.out_ch, nullptr, st)));

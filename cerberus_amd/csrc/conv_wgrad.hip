@@ -427,9 +427,13 @@ hipError_t cerb_launch_colsum(const float* d, long long group_stride, long long 
 // forward and its 96 -> 64 data gradient).  One wave = 32 rows x NC: v_mfma_f32_32x32x2_f32 with A = the rows (lane = row, half-wave = k parity block), so
 // each lane fetches its row as float4s and the k order is permuted to match (k = 8 j + 4 h + e; a sum does not care); B sits in LDS in that order, one
 // ds_read_b128 per four MFMAs.  Stores put 32 consecutive floats of one row per half-wave.
+// bn_part != nullptr: the BatchNorm that follows the layer gets its statistics HERE -- per wave the (sum, sum of squares) of every output column
+// over the rows the workgroup produced, laid out as bn_partial_kernel's partials with one "block" per workgroup ([gridDim.x][nc][2] doubles; the 16
+// values of a lane and tile are added in float, tiles in double), so that bn_finalize_kernel takes them as they are and the statistics pass over
+// the layer's output (1.2 GB per head at batch 16 x 448^2) does not run.  (One row per workgroup, not per wave: the finalising kernel walks the rows serially.)
 template <int K, int NC, bool ACCUM, bool EXACT>
 __global__ __launch_bounds__(256) void pw_mfma_kernel(const float* __restrict__ a, const float* __restrict__ w, int w_trans, const float* __restrict__ bias,
-                                                      float* __restrict__ out, long long rows, int k_rt, int nc_rt) {
+                                                      float* __restrict__ out, long long rows, int k_rt, int nc_rt, double* __restrict__ bn_part) {
     const int k_real = EXACT ? K : k_rt, nc_real = EXACT ? NC : nc_rt;  // EXACT: the shape is the template's, all strides are constants
     // K, NC: the padded GEMM (multiples of 8 / 32); k_real <= K columns of `a` and nc_real <= NC outputs exist (the heads' 96 -> 3 / 7 layer and
     // its data gradient run here with zero padding: the layer is HBM-bound, the padded MFMAs are free)
@@ -446,6 +450,9 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(const float* __restrict__ 
     float bv[NC / 32];
 #pragma unroll
     for (int nb = 0; nb < NC / 32; ++nb) bv[nb] = (bias && nb * 32 + n0 < nc_real) ? bias[nb * 32 + n0] : 0.f;
+    double bs[NC / 32], bq[NC / 32];
+#pragma unroll
+    for (int nb = 0; nb < NC / 32; ++nb) bs[nb] = bq[nb] = 0.0;
     for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
         const long long row = min(tile * 32 + n0, rows - 1);
         f32x4 av[K / 8];
@@ -477,6 +484,9 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(const float* __restrict__ 
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].z, b.z, acc[nb], 0, 0, 0);
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].w, b.w, acc[nb], 0, 0, 0);
             }
+        float ts[NC / 32], tq[NC / 32];
+#pragma unroll
+        for (int nb = 0; nb < NC / 32; ++nb) ts[nb] = tq[nb] = 0.f;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const long long r = tile * 32 + 8 * (v >> 2) + 4 * h + (v & 3);
@@ -487,19 +497,50 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(const float* __restrict__ 
                         float* p = out + r * nc_real + nb * 32 + n0;
                         const float val = acc[nb][v] + bv[nb];
                         *p = ACCUM ? *p + val : val;
+                        ts[nb] += val;
+                        tq[nb] = fmaf(val, val, tq[nb]);
                     }
             }
+        }
+        if (bn_part) {
+#pragma unroll
+            for (int nb = 0; nb < NC / 32; ++nb) {
+                bs[nb] += (double)ts[nb];
+                bq[nb] += (double)tq[nb];
+            }
+        }
+    }
+    if (bn_part) {  // the two half-waves hold the rows of different parity blocks; the four waves meet in LDS: ONE partial row per workgroup
+        __shared__ double red[4][NC][2];
+#pragma unroll
+        for (int nb = 0; nb < NC / 32; ++nb) {
+            const double os = __shfl_xor(bs[nb], 32), oq = __shfl_xor(bq[nb], 32);
+            if (h == 0) {
+                red[wave][nb * 32 + n0][0] = bs[nb] + os;
+                red[wave][nb * 32 + n0][1] = bq[nb] + oq;
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < nc_real; c += 256) {
+            double* o = bn_part + ((long long)blockIdx.x * nc_real + c) * 2;
+            o[0] = ((red[0][c][0] + red[1][c][0]) + red[2][c][0]) + red[3][c][0];
+            o[1] = ((red[0][c][1] + red[1][c][1]) + red[2][c][1]) + red[3][c][1];
         }
     }
 }
 // returns hipErrorNotSupported for shapes the kernel is not built for (the caller keeps its scalar path)
-hipError_t cerb_launch_pw_mfma(const float* a, const float* w, int w_trans, const float* bias, float* out, long long rows, int K, int NC, int accumulate, hipStream_t st) {
+// bn_part (optional, K = 64 / NC = 96 forward only): statistics partials of the output for the BatchNorm behind the layer, *bn_blocks rows of them
+hipError_t cerb_launch_pw_mfma(const float* a, const float* w, int w_trans, const float* bias, float* out, long long rows, int K, int NC, int accumulate, hipStream_t st,
+                               double* bn_part, int* bn_blocks) {
     const long long ntiles = (rows + 31) / 32;
     const unsigned blocks = (unsigned)(ntiles / 4 < 1 ? 1 : (ntiles / 4 > 2048 ? 2048 : ntiles / 4));
-    if (K == 64 && NC == 96 && !accumulate) hipLaunchKernelGGL((pw_mfma_kernel<64, 96, false, true>), dim3(blocks), dim3(256), 0, st, a, w, w_trans, bias, out, rows, K, NC);
-    else if (K == 96 && NC == 64 && accumulate) hipLaunchKernelGGL((pw_mfma_kernel<96, 64, true, true>), dim3(blocks), dim3(256), 0, st, a, w, w_trans, bias, out, rows, K, NC);
-    else if (K == 96 && NC == 64 && !accumulate) hipLaunchKernelGGL((pw_mfma_kernel<96, 64, false, true>), dim3(blocks), dim3(256), 0, st, a, w, w_trans, bias, out, rows, K, NC);
-    else if (K == 96 && NC <= 32 && !accumulate) hipLaunchKernelGGL((pw_mfma_kernel<96, 32, false, false>), dim3(blocks), dim3(256), 0, st, a, w, w_trans, bias, out, rows, K, NC);
+    if (bn_blocks) *bn_blocks = 0;
+    if (bn_part && !(K == 64 && NC == 96 && !accumulate)) bn_part = nullptr;
+    if (bn_part && bn_blocks) *bn_blocks = (int)blocks;
+    if (K == 64 && NC == 96 && !accumulate) hipLaunchKernelGGL((pw_mfma_kernel<64, 96, false, true>), dim3(blocks), dim3(256), 0, st, a, w, w_trans, bias, out, rows, K, NC, bn_part);
+    else if (K == 96 && NC == 64 && accumulate) hipLaunchKernelGGL((pw_mfma_kernel<96, 64, true, true>), dim3(blocks), dim3(256), 0, st, a, w, w_trans, bias, out, rows, K, NC, (double*)nullptr);
+    else if (K == 96 && NC == 64 && !accumulate) hipLaunchKernelGGL((pw_mfma_kernel<96, 64, false, true>), dim3(blocks), dim3(256), 0, st, a, w, w_trans, bias, out, rows, K, NC, (double*)nullptr);
+    else if (K == 96 && NC <= 32 && !accumulate) hipLaunchKernelGGL((pw_mfma_kernel<96, 32, false, false>), dim3(blocks), dim3(256), 0, st, a, w, w_trans, bias, out, rows, K, NC, (double*)nullptr);
     else return hipErrorNotSupported;
     return hipGetLastError();
 }

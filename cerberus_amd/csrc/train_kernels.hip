@@ -21,7 +21,8 @@
 
 int cerb_set_error(const std::string& m);
 
-hipError_t cerb_launch_pw_mfma(const float* a, const float* w, int w_trans, const float* bias, float* out, long long rows, int K, int NC, int accumulate, hipStream_t st);
+hipError_t cerb_launch_pw_mfma(const float* a, const float* w, int w_trans, const float* bias, float* out, long long rows, int K, int NC, int accumulate, hipStream_t st,
+                               double* bn_part = nullptr, int* bn_blocks = nullptr);
 hipError_t cerb_launch_slab_sum(const float* part, float* out, int n, int blocks, int groups, hipStream_t st);
 namespace {
 constexpr int MAXC = 16;   // classes per head (reference: 3, 7, 9)
@@ -444,6 +445,11 @@ hipError_t cerb_launch_bn_stats(const float* x, long long group_stride, long lon
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, (const double*)ws, rows, C, bpg, eps, mean, rstd, var_unbiased);
     return hipGetLastError();
 }
+// statistics from partials some producer already wrote ([blocks][C][2] doubles, ONE group): mean, 1 / sqrt(var + eps), unbiased variance
+hipError_t cerb_launch_bn_finalize(const double* partial, int blocks, long long rows, int C, float eps, float* mean, float* rstd, float* var_unbiased, hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64, 1), dim3(1024), 0, st, partial, rows, C, blocks, eps, mean, rstd, var_unbiased);
+    return hipGetLastError();
+}
 hipError_t cerb_launch_bn_apply(float* x, const float* src, const float* resid, long long group_stride, long long rows, int C, int groups, const float* mean,
                                 const float* rstd, const float* gamma, const float* beta, int relu, hipStream_t st) {
     if (C % 4 || C / 4 > 256) return hipErrorInvalidValue;
@@ -456,10 +462,14 @@ hipError_t cerb_launch_bn_apply(float* x, const float* src, const float* resid, 
                        beta, relu);
     return hipGetLastError();
 }
+// bn_part / bn_blocks (optional): BatchNorm statistics partials of the output, produced inside the layer when the MFMA path serves it (*bn_blocks > 0
+// then: rows of [cout][2] doubles for cerb_launch_bn_finalize; 0 = not produced, run cerb_launch_bn_stats)
 hipError_t cerb_launch_pointwise(const float* in, const float* w, const float* bias, float* out, long long rows, int cin, int cout, const float* in_scale,
-                                 hipStream_t st) {
+                                 hipStream_t st, double* bn_part, int* bn_blocks) {
+    if (bn_blocks) *bn_blocks = 0;
     if (cin % 4) return hipErrorInvalidValue;
-    if (!in_scale && rows >= 4096 && cerb_launch_pw_mfma(in, w, 1, bias, out, rows, cin, cout, 0, st) == hipSuccess) return hipSuccess;
+    if (!in_scale && rows >= 4096 && cerb_launch_pw_mfma(in, w, 1, bias, out, rows, cin, cout, 0, st, bn_part, bn_blocks) == hipSuccess) return hipSuccess;
+    if (bn_blocks) *bn_blocks = 0;
     long long blocks = (rows * ((cout + 3) / 4) + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     if (blocks < 1) blocks = 1;

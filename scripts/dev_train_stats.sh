@@ -5,8 +5,8 @@ import sqlite3, glob
 db=glob.glob("$O/ts/**/*.db", recursive=True)[0]
 c=sqlite3.connect(db)
 rows=list(c.execute("select name, start, end, grid_x, workgroup_x from kernels order by start"))
-for pat in ("conv1x1_dgrad8","conv_dgrad_kernel","maxpool_bwd"):
+for pat in ("bn_partial_kernel","bn_finalize_kernel","pw_mfma_kernel<64, 96"):
     d=[(round((e-s)/1e3,1),g,w) for n,s,e,g,w in rows if pat in n]
-    print(pat, d[-4:])
+    print(pat, len(d), d[-3:])
 P
 rm -rf $O/ts
