@@ -271,10 +271,10 @@ _SYMBOL = {"conv_wino4p<f4x4,16x16x2,planar>": "void conv_wino4p_kernel<1>(ConvP
            "conv_wino4p<f4x4,16x16x2,planar,half-res>": "void conv_wino4p_kernel<0>(ConvParams)",
            "conv_wino4s<f4x4,16x16x2,planar,lds-patch>": "void conv_wino4s_kernel<1>(ConvParams)",
            "conv_wino4s<f4x4,16x16x2,planar,lds-patch,half-res>": "void conv_wino4s_kernel<0>(ConvParams)",
-           "conv_wino4b<f4x4,16x16>": "void conv_wino4b_kernel<false>(ConvParams)",
-           "conv_wino4b<f4x4,16x16,res>": "void conv_wino4b_kernel<true>(ConvParams)",
-           "conv_wino4<f4x4,16x16x2>": "void conv_wino4_kernel<false>(ConvParams)",
-           "conv_wino4<f4x4,16x16x2,res>": "void conv_wino4_kernel<true>(ConvParams)",
+           "conv_wino4b<f4x4,16x16>": "void conv_wino4b_kernel<false, false>(ConvParams)",
+           "conv_wino4b<f4x4,16x16,res>": "void conv_wino4b_kernel<true, false>(ConvParams)",
+           "conv_wino4<f4x4,16x16x2>": "void conv_wino4_kernel<false, false>(ConvParams)",
+           "conv_wino4<f4x4,16x16x2,res>": "void conv_wino4_kernel<true, false>(ConvParams)",
            "conv_wino<f2x2,8x16>": "void conv_wino_kernel<false>(ConvParams)",
            "conv_wino<f2x2,8x16,res>": "void conv_wino_kernel<true>(ConvParams)"}
 

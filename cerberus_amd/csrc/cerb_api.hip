@@ -44,7 +44,9 @@ hipError_t cerb_launch_bn_stats(const float* x, long long group_stride, long lon
                                 float* var_unbiased, void* ws, hipStream_t st);
 hipError_t cerb_launch_bn_apply(float* x, const float* src, const float* resid, long long group_stride, long long rows, int C, int groups, const float* mean,
                                 const float* rstd, const float* gamma, const float* beta, int relu, hipStream_t st);
-hipError_t cerb_launch_bn_finalize(const double* partial, int blocks, long long rows, int C, float eps, float* mean, float* rstd, float* var_unbiased, hipStream_t st);
+hipError_t cerb_launch_bn_finalize(const double* partial, int blocks, long long rows, int C, float eps, float* mean, float* rstd, float* var_unbiased, hipStream_t st,
+                                   int groups = 1, void* fold_ws = nullptr);
+size_t cerb_bn_fold_workspace_bytes(int groups, int C);
 hipError_t cerb_launch_pointwise(const float* in, const float* w, const float* bias, float* out, long long rows, int cin, int cout, const float* in_scale,
                                  hipStream_t st, double* bn_part = nullptr, int* bn_blocks = nullptr);
 hipError_t cerb_launch_crop_gap(const float* x, int N, int H, int W, int C, int y0, int ch, int x0, int cw, float* out, hipStream_t st);
@@ -256,6 +258,10 @@ struct cerb_net {
     std::vector<ProfRec> prof;
     size_t prof_n = 0;
     bool prof_open = false;  // a record is open (prof_begin without its prof_end yet)
+    // training forward: where the NEXT run_conv may leave BatchNorm statistics partials (ConvParams::bn_part); run_conv clears the request and
+    // reports in conv_bn_bpg how many blocks per group it wrote (0: this convolution's kernel does not produce them)
+    double* conv_bn_part = nullptr;
+    int conv_bn_bpg = 0;
     ~cerb_net() {
         for (auto& r : prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         for (void* p : dev_allocs) (void)hipFree(p);
@@ -828,6 +834,11 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
     auto it = net->conv.find(name);
     if (it == net->conv.end()) return fail("internal: conv " + name + " not packed");
     const PackedConv& c = it->second;
+    struct BnReq {  // the request holds for this call only
+        cerb_net* n;
+        ~BnReq() { n->conv_bn_part = nullptr; }
+    } bn_req{net};
+    net->conv_bn_bpg = 0;
     ConvParams p;
     memset(&p, 0, sizeof(p));
     p.in = in; p.prev = prev; p.wpack = c.w; p.bias = c.b; p.resid = resid; p.out = out;
@@ -893,6 +904,10 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
         }
         if (prof_begin(net, name, w4s ? (p.level_tag ? "conv_wino4s<f4x4,16x16x2,planar,lds-patch>" : "conv_wino4s<f4x4,16x16x2,planar,lds-patch,half-res>") :
                                   planar ? (p.level_tag ? "conv_wino4p<f4x4,16x16x2,planar>" : "conv_wino4p<f4x4,16x16x2,planar,half-res>") : w4b ? (resid ? "conv_wino4b<f4x4,16x16,res>" : "conv_wino4b<f4x4,16x16>") : (resid ? "conv_wino4<f4x4,16x16x2,res>" : "conv_wino4<f4x4,16x16x2>"), fl_done, st)) return 1;
+        if (net->conv_bn_part && !planar && !resid && !(roi && roi[1] > roi[0] && roi[3] > roi[2])) {
+            p.bn_part = net->conv_bn_part;
+            net->conv_bn_bpg = N * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16);
+        }
         HIP_OK(w4s ? cerb_launch_wino4s(p, st) : planar ? cerb_launch_wino4p(p, st) : w4b ? cerb_launch_wino4b(p, st) : cerb_launch_wino4(p, st));
         if (prof_end(net, st)) return 1;
         return 0;
@@ -1387,12 +1402,23 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         return p;
     };
     const int saved_algo = net->conv_algo;
+    std::map<int, std::pair<double*, int>> conv_stats;  // conv output tensor -> (statistics partials, blocks per group)
     // ---------------------------------------------------------------- forward, recorded ----------------------------------------
     auto conv = [&](const std::string& name, int a, int n_, int h_, int w_, long long a_gs) -> int {
         const PackedConv& c = net->conv[name];
         const int ho = c.stride == 2 ? h_ / 2 : h_, wo = c.stride == 2 ? w_ / 2 : w_;
         const int o = newT((size_t)c.groups * n_ * ho * wo * c.cout);
+        // BatchNorm statistics partials from the convolution's own output stage (3x3 stride-1 layers on the F(4x4) kernels): one (sum, sum of
+        // squares) per 16 x 16 block, group and channel, in a buffer of the tape arena that the bn() behind this conv finalises
+        double* part = nullptr;
+        if (c.ks == 3 && c.stride == 1 && net->conv_algo && !getenv("CERB_BN_STATS_PASS")) {
+            const size_t nblk = (size_t)n_ * ((ho + 15) / 16) * ((wo + 15) / 16);
+            part = (double*)take((size_t)c.groups * nblk * c.cout * 2 * 2, false);
+            if (!part) return -1;
+            net->conv_bn_part = part;
+        }
         if (!val[o] || run_conv(net, name, val[a], nullptr, nullptr, val[o], n_, h_, w_, 0, 0, a_gs, 0, st, nullptr)) return -1;
+        if (part && net->conv_bn_bpg > 0) conv_stats[o] = std::make_pair(part, net->conv_bn_bpg);
         TapeOp op;
         op.type = 1; op.name = name; op.a = a; op.o = o; op.N = n_; op.H = h_; op.W = w_; op.Cin = c.cin; op.Cout = c.cout; op.ks = c.ks; op.stride = c.stride;
         op.G = c.groups; op.a_gs = a_gs;
@@ -1411,7 +1437,11 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         // `flops` field = algorithmic bytes of the two forward BatchNorm passes (statistics: read y; apply: read y (+ residual), write z)
         if (prof_begin(net, name + ".bn_fwd", "bn_fwd", (double)b.groups * rows * b.C * 4.0 * (3.0 + (resid >= 0 ? 1.0 : 0.0)), st)) return -1;
         if (!var_u) return -1;
-        if (pre_blocks > 0 && b.groups == 1) {
+        auto cs = conv_stats.find(y);
+        if (cs != conv_stats.end()) {  // the convolution that made y left the partials: [groups][blocks][C][2]
+            if (net->t_ws.ensure(cerb_bn_fold_workspace_bytes(b.groups, b.C), 0)) return -1;
+            if (cerb_launch_bn_finalize(cs->second.first, cs->second.second, rows, b.C, 1e-5f, mean, rstd, var_u, st, b.groups, net->t_ws.p) != hipSuccess) return -1;
+        } else if (pre_blocks > 0 && b.groups == 1) {
             if (cerb_launch_bn_finalize((const double*)net->t_ws.p, pre_blocks, rows, b.C, 1e-5f, mean, rstd, var_u, st) != hipSuccess) return -1;
         } else if (cerb_launch_bn_stats(val[y], gs, rows, b.C, b.groups, 1e-5f, mean, rstd, var_u, net->t_ws.p, st) != hipSuccess) return -1;
         if (bn_eval_override(b, mean, rstd, st)) return -1;

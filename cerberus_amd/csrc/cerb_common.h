@@ -43,6 +43,11 @@ struct ConvParams {
     // conv_wino4p.hip only: `in` / `out` are tile-planar tensors (planar_elems below); blocks per image column / row incl. the guard ring
     int pl_byp, pl_bxp;
     int level_tag;        // conv_wino4p.hip: 1 = last decoder level, 0 = the level below it -- picks the kernel SYMBOL only (profiler statistics per launch size)
+    // conv_wino4.hip / conv_wino4b.hip, training forward only: per 16 x 16 output block the (sum, sum of squares) of every output channel over the
+    // block's pixels inside the image, [group][bn_bpg blocks][Cout][2] doubles -- the BatchNorm behind the convolution finalises its batch
+    // statistics from these instead of reading the output again (train_kernels.hip: bn_finalize_kernel).  nullptr: not produced.
+    double* bn_part;
+    int bn_bpg;           // blocks per group = N * ceil(Ho / 16) * ceil(Wo / 16)
 };
 
 // Tile-planar layout of the decoder's private tensors (conv_wino4p.hip; producer upsample2_add_planar, consumers conv_wino4p and the heads):

@@ -119,9 +119,12 @@ struct Item {
 };
 }  // namespace
 
-template <bool HAS_RES>
+// STATS (training forward): the output stage also leaves BatchNorm statistics partials per block (ConvParams::bn_part) -- a separate
+// instantiation, so that the inference kernels are the same code as without it
+template <bool HAS_RES, bool STATS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino4_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ __attribute__((aligned(16))) float bnred[STATS ? 4 * 16 * 8 : 4];  // STATS: [wave][channel quad][4 sums, 4 sums of squares]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int a = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's 16 output channels of the item's 64; input path: block a >> 1
@@ -488,6 +491,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         res[k] = buf_load(r_res, rowok ? vo[k & 3] : 0x80000000u, (k >> 2) * orow + 4 * (k & 3) * opix);
                     }
                 }
+                f32x4 bts = {0.f, 0.f, 0.f, 0.f}, btq = {0.f, 0.f, 0.f, 0.f};  // STATS: this lane's 16 pixels x 4 channels
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     f32x4 o = *reinterpret_cast<const f32x4*>(stg + sr + (16 * (k >> 2) + 4 * (k & 3)) * OPX);
@@ -497,13 +501,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     o[2] = fmaxf(o[2], floor_);
                     o[3] = fmaxf(o[3], floor_);
                     const bool rowok = !partial || (by0 + 4 * a + (k >> 2) < p.Ho);
+                    if constexpr (STATS) {
+                        if (rowok && vo[k & 3] != 0x80000000u) {  // pixels inside the image only
+                            bts = bts + o;
+                            btq[0] = fmaf(o[0], o[0], btq[0]);
+                            btq[1] = fmaf(o[1], o[1], btq[1]);
+                            btq[2] = fmaf(o[2], o[2], btq[2]);
+                            btq[3] = fmaf(o[3], o[3], btq[3]);
+                        }
+                    }
 #ifndef W4_ABL_NOSTORE
                     buf_store(o, r_out, rowok ? vo[k & 3] : 0x80000000u, (k >> 2) * orow + 4 * (k & 3) * opix);
 #else
                     if (o[0] == 1.2345e-30f) buf_store(o, r_out, rowok ? vo[k & 3] : 0x80000000u, (k >> 2) * orow + 4 * (k & 3) * opix);
 #endif
                 }
+                if constexpr (STATS) {  // the four lanes that hold a channel quad, then (behind the barrier) the four waves = the block's 256 pixels
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        bts[e] += __shfl_xor(bts[e], 16);
+                        bts[e] += __shfl_xor(bts[e], 32);
+                        btq[e] += __shfl_xor(btq[e], 16);
+                        btq[e] += __shfl_xor(btq[e], 32);
+                    }
+                    if (lane_o < 16) {
+                        *reinterpret_cast<f32x4*>(bnred + (a * 16 + lane_o) * 8) = bts;
+                        *reinterpret_cast<f32x4*>(bnred + (a * 16 + lane_o) * 8 + 4) = btq;
+                    }
+                }
                 __syncthreads();  // the staging buffer is rewritten by the next block, then by the next item's second chunk
+                if constexpr (STATS) {
+                    if (a == 0 && lane_o < 16 && !dead && p.bn_part) {
+                        const long long blk = ((long long)bo.n * p.tiles_y + bo.by) * p.tiles_x + bo.bx;
+                        double* dst = p.bn_part + (((long long)w.g * p.bn_bpg + blk) * p.Cout + w.cb * 64 + 4 * lane_o) * 2;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            dst[2 * e] = (double)(((bnred[lane_o * 8 + e] + bnred[(16 + lane_o) * 8 + e]) + bnred[(32 + lane_o) * 8 + e]) + bnred[(48 + lane_o) * 8 + e]);
+                            dst[2 * e + 1] = (double)(((bnred[lane_o * 8 + 4 + e] + bnred[(16 + lane_o) * 8 + 4 + e]) + bnred[(32 + lane_o) * 8 + 4 + e]) + bnred[(48 + lane_o) * 8 + 4 + e]);
+                        }
+                    }
+                }
             }
         }
 #ifdef W4_PROF
@@ -536,9 +573,12 @@ static hipError_t launch_wino4(ConvParams p, hipStream_t st) {
     }
     const long long nblk = (long long)p.N * p.tiles_x * p.tiles_y;
     const long long items = (long long)p.groups * ((nblk + 1) / 2) * (p.Cout / 64);
-    auto kern = conv_wino4_kernel<HAS_RES>;
-    static bool attr_done[64] = {};
-    if (cerb_attr_needed(attr_done)) {
+    const bool stats = p.bn_part != nullptr;
+    if (stats && HAS_RES) return hipErrorInvalidValue;
+    p.bn_bpg = (int)nblk;
+    auto kern = stats ? conv_wino4_kernel<false, true> : conv_wino4_kernel<HAS_RES, false>;
+    static bool attr_done[2][64] = {};
+    if (cerb_attr_needed(attr_done[stats ? 1 : 0])) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + PROF_BYTES);
         if (e != hipSuccess) return e;
     }

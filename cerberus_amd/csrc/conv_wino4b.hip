@@ -82,9 +82,11 @@ struct Item {
 };
 }  // namespace
 
-template <bool HAS_RES>
+// STATS (training forward): BatchNorm statistics partials per block from the output stage (ConvParams::bn_part; see conv_wino4.hip)
+template <bool HAS_RES, bool STATS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino4b_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ __attribute__((aligned(16))) float bnred[STATS ? 4 * 16 * 8 : 4];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int a = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's 16 output channels of the item's 64 / its tile row in the input path
@@ -447,6 +449,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     res[k] = buf_load(r_res, rowok ? vo[k & 3] : 0x80000000u, (k >> 2) * orow + 4 * (k & 3) * opix);
                 }
             }
+            f32x4 bts = {0.f, 0.f, 0.f, 0.f}, btq = {0.f, 0.f, 0.f, 0.f};  // STATS: this lane's 16 pixels x 4 channels
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 f32x4 o = *reinterpret_cast<const f32x4*>(stg + sr + (16 * (k >> 2) + 4 * (k & 3)) * OPX);
@@ -456,11 +459,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 o[2] = fmaxf(o[2], floor_);
                 o[3] = fmaxf(o[3], floor_);
                 const bool rowok = !partial || (by0 + 4 * a + (k >> 2) < p.Ho);
+                if constexpr (STATS) {
+                    if (rowok && vo[k & 3] != 0x80000000u) {
+                        bts = bts + o;
+                        btq[0] = fmaf(o[0], o[0], btq[0]);
+                        btq[1] = fmaf(o[1], o[1], btq[1]);
+                        btq[2] = fmaf(o[2], o[2], btq[2]);
+                        btq[3] = fmaf(o[3], o[3], btq[3]);
+                    }
+                }
                 buf_store(o, r_out, rowok ? vo[k & 3] : 0x80000000u, (k >> 2) * orow + 4 * (k & 3) * opix);
+            }
+            if constexpr (STATS) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bts[e] += __shfl_xor(bts[e], 16);
+                    bts[e] += __shfl_xor(bts[e], 32);
+                    btq[e] += __shfl_xor(btq[e], 16);
+                    btq[e] += __shfl_xor(btq[e], 32);
+                }
+                if (lane_o < 16) {
+                    *reinterpret_cast<f32x4*>(bnred + (a * 16 + lane_o) * 8) = bts;
+                    *reinterpret_cast<f32x4*>(bnred + (a * 16 + lane_o) * 8 + 4) = btq;
+                }
             }
             W4_STAMP(3);
             __syncthreads();  // the staging buffer is V buffer 1: the next item's first chunk writes it
             W4_STAMP(4);
+            if constexpr (STATS) {
+                if (a == 0 && lane_o < 16 && p.bn_part) {
+                    const long long blk = ((long long)w.n * p.tiles_y + w.by) * p.tiles_x + w.bx;
+                    double* dst = p.bn_part + (((long long)w.g * p.bn_bpg + blk) * p.Cout + w.cb * 64 + 4 * lane_o) * 2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dst[2 * e] = (double)(((bnred[lane_o * 8 + e] + bnred[(16 + lane_o) * 8 + e]) + bnred[(32 + lane_o) * 8 + e]) + bnred[(48 + lane_o) * 8 + e]);
+                        dst[2 * e + 1] = (double)(((bnred[lane_o * 8 + 4 + e] + bnred[(16 + lane_o) * 8 + 4 + e]) + bnred[(32 + lane_o) * 8 + 4 + e]) + bnred[(48 + lane_o) * 8 + 4 + e]);
+                    }
+                }
+            }
         }
 #ifdef W4_PROF
         if (prof_on) {
@@ -489,9 +525,12 @@ static hipError_t launch_wino4b(ConvParams p, hipStream_t st) {
         p.tiles_x = (p.roi_x1 + BLK - 1) / BLK - p.tx_off;
     }
     const long long items = (long long)p.groups * p.N * p.tiles_x * p.tiles_y * (p.Cout / 64);
-    auto kern = conv_wino4b_kernel<HAS_RES>;
-    static bool attr_done[64] = {};
-    if (cerb_attr_needed(attr_done)) {
+    const bool stats = p.bn_part != nullptr;
+    if (stats && HAS_RES) return hipErrorInvalidValue;
+    p.bn_bpg = p.N * p.tiles_x * p.tiles_y;
+    auto kern = stats ? conv_wino4b_kernel<false, true> : conv_wino4b_kernel<HAS_RES, false>;
+    static bool attr_done[2][64] = {};
+    if (cerb_attr_needed(attr_done[stats ? 1 : 0])) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + PROF_BYTES);
         if (e != hipSuccess) return e;
     }
