@@ -961,16 +961,29 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
             net->cm.ensure((size_t)N * hs[4] * ws[4] * 256 * 4, guard))
             return fail("workspace allocation failed");
         if (D) {
-            // dmid holds the first conv of a level: sizes (per decoder) 32^2*256, 64^2*128, 128^2*64, 256^2*64 -> max is the last.
-            // (ADVICE r3 asked to size dmid / dsum / dout by the levels that really run NHWC when the two last levels are tile-planar -- ~8 GB of
-            // untouched HBM at 32 x 256^2.  Tried in round 4: the first forward then dies with an illegal address in the NHWC levels, i.e. a
-            // kernel of those levels reaches past its tensor into what used to be the tail of these oversized buffers; until that reach is found
-            // and bounded the allocation stays as it was -- untouched memory costs nothing but address space on a 288 GB part.)
-            if (net->dmid.ensure(D * (size_t)N * H * W * 64 * 4, guard)) return fail("workspace allocation failed");
-            if (net->conv_algo && net->dsum.ensure(D * (size_t)N * H * W * 64 * 4, guard)) return fail("workspace allocation failed");
+            // dsum / dmid hold the entry sum and the first conv's output of a level that runs NHWC (per decoder 32^2 x 256, 64^2 x 128, and -- when the
+            // tile-planar levels are off -- 128^2 x 64, 256^2 x 64), dout[u] its second conv's output; the planar levels have their own buffers, so with
+            // them on (the default) only the two coarse levels count here: 8 GB less per handle at 32 tiles of 256^2 (a first attempt in this
+            // round faulted on a wrong channel count in its own formula, not on a kernel reaching past its tensor: sized from the packed convolutions'
+            // channel counts below, every fixture and geometry of the GPU suite runs).  CERB_LEGACY_WS=1: everything at last-level size, as before.
+            static const bool exact_ws = getenv("CERB_LEGACY_WS") == nullptr;
+            size_t need_sum = 0, need_mid = 0;
             const int oc[4] = {128, 64, 64, 64};
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u) {
+                if (exact_ws && level_is_planar(u)) continue;
+                const std::string n0 = "dec." + std::to_string(u) + ".0";
+                auto c0 = net->conv.find(n0);
+                const size_t px = (size_t)D * N * hs[3 - u] * ws[3 - u];
+                need_sum = std::max(need_sum, px * (size_t)(c0 != net->conv.end() ? c0->second.cin : 256) * 4);
+                need_mid = std::max(need_mid, px * (size_t)(c0 != net->conv.end() ? c0->second.cout : 256) * 4);
+            }
+            if (!exact_ws) need_sum = need_mid = D * (size_t)N * H * W * 64 * 4;
+            if (net->dmid.ensure(need_mid, guard)) return fail("workspace allocation failed");
+            if (net->conv_algo && net->dsum.ensure(need_sum, guard)) return fail("workspace allocation failed");
+            for (int u = 0; u < 4; ++u) {
+                if (exact_ws && level_is_planar(u)) continue;  // its outputs live in the planar buffers
                 if (net->dout[u].ensure(D * (size_t)N * hs[3 - u] * ws[3 - u] * oc[u] * 4, guard)) return fail("workspace allocation failed");
+            }
         }
     }
     // ---- encoder ----------------------------------------------------------------------------------------------
