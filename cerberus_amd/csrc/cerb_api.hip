@@ -1102,9 +1102,10 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
             // its output to the last level's up-sampling in that layout.
             const bool lvl_planar = level_is_planar(u) && (u == 3 || prev_gs > 0);
             if (lvl_planar) {
-                PlanarBuf &bs = u == 3 ? net->psum : net->psum2, &bm = u == 3 ? net->pmid : net->pmid2, &bo = u == 3 ? net->pout : net->pout2;
-                if (bs.ensure((int)D, N, hh, ww, 64, st) || bm.ensure((int)D, N, hh, ww, 64, st) || bo.ensure((int)D, N, hh, ww, 64, st))
-                    return fail("workspace allocation failed");
+                // two buffers per planar level: the entry sum is dead once the first conv has read it, so the second conv writes its output there
+                // (a third buffer of 8.6 GB at 64 tiles of 256^2 held it before); same geometry, same zero ring
+                PlanarBuf &bs = u == 3 ? net->psum : net->psum2, &bm = u == 3 ? net->pmid : net->pmid2, &bo = bs;
+                if (bs.ensure((int)D, N, hh, ww, 64, st) || bm.ensure((int)D, N, hh, ww, 64, st)) return fail("workspace allocation failed");
                 if (prof_begin(net, n0 + ".up", "upsample2_add_planar", 0.0, st)) return 1;
                 HIP_OK(cerb_launch_upsample2_add_planar(skips[u], prev, bs.b.p, (int)D, N, hh, ww, cin0, prev_gs, bs.gs(), use_roi ? roi_sum[u] : nullptr, prev_planar ? 1 : 0, st));
                 if (prof_end(net, st)) return 1;
@@ -1147,7 +1148,7 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
             if (dry || !(want || wantl)) continue;
             HeadParams hp;
             memset(&hp, 0, sizeof(hp));
-            hp.feat = feat_planar ? net->pout.b.p + k * net->pout.gs() : net->dout[3].p + k * (size_t)N * H * W * 64;
+            hp.feat = feat_planar ? net->psum.b.p + k * net->psum.gs() : net->dout[3].p + k * (size_t)N * H * W * 64;  // (planar: the last level's output lives in its sum buffer)
             hp.feat_planar = feat_planar ? 1 : 0;
             hp.pl_byp = cerb_planar_blocks(H);
             hp.pl_bxp = cerb_planar_blocks(W);
