@@ -244,7 +244,8 @@ struct cerb_net {
     std::map<std::string, std::vector<std::string>> bn_keys;   // conv / bn name -> state-dict prefixes of its BatchNorm, one per group
     // workspace
     DevBuf x0, pool, x[5], ta, tb, cm, dmid, dsum, dout[4];
-    PlanarBuf psum, pmid, pout;  // the last decoder level's private tensors in the tile-planar layout (conv_wino4p.hip), cerb_net_set_planar
+    PlanarBuf psum, pmid, pout;  // the last decoder level's private tensors in the tile-planar layout (conv_wino4p.hip), cerb_net_set_planar; psum also
+                                 // receives the level's OUTPUT (it is dead once the first conv has read it): pout / pout2 are never allocated any more
     bool planar_half = false;       // set by the decoder loop around the half-resolution level's run_conv calls (names the kernel symbol)
     PlanarBuf psum2, pmid2, pout2;  // the same for the level below it (64 channels at half the resolution) when its maps are large enough
     int planar = 1;              // cerb_net_set_planar: 1 (default) = that level runs upsample2_add_planar -> conv_wino4p x2 -> heads reading planar features
