@@ -265,12 +265,10 @@ def train_leg(args, model, dev, dist, world, rank, sd=None, kw=None):
 
 # ---- kernel-family table of one batch step (per-launch HIP events on the launch stream, cerb_net_profile_*) ----------------------
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md
-HBM_FAMILIES = {"maxpool3x3s2", "maxpool_bwd", "upsample2_add", "upadd_bwd", "crop_gap", "crop_gap_bwd", "bias_colsum", "zero_fill", "head_loss"}
+HBM_FAMILIES = {"maxpool3x3s2", "maxpool_bwd", "upsample2_add", "upadd_bwd", "crop_gap", "crop_gap_bwd", "bias_colsum", "zero_fill", "head_loss", "head_fwd2", "head_bwd1", "head_bwd2"}
 XGMI_LINK_GBS = 153.0   # per peer link, SURVEY.md par.8e
 _SYMBOL = {"conv_wino4p<f4x4,16x16x2,planar>": "void conv_wino4p_kernel<1>(ConvParams)",
            "conv_wino4p<f4x4,16x16x2,planar,half-res>": "void conv_wino4p_kernel<0>(ConvParams)",
-           "conv_wino4s<f4x4,16x16x2,planar,lds-patch>": "void conv_wino4s_kernel<1>(ConvParams)",
-           "conv_wino4s<f4x4,16x16x2,planar,lds-patch,half-res>": "void conv_wino4s_kernel<0>(ConvParams)",
            "conv_wino4b<f4x4,16x16>": "void conv_wino4b_kernel<false, false>(ConvParams)",
            "conv_wino4b<f4x4,16x16,res>": "void conv_wino4b_kernel<true, false>(ConvParams)",
            "conv_wino4<f4x4,16x16x2>": "void conv_wino4_kernel<false, false>(ConvParams)",

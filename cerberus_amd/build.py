@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcerberus_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wino4b.hip", "conv_wino4p.hip", "conv_wino4s.hip", "net_kernels.hip", "postproc.hip", "slide_kernels.hip", "train_kernels.hip", "conv_wgrad.hip", "pack_kernels.hip", "cerb_api.hip"]
+SOURCES = ["conv_igemm.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wino4b.hip", "conv_wino4p.hip", "net_kernels.hip", "postproc.hip", "slide_kernels.hip", "train_kernels.hip", "head_train.hip", "conv_wgrad.hip", "pack_kernels.hip", "cerb_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 # conv_wino4.hip: the 36-step chunk (288 matrix instructions) must be fully unrolled for its 288 accumulators to be registers (the default
 # pragma-unroll budget is 16 k instructions); the matrix instructions start in VGPR form and the register allocator moves the ones that do
@@ -21,8 +21,7 @@ EXTRA_FLAGS = {"conv_wino4.hip": ["-mllvm", "-pragma-unroll-threshold=1000000", 
                # 144 accumulators fit the AccVGPR half: the default AGPR form (the VGPR-form rewrite pass of ROCm 7.2 crashes on this kernel)
                "conv_wino4b.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
                # accumulators pinned by hand (inline-asm matrix instructions with "a" / "v" constraints): no allocator flag needed
-               "conv_wino4p.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
-               "conv_wino4s.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
+               "conv_wino4p.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
 
 
 def _stale(target, deps):

@@ -22,7 +22,6 @@ hipError_t cerb_launch_wino(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino4(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino4b(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino4p(ConvParams p, hipStream_t st);
-hipError_t cerb_launch_wino4s(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_upsample2_add_planar(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C, long long prev_gs,
                                             long long out_gs, const int* roi, int prev_planar, hipStream_t st);
 hipError_t cerb_launch_upsample2_add(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C,
@@ -81,6 +80,15 @@ hipError_t cerb_launch_stem_wgrad_mfma(const unsigned char* tiles, const float* 
 hipError_t cerb_launch_colsum(const float* d, long long group_stride, long long rows, int C, int G, float* out, void* ws, hipStream_t st);
 hipError_t cerb_launch_wgrad(const float* x, const float* dy, float* dw, int G, int N, int H, int W, int Cin, int Cout, int ks, int stride, long long x_gs, void* ws,
                              hipStream_t st, float* db = nullptr);
+bool cerb_head_train_supported(long long rows, int cin, int chid, int out);
+hipError_t cerb_launch_head_fwd2(const float* hid, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w2, const float* b2,
+                                 float* logits, long long rows, int out, hipStream_t st);
+size_t cerb_head_bwd_workspace_bytes(long long rows, int out);
+hipError_t cerb_launch_head_bwd1(const float* hid, const float* dlog, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w2,
+                                 float* dw2, float* db2, float* dgamma, float* dbeta, long long rows, int out, void* ws, hipStream_t st);
+hipError_t cerb_launch_head_bwd2(const float* hid, const float* dlog, const float* prev, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                 const float* dgamma, const float* dbeta, const float* w1, const float* w2, float* dprev, float* dw1, float* db1, long long rows, int out,
+                                 int eval_mode, int assign, void* ws, hipStream_t st);
 hipError_t cerb_launch_maxpool(const float* in, float* out, int N, int H, int W, int C, hipStream_t st);
 hipError_t cerb_launch_head(const HeadParams& p, hipStream_t st);
 hipError_t cerb_launch_head_group(const HeadParams* heads, int n_heads, hipStream_t st, int w2_44);
@@ -187,7 +195,6 @@ struct PackedConv {
                                                                       // device at first use and again after every optimiser step
     float* wino4b = nullptr;  // device, the same transform in conv_wino4b.hip's layout (32-channel chunks, conv_algo 7), packed lazily
     float* wino4 = nullptr;   // device, F(4x4,3x3) transformed weights in conv_wino4.hip's layout (conv_algo 5), packed lazily from host_w
-    float* wino4s = nullptr;  // device, the same transform in conv_wino4s.hip's layout (position pairs x channel halves), packed lazily
     std::vector<float> host_w;  // BN-folded 3x3 weights [G][cout][cin][9] kept on the host for the lazily packed Winograd variants
     float* b = nullptr;     // device
 };
@@ -437,7 +444,7 @@ static void pack_wino(const float* w, const float* scale, int cout, int cin, std
 //   ->  U[xi] of W[cb*64 + 16 a + (lane & 15)][chunk*16 + 4 (lane >> 4) + t]
 //   conv_wino4b.hip (chunk32 = true): [cb][32-channel chunk][wave a][xi][channel group G][lane][t]
 //   ->  U[xi] of W[cb*64 + 16 a + (lane & 15)][chunk*32 + 16 G + 4 (lane >> 4) + t]
-static void pack_wino4(const float* w, int cout, int cin, std::vector<float>* out, int layout = 0) {  // w: BN-folded [cout][cin][3][3]; layout 0 = conv_wino4 / 4p, 1 = conv_wino4b, 2 = conv_wino4s
+static void pack_wino4(const float* w, int cout, int cin, std::vector<float>* out, int layout = 0) {  // w: BN-folded [cout][cin][3][3]; layout 0 = conv_wino4 / 4p, 1 = conv_wino4b
     const bool chunk32 = layout == 1;
     static const double Gm[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                     {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
@@ -468,20 +475,6 @@ static void pack_wino4(const float* w, int cout, int cin, std::vector<float>* ou
                                     const int co = cb * 64 + 16 * a + (lane & 15);
                                     const int ci = ch * 32 + 16 * G + 4 * (lane >> 4) + t;
                                     o[idx++] = U[((size_t)co * cin + ci) * 36 + xi];
-                                }
-        return;
-    }
-    if (layout == 2) {  // conv_wino4s.hip: one 1-KiB wave load = a PAIR of positions x the two matrix instructions (t = 2h, 2h + 1) of a channel half
-        for (int cb = 0; cb < ncb; ++cb)
-            for (int ch = 0; ch < nchunk; ++ch)
-                for (int a = 0; a < 4; ++a)
-                    for (int h = 0; h < 2; ++h)
-                        for (int s = 0; s < 18; ++s)
-                            for (int lane = 0; lane < 64; ++lane)
-                                for (int e = 0; e < 4; ++e) {
-                                    const int co = cb * 64 + 16 * a + (lane & 15);
-                                    const int ci = ch * 16 + 4 * (lane >> 4) + 2 * h + (e & 1);
-                                    o[idx++] = U[((size_t)co * cin + ci) * 36 + 2 * s + (e >> 1)];
                                 }
         return;
     }
@@ -877,11 +870,10 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
         PackedConv& cm = it->second;
         float* train_slot = nullptr;
         if (!net->fold_bn && train_wino4_slot(net, name, cm, w4b ? 1 : 0, 0, st, &train_slot)) return 1;
-        const bool w4s = planar && net->planar == 2;  // conv_wino4s.hip: raw patch staged through LDS (its own weight layout)
-        float*& slot4 = !net->fold_bn ? train_slot : (w4s ? cm.wino4s : w4b ? cm.wino4b : cm.wino4);
+        float*& slot4 = !net->fold_bn ? train_slot : (w4b ? cm.wino4b : cm.wino4);
         if (!slot4) {  // first use: F(4x4,3x3) filter transform on the host, the kernel's per-wave layout, upload
             std::vector<float> w4;
-            for (int g = 0; g < cm.groups; ++g) pack_wino4(cm.host_w.data() + (size_t)g * cm.cout * cm.cin * 9, cm.cout, cm.cin, &w4, w4s ? 2 : w4b ? 1 : 0);
+            for (int g = 0; g < cm.groups; ++g) pack_wino4(cm.host_w.data() + (size_t)g * cm.cout * cm.cin * 9, cm.cout, cm.cin, &w4, w4b ? 1 : 0);
             void* d = nullptr;
             HIP_OK(hipMalloc(&d, w4.size() * 4));
             net->dev_allocs.push_back(d);
@@ -903,13 +895,12 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
             p.pl_byp = cerb_planar_blocks(p.Ho);
             p.pl_bxp = cerb_planar_blocks(p.Wo);
         }
-        if (prof_begin(net, name, w4s ? (p.level_tag ? "conv_wino4s<f4x4,16x16x2,planar,lds-patch>" : "conv_wino4s<f4x4,16x16x2,planar,lds-patch,half-res>") :
-                                  planar ? (p.level_tag ? "conv_wino4p<f4x4,16x16x2,planar>" : "conv_wino4p<f4x4,16x16x2,planar,half-res>") : w4b ? (resid ? "conv_wino4b<f4x4,16x16,res>" : "conv_wino4b<f4x4,16x16>") : (resid ? "conv_wino4<f4x4,16x16x2,res>" : "conv_wino4<f4x4,16x16x2>"), fl_done, st)) return 1;
+        if (prof_begin(net, name, planar ? (p.level_tag ? "conv_wino4p<f4x4,16x16x2,planar>" : "conv_wino4p<f4x4,16x16x2,planar,half-res>") : w4b ? (resid ? "conv_wino4b<f4x4,16x16,res>" : "conv_wino4b<f4x4,16x16>") : (resid ? "conv_wino4<f4x4,16x16x2,res>" : "conv_wino4<f4x4,16x16x2>"), fl_done, st)) return 1;
         if (net->conv_bn_part && !planar && !resid && !(roi && roi[1] > roi[0] && roi[3] > roi[2])) {
             p.bn_part = net->conv_bn_part;
             net->conv_bn_bpg = N * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16);
         }
-        HIP_OK(w4s ? cerb_launch_wino4s(p, st) : planar ? cerb_launch_wino4p(p, st) : w4b ? cerb_launch_wino4b(p, st) : cerb_launch_wino4(p, st));
+        HIP_OK(planar ? cerb_launch_wino4p(p, st) : w4b ? cerb_launch_wino4b(p, st) : cerb_launch_wino4(p, st));
         if (prof_end(net, st)) return 1;
         return 0;
     }
@@ -1351,7 +1342,9 @@ extern "C" int cerb_net_forward_train(cerb_net* net, const cerb_train_io* io, vo
 // reverse; gradients accumulate with += into zeroed buffers, so tensors with several consumers (skips, residual identities, the
 // shared conv_map output) need no special casing.  Gradients are published per state-dict key (cerb_net_grad_lookup).
 struct TapeOp {
-    int type = 0;  // 0 stem, 1 conv, 2 bn, 3 maxpool, 4 upadd, 5 pointwise, 6 crop+gap
+    int type = 0;  // 0 stem, 1 conv, 2 bn, 3 maxpool, 4 upadd, 5 pointwise, 6 crop+gap, 7 a whole output head (head_train.hip)
+    int hid = -1, head_k = 0;          // type 7: the stored 96-channel hidden map (a = the grouped decoder tensor, o = the logits, stat = [mean | rstd])
+    std::string wkey2, bkey2;          // type 7: keys of the second pointwise layer
     std::string name;
     int a = -1, b = -1, o = -1;        // tensor ids: input, second input (residual / prev), output
     int N = 0, H = 0, W = 0, Cin = 0, Cout = 0, ks = 0, stride = 1, G = 1, relu = 0;
@@ -1441,16 +1434,18 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         return o;
     };
     // pre_blocks > 0: the producer of y already left pre_blocks rows of statistics partials in net->t_ws (one group): no statistics pass over y
-    auto bn = [&](const std::string& name, int y, int resid, long long rows, int relu, int pre_blocks = 0) -> int {
+    // stat_only != nullptr: batch statistics only (published as usual) -- *stat_only = the [mean | rstd] tensor, no normalised copy of y is
+    // made and no tape entry (the fused heads apply the normalisation inside their own kernels); returns y
+    auto bn = [&](const std::string& name, int y, int resid, long long rows, int relu, int pre_blocks = 0, int* stat_only = nullptr) -> int {
         const cerb_net::BnDev& b = net->bn[name];
-        const int z = newT(cnt[y]), stt = newT((size_t)2 * b.groups * b.C);
+        const int z = stat_only ? y : newT(cnt[y]), stt = newT((size_t)2 * b.groups * b.C);
         if (!val[z] || !val[stt] || (!pre_blocks && net->t_ws.ensure(cerb_bn_workspace_bytes(b.groups, rows, b.C), 0))) return -1;
         float* mean = val[stt];
         float* rstd = val[stt] + (size_t)b.groups * b.C;
         const long long gs = b.groups > 1 ? rows * b.C : 0;
         float* var_u = take((size_t)b.groups * b.C, false);  // unbiased batch variance: what the running_var update uses
         // `flops` field = algorithmic bytes of the two forward BatchNorm passes (statistics: read y; apply: read y (+ residual), write z)
-        if (prof_begin(net, name + ".bn_fwd", "bn_fwd", (double)b.groups * rows * b.C * 4.0 * (3.0 + (resid >= 0 ? 1.0 : 0.0)), st)) return -1;
+        if (prof_begin(net, name + ".bn_fwd", stat_only ? "bn_finalize" : "bn_fwd", stat_only ? (double)pre_blocks * b.C * 16.0 : (double)b.groups * rows * b.C * 4.0 * (3.0 + (resid >= 0 ? 1.0 : 0.0)), st)) return -1;
         if (!var_u) return -1;
         auto cs = conv_stats.find(y);
         if (cs != conv_stats.end()) {  // the convolution that made y left the partials: [groups][blocks][C][2]
@@ -1467,6 +1462,11 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 net->grads[keys[g] + ".batch_mean"] = std::make_pair(mean + (size_t)g * b.C, (long long)b.C);
                 net->grads[keys[g] + ".batch_var"] = std::make_pair(var_u + (size_t)g * b.C, (long long)b.C);
             }
+        }
+        if (stat_only) {
+            if (prof_end(net, st)) return -1;
+            *stat_only = stt;
+            return y;
         }
         if (cerb_launch_bn_apply(val[z], val[y], resid >= 0 ? val[resid] : nullptr, gs, rows, b.C, b.groups, mean, rstd, b.gamma, b.beta, relu, st) != hipSuccess) return -1;
         if (prof_end(net, st)) return -1;
@@ -1610,6 +1610,27 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
             if (net->t_ws.ensure(std::max(cerb_bn_workspace_bytes(1, rows, 96), (size_t)8192 * 96 * 16), 0)) return fail("workspace allocation failed");
             PROF(p + ".0", "pointwise_fwd", 2.0 * rows * 64 * 96, HIP_OK(cerb_launch_pointwise(val[prev] + k * (size_t)rows * 64, net->head_rw1[k], net->head_rb1[k], val[hid], rows, 64, 96, nullptr, st,
                                                                                           net->conv_algo ? (double*)net->t_ws.p : nullptr, &pre_blocks)));
+            // The head as ONE tape entry (head_train.hip): the hidden map is stored once and read three times (forward 2, backward 1, backward 2);
+            // its normalised copy and both gradients of the hidden layer never exist.  CERB_HEAD_UNFUSED=1 keeps round 4's separate passes (A/B, tests).
+            const bool heads_unfused = getenv("CERB_HEAD_UNFUSED") != nullptr;  // (read per step: the A/B test flips it inside one process)
+            if (net->conv_algo && !heads_unfused && cerb_head_train_supported(rows, 64, 96, d.out_ch)) {
+                const std::string bname = "head." + std::to_string(k);
+                int stt = -1;
+                TCHK(bn(bname, hid, -1, rows, 1, pre_blocks, &stt));
+                const cerb_net::BnDev& hb = net->bn[bname];
+                const int lg = newT((size_t)rows * d.out_ch);
+                if (!val[lg]) return fail("workspace allocation failed");
+                PROF(p + ".1", "head_fwd2", (double)rows * (96 + d.out_ch) * 4.0,
+                     HIP_OK(cerb_launch_head_fwd2(val[hid], val[stt], val[stt] + 96, hb.gamma, hb.beta, net->head_rw2[k], net->head_rb2[k], val[lg], rows, d.out_ch, st)));
+                TapeOp op;
+                op.type = 7; op.name = bname; op.a = prev; op.o = lg; op.hid = hid; op.stat = stt; op.head_k = (int)k; op.rows = rows; op.Cin = 64; op.Cout = d.out_ch;
+                op.a_gs = (long long)k * rows * 64;
+                op.wkey = p + ".0.block.0.conv.weight"; op.bkey = p + ".0.block.0.conv.bias";
+                op.wkey2 = p + ".1.conv.weight"; op.bkey2 = p + ".1.conv.bias";
+                tape.push_back(op);
+                logit_t[di] = lg;
+                continue;
+            }
             {
                 TapeOp op;
                 op.type = 5; op.a = prev; op.o = hid; op.rows = rows; op.Cin = 64; op.Cout = 96; op.w = net->head_rw1[k]; op.bias = net->head_rb1[k];
@@ -1859,6 +1880,46 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 if (prof_end(net, st)) return 1;
                 break;
             }
+            case 7: {  // a whole output head: two passes over the stored hidden map (head_train.hip)
+                const int k = op.head_k, oc = op.Cout;
+                const cerb_net::BnDev& b = net->bn[op.name];
+                float* dw2 = pub(op.wkey2, (size_t)oc * 96);
+                float* db2 = pub(op.bkey2, (size_t)oc);
+                float* dw1 = pub(op.wkey, (size_t)96 * 64);
+                float* db1 = pub(op.bkey, 96);
+                float* dgb = take(2 * 96, false);
+                if (!dw2 || !db2 || !dw1 || !db1 || !dgb || net->t_ws.ensure(cerb_head_bwd_workspace_bytes(op.rows, oc), 0)) return fail("workspace allocation failed");
+                float* dgamma = dgb;
+                float* dbeta = dgb + 96;
+                const float* mean = val[op.stat];
+                const float* rstd = val[op.stat] + 96;
+                PROF(op.name + ".bwd1", "head_bwd1", (double)op.rows * (96 + oc) * 4.0,
+                     HIP_OK(cerb_launch_head_bwd1(val[op.hid], go, mean, rstd, b.gamma, b.beta, net->head_rw2[k], dw2, db2, dgamma, dbeta, op.rows, oc, net->t_ws.p, st)));
+                // the head's slice of the grouped decoder tensor: first writer assigns (see case 5)
+                const size_t slice = (size_t)op.rows * 64;
+                bool fresh = false;
+                if (cnt[op.a] >= slice && cnt[op.a] % slice == 0 && cnt[op.a] / slice <= 64 && op.a_gs % (long long)slice == 0 && (!grd[op.a] || slice_written.count(op.a))) {
+                    if (!grd[op.a]) {
+                        if (!(grd[op.a] = take(cnt[op.a], false))) return fail("workspace allocation failed");
+                        slice_written[op.a] = 0ull;
+                        slice_geom[op.a] = std::make_pair((int)(cnt[op.a] / slice), slice);
+                    }
+                    const int sk = (int)(op.a_gs / (long long)slice);
+                    if (!((slice_written[op.a] >> sk) & 1ull)) {
+                        fresh = true;
+                        slice_written[op.a] |= 1ull << sk;
+                    }
+                }
+                float* dxp = (fresh && grd[op.a]) ? grd[op.a] : G_(op.a);
+                const int eval_mode = (!b.eval.empty() && b.eval[0]) ? 1 : 0;
+                PROF(op.name + ".bwd2", "head_bwd2", (double)op.rows * (96 + 64 + 64 + oc) * 4.0,
+                     HIP_OK(cerb_launch_head_bwd2(val[op.hid], go, val[op.a] + op.a_gs, mean, rstd, b.gamma, b.beta, dgamma, dbeta, net->head_rw1[k], net->head_rw2[k],
+                                                  dxp + op.a_gs, dw1, db1, op.rows, oc, eval_mode, fresh ? 1 : 0, net->t_ws.p, st)));
+                const std::vector<std::string>& keys = net->bn_keys[op.name];
+                net->grads[keys[0] + ".weight"] = std::make_pair(dgamma, 96ll);
+                net->grads[keys[0] + ".bias"] = std::make_pair(dbeta, 96ll);
+                break;
+            }
             case 6: {
                 float* dxc = G_(op.a);
                 PROF("pc.crop_gap.bwd", "crop_gap_bwd", (double)op.N * op.H * op.W * op.Cout * 4.0, HIP_OK(cerb_launch_crop_gap_bwd(go, dxc, op.N, op.H, op.W, op.Cout, op.y0, op.ch, op.x0, op.cw, st)));
@@ -2035,7 +2096,7 @@ extern "C" int cerb_net_set_bn_eval(cerb_net* net, const char* bn_prefix, const 
 
 extern "C" int cerb_net_set_planar(cerb_net* net, int enable) {
     if (!net) return fail("cerb_net_set_planar: null handle");
-    if (enable < 0 || enable > 2) return fail("cerb_net_set_planar: 0 (NHWC), 1 (tile-planar, conv_wino4p.hip) or 2 (tile-planar with the raw patch staged through LDS, conv_wino4s.hip)");
+    if (enable < 0 || enable > 1) return fail("cerb_net_set_planar: 0 (NHWC) or 1 (tile-planar, conv_wino4p.hip)");
     net->planar = enable;
     return 0;
 }

@@ -1232,6 +1232,10 @@ hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, f
                             mean, rstd, gamma, beta, dgamma, dbeta, relu, eval_mask);
     return hipGetLastError();
 }
+// dgamma / dbeta from [blocks][C][2] double partials (sum dz xhat -> dgamma, sum dz -> dbeta): head_train.hip's first backward pass
+void cerb_bn_bwd_finalize_launch(const double* partial, int C, int blocks, float* dgamma, float* dbeta, hipStream_t st) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64, 1), dim3(1024), 0, st, partial, C, blocks, dgamma, dbeta);
+}
 hipError_t cerb_launch_conv_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int G, int N, int H, int W, int Cin, int Cout,
                                 int ks, int stride, long long x_gs, hipStream_t st) {
     const int Ho = stride == 2 ? H / 2 : H, Wo = stride == 2 ? W / 2 : W;

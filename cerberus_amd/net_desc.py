@@ -428,8 +428,7 @@ class NetDesc(torch.nn.Module):
         _lib.check(_lib.lib().cerb_net_set_conv_algo(self._ensure_handle(), int(algo)))
 
     def set_planar(self, enable=True):
-        """The two last decoder levels: 1 / True = tile-planar layout (conv_wino4p.hip), 2 = tile-planar with the raw patch staged through LDS
-        (conv_wino4s.hip), 0 / False = NHWC (conv_wino4.hip).  Bit-identical outputs in all three."""
+        """The two last decoder levels: 1 / True = tile-planar layout (conv_wino4p.hip), 0 / False = NHWC (conv_wino4.hip).  Bit-identical outputs."""
         self._remember("set_planar", enable)
         _lib.check(_lib.lib().cerb_net_set_planar(self._ensure_handle(), int(enable)))
 

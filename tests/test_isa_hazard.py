@@ -86,9 +86,10 @@ def test_f4x4_kernels_keep_their_arrays_in_registers(unit, tmp_path):
     assert asm.count("v_mfma_f32_16x16x4") >= 1152
 
 
-# ---- conv_wino4s.hip: loads the compiler cannot see ------------------------------------------------------------------------------------
-# The kernel issues its direct-to-LDS loads from inline assembly; its -DS4_MANUAL_WAITS experiment (off by default, see the source) does the same
-# with the weight and bias loads and spells out every s_waitcnt vmcnt itself.  The price of an invisible load: the compiler believes an asm
+# ---- loads the compiler cannot see (inline-assembly loads with hand-written s_waitcnt) -------------------------------------------------------
+# Round 4's conv_wino4s.hip (now scripts/experiments/: it missed its gate and left the product in round 5) issued direct-to-LDS loads and, in one
+# experiment, its weight and bias loads from inline assembly with hand-counted waits.  The scanner it needed stays as a tool for any kernel that
+# does the same, with its own known-answer test below.  The price of an invisible load: the compiler believes an asm
 # load's destination is valid the moment the statement has run, so a register copy it decides to place between the load and the hand-written
 # wait would read (or a re-use would overwrite) a register whose data is still in flight -- silently.  (It happened: given a VGPR destination
 # for the bias, hipcc parked the value in AccVGPRs with copies right behind the load.)  This scan walks the kernel's control-flow graph with the
@@ -193,17 +194,6 @@ def _kernels(unit, tmp, extra=()):
                 if t and not t.startswith("//") and not (t.startswith(".") and not t.endswith(":")):
                     kernels[cur].append(t)
     return kernels
-
-
-@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc not available")
-@pytest.mark.parametrize("extra", [(), ("-DS4_MANUAL_WAITS",)], ids=["default", "manual-waits"])
-def test_wino4s_no_instruction_touches_a_register_with_a_load_in_flight(tmp_path, extra):
-    ks = {k: v for k, v in _kernels("conv_wino4s.hip", str(tmp_path), extra).items() if "conv_wino4s_kernel" in k}
-    assert len(ks) == 2
-    for name, lines in ks.items():
-        bad, n_loads, n_waits = scan_invisible_loads(lines)
-        assert n_loads >= 72 and n_waits >= 60, "%s: expected the unrolled chunk bodies (%d loads, %d waits seen)" % (name, n_loads, n_waits)
-        assert not bad, "%s: %d instruction(s) touch a register whose load is still in flight, first: line %d `%s` %s" % (name, len(bad), bad[0][0], bad[0][1], bad[0][2])
 
 
 def test_invisible_load_scan_catches_a_planted_copy():

@@ -595,20 +595,3 @@ def test_planar_last_level_is_bit_identical_to_nhwc(full_model, win, osz, n):
     if win * win > 4096 * 4:  # the two last levels are above 64 x 64: the planar kernels carry both
         want = 4
         assert sum(k.startswith("conv_wino4p") for k in kernels) == want and kernels.count("upsample2_add_planar") == want // 2, kernels
-    # cerb_net_set_planar(2): the same layout through conv_wino4s.hip (raw patch staged through LDS by direct-to-LDS loads, V in 8-channel halves):
-    # the same products in the same order again -- bit-identical to both
-    try:
-        m.set_planar(2)
-        m.infer_tiles(other, osz)
-        m.profile(True)
-        got2 = {k: v.clone() for k, v in m.infer_tiles(tiles, osz).items()}
-        torch.cuda.synchronize()
-        kernels2 = [r[1] for r in m.profile_records()]
-        m.profile(False)
-        for k in ref:
-            assert torch.equal(got2[k], ref[k]), (k, (got2[k].float() - ref[k].float()).abs().max().item())
-    finally:
-        m.profile(False)
-        m.set_planar(True)
-    if win * win > 4096 * 4:
-        assert sum(k.startswith("conv_wino4s") for k in kernels2) == 4 and not any(k.startswith("conv_wino4p") for k in kernels2), kernels2
