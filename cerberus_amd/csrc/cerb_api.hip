@@ -134,6 +134,8 @@ extern "C" size_t cerb_conv_guard_bytes(int tile_w);
 // Activation buffer with a zero-filled guard band in front of and behind the payload: conv_igemm reads halo tiles with
 // unclamped addresses (row wrap / out-of-image elements are masked later), so every byte it can touch must exist and hold
 // a finite value.  The whole allocation is zeroed once; kernels only ever write payload bytes.
+// The stream of the API call that is running on this thread (set at every entry point that may allocate): a fresh buffer is zero-filled ON it.
+static thread_local hipStream_t g_call_stream = nullptr;
 struct DevBuf {
     float* p = nullptr;  // payload
     char* raw = nullptr;
@@ -142,10 +144,11 @@ struct DevBuf {
         if (need <= bytes && g <= guard) return 0;
         release();
         if (hipMalloc(&raw, need + 2 * g) != hipSuccess) return 1;
-        if (hipMemset(raw, 0, need + 2 * g) != hipSuccess) return 1;
-        // hipMemset runs on the NULL stream and may return before it is done; a caller on a non-blocking stream (two handles on two side streams,
-        // cerberus_amd/wsi.py) is not ordered against that stream at all -- its first kernels raced this fill.  Allocation is rare: wait here.
-        if (hipDeviceSynchronize() != hipSuccess) return 1;
+        // The fill is queued on the CALLER's stream: round 4 used hipMemset + hipDeviceSynchronize here because the NULL-stream fill
+        // raced the first kernels of a non-blocking side stream (two handles on two streams, cerberus_amd/wsi.py) -- on the stream that will use the
+        // buffer it is ordered by construction, stalls nothing else on the device and does not break a stream capture.  (The old buffer's hipFree
+        // in release() waits for the work that may still read it.)
+        if (hipMemsetAsync(raw, 0, need + 2 * g, g_call_stream) != hipSuccess) return 1;
         p = reinterpret_cast<float*>(raw + g);
         bytes = need;
         guard = g;
@@ -928,6 +931,7 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
 }
 
 static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st, double* macs) {
+    g_call_stream = st;
     const bool dry = (macs != nullptr) && (io->tiles == nullptr) && (io->tiles_f32 == nullptr);
     const int N = io->n, H = io->h, W = io->w;
     if (N <= 0 || H <= 0 || W <= 0 || (H % 16) || (W % 16)) return fail("cerb_net_forward: tile H,W must be positive multiples of 16");
@@ -1224,6 +1228,7 @@ extern "C" int cerb_net_forward_train(cerb_net* net, const cerb_train_io* io, vo
     if (!net->finalized) return fail("cerb_net_forward_train: call cerb_net_finalize first");
     if (net->fold_bn) return fail("cerb_net_forward_train: the network was packed for inference (BatchNorm folded); call cerb_net_set_fold_bn(net, 0) before cerb_net_finalize");
     hipStream_t st = (hipStream_t)hip_stream;
+    g_call_stream = st;
     const int N = io->n, H = io->h, W = io->w;
     if (N <= 0 || H <= 0 || W <= 0 || (H % 16) || (W % 16)) return fail("cerb_net_forward_train: tile H,W must be positive multiples of 16");
     const int hs[5] = {H, H / 2, H / 4, H / 8, H / 16}, ws[5] = {W, W / 2, W / 4, W / 8, W / 16};
@@ -1359,6 +1364,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
     if (!net || !io || !io->tiles || !io->target || !io->has_target || !io->loss_out) return fail("cerb_net_train_grads: null argument");
     if (!net->finalized || net->fold_bn) return fail("cerb_net_train_grads: needs a network packed with cerb_net_set_fold_bn(net, 0)");
     hipStream_t st = (hipStream_t)hip_stream;
+    g_call_stream = st;
     const int N = io->n, H = io->h, W = io->w;
     if (N <= 0 || H <= 0 || W <= 0 || (H % 16) || (W % 16)) return fail("cerb_net_train_grads: tile H,W must be positive multiples of 16");
     const int hs[5] = {H, H / 2, H / 4, H / 8, H / 16}, ws[5] = {W, W / 2, W / 4, W / 8, W / 16};
@@ -1411,6 +1417,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
     };
     const int saved_algo = net->conv_algo;
     std::map<int, std::pair<double*, int>> conv_stats;  // conv output tensor -> (statistics partials, blocks per group)
+    const bool bn_stats_pass = getenv("CERB_BN_STATS_PASS") != nullptr;  // developer A/B: the separate statistics pass (read once per step)
     // ---------------------------------------------------------------- forward, recorded ----------------------------------------
     auto conv = [&](const std::string& name, int a, int n_, int h_, int w_, long long a_gs) -> int {
         const PackedConv& c = net->conv[name];
@@ -1419,7 +1426,11 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         // BatchNorm statistics partials from the convolution's own output stage (3x3 stride-1 layers on the F(4x4) kernels): one (sum, sum of
         // squares) per 16 x 16 block, group and channel, in a buffer of the tape arena that the bn() behind this conv finalises
         double* part = nullptr;
-        if (c.ks == 3 && c.stride == 1 && net->conv_algo && !getenv("CERB_BN_STATS_PASS")) {
+        // only where run_conv will pick an F(4x4) kernel (its own rule: maps of at least 16 x 16 pixels under the default algorithm) -- the F(2x2) and
+        // direct kernels have no statistics stage, a buffer taken for them would only be arena churn
+        const long long map_px = (long long)ho * wo;
+        const bool f4 = net->conv_algo == 5 || net->conv_algo == 7 || (net->conv_algo == 6 && map_px >= 256);
+        if (c.ks == 3 && c.stride == 1 && f4 && c.wino && !bn_stats_pass) {
             const size_t nblk = (size_t)n_ * ((ho + 15) / 16) * ((wo + 15) / 16);
             part = (double*)take((size_t)c.groups * nblk * c.cout * 2 * 2, false);
             if (!part) return -1;
