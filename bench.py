@@ -200,7 +200,7 @@ def train_measure(model, dev, dist, world, rank, steps, warmup, backend):
             if kern in HBM_FAMILIES or kern.startswith("bn_"):  # `work` = algorithmic bytes
                 row.update(bound="hbm", achieved=round(work / (ms * 1e-3) / 1e9, 1), unit="GB/s", frac=round(work / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
             elif work > 0:
-                ex = work / (ms * 1e-3) / 1e12 * (0.25 if base.startswith("conv_wino4") else 16.0 / 36.0 if base.startswith("conv_wino") else 1.0)
+                ex = work / (ms * 1e-3) / 1e12 * (0.25 if base.startswith(("conv_wino4", "wgrad_wino4")) else 16.0 / 36.0 if base.startswith("conv_wino") else 1.0)
                 row.update(bound="mfma", achieved=round(ex, 2), unit="TFLOP/s", frac=round(ex / PEAK_F32_MFMA_TFLOPS, 4))
             fam_rows.append(row)
         # the phases of the step outside the handle's own records (device time between stream events), and what the records leave of the handle's call

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcerberus_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wino4b.hip", "conv_wino4p.hip", "net_kernels.hip", "postproc.hip", "slide_kernels.hip", "train_kernels.hip", "head_train.hip", "conv_wgrad.hip", "pack_kernels.hip", "cerb_api.hip"]
+SOURCES = ["conv_igemm.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wino4b.hip", "conv_wino4p.hip", "net_kernels.hip", "postproc.hip", "slide_kernels.hip", "train_kernels.hip", "head_train.hip", "conv_wgrad.hip", "conv_wgrad_wino.hip", "pack_kernels.hip", "cerb_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 # conv_wino4.hip: the 36-step chunk (288 matrix instructions) must be fully unrolled for its 288 accumulators to be registers (the default
 # pragma-unroll budget is 16 k instructions); the matrix instructions start in VGPR form and the register allocator moves the ones that do

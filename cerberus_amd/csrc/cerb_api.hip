@@ -78,6 +78,10 @@ hipError_t cerb_launch_pw_bwd_small(const float* x, const float* dy, const float
                                     int dx_assign, void* ws, hipStream_t st);
 hipError_t cerb_launch_stem_wgrad_mfma(const unsigned char* tiles, const float* dy, float* dw, int N, int H, int W, void* ws, hipStream_t st);
 hipError_t cerb_launch_colsum(const float* d, long long group_stride, long long rows, int C, int G, float* out, void* ws, hipStream_t st);
+bool cerb_wgrad_wino_supported(int H, int W, int Cin, int Cout);
+size_t cerb_wgrad_wino_workspace_bytes(int G, int N, int H, int W, int Cin, int Cout);
+hipError_t cerb_launch_wgrad_wino(const float* x, const float* dy, float* dw, int G, int N, int H, int W, int Cin, int Cout, long long x_gs, void* ws, hipStream_t st,
+                                  float* db);
 hipError_t cerb_launch_wgrad(const float* x, const float* dy, float* dw, int G, int N, int H, int W, int Cin, int Cout, int ks, int stride, long long x_gs, void* ws,
                              hipStream_t st, float* db = nullptr);
 bool cerb_head_train_supported(long long rows, int cin, int chid, int out);
@@ -1760,7 +1764,17 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     go = grd[op.o];
                 }
                 bool dw_done = false, db_done = false;
-                if ((op.ks == 3 || op.ks == 1) && net->conv_algo) {  // weight gradient on the matrix cores
+                // 3x3 stride 1 on whole 64-channel blocks: the weight gradient in the Winograd domain (conv_wgrad_wino.hip: a quarter of the matrix
+                // instructions of the direct form); CERB_WGRAD_DIRECT=1 keeps round 4's direct kernel everywhere (A/B, tests)
+                if (op.ks == 3 && op.stride == 1 && net->conv_algo >= 5 && cerb_wgrad_wino_supported(op.H, op.W, op.Cin, op.Cout) && !getenv("CERB_WGRAD_DIRECT")) {
+                    if (net->t_ws.ensure(cerb_wgrad_wino_workspace_bytes(op.G, op.N, op.H, op.W, op.Cin, op.Cout), 0)) return fail("workspace allocation failed");
+                    if (prof_begin(net, op.name + ".wgrad", "wgrad_wino4<f4x4>", 2.0 * op.G * op.N * op.H * op.W * (double)op.Cin * op.Cout * 9.0, st)) return 1;
+                    HIP_OK(cerb_launch_wgrad_wino(val[op.a], go, dw, op.G, op.N, op.H, op.W, op.Cin, op.Cout, op.a_gs, net->t_ws.p, st, db));
+                    if (prof_end(net, st)) return 1;
+                    dw_done = true;
+                    if (db) db_done = true;
+                }
+                if (!dw_done && (op.ks == 3 || op.ks == 1) && net->conv_algo) {  // weight gradient on the matrix cores
                     const int ho = op.stride == 2 ? op.H / 2 : op.H, wo = op.stride == 2 ? op.W / 2 : op.W;
                     if (net->t_ws.ensure(cerb_wgrad_workspace_bytes(op.G, op.N, ho, wo, op.Cin, op.Cout, op.ks, nullptr), 0)) return fail("workspace allocation failed");
                     // `flops` field: executed MFMA FLOPs of the weight gradient (2 x outputs x taps x Cin x Cout)

@@ -616,3 +616,59 @@ def test_fused_output_heads_equal_the_separate_passes(gold):
         # decoder gradient moves in its last bits (the bar of the reference comparison)
         assert cos > 0.9999 and err < (2e-4 if k.startswith("output_head.") else 1e-2), (k, err, cos)
     print("fused vs separate heads: worst element error %.2e of a tensor's largest value over %d tensors" % (worst, len(ga)))
+
+
+@pytest.mark.gpu
+def test_winograd_domain_weight_gradients_equal_the_direct_kernel(gold):
+    """Round 5: the weight gradients of the 3x3 stride-1 convolutions are accumulated in the Winograd domain (csrc/conv_wgrad_wino.hip:
+    dU = sum_tiles (A dY A^T) .* (B^T d B), dg = G^T dU G -- a quarter of the direct form's matrix instructions); CERB_WGRAD_DIRECT=1 keeps round 4's
+    direct split-K kernel.  Same data gradients either way, so every OTHER tensor must be bit-identical and every 3x3 weight / conv-bias gradient
+    must agree with the direct kernel to fp32 rounding of a differently ordered sum (F(4x4) transforms included)."""
+    import os
+
+    from cerberus_amd.net_desc import create_model
+    from cerberus_amd.weights import default_model_kwargs, make_state_dict
+
+    tiles = torch.from_numpy(gold["img"]).cuda()
+    keep = torch.from_numpy(gold["step/dropout_mask"].reshape(int(gold["N"]), 512)).cuda()
+    targets, flags = {}, {}
+    for j, h in enumerate(gold["heads"]):
+        h = str(h)
+        t = gold["target/" + h][..., 0]
+        targets[h] = torch.from_numpy(t.reshape(t.shape[0]) if h == "Patch-Class" else t).cuda()
+        flags[h] = torch.from_numpy(gold["has_target"][:, j].astype(np.float32)).cuda()
+    out = {}
+    for mode in ("wino", "direct"):
+        if mode == "direct":
+            os.environ["CERB_WGRAD_DIRECT"] = "1"
+        try:
+            m = create_model(**default_model_kwargs())
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(int(gold["weight_seed"])).items()}, strict=True)
+            losses, grads = m.train_grads(tiles, targets, flags, PARAMSET_LOSS, keep)
+            m.profile(True)
+            m.train_grads(tiles, targets, flags, PARAMSET_LOSS, keep)
+            fams = [r[1] for r in m.profile_records()]
+            m.profile(False)
+            out[mode] = (losses, {k: v.detach().cpu().numpy().copy() for k, v in grads.items()}, fams)
+        finally:
+            os.environ.pop("CERB_WGRAD_DIRECT", None)
+    (la, ga, fa), (lb, gb, fb) = out["wino"], out["direct"]
+    n_wino = sum(f.startswith("wgrad_wino4") for f in fa)
+    assert n_wino >= 20 and not any(f.startswith("wgrad_wino4") for f in fb), (n_wino, sorted(set(fb)))
+    assert la == lb and set(ga) == set(gb)
+    worst, n3 = 0.0, 0
+    for k in ga:
+        a, b = ga[k].astype(np.float64), gb[k].astype(np.float64)
+        conv3 = a.ndim == 4 and a.shape[2:] == (3, 3)
+        if not conv3 and not k.endswith("conv.bias"):
+            assert np.array_equal(a, b), k  # nothing but the weight-gradient kernel changed
+            continue
+        if float(np.abs(b).max()) < 1e-7:  # a bias in front of a train-mode BatchNorm: rounding noise both ways
+            assert float(np.abs(a).max()) < 1e-5, k
+            continue
+        err = float(np.abs(a - b).max()) / float(np.abs(b).max())
+        worst = max(worst, err)
+        n3 += conv3
+        assert err < 2e-4, (k, err)
+    assert n3 >= 50
+    print("Winograd-domain vs direct weight gradients: worst element error %.2e of a tensor's largest value over %d 3x3 tensors" % (worst, n3))
