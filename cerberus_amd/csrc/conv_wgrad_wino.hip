@@ -17,9 +17,10 @@
 //     [position 18][tile pair 4][channel 64][2]: the matrix phase's operand reads are conflict-free ds_read_b64 (lane = (channel l & 15, pair l >> 4),
 //     the two values = the two k-steps of the chunk);
 //   * matrix phase: wave = (9 positions, 32 co, 32 ci): 36 accumulators of v_mfma_f32_16x16x4_f32 (144 registers), 72 instructions per chunk;
-//   * the two waves that share a SIMD run the phases in OPPOSITE order inside one barrier interval (waves 0-3: matrix then element-wise, waves
-//     4-7: element-wise then matrix; LDS is double-buffered, so both orders touch the same buffers): one wave's transforms run in the shadow of
-//     the other's matrix instructions without any hand interleaving.
+//   * per chunk every wave runs matrix phase -> element-wise phase of the NEXT chunk (into the other LDS buffer) -> raw loads of the chunk after
+//     that -> barrier; the loads travel underneath the next matrix phase.  (-DWW_SKEW: the two waves of a SIMD in opposite phase order -- built
+//     first, 7 % slower: what bounds the kernel is the CU's L2 fill path, 106 KB of raw patches per chunk at the ~23 B/clk it sustains = as
+//     long as the chunk's 4608 matrix cycles, see the ablation table in profiles/r05_wgrad_wino_ablations.txt.)
 // Bias gradient (sum of dy over the pixels) rides along in the element-wise phase of the (ci block 0, half 0) workgroups.
 #include "cerb_common.h"
 #include <algorithm>
@@ -68,6 +69,9 @@ __device__ __forceinline__ void wgrad_wino_body(const WwParams& p, float* lds, i
     const unsigned voff = (unsigned)lane * 4u;
     const int xrow = p.W * p.Cin * 4, xpix = p.Cin * 4, yrow = p.W * p.Cout * 4, ypix = p.Cout * 4;
     auto fetch = [&](long long ch) {
+#ifdef WW_ABL_NOLOAD
+        if (ch != slice) return;
+#endif
         const long long T = ch * CT + w;
         if (T < p.ntile) {
             const int tx = (int)(T % p.TX);
@@ -101,6 +105,9 @@ __device__ __forceinline__ void wgrad_wino_body(const WwParams& p, float* lds, i
     auto estage = [&](int buf) {
         float* Zl = lds + buf * BUF;
         float* Vl = Zl + OPER;
+#ifdef WW_ABL_NOE
+        if (buf >= 0 && rd[0] != 1.2345e-30f) return;
+#endif
         if (want_bias) {
             float s = 0.f;
 #pragma unroll
@@ -167,6 +174,9 @@ __device__ __forceinline__ void wgrad_wino_body(const WwParams& p, float* lds, i
         }
     };
     auto mstage = [&](int buf) {
+#ifdef WW_ABL_NOM
+        if (buf >= 0 && rd[0] != 1.2345e-30f) return;
+#endif
         const float* Zl = lds + buf * BUF + (kq * 64 + 32 * cob + c) * 2;
         const float* Vl = lds + buf * BUF + OPER + (kq * 64 + 32 * cih + c) * 2;
 #pragma unroll
@@ -187,7 +197,11 @@ __device__ __forceinline__ void wgrad_wino_body(const WwParams& p, float* lds, i
     // Waves 0-3 (X) and 4-7 (Y) share the four SIMDs pairwise.  X: M(i) E(i+1) | M(i+1) E(i+2) | ...   Y: E(i+1) M(i) | E(i+2) M(i+1) | ...  ( | = barrier):
     // between two barriers X's matrix phase runs beside Y's element-wise phase and vice versa.  E(k) writes buffer k & 1, M(k) reads it; every E(k) lies
     // between barrier k - 2 and barrier k - 1, every M(k) between k - 1 and k: no buffer is read and written in the same interval.
+#ifdef WW_SKEW
     const bool grpY = w >= 4;
+#else
+    const bool grpY = false;  // measured (profiles/r05_wgrad_wino_ablations.txt): all eight waves in X order 4.42 ms, skewed 4.75 ms on the 448^2 level
+#endif
     const long long S = p.slices;
     long long ch = slice;  // chunk i of this slice = slice + i * S
     if (ch < nchunk) {

@@ -5,7 +5,7 @@ import numpy as np
 
 
 def _sigmoid(x):
-    return 1.0 / (1.0 + np.exp(-x))
+    return 1.0 / (1.0 + np.exp(-np.clip(x, -80.0, 80.0)))  # (clipped: exp(88.7) overflows float32 with a RuntimeWarning; sigmoid(+-80) is 0 / 1 in fp32 anyway)
 
 
 def blob_maps(H, W, seed, n_blobs, rmin, rmax, sharp=1.5, noise=0.0, holes=0.0, rim=2.0, border_bias=False):

@@ -72,7 +72,7 @@ class StepLR(object):
 def allreduce_grads(grads, dist, world_size, bucket_bytes=32 << 20):
     """Average gradients over ranks in flat buckets (a ring all-reduce over xGMI is bound per link: few large messages beat 300 small
     ones).  grads: key -> tensor (any device); in place.  dist: torch.distributed or None."""
-    if dist is None or world_size == 1:
+    if dist is None:  # (a communicator of ONE rank still reduces: bench.py --force-dist / the world-1 RCCL tests run the N > 1 code path on one device)
         return
     keys, bucket, size = list(grads.keys()), [], 0
 

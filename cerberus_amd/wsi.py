@@ -167,8 +167,9 @@ class WSIRunner(object):
     """One per process / GPU.  (Single-process simulations of more ranks than patch rows get empty bands; distributed drivers call
     check_shardable first.)"""
 
-    def __init__(self, net, slide_hw, patch_input_shape=256, patch_output_shape=256, batch_size=32, rank=0, world_size=1, patch_sel=None, twin=None):
-        """twin: a second handle with the same parameters (NetDesc.twin()); batches then alternate between the two on two side streams."""
+    def __init__(self, net, slide_hw, patch_input_shape=256, patch_output_shape=256, batch_size=32, rank=0, world_size=1, patch_sel=None, twin=None, row_range=None):
+        """twin: a second handle with the same parameters (NetDesc.twin()); batches then alternate between the two on two side streams.
+        row_range: (r0, r1) patch rows instead of rank's band of the world -- the sub-bands of cerberus_amd.stream_bands (slides larger than HBM)."""
         self.net = net
         self.twin = twin
         self._side = None
@@ -176,7 +177,7 @@ class WSIRunner(object):
         self.geo = SlideGeometry(slide_hw, patch_input_shape, patch_output_shape, patch_sel)
         self.batch = int(batch_size)
         self.rank, self.world = int(rank), int(world_size)
-        self.r0, self.r1 = self.geo.band(self.rank, self.world)
+        self.r0, self.r1 = self.geo.band(self.rank, self.world) if row_range is None else (int(row_range[0]), int(row_range[1]))
         self.dev = torch.device("cuda", torch.cuda.current_device())
         g = self.geo
         self.band_h = (self.r1 - self.r0) * g.out
@@ -265,10 +266,25 @@ class WSIRunner(object):
         for b0 in range(p0, p1, self.batch):
             i = self._turn  # the alternation goes on across calls
             self._turn += 1
-            with torch.cuda.stream(self._side[i & 1]):
-                one(nets[i & 1], b0)
+            k = (i & 1) if self.twin is not None else 0  # (after the second handle was dropped: everything on side stream 0, one handle = one stream)
+            try:
+                with torch.cuda.stream(self._side[k]):
+                    one(nets[k], b0)
+            except _lib.CerberusHipError as e:
+                # the second handle's workspace did not fit after all (the plan is an estimate): go on with one handle instead of losing the slide
+                if k != 1 or "allocation" not in str(e):
+                    raise
+                import logging
+
+                logging.getLogger("cerberus_amd.wsi").warning("second inference handle dropped (%s): continuing on one handle", e)
+                self.twin = None
+                torch.cuda.synchronize(self.dev)
+                torch.cuda.empty_cache()
+                k = 0
+                with torch.cuda.stream(self._side[0]):
+                    one(self.net, b0)
             if progress is not None:
-                last[i & 1] = mark(self._side[i & 1])
+                last[k] = mark(self._side[k])
                 progress(min(p1, b0 + self.batch), list(last))
         if join:
             self.join()

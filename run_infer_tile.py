@@ -25,13 +25,26 @@ def main(argv=None):
                                 argv=[os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv), oversubscribe=bool(os.environ.get("CERB_OVERSUBSCRIBE")))
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     os.makedirs(args["--output_dir"], exist_ok=True)
-    if world > 1:
+    dist = None
+    if world > 1 or os.environ.get("CERB_FORCE_DIST"):
         import torch
+
+        from cerberus_amd import launch
 
         n_dev = max(1, torch.cuda.device_count())
         if world > n_dev and not os.environ.get("CERB_OVERSUBSCRIBE"):
             raise SystemExit("%d ranks but %d visible GPU(s)" % (world, n_dev))
         torch.cuda.set_device(local % n_dev)
+        # Tile mode shards FILES (rank r takes every world-th image): no data-path collective.  The communicator is opened all the same -- the rank
+        # identities are gathered over it (a launcher that started fewer ranks than it said, or two ranks on one device, shows here and not as a
+        # silently missing third of the output) and the ranks leave together through a barrier.  CERB_FORCE_DIST=1: also with one rank (tests).
+        backend = os.environ.get("CERB_DIST_BACKEND", "gloo" if os.environ.get("CERB_OVERSUBSCRIBE") else "nccl")
+        dist = launch.init_dist(backend, local % n_dev)
+        ident = launch.rank_identity(dist, torch.device("cuda", local % n_dev), backend)
+        if ident["world"] != world:
+            raise SystemExit("the communicator spans %d ranks, the launcher said %d" % (ident["world"], world))
+        if rank == 0:
+            print("ranks: %d over %s on %d distinct device(s)" % (ident["world"], ident["backend"], ident["distinct_devices"]))
     from cerberus_amd.tile import InferManager
     from cerberus_amd.weights import DEFAULT_REQ_TARGET_CODE, default_model_kwargs
 
@@ -57,6 +70,9 @@ def main(argv=None):
         "rank": rank,
         "world_size": world,
     })
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -94,7 +94,9 @@ def main(argv=None):
         raise SystemExit("%d ranks but %d visible GPU(s): RCCL needs one device per rank" % (world, n_dev))
     local = local % n_dev
     torch.cuda.set_device(local)
-    if world > 1:  # "nccl" = RCCL over xGMI, one process per GPU; "gloo" = host-staged collectives (cerberus_amd/hostdist.py)
+    # CERB_FORCE_DIST=1: open the communicator even for ONE rank, so that every collective of the N-rank path (skip-flag broadcast, barriers, the band
+    # protocol's all-gathers and gathers, --reference_tiling's gather_object) runs over RCCL on a one-GPU box (tests/test_cli_gpu.py)
+    if world > 1 or os.environ.get("CERB_FORCE_DIST"):  # "nccl" = RCCL over xGMI, one process per GPU; "gloo" = host-staged collectives (cerberus_amd/hostdist.py)
         dist = launch.init_dist(backend, local)
         watch = launch.PhaseWatch(rank)
         with watch.phase("rank identity all-gather (first collective on the communicator)"):
@@ -114,8 +116,10 @@ def main(argv=None):
             settings = yaml.full_load(fh)
         decoders, model_args = settings["dataset_kwargs"]["req_target_code"], settings["model_kwargs"]
     manager = InferManager(checkpoint_path=checkpoint, decoder_dict=decoders, model_args=model_args)
-    # a second handle with the same weights: WSIRunner alternates batches between the two on two streams (+2 .. 3 %; CERB_WSI_STREAMS=1: one handle)
-    twin = manager.net.twin() if os.environ.get("CERB_WSI_STREAMS", "2") == "2" else None
+    # a second handle with the same weights (WSIRunner alternates batches between the two on two streams: +2 .. 3 %; CERB_WSI_STREAMS=1: one handle)
+    # is made per slide, and only when cerberus_amd.stream_bands.plan_slide finds room for its workspace beside everything else
+    want_twin = os.environ.get("CERB_WSI_STREAMS", "2") == "2"
+    twin = None
 
     ext = args["--wsi_file_ext"]
     slides = sorted(glob.glob(os.path.join(args["--input_dir"], "*" + ext))) if args["--input_dir"] else []
@@ -160,81 +164,112 @@ def main(argv=None):
                 os.makedirs(os.path.join(out_dir, "mask"), exist_ok=True)
                 Image.fromarray(mask * 255).save(os.path.join(out_dir, "mask", base + ".png"))
         check_shardable((H, W), out, world)
-        run = WSIRunner(manager.net, (H, W), win, out, batch, rank, world, patch_sel=sel, twin=twin)
-        y0, y1 = run.slab_rows()  # this rank's band + context halo
-        t_prep = time.perf_counter()
+        # Capacity check BEFORE anything slide-sized is allocated (the reference streams any slide through 15000^2 tiles + memmaps,
+        # infer/wsi.py:551-556, 899): resident band, resident without the second handle, or -- one rank -- sequential sub-bands
+        # (cerberus_amd/stream_bands.py); a band that fits neither way ends here with the numbers instead of inside torch.zeros.
+        from cerberus_amd.stream_bands import infer_and_label_streamed, plan_slide
+
+        plan = plan_slide(manager.net, (H, W), win, out, batch, rank, world, want_twin=want_twin, max_band_px=ONE_CALL_PX if world == 1 else None,
+                          allow_stream=(mask is None and not args["--reference_tiling"]))
+        if plan.twin and twin is None:
+            twin = manager.net.twin()
         if log:
-            log.info("Preparing Input Output Placement: {0}".format(t_prep - t0))
-        # CERB_WSI_OVERLAP_TAIL=1 (one GPU, a slide labelled in several local bands): the nuclei bands are labelled on a side stream while the rows
-        # below are still being inferred (shard_postproc.IncrementalLocalLabeller); a band is started a few batches after its rows became final, so
-        # that the host's waits inside the labelling call have queued inference to hide behind.  Off by default: on resident data the labelling's
-        # kernels cost the saturated inference more than the tail they remove (bench.py --overlap-tail: 149.6 against 150.6 Mpx/s).
-        pre, progress = {}, None
-        if mask is None and world == 1 and H * W > ONE_CALL_PX and os.environ.get("CERB_WSI_OVERLAP_TAIL", "0") == "1":
-            from collections import deque
-
-            from cerberus_amd.shard_postproc import band_view, make_incremental
-
-            pre = make_incremental(band_view(run, H, W), dist, max_band_px=ONE_CALL_PX)
-            if pre:
-                pending = deque()
-
-                def progress(n_done, events, pending=pending, pre=pre, run=run):
-                    pending.append((run.rows_final(n_done), events))
-                    if len(pending) > 6:
-                        rows_final, evs = pending.popleft()
-                        for lab in pre.values():
-                            lab.feed(rows_final, evs)
-        if host is None:
-            run.infer_band(synth_slide(y1 - y0, W, y0=y0, seed=seed), y0, progress=progress)
-        elif isinstance(host, np.ndarray) and not isinstance(host, np.memmap):  # already in RAM: one 50 GB/s copy, nothing to hide
-            run.infer_band(torch.from_numpy(np.ascontiguousarray(host[y0:y1])).cuda(), y0, progress=progress)
-        else:  # a slide on disk (memory-mapped array, tiled TIFF / .svs pyramid): read / decode + upload chunk by chunk on a copy
-            up = SlabUploader(host, y0, y1)  # stream underneath the inference of the rows above
-            run.infer_band(up.slab, y0, ready=up.upload_until, progress=progress)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        if dist is not None:
-            with watch.phase("end-of-inference barrier (%s)" % base):
-                dist.barrier()
-        if log:
-            log.info("Inference Time: {0}".format(t1 - t_prep))
-        records = None
-        pprof = {}
-        if mask is None and (world > 1 or H * W > ONE_CALL_PX):
-            # band-local labelling with slide-global ids; only int32 label bands and the class maps travel to the root.  On ONE GPU a
-            # slide too large for a single labelling call (96 B / px of workspace, 2^31 px) streams through the same protocol band by band
-            from cerberus_amd.shard_postproc import postprocess_bands_and_gather
-
-            inst, _, maps = postprocess_bands_and_gather(run, H, W, rank, world, dist, max_band_px=ONE_CALL_PX if world == 1 else None, prof=pprof, watch=watch, pre=pre)
-        else:  # with a mask gland / lumen are labelled per tissue region (infer/wsi.py:730-835), on the root
-            with watch.phase("canvas gather to rank 0 (%s)" % base):
-                maps = run.gather_to_root(dist)
-            if rank == 0 and mask is not None:
-                from cerberus_amd.postproc import postproc_device
-                from cerberus_amd.tissue import postprocess_regions
-
-                regions = TissueRegions(torch.from_numpy(mask).cuda())
-                inst = {"Nuclei": postproc_device(maps["Nuclei-INST"], "Nuclei", exact_ties=False)[0]} if "Nuclei-INST" in maps else {}
-                records = postprocess_regions(maps, (H, W), regions)
-            elif rank == 0:
-                inst, _ = WSIRunner.postprocess(maps, wsi_mode=True)
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        ref_nuclei = None
-        if args["--reference_tiling"] and "Nuclei-INST" in run.canv:
-            # the reference's own tile sets and margin rules (infer/wsi.py:81-268, 642-684) over the band canvases, every rank labelling the tiles
-            # that start in its band (rows below it fetched from its neighbours), each tile with skimage's tie order: the reference's instance
-            # set exactly, seam losses included; merged on rank 0
-            from cerberus_amd.ref_tiling import reference_tiled_nuclei_sharded
-
-            valid = max(0, min(run.band_h, H - run.r0 * out))
-            tprof = {}
-            ref_nuclei = reference_tiled_nuclei_sharded(run.canv["Nuclei-INST"][:valid], None if "Nuclei-TYPE" not in run.canv else run.canv["Nuclei-TYPE"][:valid],
-                                                        run.r0 * out, (H, W), rank, world, dist, tile_shape=4096, margin=64, patch_output_shape=out, watch=watch,
-                                                        prof=tprof, as_part=True)  # arrays: the writer process builds the entries
+            log.info("Memory plan: {0}".format(plan))
+        if plan.mode == "streamed":
+            t_prep = time.perf_counter()
+            if host is None:
+                source = lambda a, b: synth_slide(b - a, W, y0=a, seed=seed)  # noqa: E731
+            elif isinstance(host, np.ndarray) and not isinstance(host, np.memmap):
+                source = lambda a, b: torch.from_numpy(np.ascontiguousarray(host[a:b])).cuda()  # noqa: E731
+            else:
+                def source(a, b):
+                    up = SlabUploader(host, a, b)
+                    return up.slab, up.upload_until
+            pprof, records, ref_nuclei = {}, None, None
+            inst, _, maps = infer_and_label_streamed(manager.net, source, (H, W), win, out, batch, plan.sub_bands, prof=pprof)
+            torch.cuda.synchronize()
+            t1 = t2 = time.perf_counter()
             if log:
-                log.info("Reference-Tiled Nuclei Time: {0} ({1} tiles on rank 0)".format(time.perf_counter() - t2, tprof.get("tiles")))
+                log.info("Inference Time: {0} ({1} sub-bands streamed through HBM)".format(pprof.get("stream_infer_s"), plan.sub_bands))
+                log.info("Nuclei, Gland & Lumen Labelling Time (inside the stream): {0}".format(pprof.get("stream_label_s")))
+        else:
+            run = WSIRunner(manager.net, (H, W), win, out, batch, rank, world, patch_sel=sel, twin=twin if plan.twin else None)
+            y0, y1 = run.slab_rows()  # this rank's band + context halo
+            t_prep = time.perf_counter()
+            if log:
+                log.info("Preparing Input Output Placement: {0}".format(t_prep - t0))
+            # CERB_WSI_OVERLAP_TAIL=1 (one GPU, a slide labelled in several local bands): the nuclei bands are labelled on a side stream while the rows
+            # below are still being inferred (shard_postproc.IncrementalLocalLabeller); a band is started a few batches after its rows became final, so
+            # that the host's waits inside the labelling call have queued inference to hide behind.  Off by default: on resident data the labelling's
+            # kernels cost the saturated inference more than the tail they remove (bench.py --overlap-tail: 149.6 against 150.6 Mpx/s).
+            pre, progress = {}, None
+            if mask is None and world == 1 and H * W > ONE_CALL_PX and os.environ.get("CERB_WSI_OVERLAP_TAIL", "0") == "1":
+                from collections import deque
+
+                from cerberus_amd.shard_postproc import band_view, make_incremental
+
+                pre = make_incremental(band_view(run, H, W), dist, max_band_px=ONE_CALL_PX)
+                if pre:
+                    pending = deque()
+
+                    def progress(n_done, events, pending=pending, pre=pre, run=run):
+                        pending.append((run.rows_final(n_done), events))
+                        if len(pending) > 6:
+                            rows_final, evs = pending.popleft()
+                            for lab in pre.values():
+                                lab.feed(rows_final, evs)
+            if host is None:
+                run.infer_band(synth_slide(y1 - y0, W, y0=y0, seed=seed), y0, progress=progress)
+            elif isinstance(host, np.ndarray) and not isinstance(host, np.memmap):  # already in RAM: one 50 GB/s copy, nothing to hide
+                run.infer_band(torch.from_numpy(np.ascontiguousarray(host[y0:y1])).cuda(), y0, progress=progress)
+            else:  # a slide on disk (memory-mapped array, tiled TIFF / .svs pyramid): read / decode + upload chunk by chunk on a copy
+                up = SlabUploader(host, y0, y1)  # stream underneath the inference of the rows above
+                run.infer_band(up.slab, y0, ready=up.upload_until, progress=progress)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            if dist is not None:
+                with watch.phase("end-of-inference barrier (%s)" % base):
+                    dist.barrier()
+            if log:
+                log.info("Inference Time: {0}".format(t1 - t_prep))
+            records = None
+            pprof = {}
+            if mask is None and (dist is not None or H * W > ONE_CALL_PX):
+                # band-local labelling with slide-global ids; only int32 label bands and the class maps travel to the root.  On ONE GPU a
+                # slide too large for a single labelling call (96 B / px of workspace, 2^31 px) streams through the same protocol band by band
+                from cerberus_amd.shard_postproc import postprocess_bands_and_gather
+
+                inst, _, maps = postprocess_bands_and_gather(run, H, W, rank, world, dist, max_band_px=ONE_CALL_PX if world == 1 else None, prof=pprof, watch=watch, pre=pre)
+            else:  # with a mask gland / lumen are labelled per tissue region (infer/wsi.py:730-835), on the root
+                with watch.phase("canvas gather to rank 0 (%s)" % base):
+                    maps = run.gather_to_root(dist)
+                if rank == 0 and mask is not None:
+                    from cerberus_amd.postproc import postproc_device
+                    from cerberus_amd.tissue import postprocess_regions
+
+                    regions = TissueRegions(torch.from_numpy(mask).cuda())
+                    inst = {"Nuclei": postproc_device(maps["Nuclei-INST"], "Nuclei", exact_ties=False)[0]} if "Nuclei-INST" in maps else {}
+                    records = postprocess_regions(maps, (H, W), regions)
+                elif rank == 0:
+                    inst, _ = WSIRunner.postprocess(maps, wsi_mode=True)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            ref_nuclei = None
+            if args["--reference_tiling"] and "Nuclei-INST" in run.canv:
+                # the reference's own tile sets and margin rules (infer/wsi.py:81-268, 642-684) over the band canvases, every rank labelling the tiles
+                # that start in its band (rows below it fetched from its neighbours), each tile with skimage's tie order: the reference's instance
+                # set exactly, seam losses included; merged on rank 0
+                from cerberus_amd.ref_tiling import reference_tiled_nuclei_sharded
+
+                valid = max(0, min(run.band_h, H - run.r0 * out))
+                tprof = {}
+                ref_nuclei = reference_tiled_nuclei_sharded(run.canv["Nuclei-INST"][:valid], None if "Nuclei-TYPE" not in run.canv else run.canv["Nuclei-TYPE"][:valid],
+                                                            run.r0 * out, (H, W), rank, world, dist, tile_shape=4096, margin=64, patch_output_shape=out, watch=watch,
+                                                            prof=tprof, as_part=True)  # arrays: the writer process builds the entries
+                if log:
+                    log.info("Reference-Tiled Nuclei Time: {0} ({1} tiles on rank 0)".format(time.perf_counter() - t2, tprof.get("tiles")))
+            if twin is not None and plan.twin and run.twin is None:
+                twin = None  # its workspace did not fit after all (WSIRunner dropped it): release the handle
         if rank != 0:
             continue
         # the reference times nuclei, the tissue map and gland + lumen as separate phases (infer/wsi.py:684, 719, 856); here the three tissues

@@ -427,3 +427,119 @@ def test_run_infer_wsi_writes_a_log_per_slide_and_self_spawns(tmp_path):
             assert np.array_equal(za[k], zb[k]), k
     text = open(glob.glob(str(tmp_path / "log2" / "s1_*_std.log"))[0]).read()
     assert "Nuclei Post Proc Time:" in text  # the band protocol times the tissues apart
+
+
+def test_run_infer_wsi_streams_a_slide_that_does_not_fit_the_hbm_budget(tmp_path):
+    """the slide driver prices the band against the free HBM (capped here through CERB_HBM_BUDGET_GB) before it allocates
+    anything; a slide that does not fit resident runs as sequential sub-bands (cerberus_amd/stream_bands.py) and must write the SAME label maps and
+    class maps as the resident run, bit for bit; a budget that fits neither way ends with a ValueError that names the bytes, not with an OOM."""
+    from cerberus_amd.stream_bands import plan_slide
+    from cerberus_amd.tile import InferManager
+    from cerberus_amd.weights import DEFAULT_REQ_TARGET_CODE, default_model_kwargs
+
+    H, W, batch = 4300, 1100, 6
+    net = InferManager(checkpoint_path=None, decoder_dict=dict(DEFAULT_REQ_TARGET_CODE), model_args=default_model_kwargs()).net
+    resident = plan_slide(net, (H, W), 256, 256, batch, budget=1e15, want_twin=False, max_band_px=400 * 1000 * 1000).need
+    spec = tmp_path / "slides"
+    spec.mkdir()
+    (spec / "s1.txt").write_text("synthetic:%dx%d:11" % (H, W))
+    cmd = [sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--synthetic", "--input_dir=%s" % spec, "--wsi_file_ext=.txt", "--batch_size=%d" % batch,
+           "--patch_input_shape=256", "--patch_output_shape=256", "--save_label_maps"]
+    env = dict(os.environ, CERB_WSI_STREAMS="1")
+    r = subprocess.run(cmd + ["--output_dir=%s" % (tmp_path / "a"), "--logging_dir=%s" % (tmp_path / "la")], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env_s = dict(env, CERB_HBM_BUDGET_GB="%.6f" % ((resident - 2e6) / 1e9))
+    r = subprocess.run(cmd + ["--output_dir=%s" % (tmp_path / "b"), "--logging_dir=%s" % (tmp_path / "lb")], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env_s)
+    assert r.returncode == 0, r.stderr[-2000:]
+    logs = "".join(open(os.path.join(str(tmp_path / "lb"), f)).read() for f in os.listdir(str(tmp_path / "lb")))
+    assert "mode='streamed'" in logs and "sub-bands streamed through HBM" in logs, logs[-1500:]
+    assert "mode='resident'" in "".join(open(os.path.join(str(tmp_path / "la"), f)).read() for f in os.listdir(str(tmp_path / "la")))
+    za, zb = np.load(str(tmp_path / "a" / "s1.npz")), np.load(str(tmp_path / "b" / "s1.npz"))
+    assert set(za.files) == set(zb.files)
+    for k in za.files:
+        assert za[k].shape == zb[k].shape, k
+        # class maps: bit for bit.  Label maps: the seeded test weights give slide-sized blobs, which any window cuts (the protocol reports it:
+        # n_truncated > 0) -- exact equality of label maps is tests/test_drivers_gpu.py::test_slide_streamed_in_sub_bands_equals_the_resident_run's
+        # job, on structured maps; here the foreground must agree on all but the cut instances' pixels
+        if k.startswith("type_") or k == "pclass":
+            assert np.array_equal(za[k], zb[k]), k
+        else:
+            assert ((za[k] > 0) != (zb[k] > 0)).mean() < 0.02, (k, ((za[k] > 0) != (zb[k] > 0)).mean())
+    env_x = dict(env, CERB_HBM_BUDGET_GB="1.0")
+    r = subprocess.run(cmd + ["--output_dir=%s" % (tmp_path / "c")], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env_x)
+    assert r.returncode != 0 and "ValueError" in r.stderr and "GB resident" in r.stderr, r.stderr[-1500:]
+
+
+def test_bench_train_nccl_branch_at_world_one():
+    """the training step's bucketed gradient all-reduce (cerberus_amd/train.py: allreduce_grads, models/opt.py has no DDP of its
+    own) over a ONE-rank RCCL communicator: `bench.py --mode train --force-dist --backend nccl` must open the communicator, reduce every bucket on
+    the device and reach the SAME loss as the run without a process group (a one-rank sum / 1 is the identity)."""
+    ref = _bench([sys.executable, "bench.py", "--mode", "train", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    one = _bench([sys.executable, "bench.py", "--mode", "train", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--force-dist", "--backend", "nccl"])
+    mg = one["multi_gpu"]
+    assert one["n_gpus"] == 1 and mg["world"] == 1 and mg["backend"].startswith("rccl") and ref["multi_gpu"]["backend"] is None
+    assert one["config"]["last_overall_loss"] == ref["config"]["last_overall_loss"]
+    phases = {r["kernel"]: r["ms_per_step"] for r in one["kernels"]}
+    assert phases.get("(allreduce)", 0.0) > 0.0  # the buckets really went through the communicator
+
+
+def test_run_infer_wsi_nccl_world_one_equals_no_dist(tmp_path):
+    """Every collective of the N-rank slide path -- skip-flag broadcast, barriers, the band protocol's all-gathers, the label / class-map
+    gathers, and (second run) --reference_tiling's tile exchange + gather_object -- over a ONE-rank RCCL communicator (CERB_FORCE_DIST=1,
+    `--gpu=0`): first contact with 8 GPUs then changes N and nothing else.  Label maps, class maps and the instance dictionary's geometry must
+    equal the run without a process group bit for bit."""
+    import joblib
+
+    spec = tmp_path / "slides"
+    spec.mkdir()
+    (spec / "s1.txt").write_text("synthetic:900x1100:5")
+    base = [sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--synthetic", "--gpu=0", "--input_dir=%s" % spec, "--wsi_file_ext=.txt", "--batch_size=6",
+            "--patch_input_shape=256", "--patch_output_shape=256", "--save_label_maps"]
+    for extra, tag in (([], "plain"), (["--reference_tiling"], "reftile")):
+        outs = {}
+        for mode in ("nodist", "nccl"):
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561")
+            if mode == "nccl":
+                env.update(CERB_FORCE_DIST="1", CERB_DIST_BACKEND="nccl")
+            out = tmp_path / ("%s_%s" % (tag, mode))
+            r = subprocess.run(base + extra + ["--output_dir=%s" % out], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+            assert r.returncode == 0, r.stderr[-2000:]
+            assert ("ranks: 1 over rccl" in r.stdout) == (mode == "nccl"), r.stdout[-1500:]
+            outs[mode] = out
+        za, zb = np.load(str(outs["nodist"] / "s1.npz")), np.load(str(outs["nccl"] / "s1.npz"))
+        assert set(za.files) == set(zb.files)
+        for k in za.files:
+            assert np.array_equal(za[k], zb[k]), (tag, k)
+        da, db = joblib.load(str(outs["nodist"] / "dat" / "s1.dat")), joblib.load(str(outs["nccl"] / "dat" / "s1.dat"))
+        for t in ("Nuclei", "Gland", "Lumen"):
+            ba = sorted(tuple(int(v) for v in d["box"]) for d in da[t].values())
+            bb = sorted(tuple(int(v) for v in d["box"]) for d in db[t].values())
+            assert ba == bb, (tag, t, len(ba), len(bb))
+
+
+def test_run_infer_tile_nccl_world_one_equals_no_dist(tmp_path):
+    """Tile mode shards files and has no data-path collective; its ranks still open the communicator (identity all-gather, leaving barrier).  With
+    CERB_FORCE_DIST=1 and `--gpu=0` that happens over a one-rank RCCL communicator, and the written maps equal the run without one."""
+    import scipy.io as sio
+    from PIL import Image
+
+    inp = tmp_path / "in"
+    inp.mkdir()
+    rs = np.random.RandomState(4)
+    Image.fromarray(rs.randint(0, 256, (300, 280, 3)).astype(np.uint8)).save(str(inp / "a.png"))
+    base = [sys.executable, os.path.join(ROOT, "run_infer_tile.py"), "--synthetic", "--gpu=0", "--input_dir=%s" % inp, "--batch_size=8", "--patch_input_shape=256",
+            "--patch_output_shape=256"]
+    outs = {}
+    for mode in ("nodist", "nccl"):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29563")
+        if mode == "nccl":
+            env.update(CERB_FORCE_DIST="1", CERB_DIST_BACKEND="nccl")
+        out = tmp_path / mode
+        r = subprocess.run(base + ["--output_dir=%s" % out], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert ("ranks: 1 over rccl" in r.stdout) == (mode == "nccl"), r.stdout[-1500:]
+        outs[mode] = out
+    for t in ("gland", "lumen", "nuclei", "pclass"):
+        a, b = sio.loadmat(str(outs["nodist"] / ("%s_mat" % t) / "a.mat")), sio.loadmat(str(outs["nccl"] / ("%s_mat" % t) / "a.mat"))
+        key = "pclass" if t == "pclass" else "inst_map"
+        assert np.array_equal(a[key], b[key]), t

@@ -459,3 +459,64 @@ def test_reference_tiling_sharded_over_ranks_equals_one_rank(world, bounds):
     assert got[0][1] == ref
     # every tile is labelled by exactly one rank; more than one rank has tiles (a rank whose band starts below the last tile row has none)
     assert sum(g[2] for g in got) == sum(len(b) for b, _ in rt.get_tile_info((W, H), [1024, 1024], 32, [16, 16])) and sum(g[2] > 0 for g in got) >= 2
+
+
+class _PixelNet(object):
+    """Stand-in for NetDesc in the streaming test: every head is a per-pixel function of the tile (win == out), so that the slide's pixels can carry
+    STRUCTURED probability maps (the seeded test weights make one slide-sized nuclei blob, which no band protocol can cut exactly).
+    R / G = nuclei inner / contour, B = gland inner; lumen = the gland's core."""
+    _decoders = [("Lumen", "INST", 3, "Lumen-INST"), ("Gland", "INST", 3, "Gland-INST"), ("Nuclei", "INST", 3, "Nuclei-INST"),
+                 ("Nuclei#TYPE", "TYPE", 7, "Nuclei-TYPE"), ("Gland#TYPE", "TYPE", 3, "Gland-TYPE"), ("Patch-Class", "OUT", 9, "Patch-Class")]
+
+    def _run(self, tiles, oh, ow, outs, _, tile_off=None, row_stride=None, type_is_u8=True):
+        t = tiles.float() / 255.0
+        zero = torch.zeros_like(t[..., 0])
+        vals = [torch.stack([(t[..., 2] - 0.6).clamp(0, 1) * 2.5, zero], -1), torch.stack([t[..., 2], zero], -1), t[..., 0:2].contiguous(),
+                (tiles[..., 0] >> 6).to(torch.uint8), (tiles[..., 2] >> 7).to(torch.uint8), (tiles[..., 1] & 7).float()]
+        idx = (tile_off[:, None, None] + torch.arange(oh, device=tiles.device)[None, :, None] * row_stride + torch.arange(ow, device=tiles.device)[None, None, :]).reshape(-1)
+        for o, v in zip(outs, vals):
+            flat = o.view(-1, 2) if o.dim() == 3 else o.view(-1)
+            flat[idx] = v.reshape((-1, 2) if o.dim() == 3 else (-1,))
+
+
+def test_slide_streamed_in_sub_bands_equals_the_resident_run(manager):
+    """cerberus_amd.stream_bands (slides whose canvases exceed HBM): the band walked as sequential sub-bands -- a sub-band's probability
+    canvases live only until the sub-band below has been inferred, labelling / ownership / global ids are the band protocol run in band order -- must
+    give the resident run's label maps and class maps BIT FOR BIT (ids come out in first-pixel raster order whatever the cuts are), with no
+    instance cut by a window (n_truncated == 0) and the same counts.  Structured maps through a per-pixel stand-in network; then the real network
+    (whose test weights give slide-sized blobs: its class maps must be equal, its label maps wherever the protocol reports them exact)."""
+    from cerberus_amd import synth_maps
+    from cerberus_amd.shard_postproc import postprocess_bands_and_gather, same_partition
+    from cerberus_amd.stream_bands import infer_and_label_streamed
+
+    H, W, margin = 1500, 1300, 256  # (the tallest gland cluster of these maps: 140 rows)
+    nuc, gl = synth_maps.nuclei_maps(H, W, 5, 1500.0), synth_maps.blob_maps(H, W, 6, 40, 24.0, 50.0, rim=4.0, sharp=1.0)
+    slide = torch.from_numpy(np.stack([nuc[..., 0], nuc[..., 1], gl[..., 0]], -1).clip(0, 1) * 255.0).to(torch.uint8).cuda()
+    for net, strict in ((_PixelNet(), True), (manager.net, False)):
+        run = WSIRunner(net, (H, W), 256, 256, batch_size=4)
+        run.infer_band(slide, 0)
+        want, want_info, want_small = postprocess_bands_and_gather(run, H, W, 0, 1, None, margin=margin, guard=16)
+        del run
+        if strict:
+            assert int(want["Nuclei"].max()) > 500 and int(want["Gland"].max()) > 5
+        for nb, twin in ((3, None), (2, None if strict else manager.net.twin())):
+            calls = []
+
+            def source(y0, y1):
+                calls.append((y0, y1))
+                return slide[y0:y1].contiguous()
+
+            prof = {}
+            got, info, small = infer_and_label_streamed(net, source, (H, W), 256, 256, 4, nb, margin=margin, guard=16, twin=twin, prof=prof)
+            assert len(calls) == nb and calls[0][0] == 0 and calls[-1][1] == H and "stream_infer_s" in prof
+            assert set(got) == set(want) and set(small) == set(want_small)
+            for k in want_small:
+                assert torch.equal(small[k], want_small[k]), (nb, k)
+            for t in want:
+                assert got[t].shape == want[t].shape and info[t]["local_bands"] == nb, (nb, t, info[t])
+                if strict:
+                    assert info[t]["n_truncated"] == 0 and info[t]["n_unresolved"] == 0, (nb, t, info[t])
+                    assert info[t]["n_total"] == want_info[t]["n_total"], (nb, t)
+                    assert torch.equal(got[t], want[t]), (nb, t)
+                elif info[t]["n_truncated"] == 0 and info[t]["n_unresolved"] == 0:  # (the test weights' slide-sized blobs are cut by any window: then the
+                    assert same_partition(got[t].cpu().numpy(), want[t].cpu().numpy()), (nb, t)  # protocol itself reports that it is not exact)

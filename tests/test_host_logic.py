@@ -537,3 +537,37 @@ def test_incremental_local_labeller_equals_run_local():
     assert lab.early == 2 and lab.done == nb and n_got == n_want > 50 and info_got == info_want
     for a, b in zip(got, want):
         assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_slide_memory_plan_picks_resident_twin_streamed_or_refuses():
+    """cerberus_amd.stream_bands.plan_slide prices a rank's band against the HBM budget BEFORE anything is allocated: resident with the second
+    handle, resident on one handle, sequential sub-bands (one rank), or a ValueError that names the bytes -- never an OOM inside torch.zeros."""
+    import pytest
+
+    from cerberus_amd.stream_bands import canvas_bytes_per_px, forward_workspace_bytes, plan_slide
+
+    class Net(object):
+        _decoders = [("Lumen", "INST", 3, "Lumen-INST"), ("Gland", "INST", 3, "Gland-INST"), ("Nuclei", "INST", 3, "Nuclei-INST"),
+                     ("Nuclei#TYPE", "TYPE", 7, "Nuclei-TYPE"), ("Gland#TYPE", "TYPE", 3, "Gland-TYPE"), ("Patch-Class", "OUT", 9, "Patch-Class")]
+
+    assert canvas_bytes_per_px(Net()) == (30, 24)
+    hw, fwd = (40000, 40000), forward_workspace_bytes(64, 256)
+    big = plan_slide(Net(), hw, 256, 256, 64, budget=288e9, max_band_px=400e6)
+    assert big.mode == "resident" and big.twin and big.need < 288e9
+    one = plan_slide(Net(), hw, 256, 256, 64, budget=big.need - 1e9, max_band_px=400e6)
+    assert one.mode == "resident" and not one.twin and abs((big.need - one.need) - fwd) < 1
+    st = plan_slide(Net(), hw, 256, 256, 64, budget=one.need - 1e9, max_band_px=400e6)
+    assert st.mode == "streamed" and st.sub_bands >= 2 and not st.twin and st.need <= st.budget
+    # the verdict's example: 100k x 80k on one 288 GB GPU (336 GB resident) streams; the same slide under a 60 GB cap does not fit even streamed
+    # (class canvases + label maps stay resident: 12 B/px = 96 GB) and says so
+    huge = plan_slide(Net(), (100000, 80000), 256, 256, 64, budget=280e9, max_band_px=400e6)
+    assert huge.mode == "streamed" and huge.sub_bands >= 2
+    with pytest.raises(ValueError, match="class canvases"):
+        plan_slide(Net(), (100000, 80000), 256, 256, 64, budget=60e9, max_band_px=400e6)
+    with pytest.raises(ValueError, match="use more ranks"):  # streaming is a one-rank path: N ranks split the slide N ways first
+        plan_slide(Net(), hw, 256, 256, 64, rank=1, world=2, budget=20e9)
+    with pytest.raises(ValueError, match="GB resident"):  # tissue masks / --reference_tiling need the resident canvases
+        plan_slide(Net(), hw, 256, 256, 64, budget=one.need - 1e9, max_band_px=400e6, allow_stream=False)
+    # sub-bands are never shorter than two halo margins (the band protocol's invariant)
+    tiny = plan_slide(Net(), (4096, 2048), 256, 256, 4, budget=plan_slide(Net(), (4096, 2048), 256, 256, 4, budget=1e12, want_twin=False).need - 1e6)
+    assert tiny.mode == "streamed" and (16 // tiny.sub_bands) * 256 >= 1024
