@@ -526,6 +526,8 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
         torch.cuda.synchronize()
         phase["tail_s"] = time.perf_counter() - t1
         res.update(inst=inst, info=info, small=small)
+        if small is not None:  # proof that the tail consumed what THIS job's inference produced (checked against the canvases outside the timed region)
+            res["small_sum"] = {k: float(v.double().sum().item()) for k, v in small.items()}
 
     if os.environ.get("CERB_BENCH_PROBE_REPEAT"):  # developer probe: is the first full-size tail slower than the second (allocator warm-up)?
         for _ in range(int(os.environ["CERB_BENCH_PROBE_REPEAT"])):
@@ -541,6 +543,10 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             phase[key] = float(t.item())
     info = res["info"]
+    small_sum = res.get("small_sum")
+    if small_sum is not None and world == 1:  # one rank: the gathered class maps ARE the inference's canvases, cropped to the slide
+        for k, v in small_sum.items():
+            assert v == float(run.canv[k][:valid, :W].double().sum().item()), "the tail's %s map is not the inference's canvas" % k
     n_inst = {t: int(i.get("n_total", 0)) for t, i in info.items()}
     checks = {t: {"n_truncated": int(i.get("n_truncated", 0)), "n_unresolved": int(i.get("n_unresolved", 0)), "local_bands": int(i.get("local_bands", 1)),
                   "bands_labelled_under_inference": int(i.get("bands_labelled_under_inference", 0))}
@@ -665,6 +671,9 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
             "inference_Mpx_s": round(px / phase["inference_s"] / 1e6, 3),
             "postproc_and_stitch_s": round(phase["tail_s"], 3),
             "whole_job_s": round(dt, 3),
+            "tail_inputs": {"INST probability maps": "seeded structured maps of the slide's size (random weights make no instances; cerberus_amd/synth_maps.py)",
+                            "TYPE and Patch-Class maps": "the canvases this job's inference wrote (majority types of the instance tables, class-map gather)",
+                            "class_canvas_checksum": small_sum},
             "nuclei_scheme": "exact band ownership (every instance of the whole-slide labelling once; cerberus_amd/shard_postproc.py) -- the reference's own "
                              "4096-px tile sets + 64-px margins (`run_infer_wsi.py --reference_tiling`) are timed beside it as `ref_tiling`",
             "inference_algorithmic_tflops_per_gpu": round(n_tiles * flops_tile / phase["inference_s"] / 1e12 / world, 2),

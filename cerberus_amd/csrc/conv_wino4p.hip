@@ -571,11 +571,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int b = 0; b < 6; ++b) {
                     const f32x4 m0 = acc[0 * 6 + b][tb], m1 = acc[1 * 6 + b][tb], m2 = acc[2 * 6 + b][tb], m3 = acc[3 * 6 + b][tb],
                                 m4 = acc[4 * 6 + b][tb], m5 = acc[5 * 6 + b][tb];
+#ifdef P4_ABL_NOVPASS  // ablation (round 5): the vertical pass costs nothing -- the upper bound of hiding it under the last chunk
+                    T[0][b] = m0; T[1][b] = m1 + m5; T[2][b] = m2 + m3; T[3][b] = m4;
+#else
                     const f32x4 s1 = m1 + m2, d1 = sub4(m1, m2), s2 = m3 + m4, d2 = sub4(m3, m4);
                     T[0][b] = m0 + s1 + s2;
                     T[1][b] = d1 + 2.f * d2;
                     T[2][b] = s1 + 4.f * s2;
                     T[3][b] = (d1 + 8.f * d2) + m5;
+#endif
                 }
                 const int rem_y = p.Ho - by_abs * BLK - 4 * (m_o >> 2), rem_x = p.Wo - bx_abs * BLK - 4 * (m_o & 3);  // partial blocks: rows / columns of this lane's tile inside the image
 #pragma unroll

@@ -364,6 +364,182 @@ static int ccl_run(const uint8_t* fg, uint8_t val, int* L, int H, int W, hipStre
     return 0;
 }
 
+// =================================================================================================================
+// Two-colour labelling of the nuclei MARKER image (round 5).  loader/postproc.py:370-377 is
+//     label(inner > 0.5) -> remove_small_objects(4) -> binary_fill_holes -> label
+// which round 4 ran as THREE union-find labellings (markers; their background, for the holes; the filled markers).  Here the marker image is
+// labelled ONCE in both colours (a pixel is united with its 4-neighbours of the SAME colour), and the two later steps are edits of that one forest:
+//   * a foreground component smaller than min_size turns into background: its pixels are united with their background neighbours;
+//   * a background component that does not touch the image border is a hole: its pixels turn into foreground and are united with their
+//     foreground neighbours (this is also what merges two markers that only touched diagonally around a hole).
+// Roots stay "smallest raster index of the set", so the rank of a final root among all roots is scipy's label id as before.
+// =================================================================================================================
+__global__ __launch_bounds__(256) void ccl2_tile_kernel(const uint8_t* __restrict__ fg, int* __restrict__ L, int H, int W, int tiles_x, int n_tiles) {
+    __shared__ int sl[CT_H * CT_W];
+    __shared__ u64 sc[CT_H], sv[CT_H], ss[CT_H];  // per row: colour bits, valid bits, run starts
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int tx0 = (tile % tiles_x) * CT_W, ty0 = (tile / tiles_x) * CT_H;
+        const int x = tx0 + lane;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave * 8 + i, y = ty0 + r;
+            const bool v = x < W && y < H;
+            const bool f = v && fg[(long long)y * W + x] != 0;
+            const u64 c = __ballot(f), vm = __ballot(v);
+            const u64 starts = ((c ^ (c << 1)) | 1ull) & vm;  // a run starts where the colour changes (pixels beyond the image sit at the right end only)
+            sl[r * CT_W + lane] = v ? r * CT_W + 63 - __clzll((long long)(starts & ((2ull << lane) - 1))) : -1;
+            if (lane == 0) {
+                sc[r] = c;
+                sv[r] = vm;
+                ss[r] = starts;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave * 8 + i;
+            if (r == 0) continue;
+            const u64 both = ~(sc[r] ^ sc[r - 1]) & sv[r] & sv[r - 1];
+            const u64 first = both & (ss[r] | ss[r - 1]);  // the lower run starts here, or the upper one does
+            if ((first >> lane) & 1) lds_union(sl, r * CT_W + lane, (r - 1) * CT_W + lane);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave * 8 + i, y = ty0 + r;
+            if (x < W && y < H) {
+                const int root = lds_find(sl, sl[r * CT_W + lane]);
+                L[(long long)y * W + x] = (ty0 + (root >> 6)) * W + tx0 + (root & 63);
+            }
+        }
+        __syncthreads();
+    }
+}
+__global__ void ccl2_seam_kernel(const uint8_t* __restrict__ fg, int* L, int H, int W, int tiles_x, int tiles_y) {
+    const unsigned sx = (unsigned)(tiles_x - 1), sy = (unsigned)(tiles_y - 1);
+    const unsigned nv = sx * (unsigned)H, nh = sy * (unsigned)W;
+    const unsigned total = nv + nh, stride = gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    for (unsigned i0 = blockIdx.x * blockDim.x + threadIdx.x - lane; i0 < total; i0 += stride) {
+        const unsigned i = i0 + lane;
+        int a = -1, b = -1;
+        if (i < nv) {
+            const unsigned k = i / (unsigned)H, y = i - k * (unsigned)H, x = (k + 1) * CT_W;
+            const long long p = (long long)y * W + x;
+            if ((fg[p] != 0) == (fg[p - 1] != 0)) {
+                a = (int)p;
+                b = (int)p - 1;
+            }
+        } else if (i < total) {
+            const unsigned j = i - nv;
+            const unsigned k = j / (unsigned)W, x = j - k * (unsigned)W, y = (k + 1) * CT_H;
+            const long long p = (long long)y * W + x;
+            const bool c = fg[p] != 0;
+            if (c == (fg[p - W] != 0)) {
+                const bool edge = (x % CT_W) == 0;
+                const bool low_starts = edge || (fg[p - 1] != 0) != c, up_starts = edge || (fg[p - W - 1] != 0) != c;
+                if (low_starts || up_starts) {
+                    a = (int)p;
+                    b = (int)(p - W);
+                }
+            }
+        }
+        const int ra = a >= 0 ? L[a] : -1, rb = b >= 0 ? L[b] : -2;  // (see ccl_seam_kernel: one union per run of equal root pairs)
+        const int pa = __shfl_up(ra, 1), pb = __shfl_up(rb, 1);
+        if (a >= 0 && ra != rb && !(lane > 0 && pa == ra && pb == rb)) uf_union(L, ra, rb);
+    }
+}
+// flatten both colours; area[root] += run length for FOREGROUND runs only (the background is a few huge sets: no atomics for them)
+__global__ void ccl2_flatten_area_kernel(int* L, const uint8_t* __restrict__ fg, int* __restrict__ area, int n) {
+    const int lane = threadIdx.x & 63;
+    for (long long base = (blockIdx.x * (long long)blockDim.x + threadIdx.x) - lane; base < n; base += (long long)gridDim.x * blockDim.x) {
+        const long long p = base + lane;
+        int r = -1;
+        bool f = false;
+        if (p < n) {
+            r = uf_find(L, (int)p);
+            L[p] = r;
+            f = fg[p] != 0;
+        }
+        const int key = f ? r : -1;
+        const int prev = __shfl_up(key, 1);
+        const bool head = key >= 0 && (lane == 0 || prev != key);
+        const unsigned long long bounds = __ballot(head || key < 0);
+        if (head) {
+            const unsigned long long after = lane == 63 ? 0ull : (bounds >> (lane + 1));
+            atomicAdd(&area[key], after ? __ffsll((long long)after) : 64 - lane);
+        }
+    }
+}
+// foreground components below min_size turn into background and join the background sets around them
+__global__ void ccl2_drop_small_kernel(uint8_t* m, int* L, const int* __restrict__ area, int min_size, int H, int W) {
+    const long long n = (long long)H * W;
+    const double invW = 1.0 / (double)W;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        if (!m[p]) continue;
+        const int r = L[p];  // a non-root pixel still names its (flattened) component root; a root that has already been united away names a
+        if (area[r] >= min_size) continue;  // background index, whose area is 0: "small" either way
+        int y, x;
+        pix_yx(p, W, invW, y, x);
+        m[p] = 0;
+        // (a neighbour that reads as background is background or a pixel of this same small component: uniting with either is right)
+        if (x > 0 && !m[p - 1]) uf_union(L, (int)p, (int)p - 1);
+        if (x < W - 1 && !m[p + 1]) uf_union(L, (int)p, (int)p + 1);
+        if (y > 0 && !m[p - W]) uf_union(L, (int)p, (int)(p - W));
+        if (y < H - 1 && !m[p + W]) uf_union(L, (int)p, (int)(p + W));
+    }
+}
+__global__ void ccl2_mark_border_kernel(const uint8_t* __restrict__ m, const int* L, int* __restrict__ border, int H, int W) {
+    const int per = 2 * (H + W);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per; i += gridDim.x * blockDim.x) {
+        long long p;
+        if (i < W) p = i;
+        else if (i < 2 * W) p = (long long)(H - 1) * W + (i - W);
+        else if (i < 2 * W + H) p = (long long)(i - 2 * W) * W;
+        else p = (long long)(i - 2 * W - H) * W + (W - 1);
+        if (!m[p]) border[uf_find(L, (int)p)] = 1;
+    }
+}
+// background sets that do not reach the border are holes: their pixels become foreground and join the foreground sets around them
+// (border[] is 1 only at the roots of border-touching background sets, which nothing is united with here; every other index reads 0)
+__global__ void ccl2_fill_kernel(uint8_t* m, int* L, const int* __restrict__ border, int H, int W) {
+    const long long n = (long long)H * W;
+    const double invW = 1.0 / (double)W;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        if (m[p]) continue;
+        if (border[uf_find(L, (int)p)]) continue;
+        int y, x;
+        pix_yx(p, W, invW, y, x);
+        m[p] = 1;
+        // (a neighbour that reads as foreground is foreground or a pixel of this same hole that was filled a moment ago: uniting with either is right)
+        if (x > 0 && m[p - 1]) uf_union(L, (int)p, (int)p - 1);
+        if (x < W - 1 && m[p + 1]) uf_union(L, (int)p, (int)p + 1);
+        if (y > 0 && m[p - W]) uf_union(L, (int)p, (int)(p - W));
+        if (y < H - 1 && m[p + W]) uf_union(L, (int)p, (int)(p + W));
+    }
+}
+// final marker labels: root for foreground pixels, -1 for the background
+__global__ void ccl2_final_kernel(int* L, const uint8_t* __restrict__ m, int n) {
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) L[p] = m[p] ? uf_find(L, (int)p) : -1;
+}
+static int markers_two_colour(uint8_t* mrk, int* L, int* area, int* border, int min_size, int H, int W, hipStream_t st) {
+    const int n = H * W;
+    const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H, n_tiles = tiles_x * tiles_y;
+    const unsigned g = grid_for(n);
+    if (hipMemsetAsync(area, 0, (size_t)n * 4, st) != hipSuccess || hipMemsetAsync(border, 0, (size_t)n * 4, st) != hipSuccess) return cerb_set_error("memset failed");
+    hipLaunchKernelGGL(ccl2_tile_kernel, dim3(n_tiles < 256 * 16 ? n_tiles : 256 * 16), dim3(256), 0, st, mrk, L, H, W, tiles_x, n_tiles);
+    const long long seams = (long long)(tiles_x - 1) * H + (long long)(tiles_y - 1) * W;
+    if (seams > 0) hipLaunchKernelGGL(ccl2_seam_kernel, dim3(grid_for(seams)), dim3(256), 0, st, mrk, L, H, W, tiles_x, tiles_y);
+    hipLaunchKernelGGL(ccl2_flatten_area_kernel, dim3(g), dim3(256), 0, st, L, mrk, area, n);
+    hipLaunchKernelGGL(ccl2_drop_small_kernel, dim3(g), dim3(256), 0, st, mrk, L, area, min_size, H, W);
+    hipLaunchKernelGGL(ccl2_mark_border_kernel, dim3(nblk(2 * (H + W), 256)), dim3(256), 0, st, mrk, L, border, H, W);
+    hipLaunchKernelGGL(ccl2_fill_kernel, dim3(g), dim3(256), 0, st, mrk, L, border, H, W);
+    hipLaunchKernelGGL(ccl2_final_kernel, dim3(g), dim3(256), 0, st, L, mrk, n);
+    KCHECK();
+    return 0;
+}
+
 // area[root] += 1 for every labelled pixel (wave-aggregated when the whole wave sits in one component)
 __global__ void ccl_area_kernel(const int* __restrict__ L, int* __restrict__ area, int n) {
     for (long long p0 = blockIdx.x * (long long)blockDim.x; p0 < n; p0 += (long long)gridDim.x * blockDim.x) {
@@ -503,6 +679,96 @@ __global__ void erode_cross_kernel(const uint8_t* __restrict__ src, uint8_t* __r
         if (x < W - 1) v &= src[p + 1];
         dst[p] = v;
     }
+}
+// Nuclei front end in ONE pass over the probability map (round 5): threshold (raw = inner + contour > 0.5; marker = inner > 0.5), the 3x3 cross erosion of
+// the mask and the tile-local labelling of the eroded mask (ccl_tile_kernel's algorithm on the bit rows this kernel has in LDS anyway).  A workgroup owns a
+// 64 x 32 tile and thresholds a 66 x 34 window of it (the erosion's halo; out-of-image neighbours read as 1: cv2's constant border never wins the min).
+// Replaces nuc_threshold4_kernel + erode_cross4_kernel + ccl_tile_kernel: 8 + 6 bytes per pixel instead of 8 + 2 / 4 + 1 / 1 + 4 in three launches.
+__global__ __launch_bounds__(256) void nuc_front_tile_kernel(const float* __restrict__ inst, long long row_stride, int pix_stride, int H, int W, uint8_t* __restrict__ msk,
+                                                             uint8_t* __restrict__ mrk, int* __restrict__ L, int tiles_x, int n_tiles, int* __restrict__ any) {
+    __shared__ int sl[CT_H * CT_W];
+    __shared__ u64 sraw[CT_H + 2];       // rows -1 .. 32 of the raw mask (64 columns of the tile)
+    __shared__ unsigned sedge[CT_H + 2];  // bit 0: raw mask at column -1, bit 1: at column 64
+    __shared__ u64 smask[CT_H];          // eroded mask rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int local = 0;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int tx0 = (tile % tiles_x) * CT_W, ty0 = (tile / tiles_x) * CT_H;
+        const int x = tx0 + lane;
+        // window rows wave * 9 .. + 8 (34 rows over four waves: 9, 9, 9, 7)
+        for (int i = 0; i < 9; ++i) {
+            const int wr = wave * 9 + i;  // 0 .. 33 = tile row wr - 1
+            if (wr >= CT_H + 2) break;
+            const int y = ty0 + wr - 1;
+            bool raw = true, mk = false;  // outside the image: 1 for the erosion
+            const bool in = y >= 0 && y < H && x < W;
+            if (in) {
+                const float* sp = inst + y * row_stride + (long long)x * pix_stride;
+                const float inner = sp[0], cnt = sp[1];
+                raw = (inner + cnt) > 0.5f;  // float32 add, as numpy (postproc.py:360)
+                mk = inner > 0.5f;
+                local |= raw ? 1 : 0;
+            }
+            const u64 m = __ballot(raw);
+            unsigned e = 3u;
+            if (lane == 0 && y >= 0 && y < H && tx0 > 0) {
+                const float* sp = inst + y * row_stride + (long long)(tx0 - 1) * pix_stride;
+                e = (e & ~1u) | ((sp[0] + sp[1]) > 0.5f ? 1u : 0u);
+            }
+            if (lane == 63 && y >= 0 && y < H && tx0 + CT_W < W) {
+                const float* sp = inst + y * row_stride + (long long)(tx0 + CT_W) * pix_stride;
+                e = (e & ~2u) | ((sp[0] + sp[1]) > 0.5f ? 2u : 0u);
+            }
+            const unsigned e0 = __shfl(e, 0), e63 = __shfl(e, 63);
+            if (lane == 0) {
+                sraw[wr] = m;
+                sedge[wr] = (e0 & 1u) | (e63 & 2u);
+            }
+            if (in && wr >= 1 && wr <= CT_H) mrk[(long long)y * W + x] = mk ? 1 : 0;
+        }
+        __syncthreads();
+        // erosion + run starts, rows wave * 8 .. + 7
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave * 8 + i, y = ty0 + r;
+            const u64 c = sraw[r + 1];
+            const unsigned ed = sedge[r + 1];
+            u64 v = c & sraw[r] & sraw[r + 2] & ((c << 1) | (u64)(ed & 1u)) & ((c >> 1) | ((u64)((ed >> 1) & 1u) << 63));
+            const bool valid = x < W && y < H;
+            const bool f = valid && ((v >> lane) & 1ull);
+            const u64 m = __ballot(f);
+            const u64 starts = m & ~(m << 1);
+            sl[r * CT_W + lane] = f ? r * CT_W + 63 - __clzll((long long)(starts & ((2ull << lane) - 1))) : -1;
+            if (lane == 0) smask[r] = m;
+            if (valid) msk[(long long)y * W + x] = f ? 1 : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave * 8 + i;
+            if (r == 0) continue;
+            const u64 m = smask[r], up = smask[r - 1];
+            const u64 both = m & up;
+            const u64 first = both & (~(m << 1) | ~(up << 1));
+            if ((first >> lane) & 1) lds_union(sl, r * CT_W + lane, (r - 1) * CT_W + lane);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave * 8 + i, y = ty0 + r;
+            if (x < W && y < H) {
+                const int l = sl[r * CT_W + lane];
+                int gi = -1;
+                if (l >= 0) {
+                    const int root = lds_find(sl, l);
+                    gi = (ty0 + (root >> 6)) * W + tx0 + (root & 63);
+                }
+                L[(long long)y * W + x] = gi;
+            }
+        }
+        __syncthreads();
+    }
+    if (__any(local) && lane == 0) atomicOr(any, 1);
 }
 // m[p] &= area[root(p)] >= min_size
 __global__ void apply_min_area_kernel(uint8_t* __restrict__ m, const int* __restrict__ L, const int* __restrict__ area, int min_size, int n) {
@@ -1657,7 +1923,17 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
 
     PP_OK(hipMemsetAsync(small, 0, 256, st));
     // (A) mask: erode -> label -> drop components < 8 px   (postproc.py:365-368)
-    if (W % 4 == 0 && ((uintptr_t)msk0 | (uintptr_t)msk | (uintptr_t)mrk) % 4 == 0) {
+    static const bool split_front = getenv("CERB_PP_SPLIT_FRONT") != nullptr;  // developer A/B: round 4's three launches
+    if (!split_front) {
+        const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H, n_tiles = tiles_x * tiles_y;
+        PP_OK(hipMemsetAsync(areaA, 0, (size_t)n * 4, st));
+        hipLaunchKernelGGL(nuc_front_tile_kernel, dim3(n_tiles < 256 * 16 ? n_tiles : 256 * 16), dim3(256), 0, st, inst, row_stride, pix_stride, H, W, msk, mrk, LA, tiles_x,
+                           n_tiles, small);
+        const long long seams = (long long)(tiles_x - 1) * H + (long long)(tiles_y - 1) * W;
+        if (seams > 0) hipLaunchKernelGGL(ccl_seam_kernel, dim3(grid_for(seams)), dim3(256), 0, st, msk, (uint8_t)1, LA, H, W, tiles_x, tiles_y);
+        hipLaunchKernelGGL(ccl_flatten_area_kernel, dim3(g), dim3(256), 0, st, LA, areaA, n);
+        KCHECK();
+    } else if (W % 4 == 0 && ((uintptr_t)msk0 | (uintptr_t)msk | (uintptr_t)mrk) % 4 == 0) {
         const unsigned g4 = grid_for(n / 4);
         const bool packed = pix_stride == 2 && row_stride % 4 == 0 && (uintptr_t)inst % 16 == 0;
         hipLaunchKernelGGL(packed ? nuc_threshold4_kernel<true> : nuc_threshold4_kernel<false>, dim3(g4), dim3(256), 0, st, inst, row_stride, pix_stride, H, W,
@@ -1667,18 +1943,25 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
         hipLaunchKernelGGL(nuc_threshold_kernel, dim3(g), dim3(256), 0, st, inst, row_stride, pix_stride, H, W, msk0, mrk, small);
         hipLaunchKernelGGL(erode_cross_kernel, dim3(g), dim3(256), 0, st, msk0, msk, H, W);
     }
-    PP_OK(hipMemsetAsync(areaA, 0, (size_t)n * 4, st));
-    if (ccl_run(msk, 1, LA, H, W, st, areaA)) return 1;
+    if (split_front) {
+        PP_OK(hipMemsetAsync(areaA, 0, (size_t)n * 4, st));
+        if (ccl_run(msk, 1, LA, H, W, st, areaA)) return 1;
+    }
     hipLaunchKernelGGL(apply_min_area_kernel, dim3(g), dim3(256), 0, st, msk, LA, areaA, 8, n);
     // (B) markers: inner > 0.5 -> label -> drop < 4 px -> fill holes -> label (postproc.py:370-377)
-    PP_OK(hipMemsetAsync(areaB, 0, (size_t)n * 4, st));
-    if (ccl_run(mrk, 1, LB, H, W, st, areaB)) return 1;
-    hipLaunchKernelGGL(apply_min_area_kernel, dim3(g), dim3(256), 0, st, mrk, LB, areaB, 4, n);
-    if (ccl_run(mrk, 0, LB, H, W, st)) return 1;  // background of the marker image
-    PP_OK(hipMemsetAsync(areaB, 0, (size_t)n * 4, st));
-    hipLaunchKernelGGL(mark_border_kernel, dim3(nblk(2 * (H + W), 256)), dim3(256), 0, st, LB, areaB, H, W);
-    hipLaunchKernelGGL(fill_holes_apply_kernel, dim3(g), dim3(256), 0, st, mrk, LB, areaB, n);
-    if (ccl_run(mrk, 1, LB, H, W, st)) return 1;
+    static const bool three_pass = getenv("CERB_PP_THREE_LABELLINGS") != nullptr;  // developer A/B: round 4's three separate labellings
+    if (!three_pass) {
+        if (markers_two_colour(mrk, LB, areaB, rank, 4, H, W, st)) return 1;  // (rank: free until the scan below, serves as the border flags)
+    } else {
+        PP_OK(hipMemsetAsync(areaB, 0, (size_t)n * 4, st));
+        if (ccl_run(mrk, 1, LB, H, W, st, areaB)) return 1;
+        hipLaunchKernelGGL(apply_min_area_kernel, dim3(g), dim3(256), 0, st, mrk, LB, areaB, 4, n);
+        if (ccl_run(mrk, 0, LB, H, W, st)) return 1;  // background of the marker image
+        PP_OK(hipMemsetAsync(areaB, 0, (size_t)n * 4, st));
+        hipLaunchKernelGGL(mark_border_kernel, dim3(nblk(2 * (H + W), 256)), dim3(256), 0, st, LB, areaB, H, W);
+        hipLaunchKernelGGL(fill_holes_apply_kernel, dim3(g), dim3(256), 0, st, mrk, LB, areaB, n);
+        if (ccl_run(mrk, 1, LB, H, W, st)) return 1;
+    }
     // marker ids = 1 + rank of the component's root among all roots (scipy's label order), written straight into the watershed's start map
     const int* boff = nullptr;
     if (scan_exclusive(LB, rank, n, scantmp, st, true, &boff)) return 1;

@@ -177,31 +177,31 @@ def test_head_w2_on_4x4_matrix_instructions_vs_padded_16_row_instruction(full_mo
         assert (lgs[1][k] - lgs[2][k]).abs().max().item() < 2e-6 * scale, k
 
 
-# What the default path ACHIEVED against the reference's float32 outputs when these bars were last set (round 4, scripts/dev_parity_achieved.py on an
-# MI355X; max |got - ref_fp32| over the fixture's INST probabilities).  The test holds every later build to max(1e-4, 1.5 x) of it: a
-# regression from 2e-6 to 9e-5 would pass the 1e-4 bar of the north star but not this one.
-ACHIEVED_R04 = {
-    'cfg1_nuclei': {'Nuclei-INST': 2.95e-06},
-    'cfg2_all': {'Lumen-INST': 3.13e-06, 'Gland-INST': 1.91e-06, 'Nuclei-INST': 2.80e-06},
-    'g448_all': {'Lumen-INST': 3.61e-06, 'Gland-INST': 1.19e-07, 'Nuclei-INST': 1.49e-06},
-    'small96_all': {'Lumen-INST': 2.80e-06, 'Gland-INST': 1.49e-06, 'Nuclei-INST': 2.65e-06},
-    'seed1_all': {'Lumen-INST': 4.23e-06, 'Gland-INST': 3.31e-06, 'Nuclei-INST': 4.65e-06},
-    'refinit_all': {'Lumen-INST': 6.86e-04, 'Gland-INST': 6.62e-05, 'Nuclei-INST': 2.52e-04},
-}
-
-
 @pytest.mark.parametrize("tag", ["cfg1_nuclei", "cfg2_all", "g448_all", "small96_all", "seed1_all", "refinit_all"])
 def test_infer_step_vs_reference_golden(golden_dir, tag):
-    """The default path (F(4x4) Winograd, planar last level, grouped heads) against what the REFERENCE's own NetDesc / infer_step produced
-    for the same seeded weights and tiles: two draws of the non-saturating recipe, four geometries, and the reference's DEFAULT
-    initialisation (refinit_all: saturated probabilities, logits in the thousands -- the regime in which the reference's own fp32 result
-    is 2e-5 .. 4.6e-4 from its fp64 result, so the bar there is 3x that noise; see _prob_bar)."""
+    """The default path against what the REFERENCE's own NetDesc / infer_step produced for the same seeded weights and tiles: two draws of the
+    non-saturating recipe, four geometries, and the reference's DEFAULT initialisation (refinit_all: logits in the thousands, saturated softmax).
+    ONE bar for every family, anchored on the reference's float64 evaluation (fixture p64_*, oracle/gen_golden_net.py with model.double()):
+
+        |got - ref_fp64|  <=  |ref_fp32 - ref_fp64| + 1e-4          (north_star's 1e-4, measured from the exact result)
+
+    None of the bars below comes from this build's own measured errors: they are the north star's constant and the reference's own
+    fp32-vs-fp64 noise.  refinit_all meets the bar because the handle probes its weights (NetDesc._auto_precision: calibration logits above 100
+    -> F(2x2,3x3) instead of F(4x4,3x3)); it is also held to 1.5x the DIRECT convolution's distance from float64 -- the algorithm the
+    reference's cuDNN may pick can never be much closer to the exact result than this path."""
     g = np.load(os.path.join(golden_dir, "net_%s.npz" % tag))
     m, sd, kw, tasks = _golden_model(g)
     n, hw, osz = int(g["n"]), int(g["hw"]), int(g["out_shape"])
     tiles = np.random.RandomState(int(g["tile_seed"])).randint(0, 256, (n, hw, hw, 3)).astype(np.uint8)
     out = infer_step(torch.from_numpy(tiles), m, osz, tasks)
     assert isinstance(out, list) and len(out) == n
+    saturated = tag == "refinit_all"
+    assert (m.calibration_logit_absmax > m.LOGIT_SATURATION) == saturated and bool(getattr(m, "_algo_is_auto", False)) == saturated, m.calibration_logit_absmax
+    direct = None
+    if saturated:  # the same network on the direct implicit-GEMM convolution (conv_algo 0)
+        md, _, _, _ = _golden_model(g)
+        md.set_conv_algo(0)
+        direct = infer_step(torch.from_numpy(tiles), md, osz, tasks)
     lg = m(torch.from_numpy(tiles))
     for k in out[0].keys():
         a = np.stack([out[i][k] for i in range(n)])
@@ -213,29 +213,24 @@ def test_infer_step_vs_reference_golden(golden_dir, tag):
         got = _crops(a4) if key in g else a4
         if a.dtype == np.float32:
             err = np.abs(got - ref).max()
-            assert err < _prob_bar(g, k), (k, err, _prob_bar(g, k))
-            # the reference's own float64 evaluation is the anchor.  Non-saturating families: this path is at most 1e-4 further from it than the
-            # reference's float32 evaluation is (achieved: 1e-7 .. 4e-6 against 1e-7 .. 2e-6).  refinit_all (the reference's default
-            # initialisation: logits in the thousands, where ITS float32 result is 7e-5 .. 4.6e-4 from ITS float64 result): F(4x4,3x3) amplifies
-            # rounding ~3x more than a direct convolution there (measured round 4, scripts/dev_parity_achieved.py: |got - p64| 5.8e-4 / 6.0e-5 /
-            # 3.2e-4 for Lumen / Gland / Nuclei with F(4x4); 6.7e-4 / 4.2e-5 / 1.3e-4 direct; 4.6e-4 / 3.6e-5 / 1.1e-4 F(2x2); the reference
-            # itself 4.6e-4 / 2.4e-5 / 6.7e-5) -- bar: 3x the whole-tensor fp32-vs-fp64 noise of the reference, and the achieved-error record
+            assert err < _prob_bar(g, k), (k, err, _prob_bar(g, k))  # against the reference's fp32 output: 1e-4, or 3x the reference's own fp32 noise
             if not k.endswith("INST"):  # Patch-Class: class ids carried in a float map, compared above
                 continue
             p64 = g["p64_crops/" + k] if ("p64_crops/" + k) in g else g["p64_full/" + k]
             e64, r64 = float(np.abs(got - p64).max()), float(np.abs(ref - p64).max())
-            if tag != "refinit_all":
-                assert e64 <= r64 + PROB_TOL, (k, e64, r64)
-            else:
-                assert e64 <= 3.0 * float(g["noise/" + k]) + PROB_TOL, (k, e64, float(g["noise/" + k]))
-            print("achieved %s %s: |got - ref32| %.3e  |got - ref64| %.3e  (|ref32 - ref64| %.3e)" % (tag, k, err, e64, r64))
-            if tag in ACHIEVED_R04:
-                assert err <= max(1.5 * ACHIEVED_R04[tag][k], 2e-6 if tag != "refinit_all" else 1e-4), (k, err, ACHIEVED_R04[tag][k])
+            assert e64 <= r64 + PROB_TOL, (k, e64, r64)
+            msg = "achieved %s %s: |got - ref32| %.3e  |got - ref64| %.3e  (|ref32 - ref64| %.3e)" % (tag, k, err, e64, r64)
+            if direct is not None:
+                d = np.stack([direct[i][k] for i in range(n)])
+                d = _crops(d) if key in g else d
+                d64 = float(np.abs(d - p64).max())
+                assert e64 <= 1.5 * d64 + 1e-5, (k, e64, d64)
+                msg += "  direct convolution |.. - ref64| %.3e" % d64
+            print(msg)
         elif k != "Patch-Class":
             _check_type_map(g, k, got, ref)
         else:
             assert np.array_equal(got, ref), k
-    assert tag in ACHIEVED_R04, "no achieved-error record for " + tag
     for k, v in lg.items():
         a = v.permute(0, 2, 3, 1).contiguous().cpu().numpy()
         key = "logits_crops/" + k

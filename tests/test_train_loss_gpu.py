@@ -143,7 +143,7 @@ def test_backward_pass_vs_reference_train_step(gold):
         err = max(abs(g.sum() - s_sum) / ref_abs, abs(np.abs(g).sum() - s_abs) / ref_abs, abs(g[0] - e0) / (50 * per_el + abs(e0)),
                   abs(g[g.size // 2] - em) / (50 * per_el + abs(em)), abs(g[-1] - e1) / (50 * per_el + abs(e1)))
         worst = max(worst, err)
-        assert err < 2e-3, (k, err, g.sum(), s_sum, np.abs(g).sum(), s_abs, g[0], e0)  # observed worst over 309 tensors: 9.5e-4 (round 4)
+        assert err < 2e-3, (k, err, g.sum(), s_sum, np.abs(g).sum(), s_abs, g[0], e0)
     # the reference's train_decoder_list quirk: the #TYPE decoders get gradients only inside their last block and head
     assert float(grads["decoder_head.Gland#TYPE.0.block.0.conv.weight"].abs().sum()) == 0.0
     assert float(grads["decoder_head.Gland#TYPE.3.block.0.conv.weight"].abs().sum()) > 0.0
@@ -155,7 +155,7 @@ def test_backward_pass_vs_reference_train_step(gold):
     #   * the 90th percentile over channels <= max(2e-3, 3 x the reference's own inter-backend fp32 noise on the tensor)
     #     (measured: 1e-6 .. 3e-3 -- decoder tensors sit at 2e-6, the backbone collects ~1e-3 of summation-order noise through ~40
     #     batch-normalised layers of a 3-sample batch);
-    #   * every channel <= 7.5e-3 (2x the worst this build shows: 3.7e-3) and cosine > 0.9999.  Isolated channels deviate by up to ~1e-2 where ONE pixel's pre-activation is
+    #   * every channel <= 2e-2 and cosine > 0.9999.  Isolated channels deviate by up to ~1.3e-2 where ONE pixel's pre-activation is
     #     within rounding of zero and the ReLU masks of two fp32 implementations differ on it (tests/tools/dev_grad_diff.py: all
     #     channels of decoder_head.Gland#TYPE.3.block.1.conv.weight at 2e-6 except channel 32 at 1.3e-2, identical under both conv
     #     algorithms; with other weights and data the outlier moves to another channel, the reference's own float64 replay agrees
@@ -175,9 +175,9 @@ def test_backward_pass_vs_reference_train_step(gold):
         cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref)))
         bar = max(2e-3, 3.0 * float(gold["step/grad_full_noise/" + k]))
         worst_p90, worst_max = max(worst_p90, p90), max(worst_max, mx)
-        # every channel: 2x what this build achieves (round 4: worst channel 3.7e-3 of the tensor's largest element, worst 90th percentile 2.2e-3);
-        # rounds 1-3 allowed 5e-2 here
-        assert p90 < bar and mx < 7.5e-3 and cos > 0.9999, (k, p90, bar, mx, cos)
+        # every channel: one flipped ReLU pixel (1.3e-2 in the REFERENCE's own fp32-vs-fp32 comparison, see above) with margin -- a bar from the
+        # reference's behaviour, not from what this build happens to achieve (the achieved figures are printed below)
+        assert p90 < bar and mx < 2e-2 and cos > 0.9999, (k, p90, bar, mx, cos)
     print("element-wise gradients over %d full tensors: worst 90th-percentile channel error %.2e, worst channel %.2e (of the tensor's largest element)"
           % (len(full_names), worst_p90, worst_max))
 
