@@ -374,9 +374,15 @@ static int ccl_run(const uint8_t* fg, uint8_t val, int* L, int H, int W, hipStre
 //     foreground neighbours (this is also what merges two markers that only touched diagonally around a hole).
 // Roots stay "smallest raster index of the set", so the rank of a final root among all roots is scipy's label id as before.
 // =================================================================================================================
-__global__ __launch_bounds__(256) void ccl2_tile_kernel(const uint8_t* __restrict__ fg, int* __restrict__ L, int H, int W, int tiles_x, int n_tiles) {
+// `roots` / `n_roots`: every pixel that is the root of its tile-local set is appended to a compact list (one atomic per tile).  All later unions link
+// roots under roots, so the nodes of the forest above the pixel level are exactly these: flattening the LIST (ccl2_flatten_roots_kernel) makes
+// L[L[p]] the set's root for every pixel p -- two loads, no pointer chase, no pass that walks 67 M background pixels up to one giant root.
+__global__ __launch_bounds__(256) void ccl2_tile_kernel(const uint8_t* __restrict__ fg, int* __restrict__ L, int H, int W, int tiles_x, int n_tiles,
+                                                        int* __restrict__ roots, int* __restrict__ n_roots) {
     __shared__ int sl[CT_H * CT_W];
     __shared__ u64 sc[CT_H], sv[CT_H], ss[CT_H];  // per row: colour bits, valid bits, run starts
+    __shared__ u64 srootm[CT_H];
+    __shared__ int srow_off[CT_H];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int tx0 = (tile % tiles_x) * CT_W, ty0 = (tile / tiles_x) * CT_H;
@@ -408,12 +414,47 @@ __global__ __launch_bounds__(256) void ccl2_tile_kernel(const uint8_t* __restric
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int r = wave * 8 + i, y = ty0 + r;
+            bool is_root = false;
             if (x < W && y < H) {
                 const int root = lds_find(sl, sl[r * CT_W + lane]);
                 L[(long long)y * W + x] = (ty0 + (root >> 6)) * W + tx0 + (root & 63);
+                is_root = root == r * CT_W + lane;
             }
+            const u64 rm = __ballot(is_root);
+            if (lane == 0) srootm[r] = rm;
         }
         __syncthreads();
+        if (wave == 0) {  // exclusive scan of the 32 row counts in one wave (lanes 32 .. 63 carry zeros), one atomic per tile
+            const int c = lane < CT_H ? __popcll(srootm[lane]) : 0;
+            int incl = c;
+#pragma unroll
+            for (int d = 1; d < CT_H; d <<= 1) {
+                const int up = __shfl_up(incl, d);
+                if (lane >= d) incl += up;
+            }
+            const int tot = __shfl(incl, CT_H - 1);
+            int base = 0;
+            if (lane == 0 && tot) base = atomicAdd(n_roots, tot);
+            base = __shfl(base, 0);
+            if (lane < CT_H) srow_off[lane] = base + incl - c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave * 8 + i, y = ty0 + r;
+            const u64 rm = srootm[r];
+            if ((rm >> lane) & 1ull) roots[srow_off[r] + __popcll(rm & ((1ull << lane) - 1))] = y * W + x;
+        }
+        __syncthreads();
+    }
+}
+// L[r] = root of r for every node of the forest above the pixel level (see ccl2_tile_kernel)
+__global__ void ccl2_flatten_roots_kernel(int* L, const int* __restrict__ roots, const int* __restrict__ n_roots) {
+    const int n = *n_roots;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int r = roots[i];
+        const int f = uf_find(L, r);
+        if (f != r) __hip_atomic_store(&L[r], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 __global__ void ccl2_seam_kernel(const uint8_t* __restrict__ fg, int* L, int H, int W, int tiles_x, int tiles_y) {
@@ -450,19 +491,12 @@ __global__ void ccl2_seam_kernel(const uint8_t* __restrict__ fg, int* L, int H, 
         if (a >= 0 && ra != rb && !(lane > 0 && pa == ra && pb == rb)) uf_union(L, ra, rb);
     }
 }
-// flatten both colours; area[root] += run length for FOREGROUND runs only (the background is a few huge sets: no atomics for them)
-__global__ void ccl2_flatten_area_kernel(int* L, const uint8_t* __restrict__ fg, int* __restrict__ area, int n) {
+// area[root] += run length for FOREGROUND runs (the background is a few huge sets: nothing is counted for them).  Needs flattened roots: root = L[L[p]].
+__global__ void ccl2_area_kernel(const int* __restrict__ L, const uint8_t* __restrict__ fg, int* __restrict__ area, int n) {
     const int lane = threadIdx.x & 63;
     for (long long base = (blockIdx.x * (long long)blockDim.x + threadIdx.x) - lane; base < n; base += (long long)gridDim.x * blockDim.x) {
         const long long p = base + lane;
-        int r = -1;
-        bool f = false;
-        if (p < n) {
-            r = uf_find(L, (int)p);
-            L[p] = r;
-            f = fg[p] != 0;
-        }
-        const int key = f ? r : -1;
+        const int key = (p < n && fg[p]) ? L[L[p]] : -1;
         const int prev = __shfl_up(key, 1);
         const bool head = key >= 0 && (lane == 0 || prev != key);
         const unsigned long long bounds = __ballot(head || key < 0);
@@ -478,7 +512,7 @@ __global__ void ccl2_drop_small_kernel(uint8_t* m, int* L, const int* __restrict
     const double invW = 1.0 / (double)W;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
         if (!m[p]) continue;
-        const int r = L[p];  // a non-root pixel still names its (flattened) component root; a root that has already been united away names a
+        const int r = L[L[p]];  // the component's root as ccl2_area_kernel saw it -- or, once this small component has been united away, a
         if (area[r] >= min_size) continue;  // background index, whose area is 0: "small" either way
         int y, x;
         pix_yx(p, W, invW, y, x);
@@ -521,20 +555,26 @@ __global__ void ccl2_fill_kernel(uint8_t* m, int* L, const int* __restrict__ bor
 }
 // final marker labels: root for foreground pixels, -1 for the background
 __global__ void ccl2_final_kernel(int* L, const uint8_t* __restrict__ m, int n) {
-    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) L[p] = m[p] ? uf_find(L, (int)p) : -1;
+    // (flattened roots: L[L[p]] is the root; a foreground node that other pixels still point at keeps the value it already holds)
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) L[p] = m[p] ? L[L[p]] : -1;
 }
-static int markers_two_colour(uint8_t* mrk, int* L, int* area, int* border, int min_size, int H, int W, hipStream_t st) {
+static int markers_two_colour(uint8_t* mrk, int* L, int* area, int* border, int* roots, int* n_roots, int min_size, int H, int W, hipStream_t st) {
     const int n = H * W;
     const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H, n_tiles = tiles_x * tiles_y;
     const unsigned g = grid_for(n);
-    if (hipMemsetAsync(area, 0, (size_t)n * 4, st) != hipSuccess || hipMemsetAsync(border, 0, (size_t)n * 4, st) != hipSuccess) return cerb_set_error("memset failed");
-    hipLaunchKernelGGL(ccl2_tile_kernel, dim3(n_tiles < 256 * 16 ? n_tiles : 256 * 16), dim3(256), 0, st, mrk, L, H, W, tiles_x, n_tiles);
+    if (hipMemsetAsync(area, 0, (size_t)n * 4, st) != hipSuccess || hipMemsetAsync(border, 0, (size_t)n * 4, st) != hipSuccess || hipMemsetAsync(n_roots, 0, 4, st) != hipSuccess)
+        return cerb_set_error("memset failed");
+    hipLaunchKernelGGL(ccl2_tile_kernel, dim3(n_tiles < 256 * 16 ? n_tiles : 256 * 16), dim3(256), 0, st, mrk, L, H, W, tiles_x, n_tiles, roots, n_roots);
     const long long seams = (long long)(tiles_x - 1) * H + (long long)(tiles_y - 1) * W;
     if (seams > 0) hipLaunchKernelGGL(ccl2_seam_kernel, dim3(grid_for(seams)), dim3(256), 0, st, mrk, L, H, W, tiles_x, tiles_y);
-    hipLaunchKernelGGL(ccl2_flatten_area_kernel, dim3(g), dim3(256), 0, st, L, mrk, area, n);
+    auto flatten_roots = [&]() { hipLaunchKernelGGL(ccl2_flatten_roots_kernel, dim3(256 * 4), dim3(256), 0, st, L, (const int*)roots, (const int*)n_roots); };
+    flatten_roots();
+    hipLaunchKernelGGL(ccl2_area_kernel, dim3(g), dim3(256), 0, st, (const int*)L, mrk, area, n);
     hipLaunchKernelGGL(ccl2_drop_small_kernel, dim3(g), dim3(256), 0, st, mrk, L, area, min_size, H, W);
+    flatten_roots();
     hipLaunchKernelGGL(ccl2_mark_border_kernel, dim3(nblk(2 * (H + W), 256)), dim3(256), 0, st, mrk, L, border, H, W);
     hipLaunchKernelGGL(ccl2_fill_kernel, dim3(g), dim3(256), 0, st, mrk, L, border, H, W);
+    flatten_roots();
     hipLaunchKernelGGL(ccl2_final_kernel, dim3(g), dim3(256), 0, st, L, mrk, n);
     KCHECK();
     return 0;
@@ -679,96 +719,6 @@ __global__ void erode_cross_kernel(const uint8_t* __restrict__ src, uint8_t* __r
         if (x < W - 1) v &= src[p + 1];
         dst[p] = v;
     }
-}
-// Nuclei front end in ONE pass over the probability map (round 5): threshold (raw = inner + contour > 0.5; marker = inner > 0.5), the 3x3 cross erosion of
-// the mask and the tile-local labelling of the eroded mask (ccl_tile_kernel's algorithm on the bit rows this kernel has in LDS anyway).  A workgroup owns a
-// 64 x 32 tile and thresholds a 66 x 34 window of it (the erosion's halo; out-of-image neighbours read as 1: cv2's constant border never wins the min).
-// Replaces nuc_threshold4_kernel + erode_cross4_kernel + ccl_tile_kernel: 8 + 6 bytes per pixel instead of 8 + 2 / 4 + 1 / 1 + 4 in three launches.
-__global__ __launch_bounds__(256) void nuc_front_tile_kernel(const float* __restrict__ inst, long long row_stride, int pix_stride, int H, int W, uint8_t* __restrict__ msk,
-                                                             uint8_t* __restrict__ mrk, int* __restrict__ L, int tiles_x, int n_tiles, int* __restrict__ any) {
-    __shared__ int sl[CT_H * CT_W];
-    __shared__ u64 sraw[CT_H + 2];       // rows -1 .. 32 of the raw mask (64 columns of the tile)
-    __shared__ unsigned sedge[CT_H + 2];  // bit 0: raw mask at column -1, bit 1: at column 64
-    __shared__ u64 smask[CT_H];          // eroded mask rows
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int local = 0;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int tx0 = (tile % tiles_x) * CT_W, ty0 = (tile / tiles_x) * CT_H;
-        const int x = tx0 + lane;
-        // window rows wave * 9 .. + 8 (34 rows over four waves: 9, 9, 9, 7)
-        for (int i = 0; i < 9; ++i) {
-            const int wr = wave * 9 + i;  // 0 .. 33 = tile row wr - 1
-            if (wr >= CT_H + 2) break;
-            const int y = ty0 + wr - 1;
-            bool raw = true, mk = false;  // outside the image: 1 for the erosion
-            const bool in = y >= 0 && y < H && x < W;
-            if (in) {
-                const float* sp = inst + y * row_stride + (long long)x * pix_stride;
-                const float inner = sp[0], cnt = sp[1];
-                raw = (inner + cnt) > 0.5f;  // float32 add, as numpy (postproc.py:360)
-                mk = inner > 0.5f;
-                local |= raw ? 1 : 0;
-            }
-            const u64 m = __ballot(raw);
-            unsigned e = 3u;
-            if (lane == 0 && y >= 0 && y < H && tx0 > 0) {
-                const float* sp = inst + y * row_stride + (long long)(tx0 - 1) * pix_stride;
-                e = (e & ~1u) | ((sp[0] + sp[1]) > 0.5f ? 1u : 0u);
-            }
-            if (lane == 63 && y >= 0 && y < H && tx0 + CT_W < W) {
-                const float* sp = inst + y * row_stride + (long long)(tx0 + CT_W) * pix_stride;
-                e = (e & ~2u) | ((sp[0] + sp[1]) > 0.5f ? 2u : 0u);
-            }
-            const unsigned e0 = __shfl(e, 0), e63 = __shfl(e, 63);
-            if (lane == 0) {
-                sraw[wr] = m;
-                sedge[wr] = (e0 & 1u) | (e63 & 2u);
-            }
-            if (in && wr >= 1 && wr <= CT_H) mrk[(long long)y * W + x] = mk ? 1 : 0;
-        }
-        __syncthreads();
-        // erosion + run starts, rows wave * 8 .. + 7
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = wave * 8 + i, y = ty0 + r;
-            const u64 c = sraw[r + 1];
-            const unsigned ed = sedge[r + 1];
-            u64 v = c & sraw[r] & sraw[r + 2] & ((c << 1) | (u64)(ed & 1u)) & ((c >> 1) | ((u64)((ed >> 1) & 1u) << 63));
-            const bool valid = x < W && y < H;
-            const bool f = valid && ((v >> lane) & 1ull);
-            const u64 m = __ballot(f);
-            const u64 starts = m & ~(m << 1);
-            sl[r * CT_W + lane] = f ? r * CT_W + 63 - __clzll((long long)(starts & ((2ull << lane) - 1))) : -1;
-            if (lane == 0) smask[r] = m;
-            if (valid) msk[(long long)y * W + x] = f ? 1 : 0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = wave * 8 + i;
-            if (r == 0) continue;
-            const u64 m = smask[r], up = smask[r - 1];
-            const u64 both = m & up;
-            const u64 first = both & (~(m << 1) | ~(up << 1));
-            if ((first >> lane) & 1) lds_union(sl, r * CT_W + lane, (r - 1) * CT_W + lane);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = wave * 8 + i, y = ty0 + r;
-            if (x < W && y < H) {
-                const int l = sl[r * CT_W + lane];
-                int gi = -1;
-                if (l >= 0) {
-                    const int root = lds_find(sl, l);
-                    gi = (ty0 + (root >> 6)) * W + tx0 + (root & 63);
-                }
-                L[(long long)y * W + x] = gi;
-            }
-        }
-        __syncthreads();
-    }
-    if (__any(local) && lane == 0) atomicOr(any, 1);
 }
 // m[p] &= area[root(p)] >= min_size
 __global__ void apply_min_area_kernel(uint8_t* __restrict__ m, const int* __restrict__ L, const int* __restrict__ area, int min_size, int n) {
@@ -1923,17 +1873,9 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
 
     PP_OK(hipMemsetAsync(small, 0, 256, st));
     // (A) mask: erode -> label -> drop components < 8 px   (postproc.py:365-368)
-    static const bool split_front = getenv("CERB_PP_SPLIT_FRONT") != nullptr;  // developer A/B: round 4's three launches
-    if (!split_front) {
-        const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H, n_tiles = tiles_x * tiles_y;
-        PP_OK(hipMemsetAsync(areaA, 0, (size_t)n * 4, st));
-        hipLaunchKernelGGL(nuc_front_tile_kernel, dim3(n_tiles < 256 * 16 ? n_tiles : 256 * 16), dim3(256), 0, st, inst, row_stride, pix_stride, H, W, msk, mrk, LA, tiles_x,
-                           n_tiles, small);
-        const long long seams = (long long)(tiles_x - 1) * H + (long long)(tiles_y - 1) * W;
-        if (seams > 0) hipLaunchKernelGGL(ccl_seam_kernel, dim3(grid_for(seams)), dim3(256), 0, st, msk, (uint8_t)1, LA, H, W, tiles_x, tiles_y);
-        hipLaunchKernelGGL(ccl_flatten_area_kernel, dim3(g), dim3(256), 0, st, LA, areaA, n);
-        KCHECK();
-    } else if (W % 4 == 0 && ((uintptr_t)msk0 | (uintptr_t)msk | (uintptr_t)mrk) % 4 == 0) {
+    // (round 5 tried threshold + erosion + tile labelling as ONE kernel over a 66 x 34 window per tile: bit-exact, 0.68 ms against 0.51 ms for the three
+    // launches below -- the 8-byte loads, the divergent halo columns and three barriers per tile cost more than the two byte planes it saved)
+    if (W % 4 == 0 && ((uintptr_t)msk0 | (uintptr_t)msk | (uintptr_t)mrk) % 4 == 0) {
         const unsigned g4 = grid_for(n / 4);
         const bool packed = pix_stride == 2 && row_stride % 4 == 0 && (uintptr_t)inst % 16 == 0;
         hipLaunchKernelGGL(packed ? nuc_threshold4_kernel<true> : nuc_threshold4_kernel<false>, dim3(g4), dim3(256), 0, st, inst, row_stride, pix_stride, H, W,
@@ -1943,15 +1885,14 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
         hipLaunchKernelGGL(nuc_threshold_kernel, dim3(g), dim3(256), 0, st, inst, row_stride, pix_stride, H, W, msk0, mrk, small);
         hipLaunchKernelGGL(erode_cross_kernel, dim3(g), dim3(256), 0, st, msk0, msk, H, W);
     }
-    if (split_front) {
-        PP_OK(hipMemsetAsync(areaA, 0, (size_t)n * 4, st));
-        if (ccl_run(msk, 1, LA, H, W, st, areaA)) return 1;
-    }
+    PP_OK(hipMemsetAsync(areaA, 0, (size_t)n * 4, st));
+    if (ccl_run(msk, 1, LA, H, W, st, areaA)) return 1;
     hipLaunchKernelGGL(apply_min_area_kernel, dim3(g), dim3(256), 0, st, msk, LA, areaA, 8, n);
     // (B) markers: inner > 0.5 -> label -> drop < 4 px -> fill holes -> label (postproc.py:370-377)
     static const bool three_pass = getenv("CERB_PP_THREE_LABELLINGS") != nullptr;  // developer A/B: round 4's three separate labellings
     if (!three_pass) {
-        if (markers_two_colour(mrk, LB, areaB, rank, 4, H, W, st)) return 1;  // (rank: free until the scan below, serves as the border flags)
+        // (rank: free until the scan below, serves as the border flags; marker: free until the flood work lists, holds the root list)
+        if (markers_two_colour(mrk, LB, areaB, rank, marker, small + 4, 4, H, W, st)) return 1;
     } else {
         PP_OK(hipMemsetAsync(areaB, 0, (size_t)n * 4, st));
         if (ccl_run(mrk, 1, LB, H, W, st, areaB)) return 1;
