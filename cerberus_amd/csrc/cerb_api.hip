@@ -65,6 +65,13 @@ hipError_t cerb_launch_adam(float* p, const float* g, float* m, float* v, long l
 size_t cerb_wgrad_workspace_bytes(int G, int N, int Ho, int Wo, int Cin, int Cout, int ks, int* slices_out);
 size_t cerb_stem_wgrad_workspace_bytes();
 hipError_t cerb_launch_pack_stem(const float* w_raw, float* out, hipStream_t st);
+struct PackJob {  // pack_kernels.hip
+    const float* w;
+    float* out;
+    long long total;
+    int cout, cin, kind, a, b, pad;
+};
+hipError_t cerb_launch_pack_multi(const PackJob* jobs, int count, void** dev_tab, size_t* dev_bytes, std::vector<char>* host_prev, hipStream_t st);
 hipError_t cerb_launch_adam_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* n, float lr, float b1,
                                   float b2, float eps, int step, hipStream_t st);
 hipError_t cerb_launch_pack_conv(const float* w_raw, float* out, int cout, int cin, int ks, int chunk, hipStream_t st);
@@ -253,6 +260,9 @@ struct cerb_net {
     void* copy_tab = nullptr;    // cerb_net_update_params: device table of the parameter copies (cerb_launch_copy_multi)
     size_t copy_tab_bytes = 0;
     std::vector<char> copy_tab_host;
+    void* pack_tab = nullptr;    // ... and of the re-pack jobs (cerb_launch_pack_multi)
+    size_t pack_tab_bytes = 0;
+    std::vector<char> pack_tab_host;
     float* zero_bias = nullptr;  // 512 zeros: the bias operand of the data-gradient convs
     std::map<std::string, std::pair<float*, long long>> grads;  // state-dict key -> (device gradient, numel) of the last cerb_net_train_grads
     std::map<std::string, std::vector<std::string>> bn_keys;   // conv / bn name -> state-dict prefixes of its BatchNorm, one per group
@@ -281,6 +291,7 @@ struct cerb_net {
         for (auto& r : prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         for (void* p : dev_allocs) (void)hipFree(p);
         if (copy_tab) (void)hipFree(copy_tab);
+        if (pack_tab) (void)hipFree(pack_tab);
         x0.release(); pool.release(); ta.release(); tb.release(); cm.release(); dmid.release(); dsum.release(); psum.release(); pmid.release(); pout.release(); psum2.release(); pmid2.release(); pout2.release();
         t_mean.release(); t_rstd.release(); t_ws.release(); t_hid.release(); t_gap.release(); t_pc1.release(); t_idn.release(); t_dil.release();
         for (auto& b : tape) b.release();
@@ -2026,22 +2037,39 @@ extern "C" int cerb_net_update_params(cerb_net* net, int count, const char* cons
     // every parameter tensor into its slot(s) in ONE launch (round 3: one hipMemcpyAsync per tensor, ~470 per optimiser step)
     HIP_OK(cerb_launch_copy_multi((int)cd.size(), cd.data(), cs.data(), cn.data(), &net->copy_tab, &net->copy_tab_bytes, &net->copy_tab_host, st));
     HIP_OK(cerb_launch_pack_stem(net->stem_raw, net->stem_w, st));
+    // every conv's re-layouts / filter transforms as jobs of ONE launch (pack_kernels.hip: pack_multi_kernel); CERB_PACK_PER_CONV=1: round 4's launches
+    static const bool per_conv = getenv("CERB_PACK_PER_CONV") != nullptr;
+    std::vector<PackJob> jobs;
+    auto job = [&](const float* w, float* out, long long total, int cout, int cin, int kind, int a, int b) { jobs.push_back(PackJob{w, out, total, cout, cin, kind, a, b, 0}); };
     for (auto& kv : net->conv) {
         PackedConv& pc = kv.second;
         const float* rawd = net->raw[kv.first].w;
         if (pc.wino && !pc.wino_used) pc.wino_stale = true;
         if (pc.wino_dgrad && !pc.wino_dgrad_used) pc.wino_dgrad_stale = true;
-        const size_t nw = (size_t)pc.cout * pc.cin * pc.ks * pc.ks, nu = (size_t)pc.cout * pc.cin * 16;
+        const size_t nw = (size_t)pc.cout * pc.cin * pc.ks * pc.ks, nu = (size_t)pc.cout * pc.cin * 16, nu4 = (size_t)pc.cout * pc.cin * 36;
         for (int g = 0; g < pc.groups; ++g) {
-            HIP_OK(cerb_launch_pack_conv(rawd + g * nw, pc.w + g * nw, pc.cout, pc.cin, pc.ks, cerb_conv_chunk(pc.ks, pc.stride), st));
-            if (pc.wino && pc.wino_used) HIP_OK(cerb_launch_pack_wino(rawd + g * nw, pc.wino + g * nu, pc.cout, pc.cin, 0, st));
-            if (pc.wino_dgrad && pc.wino_dgrad_used) HIP_OK(cerb_launch_pack_wino(rawd + g * nw, pc.wino_dgrad + g * nu, pc.cin, pc.cout, 1, st));
+            if (per_conv) {
+                HIP_OK(cerb_launch_pack_conv(rawd + g * nw, pc.w + g * nw, pc.cout, pc.cin, pc.ks, cerb_conv_chunk(pc.ks, pc.stride), st));
+                if (pc.wino && pc.wino_used) HIP_OK(cerb_launch_pack_wino(rawd + g * nw, pc.wino + g * nu, pc.cout, pc.cin, 0, st));
+                if (pc.wino_dgrad && pc.wino_dgrad_used) HIP_OK(cerb_launch_pack_wino(rawd + g * nw, pc.wino_dgrad + g * nu, pc.cin, pc.cout, 1, st));
+                continue;
+            }
+            job(rawd + g * nw, pc.w + g * nw, (long long)nw, pc.cout, pc.cin, 0, pc.ks * pc.ks, cerb_conv_chunk(pc.ks, pc.stride));
+            if (pc.wino && pc.wino_used) job(rawd + g * nw, pc.wino + g * nu, (long long)nu, pc.cout, pc.cin, 1, 0, 0);
+            if (pc.wino_dgrad && pc.wino_dgrad_used) job(rawd + g * nw, pc.wino_dgrad + g * nu, (long long)nu, pc.cin, pc.cout, 1, 1, 0);
         }
-        for (int l = 0; l < 2; ++l)  // the F(4x4) layouts in use: all groups of the conv in one launch
+        for (int l = 0; l < 2; ++l)  // the F(4x4) layouts in use
             for (int dg = 0; dg < 2; ++dg)
-                if (pc.wino4_t[l][dg])
-                    HIP_OK(cerb_launch_pack_wino4(rawd, pc.wino4_t[l][dg], dg ? pc.cin : pc.cout, dg ? pc.cout : pc.cin, dg, l, pc.groups, st));
+                if (pc.wino4_t[l][dg]) {
+                    if (per_conv) {
+                        HIP_OK(cerb_launch_pack_wino4(rawd, pc.wino4_t[l][dg], dg ? pc.cin : pc.cout, dg ? pc.cout : pc.cin, dg, l, pc.groups, st));
+                        continue;
+                    }
+                    for (int g = 0; g < pc.groups; ++g)
+                        job(rawd + g * nw, pc.wino4_t[l][dg] + g * nu4, (long long)nu4, dg ? pc.cin : pc.cout, dg ? pc.cout : pc.cin, 2, dg, l);
+                }
     }
+    if (!jobs.empty()) HIP_OK(cerb_launch_pack_multi(jobs.data(), (int)jobs.size(), &net->pack_tab, &net->pack_tab_bytes, &net->pack_tab_host, st));
     return 0;
 }
 extern "C" int cerb_net_set_fold_bn(cerb_net* net, int fold) {

@@ -264,14 +264,24 @@ extern "C" int cerb_head_loss_wmap(const float* logits, long long stride_n, long
 // =================================================================================================================
 namespace {
 constexpr int BN_ROWS_PER_BLOCK = 2048;
+// Rows one workgroup of the statistics passes reduces.  2048 suits the decoder levels (3.2 M rows x 5 groups = 7840 workgroups); the encoder's small maps
+// got 7 .. 49 workgroups for 256 CUs that way and ran latency-bound (round 5's per-layer table: 0.3 ms per layer4 BatchNorm at 0.6 TB/s, ~8 ms of a
+// 123 ms step on layers whose bytes need 1.5 ms): aim at ~2048 workgroups, between 32 and 2048 rows each.
+static inline int bn_rpb(long long rows, int groups) {
+    long long r = (rows * (long long)(groups > 0 ? groups : 1) + 2047) / 2048;
+    r = (r + 31) / 32 * 32;
+    if (r < 32) r = 32;
+    if (r > BN_ROWS_PER_BLOCK) r = BN_ROWS_PER_BLOCK;
+    return (int)r;
+}
 
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, long long group_stride, long long rows, int C, int blocks_per_group,
-                                                         double* __restrict__ partial) {
+                                                         double* __restrict__ partial, int rpb) {
     extern __shared__ double shd[];  // [256][2] per float4 lane component handled below
     const int g = blockIdx.x / blocks_per_group, b = blockIdx.x % blocks_per_group;
     const int c4n = C >> 2, tid = threadIdx.x;
     const int c4 = tid % c4n, rl = tid / c4n, nrl = 256 / c4n;  // threads with rl >= nrl idle (C / 4 need not divide 256)
-    const long long r0 = (long long)b * BN_ROWS_PER_BLOCK, r1 = min(rows, r0 + BN_ROWS_PER_BLOCK);
+    const long long r0 = (long long)b * rpb, r1 = min(rows, r0 + rpb);
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     if (rl < nrl) {
         // four rows in flight per thread (one dependent load per iteration left the pass latency-bound at 0.45 of the HBM peak); the
@@ -434,14 +444,16 @@ __global__ void crop_gap_kernel(const float* __restrict__ x, int N, int H, int W
 }  // namespace
 
 size_t cerb_bn_workspace_bytes(int groups, long long rows, int C) {
-    const long long bpg = (rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK;
+    const int rpb = bn_rpb(rows, groups);
+    const long long bpg = (rows + rpb - 1) / rpb;
     return (size_t)groups * bpg * C * 2 * 8 + 256;
 }
 hipError_t cerb_launch_bn_stats(const float* x, long long group_stride, long long rows, int C, int groups, float eps, float* mean, float* rstd,
                                 float* var_unbiased, void* ws, hipStream_t st) {
     if (C % 4 || C / 4 > 256) return hipErrorInvalidValue;  // a block covers all channel quads of a row; spare threads idle (C = 96: 24 quads x 10 row lanes)
-    const int bpg = (int)((rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK);
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(groups * bpg), dim3(256), 256 * 2 * sizeof(double), st, x, group_stride, rows, C, bpg, (double*)ws);
+    const int rpb = bn_rpb(rows, groups);
+    const int bpg = (int)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(groups * bpg), dim3(256), 256 * 2 * sizeof(double), st, x, group_stride, rows, C, bpg, (double*)ws, rpb);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, (const double*)ws, rows, C, bpg, eps, mean, rstd, var_unbiased);
     return hipGetLastError();
 }
@@ -520,12 +532,12 @@ namespace {
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ y,
                                                              long long group_stride, long long rows, int C, int blocks_per_group,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd, int relu,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta, double* __restrict__ partial) {
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, double* __restrict__ partial, int rpb) {
     extern __shared__ double shd[];
     const int g = blockIdx.x / blocks_per_group, b = blockIdx.x % blocks_per_group;
     const int c4n = C >> 2, tid = threadIdx.x;
     const int c4 = tid % c4n, rl = tid / c4n, nrl = 256 / c4n;  // thread = (channel quad, row lane); spare threads idle
-    const long long r0 = (long long)b * BN_ROWS_PER_BLOCK, r1 = min(rows, r0 + BN_ROWS_PER_BLOCK);
+    const long long r0 = (long long)b * rpb, r1 = min(rows, r0 + rpb);
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     if (rl < nrl) {
         const float4 m = *reinterpret_cast<const float4*>(mean + g * C + 4 * c4), rs = *reinterpret_cast<const float4*>(rstd + g * C + 4 * c4);
@@ -1213,12 +1225,13 @@ static unsigned gridfor(long long n) {
 hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, float* dy, float* dresid, long long group_stride, long long rows, int C, int groups,
                               const float* mean, const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, int relu, int dy_assign,
                               void* ws, hipStream_t st, unsigned long long eval_mask) {
-    const int bpg = (int)((rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK);
+    const int rpb = bn_rpb(rows, groups);
+    const int bpg = (int)((rows + rpb - 1) / rpb);
     // a ReLU behind a BatchNorm WITHOUT a residual: z > 0 <=> bn_out(y) > 0, recomputed from the y both passes read anyway (relu = 2):
     // 5 instead of 7 tensor passes over the activation
     if (relu && !dresid && beta) relu = 2;
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(groups * bpg), dim3(256), 256 * 2 * sizeof(double), st, dz, z, y, group_stride, rows, C, bpg, mean, rstd, relu,
-                       gamma, beta, (double*)ws);
+                       gamma, beta, (double*)ws, rpb);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, (const double*)ws, C, bpg, dgamma, dbeta);
     if (C % 4 || C / 4 > 256) return hipErrorInvalidValue;
     const int nrl = 256 / (C / 4);

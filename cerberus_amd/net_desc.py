@@ -255,7 +255,7 @@ class NetDesc(torch.nn.Module):
             _lib.check(_lib.lib().cerb_net_forward_train(h, C.byref(io), C.c_void_p(stream)))
         return res
 
-    def train_grads(self, tiles_u8, targets, has_target, loss_opts, dropout_keep=None, views=False, pixel_weights=None, logits_out=None):
+    def train_grads(self, tiles_u8, targets, has_target, loss_opts, dropout_keep=None, views=False, pixel_weights=None, logits_out=None, sync_losses=True):
         """One step of the reference's train_step up to all_loss.backward() (models/run_desc.py:79-170): train-mode forward, the head
         losses, the backward pass.  targets: head key -> CUDA float [N, H, W] class ids ([N] for Patch-Class); has_target: head key ->
         CUDA float [N]; loss_opts: the reference's loss_kwargs (cerberus_amd.losses.PARAMSET_LOSS).
@@ -264,7 +264,10 @@ class NetDesc(torch.nn.Module):
         pixel_weights: head key -> CUDA float [N, H, W], the head's '#WEIGHT-MAP' target (models/run_desc.py:111-117), optional.
         views=True returns tensors over the handle's own gradient memory instead of copies: valid until the next call on this network.
         logits_out: an (empty) dict that receives the train-mode logits of every head that has a target, channels last ([N, H, W, C]; Patch-Class
-        [N, C]) -- what the reference's train_step turns into its `raw` visualisation payload."""
+        [N, C]) -- what the reference's train_step turns into its `raw` visualisation payload.
+        sync_losses=False: `losses` is (device tensor [n_heads], [head keys in its order]) instead of floats and the call returns without waiting for
+        the device -- the caller (cerberus_amd.train.train_step) queues the optimiser, the running statistics and the weight re-pack underneath the
+        backward pass that is still running and reads the losses last."""
         self.train(True)
         h = self._ensure_handle()
         L = _lib.lib()
@@ -343,6 +346,9 @@ class NetDesc(torch.nn.Module):
                     g = torch.empty(v.shape, dtype=torch.float32, device=dev)
                     _lib.check(L.cerb_copy_d2d(g.data_ptr(), ptr, 4 * v.numel(), C.c_void_p(stream)))
                 grads[k] = g
+        self._train_keepalive = keep  # (the call's device arguments must outlive the queued work when nobody synchronises here)
+        if not sync_losses:
+            return (loss, [(i, key) for i, (_, _, _, key) in enumerate(self._decoders) if key in targets]), grads
         torch.cuda.synchronize(dev)
         losses = OrderedDict((key, float(loss[i])) for i, (_, _, _, key) in enumerate(self._decoders) if key in targets)
         return losses, grads
