@@ -217,6 +217,25 @@ def train_measure(model, dev, dist, world, rank, steps, warmup, backend):
                 ex = work / (ms * 1e-3) / 1e12 * (0.25 if base.startswith(("conv_wino4", "wgrad_wino4")) else 16.0 / 36.0 if base.startswith("conv_wino") else 1.0)
                 row.update(bound="mfma", achieved=round(ex, 2), unit="TFLOP/s", frac=round(ex / PEAK_F32_MFMA_TFLOPS, 4))
             fam_rows.append(row)
+        # measured HBM traffic per family and step (profiles/r05_train_pmc_hbm.json: FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950-corrected by
+        # scripts/rocprof_summary.py pmc_step); for the bandwidth-bound families beside their algorithmic bytes
+        pmc = None
+        for cand in ("r05_train_pmc_hbm.json",):
+            pth = os.path.join(ROOT, "profiles", cand)
+            if os.path.exists(pth):
+                pmc = json.load(open(pth))
+                pmc_src = cand
+        if pmc:
+            for row in fam_rows:
+                syms = _TRAIN_SYMBOLS.get(row["kernel"])
+                if not syms:
+                    continue
+                hit = [v for k, v in pmc.items() if any(sname in k for sname in syms)]
+                if hit:
+                    row["traffic"] = int(sum(v.get("hbm_bytes_per_step", 0.0) for v in hit))
+                    row["traffic_unit"] = "HBM bytes per step (PMC passes, profiles/%s)" % pmc_src
+                    if row.get("bound") == "hbm" and fam[row["kernel"]][0] > 0:
+                        row["traffic_over_algorithmic"] = round(row["traffic"] / fam[row["kernel"]][0], 3)
         # the phases of the step outside the handle's own records (device time between stream events), and what the records leave of the handle's call
         in_handle = sum(r["ms_per_step"] for r in fam_rows)
         fam_rows.append({"kernel": "(inside cerb_net_train_grads, between the records: event gaps, tape bookkeeping)", "launches": 0,
@@ -226,7 +245,7 @@ def train_measure(model, dev, dist, world, rank, steps, warmup, backend):
                 fam_rows.append({"kernel": "(" + name + ")", "launches": 0, "ms_per_step": round(phases[name], 3)})
         attributed = sum(r["ms_per_step"] for r in fam_rows)
         dom = next((r for r in fam_rows if r["kernel"].startswith("wgrad")), fam_rows[0])
-        roofline = dict(dom, peak=PEAK_F32_MFMA_TFLOPS if dom.get("bound") == "mfma" else HBM_PEAK_GBS, traffic=None,
+        roofline = dict(dom, peak=PEAK_F32_MFMA_TFLOPS if dom.get("bound") == "mfma" else HBM_PEAK_GBS, traffic=dom.get("traffic"),
                         attributed_ms=round(attributed, 3),
                         note="dominant backward family; `kernels` attributes the whole profiled step: every launch family inside the handle has its own "
                              "per-launch records (forward, data gradients, weight gradients, BatchNorm, pointwise layers, pooling, up-sampling, losses, zero "
@@ -277,9 +296,22 @@ def train_leg(args, model, dev, dist, world, rank, sd=None, kw=None):
         dist.destroy_process_group()
 
 
+# training families -> kernel symbols (substrings) whose PMC rows make up the family's HBM traffic
+_TRAIN_SYMBOLS = {
+    "wgrad_wino4<f4x4>": ["wgrad_wino_kernel", "wgrad_wino_reduce_kernel"],
+    "wgrad<ks3,s1>": ["wgrad_kernel<3, 1>"], "wgrad<ks3,s2>": ["wgrad_kernel<3, 2>"],
+    "bn_bwd": ["bn_bwd_partial_kernel", "bn_bwd_apply_kernel", "bn_bwd_finalize_kernel"],
+    "bn_fwd": ["bn_apply_kernel", "bn_partial_kernel", "bn_finalize_kernel", "bn_partial_fold_kernel"],
+    "conv_wino4<f4x4,16x16x2>": ["conv_wino4_kernel<false, true>"], "dgrad:conv_wino4<f4x4,16x16x2>": ["conv_wino4_kernel<false, false>", "conv_wino4_kernel<true, false>"],
+    "conv_wino4b<f4x4,16x16>": ["conv_wino4b_kernel<false, true>"], "dgrad:conv_wino4b<f4x4,16x16>": ["conv_wino4b_kernel<false, false>", "conv_wino4b_kernel<true, false>"],
+    "head_fwd1": ["head_fwd1_kernel"], "head_fwd2": ["head_fwd2_kernel"], "head_bwd1": ["head_bwd1_kernel"], "head_bwd2": ["head_bwd2_kernel"],
+    "upadd_bwd": ["upadd_bwd_fused_kernel"], "upsample2_add": ["upsample2_add_kernel"], "maxpool_bwd": ["maxpool_bwd_kernel"], "maxpool3x3s2": ["maxpool3x3s2_kernel"],
+    "stem_wgrad": ["stem_wgrad_mfma_kernel"], "stem_conv7x7": ["stem_conv7x7_kernel"],
+}
+
 # ---- kernel-family table of one batch step (per-launch HIP events on the launch stream, cerb_net_profile_*) ----------------------
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md
-HBM_FAMILIES = {"maxpool3x3s2", "maxpool_bwd", "upsample2_add", "upadd_bwd", "crop_gap", "crop_gap_bwd", "bias_colsum", "zero_fill", "head_loss", "head_fwd2", "head_bwd1", "head_bwd2"}
+HBM_FAMILIES = {"maxpool3x3s2", "maxpool_bwd", "upsample2_add", "upadd_bwd", "crop_gap", "crop_gap_bwd", "bias_colsum", "zero_fill", "head_loss", "head_fwd1", "head_fwd2", "head_bwd1", "head_bwd2"}
 XGMI_LINK_GBS = 153.0   # per peer link, SURVEY.md par.8e
 _SYMBOL = {"conv_wino4p<f4x4,16x16x2,planar>": "void conv_wino4p_kernel<1>(ConvParams)",
            "conv_wino4p<f4x4,16x16x2,planar,half-res>": "void conv_wino4p_kernel<0>(ConvParams)",
@@ -340,7 +372,7 @@ def kernel_table(model, step, n_tiles):
     dom = rows[0]
     fl, ms, cnt = fam[dom["kernel"]]
     traffic = None
-    for cand in ("r04_bench_pmc_hbm.json", "r03_bench_pmc_hbm.json", "r02_bench_pmc_hbm.json", "r01_bench_pmc_hbm.json"):
+    for cand in ("r05_bench_pmc_hbm.json", "r04_bench_pmc_hbm.json", "r03_bench_pmc_hbm.json", "r02_bench_pmc_hbm.json", "r01_bench_pmc_hbm.json"):
         pth = os.path.join(ROOT, "profiles", cand)
         sym = _SYMBOL.get(dom["kernel"])
         if sym and os.path.exists(pth):

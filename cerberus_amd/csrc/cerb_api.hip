@@ -92,6 +92,7 @@ hipError_t cerb_launch_wgrad_wino(const float* x, const float* dy, float* dw, in
 hipError_t cerb_launch_wgrad(const float* x, const float* dy, float* dw, int G, int N, int H, int W, int Cin, int Cout, int ks, int stride, long long x_gs, void* ws,
                              hipStream_t st, float* db = nullptr);
 bool cerb_head_train_supported(long long rows, int cin, int chid, int out);
+hipError_t cerb_launch_head_fwd1(const float* prev, const float* w1, const float* b1, float* hid, long long rows, double* bn_part, int* bn_blocks, hipStream_t st);
 hipError_t cerb_launch_head_fwd2(const float* hid, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w2, const float* b2,
                                  float* logits, long long rows, int out, hipStream_t st);
 size_t cerb_head_bwd_workspace_bytes(long long rows, int out);
@@ -1634,12 +1635,16 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
             // the hidden map's BatchNorm statistics come out of the layer itself (per-wave partials in t_ws, sized for either way before the launch)
             int pre_blocks = 0;
             if (net->t_ws.ensure(std::max(cerb_bn_workspace_bytes(1, rows, 96), (size_t)8192 * 96 * 16), 0)) return fail("workspace allocation failed");
+            const bool heads_fused = net->conv_algo && getenv("CERB_HEAD_UNFUSED") == nullptr && cerb_head_train_supported(rows, 64, 96, d.out_ch);
+            if (heads_fused)
+                PROF(p + ".0", "head_fwd1", (double)rows * (64 + 96) * 4.0,
+                     HIP_OK(cerb_launch_head_fwd1(val[prev] + k * (size_t)rows * 64, net->head_rw1[k], net->head_rb1[k], val[hid], rows, (double*)net->t_ws.p, &pre_blocks, st)));
+            else
             PROF(p + ".0", "pointwise_fwd", 2.0 * rows * 64 * 96, HIP_OK(cerb_launch_pointwise(val[prev] + k * (size_t)rows * 64, net->head_rw1[k], net->head_rb1[k], val[hid], rows, 64, 96, nullptr, st,
                                                                                           net->conv_algo ? (double*)net->t_ws.p : nullptr, &pre_blocks)));
             // The head as ONE tape entry (head_train.hip): the hidden map is stored once and read three times (forward 2, backward 1, backward 2);
             // its normalised copy and both gradients of the hidden layer never exist.  CERB_HEAD_UNFUSED=1 keeps round 4's separate passes (A/B, tests).
-            const bool heads_unfused = getenv("CERB_HEAD_UNFUSED") != nullptr;  // (read per step: the A/B test flips it inside one process)
-            if (net->conv_algo && !heads_unfused && cerb_head_train_supported(rows, 64, 96, d.out_ch)) {
+            if (heads_fused) {  // (CERB_HEAD_UNFUSED is read per step: the A/B test flips it inside one process)
                 const std::string bname = "head." + std::to_string(k);
                 int stt = -1;
                 TCHK(bn(bname, hid, -1, rows, 1, pre_blocks, &stt));

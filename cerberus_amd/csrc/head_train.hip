@@ -22,6 +22,99 @@ constexpr int PC = 64;    // decoder channels
 __device__ __forceinline__ float bn_out(float y, float m, float sc, float be) { return __fmaf_rn(y - m, sc, be); }  // sc = rstd * gamma (train_kernels.hip: bn_out)
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// forward 1:  hid[r][c] = b1[c] + sum_ci prev[r][ci] W1[c][ci]  (+ the BatchNorm statistics partials of hid, as cerb_launch_pw_mfma leaves them).
+// One wave = 16 rows per step: A = the rows (lane = (row l & 15, k-slot l >> 4) reads prev[row][16 S + 4 kq .. + 3]: 64-byte segments, four 16-byte loads
+// per lane), B = W1 held in registers (96 values per lane), 96 v_mfma_f32_16x16x4_f32 per 16 rows; the 16 x 96 result tile -- 6 KiB CONTIGUOUS in hid --
+// goes through LDS and leaves as six 1-KiB stores.  (Round 4's pw_mfma_kernel<64, 96>: row-per-lane 16-byte loads 256 bytes apart and 128-byte store
+// pieces, 3.5 TB/s on the largest stream of the heads.)
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int F1S = 100;  // LDS row stride of the output tile (floats)
+__global__ __launch_bounds__(256) void head_fwd1_kernel(const float* __restrict__ prev, const float* __restrict__ w1, const float* __restrict__ b1, float* __restrict__ hid,
+                                                        long long rows, double* __restrict__ bn_part) {
+    __shared__ __attribute__((aligned(16))) float tile[4][16 * F1S];
+    __shared__ double red[4][HC][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+    f32x4 wb[6][4];  // W1[16 nt + r][16 S + 4 kq + e]
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+        for (int S = 0; S < 4; ++S) wb[nt][S] = *reinterpret_cast<const f32x4*>(w1 + (16 * nt + r) * PC + 16 * S + 4 * kq);
+    float bias[6];
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) bias[nt] = b1[16 * nt + r];
+    double bs[6], bq[6];
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) bs[nt] = bq[nt] = 0.0;
+    float* tl = tile[wave];
+    const long long ntiles = rows >> 4, stride = (long long)gridDim.x * 4;
+    long long t = (long long)blockIdx.x * 4 + wave;
+    f32x4 v[4], nx[4];
+    if (t < ntiles) {
+#pragma unroll
+        for (int S = 0; S < 4; ++S) v[S] = *reinterpret_cast<const f32x4*>(prev + (t * 16 + r) * PC + 16 * S + 4 * kq);
+    }
+    for (; t < ntiles; t += stride) {
+        const bool more = t + stride < ntiles;
+        if (more) {
+#pragma unroll
+            for (int S = 0; S < 4; ++S) nx[S] = *reinterpret_cast<const f32x4*>(prev + ((t + stride) * 16 + r) * PC + 16 * S + 4 * kq);
+        }
+        f32x4 acc[6];
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int S = 0; S < 4; ++S)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < 6; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[S][e], wb[nt][S][e], acc[nt], 0, 0, 0);
+        // D[row 4 kq + e][channel 16 nt + r] -> LDS tile; statistics of what is stored
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) {
+            float ts = 0.f, tq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float val = acc[nt][e] + bias[nt];
+                tl[(4 * kq + e) * F1S + 16 * nt + r] = val;
+                ts += val;
+                tq = fmaf(val, val, tq);
+            }
+            bs[nt] += (double)ts;
+            bq[nt] += (double)tq;
+        }
+        // (a wave's LDS accesses complete in order: no barrier between its own writes and reads)
+        float* dst = hid + t * 16 * HC;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int f = lane + 64 * k, row = f / HQ, c4 = f % HQ;
+            *reinterpret_cast<f32x4*>(dst + 4 * f) = *reinterpret_cast<const f32x4*>(tl + row * F1S + 4 * c4);
+        }
+        if (more) {
+#pragma unroll
+            for (int S = 0; S < 4; ++S) v[S] = nx[S];
+        }
+    }
+    if (bn_part) {  // one partial row per workgroup: [gridDim.x][96][(sum, sum of squares)]
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) {
+            double s = bs[nt], q = bq[nt];
+            s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+            if (kq == 0) {
+                red[wave][16 * nt + r][0] = s;
+                red[wave][16 * nt + r][1] = q;
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < HC; c += 256) {
+            double* o = bn_part + ((long long)blockIdx.x * HC + c) * 2;
+            o[0] = ((red[0][c][0] + red[1][c][0]) + red[2][c][0]) + red[3][c][0];
+            o[1] = ((red[0][c][1] + red[1][c][1]) + red[2][c][1]) + red[3][c][1];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // forward 2:  logits[r][o] = b2[o] + sum_c relu(bn(hid[r][c])) W2[o][c].   One wave = 16 rows per step on v_mfma_f32_16x16x4_f32:
 // A[m = row][k] = the lane's own rectified values (lane = (row l & 15, k-slot kq = l >> 4) reads hid[row][16 S + 4 kq .. + 3]: 64-byte segments),
 // B[k][n = output] = W2 (zero for n >= out), 24 instructions per 16 rows.
@@ -329,6 +422,15 @@ hipError_t cerb_launch_slab_sum(const float* part, float* out, int n, int blocks
 
 bool cerb_head_train_supported(long long rows, int cin, int chid, int out) { return cin == PC && chid == HC && (out == 3 || out == 7) && rows > 0 && rows % 64 == 0; }
 
+// hid [rows][96] = prev [rows][64] W1^T + b1; bn_part: [*bn_blocks][96][2] doubles for cerb_launch_bn_finalize (rows of one group)
+hipError_t cerb_launch_head_fwd1(const float* prev, const float* w1, const float* b1, float* hid, long long rows, double* bn_part, int* bn_blocks, hipStream_t st) {
+    if (rows % 16) return hipErrorInvalidValue;
+    const long long nt = rows / 16;
+    const unsigned blocks = (unsigned)std::min<long long>((nt + 3) / 4, 2048);
+    if (bn_blocks) *bn_blocks = bn_part ? (int)blocks : 0;
+    hipLaunchKernelGGL(head_fwd1_kernel, dim3(blocks), dim3(256), 0, st, prev, w1, b1, hid, rows, bn_part);
+    return hipGetLastError();
+}
 hipError_t cerb_launch_head_fwd2(const float* hid, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w2, const float* b2,
                                  float* logits, long long rows, int out, hipStream_t st) {
     if (rows % 16 || out > 16) return hipErrorInvalidValue;

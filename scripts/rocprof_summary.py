@@ -2,6 +2,8 @@
 
   python scripts/rocprof_summary.py stats  <results.db>  <out.txt>
   python scripts/rocprof_summary.py pmc    <fetch.db> <write.db> <out.json>
+  python scripts/rocprof_summary.py pmc_step <fetch.db> <write.db> <steps> <out.json>          (bytes per kernel and STEP: the training leg's `traffic`)
+  python scripts/rocprof_summary.py sq     <results.db> <kernel regex> <out.txt> [append]
   python scripts/rocprof_summary.py timeline <results.db> <first-kernel substring> <out.txt>     (dispatches of the LAST call that starts with that kernel)
 
 PMC post-processing follows /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KiB, collected in
@@ -49,6 +51,47 @@ def pmc(fetch_db, write_db, out):
         w = r.get("WRITE_SIZE_KiB_avg_per_launch", 0.0) or 0.0
         r["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0  # gfx950: FETCH_SIZE counts 64 B per 128-B request
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    print("wrote", out)
+
+
+def pmc_step(fetch_db, write_db, steps, out):
+    """HBM bytes per kernel symbol and per STEP of a bench run profiled over `steps` steps in total (warm-up + timed + the profiled one):
+    {symbol: {launches_per_step, hbm_bytes_per_launch, hbm_bytes_per_step}} -- what bench.py --mode train reads as `traffic`."""
+    res = {}
+    for key, db in (("FETCH_SIZE", fetch_db), ("WRITE_SIZE", write_db)):
+        c = sqlite3.connect(db)
+        for name, n, tot in c.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name=? group by kernel_name", (key,)):
+            if "at::native" in name:
+                continue
+            r = res.setdefault(name, {})
+            r[key + "_KiB_total"] = tot
+            r[key + "_launches"] = n
+    steps = float(steps)
+    for name, r in res.items():
+        f, w = r.get("FETCH_SIZE_KiB_total", 0.0) or 0.0, r.get("WRITE_SIZE_KiB_total", 0.0) or 0.0
+        n = max(r.get("FETCH_SIZE_launches", 0), r.get("WRITE_SIZE_launches", 0), 1)
+        r["launches_per_step"] = n / steps
+        r["hbm_bytes_per_step"] = (2.0 * f + w) * 1024.0 / steps  # gfx950: FETCH_SIZE counts 64 B per 128-B request
+        r["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0 / n
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    print("wrote", out)
+
+
+def sq(db, pattern, out, append=False):
+    """SQ / TCP / TCC counters per kernel symbol matching `pattern` (regex): average per launch."""
+    import re
+
+    c = sqlite3.connect(db)
+    rows = list(c.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name"))
+    d = {}
+    for k, n, cnt, v in rows:
+        if re.search(pattern, k):
+            d.setdefault(k[:100], {})[n] = (cnt, v)
+    with open(out, "a" if append else "w") as f:
+        for k, m in sorted(d.items()):
+            f.write(k + "\n")
+            for n, (cnt, v) in sorted(m.items()):
+                f.write("   %-36s n=%5d avg=%.5g\n" % (n, cnt, v))
     print("wrote", out)
 
 
@@ -106,5 +149,9 @@ if __name__ == "__main__":
         timeline(sys.argv[2], sys.argv[3], sys.argv[4])
     elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "pmc_step":
+        pmc_step(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
+    elif sys.argv[1] == "sq":
+        sq(sys.argv[2], sys.argv[3], sys.argv[4], len(sys.argv) > 5)
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
