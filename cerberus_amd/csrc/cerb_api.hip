@@ -52,12 +52,14 @@ hipError_t cerb_launch_crop_gap(const float* x, int N, int H, int W, int C, int 
 hipError_t cerb_launch_copy_multi(int count, float* const* dst, const float* const* src, const long long* n, void** dev_tab, size_t* dev_bytes,
                                   std::vector<char>* host_prev, hipStream_t st);
 hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, float* dy, float* dresid, long long group_stride, long long rows, int C, int groups,
-                              const float* mean, const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, int relu, int dy_assign, void* ws, hipStream_t st, unsigned long long eval_mask = 0);
+                              const float* mean, const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, int relu, int dy_assign, void* ws, hipStream_t st, unsigned long long eval_mask = 0, int dresid_assign = 0);
 hipError_t cerb_launch_conv_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int G, int N, int H, int W, int Cin, int Cout,
                                 int ks, int stride, long long x_gs, hipStream_t st);
 hipError_t cerb_launch_stem_wgrad(const unsigned char* tiles, const float* dy, float* dw, int N, int H, int W, hipStream_t st);
 hipError_t cerb_launch_maxpool_bwd(const float* x, const float* ypool, const float* dy, float* dx, int N, int H, int W, int C, hipStream_t st);
-hipError_t cerb_launch_upadd_bwd(const float* dout, float* dskip, float* dprev, int G, int N, int H, int W, int C, long long prev_gs, int shared_prev, hipStream_t st);
+bool cerb_upadd_bwd_fused_ok(int H, int W, int C, int G);
+hipError_t cerb_launch_upadd_bwd(const float* dout, float* dskip, float* dprev, int G, int N, int H, int W, int C, long long prev_gs, int shared_prev, hipStream_t st,
+                                 unsigned group_mask = 0xffffffffu, int skip_assign = 0, int prev_assign = 0);
 hipError_t cerb_launch_pointwise_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long long rows, int cin, int cout,
                                      const float* in_scale, int dx_assign, hipStream_t st);
 hipError_t cerb_launch_crop_gap_bwd(const float* dg, float* dx, int N, int H, int W, int C, int y0, int ch, int x0, int cw, hipStream_t st);
@@ -1836,9 +1838,13 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 if (b.eval.size() > 64) return fail("cerb_net_train_grads: more than 64 groups under one eval-mode BatchNorm");
                 for (size_t g = 0; g < b.eval.size(); ++g)
                     if (b.eval[g]) eval_mask |= 1ull << g;
-                if (prof_begin(net, op.name + ".bn_bwd", "bn_bwd", (double)op.G * op.rows * op.Cout * 4.0 * (5.0 + (op.b >= 0 ? 2.0 : 0.0)), st)) return 1;
+                // the residual branch's gradient likewise: assigned when this BatchNorm is its first writer (the identity of a BasicBlock that is not a decoder skip)
+                const bool fresh_r = op.b >= 0 && !grd[op.b] && cnt[op.b] == (size_t)op.G * op.rows * op.Cout;
+                if (fresh_r && !(grd[op.b] = take(cnt[op.b], false))) return fail("workspace allocation failed");
+                if (prof_begin(net, op.name + ".bn_bwd", "bn_bwd", (double)op.G * op.rows * op.Cout * 4.0 * (5.0 + (op.b >= 0 ? (fresh_r ? 1.0 : 2.0) : 0.0)), st)) return 1;
                 HIP_OK(cerb_launch_bn_bwd(go, val[op.o], val[op.a], G_(op.a), op.b >= 0 ? G_(op.b) : nullptr, op.a_gs, op.rows, op.Cout, op.G, val[op.stat],
-                                          val[op.stat] + (size_t)op.G * op.Cout, b.gamma, b.beta, dgamma, dbeta, op.relu, fresh ? 1 : 0, net->t_ws.p, st, eval_mask));
+                                          val[op.stat] + (size_t)op.G * op.Cout, b.gamma, b.beta, dgamma, dbeta, op.relu, fresh ? 1 : 0, net->t_ws.p, st, eval_mask,
+                                          fresh_r ? 1 : 0));
                 if (prof_end(net, st)) return 1;
                 const std::vector<std::string>& keys = net->bn_keys[op.name];
                 for (int g = 0; g < op.G; ++g) {
@@ -1858,13 +1864,27 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 // INSIDE each block and stop at the skip + upsample sum.  With train_step's substring test (run_desc.py:70-74) that is the
                 // fate of the "#TYPE" decoders ("Gland#TYPE" is not a substring of "Gland-TYPE"): cut their slices here.
                 const long long per_group = (long long)op.N * op.H * op.W * op.Cout;
+                // the fused kernel takes the untrained decoders as a group mask and ASSIGNS outputs it is the first writer of (the skip tensors'
+                // gradients always: the decoders run their backward before the encoder; the level below's gradient too): round 4 zero-filled the
+                // masked slices of `go` and both outputs first -- 5 GB of fills and as many extra reads per step
+                const bool fused = cerb_upadd_bwd_fused_ok(op.H, op.W, op.Cout, op.G);
+                unsigned mask = 0xffffffffu;
+                if (io->decoder_trained)
+                    for (int k = 0; k < op.G; ++k)
+                        if (!io->decoder_trained[net->dense_idx[k]]) mask &= ~(1u << k);
+                const bool skip_fresh = fused && !grd[op.a] && cnt[op.a] == (size_t)per_group;
+                const size_t prev_n = (size_t)op.N * (op.H / 2) * (op.W / 2) * op.Cout;
+                const bool prev_fresh = fused && !grd[op.b] && (op.b_gs == 0 ? cnt[op.b] == prev_n : (cnt[op.b] == (size_t)op.G * prev_n && op.b_gs == (long long)prev_n));
+                if (skip_fresh && !(grd[op.a] = take(cnt[op.a], false))) return fail("workspace allocation failed");
+                if (prev_fresh && !(grd[op.b] = take(cnt[op.b], false))) return fail("workspace allocation failed");
                 float* ga = G_(op.a);
                 float* gb = G_(op.b);
                 PROF("upadd.bwd", "upadd_bwd", (double)op.G * per_group * 4.0 * 2.5,
-                     if (io->decoder_trained)
+                     if (!fused && io->decoder_trained)
                          for (int k = 0; k < op.G; ++k)
                              if (!io->decoder_trained[net->dense_idx[k]]) HIP_OK(hipMemsetAsync(go + k * per_group, 0, per_group * 4, st));
-                     HIP_OK(cerb_launch_upadd_bwd(go, ga, gb, op.G, op.N, op.H, op.W, op.Cout, op.b_gs, op.b_gs == 0 ? 1 : 0, st)));
+                     HIP_OK(cerb_launch_upadd_bwd(go, ga, gb, op.G, op.N, op.H, op.W, op.Cout, op.b_gs, op.b_gs == 0 ? 1 : 0, st, fused ? mask : 0xffffffffu,
+                                                  skip_fresh ? 1 : 0, prev_fresh ? 1 : 0)));
                 break;
             }
             case 5: {

@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            int groups, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu,
-                                                           unsigned long long eval_mask) {
+                                                           unsigned long long eval_mask, int resid_assign) {
     // thread = (channel quad, row lane), rows strided by the grid, blockIdx.y = group (see bn_apply_kernel): per-channel vectors loaded once
     const int c4n = C >> 2, tid = threadIdx.x, g = blockIdx.y;
     const int c4 = tid % c4n, rl = tid / c4n, nrl = 256 / c4n;
@@ -696,14 +696,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             zm[k] = relu == 1 ? ld(z, r + k * step) : zero4;
-            r4[k] = dresid ? ld(dresid, r + k * step) : zero4;
+            r4[k] = (dresid && !resid_assign) ? ld(dresid, r + k * step) : zero4;
             p[k] = ASSIGN ? zero4 : ld(dy, r + k * step);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) finish(r + k * step, d[k], yv[k], zm[k], r4[k], p[k]);
     }
     for (; r < rows; r += step)
-        finish(r, ld(dz, r), ld(y, r), relu == 1 ? ld(z, r) : zero4, dresid ? ld(dresid, r) : zero4, ASSIGN ? zero4 : ld(dy, r));
+        finish(r, ld(dz, r), ld(y, r), relu == 1 ? ld(z, r) : zero4, (dresid && !resid_assign) ? ld(dresid, r) : zero4, ASSIGN ? zero4 : ld(dy, r));
 }
 // ---- convolution backward, gather form (any ks / stride / pad = ks / 2; groups = independent convs stacked along G) ------------------
 __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int G, int N, int H,
@@ -919,8 +919,11 @@ __global__ __launch_bounds__(256) void upadd_bwd_prev_kernel(const float* __rest
 // thread = four channels of a SOURCE pixel (pm, pn) of the level below, all groups: the <= 4 x 4 output pixels it feeds give dprev (same loops, same
 // order as upadd_bwd_prev_kernel: identical bits), and the 2 x 2 of them it owns -- rows 2 pm, 2 pm + 1, columns 2 pn, 2 pn + 1 -- give dskip
 // (sum over the groups in group order, then added: as upadd_bwd_skip_kernel).
+// group_mask: bit g clear = group g's dout counts as ZERO (a decoder that does not train: the caller used to zero-fill its slice first -- 2.5 GB per
+// step); skip_assign / prev_assign: the output holds nothing yet (this is its first writer): assign, no zero fill before the launch and no read here
 __global__ __launch_bounds__(256) void upadd_bwd_fused_kernel(const float* __restrict__ dout, float* __restrict__ dskip, float* __restrict__ dprev, int G, int N,
-                                                              int H, int W, int C, long long prev_gs, int shared_prev) {
+                                                              int H, int W, int C, long long prev_gs, int shared_prev, unsigned group_mask, int skip_assign,
+                                                              int prev_assign) {
     const int Hp = H / 2, Wp = W / 2, C4 = C >> 2;
     const long long total = (long long)N * Hp * Wp * C4;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -936,7 +939,8 @@ __global__ __launch_bounds__(256) void upadd_bwd_fused_kernel(const float* __res
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int gg = 0; gg < G; ++gg) {
             if (!shared_prev) acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int y = max(2 * pm - 2, 0); y <= min(2 * pm + 2, H - 1); ++y) {
+            const bool live = (group_mask >> gg) & 1u;
+            for (int y = max(2 * pm - 2, 0); live && y <= min(2 * pm + 2, H - 1); ++y) {
                 int a0, a1;
                 float u0, u1;
                 up2_taps(y, Hp, a0, a1, u0, u1);
@@ -957,23 +961,23 @@ __global__ __launch_bounds__(256) void upadd_bwd_fused_kernel(const float* __res
                     }
                 }
             }
-            if (!shared_prev) {
+            if (!shared_prev && (live || prev_assign)) {
                 float4* o = reinterpret_cast<float4*>(dprev + gg * prev_gs + (((long long)n * Hp + pm) * Wp + pn) * C + c);
-                float4 pv = *o;
+                float4 pv = prev_assign ? make_float4(0.f, 0.f, 0.f, 0.f) : *o;
                 pv.x += acc.x; pv.y += acc.y; pv.z += acc.z; pv.w += acc.w;
                 *o = pv;
             }
         }
         if (shared_prev) {
             float4* o = reinterpret_cast<float4*>(dprev + (((long long)n * Hp + pm) * Wp + pn) * C + c);
-            float4 pv = *o;
+            float4 pv = prev_assign ? make_float4(0.f, 0.f, 0.f, 0.f) : *o;
             pv.x += acc.x; pv.y += acc.y; pv.z += acc.z; pv.w += acc.w;
             *o = pv;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float4* o = reinterpret_cast<float4*>(dskip + (((long long)n * H + 2 * pm + (k >> 1)) * W + 2 * pn + (k & 1)) * C + c);
-            float4 pv = *o;
+            float4 pv = skip_assign ? make_float4(0.f, 0.f, 0.f, 0.f) : *o;
             pv.x += sk[k].x; pv.y += sk[k].y; pv.z += sk[k].z; pv.w += sk[k].w;
             *o = pv;
         }
@@ -1224,7 +1228,7 @@ static unsigned gridfor(long long n) {
 
 hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, float* dy, float* dresid, long long group_stride, long long rows, int C, int groups,
                               const float* mean, const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, int relu, int dy_assign,
-                              void* ws, hipStream_t st, unsigned long long eval_mask) {
+                              void* ws, hipStream_t st, unsigned long long eval_mask, int dresid_assign) {
     const int rpb = bn_rpb(rows, groups);
     const int bpg = (int)((rows + rpb - 1) / rpb);
     // a ReLU behind a BatchNorm WITHOUT a residual: z > 0 <=> bn_out(y) > 0, recomputed from the y both passes read anyway (relu = 2):
@@ -1240,9 +1244,9 @@ hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, f
     if (ablocks > cap) ablocks = cap;
     const dim3 agrid((unsigned)std::max(1ll, ablocks), (unsigned)groups);
     if (dy_assign) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, agrid, dim3(256), 0, st, dz, z, y, dy, dresid, group_stride, rows, C,
-                                      groups, mean, rstd, gamma, beta, dgamma, dbeta, relu, eval_mask);
+                                      groups, mean, rstd, gamma, beta, dgamma, dbeta, relu, eval_mask, dresid_assign);
     else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, agrid, dim3(256), 0, st, dz, z, y, dy, dresid, group_stride, rows, C, groups,
-                            mean, rstd, gamma, beta, dgamma, dbeta, relu, eval_mask);
+                            mean, rstd, gamma, beta, dgamma, dbeta, relu, eval_mask, dresid_assign);
     return hipGetLastError();
 }
 // dgamma / dbeta from [blocks][C][2] double partials (sum dz xhat -> dgamma, sum dz -> dbeta): head_train.hip's first backward pass
@@ -1271,11 +1275,15 @@ hipError_t cerb_launch_maxpool_bwd(const float* x, const float* ypool, const flo
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(gridfor((long long)N * H * W * (C / 4))), dim3(256), 0, st, x, ypool, dy, dx, N, H, W, C, H / 2, W / 2);
     return hipGetLastError();
 }
-hipError_t cerb_launch_upadd_bwd(const float* dout, float* dskip, float* dprev, int G, int N, int H, int W, int C, long long prev_gs, int shared_prev, hipStream_t st) {
-    if (C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && !getenv("CERB_UPADD_BWD_TWO_PASS")) {
-        hipLaunchKernelGGL(upadd_bwd_fused_kernel, dim3(gridfor((long long)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, st, dout, dskip, dprev, G, N, H, W, C, prev_gs, shared_prev);
+bool cerb_upadd_bwd_fused_ok(int H, int W, int C, int G) { return C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && G <= 32 && !getenv("CERB_UPADD_BWD_TWO_PASS"); }
+hipError_t cerb_launch_upadd_bwd(const float* dout, float* dskip, float* dprev, int G, int N, int H, int W, int C, long long prev_gs, int shared_prev, hipStream_t st,
+                                 unsigned group_mask, int skip_assign, int prev_assign) {
+    if (cerb_upadd_bwd_fused_ok(H, W, C, G)) {
+        hipLaunchKernelGGL(upadd_bwd_fused_kernel, dim3(gridfor((long long)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, st, dout, dskip, dprev, G, N, H, W, C, prev_gs, shared_prev,
+                           group_mask, skip_assign, prev_assign);
         return hipGetLastError();
     }
+    if (group_mask != 0xffffffffu || skip_assign || prev_assign) return hipErrorInvalidValue;  // (the two-pass form accumulates all groups: the caller prepares the buffers)
     hipLaunchKernelGGL(upadd_bwd_skip_kernel, dim3(gridfor((long long)N * H * W * C)), dim3(256), 0, st, dout, dskip, G, (long long)N * H * W * C);
     hipLaunchKernelGGL(upadd_bwd_prev_kernel, dim3(gridfor((long long)N * (H / 2) * (W / 2) * (C / 4) * (shared_prev ? 1 : G))), dim3(256), 0, st, dout, dprev, G, N, H, W, C,
                        prev_gs, shared_prev);
