@@ -1481,7 +1481,9 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
             if (net->t_ws.ensure(cerb_bn_fold_workspace_bytes(b.groups, b.C), 0)) return -1;
             if (cerb_launch_bn_finalize(cs->second.first, cs->second.second, rows, b.C, 1e-5f, mean, rstd, var_u, st, b.groups, net->t_ws.p) != hipSuccess) return -1;
         } else if (pre_blocks > 0 && b.groups == 1) {
-            if (cerb_launch_bn_finalize((const double*)net->t_ws.p, pre_blocks, rows, b.C, 1e-5f, mean, rstd, var_u, st) != hipSuccess) return -1;
+            // (the producer's partial rows sit at the front of t_ws -- at most 2048 of them; rows beyond 4096 x C x 16 bytes serve as the fold area)
+            if (cerb_launch_bn_finalize((const double*)net->t_ws.p, pre_blocks, rows, b.C, 1e-5f, mean, rstd, var_u, st, 1,
+                                        net->t_ws.bytes >= (size_t)4352 * b.C * 16 ? (char*)net->t_ws.p + (size_t)4096 * b.C * 16 : nullptr) != hipSuccess) return -1;
         } else if (cerb_launch_bn_stats(val[y], gs, rows, b.C, b.groups, 1e-5f, mean, rstd, var_u, net->t_ws.p, st) != hipSuccess) return -1;
         if (bn_eval_override(b, mean, rstd, st)) return -1;
         {
@@ -1879,7 +1881,10 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 if (prev_fresh && !(grd[op.b] = take(cnt[op.b], false))) return fail("workspace allocation failed");
                 float* ga = G_(op.a);
                 float* gb = G_(op.b);
-                PROF("upadd.bwd", "upadd_bwd", (double)op.G * per_group * 4.0 * 2.5,
+                // algorithmic bytes: read the live groups' gradients, write the skip gradient (read it too when it already holds one) and the level below's
+                int live_g = 0;
+                for (int k = 0; k < op.G; ++k) live_g += (mask >> k) & 1u;
+                PROF("upadd.bwd", "upadd_bwd", (double)per_group * 4.0 * (live_g + (skip_fresh ? 1.0 : 2.0) + (op.b_gs == 0 ? 0.25 : 0.25 * op.G) * (prev_fresh ? 1.0 : 2.0)),
                      if (!fused && io->decoder_trained)
                          for (int k = 0; k < op.G; ++k)
                              if (!io->decoder_trained[net->dense_idx[k]]) HIP_OK(hipMemsetAsync(go + k * per_group, 0, per_group * 4, st));

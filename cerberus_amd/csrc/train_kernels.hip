@@ -443,19 +443,23 @@ __global__ void crop_gap_kernel(const float* __restrict__ x, int N, int H, int W
 }
 }  // namespace
 
+// [partials: groups x bpg x C x (sum, sum of squares) doubles][fold area: groups x 256 x C x 2 doubles] -- more than 256 partial rows per group are folded
+// to <= 256 by a parallel pass before the finalising kernel walks them (its 16 threads per channel took 30 us over 1500 rows: 1.4 ms per step)
+static inline size_t bn_partial_bytes(int groups, long long bpg, int C) { return ((size_t)groups * bpg * C * 2 * 8 + 255) & ~(size_t)255; }
 size_t cerb_bn_workspace_bytes(int groups, long long rows, int C) {
     const int rpb = bn_rpb(rows, groups);
     const long long bpg = (rows + rpb - 1) / rpb;
-    return (size_t)groups * bpg * C * 2 * 8 + 256;
+    return bn_partial_bytes(groups, bpg, C) + (size_t)groups * 256 * C * 16 + 256;
 }
+hipError_t cerb_launch_bn_finalize(const double* partial, int blocks, long long rows, int C, float eps, float* mean, float* rstd, float* var_unbiased, hipStream_t st,
+                                   int groups, void* fold_ws);
 hipError_t cerb_launch_bn_stats(const float* x, long long group_stride, long long rows, int C, int groups, float eps, float* mean, float* rstd,
                                 float* var_unbiased, void* ws, hipStream_t st) {
     if (C % 4 || C / 4 > 256) return hipErrorInvalidValue;  // a block covers all channel quads of a row; spare threads idle (C = 96: 24 quads x 10 row lanes)
     const int rpb = bn_rpb(rows, groups);
     const int bpg = (int)((rows + rpb - 1) / rpb);
     hipLaunchKernelGGL(bn_partial_kernel, dim3(groups * bpg), dim3(256), 256 * 2 * sizeof(double), st, x, group_stride, rows, C, bpg, (double*)ws, rpb);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, (const double*)ws, rows, C, bpg, eps, mean, rstd, var_unbiased);
-    return hipGetLastError();
+    return cerb_launch_bn_finalize((const double*)ws, bpg, rows, C, eps, mean, rstd, var_unbiased, st, groups, (char*)ws + bn_partial_bytes(groups, bpg, C));
 }
 // statistics from partials some producer already wrote ([groups][blocks][C][2] doubles): mean, 1 / sqrt(var + eps), unbiased variance
 // [G][B][C][2] -> [G][B2][C][2]: output row b2 = the sum of input rows b2 * per .. (b2 + 1) * per - 1, in that order (thread = one output value pair)
@@ -480,7 +484,7 @@ size_t cerb_bn_fold_workspace_bytes(int groups, int C) { return (size_t)groups *
 // rows with 16 threads per channel -- 12,544 rows of a 448^2 decoder level took it 0.3 ms)
 hipError_t cerb_launch_bn_finalize(const double* partial, int blocks, long long rows, int C, float eps, float* mean, float* rstd, float* var_unbiased, hipStream_t st,
                                    int groups, void* fold_ws) {
-    if (blocks > 1024 && fold_ws) {
+    if (blocks > 256 && fold_ws) {
         const int per = (blocks + 255) / 256, b2 = (blocks + per - 1) / per;
         const long long total = (long long)groups * b2 * C;
         hipLaunchKernelGGL(bn_partial_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, (double*)fold_ws, blocks, b2, per, C, groups);
@@ -1236,7 +1240,19 @@ hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, f
     if (relu && !dresid && beta) relu = 2;
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(groups * bpg), dim3(256), 256 * 2 * sizeof(double), st, dz, z, y, group_stride, rows, C, bpg, mean, rstd, relu,
                        gamma, beta, (double*)ws, rpb);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, (const double*)ws, C, bpg, dgamma, dbeta);
+    {
+        const double* part = (const double*)ws;
+        int blocks = bpg;
+        if (blocks > 256) {
+            double* fold = (double*)((char*)ws + bn_partial_bytes(groups, bpg, C));
+            const int per = (blocks + 255) / 256, b2 = (blocks + per - 1) / per;
+            const long long total = (long long)groups * b2 * C;
+            hipLaunchKernelGGL(bn_partial_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, fold, blocks, b2, per, C, groups);
+            part = fold;
+            blocks = b2;
+        }
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, part, C, blocks, dgamma, dbeta);
+    }
     if (C % 4 || C / 4 > 256) return hipErrorInvalidValue;
     const int nrl = 256 / (C / 4);
     long long ablocks = (rows + nrl - 1) / nrl;
