@@ -52,7 +52,9 @@ hipError_t cerb_launch_crop_gap(const float* x, int N, int H, int W, int C, int 
 hipError_t cerb_launch_copy_multi(int count, float* const* dst, const float* const* src, const long long* n, void** dev_tab, size_t* dev_bytes,
                                   std::vector<char>* host_prev, hipStream_t st);
 hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, float* dy, float* dresid, long long group_stride, long long rows, int C, int groups,
-                              const float* mean, const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, int relu, int dy_assign, void* ws, hipStream_t st, unsigned long long eval_mask = 0, int dresid_assign = 0);
+                              const float* mean, const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, int relu, int dy_assign, void* ws, hipStream_t st, unsigned long long eval_mask = 0, int dresid_assign = 0,
+                              const double* pre_part = nullptr, int pre_bpg = 0);
+int cerb_head_bwd2_blocks();
 hipError_t cerb_launch_conv_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, int G, int N, int H, int W, int Cin, int Cout,
                                 int ks, int stride, long long x_gs, hipStream_t st);
 hipError_t cerb_launch_stem_wgrad(const unsigned char* tiles, const float* dy, float* dw, int N, int H, int W, hipStream_t st);
@@ -94,7 +96,8 @@ hipError_t cerb_launch_wgrad_wino(const float* x, const float* dy, float* dw, in
 hipError_t cerb_launch_wgrad(const float* x, const float* dy, float* dw, int G, int N, int H, int W, int Cin, int Cout, int ks, int stride, long long x_gs, void* ws,
                              hipStream_t st, float* db = nullptr);
 bool cerb_head_train_supported(long long rows, int cin, int chid, int out);
-hipError_t cerb_launch_head_fwd1(const float* prev, const float* w1, const float* b1, float* hid, long long rows, double* bn_part, int* bn_blocks, hipStream_t st);
+hipError_t cerb_launch_head_fwd1(const float* prev, const float* w1, const float* b1, float* hid, long long rows, double* bn_part, int* bn_blocks, hipStream_t st,
+                                 const float* const* in_bn = nullptr);
 hipError_t cerb_launch_head_fwd2(const float* hid, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w2, const float* b2,
                                  float* logits, long long rows, int out, hipStream_t st);
 size_t cerb_head_bwd_workspace_bytes(long long rows, int out);
@@ -102,7 +105,7 @@ hipError_t cerb_launch_head_bwd1(const float* hid, const float* dlog, const floa
                                  float* dw2, float* db2, float* dgamma, float* dbeta, long long rows, int out, void* ws, hipStream_t st);
 hipError_t cerb_launch_head_bwd2(const float* hid, const float* dlog, const float* prev, const float* mean, const float* rstd, const float* gamma, const float* beta,
                                  const float* dgamma, const float* dbeta, const float* w1, const float* w2, float* dprev, float* dw1, float* db1, long long rows, int out,
-                                 int eval_mode, int assign, void* ws, hipStream_t st);
+                                 int eval_mode, int assign, void* ws, hipStream_t st, const float* const* in_bn = nullptr, double* in_part = nullptr);
 hipError_t cerb_launch_maxpool(const float* in, float* out, int N, int H, int W, int C, hipStream_t st);
 hipError_t cerb_launch_head(const HeadParams& p, hipStream_t st);
 hipError_t cerb_launch_head_group(const HeadParams* heads, int n_heads, hipStream_t st, int w2_44);
@@ -1368,6 +1371,9 @@ struct TapeOp {
     int type = 0;  // 0 stem, 1 conv, 2 bn, 3 maxpool, 4 upadd, 5 pointwise, 6 crop+gap, 7 a whole output head (head_train.hip)
     int hid = -1, head_k = 0;          // type 7: the stored 96-channel hidden map (a = the grouped decoder tensor, o = the logits, stat = [mean | rstd])
     std::string wkey2, bkey2;          // type 7: keys of the second pointwise layer
+    int in_stat = -1;                  // type 7: [mean | rstd] tensor of a BatchNorm applied on the head's LOAD of `a` (a = that BatchNorm's raw input); -1: a is normalised
+    std::string in_bn;                 // ... and its name (gamma / beta, group = head_k)
+    int deferred = 0;                  // type 2: the normalised output was never written (o aliases a): its consumers apply the BatchNorm themselves
     std::string name;
     int a = -1, b = -1, o = -1;        // tensor ids: input, second input (residual / prev), output
     int N = 0, H = 0, W = 0, Cin = 0, Cout = 0, ks = 0, stride = 1, G = 1, relu = 0;
@@ -1427,6 +1433,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         return grd[t];
     };
     std::vector<TapeOp> tape;
+    std::map<int, std::pair<double*, bool>> deferred_part;  // [mean | rstd] tensor of a deferred BatchNorm -> (its backward partials from the heads, still complete?)
     net->grads.clear();
     auto pub = [&](const std::string& key, size_t n) -> float* {  // a published parameter gradient
         float* p = take(n, true);
@@ -1465,16 +1472,27 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
     // pre_blocks > 0: the producer of y already left pre_blocks rows of statistics partials in net->t_ws (one group): no statistics pass over y
     // stat_only != nullptr: batch statistics only (published as usual) -- *stat_only = the [mean | rstd] tensor, no normalised copy of y is
     // made and no tape entry (the fused heads apply the normalisation inside their own kernels); returns y
-    auto bn = [&](const std::string& name, int y, int resid, long long rows, int relu, int pre_blocks = 0, int* stat_only = nullptr) -> int {
+    // defer_stat != nullptr: the statistics are taken and the tape entry is made as usual, but the normalised tensor is NOT written -- the returned tensor
+    // id aliases y's values (its own gradient buffer), *defer_stat = the [mean | rstd] tensor, and every consumer applies relu(bn(.)) on its loads
+    // (the fused heads behind the last decoder level: head_fwd1 / head_bwd2; the BatchNorm's backward reads y only -- relu mode 2 -- so it does not care)
+    auto bn = [&](const std::string& name, int y, int resid, long long rows, int relu, int pre_blocks = 0, int* stat_only = nullptr, int* defer_stat = nullptr) -> int {
         const cerb_net::BnDev& b = net->bn[name];
-        const int z = stat_only ? y : newT(cnt[y]), stt = newT((size_t)2 * b.groups * b.C);
+        int z;
+        if (stat_only) z = y;
+        else if (defer_stat) {
+            val.push_back(val[y]);
+            grd.push_back(nullptr);
+            cnt.push_back(cnt[y]);
+            z = (int)val.size() - 1;
+        } else z = newT(cnt[y]);
+        const int stt = newT((size_t)2 * b.groups * b.C);
         if (!val[z] || !val[stt] || (!pre_blocks && net->t_ws.ensure(cerb_bn_workspace_bytes(b.groups, rows, b.C), 0))) return -1;
         float* mean = val[stt];
         float* rstd = val[stt] + (size_t)b.groups * b.C;
         const long long gs = b.groups > 1 ? rows * b.C : 0;
         float* var_u = take((size_t)b.groups * b.C, false);  // unbiased batch variance: what the running_var update uses
         // `flops` field = algorithmic bytes of the two forward BatchNorm passes (statistics: read y; apply: read y (+ residual), write z)
-        if (prof_begin(net, name + ".bn_fwd", stat_only ? "bn_finalize" : "bn_fwd", stat_only ? (double)pre_blocks * b.C * 16.0 : (double)b.groups * rows * b.C * 4.0 * (3.0 + (resid >= 0 ? 1.0 : 0.0)), st)) return -1;
+        if (prof_begin(net, name + ".bn_fwd", (stat_only || defer_stat) ? "bn_finalize" : "bn_fwd", (stat_only || defer_stat) ? (double)(pre_blocks > 0 ? pre_blocks : 256) * b.C * 16.0 : (double)b.groups * rows * b.C * 4.0 * (3.0 + (resid >= 0 ? 1.0 : 0.0)), st)) return -1;
         if (!var_u) return -1;
         auto cs = conv_stats.find(y);
         if (cs != conv_stats.end()) {  // the convolution that made y left the partials: [groups][blocks][C][2]
@@ -1498,6 +1516,14 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
             if (prof_end(net, st)) return -1;
             *stat_only = stt;
             return y;
+        }
+        if (defer_stat) {
+            if (prof_end(net, st)) return -1;
+            *defer_stat = stt;
+            TapeOp op;
+            op.type = 2; op.name = name; op.a = y; op.b = resid; op.o = z; op.stat = stt; op.rows = rows; op.Cout = b.C; op.G = b.groups; op.relu = relu; op.a_gs = gs; op.deferred = 1;
+            tape.push_back(op);
+            return z;
         }
         if (cerb_launch_bn_apply(val[z], val[y], resid >= 0 ? val[resid] : nullptr, gs, rows, b.C, b.groups, mean, rstd, b.gamma, b.beta, relu, st) != hipSuccess) return -1;
         if (prof_end(net, st)) return -1;
@@ -1607,6 +1633,8 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         const int oc[4] = {128, 64, 64, 64};
         int prev = cm;
         long long prev_gs = 0;
+        int last_stat = -1;     // >= 0: the last level's BatchNorm was deferred to the heads ([mean | rstd] tensor)
+        std::string last_bn;
         for (int u = 0; u < 4; ++u) {
             const int hh = hs[3 - u], ww = ws[3 - u];
             const std::string n0 = "dec." + std::to_string(u) + ".0", n1 = "dec." + std::to_string(u) + ".1";
@@ -1625,7 +1653,13 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
             TCHK(z0);
             const int c1 = conv(n1, z0, N, hh, ww, rows * net->conv[n0].cout);
             TCHK(c1);
-            prev = bn(n1, c1, -1, rows, 1);
+            // last level: its output feeds the heads only -- when they all run fused (head_train.hip) they normalise on their loads
+            bool defer = u == 3 && net->conv_algo && getenv("CERB_HEAD_UNFUSED") == nullptr && getenv("CERB_HEAD_BN_APPLY_PASS") == nullptr && net->bn[n1].eval.empty();
+            for (size_t k = 0; defer && k < D; ++k) defer = cerb_head_train_supported(rows, 64, 96, net->dec[net->dense_idx[k]].out_ch);
+            if (defer) {
+                prev = bn(n1, c1, -1, rows, 1, 0, nullptr, &last_stat);
+                last_bn = n1;
+            } else prev = bn(n1, c1, -1, rows, 1);
             TCHK(prev);
             prev_gs = rows * oc[u];
         }
@@ -1640,9 +1674,19 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
             int pre_blocks = 0;
             if (net->t_ws.ensure(std::max(cerb_bn_workspace_bytes(1, rows, 96), (size_t)8192 * 96 * 16), 0)) return fail("workspace allocation failed");
             const bool heads_fused = net->conv_algo && getenv("CERB_HEAD_UNFUSED") == nullptr && cerb_head_train_supported(rows, 64, 96, d.out_ch);
+            const float* in_bn[4] = {nullptr, nullptr, nullptr, nullptr};
+            if (last_stat >= 0) {  // group k's statistics and affine parameters of the deferred BatchNorm
+                const cerb_net::BnDev& lb = net->bn[last_bn];
+                in_bn[0] = val[last_stat] + k * (size_t)lb.C;
+                in_bn[1] = val[last_stat] + (size_t)lb.groups * lb.C + k * (size_t)lb.C;
+                in_bn[2] = lb.gamma + k * (size_t)lb.C;
+                in_bn[3] = lb.beta + k * (size_t)lb.C;
+                if (!heads_fused) return fail("internal: deferred BatchNorm in front of an unfused head");
+            }
             if (heads_fused)
                 PROF(p + ".0", "head_fwd1", (double)rows * (64 + 96) * 4.0,
-                     HIP_OK(cerb_launch_head_fwd1(val[prev] + k * (size_t)rows * 64, net->head_rw1[k], net->head_rb1[k], val[hid], rows, (double*)net->t_ws.p, &pre_blocks, st)));
+                     HIP_OK(cerb_launch_head_fwd1(val[prev] + k * (size_t)rows * 64, net->head_rw1[k], net->head_rb1[k], val[hid], rows, (double*)net->t_ws.p, &pre_blocks, st,
+                                                  last_stat >= 0 ? in_bn : nullptr)));
             else
             PROF(p + ".0", "pointwise_fwd", 2.0 * rows * 64 * 96, HIP_OK(cerb_launch_pointwise(val[prev] + k * (size_t)rows * 64, net->head_rw1[k], net->head_rb1[k], val[hid], rows, 64, 96, nullptr, st,
                                                                                           net->conv_algo ? (double*)net->t_ws.p : nullptr, &pre_blocks)));
@@ -1662,6 +1706,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 op.a_gs = (long long)k * rows * 64;
                 op.wkey = p + ".0.block.0.conv.weight"; op.bkey = p + ".0.block.0.conv.bias";
                 op.wkey2 = p + ".1.conv.weight"; op.bkey2 = p + ".1.conv.bias";
+                op.in_stat = last_stat; op.in_bn = last_bn;
                 tape.push_back(op);
                 logit_t[di] = lg;
                 continue;
@@ -1843,10 +1888,16 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 // the residual branch's gradient likewise: assigned when this BatchNorm is its first writer (the identity of a BasicBlock that is not a decoder skip)
                 const bool fresh_r = op.b >= 0 && !grd[op.b] && cnt[op.b] == (size_t)op.G * op.rows * op.Cout;
                 if (fresh_r && !(grd[op.b] = take(cnt[op.b], false))) return fail("workspace allocation failed");
-                if (prof_begin(net, op.name + ".bn_bwd", "bn_bwd", (double)op.G * op.rows * op.Cout * 4.0 * (5.0 + (op.b >= 0 ? (fresh_r ? 1.0 : 2.0) : 0.0)), st)) return 1;
+                // a deferred BatchNorm whose gradient came from the fused heads alone: its reduction pass already happened in their epilogues
+                const double* pre_part = nullptr;
+                if (op.deferred && !getenv("CERB_HEAD_BN_BWD_PASS")) {
+                    auto dp = deferred_part.find(op.stat);
+                    if (dp != deferred_part.end() && dp->second.second && !slice_written.count(op.o)) pre_part = dp->second.first;
+                }
+                if (prof_begin(net, op.name + ".bn_bwd", "bn_bwd", (double)op.G * op.rows * op.Cout * 4.0 * ((pre_part ? 3.0 : 5.0) + (op.b >= 0 ? (fresh_r ? 1.0 : 2.0) : 0.0)), st)) return 1;
                 HIP_OK(cerb_launch_bn_bwd(go, val[op.o], val[op.a], G_(op.a), op.b >= 0 ? G_(op.b) : nullptr, op.a_gs, op.rows, op.Cout, op.G, val[op.stat],
                                           val[op.stat] + (size_t)op.G * op.Cout, b.gamma, b.beta, dgamma, dbeta, op.relu, fresh ? 1 : 0, net->t_ws.p, st, eval_mask,
-                                          fresh_r ? 1 : 0));
+                                          fresh_r ? 1 : 0, pre_part, pre_part ? cerb_head_bwd2_blocks() : 0));
                 if (prof_end(net, st)) return 1;
                 const std::vector<std::string>& keys = net->bn_keys[op.name];
                 for (int g = 0; g < op.G; ++g) {
@@ -1978,9 +2029,30 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 }
                 float* dxp = (fresh && grd[op.a]) ? grd[op.a] : G_(op.a);
                 const int eval_mode = (!b.eval.empty() && b.eval[0]) ? 1 : 0;
+                const float* in_bn[4] = {nullptr, nullptr, nullptr, nullptr};
+                if (op.in_stat >= 0) {
+                    const cerb_net::BnDev& lb = net->bn[op.in_bn];
+                    in_bn[0] = val[op.in_stat] + k * (size_t)lb.C;
+                    in_bn[1] = val[op.in_stat] + (size_t)lb.groups * lb.C + k * (size_t)lb.C;
+                    in_bn[2] = lb.gamma + k * (size_t)lb.C;
+                    in_bn[3] = lb.beta + k * (size_t)lb.C;
+                }
+                double* in_part = nullptr;
+                if (op.in_stat >= 0) {  // the deferred BatchNorm's backward sums come out of this launch's epilogue -- as long as every head is its slice's first writer
+                    const cerb_net::BnDev& lb = net->bn[op.in_bn];
+                    const size_t per = (size_t)cerb_head_bwd2_blocks() * lb.C * 2;  // doubles per group
+                    auto dp = deferred_part.find(op.in_stat);
+                    if (dp == deferred_part.end()) {
+                        double* pb_ = (double*)take((size_t)lb.groups * per * 2, true);
+                        if (!pb_) return fail("workspace allocation failed");
+                        dp = deferred_part.insert(std::make_pair(op.in_stat, std::make_pair(pb_, true))).first;
+                    }
+                    if (fresh) in_part = dp->second.first + (size_t)k * per;
+                    else dp->second.second = false;
+                }
                 PROF(op.name + ".bwd2", "head_bwd2", (double)op.rows * (96 + 64 + 64 + oc) * 4.0,
                      HIP_OK(cerb_launch_head_bwd2(val[op.hid], go, val[op.a] + op.a_gs, mean, rstd, b.gamma, b.beta, dgamma, dbeta, net->head_rw1[k], net->head_rw2[k],
-                                                  dxp + op.a_gs, dw1, db1, op.rows, oc, eval_mode, fresh ? 1 : 0, net->t_ws.p, st)));
+                                                  dxp + op.a_gs, dw1, db1, op.rows, oc, eval_mode, fresh ? 1 : 0, net->t_ws.p, st, op.in_stat >= 0 ? in_bn : nullptr, in_part)));
                 const std::vector<std::string>& keys = net->bn_keys[op.name];
                 net->grads[keys[0] + ".weight"] = std::make_pair(dgamma, 96ll);
                 net->grads[keys[0] + ".bias"] = std::make_pair(dbeta, 96ll);

@@ -29,16 +29,31 @@ __device__ __forceinline__ float bn_out(float y, float m, float sc, float be) { 
 // pieces, 3.5 TB/s on the largest stream of the heads.)
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int F1S = 100;  // LDS row stride of the output tile (floats)
+// in_mean != nullptr: `prev` is the RAW output of the decoder's last convolution and its BatchNorm + ReLU are applied here, on the load
+// (z = relu(bn_out(y)) with the one expression every BatchNorm kernel uses): the normalised copy of the largest decoder tensor is never written.
 __global__ __launch_bounds__(256) void head_fwd1_kernel(const float* __restrict__ prev, const float* __restrict__ w1, const float* __restrict__ b1, float* __restrict__ hid,
-                                                        long long rows, double* __restrict__ bn_part) {
+                                                        long long rows, double* __restrict__ bn_part, const float* __restrict__ in_mean, const float* __restrict__ in_rstd,
+                                                        const float* __restrict__ in_gamma, const float* __restrict__ in_beta) {
     __shared__ __attribute__((aligned(16))) float tile[4][16 * F1S];
+    __shared__ __attribute__((aligned(16))) float wl[6 * 4 * 64 * 4];  // [nt][S][lane][e] = W1[16 nt + (lane & 15)][16 S + 4 (lane >> 4) + e]
     __shared__ double red[4][HC][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
-    f32x4 wb[6][4];  // W1[16 nt + r][16 S + 4 kq + e]
+    for (int i = threadIdx.x; i < 6 * 4 * 64 * 4; i += 256) {
+        const int e = i & 3, l = (i >> 2) & 63, S = (i >> 8) & 3, nt = i >> 10;
+        wl[i] = w1[(16 * nt + (l & 15)) * PC + 16 * S + 4 * (l >> 4) + e];
+    }
+    const bool in_bn = in_mean != nullptr;
+    f32x4 pm[4], ps[4], pb[4];
 #pragma unroll
-    for (int nt = 0; nt < 6; ++nt)
-#pragma unroll
-        for (int S = 0; S < 4; ++S) wb[nt][S] = *reinterpret_cast<const f32x4*>(w1 + (16 * nt + r) * PC + 16 * S + 4 * kq);
+    for (int S = 0; S < 4; ++S) {
+        const int c = 16 * S + 4 * kq;
+        pm[S] = ps[S] = pb[S] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (in_bn) {
+            pm[S] = *reinterpret_cast<const f32x4*>(in_mean + c);
+            ps[S] = *reinterpret_cast<const f32x4*>(in_rstd + c) * *reinterpret_cast<const f32x4*>(in_gamma + c);
+            pb[S] = *reinterpret_cast<const f32x4*>(in_beta + c);
+        }
+    }
     float bias[6];
 #pragma unroll
     for (int nt = 0; nt < 6; ++nt) bias[nt] = b1[16 * nt + r];
@@ -46,6 +61,7 @@ __global__ __launch_bounds__(256) void head_fwd1_kernel(const float* __restrict_
 #pragma unroll
     for (int nt = 0; nt < 6; ++nt) bs[nt] = bq[nt] = 0.0;
     float* tl = tile[wave];
+    __syncthreads();
     const long long ntiles = rows >> 4, stride = (long long)gridDim.x * 4;
     long long t = (long long)blockIdx.x * 4 + wave;
     f32x4 v[4], nx[4];
@@ -59,15 +75,24 @@ __global__ __launch_bounds__(256) void head_fwd1_kernel(const float* __restrict_
 #pragma unroll
             for (int S = 0; S < 4; ++S) nx[S] = *reinterpret_cast<const f32x4*>(prev + ((t + stride) * 16 + r) * PC + 16 * S + 4 * kq);
         }
+        if (in_bn) {
+#pragma unroll
+            for (int S = 0; S < 4; ++S)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[S][e] = fmaxf(bn_out(v[S][e], pm[S][e], ps[S][e], pb[S][e]), 0.f);
+        }
+        asm volatile("" ::: "memory");  // (keeps the 24 W1 reads below inside the loop: hoisted, they are 96 registers -- the reason W1 sits in LDS)
         f32x4 acc[6];
 #pragma unroll
         for (int nt = 0; nt < 6; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int S = 0; S < 4; ++S)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int nt = 0; nt < 6; ++nt) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(wl + ((nt * 4 + S) * 64 + lane) * 4);
 #pragma unroll
-                for (int nt = 0; nt < 6; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[S][e], wb[nt][S][e], acc[nt], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[S][e], b[e], acc[nt], 0, 0, 0);
+            }
         // D[row 4 kq + e][channel 16 nt + r] -> LDS tile; statistics of what is stored
 #pragma unroll
         for (int nt = 0; nt < 6; ++nt) {
@@ -278,6 +303,8 @@ __global__ __launch_bounds__(256) void head_bwd1_kernel(const float* __restrict_
 constexpr int DS = 100, PS_ = 68;  // row strides (floats) of the LDS tiles: 100 = 25 16-byte chunks (odd: b128 row reads conflict-free), 68 likewise
 struct Bwd2Params {
     const float *hid, *dlog, *prev, *mean, *rstd, *gamma, *dgamma, *dbeta, *beta, *w1, *w2;
+    const float *in_mean, *in_rstd, *in_gamma, *in_beta;  // optional: `prev` is the raw input of the BatchNorm + ReLU in front of the head (applied on the LDS reads)
+    double* in_part;  // optional, with in_*: [gridDim.x][64][2] -- that BatchNorm's backward sums (sum dz, sum dz xhat over this workgroup's rows; dz = dprev masked by its ReLU)
     float *dprev, *part_w1, *part_b1;
     long long rows;
     float inv_m;   // 1 / rows; 0 for an eval-mode BatchNorm (no batch-statistics terms)
@@ -306,6 +333,21 @@ __global__ __launch_bounds__(256, 2) void head_bwd2_kernel(Bwd2Params p) {
 #pragma unroll
     for (int o = 0; o < OUT; ++o) wc[o] = *reinterpret_cast<const f32x4*>(p.w2 + o * HC + c0);
     f32x4 sb = {0.f, 0.f, 0.f, 0.f};
+    const bool in_bn = p.in_mean != nullptr;
+    // the channels this lane meets `prev` at: 16 wave + mr as the B operand of the weight gradient, 16 nt + mr in the data gradient's output tile
+    float wm = 0.f, wsc = 0.f, wb_ = 0.f;
+    float em[4], es[4], eb[4], er[4], s1[4], s2[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) em[nt] = es[nt] = eb[nt] = er[nt] = s1[nt] = s2[nt] = 0.f;
+    if (in_bn) {
+        const int cw = 16 * wave + mr;
+        wm = p.in_mean[cw]; wsc = p.in_rstd[cw] * p.in_gamma[cw]; wb_ = p.in_beta[cw];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int ce = 16 * nt + mr;
+            em[nt] = p.in_mean[ce]; er[nt] = p.in_rstd[ce]; es[nt] = er[nt] * p.in_gamma[ce]; eb[nt] = p.in_beta[ce];
+        }
+    }
     f32x4 accw[6];
 #pragma unroll
     for (int m = 0; m < 6; ++m) accw[m] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -328,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void head_bwd2_kernel(Bwd2Params p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = tid + 256 * k, row = i >> 4, c4 = i & 15;
-            *reinterpret_cast<f32x4*>(Pl + row * PS_ + 4 * c4) = pv[k];
+            *reinterpret_cast<f32x4*>(Pl + row * PS_ + 4 * c4) = pv[k];  // (raw: with in_bn the readers below normalise, and the epilogue needs the raw values)
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -385,12 +427,19 @@ __global__ __launch_bounds__(256, 2) void head_bwd2_kernel(Bwd2Params p) {
                 for (int e = 0; e < 4; ++e) {
                     float* o = p.dprev + (rb + 16 * wave + 4 * kq + e) * PC + 16 * nt + mr;
                     *o = p.assign ? acc[nt][e] : *o + acc[nt][e];
+                    if (in_bn && p.in_part) {  // the BatchNorm in front: its backward sums over what this head contributes (assign mode: dprev IS this head's dz)
+                        const float y = Pl[(16 * wave + 4 * kq + e) * PS_ + 16 * nt + mr];
+                        const float dz = bn_out(y, em[nt], es[nt], eb[nt]) > 0.f ? acc[nt][e] : 0.f;
+                        s1[nt] += dz;
+                        s2[nt] = fmaf(dz, (y - em[nt]) * er[nt], s2[nt]);
+                    }
                 }
         }
         // ---- M2: dW1[c = 16 mt + mr][ci = 16 wave + ..] += sum over the tile's rows ---------------------------------------------------
 #pragma unroll 4
         for (int s = 0; s < 16; ++s) {
-            const float b = Pl[(4 * s + kq) * PS_ + 16 * wave + mr];
+            float b = Pl[(4 * s + kq) * PS_ + 16 * wave + mr];
+            if (in_bn) b = fmaxf(bn_out(b, wm, wsc, wb_), 0.f);
 #pragma unroll
             for (int mt = 0; mt < 6; ++mt) {
                 const float a = Dl[(4 * s + kq) * DS + 16 * mt + mr];
@@ -405,6 +454,26 @@ __global__ __launch_bounds__(256, 2) void head_bwd2_kernel(Bwd2Params p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) ow[(16 * mt + 4 * kq + e) * PC + 16 * wave + mr] = accw[mt][e];  // D[c 4 kq + e][ci mr]
     __syncthreads();
+    if (in_bn && p.in_part) {  // lanes kq = 0 .. 3 and the four waves hold different rows of the same 64 channels
+        float* r2 = Pl;  // [wave][64][2]
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            float a = s1[nt], b = s2[nt];
+            a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+            a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+            if (kq == 0) {
+                r2[(wave * 64 + 16 * nt + mr) * 2] = a;
+                r2[(wave * 64 + 16 * nt + mr) * 2 + 1] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int c = tid >> 1, which = tid & 1;
+            p.in_part[((long long)blockIdx.x * 64 + c) * 2 + which] =
+                (double)(((r2[(0 * 64 + c) * 2 + which] + r2[(1 * 64 + c) * 2 + which]) + r2[(2 * 64 + c) * 2 + which]) + r2[(3 * 64 + c) * 2 + which]);
+        }
+        __syncthreads();
+    }
     float* redb = Dl;  // [8 row slots][96]
     if (live)
 #pragma unroll
@@ -423,12 +492,15 @@ hipError_t cerb_launch_slab_sum(const float* part, float* out, int n, int blocks
 bool cerb_head_train_supported(long long rows, int cin, int chid, int out) { return cin == PC && chid == HC && (out == 3 || out == 7) && rows > 0 && rows % 64 == 0; }
 
 // hid [rows][96] = prev [rows][64] W1^T + b1; bn_part: [*bn_blocks][96][2] doubles for cerb_launch_bn_finalize (rows of one group)
-hipError_t cerb_launch_head_fwd1(const float* prev, const float* w1, const float* b1, float* hid, long long rows, double* bn_part, int* bn_blocks, hipStream_t st) {
+// in_bn (optional): {mean, rstd, gamma, beta} [64] of the BatchNorm in FRONT of the head -- `prev` is then its raw input (see the kernel)
+hipError_t cerb_launch_head_fwd1(const float* prev, const float* w1, const float* b1, float* hid, long long rows, double* bn_part, int* bn_blocks, hipStream_t st,
+                                 const float* const* in_bn) {
     if (rows % 16) return hipErrorInvalidValue;
     const long long nt = rows / 16;
     const unsigned blocks = (unsigned)std::min<long long>((nt + 3) / 4, 2048);
     if (bn_blocks) *bn_blocks = bn_part ? (int)blocks : 0;
-    hipLaunchKernelGGL(head_fwd1_kernel, dim3(blocks), dim3(256), 0, st, prev, w1, b1, hid, rows, bn_part);
+    hipLaunchKernelGGL(head_fwd1_kernel, dim3(blocks), dim3(256), 0, st, prev, w1, b1, hid, rows, bn_part, in_bn ? in_bn[0] : (const float*)nullptr,
+                       in_bn ? in_bn[1] : (const float*)nullptr, in_bn ? in_bn[2] : (const float*)nullptr, in_bn ? in_bn[3] : (const float*)nullptr);
     return hipGetLastError();
 }
 hipError_t cerb_launch_head_fwd2(const float* hid, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w2, const float* b2,
@@ -442,6 +514,7 @@ hipError_t cerb_launch_head_fwd2(const float* hid, const float* mean, const floa
 
 constexpr long long B1_ROWS = 2048;
 constexpr int B2_BLOCKS = 512;
+int cerb_head_bwd2_blocks() { return B2_BLOCKS; }
 // workspace of the two backward launches (floats): bwd1 partials [blocks1][out][96] + [blocks1][out] + BN partials (doubles) [blocks1][96][2];
 // bwd2 partials [512][96][64] + [512][96]
 size_t cerb_head_bwd_workspace_bytes(long long rows, int out) {
@@ -481,11 +554,13 @@ hipError_t cerb_launch_head_bwd1(const float* hid, const float* dlog, const floa
 // dprev [rows][64] (assigned or accumulated), dW1 [96][64], db1 [96]; dgamma / dbeta: what cerb_launch_head_bwd1 left
 hipError_t cerb_launch_head_bwd2(const float* hid, const float* dlog, const float* prev, const float* mean, const float* rstd, const float* gamma, const float* beta,
                                  const float* dgamma, const float* dbeta, const float* w1, const float* w2, float* dprev, float* dw1, float* db1, long long rows, int out,
-                                 int eval_mode, int assign, void* ws, hipStream_t st) {
-    if (rows % 64) return hipErrorInvalidValue;
+                                 int eval_mode, int assign, void* ws, hipStream_t st, const float* const* in_bn, double* in_part) {
+    if (rows % 64 || (in_part && !assign)) return hipErrorInvalidValue;  // (the sums are over dprev as THIS launch leaves it: first writer only)
     const HeadBwdWs w = head_ws(ws, rows, out);
     Bwd2Params p;
     p.hid = hid; p.dlog = dlog; p.prev = prev; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.dgamma = dgamma; p.dbeta = dbeta; p.w1 = w1; p.w2 = w2;
+    p.in_mean = in_bn ? in_bn[0] : nullptr; p.in_rstd = in_bn ? in_bn[1] : nullptr; p.in_gamma = in_bn ? in_bn[2] : nullptr; p.in_beta = in_bn ? in_bn[3] : nullptr;
+    p.in_part = in_bn ? in_part : nullptr;
     p.dprev = dprev; p.part_w1 = w.pw1; p.part_b1 = w.pb1; p.rows = rows; p.inv_m = eval_mode ? 0.f : 1.f / (float)rows; p.assign = assign;
     const int blocks = (int)std::min<long long>(rows / 64, B2_BLOCKS);
     constexpr size_t LDS_BYTES = (size_t)(64 * DS + 64 * PS_ + HC * PC + 64 * 8) * 4;  // 69.6 KB: two workgroups per CU

@@ -1232,19 +1232,22 @@ static unsigned gridfor(long long n) {
 
 hipError_t cerb_launch_bn_bwd(const float* dz, const float* z, const float* y, float* dy, float* dresid, long long group_stride, long long rows, int C, int groups,
                               const float* mean, const float* rstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, int relu, int dy_assign,
-                              void* ws, hipStream_t st, unsigned long long eval_mask, int dresid_assign) {
+                              void* ws, hipStream_t st, unsigned long long eval_mask, int dresid_assign, const double* pre_part, int pre_bpg) {
+    // pre_part: the reduction pass's partials ([groups][pre_bpg][C][2] doubles: sum dz, sum dz xhat over the ReLU-masked gradient) were already
+    // produced by the kernels that wrote dz (head_train.hip: head_bwd2 behind a deferred BatchNorm) -- no pass over dz / y for them here
     const int rpb = bn_rpb(rows, groups);
-    const int bpg = (int)((rows + rpb - 1) / rpb);
+    const int bpg = pre_part ? pre_bpg : (int)((rows + rpb - 1) / rpb);
     // a ReLU behind a BatchNorm WITHOUT a residual: z > 0 <=> bn_out(y) > 0, recomputed from the y both passes read anyway (relu = 2):
     // 5 instead of 7 tensor passes over the activation
     if (relu && !dresid && beta) relu = 2;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(groups * bpg), dim3(256), 256 * 2 * sizeof(double), st, dz, z, y, group_stride, rows, C, bpg, mean, rstd, relu,
-                       gamma, beta, (double*)ws, rpb);
+    if (!pre_part)
+        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(groups * bpg), dim3(256), 256 * 2 * sizeof(double), st, dz, z, y, group_stride, rows, C, bpg, mean, rstd, relu,
+                           gamma, beta, (double*)ws, rpb);
     {
-        const double* part = (const double*)ws;
+        const double* part = pre_part ? pre_part : (const double*)ws;
         int blocks = bpg;
         if (blocks > 256) {
-            double* fold = (double*)((char*)ws + bn_partial_bytes(groups, bpg, C));
+            double* fold = pre_part ? (double*)ws : (double*)((char*)ws + bn_partial_bytes(groups, bpg, C));  // (pre_part: ws holds no partials of its own)
             const int per = (blocks + 255) / 256, b2 = (blocks + per - 1) / per;
             const long long total = (long long)groups * b2 * C;
             hipLaunchKernelGGL(bn_partial_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, fold, blocks, b2, per, C, groups);

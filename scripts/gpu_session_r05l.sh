@@ -10,5 +10,5 @@ import json
 d = json.loads(open("gpurun_out/r05l/train.json").read().strip().splitlines()[-1])
 print("train", d["ms_per_step"], "ms/step")
 for r in d["kernels"]:
-    if r["kernel"].startswith(("(", "wgrad", "bn_", "upadd")): print("   %-90s %8.3f ms" % (r["kernel"][:90], r["ms_per_step"]))
+    if r["kernel"].startswith(("(", "head", "bn_")): print("   %-90s %8.3f ms" % (r["kernel"][:90], r["ms_per_step"]))
 PY

@@ -581,9 +581,11 @@ def test_fused_output_heads_equal_the_separate_passes(gold):
         targets[h] = torch.from_numpy(t.reshape(t.shape[0]) if h == "Patch-Class" else t).cuda()
         flags[h] = torch.from_numpy(gold["has_target"][:, j].astype(np.float32)).cuda()
     out = {}
-    for mode in ("fused", "separate"):
+    for mode in ("fused", "separate", "fused_own_bn_passes"):
         if mode == "separate":
             os.environ["CERB_HEAD_UNFUSED"] = "1"
+        if mode == "fused_own_bn_passes":  # fused heads, but the last decoder BatchNorm applied / reduced by its own passes (no deferral to the heads' loads)
+            os.environ["CERB_HEAD_BN_APPLY_PASS"] = "1"
         try:
             m = create_model(**default_model_kwargs())
             m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(int(gold["weight_seed"])).items()}, strict=True)
@@ -596,6 +598,14 @@ def test_fused_output_heads_equal_the_separate_passes(gold):
             out[mode] = (losses, {k: v.detach().cpu().numpy().copy() for k, v in grads.items()}, {k: v.detach().cpu().numpy().copy() for k, v in logits.items()}, fams)
         finally:
             os.environ.pop("CERB_HEAD_UNFUSED", None)
+            os.environ.pop("CERB_HEAD_BN_APPLY_PASS", None)
+    # the deferred BatchNorm (normalised on the heads' loads, backward sums from head_bwd2's epilogue) against the same fused heads behind its own passes
+    (lc, gc, zc, fc) = out["fused_own_bn_passes"]
+    for k in out["fused"][1]:
+        a, c = out["fused"][1][k].astype(np.float64).ravel(), gc[k].astype(np.float64).ravel()
+        if float(np.abs(c).max()) < 1e-7:
+            continue
+        assert float(np.abs(a - c).max()) / float(np.abs(c).max()) < (2e-4 if k.startswith(("output_head.", "decoder_head.")) else 1e-2), k
     (la, ga, za, fa), (lb, gb, zb, fb) = out["fused"], out["separate"]
     assert {"head_fwd2", "head_bwd1", "head_bwd2"} <= fa and not ({"head_fwd2", "head_bwd1", "head_bwd2"} & fb), (fa, fb)  # the A/B really ran both ways
     assert set(ga) == set(gb) and set(za) == set(zb)
