@@ -558,8 +558,6 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
         torch.cuda.synchronize()
         phase["tail_s"] = time.perf_counter() - t1
         res.update(inst=inst, info=info, small=small)
-        if small is not None:  # proof that the tail consumed what THIS job's inference produced (checked against the canvases outside the timed region)
-            res["small_sum"] = {k: float(v.double().sum().item()) for k, v in small.items()}
 
     if os.environ.get("CERB_BENCH_PROBE_REPEAT"):  # developer probe: is the first full-size tail slower than the second (allocator warm-up)?
         for _ in range(int(os.environ["CERB_BENCH_PROBE_REPEAT"])):
@@ -575,10 +573,15 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             phase[key] = float(t.item())
     info = res["info"]
-    small_sum = res.get("small_sum")
+    # proof that the tail consumed what THIS job's inference produced: checksums of the class maps the timed tail returned (taken here, outside the
+    # timed region) against the canvases the timed inference wrote
+    def _csum(v):
+        return float(v.sum(dtype=torch.float64 if v.is_floating_point() else torch.int64).item())
+
+    small_sum = {k: _csum(v) for k, v in res["small"].items()} if res.get("small") is not None else None
     if small_sum is not None and world == 1:  # one rank: the gathered class maps ARE the inference's canvases, cropped to the slide
         for k, v in small_sum.items():
-            assert v == float(run.canv[k][:valid, :W].double().sum().item()), "the tail's %s map is not the inference's canvas" % k
+            assert v == _csum(run.canv[k][:valid, :W]), "the tail's %s map is not the inference's canvas" % k
     n_inst = {t: int(i.get("n_total", 0)) for t, i in info.items()}
     checks = {t: {"n_truncated": int(i.get("n_truncated", 0)), "n_unresolved": int(i.get("n_unresolved", 0)), "local_bands": int(i.get("local_bands", 1)),
                   "bands_labelled_under_inference": int(i.get("bands_labelled_under_inference", 0))}

@@ -15,13 +15,15 @@ operator only has a CUDA implementation: on CPU tensors the dispatcher raises No
 The NetDesc / postproc mirrors keep calling the C ABI directly (one ctypes call per batch; the dispatcher would add nothing); the
 operators are the public torch-level surface and tests/test_ops_gpu.py holds them to the mirrors bit for bit."""
 import ctypes as C
+import weakref
 
 import torch
 
 from . import _lib
 
 _HEAD_KIND = {"INST": 0, "TYPE": 1, "OUT": 2}
-_nets = {}  # handle value -> NetDesc (weak registry filled by NetDesc.handle_value: keeps the decoder list an operator call needs)
+_nets = weakref.WeakValueDictionary()  # handle value -> NetDesc, filled by NetDesc.handle_value; weak: a dropped model frees its handle and workspace, and a
+# recycled handle value can never resolve to a dead model's decoder list
 
 
 def register_net(model):

@@ -210,7 +210,13 @@ class IncrementalLocalLabeller(object):
 
     def finish(self):
         if self.side is not None:
-            torch.cuda.current_stream(self.side.device).wait_stream(self.side)
+            cur = torch.cuda.current_stream(self.side.device)
+            cur.wait_stream(self.side)
+            for s in self.states[: self.done]:
+                # labelled on the side stream, relabelled and handed on on the caller's: without this the caching allocator may give a freed window back to
+                # the side stream while the caller's stream still reads it
+                if torch.is_tensor(getattr(s, "lab", None)) and s.lab.is_cuda:
+                    s.lab.record_stream(cur)
         for r in range(self.done, self.nb):
             self._label(r)
         self.done = self.nb
