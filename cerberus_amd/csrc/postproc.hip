@@ -111,6 +111,50 @@ static int scan_exclusive(const int* in, int* out, int n, int* tmp, hipStream_t 
     return 0;
 }
 
+// ---- root bitmaps (round 5) -------------------------------------------------------------------------------------
+// The roots of a labelling are ~1 pixel in 1000; the passes that only want THEM (ranks = scipy's label ids, per-component setup, heap offsets, work
+// lists) used to scan the whole pixel map (0.12 - 0.19 ms each at 8192^2).  The last per-pixel pass of a labelling leaves one bit per pixel instead
+// ("is a kept root": a wave ballot, one 8-byte store per 64 pixels), and those passes walk n / 64 words.
+//   rank of root r = wpre[r >> 6] (+ block offset) + popcount(bits[r >> 6] below bit r & 63)
+__global__ __launch_bounds__(256) void scan_block_popc_kernel(const u64* __restrict__ bits, int* __restrict__ out, int* __restrict__ sums, int nw) {
+    __shared__ int wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long base = (long long)blockIdx.x * SCAN_ITEMS + tid * 4;
+    int v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (base + i < nw) ? __popcll(bits[base + i]) : 0;
+    const int tsum = v[0] + v[1] + v[2] + v[3];
+    int inc = tsum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    int run = woff + inc - tsum;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (base + i < nw) out[base + i] = run;
+        run += v[i];
+    }
+    if (tid == 255 && sums) sums[blockIdx.x] = woff + inc;
+}
+// wpre[w] (+ (*block_offsets)[w >> 10] when that is not nullptr) = number of set bits in the words before w
+static int scan_exclusive_popc(const u64* bits, int* wpre, int nw, int* tmp, hipStream_t st, const int** block_offsets) {
+    const int nb = (nw + SCAN_ITEMS - 1) / SCAN_ITEMS;
+    *block_offsets = nullptr;
+    hipLaunchKernelGGL(scan_block_popc_kernel, dim3(nb), dim3(256), 0, st, bits, wpre, nb > 1 ? tmp : (int*)nullptr, nw);
+    KCHECK();
+    if (nb > 1) {
+        if (scan_exclusive(tmp, tmp, nb, tmp + ((nb + 3) & ~3), st)) return 1;
+        *block_offsets = tmp;
+    }
+    return 0;
+}
+
 // (row, column) of a linear pixel index p < 2^31 without the 64-bit integer division a per-pixel `p / W`, `p % W` costs (~100 VALU
 // instructions): one fp64 multiply by a per-thread reciprocal, exact after a one-step fix-up.
 __device__ __forceinline__ void pix_yx(long long p, int W, double invW, int& y, int& x) {
@@ -263,9 +307,17 @@ __device__ __forceinline__ void lds_union(int* L, int a, int b) {
             done = true;
     } while (!done);
 }
-__global__ __launch_bounds__(256) void ccl_tile_kernel(const uint8_t* __restrict__ fg, uint8_t val, int* __restrict__ L, int H, int W, int tiles_x, int n_tiles) {
+// ROOTS (round 5): every tile-local root is appended to a compact list (one atomic per tile) and area[root] = the pixels of its tile-local set (counted
+// per run in LDS) -- with the list flattened after the seam unions (ccl2_flatten_roots_kernel) L[L[p]] is a pixel's root and roots_area_merge_kernel
+// adds the merged sets' counts up over the LIST: no pass over the pixel map for the flatten, none for the areas, no zero fill of `area`.
+template <bool ROOTS>
+__global__ __launch_bounds__(256) void ccl_tile_kernel(const uint8_t* __restrict__ fg, uint8_t val, int* __restrict__ L, int H, int W, int tiles_x, int n_tiles,
+                                                       int* __restrict__ roots, int* __restrict__ n_roots, int* __restrict__ area) {
     __shared__ int sl[CT_H * CT_W];
     __shared__ u64 smask[CT_H];
+    __shared__ int scnt[ROOTS ? CT_H * CT_W : 1];
+    __shared__ u64 srootm[ROOTS ? CT_H : 1];
+    __shared__ int srow_off[ROOTS ? CT_H : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int tx0 = (tile % tiles_x) * CT_W, ty0 = (tile / tiles_x) * CT_H;
@@ -278,6 +330,7 @@ __global__ __launch_bounds__(256) void ccl_tile_kernel(const uint8_t* __restrict
             const u64 m = __ballot(f);
             const u64 starts = m & ~(m << 1);
             sl[r * CT_W + lane] = f ? r * CT_W + 63 - __clzll((long long)(starts & ((2ull << lane) - 1))) : -1;
+            if (ROOTS) scnt[r * CT_W + lane] = 0;
             if (lane == 0) smask[r] = m;
         }
         __syncthreads();
@@ -295,17 +348,69 @@ __global__ __launch_bounds__(256) void ccl_tile_kernel(const uint8_t* __restrict
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int r = wave * 8 + i, y = ty0 + r;
+            bool is_root = false;
             if (x < W && y < H) {
                 const int l = sl[r * CT_W + lane];
                 int g = -1;
                 if (l >= 0) {
                     const int root = lds_find(sl, l);
                     g = (ty0 + (root >> 6)) * W + tx0 + (root & 63);
+                    if (ROOTS) {
+                        is_root = root == r * CT_W + lane;
+                        const u64 mrow = smask[r];
+                        if (((mrow & ~(mrow << 1)) >> lane) & 1ull) {  // first pixel of a run: the run's length goes to the set's counter
+                            const u64 rest = ~(mrow >> lane);
+                            atomicAdd(&scnt[root], rest ? __ffsll((long long)rest) - 1 : 64 - lane);
+                        }
+                    }
                 }
                 L[(long long)y * W + x] = g;
             }
+            if (ROOTS) {
+                const u64 rm = __ballot(is_root);
+                if (lane == 0) srootm[r] = rm;
+            }
         }
         __syncthreads();
+        if (ROOTS) {
+            if (wave == 0) {  // exclusive scan of the 32 row counts in one wave, one atomic per tile
+                const int c = lane < CT_H ? __popcll(srootm[lane]) : 0;
+                int incl = c;
+#pragma unroll
+                for (int d = 1; d < CT_H; d <<= 1) {
+                    const int up = __shfl_up(incl, d);
+                    if (lane >= d) incl += up;
+                }
+                const int tot = __shfl(incl, CT_H - 1);
+                int base = 0;
+                if (lane == 0 && tot) base = atomicAdd(n_roots, tot);
+                base = __shfl(base, 0);
+                if (lane < CT_H) srow_off[lane] = base + incl - c;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = wave * 8 + i, y = ty0 + r;
+                const u64 rm = srootm[r];
+                if ((rm >> lane) & 1ull) {
+                    roots[srow_off[r] + __popcll(rm & ((1ull << lane) - 1))] = y * W + x;
+                    area[(long long)y * W + x] = scnt[r * CT_W + lane];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+// area[root] += the counts of the tile-local sets that were united into it (needs the flattened list: L[t] is t's root)
+__global__ void roots_area_merge_kernel(const int* __restrict__ L, const int* __restrict__ roots, const int* __restrict__ n_roots, int* __restrict__ area) {
+    const int n = *n_roots;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int t = roots[i];
+        const int f = L[t];
+        if (f != t) {
+            const int a = area[t];
+            if (a) atomicAdd(&area[f], a);
+        }
     }
 }
 // unions across tile borders: vertical seams (x a multiple of 64: the run continues), horizontal seams (y a multiple of 32: one union per
@@ -354,7 +459,8 @@ static int ccl_run(const uint8_t* fg, uint8_t val, int* L, int H, int W, hipStre
 #else
     const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H;
     const int n_tiles = tiles_x * tiles_y;
-    hipLaunchKernelGGL(ccl_tile_kernel, dim3(n_tiles < 256 * 16 ? n_tiles : 256 * 16), dim3(256), 0, st, fg, val, L, H, W, tiles_x, n_tiles);
+    hipLaunchKernelGGL(ccl_tile_kernel<false>, dim3(n_tiles < 256 * 16 ? n_tiles : 256 * 16), dim3(256), 0, st, fg, val, L, H, W, tiles_x, n_tiles, (int*)nullptr,
+                       (int*)nullptr, (int*)nullptr);
     const long long seams = (long long)(tiles_x - 1) * H + (long long)(tiles_y - 1) * W;
     if (seams > 0) hipLaunchKernelGGL(ccl_seam_kernel, dim3(grid_for(seams)), dim3(256), 0, st, fg, val, L, H, W, tiles_x, tiles_y);
 #endif
@@ -378,8 +484,9 @@ static int ccl_run(const uint8_t* fg, uint8_t val, int* L, int H, int W, hipStre
 // roots under roots, so the nodes of the forest above the pixel level are exactly these: flattening the LIST (ccl2_flatten_roots_kernel) makes
 // L[L[p]] the set's root for every pixel p -- two loads, no pointer chase, no pass that walks 67 M background pixels up to one giant root.
 __global__ __launch_bounds__(256) void ccl2_tile_kernel(const uint8_t* __restrict__ fg, int* __restrict__ L, int H, int W, int tiles_x, int n_tiles,
-                                                        int* __restrict__ roots, int* __restrict__ n_roots) {
+                                                        int* __restrict__ roots, int* __restrict__ n_roots, int* __restrict__ area) {
     __shared__ int sl[CT_H * CT_W];
+    __shared__ int scnt[CT_H * CT_W];  // FOREGROUND pixels of every tile-local set (background sets stay at 0: ccl2_drop_small_kernel relies on it)
     __shared__ u64 sc[CT_H], sv[CT_H], ss[CT_H];  // per row: colour bits, valid bits, run starts
     __shared__ u64 srootm[CT_H];
     __shared__ int srow_off[CT_H];
@@ -395,6 +502,7 @@ __global__ __launch_bounds__(256) void ccl2_tile_kernel(const uint8_t* __restric
             const u64 c = __ballot(f), vm = __ballot(v);
             const u64 starts = ((c ^ (c << 1)) | 1ull) & vm;  // a run starts where the colour changes (pixels beyond the image sit at the right end only)
             sl[r * CT_W + lane] = v ? r * CT_W + 63 - __clzll((long long)(starts & ((2ull << lane) - 1))) : -1;
+            scnt[r * CT_W + lane] = 0;
             if (lane == 0) {
                 sc[r] = c;
                 sv[r] = vm;
@@ -419,6 +527,11 @@ __global__ __launch_bounds__(256) void ccl2_tile_kernel(const uint8_t* __restric
                 const int root = lds_find(sl, sl[r * CT_W + lane]);
                 L[(long long)y * W + x] = (ty0 + (root >> 6)) * W + tx0 + (root & 63);
                 is_root = root == r * CT_W + lane;
+                const u64 c = sc[r];
+                if (((c & ss[r]) >> lane) & 1ull) {  // first pixel of a foreground run: its length (the colour bits beyond the image are 0)
+                    const u64 rest = ~(c >> lane);
+                    atomicAdd(&scnt[root], rest ? __ffsll((long long)rest) - 1 : 64 - lane);
+                }
             }
             const u64 rm = __ballot(is_root);
             if (lane == 0) srootm[r] = rm;
@@ -443,7 +556,10 @@ __global__ __launch_bounds__(256) void ccl2_tile_kernel(const uint8_t* __restric
         for (int i = 0; i < 8; ++i) {
             const int r = wave * 8 + i, y = ty0 + r;
             const u64 rm = srootm[r];
-            if ((rm >> lane) & 1ull) roots[srow_off[r] + __popcll(rm & ((1ull << lane) - 1))] = y * W + x;
+            if ((rm >> lane) & 1ull) {
+                roots[srow_off[r] + __popcll(rm & ((1ull << lane) - 1))] = y * W + x;
+                area[(long long)y * W + x] = scnt[r * CT_W + lane];
+            }
         }
         __syncthreads();
     }
@@ -491,28 +607,13 @@ __global__ void ccl2_seam_kernel(const uint8_t* __restrict__ fg, int* L, int H, 
         if (a >= 0 && ra != rb && !(lane > 0 && pa == ra && pb == rb)) uf_union(L, ra, rb);
     }
 }
-// area[root] += run length for FOREGROUND runs (the background is a few huge sets: nothing is counted for them).  Needs flattened roots: root = L[L[p]].
-__global__ void ccl2_area_kernel(const int* __restrict__ L, const uint8_t* __restrict__ fg, int* __restrict__ area, int n) {
-    const int lane = threadIdx.x & 63;
-    for (long long base = (blockIdx.x * (long long)blockDim.x + threadIdx.x) - lane; base < n; base += (long long)gridDim.x * blockDim.x) {
-        const long long p = base + lane;
-        const int key = (p < n && fg[p]) ? L[L[p]] : -1;
-        const int prev = __shfl_up(key, 1);
-        const bool head = key >= 0 && (lane == 0 || prev != key);
-        const unsigned long long bounds = __ballot(head || key < 0);
-        if (head) {
-            const unsigned long long after = lane == 63 ? 0ull : (bounds >> (lane + 1));
-            atomicAdd(&area[key], after ? __ffsll((long long)after) : 64 - lane);
-        }
-    }
-}
 // foreground components below min_size turn into background and join the background sets around them
 __global__ void ccl2_drop_small_kernel(uint8_t* m, int* L, const int* __restrict__ area, int min_size, int H, int W) {
     const long long n = (long long)H * W;
     const double invW = 1.0 / (double)W;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
         if (!m[p]) continue;
-        const int r = L[L[p]];  // the component's root as ccl2_area_kernel saw it -- or, once this small component has been united away, a
+        const int r = L[L[p]];  // the component's root as the area merge saw it -- or, once this small component has been united away, a
         if (area[r] >= min_size) continue;  // background index, whose area is 0: "small" either way
         int y, x;
         pix_yx(p, W, invW, y, x);
@@ -558,24 +659,186 @@ __global__ void ccl2_final_kernel(int* L, const uint8_t* __restrict__ m, int n) 
     // (flattened roots: L[L[p]] is the root; a foreground node that other pixels still point at keeps the value it already holds)
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) L[p] = m[p] ? L[L[p]] : -1;
 }
-static int markers_two_colour(uint8_t* mrk, int* L, int* area, int* border, int* roots, int* n_roots, int min_size, int H, int W, hipStream_t st) {
+// the same, and bits[p >> 6] |= "p is the root of a marker" (whole waves step together: the ballot covers 64 consecutive pixels)
+__global__ void ccl2_final_bits_kernel(int* L, const uint8_t* __restrict__ m, int n, u64* __restrict__ bits) {
+    const int lane = threadIdx.x & 63;
+    for (long long base = (blockIdx.x * (long long)blockDim.x + threadIdx.x) - lane; base < n; base += (long long)gridDim.x * blockDim.x) {
+        const long long p = base + lane;
+        int r = -1;
+        if (p < n) {
+            r = m[p] ? L[L[p]] : -1;
+            L[p] = r;
+        }
+        const u64 b = __ballot(r == (int)p && p < n);
+        if (lane == 0) bits[base >> 6] = b;
+    }
+}
+// ---- four pixels per thread (see nuc_marker_out4_kernel for why) -------------------------------------------------
+// 16 consecutive lanes hold 64 consecutive pixels: their 4-bit root flags make one bitmap word (every lane of the wave calls this)
+__device__ __forceinline__ void store_root_bits4(u64* __restrict__ bits, long long q, long long nq, unsigned nib, int lane) {
+    u64 v = (u64)nib << (4 * (lane & 15));
+    v |= __shfl_xor(v, 1);
+    v |= __shfl_xor(v, 2);
+    v |= __shfl_xor(v, 4);
+    v |= __shfl_xor(v, 8);
+    if ((lane & 15) == 0 && q < nq) bits[q >> 4] = v;
+}
+__global__ void ccl2_drop_small4_kernel(uint32_t* m4, int4* L4, const int* __restrict__ area, int min_size, int H, int W) {
+    const long long nq = (long long)H * W / 4;
+    const int qw = W / 4;
+    const double invQ = 1.0 / (double)qw;
+    uint8_t* m = (uint8_t*)m4;
+    int* L = (int*)L4;
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < nq; q += (long long)gridDim.x * blockDim.x) {
+        const uint32_t mw = m4[q];
+        if (!mw) continue;
+        const int4 l = L4[q];
+        const int t[4] = {l.x, l.y, l.z, l.w};
+        int pt = -1;
+        bool small = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!((mw >> (8 * i)) & 0xffu)) continue;
+            if (t[i] != pt) {  // (pixels of one tile-local set share the decision; see ccl2_drop_small_kernel for the races that do not matter)
+                pt = t[i];
+                small = area[L[pt]] < min_size;
+            }
+            if (!small) continue;
+            int y, xq;
+            pix_yx(q, qw, invQ, y, xq);
+            const int x = xq * 4 + i;
+            const long long p = q * 4 + i;
+            m[p] = 0;
+            if (x > 0 && !m[p - 1]) uf_union(L, (int)p, (int)p - 1);
+            if (x < W - 1 && !m[p + 1]) uf_union(L, (int)p, (int)p + 1);
+            if (y > 0 && !m[p - W]) uf_union(L, (int)p, (int)(p - W));
+            if (y < H - 1 && !m[p + W]) uf_union(L, (int)p, (int)(p + W));
+        }
+    }
+}
+__global__ void ccl2_fill4_kernel(uint32_t* m4, int4* L4, const int* __restrict__ border, int H, int W) {
+    const long long nq = (long long)H * W / 4;
+    const int qw = W / 4;
+    const double invQ = 1.0 / (double)qw;
+    uint8_t* m = (uint8_t*)m4;
+    int* L = (int*)L4;
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < nq; q += (long long)gridDim.x * blockDim.x) {
+        const uint32_t mw = m4[q];
+        if (mw == 0x01010101u) continue;
+        const int4 l = L4[q];
+        const int t[4] = {l.x, l.y, l.z, l.w};
+        int pt = -1;
+        bool hole = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if ((mw >> (8 * i)) & 0xffu) continue;
+            if (t[i] != pt) {
+                pt = t[i];
+                hole = !border[uf_find(L, pt)];
+            }
+            if (!hole) continue;
+            int y, xq;
+            pix_yx(q, qw, invQ, y, xq);
+            const int x = xq * 4 + i;
+            const long long p = q * 4 + i;
+            m[p] = 1;
+            if (x > 0 && m[p - 1]) uf_union(L, (int)p, (int)p - 1);
+            if (x < W - 1 && m[p + 1]) uf_union(L, (int)p, (int)p + 1);
+            if (y > 0 && m[p - W]) uf_union(L, (int)p, (int)(p - W));
+            if (y < H - 1 && m[p + W]) uf_union(L, (int)p, (int)(p + W));
+        }
+    }
+}
+__global__ void ccl2_final_bits4_kernel(int4* L4, const uint32_t* __restrict__ m4, long long nq, u64* __restrict__ bits) {
+    const int lane = threadIdx.x & 63;
+    const int* L = (const int*)L4;
+    for (long long q0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) - lane; q0 < nq; q0 += (long long)gridDim.x * blockDim.x) {
+        const long long q = q0 + lane;
+        unsigned nib = 0;
+        if (q < nq) {
+            const uint32_t mw = m4[q];
+            int r[4] = {-1, -1, -1, -1};
+            if (mw) {
+                const int4 l = L4[q];
+                const int t[4] = {l.x, l.y, l.z, l.w};
+                int pt = -1, pr = -1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (!((mw >> (8 * i)) & 0xffu)) continue;
+                    if (t[i] != pt) {
+                        pt = t[i];
+                        pr = L[pt];
+                    }
+                    r[i] = pr;
+                    if (pr == (int)(q * 4 + i)) nib |= 1u << i;
+                }
+            }
+            L4[q] = make_int4(r[0], r[1], r[2], r[3]);
+        }
+        store_root_bits4(bits, q, nq, nib, lane);
+    }
+}
+// mask side: m = "the pixel's component has at least min_size pixels", L[p] <- its root (the list is flat: L[L[p]]), bitmap of the kept roots
+__global__ void apply_min_area_bits4_kernel(uint32_t* __restrict__ m4, int4* L4, const int* __restrict__ area, int min_size, long long nq, u64* __restrict__ bits) {
+    const int lane = threadIdx.x & 63;
+    const int* L = (const int*)L4;
+    for (long long q0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) - lane; q0 < nq; q0 += (long long)gridDim.x * blockDim.x) {
+        const long long q = q0 + lane;
+        unsigned nib = 0;
+        if (q < nq) {
+            const int4 l = L4[q];
+            uint32_t mw = 0;
+            if (l.x >= 0 || l.y >= 0 || l.z >= 0 || l.w >= 0) {
+                const int t[4] = {l.x, l.y, l.z, l.w};
+                int r[4] = {-1, -1, -1, -1};
+                int pt = -1, pr = -1;
+                bool keep = false;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (t[i] < 0) continue;
+                    if (t[i] != pt) {
+                        pt = t[i];
+                        pr = L[pt];
+                        keep = area[pr] >= min_size;
+                    }
+                    r[i] = pr;
+                    if (keep) {
+                        mw |= 1u << (8 * i);
+                        if (pr == (int)(q * 4 + i)) nib |= 1u << i;
+                    }
+                }
+                L4[q] = make_int4(r[0], r[1], r[2], r[3]);
+            }
+            m4[q] = mw;
+        }
+        store_root_bits4(bits, q, nq, nib, lane);
+    }
+}
+static int markers_two_colour(uint8_t* mrk, int* L, int* area, int* border, int* roots, int* n_roots, int min_size, int H, int W, hipStream_t st,
+                              u64* root_bits = nullptr, bool wide = false) {
     const int n = H * W;
     const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H, n_tiles = tiles_x * tiles_y;
     const unsigned g = grid_for(n);
-    if (hipMemsetAsync(area, 0, (size_t)n * 4, st) != hipSuccess || hipMemsetAsync(border, 0, (size_t)n * 4, st) != hipSuccess || hipMemsetAsync(n_roots, 0, 4, st) != hipSuccess)
-        return cerb_set_error("memset failed");
-    hipLaunchKernelGGL(ccl2_tile_kernel, dim3(n_tiles < 256 * 16 ? n_tiles : 256 * 16), dim3(256), 0, st, mrk, L, H, W, tiles_x, n_tiles, roots, n_roots);
+    // (area: written by the tile kernel at every tile-local root, read at roots only -- no zero fill)
+    if (hipMemsetAsync(border, 0, (size_t)n * 4, st) != hipSuccess || hipMemsetAsync(n_roots, 0, 4, st) != hipSuccess) return cerb_set_error("memset failed");
+    hipLaunchKernelGGL(ccl2_tile_kernel, dim3(n_tiles < 256 * 16 ? n_tiles : 256 * 16), dim3(256), 0, st, mrk, L, H, W, tiles_x, n_tiles, roots, n_roots, area);
     const long long seams = (long long)(tiles_x - 1) * H + (long long)(tiles_y - 1) * W;
     if (seams > 0) hipLaunchKernelGGL(ccl2_seam_kernel, dim3(grid_for(seams)), dim3(256), 0, st, mrk, L, H, W, tiles_x, tiles_y);
     auto flatten_roots = [&]() { hipLaunchKernelGGL(ccl2_flatten_roots_kernel, dim3(256 * 4), dim3(256), 0, st, L, (const int*)roots, (const int*)n_roots); };
     flatten_roots();
-    hipLaunchKernelGGL(ccl2_area_kernel, dim3(g), dim3(256), 0, st, (const int*)L, mrk, area, n);
-    hipLaunchKernelGGL(ccl2_drop_small_kernel, dim3(g), dim3(256), 0, st, mrk, L, area, min_size, H, W);
+    hipLaunchKernelGGL(roots_area_merge_kernel, dim3(256 * 4), dim3(256), 0, st, (const int*)L, (const int*)roots, (const int*)n_roots, area);
+    wide = wide && W % 4 == 0;
+    const unsigned g4 = grid_for(n / 4);
+    if (wide) hipLaunchKernelGGL(ccl2_drop_small4_kernel, dim3(g4), dim3(256), 0, st, (uint32_t*)mrk, (int4*)L, area, min_size, H, W);
+    else hipLaunchKernelGGL(ccl2_drop_small_kernel, dim3(g), dim3(256), 0, st, mrk, L, area, min_size, H, W);
     flatten_roots();
     hipLaunchKernelGGL(ccl2_mark_border_kernel, dim3(nblk(2 * (H + W), 256)), dim3(256), 0, st, mrk, L, border, H, W);
-    hipLaunchKernelGGL(ccl2_fill_kernel, dim3(g), dim3(256), 0, st, mrk, L, border, H, W);
+    if (wide) hipLaunchKernelGGL(ccl2_fill4_kernel, dim3(g4), dim3(256), 0, st, (uint32_t*)mrk, (int4*)L, border, H, W);
+    else hipLaunchKernelGGL(ccl2_fill_kernel, dim3(g), dim3(256), 0, st, mrk, L, border, H, W);
     flatten_roots();
-    hipLaunchKernelGGL(ccl2_final_kernel, dim3(g), dim3(256), 0, st, L, mrk, n);
+    if (root_bits && wide) hipLaunchKernelGGL(ccl2_final_bits4_kernel, dim3(g4), dim3(256), 0, st, (int4*)L, (const uint32_t*)mrk, (long long)n / 4, root_bits);
+    else if (root_bits) hipLaunchKernelGGL(ccl2_final_bits_kernel, dim3(g), dim3(256), 0, st, L, mrk, n, root_bits);
+    else hipLaunchKernelGGL(ccl2_final_kernel, dim3(g), dim3(256), 0, st, L, mrk, n);
     KCHECK();
     return 0;
 }
@@ -616,6 +879,85 @@ __global__ void nuc_marker_out_kernel(const int* __restrict__ L, const int* __re
         const int r = L[p];
         out[p] = (r >= 0 && mask[p]) ? rank[r] + (boff ? boff[r / SCAN_ITEMS] : 0) + 1 : 0;
     }
+}
+// the same from the root bitmap: label = 1 + number of roots before the pixel's root in raster order.
+// Also the smallest / largest marker label inside every mask component (lmin / lmax at the component's root LA[p]; roots_setup_kernel has initialised
+// them): one pair of atomics per RUN of equal (label, component) inside a wave, and only where a plain read does not already cover the label (the
+// extremes are monotone, a stale read costs an atomic, never a miss).  Taken over all labelled pixels this equals the extremes over the SEEDS (labelled
+// pixels with an unlabelled mask neighbour) in every component that has an unlabelled pixel at all: a marker none of whose pixels touches an unlabelled
+// mask pixel has only itself and non-mask around it, i.e. it IS its component.  Knowing them here lets ws_seed_kernel skip the single-label components.
+__global__ void nuc_marker_out_bits_kernel(const int* __restrict__ L, const u64* __restrict__ bits, const int* __restrict__ wpre, const int* __restrict__ boff,
+                                           const uint8_t* __restrict__ mask, int* __restrict__ out, int n, const int* __restrict__ LA, int* lmin, int* lmax) {
+    const int lane = threadIdx.x & 63;
+    for (long long base = (blockIdx.x * (long long)blockDim.x + threadIdx.x) - lane; base < n; base += (long long)gridDim.x * blockDim.x) {
+        const long long p = base + lane;
+        int v = 0, ra = -1;
+        if (p < n) {
+            const int r = L[p];
+            if (r >= 0 && mask[p]) {
+                const int w = r >> 6;
+                v = wpre[w] + (boff ? boff[w / SCAN_ITEMS] : 0) + __popcll(bits[w] & ((1ull << (r & 63)) - 1ull)) + 1;
+                ra = LA[p];
+            }
+            out[p] = v;
+        }
+        const int pv = __shfl_up(v, 1), pr = __shfl_up(ra, 1);
+        if (v > 0 && (lane == 0 || pv != v || pr != ra)) {
+            const volatile int* vmin = lmin + ra;
+            const volatile int* vmax = lmax + ra;
+            if (v < *vmin) atomicMin(lmin + ra, v);
+            if (v > *vmax) atomicMax(lmax + ra, v);
+        }
+    }
+}
+// Four pixels per thread (W % 4 == 0, 16-byte aligned maps).  The per-pixel passes of this file are LATENCY-bound, not bandwidth-bound: 8192 resident
+// waves x one dependent chain of 3 - 4 loads (~3 us under load) per 64 pixels = 0.3 - 0.5 ms per pass over 67 Mpx, whatever the bytes.  One 16-byte load
+// per map and thread instead of four dword loads quarters the chains per pixel, and the common case (background) ends after the first load.
+__global__ void nuc_marker_out4_kernel(const int4* __restrict__ L4, const u64* __restrict__ bits, const int* __restrict__ wpre, const int* __restrict__ boff,
+                                       const uint32_t* __restrict__ mask4, int4* __restrict__ out4, long long nq, const int4* __restrict__ LA4, int* lmin,
+                                       int* lmax) {
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < nq; q += (long long)gridDim.x * blockDim.x) {
+        const uint32_t m = mask4[q];
+        if (!m) {
+            out4[q] = make_int4(0, 0, 0, 0);
+            continue;
+        }
+        const int4 l = L4[q];
+        const int r[4] = {l.x, l.y, l.z, l.w};
+        int v[4];
+        int pr = -1, pv = 0;
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = 0;
+            if (r[i] >= 0 && ((m >> (8 * i)) & 0xffu)) {
+                if (r[i] != pr) {
+                    const int w = r[i] >> 6;
+                    pv = wpre[w] + (boff ? boff[w / SCAN_ITEMS] : 0) + __popcll(bits[w] & ((1ull << (r[i] & 63)) - 1ull)) + 1;
+                    pr = r[i];
+                }
+                v[i] = pv;
+                any = true;
+            }
+        }
+        out4[q] = make_int4(v[0], v[1], v[2], v[3]);
+        if (!any) continue;
+        const int4 a = LA4[q];
+        const int ra[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (v[i] > 0 && (i == 0 || v[i] != v[i - 1] || ra[i] != ra[i - 1])) {
+                const volatile int* vmin = lmin + ra[i];
+                const volatile int* vmax = lmax + ra[i];
+                if (v[i] < *vmin) atomicMin(lmin + ra[i], v[i]);
+                if (v[i] > *vmax) atomicMax(lmax + ra[i], v[i]);
+            }
+    }
+}
+__global__ void count_roots_from_bits_kernel(const u64* __restrict__ bits, const int* __restrict__ wpre, const int* __restrict__ boff, int nw, int* __restrict__ out,
+                                             const int* __restrict__ any) {
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        *out = (any && !*any) ? -1 : (nw > 0 ? wpre[nw - 1] + (boff ? boff[(nw - 1) / SCAN_ITEMS] : 0) + __popcll(bits[nw - 1]) : 0);
 }
 __global__ void count_roots_from_scan_kernel(const int* __restrict__ L, const int* __restrict__ rank, const int* __restrict__ boff, int n, int* __restrict__ out,
                                              const int* __restrict__ any) {
@@ -727,6 +1069,23 @@ __global__ void apply_min_area_kernel(uint8_t* __restrict__ m, const int* __rest
         m[p] = (r >= 0 && area[r] >= min_size) ? 1 : 0;
     }
 }
+// the same, and bits[p >> 6] |= "p is the root of a kept component"
+__global__ void apply_min_area_bits_kernel(uint8_t* __restrict__ m, const int* __restrict__ L, const int* __restrict__ area, int min_size, int n,
+                                           u64* __restrict__ bits) {
+    const int lane = threadIdx.x & 63;
+    for (long long base = (blockIdx.x * (long long)blockDim.x + threadIdx.x) - lane; base < n; base += (long long)gridDim.x * blockDim.x) {
+        const long long p = base + lane;
+        bool root = false;
+        if (p < n) {
+            const int r = L[p];
+            const bool keep = r >= 0 && area[r] >= min_size;
+            m[p] = keep ? 1 : 0;
+            root = keep && r == (int)p;
+        }
+        const u64 b = __ballot(root);
+        if (lane == 0) bits[base >> 6] = b;
+    }
+}
 // border[root] = 1 for background components touching the border of the H x W domain
 __global__ void mark_border_kernel(const int* __restrict__ L, int* __restrict__ border, int H, int W) {
     const int per = 2 * (H + W);
@@ -777,7 +1136,9 @@ __global__ void ws_cap_kernel(const int* __restrict__ L, const int* __restrict__
 __global__ void ws_seed_kernel(const float* __restrict__ inst, long long row_stride, int pix_stride, const uint8_t* __restrict__ mask,
                                const int* __restrict__ out, const int* __restrict__ L, const int* __restrict__ hoff, int* __restrict__ hcnt,
                                u64* __restrict__ hkey, u32* __restrict__ hidx, int H, int W, int* __restrict__ unl, int* __restrict__ lmin,
-                               int* __restrict__ lmax) {
+                               int* __restrict__ lmax, int known) {
+    // known: lmin / lmax are final already (nuc_marker_out_bits_kernel): components whose markers carry ONE label never reach a flood
+    // (ws_fill_single_kernel paints them), so neither their seeds nor their floodable-pixel counts are wanted -- isolated nuclei issue no atomic here
     const long long n = (long long)H * W;
     const double invW = 1.0 / (double)W;
     const int lane = threadIdx.x & 63;
@@ -791,7 +1152,7 @@ __global__ void ws_seed_kernel(const float* __restrict__ inst, long long row_str
         const int prev = __shfl_up(key, 1);
         const bool head = key >= 0 && (lane == 0 || prev != key);
         const unsigned long long bounds = __ballot(head || key < 0);
-        if (head) {
+        if (head && (!known || lmin[key] < lmax[key])) {
             const unsigned long long after = lane == 63 ? 0ull : (bounds >> (lane + 1));
             const int run = after ? __ffsll((long long)after) : 64 - lane;
             atomicAdd(&unl[key], run);
@@ -806,8 +1167,12 @@ __global__ void ws_seed_kernel(const float* __restrict__ inst, long long row_str
         if (y < H - 1 && mask[p + W] && !out[p + W]) active = true;
         if (!active) continue;
         const int root = L[p];
-        atomicMin(&lmin[root], out[p]);
-        atomicMax(&lmax[root], out[p]);
+        if (known) {
+            if (lmin[root] >= lmax[root]) continue;
+        } else {
+            atomicMin(&lmin[root], out[p]);
+            atomicMax(&lmax[root], out[p]);
+        }
         const int slot = hoff[root] + atomicAdd(&hcnt[root], 1);
         const float v = -inst[y * row_stride + (long long)x * pix_stride];  // watershed(-inst_inner_raw, ...)
         hkey[slot] = ((u64)order_key(v) << 32);  // age 0
@@ -831,11 +1196,12 @@ __global__ void ws_bbox_kernel(const int* __restrict__ L, const uint8_t* __restr
     const double invW = 1.0 / (double)W;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
         if (!mask[p]) continue;
-        const int root = L[p];
-        if (lmin[root] >= lmax[root]) continue;
         int y, x;
         pix_yx(p, W, invW, y, x);
+        // (outline test first: its loads are neighbours of the pixel's own; the per-root gathers are then paid by ~1 mask pixel in 6)
         if (y > 0 && y < H - 1 && x > 0 && x < W - 1 && mask[p - W] && mask[p + W] && mask[p - 1] && mask[p + 1]) continue;
+        const int root = L[p];
+        if (lmin[root] >= lmax[root]) continue;
         CBox* b = bb + root;
         const volatile CBox* vb = b;  // monotone extremes: skip the atomic when a plain read already covers the pixel
         if (y < vb->y1) atomicMin(&b->y1, y);
@@ -843,6 +1209,128 @@ __global__ void ws_bbox_kernel(const int* __restrict__ L, const uint8_t* __restr
         if (x < vb->x1) atomicMin(&b->x1, x);
         if (x > vb->x2) atomicMax(&b->x2, x);
     }
+}
+// floodable = in the mask and unlabelled; a seed = labelled with a floodable 4-neighbour
+__device__ __forceinline__ uint32_t floodable4(uint32_t m, const int4& o) {  // byte i = 1 when pixel i is in the mask and unlabelled
+    return m & ((o.x ? 0u : 1u) | (o.y ? 0u : 0x100u) | (o.z ? 0u : 0x10000u) | (o.w ? 0u : 0x1000000u));
+}
+// ONE pass for the seeds, the floodable-pixel counts and the boxes (round 5): all three want the same neighbourhood of a mask pixel, and the passes are
+// latency-bound -- a second kernel costs its whole chain of dependent loads again (0.34 ms for the boxes alone), a few more loads in the same level of an
+// existing chain cost next to nothing.  Level 1: the mask word; level 2 (threads inside the mask, 1 in 5): start map, component roots and mask words of
+// the neighbourhood; level 3: the label extremes of the roots met.  Box atomics per RUN of lanes that hold outline pixels of one component in one row (the
+// run's first lane carries the row and the smallest column, its last lane the largest column).
+__global__ void ws_seed_bbox4_kernel(const float* __restrict__ inst, long long row_stride, int pix_stride, const uint32_t* __restrict__ mask4,
+                                     const int4* __restrict__ out4, const int4* __restrict__ L4, const int* __restrict__ hoff, int* __restrict__ hcnt,
+                                     u64* __restrict__ hkey, u32* __restrict__ hidx, int H, int W, int* __restrict__ unl, const int* __restrict__ lmin,
+                                     const int* __restrict__ lmax, CBox* bb) {
+    const long long nq = (long long)H * W / 4;
+    const int qw = W / 4;
+    const double invQ = 1.0 / (double)qw;
+    const uint8_t* mask = (const uint8_t*)mask4;
+    const int* out = (const int*)out4;
+    const int lane = threadIdx.x & 63;
+    for (long long q0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) - lane; q0 < nq; q0 += (long long)gridDim.x * blockDim.x) {
+        const long long q = q0 + lane;
+        int key = -1, y = 0, xa = 0, xb = 0;  // this thread's outline pixels of a flooded component (box run)
+        const uint32_t m = q < nq ? mask4[q] : 0u;
+        if (m) {  // (a label outside the mask does not exist: the start map is mask ? marker : 0)
+            int xq;
+            pix_yx(q, qw, invQ, y, xq);
+            const bool up = y > 0, down = y < H - 1, lft = xq > 0, rgt = xq < qw - 1;
+            const int4 o = out4[q];
+            const int4 l = L4[q];
+            const uint32_t mu = up ? mask4[q - qw] : 0u, md = down ? mask4[q + qw] : 0u;
+            const uint32_t ml = lft ? mask4[q - 1] : 0u, mr = rgt ? mask4[q + 1] : 0u;
+            const int root[4] = {l.x, l.y, l.z, l.w};
+            const uint32_t f = floodable4(m, o);
+            const uint32_t lab = m & ~f;  // bytes are 0 / 1
+            // multi[i]: pixel i belongs to a component whose markers carry more than one label (the only ones that reach a flood)
+            bool multi[4];
+            {
+                int pr = -1;
+                bool pm = false;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    multi[i] = false;
+                    if (!((m >> (8 * i)) & 1u)) continue;
+                    if (root[i] != pr) {
+                        pr = root[i];
+                        pm = lmin[pr] < lmax[pr];
+                    }
+                    multi[i] = pm;
+                }
+            }
+            if (multi[0] || multi[1] || multi[2] || multi[3]) {
+                // floodable pixels, counted per run of equal roots inside the thread
+                int i = 0;
+                while (i < 4) {
+                    if (!((f >> (8 * i)) & 1u) || !multi[i]) {
+                        ++i;
+                        continue;
+                    }
+                    int j = i + 1;
+                    while (j < 4 && ((f >> (8 * j)) & 1u) && root[j] == root[i]) ++j;
+                    atomicAdd(&unl[root[i]], j - i);
+                    i = j;
+                }
+                // outline = mask minus its cross erosion (the image border counts as outside)
+                uint32_t v = m & mu & md;
+                v &= (m << 8) | (ml >> 24);
+                v &= (m >> 8) | (mr << 24);
+                const uint32_t outline = m & ~v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (!((outline >> (8 * k)) & 1u) || !multi[k]) continue;
+                    const int x = xq * 4 + k;
+                    if (key < 0) {
+                        key = root[k];
+                        xa = xb = x;
+                    } else if (root[k] == key) {
+                        xb = x;
+                    } else {  // a second component inside one thread's four pixels: on its own
+                        CBox* b = bb + root[k];
+                        const volatile CBox* vb = b;
+                        if (y < vb->y1) atomicMin(&b->y1, y);
+                        if (y > vb->y2) atomicMax(&b->y2, y);
+                        if (x < vb->x1) atomicMin(&b->x1, x);
+                        if (x > vb->x2) atomicMax(&b->x2, x);
+                    }
+                }
+                // seeds: labelled pixels with a floodable 4-neighbour
+                if (lab) {
+                    uint32_t nb = (f << 8) | (f >> 8);  // left / right neighbours inside the word
+                    if (mu) nb |= floodable4(mu, out4[q - qw]);
+                    if (md) nb |= floodable4(md, out4[q + qw]);
+                    const long long p0 = q * 4;
+                    if ((lab & 1u) && (ml >> 24) && !out[p0 - 1]) nb |= 1u;
+                    if ((lab & 0x1000000u) && (mr & 0xffu) && !out[p0 + 4]) nb |= 0x1000000u;
+                    const uint32_t act = lab & nb;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (!((act >> (8 * k)) & 1u) || !multi[k]) continue;
+                        const int r = root[k];
+                        const int slot = hoff[r] + atomicAdd(&hcnt[r], 1);
+                        const float val = -inst[y * row_stride + (long long)(xq * 4 + k) * pix_stride];  // watershed(-inst_inner_raw, ...)
+                        hkey[slot] = ((u64)order_key(val) << 32);  // age 0
+                        hidx[slot] = (u32)(p0 + k) | WS_UNC32;     // every seed's pop position among equal-valued seeds is skimage's heap layout's choice
+                    }
+                }
+            }
+        }
+        const int pk = __shfl_up(key, 1), py = __shfl_up(y, 1), nk = __shfl_down(key, 1), ny = __shfl_down(y, 1);
+        if (key >= 0) {
+            CBox* b = bb + key;
+            const volatile CBox* vb = b;
+            if (lane == 0 || pk != key || py != y) {
+                if (y < vb->y1) atomicMin(&b->y1, y);
+                if (y > vb->y2) atomicMax(&b->y2, y);
+                if (xa < vb->x1) atomicMin(&b->x1, xa);
+            }
+            if (lane == 63 || nk != key || ny != y)
+                if (xb > vb->x2) atomicMax(&b->x2, xb);
+        }
+    }
+    (void)mask;
 }
 // Compact lists of component roots that own at least one seed, in three tiers:
 //   window tier : bounding box (+1 px ring) fits WS_WIN_CAP pixels and area <= WS_LDS_CAP -> whole flood in LDS   (front of wl)
@@ -915,6 +1403,63 @@ __global__ void ws_worklist_kernel(const int* __restrict__ hcnt, const int* __re
             else if (need <= WS_BIGHEAP_CAP && win <= WS_BIGWIN_CAP) wl3[atomicAdd(counts + 3, 1)] = (int)p;
             else if (area[p] <= WS_LDS_CAP) wl2[atomicAdd(counts + 1, 1)] = (int)p;
             else wl[n - 1 - atomicAdd(counts + 2, 1)] = (int)p;
+        }
+}
+
+// Per-component setup over the root bitmap (one thread per 64-pixel word): counters, label extremes, box, and the heap offset -- any disjoint
+// partition of the heap arrays will do (the floods address their heap as hoff[root] + i), so a block adds the areas of its roots up and takes its
+// range with ONE atomic; the exclusive scan over the pixel map (scan_block_cap_kernel + two small scans + a whole-map add) is not needed.
+__global__ __launch_bounds__(256) void roots_setup_kernel(const u64* __restrict__ bits, int nw, const int* __restrict__ area, int* __restrict__ hoff,
+                                                          int* __restrict__ hcnt, int* __restrict__ unl, int* __restrict__ lmin, int* __restrict__ lmax,
+                                                          CBox* __restrict__ bb, int H, int W, int* __restrict__ total) {
+    __shared__ int wsum[4];
+    __shared__ int bbase;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w = blockIdx.x * 256 + tid;
+    const u64 word = w < nw ? bits[w] : 0ull;
+    int tsum = 0;
+    for (u64 b = word; b; b &= b - 1) tsum += area[(long long)w * 64 + (__ffsll((long long)b) - 1)];
+    int inc = tsum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    if (tid == 0) {
+        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        bbase = tot ? atomicAdd(total, tot) : 0;
+    }
+    __syncthreads();
+    int run = bbase + inc - tsum;
+    for (int k = 0; k < wave; ++k) run += wsum[k];
+    for (u64 b = word; b; b &= b - 1) {
+        const long long j = (long long)w * 64 + (__ffsll((long long)b) - 1);
+        hoff[j] = run;
+        run += area[j];
+        hcnt[j] = 0;
+        unl[j] = 0;
+        lmin[j] = 0x7f7f7f7f;
+        lmax[j] = 0;
+        bb[j] = CBox{H, -1, W, -1};
+    }
+}
+__global__ void ws_worklist_bits_kernel(const u64* __restrict__ bits, int nw, const int* __restrict__ hcnt, const int* __restrict__ area,
+                                        const int* __restrict__ unl, const CBox* __restrict__ bb, const int* __restrict__ lmin, const int* __restrict__ lmax,
+                                        int* __restrict__ wl, int* __restrict__ wl2, int* __restrict__ wl3, int* __restrict__ wl4, int* __restrict__ counts, int n) {
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += gridDim.x * blockDim.x)
+        for (u64 bw = bits[w]; bw; bw &= bw - 1) {
+            const int p = w * 64 + (__ffsll((long long)bw) - 1);
+            if (!(hcnt[p] > 0 && lmin[p] != lmax[p])) continue;
+            const CBox b = bb[p];
+            const long long win = (long long)(b.y2 - b.y1 + 3) * (b.x2 - b.x1 + 3);
+            const int need = hcnt[p] + unl[p];
+            if (need <= WS_TINY_CAP && win <= WS_TINY_WIN) wl4[atomicAdd(counts + 4, 1)] = p;
+            else if (need <= WS_LDS_CAP && win <= WS_WIN_CAP) wl[atomicAdd(counts + 0, 1)] = p;
+            else if (need <= WS_BIGHEAP_CAP && win <= WS_BIGWIN_CAP) wl3[atomicAdd(counts + 3, 1)] = p;
+            else if (area[p] <= WS_LDS_CAP) wl2[atomicAdd(counts + 1, 1)] = p;
+            else wl[n - 1 - atomicAdd(counts + 2, 1)] = p;
         }
 }
 
@@ -1867,9 +2412,15 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
     int* scantmp = (int*)cv.take((size_t)(n / SCAN_ITEMS + 4096) * 4 * 2);
     int* wl4 = (int*)cv.take((size_t)n * 4);    // tiny-window tier list
     int* lmax = (int*)cv.take((size_t)n * 4);   // per mask component: largest seed label (smallest one lives in LB once the markers are final)
-    int* small = (int*)cv.take(256);  // [0]=any [1]=worklist count [2]=n_inst scratch [3]=ambiguous scratch
+    const int nw = (n + 63) / 64;               // root bitmaps: one bit per pixel
+    u64* bitsA = (u64*)cv.take((size_t)nw * 8); // kept mask components
+    u64* bitsB = (u64*)cv.take((size_t)nw * 8); // final markers
+    int* wpre = (int*)cv.take((size_t)nw * 4);  // roots before a bitmap word
+    int* lminbuf = (int*)cv.take((size_t)n * 4); // per mask component: smallest marker label (written while LB is still read)
+    int* small = (int*)cv.take(256);  // [0]=any [1]=worklist count [2]=n_inst scratch [3]=ambiguous scratch [4]=two-colour root list [8..12]=tier counts [16]=heap total
     if (!small) return cerb_set_error("cerb_postproc_nuclei: workspace carve failed");
     const unsigned g = grid_for(n);
+    static const bool pixel_scans = getenv("CERB_PP_PIXEL_SCANS") != nullptr;  // developer A/B: round 4's whole-map scans instead of the root bitmaps
 
     PP_OK(hipMemsetAsync(small, 0, 256, st));
     // (A) mask: erode -> label -> drop components < 8 px   (postproc.py:365-368)
@@ -1885,14 +2436,31 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
         hipLaunchKernelGGL(nuc_threshold_kernel, dim3(g), dim3(256), 0, st, inst, row_stride, pix_stride, H, W, msk0, mrk, small);
         hipLaunchKernelGGL(erode_cross_kernel, dim3(g), dim3(256), 0, st, msk0, msk, H, W);
     }
-    PP_OK(hipMemsetAsync(areaA, 0, (size_t)n * 4, st));
-    if (ccl_run(msk, 1, LA, H, W, st, areaA)) return 1;
-    hipLaunchKernelGGL(apply_min_area_kernel, dim3(g), dim3(256), 0, st, msk, LA, areaA, 8, n);
+    static const bool narrow = getenv("CERB_PP_ONE_PIXEL_THREADS") != nullptr;  // developer A/B: the one-pixel-per-thread passes
+    const bool wide = !pixel_scans && !narrow && W % 4 == 0 && (uintptr_t)labels_out % 16 == 0;  // (the workspace arrays are 256-byte aligned)
+    if (wide) {  // tile labelling with the root list + per-set counts, flatten and areas over the LIST, then one pass: min-area, root of every pixel, bitmap
+        int* rootsA = hoff;       // free until roots_setup_kernel
+        int* n_rootsA = small + 20;
+        const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H, n_tiles = tiles_x * tiles_y;
+        hipLaunchKernelGGL(ccl_tile_kernel<true>, dim3(n_tiles < 256 * 16 ? n_tiles : 256 * 16), dim3(256), 0, st, (const uint8_t*)msk, (uint8_t)1, LA, H, W, tiles_x, n_tiles,
+                           rootsA, n_rootsA, areaA);
+        const long long seams = (long long)(tiles_x - 1) * H + (long long)(tiles_y - 1) * W;
+        if (seams > 0) hipLaunchKernelGGL(ccl_seam_kernel, dim3(grid_for(seams)), dim3(256), 0, st, (const uint8_t*)msk, (uint8_t)1, LA, H, W, tiles_x, tiles_y);
+        hipLaunchKernelGGL(ccl2_flatten_roots_kernel, dim3(256 * 4), dim3(256), 0, st, LA, (const int*)rootsA, (const int*)n_rootsA);
+        hipLaunchKernelGGL(roots_area_merge_kernel, dim3(256 * 4), dim3(256), 0, st, (const int*)LA, (const int*)rootsA, (const int*)n_rootsA, areaA);
+        hipLaunchKernelGGL(apply_min_area_bits4_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, (uint32_t*)msk, (int4*)LA, (const int*)areaA, 8, (long long)n / 4, bitsA);
+        KCHECK();
+    } else {
+        PP_OK(hipMemsetAsync(areaA, 0, (size_t)n * 4, st));
+        if (ccl_run(msk, 1, LA, H, W, st, areaA)) return 1;
+        if (pixel_scans) hipLaunchKernelGGL(apply_min_area_kernel, dim3(g), dim3(256), 0, st, msk, LA, areaA, 8, n);
+        else hipLaunchKernelGGL(apply_min_area_bits_kernel, dim3(g), dim3(256), 0, st, msk, LA, areaA, 8, n, bitsA);
+    }
     // (B) markers: inner > 0.5 -> label -> drop < 4 px -> fill holes -> label (postproc.py:370-377)
     static const bool three_pass = getenv("CERB_PP_THREE_LABELLINGS") != nullptr;  // developer A/B: round 4's three separate labellings
     if (!three_pass) {
         // (rank: free until the scan below, serves as the border flags; marker: free until the flood work lists, holds the root list)
-        if (markers_two_colour(mrk, LB, areaB, rank, marker, small + 4, 4, H, W, st)) return 1;
+        if (markers_two_colour(mrk, LB, areaB, rank, marker, small + 4, 4, H, W, st, pixel_scans ? nullptr : bitsB, wide)) return 1;
     } else {
         PP_OK(hipMemsetAsync(areaB, 0, (size_t)n * 4, st));
         if (ccl_run(mrk, 1, LB, H, W, st, areaB)) return 1;
@@ -1905,14 +2473,30 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
     }
     // marker ids = 1 + rank of the component's root among all roots (scipy's label order), written straight into the watershed's start map
     const int* boff = nullptr;
-    if (scan_exclusive(LB, rank, n, scantmp, st, true, &boff)) return 1;
-    if (n_inst_out) hipLaunchKernelGGL(count_roots_from_scan_kernel, dim3(1), dim3(1), 0, st, LB, rank, boff, n, n_inst_out, small);
-    // (C) watershed(-inner, marker, mask)   (postproc.py:378)
-    hipLaunchKernelGGL(nuc_marker_out_kernel, dim3(g), dim3(256), 0, st, LB, rank, boff, msk, labels_out, n);
+    const bool bitmaps = !pixel_scans && !three_pass;
     int* unl = areaB;  // free again: per-root count of unlabelled mask pixels
     int* wl3 = marker; // big-window tier list
-    int* lmin = LB;    // free after nuc_marker_out_kernel
-    {   // heap offsets = exclusive scan of the kept components' areas at their roots; the same pass initialises the per-root state
+    int* lmin = bitmaps ? lminbuf : LB;  // (LB: free after nuc_marker_out_kernel)
+    if (!pixel_scans && bitmaps) {  // per-component state and heap ranges from the root bitmap, before the pass that fills in the label extremes
+        hipLaunchKernelGGL(roots_setup_kernel, dim3(nblk(nw, 256)), dim3(256), 0, st, bitsA, nw, areaA, hoff, hcnt, unl, lmin, lmax, cbox, H, W, small + 16);
+        KCHECK();
+    }
+    if (bitmaps) {
+        if (scan_exclusive_popc(bitsB, wpre, nw, scantmp, st, &boff)) return 1;
+        if (n_inst_out) hipLaunchKernelGGL(count_roots_from_bits_kernel, dim3(1), dim3(1), 0, st, bitsB, wpre, boff, nw, n_inst_out, small);
+        // (C) watershed(-inner, marker, mask)   (postproc.py:378)
+        if (wide && bitmaps) hipLaunchKernelGGL(nuc_marker_out4_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, (const int4*)LB, bitsB, wpre, boff, (const uint32_t*)msk, (int4*)labels_out,
+                                     (long long)n / 4, (const int4*)LA, lmin, lmax);
+        else hipLaunchKernelGGL(nuc_marker_out_bits_kernel, dim3(g), dim3(256), 0, st, LB, bitsB, wpre, boff, msk, labels_out, n, LA, lmin, lmax);
+    } else {
+        if (scan_exclusive(LB, rank, n, scantmp, st, true, &boff)) return 1;
+        if (n_inst_out) hipLaunchKernelGGL(count_roots_from_scan_kernel, dim3(1), dim3(1), 0, st, LB, rank, boff, n, n_inst_out, small);
+        hipLaunchKernelGGL(nuc_marker_out_kernel, dim3(g), dim3(256), 0, st, LB, rank, boff, msk, labels_out, n);
+    }
+    if (!pixel_scans && !bitmaps) {  // (three separate labellings: the markers' L doubles as lmin, so the setup has to follow the start-map pass)
+        hipLaunchKernelGGL(roots_setup_kernel, dim3(nblk(nw, 256)), dim3(256), 0, st, bitsA, nw, areaA, hoff, hcnt, unl, lmin, lmax, cbox, H, W, small + 16);
+        KCHECK();
+    } else if (pixel_scans) {   // heap offsets = exclusive scan of the kept components' areas at their roots; the same pass initialises the per-root state
         const int nbk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
         hipLaunchKernelGGL(scan_block_cap_kernel, dim3(nbk), dim3(256), 0, st, LA, areaA, msk, hoff, nbk > 1 ? scantmp : (int*)nullptr, n, hcnt, unl, lmin, lmax, cbox, H, W);
         KCHECK();
@@ -1922,11 +2506,17 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
             KCHECK();
         }
     }
-    hipLaunchKernelGGL(ws_seed_kernel, dim3(g), dim3(256), 0, st, inst, row_stride, pix_stride, msk, labels_out, LA, hoff, hcnt, hkey, hidx, H, W, unl,
-                       lmin, lmax);
-    hipLaunchKernelGGL(ws_bbox_kernel, dim3(g), dim3(256), 0, st, LA, msk, cbox, H, W, lmin, lmax);
+    if (wide && bitmaps) {
+        hipLaunchKernelGGL(ws_seed_bbox4_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, inst, row_stride, pix_stride, (const uint32_t*)msk, (const int4*)labels_out,
+                           (const int4*)LA, hoff, hcnt, hkey, hidx, H, W, unl, lmin, lmax, cbox);
+    } else {
+        hipLaunchKernelGGL(ws_seed_kernel, dim3(g), dim3(256), 0, st, inst, row_stride, pix_stride, msk, labels_out, LA, hoff, hcnt, hkey, hidx, H, W, unl,
+                           lmin, lmax, bitmaps ? 1 : 0);
+        hipLaunchKernelGGL(ws_bbox_kernel, dim3(g), dim3(256), 0, st, LA, msk, cbox, H, W, lmin, lmax);
+    }
     int* counts = small + 8;  // [0] window tier, [1] LDS-heap tier, [2] global tier
-    hipLaunchKernelGGL(ws_worklist_kernel, dim3(g), dim3(256), 0, st, hcnt, areaA, unl, cbox, lmin, lmax, wl, rank, wl3, wl4, counts, n, LA, msk);
+    if (pixel_scans) hipLaunchKernelGGL(ws_worklist_kernel, dim3(g), dim3(256), 0, st, hcnt, areaA, unl, cbox, lmin, lmax, wl, rank, wl3, wl4, counts, n, LA, msk);
+    else hipLaunchKernelGGL(ws_worklist_bits_kernel, dim3(nblk(nw, 256) < 4096 ? nblk(nw, 256) : 4096), dim3(256), 0, st, bitsA, nw, hcnt, areaA, unl, cbox, lmin, lmax, wl, rank, wl3, wl4, counts, n);
     {
         auto k_tiny = ws_flood_window_kernel<WS_TINY_WIN, WS_TINY_CAP, 4>;
         auto k_small = ws_flood_window_kernel<WS_WIN_CAP, WS_LDS_CAP, 2>;
