@@ -6,7 +6,7 @@
 #   r05_bench_train_kernel_stats.txt    of `bench.py --mode train` (+ the line it printed: r05_bench_train_under_rocprof.json)
 #   r05_train_pmc_hbm.json              FETCH_SIZE / WRITE_SIZE per kernel and STEP of the training leg (bench.py reads it as `traffic`)
 #   r05_sq_counters.txt                 SQ_INSTS_MFMA, SQ_VALU_MFMA_BUSY_CYCLES, SQ_WAIT_INST_ANY, TCP / TCC counters for the inference and training kernels
-#   r05_postproc_nuclei_8192_kernel_stats.txt
+#   r05_postproc_nuclei_8192_kernel_stats.txt, ..._pmc_hbm.json (FETCH_SIZE / WRITE_SIZE per kernel), ..._timeline.txt (dispatches of one call)
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_r05
@@ -41,6 +41,13 @@ for SET in "$SQ1" "$SQ2" "$SQ3"; do
 done
 timeout -k 5 200 rocprofv3 --kernel-trace --stats -d $OUT/pstats -o p -- python scripts/dev_pp_nuclei_only.py 8192 > $OUT/pp_nuclei.log 2>&1
 python scripts/rocprof_summary.py stats "$(find $OUT/pstats -name '*.db' | head -1)" $OUT/r05_postproc_nuclei_8192_kernel_stats.txt
+# nuclei labelling, HBM counters per kernel (4 calls per run) + the dispatches of one call in order
+timeout -k 5 200 rocprofv3 --pmc FETCH_SIZE -d $OUT/pfetch -o f -- python scripts/dev_pp_nuclei_only.py 8192 > $OUT/pfetch.log 2>&1
+timeout -k 5 200 rocprofv3 --pmc WRITE_SIZE -d $OUT/pwrite -o w -- python scripts/dev_pp_nuclei_only.py 8192 > $OUT/pwrite.log 2>&1
+python scripts/rocprof_summary.py pmc "$(find $OUT/pfetch -name '*.db' | head -1)" "$(find $OUT/pwrite -name '*.db' | head -1)" $OUT/r05_postproc_nuclei_8192_pmc_hbm.json
+timeout -k 5 200 rocprofv3 --kernel-trace -d $OUT/ptrace -o p -- python scripts/dev_pp_nuclei_only.py 8192 > $OUT/ptrace.log 2>&1
+python scripts/rocprof_summary.py timeline "$(find $OUT/ptrace -name '*.db' | head -1)" nuc_threshold $OUT/r05_postproc_nuclei_8192_timeline.txt
+rm -rf $OUT/pfetch $OUT/pwrite $OUT/ptrace
 rm -rf $OUT/stats $OUT/bstats $OUT/fetch $OUT/write $OUT/tstats $OUT/pstats $OUT/tfetch $OUT/twrite $OUT/sqb1 $OUT/sqb2 $OUT/sqb3 $OUT/sqt1 $OUT/sqt2 $OUT/sqt3
 head -24 $OUT/r05_batch32_kernel_stats.txt
 head -30 $OUT/r05_bench_train_kernel_stats.txt | cut -c1-150
