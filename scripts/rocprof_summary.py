@@ -109,6 +109,30 @@ def timeline(db, first, out):
     print("wrote", out)
 
 
+def fills(db, first, out):
+    """The fillBuffer / copyBuffer dispatches of the last step (from the last kernel whose name contains `first`): how many, how long, and which
+    kernel follows each -- finds the zero fills a step still issues and whose they are."""
+    import collections
+
+    c = sqlite3.connect(db)
+    rows = list(c.execute("select name, start, end, grid_x from kernels order by start"))
+    idx = [i for i, r in enumerate(rows) if first in r[0]]
+    rows = rows[idx[-1]:]
+    cnt, tot, grid = collections.Counter(), collections.Counter(), collections.Counter()
+    for i, r in enumerate(rows):
+        if "fillBuffer" in r[0] or "copyBuffer" in r[0]:
+            k = (r[0][13:24], rows[i + 1][0][:70] if i + 1 < len(rows) else "")
+            cnt[k] += 1
+            tot[k] += (r[2] - r[1]) / 1e3
+            grid[k] += r[3]
+    with open(out, "w") as f:
+        f.write("# fills / copies of the last step (%d dispatches, %.1f ms wall): count, total us, mean grid_x, kind, the kernel that follows\n" % (len(rows), (rows[-1][2] - rows[0][1]) / 1e6))
+        for k, v in sorted(cnt.items(), key=lambda kv: -tot[kv[0]]):
+            f.write("%4d %9.1f %10d  %-12s %s\n" % (v, tot[k], grid[k] // v, k[0], k[1]))
+        f.write("# total: %d dispatches, %.1f us\n" % (sum(cnt.values()), sum(tot.values())))
+    print("wrote", out)
+
+
 def busy(db, out):
     """Device occupancy of the last second of a trace: union of the kernel intervals / wall, the overlap between queues, the largest gaps."""
     c = sqlite3.connect(db)
@@ -145,6 +169,8 @@ def busy(db, out):
 if __name__ == "__main__":
     if sys.argv[1] == "busy":
         busy(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "fills":
+        fills(sys.argv[2], sys.argv[3], sys.argv[4])
     elif sys.argv[1] == "timeline":
         timeline(sys.argv[2], sys.argv[3], sys.argv[4])
     elif sys.argv[1] == "stats":
