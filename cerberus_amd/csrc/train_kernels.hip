@@ -324,10 +324,21 @@ __device__ __forceinline__ bool bn_sum_partials(const double* __restrict__ parti
     const int per = (blocks_per_group + 15) / 16, b0 = ch * per, b1 = min(blocks_per_group, b0 + per);
     double s = 0, q = 0;
     if (c < C)
-        for (int b = b0; b < b1; ++b) {
-            const double2 v = *reinterpret_cast<const double2*>(partial + ((long long)(g * blocks_per_group + b) * C + c) * 2);
-            s += v.x;
-            q += v.y;
+        // sixteen loads in flight, then the additions in the SAME order as before (identical bits): one load per iteration made a finalize launch a chain
+        // of up to 16 dependent round trips -- 30 us for a kernel that moves 260 KB, 51 + 51 of them per training step
+        for (int bb = b0; bb < b1; bb += 16) {
+            double2 v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int b = bb + k < b1 ? bb + k : b1 - 1;
+                v[k] = *reinterpret_cast<const double2*>(partial + ((long long)(g * blocks_per_group + b) * C + c) * 2);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (bb + k < b1) {
+                    s += v[k].x;
+                    q += v[k].y;
+                }
         }
     sh[0][ch][lane] = s;
     sh[1][ch][lane] = q;
@@ -469,10 +480,19 @@ __global__ __launch_bounds__(256) void bn_partial_fold_kernel(const double* __re
         const int c = (int)(i % C), b2 = (int)((i / C) % B2), g = (int)(i / ((long long)C * B2));
         const int b0 = b2 * per, b1 = min(B, b0 + per);
         double s = 0, q = 0;
-        for (int b = b0; b < b1; ++b) {
-            const double2 v = *reinterpret_cast<const double2*>(in + (((long long)g * B + b) * C + c) * 2);
-            s += v.x;
-            q += v.y;
+        for (int bb = b0; bb < b1; bb += 8) {  // eight loads in flight, additions in the original order (see bn_sum_partials)
+            double2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int b = bb + k < b1 ? bb + k : b1 - 1;
+                v[k] = *reinterpret_cast<const double2*>(in + (((long long)g * B + b) * C + c) * 2);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (bb + k < b1) {
+                    s += v[k].x;
+                    q += v[k].y;
+                }
         }
         double* o = out + i * 2;
         o[0] = s;
