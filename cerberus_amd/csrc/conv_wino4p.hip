@@ -288,8 +288,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned wlane = (unsigned)lane * 16u;
 
     f32x2 d[6][6];  // raw patch of the NEXT chunk (two channels), transformed in place in the shadow of the matrix pipe
+#ifdef P4_ABL_PREVADD
+    // ablation (round 5, VERDICT r4 "missing" item 4: the decoder entry `skip + up2(prev)` fused into the first convolution's patch fetch): a 6 x 6 patch
+    // of the sum needs the 4 x 4 half-resolution pixels under it as well -- 16 more 8-byte loads per thread and chunk (from lines some other patch
+    // element fetches anyway: prev is a quarter of the bytes and every value serves four pixels) and 36 more packed adds.  The values are garbage; the
+    // row prices the instruction issue and the 32 registers, i.e. the floor of what the fused kernel would cost over the plain one.
+    f32x2 pv[4][4];
+#endif
     auto issue = [&](__amdgpu_buffer_rsrc_t r, int chunk_off, int rr, int qq) __attribute__((always_inline)) {
         const int ii = rr == 0 ? 3 : rr == 5 ? 0 : rr - 1, jj = qq == 0 ? 3 : qq == 5 ? 0 : qq - 1;
+#ifdef P4_ABL_PREVADD
+        if ((rr == 0 || rr == 1 || rr == 3 || rr == 5) && (qq == 0 || qq == 1 || qq == 3 || qq == 5))
+            pv[rr == 0 ? 0 : rr == 1 ? 1 : rr == 3 ? 2 : 3][qq == 0 ? 0 : qq == 1 ? 1 : qq == 3 ? 2 : 3] =
+                buf_load2(r, poff[rr == 0 ? 0 : rr == 5 ? 2 : 1][qq == 0 ? 0 : qq == 5 ? 2 : 1], chunk_off + ((ii ^ 1) * 4 + (jj ^ 2)) * 1024);
+#endif
 #ifdef P4_ABL_LDSPATCH  // ablation (round 4): what an LDS-staged raw patch would cost -- the thread reads its 36 pixels from LDS
         // (any in-range address: the values are garbage) and the workgroup's unique pixels arrive through stage_lds() below
         d[rr][qq] = *reinterpret_cast<const f32x2*>(lds + (rr * 6 + qq) * NT * CB + vw);
@@ -330,7 +342,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "=&v"(t0), "=&v"(t1), "=&v"(u0), "=&v"(u1)
             : "v"(k2), "v"(k4), "v"(k5));
     };
+#if defined(P4_ABL_PREVADD) && P4_ABL_PREVADD + 0 == 2
+    // ... and the bilinear blend itself (the decoder entry is align_corners = False bilinear, net_kernels.hip: blend2 = fma(a, x, b * y)): per patch column
+    // four horizontal blends of the 4 x 4 source pixels, six vertical ones, six adds -- 26 packed operations x 6 columns beside the input transform's 144
+    f32x2 k75 = {0.75f, 0.75f}, k25 = {0.25f, 0.25f};
+    asm volatile("" : "+v"(k75), "+v"(k25));
+    auto blend = [&](const f32x2& wa, const f32x2& x, const f32x2& wb, const f32x2& y) __attribute__((always_inline)) {
+        f32x2 t, r;
+        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(wb), "v"(y));
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(wa), "v"(x), "v"(t));
+        return r;
+    };
+    auto pass_v = [&](int q) __attribute__((always_inline)) {
+        const int qa = q <= 1 ? 0 : q <= 3 ? 1 : 2, qb = qa + 1;
+        const bool odd = (q & 1) != 0;
+        f32x2 h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = odd ? blend(k75, pv[r][qa], k25, pv[r][qb]) : blend(k25, pv[r][qa], k75, pv[r][qb]);
+        const f32x2 v0 = blend(k25, h[0], k75, h[1]), v1 = blend(k75, h[1], k25, h[2]), v2 = blend(k25, h[1], k75, h[2]);
+        const f32x2 v3 = blend(k75, h[2], k25, h[3]), v4 = blend(k25, h[2], k75, h[3]), v5 = blend(k75, h[2], k25, h[3]);
+        asm("v_pk_add_f32 %0, %0, %1" : "+v"(d[0][q]) : "v"(v0));
+        asm("v_pk_add_f32 %0, %0, %1" : "+v"(d[1][q]) : "v"(v1));
+        asm("v_pk_add_f32 %0, %0, %1" : "+v"(d[2][q]) : "v"(v2));
+        asm("v_pk_add_f32 %0, %0, %1" : "+v"(d[3][q]) : "v"(v3));
+        asm("v_pk_add_f32 %0, %0, %1" : "+v"(d[4][q]) : "v"(v4));
+        asm("v_pk_add_f32 %0, %0, %1" : "+v"(d[5][q]) : "v"(v5));
+        bt6(d[0][q], d[1][q], d[2][q], d[3][q], d[4][q], d[5][q]);
+    };
+#elif defined(P4_ABL_PREVADD)
+    auto pass_v = [&](int q) __attribute__((always_inline)) {
+        const int qi = q == 0 ? 0 : q <= 2 ? 1 : q <= 4 ? 2 : 3;
+        asm("v_pk_add_f32 %0, %0, %1" : "+v"(d[0][q]) : "v"(pv[0][qi]));
+        asm("v_pk_add_f32 %0, %0, %1" : "+v"(d[1][q]) : "v"(pv[1][qi]));
+        asm("v_pk_add_f32 %0, %0, %1" : "+v"(d[2][q]) : "v"(pv[1][qi]));
+        asm("v_pk_add_f32 %0, %0, %1" : "+v"(d[3][q]) : "v"(pv[2][qi]));
+        asm("v_pk_add_f32 %0, %0, %1" : "+v"(d[4][q]) : "v"(pv[2][qi]));
+        asm("v_pk_add_f32 %0, %0, %1" : "+v"(d[5][q]) : "v"(pv[3][qi]));
+        bt6(d[0][q], d[1][q], d[2][q], d[3][q], d[4][q], d[5][q]);
+    };
+#else
     auto pass_v = [&](int q) __attribute__((always_inline)) { bt6(d[0][q], d[1][q], d[2][q], d[3][q], d[4][q], d[5][q]); };  // down column q
+#endif
     auto pass_h = [&](int r) __attribute__((always_inline)) { bt6(d[r][0], d[r][1], d[r][2], d[r][3], d[r][4], d[r][5]); };  // along row r
     auto write_row = [&](int buf, int r) __attribute__((always_inline)) {
 #pragma unroll
