@@ -432,3 +432,42 @@ def test_reference_tiling_two_tiles_wide_equals_the_oracle_instance_for_instance
     ref = [tuple(int(v) for v in b) for b in g["boxes"]]
     assert prof["tiles_total"] == 4 + 2 + 2 + 1 and len(ref) > 30000
     assert boxes == ref and len(set(boxes)) == len(boxes)
+
+
+_AB_SCRIPT = r"""
+import hashlib, sys
+import numpy as np, torch
+from cerberus_amd.postproc import postproc_device
+from cerberus_amd import synth_maps as synth
+h = hashlib.sha1()
+for (H, W, seed, dens) in [(512, 768, 3, 1500.0), (515, 773, 4, 3000.0), (1024, 1024, 5, 600.0)]:
+    m = torch.from_numpy(synth.nuclei_maps(H, W, seed, dens, noise=0.05)).cuda()
+    lab, info = postproc_device(m, "Nuclei")
+    h.update(lab.cpu().numpy().tobytes())
+    h.update(str(int(info["n_inst"])).encode())
+print("LABELS", h.hexdigest())
+"""
+
+
+def _labels_digest(env_extra):
+    import subprocess
+    import sys
+
+    env = dict(os.environ)
+    for k in ("CERB_PP_ONE_PIXEL_THREADS", "CERB_PP_PIXEL_SCANS", "CERB_PP_SEAM_STRICT", "CERB_PP_THREE_LABELLINGS"):
+        env.pop(k, None)
+    env.update(env_extra)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    out = subprocess.run([sys.executable, "-c", _AB_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return [l for l in out.stdout.splitlines() if l.startswith("LABELS")][-1]
+
+
+def test_every_front_variant_gives_the_same_labels():
+    """Round 5 rebuilt the nuclei front (root bitmaps, four pixels per thread, one seeds + counts + boxes pass, list-based areas, cached seam finds) and kept
+    the passes it replaces behind developer switches (read once per process: each variant runs in its own interpreter).  Every one of them must label three
+    seeded maps -- one with a width that is not a multiple of four, which takes the one-pixel passes anyway -- to the same bytes as the default."""
+    want = _labels_digest({})
+    for sw in ("CERB_PP_ONE_PIXEL_THREADS", "CERB_PP_PIXEL_SCANS", "CERB_PP_SEAM_STRICT", "CERB_PP_THREE_LABELLINGS"):
+        assert _labels_digest({sw: "1"}) == want, sw
