@@ -1619,14 +1619,19 @@ __device__ __forceinline__ bool ws_conflict_global(const float* __restrict__ ins
     return hit;
 }
 
+// Work items are handed out one at a time (a counter per tier, zeroed with the call's scratch words): the floods of a tier differ several-fold in
+// length, and a static stride over the list left a tier waiting for the wave that happened to draw the long ones.
+__device__ __forceinline__ int ws_next_item(int* next) {
+    int v = 0;
+    if ((threadIdx.x & 63) == 0) v = atomicAdd(next, 1);
+    return __shfl(v, 0);
+}
 __global__ __launch_bounds__(256) void ws_flood_kernel(const float* __restrict__ inst, long long row_stride, int pix_stride,
                                                        const uint8_t* __restrict__ mask, int* out, const int* __restrict__ wl,
                                                        const int* __restrict__ wl_n, const int* __restrict__ hoff, const int* __restrict__ hcnt,
-                                                       u64* hkey, u32* hidx, int H, int W, int* __restrict__ n_ambiguous, int wl_len) {
+                                                       u64* hkey, u32* hidx, int H, int W, int* __restrict__ n_ambiguous, int wl_len, int* next) {
     const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int nw = gridDim.x * (blockDim.x >> 6);
-    for (int w = wid; w < *wl_n; w += nw) {
+    for (int w = ws_next_item(next); w < *wl_n; w = ws_next_item(next)) {
         const int root = wl[wl_len - 1 - w];  // large-component list grows from the back of wl
         volatile u64* hk = hkey + hoff[root];
         volatile u32* hi = hidx + hoff[root];
@@ -1696,17 +1701,16 @@ template <int WIN_CAP, int HEAP_CAP, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void ws_flood_window_kernel(const float* __restrict__ inst, long long row_stride, int pix_stride,
                                                                      const uint8_t* __restrict__ mask, const int* __restrict__ L, int* out,
                                                                      const int* __restrict__ wl, const int* __restrict__ wl_n,
-                                                                     const CBox* __restrict__ bb, int H, int W, int* __restrict__ n_ambiguous) {
+                                                                     const CBox* __restrict__ bb, int H, int W, int* __restrict__ n_ambiguous, int* next) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wid = blockIdx.x * WAVES + wv, nw = gridDim.x * WAVES;
     constexpr size_t PER_WAVE = (size_t)HEAP_CAP * 8 + (size_t)WIN_CAP * 8 + (size_t)HEAP_CAP * 2;
     unsigned char* mine = s_raw + (size_t)wv * PER_WAVE;
     volatile u64* hk = reinterpret_cast<u64*>(mine);
     volatile int* st = reinterpret_cast<int*>(mine + (size_t)HEAP_CAP * 8);
     volatile u32* vl = reinterpret_cast<u32*>(mine + (size_t)HEAP_CAP * 8 + (size_t)WIN_CAP * 4);
     volatile unsigned short* hi = reinterpret_cast<unsigned short*>(mine + (size_t)HEAP_CAP * 8 + (size_t)WIN_CAP * 8);
-    for (int w = wid; w < *wl_n; w += nw) {
+    for (int w = ws_next_item(next); w < *wl_n; w = ws_next_item(next)) {
         const int root = wl[w];
         const CBox b = bb[root];
         const int wh = b.y2 - b.y1 + 3, ww = b.x2 - b.x1 + 3, wn = wh * ww;
@@ -1841,16 +1845,15 @@ __global__ __launch_bounds__(256) void ws_flood_lds_kernel(const float* __restri
                                                            const uint8_t* __restrict__ mask, int* out, const int* __restrict__ wl,
                                                            const int* __restrict__ wl_n, const int* __restrict__ hoff,
                                                            const int* __restrict__ hcnt, const u64* __restrict__ hkey,
-                                                           const u32* __restrict__ hidx, int H, int W, int* __restrict__ n_ambiguous) {
+                                                           const u32* __restrict__ hidx, int H, int W, int* __restrict__ n_ambiguous, int* next) {
     __shared__ u64 s_key[4][WS_LDS_CAP];
     __shared__ u32 s_idx[4][WS_LDS_CAP];
     __shared__ int s_lab[4][WS_LDS_CAP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wid = blockIdx.x * 4 + wv, nw = gridDim.x * 4;
     volatile u64* hk = s_key[wv];
     volatile u32* hi = s_idx[wv];
     volatile int* hl = s_lab[wv];
-    for (int w = wid; w < *wl_n; w += nw) {
+    for (int w = ws_next_item(next); w < *wl_n; w = ws_next_item(next)) {
         const int root = wl[w];
         int n = hcnt[root];
         const int base = hoff[root];
@@ -2595,19 +2598,19 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
         PP_OK(hipEventRecord(ss->fork, st));
         for (int i = 0; i < 3; ++i) PP_OK(hipStreamWaitEvent(ss->s[i], ss->fork, 0));
         hipLaunchKernelGGL(k_tiny, dim3(256 * 3), dim3(256), lds_tiny, ss->s[0], inst, row_stride, pix_stride, msk, LA, labels_out, wl4, counts + 4, cbox,
-                           H, W, small + 3);
+                           H, W, small + 3, small + 24);
         hipLaunchKernelGGL(k_small, dim3(256 * 2), dim3(128), lds_small, ss->s[1], inst, row_stride, pix_stride, msk, LA, labels_out, wl, counts + 0, cbox,
-                           H, W, small + 3);
+                           H, W, small + 3, small + 25);
         // (launching this tier FIRST -- its longest flood is the critical path -- measured worse: its 151-KB workgroups then keep the other tiers off
         // every CU that holds one; behind them it starts where they have left)
         hipLaunchKernelGGL(k_big, dim3(256), dim3(64), lds_big, st, inst, row_stride, pix_stride, msk, LA, labels_out, wl3, counts + 3, cbox, H, W,
-                           small + 3);
+                           small + 3, small + 26);
         // the fill of the single-label components (isolated nuclei: no flood) touches other pixels than any flood: beside them, not before them
         hipLaunchKernelGGL(ws_fill_single_kernel, dim3(g), dim3(256), 0, ss->s[2], msk, LA, lmin, lmax, labels_out, n);
         hipLaunchKernelGGL(ws_flood_lds_kernel, dim3(256 * 2), dim3(256), 0, ss->s[2], inst, row_stride, pix_stride, msk, labels_out, rank, counts + 1,
-                           hoff, hcnt, hkey, hidx, H, W, small + 3);
+                           hoff, hcnt, hkey, hidx, H, W, small + 3, small + 27);
         hipLaunchKernelGGL(ws_flood_kernel, dim3(256 * 4), dim3(256), 0, ss->s[2], inst, row_stride, pix_stride, msk, labels_out, wl, counts + 2, hoff,
-                           hcnt, hkey, hidx, H, W, small + 3, n);
+                           hcnt, hkey, hidx, H, W, small + 3, n, small + 28);
         for (int i = 0; i < 3; ++i) {
             PP_OK(hipEventRecord(ss->join[i], ss->s[i]));
             PP_OK(hipStreamWaitEvent(st, ss->join[i], 0));
