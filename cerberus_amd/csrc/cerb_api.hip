@@ -21,6 +21,8 @@ hipError_t cerb_launch_conv(const ConvParams& p, int ks, int stride, int mode, h
 hipError_t cerb_launch_wino(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino4(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_wino4b(ConvParams p, hipStream_t st);
+int cerb_wino4b_bn_blocks(const ConvParams& p);
+bool cerb_wino4b_packed(const ConvParams& p);     // this launch takes packed items (16 consecutive tiles instead of a 16 x 16 block)  // BatchNorm partial rows per group the kernel leaves (packed items on 28^2 / 56^2 maps: fewer)
 hipError_t cerb_launch_wino4p(ConvParams p, hipStream_t st);
 hipError_t cerb_launch_upsample2_add_planar(const float* skip, const float* prev, float* out, int groups, int N, int H, int W, int C, long long prev_gs,
                                             long long out_gs, const int* roi, int prev_planar, hipStream_t st);
@@ -278,6 +280,7 @@ struct cerb_net {
                                  // receives the level's OUTPUT (it is dead once the first conv has read it): pout / pout2 are never allocated any more
     bool planar_half = false;       // set by the decoder loop around the half-resolution level's run_conv calls (names the kernel symbol)
     PlanarBuf psum2, pmid2, pout2;  // the same for the level below it (64 channels at half the resolution) when its maps are large enough
+    int packed_items = 1;        // cerb_net_set_packed_items: conv_wino4b.hip packs 16 consecutive tiles per item on maps that are not whole 16 x 16 blocks (28^2, 56^2)
     int planar = 1;              // cerb_net_set_planar: 1 (default) = that level runs upsample2_add_planar -> conv_wino4p x2 -> heads reading planar features
     // optional per-launch timing (HIP events on the caller's stream)
     bool profiling = false;
@@ -870,6 +873,7 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
     p.bias_gs = c.cout;
     p.resid_gs = 0;
     p.out_gs = (long long)N * p.Ho * p.Wo * c.cout;
+    p.pk_off = net->packed_items ? 0 : 1;
     if (macs) {
         *macs += (double)c.groups * N * p.Ho * p.Wo * (double)c.cout * c.cin * c.ks * c.ks;
         if (!out) return 0;
@@ -919,10 +923,10 @@ static int run_conv(cerb_net* net, const std::string& name, const float* in, con
             p.pl_byp = cerb_planar_blocks(p.Ho);
             p.pl_bxp = cerb_planar_blocks(p.Wo);
         }
-        if (prof_begin(net, name, planar ? (p.level_tag ? "conv_wino4p<f4x4,16x16x2,planar>" : "conv_wino4p<f4x4,16x16x2,planar,half-res>") : w4b ? (resid ? "conv_wino4b<f4x4,16x16,res>" : "conv_wino4b<f4x4,16x16>") : (resid ? "conv_wino4<f4x4,16x16x2,res>" : "conv_wino4<f4x4,16x16x2>"), fl_done, st)) return 1;
+        if (prof_begin(net, name, planar ? (p.level_tag ? "conv_wino4p<f4x4,16x16x2,planar>" : "conv_wino4p<f4x4,16x16x2,planar,half-res>") : w4b ? (cerb_wino4b_packed(p) ? (resid ? "conv_wino4b<f4x4,16t,res>" : "conv_wino4b<f4x4,16t>") : (resid ? "conv_wino4b<f4x4,16x16,res>" : "conv_wino4b<f4x4,16x16>")) : (resid ? "conv_wino4<f4x4,16x16x2,res>" : "conv_wino4<f4x4,16x16x2>"), fl_done, st)) return 1;
         if (net->conv_bn_part && !planar && !resid && !(roi && roi[1] > roi[0] && roi[3] > roi[2])) {
             p.bn_part = net->conv_bn_part;
-            net->conv_bn_bpg = N * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16);
+            net->conv_bn_bpg = w4b ? cerb_wino4b_bn_blocks(p) : N * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16);
         }
         HIP_OK(planar ? cerb_launch_wino4p(p, st) : w4b ? cerb_launch_wino4b(p, st) : cerb_launch_wino4(p, st));
         if (prof_end(net, st)) return 1;
@@ -1795,7 +1799,11 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     const bool d_w4b = (saved_algo == 7 || (saved_algo == 6 && map_px <= d_w4b_max_px)) && op.Cout % 64 == 0;
                     const bool d_f4 = d_w4 && op.Cout % 16 == 0 && op.Cin % 64 == 0;
                     // the data gradient as its own family: the forward Winograd kernels on rotated weights (+ the stride-2 dilation pass)
-                    if (prof_begin(net, op.name + ".dgrad", std::string("dgrad:") + (d_f4 ? (d_w4b ? "conv_wino4b<f4x4,16x16>" : "conv_wino4<f4x4,16x16x2>") : "conv_wino<f2x2,8x16>"),
+                    ConvParams q;  // the geometry conv_wino4b's launcher decides its item form by
+                    memset(&q, 0, sizeof(q));
+                    q.N = op.N; q.H = q.Ho = op.H; q.W = q.Wo = op.W; q.Cin = op.Cout; q.Cout = op.Cin; q.pk_off = net->packed_items ? 0 : 1;
+                    const bool d_pk = d_f4 && d_w4b && cerb_wino4b_packed(q);
+                    if (prof_begin(net, op.name + ".dgrad", std::string("dgrad:") + (d_f4 ? (d_w4b ? (d_pk ? "conv_wino4b<f4x4,16t>" : "conv_wino4b<f4x4,16x16>") : "conv_wino4<f4x4,16x16x2>") : "conv_wino<f2x2,8x16>"),
                                    2.0 * op.G * op.N * op.H * op.W * (double)op.Cin * op.Cout * 9.0, st)) return 1;
                     if (op.stride == 2) {  // y = 2 yo - 1 + ky  <=>  dx = conv_s1(D, W'), D[2 yo][2 xo] = dy[yo][xo], zero elsewhere
                         const long long dn = (long long)op.G * op.N * op.H * op.W * op.Cout;
@@ -1813,6 +1821,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     p.resid_gs = op.a_gs;
                     p.out_gs = op.a_gs;
                     if (op.G == 1) p.resid_gs = p.out_gs = 0;
+                    p.pk_off = net->packed_items ? 0 : 1;
                     // the same per-geometry choice as the forward convolutions (run_conv): F(4x4,3x3) for maps of 16 x 16 and more
                     if (d_f4) {
                         float* w4 = nullptr;
@@ -2253,6 +2262,13 @@ extern "C" int cerb_net_set_planar(cerb_net* net, int enable) {
     if (!net) return fail("cerb_net_set_planar: null handle");
     if (enable < 0 || enable > 1) return fail("cerb_net_set_planar: 0 (NHWC) or 1 (tile-planar, conv_wino4p.hip)");
     net->planar = enable;
+    return 0;
+}
+
+extern "C" int cerb_net_set_packed_items(cerb_net* net, int enable) {
+    if (!net) return fail("cerb_net_set_packed_items: null handle");
+    if (enable < 0 || enable > 1) return fail("cerb_net_set_packed_items: 0 (16 x 16 blocks everywhere) or 1 (16 consecutive tiles per item on maps that are not whole blocks)");
+    net->packed_items = enable;
     return 0;
 }
 

@@ -47,7 +47,9 @@ struct ConvParams {
     // block's pixels inside the image, [group][bn_bpg blocks][Cout][2] doubles -- the BatchNorm behind the convolution finalises its batch
     // statistics from these instead of reading the output again (train_kernels.hip: bn_finalize_kernel).  nullptr: not produced.
     double* bn_part;
-    int bn_bpg;           // blocks per group = N * ceil(Ho / 16) * ceil(Wo / 16)
+    int bn_bpg;           // blocks per group = N * ceil(Ho / 16) * ceil(Wo / 16) (conv_wino4b.hip's packed items: ceil(tiles / 16), cerb_wino4b_bn_blocks)
+    int pk_ty, pk_tx, pk_ntile;  // conv_wino4b.hip, packed items (set by the launcher): 4x4 tiles per image column / row, tiles per group
+    int pk_off;           // 1: keep the block form on maps that would take packed items (cerb_net_set_packed_items(net, 0), A/B)
 };
 
 // Tile-planar layout of the decoder's private tensors (conv_wino4p.hip; producer upsample2_add_planar, consumers conv_wino4p and the heads):

@@ -13,6 +13,7 @@
 // V tile [36][16 tiles][32 ch] = 72 KiB, double-buffered; 16-byte slots XOR-swizzled by the tile index (conflict-free ds_read_b128 /
 // ds_write_b64 without padding).  Output rows leave through the free V buffer as whole lines (conv_wino4.hip).
 // Reference layers: models/utils/conv_layers.py:24-60 (_ConvLayer) and models/backbone/resnet.py:81-97 (BasicBlock).
+#include <stdlib.h>
 #include <type_traits>
 
 #include "cerb_common.h"
@@ -83,7 +84,11 @@ struct Item {
 }  // namespace
 
 // STATS (training forward): BatchNorm statistics partials per block from the output stage (ConvParams::bn_part; see conv_wino4.hip)
-template <bool HAS_RES, bool STATS>
+// PACKED (maps whose sides are multiples of 4 but not of 16 -- the 28^2 / 56^2 maps of a 448-pixel patch, where whole 16x16 blocks would be 31 %
+// padding): an item's 16 tiles are 16 CONSECUTIVE 4x4 tiles of the flattened (image, tile row, tile column) order instead of one 4x4-tile block, so
+// only the launch's last item carries empty tiles.  Every tile's arithmetic is the block form's (a matrix-instruction column per tile): same bits.
+// The lane's patch offset and edge flags become per-lane values recomputed per item, the output rows leave per tile (4 pixels x 256 bytes).
+template <bool HAS_RES, bool STATS, bool PACKED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino4b_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ __attribute__((aligned(16))) float bnred[STATS ? 4 * 16 * 8 : 4];
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int ks = lane >> 4;                                // k-slot
 
     const int ncb = p.Cout >> 6;
-    const int nblk = p.N * p.tiles_y * p.tiles_x;  // blocks per group
+    const int nblk = PACKED ? (p.pk_ntile + NT - 1) / NT : p.N * p.tiles_y * p.tiles_x;  // blocks per group
     const int per_group = nblk * ncb;
     const int total = per_group * p.groups;
     const int nchunk = p.Cin / CB;  // even (launcher)
@@ -120,6 +125,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int L = it - w.g * per_group;
         w.cb = L % ncb;
         const int id = L / ncb;
+        if (PACKED) {  // n = the packed block: tiles 16 n .. 16 n + 15 of the group
+            w.n = id;
+            w.by = w.bx = 0;
+            return w;
+        }
         w.bx = id % p.tiles_x;
         const int r = id / p.tiles_x;
         w.by = r % p.tiles_y;
@@ -129,12 +139,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto oy0 = [&](const Item& b) { return (b.by + p.ty_off) * BLK; };
     auto ox0 = [&](const Item& b) { return (b.bx + p.tx_off) * BLK; };
     auto in_base = [&](const Item& b) {
+        // PACKED: the group's tensor, one row + one pixel early, so that a lane's offset of patch element (0, 0) is never negative
+        if (PACKED) return reinterpret_cast<const char*>(p.in + b.g * p.in_gs) - (long long)(p.W + 1) * p.Cin * 4;
         return reinterpret_cast<const char*>(p.in + b.g * p.in_gs) + ((((long long)b.n * p.H + (oy0(b) - 1)) * p.W + (ox0(b) - 1)) * p.Cin) * 4;
     };
     auto w_base = [&](const Item& w) {
         return reinterpret_cast<const char*>(p.wpack + w.g * p.w_gs) + (long long)w.cb * nchunk * CHUNK_W_BYTES + a * WAVE_W_BYTES;
     };
-    auto hangs_over = [&](const Item& b) { return oy0(b) + BLK > p.H || ox0(b) + BLK > p.W; };
+    auto hangs_over = [&](const Item& b) { return !PACKED && (oy0(b) + BLK > p.H || ox0(b) + BLK > p.W); };
     auto edge_bits = [&](const Item& b) {  // 1 top, 2 bottom, 4 left, 8 right
         return (oy0(b) == 0 ? 1 : 0) | (oy0(b) + BLK == p.H ? 2 : 0) | (ox0(b) == 0 ? 4 : 0) | (ox0(b) + BLK == p.W ? 8 : 0);
     };
@@ -155,11 +167,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // chunk; the former in-register masking cost ~100 VALU instructions per chunk (selects + the copies that merged its two code paths),
     // each of them matrix-pipe time at one wave per SIMD.  Blocks hanging over the image keep the per-pixel mask (mask_border).
     struct EdgeOff { unsigned o[3][3]; };
-    auto edge_offsets = [&](int bits) __attribute__((always_inline)) {
+    // tile index of the group -> (image, tile row, tile column); quotients by float reciprocal + one correction step (tile counts are far below 2^24)
+    const float pk_inv_img = PACKED ? 1.0f / (float)(p.pk_ty * p.pk_tx) : 0.f, pk_inv_tx = PACKED ? 1.0f / (float)p.pk_tx : 0.f;
+    auto pk_div = [&](int x, int dv, float inv) __attribute__((always_inline)) {
+        int q = (int)((float)x * inv);
+        const int r = x - q * dv;
+        q += (r >= dv) ? 1 : 0;
+        q -= (r < 0) ? 1 : 0;
+        return q;
+    };
+    auto pk_decode = [&](int T, int& n, int& ty, int& tx) __attribute__((always_inline)) {
+        const int per_img = p.pk_ty * p.pk_tx;
+        n = pk_div(T, per_img, pk_inv_img);
+        const int r = T - n * per_img;
+        ty = pk_div(r, p.pk_tx, pk_inv_tx);
+        tx = r - ty * p.pk_tx;
+    };
+    // PACKED: the lane's tile is tile 16 n + t of the group: its patch offset (from in_base) and its own edge flags; an empty tile's offset is out of range
+    struct LaneGeo { unsigned ioff; int eb; };
+    auto lane_geo = [&](const Item& b) __attribute__((always_inline)) {
+        LaneGeo L;
+        L.ioff = ioff;
+        L.eb = 0;
+        if (PACKED) {
+            const int T = b.n * NT + t;
+            const bool valid = T < p.pk_ntile;
+            const int Tc = valid ? T : 0;
+            int n, ty, tx;
+            pk_decode(Tc, n, ty, tx);
+            L.ioff = valid ? (unsigned)(((((n * p.H + 4 * ty) * p.W) + 4 * tx) * p.Cin + 2 * c) * 4) : 0x80000000u;
+            L.eb = (ty == 0 ? 1 : 0) | (ty == p.pk_ty - 1 ? 2 : 0) | (tx == 0 ? 4 : 0) | (tx == p.pk_tx - 1 ? 8 : 0);
+        }
+        return L;
+    };
+    auto edge_offsets = [&](int bits, const LaneGeo& lg) __attribute__((always_inline)) {
         EdgeOff e;
-        const bool zt = (bits & 1) && a == 0, zb = (bits & 2) && a == 3;  // wave-uniform: a wave is one tile row
-        const bool zl = (bits & 4) && lane_left, zr = (bits & 8) && lane_right;
-        const unsigned col[3] = {zl ? 0x80000000u : ioff, ioff, zr ? 0x80000000u : ioff};
+        const bool zt = PACKED ? (lg.eb & 1) != 0 : ((bits & 1) && a == 0), zb = PACKED ? (lg.eb & 2) != 0 : ((bits & 2) && a == 3);  // block form: wave-uniform, a wave is one tile row
+        const bool zl = PACKED ? (lg.eb & 4) != 0 : ((bits & 4) && lane_left), zr = PACKED ? (lg.eb & 8) != 0 : ((bits & 8) && lane_right);
+        const unsigned io = PACKED ? lg.ioff : ioff;
+        const unsigned col[3] = {zl ? 0x80000000u : io, io, zr ? 0x80000000u : io};
 #pragma unroll
         for (int qc = 0; qc < 3; ++qc) {
             e.o[0][qc] = zt ? 0x80000000u : col[qc];
@@ -240,8 +286,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- prologue: chunk 0 of the first item into V buffer 0, chunk 1's patch requested ------------------------------------------
     Item w = decode(item);
     {
+        const LaneGeo geo_cur = lane_geo(w);
         const __amdgpu_buffer_rsrc_t r0 = make_rsrc_lim(in_base(w));
-        const EdgeOff e0 = edge_offsets(hangs_over(w) ? 0 : edge_bits(w));
+        const EdgeOff e0 = edge_offsets(hangs_over(w) ? 0 : edge_bits(w), geo_cur);
 #pragma unroll
         for (int k = 0; k < 36; ++k) issue(0, r0, e0, 0, k);
 #pragma unroll
@@ -303,7 +350,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int stage_off = 0;
 #else
             const __amdgpu_buffer_rsrc_t r_stage = make_rsrc_lim(b_next ? in_nx : in_cur);
-            const EdgeOff eB = edge_offsets((b_next ? mask_next : mask_cur) ? 0 : (b_next ? edge_next : edge_cur));
+            const EdgeOff eB = edge_offsets((b_next ? mask_next : mask_cur) ? 0 : (b_next ? edge_next : edge_cur), lane_geo(b_next ? wnx : w));  // PACKED: recomputed per chunk (~30 instructions) rather than held in two more registers across the matrix loop
             const int stage_off = (b_next ? ch + 2 - nchunk : ch + 2) * (CB * 4);
 #endif
             const int wcur_off = ch * CHUNK_W_BYTES;
@@ -403,13 +450,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // read side: wave a stores pixel rows 4 a .. 4 a + 3; lane = (pixel lane_o >> 4 of a group of four, 16-byte piece lane_o & 15)
             const int sr = ((64 * a + (lane_o >> 4)) * OPX + 4 * a + 4 * (lane_o & 15));
             const int orow = p.Wo * p.Cout * 4, opix = p.Cout * 4;
-            const unsigned ooff = (unsigned)(((4 * a * p.Wo + (lane_o >> 4)) * p.Cout + 4 * (lane_o & 15)) * 4);
+            const unsigned ooff = (unsigned)((((PACKED ? 0 : 4 * a * p.Wo) + (lane_o >> 4)) * p.Cout + 4 * (lane_o & 15)) * 4);
             const float floor_ = p.relu ? 0.f : -3.402823466e38f;
-            const unsigned span = (unsigned)(BLK * p.Wo * p.Cout * 4);
+            const unsigned span = PACKED ? (unsigned)((long long)p.N * p.Ho * p.Wo * p.Cout * 4) : (unsigned)(BLK * p.Wo * p.Cout * 4);
             const int by0 = oy0(w), bx0 = ox0(w);
-            const long long origin = (((long long)w.n * p.Ho + by0) * p.Wo + bx0) * p.Cout + w.cb * 64;  // floats, uniform
+            const long long origin = PACKED ? (long long)w.cb * 64 : (((long long)w.n * p.Ho + by0) * p.Wo + bx0) * p.Cout + w.cb * 64;  // floats, uniform
             const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + w.g * p.out_gs + origin, 0, span, 0x00020000);
-            const bool partial = (by0 + BLK > p.Ho) || (bx0 + BLK > p.Wo);
+            const bool partial = !PACKED && ((by0 + BLK > p.Ho) || (bx0 + BLK > p.Wo));
+            // PACKED: this wave stores tiles 4 a .. 4 a + 3 of the item; a tile's byte offset in the group's tensor joins the lane's own offset
+            unsigned toff[4] = {0u, 0u, 0u, 0u};
+            bool tvalid[4] = {true, true, true, true};
+            if (PACKED) {
+#pragma unroll
+                for (int x4 = 0; x4 < 4; ++x4) {
+                    const int T = w.n * NT + 4 * a + x4;
+                    tvalid[x4] = T < p.pk_ntile;
+                    int n, ty, tx;
+                    pk_decode(tvalid[x4] ? T : 0, n, ty, tx);
+                    toff[x4] = (unsigned)(((n * p.Ho + 4 * ty) * p.Wo + 4 * tx) * p.Cout * 4);
+                }
+            }
             // vertical pass: T[i][b] = sum_a A^T[i][a] M[a][b]
             f32x4 T[4][6];
 #pragma unroll
@@ -436,8 +496,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             unsigned vo[4];
 #pragma unroll
             for (int x4 = 0; x4 < 4; ++x4) {
-                const bool ok = !partial || (bx0 + 4 * x4 + (lane_o >> 4) < p.Wo);
-                vo[x4] = ok ? ooff : 0x80000000u;  // out-of-range offsets: the hardware drops the store / returns 0
+                const bool ok = PACKED ? tvalid[x4] : (!partial || (bx0 + 4 * x4 + (lane_o >> 4) < p.Wo));
+                vo[x4] = ok ? ooff + toff[x4] : 0x80000000u;  // out-of-range offsets: the hardware drops the store / returns 0
             }
             f32x4 res[16];
             if (HAS_RES) {
@@ -446,7 +506,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const bool rowok = !partial || (by0 + 4 * a + (k >> 2) < p.Ho);
-                    res[k] = buf_load(r_res, rowok ? vo[k & 3] : 0x80000000u, (k >> 2) * orow + 4 * (k & 3) * opix);
+                    res[k] = buf_load(r_res, rowok ? vo[k & 3] : 0x80000000u, (k >> 2) * orow + (PACKED ? 0 : 4 * (k & 3) * opix));
                 }
             }
             f32x4 bts = {0.f, 0.f, 0.f, 0.f}, btq = {0.f, 0.f, 0.f, 0.f};  // STATS: this lane's 16 pixels x 4 channels
@@ -468,7 +528,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         btq[3] = fmaf(o[3], o[3], btq[3]);
                     }
                 }
-                buf_store(o, r_out, rowok ? vo[k & 3] : 0x80000000u, (k >> 2) * orow + 4 * (k & 3) * opix);
+                buf_store(o, r_out, rowok ? vo[k & 3] : 0x80000000u, (k >> 2) * orow + (PACKED ? 0 : 4 * (k & 3) * opix));
             }
             if constexpr (STATS) {
 #pragma unroll
@@ -488,7 +548,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             W4_STAMP(4);
             if constexpr (STATS) {
                 if (a == 0 && lane_o < 16 && p.bn_part) {
-                    const long long blk = ((long long)w.n * p.tiles_y + w.by) * p.tiles_x + w.bx;
+                    const long long blk = PACKED ? (long long)w.n : ((long long)w.n * p.tiles_y + w.by) * p.tiles_x + w.bx;
                     double* dst = p.bn_part + (((long long)w.g * p.bn_bpg + blk) * p.Cout + w.cb * 64 + 4 * lane_o) * 2;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -513,6 +573,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// Packed items: maps whose sides are multiples of 4 but not both of 16, whole map (no region of interest), tensors below 2 GiB per group (a lane's
+// offset is 32 bits from the group's base).  cerb_net_set_packed_items(net, 0) / CERB_W4B_PACKED=0 keep the block form (A/B: bitwise the same results).
+bool cerb_wino4b_packed(const ConvParams& p) {
+    static const bool off = [] { const char* e = getenv("CERB_W4B_PACKED"); return e && e[0] == '0'; }();
+    if (off || p.pk_off || p.H != p.Ho || p.W != p.Wo) return false;
+    if (p.Ho % 4 || p.Wo % 4 || (p.Ho % 16 == 0 && p.Wo % 16 == 0)) return false;
+    if (p.roi_y1 > p.roi_y0 && p.roi_x1 > p.roi_x0) return false;
+    const long long px = (long long)p.N * p.Ho * p.Wo;
+    return px * p.Cin * 4 < 0x7fffffffll && px * p.Cout * 4 < 0x7fffffffll;
+}
+// blocks per group of the BatchNorm partials the kernel leaves (ConvParams::bn_part): what cerb_api.hip sizes the buffer by and the finalize kernel walks
+int cerb_wino4b_bn_blocks(const ConvParams& p) {
+    if (cerb_wino4b_packed(p)) return (p.N * (p.Ho / 4) * (p.Wo / 4) + NT - 1) / NT;
+    return p.N * ((p.Ho + BLK - 1) / BLK) * ((p.Wo + BLK - 1) / BLK);
+}
+
 template <bool HAS_RES>
 static hipError_t launch_wino4b(ConvParams p, hipStream_t st) {
     p.tiles_x = (p.Wo + BLK - 1) / BLK;  // blocks, not tiles
@@ -524,13 +600,20 @@ static hipError_t launch_wino4b(ConvParams p, hipStream_t st) {
         p.tiles_y = (p.roi_y1 + BLK - 1) / BLK - p.ty_off;
         p.tiles_x = (p.roi_x1 + BLK - 1) / BLK - p.tx_off;
     }
-    const long long items = (long long)p.groups * p.N * p.tiles_x * p.tiles_y * (p.Cout / 64);
+    const bool packed = cerb_wino4b_packed(p);
+    if (packed) {
+        p.pk_ty = p.Ho / 4;
+        p.pk_tx = p.Wo / 4;
+        p.pk_ntile = p.N * p.pk_ty * p.pk_tx;
+    }
+    const long long items = packed ? (long long)p.groups * ((p.pk_ntile + NT - 1) / NT) * (p.Cout / 64) : (long long)p.groups * p.N * p.tiles_x * p.tiles_y * (p.Cout / 64);
     const bool stats = p.bn_part != nullptr;
     if (stats && HAS_RES) return hipErrorInvalidValue;
-    p.bn_bpg = p.N * p.tiles_x * p.tiles_y;
-    auto kern = stats ? conv_wino4b_kernel<false, true> : conv_wino4b_kernel<HAS_RES, false>;
-    static bool attr_done[2][64] = {};
-    if (cerb_attr_needed(attr_done[stats ? 1 : 0])) {
+    p.bn_bpg = packed ? cerb_wino4b_bn_blocks(p) : p.N * p.tiles_x * p.tiles_y;
+    auto kern = packed ? (stats ? conv_wino4b_kernel<false, true, true> : conv_wino4b_kernel<HAS_RES, false, true>)
+                       : (stats ? conv_wino4b_kernel<false, true, false> : conv_wino4b_kernel<HAS_RES, false, false>);
+    static bool attr_done[4][64] = {};
+    if (cerb_attr_needed(attr_done[(stats ? 1 : 0) + (packed ? 2 : 0)])) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + PROF_BYTES);
         if (e != hipSuccess) return e;
     }

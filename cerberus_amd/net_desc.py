@@ -441,6 +441,12 @@ class NetDesc(torch.nn.Module):
         self._remember("set_planar", enable)
         _lib.check(_lib.lib().cerb_net_set_planar(self._ensure_handle(), int(enable)))
 
+    def set_packed_items(self, enable=True):
+        """conv_wino4b.hip on maps that are not whole 16 x 16 blocks (28^2 / 56^2 of a 448-pixel patch): 1 / True = 16 consecutive tiles per work item
+        (default), 0 / False = 16 x 16-pixel blocks with padding tiles.  Bit-identical outputs (include/cerberus_hip.h)."""
+        self._remember("set_packed_items", enable)
+        _lib.check(_lib.lib().cerb_net_set_packed_items(self._ensure_handle(), int(enable)))
+
     def set_crop_roi(self, enable=True):
         """Compute only what the centre crop keeps in the decoders / heads (default on; include/cerberus_hip.h)."""
         self._remember("set_crop_roi", enable)

@@ -95,6 +95,13 @@ int cerb_net_set_conv_algo(cerb_net* net, int algo);
  *   0           = NHWC through conv_wino4.hip (round 2's path).
  * Same arithmetic in the same order: the outputs are bit-identical (tests/test_net_gpu.py).  Applies with conv_algo 6 and head_algo 1. */
 int cerb_net_set_planar(cerb_net* net, int enable);
+/* Work items of the F(4x4,3x3) kernel for maps up to 64 x 64 pixels (conv_wino4b.hip) on maps whose sides are multiples of 4 but not of 16 -- the
+ * 28 x 28 / 56 x 56 maps of the reference's default 448-pixel patch (infer/tile.py:43-106, models/backbone/resnet.py:273-286), in inference and in
+ * the training step's forward and data-gradient convolutions:
+ *   1 (default) = an item is 16 CONSECUTIVE 4x4 tiles of the batch (image-major, row-major): no padding tiles but in the launch's last item;
+ *   0           = an item is a 16 x 16-pixel block (28 x 28 -> 2 x 2 blocks per image, 23 % of them padding).
+ * A tile's arithmetic does not depend on the item it rides in: the outputs are bit-identical (tests/test_net_gpu.py).  For A/B. */
+int cerb_net_set_packed_items(cerb_net* net, int enable);
 /* Output heads (models/utils/net_layers.py:31-38): 1 (default) = every dense head of the batch in ONE grouped launch with the head's
  * weights resident in LDS (head_group_kernel) and the 96 -> 3 / 7 logits on 4x4x1 matrix instructions (no zero-padded rows); 2 = round 3's
  * grouped launch (logits on a 16-row instruction, 13 / 9 rows of zeros); 0 = one launch per head (round-1 head_kernel).  0 and 2 are

@@ -558,6 +558,47 @@ def test_winograd_partial_tiles_and_odd_blocks_vs_direct(full_model, win, osz, n
         m.set_conv_algo(DEFAULT_ALGO)
 
 
+@pytest.mark.parametrize("win,osz,n", [(448, 448, 3), (448, 144, 2), (224, 224, 5), (208, 80, 2), (240, 240, 3), (160, 160, 7), (256, 256, 2)])
+def test_packed_items_are_bit_identical_to_block_items(full_model, win, osz, n):
+    """cerb_net_set_packed_items(1) (default): on maps whose sides are multiples of 4 but not of 16 -- the 56^2 / 28^2 maps of the reference's 448-pixel
+    patch, 52^2 of a 208-pixel one, 60^2 of 240, 40^2 / 20^2 of 160 -- conv_wino4b takes 16 CONSECUTIVE tiles of the batch per work item instead of a
+    16 x 16-pixel block with padding tiles (3 x 49 tiles = 9 items + 3 tiles: the last item runs with 13 empty tiles).  A tile's arithmetic does not
+    depend on the item it rides in: every head's output must be BITWISE equal to the block form's -- residual layers, grouped decoder launches,
+    centre crops (the cropped decoder launches stay on blocks) and a different batch in between included.  256-pixel tiles have no such map: the
+    switch must not change which kernels run there."""
+    m, sd, kw = full_model
+    rs = np.random.RandomState(900 + win + osz)
+    tiles = torch.from_numpy(rs.randint(0, 256, (n, win, win, 3)).astype(np.uint8)).cuda()
+    other = torch.from_numpy(rs.randint(0, 256, (n + 2, win, win, 3)).astype(np.uint8)).cuda()
+    try:
+        m.set_packed_items(False)
+        m.profile(True)
+        ref = {k: v.clone() for k, v in m.infer_tiles(tiles, osz).items()}
+        torch.cuda.synchronize()
+        kern_blk = [r[1] for r in m.profile_records()]
+        m.profile(False)
+        m.set_packed_items(True)
+        m.infer_tiles(other, osz)
+        m.profile(True)
+        got = {k: v.clone() for k, v in m.infer_tiles(tiles, osz).items()}
+        torch.cuda.synchronize()
+        kern_pk = [r[1] for r in m.profile_records()]
+        m.profile(False)
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), (k, (got[k].float() - ref[k].float()).abs().max().item())
+    finally:
+        m.profile(False)
+        m.set_packed_items(True)
+    n_pk = sum(k.startswith("conv_wino4b<f4x4,16t") for k in kern_pk)
+    assert not any(k.startswith("conv_wino4b<f4x4,16t") for k in kern_blk), kern_blk
+    assert len(kern_pk) == len(kern_blk)
+    if win == 256:
+        assert n_pk == 0 and kern_pk == kern_blk
+    else:
+        assert n_pk >= 5, (n_pk, sorted(set(kern_pk)))
+        assert [k.replace(",16t", ",16x16") for k in kern_pk] == kern_blk
+
+
 @pytest.mark.parametrize("win,osz,n", [(256, 256, 3), (448, 144, 2), (272, 272, 2), (304, 144, 3), (96, 96, 5), (208, 80, 2), (256, 256, 40)])  # 40 tiles: planar tensors beyond 4 GiB
 def test_planar_last_level_is_bit_identical_to_nhwc(full_model, win, osz, n):
     """cerb_net_set_planar(1) (default): the last decoder level in the tile-planar layout (upsample2_add_planar -> conv_wino4p x2 -> heads

@@ -682,3 +682,54 @@ def test_winograd_domain_weight_gradients_equal_the_direct_kernel(gold):
         assert err < 2e-4, (k, err)
     assert n3 >= 50
     print("Winograd-domain vs direct weight gradients: worst element error %.2e of a tensor's largest value over %d 3x3 tensors" % (worst, n3))
+
+
+@pytest.mark.gpu
+def test_training_step_with_packed_items_equals_block_items():
+    """Round 5: the training step's forward and data-gradient convolutions on the 56^2 / 28^2 maps of a 448-pixel batch take packed work items
+    (conv_wino4b.hip: 16 consecutive tiles, no padding tiles); cerb_net_set_packed_items(0) keeps the 16 x 16 blocks.  Convolution outputs and data
+    gradients are bitwise the same either way; the BatchNorm partial sums behind the convolutions are grouped by item, so batch statistics, losses and
+    gradients may move by the rounding of re-ordered fp32 sums and no more."""
+    from cerberus_amd.net_desc import create_model
+    from cerberus_amd.weights import default_model_kwargs, make_state_dict
+
+    n, win = 3, 448
+    g = torch.Generator(device="cuda").manual_seed(77)
+    heads = {"Lumen-INST": 3, "Gland-INST": 3, "Nuclei-INST": 3, "Nuclei-TYPE": 7, "Gland-TYPE": 3, "Patch-Class": 9}
+    batch = {"tiles": torch.randint(0, 256, (n, win, win, 3), dtype=torch.uint8, device="cuda", generator=g), "targets": {}, "flags": {},
+             "keep": torch.rand((n, 512), device="cuda", generator=g) < 0.7}
+    for h, c in heads.items():
+        if h == "Patch-Class":
+            batch["targets"][h] = torch.randint(0, c, (n,), device="cuda", generator=g).float()
+        else:
+            fg = torch.rand((n, win, win), device="cuda", generator=g) < 0.3
+            batch["targets"][h] = (fg * torch.randint(1, c, (n, win, win), device="cuda", generator=g)).float()
+        batch["flags"][h] = torch.ones(n, device="cuda")
+    out = {}
+    for mode in ("packed", "blocks"):
+        m = create_model(**default_model_kwargs())
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(5).items()}, strict=True)
+        m.train()  # the handle is created by the first switch: it has to be packed for training
+        m.set_packed_items(mode == "packed")
+        losses, grads = m.train_grads(batch["tiles"], batch["targets"], batch["flags"], PARAMSET_LOSS, batch["keep"])
+        m.profile(True)
+        m.train_grads(batch["tiles"], batch["targets"], batch["flags"], PARAMSET_LOSS, batch["keep"])
+        fams = [r[1] for r in m.profile_records()]
+        m.profile(False)
+        out[mode] = (losses, {k: (v.detach().cpu().numpy().copy() if torch.is_tensor(v) else np.array(v)) for k, v in grads.items()}, fams)
+    (la, ga, fa), (lb, gb, fb) = out["packed"], out["blocks"]
+    n_fwd = sum(f.startswith("conv_wino4b<f4x4,16t") for f in fa), sum(f.startswith("dgrad:conv_wino4b<f4x4,16t") for f in fa)
+    assert n_fwd[0] >= 16 and n_fwd[1] >= 16 and not any(",16t" in f for f in fb), (n_fwd, sorted(set(fa)))
+    assert set(ga) == set(gb)
+    for h in la:
+        assert abs(la[h] - lb[h]) <= 1e-5 * max(1.0, abs(lb[h])), (h, la[h], lb[h])
+    for k in ga:
+        a, b = ga[k].astype(np.float64).ravel(), gb[k].astype(np.float64).ravel()
+        if k.endswith(("running_mean", "running_var")):
+            assert float(np.abs(a - b).max()) <= 1e-4 * max(float(np.abs(b).max()), 1e-6) + 1e-9, k
+            continue
+        if float(np.abs(b).max()) < 1e-7:
+            continue
+        den = float(np.linalg.norm(a) * np.linalg.norm(b))
+        if den > 0:
+            assert float(a @ b) / den > 0.9999, k
