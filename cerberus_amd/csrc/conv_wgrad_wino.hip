@@ -86,13 +86,23 @@ __device__ __forceinline__ void wgrad_wino_body(const WwParams& p, float* lds, i
             for (int i = 0; i < 6; ++i)
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
+#if defined(WW_ABL_HALFX)  // ablations (scripts/dev_wwabl.sh): how the launch time follows the bytes a chunk pulls -- half the patch / no patch / no gradients
+                    const bool out = i >= 3 || (i == 0 && top) || (j == 0 && left) || (j == 5 && right);
+#elif defined(WW_ABL_NOX)
+                    const bool out = true;
+#else
                     const bool out = (i == 0 && top) || (i == 5 && bot) || (j == 0 && left) || (j == 5 && right);  // wave-uniform
+#endif
                     rd[i * 6 + j] = out ? 0.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)voff, i * xrow + j * xpix, 0));
                 }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
+#ifdef WW_ABL_NOY
+                for (int j = 0; j < 4; ++j) ry[i * 4 + j] = 0.f;
+#else
                 for (int j = 0; j < 4; ++j) ry[i * 4 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry_, (int)voff, i * yrow + j * ypix, 0));
+#endif
         } else {
 #pragma unroll
             for (int k = 0; k < 36; ++k) rd[k] = 0.f;

