@@ -148,6 +148,55 @@ def cpu_baseline_train(sd, kw):
 TRAIN_BATCH, TRAIN_TILE = 16, 448  # BASELINE.json configs[4]: batch 16; 448 x 448 is the reference's training patch (paramset.yml)
 
 
+def dice_vs_reference():
+    """BASELINE.json metric, second half ("per-head Dice vs ref"): the committed fixture tests/golden/net_cfg2_all.npz holds the REFERENCE's own
+    infer_step outputs (oracle/gen_golden_net.py imported /root/reference in the build container: 3 seeded 256^2 tiles, all six heads, fp32).  The same
+    tiles go through the HIP path here, outside every timed region; per head: Dice (2 |A & B| / (|A| + |B| + 1e-8), models/run_desc.py:526-531) of the
+    INST foreground (probability > 0.5) per channel / of every TYPE class with support, the smallest of them reported, and the largest absolute
+    difference of the probability maps (north star: 1e-4)."""
+    import os
+
+    from cerberus_amd.net_desc import create_model
+    from cerberus_amd.run_desc import infer_step
+    from cerberus_amd.weights import default_model_kwargs, make_state_dict
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "net_cfg2_all.npz")
+    g = np.load(path)
+    tasks = [str(t) for t in g["tasks"]]
+    kw = default_model_kwargs(tasks)
+    m = create_model(**kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(int(g["weight_seed"]), kw["decoder_kwargs"], kw["considered_tasks"]).items()}, strict=True)
+    n, hw, osz = int(g["n"]), int(g["hw"]), int(g["out_shape"])
+    tiles = np.random.RandomState(int(g["tile_seed"])).randint(0, 256, (n, hw, hw, 3)).astype(np.uint8)
+    out = infer_step(torch.from_numpy(tiles), m, osz, tasks)
+    crops, cs = [(0, 0), (96, 96), (192, 192)], 64  # the fixture keeps three 64 x 64 windows of the large maps (oracle/gen_golden_net.py)
+
+    def dice(a, b):
+        a, b = a.astype(np.float64), b.astype(np.float64)
+        return 2.0 * (a * b).sum() / (a.sum() + b.sum() + 1e-8)
+
+    per_head, worst_err = {}, 0.0
+    for k in out[0].keys():
+        a = np.stack([out[i][k] for i in range(n)])
+        a4 = a[..., None] if a.ndim == 3 else a
+        key = "out_crops/" + k
+        ref = g[key] if key in g else g["out_full/" + k]
+        got = np.stack([a4[:, y:y + cs, x:x + cs] for (y, x) in crops], axis=1) if key in g else a4
+        ds = []
+        if k.endswith("-INST"):
+            worst_err = max(worst_err, float(np.abs(got.astype(np.float64) - ref).max()))
+            ds = [dice(got[..., c] > 0.5, ref[..., c] > 0.5) for c in range(ref.shape[-1]) if (ref[..., c] > 0.5).sum() > 50]
+        elif k.endswith("-TYPE"):
+            ds = [dice(got == cls, ref == cls) for cls in np.unique(ref) if (ref == cls).sum() > 50]
+        elif k == "Patch-Class":
+            worst_err = max(worst_err, float(np.abs(got.astype(np.float64) - ref).max()))
+        if ds:
+            per_head[k] = round(float(min(ds)), 6)
+    del m
+    return {"fixture": "tests/golden/net_cfg2_all.npz (the reference's own infer_step outputs: %d seeded %dx%d tiles, all six heads)" % (n, hw, hw),
+            "per_head_min_dice": per_head, "min": min(per_head.values()) if per_head else None, "max_abs_err_probability_maps": worst_err}
+
+
 def train_measure(model, dev, dist, world, rank, steps, warmup, backend):
     """K whole training steps (train-mode forward, six losses, backward, bucketed gradient all-reduce over the ranks, Adam, BatchNorm running
     statistics, on-device weight re-pack) on a synthetic batch resident in HBM; every rank has its own batch (weak scaling).  Returns
@@ -747,6 +796,11 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
             del tm
         except Exception as e:  # never fails the headline
             line["train_step"] = {"error": str(e)[:300]}
+    if world == 1:  # per-head Dice against the reference's own outputs (the metric's second half), outside the timed region
+        try:
+            line["dice_vs_reference"] = dice_vs_reference()
+        except Exception as e:  # never fails the headline
+            line["dice_vs_reference"] = {"error": str(e)[:300]}
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(sd, kw)
     print(json.dumps(line), flush=True)

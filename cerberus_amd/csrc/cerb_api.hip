@@ -61,6 +61,8 @@ hipError_t cerb_launch_conv_bwd(const float* x, const float* dy, const float* w,
                                 int ks, int stride, long long x_gs, hipStream_t st);
 hipError_t cerb_launch_stem_wgrad(const unsigned char* tiles, const float* dy, float* dw, int N, int H, int W, hipStream_t st);
 hipError_t cerb_launch_maxpool_bwd(const float* x, const float* ypool, const float* dy, float* dx, int N, int H, int W, int C, hipStream_t st);
+hipError_t cerb_launch_maxpool_idx(const float* in, float* out, unsigned* idx, int N, int H, int W, int C, hipStream_t st);       // training forward: pooled map + window positions
+hipError_t cerb_launch_maxpool_bwd_idx(const unsigned* idx, const float* dy, float* dx, int N, int H, int W, int C, hipStream_t st);  // backward by the recorded positions
 bool cerb_upadd_bwd_fused_ok(int H, int W, int C, int G);
 hipError_t cerb_launch_upadd_bwd(const float* dout, float* dskip, float* dprev, int G, int N, int H, int W, int C, long long prev_gs, int shared_prev, hipStream_t st,
                                  unsigned group_mask = 0xffffffffu, int skip_assign = 0, int prev_assign = 0);
@@ -1554,10 +1556,20 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
     const int x0 = bn("stem", t_stem, -1, (long long)N * H * W, 1);
     TCHK(x0);
     const int pool = newT((size_t)N * hs[1] * ws[1] * 64);
-    PROF("maxpool", "maxpool3x3s2", (double)N * H * W * 64 * 4.0 * 1.25, HIP_OK(cerb_launch_maxpool(val[x0], val[pool], N, H, W, 64, st)));
+    // the pooling records the position of every window's first maximum (one byte per element) and the backward pass routes by it;
+    // CERB_MAXPOOL_SCAN=1 keeps round 4's backward that re-finds the maxima from the input and the pooled map (developer A/B: identical bits)
+    const bool pool_scan = getenv("CERB_MAXPOOL_SCAN") != nullptr;  // read once per step
+    const int pool_idx = pool_scan ? -1 : newT(((size_t)N * hs[1] * ws[1] * 64 + 3) / 4);
+    if (pool_idx >= 0) {
+        if (!val[pool_idx]) { net->conv_algo = saved_algo; return fail("workspace allocation failed"); }
+        PROF("maxpool", "maxpool3x3s2", (double)N * H * W * 64 * 4.0 * 1.25 + (double)N * hs[1] * ws[1] * 64.0,
+             HIP_OK(cerb_launch_maxpool_idx(val[x0], val[pool], reinterpret_cast<unsigned*>(val[pool_idx]), N, H, W, 64, st)));
+    } else {
+        PROF("maxpool", "maxpool3x3s2", (double)N * H * W * 64 * 4.0 * 1.25, HIP_OK(cerb_launch_maxpool(val[x0], val[pool], N, H, W, 64, st)));
+    }
     {
         TapeOp op;
-        op.type = 3; op.a = x0; op.o = pool; op.N = N; op.H = H; op.W = W; op.Cout = 64;
+        op.type = 3; op.a = x0; op.o = pool; op.b = pool_idx; op.N = N; op.H = H; op.W = W; op.Cout = 64;
         tape.push_back(op);
     }
     int cur = pool, inpl = 64, xs[5] = {x0, -1, -1, -1, -1};
@@ -1917,7 +1929,12 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
             }
             case 3: {
                 float* dxp = G_(op.a);
-                PROF("maxpool.bwd", "maxpool_bwd", (double)op.N * op.H * op.W * op.Cout * 4.0 * 2.5, HIP_OK(cerb_launch_maxpool_bwd(val[op.a], val[op.o], go, dxp, op.N, op.H, op.W, op.Cout, st)));
+                if (op.b >= 0) {  // by the recorded positions: dx read + written, dy and the position bytes read
+                    PROF("maxpool.bwd", "maxpool_bwd", (double)op.N * op.H * op.W * op.Cout * 4.0 * 2.25 + (double)op.N * op.H * op.W * op.Cout / 4.0,
+                         HIP_OK(cerb_launch_maxpool_bwd_idx(reinterpret_cast<const unsigned*>(val[op.b]), go, dxp, op.N, op.H, op.W, op.Cout, st)));
+                } else {
+                    PROF("maxpool.bwd", "maxpool_bwd", (double)op.N * op.H * op.W * op.Cout * 4.0 * 2.5, HIP_OK(cerb_launch_maxpool_bwd(val[op.a], val[op.o], go, dxp, op.N, op.H, op.W, op.Cout, st)));
+                }
                 break;
             }
             case 4: {

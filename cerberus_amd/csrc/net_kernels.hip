@@ -141,6 +141,58 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restr
     }
 }
 
+// Training forward: the same pooling that also records, per output element, WHICH of its nine window positions (3 ky + kx, row-major) held the first
+// maximum -- what torch.nn.functional.max_pool2d keeps as its indices (strict comparison in scan order).  One byte per element (51 MB at 16 x 448^2):
+// the backward pass (train_kernels.hip: maxpool_bwd_idx_kernel) routes gradients by it and reads neither the input nor the pooled map again.
+__global__ void maxpool3x3s2_idx_kernel(const float* __restrict__ in, float* __restrict__ out, unsigned* __restrict__ idx, int N, int H, int W, int C, int Ho, int Wo) {
+    const long long total = (long long)N * Ho * Wo * (C / 4);
+    const long long per_xcd = gridDim.x / 8, vb = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    for (long long i = vb * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % (C / 4));
+        long long r = i / (C / 4);
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+        bool first = true;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int y = oy * 2 - 1 + ky;
+            if (y < 0 || y >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int x = ox * 2 - 1 + kx;
+                if (x < 0 || x >= W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(in + (((long long)n * H + y) * W + x) * C + c4 * 4);
+                const unsigned k = (unsigned)(ky * 3 + kx);
+                // the value is the plain kernel's (fmaxf); the position moves only on a strictly larger element, the first valid one starts it
+                if (first || v[0] > m[0]) w0 = k;
+                if (first || v[1] > m[1]) w1 = k;
+                if (first || v[2] > m[2]) w2 = k;
+                if (first || v[3] > m[3]) w3 = k;
+                first = false;
+                m[0] = fmaxf(m[0], v[0]);
+                m[1] = fmaxf(m[1], v[1]);
+                m[2] = fmaxf(m[2], v[2]);
+                m[3] = fmaxf(m[3], v[3]);
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = m;
+        idx[i] = w0 | (w1 << 8) | (w2 << 16) | (w3 << 24);
+    }
+}
+
+hipError_t cerb_launch_maxpool_idx(const float* in, float* out, unsigned* idx, int N, int H, int W, int C, hipStream_t st) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)N * Ho * Wo * (C / 4);
+    long long blocks = ((total + 255) / 256 + 7) / 8 * 8;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(maxpool3x3s2_idx_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, idx, N, H, W, C, Ho, Wo);
+    return hipGetLastError();
+}
+
 hipError_t cerb_launch_maxpool(const float* in, float* out, int N, int H, int W, int C, hipStream_t st) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)N * Ho * Wo * (C / 4);

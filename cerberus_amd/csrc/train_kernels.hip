@@ -1009,6 +1009,43 @@ __global__ __launch_bounds__(256) void upadd_bwd_fused_kernel(const float* __res
         }
     }
 }
+// max-pool backward by the recorded positions (net_kernels.hip: maxpool3x3s2_idx_kernel): thread = four channels of an input pixel; of the <= 4 windows
+// that contain it, those whose recorded position is this pixel hand their gradient over.  Reads one packed word per window (four channels' bytes) and the
+// gradient rows it wins; neither the input nor the pooled map (the scan kernel above reads both and re-walks windows to find first maxima: 5.1 GB, 1.3 ms).
+__global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const unsigned* __restrict__ idx, const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W,
+                                                              int C, int Ho, int Wo) {
+    const int C4 = C >> 2;
+    const long long total = (long long)N * H * W * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long r = i / C4;
+        const int ix = (int)(r % W);
+        r /= W;
+        const int iy = (int)(r % H), n = (int)(r / H);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {  // windows with 2 oy - 1 <= iy <= 2 oy + 1
+            if (oy >= Ho) continue;
+            const unsigned ky = (unsigned)(iy - (2 * oy - 1));
+            for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+                if (ox >= Wo) continue;
+                const unsigned k = ky * 3u + (unsigned)(ix - (2 * ox - 1));
+                const long long o = (((long long)n * Ho + oy) * Wo + ox) * C4 + c4;
+                const unsigned w = idx[o];
+                const bool h0 = (w & 255u) == k, h1 = ((w >> 8) & 255u) == k, h2 = ((w >> 16) & 255u) == k, h3 = (w >> 24) == k;
+                if (h0 | h1 | h2 | h3) {
+                    const float4 g = *reinterpret_cast<const float4*>(dy + o * 4);
+                    if (h0) acc.x += g.x;
+                    if (h1) acc.y += g.y;
+                    if (h2) acc.z += g.z;
+                    if (h3) acc.w += g.w;
+                }
+            }
+        }
+        float4 d = *reinterpret_cast<float4*>(dx + i * 4);  // the stem's output is also the decoders' first skip: their gradient is already here
+        d.x += acc.x; d.y += acc.y; d.z += acc.z; d.w += acc.w;
+        *reinterpret_cast<float4*>(dx + i * 4) = d;
+    }
+}
 // data gradient of a 1x1 stride-2 conv (the residual downsample branches): only the even input positions receive anything --
 // dx[n][2 yo][2 xo][ci] += sum_co dy[n][yo][xo][co] W[co][ci]; thread = (output pixel, ci), the dy row is a broadcast
 __global__ __launch_bounds__(256) void conv1x1s2_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int N, int H, int W,
@@ -1314,6 +1351,10 @@ hipError_t cerb_launch_stem_wgrad(const unsigned char* tiles, const float* dy, f
 }
 hipError_t cerb_launch_maxpool_bwd(const float* x, const float* ypool, const float* dy, float* dx, int N, int H, int W, int C, hipStream_t st) {
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(gridfor((long long)N * H * W * (C / 4))), dim3(256), 0, st, x, ypool, dy, dx, N, H, W, C, H / 2, W / 2);
+    return hipGetLastError();
+}
+hipError_t cerb_launch_maxpool_bwd_idx(const unsigned* idx, const float* dy, float* dx, int N, int H, int W, int C, hipStream_t st) {
+    hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(gridfor((long long)N * H * W * (C / 4))), dim3(256), 0, st, idx, dy, dx, N, H, W, C, H / 2, W / 2);
     return hipGetLastError();
 }
 bool cerb_upadd_bwd_fused_ok(int H, int W, int C, int G) { return C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && G <= 32 && !getenv("CERB_UPADD_BWD_TWO_PASS"); }

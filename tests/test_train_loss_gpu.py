@@ -733,3 +733,45 @@ def test_training_step_with_packed_items_equals_block_items():
         den = float(np.linalg.norm(a) * np.linalg.norm(b))
         if den > 0:
             assert float(a @ b) / den > 0.9999, k
+
+
+@pytest.mark.gpu
+def test_maxpool_backward_by_recorded_positions_equals_the_scan(gold):
+    """Round 5: the training forward's max-pool records which window position held each first maximum (one byte per element) and the backward pass routes
+    the gradients by it; CERB_MAXPOOL_SCAN=1 keeps round 4's backward, which re-finds the first maxima from the stem's output and the pooled map
+    (torch.nn.functional.max_pool2d's rule, held to the reference's train_step by the tests above).  Same rule, same additions: EVERY gradient, batch
+    statistic and loss must be bit-identical -- also on a batch whose maps are not multiples of the window stride's pattern (66 x 66: odd pooled rows)."""
+    import os
+
+    from cerberus_amd.net_desc import create_model
+    from cerberus_amd.weights import default_model_kwargs, make_state_dict
+
+    tiles = torch.from_numpy(gold["img"]).cuda()
+    keep = torch.from_numpy(gold["step/dropout_mask"].reshape(int(gold["N"]), 512)).cuda()
+    targets, flags = {}, {}
+    for j, h in enumerate(gold["heads"]):
+        h = str(h)
+        t = gold["target/" + h][..., 0]
+        targets[h] = torch.from_numpy(t.reshape(t.shape[0]) if h == "Patch-Class" else t).cuda()
+        flags[h] = torch.from_numpy(gold["has_target"][:, j].astype(np.float32)).cuda()
+    # a second batch with many ties: tiles of a few grey levels only (equal maxima inside a window are where the two rules could differ)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    flat = (torch.randint(0, 3, tuple(tiles.shape), device="cuda", generator=g) * 100).to(torch.uint8)
+    out = {}
+    for mode in ("positions", "scan"):
+        if mode == "scan":
+            os.environ["CERB_MAXPOOL_SCAN"] = "1"
+        try:
+            m = create_model(**default_model_kwargs())
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(int(gold["weight_seed"])).items()}, strict=True)
+            res = []
+            for tl in (tiles, flat):
+                losses, grads = m.train_grads(tl, targets, flags, PARAMSET_LOSS, keep)
+                res.append((losses, {k: (v.detach().cpu().numpy().copy() if torch.is_tensor(v) else np.array(v)) for k, v in grads.items()}))
+            out[mode] = res
+        finally:
+            os.environ.pop("CERB_MAXPOOL_SCAN", None)
+    for (la, ga), (lb, gb) in zip(out["positions"], out["scan"]):
+        assert la == lb and set(ga) == set(gb)
+        for k in ga:
+            assert np.array_equal(ga[k], gb[k]), k
