@@ -110,6 +110,59 @@ __device__ __forceinline__ void wgrad_wino_body(const WwParams& p, float* lds, i
             for (int k = 0; k < 16; ++k) ry[k] = 0.f;
         }
     };
+    // The same fetch in NINE parts, one behind each position of the matrix phase (WW_INTERLEAVE, default): the CU's address path takes a wave's load every
+    // ~12 cycles (368 loads per chunk = the 4608 matrix cycles of a chunk), and a wave whose load is not accepted yet issues nothing else -- 52 loads in a
+    // row in front of the barrier stalled every wave for about the time the matrix phase then took (round 5 ablations: matrix 2.5 + loads 2.1 + element-wise
+    // 0.5 us per chunk measured 4.4 together).  Spread between the matrix instructions they are accepted while the matrix pipe works.
+    struct FetchDesc {
+        __amdgpu_buffer_rsrc_t rx, ry;
+        unsigned xo[3][3], yo;  // lane offsets by patch row (first / inner / last) and column, and of the gradients: voff, or out of range (zero padding / no tile)
+    };
+    auto fetch_desc = [&](long long ch) {
+        FetchDesc f;
+        const long long T = ch * CT + w;
+        const bool valid = ch < nchunk && T < p.ntile;
+        const long long Tc = valid ? T : 0;
+        const int tx = (int)(Tc % p.TX);
+        const long long r = Tc / p.TX;
+        const int ty = (int)(r % p.TY), n = (int)(r / p.TY);
+        const float* xb = p.x + g * p.x_gs + cib * 64 + (((long long)n * p.H + 4 * ty - 1) * p.W + 4 * tx - 1) * p.Cin;
+        const float* yb = p.dy + g * p.dy_gs + cb * 64 + (((long long)n * p.H + 4 * ty) * p.W + 4 * tx) * p.Cout;
+        f.rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, 0x7fffffff, 0x00020000);
+        f.ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(yb), 0, 0x7fffffff, 0x00020000);
+        // zero padding (and chunks past the end) by ADDRESS: an offset beyond the descriptor's range returns 0.  Nine offsets pinned in registers once per
+        // chunk (conv_wino4b.hip's edge offsets): a select or a move in front of every load made the compiler wait for the loads in flight (its temporaries
+        // reuse the loads' destination registers) in the middle of the matrix phase
+        const bool top = ty == 0, bot = ty == p.TY - 1, left = tx == 0, right = tx == p.TX - 1;
+        const unsigned oor = 0x80000000u;
+#pragma unroll
+        for (int rc = 0; rc < 3; ++rc)
+#pragma unroll
+            for (int qc = 0; qc < 3; ++qc) {
+                const bool out = !valid || (rc == 0 && top) || (rc == 2 && bot) || (qc == 0 && left) || (qc == 2 && right);  // wave-uniform
+                f.xo[rc][qc] = out ? oor : voff;
+                asm volatile("" : "+v"(f.xo[rc][qc]));
+            }
+        f.yo = valid ? voff : oor;
+        asm volatile("" : "+v"(f.yo));
+        return f;
+    };
+#ifndef WW_LPP
+#define WW_LPP 9  // loads behind each of the first six positions of the matrix phase; the last three cover the tail's latency (6 / 7 / 8 / 9 / 10 / 11 / 13 / 26 per position: 20.4 / 19.6 / 19.4 / 19.4 / 19.4 / 19.5 / 20.0 / 20.7 ms per step; one load behind every matrix instruction: 19.2; two: 20.3; all 52 in front of the barrier, round 5's first form: 23.1)
+#endif
+    auto fetch_part = [&](const FetchDesc& f, int part) __attribute__((always_inline)) {  // loads 6 part .. 6 part + 5 of the 52 (patch first, then the gradients)
+#pragma unroll
+        for (int l = 0; l < 52; ++l) {
+            if (l / WW_LPP != part) continue;
+            if (l < 36) {
+                const int i = l / 6, j = l % 6;
+                rd[l] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(f.rx, (int)f.xo[i == 0 ? 0 : i == 5 ? 2 : 1][j == 0 ? 0 : j == 5 ? 2 : 1], i * xrow + j * xpix, 0));
+            } else {
+                const int i = (l - 36) / 4, j = (l - 36) % 4;
+                ry[l - 36] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(f.ry, (int)f.yo, i * yrow + j * ypix, 0));
+            }
+        }
+    };
     // write position of (local position xi, this thread's tile w and channel lane): [xi][pair w >> 1][channel][w & 1]
     const int wpos = ((w >> 1) * 64 + lane) * 2 + (w & 1);
     auto estage = [&](int buf) {
@@ -183,7 +236,7 @@ __device__ __forceinline__ void wgrad_wino_body(const WwParams& p, float* lds, i
             o[5 * 512] = z3;
         }
     };
-    auto mstage = [&](int buf) {
+    auto mstage = [&](int buf, const FetchDesc& nf, bool nf_on) __attribute__((always_inline)) {
 #ifdef WW_ABL_NOM
         if (buf >= 0 && rd[0] != 1.2345e-30f) return;
 #endif
@@ -192,8 +245,13 @@ __device__ __forceinline__ void wgrad_wino_body(const WwParams& p, float* lds, i
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int xi = 9 * gq + i;
+#ifdef WW_ABL_NOLDSR  // ablation: the matrix phase without its operand reads (do LDS returns and global-load returns share a path?)
+            f32x2 a0 = {(float)xi, 1.f}, a1 = {2.f, (float)lane}, b0 = {3.f, (float)i}, b1 = {(float)buf, 4.f};
+            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+#else
             const f32x2 a0 = *reinterpret_cast<const f32x2*>(Zl + xi * 512), a1 = *reinterpret_cast<const f32x2*>(Zl + xi * 512 + 32);
             const f32x2 b0 = *reinterpret_cast<const f32x2*>(Vl + xi * 512), b1 = *reinterpret_cast<const f32x2*>(Vl + xi * 512 + 32);
+#endif
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 acc[i][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[j], acc[i][0][0], 0, 0, 0);
@@ -201,19 +259,41 @@ __device__ __forceinline__ void wgrad_wino_body(const WwParams& p, float* lds, i
                 acc[i][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b0[j], acc[i][1][0], 0, 0, 0);
                 acc[i][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], acc[i][1][1], 0, 0, 0);
             }
+#ifndef WW_ABL_NOLOAD
+            if (nf_on) fetch_part(nf, i);
+#endif
         }
     };
 
     // Waves 0-3 (X) and 4-7 (Y) share the four SIMDs pairwise.  X: M(i) E(i+1) | M(i+1) E(i+2) | ...   Y: E(i+1) M(i) | E(i+2) M(i+1) | ...  ( | = barrier):
     // between two barriers X's matrix phase runs beside Y's element-wise phase and vice versa.  E(k) writes buffer k & 1, M(k) reads it; every E(k) lies
     // between barrier k - 2 and barrier k - 1, every M(k) between k - 1 and k: no buffer is read and written in the same interval.
+    const long long S = p.slices;
+    long long ch = slice;  // chunk i of this slice = slice + i * S
+#ifndef WW_BULK_FETCH
+    // M(i) with the loads of chunk i + 1 between its matrix instructions -> E(i + 1) -> barrier
+    if (ch < nchunk) {
+        fetch(ch);
+        estage(0);
+    }
+    __syncthreads();
+    {
+        int buf = 0;
+        for (; ch < nchunk; ch += S) {
+            const bool more = ch + S < nchunk;
+            const FetchDesc nf = fetch_desc(ch + S);
+            mstage(buf, nf, more);
+            if (more) estage(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+#else
 #ifdef WW_SKEW
     const bool grpY = w >= 4;
 #else
     const bool grpY = false;  // measured (profiles/r05_wgrad_wino_ablations.txt): all eight waves in X order 4.42 ms, skewed 4.75 ms on the 448^2 level
 #endif
-    const long long S = p.slices;
-    long long ch = slice;  // chunk i of this slice = slice + i * S
     if (ch < nchunk) {
         fetch(ch);
         estage(0);
@@ -226,7 +306,7 @@ __device__ __forceinline__ void wgrad_wino_body(const WwParams& p, float* lds, i
     }
     int buf = 0;
     for (; ch < nchunk; ch += S) {
-        mstage(buf);
+        mstage(buf, fetch_desc(nchunk), false);
         if (!grpY && ch + S < nchunk) {
             estage(buf ^ 1);
             if (ch + 2 * S < nchunk) fetch(ch + 2 * S);
@@ -238,6 +318,7 @@ __device__ __forceinline__ void wgrad_wino_body(const WwParams& p, float* lds, i
         }
         buf ^= 1;
     }
+#endif
     // ---- this slice's partial dU: part[slice][tile][xi 36][co 64][ci 64]; D[co 4 kq + e][ci c] ----------------------------------------------
     float* o = p.part + ((long long)slice * tiles + tile) * 36 * 4096 + (long long)(18 * HALF + 9 * gq) * 4096;
 #pragma unroll
