@@ -1458,12 +1458,20 @@ hipError_t cerb_launch_adam_multi(int count, float* const* p, const float* const
         if (dev_tab) (void)hipFree(dev_tab);
         if ((e = hipMalloc(&dev_tab, need * 2)) != hipSuccess) return e;
         dev_bytes = need * 2;
+        host.clear();
     }
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;  // the previous step's launch has consumed the table
-    host.resize(need);
-    memcpy(host.data(), tt.data(), tt.size() * sizeof(AdamTensor));
-    memcpy(host.data() + tb, ch.data(), ch.size() * sizeof(int2));
-    if ((e = hipMemcpyAsync(dev_tab, host.data(), need, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+    // the optimiser's tensors are the same pointers every step: the table is uploaded only when it differs from the one on the device (as
+    // cerb_launch_copy_multi does).  Round 4 synchronised the stream and uploaded it every step -- the host stood still until the whole backward pass
+    // had drained and the device then waited for the host to queue the optimiser, the running statistics and the re-pack.
+    std::vector<char> now(need);
+    memcpy(now.data(), tt.data(), tt.size() * sizeof(AdamTensor));
+    memcpy(now.data() + tb, ch.data(), ch.size() * sizeof(int2));
+    if (now != host) {
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;  // an earlier launch may still be reading the old table
+        host.swap(now);
+        if ((e = hipMemcpyAsync(dev_tab, host.data(), need, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;  // `host` may be rebuilt by the next call
+    }
     const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)ch.size()), dim3(256), 0, st, (const AdamTensor*)dev_tab, (const int2*)((const char*)dev_tab + tb), lr, b1,
                        b2, eps, bc1, bc2);
