@@ -355,7 +355,7 @@ _TRAIN_SYMBOLS = {
     "conv_wino4b<f4x4,16x16>": ["conv_wino4b_kernel<false, true, false>"], "dgrad:conv_wino4b<f4x4,16x16>": ["conv_wino4b_kernel<false, false, false>", "conv_wino4b_kernel<true, false, false>"],
     "conv_wino4b<f4x4,16t>": ["conv_wino4b_kernel<false, true, true>"], "dgrad:conv_wino4b<f4x4,16t>": ["conv_wino4b_kernel<false, false, true>", "conv_wino4b_kernel<true, false, true>"],
     "head_fwd1": ["head_fwd1_kernel"], "head_fwd2": ["head_fwd2_kernel"], "head_bwd1": ["head_bwd1_kernel"], "head_bwd2": ["head_bwd2_kernel"],
-    "upadd_bwd": ["upadd_bwd_fused_kernel"], "upsample2_add": ["upsample2_add_kernel"], "maxpool_bwd": ["maxpool_bwd_kernel"], "maxpool3x3s2": ["maxpool3x3s2_kernel"],
+    "upadd_bwd": ["upadd_bwd_fused_kernel"], "upsample2_add": ["upsample2_add_kernel"], "maxpool_bwd": ["maxpool_bwd_kernel", "maxpool_bwd_idx_kernel"], "maxpool3x3s2": ["maxpool3x3s2_kernel", "maxpool3x3s2_idx_kernel"],
     "stem_wgrad": ["stem_wgrad_mfma_kernel"], "stem_conv7x7": ["stem_conv7x7_kernel"],
 }
 
