@@ -24,6 +24,7 @@
 // Bias gradient (sum of dy over the pixels) rides along in the element-wise phase of the (ci block 0, half 0) workgroups.
 #include "cerb_common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 constexpr int CT = 8;                        // tiles per chunk
@@ -165,7 +166,7 @@ __device__ __forceinline__ void wgrad_wino_body(const WwParams& p, float* lds, i
     };
     // write position of (local position xi, this thread's tile w and channel lane): [xi][pair w >> 1][channel][w & 1]
     const int wpos = ((w >> 1) * 64 + lane) * 2 + (w & 1);
-    auto estage = [&](int buf) {
+    auto estage = [&](int buf, const float (&ryv)[16]) __attribute__((always_inline)) {
         float* Zl = lds + buf * BUF;
         float* Vl = Zl + OPER;
 #ifdef WW_ABL_NOE
@@ -174,7 +175,7 @@ __device__ __forceinline__ void wgrad_wino_body(const WwParams& p, float* lds, i
         if (want_bias) {
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) s += ry[k];
+            for (int k = 0; k < 16; ++k) s += ryv[k];
             bsum += s;
         }
         // ---- V = B^T d B, rows 3 HALF .. 3 HALF + 2: the row pass (down each column) first, then the full column pass on those three rows ----
@@ -210,7 +211,7 @@ __device__ __forceinline__ void wgrad_wino_body(const WwParams& p, float* lds, i
         float zm[3][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float y0 = ry[j], y1 = ry[4 + j], y2 = ry[8 + j], y3 = ry[12 + j];
+            const float y0 = ryv[j], y1 = ryv[4 + j], y2 = ryv[8 + j], y3 = ryv[12 + j];
             if (HALF == 0) {
                 const float s = y0 + y2, t = y1 + y3;
                 zm[0][j] = y0;
@@ -236,7 +237,7 @@ __device__ __forceinline__ void wgrad_wino_body(const WwParams& p, float* lds, i
             o[5 * 512] = z3;
         }
     };
-    auto mstage = [&](int buf, const FetchDesc& nf, bool nf_on) __attribute__((always_inline)) {
+    auto mstage = [&](int buf, auto&& hook) __attribute__((always_inline)) {
 #ifdef WW_ABL_NOM
         if (buf >= 0 && rd[0] != 1.2345e-30f) return;
 #endif
@@ -260,7 +261,7 @@ __device__ __forceinline__ void wgrad_wino_body(const WwParams& p, float* lds, i
                 acc[i][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], acc[i][1][1], 0, 0, 0);
             }
 #ifndef WW_ABL_NOLOAD
-            if (nf_on) fetch_part(nf, i);
+            hook(i);
 #endif
         }
     };
@@ -271,10 +272,11 @@ __device__ __forceinline__ void wgrad_wino_body(const WwParams& p, float* lds, i
     const long long S = p.slices;
     long long ch = slice;  // chunk i of this slice = slice + i * S
 #ifndef WW_BULK_FETCH
-    // M(i) with the loads of chunk i + 1 between its matrix instructions -> E(i + 1) -> barrier
+    // M(i) with the loads of chunk i + 1 between its matrix instructions -> E(i + 1) -> barrier.  (Tried: the 16 gradient loads one MORE chunk ahead in a second
+    // register set, so that E waits for the 36 patch loads only -- 18.7 -> 20.6 ms per step, slower; scheduling barriers around the loads: no difference.)
     if (ch < nchunk) {
         fetch(ch);
-        estage(0);
+        estage(0, ry);
     }
     __syncthreads();
     {
@@ -282,8 +284,8 @@ __device__ __forceinline__ void wgrad_wino_body(const WwParams& p, float* lds, i
         for (; ch < nchunk; ch += S) {
             const bool more = ch + S < nchunk;
             const FetchDesc nf = fetch_desc(ch + S);
-            mstage(buf, nf, more);
-            if (more) estage(buf ^ 1);
+            mstage(buf, [&](int i) __attribute__((always_inline)) { if (more) fetch_part(nf, i); });
+            if (more) estage(buf ^ 1, ry);
             __syncthreads();
             buf ^= 1;
         }
@@ -296,24 +298,24 @@ __device__ __forceinline__ void wgrad_wino_body(const WwParams& p, float* lds, i
 #endif
     if (ch < nchunk) {
         fetch(ch);
-        estage(0);
+        estage(0, ry);
         if (ch + S < nchunk) fetch(ch + S);
     }
     __syncthreads();
     if (grpY && ch + S < nchunk) {
-        estage(1);
+        estage(1, ry);
         if (ch + 2 * S < nchunk) fetch(ch + 2 * S);
     }
     int buf = 0;
     for (; ch < nchunk; ch += S) {
-        mstage(buf, fetch_desc(nchunk), false);
+        mstage(buf, [](int) {});
         if (!grpY && ch + S < nchunk) {
-            estage(buf ^ 1);
+            estage(buf ^ 1, ry);
             if (ch + 2 * S < nchunk) fetch(ch + 2 * S);
         }
         __syncthreads();
         if (grpY && ch + 2 * S < nchunk) {
-            estage(buf);
+            estage(buf, ry);
             if (ch + 3 * S < nchunk) fetch(ch + 3 * S);
         }
         buf ^= 1;
@@ -351,18 +353,18 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(WwParams p, int npair) 
     else wgrad_wino_body<1>(p, lds, pair);
 }
 
-// dw[g][co][ci][ky][kx] = G^T (sum over slices of dU) G.  Workgroup = (tile, co, 16 ci): thread = (slice group sg of 16, ci); a thread adds the slices
-// sg, sg + 16, .. in order, the 16 groups meet in LDS and are added in group order (fixed order: reproducible), 16 threads apply G^T . G.
-// (The first version ran one thread per (co, ci) over ALL slices: 16 workgroups for a 64 -> 64 layer with 128 slices, 40 us per launch, 1.4 ms per step.)
+// dw[g][co][ci][ky][kx] = G^T (sum over slices of dU) G.  Workgroup = (tile, co): thread = (slice group sg of 4, ci of 64) -- a wave reads whole 256-byte rows of a
+// partial; a thread adds the slices sg, sg + 4, .. in order, the four groups meet in LDS and are added in group order (fixed order: reproducible), 64 threads apply G^T . G.
+// (First version: one thread per (co, ci) over ALL slices, 40 us per launch; second: 16 groups x 16 ci, 64-byte pieces, 1.47 ms per step over the 37 launches.)
 __global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int G, int Cin, int Cout, int slices) {
-    __shared__ float red[16][36][16];
+    __shared__ float red[4][36][64];
     const int ncb = Cout >> 6, ncib = Cin >> 6, tiles = G * ncb * ncib;
-    const int cq = blockIdx.x & 3, co = (blockIdx.x >> 2) & 63, tile = blockIdx.x >> 8;
-    const int sg = threadIdx.x >> 4, cl = threadIdx.x & 15, ci = 16 * cq + cl;
+    const int co = blockIdx.x & 63, tile = blockIdx.x >> 6;
+    const int sg = threadIdx.x >> 6, cl = threadIdx.x & 63, ci = cl;
     float u[36];
 #pragma unroll
     for (int xi = 0; xi < 36; ++xi) u[xi] = 0.f;
-    for (int s = sg; s < slices; s += 16) {
+    for (int s = sg; s < slices; s += 4) {
         const float* src = part + ((long long)s * tiles + tile) * 36 * 4096 + co * 64 + ci;
 #pragma unroll
         for (int xi = 0; xi < 36; ++xi) u[xi] += src[xi * 4096];
@@ -372,11 +374,7 @@ __global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const float* __r
     __syncthreads();
     if (sg != 0) return;
 #pragma unroll
-    for (int xi = 0; xi < 36; ++xi) {
-        float a = red[0][xi][cl];
-        for (int k = 1; k < 16; ++k) a += red[k][xi][cl];
-        u[xi] = a;
-    }
+    for (int xi = 0; xi < 36; ++xi) u[xi] = ((red[0][xi][cl] + red[1][xi][cl]) + red[2][xi][cl]) + red[3][xi][cl];
     // t[x][b] = sum_a G[a][x] u[a][b];  dg[x][y] = sum_b t[x][b] G[b][y]
     float t[3][6];
 #pragma unroll
@@ -435,7 +433,7 @@ hipError_t cerb_launch_wgrad_wino(const float* x, const float* dy, float* dw, in
     const int npair = tiles * p.slices;
     const dim3 grid((unsigned)(((npair + 7) / 8) * 16));
     hipLaunchKernelGGL(wgrad_wino_kernel, grid, dim3(512), WW_LDS_BYTES, st, p, npair);
-    hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3((unsigned)(tiles * 256)), dim3(256), 0, st, (const float*)ws, dw, G, Cin, Cout, p.slices);
+    hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3((unsigned)(tiles * 64)), dim3(256), 0, st, (const float*)ws, dw, G, Cin, Cout, p.slices);
     if (db) (void)cerb_launch_slab_sum(p.part_b, db, G * Cout, p.slices, 1, st);
     return hipGetLastError();
 }
