@@ -558,10 +558,10 @@ def test_winograd_partial_tiles_and_odd_blocks_vs_direct(full_model, win, osz, n
         m.set_conv_algo(DEFAULT_ALGO)
 
 
-@pytest.mark.parametrize("win,osz,n", [(448, 448, 3), (448, 144, 2), (224, 224, 5), (208, 80, 2), (240, 240, 3), (160, 160, 7), (256, 256, 2)])
+@pytest.mark.parametrize("win,osz,n", [(448, 448, 3), (448, 144, 2), (224, 224, 5), (208, 80, 2), (240, 240, 3), (160, 160, 7), (176, 176, 5), (112, 112, 9), (256, 256, 2)])
 def test_packed_items_are_bit_identical_to_block_items(full_model, win, osz, n):
     """cerb_net_set_packed_items(1) (default): on maps whose sides are multiples of 4 but not of 16 -- the 56^2 / 28^2 maps of the reference's 448-pixel
-    patch, 52^2 of a 208-pixel one, 60^2 of 240, 40^2 / 20^2 of 160 -- conv_wino4b takes 16 CONSECUTIVE tiles of the batch per work item instead of a
+    patch, 52^2 of a 208-pixel one, 60^2 of 240, 40^2 / 20^2 of 160, 44^2 of 176, 28^2 of 112 -- conv_wino4b takes 16 CONSECUTIVE tiles of the batch per work item instead of a
     16 x 16-pixel block with padding tiles (3 x 49 tiles = 9 items + 3 tiles: the last item runs with 13 empty tiles).  A tile's arithmetic does not
     depend on the item it rides in: every head's output must be BITWISE equal to the block form's -- residual layers, grouped decoder launches,
     centre crops (the cropped decoder launches stay on blocks) and a different batch in between included.  256-pixel tiles have no such map: the
