@@ -298,7 +298,17 @@ struct cerb_net {
     // reports in conv_bn_bpg how many blocks per group it wrote (0: this convolution's kernel does not produce them)
     double* conv_bn_part = nullptr;
     int conv_bn_bpg = 0;
+    // training backward: the weight gradients of the 3x3 / 1x1 convolutions run on a side stream of the handle's own (forked from the caller's stream when the
+    // layer's output gradient is final, joined at the end of cerb_net_train_grads): matrix-core work that overlaps the BatchNorm backward passes (HBM-bound, no
+    // LDS) and fills the last-round tails of the data-gradient launches.  Same kernels, same arithmetic.  CERB_WGRAD_SIDE=0 / profiling: everything on one stream.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    DevBuf t_ws2;  // the side stream's split-K workspace
     ~cerb_net() {
+        if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        t_ws2.release();
         for (auto& r : prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         for (void* p : dev_allocs) (void)hipFree(p);
         if (copy_tab) (void)hipFree(copy_tab);
@@ -1447,6 +1457,22 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         return p;
     };
     const int saved_algo = net->conv_algo;
+    // side stream of the weight gradients (see cerb_net::side): off under per-launch profiling (the records time one stream) and with CERB_WGRAD_SIDE=0
+    bool side_wgrad = !net->profiling;
+    {
+        const char* e = getenv("CERB_WGRAD_SIDE");
+        if (e && e[0] == '0') side_wgrad = false;
+    }
+    bool side_used = false;
+    if (side_wgrad && !net->side) {
+        HIP_OK(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
+    }
+    if (net->side) {  // whatever an earlier call left on the side stream (a call that failed half way) is complete before this call's tape is written
+        HIP_OK(hipEventRecord(net->ev_join, net->side));
+        HIP_OK(hipStreamWaitEvent(st, net->ev_join, 0));
+    }
     std::map<int, std::pair<double*, int>> conv_stats;  // conv output tensor -> (statistics partials, blocks per group)
     const bool bn_stats_pass = getenv("CERB_BN_STATS_PASS") != nullptr;  // developer A/B: the separate statistics pass (read once per step)
     // ---------------------------------------------------------------- forward, recorded ----------------------------------------
@@ -1787,6 +1813,21 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
             case 1: {
                 const cerb_net::RawW& r = net->raw[op.name];
                 const size_t wn = (size_t)op.Cout * op.Cin * op.ks * op.ks;
+                // which weight-gradient kernel this layer takes, decided up front: its workspace is sized and the side stream forked BEFORE the data gradient is queued
+                const bool wg_wino = op.ks == 3 && op.stride == 1 && net->conv_algo >= 5 && cerb_wgrad_wino_supported(op.H, op.W, op.Cin, op.Cout) && !getenv("CERB_WGRAD_DIRECT");
+                const bool wg_mfma = !wg_wino && (op.ks == 3 || op.ks == 1) && net->conv_algo;
+                hipStream_t wst = st;        // the stream the weight gradient is queued on
+                DevBuf* wws = &net->t_ws;    // ... and its workspace
+                if (side_wgrad && (wg_wino || wg_mfma)) {
+                    const int ho_ = op.stride == 2 ? op.H / 2 : op.H, wo_ = op.stride == 2 ? op.W / 2 : op.W;
+                    const size_t need = wg_wino ? cerb_wgrad_wino_workspace_bytes(op.G, op.N, op.H, op.W, op.Cin, op.Cout) : cerb_wgrad_workspace_bytes(op.G, op.N, ho_, wo_, op.Cin, op.Cout, op.ks, nullptr);
+                    if (net->t_ws2.ensure(need, 0)) return fail("workspace allocation failed");
+                    HIP_OK(hipEventRecord(net->ev_fork, st));  // the layer's output gradient (and a fresh workspace's fill) is complete on the caller's stream
+                    HIP_OK(hipStreamWaitEvent(net->side, net->ev_fork, 0));
+                    wst = net->side;
+                    wws = &net->t_ws2;
+                    side_used = true;
+                }
                 // the MFMA weight gradient (wgrad_reduce_kernel) and the bias column sums ASSIGN their outputs: no zero fill (a step issued
                 // ~230 of these 18-us memsets: 4 ms)
                 const bool dw_assigned = (op.ks == 3 || op.ks == 1) && net->conv_algo;
@@ -1852,23 +1893,23 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 bool dw_done = false, db_done = false;
                 // 3x3 stride 1 on whole 64-channel blocks: the weight gradient in the Winograd domain (conv_wgrad_wino.hip: a quarter of the matrix
                 // instructions of the direct form); CERB_WGRAD_DIRECT=1 keeps round 4's direct kernel everywhere (A/B, tests)
-                if (op.ks == 3 && op.stride == 1 && net->conv_algo >= 5 && cerb_wgrad_wino_supported(op.H, op.W, op.Cin, op.Cout) && !getenv("CERB_WGRAD_DIRECT")) {
-                    if (net->t_ws.ensure(cerb_wgrad_wino_workspace_bytes(op.G, op.N, op.H, op.W, op.Cin, op.Cout), 0)) return fail("workspace allocation failed");
+                if (wg_wino) {
+                    if (wws->ensure(cerb_wgrad_wino_workspace_bytes(op.G, op.N, op.H, op.W, op.Cin, op.Cout), 0)) return fail("workspace allocation failed");
                     if (prof_begin(net, op.name + ".wgrad", "wgrad_wino4<f4x4>", 2.0 * op.G * op.N * op.H * op.W * (double)op.Cin * op.Cout * 9.0, st)) return 1;
-                    HIP_OK(cerb_launch_wgrad_wino(val[op.a], go, dw, op.G, op.N, op.H, op.W, op.Cin, op.Cout, op.a_gs, net->t_ws.p, st, db));
+                    HIP_OK(cerb_launch_wgrad_wino(val[op.a], go, dw, op.G, op.N, op.H, op.W, op.Cin, op.Cout, op.a_gs, wws->p, wst, db));
                     if (prof_end(net, st)) return 1;
                     dw_done = true;
                     if (db) db_done = true;
                 }
-                if (!dw_done && (op.ks == 3 || op.ks == 1) && net->conv_algo) {  // weight gradient on the matrix cores
+                if (!dw_done && wg_mfma) {  // weight gradient on the matrix cores
                     const int ho = op.stride == 2 ? op.H / 2 : op.H, wo = op.stride == 2 ? op.W / 2 : op.W;
-                    if (net->t_ws.ensure(cerb_wgrad_workspace_bytes(op.G, op.N, ho, wo, op.Cin, op.Cout, op.ks, nullptr), 0)) return fail("workspace allocation failed");
+                    if (wws->ensure(cerb_wgrad_workspace_bytes(op.G, op.N, ho, wo, op.Cin, op.Cout, op.ks, nullptr), 0)) return fail("workspace allocation failed");
                     // `flops` field: executed MFMA FLOPs of the weight gradient (2 x outputs x taps x Cin x Cout)
                     if (prof_begin(net, op.name + ".wgrad", "wgrad<ks" + std::to_string(op.ks) + ",s" + std::to_string(op.stride) + ">",
                                    2.0 * op.G * op.N * ho * wo * (double)op.Cin * op.Cout * op.ks * op.ks, st)) return 1;
                     // the bias gradient (sums of dy over the pixels) rides inside the same pass when the channel count allows
                     const bool db_in_wgrad = db && op.Cout % 64 == 0;
-                    HIP_OK(cerb_launch_wgrad(val[op.a], go, dw, op.G, op.N, op.H, op.W, op.Cin, op.Cout, op.ks, op.stride, op.a_gs, net->t_ws.p, st, db_in_wgrad ? db : nullptr));
+                    HIP_OK(cerb_launch_wgrad(val[op.a], go, dw, op.G, op.N, op.H, op.W, op.Cin, op.Cout, op.ks, op.stride, op.a_gs, wws->p, wst, db_in_wgrad ? db : nullptr));
                     if (prof_end(net, st)) return 1;
                     dw_done = true;
                     if (db_in_wgrad) db_done = true;
@@ -2095,6 +2136,10 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
 #undef PROF
 #undef PROFN
     net->conv_algo = saved_algo;
+    if (side_used) {  // the caller's stream continues (optimiser, all-reduce, the next step's tape) once the side stream's weight gradients are complete
+        HIP_OK(hipEventRecord(net->ev_join, net->side));
+        HIP_OK(hipStreamWaitEvent(st, net->ev_join, 0));
+    }
     return 0;
 }
 

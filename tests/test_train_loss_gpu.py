@@ -775,3 +775,52 @@ def test_maxpool_backward_by_recorded_positions_equals_the_scan(gold):
         assert la == lb and set(ga) == set(gb)
         for k in ga:
             assert np.array_equal(ga[k], gb[k]), k
+
+
+@pytest.mark.gpu
+def test_weight_gradients_on_the_side_stream_equal_the_single_stream_step(gold):
+    """Round 5: the backward pass queues the weight gradients of the 3x3 / 1x1 convolutions on a side stream of the handle (forked when a layer's output gradient is
+    final, joined at the end of cerb_net_train_grads) so that they overlap the BatchNorm backward passes; CERB_WGRAD_SIDE=0 keeps everything on the caller's stream.
+    Same kernels on the same data: every gradient, statistic and loss must be BITWISE equal, step after step (the second step re-uses the tape arena and the side
+    stream's workspace while nothing may still be in flight), on the 64-pixel fixture batch and on a 448-pixel batch."""
+    import os
+
+    from cerberus_amd.net_desc import create_model
+    from cerberus_amd.weights import default_model_kwargs, make_state_dict
+
+    tiles = torch.from_numpy(gold["img"]).cuda()
+    keep = torch.from_numpy(gold["step/dropout_mask"].reshape(int(gold["N"]), 512)).cuda()
+    targets, flags = {}, {}
+    for j, h in enumerate(gold["heads"]):
+        h = str(h)
+        t = gold["target/" + h][..., 0]
+        targets[h] = torch.from_numpy(t.reshape(t.shape[0]) if h == "Patch-Class" else t).cuda()
+        flags[h] = torch.from_numpy(gold["has_target"][:, j].astype(np.float32)).cuda()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    n2, win = 2, 448
+    big = {"tiles": torch.randint(0, 256, (n2, win, win, 3), dtype=torch.uint8, device="cuda", generator=g), "targets": {}, "flags": {},
+           "keep": torch.rand((n2, 512), device="cuda", generator=g) < 0.7}
+    for h, c in {"Lumen-INST": 3, "Gland-INST": 3, "Nuclei-INST": 3, "Nuclei-TYPE": 7, "Gland-TYPE": 3, "Patch-Class": 9}.items():
+        big["targets"][h] = torch.randint(0, c, (n2,), device="cuda", generator=g).float() if h == "Patch-Class" else \
+            ((torch.rand((n2, win, win), device="cuda", generator=g) < 0.3) * torch.randint(1, c, (n2, win, win), device="cuda", generator=g)).float()
+        big["flags"][h] = torch.ones(n2, device="cuda")
+    out = {}
+    for mode in ("side", "single"):
+        if mode == "single":
+            os.environ["CERB_WGRAD_SIDE"] = "0"
+        try:
+            m = create_model(**default_model_kwargs())
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(int(gold["weight_seed"])).items()}, strict=True)
+            res = []
+            for rep in range(2):
+                for (tl, tg, fl, kp) in ((tiles, targets, flags, keep), (big["tiles"], big["targets"], big["flags"], big["keep"])):
+                    losses, grads = m.train_grads(tl, tg, fl, PARAMSET_LOSS, kp)
+                    res.append((losses, {k: (v.detach().cpu().numpy().copy() if torch.is_tensor(v) else np.array(v)) for k, v in grads.items()}))
+            out[mode] = res
+        finally:
+            os.environ.pop("CERB_WGRAD_SIDE", None)
+    assert len(out["side"]) == 4
+    for (la, ga), (lb, gb) in zip(out["side"], out["single"]):
+        assert la == lb and set(ga) == set(gb)
+        for k in ga:
+            assert np.array_equal(ga[k], gb[k]), k
