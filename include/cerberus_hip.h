@@ -279,6 +279,10 @@ typedef struct cerb_train_step_io {
     const float* const* pixel_weight; /* NULL, or per decoder NULL / device float [n][h][w]: the head's "#WEIGHT-MAP" target
                                          (models/run_desc.py:111-117), see cerb_head_loss_wmap */
 } cerb_train_step_io;
+/* Streams: everything is ordered on `hip_stream` as the caller sees it.  Inside, the weight gradients of the convolutions are queued on a second stream that
+ * the handle owns -- forked from `hip_stream` by an event when a layer's output gradient is final, joined back into `hip_stream` before the call returns -- so work
+ * the caller queues on `hip_stream` afterwards (optimiser, all-reduce, the next step) sees every gradient complete.  Not capturable into a hipGraph with the side
+ * stream on; CERB_WGRAD_SIDE=0 keeps the call on `hip_stream` alone (same bits). */
 int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io, void* hip_stream);
 int cerb_net_grad_lookup(cerb_net* net, const char* key, float** dev_ptr, long long* numel);
 /* The same lookup also serves the batch statistics of every BatchNorm of the step under "<bn prefix>.batch_mean" and
