@@ -581,7 +581,7 @@ bool cerb_wino4b_packed(const ConvParams& p) {
     if (p.Ho % 4 || p.Wo % 4 || (p.Ho % 16 == 0 && p.Wo % 16 == 0)) return false;
     if (p.roi_y1 > p.roi_y0 && p.roi_x1 > p.roi_x0) return false;
     const long long px = (long long)p.N * p.Ho * p.Wo;
-    return px * p.Cin * 4 < 0x7fffffffll && px * p.Cout * 4 < 0x7fffffffll;
+    return (px + p.W + 1) * p.Cin * 4 < 0x7f000000ll && px * p.Cout * 4 < 0x7f000000ll;  // (the input's base sits one row + one pixel early)
 }
 // blocks per group of the BatchNorm partials the kernel leaves (ConvParams::bn_part): what cerb_api.hip sizes the buffer by and the finalize kernel walks
 int cerb_wino4b_bn_blocks(const ConvParams& p) {
