@@ -223,13 +223,30 @@ def _raw_payload(img, targets, logits, has):
         p = torch.squeeze(p)
         if "TYPE" in key:
             p = torch.argmax(p, dim=-1, keepdim=False)
-        pred[key] = p.detach().cpu().numpy()
+        pred[key] = p.detach()
         t = targets[key][idx.to(targets[key].device)]
         t = t.reshape(2, 1, 1, 1) if key == "Patch-Class" else t.reshape(2, h, w, 1)
         if key == "Patch-Class" or pc_in_targets:
             t = F.interpolate(t.permute(0, 3, 1, 2).float(), size=(h, w), mode="nearest").permute(0, 2, 3, 1)
-        true[key] = torch.squeeze(t).detach().cpu().numpy()
-    return {"img": img[idx].to(torch.uint8).cpu().numpy(), "true": true, "pred": pred}
+        true[key] = torch.squeeze(t).detach()
+    out = {"img": img[idx.to(img.device)].to(torch.uint8), "true": true, "pred": pred}
+    # 13 arrays, ~30 MB at batch 16 x 448^2: every device tensor goes to a fresh PINNED host tensor without a wait in between and the host waits once (thirteen
+    # `.cpu()` calls were thirteen waits and pageable copies: ~2 ms of a 98 ms step with the device idle).  The numpy arrays keep their pinned tensors alive.
+    pend = []
+    for d in (out, true, pred):
+        for k, v in list(d.items()):
+            if torch.is_tensor(v) and v.is_cuda:
+                hbuf = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                hbuf.copy_(v.contiguous(), non_blocking=True)
+                pend.append((d, k, hbuf, v.device))
+            elif torch.is_tensor(v):
+                d[k] = v.contiguous().numpy()
+    if pend:
+        for dev in set(e[3] for e in pend):
+            torch.cuda.current_stream(dev).synchronize()
+        for d, k, hbuf, _ in pend:
+            d[k] = hbuf.numpy()
+    return out
 
 
 def _eval_twin(model):
