@@ -1441,9 +1441,17 @@ hipError_t cerb_launch_copy_multi(int count, float* const* dst, const float* con
 // tables live in one device buffer that grows on demand and is reused by later steps (single optimiser stream assumed, as torch's own)
 hipError_t cerb_launch_adam_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* n, float lr, float b1,
                                   float b2, float eps, int step, hipStream_t st) {
-    static void* dev_tab = nullptr;
-    static size_t dev_bytes = 0;
-    static std::vector<char> host;
+    struct Tab {  // one table per device (a host process may drive several)
+        void* dev = nullptr;
+        size_t bytes = 0;
+        std::vector<char> host;
+    };
+    static Tab tabs[64];
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return hipErrorInvalidDevice;
+    void*& dev_tab = tabs[devid].dev;
+    size_t& dev_bytes = tabs[devid].bytes;
+    std::vector<char>& host = tabs[devid].host;
     std::vector<AdamTensor> tt(count);
     std::vector<int2> ch;
     for (int i = 0; i < count; ++i) {
