@@ -300,7 +300,9 @@ def train_measure(model, dev, dist, world, rank, steps, warmup, backend):
                              "per-launch records (forward, data gradients, weight gradients, BatchNorm, pointwise layers, pooling, up-sampling, losses, zero "
                              "fills), the phases around it (upload, all-reduce, Adam + running statistics, parameter copy + re-pack, visualisation "
                              "payload) are timed between stream events; attributed_ms is their sum, to compare with ms_per_step (the profiled step runs "
-                             "with an event pair around every launch, so it is a few per cent slower than the timed ones)")
+                             "with an event pair around every launch AND on one stream -- the timed steps queue the convolutions' weight gradients on the handle's side "
+                             "stream (CERB_WGRAD_SIDE, default on), where they overlap the BatchNorm backward passes and the data gradients' tails: the "
+                             "timed step is ~5 % shorter than attributed_ms)")
     except Exception as e:  # the profile leg never fails the benchmark line
         roofline = {"error": str(e)[:200]}
     return dt, res, roofline, fam_rows
