@@ -353,9 +353,9 @@ _TRAIN_SYMBOLS = {
     "wgrad<ks3,s1>": ["wgrad_kernel<3, 1>"], "wgrad<ks3,s2>": ["wgrad_kernel<3, 2>"],
     "bn_bwd": ["bn_bwd_partial_kernel", "bn_bwd_apply_kernel", "bn_bwd_finalize_kernel"],
     "bn_fwd": ["bn_apply_kernel", "bn_partial_kernel", "bn_finalize_kernel", "bn_partial_fold_kernel"],
-    "conv_wino4<f4x4,16x16x2>": ["conv_wino4_kernel<false, true>"], "dgrad:conv_wino4<f4x4,16x16x2>": ["conv_wino4_kernel<false, false>", "conv_wino4_kernel<true, false>"],
-    "conv_wino4b<f4x4,16x16>": ["conv_wino4b_kernel<false, true, false>"], "dgrad:conv_wino4b<f4x4,16x16>": ["conv_wino4b_kernel<false, false, false>", "conv_wino4b_kernel<true, false, false>"],
-    "conv_wino4b<f4x4,16t>": ["conv_wino4b_kernel<false, true, true>"], "dgrad:conv_wino4b<f4x4,16t>": ["conv_wino4b_kernel<false, false, true>", "conv_wino4b_kernel<true, false, true>"],
+    "conv_wino4<f4x4,16x16x2>": ["conv_wino4_kernel<false, 1>"], "dgrad:conv_wino4<f4x4,16x16x2>": ["conv_wino4_kernel<false, 0>", "conv_wino4_kernel<true, 0>", "conv_wino4_kernel<false, 2>"],
+    "conv_wino4b<f4x4,16x16>": ["conv_wino4b_kernel<false, 1, false>"], "dgrad:conv_wino4b<f4x4,16x16>": ["conv_wino4b_kernel<false, 0, false>", "conv_wino4b_kernel<true, 0, false>", "conv_wino4b_kernel<false, 2, false>"],
+    "conv_wino4b<f4x4,16t>": ["conv_wino4b_kernel<false, 1, true>"], "dgrad:conv_wino4b<f4x4,16t>": ["conv_wino4b_kernel<false, 0, true>", "conv_wino4b_kernel<true, 0, true>", "conv_wino4b_kernel<false, 2, true>"],
     "head_fwd1": ["head_fwd1_kernel"], "head_fwd2": ["head_fwd2_kernel"], "head_bwd1": ["head_bwd1_kernel"], "head_bwd2": ["head_bwd2_kernel"],
     "upadd_bwd": ["upadd_bwd_fused_kernel"], "upsample2_add": ["upsample2_add_kernel"], "maxpool_bwd": ["maxpool_bwd_kernel", "maxpool_bwd_idx_kernel"], "maxpool3x3s2": ["maxpool3x3s2_kernel", "maxpool3x3s2_idx_kernel"],
     "stem_wgrad": ["stem_wgrad_mfma_kernel"], "stem_conv7x7": ["stem_conv7x7_kernel"],
@@ -367,12 +367,12 @@ HBM_FAMILIES = {"maxpool3x3s2", "maxpool_bwd", "upsample2_add", "upadd_bwd", "cr
 XGMI_LINK_GBS = 153.0   # per peer link, SURVEY.md par.8e
 _SYMBOL = {"conv_wino4p<f4x4,16x16x2,planar>": "void conv_wino4p_kernel<1>(ConvParams)",
            "conv_wino4p<f4x4,16x16x2,planar,half-res>": "void conv_wino4p_kernel<0>(ConvParams)",
-           "conv_wino4b<f4x4,16x16>": "void conv_wino4b_kernel<false, false, false>(ConvParams)",
-           "conv_wino4b<f4x4,16x16,res>": "void conv_wino4b_kernel<true, false, false>(ConvParams)",
-           "conv_wino4b<f4x4,16t>": "void conv_wino4b_kernel<false, false, true>(ConvParams)",
-           "conv_wino4b<f4x4,16t,res>": "void conv_wino4b_kernel<true, false, true>(ConvParams)",
-           "conv_wino4<f4x4,16x16x2>": "void conv_wino4_kernel<false, false>(ConvParams)",
-           "conv_wino4<f4x4,16x16x2,res>": "void conv_wino4_kernel<true, false>(ConvParams)",
+           "conv_wino4b<f4x4,16x16>": "void conv_wino4b_kernel<false, 0, false>(ConvParams)",
+           "conv_wino4b<f4x4,16x16,res>": "void conv_wino4b_kernel<true, 0, false>(ConvParams)",
+           "conv_wino4b<f4x4,16t>": "void conv_wino4b_kernel<false, 0, true>(ConvParams)",
+           "conv_wino4b<f4x4,16t,res>": "void conv_wino4b_kernel<true, 0, true>(ConvParams)",
+           "conv_wino4<f4x4,16x16x2>": "void conv_wino4_kernel<false, 0>(ConvParams)",
+           "conv_wino4<f4x4,16x16x2,res>": "void conv_wino4_kernel<true, 0>(ConvParams)",
            "conv_wino<f2x2,8x16>": "void conv_wino_kernel<false>(ConvParams)",
            "conv_wino<f2x2,8x16,res>": "void conv_wino_kernel<true>(ConvParams)"}
 

@@ -1449,6 +1449,10 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         return grd[t];
     };
     std::vector<TapeOp> tape;
+    // BatchNorm backward sums out of the data gradient that produced the BatchNorm's output gradient (conv_wino4 / conv_wino4b STATS 2): [mean | rstd] tensor of
+    // the BatchNorm -> (partials, blocks per group).  CERB_BN_BWD_PASS1=1 keeps the BatchNorm's own reduction pass (developer A/B).
+    std::map<int, std::pair<double*, int>> bst_part;
+    const bool bst_on = getenv("CERB_BN_BWD_PASS1") == nullptr;
     std::map<int, std::pair<double*, bool>> deferred_part;  // [mean | rstd] tensor of a deferred BatchNorm -> (its backward partials from the heads, still complete?)
     net->grads.clear();
     auto pub = [&](const std::string& key, size_t n) -> float* {  // a published parameter gradient
@@ -1881,6 +1885,36 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                         if (train_wino4_slot(net, op.name, net->conv[op.name], d_w4b ? 1 : 0, 1, st, &w4)) return 1;
                         p.wpack = w4;
                         p.w_gs = (long long)op.Cout * op.Cin * 36;
+                        // Is this data gradient the ONLY writer of the gradient behind a train-mode BatchNorm + ReLU (no residual)?  Then its output stage leaves
+                        // that BatchNorm's backward sums (it reads the BatchNorm's input at its own pixels) and the BatchNorm's reduction pass does not run.
+                        if (bst_on && fresh && op.stride == 1) {
+                            int n_read = 0, bi = -1;
+                            for (size_t k = 0; k < tape.size(); ++k) {
+                                const TapeOp& o2 = tape[k];
+                                if (o2.a == op.a || o2.b == op.a) ++n_read;
+                                if (o2.type == 2 && o2.o == op.a && o2.o != o2.a) bi = (int)k;
+                            }
+                            if (bi >= 0 && n_read == 1) {
+                                const TapeOp& bo = tape[bi];
+                                const cerb_net::BnDev& bb = net->bn[bo.name];
+                                bool any_eval = false;
+                                for (size_t g = 0; g < bb.eval.size(); ++g) any_eval = any_eval || bb.eval[g];
+                                if (bo.relu && bo.b < 0 && !bo.deferred && !any_eval && bo.G == op.G && bo.Cout == op.Cin && bo.rows == (long long)op.N * op.H * op.W &&
+                                    (op.G == 1 || bo.a_gs == in_n)) {
+                                    const int bpg = d_w4b ? cerb_wino4b_bn_blocks(p) : op.N * ((op.H + 15) / 16) * ((op.W + 15) / 16);
+                                    double* part = (double*)take((size_t)op.G * bpg * op.Cin * 2 * 2, false);
+                                    if (!part) return fail("workspace allocation failed");
+                                    p.bn_part = part;
+                                    p.bst_y = val[bo.a];
+                                    p.bst_y_gs = op.G == 1 ? 0 : bo.a_gs;
+                                    p.bst_mean = val[bo.stat];
+                                    p.bst_rstd = val[bo.stat] + (size_t)bo.G * bo.Cout;
+                                    p.bst_gamma = bb.gamma;
+                                    p.bst_beta = bb.beta;
+                                    bst_part[bo.stat] = std::make_pair(part, bpg);
+                                }
+                            }
+                        }
                         HIP_OK(d_w4b ? cerb_launch_wino4b(p, st) : cerb_launch_wino4(p, st));
                     } else {
                         if (train_wino2_fresh(net, op.name, net->conv[op.name], 1, st)) return 1;
@@ -1956,10 +1990,18 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     auto dp = deferred_part.find(op.stat);
                     if (dp != deferred_part.end() && dp->second.second && !slice_written.count(op.o)) pre_part = dp->second.first;
                 }
+                int pre_bpg = pre_part ? cerb_head_bwd2_blocks() : 0;
+                if (!pre_part) {  // ... or in the output stage of the data gradient that wrote this BatchNorm's output gradient
+                    auto bp = bst_part.find(op.stat);
+                    if (bp != bst_part.end()) {
+                        pre_part = bp->second.first;
+                        pre_bpg = bp->second.second;
+                    }
+                }
                 if (prof_begin(net, op.name + ".bn_bwd", "bn_bwd", (double)op.G * op.rows * op.Cout * 4.0 * ((pre_part ? 3.0 : 5.0) + (op.b >= 0 ? (fresh_r ? 1.0 : 2.0) : 0.0)), st)) return 1;
                 HIP_OK(cerb_launch_bn_bwd(go, val[op.o], val[op.a], G_(op.a), op.b >= 0 ? G_(op.b) : nullptr, op.a_gs, op.rows, op.Cout, op.G, val[op.stat],
                                           val[op.stat] + (size_t)op.G * op.Cout, b.gamma, b.beta, dgamma, dbeta, op.relu, fresh ? 1 : 0, net->t_ws.p, st, eval_mask,
-                                          fresh_r ? 1 : 0, pre_part, pre_part ? cerb_head_bwd2_blocks() : 0));
+                                          fresh_r ? 1 : 0, pre_part, pre_bpg));
                 if (prof_end(net, st)) return 1;
                 const std::vector<std::string>& keys = net->bn_keys[op.name];
                 for (int g = 0; g < op.G; ++g) {

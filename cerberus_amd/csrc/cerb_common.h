@@ -49,6 +49,11 @@ struct ConvParams {
     double* bn_part;
     int bn_bpg;           // blocks per group = N * ceil(Ho / 16) * ceil(Wo / 16) (conv_wino4b.hip's packed items: ceil(tiles / 16), cerb_wino4b_bn_blocks)
     int pk_ty, pk_tx, pk_ntile;  // conv_wino4b.hip, packed items (set by the launcher): 4x4 tiles per image column / row, tiles per group
+    // conv_wino4.hip / conv_wino4b.hip, training backward (bn_part set as well): this launch is the data gradient whose output IS the gradient behind a
+    // BatchNorm + ReLU and its only writer -- bst_y = that BatchNorm's input [G][N][Ho][Wo][Cout] (group stride bst_y_gs), bst_* = its batch mean / rstd /
+    // gamma / beta [G][Cout]: the output stage leaves (sum dz', sum dz' xhat) per block in bn_part instead of (sum, sum of squares).  nullptr: not asked.
+    const float *bst_y, *bst_mean, *bst_rstd, *bst_gamma, *bst_beta;
+    long long bst_y_gs;
     int pk_off;           // 1: keep the block form on maps that would take packed items (cerb_net_set_packed_items(net, 0), A/B)
 };
 

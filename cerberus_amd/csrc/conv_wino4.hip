@@ -119,9 +119,12 @@ struct Item {
 };
 }  // namespace
 
-// STATS (training forward): the output stage also leaves BatchNorm statistics partials per block (ConvParams::bn_part) -- a separate
-// instantiation, so that the inference kernels are the same code as without it
-template <bool HAS_RES, bool STATS>
+// STATS 1 (training forward): the output stage also leaves BatchNorm statistics partials per block (ConvParams::bn_part) -- a separate
+// instantiation, so that the inference kernels are the same code as without it.
+// STATS 2 (training backward, this launch is a data gradient whose output is the gradient dz behind a BatchNorm + ReLU and its only writer): the output stage
+// reads the BatchNorm's INPUT y at its own pixels and leaves that BatchNorm's backward sums per block -- (sum dz', sum dz' xhat), dz' = dz where bn_out(y) > 0 --
+// in the same place and layout: the BatchNorm's reduction pass over dz and y (train_kernels.hip: bn_bwd_partial_kernel) does not run (ConvParams::bst_*).
+template <bool HAS_RES, int STATS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino4_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ __attribute__((aligned(16))) float bnred[STATS ? 4 * 16 * 8 : 4];  // STATS: [wave][channel quad][4 sums, 4 sums of squares]
@@ -491,6 +494,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         res[k] = buf_load(r_res, rowok ? vo[k & 3] : 0x80000000u, (k >> 2) * orow + 4 * (k & 3) * opix);
                     }
                 }
+                // (requested here, behind the staging barrier; requested before the output transform instead: no faster, and one instantiation of conv_wino4b spilled)
+                f32x4 yv[STATS == 2 ? 16 : 1], bm, brs, bga, bbe;  // STATS 2: the BatchNorm's input at this lane's pixels, its parameters for this lane's four channels
+                if constexpr (STATS == 2) {
+                    const __amdgpu_buffer_rsrc_t r_y =
+                        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bst_y + w.g * p.bst_y_gs + origin), 0, span, 0x00020000);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const bool rowok = !partial || (by0 + 4 * a + (k >> 2) < p.Ho);
+                        yv[k] = buf_load(r_y, rowok ? vo[k & 3] : 0x80000000u, (k >> 2) * orow + 4 * (k & 3) * opix);
+                    }
+                    const int pc = w.g * p.Cout + w.cb * 64 + 4 * (lane_o & 15);
+                    bm = *reinterpret_cast<const f32x4*>(p.bst_mean + pc);
+                    brs = *reinterpret_cast<const f32x4*>(p.bst_rstd + pc);
+                    bga = *reinterpret_cast<const f32x4*>(p.bst_gamma + pc);
+                    bbe = *reinterpret_cast<const f32x4*>(p.bst_beta + pc);
+                }
                 f32x4 bts = {0.f, 0.f, 0.f, 0.f}, btq = {0.f, 0.f, 0.f, 0.f};  // STATS: this lane's 16 pixels x 4 channels
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
@@ -501,13 +520,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     o[2] = fmaxf(o[2], floor_);
                     o[3] = fmaxf(o[3], floor_);
                     const bool rowok = !partial || (by0 + 4 * a + (k >> 2) < p.Ho);
-                    if constexpr (STATS) {
+                    if constexpr (STATS == 1) {
                         if (rowok && vo[k & 3] != 0x80000000u) {  // pixels inside the image only
                             bts = bts + o;
                             btq[0] = fmaf(o[0], o[0], btq[0]);
                             btq[1] = fmaf(o[1], o[1], btq[1]);
                             btq[2] = fmaf(o[2], o[2], btq[2]);
                             btq[3] = fmaf(o[3], o[3], btq[3]);
+                        }
+                    }
+                    if constexpr (STATS == 2) {
+                        if (rowok && vo[k & 3] != 0x80000000u) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {  // the mask by the ONE expression every BatchNorm kernel uses (train_kernels.hip: bn_out): identical ReLU masks
+                                const float yy = yv[k][e];
+                                const float z = __fmaf_rn(yy - bm[e], brs[e] * bga[e], bbe[e]);
+                                const float g = z > 0.f ? o[e] : 0.f;
+                                bts[e] += g;
+                                btq[e] = fmaf(g, (yy - bm[e]) * brs[e], btq[e]);
+                            }
                         }
                     }
 #ifndef W4_ABL_NOSTORE
@@ -573,12 +604,12 @@ static hipError_t launch_wino4(ConvParams p, hipStream_t st) {
     }
     const long long nblk = (long long)p.N * p.tiles_x * p.tiles_y;
     const long long items = (long long)p.groups * ((nblk + 1) / 2) * (p.Cout / 64);
-    const bool stats = p.bn_part != nullptr;
+    const int stats = p.bn_part == nullptr ? 0 : (p.bst_y ? 2 : 1);
     if (stats && HAS_RES) return hipErrorInvalidValue;
     p.bn_bpg = (int)nblk;
-    auto kern = stats ? conv_wino4_kernel<false, true> : conv_wino4_kernel<HAS_RES, false>;
-    static bool attr_done[2][64] = {};
-    if (cerb_attr_needed(attr_done[stats ? 1 : 0])) {
+    auto kern = stats == 2 ? conv_wino4_kernel<false, 2> : stats == 1 ? conv_wino4_kernel<false, 1> : conv_wino4_kernel<HAS_RES, 0>;
+    static bool attr_done[3][64] = {};
+    if (cerb_attr_needed(attr_done[stats])) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + PROF_BYTES);
         if (e != hipSuccess) return e;
     }

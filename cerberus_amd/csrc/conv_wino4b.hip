@@ -88,7 +88,8 @@ struct Item {
 // padding): an item's 16 tiles are 16 CONSECUTIVE 4x4 tiles of the flattened (image, tile row, tile column) order instead of one 4x4-tile block, so
 // only the launch's last item carries empty tiles.  Every tile's arithmetic is the block form's (a matrix-instruction column per tile): same bits.
 // The lane's patch offset and edge flags become per-lane values recomputed per item, the output rows leave per tile (4 pixels x 256 bytes).
-template <bool HAS_RES, bool STATS, bool PACKED>
+// STATS: 0 none, 1 training forward (sum, sum of squares of the outputs), 2 training backward (the BatchNorm-backward sums of conv_wino4.hip's STATS 2: ConvParams::bst_*)
+template <bool HAS_RES, int STATS, bool PACKED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino4b_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ __attribute__((aligned(16))) float bnred[STATS ? 4 * 16 * 8 : 4];
@@ -509,6 +510,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     res[k] = buf_load(r_res, rowok ? vo[k & 3] : 0x80000000u, (k >> 2) * orow + (PACKED ? 0 : 4 * (k & 3) * opix));
                 }
             }
+            f32x4 yv[STATS == 2 ? 16 : 1], bm, brs, bga, bbe;  // STATS 2: the BatchNorm's input at this lane's pixels, its parameters for this lane's four channels
+            if constexpr (STATS == 2) {
+                const __amdgpu_buffer_rsrc_t r_y =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bst_y + w.g * p.bst_y_gs + origin), 0, span, 0x00020000);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const bool rowok = !partial || (by0 + 4 * a + (k >> 2) < p.Ho);
+                    yv[k] = buf_load(r_y, rowok ? vo[k & 3] : 0x80000000u, (k >> 2) * orow + (PACKED ? 0 : 4 * (k & 3) * opix));
+                }
+                const int pc = w.g * p.Cout + w.cb * 64 + 4 * (lane_o & 15);
+                bm = *reinterpret_cast<const f32x4*>(p.bst_mean + pc);
+                brs = *reinterpret_cast<const f32x4*>(p.bst_rstd + pc);
+                bga = *reinterpret_cast<const f32x4*>(p.bst_gamma + pc);
+                bbe = *reinterpret_cast<const f32x4*>(p.bst_beta + pc);
+            }
             f32x4 bts = {0.f, 0.f, 0.f, 0.f}, btq = {0.f, 0.f, 0.f, 0.f};  // STATS: this lane's 16 pixels x 4 channels
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
@@ -519,13 +535,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 o[2] = fmaxf(o[2], floor_);
                 o[3] = fmaxf(o[3], floor_);
                 const bool rowok = !partial || (by0 + 4 * a + (k >> 2) < p.Ho);
-                if constexpr (STATS) {
+                if constexpr (STATS == 1) {
                     if (rowok && vo[k & 3] != 0x80000000u) {
                         bts = bts + o;
                         btq[0] = fmaf(o[0], o[0], btq[0]);
                         btq[1] = fmaf(o[1], o[1], btq[1]);
                         btq[2] = fmaf(o[2], o[2], btq[2]);
                         btq[3] = fmaf(o[3], o[3], btq[3]);
+                    }
+                }
+                if constexpr (STATS == 2) {
+                    if (rowok && vo[k & 3] != 0x80000000u) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {  // the mask by the ONE expression every BatchNorm kernel uses (train_kernels.hip: bn_out)
+                            const float yy = yv[k][e];
+                            const float z = __fmaf_rn(yy - bm[e], brs[e] * bga[e], bbe[e]);
+                            const float g = z > 0.f ? o[e] : 0.f;
+                            bts[e] += g;
+                            btq[e] = fmaf(g, (yy - bm[e]) * brs[e], btq[e]);
+                        }
                     }
                 }
                 buf_store(o, r_out, rowok ? vo[k & 3] : 0x80000000u, (k >> 2) * orow + (PACKED ? 0 : 4 * (k & 3) * opix));
@@ -607,13 +635,13 @@ static hipError_t launch_wino4b(ConvParams p, hipStream_t st) {
         p.pk_ntile = p.N * p.pk_ty * p.pk_tx;
     }
     const long long items = packed ? (long long)p.groups * ((p.pk_ntile + NT - 1) / NT) * (p.Cout / 64) : (long long)p.groups * p.N * p.tiles_x * p.tiles_y * (p.Cout / 64);
-    const bool stats = p.bn_part != nullptr;
+    const int stats = p.bn_part == nullptr ? 0 : (p.bst_y ? 2 : 1);
     if (stats && HAS_RES) return hipErrorInvalidValue;
     p.bn_bpg = packed ? cerb_wino4b_bn_blocks(p) : p.N * p.tiles_x * p.tiles_y;
-    auto kern = packed ? (stats ? conv_wino4b_kernel<false, true, true> : conv_wino4b_kernel<HAS_RES, false, true>)
-                       : (stats ? conv_wino4b_kernel<false, true, false> : conv_wino4b_kernel<HAS_RES, false, false>);
-    static bool attr_done[4][64] = {};
-    if (cerb_attr_needed(attr_done[(stats ? 1 : 0) + (packed ? 2 : 0)])) {
+    auto kern = packed ? (stats == 2 ? conv_wino4b_kernel<false, 2, true> : stats == 1 ? conv_wino4b_kernel<false, 1, true> : conv_wino4b_kernel<HAS_RES, 0, true>)
+                       : (stats == 2 ? conv_wino4b_kernel<false, 2, false> : stats == 1 ? conv_wino4b_kernel<false, 1, false> : conv_wino4b_kernel<HAS_RES, 0, false>);
+    static bool attr_done[6][64] = {};
+    if (cerb_attr_needed(attr_done[stats + (packed ? 3 : 0)])) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + PROF_BYTES);
         if (e != hipSuccess) return e;
     }

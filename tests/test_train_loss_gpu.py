@@ -824,3 +824,65 @@ def test_weight_gradients_on_the_side_stream_equal_the_single_stream_step(gold):
         assert la == lb and set(ga) == set(gb)
         for k in ga:
             assert np.array_equal(ga[k], gb[k]), k
+
+
+@pytest.mark.gpu
+def test_batchnorm_backward_sums_from_the_data_gradient_equal_the_reduction_pass(gold):
+    """Round 5: where a data gradient (conv_wino4 / conv_wino4b on rotated weights) is the only writer of the gradient behind a train-mode BatchNorm + ReLU -- the first
+    BatchNorm of every BasicBlock and of every decoder level -- its output stage reads the BatchNorm's input at its own pixels and leaves that BatchNorm's backward sums
+    (sum dz', sum dz' xhat per block, STATS 2); CERB_BN_BWD_PASS1=1 keeps the BatchNorm's own reduction pass over dz and y.  Same masks (one bn_out expression), the sums
+    taken in another order and in float per 256-pixel block instead of double: losses identical, every gradient within the rounding of re-ordered sums, on the 64-pixel
+    fixture batch (block form with partial blocks) and on a 448-pixel batch (packed items)."""
+    import os
+
+    from cerberus_amd.net_desc import create_model
+    from cerberus_amd.weights import default_model_kwargs, make_state_dict
+
+    tiles = torch.from_numpy(gold["img"]).cuda()
+    keep = torch.from_numpy(gold["step/dropout_mask"].reshape(int(gold["N"]), 512)).cuda()
+    targets, flags = {}, {}
+    for j, h in enumerate(gold["heads"]):
+        h = str(h)
+        t = gold["target/" + h][..., 0]
+        targets[h] = torch.from_numpy(t.reshape(t.shape[0]) if h == "Patch-Class" else t).cuda()
+        flags[h] = torch.from_numpy(gold["has_target"][:, j].astype(np.float32)).cuda()
+    g = torch.Generator(device="cuda").manual_seed(13)
+    n2, win = 2, 448
+    big = {"tiles": torch.randint(0, 256, (n2, win, win, 3), dtype=torch.uint8, device="cuda", generator=g), "targets": {}, "flags": {},
+           "keep": torch.rand((n2, 512), device="cuda", generator=g) < 0.7}
+    for h, c in {"Lumen-INST": 3, "Gland-INST": 3, "Nuclei-INST": 3, "Nuclei-TYPE": 7, "Gland-TYPE": 3, "Patch-Class": 9}.items():
+        big["targets"][h] = torch.randint(0, c, (n2,), device="cuda", generator=g).float() if h == "Patch-Class" else \
+            ((torch.rand((n2, win, win), device="cuda", generator=g) < 0.3) * torch.randint(1, c, (n2, win, win), device="cuda", generator=g)).float()
+        big["flags"][h] = torch.ones(n2, device="cuda")
+    out = {}
+    for mode in ("fused", "pass"):
+        if mode == "pass":
+            os.environ["CERB_BN_BWD_PASS1"] = "1"
+        try:
+            m = create_model(**default_model_kwargs())
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(int(gold["weight_seed"])).items()}, strict=True)
+            res = []
+            for (tl, tg, fl, kp) in ((tiles, targets, flags, keep), (big["tiles"], big["targets"], big["flags"], big["keep"])):
+                losses, grads = m.train_grads(tl, tg, fl, PARAMSET_LOSS, kp)
+                m.profile(True)
+                m.train_grads(tl, tg, fl, PARAMSET_LOSS, kp)
+                recs = m.profile_records()
+                m.profile(False)
+                res.append((losses, {k: (v.detach().cpu().numpy().copy() if torch.is_tensor(v) else np.array(v)) for k, v in grads.items()},
+                            sum(r[2] for r in recs if r[1] == "bn_bwd")))
+            out[mode] = res
+        finally:
+            os.environ.pop("CERB_BN_BWD_PASS1", None)
+    for (la, ga, ba), (lb, gb, bb) in zip(out["fused"], out["pass"]):
+        assert la == lb and set(ga) == set(gb)  # the forward pass is the same code
+        assert ba < 0.93 * bb, (ba, bb)         # the BatchNorm backward family moves fewer bytes: the fused path is the one that ran
+        for k in ga:
+            a, b = ga[k].astype(np.float64).ravel(), gb[k].astype(np.float64).ravel()
+            if k.endswith(("running_mean", "running_var")):
+                assert np.array_equal(a, b), k
+                continue
+            if float(np.abs(b).max()) < 1e-6:
+                continue
+            den = float(np.linalg.norm(a) * np.linalg.norm(b))
+            assert den > 0 and float(a @ b) / den > 0.99999, k
+            assert float(np.abs(a - b).max()) <= 2e-4 * float(np.abs(b).max()), (k, float(np.abs(a - b).max()), float(np.abs(b).max()))
