@@ -450,6 +450,14 @@ def kernel_table(model, step, n_tiles):
     return roofline, rows
 
 
+CONV_ALGO_NAMES = {6: "Winograd F(4x4,3x3) on maps of 16x16 and more, F(2x2,3x3) below (default)", 5: "Winograd F(4x4,3x3), conv_wino4", 7: "Winograd F(4x4,3x3), conv_wino4b",
+                   1: "Winograd F(2x2,3x3)", 0: "direct implicit GEMM"}
+
+
+def px_all(h, w):
+    return float(h) * float(w)
+
+
 def batch_loop(model, dev, rank, steps, warmup, dist, backend):
     """configs[1]: 32 resident tiles, forward + fused output wrapper + scatter into a 4 x 8-tile canvas.  Returns (dt, step, n_tiles)."""
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
@@ -709,6 +717,43 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
     # secondary: the inner loop alone (configs[1]) + the per-kernel table of one batch step
     bdt, bstep, bn = batch_loop(model, dev, rank, 20, 3, None, args.backend)
     roofline, rows = kernel_table(model, bstep, bn)
+    # what the head kernels saw during the timed job (cerb_forward_io.logit_absmax, one row per batch) and the algorithm the headline ran on
+    guard = run.logit_report()
+    precision = dict(model.precision_decision(), name=CONV_ALGO_NAMES.get(model.precision_decision()["conv_algo"]),
+                     logit_saturation=model.LOGIT_SATURATION,
+                     logit_guard={"batches": guard["batches"], "batches_above": guard["above"], "largest_abs_logit": round(guard["max"], 3)})
+    # The headline's precondition made explicit: the same slide's inference on the algorithms a model that trips the
+    # calibration probe (conv_algo 1) or a caller's explicit choice (0) would run -- 4 of the K stripes each, same runner, same handles, same
+    # streams, barrier + synchronize on both sides; `value_with_default_tail` = slide pixels / (that inference rate over the whole slide + the
+    # default run's measured tail): an estimate built from two measurements, said so.
+    algo_values = {}
+    try:
+        ks = min(4, K)
+        for algo in (1, 0):
+            for h in (model, run.twin):
+                if h is not None:
+                    h.set_conv_algo(algo)
+            run.infer_patches(slab, y0, cuts[0], min(cuts[0] + 2 * WSI_BATCH, cuts[1]))  # warm-up (workspaces of this algorithm)
+            torch.cuda.synchronize()
+
+            def part():
+                for k in range(ks):
+                    run.infer_patches(slab, y0, cuts[k], cuts[k + 1], join=False)
+                run.join()
+
+            adt = _timed(part, dev, dist, args.backend)
+            apx = (cuts[ks] - cuts[0]) * TILE * TILE * world  # (every rank runs the same number of its own patches, up to one batch)
+            abdt, _, _ = batch_loop(model, dev, rank, 4, 1, None, args.backend)
+            inf_s = px_all(H, W) / (apx / adt)
+            algo_values[str(algo)] = {"name": CONV_ALGO_NAMES[algo], "stripes": ks, "inference_Mpx_s": round(apx / adt / 1e6, 3),
+                                      "value_with_default_tail": round(px_all(H, W) / (inf_s + phase["tail_s"]) / 1e6, 3),
+                                      "batch_step_ms": round(abdt / 4 * 1e3, 3)}
+    except Exception as e:  # never fails the headline
+        algo_values["error"] = str(e)[:300]
+    finally:
+        for h in (model, run.twin):
+            if h is not None:
+                h.set_conv_algo(6)
     if rank != 0:
         return
     px = H * W
@@ -756,6 +801,7 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
             "slide": [H, W],
             "tiles": n_tiles,
             "batch_tiles": WSI_BATCH, "streams": args.streams, "overlap_tail": int(bool(args.overlap_tail and dist is None)),
+            "conv_algo": precision["conv_algo"], "precision": precision, "other_conv_algos": algo_values,
             "inference_s": round(phase["inference_s"], 3),
             "inference_Mpx_s": round(px / phase["inference_s"] / 1e6, 3),
             "postproc_and_stitch_s": round(phase["tail_s"], 3),
@@ -875,6 +921,8 @@ def main():
     model.load_state_dict(sd, strict=True)
     if args.planar != 1:
         model.set_planar(args.planar)
+    if args.mode != "train":
+        model.prepare(dev)  # the precision decision at load time, outside every timed region (CERB_AUTO_PRECISION=0: no calibration launch, for profiling runs)
     if args.mode == "train":
         return train_leg(args, model, dev, dist, world, rank, sd, kw)
     if args.mode == "wsi":
@@ -891,6 +939,7 @@ def main():
                 "config": {"workload": "Full Cerberus (ResNet34 encoder + 6 decoder heads) batch=32 256x256x3 uint8 tiles, fp32, all heads + fused "
                                        "softmax/crop/argmax scattered into a device-resident canvas (BASELINE.json configs[1]; inner loop of the slide job)",
                            "batch_tiles": BATCH, "tile": TILE, "gflop_per_tile": round(flops_step / BATCH / 1e9, 3),
+                           "conv_algo": model.precision_decision()["conv_algo"], "precision": model.precision_decision(),
                            "whole_step_tflops": round(flops_step / (dt / args.steps) / 1e12 * world, 2),
                            "parallelism": "tile-sharded x%d, no data-path collective" % world},
                 "roofline": roofline, "kernels": rows, "multi_gpu": dict(args.identity),

@@ -27,6 +27,7 @@ class ForwardIO(C.Structure):
         ("type_is_u8", C.c_int),
         ("feats", C.POINTER(C.c_void_p)),
         ("tiles_f32", C.c_void_p),
+        ("logit_absmax", C.c_void_p),
     ]
 
 

@@ -1191,6 +1191,7 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
             hp.out_h = want ? out_h : 0; hp.out_w = want ? out_w : 0;
             hp.roi = use_roi ? 1 : 0;
             hp.logits = wantl ? io->logits[di] : nullptr;
+            hp.absmax_bits = io->logit_absmax ? io->logit_absmax + di : nullptr;
             if (want) {
                 if (d.kind == 0) hp.out_inst = (float*)io->out[di];
                 else if (io->type_is_u8) hp.out_type_u8 = (unsigned char*)io->out[di];

@@ -92,6 +92,7 @@ struct HeadParams {
     const long long* tile_off;   // optional per-tile element offset (in pixels) into the destination canvas
     long long tile_stride;       // pixels between consecutive tiles when tile_off == nullptr
     long long row_stride;        // pixels between consecutive output rows
+    unsigned int* absmax_bits;   // optional device uint32: atomicMax of the float bits of |logit| over every pixel this launch evaluates (cerb_forward_io.logit_absmax)
     int feat_planar;             // head_group_kernel only: `feat` is a tile-planar tensor (cerb_planar_offset) with pl_byp x pl_bxp blocks per image
     int pl_byp, pl_bxp;
 };

@@ -392,6 +392,18 @@ hipError_t cerb_launch_upsample2_add_planar(const float* skip, const float* prev
 #define HEAD_TPW 2  // 64-pixel tasks per wave
 #endif
 typedef float f32x4h __attribute__((ext_vector_type(4)));
+// The data-aware precision guard (cerb_forward_io.logit_absmax): a lane keeps the largest |logit| of the pixels it finishes; at the end of its
+// walk the wave reduces and ONE lane raises the head's word -- non-negative floats order like their bit patterns, so an integer atomicMax
+// does it -- and only when the word is not already as large (a plain load first: after the first waves almost nobody issues the atomic).
+__device__ __forceinline__ void head_absmax_commit(unsigned int* word, float m) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned int b = __float_as_uint(m);
+        if (b > __atomic_load_n(word, __ATOMIC_RELAXED)) atomicMax(word, b);
+    }
+}
+
 template <bool ROI>
 __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
     // v_mfma_f32_16x16x4_f32 throughout: D[16 x 16] += A[16 x 4] B[4 x 16]; lane l supplies row/column l & 15 and k-slot l >> 4,
@@ -451,6 +463,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
     f32x4h x[4];
 #pragma unroll
     for (int pb = 0; pb < 4; ++pb) x[pb] = *reinterpret_cast<const f32x4h*>(feat_ptr(pb, false));
+    float amax = 0.f;  // largest |logit| this lane has finished (head_absmax_commit)
 #pragma unroll 1
     for (int task = 0; task < HEAD_TPW; ++task, pbase += 64) {
     f32x4h acc1[6][4];
@@ -550,6 +563,9 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
         y_ = (int)(r_ % p.H);
         n = (int)(r_ / p.H);
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (e < p.out_ch) amax = fmaxf(amax, fabsf(lg[e]));
     if (p.logits) {
         const long long P = ((long long)n * p.H + y_) * p.W + x_;
         for (int e = 0; e < p.out_ch; ++e) p.logits[P * p.out_ch + e] = lg[e];
@@ -588,6 +604,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
         if (p.out_type_u8) p.out_type_u8[dst] = (unsigned char)best;
     }
     }  // task
+    if (p.absmax_bits) head_absmax_commit(p.absmax_bits, amax);
 }
 
 hipError_t cerb_launch_head(const HeadParams& p_in, hipStream_t st) {
@@ -687,6 +704,7 @@ __global__ __launch_bounds__(256, HEAD_G_OCC) void head_group_kernel(HeadGroupPa
         }
     };
     request(task);
+    float amax = 0.f;  // largest |logit| this lane has finished (head_absmax_commit)
 #pragma unroll 1
     for (; task < task_end; ++task) {
         f32x4h x[4][2];
@@ -796,6 +814,9 @@ __global__ __launch_bounds__(256, HEAD_G_OCC) void head_group_kernel(HeadGroupPa
         const BPos bp = decode(2u * task + (unsigned)ks);
         const int n = bp.n, y_ = bp.row + p.row0, x_ = p.xa0 + 16 * bp.xb + px;
         if (2u * task + (unsigned)ks >= nblk || x_ >= p.W) continue;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (e < p.out_ch) amax = fmaxf(amax, fabsf(lg[e]));
         if (p.logits) {
             const long long P = ((long long)n * p.H + y_) * p.W + x_;
             for (int e = 0; e < p.out_ch; ++e) p.logits[P * p.out_ch + e] = lg[e];
@@ -833,6 +854,7 @@ __global__ __launch_bounds__(256, HEAD_G_OCC) void head_group_kernel(HeadGroupPa
             if (p.out_type_u8) p.out_type_u8[dst] = (unsigned char)best;
         }
     }
+    if (p.absmax_bits) head_absmax_commit(p.absmax_bits, amax);
 }
 
 hipError_t cerb_launch_head_group(const HeadParams* heads, int n_heads, hipStream_t st, int w2_44) {

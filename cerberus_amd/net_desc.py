@@ -412,10 +412,14 @@ class NetDesc(torch.nn.Module):
         256 work items for 256 CUs, every launch has a ramp and a tail) overlap the other batch's.  Measured: +3 % at batch 32, +1.6 % at batch 64."""
         t = NetDesc(**self._init_kwargs)
         t.load_state_dict(self.state_dict(), strict=True)
+        auto = getattr(self, "_algo_is_auto", False)
         for name, value in getattr(self, "_switches", {}).items():
-            if name == "set_conv_algo" and getattr(self, "_algo_is_auto", False):
-                continue  # (the twin probes the same weights itself and decides the same way)
             getattr(t, name)(value)
+        if getattr(self, "_precision_version", None) == self._param_version:  # same weights, same decision: the twin does not probe again
+            t._algo_is_auto = auto
+            t._precision_version = t._param_version
+            if hasattr(self, "calibration_logit_absmax"):
+                t.calibration_logit_absmax = self.calibration_logit_absmax
         return t
 
     def _remember(self, name, value):
@@ -466,46 +470,94 @@ class NetDesc(torch.nn.Module):
             out.append((nm.value.decode(), kn.value.decode(), fl.value, ms.value))
         return out
 
-    LOGIT_SATURATION = 100.0  # calibration threshold of _auto_precision (trained-like weights: logits of 4 .. 17; the reference's default init: 650 .. 2200)
+    LOGIT_SATURATION = 100.0  # largest |logit| the F(4x4,3x3) default is held to the 1e-4 contract for (fixtures at 4 .. 17, 30 and 80: DESIGN.md par.5; the reference's default init: 650 .. 2200)
 
-    def _auto_precision(self, device):
-        """Pick the 3x3 convolution algorithm from the WEIGHTS, once per parameter version (VERDICT r4 item 9 / ADVICE r4): F(4x4,3x3) Winograd
-        amplifies fp32 rounding ~3x more than a direct convolution; with trained-like weights that is 1e-7 .. 4e-6 on the probability maps, far inside
-        the 1e-4 contract, but under the reference's DEFAULT initialisation (logits in the thousands, saturated softmax) it was 5.8e-4 / 3.2e-4 from
-        the reference's own float64 evaluation where the reference's float32 path is 4.6e-4 / 6.7e-5.  So the network is probed with ONE fixed,
-        seeded tile -- a function of the weights alone: every rank, shard and handle of the same weights decides the same way, batches and tiles
-        never enter -- and when a dense head's logits exceed LOGIT_SATURATION the handle runs F(2x2,3x3) everywhere (cerb_net_set_conv_algo(1):
-        closer to float64 than the direct convolution on that network, ~1.3x slower).  An explicit set_conv_algo() by the caller is final;
-        CERB_AUTO_PRECISION=0 switches the probe off."""
+    def prepare(self, device=None):
+        """Decide the 3x3 convolution algorithm from the WEIGHTS, once per parameter version, at LOAD time (not inside the first
+        forward of a stream).  F(4x4,3x3) Winograd amplifies fp32 rounding ~3x more than a direct convolution: on every weight family whose dense
+        logits stay below LOGIT_SATURATION that is 1e-7 .. 3e-5 on the probability maps (tests/test_net_gpu.py: calibration logits 4 .. 17, 30, 80;
+        noise, stain-field, half-glass, white and black tiles), inside the 1e-4 contract measured from the reference's float64 evaluation; under the
+        reference's DEFAULT initialisation (logits in the thousands, a step-function softmax) it was 5.8e-4 where the reference's own fp32 is 4.6e-4.
+        So the network is probed with ONE fixed seeded tile on the device's DEFAULT stream -- a function of the weights alone: every rank, shard and
+        handle of the same weights decides the same way -- and when a dense head's logits exceed LOGIT_SATURATION the handle runs F(2x2,3x3)
+        (cerb_net_set_conv_algo(1): closer to float64 than the direct convolution there, ~1.3x slower).  An explicit set_conv_algo() is final;
+        CERB_AUTO_PRECISION=0 switches the probe off.  What the probe cannot see -- real tiles that drive a trained model's logits past the bar --
+        is watched per batch by the head kernels (watch_logits / cerb_forward_io.logit_absmax).
+        Returns {"conv_algo", "calibration_logit_absmax", "auto", "probed"}; loaders call it and log it (run_infer_*.py), a handle nobody prepared
+        calls it from its first forward."""
         import os
 
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         if getattr(self, "_precision_version", None) == self._param_version or getattr(self, "_train_packing", False):
-            return
+            return self.precision_decision()
         self._precision_version = self._param_version
         auto = getattr(self, "_algo_is_auto", False)
         if ("set_conv_algo" in getattr(self, "_switches", {}) and not auto) or os.environ.get("CERB_AUTO_PRECISION", "1") == "0":
-            return
+            return self.precision_decision()
         if auto:  # new weights: decide again from the default algorithm
             self._switches.pop("set_conv_algo", None)
             self._algo_is_auto = False
             _lib.check(_lib.lib().cerb_net_set_conv_algo(self._ensure_handle(), 6))
-        tile = torch.from_numpy(np.random.RandomState(20240229).randint(0, 256, (1, 256, 256, 3)).astype(np.uint8)).to(device)
-        lg = self.forward(tile)
-        amax = max([float(v.abs().max()) for k, v in lg.items() if k != "Patch-Class"] or [0.0])
+        tile = torch.from_numpy(np.random.RandomState(20240229).randint(0, 256, (1, 256, 256, 3)).astype(np.uint8))
+        cur = torch.cuda.current_stream(device)
+        dflt = torch.cuda.default_stream(device)
+        with torch.cuda.stream(dflt):  # never on a caller's side stream; the host waits for the result below, so the handle is idle again on return
+            dflt.wait_stream(cur)
+            lg = self.forward(tile.to(device))
+            amax = max([float(v.abs().max()) for k, v in lg.items() if k != "Patch-Class"] or [0.0])
         self.calibration_logit_absmax = amax
-        if amax > self.LOGIT_SATURATION:
-            import logging
+        import logging
 
-            logging.getLogger("cerberus_amd").warning(
-                "calibration logits reach %.0f (saturated softmax): 3x3 convolutions run F(2x2,3x3) instead of F(4x4,3x3) on this handle", amax)
+        log = logging.getLogger("cerberus_amd")
+        if amax > self.LOGIT_SATURATION:
+            log.warning("calibration logits reach %.0f (saturated softmax): 3x3 convolutions run F(2x2,3x3) instead of F(4x4,3x3) on this handle", amax)
             self._remember("set_conv_algo", 1)
             self._algo_is_auto = True
             _lib.check(_lib.lib().cerb_net_set_conv_algo(self._ensure_handle(), 1))
+        else:
+            log.info("calibration logits reach %.1f: 3x3 convolutions run F(4x4,3x3)", amax)
+        return self.precision_decision()
 
-    def _run(self, tiles_u8, out_h, out_w, outs, logits, tile_off=None, tile_stride=0, row_stride=0, type_is_u8=False, feats=None):
+    def precision_decision(self):
+        """What prepare() decided (or the caller set): the algorithm the next forward runs, the calibration measurement, who chose."""
+        return {"conv_algo": int(getattr(self, "_switches", {}).get("set_conv_algo", 6)),
+                "calibration_logit_absmax": getattr(self, "calibration_logit_absmax", None),
+                "auto": bool(getattr(self, "_algo_is_auto", False)),
+                "probed": getattr(self, "calibration_logit_absmax", None) is not None}
+
+    _auto_precision = prepare  # (round 5's name)
+
+    # ---- the data-aware half of the guard: the head kernels report the largest |logit| they produce ------------------------------------------
+    def watch_logits(self, enable=True, device=None):
+        """Every forward from now on raises a device word per dense head to the largest |logit| it produced (cerb_forward_io.logit_absmax: one
+        wave-level maximum and at most one atomic per wave, nothing on the host) -- read with logit_absmax().  Callers that want the maximum
+        per batch (cerberus_amd.wsi.WSIRunner) hand _run their own row instead."""
+        if not enable:
+            self._logit_watch = None
+            return
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self._logit_watch = torch.zeros(len(self._decoders), dtype=torch.int32, device=device)
+
+    def logit_absmax(self, reset=True, words=None):
+        """OrderedDict head key -> largest |logit| since the last reset (host sync).  words: another int32 [.., n_decoders] tensor of such words
+        (a per-batch log): returns a float32 array of the same shape instead."""
+        if words is not None:
+            return words.detach().cpu().numpy().view(np.float32)
+        w = getattr(self, "_logit_watch", None)
+        if w is None:
+            raise RuntimeError("logit_absmax: call watch_logits() first")
+        vals = w.cpu().numpy().view(np.float32)
+        if reset:
+            w.zero_()
+        return OrderedDict((d[3], float(v)) for d, v in zip(self._decoders, vals) if d[0] != "Patch-Class")
+
+    def _run(self, tiles_u8, out_h, out_w, outs, logits, tile_off=None, tile_stride=0, row_stride=0, type_is_u8=False, feats=None, logit_absmax=None):
         # uint8 tiles (what infer_step receives), or float32 NHWC pixel values for forward() on inputs that are not whole numbers in 0..255
         assert tiles_u8.is_cuda and tiles_u8.dtype in (torch.uint8, torch.float32) and tiles_u8.dim() == 4 and tiles_u8.shape[3] == 3
-        self._auto_precision(tiles_u8.device)
+        if getattr(self, "_precision_version", None) != self._param_version:
+            self.prepare(tiles_u8.device)
         tiles_u8 = tiles_u8.contiguous()
         n, h, w, _ = tiles_u8.shape
         nd = len(self._decoders)
@@ -527,6 +579,11 @@ class NetDesc(torch.nn.Module):
         if feats is not None:
             f_arr = (C.c_void_p * 6)(*[(t.data_ptr() if t is not None else None) for t in feats])
             io.feats = f_arr
+        if logit_absmax is None:
+            logit_absmax = getattr(self, "_logit_watch", None)
+        if logit_absmax is not None:
+            assert logit_absmax.is_cuda and logit_absmax.dtype == torch.int32 and logit_absmax.numel() == nd and logit_absmax.is_contiguous()
+            io.logit_absmax = logit_absmax.data_ptr()
         stream = torch.cuda.current_stream(tiles_u8.device).cuda_stream
         with torch.cuda.device(tiles_u8.device):
             _lib.check(_lib.lib().cerb_net_forward(self._ensure_handle(), C.byref(io), C.c_void_p(stream)))

@@ -187,6 +187,14 @@ class InferManager(object):
                 saved = {".".join(k.split(".")[1:]): v for k, v in saved.items()}
             net.load_state_dict(saved, strict=True)
         self.net = net
+        # the precision decision belongs to LOADING: one calibration tile on the default stream, the algorithm of the 3x3 convolutions
+        # fixed and logged before the first batch (NetDesc.prepare; without a GPU the first compute call raises CerberusHipError as before)
+        self.precision = None
+        if torch.cuda.is_available():
+            self.precision = net.prepare()
+            import logging
+
+            logging.getLogger("cerberus_amd").info("precision decision at load: %s", self.precision)
         self.run_step = lambda input_batch, output_shape: infer_step(input_batch, net, output_shape, self.model_args["considered_tasks"])
 
     # ---- one image, everything on the GPU ---------------------------------------------------------------------

@@ -117,7 +117,7 @@ def state_dict_schema(decoder_kwargs=None, considered_tasks=None):
     return out + dec_entries + head_entries
 
 
-def make_state_dict(seed=0, decoder_kwargs=None, considered_tasks=None):
+def make_state_dict(seed=0, decoder_kwargs=None, considered_tasks=None, head_logit_scale=None):
     """Seeded, non-saturating fp32 weights as an OrderedDict[str, np.ndarray].
 
     conv: N(0, 2/fan_in) (keeps ReLU activations O(1) through ~40 layers);
@@ -125,6 +125,10 @@ def make_state_dict(seed=0, decoder_kwargs=None, considered_tasks=None):
     argmax / 0.5-threshold decisions to be non-trivial but unsaturated;
     BN: gamma U(0.7,1.1) (U(0.2,0.4) for the second BN of every residual block),
     beta N(0,0.1), running_mean N(0,0.1), running_var U(0.8,1.25).
+
+    head_logit_scale: optional {"<decoder>.<head>": float32 factor} -- the LAST 1x1 convolution (weight and bias) of that output head is
+    multiplied by the factor in float32, i.e. its logits are exactly `factor` times the unscaled recipe's up to rounding: the "confident
+    model" families of oracle/gen_golden_net.py (calibration logits moved to ~30 / ~80 with everything upstream unchanged).
     """
     rs = np.random.RandomState(seed)
     sd = OrderedDict()
@@ -153,6 +157,11 @@ def make_state_dict(seed=0, decoder_kwargs=None, considered_tasks=None):
         else:  # pragma: no cover
             raise ValueError(kind)
         sd[key] = np.ascontiguousarray(w, dtype=np.float32)
+    for name, factor in (head_logit_scale or {}).items():
+        dec, clf = name.rsplit(".", 1)
+        for leaf in ("weight", "bias"):
+            key = "output_head.%s.%s.x.1.conv.%s" % (dec, clf, leaf)
+            sd[key] = np.ascontiguousarray(sd[key] * np.float32(factor), dtype=np.float32)
     return sd
 
 

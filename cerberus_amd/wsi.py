@@ -200,6 +200,13 @@ class WSIRunner(object):
         self._tl_y = torch.from_numpy((rr.ravel() * g.out - g.ctx).astype(np.int64)).to(self.dev)
         self._tl_x = torch.from_numpy((cc.ravel() * g.out - g.ctx).astype(np.int64)).to(self.dev)
         self._off = torch.from_numpy(((rr.ravel() - self.r0) * g.out * self.canvas_w + cc.ravel() * g.out).astype(np.int64)).to(self.dev)
+        # the data-aware precision guard: one row of cerb_forward_io.logit_absmax words per queued batch (the head kernels raise them; nothing is
+        # read on the host until logit_report()).  CERB_LOGIT_GUARD=0 switches the log off, =rerun makes the drivers re-run flagged batches.
+        import os
+
+        self.logit_guard = os.environ.get("CERB_LOGIT_GUARD", "count")
+        self._logit_rows = []  # (b0, b1) of the batch that owns row i of the log
+        self._logit_log = None if self.logit_guard == "0" else torch.zeros((max(1, self.n_patches), len(net._decoders)), dtype=torch.int32, device=self.dev)
 
     def slab_rows(self):
         return self.geo.input_rows(self.r0, self.r1)
@@ -240,7 +247,11 @@ class WSIRunner(object):
             if ready is not None:  # mirror padding only ever folds back to rows above the window's last in-slide row
                 ready(min(int(tl_y_host[b0:b1].max()) + g.win, g.H) - slab_y0)
             tiles = gather_patches(slab, slab_y0, g.H, self._tl_y[b0:b1], self._tl_x[b0:b1], g.win)
-            net._run(tiles, g.out, g.out, self._outs, None, tile_off=self._off[b0:b1], row_stride=self.canvas_w, type_is_u8=True)
+            row = None
+            if self._logit_log is not None and len(self._logit_rows) < self._logit_log.shape[0]:
+                row = self._logit_log[len(self._logit_rows)]
+                self._logit_rows.append((b0, b1))
+            net._run(tiles, g.out, g.out, self._outs, None, tile_off=self._off[b0:b1], row_stride=self.canvas_w, type_is_u8=True, logit_absmax=row)
 
         def mark(stream):
             e = torch.cuda.Event()
@@ -289,6 +300,50 @@ class WSIRunner(object):
         if join:
             self.join()
         return p1 - p0
+
+    def logit_report(self, threshold=None):
+        """What the head kernels saw (host sync): {"batches", "above", "max", "per_head_max", "flagged": [(b0, b1), ..]} -- `above` counts the
+        batches whose largest dense |logit| exceeded `threshold` (default NetDesc.LOGIT_SATURATION: the range the F(4x4,3x3) default is
+        held to 1e-4 on).  A model prepare() already moved to F(2x2) is never flagged (nothing faster to fall back from)."""
+        rep = {"batches": len(self._logit_rows), "above": 0, "max": 0.0, "per_head_max": {}, "flagged": []}
+        if self._logit_log is None or not self._logit_rows:
+            return rep
+        thr = float(self.net.LOGIT_SATURATION if threshold is None else threshold)
+        vals = self.net.logit_absmax(words=self._logit_log[: len(self._logit_rows)])
+        dense = [i for i, d in enumerate(self.net._decoders) if d[0] != "Patch-Class"]
+        if not dense:
+            return rep
+        per_batch = vals[:, dense].max(axis=1)
+        rep["max"] = float(per_batch.max())
+        rep["per_head_max"] = {self.net._decoders[i][3]: float(vals[:, i].max()) for i in dense}
+        if self.net.precision_decision()["conv_algo"] not in (1, 0):
+            hot = np.nonzero(per_batch > thr)[0]
+            rep["above"] = int(hot.size)
+            rep["flagged"] = [self._logit_rows[i] for i in hot]
+        if rep["above"]:
+            import logging
+
+            logging.getLogger("cerberus_amd.wsi").warning(
+                "%d of %d batches produced logits above %.0f (largest %.0f): the F(4x4,3x3) default is held to 1e-4 below that; "
+                "CERB_LOGIT_GUARD=rerun re-runs such batches on F(2x2,3x3)", rep["above"], rep["batches"], thr, rep["max"])
+        return rep
+
+    def rerun_flagged(self, slab, slab_y0, flagged):
+        """Re-run the batches logit_report() flagged on cerb_net_set_conv_algo(1) (F(2x2,3x3): the algorithm saturated models are held to the
+        bar on), on the current stream and the first handle; their canvas windows are overwritten.  The slab must still hold their rows."""
+        if not flagged:
+            return 0
+        g = self.geo
+        L, h = _lib.lib(), self.net._ensure_handle()
+        was = self.net.precision_decision()["conv_algo"]
+        _lib.check(L.cerb_net_set_conv_algo(h, 1))
+        try:
+            for b0, b1 in flagged:
+                tiles = gather_patches(slab, slab_y0, g.H, self._tl_y[b0:b1], self._tl_x[b0:b1], g.win)
+                self.net._run(tiles, g.out, g.out, self._outs, None, tile_off=self._off[b0:b1], row_stride=self.canvas_w, type_is_u8=True)
+        finally:
+            _lib.check(L.cerb_net_set_conv_algo(h, was))
+        return len(flagged)
 
     def gather_to_root(self, dist=None):
         """Stitch the per-head band canvases on rank 0 (one gather per head over RCCL / xGMI).  Returns the full

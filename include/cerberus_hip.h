@@ -70,6 +70,13 @@ typedef struct cerb_forward_io {
     float* const* feats;       /* optional [6]: x0,x1,x2,x3,conv_map(x4),x4 NHWC dumps for tests, or NULL */
     const float* tiles_f32;    /* used when tiles == NULL: device [N][H][W][3] float pixel values (any floats; divided by 255 in fp32 like
                                 * `imgs / 255.0`, models/net_desc.py:147) -- NetDesc.forward on inputs that are not whole numbers in 0..255 */
+    unsigned int* logit_absmax; /* optional device uint32 [n_decoders] or NULL: the data-aware precision guard.  The head kernels raise word i
+                                * (atomic max) to the IEEE-754 bit pattern of the largest |logit| of dense head i over every pixel this forward
+                                * evaluates (non-negative floats order like their bits) -- the caller zeroes it when it wants a fresh maximum and
+                                * reads it back as float.  Words of heads that were not requested, and of the OUT head, are left alone.  The
+                                * F(4x4,3x3) default of cerb_net_set_conv_algo holds the 1e-4 contract while a model's logits stay in the range
+                                * the parity fixtures cover; this is how a caller watches REAL data for batches that leave it
+                                * (cerberus_amd/wsi.py counts them and can re-run them on conv_algo 1). */
 } cerb_forward_io;
 
 int cerb_net_forward(cerb_net* net, const cerb_forward_io* io, void* hip_stream);

@@ -48,6 +48,8 @@ from models.net_desc import create_model  # noqa: E402  (reference)
 from models.run_desc import infer_step as ref_infer_step  # noqa: E402  (reference)
 
 from cerberus_amd.weights import default_model_kwargs, make_state_dict, reference_init_state_dict, state_dict_sha256  # noqa: E402
+from cerberus_amd.synth_tiles import structured_tiles, tiles_sha256  # noqa: E402
+from collections import OrderedDict  # noqa: E402
 from oracle import net_ref  # noqa: E402
 
 torch.manual_seed(0)
@@ -62,20 +64,51 @@ def crops(a, axes=(1, 2)):
     return np.stack([a[:, y:y + CS, x:x + CS] for (y, x) in CROPS], axis=1)
 
 
-def run_case(tag, tile_seed, n, hw, out_shape, tasks, weight_seed=0, family="seeded"):
+PROBE_SEED = 20240229  # cerberus_amd.net_desc.NetDesc's calibration tile (one seeded 256^2 noise tile)
+
+
+def calibration_head_scale(kw, weight_seed, target):
+    """Per dense head: target / (largest |logit| of the REFERENCE on the calibration tile with the unscaled seeded recipe), as float32 -- the
+    factors of make_state_dict(head_logit_scale=...), with which the reference's calibration logits of every dense head land on `target`."""
+    sd = {k: torch.from_numpy(v) for k, v in make_state_dict(weight_seed, kw["decoder_kwargs"], kw["considered_tasks"]).items()}
+    model = create_model(**kw)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    tile = np.random.RandomState(PROBE_SEED).randint(0, 256, (1, 256, 256, 3)).astype(np.uint8)
+    with torch.no_grad():
+        lg = model(torch.from_numpy(tile).float().permute(0, 3, 1, 2).contiguous())
+    out = OrderedDict()
+    for dec, heads in kw["decoder_kwargs"].items():
+        if dec == "Patch-Class" or dec not in kw["considered_tasks"]:
+            continue
+        for clf in heads:
+            key = dec.split("#")[0] + "-" + clf
+            out[dec + "." + clf] = np.float32(target / float(lg[key].abs().max()))
+    return out
+
+
+def run_case(tag, tile_seed, n, hw, out_shape, tasks, weight_seed=0, family="seeded", logit_target=None, tiles_kind="noise"):
     """family "seeded": cerberus_amd.weights.make_state_dict (non-saturating); "refinit": the distribution the reference's own constructor
     leaves in a fresh model (weights_init_cnn, models/net_desc.py:89-103: kaiming-normal convs, identity BatchNorm) drawn from a seeded
     torch generator (cerberus_amd.weights.reference_init_state_dict) so that the GPU box can rebuild the same tensors."""
     kw = default_model_kwargs(tasks)
+    head_scale = None
     if family == "refinit":
         sd_np = reference_init_state_dict(kw["decoder_kwargs"], kw["considered_tasks"], generator=torch.Generator().manual_seed(weight_seed))
+    elif family == "scaled":  # "a confident trained model": the seeded recipe with every dense head's last 1x1 scaled so that its calibration logits reach logit_target
+        head_scale = calibration_head_scale(kw, weight_seed, logit_target)
+        sd_np = make_state_dict(weight_seed, kw["decoder_kwargs"], kw["considered_tasks"], head_logit_scale=head_scale)
     else:
         sd_np = make_state_dict(weight_seed, kw["decoder_kwargs"], kw["considered_tasks"])
     sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
     model = create_model(**kw)
     model.load_state_dict(sd, strict=True)  # pins the key schema too
     model.eval()
-    tiles = np.random.RandomState(tile_seed).randint(0, 256, (n, hw, hw, 3)).astype(np.uint8)
+    if tiles_kind == "structured":  # stain field / half glass / all white / all black (cerberus_amd.synth_tiles): what a slide feeds the network besides texture
+        tiles = structured_tiles(hw, tile_seed)
+        assert tiles.shape[0] == n
+    else:
+        tiles = np.random.RandomState(tile_seed).randint(0, 256, (n, hw, hw, 3)).astype(np.uint8)
     x = torch.from_numpy(tiles).float().permute(0, 3, 1, 2).contiguous()
     with torch.no_grad():
         ref_logits = model(x)
@@ -86,7 +119,11 @@ def run_case(tag, tile_seed, n, hw, out_shape, tasks, weight_seed=0, family="see
     orc_logits = net_ref.net_forward(sd, x, kw["decoder_kwargs"], kw["considered_tasks"])
     orc_out = net_ref.infer_step(sd, tiles, out_shape, kw["considered_tasks"], kw["decoder_kwargs"])
     store = {"tile_seed": tile_seed, "weight_seed": weight_seed, "weight_family": family, "n": n, "hw": hw, "out_shape": out_shape,
-             "tasks": np.array(tasks), "weights_sha256": state_dict_sha256(sd_np)}
+             "tasks": np.array(tasks), "weights_sha256": state_dict_sha256(sd_np), "tiles_kind": tiles_kind, "tiles_sha256": tiles_sha256(tiles)}
+    if head_scale is not None:
+        store["head_scale_names"] = np.array(list(head_scale.keys()))
+        store["head_scale_values"] = np.array(list(head_scale.values()), np.float32)
+        store["logit_target"] = np.float64(logit_target)
     # The reference's OWN rounding noise: the same model and tiles evaluated in float64 (model.double()), read out like infer_step does
     # (softmax, channels 1..2 of INST heads, argmax of TYPE heads).  noise/<head> = max |p_fp32 - p_fp64| over the whole tensor: two faithful
     # fp32 evaluations of this network cannot be expected to agree more closely than this.  margin/<head>: top-1 minus top-2 softmax
@@ -170,6 +207,12 @@ def run_case(tag, tile_seed, n, hw, out_shape, tasks, weight_seed=0, family="see
 
 if __name__ == "__main__":
     all_tasks = list(default_model_kwargs()["considered_tasks"])
+    only = set(sys.argv[1:])  # optional: regenerate the named fixtures only
+
+    def run_case(tag, _f=run_case, **k):
+        if not only or tag in only:
+            _f(tag, **k)
+
     # cfg-1: one 256^2 tile, nuclei head only (BASELINE.json configs[0])
     run_case("cfg1_nuclei", tile_seed=0, n=1, hw=256, out_shape=256, tasks=["Nuclei"])
     # cfg-2 subset: 2 tiles, all six heads
@@ -183,3 +226,10 @@ if __name__ == "__main__":
     # the reference's default initialisation: logits in the hundreds / thousands, saturated probabilities -- every fp32 evaluation is far
     # from the fp64 one here (noise/<head> in the fixture); the regime DESIGN.md par.4.0 calls the stress case
     run_case("refinit_all", tile_seed=5, n=2, hw=256, out_shape=256, tasks=all_tasks, weight_seed=0, family="refinit")
+    # round 6: the band between "seeded" (calibration logits 4 .. 17) and "refinit" (650 .. 2200) -- a confident trained
+    # model: every dense head's calibration logits at 30 and at 80 -- and structured inputs (stain field, half glass, white, black) on the
+    # seeded weights and on the logit-80 family
+    run_case("logit30_all", tile_seed=6, n=2, hw=256, out_shape=256, tasks=all_tasks, weight_seed=0, family="scaled", logit_target=30.0)
+    run_case("logit80_all", tile_seed=7, n=2, hw=256, out_shape=256, tasks=all_tasks, weight_seed=0, family="scaled", logit_target=80.0)
+    run_case("struct_all", tile_seed=8, n=4, hw=256, out_shape=256, tasks=all_tasks, weight_seed=0, tiles_kind="structured")
+    run_case("struct80_all", tile_seed=9, n=4, hw=256, out_shape=256, tasks=all_tasks, weight_seed=0, family="scaled", logit_target=80.0, tiles_kind="structured")

@@ -219,13 +219,27 @@ def main(argv=None):
                             for lab in pre.values():
                                 lab.feed(rows_final, evs)
             if host is None:
-                run.infer_band(synth_slide(y1 - y0, W, y0=y0, seed=seed), y0, progress=progress)
+                slab_dev = synth_slide(y1 - y0, W, y0=y0, seed=seed)
+                run.infer_band(slab_dev, y0, progress=progress)
             elif isinstance(host, np.ndarray) and not isinstance(host, np.memmap):  # already in RAM: one 50 GB/s copy, nothing to hide
-                run.infer_band(torch.from_numpy(np.ascontiguousarray(host[y0:y1])).cuda(), y0, progress=progress)
+                slab_dev = torch.from_numpy(np.ascontiguousarray(host[y0:y1])).cuda()
+                run.infer_band(slab_dev, y0, progress=progress)
             else:  # a slide on disk (memory-mapped array, tiled TIFF / .svs pyramid): read / decode + upload chunk by chunk on a copy
                 up = SlabUploader(host, y0, y1)  # stream underneath the inference of the rows above
-                run.infer_band(up.slab, y0, ready=up.upload_until, progress=progress)
+                slab_dev = up.slab
+                run.infer_band(slab_dev, y0, ready=up.upload_until, progress=progress)
             torch.cuda.synchronize()
+            # what the head kernels saw, batch by batch (cerb_forward_io.logit_absmax): batches whose logits left the range the F(4x4,3x3) default is
+            # held to 1e-4 on are counted in the slide's log; CERB_LOGIT_GUARD=rerun re-runs them on F(2x2,3x3) while the slab is still in HBM
+            guard = run.logit_report()
+            if guard["above"] and run.logit_guard == "rerun":
+                run.rerun_flagged(slab_dev, y0, guard["flagged"])
+                torch.cuda.synchronize()
+            del slab_dev
+            if log:
+                log.info("Logit guard: {0} of {1} batches above {2:.0f} (largest |logit| {3:.1f}; conv_algo {4}{5})".format(
+                    guard["above"], guard["batches"], manager.net.LOGIT_SATURATION, guard["max"], manager.net.precision_decision()["conv_algo"],
+                    ", flagged batches re-run on F(2x2,3x3)" if guard["above"] and run.logit_guard == "rerun" else ""))
             t1 = time.perf_counter()
             if dist is not None:
                 with watch.phase("end-of-inference barrier (%s)" % base):

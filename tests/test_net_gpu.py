@@ -23,14 +23,15 @@ def _crops(a):
     return np.stack([a[:, y:y + CS, x:x + CS] for (y, x) in CROPS], axis=1)
 
 
-def _model(tasks, seed=0, family="seeded"):
+def _model(tasks, seed=0, family="seeded", head_scale=None):
     """family "seeded": cerberus_amd.weights.make_state_dict; "refinit": the reference's default initialisation (weights_init_cnn,
-    models/net_desc.py:89-103) from a seeded generator -- exactly what oracle/gen_golden_net.py loaded into the reference."""
+    models/net_desc.py:89-103) from a seeded generator; "scaled": the seeded recipe with every dense head's last 1x1 multiplied by the
+    fixture's float32 factors (calibration logits at 30 / 80) -- exactly what oracle/gen_golden_net.py loaded into the reference."""
     kw = default_model_kwargs(tasks)
     if family == "refinit":
         sd_np = reference_init_state_dict(kw["decoder_kwargs"], kw["considered_tasks"], generator=torch.Generator().manual_seed(seed))
     else:
-        sd_np = make_state_dict(seed, kw["decoder_kwargs"], kw["considered_tasks"])
+        sd_np = make_state_dict(seed, kw["decoder_kwargs"], kw["considered_tasks"], head_logit_scale=head_scale)
     sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
     m = create_model(**kw)
     m.load_state_dict(sd, strict=True)
@@ -40,10 +41,31 @@ def _model(tasks, seed=0, family="seeded"):
 def _golden_model(g):
     tasks = [str(t) for t in g["tasks"]]
     fam = str(g["weight_family"]) if "weight_family" in g else "seeded"
-    m, sd, kw = _model(tasks, int(g["weight_seed"]), fam)
+    scale = None
+    if fam == "scaled":
+        scale = {str(k): np.float32(v) for k, v in zip(g["head_scale_names"], g["head_scale_values"])}
+    m, sd, kw = _model(tasks, int(g["weight_seed"]), fam, scale)
     from cerberus_amd.weights import state_dict_sha256
     assert state_dict_sha256({k: v.numpy() for k, v in sd.items()}) == str(g["weights_sha256"]), "the fixture's weights were not rebuilt bit for bit"
     return m, sd, kw, tasks
+
+
+def _golden_tiles(g):
+    """The fixture's input tiles, rebuilt from its seed: uniform noise (rounds 1-5) or the structured set of cerberus_amd.synth_tiles (stain field,
+    half glass, all white, all black), checked against the sha256 the generator stored."""
+    n, hw = int(g["n"]), int(g["hw"])
+    if "tiles_kind" in g and str(g["tiles_kind"]) == "structured":
+        from cerberus_amd.synth_tiles import structured_tiles
+
+        tiles = structured_tiles(hw, int(g["tile_seed"]))
+    else:
+        tiles = np.random.RandomState(int(g["tile_seed"])).randint(0, 256, (n, hw, hw, 3)).astype(np.uint8)
+    if "tiles_sha256" in g:
+        from cerberus_amd.synth_tiles import tiles_sha256
+
+        assert tiles_sha256(tiles) == str(g["tiles_sha256"]), "the fixture's tiles were not rebuilt bit for bit"
+    assert tiles.shape[0] == n
+    return tiles
 
 
 # The bars (north_star: "within 1e-4 on float probability maps ... bit-exact on integer maps given identical seeds"):
@@ -177,7 +199,12 @@ def test_head_w2_on_4x4_matrix_instructions_vs_padded_16_row_instruction(full_mo
         assert (lgs[1][k] - lgs[2][k]).abs().max().item() < 2e-6 * scale, k
 
 
-@pytest.mark.parametrize("tag", ["cfg1_nuclei", "cfg2_all", "g448_all", "small96_all", "seed1_all", "refinit_all"])
+GOLDEN_TAGS = ["cfg1_nuclei", "cfg2_all", "g448_all", "small96_all", "seed1_all", "refinit_all",
+               # round 6: "a confident trained model" -- every dense head's calibration logits at 30 / 80 -- and structured inputs
+               "logit30_all", "logit80_all", "struct_all", "struct80_all"]
+
+
+@pytest.mark.parametrize("tag", GOLDEN_TAGS)
 def test_infer_step_vs_reference_golden(golden_dir, tag):
     """The default path against what the REFERENCE's own NetDesc / infer_step produced for the same seeded weights and tiles: two draws of the
     non-saturating recipe, four geometries, and the reference's DEFAULT initialisation (refinit_all: logits in the thousands, saturated softmax).
@@ -192,11 +219,21 @@ def test_infer_step_vs_reference_golden(golden_dir, tag):
     g = np.load(os.path.join(golden_dir, "net_%s.npz" % tag))
     m, sd, kw, tasks = _golden_model(g)
     n, hw, osz = int(g["n"]), int(g["hw"]), int(g["out_shape"])
-    tiles = np.random.RandomState(int(g["tile_seed"])).randint(0, 256, (n, hw, hw, 3)).astype(np.uint8)
+    tiles = _golden_tiles(g)
+    dec = m.prepare()  # the load-time decision (run_infer_*.py log it)
+    m.watch_logits()
     out = infer_step(torch.from_numpy(tiles), m, osz, tasks)
     assert isinstance(out, list) and len(out) == n
     saturated = tag == "refinit_all"
     assert (m.calibration_logit_absmax > m.LOGIT_SATURATION) == saturated and bool(getattr(m, "_algo_is_auto", False)) == saturated, m.calibration_logit_absmax
+    assert dec["conv_algo"] == (1 if saturated else DEFAULT_ALGO) and dec["auto"] == saturated and dec["probed"], dec
+    if "logit_target" in g:  # the scaled families sit where the generator put them: the calibration tile's logits at the target on every dense head
+        assert abs(m.calibration_logit_absmax - float(g["logit_target"])) < 0.02 * float(g["logit_target"]), m.calibration_logit_absmax
+    # the data-aware guard: the head kernels' own maximum over THIS batch equals the largest |logit| of the reference's float64 evaluation
+    seen = m.logit_absmax()
+    for k, v in seen.items():
+        want = float(g["logit_absmax/" + k])  # (over the whole map; a cropped forward evaluates the kept window only)
+        assert (abs(v - want) if osz == hw else max(0.0, v - want)) <= 2e-3 * max(1.0, want), (k, v, want)
     direct = None
     if saturated:  # the same network on the direct implicit-GEMM convolution (conv_algo 0)
         md, _, _, _ = _golden_model(g)
@@ -631,3 +668,93 @@ def test_planar_last_level_is_bit_identical_to_nhwc(full_model, win, osz, n):
     if win * win > 4096 * 4:  # the two last levels are above 64 x 64: the planar kernels carry both
         want = 4
         assert sum(k.startswith("conv_wino4p") for k in kernels) == want and kernels.count("upsample2_add_planar") == want // 2, kernels
+
+
+def test_logit_guard_words_are_the_batch_maximum_and_follow_the_data(golden_dir):
+    """cerb_forward_io.logit_absmax: the head kernels' per-head word after a forward IS the largest |logit| of that forward
+    (bit for bit: the same kernel writes the logits), it rises with later batches and never falls (atomic max), words of a batch of stain-field /
+    white / black tiles stay below those of a noise batch on the logit-80 family, and the Patch-Class word is left alone."""
+    g = np.load(os.path.join(golden_dir, "net_struct80_all.npz"))
+    m, sd, kw, tasks = _golden_model(g)
+    m.prepare()
+    smooth = torch.from_numpy(_golden_tiles(g)).cuda()
+    noise = torch.from_numpy(np.random.RandomState(3).randint(0, 256, (3, 256, 256, 3)).astype(np.uint8)).cuda()
+    nd = len(m._decoders)
+    rows = torch.zeros((3, nd), dtype=torch.int32, device="cuda")
+    rows[:, nd - 1] = 12345  # Patch-Class: untouched
+    outs = [None] * nd
+
+    def run(tiles, row):
+        lg = [torch.empty((tiles.shape[0], 256, 256, d[2]), dtype=torch.float32, device="cuda") if d[0] != "Patch-Class" else None for d in m._decoders]
+        m._run(tiles, 256, 256, outs, lg, logit_absmax=row)
+        torch.cuda.synchronize()
+        return [None if t is None else float(t.abs().max()) for t in lg]
+
+    lg_smooth = run(smooth, rows[0])
+    lg_noise = run(noise, rows[1])
+    run(smooth, rows[2])
+    run(noise, rows[2])  # two batches into one row: the maximum of both
+    vals = m.logit_absmax(words=rows)
+    for i, d in enumerate(m._decoders):
+        if d[0] == "Patch-Class":
+            assert (rows[:, i].cpu().numpy() == 12345).all()
+            continue
+        assert vals[0, i] == np.float32(lg_smooth[i]) and vals[1, i] == np.float32(lg_noise[i]), (d[3], vals[:, i], lg_smooth[i], lg_noise[i])
+        assert vals[2, i] == max(vals[0, i], vals[1, i])
+        assert vals[0, i] < vals[1, i], d[3]  # smooth tiles drive this family's heads less hard than texture does
+    # the cropped forward (heads evaluate the kept window only) reports the window's maximum: never above the whole map's
+    crop = torch.zeros(nd, dtype=torch.int32, device="cuda")
+    m.infer_tiles(noise, 144)  # no row: nothing written, nothing read
+    res = [torch.empty((3, 144, 144, 2), dtype=torch.float32, device="cuda") if d[1] == "INST" else
+           (torch.empty((3, 144, 144), dtype=torch.uint8, device="cuda") if d[1] == "TYPE" else torch.empty((3, 144, 144), dtype=torch.float32, device="cuda")) for d in m._decoders]
+    m._run(noise, 144, 144, res, None, type_is_u8=True, logit_absmax=crop)
+    cv = m.logit_absmax(words=crop)
+    for i, d in enumerate(m._decoders):
+        if d[0] != "Patch-Class":
+            assert 0.0 < cv[i] <= vals[1, i], d[3]
+
+
+def test_wsi_runner_counts_and_reruns_a_planted_high_logit_batch(golden_dir):
+    """The slide loop's use of the guard: a slab of smooth stain field with ONE patch of texture planted in it, the logit-80 model, the bar put
+    between the two regimes -- logit_report() flags exactly the batch holding the planted patch, and rerun_flagged() leaves that batch's canvas
+    windows equal to a run of the same tiles on conv_algo 1 while every other window keeps its F(4x4) bytes."""
+    from cerberus_amd.synth_tiles import stain_field
+    from cerberus_amd.wsi import WSIRunner, gather_patches
+
+    g = np.load(os.path.join(golden_dir, "net_logit80_all.npz"))
+    m, sd, kw, tasks = _golden_model(g)
+    m.prepare()
+    H, W, win, batch = 512, 1536, 256, 4  # 2 x 6 patches, 3 batches of 4
+    slab = np.concatenate([np.concatenate([stain_field(256, 20 + 6 * r + c) for c in range(6)], axis=1) for r in range(2)], axis=0)
+    slab[256:512, 512:768] = np.random.RandomState(5).randint(0, 256, (256, 256, 3))  # patch (1, 2) = index 8 -> batch 2 (patches 8 .. 11)
+    slab_dev = torch.from_numpy(slab).cuda()
+    run = WSIRunner(m, (H, W), win, win, batch)
+    run.infer_band(slab_dev, 0)
+    rep = run.logit_report(threshold=1e9)
+    assert rep["batches"] == 3 and rep["above"] == 0
+    words = m.logit_absmax(words=run._logit_log[:3])
+    dense = [i for i, d in enumerate(m._decoders) if d[0] != "Patch-Class"]
+    per_batch = words[:, dense].max(axis=1)
+    assert per_batch[2] > per_batch[:2].max(), per_batch  # the planted texture drives the heads harder than the stain field
+    thr = 0.5 * (per_batch[2] + per_batch[:2].max())
+    m.LOGIT_SATURATION = float(thr)
+    rep = run.logit_report()
+    assert rep["above"] == 1 and rep["flagged"] == [(8, 12)] and abs(rep["max"] - per_batch[2]) < 1e-6
+    before = {k: v.clone() for k, v in run.canv.items()}
+    assert run.rerun_flagged(slab_dev, 0, rep["flagged"]) == 1
+    torch.cuda.synchronize()
+    assert m.precision_decision()["conv_algo"] == DEFAULT_ALGO  # the handle is back on its default
+    tiles = gather_patches(slab_dev, 0, H, run._tl_y[8:12], run._tl_x[8:12], win)
+    m.set_conv_algo(1)
+    want = m.infer_tiles(tiles, win, type_dtype=torch.uint8)
+    m.set_conv_algo(DEFAULT_ALGO)
+    changed = 0
+    for k, v in run.canv.items():
+        for j, p in enumerate(range(8, 12)):
+            r, c = divmod(p, 6)
+            assert torch.equal(v[r * 256:(r + 1) * 256, c * 256:(c + 1) * 256], want[k][j]), (k, p)
+        keep = torch.ones(v.shape[:2], dtype=torch.bool, device="cuda")
+        keep[256:512, 512:] = False
+        assert torch.equal(v[keep], before[k][keep]), k
+        changed += int((v != before[k]).any())
+    assert changed > 0  # F(2x2) and F(4x4) differ in the last bits somewhere
