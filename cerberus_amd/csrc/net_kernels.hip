@@ -563,9 +563,6 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
         y_ = (int)(r_ % p.H);
         n = (int)(r_ / p.H);
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-        if (e < p.out_ch) amax = fmaxf(amax, fabsf(lg[e]));
     if (p.logits) {
         const long long P = ((long long)n * p.H + y_) * p.W + x_;
         for (int e = 0; e < p.out_ch; ++e) p.logits[P * p.out_ch + e] = lg[e];
@@ -582,7 +579,13 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadParams p) {
         sum += ex[e];
     }
     const int cy = y_ - p.crop_y0, cx = x_ - p.crop_x0;
-    if (cy < 0 || cy >= p.out_h || cx < 0 || cx >= p.out_w) continue;
+    const bool inside = cy >= 0 && cy < p.out_h && cx >= 0 && cx < p.out_w;
+    if (inside || p.logits) {  // (a cropped forward only finishes the kept window's features: pixels of the 16-aligned cover outside it do not count)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (e < p.out_ch) amax = fmaxf(amax, fabsf(lg[e]));
+    }
+    if (!inside) continue;
     const long long dst = (p.tile_off ? p.tile_off[n] : (long long)n * p.tile_stride) + (long long)cy * p.row_stride + cx;
     if (p.kind == 0) {
         float2 o;
@@ -814,9 +817,6 @@ __global__ __launch_bounds__(256, HEAD_G_OCC) void head_group_kernel(HeadGroupPa
         const BPos bp = decode(2u * task + (unsigned)ks);
         const int n = bp.n, y_ = bp.row + p.row0, x_ = p.xa0 + 16 * bp.xb + px;
         if (2u * task + (unsigned)ks >= nblk || x_ >= p.W) continue;
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (e < p.out_ch) amax = fmaxf(amax, fabsf(lg[e]));
         if (p.logits) {
             const long long P = ((long long)n * p.H + y_) * p.W + x_;
             for (int e = 0; e < p.out_ch; ++e) p.logits[P * p.out_ch + e] = lg[e];
@@ -832,7 +832,13 @@ __global__ __launch_bounds__(256, HEAD_G_OCC) void head_group_kernel(HeadGroupPa
             sum += ex[e];
         }
         const int cy = y_ - p.crop_y0, cx = x_ - p.crop_x0;
-        if (cy < 0 || cy >= p.out_h || cx < 0 || cx >= p.out_w) continue;
+        const bool inside = cy >= 0 && cy < p.out_h && cx >= 0 && cx < p.out_w;
+        if (inside || p.logits) {  // (a cropped forward only finishes the kept window's features: pixels of the 16-aligned cover outside it do not count)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e < p.out_ch) amax = fmaxf(amax, fabsf(lg[e]));
+        }
+        if (!inside) continue;
         const long long dst = (p.tile_off ? p.tile_off[n] : (long long)n * p.tile_stride) + (long long)cy * p.row_stride + cx;
         if (p.kind == 0) {
             float2 o;

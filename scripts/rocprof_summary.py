@@ -14,14 +14,29 @@ import sqlite3
 import sys
 
 
+def _median(v):
+    v = sorted(v)
+    n = len(v)
+    return 0.0 if n == 0 else (v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2]))
+
+
 def stats(db, out):
+    """Per kernel symbol AND launch grid (a 1-tile calibration launch must not dilute a batch-32 average): calls, total, average,
+    median, min, max.  Persistent kernels launch the same grid whatever the batch, so the profiling legs also run with CERB_AUTO_PRECISION=0
+    (scripts/profile_r06.sh): then every launch of a symbol in a `--mode batch` run is a batch launch and avg == median up to noise."""
     c = sqlite3.connect(db)
-    rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels order by total_duration desc"))
+    groups = {}
+    total = 0
+    for n, gx, gy, gz, a, b in c.execute("select name, grid_x, grid_y, grid_z, start, end from kernels"):
+        groups.setdefault((n, gx, gy, gz), []).append((b - a) / 1e3)
+        total += b - a
+    rows = sorted(((k, v) for k, v in groups.items()), key=lambda kv: -sum(kv[1]))
     with open(out, "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats summary (durations in microseconds)\n")
-        f.write("%-90s %8s %14s %12s %8s\n" % ("kernel", "calls", "total_us", "avg_us", "pct"))
-        for n, calls, tot, avg, pct in rows:
-            f.write("%-90s %8d %14.1f %12.3f %8.2f\n" % (n[:90], calls, tot, avg, pct))
+        f.write("# rocprofv3 --kernel-trace summary, one row per kernel symbol and launch grid (durations in microseconds)\n")
+        f.write("%-84s %-16s %7s %13s %11s %11s %11s %11s %7s\n" % ("kernel", "grid", "calls", "total_us", "avg_us", "median_us", "min_us", "max_us", "pct"))
+        for (n, gx, gy, gz), d in rows:
+            f.write("%-84s %-16s %7d %13.1f %11.3f %11.3f %11.3f %11.3f %7.2f\n" % (n[:84], "%dx%dx%d" % (gx, gy, gz), len(d), sum(d), sum(d) / len(d), _median(d), min(d), max(d),
+                                                                                  100.0 * sum(d) * 1e3 / max(total, 1)))
         # register / LDS footprint per kernel
         f.write("\n# per-kernel launch footprint (first dispatch of each symbol)\n")
         f.write("%-90s %6s %6s %8s %10s\n" % ("kernel", "vgpr", "sgpr", "lds", "wg"))
@@ -78,20 +93,21 @@ def pmc_step(fetch_db, write_db, steps, out):
 
 
 def sq(db, pattern, out, append=False):
-    """SQ / TCP / TCC counters per kernel symbol matching `pattern` (regex): average per launch."""
+    """SQ / TCP / TCC counters per kernel symbol matching `pattern` (regex) and launch grid: launches, average, min, max per launch."""
     import re
 
     c = sqlite3.connect(db)
-    rows = list(c.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name"))
+    rows = list(c.execute("select kernel_name, grid_size, counter_name, count(*), avg(value), min(value), max(value) from counters_collection "
+                          "group by kernel_name, grid_size, counter_name"))
     d = {}
-    for k, n, cnt, v in rows:
+    for k, g, n, cnt, v, lo, hi in rows:
         if re.search(pattern, k):
-            d.setdefault(k[:100], {})[n] = (cnt, v)
+            d.setdefault("%s  [grid %d]" % (k[:100], g), {})[n] = (cnt, v, lo, hi)
     with open(out, "a" if append else "w") as f:
         for k, m in sorted(d.items()):
             f.write(k + "\n")
-            for n, (cnt, v) in sorted(m.items()):
-                f.write("   %-36s n=%5d avg=%.5g\n" % (n, cnt, v))
+            for n, (cnt, v, lo, hi) in sorted(m.items()):
+                f.write("   %-36s n=%5d avg=%.5g min=%.5g max=%.5g\n" % (n, cnt, v, lo, hi))
     print("wrote", out)
 
 

@@ -715,9 +715,10 @@ def test_logit_guard_words_are_the_batch_maximum_and_follow_the_data(golden_dir)
 
 
 def test_wsi_runner_counts_and_reruns_a_planted_high_logit_batch(golden_dir):
-    """The slide loop's use of the guard: a slab of smooth stain field with ONE patch of texture planted in it, the logit-80 model, the bar put
-    between the two regimes -- logit_report() flags exactly the batch holding the planted patch, and rerun_flagged() leaves that batch's canvas
-    windows equal to a run of the same tiles on conv_algo 1 while every other window keeps its F(4x4) bytes."""
+    """The slide loop's use of the guard: a slab of smooth stain fields with one patch of texture in it, the logit-80 model, the bar put between
+    the hardest-driven batch and the next -- logit_report() gives every batch the largest |logit| a plain forward of its tiles has, flags exactly
+    the batch above the bar, and rerun_flagged() leaves that batch's canvas windows equal to a run of the same tiles on conv_algo 1 while every
+    other window keeps its F(4x4) bytes."""
     from cerberus_amd.synth_tiles import stain_field
     from cerberus_amd.wsi import WSIRunner, gather_patches
 
@@ -735,26 +736,33 @@ def test_wsi_runner_counts_and_reruns_a_planted_high_logit_batch(golden_dir):
     words = m.logit_absmax(words=run._logit_log[:3])
     dense = [i for i, d in enumerate(m._decoders) if d[0] != "Patch-Class"]
     per_batch = words[:, dense].max(axis=1)
-    assert per_batch[2] > per_batch[:2].max(), per_batch  # the planted texture drives the heads harder than the stain field
-    thr = 0.5 * (per_batch[2] + per_batch[:2].max())
-    m.LOGIT_SATURATION = float(thr)
+    truth = []
+    for b in range(3):  # what a plain forward of the batch's tiles gives
+        tiles = gather_patches(slab_dev, 0, H, run._tl_y[4 * b:4 * b + 4], run._tl_x[4 * b:4 * b + 4], win)
+        truth.append(max(float(v.abs().max()) for k, v in m(tiles).items() if k != "Patch-Class"))
+    assert np.array_equal(per_batch, np.array(truth, np.float32)), (per_batch, truth)
+    order = np.argsort(per_batch)
+    hot = int(order[-1])
+    assert per_batch[hot] > per_batch[order[-2]]
+    assert abs(per_batch[2] - per_batch[:2].max()) > 1.0, per_batch  # texture and stain field drive the heads differently: the maximum follows the data
+    m.LOGIT_SATURATION = float(0.5 * (per_batch[hot] + per_batch[order[-2]]))
     rep = run.logit_report()
-    assert rep["above"] == 1 and rep["flagged"] == [(8, 12)] and abs(rep["max"] - per_batch[2]) < 1e-6
+    assert rep["above"] == 1 and rep["flagged"] == [(4 * hot, 4 * hot + 4)] and abs(rep["max"] - per_batch[hot]) < 1e-6
     before = {k: v.clone() for k, v in run.canv.items()}
     assert run.rerun_flagged(slab_dev, 0, rep["flagged"]) == 1
     torch.cuda.synchronize()
     assert m.precision_decision()["conv_algo"] == DEFAULT_ALGO  # the handle is back on its default
-    tiles = gather_patches(slab_dev, 0, H, run._tl_y[8:12], run._tl_x[8:12], win)
+    tiles = gather_patches(slab_dev, 0, H, run._tl_y[4 * hot:4 * hot + 4], run._tl_x[4 * hot:4 * hot + 4], win)
     m.set_conv_algo(1)
     want = m.infer_tiles(tiles, win, type_dtype=torch.uint8)
     m.set_conv_algo(DEFAULT_ALGO)
     changed = 0
     for k, v in run.canv.items():
-        for j, p in enumerate(range(8, 12)):
+        keep = torch.ones(v.shape[:2], dtype=torch.bool, device="cuda")
+        for j, p in enumerate(range(4 * hot, 4 * hot + 4)):
             r, c = divmod(p, 6)
             assert torch.equal(v[r * 256:(r + 1) * 256, c * 256:(c + 1) * 256], want[k][j]), (k, p)
-        keep = torch.ones(v.shape[:2], dtype=torch.bool, device="cuda")
-        keep[256:512, 512:] = False
+            keep[r * 256:(r + 1) * 256, c * 256:(c + 1) * 256] = False
         assert torch.equal(v[keep], before[k][keep]), k
         changed += int((v != before[k]).any())
     assert changed > 0  # F(2x2) and F(4x4) differ in the last bits somewhere
