@@ -689,6 +689,31 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
                        "underneath the next slide; end_to_end_Mpx_s counts all four "
                        "serially, as a one-slide run pays them"}
         del parts
+    # The same dictionary the way run_infer_wsi.py builds it on SEVERAL ranks (round 6): every rank computes the tables + contours of
+    # the instances it owns on its halo + band + halo window and rank 0 receives the compact arrays and the quarter-resolution tissue map -- the
+    # label bands and class canvases (15 B/px) stay on their ranks.  The whole tail again with that hand-over, untimed by `value` (which keeps the
+    # map stitch north_star names): seconds of the per-rank tables + contours (slowest rank), bytes into the root either way.
+    per_rank = None
+    if dist is not None and not args.no_dat:
+        parts2, prof2 = [], {}
+
+        def arr_job():
+            postprocess_bands_and_gather(run, H, W, rank, world, dist, margin=MARGINS, guard=48, canv=OrderedDict(struct), max_band_px=max_band_px, prof=prof2,
+                                         watch=args.watch, parts=parts2, gather_maps=False)
+
+        adt = _timed(arr_job, dev, dist, args.backend)
+        t = torch.tensor([prof2.get("tables_and_contours", {}).get("s", 0.0)], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            arr_bytes = prof2.get("parts_gather", {}).get("bytes", 0) + prof2.get("root_gather", {}).get("bytes", 0)
+            map_bytes = prof.get("root_gather", {}).get("bytes", 0)
+            per_rank = {"tail_with_array_hand_over_s": round(adt, 4), "tables_and_contours_s_slowest_rank": round(float(t.item()), 4),
+                        "bytes_into_rank0": {"instance_arrays_and_quarter_map": int(arr_bytes), "label_bands_and_class_maps": int(map_bytes),
+                                             "ratio": round(map_bytes / max(1, arr_bytes), 1)},
+                        "entries": {p_[0]: int(((p_[1][:, 0] > 0) & (p_[2] >= 3)).sum()) for p_ in parts2}}
+            if dat is not None:
+                dat["per_rank_arrays"] = per_rank
+        del parts2
     res.clear()
     # The REFERENCE's nuclei scheme over the same maps (infer/wsi.py:81-268, 642-684: 4096-px tiles, 64-px margins, strips, cross sections; every
     # tile labelled with skimage's tie order), tiles sharded over the ranks (cerberus_amd/ref_tiling.py) -- what `run_infer_wsi.py
@@ -819,7 +844,7 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
         "roofline": roofline,
         "kernels": rows,
         "postproc": pp,
-        "dat": dat,
+        "dat": dat if dat is not None else ({"per_rank_arrays": per_rank} if per_rank else None),
         "ref_tiling": rt,
         "end_to_end_Mpx_s": round(px / (dt + dat["dat_s"]) / 1e6, 3) if dat else None,
         "multi_gpu": mg,

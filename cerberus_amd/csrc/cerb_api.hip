@@ -1823,6 +1823,13 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 const bool wg_mfma = !wg_wino && (op.ks == 3 || op.ks == 1) && net->conv_algo;
                 hipStream_t wst = st;        // the stream the weight gradient is queued on
                 DevBuf* wws = &net->t_ws;    // ... and its workspace
+                // the MFMA weight gradient (wgrad_reduce_kernel) and the bias column sums ASSIGN their outputs: no zero fill (a step issued
+                // ~230 of these 18-us memsets: 4 ms).  Taken BEFORE the fork event: a new arena slot queues its zero fill on the
+                // caller's stream, and the side stream -- which writes dw / db -- only waits for what that event covers.
+                const bool dw_assigned = (op.ks == 3 || op.ks == 1) && net->conv_algo;
+                float* dw = take(wn * op.G, !dw_assigned);
+                float* db = r.b ? take((size_t)op.Cout * op.G, false) : nullptr;
+                if (!dw) return fail("workspace allocation failed");
                 if (side_wgrad && (wg_wino || wg_mfma)) {
                     const int ho_ = op.stride == 2 ? op.H / 2 : op.H, wo_ = op.stride == 2 ? op.W / 2 : op.W;
                     const size_t need = wg_wino ? cerb_wgrad_wino_workspace_bytes(op.G, op.N, op.H, op.W, op.Cin, op.Cout) : cerb_wgrad_workspace_bytes(op.G, op.N, ho_, wo_, op.Cin, op.Cout, op.ks, nullptr);
@@ -1833,12 +1840,6 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     wws = &net->t_ws2;
                     side_used = true;
                 }
-                // the MFMA weight gradient (wgrad_reduce_kernel) and the bias column sums ASSIGN their outputs: no zero fill (a step issued
-                // ~230 of these 18-us memsets: 4 ms)
-                const bool dw_assigned = (op.ks == 3 || op.ks == 1) && net->conv_algo;
-                float* dw = take(wn * op.G, !dw_assigned);
-                float* db = r.b ? take((size_t)op.Cout * op.G, false) : nullptr;
-                if (!dw) return fail("workspace allocation failed");
                 const PackedConv& pcv = net->conv[op.name];
                 bool dx_done = false;
                 if (pcv.wino_dgrad && net->conv_algo && (op.stride == 1 || (op.H % 2 == 0 && op.W % 2 == 0))) {

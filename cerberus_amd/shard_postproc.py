@@ -55,13 +55,38 @@ def _device_relabel_fn(lab_rows, mapping):
     return out
 
 
+def _device_arrays_fn(lab, n, type_window, owned):
+    """cerb_inst_table (with the class votes) + cerb_inst_contour_* over a rank's WINDOW label map, for the instances it owns (`owned`: 0-based
+    local ids; the other rows are zeroed, which is how the contour kernels skip an id).  -> host arrays (tab [n, 16], cnts [n], pts [P, 2], offs [n])."""
+    from .postproc import inst_contours_device, inst_table_device
+
+    tab = inst_table_device(lab, type_window, n)
+    keep = torch.zeros(max(n, 0), dtype=torch.bool, device=lab.device)
+    if len(owned):
+        keep[torch.from_numpy(np.ascontiguousarray(owned, dtype=np.int64)).to(lab.device)] = True
+    tab = tab * keep[:, None].to(tab.dtype)
+    cnts, pts, offs = inst_contours_device(lab, tab)
+    return tab.cpu().numpy(), cnts, pts, offs
+
+
+def _device_mask_fn(lumen_window, gland_rows):
+    from .postproc import mask_lumen_by_gland
+
+    mask_lumen_by_gland(lumen_window, gland_rows)
+
+
 class BandState(object):
     """Per-rank, per-tissue state carried between the phases."""
 
-    def __init__(self, rank, world, band, y0_global, margin, guard, tissue, ds_factor=1.0):
+    def __init__(self, rank, world, band, y0_global, margin, guard, tissue, ds_factor=1.0, type_band=None):
         assert band.dim() == 3 and band.shape[2] == 2, "band: (rows, W, 2) probability canvas of this rank"
         self.rank, self.world = rank, world
         self.band = band
+        # the tissue's class map over the same rows (uint8, at the band's resolution), or None: its halo rows travel with the probability halos so
+        # that the owner of an instance can take the instance's class votes over ALL of its pixels (owned_parts)
+        self.type_band = type_band
+        self.type_window = None
+        assert type_band is None or tuple(type_band.shape) == tuple(band.shape[:2]), "type_band: (rows, W) class ids over the band's rows"
         self.y0 = int(y0_global)  # global canvas row of band row 0 (at the resolution of `band`)
         self.margin, self.guard = int(margin), int(guard)
         self.tissue, self.ds = tissue, float(ds_factor)
@@ -74,6 +99,21 @@ class BandState(object):
         up = self.band[: self.margin].contiguous() if self.rank > 0 else None
         down = self.band[self.band.shape[0] - self.margin:].contiguous() if self.rank < self.world - 1 else None
         return up, down
+
+    def type_strips(self):
+        """The same rows of the class map (None without one)."""
+        if self.type_band is None:
+            return None, None
+        up = self.type_band[: self.margin].contiguous() if self.rank > 0 else None
+        down = self.type_band[self.type_band.shape[0] - self.margin:].contiguous() if self.rank < self.world - 1 else None
+        return up, down
+
+    def set_type_window(self, type_above, type_below):
+        if self.type_band is None:
+            return
+        parts = [p for p in (type_above, self.type_band, type_below) if p is not None]
+        tw = torch.cat(parts, dim=0) if torch.is_tensor(self.type_band) else np.concatenate([np.asarray(p) for p in parts], axis=0)
+        self.type_window = tw.contiguous() if torch.is_tensor(tw) else np.ascontiguousarray(tw)
 
     # ---- phase 2: label the window ------------------------------------------------------------------------------------
     def label(self, from_above, from_below, label_fn=_device_label_fn, table_fn=_device_table_fn):
@@ -89,7 +129,7 @@ class BandState(object):
         else:
             tab = np.zeros((0, 16), np.int64)
         area, y1, y2, first = tab[:, 0], tab[:, 3], tab[:, 4], tab[:, 7]
-        self.y2 = y2
+        self.y1, self.y2 = y1, y2
         alive = area > 0
         fy = first // self.w
         # global key of an instance: its first pixel in slide raster order
@@ -102,6 +142,7 @@ class BandState(object):
             cut |= y1 < self.guard
         if art_bot:
             cut |= y2 > self.h_win - self.guard
+        self.cut = cut & alive
         self.n_truncated = int((cut & self.in_band).sum())
         # rank-local order of the owned instances = order of their first pixels
         own_idx = np.nonzero(self.owned)[0]
@@ -142,6 +183,49 @@ class BandState(object):
             out = relabel_fn(rows, mapping)
         info = {"n_owned": self.n_owned, "n_truncated": self.n_truncated, "n_unresolved": self.n_unresolved}
         return out, info
+
+    # ---- lumen *= (gland > 0) on the WINDOWS (infer/wsi.py:799-804), before the band rows are cut out of them ------------------------
+    def mask_by(self, gland, mask_fn=_device_mask_fn):
+        """self: the lumen state, gland: the gland state of the same band (both labelled).  The lumen window's rows are taken out of the gland
+        window (its halo is at least as tall), so that an owned lumen is masked over ALL of its pixels -- the halo part included, which is where
+        its table and contour come from (owned_parts).  A gland the window cut and that reaches into the lumen window could mask differently
+        from the whole-slide labelling (an opened hole): such glands are added to the lumen's n_truncated."""
+        d = gland.top - self.top
+        if d < 0 or d + self.h_win > gland.h_win or gland.w != self.w or gland.y0 != self.y0:
+            raise ValueError("lumen masking on windows needs the gland halo to cover the lumen halo (margins: gland >= lumen)")
+        rows = gland.lab[d: d + self.h_win]
+        mask_fn(self.lab, rows)
+        hit = gland.cut & (gland.y2 > d) & (gland.y1 < d + self.h_win)
+        self.n_truncated += int(hit.sum())
+
+    # ---- per-rank instance arrays (VERDICT r5 item 3): what the root needs for dat/<slide>.dat, without the label maps -----------------
+    def owned_parts(self, arrays_fn=_device_arrays_fn):
+        """(tab int64 [k, 16], cnts int32 [k], pts int32 [P, 2]) of the k instances this rank OWNS, in the order of their slide-global ids and in
+        SLIDE coordinates (of this tissue's resolution): cerb_inst_table rows (class votes over the whole instance: the window holds all of it
+        when n_truncated == 0) and the contour runs, shifted from window rows to slide rows in the integer domain -- sum_y += area * dy,
+        y1 / y2 += dy, first += dy * w, contour y += dy -- so that the ranks' arrays, concatenated in rank order, ARE the arrays a one-GPU run
+        computes on the whole label map (ids are ordered by (band, first pixel) = the raster order of the first pixels)."""
+        order = np.asarray(self.own_sorted, dtype=np.int64)
+        if self.n <= 0 or order.size == 0:
+            return np.zeros((0, 16), np.int64), np.zeros(0, np.int32), np.zeros((0, 2), np.int32)
+        tab, cnts, pts, offs = arrays_fn(self.lab, self.n, self.type_window, order)
+        tab, cnts, pts, offs = np.asarray(tab), np.asarray(cnts), np.asarray(pts).reshape(-1, 2), np.asarray(offs)
+        dy = int(self.y0 - self.top)
+        sel = tab[order].astype(np.int64, copy=True)
+        alive = sel[:, 0] > 0  # (a lumen its gland masked away entirely stays as an all-zero row: its id exists, its entry does not)
+        sel[~alive] = 0
+        sel[alive, 2] += sel[alive, 0] * dy
+        sel[alive, 3] += dy
+        sel[alive, 4] += dy
+        sel[alive, 7] += dy * self.w
+        c = cnts[order].astype(np.int64)
+        c[~alive] = 0
+        total = int(c.sum())
+        new_offs = np.cumsum(c) - c
+        idx = np.repeat(offs[order].astype(np.int64) - new_offs, c) + np.arange(total, dtype=np.int64)
+        p = pts[idx].astype(np.int32, copy=True) if total else np.zeros((0, 2), np.int32)
+        p[:, 1] += dy
+        return sel, c.astype(np.int32), p
 
 
 def run_local(bands, tissue, margin, guard, ds_factor=1.0, label_fn=_device_label_fn, table_fn=_device_table_fn,
@@ -271,32 +355,57 @@ def _tock(prof):
     return time.perf_counter()
 
 
-def run_distributed(band, y0_global, tissue, margin, guard, dist, ds_factor=1.0, label_fn=_device_label_fn,
-                    table_fn=_device_table_fn, relabel_fn=_device_relabel_fn, prof=None, watch=None):
-    """One rank of the real thing.  `dist` = torch.distributed (initialised).  Returns (band labels with global ids,
-    total instance count over all ranks, info dict).  watch: a launch.PhaseWatch -- a collective that does not return ends the rank with
-    the name of the phase it was in."""
+def dist_label(band, y0_global, tissue, margin, guard, dist, ds_factor=1.0, label_fn=_device_label_fn, table_fn=_device_table_fn, prof=None, watch=None,
+               type_band=None):
+    """First half of one rank's work for one tissue: halo exchange (probabilities, and the class map's rows when `type_band` is given) and the
+    labelling of halo + band + halo.  -> the labelled BandState."""
     from .launch import null_watch
 
     watch = watch or null_watch()
     rank, world = dist.get_rank(), dist.get_world_size()
-    st = BandState(rank, world, band, y0_global, margin, guard, tissue, ds_factor)
+    st = BandState(rank, world, band, y0_global, margin, guard, tissue, ds_factor, type_band=type_band)
     up, down = st.strips()
     above = torch.empty_like(up) if rank > 0 else None
     below = torch.empty_like(down) if rank < world - 1 else None
     t0 = _tock(prof)
     with watch.phase("halo exchange (%s)" % tissue):
         halo_exchange(dist, rank, world, up, down, above, below)
-    _tick(prof, "halo_exchange", sum(t.numel() * t.element_size() for t in (above, below) if t is not None), t0)
+        nb = sum(t.numel() * t.element_size() for t in (above, below) if t is not None)
+        if type_band is not None:
+            tup, tdown = st.type_strips()
+            tabove = torch.empty_like(tup) if rank > 0 else None
+            tbelow = torch.empty_like(tdown) if rank < world - 1 else None
+            halo_exchange(dist, rank, world, tup, tdown, tabove, tbelow)
+            st.set_type_window(tabove, tbelow)
+            nb += sum(t.numel() * t.element_size() for t in (tabove, tbelow) if t is not None)
+    _tick(prof, "halo_exchange", nb, t0)
     t0 = _tock(prof)
     with watch.phase("band labelling (%s)" % tissue):
-        n_owned = st.label(above, below, label_fn, table_fn)
+        st.n_owned_ = st.label(above, below, label_fn, table_fn)
     _tick(prof, "label_" + tissue, 0, t0)
+    return st
+
+
+def dist_resolve(st, dist, relabel_fn=_device_relabel_fn, prof=None, watch=None):
+    """Second half: the count / border-id all-gathers and the relabelling of the band rows.  -> (band labels with global ids, total, info)."""
+    from .launch import null_watch
+
+    watch = watch or null_watch()
+    rank, world = dist.get_rank(), dist.get_world_size()
     t0 = _tock(prof)
-    with watch.phase("instance-count / border-id all-gathers (%s)" % tissue):
-        out, total, info = _publish_and_resolve(st, n_owned, band.device, dist, rank, world, relabel_fn)
-    _tick(prof, "ids_" + tissue, 0, t0)
+    with watch.phase("instance-count / border-id all-gathers (%s)" % st.tissue):
+        out, total, info = _publish_and_resolve(st, st.n_owned_, st.band.device, dist, rank, world, relabel_fn)
+    _tick(prof, "ids_" + st.tissue, 0, t0)
     return out, total, info
+
+
+def run_distributed(band, y0_global, tissue, margin, guard, dist, ds_factor=1.0, label_fn=_device_label_fn,
+                    table_fn=_device_table_fn, relabel_fn=_device_relabel_fn, prof=None, watch=None):
+    """One rank of the real thing.  `dist` = torch.distributed (initialised).  Returns (band labels with global ids,
+    total instance count over all ranks, info dict).  watch: a launch.PhaseWatch -- a collective that does not return ends the rank with
+    the name of the phase it was in."""
+    st = dist_label(band, y0_global, tissue, margin, guard, dist, ds_factor, label_fn, table_fn, prof, watch)
+    return dist_resolve(st, dist, relabel_fn, prof, watch)
 
 
 def halo_exchange(dist, rank, world, up, down, above, below):
@@ -373,18 +482,30 @@ def local_band_count(rows, cols, max_band_px, margin=0):
     return nb
 
 
-def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guard=48, max_band_px=None, prof=None, watch=None, pre=None):
+def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guard=48, max_band_px=None, prof=None, watch=None, pre=None, arrays=None,
+                        type_canv=None, fns=None):
     """Per-rank replacement of WSIRunner.postprocess for band canvases: label maps of THIS rank's band with slide-global
     ids, nothing gathered.  margin: halo rows at full resolution, an int or {tissue: rows, "default": rows} (the reference's
     own nuclei margin is 64 px, infer/wsi.py:906-915; gland clusters need hundreds).  canv: the band canvases of this rank (full-resolution rows of equal count on every rank except
     the last).  Gland / lumen run at x0.5 in wsi_mode (infer/wsi.py:786-804); their margin / guard are halved accordingly.
     max_band_px (world == 1 only): a canvas larger than this is labelled as several row bands one after the other through the
     same halo / ownership / id protocol the ranks use (`run_local`) -- the one-GPU streaming path for slides whose 96 B / px
-    labelling workspace would not fit, or that exceed the 2^31-pixel limit of one call."""
+    labelling workspace would not fit, or that exceed the 2^31-pixel limit of one call.
+    arrays (multi-rank path): a dict that receives {tissue: (tab, cnts, pts, has_type, ds_factor)} -- the instance-table rows and contour runs of
+    the instances THIS rank owns, in slide coordinates and global-id order (BandState.owned_parts): what rank 0 needs for dat/<slide>.dat
+    instead of the label maps (infer/wsi.py:805-853).  type_canv: the band's class canvases ("<Tissue>-TYPE", uint8, full resolution; default:
+    the TYPE entries of `canv`) whose halo rows then travel with the probability halos.
+    fns (multi-rank path): {"label", "table", "relabel", "arrays", "mask"} overriding the HIP kernels -- the gloo tests inject numpy stand-ins to
+    exercise the protocol (tests/test_host_logic.py); the product never passes it."""
+    fns = fns or {}
+    f_label, f_table = fns.get("label", _device_label_fn), fns.get("table", _device_table_fn)
+    f_relabel, f_arrays, f_mask = fns.get("relabel", _device_relabel_fn), fns.get("arrays", _device_arrays_fn), fns.get("mask", _device_mask_fn)
     from .postproc import mask_lumen_by_gland
     from .wsi import downsample2_inst
 
     inst, info = OrderedDict(), OrderedDict()
+    states = OrderedDict()
+    type_canv = canv if type_canv is None else type_canv
     rows = int(next(iter(canv.values())).shape[0])
     cnt = torch.tensor([rows], dtype=torch.int64, device=next(iter(canv.values())).device)
     allr = [torch.zeros_like(cnt) for _ in range(world)]
@@ -405,7 +526,13 @@ def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guar
         mt = margin.get(t, margin.get("default", 512)) if isinstance(margin, dict) else margin  # per-tissue halo: nuclei need far less than glands
         m, g, yy, ds = (mt // 2, guard // 2, y0 // 2, 0.5) if half else (mt, guard, y0, 1.0)
         if dist is not None:  # also at world == 1 when the caller initialised a process group (bench.py --force-dist, the nccl test)
-            inst[t], _, info[t] = run_distributed(band, yy, t, m, g, dist, ds, prof=prof, watch=watch)
+            tb = None
+            if arrays is not None and (t + "-TYPE") in type_canv:
+                tb = type_canv[t + "-TYPE"]
+                # the half-resolution tissues read the strided sub-sample of the class canvas (cerberus_amd.wsi.build_wsi_inst_info's stated deviation);
+                # band row offsets are even, so the band's sub-sample is the band's rows of the slide's sub-sample
+                tb = (tb[::2, ::2][: band.shape[0], : band.shape[1]] if half else tb[: band.shape[0], : band.shape[1]]).contiguous()
+            states[t] = dist_label(band, yy, t, m, g, dist, ds, f_label, f_table, prof=prof, watch=watch, type_band=tb)
         else:
             t0 = _tock(prof)
             nb = local_band_count(int(band.shape[0]), int(band.shape[1]), max_band_px, m)  # (half-resolution maps: their own pixel count, halved margin)
@@ -421,9 +548,62 @@ def sharded_postprocess(canv, rank, world, dist, wsi_mode=True, margin=512, guar
             if pre and t in pre:
                 info[t]["bands_labelled_under_inference"] = pre[t].early
             _tick(prof, "label_" + t, 0, t0)
-    if "Lumen" in inst and "Gland" in inst:
+    if states:
+        # lumen *= (gland > 0) on the windows, before band rows and instance arrays are taken out of them (a no-op later on the band rows)
+        masked_on_windows = False
+        if "Lumen" in states and "Gland" in states:
+            try:
+                states["Lumen"].mask_by(states["Gland"], f_mask)
+                masked_on_windows = True
+            except ValueError:
+                if arrays is not None:  # the owner's table needs the masked window
+                    raise
+        for t, st in states.items():
+            inst[t], _, info[t] = dist_resolve(st, dist, f_relabel, prof=prof, watch=watch)
+        if "Lumen" in inst and "Gland" in inst and not masked_on_windows:
+            mask_lumen_by_gland(inst["Lumen"], inst["Gland"])
+        if arrays is not None:
+            t0 = _tock(prof)
+            for t, st in states.items():
+                half = wsi_mode and t != "Nuclei"
+                tab, cnts, pts = st.owned_parts(f_arrays)
+                arrays[t] = (tab, cnts, pts, st.type_window is not None, 0.5 if half else 1.0)
+            _tick(prof, "tables_and_contours", 0, t0)
+    elif "Lumen" in inst and "Gland" in inst:
         mask_lumen_by_gland(inst["Lumen"], inst["Gland"])
     return inst, info
+
+
+def gather_parts(local, dist, rank, world, dev, prof=None):
+    """Per-rank instance arrays -> the root's `parts` list ([(tissue, tab, cnts, pts, offs, has_type, ds_factor)], the format of
+    cerberus_amd.wsi.collect_wsi_inst_arrays): per tissue one all-gather of the two lengths, then three padded gathers (table rows, contour
+    counts, contour points).  ~0.36 GB for the 885 k instances of a 40000^2 slide against 21 GB of label + class maps.  None off the root."""
+    parts = [] if rank == 0 else None
+    moved = 0
+    t0 = _tock(prof)
+    for t, (tab, cnts, pts, has_type, ds) in local.items():
+        ln = torch.tensor([tab.shape[0], pts.shape[0]], dtype=torch.int64, device=dev)
+        alln = [torch.zeros_like(ln) for _ in range(world)]
+        dist.all_gather(alln, ln)
+        lens = [(int(x[0].item()), int(x[1].item())) for x in alln]
+        kmax, pmax = max(1, max(k for k, _ in lens)), max(1, max(p_ for _, p_ in lens))
+        got = []
+        for arr, rows, cols, dt in ((tab, kmax, 16, torch.int64), (cnts.reshape(-1, 1), kmax, 1, torch.int32), (pts, pmax, 2, torch.int32)):
+            buf = torch.zeros((rows, cols), dtype=dt, device=dev)
+            if arr.shape[0]:
+                buf[: arr.shape[0]] = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+            lst = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+            dist.gather(buf, lst, dst=0)
+            moved += (world - 1) * buf.numel() * buf.element_size()
+            got.append(lst)
+        if rank == 0:
+            tabs = np.concatenate([got[0][r][: lens[r][0]].cpu().numpy() for r in range(world)], axis=0)
+            cn = np.concatenate([got[1][r][: lens[r][0], 0].cpu().numpy() for r in range(world)], axis=0)
+            pt = np.concatenate([got[2][r][: lens[r][1]].cpu().numpy() for r in range(world)], axis=0)
+            offs = np.cumsum(cn.astype(np.int64)) - cn
+            parts.append((t, tabs, cn, pt, offs, has_type, ds))
+    _tick(prof, "parts_gather", moved, t0)
+    return parts
 
 
 def band_view(run, H, W, canv=None):
@@ -447,28 +627,67 @@ def _gather_rows(lab, rows_per_rank, cols, dist, rank, world):
     return torch.cat([lst[i][: rows_per_rank[i]] for i in range(world)], dim=0)
 
 
-def postprocess_bands_and_gather(run, H, W, rank, world, dist, margin=512, guard=48, canv=None, max_band_px=None, prof=None, watch=None, pre=None):
+def postprocess_bands_and_gather(run, H, W, rank, world, dist, margin=512, guard=48, canv=None, max_band_px=None, prof=None, watch=None, pre=None,
+                                 parts=None, gather_maps=True):
     """The tail of a slide on 1..N GPUs: band-local label maps with slide-global ids, then only the int32 label bands and the
     uint8 / float class canvases travel to the root (12 + 3 B/px instead of the 36 B/px of raw probability canvases).
     `run` is this rank's WSIRunner after infer_band.  Returns (inst, info, small) -- inst / small are None off the root.
     pre: band_view(run, H, W, canv) labellers from make_incremental that were fed during the inference (one-GPU jobs).
     canv: label these band canvases instead of run.canv (bench.py's structured probability maps); max_band_px: see
-    sharded_postprocess; prof: dict collecting bytes / seconds of the halo exchange and the root gather."""
+    sharded_postprocess; prof: dict collecting bytes / seconds of the halo exchange and the root gather.
+    parts (a list; multi-rank path only): every rank builds the instance tables + contours of the instances it OWNS on its halo + band + halo
+    window and the root receives the compact arrays -- `parts` is extended there with collect_wsi_inst_arrays' tuples, ready for the .dat
+    writer (infer/wsi.py:805-853).  gather_maps=False: the label bands and the class canvases then stay where they are (`inst` is None, `small`
+    holds only the quarter-resolution tissue map "Patch-Class@0.25" that tissue/<slide>.mat is written from): ~0.8 GB into the root
+    instead of 21 GB for a 40000^2 slide.  run_infer_wsi.py gathers the maps only under --save_label_maps."""
     from .wsi import gather_bands, half_size
 
     geo = run.geo
     src = run.canv if canv is None else canv
     valid = max(0, min(run.band_h, H - run.r0 * geo.out))
     band = OrderedDict((k, v[:valid, :W]) for k, v in src.items())
-    inst_b, info = sharded_postprocess(band, rank, world, dist, wsi_mode=True, margin=margin, guard=guard, max_band_px=max_band_px, prof=prof, watch=watch, pre=pre)
+    local = OrderedDict() if (parts is not None and dist is not None) else None
+    tcanv = OrderedDict((k, v[:valid, :W]) for k, v in run.canv.items() if k.endswith("TYPE"))
+    inst_b, info = sharded_postprocess(band, rank, world, dist, wsi_mode=True, margin=margin, guard=guard, max_band_px=max_band_px, prof=prof, watch=watch, pre=pre,
+                                       arrays=local, type_canv=tcanv)
     bounds = geo.bounds(world)
     rows = [max(0, min((bounds[i + 1] - bounds[i]) * geo.out, H - bounds[i] * geo.out)) for i in range(world)]
-    inst = OrderedDict() if rank == 0 else None
-    t0 = _tock(prof)
-    moved = 0
     from .launch import null_watch
 
     watch = watch or null_watch()
+    dev = next(iter(run.canv.values())).device
+    if local is not None:
+        with watch.phase("instance-array gather to rank 0"):
+            got = gather_parts(local, dist, rank, world, dev, prof=prof)
+        if rank == 0:
+            parts.extend(got)
+    if not gather_maps:
+        if dist is None:
+            raise ValueError("gather_maps=False is the multi-rank path (one rank holds its maps already)")
+        small = None
+        if "Patch-Class" in run.canv:
+            from .tissue import pclass_tissue_map
+
+            t0 = _tock(prof)
+            pc = run.canv["Patch-Class"][:valid, :W]
+            aligned = all(r % 8 == 0 for r in rows[:-1])  # then the bands' quarter maps are the rows of the slide's (cv2 INTER_NEAREST samples 4 y, 4 x)
+            with watch.phase("tissue-map gather to rank 0"):
+                if aligned:
+                    q = pclass_tissue_map(pc)
+                    rq = [int(round(r * 0.25)) for r in rows]
+                    g = _gather_rows(q, rq, int(round(W * 0.25)), dist, rank, world)
+                    moved = (world - 1) * max(rq) * int(round(W * 0.25)) * 4
+                    small = None if rank != 0 else OrderedDict([("Patch-Class@0.25", g)])
+                else:  # (patch rows that are not multiples of 8 pixels: the whole class map travels, as before)
+                    small = gather_bands(OrderedDict([("Patch-Class", run.canv["Patch-Class"])]), geo, rank, world, dist)
+                    moved = (world - 1) * run.canv["Patch-Class"].numel() * 4
+            _tick(prof, "root_gather", moved, t0)
+        elif rank == 0:
+            small = OrderedDict()
+        return None, info, small
+    inst = OrderedDict() if rank == 0 else None
+    t0 = _tock(prof)
+    moved = 0
     for t, lab in inst_b.items():
         half = t != "Nuclei"
         rr = [half_size(r) for r in rows] if half else rows

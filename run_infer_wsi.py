@@ -185,7 +185,7 @@ def main(argv=None):
                 def source(a, b):
                     up = SlabUploader(host, a, b)
                     return up.slab, up.upload_until
-            pprof, records, ref_nuclei = {}, None, None
+            pprof, records, ref_nuclei, rank_parts = {}, None, None, None
             inst, _, maps = infer_and_label_streamed(manager.net, source, (H, W), win, out, batch, plan.sub_bands, prof=pprof)
             torch.cuda.synchronize()
             t1 = t2 = time.perf_counter()
@@ -248,12 +248,18 @@ def main(argv=None):
                 log.info("Inference Time: {0}".format(t1 - t_prep))
             records = None
             pprof = {}
+            rank_parts = None
             if mask is None and (dist is not None or H * W > ONE_CALL_PX):
                 # band-local labelling with slide-global ids; only int32 label bands and the class maps travel to the root.  On ONE GPU a
                 # slide too large for a single labelling call (96 B / px of workspace, 2^31 px) streams through the same protocol band by band
                 from cerberus_amd.shard_postproc import postprocess_bands_and_gather
 
-                inst, _, maps = postprocess_bands_and_gather(run, H, W, rank, world, dist, max_band_px=ONE_CALL_PX if world == 1 else None, prof=pprof, watch=watch, pre=pre)
+                # Several ranks: every rank builds the instance tables + contours of the instances it owns (on its halo + band + halo window) and rank 0
+                # receives those compact arrays (~0.4 GB for a 40000^2 slide) plus the quarter-resolution tissue map; the int32 label bands and the
+                # class canvases (15 B / px = 21 GB) only travel when the maps themselves are asked for (--save_label_maps)
+                rank_parts = [] if (dist is not None and not args["--save_label_maps"]) else None
+                inst, _, maps = postprocess_bands_and_gather(run, H, W, rank, world, dist, max_band_px=ONE_CALL_PX if world == 1 else None, prof=pprof, watch=watch, pre=pre,
+                                                             parts=rank_parts, gather_maps=rank_parts is None)
             else:  # with a mask gland / lumen are labelled per tissue region (infer/wsi.py:730-835), on the root
                 with watch.phase("canvas gather to rank 0 (%s)" % base):
                     maps = run.gather_to_root(dist)
@@ -295,13 +301,14 @@ def main(argv=None):
                 log.info("Nuclei Post Proc Time: {0}".format(t_nuc))
             else:
                 log.info("Nuclei, Gland & Lumen Labelling Time: {0}".format(t2 - t1))
-        if "Patch-Class" in maps:  # tissue-region map (infer/wsi.py:688-716)
+        if "Patch-Class" in maps or "Patch-Class@0.25" in maps:  # tissue-region map (infer/wsi.py:688-716)
             import scipy.io as sio
 
             from cerberus_amd.tissue import pclass_tissue_map
 
             os.makedirs(os.path.join(out_dir, "tissue"), exist_ok=True)
-            pmap = pclass_tissue_map(maps["Patch-Class"], None if regions is None else regions.mask)
+            # (several ranks without --save_label_maps: every rank resized its own band, the root holds the stitched quarter-resolution map)
+            pmap = maps["Patch-Class@0.25"] if "Patch-Class@0.25" in maps else pclass_tissue_map(maps["Patch-Class"], None if regions is None else regions.mask)
             sio.savemat(os.path.join(out_dir, "tissue", base + ".mat"), {"pclass": pmap.cpu().numpy()})
         if log:
             log.info("Tissue Region Post Proc Time: {0}".format(time.perf_counter() - t2))
@@ -316,7 +323,7 @@ def main(argv=None):
                                 **({"pclass": maps["Patch-Class"].cpu().numpy()[::4, ::4]} if "Patch-Class" in maps else {}))
         t3 = time.perf_counter()
         os.makedirs(os.path.dirname(dat_path), exist_ok=True)
-        nuc_only = {k: v for k, v in inst.items() if k == "Nuclei"} if records is not None else inst
+        nuc_only = None if inst is None else ({k: v for k, v in inst.items() if k == "Nuclei"} if records is not None else inst)
         bw, bh = reader.info.slide_dimensions
         prebuilt = None
         # The dictionary's GPU half (tables, contours) here; its ~1e6 per-instance Python objects, the uuid keys and the pickle in a separate,
@@ -333,7 +340,11 @@ def main(argv=None):
                         dst[uuid.uuid4().hex] = v
         for tissue, d in (prebuilt or {}).items():
             extra[tissue] = d
-        parts = collect_wsi_inst_arrays(nuc_only, maps, (H, W), skip=tuple(extra.keys()) + (("Nuclei",) if ref_nuclei is not None else ()))
+        skip = tuple(extra.keys()) + (("Nuclei",) if ref_nuclei is not None else ())
+        if rank_parts is not None:  # built by the ranks that own the instances, gathered as arrays
+            parts = [p_ for p_ in rank_parts if p_[0] not in skip]
+        else:
+            parts = collect_wsi_inst_arrays(nuc_only, maps, (H, W), skip=skip)
         if ref_nuclei is not None:  # the reference-tiled nuclei replace the band scheme's: same kind of arrays (+ per-instance tile origins)
             parts.insert(0, ref_nuclei)
         meta = wsi_meta((H, W), float(args["--wsi_proc_mag"]), base_mag=None if reader.info.mpp is None else float(reader.info.mpp[0]), base_hw=(bh, bw))

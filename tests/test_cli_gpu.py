@@ -211,6 +211,11 @@ def test_bench_contract_eight_ranks_time_sharing_one_gpu():
         assert eight["postproc"][t]["n_truncated"] == 0 and eight["postproc"][t]["n_unresolved"] == 0, eight["postproc"][t]
     mg = eight["multi_gpu"]
     assert mg["halo_exchange"]["bytes_into_rank0"] > 0 and mg["root_gather"]["bytes_into_rank0"] > 0
+    # round 6: the dictionary from per-rank tables + contours -- the eight ranks' owned instances make exactly the entries the one-GPU run writes,
+    # and the root receives >= 20x fewer bytes than the label bands + class maps it no longer needs
+    pr = eight["dat"]["per_rank_arrays"]
+    assert pr["entries"] == one["dat"]["entries"] == eight["dat"]["entries"], (pr["entries"], one["dat"]["entries"])
+    assert pr["bytes_into_rank0"]["ratio"] >= 20.0 and pr["tables_and_contours_s_slowest_rank"] > 0, pr
 
 
 def test_bench_nccl_branch_at_world_one():
@@ -514,6 +519,57 @@ def test_run_infer_wsi_nccl_world_one_equals_no_dist(tmp_path):
             ba = sorted(tuple(int(v) for v in d["box"]) for d in da[t].values())
             bb = sorted(tuple(int(v) for v in d["box"]) for d in db[t].values())
             assert ba == bb, (tag, t, len(ba), len(bb))
+
+
+def _dat_entries(path):
+    import joblib
+
+    d = joblib.load(path)
+    out = {}
+    for t in ("Nuclei", "Gland", "Lumen"):
+        out[t] = sorted((tuple(int(v) for v in e["box"]), tuple(float(v) for v in np.asarray(e["centroid"], np.float64)), np.asarray(e["contour"], np.int64).tobytes(),
+                         e.get("type"), None if "type_prob" not in e else round(float(e["type_prob"]), 12)) for e in d.get(t, {}).values())
+    return out, d
+
+
+def test_run_infer_wsi_dat_from_per_rank_arrays(tmp_path):
+    """run_infer_wsi.py WITHOUT --save_label_maps on a process group: the ranks build instance tables + contours for the instances they own and rank 0
+    only receives arrays + the quarter-resolution tissue map (cerberus_amd/shard_postproc.py gather_parts).  Over a one-rank RCCL communicator the
+    dat/<slide>.dat equals the file of the run without a process group entry for entry (uuid keys aside) and tissue/<slide>.mat bit for bit; two
+    ranks over host-staged gloo (both on this GPU) write the same tissue map and a dictionary with the same tissues (this random-weight network
+    paints slide-sized blobs that no halo resolves: the instance-level equality of several ranks is tests/test_drivers_gpu.py's, on structured maps)."""
+    import scipy.io as sio
+
+    spec = tmp_path / "slides"
+    spec.mkdir()
+    (spec / "s1.txt").write_text("synthetic:1500x1100:5")
+    base = ["--synthetic", "--input_dir=%s" % spec, "--wsi_file_ext=.txt", "--batch_size=6", "--patch_input_shape=256", "--patch_output_shape=256"]
+    outs = {}
+    for mode in ("nodist", "nccl1", "gloo2"):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571")
+        cmd = [sys.executable, os.path.join(ROOT, "run_infer_wsi.py")]
+        if mode == "nccl1":
+            env.update(CERB_FORCE_DIST="1", CERB_DIST_BACKEND="nccl")
+            cmd += ["--gpu=0"]
+        elif mode == "gloo2":
+            env.update(CERB_DIST_BACKEND="gloo")
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29572",
+                   os.path.join(ROOT, "run_infer_wsi.py")]
+        out = tmp_path / mode
+        r = subprocess.run(cmd + base + ["--output_dir=%s" % out], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert not (out / "s1.npz").exists()
+        outs[mode] = out
+    want, dw = _dat_entries(str(outs["nodist"] / "dat" / "s1.dat"))
+    have, dh = _dat_entries(str(outs["nccl1"] / "dat" / "s1.dat"))
+    assert sum(len(v) for v in want.values()) > 0
+    for t in want:
+        assert have[t] == want[t], (t, len(have[t]), len(want[t]))
+    two, d2 = _dat_entries(str(outs["gloo2"] / "dat" / "s1.dat"))
+    assert set(d2.keys()) == set(dw.keys()) == set(dh.keys())
+    pm = sio.loadmat(str(outs["nodist"] / "tissue" / "s1.mat"))["pclass"]
+    for mode in ("nccl1", "gloo2"):
+        assert np.array_equal(sio.loadmat(str(outs[mode] / "tissue" / "s1.mat"))["pclass"], pm), mode
 
 
 def test_run_infer_tile_nccl_world_one_equals_no_dist(tmp_path):

@@ -520,3 +520,127 @@ def test_slide_streamed_in_sub_bands_equals_the_resident_run(manager):
                     assert torch.equal(got[t], want[t]), (nb, t)
                 elif info[t]["n_truncated"] == 0 and info[t]["n_unresolved"] == 0:  # (the test weights' slide-sized blobs are cut by any window: then the
                     assert same_partition(got[t].cpu().numpy(), want[t].cpu().numpy()), (nb, t)  # protocol itself reports that it is not exact)
+
+
+# ---- per-rank instance tables + contours, arrays gathered instead of label maps ------------------------------------------
+def _parts_maps(H, W):
+    from cerberus_amd import synth_maps as synth
+
+    maps = {"Nuclei-INST": synth.nuclei_maps(H, W, 31, 600.0, noise=0.02),
+            "Gland-INST": synth.blob_maps(H, W, 9, 40, 20.0, 70.0, rim=4.0, sharp=1.0, noise=0.02, holes=0.3),
+            "Lumen-INST": synth.blob_maps(H, W, 11, 90, 8.0, 30.0, rim=2.0, sharp=1.0, noise=0.02)}
+    rs = np.random.RandomState(12)
+    # class maps in coarse random blocks (so that an instance's majority vote depends on ALL of its pixels, the ones in the halo included)
+    blk = lambda k: np.kron(rs.randint(0, k, (H // 16, W // 16)), np.ones((16, 16), np.int64)).astype(np.uint8)  # noqa: E731
+    types = {"Nuclei-TYPE": blk(7), "Gland-TYPE": blk(3), "Patch-Class": np.kron(rs.randint(0, 9, (H // 256, W // 256)), np.ones((256, 256))).astype(np.float32)}
+    return maps, types
+
+
+class _BandRun(object):
+    """What postprocess_bands_and_gather reads of a WSIRunner: geometry, band position, the band's canvases."""
+
+    def __init__(self, geo, rank, world, canv):
+        self.geo = geo
+        self.r0, self.r1 = geo.band(rank, world)
+        self.band_h = (self.r1 - self.r0) * geo.out
+        self.canv = canv
+
+
+def _gpu_parts_worker(rank, world, port, backend, ret):
+    import os
+
+    import torch.distributed as dist
+
+    from cerberus_amd.hostdist import HostStagedDist
+    from cerberus_amd.shard_postproc import postprocess_bands_and_gather
+    from cerberus_amd.wsi import SlideGeometry
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    d = dist if backend == "nccl" else HostStagedDist(dist)
+    H, W = 1500, 1024  # 6 patch rows of 256, the last one ragged
+    geo = SlideGeometry((H, W), 256, 256)
+    maps, types = _parts_maps(geo.rows * 256, W)
+    r0, r1 = geo.band(rank, world)
+    canv = {k: torch.from_numpy(v[r0 * 256:r1 * 256].copy()).cuda() for k, v in list(maps.items()) + list(types.items())}
+    run = _BandRun(geo, rank, world, canv)
+    parts, prof = [], {}
+    inst, info, small = postprocess_bands_and_gather(run, H, W, rank, world, d, margin={"Nuclei": 128, "Gland": 448, "Lumen": 256}, guard=48, parts=parts,
+                                                     gather_maps=False, prof=prof)
+    assert inst is None
+    ret.put((rank, parts if rank == 0 else None, {t: {k: int(v) for k, v in i.items()} for t, i in info.items()},
+             None if small is None else {k: v.cpu().numpy() for k, v in small.items()},
+             {k: (int(v["bytes"]), float(v["s"])) for k, v in prof.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _entries(parts):
+    """The dictionary entries of a parts list as sortable tuples (uuid keys aside)."""
+    from cerberus_amd.inst_info import info_from_table
+
+    out = {}
+    for part in parts:
+        tissue, tab, cnts, pts, offs, has_type, ds = part[:7]
+        info = info_from_table(tab, cnts, pts, offs, bool(has_type), float(ds), flat_box=True)
+        out[tissue] = sorted((tuple(int(v) for v in d["box"]), tuple(float(v) for v in np.asarray(d["centroid"], np.float64)), d["contour"].astype(np.int64).tobytes(),
+                              d.get("type"), None if "type_prob" not in d else round(float(d["type_prob"]), 12)) for d in info.values())
+    return out
+
+
+@pytest.mark.parametrize("world,backend", [(2, "gloo"), (3, "gloo"), (1, "nccl")])
+def test_per_rank_instance_tables_and_contours_equal_the_one_gpu_dictionary(world, backend):
+    """postprocess_bands_and_gather(parts=..., gather_maps=False) with the DEVICE kernels in every rank (gloo: the ranks share this GPU and stage
+    their collectives through the host; nccl: a one-rank RCCL communicator): the entries built from the gathered arrays -- box, centroid, contour,
+    type, type_prob -- are the entries of the one-GPU run over the whole maps, one for one; the root receives arrays and the quarter-resolution
+    tissue map only."""
+    import queue
+    import socket
+    import time
+
+    import torch.multiprocessing as mp
+
+    from cerberus_amd.tissue import pclass_tissue_map
+    from cerberus_amd.wsi import WSIRunner, collect_wsi_inst_arrays
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_parts_worker, args=(r, world, port, backend, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, t_end = [], time.time() + 400
+    while len(got) < world:
+        try:
+            got.append(ret.get(timeout=2))
+        except queue.Empty:
+            if [p.exitcode for p in procs if p.exitcode not in (None, 0)] or time.time() > t_end:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise AssertionError("a rank died or timed out: exit codes %s" % [p.exitcode for p in procs])
+    got.sort(key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    H, W = 1500, 1024
+    maps, types = _parts_maps(1536, W)
+    canv = {k: torch.from_numpy(v[:H]).cuda() for k, v in list(maps.items()) + list(types.items())}
+    inst, _ = WSIRunner.postprocess(canv, wsi_mode=True)
+    want = _entries(collect_wsi_inst_arrays(inst, canv, (H, W)))
+    have = _entries(got[0][1])
+    for t in ("Nuclei", "Gland", "Lumen"):
+        assert all(g[2][t]["n_truncated"] == 0 and g[2][t]["n_unresolved"] == 0 for g in got), (t, [g[2][t] for g in got])
+        assert len(want[t]) > (300 if t == "Nuclei" else 5), (t, len(want[t]))
+        assert have[t] == want[t], (t, len(have[t]), len(want[t]))
+    assert any(e[3] not in (None, 0) for e in have["Nuclei"]) and any(e[3] is not None for e in have["Gland"]) and all(e[3] is None for e in have["Lumen"])
+    # the root got the quarter-resolution tissue map, stitched from the bands' own resizes
+    assert list(got[0][3].keys()) == ["Patch-Class@0.25"]
+    assert np.array_equal(got[0][3]["Patch-Class@0.25"], pclass_tissue_map(canv["Patch-Class"]).cpu().numpy())
+    if world > 1:  # bytes into the root: arrays + the small map, against 15 B / px of label + class maps
+        moved = got[0][4]["parts_gather"][0] + got[0][4]["root_gather"][0]
+        assert moved * 5 < 15 * H * W * (world - 1) / world, moved  # (a 1.5 Mpx toy slide with padded buffers: already 5x below the maps; bench.py reports the slide-scale figure)

@@ -202,6 +202,145 @@ def test_sharded_postproc_protocol_gloo(world, tissue):
     assert len(crossing) > 0  # the case exercises instances that straddle a band edge
 
 
+# ---- per-rank instance arrays: tables + contours where the instances live, compact arrays to the root ----------------
+def _np_full_table(lab, n, tmap=None):
+    """numpy stand-in for cerb_inst_table with every column (area, sum_x, sum_y, y1, y2, x1, x2, first, 8 class votes)"""
+    lab = np.asarray(lab)
+    h, w = lab.shape
+    t = np.zeros((n, 16), np.int64)
+    t[:, 3], t[:, 5], t[:, 7] = h, w, h * w
+    ys, xs = np.nonzero(lab)
+    ids = lab[ys, xs] - 1
+    np.add.at(t[:, 0], ids, 1)
+    np.add.at(t[:, 1], ids, xs)
+    np.add.at(t[:, 2], ids, ys)
+    np.minimum.at(t[:, 3], ids, ys)
+    np.maximum.at(t[:, 4], ids, ys + 1)
+    np.minimum.at(t[:, 5], ids, xs)
+    np.maximum.at(t[:, 6], ids, xs + 1)
+    np.minimum.at(t[:, 7], ids, ys * w + xs)
+    if tmap is not None:
+        np.add.at(t, (ids, 8 + (np.asarray(tmap)[ys, xs] & 7)), 1)
+    return t
+
+
+def _np_arrays_fn(lab, n, type_window, owned):
+    """Stand-in for the device arrays function: the full table, rows of the instances the rank does not own zeroed, and as the "contour" of an
+    instance the four corners of its box in window coordinates (the protocol only moves and shifts the points)."""
+    tab = _np_full_table(lab, n, type_window)
+    keep = np.zeros(n, bool)
+    keep[np.asarray(owned, np.int64)] = True
+    tab[~keep] = 0
+    alive = tab[:, 0] > 0
+    cnts = np.where(alive, 4, 0).astype(np.int32)
+    offs = (np.cumsum(cnts) - cnts).astype(np.int64)
+    pts = np.zeros((int(cnts.sum()), 2), np.int32)
+    for i in np.nonzero(alive)[0]:
+        y1, y2, x1, x2 = tab[i, 3], tab[i, 4] - 1, tab[i, 5], tab[i, 6] - 1
+        pts[offs[i]:offs[i] + 4] = [(x1, y1), (x2, y1), (x2, y2), (x1, y2)]
+    return tab, cnts, pts, offs
+
+
+def _np_mask_fn(lumen_window, gland_rows):
+    lumen_window *= (np.asarray(gland_rows) > 0).astype(lumen_window.dtype)
+
+
+def _parts_case():
+    from oracle import synth
+
+    H, W = 720, 400
+    maps = {"Nuclei-INST": synth.nuclei_maps(H, W, 3, 900.0, noise=0.02),
+            "Gland-INST": synth.blob_maps(H, W, 5, 40, 8.0, 22.0, rim=3.0, sharp=1.0, noise=0.02, holes=0.3),
+            "Lumen-INST": synth.blob_maps(H, W, 6, 70, 5.0, 14.0, rim=2.0, sharp=1.0, noise=0.02)}
+    rs = np.random.RandomState(4)
+    types = {"Nuclei-TYPE": rs.randint(0, 7, (H, W)).astype(np.uint8), "Gland-TYPE": rs.randint(0, 3, (H, W)).astype(np.uint8)}
+    return H, W, maps, types
+
+
+_PARTS_DS = {"Nuclei": 1.0, "Gland": 0.3, "Lumen": 0.5}  # (small structuring elements / size bars: instances stay inside the margins)
+
+
+def _parts_label_fn(window, tissue, ds):
+    return _oracle_label_fn(window, tissue, _PARTS_DS[tissue])
+
+
+def _parts_worker(rank, world, port, ret):
+    import torch.distributed as dist
+
+    from cerberus_amd import shard_postproc as sp
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H, W, maps, types = _parts_case()
+    bounds = {2: [0, 384, H], 3: [0, 256, 512, H]}[world]
+    a, b = bounds[rank], bounds[rank + 1]
+    canv = {k: torch.from_numpy(v[a:b].copy()) for k, v in maps.items()}
+    canv.update({k: torch.from_numpy(v[a:b].copy()) for k, v in types.items()})
+    arrays = {}
+    fns = {"label": _parts_label_fn, "table": _np_table, "relabel": lambda rows, m: np.asarray(m)[rows], "arrays": _np_arrays_fn, "mask": _np_mask_fn}
+    inst, info = sp.sharded_postprocess(canv, rank, world, dist, wsi_mode=False, margin={"Nuclei": 96, "Gland": 176, "Lumen": 96}, guard=16,
+                                        arrays=arrays, fns=fns)
+    parts = sp.gather_parts(arrays, dist, rank, world, "cpu")
+    ret.put((rank, {t: np.asarray(v) for t, v in inst.items()}, info, parts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_per_rank_instance_arrays_equal_the_whole_map_arrays_gloo(world):
+    """shard_postproc.sharded_postprocess(arrays=...) + gather_parts over gloo: every rank computes table rows (class votes included: the class
+    map's halo rows travel with the probability halos) and contour runs for the instances it OWNS on its halo + band + halo window, lumen masked
+    by gland on the windows, coordinates shifted to the slide -- the root's concatenation equals the arrays of the whole label map: same rows in
+    the same (first-pixel) order, same points, nothing but arrays gathered."""
+    import torch.multiprocessing as mp
+
+    from oracle import postproc_ref as pr
+
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_parts_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([ret.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    H, W, maps, types = _parts_case()
+    parts = {p_[0]: p_ for p_ in got[0][3]}
+    assert all(g[3] is None for g in got[1:]) and list(parts) == ["Nuclei", "Gland", "Lumen"]
+    ref = {"Nuclei": pr.proc(maps["Nuclei-INST"], "Nuclei").astype(np.int32), "Gland": pr.proc(maps["Gland-INST"], "Gland", 0.3).astype(np.int32),
+           "Lumen": pr.proc(maps["Lumen-INST"], "Lumen", 0.5).astype(np.int32)}
+    crossing = 0
+    for t in ("Nuclei", "Gland", "Lumen"):
+        assert all(g[2][t]["n_truncated"] == 0 and g[2][t]["n_unresolved"] == 0 for g in got), (t, [g[2][t] for g in got])
+        lab = ref[t]
+        n = int(lab.max())
+        order = np.argsort(_np_full_table(lab, n)[:, 7], kind="stable")  # the protocol's ids: first pixels in raster order (of the UNMASKED labelling)
+        if t == "Lumen":
+            lab = lab * (ref["Gland"] > 0)
+        tmap = types.get(t + "-TYPE")
+        want, wc, wp, wo = _np_arrays_fn(lab, n, tmap, np.arange(n))
+        want = want[order]
+        want[want[:, 0] == 0] = 0
+        name, tab, cnts, pts, offs, has_type, ds = parts[t]
+        assert has_type == (tmap is not None) and ds == 1.0 and tab.shape == want.shape, (t, tab.shape, want.shape)
+        assert np.array_equal(tab, want), (t, np.nonzero((tab != want).any(axis=1))[0][:5])
+        assert np.array_equal(cnts, wc[order]) and np.array_equal(offs, np.cumsum(cnts.astype(np.int64)) - cnts)
+        assert n > 20 and np.array_equal(pts, np.concatenate([wp[wo[i]:wo[i] + wc[i]] for i in order]).reshape(-1, 2))
+        # the stitched band label maps (ids relabelled) are still the whole-map partition, lumen masked
+        stitched = np.concatenate([g[1][t] for g in got], axis=0)
+        from cerberus_amd.shard_postproc import same_partition
+
+        assert same_partition(lab, stitched), t
+        edges = {2: [384], 3: [256, 512]}[world]
+        for e in edges:
+            crossing += len((set(np.unique(stitched[e - 1])) & set(np.unique(stitched[e]))) - {0})
+        if t == "Lumen":
+            assert (want[:, 0] == 0).any() or (lab != ref["Lumen"]).any()  # the gland mask really removed lumen pixels
+    assert crossing > 3  # instances straddle the band edges: their owners measured them across the edge
+
+
 def test_overlay_rendering():
     """visualize_instances_dict_orig mirror: tissue draw order, type colours, closed outlines (PIL stand-in for cv2.drawContours)."""
     from cerberus_amd.viz import DEFAULT_VIZ_INFO, up2_nearest, visualize_instances_dict_orig
