@@ -129,7 +129,7 @@ class BandState(object):
         else:
             tab = np.zeros((0, 16), np.int64)
         area, y1, y2, first = tab[:, 0], tab[:, 3], tab[:, 4], tab[:, 7]
-        self.y1, self.y2 = y1, y2
+        self.y1, self.y2, self.x1, self.x2 = y1, y2, tab[:, 5], tab[:, 6]
         alive = area > 0
         fy = first // self.w
         # global key of an instance: its first pixel in slide raster order
@@ -159,8 +159,11 @@ class BandState(object):
         crossing = self.owned & (self.y2 > self.top + self.h_band)
         return np.stack([self.key[crossing], self.gid[crossing]], axis=1).astype(np.int64).reshape(-1, 2)
 
-    def resolve(self, published_from_above, relabel_fn=_device_relabel_fn):
-        """Name the instances I see but do not own (their owner is a rank above), relabel my band rows."""
+    def resolve(self, published_from_above, relabel_fn=_device_relabel_fn, defer=None):
+        """Name the instances I see but do not own (their owner is a rank above), relabel my band rows.
+        defer: a list -- instances whose owner has not published yet are not counted as unresolved: their keys are appended to it and their pixels
+        get the NEGATIVE placeholder -(position in the list + 1), to be renamed by the caller (cerberus_amd.stream_bands: the first sub-band of
+        a rank whose neighbour above is still walking its band)."""
         lut = {}
         for tab in published_from_above:
             for k, g in np.asarray(tab).reshape(-1, 2):
@@ -169,7 +172,10 @@ class BandState(object):
         unresolved = 0
         for i in foreign:
             g = lut.get(int(self.key[i]))
-            if g is None:
+            if g is None and defer is not None:
+                defer.append(int(self.key[i]))
+                self.gid[i] = -len(defer)
+            elif g is None:
                 unresolved += 1
             else:
                 self.gid[i] = g
@@ -188,14 +194,18 @@ class BandState(object):
     def mask_by(self, gland, mask_fn=_device_mask_fn):
         """self: the lumen state, gland: the gland state of the same band (both labelled).  The lumen window's rows are taken out of the gland
         window (its halo is at least as tall), so that an owned lumen is masked over ALL of its pixels -- the halo part included, which is where
-        its table and contour come from (owned_parts).  A gland the window cut and that reaches into the lumen window could mask differently
-        from the whole-slide labelling (an opened hole): such glands are added to the lumen's n_truncated."""
+        its table and contour come from (owned_parts).  A gland the window cut could mask differently from the whole-slide labelling inside its
+        bounding box (a hole the cut opened is not filled): every OWNED lumen whose box meets the box of such a gland is added to the lumen's
+        n_truncated (in-band rows are covered by the gland's own count)."""
         d = gland.top - self.top
         if d < 0 or d + self.h_win > gland.h_win or gland.w != self.w or gland.y0 != self.y0:
             raise ValueError("lumen masking on windows needs the gland halo to cover the lumen halo (margins: gland >= lumen)")
         rows = gland.lab[d: d + self.h_win]
         mask_fn(self.lab, rows)
-        hit = gland.cut & (gland.y2 > d) & (gland.y1 < d + self.h_win)
+        own = np.nonzero(self.owned)[0]
+        hit = np.zeros(len(own), bool)
+        for g in np.nonzero(gland.cut)[0]:
+            hit |= (self.y1[own] + d < gland.y2[g]) & (self.y2[own] + d > gland.y1[g]) & (self.x1[own] < gland.x2[g]) & (self.x2[own] > gland.x1[g])
         self.n_truncated += int(hit.sum())
 
     # ---- per-rank instance arrays (VERDICT r5 item 3): what the root needs for dat/<slide>.dat, without the label maps -----------------
@@ -446,6 +456,41 @@ def _publish_and_resolve(st, n_owned, dev, dist, rank, world, relabel_fn):
     out, info = st.resolve(pubs, relabel_fn)
     info["n_total"] = int(offs[-1])
     return out, int(offs[-1]), info
+
+
+def gather_streamed_maps(inst, small, slide_hw, out, rank, world, dist, labels=True):
+    """Root-side stitch after cerberus_amd.stream_bands on several ranks, where every rank holds ITS rows of the label maps (`inst`) and class
+    canvases (`small`).  labels=True (--save_label_maps): everything travels, -> (inst, small) of the whole slide on the root.  labels=False:
+    only the quarter-resolution tissue map does ("Patch-Class@0.25"; the bands' own cv2-nearest resizes are the slide's rows when band heights are
+    multiples of 8) -> (None, {that map}).  (None, None) off the root."""
+    from .tissue import pclass_tissue_map
+    from .wsi import SlideGeometry, half_size
+
+    H, W = int(slide_hw[0]), int(slide_hw[1])
+    geo = SlideGeometry((H, W), out, out)
+    b = geo.bounds(world)
+    rows = [max(0, min((b[i + 1] - b[i]) * out, H - b[i] * out)) for i in range(world)]
+    if labels:
+        g_inst = OrderedDict()
+        for t, lab in inst.items():
+            half = t != "Nuclei"
+            g = _gather_rows(lab, [half_size(r) for r in rows] if half else rows, half_size(W) if half else W, dist, rank, world)
+            if rank == 0:
+                g_inst[t] = g
+        g_small = OrderedDict()
+        for k, v in small.items():
+            g = _gather_rows(v, rows, W, dist, rank, world)
+            if rank == 0:
+                g_small[k] = g
+        return (g_inst, g_small) if rank == 0 else (None, None)
+    res = OrderedDict()
+    if "Patch-Class" in small:
+        if all(r % 8 == 0 for r in rows[:-1]):
+            g = _gather_rows(pclass_tissue_map(small["Patch-Class"]), [int(round(r * 0.25)) for r in rows], int(round(W * 0.25)), dist, rank, world)
+            res["Patch-Class@0.25"] = g
+        else:
+            res["Patch-Class"] = _gather_rows(small["Patch-Class"], rows, W, dist, rank, world)
+    return (None, res) if rank == 0 else (None, None)
 
 
 def assemble(band_labels):

@@ -167,14 +167,19 @@ def main(argv=None):
         # Capacity check BEFORE anything slide-sized is allocated (the reference streams any slide through 15000^2 tiles + memmaps,
         # infer/wsi.py:551-556, 899): resident band, resident without the second handle, or -- one rank -- sequential sub-bands
         # (cerberus_amd/stream_bands.py); a band that fits neither way ends here with the numbers instead of inside torch.zeros.
-        from cerberus_amd.stream_bands import infer_and_label_streamed, plan_slide
+        from cerberus_amd.stream_bands import agree_on_plan, infer_and_label_streamed, plan_slide
 
         plan = plan_slide(manager.net, (H, W), win, out, batch, rank, world, want_twin=want_twin, max_band_px=ONE_CALL_PX if world == 1 else None,
                           allow_stream=(mask is None and not args["--reference_tiling"]))
+        if dist is not None:  # the streamed and the resident tail use different collectives: one mode for all ranks
+            with watch.phase("memory-plan agreement (%s)" % base):
+                plan = agree_on_plan(plan, dist, torch.device("cuda", local) if backend == "nccl" else "cpu")
         if plan.twin and twin is None:
             twin = manager.net.twin()
         if log:
             log.info("Memory plan: {0}".format(plan))
+        if getattr(plan, "over_budget", None):
+            print("warning:", plan.over_budget)
         if plan.mode == "streamed":
             t_prep = time.perf_counter()
             if host is None:
@@ -186,8 +191,21 @@ def main(argv=None):
                     up = SlabUploader(host, a, b)
                     return up.slab, up.upload_until
             pprof, records, ref_nuclei, rank_parts = {}, None, None, None
-            inst, _, maps = infer_and_label_streamed(manager.net, source, (H, W), win, out, batch, plan.sub_bands, prof=pprof)
+            several = dist is not None and world > 1
+            own_parts = [] if (several and not args["--save_label_maps"]) else None
+            inst, _, maps = infer_and_label_streamed(manager.net, source, (H, W), win, out, batch, plan.sub_bands, prof=pprof, rank=rank, world=world,
+                                                     dist=dist if several else None, parts=own_parts, watch=watch)
             torch.cuda.synchronize()
+            if several:
+                # every rank holds its own rows: the root gets the instance arrays (+ the quarter-resolution tissue map), or -- --save_label_maps -- the maps
+                from cerberus_amd.shard_postproc import gather_parts, gather_streamed_maps
+
+                dev_ = torch.device("cuda", local)
+                if own_parts is not None:
+                    with watch.phase("instance-array gather to rank 0 (%s)" % base):
+                        rank_parts = gather_parts(own_parts[0], dist, rank, world, dev_, prof=pprof)
+                with watch.phase("map gather to rank 0 (%s)" % base):
+                    inst, maps = gather_streamed_maps(inst, maps, (H, W), out, rank, world, dist, labels=own_parts is None)
             t1 = t2 = time.perf_counter()
             if log:
                 log.info("Inference Time: {0} ({1} sub-bands streamed through HBM)".format(pprof.get("stream_infer_s"), plan.sub_bands))

@@ -468,6 +468,33 @@ def test_run_infer_wsi_streams_a_slide_that_does_not_fit_the_hbm_budget(tmp_path
         # tests/test_drivers_gpu.py::test_slide_streamed_in_sub_bands_equals_the_resident_run's job, on structured maps
         if k.startswith("type_") or k == "pclass":
             assert np.array_equal(za[k], zb[k]), k
+    # round 6: the same on TWO ranks -- the budget sits just under rank 0's resident need, so rank 0 plans two sub-bands, rank 1 plans
+    # resident, and the agreement makes both walk the streamed path (rank 1 in one sub-band): class maps equal the one-rank resident run's bit for bit,
+    # with the maps gathered (--save_label_maps) and, without them, a dictionary of the same tissues from the per-rank arrays
+    need0 = plan_slide(net, (H, W), 256, 256, batch, rank=0, world=2, budget=1e15, want_twin=False).need
+    env_2 = dict(env, CERB_HBM_BUDGET_GB="%.6f" % ((need0 - 2e6) / 1e9), MASTER_ADDR="127.0.0.1", CERB_DIST_BACKEND="gloo")
+    two = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29581"] + cmd[1:]
+    r = subprocess.run(two + ["--output_dir=%s" % (tmp_path / "d"), "--logging_dir=%s" % (tmp_path / "ld")], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env_2)
+    assert r.returncode == 0, r.stderr[-3000:]
+    logs = "".join(open(os.path.join(str(tmp_path / "ld"), f)).read() for f in os.listdir(str(tmp_path / "ld")))
+    assert "mode='streamed'" in logs and "sub-bands streamed through HBM" in logs, logs[-1500:]
+    zd = np.load(str(tmp_path / "d" / "s1.npz"))
+    assert set(za.files) == set(zd.files)
+    for k in za.files:
+        assert za[k].shape == zd[k].shape, k
+        if k.startswith("type_") or k == "pclass":
+            assert np.array_equal(za[k], zd[k]), k
+    two_nomaps = [a for a in two if a != "--save_label_maps"]
+    two_nomaps[two_nomaps.index("29581")] = "29582"
+    r = subprocess.run(two_nomaps + ["--output_dir=%s" % (tmp_path / "e")], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env_2)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import joblib
+    import scipy.io as sio
+
+    assert not (tmp_path / "e" / "s1.npz").exists()
+    da, de = joblib.load(str(tmp_path / "a" / "dat" / "s1.dat")), joblib.load(str(tmp_path / "e" / "dat" / "s1.dat"))
+    assert set(da.keys()) == set(de.keys())
+    assert np.array_equal(sio.loadmat(str(tmp_path / "a" / "tissue" / "s1.mat"))["pclass"], sio.loadmat(str(tmp_path / "e" / "tissue" / "s1.mat"))["pclass"])
     env_x = dict(env, CERB_HBM_BUDGET_GB="1.0")
     r = subprocess.run(cmd + ["--output_dir=%s" % (tmp_path / "c")], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env_x)
     assert r.returncode != 0 and "ValueError" in r.stderr and "GB resident" in r.stderr, r.stderr[-1500:]

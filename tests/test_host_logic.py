@@ -277,7 +277,7 @@ def _parts_worker(rank, world, port, ret):
     canv = {k: torch.from_numpy(v[a:b].copy()) for k, v in maps.items()}
     canv.update({k: torch.from_numpy(v[a:b].copy()) for k, v in types.items()})
     arrays = {}
-    fns = {"label": _parts_label_fn, "table": _np_table, "relabel": lambda rows, m: np.asarray(m)[rows], "arrays": _np_arrays_fn, "mask": _np_mask_fn}
+    fns = {"label": _parts_label_fn, "table": _np_full_table, "relabel": lambda rows, m: np.asarray(m)[rows], "arrays": _np_arrays_fn, "mask": _np_mask_fn}
     inst, info = sp.sharded_postprocess(canv, rank, world, dist, wsi_mode=False, margin={"Nuclei": 96, "Gland": 176, "Lumen": 96}, guard=16,
                                         arrays=arrays, fns=fns)
     parts = sp.gather_parts(arrays, dist, rank, world, "cpu")
@@ -680,7 +680,7 @@ def test_incremental_local_labeller_equals_run_local():
 
 def test_slide_memory_plan_picks_resident_twin_streamed_or_refuses():
     """cerberus_amd.stream_bands.plan_slide prices a rank's band against the HBM budget BEFORE anything is allocated: resident with the second
-    handle, resident on one handle, sequential sub-bands (one rank), or a ValueError that names the bytes -- never an OOM inside torch.zeros."""
+    handle, resident on one handle, sequential sub-bands (any rank count), or a ValueError that names the bytes -- never an OOM inside torch.zeros."""
     import pytest
 
     from cerberus_amd.stream_bands import canvas_bytes_per_px, forward_workspace_bytes, plan_slide
@@ -703,10 +703,16 @@ def test_slide_memory_plan_picks_resident_twin_streamed_or_refuses():
     assert huge.mode == "streamed" and huge.sub_bands >= 2
     with pytest.raises(ValueError, match="class canvases"):
         plan_slide(Net(), (100000, 80000), 256, 256, 64, budget=60e9, max_band_px=400e6)
-    with pytest.raises(ValueError, match="use more ranks"):  # streaming is a one-rank path: N ranks split the slide N ways first
-        plan_slide(Net(), hw, 256, 256, 64, rank=1, world=2, budget=20e9)
-    with pytest.raises(ValueError, match="GB resident"):  # tissue masks / --reference_tiling need the resident canvases
-        plan_slide(Net(), hw, 256, 256, 64, budget=one.need - 1e9, max_band_px=400e6, allow_stream=False)
+    # round 6: a rank of several streams its own band too (the reference takes any slide on any GPU count: infer/wsi.py:551-556, infer/base.py:46)
+    two = plan_slide(Net(), hw, 256, 256, 64, rank=1, world=2, budget=60e9)
+    assert two.mode == "streamed" and two.sub_bands >= 2 and two.need <= 60e9
+    with pytest.raises(ValueError, match="class canvases"):  # ... unless what stays resident + one sub-band's canvases and workspace does not fit either
+        plan_slide(Net(), hw, 256, 256, 64, rank=1, world=2, budget=30e9)
+    # tissue masks / --reference_tiling need the resident canvases: an over-budget estimate is tried anyway, and says so
+    forced = plan_slide(Net(), hw, 256, 256, 64, budget=one.need - 1e9, max_band_px=400e6, allow_stream=False)
+    assert forced.mode == "resident" and not forced.twin and "GB resident" in forced.over_budget
+    # the resident price is the larger of the two phases (slab during inference, labels + labelling workspace afterwards), not their sum
+    assert one.need < 40000 * 40000 * 3 + 40000 * 40000 * 36 + 96 * (400e6 + 2 * 512 * 40000) + fwd + (2 << 30)
     # sub-bands are never shorter than two halo margins (the band protocol's invariant)
     tiny = plan_slide(Net(), (4096, 2048), 256, 256, 4, budget=plan_slide(Net(), (4096, 2048), 256, 256, 4, budget=1e12, want_twin=False).need - 1e6)
     assert tiny.mode == "streamed" and (16 // tiny.sub_bands) * 256 >= 1024
