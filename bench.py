@@ -523,6 +523,30 @@ def structured_band(dev, y0, rows, W, period=4096):
     return out
 
 
+def sparse_foreground_weights(model, sd, dev, q=0.03):
+    """`--tail-from-inference`: the seeded test weights paint slide-sized blobs (99 % of the nuclei map is foreground), which no labelling window can
+    hold.  The same weights with the BACKGROUND logit's bias of every INST head raised by the (1 - q) quantile of `logit_inner - logsumexp(the
+    others)` over the calibration tile: about q of a noise slide's pixels are then foreground, in islands as wide as the network's own spatial
+    correlation -- maps the timed inference itself writes, with instances a band protocol can own.  A function of the weights alone (every rank
+    derives the same shift)."""
+    tile = torch.from_numpy(np.random.RandomState(20240229).randint(0, 256, (1, TILE, TILE, 3)).astype(np.uint8)).to(dev)
+    lg = model(tile)
+    new = {k: v.clone() for k, v in sd.items()}
+    shifts = {}
+    for name, hname, och, key in model._decoders:
+        if hname != "INST":
+            continue
+        v = lg[key][0]  # (3, H, W)
+        margin = v[1] - torch.logsumexp(torch.stack([v[0], v[2]]), 0)
+        d = float(torch.quantile(margin.flatten().float(), 1.0 - q))
+        bkey = "output_head.%s.INST.x.1.conv.bias" % name
+        new[bkey][0] += d
+        shifts[key] = round(d, 4)
+    model.load_state_dict(new, strict=True)
+    model.prepare(dev)
+    return new, shifts
+
+
 def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
     from collections import OrderedDict
 
@@ -542,11 +566,21 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
     global WSI_BATCH
     WSI_BATCH = WSI_BATCH or (64 if args.streams == 2 else 96)
     check_shardable((H, W), TILE, world)
+    fg_shifts = None
+    if args.tail_from_inference:
+        sd, fg_shifts = sparse_foreground_weights(model, sd, dev, q=0.02)
+        # (a random network's islands are as wide as its 16x-downsampled encoder correlates -- hundreds of pixels, not a nucleus's 20: every tissue
+        #  gets the gland's halo)
+        global MARGINS
+        MARGINS = {"Nuclei": MARGIN, "Gland": MARGIN, "Lumen": MARGIN}
     run = WSIRunner(model, (H, W), TILE, TILE, WSI_BATCH, rank, world)
     y0, y1 = run.slab_rows()
     slab = synth_slide(y1 - y0, W, y0=y0, seed=3)
     valid = max(0, min(run.band_h, H - run.r0 * TILE))
-    struct = structured_band(dev, run.r0 * TILE, valid, W)
+    if args.tail_from_inference:  # the labelling reads what the inference writes: views of the runner's own canvases
+        struct = OrderedDict((k, v[:valid, :W]) for k, v in run.canv.items() if k.endswith("INST"))
+    else:
+        struct = structured_band(dev, run.r0 * TILE, valid, W)
     # stripes: this rank's patches in K contiguous pieces, cut at batch boundaries
     nb = -(-run.n_patches // WSI_BATCH)
     cuts = [min(run.n_patches, c * WSI_BATCH) for c in band_partition(nb, K)]
@@ -831,7 +865,9 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
             "inference_Mpx_s": round(px / phase["inference_s"] / 1e6, 3),
             "postproc_and_stitch_s": round(phase["tail_s"], 3),
             "whole_job_s": round(dt, 3),
-            "tail_inputs": {"INST probability maps": "seeded structured maps of the slide's size (random weights make no instances; cerberus_amd/synth_maps.py)",
+            "tail_inputs": {"INST probability maps": ("the canvases this job's timed inference wrote (--tail-from-inference: the seeded weights with the INST heads' "
+                                                      "background bias raised so that ~3 %% of the pixels are foreground; shifts %s)" % fg_shifts) if args.tail_from_inference else
+                                                     "seeded structured maps of the slide's size (random weights make no instances; cerberus_amd/synth_maps.py)",
                             "TYPE and Patch-Class maps": "the canvases this job's inference wrote (majority types of the instance tables, class-map gather)",
                             "class_canvas_checksum": small_sum},
             "nuclei_scheme": "exact band ownership (every instance of the whole-slide labelling once; cerberus_amd/shard_postproc.py) -- the reference's own "
@@ -891,6 +927,9 @@ def main():
     ap.add_argument("--mode", default="wsi", choices=["wsi", "batch", "infer", "train"],
                     help='"wsi" (default): the headline, whole-slide job of north_star / configs[2-3]; "batch" (= "infer"): configs[1] inner loop; '
                          '"train": the multi-task training step of configs[4]')
+    ap.add_argument("--tail-from-inference", action="store_true",
+                    help="slide job: the labelling reads the INST canvases the timed inference wrote instead of the seeded structured maps (the data dependency "
+                         "inference -> labelling at slide scale); the seeded weights get a sparse-foreground bias calibration so that those maps hold instances")
     ap.add_argument("--slide", type=int, default=0, help="slide side in pixels (default: 40000, or 20000 when HBM is short)")
     ap.add_argument("--max-band-mpx", type=float, default=220.0, help="largest labelling call on one GPU, in Mpx (96 B/px of workspace)")
     ap.add_argument("--force-dist", action="store_true",

@@ -644,3 +644,22 @@ def test_bench_configs2_slide_20000_full_size_one_vs_three_local_bands():
     ti = one["config"]["tail_inputs"]
     assert ti["class_canvas_checksum"] and ti["class_canvas_checksum"] == three["config"]["tail_inputs"]["class_canvas_checksum"]
     assert one["value"] > 50 and one["roofline"]["frac"] > 0.3
+
+
+def test_bench_slide_20000_labels_the_canvases_its_own_inference_wrote():
+    """`bench.py --tail-from-inference` -- the tail labels the INST canvases the timed inference of the SAME job wrote
+    (the seeded weights with a sparse-foreground bias calibration: ~3 % of a noise slide's pixels are foreground), at BASELINE configs[2]'s full
+    20000^2: the inference -> labelling data dependency at slide scale.  One labelling call against three local bands: no instance cut by a window,
+    no unresolved border instance, the same instance counts -- and well above zero, i.e. the labelling really had network-made instances to own."""
+    common = [sys.executable, "bench.py", "--slide", "20000", "--steps", "4", "--warmup", "1", "--no-train-leg", "--no-cpu-baseline", "--no-dat", "--no-ref-tiling",
+              "--tail-from-inference"]
+    one = _bench(common + ["--max-band-mpx", "420"], timeout=1500)
+    three = _bench(common + ["--max-band-mpx", "150"], timeout=1500)
+    assert "timed inference wrote" in one["config"]["tail_inputs"]["INST probability maps"]
+    assert one["postproc"]["Nuclei"]["local_bands"] == 1 and three["postproc"]["Nuclei"]["local_bands"] >= 3
+    for t in ("Nuclei", "Gland", "Lumen"):
+        for line in (one, three):
+            assert line["postproc"][t]["n_truncated"] == 0 and line["postproc"][t]["n_unresolved"] == 0, (t, line["postproc"][t])
+        assert one["postproc"][t]["n_inst"] == three["postproc"][t]["n_inst"], (t, one["postproc"][t], three["postproc"][t])
+    assert one["postproc"]["Nuclei"]["n_inst"] > 10000, one["postproc"]["Nuclei"]
+    assert one["config"]["precision"]["logit_guard"]["batches_above"] == 0
