@@ -25,6 +25,36 @@ import zlib
 import numpy as np
 
 
+_POOL = {"n": None, "pool": None}
+
+
+def decode_threads():
+    """Tile-decode threads of the TIFF / .svs reader: CERB_DECODE_THREADS, default min(32, host cores) -- `bench.py --mode ingest` reports the count
+    that saturates one GPU's inference (a JPEG tile decodes at ~160 Mpx/s per core, the network eats ~150 Mpx/s)."""
+    v = os.environ.get("CERB_DECODE_THREADS")
+    if v:
+        return max(1, int(v))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(32, n))
+
+
+def decode_pool():
+    """The shared thread pool (None for one thread); re-made when CERB_DECODE_THREADS changes (bench.py's sweep)."""
+    n = decode_threads()
+    if n <= 1:
+        return None
+    if _POOL["n"] != n:
+        from concurrent.futures import ThreadPoolExecutor
+
+        if _POOL["pool"] is not None:
+            _POOL["pool"].shutdown(wait=True)
+        _POOL["pool"], _POOL["n"] = ThreadPoolExecutor(max_workers=n, thread_name_prefix="cerb-decode"), n
+    return _POOL["pool"]
+
+
 class SlideInfo(object):
     def __init__(self, path, dims_wh, mpp=None, level_dimensions=None, level_downsamples=None):
         self.file_path = path
@@ -89,6 +119,12 @@ class _Rows(object):
         w, h = reader.slide_dimensions(resolution, units)
         self.shape = (int(h), int(w), 3)
         self.dtype = np.dtype(np.uint8)
+        # rows per storage tile when this resolution IS a stored level: a caller that reads whole multiples of it (wsi.SlabUploader's chunks)
+        # decodes every tile once instead of once per chunk that touches it
+        self.row_align = 1
+        lv = getattr(reader, "levels", None)
+        if lv is not None and abs(reader._scale(resolution, units) - 1.0) < 1e-9 and getattr(lv[0], "tiled", False):
+            self.row_align = int(lv[0].th)
 
     def __getitem__(self, key):
         rows = key[0] if isinstance(key, tuple) else key
@@ -319,8 +355,7 @@ class TiffReader(WSIReader):
         return p, nxt
 
     def _decode(self, p, idx, rows, cols):
-        self.fh.seek(p.offsets[idx])
-        data = self.fh.read(p.counts[idx])
+        data = os.pread(self.fh.fileno(), p.counts[idx], p.offsets[idx])  # positional read: decode threads share the descriptor
         c = p.compression
         if c == 1:
             buf = np.frombuffer(data, np.uint8)
@@ -339,8 +374,10 @@ class TiffReader(WSIReader):
                 # in front of the frame header is dropped first.
                 data = _strip_jfif_app0(data)
                 data = data[:2] + b"\xff\xee\x00\x0eAdobe\x00\x64\x00\x00\x00\x00\x00" + data[2:]
-            arr = np.array(Image.open(io.BytesIO(data)).convert("RGB"))
-            return arr[:rows, :cols]
+            img = Image.open(io.BytesIO(data))
+            if img.mode != "RGB":
+                img = img.convert("RGB")
+            return np.asarray(img)[:rows, :cols]
         elif c in (33003, 33005):
             raise NotImplementedError("%s: JPEG 2000 tiles (Aperio compression %d) need a JP2K decoder that is not in this image" % (self.path, c))
         elif c == 5:
@@ -359,17 +396,26 @@ class TiffReader(WSIReader):
         x0, y0, x1, y1 = max(0, x0), max(0, y0), min(p.w, x1), min(p.h, y1)
         out = np.zeros((max(0, y1 - y0), max(0, x1 - x0), 3), np.uint8)
         across = -(-p.w // p.tw)
-        for ty in range(y0 // p.th, -(-y1 // p.th)):
-            for tx in range(x0 // p.tw, -(-x1 // p.tw)):
-                # tiles are stored whole (padded); strips are cropped to the image on the last rows
-                rows = p.th if p.tiled else min(p.th, p.h - ty * p.th)
-                cols = p.tw if p.tiled else p.w
-                tile = self._decode(p, ty * across + tx, rows, cols)
-                gy0, gx0 = ty * p.th, tx * p.tw
-                a0, a1 = max(y0, gy0), min(y1, gy0 + tile.shape[0])
-                b0, b1 = max(x0, gx0), min(x1, gx0 + tile.shape[1])
-                if a1 > a0 and b1 > b0:
-                    out[a0 - y0:a1 - y0, b0 - x0:b1 - x0] = tile[a0 - gy0:a1 - gy0, b0 - gx0:b1 - gx0]
+
+        def one(tt):
+            ty, tx = tt
+            # tiles are stored whole (padded); strips are cropped to the image on the last rows
+            rows = p.th if p.tiled else min(p.th, p.h - ty * p.th)
+            cols = p.tw if p.tiled else p.w
+            tile = self._decode(p, ty * across + tx, rows, cols)
+            gy0, gx0 = ty * p.th, tx * p.tw
+            a0, a1 = max(y0, gy0), min(y1, gy0 + tile.shape[0])
+            b0, b1 = max(x0, gx0), min(x1, gx0 + tile.shape[1])
+            if a1 > a0 and b1 > b0:  # tiles do not overlap: every thread writes its own window of `out`
+                out[a0 - y0:a1 - y0, b0 - x0:b1 - x0] = tile[a0 - gy0:a1 - gy0, b0 - gx0:b1 - gx0]
+
+        tiles = [(ty, tx) for ty in range(y0 // p.th, -(-y1 // p.th)) for tx in range(x0 // p.tw, -(-x1 // p.tw))]
+        pool = decode_pool()
+        if pool is None or len(tiles) < 2:
+            for tt in tiles:
+                one(tt)
+        else:  # the reference feeds its GPU from 12 DataLoader workers (infer/wsi.py:936-950); libjpeg / zlib release the interpreter lock while they decode
+            list(pool.map(one, tiles))
         return out
 
 

@@ -544,36 +544,86 @@ class DatWriter(object):
 
 
 class SlabUploader(object):
-    """Host-resident slide band -> device slab, chunk by chunk through two pinned staging buffers on a copy stream, so that the
-    upload (and the page-cache / mmap read behind it) runs underneath the inference of the rows already on the device instead of
-    in front of it.  `upload_until(n_rows)` issues whatever chunks are still missing for the first n_rows rows and makes the
-    CURRENT stream wait for them; chunks are issued in order on one copy stream, so waiting for the last one covers all."""
+    """Host-resident slide band -> device slab, chunk by chunk through a ring of pinned staging buffers on a copy stream, AHEAD of the inference: a
+    producer thread reads / decodes the next chunks (cerberus_amd.reader decodes a chunk's tiles on its thread pool; libjpeg / zlib / the page
+    cache all run without the interpreter lock) and issues their copies while the caller's thread queues the batches of the rows already on the
+    device -- the role of the reference's 12 persistent DataLoader workers (infer/wsi.py:936-950).  `upload_until(n_rows)` waits until the
+    first n_rows rows have been issued and makes the CURRENT stream wait for their copies; chunks are issued in order on one copy stream, so
+    waiting for the last one covers all.  CERB_UPLOAD_AHEAD=0: round 5's behaviour (the caller's thread reads each chunk when it is asked for)."""
 
-    def __init__(self, host, y0, y1, device=None, chunk_bytes=64 << 20):
+    def __init__(self, host, y0, y1, device=None, chunk_bytes=24 << 20, buffers=3):
+        import os
+        import threading
+
         self.host, self.y0 = host, int(y0)
         self.rows, self.w = int(y1 - y0), int(host.shape[1])
         self.dev = device or torch.device("cuda", torch.cuda.current_device())
         self.slab = torch.empty((self.rows, self.w, 3), dtype=torch.uint8, device=self.dev)
-        self.chunk = max(1, min(self.rows, int(chunk_bytes) // max(1, self.w * 3)))
-        self.pinned = [torch.empty((self.chunk, self.w, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
-        self.busy = [None, None]  # event after which a staging buffer may be overwritten
+        # chunks end at absolute multiples of the chunk height, itself a multiple of the source's storage tile height (reader._Rows.row_align): a
+        # tiled file's tiles are decoded once; the first chunk is the short one, so the first batch starts after a few tile rows, not after 64 MB
+        self.align = max(1, int(getattr(host, "row_align", 1)))
+        self.chunk = max(self.align, (int(chunk_bytes) // max(1, self.w * 3)) // self.align * self.align)
+        self.ahead = os.environ.get("CERB_UPLOAD_AHEAD", "1") != "0"
+        nb = max(2, int(buffers)) if self.ahead else 2
+        self.pinned = [torch.empty((min(self.chunk, max(1, self.rows)), self.w, 3), dtype=torch.uint8).pin_memory() for _ in range(nb)]
+        self.busy = [None] * nb  # event after which a staging buffer may be overwritten
         self.copy_stream = torch.cuda.Stream(device=self.dev)
         self.next_row, self.k, self.last_event = 0, 0, None
+        self.read_s = 0.0  # seconds the reads / decodes took (bench.py --mode ingest)
+        self._cv, self._err, self._thr, self._stop = threading.Condition(), None, None, False
+        if self.ahead and self.rows > 0:
+            self._thr = threading.Thread(target=self._produce, name="cerb-slab-upload", daemon=True)
+            self._thr.start()
 
-    def upload_until(self, n_rows):
-        n_rows = min(int(n_rows), self.rows)
-        while self.next_row < n_rows:
-            i = self.k & 1
-            if self.busy[i] is not None:
-                self.busy[i].synchronize()
-            n = min(self.chunk, self.rows - self.next_row)
-            np.copyto(self.pinned[i][:n].numpy(), self.host[self.y0 + self.next_row: self.y0 + self.next_row + n])
-            with torch.cuda.stream(self.copy_stream):
-                self.slab[self.next_row: self.next_row + n].copy_(self.pinned[i][:n], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(self.copy_stream)
+    def _issue_one(self):
+        import time
+
+        i = self.k % len(self.pinned)
+        if self.busy[i] is not None:
+            self.busy[i].synchronize()
+        a = self.y0 + self.next_row
+        n = min((a // self.chunk + 1) * self.chunk - a, self.rows - self.next_row)
+        t0 = time.perf_counter()
+        np.copyto(self.pinned[i][:n].numpy(), self.host[self.y0 + self.next_row: self.y0 + self.next_row + n])
+        self.read_s += time.perf_counter() - t0
+        with torch.cuda.stream(self.copy_stream):
+            self.slab[self.next_row: self.next_row + n].copy_(self.pinned[i][:n], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        with self._cv:
             self.busy[i] = self.last_event = ev
             self.next_row += n
             self.k += 1
-        if self.last_event is not None:
-            torch.cuda.current_stream(self.dev).wait_event(self.last_event)
+            self._cv.notify_all()
+
+    def _produce(self):
+        try:
+            torch.cuda.set_device(self.dev)
+            while self.next_row < self.rows and not self._stop:
+                self._issue_one()
+        except BaseException as e:  # handed to the caller's thread at its next upload_until
+            with self._cv:
+                self._err = e
+                self._cv.notify_all()
+
+    def upload_until(self, n_rows):
+        n_rows = min(int(n_rows), self.rows)
+        if self._thr is None:
+            while self.next_row < n_rows:
+                self._issue_one()
+        else:
+            with self._cv:
+                while self.next_row < n_rows and self._err is None:
+                    self._cv.wait(0.5)
+                if self._err is not None:
+                    raise self._err
+        with self._cv:
+            ev = self.last_event
+        if ev is not None:
+            torch.cuda.current_stream(self.dev).wait_event(ev)
+
+    def close(self):
+        """Stop the producer (a caller that does not consume the whole band) and wait for it."""
+        self._stop = True
+        if self._thr is not None:
+            self._thr.join()
