@@ -67,9 +67,13 @@ _lib = None
 
 def lib():
     """Load the shared library (building is `python -m cerberus_amd.build` / __graft_entry__.build())."""
-    global _lib
+    global _lib, LIB_PATH
     if _lib is not None:
         return _lib
+    if os.environ.get("CERB_DEV_LIB") == "1":
+        # the developers' build of the same sources (-DCERB_DEV_SWITCHES: the CERB_* A/B environment switches inside the schedules exist only there);
+        # the A/B tests run in a child process that sets this (tests/conftest.py: dev_switches) -- the product library carries none of them
+        LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libcerberus_hip_dev.so")
     if not os.path.exists(LIB_PATH):
         raise CerberusHipError(
             "libcerberus_hip.so not found at %s -- run `python -m cerberus_amd.build` (needs hipcc). "

@@ -12,7 +12,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcerberus_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wino4b.hip", "conv_wino4p.hip", "net_kernels.hip", "postproc.hip", "slide_kernels.hip", "train_kernels.hip", "head_train.hip", "conv_wgrad.hip", "conv_wgrad_wino.hip", "pack_kernels.hip", "cerb_api.hip"]
+LIB_DEV = os.path.join(HERE, "libcerberus_hip_dev.so")
+SOURCES = ["conv_igemm.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wino4b.hip", "conv_wino4p.hip", "net_kernels.hip", "postproc.hip", "slide_kernels.hip", "train_kernels.hip", "head_train.hip", "conv_wgrad.hip", "conv_wgrad_wino.hip", "pack_kernels.hip", "cerb_api.hip", "cerb_train.hip"]
+# The translation units that read developer A/B switches (cerb_common.h: cerb_dev_getenv).  The product library compiles them WITHOUT the switches
+# (every one folds to its default); the same units compiled with -DCERB_DEV_SWITCHES, linked with the other units' objects, make
+# libcerberus_hip_dev.so -- loaded only by the A/B tests' child processes (CERB_DEV_LIB=1, cerberus_amd/_lib.py).
+DEV_SOURCES = ["cerb_api.hip", "cerb_train.hip", "postproc.hip", "conv_wino4b.hip", "train_kernels.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 # conv_wino4.hip: the 36-step chunk (288 matrix instructions) must be fully unrolled for its 288 accumulators to be registers (the default
 # pragma-unroll budget is 16 k instructions); the matrix instructions start in VGPR form and the register allocator moves the ones that do
@@ -48,14 +53,27 @@ def build(force=False, verbose=True):
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))
+    dev_objs = list(objs)
+    for src in DEV_SOURCES:
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        obj = os.path.join(CSRC, "dev_" + src.replace(".hip", ".o"))
+        dev_objs[dev_objs.index(os.path.join(CSRC, src.replace(".hip", ".o")))] = obj
+        if force or _stale(obj, [sp] + headers):
+            cmd = [hipcc] + FLAGS + ["-DCERB_DEV_SWITCHES"] + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src + " (dev)", subprocess.Popen(cmd)))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on %s" % src)
-    if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+    for lib, lobjs in ((LIB, objs), (LIB_DEV, dev_objs)):
+        if force or procs or _stale(lib, lobjs):
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + lobjs
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
     return LIB
 
 

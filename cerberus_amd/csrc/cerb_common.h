@@ -1,6 +1,7 @@
 // Shared declarations for the gfx950 kernels of the Cerberus tiled-inference path.
 // Everything here is CDNA4-only (wave64, v_mfma_f32_32x32x2_f32); there is no other target.
 #pragma once
+#include "cerb_dev.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

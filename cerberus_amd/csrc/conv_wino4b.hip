@@ -604,7 +604,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // Packed items: maps whose sides are multiples of 4 but not both of 16, whole map (no region of interest), tensors below 2 GiB per group (a lane's
 // offset is 32 bits from the group's base).  cerb_net_set_packed_items(net, 0) / CERB_W4B_PACKED=0 keep the block form (A/B: bitwise the same results).
 bool cerb_wino4b_packed(const ConvParams& p) {
-    static const bool off = [] { const char* e = getenv("CERB_W4B_PACKED"); return e && e[0] == '0'; }();
+    static const bool off = [] { const char* e = cerb_dev_getenv("CERB_W4B_PACKED"); return e && e[0] == '0'; }();
     if (off || p.pk_off || p.H != p.Ho || p.W != p.Wo) return false;
     if (p.Ho % 4 || p.Wo % 4 || (p.Ho % 16 == 0 && p.Wo % 16 == 0)) return false;
     if (p.roi_y1 > p.roi_y0 && p.roi_x1 > p.roi_x0) return false;

@@ -32,6 +32,7 @@
 #include <string>
 
 #include "../../include/cerberus_hip.h"
+#include "cerb_dev.h"
 
 int cerb_set_error(const std::string& m);  // cerb_api.hip
 #define PP_OK(expr)                                                                                   \
@@ -864,7 +865,7 @@ static int markers_two_colour(uint8_t* mrk, int* L, int* area, int* border, int*
     if (hipMemsetAsync(border, 0, (size_t)n * 4, st) != hipSuccess) return cerb_set_error("memset failed");
     hipLaunchKernelGGL(ccl2_tile_kernel, dim3(n_tiles < 256 * 16 ? n_tiles : 256 * 16), dim3(256), 0, st, mrk, L, H, W, tiles_x, n_tiles, roots, n_roots, area);
     const long long seams = (long long)(tiles_x - 1) * H + (long long)(tiles_y - 1) * W;
-    static const bool seam_relaxed = getenv("CERB_PP_SEAM_STRICT") == nullptr;
+    static const bool seam_relaxed = cerb_dev_getenv("CERB_PP_SEAM_STRICT") == nullptr;
     if (seams > 0) hipLaunchKernelGGL(seam_relaxed ? ccl2_seam_kernel<true> : ccl2_seam_kernel<false>, dim3(grid_for(seams)), dim3(256), 0, st, mrk, L, H, W, tiles_x, tiles_y);
     const unsigned gl = nblk(n_tiles, 4) < 4096 ? nblk(n_tiles, 4) : 4096;  // one wave per tile
     auto flatten_roots = [&]() { hipLaunchKernelGGL(ccl2_flatten_roots_kernel, dim3(gl), dim3(256), 0, st, L, (const int*)roots, (const int*)n_roots, n_tiles, tiles_x, H, W); };
@@ -2468,7 +2469,7 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
     int* small = (int*)cv.take(256);  // [0]=any [1]=worklist count [2]=n_inst scratch [3]=ambiguous scratch [4]=two-colour root list [8..12]=tier counts [16]=heap total
     if (!small) return cerb_set_error("cerb_postproc_nuclei: workspace carve failed");
     const unsigned g = grid_for(n);
-    static const bool pixel_scans = getenv("CERB_PP_PIXEL_SCANS") != nullptr;  // developer A/B: round 4's whole-map scans instead of the root bitmaps
+    static const bool pixel_scans = cerb_dev_getenv("CERB_PP_PIXEL_SCANS") != nullptr;  // developer A/B: round 4's whole-map scans instead of the root bitmaps
 
     PP_OK(hipMemsetAsync(small, 0, 256, st));
     // (A) mask: erode -> label -> drop components < 8 px   (postproc.py:365-368)
@@ -2484,7 +2485,7 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
         hipLaunchKernelGGL(nuc_threshold_kernel, dim3(g), dim3(256), 0, st, inst, row_stride, pix_stride, H, W, msk0, mrk, small);
         hipLaunchKernelGGL(erode_cross_kernel, dim3(g), dim3(256), 0, st, msk0, msk, H, W);
     }
-    static const bool narrow = getenv("CERB_PP_ONE_PIXEL_THREADS") != nullptr;  // developer A/B: the one-pixel-per-thread passes
+    static const bool narrow = cerb_dev_getenv("CERB_PP_ONE_PIXEL_THREADS") != nullptr;  // developer A/B: the one-pixel-per-thread passes
     const bool wide = !pixel_scans && !narrow && W % 4 == 0 && (uintptr_t)labels_out % 16 == 0;  // (the workspace arrays are 256-byte aligned)
     if (wide) {  // tile labelling with the root list + per-set counts, flatten and areas over the LIST, then one pass: min-area, root of every pixel, bitmap
         int* rootsA = hoff;       // free until roots_setup_kernel
@@ -2506,7 +2507,7 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
         else hipLaunchKernelGGL(apply_min_area_bits_kernel, dim3(g), dim3(256), 0, st, msk, LA, areaA, 8, n, bitsA);
     }
     // (B) markers: inner > 0.5 -> label -> drop < 4 px -> fill holes -> label (postproc.py:370-377)
-    static const bool three_pass = getenv("CERB_PP_THREE_LABELLINGS") != nullptr;  // developer A/B: round 4's three separate labellings
+    static const bool three_pass = cerb_dev_getenv("CERB_PP_THREE_LABELLINGS") != nullptr;  // developer A/B: round 4's three separate labellings
     if (!three_pass) {
         // (rank: free until the scan below, serves as the border flags; marker: free until the flood work lists, holds the root list)
         if (markers_two_colour(mrk, LB, areaB, rank, marker, tcnt, 4, H, W, st, pixel_scans ? nullptr : bitsB, wide)) return 1;
@@ -2582,13 +2583,13 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
         // (created once per device) so that the tails overlap instead of adding up; `st` resumes when all of them are done.
         SideStreams* ss = side_streams();
         if (!ss) return cerb_set_error("cerb_postproc_nuclei: side stream creation failed");
-        if (getenv("CERB_PP_DEBUG_COUNTS")) {  // developer probe: components per flood tier
+        if (cerb_dev_getenv("CERB_PP_DEBUG_COUNTS")) {  // developer probe: components per flood tier
             int hc[8] = {};
             PP_OK(hipStreamSynchronize(st));
             PP_OK(hipMemcpy(hc, counts, sizeof(hc), hipMemcpyDeviceToHost));
             fprintf(stderr, "flood tiers: small-window %d, lds-heap %d, global-heap %d, big-window %d, tiny-window %d\n", hc[0], hc[1], hc[2], hc[3], hc[4]);
         }
-        static const bool serial_floods = getenv("CERB_PP_SERIAL_FLOODS") != nullptr;  // developer probe: the tiers one after the other on `st`
+        static const bool serial_floods = cerb_dev_getenv("CERB_PP_SERIAL_FLOODS") != nullptr;  // developer probe: the tiers one after the other on `st`
         SideStreams serial_ss;
         if (serial_floods) {
             serial_ss = *ss;

@@ -18,6 +18,7 @@
 #include <string>
 
 #include "../../include/cerberus_hip.h"
+#include "cerb_dev.h"
 
 int cerb_set_error(const std::string& m);
 
@@ -1357,7 +1358,7 @@ hipError_t cerb_launch_maxpool_bwd_idx(const unsigned* idx, const float* dy, flo
     hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(gridfor((long long)N * H * W * (C / 4))), dim3(256), 0, st, idx, dy, dx, N, H, W, C, H / 2, W / 2);
     return hipGetLastError();
 }
-bool cerb_upadd_bwd_fused_ok(int H, int W, int C, int G) { return C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && G <= 32 && !getenv("CERB_UPADD_BWD_TWO_PASS"); }
+bool cerb_upadd_bwd_fused_ok(int H, int W, int C, int G) { return C % 4 == 0 && H % 2 == 0 && W % 2 == 0 && G <= 32 && !cerb_dev_getenv("CERB_UPADD_BWD_TWO_PASS"); }
 hipError_t cerb_launch_upadd_bwd(const float* dout, float* dskip, float* dprev, int G, int N, int H, int W, int C, long long prev_gs, int shared_prev, hipStream_t st,
                                  unsigned group_mask, int skip_assign, int prev_assign) {
     if (cerb_upadd_bwd_fused_ok(H, W, C, G)) {

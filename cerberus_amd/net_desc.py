@@ -68,11 +68,17 @@ class NetDesc(torch.nn.Module):
         for name, heads in self.decoder_info_list.items():
             if name not in self.considered_tasks:
                 continue
-            if len(heads) != 1:
-                raise NotImplementedError("one output head per decoder (as in models/paramset.yml); got %r for %s" % (dict(heads), name))
-            (hname, och), = heads.items()
-            key = name if name == "Patch-Class" else name.split("#")[0] + "-" + hname
-            self._decoders.append((name, hname, int(och), key))
+            if name == "Patch-Class":  # the reference builds ONE Patch-Class branch whatever the dict holds: the last entry's width wins (net_desc.py:64-78)
+                hname, och = list(heads.items())[-1]
+                self._decoders.append((name, hname, int(och), name))
+                continue
+            # a decoder may carry several output heads over one trunk (models/net_desc.py:81-87, 196-198): one entry per head, output key
+            # "<decoder without #suffix>-<head>"; the C side runs the trunk once (cerb_net_create)
+            for hname, och in heads.items():
+                key = name.split("#")[0] + "-" + hname
+                if any(d[3] == key for d in self._decoders):
+                    raise ValueError("two heads would both be returned as %r (the reference's output dict would keep the last one only)" % key)
+                self._decoders.append((name, hname, int(och), key))
         self._schema = state_dict_schema(self.decoder_info_list, self.considered_tasks)
         if backbone_imagenet_pretrained:
             # the reference pulls torchvision's ImageNet ResNet34 here (models/backbone/__init__.py:67); no such file travels with this package

@@ -1,6 +1,6 @@
 """Seeded STRUCTURED uint8 RGB tiles -- the inputs a slide really feeds the network besides texture: a smooth H&E-like stain field,
 a tile half of which is glass (white), an all-white and an all-black tile.  Input generator for the parity fixtures
-(oracle/gen_golden_net.py "structured" case), tests and bench.py; no checker lives here.
+(the golden-vector generator's "structured" case), tests and bench.py; no checker lives here.
 
 Integer arithmetic only (numpy int64, floor divisions): the build container, the conda interpreter and the GPU box rebuild the same bytes
 whatever their libm does -- the fixture stores the tiles' sha256 beside the seed."""

@@ -128,7 +128,7 @@ def make_state_dict(seed=0, decoder_kwargs=None, considered_tasks=None, head_log
 
     head_logit_scale: optional {"<decoder>.<head>": float32 factor} -- the LAST 1x1 convolution (weight and bias) of that output head is
     multiplied by the factor in float32, i.e. its logits are exactly `factor` times the unscaled recipe's up to rounding: the "confident
-    model" families of oracle/gen_golden_net.py (calibration logits moved to ~30 / ~80 with everything upstream unchanged).
+    model" families of the golden-vector generator (calibration logits moved to ~30 / ~80 with everything upstream unchanged).
     """
     rs = np.random.RandomState(seed)
     sd = OrderedDict()

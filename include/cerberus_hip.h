@@ -30,8 +30,11 @@ const char* cerb_last_error(void);
 /* ---- network construction: replaces create_model / NetDesc.__init__ (models/net_desc.py:23-103,203) ----------
  * decoder_names[i]  e.g. "Lumen","Gland","Nuclei","Nuclei#TYPE","Gland#TYPE","Patch-Class"  (decoder_kwargs order,
  *                   already filtered by considered_tasks, models/net_desc.py:61-63)
- * head_names[i]     "INST" | "TYPE" | "OUT"        (the single output head of that decoder)
+ * head_names[i]     "INST" | "TYPE" | "OUT"        (an output head of that decoder)
  * out_ch[i]         number of output channels of that head (3,3,3,7,3,9 in models/paramset.yml:46-60)
+ * One entry per OUTPUT HEAD.  A decoder with several heads (models/net_desc.py:81-87: `{"Gland": {"INST": 3, "TYPE": 3}}` builds one decoder
+ * trunk and a ModuleDict of heads over it, :196-198) is listed once per head, the decoder name repeated: the trunk's convolutions are loaded and
+ * run ONCE, every head reads its features; out[] / logits[] of cerb_forward_io stay per entry.  (Inference only: a train-packed handle refuses it.)
  * Only encoder_backbone_name == "resnet34" exists in this library. */
 int cerb_net_create(const char* const* decoder_names, const char* const* head_names, const int* out_ch,
                     int n_decoders, cerb_net** out_net);
@@ -289,7 +292,7 @@ typedef struct cerb_train_step_io {
 /* Streams: everything is ordered on `hip_stream` as the caller sees it.  Inside, the weight gradients of the convolutions are queued on a second stream that
  * the handle owns -- forked from `hip_stream` by an event when a layer's output gradient is final, joined back into `hip_stream` before the call returns -- so work
  * the caller queues on `hip_stream` afterwards (optimiser, all-reduce, the next step) sees every gradient complete.  Not capturable into a hipGraph with the side
- * stream on; CERB_WGRAD_SIDE=0 keeps the call on `hip_stream` alone (same bits). */
+ * stream on (the developers' build of the library, libcerberus_hip_dev.so, reads CERB_WGRAD_SIDE=0 to keep the call on `hip_stream` alone: same bits). */
 int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io, void* hip_stream);
 int cerb_net_grad_lookup(cerb_net* net, const char* key, float** dev_ptr, long long* numel);
 /* The same lookup also serves the batch statistics of every BatchNorm of the step under "<bn prefix>.batch_mean" and

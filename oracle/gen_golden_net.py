@@ -87,11 +87,14 @@ def calibration_head_scale(kw, weight_seed, target):
     return out
 
 
-def run_case(tag, tile_seed, n, hw, out_shape, tasks, weight_seed=0, family="seeded", logit_target=None, tiles_kind="noise"):
+def run_case(tag, tile_seed, n, hw, out_shape, tasks, weight_seed=0, family="seeded", logit_target=None, tiles_kind="noise", decoder_kwargs=None, head_list=None):
     """family "seeded": cerberus_amd.weights.make_state_dict (non-saturating); "refinit": the distribution the reference's own constructor
     leaves in a fresh model (weights_init_cnn, models/net_desc.py:89-103: kaiming-normal convs, identity BatchNorm) drawn from a seeded
     torch generator (cerberus_amd.weights.reference_init_state_dict) so that the GPU box can rebuild the same tensors."""
     kw = default_model_kwargs(tasks)
+    if decoder_kwargs is not None:  # another decoder / head layout than models/paramset.yml's (several heads over one decoder: models/net_desc.py:81-87)
+        kw["decoder_kwargs"] = OrderedDict((k, OrderedDict(v)) for k, v in decoder_kwargs)
+    head_list = list(kw["considered_tasks"]) if head_list is None else list(head_list)  # infer_step's head_name_list (models/run_desc.py:475-476)
     head_scale = None
     if family == "refinit":
         sd_np = reference_init_state_dict(kw["decoder_kwargs"], kw["considered_tasks"], generator=torch.Generator().manual_seed(weight_seed))
@@ -113,13 +116,18 @@ def run_case(tag, tile_seed, n, hw, out_shape, tasks, weight_seed=0, family="see
     with torch.no_grad():
         ref_logits = model(x)
         ref_feats = model.backbone(x / 255.0)
-    ref_out = ref_infer_step(torch.from_numpy(tiles), model, out_shape, kw["considered_tasks"])
+    ref_out = ref_infer_step(torch.from_numpy(tiles), model, out_shape, head_list)
 
     # oracle vs reference (same machine, same torch) -- must agree to rounding
     orc_logits = net_ref.net_forward(sd, x, kw["decoder_kwargs"], kw["considered_tasks"])
-    orc_out = net_ref.infer_step(sd, tiles, out_shape, kw["considered_tasks"], kw["decoder_kwargs"])
+    orc_out = net_ref.infer_step(sd, tiles, out_shape, head_list, kw["decoder_kwargs"])
     store = {"tile_seed": tile_seed, "weight_seed": weight_seed, "weight_family": family, "n": n, "hw": hw, "out_shape": out_shape,
              "tasks": np.array(tasks), "weights_sha256": state_dict_sha256(sd_np), "tiles_kind": tiles_kind, "tiles_sha256": tiles_sha256(tiles)}
+    if decoder_kwargs is not None:
+        import json
+
+        store["decoder_kwargs_json"] = json.dumps([[k, list(v.items())] for k, v in kw["decoder_kwargs"].items()])
+        store["head_name_list"] = np.array(head_list)
     if head_scale is not None:
         store["head_scale_names"] = np.array(list(head_scale.keys()))
         store["head_scale_values"] = np.array(list(head_scale.values()), np.float32)
@@ -232,4 +240,8 @@ if __name__ == "__main__":
     run_case("logit30_all", tile_seed=6, n=2, hw=256, out_shape=256, tasks=all_tasks, weight_seed=0, family="scaled", logit_target=30.0)
     run_case("logit80_all", tile_seed=7, n=2, hw=256, out_shape=256, tasks=all_tasks, weight_seed=0, family="scaled", logit_target=80.0)
     run_case("struct_all", tile_seed=8, n=4, hw=256, out_shape=256, tasks=all_tasks, weight_seed=0, tiles_kind="structured")
+    # several output heads over ONE decoder (models/net_desc.py:81-87, 196-198): the Gland decoder carries INST and TYPE
+    run_case("multihead", tile_seed=10, n=2, hw=256, out_shape=256, tasks=["Gland", "Nuclei", "Patch-Class"],
+             decoder_kwargs=[("Gland", [("INST", 3), ("TYPE", 3)]), ("Nuclei", [("INST", 3)]), ("Patch-Class", [("OUT", 9)])],
+             head_list=["Gland", "Gland#TYPE", "Nuclei", "Patch-Class"])
     run_case("struct80_all", tile_seed=9, n=4, hw=256, out_shape=256, tasks=all_tasks, weight_seed=0, family="scaled", logit_target=80.0, tiles_kind="structured")

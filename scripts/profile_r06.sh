@@ -23,7 +23,7 @@ timeout -k 5 200 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w -- python bench.p
 python scripts/rocprof_summary.py pmc "$(find $OUT/fetch -name '*.db' | head -1)" "$(find $OUT/write -name '*.db' | head -1)" $OUT/r06_bench_pmc_hbm.json
 # (CERB_WGRAD_SIDE=0: every launch of the step on ONE stream, so that a kernel's duration is its own -- with the weight gradients on their side stream, the default,
 #  two kernels share the device and both read longer; the timed figure of the default is in r06_bench_train.json)
-CERB_WGRAD_SIDE=0 timeout -k 5 400 rocprofv3 --kernel-trace --stats -d $OUT/tstats -o t -- python bench.py --mode train --steps 5 --warmup 2 --no-cpu-baseline > $OUT/r06_bench_train_under_rocprof.json 2> $OUT/tstats.log
+CERB_DEV_LIB=1 CERB_WGRAD_SIDE=0 timeout -k 5 400 rocprofv3 --kernel-trace --stats -d $OUT/tstats -o t -- python bench.py --mode train --steps 5 --warmup 2 --no-cpu-baseline > $OUT/r06_bench_train_under_rocprof.json 2> $OUT/tstats.log
 python scripts/rocprof_summary.py stats "$(find $OUT/tstats -name '*.db' | head -1)" $OUT/r06_bench_train_kernel_stats.txt
 # training leg, HBM counters: 1 warm-up + 2 timed + 1 profiled step = 4 steps per run
 timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/tfetch -o f -- python bench.py --mode train --no-cpu-baseline --steps 2 --warmup 1 > $OUT/tfetch.log 2>&1

@@ -23,11 +23,15 @@ def _crops(a):
     return np.stack([a[:, y:y + CS, x:x + CS] for (y, x) in CROPS], axis=1)
 
 
-def _model(tasks, seed=0, family="seeded", head_scale=None):
+def _model(tasks, seed=0, family="seeded", head_scale=None, decoder_kwargs=None):
     """family "seeded": cerberus_amd.weights.make_state_dict; "refinit": the reference's default initialisation (weights_init_cnn,
     models/net_desc.py:89-103) from a seeded generator; "scaled": the seeded recipe with every dense head's last 1x1 multiplied by the
     fixture's float32 factors (calibration logits at 30 / 80) -- exactly what oracle/gen_golden_net.py loaded into the reference."""
     kw = default_model_kwargs(tasks)
+    if decoder_kwargs is not None:
+        from collections import OrderedDict
+
+        kw["decoder_kwargs"] = OrderedDict((k, OrderedDict(v)) for k, v in decoder_kwargs)
     if family == "refinit":
         sd_np = reference_init_state_dict(kw["decoder_kwargs"], kw["considered_tasks"], generator=torch.Generator().manual_seed(seed))
     else:
@@ -44,7 +48,14 @@ def _golden_model(g):
     scale = None
     if fam == "scaled":
         scale = {str(k): np.float32(v) for k, v in zip(g["head_scale_names"], g["head_scale_values"])}
-    m, sd, kw = _model(tasks, int(g["weight_seed"]), fam, scale)
+    dk = None
+    if "decoder_kwargs_json" in g:  # another head layout than paramset.yml's (several heads over one decoder)
+        import json
+
+        dk = [(k, [tuple(h) for h in v]) for k, v in json.loads(str(g["decoder_kwargs_json"]))]
+    m, sd, kw = _model(tasks, int(g["weight_seed"]), fam, scale, dk)
+    if "head_name_list" in g:
+        tasks = [str(t) for t in g["head_name_list"]]  # what infer_step is called with (models/run_desc.py:475-476)
     from cerberus_amd.weights import state_dict_sha256
     assert state_dict_sha256({k: v.numpy() for k, v in sd.items()}) == str(g["weights_sha256"]), "the fixture's weights were not rebuilt bit for bit"
     return m, sd, kw, tasks
@@ -201,7 +212,9 @@ def test_head_w2_on_4x4_matrix_instructions_vs_padded_16_row_instruction(full_mo
 
 GOLDEN_TAGS = ["cfg1_nuclei", "cfg2_all", "g448_all", "small96_all", "seed1_all", "refinit_all",
                # round 6: "a confident trained model" -- every dense head's calibration logits at 30 / 80 -- and structured inputs
-               "logit30_all", "logit80_all", "struct_all", "struct80_all"]
+               "logit30_all", "logit80_all", "struct_all", "struct80_all",
+               # several output heads over one decoder (models/net_desc.py:81-87: {"Gland": {"INST": 3, "TYPE": 3}}): the trunk runs once, both heads read it
+               "multihead"]
 
 
 @pytest.mark.parametrize("tag", GOLDEN_TAGS)

@@ -17,7 +17,7 @@ def _crops(a):
     return np.stack([a[:, y:y + CS, x:x + CS] for (y, x) in CROPS], axis=1)
 
 
-@pytest.mark.parametrize("tag", ["cfg1_nuclei", "cfg2_all", "g448_all", "small96_all", "seed1_all", "refinit_all", "logit30_all", "logit80_all", "struct_all", "struct80_all"])
+@pytest.mark.parametrize("tag", ["cfg1_nuclei", "cfg2_all", "g448_all", "small96_all", "seed1_all", "refinit_all", "logit30_all", "logit80_all", "struct_all", "struct80_all", "multihead"])
 def test_oracle_matches_reference_fixtures(golden_dir, tag):
     """Two draws of the seeded non-saturating recipe and the reference's default initialisation (refinit_all: logits in the thousands,
     so the tolerances scale with the logit magnitude and with the reference's own fp32-vs-fp64 noise recorded in the fixture); round 6: the
@@ -25,6 +25,13 @@ def test_oracle_matches_reference_fixtures(golden_dir, tag):
     g = np.load(os.path.join(golden_dir, "net_%s.npz" % tag))
     tasks = [str(t) for t in g["tasks"]]
     kw = default_model_kwargs(tasks)
+    heads = tasks
+    if "decoder_kwargs_json" in g:
+        import json
+        from collections import OrderedDict
+
+        kw["decoder_kwargs"] = OrderedDict((k, OrderedDict(tuple(h) for h in v)) for k, v in json.loads(str(g["decoder_kwargs_json"])))
+        heads = [str(t) for t in g["head_name_list"]]
     if str(g["weight_family"]) == "refinit":
         sd_np = reference_init_state_dict(kw["decoder_kwargs"], tasks, generator=torch.Generator().manual_seed(int(g["weight_seed"])))
     else:
@@ -54,7 +61,7 @@ def test_oracle_matches_reference_fixtures(golden_dir, tag):
         scale = max(1.0, float(g["logit_absmax/" + k]) / 10.0)
         assert np.abs(got - ref).max() < 2e-4 * scale, k
         assert abs(a.astype(np.float64).mean() - float(g["logits_mean/" + k])) < 1e-5 * scale
-    out = net_ref.infer_step(sd, tiles, osz, tasks, kw["decoder_kwargs"])
+    out = net_ref.infer_step(sd, tiles, osz, heads, kw["decoder_kwargs"])
     for k in out[0].keys():
         a = np.stack([out[i][k] for i in range(n)])
         assert str(a.dtype) == str(g["out_dtype/" + k])

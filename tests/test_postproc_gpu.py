@@ -4,6 +4,7 @@ import os
 
 import numpy as np
 import pytest
+
 import torch
 
 from cerberus_amd.postproc import PostProcInstErodedContourMap, mask_lumen_by_gland, postproc_device
@@ -457,6 +458,9 @@ def _labels_digest(env_extra):
     for k in ("CERB_PP_ONE_PIXEL_THREADS", "CERB_PP_PIXEL_SCANS", "CERB_PP_SEAM_STRICT", "CERB_PP_THREE_LABELLINGS"):
         env.pop(k, None)
     env.update(env_extra)
+    env.pop("CERB_DEV_LIB", None)
+    if env_extra:  # the switches exist only in the developers' build of the library (csrc/cerb_dev.h); the default run is the PRODUCT library's
+        env["CERB_DEV_LIB"] = "1"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
     out = subprocess.run([sys.executable, "-c", _AB_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=600)

@@ -4,6 +4,8 @@ import os
 
 import numpy as np
 import pytest
+
+from conftest import dev_switches
 import torch
 
 from cerberus_amd.losses import PARAMSET_LOSS, head_loss
@@ -510,6 +512,7 @@ def test_data_gradients_upstream_of_an_eval_mode_batchnorm():
 
 
 @pytest.mark.gpu
+@dev_switches
 def test_batchnorm_statistics_from_the_conv_output_stage_equal_the_separate_pass(gold):
     """Training forward: the F(4x4) convolutions (conv_wino4 / conv_wino4b STATS instantiations) and the heads' 64 -> 96 pointwise layer leave
     per-block (sum, sum of squares) partials from their own output stage and the BatchNorm behind them finalises its batch statistics from those;
@@ -563,6 +566,7 @@ def test_batchnorm_statistics_from_the_conv_output_stage_equal_the_separate_pass
 
 
 @pytest.mark.gpu
+@dev_switches
 def test_fused_output_heads_equal_the_separate_passes(gold):
     """Round 5: an output head's train-mode chain (1x1 64->96 -> BatchNorm -> ReLU -> 1x1 96->out) stores only its hidden map and reads it three times
     (csrc/head_train.hip: forward 2, backward 1, backward 2) instead of running seven separate passes; CERB_HEAD_UNFUSED=1 keeps round 4's passes.
@@ -629,6 +633,7 @@ def test_fused_output_heads_equal_the_separate_passes(gold):
 
 
 @pytest.mark.gpu
+@dev_switches
 def test_winograd_domain_weight_gradients_equal_the_direct_kernel(gold):
     """Round 5: the weight gradients of the 3x3 stride-1 convolutions are accumulated in the Winograd domain (csrc/conv_wgrad_wino.hip:
     dU = sum_tiles (A dY A^T) .* (B^T d B), dg = G^T dU G -- a quarter of the direct form's matrix instructions); CERB_WGRAD_DIRECT=1 keeps round 4's
@@ -736,6 +741,7 @@ def test_training_step_with_packed_items_equals_block_items():
 
 
 @pytest.mark.gpu
+@dev_switches
 def test_maxpool_backward_by_recorded_positions_equals_the_scan(gold):
     """Round 5: the training forward's max-pool records which window position held each first maximum (one byte per element) and the backward pass routes
     the gradients by it; CERB_MAXPOOL_SCAN=1 keeps round 4's backward, which re-finds the first maxima from the stem's output and the pooled map
@@ -778,6 +784,7 @@ def test_maxpool_backward_by_recorded_positions_equals_the_scan(gold):
 
 
 @pytest.mark.gpu
+@dev_switches
 def test_weight_gradients_on_the_side_stream_equal_the_single_stream_step(gold):
     """Round 5: the backward pass queues the weight gradients of the 3x3 / 1x1 convolutions on a side stream of the handle (forked when a layer's output gradient is
     final, joined at the end of cerb_net_train_grads) so that they overlap the BatchNorm backward passes; CERB_WGRAD_SIDE=0 keeps everything on the caller's stream.
@@ -827,6 +834,7 @@ def test_weight_gradients_on_the_side_stream_equal_the_single_stream_step(gold):
 
 
 @pytest.mark.gpu
+@dev_switches
 def test_batchnorm_backward_sums_from_the_data_gradient_equal_the_reduction_pass(gold):
     """Round 5: where a data gradient (conv_wino4 / conv_wino4b on rotated weights) is the only writer of the gradient behind a train-mode BatchNorm + ReLU -- the first
     BatchNorm of every BasicBlock and of every decoder level -- its output stage reads the BatchNorm's input at its own pixels and leaves that BatchNorm's backward sums
