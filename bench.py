@@ -269,7 +269,7 @@ def train_measure(model, dev, dist, world, rank, steps, warmup, backend):
         # measured HBM traffic per family and step (profiles/r05_train_pmc_hbm.json: FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950-corrected by
         # scripts/rocprof_summary.py pmc_step); for the bandwidth-bound families beside their algorithmic bytes
         pmc = None
-        for cand in ("r05_train_pmc_hbm.json",):
+        for cand in ("r06_train_pmc_hbm.json", "r05_train_pmc_hbm.json"):
             pth = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(pth):
                 pmc = json.load(open(pth))
@@ -426,7 +426,7 @@ def kernel_table(model, step, n_tiles):
     dom = rows[0]
     fl, ms, cnt = fam[dom["kernel"]]
     traffic = None
-    for cand in ("r05_bench_pmc_hbm.json", "r04_bench_pmc_hbm.json", "r03_bench_pmc_hbm.json", "r02_bench_pmc_hbm.json", "r01_bench_pmc_hbm.json"):
+    for cand in ("r06_bench_pmc_hbm.json", "r05_bench_pmc_hbm.json", "r04_bench_pmc_hbm.json", "r03_bench_pmc_hbm.json", "r02_bench_pmc_hbm.json", "r01_bench_pmc_hbm.json"):
         pth = os.path.join(ROOT, "profiles", cand)
         sym = _SYMBOL.get(dom["kernel"])
         if sym and os.path.exists(pth):

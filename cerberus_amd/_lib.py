@@ -150,6 +150,11 @@ def lib():
     return L
 
 
+class CerberusHipAllocError(CerberusHipError):
+    """CERB_ERR_ALLOC (return code 2): a workspace / tape allocation did not fit the device."""
+
+
 def check(rc):
     if rc != 0:
-        raise CerberusHipError(lib().cerb_last_error().decode("utf-8", "replace"))
+        msg = lib().cerb_last_error().decode("utf-8", "replace")
+        raise (CerberusHipAllocError if rc == 2 else CerberusHipError)(msg)

@@ -690,12 +690,12 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
         return (long long)hs[3 - u] * ws[3 - u] > 4096 && c0->second.cin == 64 && c0->second.cout == 64 && c1->second.cout == 64;
     };
     if (!dry) {
-        if (net->x0.ensure((size_t)N * H * W * 64 * 4, guard) || net->pool.ensure((size_t)N * hs[1] * ws[1] * 64 * 4, guard)) return fail("workspace allocation failed");
+        if (net->x0.ensure((size_t)N * H * W * 64 * 4, guard) || net->pool.ensure((size_t)N * hs[1] * ws[1] * 64 * 4, guard)) return fail_alloc();
         for (int i = 1; i < 5; ++i)
-            if (net->x[i].ensure((size_t)N * hs[i] * ws[i] * kFilters[i] * 4, guard)) return fail("workspace allocation failed");
+            if (net->x[i].ensure((size_t)N * hs[i] * ws[i] * kFilters[i] * 4, guard)) return fail_alloc();
         if (net->ta.ensure((size_t)N * hs[1] * ws[1] * 64 * 4, guard) || net->tb.ensure((size_t)N * hs[1] * ws[1] * 64 * 4, guard) ||
             net->cm.ensure((size_t)N * hs[4] * ws[4] * 256 * 4, guard))
-            return fail("workspace allocation failed");
+            return fail_alloc();
         if (D) {
             // dsum / dmid hold the entry sum and the first conv's output of a level that runs NHWC (per decoder 32^2 x 256, 64^2 x 128, and -- when the
             // tile-planar levels are off -- 128^2 x 64, 256^2 x 64), dout[u] its second conv's output; the planar levels have their own buffers, so with
@@ -714,11 +714,11 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
                 need_mid = std::max(need_mid, px * (size_t)(c0 != net->conv.end() ? c0->second.cout : 256) * 4);
             }
             if (!exact_ws) need_sum = need_mid = D * (size_t)N * H * W * 64 * 4;
-            if (net->dmid.ensure(need_mid, guard)) return fail("workspace allocation failed");
-            if (net->conv_algo && net->dsum.ensure(need_sum, guard)) return fail("workspace allocation failed");
+            if (net->dmid.ensure(need_mid, guard)) return fail_alloc();
+            if (net->conv_algo && net->dsum.ensure(need_sum, guard)) return fail_alloc();
             for (int u = 0; u < 4; ++u) {
                 if (exact_ws && level_is_planar(u)) continue;  // its outputs live in the planar buffers
-                if (net->dout[u].ensure(D * (size_t)N * hs[3 - u] * ws[3 - u] * oc[u] * 4, guard)) return fail("workspace allocation failed");
+                if (net->dout[u].ensure(D * (size_t)N * hs[3 - u] * ws[3 - u] * oc[u] * 4, guard)) return fail_alloc();
             }
         }
     }
@@ -841,7 +841,7 @@ static int forward_impl(cerb_net* net, const cerb_forward_io* io, hipStream_t st
                 // two buffers per planar level: the entry sum is dead once the first conv has read it, so the second conv writes its output there
                 // (a third buffer of 8.6 GB at 64 tiles of 256^2 held it before); same geometry, same zero ring
                 PlanarBuf &bs = u == 3 ? net->psum : net->psum2, &bm = u == 3 ? net->pmid : net->pmid2, &bo = bs;
-                if (bs.ensure((int)D, N, hh, ww, 64, st) || bm.ensure((int)D, N, hh, ww, 64, st)) return fail("workspace allocation failed");
+                if (bs.ensure((int)D, N, hh, ww, 64, st) || bm.ensure((int)D, N, hh, ww, 64, st)) return fail_alloc();
                 if (prof_begin(net, n0 + ".up", "upsample2_add_planar", 0.0, st)) return 1;
                 HIP_OK(cerb_launch_upsample2_add_planar(skips[u], prev, bs.b.p, (int)D, N, hh, ww, cin0, prev_gs, bs.gs(), use_roi ? roi_sum[u] : nullptr, prev_planar ? 1 : 0, st));
                 if (prof_end(net, st)) return 1;

@@ -133,6 +133,9 @@ hipError_t cerb_launch_patch_class(const PatchClassParams& p, hipStream_t st);
 
 int cerb_set_error(const std::string& m);  // thread-local message of cerb_last_error(); returns 1
 static inline int fail(const std::string& m) { return cerb_set_error(m); }
+// Return code 2 (include/cerberus_hip.h: CERB_ERR_ALLOC): a workspace / tape allocation did not fit -- the one failure a caller can act on (run on a
+// smaller batch, drop its second handle: cerberus_amd/wsi.py) without parsing the message.
+static inline int fail_alloc() { return cerb_set_error("workspace allocation failed") + 1; }
 #define HIP_OK(expr)                                                                              \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \

@@ -25,7 +25,7 @@ static int bn_train(cerb_net* net, const std::string& name, float* x, const floa
     const cerb_net::BnDev& b = it->second;
     if (net->t_mean.ensure((size_t)b.groups * b.C * 4, 0) || net->t_rstd.ensure((size_t)b.groups * b.C * 4, 0) ||
         net->t_ws.ensure(cerb_bn_workspace_bytes(b.groups, rows, b.C), 0))
-        return fail("workspace allocation failed");
+        return fail_alloc();
     HIP_OK(cerb_launch_bn_stats(x, group_stride, rows, b.C, b.groups, 1e-5f, net->t_mean.p, net->t_rstd.p, nullptr, net->t_ws.p, st));
     if (bn_eval_override(b, net->t_mean.p, net->t_rstd.p, st)) return 1;
     HIP_OK(cerb_launch_bn_apply(x, nullptr, resid, group_stride, rows, b.C, b.groups, net->t_mean.p, net->t_rstd.p, b.gamma, b.beta, relu, st));
@@ -46,14 +46,14 @@ extern "C" int cerb_net_forward_train(cerb_net* net, const cerb_train_io* io, vo
     if (net->x0.ensure((size_t)N * H * W * 64 * 4, guard) || net->pool.ensure((size_t)N * hs[1] * ws[1] * 64 * 4, guard) ||
         net->ta.ensure((size_t)N * hs[1] * ws[1] * 64 * 4, guard) || net->tb.ensure((size_t)N * hs[1] * ws[1] * 64 * 4, guard) ||
         net->cm.ensure((size_t)N * hs[4] * ws[4] * 256 * 4, guard))
-        return fail("workspace allocation failed");
+        return fail_alloc();
     for (int i = 1; i < 5; ++i)
-        if (net->x[i].ensure((size_t)N * hs[i] * ws[i] * kFilters[i] * 4, guard)) return fail("workspace allocation failed");
+        if (net->x[i].ensure((size_t)N * hs[i] * ws[i] * kFilters[i] * 4, guard)) return fail_alloc();
     const int oc[4] = {128, 64, 64, 64};
     if (D) {
-        if (net->dmid.ensure(D * (size_t)N * H * W * 64 * 4, guard) || net->dsum.ensure(D * (size_t)N * H * W * 64 * 4, guard)) return fail("workspace allocation failed");
+        if (net->dmid.ensure(D * (size_t)N * H * W * 64 * 4, guard) || net->dsum.ensure(D * (size_t)N * H * W * 64 * 4, guard)) return fail_alloc();
         for (int u = 0; u < 4; ++u)
-            if (net->dout[u].ensure(D * (size_t)N * hs[3 - u] * ws[3 - u] * oc[u] * 4, guard)) return fail("workspace allocation failed");
+            if (net->dout[u].ensure(D * (size_t)N * hs[3 - u] * ws[3 - u] * oc[u] * 4, guard)) return fail_alloc();
     }
     const int saved_algo = net->conv_algo;
     // ---- encoder: conv -> BN(batch) -> ReLU -----------------------------------------------------------------------------------
@@ -82,7 +82,7 @@ extern "C" int cerb_net_forward_train(cerb_net* net, const cerb_train_io* io, vo
             if (bn_train(net, p + ".conv1", t1, nullptr, 0, rows_out, 1, st)) return 1;
             if (stride != 1 || inpl != planes) {
                 // the identity branch needs its own buffer here: in layer1.0 there is none, later the pool buffer is free but smaller maps fit
-                if (net->t_idn.ensure((size_t)rows_out * planes * 4, guard)) return fail("workspace allocation failed");
+                if (net->t_idn.ensure((size_t)rows_out * planes * 4, guard)) return fail_alloc();
                 if (run_conv(net, p + ".downsample", cur, nullptr, nullptr, net->t_idn.p, N, hin, win, 0, 0, 0, 0, st, nullptr)) return 1;
                 if (bn_train(net, p + ".downsample", net->t_idn.p, nullptr, 0, rows_out, 0, st)) return 1;
                 idt = net->t_idn.p;
@@ -110,7 +110,7 @@ extern "C" int cerb_net_forward_train(cerb_net* net, const cerb_train_io* io, vo
             py_slice(ws[4], x0, cw);
         }
         if (ch <= 0 || cw <= 0) return fail("cerb_net_forward_train: empty Patch-Class crop");
-        if (net->t_gap.ensure((size_t)N * 512 * 4, 0) || net->t_pc1.ensure((size_t)N * 256 * 4, 0)) return fail("workspace allocation failed");
+        if (net->t_gap.ensure((size_t)N * 512 * 4, 0) || net->t_pc1.ensure((size_t)N * 256 * 4, 0)) return fail_alloc();
         HIP_OK(cerb_launch_crop_gap(net->x[4].p, N, hs[4], ws[4], 512, y0, ch, x0, cw, net->t_gap.p, st));
         if (bn_train(net, "pc.bn1", net->t_gap.p, nullptr, 0, N, 1, st)) return 1;
         HIP_OK(cerb_launch_pointwise(net->t_gap.p, net->pc_rw1, net->pc_rb1, net->t_pc1.p, N, 512, 256, io->dropout_scale, st));
@@ -136,7 +136,7 @@ extern "C" int cerb_net_forward_train(cerb_net* net, const cerb_train_io* io, vo
             prev_gs = rows * oc[u];
         }
         const long long rows = (long long)N * H * W;
-        if (net->t_hid.ensure((size_t)rows * 96 * 4, 0)) return fail("workspace allocation failed");
+        if (net->t_hid.ensure((size_t)rows * 96 * 4, 0)) return fail_alloc();
         for (size_t k = 0; k < D; ++k) {
             const int di = net->dense_idx[k];
             if (!io->logits[di]) continue;
@@ -363,7 +363,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
     const bool pool_scan = cerb_dev_getenv("CERB_MAXPOOL_SCAN") != nullptr;  // read once per step
     const int pool_idx = pool_scan ? -1 : newT(((size_t)N * hs[1] * ws[1] * 64 + 3) / 4);
     if (pool_idx >= 0) {
-        if (!val[pool_idx]) { net->conv_algo = saved_algo; return fail("workspace allocation failed"); }
+        if (!val[pool_idx]) { net->conv_algo = saved_algo; return fail_alloc(); }
         PROF("maxpool", "maxpool3x3s2", (double)N * H * W * 64 * 4.0 * 1.25 + (double)N * hs[1] * ws[1] * 64.0,
              HIP_OK(cerb_launch_maxpool_idx(val[x0], val[pool], reinterpret_cast<unsigned*>(val[pool_idx]), N, H, W, 64, st)));
     } else {
@@ -490,7 +490,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
             const int hid = newT((size_t)rows * 96);
             // the hidden map's BatchNorm statistics come out of the layer itself (per-wave partials in t_ws, sized for either way before the launch)
             int pre_blocks = 0;
-            if (net->t_ws.ensure(std::max(cerb_bn_workspace_bytes(1, rows, 96), (size_t)8192 * 96 * 16), 0)) return fail("workspace allocation failed");
+            if (net->t_ws.ensure(std::max(cerb_bn_workspace_bytes(1, rows, 96), (size_t)8192 * 96 * 16), 0)) return fail_alloc();
             const bool heads_fused = net->conv_algo && cerb_dev_getenv("CERB_HEAD_UNFUSED") == nullptr && cerb_head_train_supported(rows, 64, 96, d.out_ch);
             const float* in_bn[4] = {nullptr, nullptr, nullptr, nullptr};
             if (last_stat >= 0) {  // group k's statistics and affine parameters of the deferred BatchNorm
@@ -516,7 +516,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 TCHK(bn(bname, hid, -1, rows, 1, pre_blocks, &stt));
                 const cerb_net::BnDev& hb = net->bn[bname];
                 const int lg = newT((size_t)rows * d.out_ch);
-                if (!val[lg]) return fail("workspace allocation failed");
+                if (!val[lg]) return fail_alloc();
                 PROF(p + ".1", "head_fwd2", (double)rows * (96 + d.out_ch) * 4.0,
                      HIP_OK(cerb_launch_head_fwd2(val[hid], val[stt], val[stt] + 96, hb.gamma, hb.beta, net->head_rw2[k], net->head_rb2[k], val[lg], rows, d.out_ch, st)));
                 TapeOp op;
@@ -556,7 +556,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         const DecoderCfg& d = net->dec[di];
         const bool pc = (int)di == net->pc_idx;
         const int hh = pc ? 1 : H, ww = pc ? 1 : W, C = d.out_ch;
-        if (net->t_hid.ensure(cerb_head_loss_workspace_bytes(N, hh, ww), 0)) return fail("workspace allocation failed");
+        if (net->t_hid.ensure(cerb_head_loss_workspace_bytes(N, hh, ww), 0)) return fail_alloc();
         // NHWC logits: strides (n, c, y, x) = (h w C, 1, w C, C)
         float* glg = G_(lg);
         PROF("loss." + d.name, "head_loss", (double)N * hh * ww * (C * 8.0 + 8.0),
@@ -581,7 +581,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
         }
         switch (op.type) {
             case 0: {  // stem: weight gradient only
-                if (net->t_ws.ensure(cerb_stem_wgrad_workspace_bytes(), 0)) return fail("workspace allocation failed");
+                if (net->t_ws.ensure(cerb_stem_wgrad_workspace_bytes(), 0)) return fail_alloc();
                 float* dws = pub("backbone.conv1.weight", 64 * 147);
                 PROF("stem.wgrad", "stem_wgrad", 2.0 * N * H * W * 64.0 * 147.0, HIP_OK(cerb_launch_stem_wgrad_mfma(io->tiles, go, dws, N, H, W, net->t_ws.p, st)));
                 break;
@@ -600,11 +600,11 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 const bool dw_assigned = (op.ks == 3 || op.ks == 1) && net->conv_algo;
                 float* dw = take(wn * op.G, !dw_assigned);
                 float* db = r.b ? take((size_t)op.Cout * op.G, false) : nullptr;
-                if (!dw) return fail("workspace allocation failed");
+                if (!dw) return fail_alloc();
                 if (side_wgrad && (wg_wino || wg_mfma)) {
                     const int ho_ = op.stride == 2 ? op.H / 2 : op.H, wo_ = op.stride == 2 ? op.W / 2 : op.W;
                     const size_t need = wg_wino ? cerb_wgrad_wino_workspace_bytes(op.G, op.N, op.H, op.W, op.Cin, op.Cout) : cerb_wgrad_workspace_bytes(op.G, op.N, ho_, wo_, op.Cin, op.Cout, op.ks, nullptr);
-                    if (net->t_ws2.ensure(need, 0)) return fail("workspace allocation failed");
+                    if (net->t_ws2.ensure(need, 0)) return fail_alloc();
                     HIP_OK(hipEventRecord(net->ev_fork, st));  // the layer's output gradient (and a fresh workspace's fill) is complete on the caller's stream
                     HIP_OK(hipStreamWaitEvent(net->side, net->ev_fork, 0));
                     wst = net->side;
@@ -618,7 +618,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     // input (other consumers) rides in as the residual and is written back in place
                     const long long in_n = (long long)op.N * op.H * op.W * op.Cin;
                     const bool fresh = !grd[op.a] && cnt[op.a] == (size_t)op.G * in_n && (op.G == 1 || op.a_gs == in_n);  // first writer: no residual, no zero fill
-                    if (fresh && !(grd[op.a] = take(cnt[op.a], false))) return fail("workspace allocation failed");
+                    if (fresh && !(grd[op.a] = take(cnt[op.a], false))) return fail_alloc();
                     float* dx = G_(op.a);
                     const long long map_px = (long long)op.H * op.W;
                     const bool d_w4 = saved_algo == 5 || saved_algo == 7 || (saved_algo == 6 && map_px >= 256);
@@ -637,7 +637,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                                    2.0 * op.G * op.N * op.H * op.W * (double)op.Cin * op.Cout * 9.0, st)) return 1;
                     if (op.stride == 2) {  // y = 2 yo - 1 + ky  <=>  dx = conv_s1(D, W'), D[2 yo][2 xo] = dy[yo][xo], zero elsewhere
                         const long long dn = (long long)op.G * op.N * op.H * op.W * op.Cout;
-                        if (net->t_dil.ensure((size_t)dn * 4, cerb_conv_guard_bytes(W))) return fail("workspace allocation failed");
+                        if (net->t_dil.ensure((size_t)dn * 4, cerb_conv_guard_bytes(W))) return fail_alloc();
                         HIP_OK(cerb_launch_dilate2(go, net->t_dil.p, (long long)op.G * op.N, op.H, op.W, op.Cout, st));
                         go = net->t_dil.p;
                     }
@@ -676,7 +676,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                                     (op.G == 1 || bo.a_gs == in_n)) {
                                     const int bpg = d_w4b ? cerb_wino4b_bn_blocks(p) : op.N * ((op.H + 15) / 16) * ((op.W + 15) / 16);
                                     double* part = (double*)take((size_t)op.G * bpg * op.Cin * 2 * 2, false);
-                                    if (!part) return fail("workspace allocation failed");
+                                    if (!part) return fail_alloc();
                                     p.bn_part = part;
                                     p.bst_y = val[bo.a];
                                     p.bst_y_gs = op.G == 1 ? 0 : bo.a_gs;
@@ -701,7 +701,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 // 3x3 stride 1 on whole 64-channel blocks: the weight gradient in the Winograd domain (conv_wgrad_wino.hip: a quarter of the matrix
                 // instructions of the direct form); CERB_WGRAD_DIRECT=1 keeps round 4's direct kernel everywhere (A/B, tests)
                 if (wg_wino) {
-                    if (wws->ensure(cerb_wgrad_wino_workspace_bytes(op.G, op.N, op.H, op.W, op.Cin, op.Cout), 0)) return fail("workspace allocation failed");
+                    if (wws->ensure(cerb_wgrad_wino_workspace_bytes(op.G, op.N, op.H, op.W, op.Cin, op.Cout), 0)) return fail_alloc();
                     if (prof_begin(net, op.name + ".wgrad", "wgrad_wino4<f4x4>", 2.0 * op.G * op.N * op.H * op.W * (double)op.Cin * op.Cout * 9.0, st)) return 1;
                     HIP_OK(cerb_launch_wgrad_wino(val[op.a], go, dw, op.G, op.N, op.H, op.W, op.Cin, op.Cout, op.a_gs, wws->p, wst, db));
                     if (prof_end(net, st)) return 1;
@@ -710,7 +710,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 }
                 if (!dw_done && wg_mfma) {  // weight gradient on the matrix cores
                     const int ho = op.stride == 2 ? op.H / 2 : op.H, wo = op.stride == 2 ? op.W / 2 : op.W;
-                    if (wws->ensure(cerb_wgrad_workspace_bytes(op.G, op.N, ho, wo, op.Cin, op.Cout, op.ks, nullptr), 0)) return fail("workspace allocation failed");
+                    if (wws->ensure(cerb_wgrad_workspace_bytes(op.G, op.N, ho, wo, op.Cin, op.Cout, op.ks, nullptr), 0)) return fail_alloc();
                     // `flops` field: executed MFMA FLOPs of the weight gradient (2 x outputs x taps x Cin x Cout)
                     if (prof_begin(net, op.name + ".wgrad", "wgrad<ks" + std::to_string(op.ks) + ",s" + std::to_string(op.stride) + ">",
                                    2.0 * op.G * op.N * ho * wo * (double)op.Cin * op.Cout * op.ks * op.ks, st)) return 1;
@@ -723,7 +723,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 }
                 if (db && !db_done) {
                     const long long orow = (long long)op.N * (op.stride == 2 ? op.H / 2 : op.H) * (op.stride == 2 ? op.W / 2 : op.W);
-                    if (net->t_ws.ensure((size_t)op.G * 2048 * op.Cout * 4 + 256, 0)) return fail("workspace allocation failed");
+                    if (net->t_ws.ensure((size_t)op.G * 2048 * op.Cout * 4 + 256, 0)) return fail_alloc();
                     PROF(op.name + ".dbias", "bias_colsum", (double)op.G * orow * op.Cout * 4.0, HIP_OK(cerb_launch_colsum(go, orow * op.Cout, orow, op.Cout, op.G, db, net->t_ws.p, st)));
                 }
                 if (!dx_done || !dw_done) {
@@ -740,12 +740,12 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
             case 2: {
                 const cerb_net::BnDev& b = net->bn[op.name];
                 float* dgb = take((size_t)2 * op.G * op.Cout, false);  // bn_bwd_finalize_kernel assigns both halves
-                if (!dgb || net->t_ws.ensure(cerb_bn_workspace_bytes(op.G, op.rows, op.Cout), 0)) return fail("workspace allocation failed");
+                if (!dgb || net->t_ws.ensure(cerb_bn_workspace_bytes(op.G, op.rows, op.Cout), 0)) return fail_alloc();
                 float* dgamma = dgb;
                 float* dbeta = dgb + (size_t)op.G * op.Cout;
                 // the conv output's gradient has this BatchNorm as its first writer almost always: then the kernel assigns and the buffer needs no zero fill
                 const bool fresh = !grd[op.a] && cnt[op.a] == (size_t)op.G * op.rows * op.Cout && (op.G == 1 || op.a_gs == op.rows * op.Cout);
-                if (fresh && !(grd[op.a] = take(cnt[op.a], false))) return fail("workspace allocation failed");
+                if (fresh && !(grd[op.a] = take(cnt[op.a], false))) return fail_alloc();
                 // `flops` field of an HBM-bound family: its algorithmic BYTES (reads dz, z, y twice -- reduction pass + apply pass --, writes dy
                 // (+ the residual branch's gradient)), fp32
                 // groups whose BatchNorm ran in eval mode (cerb_net_set_bn_eval): the backward of a normalisation by CONSTANTS -- the data gradient
@@ -756,7 +756,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     if (b.eval[g]) eval_mask |= 1ull << g;
                 // the residual branch's gradient likewise: assigned when this BatchNorm is its first writer (the identity of a BasicBlock that is not a decoder skip)
                 const bool fresh_r = op.b >= 0 && !grd[op.b] && cnt[op.b] == (size_t)op.G * op.rows * op.Cout;
-                if (fresh_r && !(grd[op.b] = take(cnt[op.b], false))) return fail("workspace allocation failed");
+                if (fresh_r && !(grd[op.b] = take(cnt[op.b], false))) return fail_alloc();
                 // a deferred BatchNorm whose gradient came from the fused heads alone: its reduction pass already happened in their epilogues
                 const double* pre_part = nullptr;
                 if (op.deferred && !cerb_dev_getenv("CERB_HEAD_BN_BWD_PASS")) {
@@ -810,8 +810,8 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 const bool skip_fresh = fused && !grd[op.a] && cnt[op.a] == (size_t)per_group;
                 const size_t prev_n = (size_t)op.N * (op.H / 2) * (op.W / 2) * op.Cout;
                 const bool prev_fresh = fused && !grd[op.b] && (op.b_gs == 0 ? cnt[op.b] == prev_n : (cnt[op.b] == (size_t)op.G * prev_n && op.b_gs == (long long)prev_n));
-                if (skip_fresh && !(grd[op.a] = take(cnt[op.a], false))) return fail("workspace allocation failed");
-                if (prev_fresh && !(grd[op.b] = take(cnt[op.b], false))) return fail("workspace allocation failed");
+                if (skip_fresh && !(grd[op.a] = take(cnt[op.a], false))) return fail_alloc();
+                if (prev_fresh && !(grd[op.b] = take(cnt[op.b], false))) return fail_alloc();
                 float* ga = G_(op.a);
                 float* gb = G_(op.b);
                 // algorithmic bytes: read the live groups' gradients, write the skip gradient (read it too when it already holds one) and the level below's
@@ -828,11 +828,11 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
             case 5: {
                 float* dw = pub(op.wkey, (size_t)op.Cin * op.Cout);
                 float* db = pub(op.bkey, (size_t)op.Cout);
-                if (!dw || !db) return fail("workspace allocation failed");
+                if (!dw || !db) return fail_alloc();
                 bool pw_dw = false, pw_db = false;
                 if (prof_begin(net, op.wkey + ".bwd", "pointwise_bwd", 4.0 * op.rows * (double)op.Cin * op.Cout, st)) return 1;  // weight + data gradient + bias sums
                 if (op.Cin % 4 == 0 && op.Cout % 4 == 0 && !op.scale && op.rows >= 4096 && op.rows < (1ll << 31) && net->conv_algo) {
-                    if (net->t_ws.ensure(cerb_wgrad_workspace_bytes(1, 1, 1, (int)op.rows, op.Cin, op.Cout, 1, nullptr), 0)) return fail("workspace allocation failed");
+                    if (net->t_ws.ensure(cerb_wgrad_workspace_bytes(1, 1, 1, (int)op.rows, op.Cin, op.Cout, 1, nullptr), 0)) return fail_alloc();
                     HIP_OK(cerb_launch_wgrad(val[op.a] + op.a_gs, go, dw, 1, 1, 1, (int)op.rows, op.Cin, op.Cout, 1, 1, 0, net->t_ws.p, st, db));  // (+ the bias sums)
                     pw_dw = true;
                     pw_db = true;
@@ -840,30 +840,30 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 if (!pw_dw && op.Cout <= 8 && !op.scale && op.rows >= 4096 && net->conv_algo) {
                     // the heads' 96 -> 3 / 7: weight gradient, bias sums and data gradient in one pass over the rows (cerb_launch_pw_bwd_small)
                     const bool fresh1 = !grd[op.a] && op.a_gs == 0 && cnt[op.a] == (size_t)op.rows * op.Cin;
-                    if (fresh1 && !(grd[op.a] = take(cnt[op.a], false))) return fail("workspace allocation failed");
+                    if (fresh1 && !(grd[op.a] = take(cnt[op.a], false))) return fail_alloc();
                     float* dxs = G_(op.a) + op.a_gs;
-                    if (net->t_ws.ensure(cerb_pw_bwd_small_workspace_bytes(op.rows, op.Cin, op.Cout), 0)) return fail("workspace allocation failed");
+                    if (net->t_ws.ensure(cerb_pw_bwd_small_workspace_bytes(op.rows, op.Cin, op.Cout), 0)) return fail_alloc();
                     HIP_OK(cerb_launch_pw_bwd_small(val[op.a] + op.a_gs, go, op.w, dxs, dw, db, op.rows, op.Cin, op.Cout, fresh1 ? 1 : 0, net->t_ws.p, st));
                     if (prof_end(net, st)) return 1;
                     break;
                 }
                 if (!pw_dw && op.Cout <= 8 && !op.scale && op.rows >= 4096) {  // (conv_algo 0: the separate passes)
-                    if (net->t_ws.ensure(cerb_pw_wgrad_small_workspace_bytes(op.rows, op.Cin, op.Cout), 0)) return fail("workspace allocation failed");
+                    if (net->t_ws.ensure(cerb_pw_wgrad_small_workspace_bytes(op.rows, op.Cin, op.Cout), 0)) return fail_alloc();
                     HIP_OK(cerb_launch_pw_wgrad_small(val[op.a] + op.a_gs, go, dw, op.rows, op.Cin, op.Cout, net->t_ws.p, st));
                     pw_dw = true;
                 }
                 if (!pw_db) {
-                    if (net->t_ws.ensure((size_t)2048 * op.Cout * 4 + 256, 0)) return fail("workspace allocation failed");
+                    if (net->t_ws.ensure((size_t)2048 * op.Cout * 4 + 256, 0)) return fail_alloc();
                     HIP_OK(cerb_launch_colsum(go, 0, op.rows, op.Cout, 1, db, net->t_ws.p, st));
                 }
                 // a hidden map read by this layer alone gets its gradient assigned (no zero fill, no read-modify-write)
                 bool fresh = !grd[op.a] && op.a_gs == 0 && cnt[op.a] == (size_t)op.rows * op.Cin;
-                if (fresh && !(grd[op.a] = take(cnt[op.a], false))) return fail("workspace allocation failed");
+                if (fresh && !(grd[op.a] = take(cnt[op.a], false))) return fail_alloc();
                 const size_t slice = (size_t)op.rows * op.Cin;
                 if (!fresh && cnt[op.a] > slice && cnt[op.a] % slice == 0 && cnt[op.a] / slice <= 64 && op.a_gs % (long long)slice == 0 &&
                     (!grd[op.a] || slice_written.count(op.a))) {  // one slice of a grouped tensor that only such layers have written so far
                     if (!grd[op.a]) {
-                        if (!(grd[op.a] = take(cnt[op.a], false))) return fail("workspace allocation failed");
+                        if (!(grd[op.a] = take(cnt[op.a], false))) return fail_alloc();
                         slice_written[op.a] = 0ull;
                         slice_geom[op.a] = std::make_pair((int)(cnt[op.a] / slice), slice);
                     }
@@ -887,7 +887,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 float* dw1 = pub(op.wkey, (size_t)96 * 64);
                 float* db1 = pub(op.bkey, 96);
                 float* dgb = take(2 * 96, false);
-                if (!dw2 || !db2 || !dw1 || !db1 || !dgb || net->t_ws.ensure(cerb_head_bwd_workspace_bytes(op.rows, oc), 0)) return fail("workspace allocation failed");
+                if (!dw2 || !db2 || !dw1 || !db1 || !dgb || net->t_ws.ensure(cerb_head_bwd_workspace_bytes(op.rows, oc), 0)) return fail_alloc();
                 float* dgamma = dgb;
                 float* dbeta = dgb + 96;
                 const float* mean = val[op.stat];
@@ -899,7 +899,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                 bool fresh = false;
                 if (cnt[op.a] >= slice && cnt[op.a] % slice == 0 && cnt[op.a] / slice <= 64 && op.a_gs % (long long)slice == 0 && (!grd[op.a] || slice_written.count(op.a))) {
                     if (!grd[op.a]) {
-                        if (!(grd[op.a] = take(cnt[op.a], false))) return fail("workspace allocation failed");
+                        if (!(grd[op.a] = take(cnt[op.a], false))) return fail_alloc();
                         slice_written[op.a] = 0ull;
                         slice_geom[op.a] = std::make_pair((int)(cnt[op.a] / slice), slice);
                     }
@@ -926,7 +926,7 @@ extern "C" int cerb_net_train_grads(cerb_net* net, const cerb_train_step_io* io,
                     auto dp = deferred_part.find(op.in_stat);
                     if (dp == deferred_part.end()) {
                         double* pb_ = (double*)take((size_t)lb.groups * per * 2, true);
-                        if (!pb_) return fail("workspace allocation failed");
+                        if (!pb_) return fail_alloc();
                         dp = deferred_part.insert(std::make_pair(op.in_stat, std::make_pair(pb_, true))).first;
                     }
                     if (fresh) in_part = dp->second.first + (size_t)k * per;

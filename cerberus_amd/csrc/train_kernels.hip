@@ -12,6 +12,9 @@
 
 #include <algorithm>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 #include <stdint.h>
 
@@ -1442,17 +1445,23 @@ hipError_t cerb_launch_copy_multi(int count, float* const* dst, const float* con
 // tables live in one device buffer that grows on demand and is reused by later steps (single optimiser stream assumed, as torch's own)
 hipError_t cerb_launch_adam_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* n, float lr, float b1,
                                   float b2, float eps, int step, hipStream_t st) {
-    struct Tab {  // one table per device (a host process may drive several)
+    struct Tab {
         void* dev = nullptr;
         size_t bytes = 0;
         std::vector<char> host;
     };
-    static Tab tabs[64];
+    // One table per (device, stream): a launch still reading its table on ANOTHER stream is never overwritten -- the synchronisations below
+    // cover this stream only --, and host threads driving different handles go through the mutex.  (Two optimisers alternating on one stream
+    // share a table and re-upload it every step: correct, not fast; torch's own optimisers are one per stream too.)
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Tab> tabs;
     int devid = 0;
-    if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return hipErrorInvalidDevice;
-    void*& dev_tab = tabs[devid].dev;
-    size_t& dev_bytes = tabs[devid].bytes;
-    std::vector<char>& host = tabs[devid].host;
+    if (hipGetDevice(&devid) != hipSuccess) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    Tab& tab = tabs[std::make_pair(devid, st)];
+    void*& dev_tab = tab.dev;
+    size_t& dev_bytes = tab.bytes;
+    std::vector<char>& host = tab.host;
     std::vector<AdamTensor> tt(count);
     std::vector<int2> ch;
     for (int i = 0; i < count; ++i) {

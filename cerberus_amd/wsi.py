@@ -281,15 +281,18 @@ class WSIRunner(object):
             try:
                 with torch.cuda.stream(self._side[k]):
                     one(nets[k], b0)
-            except _lib.CerberusHipError as e:
-                # the second handle's workspace did not fit after all (the plan is an estimate): go on with one handle instead of losing the slide
-                if k != 1 or "allocation" not in str(e):
+            except _lib.CerberusHipAllocError as e:
+                # the second handle's workspace did not fit after all (the plan is an estimate): go on with one handle instead of losing the slide.
+                # (CERB_ERR_ALLOC, not a message match; a failure on the FIRST handle stays fatal: there is nothing left to drop)
+                if k != 1:
                     raise
                 import logging
 
                 logging.getLogger("cerberus_amd.wsi").warning("second inference handle dropped (%s): continuing on one handle", e)
-                self.twin = None
                 torch.cuda.synchronize(self.dev)
+                self.twin._release()  # its packed weights and whatever workspace it did get go back to the device BEFORE the retry
+                self.twin = None
+                nets = (self.net, None)
                 torch.cuda.empty_cache()
                 k = 0
                 with torch.cuda.stream(self._side[0]):

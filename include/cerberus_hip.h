@@ -5,7 +5,8 @@
  * pointers (device pointers are raw hipMalloc/torch addresses), sizes, and a hipStream_t passed as void*.
  *
  * Conventions
- *   - every function returns 0 on success, non-zero on failure; cerb_last_error() returns a thread-local
+ *   - every function returns 0 on success, non-zero on failure (CERB_ERR_ALLOC = 2 when a workspace allocation did not fit the
+ *     device -- the one failure a caller can react to, e.g. with a smaller batch --, 1 otherwise); cerb_last_error() returns a thread-local
  *     message (the reference's only error convention is Python exceptions / assert, e.g.
  *     loader/postproc.py:390,395 and load_state_dict(strict=True) at infer/base.py:45).
  *   - one cerb_net per GPU / per process; calls on one handle must be serialised by the caller (the reference
@@ -23,6 +24,7 @@ extern "C" {
 #endif
 
 typedef struct cerb_net cerb_net;
+#define CERB_ERR_ALLOC 2
 
 int cerb_version(void);
 const char* cerb_last_error(void);

@@ -16,7 +16,7 @@ OUT=gpurun_out/prof_r06
 rm -rf $OUT; mkdir -p $OUT
 timeout -k 5 300 rocprofv3 --kernel-trace --stats -d $OUT/bstats -o b -- python bench.py --mode batch --no-cpu-baseline --steps 20 --warmup 3 > $OUT/r06_batch32_under_rocprof.json 2> $OUT/bstats.log
 python scripts/rocprof_summary.py stats "$(find $OUT/bstats -name '*.db' | head -1)" $OUT/r06_batch32_kernel_stats.txt
-timeout -k 5 500 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python bench.py --slide 12288 --steps 20 --warmup 5 > $OUT/r06_bench_under_rocprof.json 2> $OUT/stats.log
+timeout -k 5 500 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python bench.py --slide 12288 --steps 20 --warmup 5 --no-ingest-leg > $OUT/r06_bench_under_rocprof.json 2> $OUT/stats.log
 python scripts/rocprof_summary.py stats "$(find $OUT/stats -name '*.db' | head -1)" $OUT/r06_bench_kernel_stats.txt
 timeout -k 5 200 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f -- python bench.py --mode batch --no-cpu-baseline --steps 5 --warmup 1 > $OUT/fetch.log 2>&1
 timeout -k 5 200 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w -- python bench.py --mode batch --no-cpu-baseline --steps 5 --warmup 1 > $OUT/write.log 2>&1
@@ -50,6 +50,8 @@ python scripts/rocprof_summary.py stats "$(find $OUT/pstats -name '*.db' | head 
 timeout -k 5 200 rocprofv3 --pmc FETCH_SIZE -d $OUT/pfetch -o f -- python scripts/dev_pp_nuclei_only.py 8192 > $OUT/pfetch.log 2>&1
 timeout -k 5 200 rocprofv3 --pmc WRITE_SIZE -d $OUT/pwrite -o w -- python scripts/dev_pp_nuclei_only.py 8192 > $OUT/pwrite.log 2>&1
 python scripts/rocprof_summary.py pmc "$(find $OUT/pfetch -name '*.db' | head -1)" "$(find $OUT/pwrite -name '*.db' | head -1)" $OUT/r06_postproc_nuclei_8192_pmc_hbm.json
+# bytes per pixel and pass next to the 12 B/px a call needs (dev_pp_nuclei_only.py makes 4 calls at 8192^2)
+python scripts/rocprof_summary.py pmc_table $OUT/r06_postproc_nuclei_8192_pmc_hbm.json 4 67108864 12 $OUT/r06_postproc_nuclei_8192_bytes_per_pass.txt
 timeout -k 5 200 rocprofv3 --kernel-trace -d $OUT/ptrace -o p -- python scripts/dev_pp_nuclei_only.py 8192 > $OUT/ptrace.log 2>&1
 python scripts/rocprof_summary.py timeline "$(find $OUT/ptrace -name '*.db' | head -1)" nuc_threshold $OUT/r06_postproc_nuclei_8192_timeline.txt
 rm -rf $OUT/pfetch $OUT/pwrite $OUT/ptrace

@@ -92,6 +92,29 @@ def pmc_step(fetch_db, write_db, steps, out):
     print("wrote", out)
 
 
+def pmc_table(pmc_json, calls, px, algorithmic_b_px, out):
+    """Bytes per pixel and pass of one call: the pmc() summary of a run that made `calls` calls over `px` pixels each, as a table
+    sorted by traffic, beside the algorithmic bytes per pixel of the whole call."""
+    d = json.load(open(pmc_json))
+    rows = []
+    for k, v in d.items():
+        n = max(v.get("FETCH_SIZE_launches", 0), v.get("WRITE_SIZE_launches", 0)) / float(calls)
+        b = v.get("hbm_bytes_per_launch", 0.0) * n
+        rd = 2.0 * (v.get("FETCH_SIZE_KiB_avg_per_launch", 0.0) or 0.0) * 1024.0 * n
+        rows.append((b, rd, n, k))
+    rows.sort(reverse=True)
+    tot = sum(r[0] for r in rows)
+    with open(out, "w") as f:
+        f.write("# HBM bytes per pixel and pass of ONE call (PMC FETCH_SIZE x 2 + WRITE_SIZE, separate passes; %d pixels per call, %d calls profiled)\n" % (px, calls))
+        f.write("# whole call: %.2f B/px measured against %.1f B/px algorithmic = %.2fx\n" % (tot / px, algorithmic_b_px, tot / px / algorithmic_b_px))
+        f.write("%8s %8s %8s %7s  %s\n" % ("B/px", "read", "written", "n/call", "kernel"))
+        for b, rd, n, k in rows:
+            if b <= 0:
+                continue
+            f.write("%8.2f %8.2f %8.2f %7.1f  %s\n" % (b / px, rd / px, (b - rd) / px, n, k[:110]))
+    print("wrote", out)
+
+
 def sq(db, pattern, out, append=False):
     """SQ / TCP / TCC counters per kernel symbol matching `pattern` (regex) and launch grid: launches, average, min, max per launch."""
     import re
@@ -193,6 +216,8 @@ if __name__ == "__main__":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "pmc_step":
         pmc_step(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
+    elif sys.argv[1] == "pmc_table":
+        pmc_table(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]), sys.argv[6])
     elif sys.argv[1] == "sq":
         sq(sys.argv[2], sys.argv[3], sys.argv[4], len(sys.argv) > 5)
     else:
