@@ -319,7 +319,7 @@ __device__ __forceinline__ void lds_union(int* L, int a, int b) {
 // adds the merged sets' counts up over the LIST: no pass over the pixel map for the flatten, none for the areas, no zero fill of `area`.
 template <bool ROOTS>
 __global__ __launch_bounds__(256) void ccl_tile_kernel(const uint8_t* __restrict__ fg, uint8_t val, int* __restrict__ L, int H, int W, int tiles_x, int n_tiles,
-                                                       int* __restrict__ roots, int* __restrict__ cnt, int* __restrict__ area) {
+                                                       int* __restrict__ roots, int* __restrict__ cnt, int* __restrict__ area, int* __restrict__ colbuf = nullptr) {
     __shared__ int sl[CT_H * CT_W];
     __shared__ u64 smask[CT_H];
     __shared__ int scnt[ROOTS ? CT_H * CT_W : 1];
@@ -372,6 +372,11 @@ __global__ __launch_bounds__(256) void ccl_tile_kernel(const uint8_t* __restrict
                     }
                 }
                 L[(long long)y * W + x] = g;
+                // the tile's border columns, compactly: what the seam pass wants of this tile (seam_cols: [right-of-seam | left-of-seam][seam k][y])
+                if (colbuf) {
+                    if (lane == 0 && tx0 > 0) colbuf[(long long)(tx0 / CT_W - 1) * H + y] = g;
+                    if (lane == CT_W - 1 && tx0 + CT_W < W) colbuf[(long long)(tiles_x - 1) * H + (long long)(tx0 / CT_W) * H + y] = g;
+                }
             }
             if (ROOTS) rmv[i] = __ballot(is_root);
         }
@@ -422,7 +427,12 @@ __global__ void roots_area_merge_kernel(const int* __restrict__ L, const int* __
 }
 // unions across tile borders: vertical seams (x a multiple of 64: the run continues), horizontal seams (y a multiple of 32: one union per
 // pair of tile-clipped runs, at the first column where they overlap)
-__global__ void ccl_seam_kernel(const uint8_t* __restrict__ fg, uint8_t val, int* L, int H, int W, int tiles_x, int tiles_y) {
+// cols (round 6): the tile kernel's compact copy of its border columns -- [0, nv): the label RIGHT of seam k at row y (the right tile's first
+// column), [nv, 2 nv): left of it (the left tile's last column); -1 = not `val`.  A vertical seam then reads two coalesced ints per pixel pair instead of two
+// bytes and two labels out of four different 64-byte lines (4 B/px of HBM traffic for 3 % of the pixels: profiles/r06_postproc_nuclei_8192_bytes_per_pass.txt).
+// What a column entry holds is the pixel's tile root as the tile pass left it: an ancestor of the pixel whatever unions have happened since -- the same
+// starting point L[pixel] gives.
+__global__ void ccl_seam_kernel(const uint8_t* __restrict__ fg, uint8_t val, int* L, int H, int W, int tiles_x, int tiles_y, const int* __restrict__ cols = nullptr) {
     const unsigned sx = (unsigned)(tiles_x - 1), sy = (unsigned)(tiles_y - 1);
     const unsigned nv = sx * (unsigned)H, nh = sy * (unsigned)W;  // < 2^31 / 32
     const unsigned total = nv + nh, stride = gridDim.x * blockDim.x;
@@ -430,7 +440,12 @@ __global__ void ccl_seam_kernel(const uint8_t* __restrict__ fg, uint8_t val, int
     for (unsigned i0 = blockIdx.x * blockDim.x + threadIdx.x - lane; i0 < total; i0 += stride) {  // wave-uniform trip count (shuffles below)
         const unsigned i = i0 + lane;
         int a = -1, b = -1;
-        if (i < nv) {  // consecutive threads walk down one seam (a row-major order was 2.6x slower)
+        int ca = -1, cb = -1;  // vertical seam through the compact columns: the two roots themselves
+        if (i < nv && cols) {
+            ca = cols[i];
+            cb = cols[nv + i];
+            if (ca < 0 || cb < 0) ca = cb = -1;
+        } else if (i < nv) {  // consecutive threads walk down one seam (a row-major order was 2.6x slower)
             const unsigned k = i / (unsigned)H, y = i - k * (unsigned)H, x = (k + 1) * CT_W;
             const long long p = (long long)y * W + x;
             if (fg[p] == val && fg[p - 1] == val) {
@@ -453,9 +468,9 @@ __global__ void ccl_seam_kernel(const uint8_t* __restrict__ fg, uint8_t val, int
         // a component that crosses many seams (the background of a marker image is ONE component) would hammer one root with atomics:
         // the tile pass left every pixel pointing at its tile root, so neighbouring lanes mostly ask for the same (root, root) pair --
         // only the first lane of each run of equal pairs performs the union
-        const int ra = a >= 0 ? L[a] : -1, rb = b >= 0 ? L[b] : -2;
+        const int ra = ca >= 0 ? ca : a >= 0 ? L[a] : -1, rb = ca >= 0 ? cb : b >= 0 ? L[b] : -2;
         const int pa = __shfl_up(ra, 1), pb = __shfl_up(rb, 1);
-        if (a >= 0 && ra != rb && !(lane > 0 && pa == ra && pb == rb)) uf_union(L, ra, rb);
+        if ((a >= 0 || ca >= 0) && ra != rb && !(lane > 0 && pa == ra && pb == rb)) uf_union(L, ra, rb);
     }
 }
 static int ccl_run(const uint8_t* fg, uint8_t val, int* L, int H, int W, hipStream_t st, int* area = nullptr) {
@@ -491,7 +506,7 @@ static int ccl_run(const uint8_t* fg, uint8_t val, int* L, int H, int W, hipStre
 // roots under roots, so the nodes of the forest above the pixel level are exactly these: flattening the LIST (ccl2_flatten_roots_kernel) makes
 // L[L[p]] the set's root for every pixel p -- two loads, no pointer chase, no pass that walks 67 M background pixels up to one giant root.
 __global__ __launch_bounds__(256) void ccl2_tile_kernel(const uint8_t* __restrict__ fg, int* __restrict__ L, int H, int W, int tiles_x, int n_tiles,
-                                                        int* __restrict__ roots, int* __restrict__ cnt, int* __restrict__ area) {
+                                                        int* __restrict__ roots, int* __restrict__ cnt, int* __restrict__ area, int* __restrict__ colbuf = nullptr) {
     __shared__ int swtot[4];
     __shared__ int sl[CT_H * CT_W];
     __shared__ int scnt[CT_H * CT_W];  // FOREGROUND pixels of every tile-local set (background sets stay at 0: ccl2_drop_small_kernel relies on it)
@@ -532,9 +547,15 @@ __global__ __launch_bounds__(256) void ccl2_tile_kernel(const uint8_t* __restric
             bool is_root = false;
             if (x < W && y < H) {
                 const int root = lds_find(sl, sl[r * CT_W + lane]);
-                L[(long long)y * W + x] = (ty0 + (root >> 6)) * W + tx0 + (root & 63);
+                const int g = (ty0 + (root >> 6)) * W + tx0 + (root & 63);
+                L[(long long)y * W + x] = g;
                 is_root = root == r * CT_W + lane;
                 const u64 c = sc[r];
+                if (colbuf) {  // border columns for the seam pass (see ccl_seam_kernel): the tile root, the pixel's colour in bit 31 (indices stay below 2^31)
+                    const int gc = g | (int)(((c >> lane) & 1ull) << 31);
+                    if (lane == 0 && tx0 > 0) colbuf[(long long)(tx0 / CT_W - 1) * H + y] = gc;
+                    if (lane == CT_W - 1 && tx0 + CT_W < W) colbuf[(long long)(tiles_x - 1) * H + (long long)(tx0 / CT_W) * H + y] = gc;
+                }
                 if (((c & ss[r]) >> lane) & 1ull) {  // first pixel of a foreground run: its length (the colour bits beyond the image are 0)
                     const u64 rest = ~(c >> lane);
                     atomicAdd(&scnt[root], rest ? __ffsll((long long)rest) - 1 : 64 - lane);
@@ -567,12 +588,16 @@ __global__ __launch_bounds__(256) void ccl2_tile_kernel(const uint8_t* __restric
     }
 }
 // L[r] = root of r for every node of the forest above the pixel level (see ccl2_tile_kernel)
-__global__ void ccl2_flatten_roots_kernel(int* L, const int* __restrict__ roots, const int* __restrict__ cnt, int n_tiles, int tiles_x, int H, int W) {
+// zero (optional): an int map that is only ever read at roots (the border flags of the two-colour labelling) is cleared at the LIST's entries here -- every
+// root there will ever be is one of them -- instead of by a whole-map fill (4 B/px of a call's 82: round 6)
+__global__ void ccl2_flatten_roots_kernel(int* L, const int* __restrict__ roots, const int* __restrict__ cnt, int n_tiles, int tiles_x, int H, int W,
+                                          int* __restrict__ zero = nullptr) {
     const int lane = threadIdx.x & 63, nwaves = gridDim.x * (blockDim.x >> 6);
     for (int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < n_tiles; tile += nwaves) {
         const int c = cnt[tile], base = tile_list_base((tile % tiles_x) * CT_W, (tile / tiles_x) * CT_H, H, W);
         for (int k = lane; k < c; k += 64) {
             const int r = roots[base + k];
+            if (zero) zero[r] = 0;
             const int f = uf_find(L, r);
             if (f != r) __hip_atomic_store(&L[r], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -611,7 +636,7 @@ __device__ __forceinline__ void uf_union_relaxed(int* L, int a, int b) {
     } while (!done);
 }
 template <bool RELAXED>
-__global__ void ccl2_seam_kernel(const uint8_t* __restrict__ fg, int* L, int H, int W, int tiles_x, int tiles_y) {
+__global__ void ccl2_seam_kernel(const uint8_t* __restrict__ fg, int* L, int H, int W, int tiles_x, int tiles_y, const int* __restrict__ cols = nullptr) {
     const unsigned sx = (unsigned)(tiles_x - 1), sy = (unsigned)(tiles_y - 1);
     const unsigned nv = sx * (unsigned)H, nh = sy * (unsigned)W;
     const unsigned total = nv + nh, stride = gridDim.x * blockDim.x;
@@ -619,7 +644,14 @@ __global__ void ccl2_seam_kernel(const uint8_t* __restrict__ fg, int* L, int H, 
     for (unsigned i0 = blockIdx.x * blockDim.x + threadIdx.x - lane; i0 < total; i0 += stride) {
         const unsigned i = i0 + lane;
         int a = -1, b = -1;
-        if (i < nv) {
+        int ca = -1, cb = -1;  // vertical seam through the compact columns (two colours: bit 31)
+        if (i < nv && cols) {
+            const int va = cols[i], vb = cols[nv + i];
+            if ((va ^ vb) >= 0) {  // same colour
+                ca = va & 0x7fffffff;
+                cb = vb & 0x7fffffff;
+            }
+        } else if (i < nv) {
             const unsigned k = i / (unsigned)H, y = i - k * (unsigned)H, x = (k + 1) * CT_W;
             const long long p = (long long)y * W + x;
             if ((fg[p] != 0) == (fg[p - 1] != 0)) {
@@ -640,9 +672,9 @@ __global__ void ccl2_seam_kernel(const uint8_t* __restrict__ fg, int* L, int H, 
                 }
             }
         }
-        const int ra = a >= 0 ? L[a] : -1, rb = b >= 0 ? L[b] : -2;  // (see ccl_seam_kernel: one union per run of equal root pairs)
+        const int ra = ca >= 0 ? ca : a >= 0 ? L[a] : -1, rb = ca >= 0 ? cb : b >= 0 ? L[b] : -2;  // (see ccl_seam_kernel: one union per run of equal root pairs)
         const int pa = __shfl_up(ra, 1), pb = __shfl_up(rb, 1);
-        if (a >= 0 && ra != rb && !(lane > 0 && pa == ra && pb == rb)) {
+        if ((a >= 0 || ca >= 0) && ra != rb && !(lane > 0 && pa == ra && pb == rb)) {
             if (RELAXED) uf_union_relaxed(L, ra, rb);
             else uf_union(L, ra, rb);
         }
@@ -857,19 +889,19 @@ __global__ void apply_min_area_bits4_kernel(uint32_t* __restrict__ m4, int4* L4,
 }
 // roots: H * W ints (every tile its own range), n_roots: one int per tile
 static int markers_two_colour(uint8_t* mrk, int* L, int* area, int* border, int* roots, int* n_roots, int min_size, int H, int W, hipStream_t st,
-                              u64* root_bits = nullptr, bool wide = false) {
+                              u64* root_bits = nullptr, bool wide = false, int* colbuf = nullptr) {
     const int n = H * W;
     const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H, n_tiles = tiles_x * tiles_y;
     const unsigned g = grid_for(n);
-    // (area: written by the tile kernel at every tile-local root, read at roots only -- no zero fill)
-    if (hipMemsetAsync(border, 0, (size_t)n * 4, st) != hipSuccess) return cerb_set_error("memset failed");
-    hipLaunchKernelGGL(ccl2_tile_kernel, dim3(n_tiles < 256 * 16 ? n_tiles : 256 * 16), dim3(256), 0, st, mrk, L, H, W, tiles_x, n_tiles, roots, n_roots, area);
+    // (area: written by the tile kernel at every tile-local root, read at roots only -- no zero fill; border: read at roots only as well, cleared at the
+    //  root list's entries by the first flatten pass below)
+    hipLaunchKernelGGL(ccl2_tile_kernel, dim3(n_tiles < 256 * 16 ? n_tiles : 256 * 16), dim3(256), 0, st, mrk, L, H, W, tiles_x, n_tiles, roots, n_roots, area, colbuf);
     const long long seams = (long long)(tiles_x - 1) * H + (long long)(tiles_y - 1) * W;
     static const bool seam_relaxed = cerb_dev_getenv("CERB_PP_SEAM_STRICT") == nullptr;
-    if (seams > 0) hipLaunchKernelGGL(seam_relaxed ? ccl2_seam_kernel<true> : ccl2_seam_kernel<false>, dim3(grid_for(seams)), dim3(256), 0, st, mrk, L, H, W, tiles_x, tiles_y);
+    if (seams > 0) hipLaunchKernelGGL(seam_relaxed ? ccl2_seam_kernel<true> : ccl2_seam_kernel<false>, dim3(grid_for(seams)), dim3(256), 0, st, mrk, L, H, W, tiles_x, tiles_y, (const int*)colbuf);
     const unsigned gl = nblk(n_tiles, 4) < 4096 ? nblk(n_tiles, 4) : 4096;  // one wave per tile
-    auto flatten_roots = [&]() { hipLaunchKernelGGL(ccl2_flatten_roots_kernel, dim3(gl), dim3(256), 0, st, L, (const int*)roots, (const int*)n_roots, n_tiles, tiles_x, H, W); };
-    flatten_roots();
+    auto flatten_roots = [&]() { hipLaunchKernelGGL(ccl2_flatten_roots_kernel, dim3(gl), dim3(256), 0, st, L, (const int*)roots, (const int*)n_roots, n_tiles, tiles_x, H, W, (int*)nullptr); };
+    hipLaunchKernelGGL(ccl2_flatten_roots_kernel, dim3(gl), dim3(256), 0, st, L, (const int*)roots, (const int*)n_roots, n_tiles, tiles_x, H, W, border);
     hipLaunchKernelGGL(roots_area_merge_kernel, dim3(gl), dim3(256), 0, st, (const int*)L, (const int*)roots, (const int*)n_roots, n_tiles, tiles_x, H, W, area);
     wide = wide && W % 4 == 0;
     const unsigned g4 = grid_for(n / 4);
@@ -2485,6 +2517,10 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
         hipLaunchKernelGGL(nuc_threshold_kernel, dim3(g), dim3(256), 0, st, inst, row_stride, pix_stride, H, W, msk0, mrk, small);
         hipLaunchKernelGGL(erode_cross_kernel, dim3(g), dim3(256), 0, st, msk0, msk, H, W);
     }
+    // round 6: the tile labellings leave their border columns in a compact array (2 x (tiles_x - 1) x H ints: wl4 is free until the flood work lists) and the
+    // seam passes read their vertical seams from it -- CERB_PP_SEAM_COLUMNS=0 (developers' build) keeps the strided reads of the maps
+    static const bool seam_compact = cerb_dev_getenv("CERB_PP_SEAM_COLUMNS") == nullptr || atoi(cerb_dev_getenv("CERB_PP_SEAM_COLUMNS")) != 0;
+    int* seam_cols = seam_compact ? wl4 : nullptr;
     static const bool narrow = cerb_dev_getenv("CERB_PP_ONE_PIXEL_THREADS") != nullptr;  // developer A/B: the one-pixel-per-thread passes
     const bool wide = !pixel_scans && !narrow && W % 4 == 0 && (uintptr_t)labels_out % 16 == 0;  // (the workspace arrays are 256-byte aligned)
     if (wide) {  // tile labelling with the root list + per-set counts, flatten and areas over the LIST, then one pass: min-area, root of every pixel, bitmap
@@ -2492,9 +2528,9 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
         int* n_rootsA = tcnt;     // roots per tile
         const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H, n_tiles = tiles_x * tiles_y;
         hipLaunchKernelGGL(ccl_tile_kernel<true>, dim3(n_tiles < 256 * 16 ? n_tiles : 256 * 16), dim3(256), 0, st, (const uint8_t*)msk, (uint8_t)1, LA, H, W, tiles_x, n_tiles,
-                           rootsA, n_rootsA, areaA);
+                           rootsA, n_rootsA, areaA, seam_cols);
         const long long seams = (long long)(tiles_x - 1) * H + (long long)(tiles_y - 1) * W;
-        if (seams > 0) hipLaunchKernelGGL(ccl_seam_kernel, dim3(grid_for(seams)), dim3(256), 0, st, (const uint8_t*)msk, (uint8_t)1, LA, H, W, tiles_x, tiles_y);
+        if (seams > 0) hipLaunchKernelGGL(ccl_seam_kernel, dim3(grid_for(seams)), dim3(256), 0, st, (const uint8_t*)msk, (uint8_t)1, LA, H, W, tiles_x, tiles_y, (const int*)seam_cols);
         const unsigned gl = nblk(n_tiles, 4) < 4096 ? nblk(n_tiles, 4) : 4096;
         hipLaunchKernelGGL(ccl2_flatten_roots_kernel, dim3(gl), dim3(256), 0, st, LA, (const int*)rootsA, (const int*)n_rootsA, n_tiles, tiles_x, H, W);
         hipLaunchKernelGGL(roots_area_merge_kernel, dim3(gl), dim3(256), 0, st, (const int*)LA, (const int*)rootsA, (const int*)n_rootsA, n_tiles, tiles_x, H, W, areaA);
@@ -2510,7 +2546,7 @@ extern "C" int cerb_postproc_nuclei(const float* inst, int H, int W, long long r
     static const bool three_pass = cerb_dev_getenv("CERB_PP_THREE_LABELLINGS") != nullptr;  // developer A/B: round 4's three separate labellings
     if (!three_pass) {
         // (rank: free until the scan below, serves as the border flags; marker: free until the flood work lists, holds the root list)
-        if (markers_two_colour(mrk, LB, areaB, rank, marker, tcnt, 4, H, W, st, pixel_scans ? nullptr : bitsB, wide)) return 1;
+        if (markers_two_colour(mrk, LB, areaB, rank, marker, tcnt, 4, H, W, st, pixel_scans ? nullptr : bitsB, wide, seam_cols)) return 1;
     } else {
         PP_OK(hipMemsetAsync(areaB, 0, (size_t)n * 4, st));
         if (ccl_run(mrk, 1, LB, H, W, st, areaB)) return 1;
