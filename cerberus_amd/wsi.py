@@ -512,8 +512,24 @@ class DatWriter(object):
         self = cls.__new__(cls)
         self.path, self._pid, self._thr, self._err = path, None, None, None
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        # the hand-over file lives in RAM when the host has a tmpfs with room for it (a 40000^2 slide's arrays: ~0.3 GB; 0.17 s on the output disk, 0.05 s in
+        # /dev/shm -- time the parent spends between two slides); CERB_DAT_TMP names another directory, a failed write falls back to the output directory
         src = path + ".parts.npz"
-        inst_info.save_parts(src, parts, meta)
+        nbytes = sum(int(getattr(a, "nbytes", 0)) for p_ in parts for a in p_ if hasattr(a, "nbytes"))
+        tmpdir = os.environ.get("CERB_DAT_TMP", "/dev/shm")
+        cand = None
+        try:
+            st = os.statvfs(tmpdir)
+            if os.path.isdir(tmpdir) and os.access(tmpdir, os.W_OK) and st.f_bavail * st.f_frsize > 2 * nbytes + (64 << 20):
+                cand = os.path.join(tmpdir, "cerb_parts_%d_%s.npz" % (os.getpid(), os.path.basename(path)))
+                inst_info.save_parts(cand, parts, meta)
+                src = cand
+        except OSError:
+            src = path + ".parts.npz"
+            if cand and os.path.exists(cand):
+                os.remove(cand)
+        if src == path + ".parts.npz":
+            inst_info.save_parts(src, parts, meta)
         xtra = ""
         if extra:
             xtra = path + ".extra.pkl"
