@@ -476,7 +476,8 @@ class NetDesc(torch.nn.Module):
             out.append((nm.value.decode(), kn.value.decode(), fl.value, ms.value))
         return out
 
-    LOGIT_SATURATION = 100.0  # largest |logit| the F(4x4,3x3) default is held to the 1e-4 contract for (fixtures at 4 .. 17, 30 and 80: DESIGN.md par.5; the reference's default init: 650 .. 2200)
+    # (CERB_LOGIT_SATURATION overrides the bar: an operator who wants the guard tighter -- or a test that wants it to fire)
+    LOGIT_SATURATION = float(__import__("os").environ.get("CERB_LOGIT_SATURATION", "100.0"))  # largest |logit| the F(4x4,3x3) default is held to the 1e-4 contract for (fixtures at 4 .. 17, 30 and 80: DESIGN.md par.5; the reference's default init: 650 .. 2200)
 
     def prepare(self, device=None):
         """Decide the 3x3 convolution algorithm from the WEIGHTS, once per parameter version, at LOAD time (not inside the first

@@ -663,3 +663,29 @@ def test_bench_slide_20000_labels_the_canvases_its_own_inference_wrote():
         assert one["postproc"][t]["n_inst"] == three["postproc"][t]["n_inst"], (t, one["postproc"][t], three["postproc"][t])
     assert one["postproc"]["Nuclei"]["n_inst"] > 10000, one["postproc"]["Nuclei"]
     assert one["config"]["precision"]["logit_guard"]["batches_above"] == 0
+
+
+def test_run_infer_wsi_logit_guard_counts_and_reruns(tmp_path):
+    """The slide driver's use of the data-aware guard (cerb_forward_io.logit_absmax): with the bar lowered under this model's logits (CERB_LOGIT_SATURATION=5,
+    the probe switched off so that the handle stays on F(4x4)) every batch is counted in the slide's log, and CERB_LOGIT_GUARD=rerun re-runs them on
+    F(2x2) -- the run completes, says so, and writes the same class maps up to rounding-sized ties."""
+    spec = tmp_path / "slides"
+    spec.mkdir()
+    (spec / "s1.txt").write_text("synthetic:900x1100:5")
+    base = [sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--synthetic", "--input_dir=%s" % spec, "--wsi_file_ext=.txt", "--batch_size=6",
+            "--patch_input_shape=256", "--patch_output_shape=256", "--save_label_maps"]
+    outs = {}
+    for mode, extra in (("plain", {}), ("count", {"CERB_LOGIT_SATURATION": "5", "CERB_AUTO_PRECISION": "0"}),
+                        ("rerun", {"CERB_LOGIT_SATURATION": "5", "CERB_AUTO_PRECISION": "0", "CERB_LOGIT_GUARD": "rerun"})):
+        out, logd = tmp_path / mode, tmp_path / (mode + "_log")
+        r = subprocess.run(base + ["--output_dir=%s" % out, "--logging_dir=%s" % logd], capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, **extra))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = (out, "".join(open(os.path.join(str(logd), f)).read() for f in os.listdir(str(logd))))
+    assert "Logit guard: 0 of " in outs["plain"][1]
+    assert "Logit guard: 0 of " not in outs["count"][1] and "above 5" in outs["count"][1] and "re-run" not in outs["count"][1]
+    assert "flagged batches re-run on F(2x2,3x3)" in outs["rerun"][1]
+    za, zb, zc = (np.load(str(outs[m][0] / "s1.npz")) for m in ("plain", "count", "rerun"))
+    for k in za.files:
+        if k.startswith("type_") or k == "pclass":
+            assert np.array_equal(za[k], zb[k]), k                      # counting changes nothing
+            assert (za[k] != zc[k]).mean() < 1e-3, k                    # F(2x2) against F(4x4): argmax flips only at rounding-sized ties
