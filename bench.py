@@ -16,7 +16,13 @@ A random-weight network paints slide-sized blobs, so the labelling leg reads see
 size instead (600 nuclei / Mpx of radius 4-9 px, glands of 25-150 px; SURVEY.md par.8d cfg 3): same kernels, same band
 protocol, realistic instance counts (~1 M nuclei).  `value` = slide pixels / wall time of that whole region (max over ranks);
 `config.inference_Mpx_s` is the same slide over the K inference steps alone.
-`--mode batch`: the inner loop alone on 32 resident tiles (BASELINE.json configs[1]); `--mode train`: configs[4].
+`--mode batch`: the inner loop alone on 32 resident tiles (BASELINE.json configs[1]); `--mode train`: configs[4]; `--mode ingest`: a JPEG-tiled
+pyramidal TIFF on disk through reader -> decode pool -> upload-ahead -> inference, beside the resident figure.
+Beside `value` the default line carries (all outside the timed region): `config.conv_algo` / `config.precision` (the 3x3 algorithm the headline ran on, the
+calibration measurement, what the head kernels' max-|logit| guard saw over the job's batches), `config.other_conv_algos` (the same slide's inference on
+F(2x2) and on the direct kernels), `dat` (instance tables + contours + the .dat writer; with several ranks `dat.per_rank_arrays`: tables + contours where
+the instances live, compact arrays gathered, bytes into rank 0 either way), `ref_tiling`, `ingest` (a 12288^2 TIFF), `batch_step`, `train_step`,
+`dice_vs_reference`, `cpu_baseline`.  `--tail-from-inference`: the tail labels the canvases the timed inference wrote.
 Rank 0 prints ONE JSON line.
 """
 import argparse
