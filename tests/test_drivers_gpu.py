@@ -525,11 +525,11 @@ def test_slide_streamed_in_sub_bands_equals_the_resident_run(manager):
 def _stream_slide(H, W):
     from cerberus_amd import synth_maps
 
-    nuc, gl = synth_maps.nuclei_maps(H, W, 5, 1500.0), synth_maps.blob_maps(H, W, 6, 80, 24.0, 50.0, rim=4.0, sharp=1.0)
+    nuc, gl = synth_maps.nuclei_maps(H, W, 5, 1500.0), synth_maps.blob_maps(H, W, 6, max(4, int(round(80 * H * W / 3.9e6))), 24.0, 50.0, rim=4.0, sharp=1.0)
     return torch.from_numpy(np.stack([nuc[..., 0], nuc[..., 1], gl[..., 0]], -1).clip(0, 1) * 255.0).to(torch.uint8)
 
 
-def _gpu_stream_worker(rank, world, port, subs, ret):
+def _gpu_stream_worker(rank, world, port, subs, ret, H=3000, W=1300):
     import os
 
     import torch.distributed as dist
@@ -542,7 +542,6 @@ def _gpu_stream_worker(rank, world, port, subs, ret):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     hd = HostStagedDist(dist)
-    H, W = 3000, 1300
     slide = _stream_slide(H, W).cuda()
     calls, parts = [], []
 
@@ -563,6 +562,10 @@ def _gpu_stream_worker(rank, world, port, subs, ret):
 
 @pytest.mark.parametrize("world,subs", [(2, (3, 2)), (3, (2, 1, 2))])
 def test_slide_streamed_in_sub_bands_on_several_ranks_equals_the_resident_run(world, subs):
+    _check_streamed_ranks(world, subs, 3000, 1300)
+
+
+def _check_streamed_ranks(world, subs, H, W):
     """cerberus_amd.stream_bands on N ranks: every rank walks its own band in sequential sub-bands -- one early halo exchange
     at the rank boundaries (a rank infers its last patch row ahead for the neighbour below), ids offset after the walks, the instances a rank's
     first sub-band sees but the rank above owns named from the border all-gather -- and the ranks' rows, stacked, are the resident ONE-rank run's
@@ -584,7 +587,7 @@ def test_slide_streamed_in_sub_bands_on_several_ranks_equals_the_resident_run(wo
     s.close()
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    procs = [ctx.Process(target=_gpu_stream_worker, args=(r, world, port, subs, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_gpu_stream_worker, args=(r, world, port, subs, ret, H, W)) for r in range(world)]
     for p in procs:
         p.start()
     got, t_end = [], time.time() + 500
@@ -601,12 +604,11 @@ def test_slide_streamed_in_sub_bands_on_several_ranks_equals_the_resident_run(wo
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    H, W = 3000, 1300
     slide = _stream_slide(H, W).cuda()
     run = WSIRunner(_PixelNet(), (H, W), 256, 256, batch_size=4)
     run.infer_band(slide, 0)
     want, want_info, want_small = postprocess_bands_and_gather(run, H, W, 0, 1, None, margin=256, guard=16)
-    assert int(want["Nuclei"].max()) > 2000 and int(want["Gland"].max()) > 10
+    assert int(want["Nuclei"].max()) > 0.0004 * H * W and int(want["Gland"].max()) >= 3
     inst, small, infos = got[0][1], got[0][2], [g[3] for g in got]
     for k in want_small:
         assert np.array_equal(small[k], want_small[k].cpu().numpy()), k
@@ -616,7 +618,7 @@ def test_slide_streamed_in_sub_bands_on_several_ranks_equals_the_resident_run(wo
         assert np.array_equal(inst[t], want[t].cpu().numpy()), t
     have, ref = _entries(got[0][4]), _entries(collect_wsi_inst_arrays(want, want_small, (H, W)))
     for t in want:
-        assert have[t] == ref[t] and len(ref[t]) > 10, (t, len(have[t]), len(ref[t]))
+        assert have[t] == ref[t] and len(ref[t]) >= 3, (t, len(have[t]), len(ref[t]))
     assert np.array_equal(got[0][6]["Patch-Class@0.25"], pclass_tissue_map(want_small["Patch-Class"]).cpu().numpy())
     # every rank read its sub-bands once, plus -- all but the last -- the patch row it infers ahead for the neighbour below
     assert [g[5] for g in got] == [subs[r] + (1 if r < world - 1 else 0) for r in range(world)]
