@@ -175,6 +175,14 @@ def test_bench_contract_single_and_two_ranks(tmp_path):
     assert "head_group" in kern and abs(sum(r["share"] for r in one["kernels"]) - 1.0) < 0.01
     for t in ("Nuclei", "Gland", "Lumen"):
         assert one["postproc"][t]["n_inst"] > 10 and one["postproc"][t]["n_truncated"] == 0, one["postproc"]
+    # round 6: the line names the algorithm the headline ran on, what the load-time probe and the head kernels' guard saw, and carries the other algorithms' figures
+    cfg = one["config"]
+    assert cfg["conv_algo"] == 6 and cfg["precision"]["probed"] and not cfg["precision"]["auto"] and 1.0 < cfg["precision"]["calibration_logit_absmax"] < 100.0
+    assert cfg["precision"]["logit_guard"]["batches"] > 0 and cfg["precision"]["logit_guard"]["batches_above"] == 0
+    assert 1.0 < cfg["precision"]["logit_guard"]["largest_abs_logit"] < 100.0
+    oa = cfg["other_conv_algos"]
+    assert "error" not in oa and 0 < oa["0"]["inference_Mpx_s"] < oa["1"]["inference_Mpx_s"] and oa["0"]["batch_step_ms"] > oa["1"]["batch_step_ms"] > 0, oa
+    assert "error" not in one["ingest"] and one["ingest"]["best"]["of_resident"] > 0.3, one["ingest"]
     two = _bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
                   "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--slide", "3072"])
     assert two["n_gpus"] == 2 and "cpu_baseline" not in two and two["scaling"] == "strong"
@@ -689,3 +697,16 @@ def test_run_infer_wsi_logit_guard_counts_and_reruns(tmp_path):
         if k.startswith("type_") or k == "pclass":
             assert np.array_equal(za[k], zb[k]), k                      # counting changes nothing
             assert (za[k] != zc[k]).mean() < 1e-3, k                    # F(2x2) against F(4x4): argmax flips only at rounding-sized ties
+
+
+def test_bench_ingest_mode_file_fed_run_equals_resident():
+    """`bench.py --mode ingest` on a small slide: a JPEG-tiled pyramidal TIFF written with reader.write_tiled_tiff goes through reader ->
+    decode pool -> SlabUploader's producer thread -> WSIRunner for every decode-thread count and with / without the upload-ahead thread; the leg itself asserts
+    that each file-fed run writes checksum-identical canvases to the resident run of the same pixels and that the pixels do not depend on the thread count."""
+    line = _bench([sys.executable, "bench.py", "--mode", "ingest", "--slide", "3072", "--streams", "1"], timeout=900)
+    ing = line["ingest"]
+    assert line["unit"] == "Mpx/s" and ing["slide"] == [3072, 3072] and ing["file"]["tiles"] == 144
+    assert len(ing["decode"]["sweep"]) >= 3 and all(p_["Mpx_s"] > 10 for p_ in ing["decode"]["sweep"])
+    modes = {(e["decode_threads"], e["upload_ahead"]) for e in ing["end_to_end_from_file"]}
+    assert any(not a for _, a in modes) and sum(1 for _, a in modes if a) >= 3
+    assert ing["best"]["of_resident"] > 0.3 and line["value"] == ing["best"]["Mpx_s"]
