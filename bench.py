@@ -880,6 +880,8 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
             arr_bytes = prof2.get("parts_gather", {}).get("bytes", 0) + prof2.get("root_gather", {}).get("bytes", 0)
             map_bytes = prof.get("root_gather", {}).get("bytes", 0)
             per_rank = {"tail_with_array_hand_over_s": round(adt, 4), "tables_and_contours_s_slowest_rank": round(float(t.item()), 4),
+                        # the whole job if the tail ended with what run_infer_wsi.py hands to rank 0 (arrays) instead of the map stitch `value` keeps timing
+                        "whole_job_Mpx_s_with_array_hand_over": round(H * W / (phase["inference_s"] + adt) / 1e6, 3),
                         "bytes_into_rank0": {"instance_arrays_and_quarter_map": int(arr_bytes), "label_bands_and_class_maps": int(map_bytes),
                                              "ratio": round(map_bytes / max(1, arr_bytes), 1)},
                         "entries": {p_[0]: int(((p_[1][:, 0] > 0) & (p_[2] >= 3)).sum()) for p_ in parts2}}
