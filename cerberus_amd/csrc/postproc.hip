@@ -2902,12 +2902,46 @@ extern "C" int cerb_label_mask(const uint8_t* mask, long long row_stride, int H,
 // [0] is the outer border of the piece whose first pixel comes LAST in raster order (loader/postproc.py:29-33 takes [0][0]).
 // One union-find pass over "same id, 8-neighbour" links; start[id-1] = max over the pieces of their first pixel.
 // =================================================================================================================
-__global__ void cc8_init_kernel(const int* __restrict__ lab, long long ls, int H, int W, int* __restrict__ L) {
-    const long long n = (long long)H * W;
-    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
-        L[p] = lab[(p / W) * ls + (p % W)] > 0 ? (int)p : -1;
+// IDX = int for maps below 2^31 pixels (4 bytes of workspace per pixel), long long above (8): a 0.5-mpp scan of a large section is 60000 x 50000.
+template <typename IDX>
+__device__ __forceinline__ IDX uf_find_t(const IDX* L, IDX x) {
+    IDX p = __hip_atomic_load(&L[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != x) {
+        x = p;
+        p = __hip_atomic_load(&L[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return x;
 }
-__global__ void cc8_merge_kernel(const int* __restrict__ lab, long long ls, int H, int W, int* L) {
+template <typename IDX>
+__device__ __forceinline__ void uf_union_t(IDX* L, IDX a, IDX b) {
+    bool done;
+    do {
+        a = uf_find_t<IDX>(L, a);
+        b = uf_find_t<IDX>(L, b);
+        if (a < b) {
+            const IDX old = atomicMin(&L[b], a);
+            done = (old == b);
+            b = old;
+        } else if (b < a) {
+            const IDX old = atomicMin(&L[a], b);
+            done = (old == a);
+            a = old;
+        } else
+            done = true;
+    } while (!done);
+}
+template <typename IDX>
+__global__ void cc8_init_kernel(const int* __restrict__ lab, long long ls, int H, int W, IDX* __restrict__ L) {
+    const long long n = (long long)H * W;
+    const double invW = 1.0 / (double)W;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        int y, x;
+        pix_yx(p, W, invW, y, x);
+        L[p] = lab[y * ls + x] > 0 ? (IDX)p : (IDX)-1;
+    }
+}
+template <typename IDX>
+__global__ void cc8_merge_kernel(const int* __restrict__ lab, long long ls, int H, int W, IDX* L) {
     const long long n = (long long)H * W;
     const double invW = 1.0 / (double)W;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
@@ -2915,41 +2949,62 @@ __global__ void cc8_merge_kernel(const int* __restrict__ lab, long long ls, int 
         pix_yx(p, W, invW, y, x);
         const int id = lab[y * ls + x];
         if (id <= 0) continue;
-        if (x > 0 && lab[y * ls + x - 1] == id) uf_union(L, (int)p, (int)p - 1);
+        if (x > 0 && lab[y * ls + x - 1] == id) uf_union_t<IDX>(L, (IDX)p, (IDX)(p - 1));
         if (y > 0) {
             const int* up = lab + (y - 1) * ls;
-            if (up[x] == id) uf_union(L, (int)p, (int)p - W);
+            if (up[x] == id) uf_union_t<IDX>(L, (IDX)p, (IDX)(p - W));
             else {  // the diagonal links only matter when the pixel above does not already join all three
-                if (x > 0 && up[x - 1] == id) uf_union(L, (int)p, (int)p - W - 1);
-                if (x + 1 < W && up[x + 1] == id) uf_union(L, (int)p, (int)p - W + 1);
+                if (x > 0 && up[x - 1] == id) uf_union_t<IDX>(L, (IDX)p, (IDX)(p - W - 1));
+                if (x + 1 < W && up[x + 1] == id) uf_union_t<IDX>(L, (IDX)p, (IDX)(p - W + 1));
             }
         }
     }
 }
-__global__ void cc8_last_root_kernel(const int* __restrict__ lab, long long ls, int H, int W, const int* __restrict__ L, int n_inst,
+template <typename IDX>
+__global__ void cc8_flatten_kernel(IDX* L, long long n) {
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        if (L[p] < 0) continue;
+        L[p] = uf_find_t<IDX>(L, (IDX)p);
+    }
+}
+template <typename IDX>
+__global__ void cc8_last_root_kernel(const int* __restrict__ lab, long long ls, int H, int W, const IDX* __restrict__ L, int n_inst,
                                      long long* __restrict__ start) {
     const long long n = (long long)H * W;
+    const double invW = 1.0 / (double)W;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
-        if (L[p] != (int)p) continue;
-        const int id = lab[(p / W) * ls + (p % W)];
+        if (L[p] != (IDX)p) continue;
+        int y, x;
+        pix_yx(p, W, invW, y, x);
+        const int id = lab[y * ls + x];
         if (id >= 1 && id <= n_inst) atomicMax((unsigned long long*)&start[id - 1], (unsigned long long)p);
     }
+}
+template <typename IDX>
+static void contour_start_launch(const int32_t* labels, long long ls, int H, int W, int n_inst, long long* start, void* ws, hipStream_t st) {
+    const long long n = (long long)H * W;
+    IDX* L = (IDX*)ws;
+    const unsigned g = grid_for(n);
+    hipLaunchKernelGGL(cc8_init_kernel<IDX>, dim3(g), dim3(256), 0, st, labels, ls, H, W, L);
+    hipLaunchKernelGGL(cc8_merge_kernel<IDX>, dim3(g), dim3(256), 0, st, labels, ls, H, W, L);
+    hipLaunchKernelGGL(cc8_flatten_kernel<IDX>, dim3(g), dim3(256), 0, st, L, n);
+    hipLaunchKernelGGL(cc8_last_root_kernel<IDX>, dim3(g), dim3(256), 0, st, labels, ls, H, W, (const IDX*)L, n_inst, start);
+}
+extern "C" size_t cerb_inst_contour_start_workspace_bytes(int H, int W) {
+    const long long n = (long long)(H > 0 ? H : 0) * (W > 0 ? W : 0);
+    return (size_t)n * (n >= (1ll << 31) ? 8 : 4);
 }
 extern "C" int cerb_inst_contour_start(const int32_t* labels, long long lab_row_stride, int H, int W, int n_inst, long long* start, void* ws,
                                        size_t ws_bytes, void* hip_stream) {
     if (!labels || !start || !ws || H <= 0 || W <= 0 || n_inst < 0) return cerb_set_error("cerb_inst_contour_start: bad arguments");
-    if ((long long)H * W >= (1ll << 31)) return cerb_set_error("cerb_inst_contour_start: map too large (H*W must be < 2^31)");
-    if (ws_bytes < (size_t)H * W * 4) return cerb_set_error("cerb_inst_contour_start: workspace too small (4 bytes per pixel)");
+    const bool wide = (long long)H * W >= (1ll << 31);
+    if (ws_bytes < cerb_inst_contour_start_workspace_bytes(H, W))
+        return cerb_set_error("cerb_inst_contour_start: workspace too small (4 bytes per pixel, 8 for maps of 2^31 pixels and more)");
     if (n_inst == 0) return 0;
     hipStream_t st = (hipStream_t)hip_stream;
-    const int n = H * W;
-    int* L = (int*)ws;
-    const unsigned g = grid_for(n);
     PP_OK(hipMemsetAsync(start, 0, (size_t)n_inst * 8, st));
-    hipLaunchKernelGGL(cc8_init_kernel, dim3(g), dim3(256), 0, st, labels, lab_row_stride, H, W, L);
-    hipLaunchKernelGGL(cc8_merge_kernel, dim3(g), dim3(256), 0, st, labels, lab_row_stride, H, W, L);
-    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(g), dim3(256), 0, st, L, n);
-    hipLaunchKernelGGL(cc8_last_root_kernel, dim3(g), dim3(256), 0, st, labels, lab_row_stride, H, W, (const int*)L, n_inst, start);
+    if (wide) contour_start_launch<long long>(labels, lab_row_stride, H, W, n_inst, start, ws, st);
+    else contour_start_launch<int>(labels, lab_row_stride, H, W, n_inst, start, ws, st);
     KCHECK();
     return 0;
 }

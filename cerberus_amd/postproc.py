@@ -27,6 +27,10 @@ def _workspace(device, h, w, nbytes=None):
     key = (device.index if device.index is not None else torch.cuda.current_device())
     t = _ws_cache.get(key)
     if t is None or t.numel() < need:
+        # growing: the old block goes back to the allocator BEFORE the new one is asked for -- held through the assignment, a 80 GiB workspace
+        # and its 88 GiB successor were both alive at the peak (a 98304^2 slide walked in sub-bands died there with 27 GiB free)
+        _ws_cache.pop(key, None)
+        t = None
         _ws_cache[key] = t = torch.empty(need, dtype=torch.uint8, device=device)
     return t
 
@@ -140,8 +144,9 @@ def inst_contours_device(inst_map, table):
     h, w = int(inst_map.shape[0]), int(inst_map.shape[1])
     stream = torch.cuda.current_stream(inst_map.device).cuda_stream
     counts = torch.empty(n, dtype=torch.int32, device=inst_map.device)
-    ws = _workspace(inst_map.device, h, w, nbytes=4 * h * w + 256)  # cerb_inst_contour_start: one int32 union-find label per pixel (not the 96 B / px
-    #                                                                   of a labelling call: a 40000^2 slide map needs 6.4 GB here, not 143 GiB)
+    # cerb_inst_contour_start: one union-find label per pixel (int32; int64 for maps of 2^31 pixels and more) -- not the 96 B / px of a labelling
+    # call: a 40000^2 slide map needs 6.4 GB here, not 143 GiB
+    ws = _workspace(inst_map.device, h, w, nbytes=int(L.cerb_inst_contour_start_workspace_bytes(h, w)) + 256)
     table = table.clone()  # column 7 becomes the start pixel of the border findContours lists first (several-piece instances)
     start = torch.empty(n, dtype=torch.int64, device=inst_map.device)
     with torch.cuda.device(inst_map.device):

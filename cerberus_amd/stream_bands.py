@@ -26,6 +26,7 @@ from .wsi import SlideGeometry, WSIRunner, band_partition, downsample2_inst, hal
 LABEL_WS_BYTES_PX = 96      # cerb_pp_workspace_bytes
 LABEL_BYTES_PX = 6          # nuclei int32 at full resolution + gland / lumen int32 at half resolution
 RESERVE_BYTES = 2 << 30     # allocator slack, tables, RCCL channels
+STREAM_HEADROOM = 0.10      # a streamed plan takes the fewest sub-bands that leave this share of the budget unspent (when any does)
 
 
 def canvas_bytes_per_px(net):
@@ -95,7 +96,7 @@ def plan_slide(net, slide_hw, win, out, batch, rank=0, world=1, want_twin=True, 
     rows = r1 - r0
     min_rows = max(1, -(-2 * margin // geo.out))  # a sub-band is at least two halo margins tall (shard_postproc.local_band_count's invariant)
     tail = (-(-margin // geo.out)) * geo.out * cw * cb_all if world > 1 else 0  # the rows inferred ahead for the neighbour below (released after the exchange)
-    best = None
+    best = tight = None
     for S in range(2, rows // min_rows + 1):
         rs = -(-rows // S)
         if rs < min_rows:
@@ -105,8 +106,14 @@ def plan_slide(net, slide_hw, win, out, batch, rank=0, world=1, want_twin=True, 
         strips = 2 * 3 * margin * cw * 8 + halo * (cb_inst + 4)
         need = sub_slab + 2 * sub_px * cb_all + tail + px * ((cb_all - cb_inst) + LABEL_BYTES_PX) + LABEL_WS_BYTES_PX * (sub_px + 2 * margin * cw) + 2 * sub_px * 4 + strips + fwd + RESERVE_BYTES
         best = need if best is None else min(best, need)
-        if need <= budget:
+        if need <= budget and tight is None:
+            tight = SlidePlan(mode="streamed", sub_bands=S, twin=False, need=need, budget=budget, resident_need=resident)
+        # the fewest sub-bands that leave STREAM_HEADROOM of the budget free: the price is an estimate and the allocator fragments -- more, thinner
+        # sub-bands cost a few re-read context rows each, a plan that fits to the last GB costs the run (S = 11 for a 98304^2 slide priced 303 of 307 GB)
+        if need <= budget * (1.0 - STREAM_HEADROOM):
             return SlidePlan(mode="streamed", sub_bands=S, twin=False, need=need, budget=budget, resident_need=resident)
+    if tight is not None:
+        return tight
     raise ValueError(why + "; streamed in sub-bands it still needs %.1f GB (class canvases + label maps stay resident: %.1f GB)" % (
         (best or 0) / 1e9, px * ((cb_all - cb_inst) + LABEL_BYTES_PX) / 1e9))
 

@@ -214,9 +214,11 @@ int cerb_inst_table(const int32_t* labels, long long lab_row_stride, const uint8
  *   cerb_inst_contour_points -> points[2*(offsets[i] + k)] = x, [.. + 1] = y of point k; offsets = exclusive scan of counts (int64).
  * cerb_inst_contour_start -> start[i] = y*w + x of the pixel whose border findContours returns FIRST: OpenCV lists top-level
  *   contours most-recently-found first, so [0][0] belongs to the 8-connected piece whose first pixel comes last in raster
- *   order (one union-find pass over the label map; ws >= 4*h*w bytes).  Not modelled: a piece lying inside a HOLE of another
+ *   order (one union-find pass over the label map; ws >= cerb_inst_contour_start_workspace_bytes(h, w) = 4 bytes per pixel,
+ *   8 for maps of 2^31 pixels and more -- a 0.5-mpp scan of 60000 x 50000 is one).  Not modelled: a piece lying inside a HOLE of another
  *   piece of the same id is not a top-level contour in RETR_TREE and would be skipped by OpenCV.
  * OpenCV is not installed in this image: restated from the published algorithm, not pinned against the library. */
+size_t cerb_inst_contour_start_workspace_bytes(int h, int w);
 int cerb_inst_contour_start(const int32_t* labels, long long lab_row_stride, int h, int w, int n_inst, long long* start,
                             void* ws, size_t ws_bytes, void* hip_stream);
 int cerb_inst_contour_count(const int32_t* labels, long long lab_row_stride, int h, int w, int n_inst, const long long* table,

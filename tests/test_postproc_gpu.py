@@ -269,6 +269,41 @@ def test_contour_of_an_instance_in_several_pieces():
     assert got[3]["contour"].tolist() == [[50, 52], [50, 57], [56, 57], [56, 52]]
 
 
+def test_instance_dictionary_of_a_label_map_with_more_than_2_31_pixels():
+    """A 0.5-mpp scan of a large section (60000 x 50000) is a label map past int32 pixel indices: cerb_inst_table, cerb_inst_contour_start (its
+    union-find takes int64 labels there, 8 bytes of workspace per pixel) and the border following must give, for instances planted at the map's far
+    end (every pixel index > 2^31), exactly the entries they give for the same instances on a small map -- shifted."""
+    from cerberus_amd.postproc import get_inst_info_dict
+
+    L = np.zeros((60, 70), np.int32)
+    L[2:12, 3:15] = 1       # instance 1 in three pieces: the last one found is the one reported
+    L[20:33, 40:60] = 1
+    L[33:40, 60:66] = 1
+    L[45:50, 5:30] = 1
+    L[15:30, 5:20] = 2      # one piece with a hole
+    L[20:25, 10:15] = 0
+    L[52:58, 40:44] = 3     # two pieces on the same rows
+    L[52:58, 50:57] = 3
+    small = get_inst_info_dict(L)
+    H, W = 32768 + 64, 65536
+    assert H * W >= 2 ** 31
+    big = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    y0, x0 = H - 60, W - 70
+    assert y0 * W + x0 > 2 ** 31
+    big[y0:, x0:] = torch.from_numpy(L).cuda()
+    got = get_inst_info_dict(big)
+    del big
+    assert sorted(got.keys()) == sorted(small.keys()) == [1, 2, 3]
+    for k in small:
+        assert np.array_equal(got[k]["contour"], small[k]["contour"] + np.array([x0, y0])), k
+        assert np.array_equal(np.asarray(got[k]["box"]).reshape(-1), np.asarray(small[k]["box"]).reshape(-1) + np.array([y0, x0, y0, x0])), k
+        assert np.allclose(got[k]["centroid"], np.asarray(small[k]["centroid"]) + np.array([x0, y0]), atol=1e-6), k
+    from cerberus_amd import postproc as pp
+
+    pp._ws_cache.clear()  # (17 GB of union-find labels: not something the rest of the suite should keep)
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("tissue", ["Nuclei", "Gland", "Lumen"])
 def test_postproc_is_bitwise_reproducible(tissue):
     """The CCL / flood kernels use atomics and lock-free union-find; the label maps must not depend on scheduling."""
