@@ -5,7 +5,7 @@ second slide, `stream_bands.plan_slide` deciding against the REAL free HBM (no C
 The slide file is a JPEG-tiled pyramidal TIFF whose TileOffsets point into an atlas of 64 encoded stain-field tiles (a few MB on disk for
 10 Gpx; the reader does not care that offsets repeat) plus a x16 level for the tissue thumbnail.
 
-    python scripts/dev_r06_giant_slide.py <H> <W> [out.json]
+    python scripts/dev_r06_giant_slide.py <H> <W> [out.json] [share of glass blocks] [ranks]
 """
 import io
 import json
@@ -34,17 +34,24 @@ def _jpeg_rgb_components(t):
     return raw[:2] + raw[4 + n:] if raw[2:4] == b"\xff\xe0" else raw
 
 
-def write_atlas_tiff(path, H, W, mpp=0.5, seed=17):
-    """H, W multiples of 16 * TILE.  Level 0: tile (ty, tx) = atlas[pick[ty, tx]]; level 1 (x16): assembled from the atlas tiles' x16 reductions."""
+def write_atlas_tiff(path, H, W, mpp=0.5, seed=17, glass=0.0):
+    """Level 0: tile (ty, tx) = atlas[pick[ty, tx]] (the image's last tile row / column may be partial: TIFF tiles are whole, the image size crops them);
+    level 1 (x16): assembled from the atlas tiles' x16 reductions.  glass: share of 16 x 16-tile blocks that are white (a slide is 30 - 70 % glass:
+    the tissue mask then drops patches, which an all-tissue slide never exercises)."""
     from cerberus_amd.synth_tiles import stain_field
 
-    assert H % (16 * TILE) == 0 and W % (16 * TILE) == 0
     rs = np.random.RandomState(seed)
     atlas = [np.clip(stain_field(TILE, 100 + i).astype(np.int16) + rs.randint(-10, 11, (TILE, TILE, 3)), 0, 255).astype(np.uint8) for i in range(64)]
-    ny, nx = H // TILE, W // TILE
+    atlas.append(np.full((TILE, TILE, 3), 255, np.uint8))
+    ny, nx = -(-H // TILE), -(-W // TILE)
     pick = rs.randint(0, 64, (ny, nx))
-    small = np.stack([a.reshape(16, 16, 16, 16, 3).mean(axis=(1, 3)).astype(np.uint8) for a in atlas])  # [64, 16, 16, 3]
-    l1 = small[pick].transpose(0, 2, 1, 3, 4).reshape(ny * 16, nx * 16, 3)
+    if glass > 0:
+        blocks = rs.rand(-(-ny // 16), -(-nx // 16)) < glass
+        pick[np.kron(blocks, np.ones((16, 16), bool))[:ny, :nx]] = 64
+    small = np.stack([a.reshape(16, 16, 16, 16, 3).mean(axis=(1, 3)).astype(np.uint8) for a in atlas])  # [65, 16, 16, 3]
+    h1, w1 = -(-H // 16), -(-W // 16)
+    l1 = np.full((-(-h1 // TILE) * TILE, -(-w1 // TILE) * TILE, 3), 255, np.uint8)
+    l1[: ny * 16, : nx * 16] = small[pick].transpose(0, 2, 1, 3, 4).reshape(ny * 16, nx * 16, 3)
     with open(path, "wb") as fh:
         fh.write(b"II" + struct.pack("<HI", 42, 0))
         link = 4
@@ -61,9 +68,9 @@ def write_atlas_tiff(path, H, W, mpp=0.5, seed=17):
                     cnts.append(where[i][1])
                 h, w = H, W
             else:
-                h, w = l1.shape[:2]
-                for ty in range(h // TILE):
-                    for tx in range(w // TILE):
+                h, w = h1, w1
+                for ty in range(l1.shape[0] // TILE):
+                    for tx in range(l1.shape[1] // TILE):
                         data = _jpeg_rgb_components(l1[ty * TILE:(ty + 1) * TILE, tx * TILE:(tx + 1) * TILE])
                         offs.append(fh.tell())
                         cnts.append(len(data))
@@ -139,11 +146,13 @@ def write_model_dir(path, q=0.02):
 def main():
     H, W = int(sys.argv[1]), int(sys.argv[2])
     out_json = sys.argv[3] if len(sys.argv) > 3 else None
+    glass = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
+    ranks = int(sys.argv[5]) if len(sys.argv) > 5 else 1  # > 1: that many ranks on THIS box's one GPU (torch.distributed.run, collectives staged through gloo)
     td = tempfile.mkdtemp(prefix="giant_")
     os.makedirs(os.path.join(td, "in"))
     path = os.path.join(td, "in", "giant.tif")
     t0 = time.perf_counter()
-    size = write_atlas_tiff(path, H, W)
+    size = write_atlas_tiff(path, H, W, glass=glass)
     build_s = time.perf_counter() - t0
     from cerberus_amd import reader as rd
 
@@ -152,13 +161,18 @@ def main():
     assert tuple(rows.shape) == (H, W, 3), rows.shape
     assert rows[H - 300:H - 290].shape == (10, W, 3)
     del rows, r
-    res = {"slide": [H, W], "pixels": H * W, "over_int32": H * W > 2 ** 31, "file_MB": round(size / 1e6, 1), "build_s": round(build_s, 1)}
+    res = {"slide": [H, W], "pixels": H * W, "over_int32": H * W > 2 ** 31, "glass_share_of_blocks": glass, "file_MB": round(size / 1e6, 1), "build_s": round(build_s, 1)}
     res["background_bias_shifts"] = write_model_dir(os.path.join(td, "model"))
     cmd = [sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--model=%s" % os.path.join(td, "model"), "--gpu=0", "--input_dir=%s" % os.path.join(td, "in"), "--wsi_file_ext=.tif",
            "--output_dir=%s" % os.path.join(td, "out"), "--logging_dir=%s" % os.path.join(td, "log"), "--batch_size=64", "--patch_input_shape=256",
            "--patch_output_shape=256"]
+    env = dict(os.environ)
+    if ranks > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1", "--master-port", "29611"] + cmd[1:]
+        env.update(MASTER_ADDR="127.0.0.1", CERB_DIST_BACKEND="gloo")
+    res["ranks"] = ranks
     t0 = time.perf_counter()
-    p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env)
     wall = time.perf_counter() - t0
     res["rc"] = p.returncode
     res["wall_s"] = round(wall, 1)
@@ -170,6 +184,9 @@ def main():
             logs += open(os.path.join(ld, f)).read().splitlines()
     res["log"] = logs[-60:]
     res["stderr_tail"] = p.stderr.splitlines()[-25:]
+    if p.returncode != 0 and out_json:
+        open(out_json + ".stderr.txt", "w").write(p.stderr[-200000:])
+    res["CERB_HBM_BUDGET_GB"] = os.environ.get("CERB_HBM_BUDGET_GB")
     res["stdout_tail"] = p.stdout.splitlines()[-25:]
     dat = os.path.join(td, "out", "dat", "giant.dat")
     if os.path.exists(dat):
