@@ -21,7 +21,8 @@ import numpy as np
 from cerberus_amd.cli import WSI_OPTIONS, parse, require_model
 
 
-ONE_CALL_PX = 400 * 1000 * 1000  # largest map labelled in one call on one GPU (38 GB of workspace); larger slides are banded
+# largest map labelled in one call on one GPU (400 Mpx = 38 GB of workspace); larger slides are labelled in row bands (CERB_ONE_CALL_MPX moves the line)
+ONE_CALL_PX = int(float(os.environ.get("CERB_ONE_CALL_MPX", "400")) * 1e6)
 
 
 def _basename(path, ext):
@@ -286,7 +287,19 @@ def main(argv=None):
                     from cerberus_amd.tissue import postprocess_regions
 
                     regions = TissueRegions(torch.from_numpy(mask).cuda())
-                    inst = {"Nuclei": postproc_device(maps["Nuclei-INST"], "Nuclei", exact_ties=False)[0]} if "Nuclei-INST" in maps else {}
+                    inst = {}
+                    if "Nuclei-INST" in maps and H * W > ONE_CALL_PX:
+                        # (nuclei do not care about tissue regions -- unselected patches left zeros -- so a slide too large for one labelling call, or past
+                        #  2^31 pixels, goes through the row bands of the mask-less path: exact ownership, slide-global ids)
+                        from cerberus_amd.shard_postproc import sharded_postprocess
+
+                        nb, ninfo = sharded_postprocess(OrderedDict([("Nuclei-INST", maps["Nuclei-INST"][:H, :W])]), 0, 1, None, wsi_mode=True, max_band_px=ONE_CALL_PX, prof=pprof)
+                        inst["Nuclei"] = nb["Nuclei"]
+                        if log:
+                            bad = ninfo["Nuclei"].get("n_truncated") or ninfo["Nuclei"].get("n_unresolved")
+                            (log.warning if bad else log.info)("Nuclei labelled in {0} row bands under the tissue mask: {1}".format(ninfo["Nuclei"].get("local_bands"), ninfo["Nuclei"]))
+                    elif "Nuclei-INST" in maps:
+                        inst["Nuclei"] = postproc_device(maps["Nuclei-INST"], "Nuclei", exact_ties=False)[0]
                     records = postprocess_regions(maps, (H, W), regions)
                 elif rank == 0:
                     inst, _ = WSIRunner.postprocess(maps, wsi_mode=True)

@@ -5,7 +5,7 @@ second slide, `stream_bands.plan_slide` deciding against the REAL free HBM (no C
 The slide file is a JPEG-tiled pyramidal TIFF whose TileOffsets point into an atlas of 64 encoded stain-field tiles (a few MB on disk for
 10 Gpx; the reader does not care that offsets repeat) plus a x16 level for the tissue thumbnail.
 
-    python scripts/dev_r06_giant_slide.py <H> <W> [out.json] [share of glass blocks] [ranks]
+    python scripts/dev_r06_giant_slide.py <H> <W> [out.json] [share of glass blocks] [ranks] [mask]
 """
 import io
 import json
@@ -100,47 +100,16 @@ def write_atlas_tiff(path, H, W, mpp=0.5, seed=17, glass=0.0):
             fh.write(struct.pack("<I", ifd))
             fh.seek(end)
             link = ifd + 2 + 12 * len(packed)
-    return os.path.getsize(path)
+    return os.path.getsize(path), pick
 
 
 def write_model_dir(path, q=0.02):
-    """settings.yml + weights.tar (the reference's checkpoint layout) holding the seeded test weights with every INST head's background bias raised
-    so that ~q of a stain-field tile's pixels are foreground (bench.py's sparse_foreground_weights, calibrated on this slide's texture): the plain
-    seeded weights call half the slide one nucleus, and a flood of 10^9 pixels is no test of anything."""
-    import json as _json
+    """settings.yml + weights.tar with ~q of a stain-field tile's pixels foreground (tests/tools/model_dir.py): the plain seeded weights call half
+    the slide one nucleus, and a flood of 10^9 pixels is no test of anything."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    from model_dir import stain_atlas, write_sparse_model_dir
 
-    import torch
-    import yaml
-
-    from cerberus_amd.net_desc import create_model
-    from cerberus_amd.synth_tiles import stain_field
-    from cerberus_amd.weights import DEFAULT_REQ_TARGET_CODE, default_model_kwargs, make_state_dict
-
-    kw = default_model_kwargs()
-    sd = {k: torch.from_numpy(v) for k, v in make_state_dict(0).items()}
-    m = create_model(**kw)
-    m.load_state_dict(sd, strict=True)
-    rs = np.random.RandomState(17)
-    tiles = np.stack([np.clip(stain_field(TILE, 100 + i).astype(np.int16) + rs.randint(-10, 11, (TILE, TILE, 3)), 0, 255).astype(np.uint8) for i in range(4)])
-    lg = m(torch.from_numpy(tiles).cuda())
-    shifts = {}
-    for name, hname, och, key in m._decoders:
-        if hname != "INST":
-            continue
-        v = lg[key]  # (n, 3, H, W)
-        margin = v[:, 1] - torch.logsumexp(torch.stack([v[:, 0], v[:, 2]]), 0)
-        flat = margin.flatten().float()
-        d = float(torch.quantile(flat[:: max(1, flat.numel() // 1000000)], 1.0 - q))
-        sd["output_head.%s.INST.x.1.conv.bias" % name][0] += d
-        shifts[key] = round(d, 4)
-    os.makedirs(path, exist_ok=True)
-    torch.save({"desc": sd}, os.path.join(path, "weights.tar"))
-    plain = _json.loads(_json.dumps({"dataset_kwargs": {"req_target_code": DEFAULT_REQ_TARGET_CODE}, "model_kwargs": kw}))
-    with open(os.path.join(path, "settings.yml"), "w") as fh:
-        yaml.safe_dump(plain, fh, sort_keys=False)
-    del m
-    torch.cuda.empty_cache()
-    return shifts
+    return write_sparse_model_dir(path, np.stack(stain_atlas(4)), q)
 
 
 def main():
@@ -148,11 +117,12 @@ def main():
     out_json = sys.argv[3] if len(sys.argv) > 3 else None
     glass = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
     ranks = int(sys.argv[5]) if len(sys.argv) > 5 else 1  # > 1: that many ranks on THIS box's one GPU (torch.distributed.run, collectives staged through gloo)
+    with_mask = len(sys.argv) > 6 and sys.argv[6] == "mask"  # --msk_dir: the tissue mask = the blocks that are not glass (4 mask pixels per tile side)
     td = tempfile.mkdtemp(prefix="giant_")
     os.makedirs(os.path.join(td, "in"))
     path = os.path.join(td, "in", "giant.tif")
     t0 = time.perf_counter()
-    size = write_atlas_tiff(path, H, W, glass=glass)
+    size, pick = write_atlas_tiff(path, H, W, glass=glass)
     build_s = time.perf_counter() - t0
     from cerberus_amd import reader as rd
 
@@ -166,6 +136,14 @@ def main():
     cmd = [sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--model=%s" % os.path.join(td, "model"), "--gpu=0", "--input_dir=%s" % os.path.join(td, "in"), "--wsi_file_ext=.tif",
            "--output_dir=%s" % os.path.join(td, "out"), "--logging_dir=%s" % os.path.join(td, "log"), "--batch_size=64", "--patch_input_shape=256",
            "--patch_output_shape=256"]
+    if with_mask:
+        from PIL import Image
+
+        os.makedirs(os.path.join(td, "msk"))
+        m = np.kron((pick != 64).astype(np.uint8) * 255, np.ones((4, 4), np.uint8))
+        Image.fromarray(np.stack([m] * 3, -1)).save(os.path.join(td, "msk", "giant.png"))
+        cmd.append("--msk_dir=%s" % os.path.join(td, "msk"))
+        res["mask"] = {"shape": list(m.shape), "tissue_share": round(float((m > 0).mean()), 4)}
     env = dict(os.environ)
     if ranks > 1:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1", "--master-port", "29611"] + cmd[1:]

@@ -442,6 +442,65 @@ def test_run_infer_wsi_writes_a_log_per_slide_and_self_spawns(tmp_path):
     assert "Nuclei Post Proc Time:" in text  # the band protocol times the tissues apart
 
 
+def test_run_infer_wsi_with_a_mask_labels_nuclei_in_row_bands_when_the_slide_exceeds_one_call(tmp_path):
+    """--msk_dir on a slide larger than one labelling call (400 Mpx; a 49152 x 65536 scan is past the 2^31 pixels a call can address at all, and the
+    masked path used to hand the whole nuclei canvas to ONE call): the nuclei go through the row bands of the mask-less path -- exact ownership,
+    slide-global ids -- while gland / lumen stay per tissue region.  Here CERB_ONE_CALL_MPX moves the line under a 3072 x 2304 slide: label maps and
+    dictionary entries of the banded run equal the one-call run's.  Weights: tests/tools/model_dir.py (islands a window can hold)."""
+    import glob
+
+    import joblib
+    from PIL import Image
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    from model_dir import stain_atlas, write_sparse_model_dir
+
+    atlas = stain_atlas(16)
+    H, W = 3072, 2304
+    pick = np.random.RandomState(3).randint(0, 16, (H // 256, W // 256))
+    img = np.concatenate([np.concatenate([atlas[i] for i in row], axis=1) for row in pick], axis=0)
+    spec, msk = tmp_path / "slides", tmp_path / "masks"
+    spec.mkdir()
+    msk.mkdir()
+    np.save(str(spec / "s1.npy"), img)
+    m = np.zeros((H // 16, W // 16), np.uint8)
+    m[:, : int(0.65 * W / 16)] = 255
+    m[40:60, :] = 0  # two tissue regions
+    Image.fromarray(np.stack([m] * 3, -1)).save(str(msk / "s1.png"))
+    write_sparse_model_dir(str(tmp_path / "model"), np.stack(atlas[:4]))
+    base = [sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--model=%s" % (tmp_path / "model"), "--input_dir=%s" % spec, "--msk_dir=%s" % msk, "--wsi_file_ext=.npy",
+            "--batch_size=8", "--patch_input_shape=256", "--patch_output_shape=256", "--save_label_maps"]
+    outs = []
+    for tag, env in (("one", dict(os.environ)), ("banded", dict(os.environ, CERB_ONE_CALL_MPX="5"))):
+        r = subprocess.run(base + ["--output_dir=%s" % (tmp_path / tag), "--logging_dir=%s" % (tmp_path / ("log_" + tag))], capture_output=True, text=True, timeout=900,
+                           cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append((np.load(str(tmp_path / tag / "s1.npz")), joblib.load(str(tmp_path / tag / "dat" / "s1.dat")),
+                     open(glob.glob(str(tmp_path / ("log_" + tag) / "s1_*_std.log"))[0]).read()))
+    (za, da, la), (zb, db, lb) = outs
+    assert "row bands under the tissue mask" not in la
+    import re
+
+    nb = re.search(r"Nuclei labelled in (\d+) row bands under the tissue mask", lb)
+    assert nb and int(nb.group(1)) >= 2 and "WARNING" not in lb, lb[-1500:]
+    assert set(za.files) == set(zb.files) and "Nuclei" in za.files
+    from cerberus_amd.shard_postproc import same_partition
+
+    for k in za.files:
+        if k == "Nuclei":  # the same instances; a single call numbers them by their markers' first pixels, the bands by the instances' own
+            assert same_partition(za[k], zb[k])
+        else:
+            assert np.array_equal(za[k], zb[k]), k
+    assert len(np.unique(zb["Nuclei"])) > 50
+    assert not za["Nuclei"][:, int(0.65 * W / 16) * 16 + 256:].any()  # patches outside the mask did not run
+
+    def entries(d):
+        return sorted((tuple(int(v) for v in e["box"]), tuple(float(v) for v in np.asarray(e["centroid"], np.float64)), np.asarray(e["contour"], np.int64).tobytes(),
+                       int(e.get("type", -1))) for e in d["Nuclei"].values())
+
+    assert entries(da) == entries(db) and len(da["Nuclei"]) > 50
+
+
 def test_run_infer_wsi_streams_a_slide_that_does_not_fit_the_hbm_budget(tmp_path):
     """the slide driver prices the band against the free HBM (capped here through CERB_HBM_BUDGET_GB) before it allocates
     anything; a slide that does not fit resident runs as sequential sub-bands (cerberus_amd/stream_bands.py) and must write the SAME label maps and
