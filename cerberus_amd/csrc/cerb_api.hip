@@ -11,6 +11,8 @@ int cerb_set_error(const std::string& m) {
 }
 extern "C" int cerb_version(void) { return 1; }
 extern "C" const char* cerb_last_error(void) { return g_err.c_str(); }
+std::atomic<long long> g_devbuf_bytes{0};
+extern "C" size_t cerb_device_bytes_held(void) { const long long v = g_devbuf_bytes.load(); return v > 0 ? (size_t)v : 0; }
 thread_local hipStream_t g_call_stream = nullptr;  // the stream of the API call running on this thread (DevBuf::ensure fills fresh buffers on it)
 
 static int alloc_dev(cerb_net* net, size_t bytes, void** out) {

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -154,14 +155,22 @@ extern "C" size_t cerb_conv_guard_bytes(int tile_w);
 // a finite value.  The whole allocation is zeroed once; kernels only ever write payload bytes.
 // The stream of the API call that is running on this thread (set at every entry point that may allocate): a fresh buffer is zero-filled ON it.
 extern thread_local hipStream_t g_call_stream;
+// bytes of activation workspace all handles of this process hold (cerb_device_bytes_held: a caller that prices its next job against the free HBM
+// must not count them twice -- they are allocated already AND part of what a forward needs)
+extern std::atomic<long long> g_devbuf_bytes;
 struct DevBuf {
     float* p = nullptr;  // payload
     char* raw = nullptr;
-    size_t bytes = 0, guard = 0;
+    size_t bytes = 0, guard = 0, held = 0;
     int ensure(size_t need, size_t g) {
         if (need <= bytes && g <= guard) return 0;
         release();
-        if (hipMalloc(&raw, need + 2 * g) != hipSuccess) return 1;
+        if (hipMalloc(&raw, need + 2 * g) != hipSuccess) {
+            raw = nullptr;
+            return 1;
+        }
+        g_devbuf_bytes += (long long)(need + 2 * g);
+        held = need + 2 * g;
         // The fill is queued on the CALLER's stream: round 4 used hipMemset + hipDeviceSynchronize here because the NULL-stream fill
         // raced the first kernels of a non-blocking side stream (two handles on two streams, cerberus_amd/wsi.py) -- on the stream that will use the
         // buffer it is ordered by construction, stalls nothing else on the device and does not break a stream capture.  (The old buffer's hipFree
@@ -173,7 +182,11 @@ struct DevBuf {
         return 0;
     }
     void release() {
-        if (raw) (void)hipFree(raw);
+        if (raw) {
+            (void)hipFree(raw);
+            g_devbuf_bytes -= (long long)held;
+        }
+        held = 0;
         raw = nullptr;
         p = nullptr;
         bytes = guard = 0;

@@ -48,6 +48,13 @@ def hbm_budget(device=None):
     """Bytes the plan may spend: the device's free HBM, capped by CERB_HBM_BUDGET_GB (how the tests force the streamed path); with
     CERB_HBM_BUDGET_FORCE=1 the variable REPLACES the measurement (an estimate that refuses a run the operator knows to fit needs an override)."""
     free = int(torch.cuda.mem_get_info(device)[0]) if torch.cuda.is_available() else 0
+    if torch.cuda.is_available():  # blocks the caching allocator holds but nothing uses are as good as free (it hands them out, or back, on demand)
+        free += max(0, int(torch.cuda.memory_reserved(device)) - int(torch.cuda.memory_allocated(device)))
+        # ... and so is the activation workspace the handles hold since the previous slide (a directory of slides): plan_slide prices a forward's
+        # workspace into every plan, so what is allocated for it already must not be missing from the budget as well
+        from . import _lib
+
+        free += int(_lib.lib().cerb_device_bytes_held())
     cap = os.environ.get("CERB_HBM_BUDGET_GB")
     if cap and os.environ.get("CERB_HBM_BUDGET_FORCE", "0") == "1":
         return int(float(cap) * 1e9)

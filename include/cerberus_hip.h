@@ -130,6 +130,11 @@ int cerb_net_set_crop_roi(cerb_net* net, int enable);
 /* FLOPs (2*MAC) of one forward for the given geometry -- used by bench.py for the roofline figure. */
 double cerb_net_flops(const cerb_net* net, int n, int h, int w);
 
+/* Bytes of activation workspace the handles of this process hold right now (they grow with the largest batch run and stay until the handle is
+ * destroyed).  A caller that prices its next job against the FREE device memory -- cerberus_amd/stream_bands.py::plan_slide, the counterpart of the
+ * reference's chunk / tile sizing in infer/wsi.py:551-556 -- adds them back: they are allocated already and part of what a forward needs. */
+size_t cerb_device_bytes_held(void);
+
 /* Per-launch timing of the NEXT forwards with HIP events on the caller's stream (bench.py roofline leg; adds two
  * event records per kernel, so never enabled inside a timed region).  After a forward + stream sync,
  * cerb_net_profile_get(i) returns layer name, kernel family, algorithmic FLOPs and elapsed ms of launch i. */

@@ -25,6 +25,21 @@ from cerberus_amd.cli import WSI_OPTIONS, parse, require_model
 ONE_CALL_PX = int(float(os.environ.get("CERB_ONE_CALL_MPX", "400")) * 1e6)
 
 
+def _release_device_memory():
+    """Between two slides: the labelling workspace (up to 96 B / px of the largest call) and the allocator's cached blocks go back to the driver, so that
+    stream_bands.plan_slide prices the next slide against the HBM it can really have."""
+    import gc
+
+    import torch
+
+    from cerberus_amd import postproc
+
+    postproc._ws_cache.clear()
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+
+
 def _basename(path, ext):
     base = os.path.basename(path)
     return base[: -len(ext)] if ext else base
@@ -150,6 +165,10 @@ def main(argv=None):
             continue
         if log:
             log.info("Processing %s ..." % base)
+        # nothing of the previous slide may still hold HBM when this one is priced: its runner and canvases, label maps, closures over them
+        # (a directory of slides is the reference's normal job; the second 40000^2 slide used to be planned against what the first had left)
+        run = maps = inst = pre = progress = up = regions = records = ref_nuclei = rank_parts = source = own_parts = None  # noqa: F841
+        _release_device_memory()
         t0 = time.perf_counter()
         host, H, W, seed, reader = _open_slide(path, float(args["--wsi_proc_mag"]))
         mask, sel, regions = None, None, None

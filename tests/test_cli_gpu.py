@@ -442,6 +442,33 @@ def test_run_infer_wsi_writes_a_log_per_slide_and_self_spawns(tmp_path):
     assert "Nuclei Post Proc Time:" in text  # the band protocol times the tissues apart
 
 
+def test_second_slide_of_a_directory_is_planned_against_the_same_free_hbm_as_alone(tmp_path):
+    """A directory of slides is the reference's normal job (run_infer_wsi.py:76-83 there).  plan_slide prices a slide against the FREE HBM, so nothing
+    of the previous slide may still hold memory when the next one is priced: the runner, canvases and label maps (alive until their names were
+    re-bound), the labelling workspace cache, the allocator's cached blocks.  The budget logged for slide b after slide a (~5 GB of canvases, labels
+    and workspace) must be the budget logged for b alone."""
+    import glob
+    import re
+
+    def budget_of_b(names):
+        d = tmp_path / ("in_" + "".join(names))
+        d.mkdir()
+        for n in names:
+            (d / (n + ".txt")).write_text({"a": "synthetic:6144x6144:3", "b": "synthetic:1024x1280:4"}[n])
+        tag = "".join(names)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--synthetic", "--input_dir=%s" % d, "--wsi_file_ext=.txt", "--output_dir=%s" % (tmp_path / ("out_" + tag)),
+                            "--logging_dir=%s" % (tmp_path / ("log_" + tag)), "--batch_size=8", "--patch_input_shape=256", "--patch_output_shape=256"],
+                           capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        text = open(glob.glob(str(tmp_path / ("log_" + tag) / "b_*_std.log"))[0]).read()
+        return int(re.search(r"Memory plan: SlidePlan\(budget=(\d+)", text).group(1))
+
+    alone, after_a = budget_of_b(["b"]), budget_of_b(["a", "b"])
+    # what legitimately stays from slide a: the second handle's packed weights and tables (~1 GB).  Before: 6.3 GB at this batch size (two forward
+    # workspaces counted as used AND priced again; 50 GB at batch 64), plus slide a's own canvases while its names were alive
+    assert abs(alone - after_a) < 1.5e9, (alone, after_a)
+
+
 def test_run_infer_wsi_with_a_mask_labels_nuclei_in_row_bands_when_the_slide_exceeds_one_call(tmp_path):
     """--msk_dir on a slide larger than one labelling call (400 Mpx; a 49152 x 65536 scan is past the 2^31 pixels a call can address at all, and the
     masked path used to hand the whole nuclei canvas to ONE call): the nuclei go through the row bands of the mask-less path -- exact ownership,
