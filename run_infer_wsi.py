@@ -171,6 +171,8 @@ def main(argv=None):
         _release_device_memory()
         t0 = time.perf_counter()
         host, H, W, seed, reader = _open_slide(path, float(args["--wsi_proc_mag"]))
+        if min(H, W) < 4:  # (the quarter-resolution tissue map and the half-resolution gland maps have no pixels: the reference dies in cv2.resize there)
+            raise ValueError("%s is %d x %d pixels at the processing resolution: nothing to segment" % (base, H, W))
         mask, sel, regions = None, None, None
         if msk_dir:
             from cerberus_amd.tissue import TissueRegions, load_mask, select_patches

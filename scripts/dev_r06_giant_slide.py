@@ -136,6 +136,8 @@ def main():
     cmd = [sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--model=%s" % os.path.join(td, "model"), "--gpu=0", "--input_dir=%s" % os.path.join(td, "in"), "--wsi_file_ext=.tif",
            "--output_dir=%s" % os.path.join(td, "out"), "--logging_dir=%s" % os.path.join(td, "log"), "--batch_size=64", "--patch_input_shape=256",
            "--patch_output_shape=256"]
+    cmd += [a for a in os.environ.get("GIANT_EXTRA_FLAGS", "").split() if a]  # e.g. --reference_tiling
+    res["extra_flags"] = os.environ.get("GIANT_EXTRA_FLAGS")
     if with_mask:
         from PIL import Image
 
