@@ -109,6 +109,8 @@ def write_model_dir(path, q=0.02):
     sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     from model_dir import stain_atlas, write_sparse_model_dir
 
+    if os.environ.get("GIANT_Q"):  # e.g. GIANT_Q='{"Gland": 0.2, "Lumen": 0.08, "default": 0.02}': glands / lumina large enough to survive their size filters
+        q = json.loads(os.environ["GIANT_Q"])
     return write_sparse_model_dir(path, np.stack(stain_atlas(4)), q)
 
 

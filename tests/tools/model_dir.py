@@ -18,7 +18,7 @@ def stain_atlas(n=64, tile=256, seed=17):
 
 
 def write_sparse_model_dir(path, tiles, q=0.02):
-    """tiles: uint8 [n, 256, 256, 3].  -> {head key: bias shift}"""
+    """tiles: uint8 [n, 256, 256, 3]; q: foreground share, a float or {decoder name: share, "default": share}.  -> {head key: bias shift}"""
     import yaml
 
     from cerberus_amd.net_desc import create_model
@@ -36,7 +36,8 @@ def write_sparse_model_dir(path, tiles, q=0.02):
         v = lg[key]  # (n, 3, H, W)
         margin = v[:, 1] - torch.logsumexp(torch.stack([v[:, 0], v[:, 2]]), 0)
         flat = margin.flatten().float()
-        d = float(torch.quantile(flat[:: max(1, flat.numel() // 1000000)], 1.0 - q))
+        qq = q.get(name, q.get("default", 0.02)) if isinstance(q, dict) else q
+        d = float(torch.quantile(flat[:: max(1, flat.numel() // 1000000)], 1.0 - qq))
         sd["output_head.%s.INST.x.1.conv.bias" % name][0] += d
         shifts[key] = round(d, 4)
     os.makedirs(path, exist_ok=True)
