@@ -10,7 +10,7 @@ EXPORTS = [
     "cerb_net_finalize", "cerb_net_forward", "cerb_net_flops", "cerb_device_bytes_held", "cerb_pp_workspace_bytes", "cerb_postproc_nuclei",
     "cerb_postproc_gland", "cerb_postproc_lumen", "cerb_mask_lumen_by_gland", "cerb_event_create",
     "cerb_event_record", "cerb_event_elapsed_ms", "cerb_event_destroy", "cerb_net_profile_enable",
-    "cerb_net_profile_count", "cerb_net_profile_get", "cerb_net_set_conv_algo", "cerb_net_set_head_algo", "cerb_net_set_planar", "cerb_net_set_packed_items", "cerb_net_set_crop_roi", "cerb_net_set_fold_bn", "cerb_net_set_bn_eval", "cerb_net_begin_reload", "cerb_net_update_params", "cerb_net_forward_train", "cerb_net_train_grads", "cerb_net_grad_lookup", "cerb_copy_d2d", "cerb_adam_step", "cerb_adam_step_multi", "cerb_synth_slide", "cerb_gather_patches", "cerb_downsample2_inst", "cerb_half_size", "cerb_downsample2_inst_region", "cerb_pclass_tissue_map", "cerb_label_mask", "cerb_inst_table", "cerb_relabel", "cerb_head_loss_workspace_bytes", "cerb_head_loss", "cerb_head_loss_wmap", "cerb_inst_contour_start", "cerb_inst_contour_start_workspace_bytes", "cerb_inst_contour_count", "cerb_inst_contour_points",
+    "cerb_net_profile_count", "cerb_net_profile_get", "cerb_net_set_conv_algo", "cerb_net_set_head_algo", "cerb_net_set_planar", "cerb_net_set_packed_items", "cerb_net_set_crop_roi", "cerb_net_set_fold_bn", "cerb_net_set_bn_eval", "cerb_net_begin_reload", "cerb_net_update_params", "cerb_net_forward_train", "cerb_net_train_grads", "cerb_net_grad_lookup", "cerb_copy_d2d", "cerb_adam_step", "cerb_adam_step_multi", "cerb_synth_slide", "cerb_gather_patches", "cerb_downsample2_inst", "cerb_half_size", "cerb_downsample2_inst_region", "cerb_pclass_tissue_map", "cerb_resample_box", "cerb_resample_area", "cerb_label_mask", "cerb_inst_table", "cerb_relabel", "cerb_head_loss_workspace_bytes", "cerb_head_loss", "cerb_head_loss_wmap", "cerb_inst_contour_start", "cerb_inst_contour_start_workspace_bytes", "cerb_inst_contour_count", "cerb_inst_contour_points",
 ]
 
 
@@ -97,6 +97,9 @@ def lib():
     L.cerb_net_flops.restype = C.c_double
     L.cerb_device_bytes_held.argtypes = []
     L.cerb_device_bytes_held.restype = C.c_size_t
+    L.cerb_resample_box.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p]
+    L.cerb_resample_area.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int] + \
+        [C.c_void_p] * 4 + [C.c_int, C.c_void_p]
     L.cerb_pp_workspace_bytes.argtypes = [C.c_int, C.c_int]
     L.cerb_pp_workspace_bytes.restype = C.c_size_t
     L.cerb_postproc_nuclei.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

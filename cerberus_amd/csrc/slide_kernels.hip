@@ -375,3 +375,123 @@ extern "C" int cerb_inst_contour_points(const int32_t* labels, long long lab_row
     SK_CHECK();
     return 0;
 }
+
+// =================================================================================================================
+// cerb_resample_box / cerb_resample_area: the reader's reduction of a stored pyramid level to the processing resolution, on the device.
+// A 40x scan (0.25 mpp; levels x1, x4, x16) is read at the 0.5 mpp the network runs on -- the reference's reader does that resize per patch on
+// its 12 DataLoader workers (infer/wsi.py:936-950 through tiatoolbox's read_bounds); cerberus_amd/reader.py::read_bounds is the host statement of
+// it (exact k x k box means for an integer factor, area means on one global grid otherwise) and these kernels return ITS bytes: the box kernel
+// rounds the integer sum half to even (= rint of the exact mean), the area kernel applies the host's float32 tables with the host's operation
+// order (multiply, add, one division per axis, rows first; no fused multiply-add), so a slab filled here equals a slab filled from read_bounds.
+// src: uint8 RGB rows of the level's window (row stride in BYTES), edges replicate (indices are clamped / come clamped in the tables).
+// =================================================================================================================
+__global__ void resample_box_kernel(const uint8_t* __restrict__ src, long long ss, int src_rows, int src_cols, int k, uint8_t* __restrict__ dst,
+                                    long long ds, int out_rows, int out_cols) {
+    const long long n = (long long)out_rows * out_cols;
+    const unsigned kk = (unsigned)(k * k);
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(p / out_cols), x = (int)(p % out_cols);
+        unsigned s[3] = {0u, 0u, 0u};
+        for (int i = 0; i < k; ++i) {
+            const int sy = min(y * k + i, src_rows - 1);
+            const uint8_t* row = src + sy * ss;
+            for (int j = 0; j < k; ++j) {
+                const uint8_t* q = row + 3ll * min(x * k + j, src_cols - 1);
+                s[0] += q[0];
+                s[1] += q[1];
+                s[2] += q[2];
+            }
+        }
+        uint8_t* o = dst + y * ds + 3ll * x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const unsigned q = s[c] / kk, r = s[c] % kk;
+            o[c] = (uint8_t)(q + ((2u * r > kk || (2u * r == kk && (q & 1u))) ? 1u : 0u));
+        }
+    }
+}
+// HIP's __fmul_rn / __fadd_rn are the plain operators and device code is compiled with floating-point contraction on: a + s * w becomes one fused
+// multiply-add -- one rounding instead of numpy's two, a different byte in ~1 of 10^6 pixels.  The product goes through an empty asm statement:
+// the compiler has to materialise it (rounded) before the sum.
+__device__ __forceinline__ float mul_rounded(float a, float b) {
+    float p = a * b;
+    asm volatile("" : "+v"(p));
+    return p;
+}
+__global__ void resample_area_kernel(const uint8_t* __restrict__ src, long long ss, uint8_t* __restrict__ dst, long long ds, int out_rows, int out_cols,
+                                     const int* __restrict__ ridx, const float* __restrict__ rw, const float* __restrict__ rws,
+                                     const int* __restrict__ rrep, int rt, const int* __restrict__ cidx, const float* __restrict__ cw,
+                                     const float* __restrict__ cws, const int* __restrict__ crep, int ct) {
+    const long long n = (long long)out_rows * out_cols;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(p / out_cols), x = (int)(p % out_cols);
+        const int yrep = rrep[y], xrep = crep[x];
+        const float ysum = rws[y], xsum = cws[x];
+        // the row pass of source column c for this output row: ((0 + s0 * w0) + s1 * w1 + ...) / ws, or the repeated row past the level's end
+        auto col = [&](int c, float* v) {
+            if (yrep >= 0) {
+                const uint8_t* q = src + yrep * ss + 3ll * c;
+                v[0] = (float)q[0];
+                v[1] = (float)q[1];
+                v[2] = (float)q[2];
+                return;
+            }
+            float a[3] = {0.f, 0.f, 0.f};
+            for (int t = 0; t < rt; ++t) {
+                const uint8_t* q = src + ridx[(long long)y * rt + t] * ss + 3ll * c;
+                const float w = rw[(long long)y * rt + t];
+                a[0] = a[0] + mul_rounded((float)q[0], w);
+                a[1] = a[1] + mul_rounded((float)q[1], w);
+                a[2] = a[2] + mul_rounded((float)q[2], w);
+            }
+            v[0] = a[0] / ysum;
+            v[1] = a[1] / ysum;
+            v[2] = a[2] / ysum;
+        };
+        float r[3];
+        if (xrep >= 0) {
+            col(xrep, r);
+        } else {
+            float a[3] = {0.f, 0.f, 0.f};
+            for (int t = 0; t < ct; ++t) {
+                float v[3];
+                col(cidx[(long long)x * ct + t], v);
+                const float w = cw[(long long)x * ct + t];
+                a[0] = a[0] + mul_rounded(v[0], w);
+                a[1] = a[1] + mul_rounded(v[1], w);
+                a[2] = a[2] + mul_rounded(v[2], w);
+            }
+            r[0] = a[0] / xsum;
+            r[1] = a[1] / xsum;
+            r[2] = a[2] / xsum;
+        }
+        uint8_t* o = dst + y * ds + 3ll * x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = (uint8_t)fminf(fmaxf(rintf(r[c]), 0.f), 255.f);
+    }
+}
+static unsigned resample_grid(long long n) {
+    const long long b = (n + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
+}
+extern "C" int cerb_resample_box(const uint8_t* src, long long src_row_stride, int src_rows, int src_cols, int k, uint8_t* dst, long long dst_row_stride,
+                                 int out_rows, int out_cols, void* hip_stream) {
+    if (!src || !dst || src_rows <= 0 || src_cols <= 0 || k < 1 || k > 64 || out_rows < 0 || out_cols < 0) return cerb_set_error("cerb_resample_box: bad arguments");
+    if (out_rows == 0 || out_cols == 0) return 0;
+    hipLaunchKernelGGL(resample_box_kernel, dim3(resample_grid((long long)out_rows * out_cols)), dim3(256), 0, (hipStream_t)hip_stream, src, src_row_stride,
+                       src_rows, src_cols, k, dst, dst_row_stride, out_rows, out_cols);
+    SK_CHECK();
+    return 0;
+}
+extern "C" int cerb_resample_area(const uint8_t* src, long long src_row_stride, int src_rows, int src_cols, uint8_t* dst, long long dst_row_stride, int out_rows,
+                                  int out_cols, const int32_t* row_idx, const float* row_w, const float* row_wsum, const int32_t* row_rep, int row_taps,
+                                  const int32_t* col_idx, const float* col_w, const float* col_wsum, const int32_t* col_rep, int col_taps, void* hip_stream) {
+    if (!src || !dst || src_rows <= 0 || src_cols <= 0 || out_rows < 0 || out_cols < 0 || !row_idx || !row_w || !row_wsum || !row_rep || row_taps < 1 ||
+        !col_idx || !col_w || !col_wsum || !col_rep || col_taps < 1)
+        return cerb_set_error("cerb_resample_area: bad arguments");
+    if (out_rows == 0 || out_cols == 0) return 0;
+    hipLaunchKernelGGL(resample_area_kernel, dim3(resample_grid((long long)out_rows * out_cols)), dim3(256), 0, (hipStream_t)hip_stream, src, src_row_stride, dst,
+                       dst_row_stride, out_rows, out_cols, row_idx, row_w, row_wsum, row_rep, row_taps, col_idx, col_w, col_wsum, col_rep, col_taps);
+    SK_CHECK();
+    return 0;
+}

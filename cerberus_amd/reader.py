@@ -55,6 +55,145 @@ def decode_pool():
     return _POOL["pool"]
 
 
+# ---- decode PROCESSES ------------------------------------------------------------------------------------------------------------
+# Threads stop paying at two: PIL parses the JPEG markers, hands pixels over and closes the image under the interpreter lock, and only
+# libjpeg's inner loop runs without it -- 236 Mpx/s on one thread, ~350 on any number (256-core host; scripts/experiments/dev_r06_decode_scaling.py),
+# enough for a slide stored at the processing resolution (150 Mpx/s) and a quarter of what a 40x scan read at 0.5 mpp needs (4 source pixels per
+# pixel).  Worker processes scale linearly (8: 1.9 Gpx/s, 32: 4.8): the reference's own answer (12 DataLoader workers, infer/wsi.py:936-950).
+# A read of many tiles is cut into groups; every worker opens the file itself, decodes its group and writes the pixels into a shared-memory
+# window; nothing but a few integers crosses the pipes.  Workers are fresh interpreters (cerberus_amd/decode_worker.py: no torch, no GPU context,
+# the parent's __main__ is not re-imported).
+_PROCS = {"n": None, "pool": None}
+PROC_MIN_TILES = 96  # below this many tiles a read stays on the thread pool (thumbnails, edge strips, tests)
+
+
+def decode_procs():
+    """Worker processes of large tile reads: CERB_DECODE_PROCS, default min(16, host cores / 4); 0 = threads only."""
+    if os.environ.get("CERB_DECODE_WORKER") == "1":
+        return 0
+    v = os.environ.get("CERB_DECODE_PROCS")
+    if v is not None and v != "":
+        return max(0, int(v))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(0, min(16, n // 4))
+
+
+class _WorkerPool(object):
+    """n decode_worker processes behind pipes.  run(tasks): every task goes to the next idle worker (n feeder threads: the pipe I/O and the wait for
+    the reply run without the interpreter lock); raises with the worker's traceback when one fails."""
+
+    def __init__(self, n):
+        import queue
+        import subprocess
+        import sys
+        from concurrent.futures import ThreadPoolExecutor
+
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        code = "import sys; sys.path.insert(0, %r); from cerberus_amd import decode_worker; decode_worker.main()" % root
+        env = dict(os.environ, CERB_DECODE_WORKER="1", CERB_DECODE_THREADS="1", OMP_NUM_THREADS="1")
+        self.procs = [subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env) for _ in range(n)]
+        self.idle = queue.Queue()
+        for p in self.procs:
+            self.idle.put(p)
+        self.feeders = ThreadPoolExecutor(max_workers=n, thread_name_prefix="cerb-decode-feed")
+        self.n = n
+
+    def _one(self, task):
+        import pickle
+
+        p = self.idle.get()
+        try:
+            body = pickle.dumps(task)
+            p.stdin.write(struct.pack("<I", len(body)) + body)
+            p.stdin.flush()
+            head = p.stdout.read(4)
+            if len(head) < 4:
+                raise RuntimeError("a tile-decode worker died (exit code %s)" % p.poll())
+            n = struct.unpack("<I", head)[0]
+            buf = b""
+            while len(buf) < n:
+                part = p.stdout.read(n - len(buf))
+                if not part:
+                    raise RuntimeError("a tile-decode worker died mid-reply (exit code %s)" % p.poll())
+                buf += part
+            kind, val = pickle.loads(buf)
+            if kind != "ok":
+                raise RuntimeError("tile-decode worker: " + str(val))
+            return val
+        finally:
+            self.idle.put(p)
+
+    def run(self, tasks):
+        return list(self.feeders.map(self._one, tasks))
+
+    def shutdown(self):
+        for p in self.procs:
+            try:
+                p.stdin.close()
+            except Exception:  # noqa: BLE001
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=5)
+            except Exception:  # noqa: BLE001
+                p.kill()
+        self.feeders.shutdown(wait=False)
+
+
+def _proc_pool():
+    n = decode_procs()
+    if n <= 0:
+        return None
+    if _PROCS["n"] != n:
+        import atexit
+
+        if _PROCS["pool"] is not None:
+            _PROCS["pool"].shutdown()
+        else:
+            atexit.register(_shutdown_procs)
+        _PROCS["pool"], _PROCS["n"] = _WorkerPool(n), n
+    return _PROCS["pool"]
+
+
+def _shutdown_procs():
+    if _PROCS["pool"] is not None:
+        _PROCS["pool"].shutdown()
+        _PROCS["pool"], _PROCS["n"] = None, None
+
+
+_WORKER = {"readers": {}, "shm": {}}
+
+
+def _worker_decode(path, mpp, level, tiles, window, shm_name, shape):
+    """In a worker: decode `tiles` [(ty, tx)] of a level and write their parts inside `window` = (x0, y0, x1, y1) into the shared block."""
+    from multiprocessing import shared_memory
+
+    r = _WORKER["readers"].get(path)
+    if r is None:
+        if len(_WORKER["readers"]) > 4:
+            _WORKER["readers"].clear()
+        r = _WORKER["readers"][path] = TiffReader(path, mpp=mpp)
+    sh = _WORKER["shm"].get(shm_name)
+    if sh is None:
+        for k in list(_WORKER["shm"]):
+            _WORKER["shm"].pop(k).close()
+        sh = _WORKER["shm"][shm_name] = shared_memory.SharedMemory(name=shm_name)
+        try:  # (Python < 3.13 registers every ATTACHMENT with the resource tracker, which then unlinks the parent's block when this worker exits)
+            from multiprocessing import resource_tracker
+
+            resource_tracker.unregister(sh._name, "shared_memory")
+        except Exception:  # noqa: BLE001
+            pass
+    out = np.ndarray(shape, np.uint8, buffer=sh.buf)
+    p = r.levels[level]
+    for tt in tiles:
+        r._place_tile(p, tt, window, out)
+    return len(tiles)
+
+
 class SlideInfo(object):
     def __init__(self, path, dims_wh, mpp=None, level_dimensions=None, level_downsamples=None):
         self.file_path = path
@@ -79,6 +218,31 @@ def _strip_jfif_app0(data):
     return bytes(out) + data[i:]
 
 
+def area_tables(o0, o1, rel, s0, n, size):
+    """The numbers of _resample_axis' area-mean branch (rel >= 1) for output pixels o0 .. o1-1, as tables a device kernel can apply
+    (cerb_resample_area: same float32 products, sums and quotient in the same order -> the same bytes): idx int32 [n_out, T] (positions in the
+    source window s0 .. s0 + n - 1, clipped), w float32 [n_out, T] (0 where a tap lies outside), ws float32 [n_out] (the divisor), rep int32 [n_out]
+    (>= 0: the output pixel lies wholly past the level's end and repeats that source position)."""
+    o = np.arange(o0, o1, dtype=np.float64)
+    lo, hi = o * rel, np.minimum((o + 1) * rel, float(size))
+    first = np.floor(lo).astype(np.int64)
+    T = int(np.ceil(rel)) + 1
+    idx = np.zeros((len(o), T), np.int32)
+    w = np.zeros((len(o), T), np.float32)
+    wsum = np.zeros(len(o), np.float64)
+    for t in range(T):
+        i = first + t
+        wgt = np.clip(np.minimum(hi, i + 1.0) - np.maximum(lo, i.astype(np.float64)), 0.0, 1.0)
+        ok = (i - s0 >= 0) & (i - s0 < n)
+        wgt = np.where(ok, wgt, 0.0)
+        idx[:, t] = np.clip(i - s0, 0, n - 1)
+        w[:, t] = wgt.astype(np.float32)
+        wsum += wgt
+    ws = np.maximum(wsum, 1e-12).astype(np.float32)
+    rep = np.where(wsum <= 0.0, np.clip(size - 1 - s0, 0, n - 1), -1).astype(np.int32)
+    return idx, w, ws, rep
+
+
 def _resample_axis(src, axis, o0, o1, rel, s0, size):
     """Output pixels o0 .. o1-1 of a global resampling grid along `axis`: src holds the source pixels s0 .. s0 + n - 1 of a level that is
     `size` pixels long.  rel >= 1: area mean over [o * rel, (o + 1) * rel) clipped to the level (fractional end pixels weighted by their overlap);
@@ -88,20 +252,14 @@ def _resample_axis(src, axis, o0, o1, rel, s0, size):
     o = np.arange(o0, o1, dtype=np.float64)
     out = np.zeros((len(o),) + src.shape[1:], np.float32)
     if rel >= 1:
-        lo, hi = o * rel, np.minimum((o + 1) * rel, float(size))
-        first = np.floor(lo).astype(np.int64)
-        wsum = np.zeros(len(o), np.float64)
-        for t in range(int(np.ceil(rel)) + 1):
-            idx = first + t
-            wgt = np.clip(np.minimum(hi, idx + 1.0) - np.maximum(lo, idx.astype(np.float64)), 0.0, 1.0)
-            ok = (idx - s0 >= 0) & (idx - s0 < n)
-            wgt = np.where(ok, wgt, 0.0)
-            out += src[np.clip(idx - s0, 0, n - 1)] * wgt.astype(np.float32).reshape((-1,) + (1,) * (src.ndim - 1))
-            wsum += wgt
-        out /= np.maximum(wsum, 1e-12).astype(np.float32).reshape((-1,) + (1,) * (src.ndim - 1))
-        beyond = wsum <= 0.0  # output pixels wholly past the level's end: replicate the last source pixel like the integer-factor path
+        idx, w, ws, rep = area_tables(o0, o1, rel, s0, n, size)
+        tail = (-1,) + (1,) * (src.ndim - 1)
+        for t in range(idx.shape[1]):
+            out += src[idx[:, t]] * w[:, t].reshape(tail)
+        out /= ws.reshape(tail)
+        beyond = rep >= 0  # output pixels wholly past the level's end: replicate the last source pixel like the integer-factor path
         if beyond.any():
-            out[beyond] = src[np.clip(size - 1 - s0, 0, n - 1)]
+            out[beyond] = src[rep[beyond]]
     else:
         c = np.clip((o + 0.5) * rel - 0.5, 0.0, size - 1.0)
         i0 = np.floor(c).astype(np.int64)
@@ -126,6 +284,29 @@ class _Rows(object):
         if lv is not None and abs(reader._scale(resolution, units) - 1.0) < 1e-9 and getattr(lv[0], "tiled", False):
             self.row_align = int(lv[0].th)
 
+    def device_plan(self):
+        """None, or how a caller with a GPU gets these rows WITHOUT the host-side reduction (wsi.SlabUploader): a 40x scan (0.25 mpp, pyramid levels
+        x1 / x4 / x16) read at the 0.5 mpp the network runs on is a x2 reduction of level 0 -- 4 source pixels per output pixel through numpy on ONE
+        thread ran a slide at 9 Mpx/s against 150 from a file at the processing resolution.  The plan names the stored level, the remaining
+        reduction `rel` >= 1 (`k`: the integer factor, exact box means; else area means on the global grid), and hands out source rows (decoded on
+        the reader's pool) and the tables of the reduction; the device applies them (cerb_resample_box / cerb_resample_area) to the same bytes
+        read_bounds returns."""
+        r = self.reader
+        if not hasattr(r, "levels"):
+            return None
+        s = r._scale(self.resolution, self.units)
+        if abs(s - 1.0) < 1e-9:
+            return None
+        want = 1.0 / s
+        lvl = 0
+        for i, d in enumerate(r.info.level_downsamples):
+            if d <= want * (1 + 1e-6):
+                lvl = i
+        rel = want / r.info.level_downsamples[lvl]
+        if rel < 1.0 - 1e-9:  # enlarging (bilinear on the host): rare, and no reduction to save
+            return None
+        return _DevicePlan(r, lvl, rel, self.shape)
+
     def __getitem__(self, key):
         rows = key[0] if isinstance(key, tuple) else key
         if not isinstance(rows, slice):
@@ -134,6 +315,42 @@ class _Rows(object):
         assert step == 1
         out = self.reader.read_bounds((0, a, self.shape[1], b), self.resolution, self.units)
         return out if not isinstance(key, tuple) else out[(slice(None),) + tuple(key[1:])]
+
+
+class _DevicePlan(object):
+    """See _Rows.device_plan.  Source windows follow read_bounds exactly (same first / last source row for an output row range)."""
+
+    def __init__(self, reader, lvl, rel, out_shape):
+        self.reader, self.lvl, self.rel = reader, int(lvl), float(rel)
+        self.lw, self.lh = [int(v) for v in reader.info.level_dimensions[lvl]]
+        self.out_h, self.out_w = int(out_shape[0]), int(out_shape[1])
+        k = int(round(rel))
+        self.k = k if abs(rel - k) < 1e-9 else None
+        p = reader.levels[lvl]
+        self.tile_rows = int(p.th) if getattr(p, "tiled", False) else 1
+
+    def source_rows(self, a, b):
+        """[sy0, sy1) of the level for output rows [a, b)"""
+        if self.k is not None:
+            return a * self.k, min(b * self.k, self.lh)
+        return max(int(np.floor(a * self.rel)), 0), min(int(np.ceil(b * self.rel)), self.lh)
+
+    def out_rows_for_source_tiles(self, a, tiles):
+        """the last output row (exclusive) whose source rows end within `tiles` storage tile rows of the tile row output row a starts in"""
+        sy0 = self.source_rows(a, a + 1)[0]
+        end = (sy0 // self.tile_rows + tiles) * self.tile_rows
+        b = int(np.floor(end / self.rel))
+        return max(a + 1, min(b, self.out_h))
+
+    def read(self, sy0, sy1, out=None):
+        """uint8 [sy1 - sy0, lw, 3] of the level (tiles decoded on the reader's pool)"""
+        return self.reader._read_level(self.lvl, 0, sy0, self.lw, sy1, out=out)
+
+    def row_tables(self, a, b, sy0, n):
+        return area_tables(a, b, self.rel, sy0, n, self.lh)
+
+    def col_tables(self):
+        return area_tables(0, self.out_w, self.rel, 0, self.lw, self.lw)
 
 
 class WSIReader(object):
@@ -391,31 +608,77 @@ class TiffReader(WSIReader):
             arr = np.cumsum(arr, axis=1, dtype=np.uint8)
         return arr[:, :, :3]
 
-    def _read_level(self, level, x0, y0, x1, y1):
+    def _place_tile(self, p, tt, window, out):
+        """decode tile (ty, tx) of page p and write the part of it inside window = (x0, y0, x1, y1) into out (the window's pixels)"""
+        ty, tx = tt
+        x0, y0, x1, y1 = window
+        across = -(-p.w // p.tw)
+        # tiles are stored whole (padded); strips are cropped to the image on the last rows
+        rows = p.th if p.tiled else min(p.th, p.h - ty * p.th)
+        cols = p.tw if p.tiled else p.w
+        tile = self._decode(p, ty * across + tx, rows, cols)
+        gy0, gx0 = ty * p.th, tx * p.tw
+        a0, a1 = max(y0, gy0), min(y1, gy0 + tile.shape[0])
+        b0, b1 = max(x0, gx0), min(x1, gx0 + tile.shape[1])
+        if a1 > a0 and b1 > b0:  # tiles do not overlap: every thread / process writes its own window of `out`
+            out[a0 - y0:a1 - y0, b0 - x0:b1 - x0] = tile[a0 - gy0:a1 - gy0, b0 - gx0:b1 - gx0]
+
+    def _shared_block(self, nbytes):
+        """this reader's shared-memory block (grown on demand, unlinked when the reader goes)"""
+        from multiprocessing import shared_memory
+
+        sh = getattr(self, "_shm", None)
+        if sh is None or sh.size < nbytes:
+            if sh is not None:
+                sh.close()
+                sh.unlink()
+            self._shm = sh = shared_memory.SharedMemory(create=True, size=int(nbytes * 1.25) + 4096)
+        return sh
+
+    def __del__(self):
+        sh = getattr(self, "_shm", None)
+        if sh is not None:
+            try:
+                sh.close()
+                sh.unlink()
+            except Exception:  # noqa: BLE001  (interpreter shutdown)
+                pass
+
+    def _read_level(self, level, x0, y0, x1, y1, out=None):
+        """out: a uint8 array at least as large as the window -- the pixels go into its first rows / columns and that view is returned
+        (wsi.SlabUploader hands its pinned staging buffer in: one copy less per chunk)"""
         p = self.levels[level]
         x0, y0, x1, y1 = max(0, x0), max(0, y0), min(p.w, x1), min(p.h, y1)
-        out = np.zeros((max(0, y1 - y0), max(0, x1 - x0), 3), np.uint8)
-        across = -(-p.w // p.tw)
-
-        def one(tt):
-            ty, tx = tt
-            # tiles are stored whole (padded); strips are cropped to the image on the last rows
-            rows = p.th if p.tiled else min(p.th, p.h - ty * p.th)
-            cols = p.tw if p.tiled else p.w
-            tile = self._decode(p, ty * across + tx, rows, cols)
-            gy0, gx0 = ty * p.th, tx * p.tw
-            a0, a1 = max(y0, gy0), min(y1, gy0 + tile.shape[0])
-            b0, b1 = max(x0, gx0), min(x1, gx0 + tile.shape[1])
-            if a1 > a0 and b1 > b0:  # tiles do not overlap: every thread writes its own window of `out`
-                out[a0 - y0:a1 - y0, b0 - x0:b1 - x0] = tile[a0 - gy0:a1 - gy0, b0 - gx0:b1 - gx0]
-
+        shape = (max(0, y1 - y0), max(0, x1 - x0), 3)
+        dest = None if out is None else out[: shape[0], : shape[1]]
+        window = (x0, y0, x1, y1)
         tiles = [(ty, tx) for ty in range(y0 // p.th, -(-y1 // p.th)) for tx in range(x0 // p.tw, -(-x1 // p.tw))]
+        procs = _proc_pool() if len(tiles) >= PROC_MIN_TILES and p.compression == 7 else None
+        if procs is not None:
+            import threading
+
+            lock = self.__dict__.setdefault("_shm_lock", threading.Lock())
+            with lock:
+                nbytes = shape[0] * shape[1] * 3
+                sh = self._shared_block(nbytes)
+                n = _PROCS["n"]
+                per = max(8, -(-len(tiles) // (4 * n)))
+                mpp = None if self.info.mpp is None else tuple(float(v) for v in self.info.mpp)
+                procs.run([(self.path, mpp, level, tiles[i:i + per], window, sh.name, shape) for i in range(0, len(tiles), per)])
+                got = np.ndarray(shape, np.uint8, buffer=sh.buf)
+                if dest is None:
+                    return got.copy()
+                np.copyto(dest, got)
+                return dest
+        out = np.zeros(shape, np.uint8) if dest is None else dest
+        if dest is not None:
+            dest[...] = 0
         pool = decode_pool()
         if pool is None or len(tiles) < 2:
             for tt in tiles:
-                one(tt)
-        else:  # the reference feeds its GPU from 12 DataLoader workers (infer/wsi.py:936-950); libjpeg / zlib release the interpreter lock while they decode
-            list(pool.map(one, tiles))
+                self._place_tile(p, tt, window, out)
+        else:  # libjpeg / zlib release the interpreter lock while they decode
+            list(pool.map(lambda tt: self._place_tile(p, tt, window, out), tiles))
         return out
 
 

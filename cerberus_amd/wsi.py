@@ -584,7 +584,23 @@ class SlabUploader(object):
         self.chunk = max(self.align, (int(chunk_bytes) // max(1, self.w * 3)) // self.align * self.align)
         self.ahead = os.environ.get("CERB_UPLOAD_AHEAD", "1") != "0"
         nb = max(2, int(buffers)) if self.ahead else 2
-        self.pinned = [torch.empty((min(self.chunk, max(1, self.rows)), self.w, 3), dtype=torch.uint8).pin_memory() for _ in range(nb)]
+        # A slide stored finer than it is processed (a 40x scan read at 0.5 mpp: the common case): the host decodes the STORED level's rows and the
+        # device reduces them (cerb_resample_box / cerb_resample_area = reader.read_bounds' bytes) -- the numpy reduction on this one producer
+        # thread ran such a slide at 9 Mpx/s.  Chunks are whole storage tile rows of the source level (>= 4 when the factor is not an integer: the
+        # tile row a chunk boundary cuts is decoded by both neighbours).  CERB_DEVICE_RESAMPLE=0: the host path.
+        self.plan = host.device_plan() if (hasattr(host, "device_plan") and os.environ.get("CERB_DEVICE_RESAMPLE", "1") != "0") else None
+        self.stage, self.tabs, self.col_tabs = None, [None] * nb, None
+        if self.plan is not None:
+            pl = self.plan
+            src_row = pl.lw * 3
+            self.src_tiles = max(2 if pl.k is not None else 4, (4 * int(chunk_bytes)) // max(1, src_row * pl.tile_rows))
+            cap = min((self.src_tiles + 1) * pl.tile_rows + int(np.ceil(pl.rel)) + 2, pl.lh)
+            self.pinned = [torch.empty((cap, pl.lw, 3), dtype=torch.uint8).pin_memory() for _ in range(nb)]
+            self.stage = [torch.empty((cap, pl.lw, 3), dtype=torch.uint8, device=self.dev) for _ in range(nb)]
+            if pl.k is None:
+                self.col_tabs = [torch.from_numpy(np.ascontiguousarray(t)).to(self.dev) for t in pl.col_tables()]
+        else:
+            self.pinned = [torch.empty((min(self.chunk, max(1, self.rows)), self.w, 3), dtype=torch.uint8).pin_memory() for _ in range(nb)]
         self.busy = [None] * nb  # event after which a staging buffer may be overwritten
         self.copy_stream = torch.cuda.Stream(device=self.dev)
         self.next_row, self.k, self.last_event = 0, 0, None
@@ -601,19 +617,54 @@ class SlabUploader(object):
         if self.busy[i] is not None:
             self.busy[i].synchronize()
         a = self.y0 + self.next_row
-        n = min((a // self.chunk + 1) * self.chunk - a, self.rows - self.next_row)
-        t0 = time.perf_counter()
-        np.copyto(self.pinned[i][:n].numpy(), self.host[self.y0 + self.next_row: self.y0 + self.next_row + n])
-        self.read_s += time.perf_counter() - t0
-        with torch.cuda.stream(self.copy_stream):
-            self.slab[self.next_row: self.next_row + n].copy_(self.pinned[i][:n], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.copy_stream)
+        if self.plan is not None:
+            ev, n = self._issue_resampled(i, a)
+        else:
+            n = min((a // self.chunk + 1) * self.chunk - a, self.rows - self.next_row)
+            t0 = time.perf_counter()
+            np.copyto(self.pinned[i][:n].numpy(), self.host[self.y0 + self.next_row: self.y0 + self.next_row + n])
+            self.read_s += time.perf_counter() - t0
+            with torch.cuda.stream(self.copy_stream):
+                self.slab[self.next_row: self.next_row + n].copy_(self.pinned[i][:n], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.copy_stream)
         with self._cv:
             self.busy[i] = self.last_event = ev
             self.next_row += n
             self.k += 1
             self._cv.notify_all()
+
+    def _issue_resampled(self, i, a):
+        """output rows [a, a + n) of the slide from the stored level's rows: decode -> pinned -> device staging -> reduction into the slab"""
+        import ctypes as C
+        import time
+
+        pl = self.plan
+        b = pl.out_rows_for_source_tiles(a, 1 if self.k == 0 else self.src_tiles)  # (the first chunk is the short one: the first batch starts early)
+        n = min(b - a, self.rows - self.next_row)
+        sy0, sy1 = pl.source_rows(a, a + n)
+        m = sy1 - sy0
+        assert 0 < m <= self.pinned[i].shape[0], (m, self.pinned[i].shape, a, n)
+        t0 = time.perf_counter()
+        pl.read(sy0, sy1, out=self.pinned[i].numpy())
+        self.read_s += time.perf_counter() - t0
+        L = _lib.lib()
+        dst = self.slab[self.next_row: self.next_row + n]
+        with torch.cuda.stream(self.copy_stream):
+            self.stage[i][:m].copy_(self.pinned[i][:m], non_blocking=True)
+            st = C.c_void_p(self.copy_stream.cuda_stream)
+            if pl.k is not None:
+                _lib.check(L.cerb_resample_box(self.stage[i].data_ptr(), pl.lw * 3, m, pl.lw, pl.k, dst.data_ptr(), self.w * 3, n, self.w, st))
+            else:
+                rt = [torch.from_numpy(np.ascontiguousarray(t)).to(self.dev) for t in pl.row_tables(a, a + n, sy0, m)]
+                self.tabs[i] = rt  # alive until this buffer's event has passed
+                ct = self.col_tabs
+                _lib.check(L.cerb_resample_area(self.stage[i].data_ptr(), pl.lw * 3, m, pl.lw, dst.data_ptr(), self.w * 3, n, self.w,
+                                                rt[0].data_ptr(), rt[1].data_ptr(), rt[2].data_ptr(), rt[3].data_ptr(), int(rt[0].shape[1]),
+                                                ct[0].data_ptr(), ct[1].data_ptr(), ct[2].data_ptr(), ct[3].data_ptr(), int(ct[0].shape[1]), st))
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        return ev, n
 
     def _produce(self):
         try:

@@ -170,6 +170,22 @@ int cerb_postproc_lumen(const float* inst, int h, int w, long long row_stride, i
 /* Lumen *= (Gland > 0)   (infer/tile.py:187-191, infer/wsi.py:799-804) */
 int cerb_mask_lumen_by_gland(int32_t* lumen_labels, const int32_t* gland_labels, long long n_pix, void* hip_stream);
 
+/* ---- the slide reader's reduction to the processing resolution, on the device ------------------------------------------
+ * The reference reads every patch through tiatoolbox's read_bounds at `wsi_proc_mag` (infer/wsi.py:521-527, 936-950): for a 40x scan that is a
+ * x2 reduction of level 0 done on its DataLoader workers.  Here the host only decodes the stored level's rows; these two apply the reduction
+ * (cerberus_amd/reader.py::read_bounds is the host statement, and they return its bytes).
+ *   src : uint8 RGB rows of the level's window, src_row_stride BYTES between rows, src_rows x src_cols pixels; dst likewise.
+ *   cerb_resample_box : integer factor k, exact k x k means rounded half to even, source indices clamped to the window (edge replication).
+ *   cerb_resample_area: area means on a global grid through per-axis tables (reader.area_tables): idx int32 [n_out][taps] source positions,
+ *                       w float32 [n_out][taps], wsum float32 [n_out] (the divisor), rep int32 [n_out] (>= 0: repeat that source position);
+ *                       rows first, then columns, float32 multiply / add / divide in the host's order, rint, clip. */
+int cerb_resample_box(const uint8_t* src, long long src_row_stride, int src_rows, int src_cols, int k, uint8_t* dst,
+                      long long dst_row_stride, int out_rows, int out_cols, void* hip_stream);
+int cerb_resample_area(const uint8_t* src, long long src_row_stride, int src_rows, int src_cols, uint8_t* dst,
+                       long long dst_row_stride, int out_rows, int out_cols, const int32_t* row_idx, const float* row_w,
+                       const float* row_wsum, const int32_t* row_rep, int row_taps, const int32_t* col_idx, const float* col_w,
+                       const float* col_wsum, const int32_t* col_rep, int col_taps, void* hip_stream);
+
 /* ---- slide-level data movement (device-resident slide; replaces the DataLoader side of the hot loop) ------------
  * cerb_synth_slide    : synthetic RGB slab [h][w][3]; pixel value depends only on (seed, y0+y, x0+x) so every sharding
  *                       of a slide sees the same pixels (BASELINE.json configs[2..3] "synthetic WSI").

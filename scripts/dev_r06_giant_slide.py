@@ -124,16 +124,18 @@ def main():
     os.makedirs(os.path.join(td, "in"))
     path = os.path.join(td, "in", "giant.tif")
     t0 = time.perf_counter()
-    size, pick = write_atlas_tiff(path, H, W, glass=glass)
+    base_mpp = float(os.environ.get("GIANT_BASE_MPP", "0.5"))  # 0.25: a 40x scan read at the 0.5 mpp the network runs on (H, W are the FILE's pixels)
+    size, pick = write_atlas_tiff(path, H, W, mpp=base_mpp, glass=glass)
     build_s = time.perf_counter() - t0
     from cerberus_amd import reader as rd
 
     r = rd.WSIReader.open(input_img=path)
     rows = r.rows(0.5, "mpp")
-    assert tuple(rows.shape) == (H, W, 3), rows.shape
+    fH, fW = H, W
+    H, W = int(rows.shape[0]), int(rows.shape[1])  # the processing resolution
     assert rows[H - 300:H - 290].shape == (10, W, 3)
     del rows, r
-    res = {"slide": [H, W], "pixels": H * W, "over_int32": H * W > 2 ** 31, "glass_share_of_blocks": glass, "file_MB": round(size / 1e6, 1), "build_s": round(build_s, 1)}
+    res = {"file_pixels": [fH, fW], "base_mpp": base_mpp, "slide": [H, W], "pixels": H * W, "over_int32": H * W > 2 ** 31, "glass_share_of_blocks": glass, "file_MB": round(size / 1e6, 1), "build_s": round(build_s, 1)}
     res["background_bias_shifts"] = write_model_dir(os.path.join(td, "model"))
     cmd = [sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--model=%s" % os.path.join(td, "model"), "--gpu=0", "--input_dir=%s" % os.path.join(td, "in"), "--wsi_file_ext=.tif",
            "--output_dir=%s" % os.path.join(td, "out"), "--logging_dir=%s" % os.path.join(td, "log"), "--batch_size=64", "--patch_input_shape=256",

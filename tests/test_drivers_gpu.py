@@ -1,5 +1,7 @@
 """Tile / WSI drivers on the GPU: stitched maps vs the CPU oracle, tile-mode vs WSI-mode self-consistency, sharded vs
 unsharded equivalence (SURVEY.md par.4 'multi-GPU' row), and label maps bit-exact given identical probability maps."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -203,6 +205,58 @@ def test_pipelined_band_upload_equals_resident_slab(manager):
     torch.cuda.synchronize()
     for k in ref:
         assert torch.equal(ref[k], r2.canv[k]), k
+
+
+@pytest.mark.parametrize("base_mpp, levels", [(0.25, (1,)), (0.2431, (1,)), (0.5 / 3, (1,)), (0.125, (1, 4)), (0.2528, (1, 4))])
+def test_slab_of_a_slide_stored_finer_than_processed_is_reduced_on_the_device(tmp_path, base_mpp, levels):
+    """A 40x scan (0.25 mpp -- or the 0.2431 / 0.2528 real scanners write -- with pyramid levels x1, x4, ..) read at the 0.5 mpp the network runs on:
+    SlabUploader uploads the stored level's decoded rows and the device reduces them (cerb_resample_box: integer factors; cerb_resample_area: the
+    reader's area means through its own float32 tables).  The slab must hold the bytes reader.read_bounds returns -- whole slide, a band in the
+    middle, ragged last tiles, the slide's end inside the last output row / column -- and the host path (CERB_DEVICE_RESAMPLE=0) the same."""
+    from cerberus_amd import reader as rd
+    from cerberus_amd.wsi import SlabUploader
+
+    rs = np.random.RandomState(int(base_mpp * 1e4))
+    H, W = 1493, 2101
+    base = rs.randint(0, 256, (H, W, 3)).astype(np.uint8)
+    base[200:500, 300:900] = np.linspace(0, 255, 600).astype(np.uint8)[None, :, None]  # a ramp: rounding cases that noise rarely hits
+    lv = [base]
+    for d in levels[1:]:
+        hh, ww = -(-H // d), -(-W // d)
+        pad = np.zeros((hh * d, ww * d, 3), np.uint8)
+        pad[:H, :W] = base
+        lv.append(pad.reshape(hh, d, ww, d, 3).mean(axis=(1, 3)).astype(np.uint8))
+    path = str(tmp_path / "s.tif")
+    rd.write_tiled_tiff(path, lv, tile=256, mpp=base_mpp)
+    reader = rd.WSIReader.open(input_img=path)
+    rows = reader.rows(0.5, "mpp")
+    plan = rows.device_plan()
+    assert plan is not None and plan.rel >= 1.0
+    want = 0.5 / base_mpp
+    rel = want / max(d for d in reader.info.level_downsamples if d <= want * (1 + 1e-6))  # (a level's downsample is its width ratio: 2101 / 526, not 4)
+    assert abs(plan.rel - rel) < 1e-6 and (plan.k is not None) == (abs(rel - round(rel)) < 1e-9)
+    assert plan.lvl == (1 if len(levels) > 1 and base_mpp < 0.13 else 0)
+    oh, ow = rows.shape[:2]
+    whole = rows[0:oh]
+    for a, b in ((0, oh), (oh // 3, oh - 57), (oh - 5, oh)):
+        up = SlabUploader(rows, a, b, chunk_bytes=1 << 16)  # small chunks: several per band, boundaries inside tile rows
+        assert up.plan is not None
+        up.upload_until(b - a)
+        torch.cuda.synchronize()
+        got = up.slab.cpu().numpy()
+        assert got.shape == (b - a, ow, 3)
+        bad = np.argwhere(got != whole[a:b])
+        assert bad.size == 0, (base_mpp, a, b, bad[:5], got[tuple(bad[0])] if bad.size else None)
+        assert up.k >= (2 if b - a > 300 else 1)
+    os.environ["CERB_DEVICE_RESAMPLE"] = "0"
+    try:
+        up = SlabUploader(rows, 0, oh)
+        assert up.plan is None
+        up.upload_until(oh)
+        torch.cuda.synchronize()
+        assert np.array_equal(up.slab.cpu().numpy(), whole)
+    finally:
+        del os.environ["CERB_DEVICE_RESAMPLE"]
 
 
 def test_images_sharing_batches_equal_images_alone(manager):

@@ -172,3 +172,51 @@ def test_rgb_photometric_jpeg_tile_with_a_jfif_header_and_resampling_past_the_ed
     src = np.arange(10, dtype=np.float32).reshape(10, 1)
     out = _resample_axis(src, 0, 0, 5, 2.5, 0, 10).ravel()
     assert abs(out[3] - 8.2) < 1e-5 and out[4] == 9.0
+
+
+def test_large_reads_on_decode_processes_equal_the_thread_pool(tmp_path, monkeypatch):
+    """Reads of many JPEG tiles go to worker PROCESSES (cerberus_amd/decode_worker.py; threads stop scaling at two because PIL parses and hands over
+    pixels under the interpreter lock): fresh interpreters behind pipes, tiles decoded into a shared-memory window.  Same bytes as the thread pool,
+    for a window that cuts tiles on all four sides, into a caller's buffer too; a worker's failure comes back as an exception with its traceback."""
+    import io
+
+    from PIL import Image
+
+    from cerberus_amd import reader as rd
+
+    rs = np.random.RandomState(5)
+    small = rs.randint(0, 256, (17, 23, 3)).astype(np.uint8)
+    base = np.kron(small, np.ones((64, 64, 1), np.uint8))[:1000, :1400]  # smooth blocks: JPEG keeps them recognisable
+
+    def enc(t):  # Aperio-style: the R, G, B planes are the stream's components (the writer tags the page PhotometricInterpretation = RGB)
+        buf = io.BytesIO()
+        Image.merge("YCbCr", [Image.fromarray(np.ascontiguousarray(t[..., i])) for i in range(3)]).save(buf, format="JPEG", quality=90, subsampling=0)
+        return buf.getvalue()
+
+    path = str(tmp_path / "many_tiles.tif")
+    write_tiled_tiff(path, [base], tile=64, mpp=0.5, encode=(enc, 7))  # 16 x 22 = 352 tiles
+    monkeypatch.setenv("CERB_DECODE_PROCS", "0")
+    r = WSIReader.open(path)
+    ref = r._read_level(0, 0, 0, 1400, 1000)
+    cut = r._read_level(0, 37, 21, 1333, 977)
+    assert np.abs(ref.astype(int) - base.astype(int)).mean() < 4.0
+    monkeypatch.setenv("CERB_DECODE_PROCS", "3")
+    try:
+        r2 = WSIReader.open(path)
+        assert rd._proc_pool() is not None and rd._proc_pool().n == 3
+        assert np.array_equal(r2._read_level(0, 0, 0, 1400, 1000), ref)
+        assert np.array_equal(r2._read_level(0, 37, 21, 1333, 977), cut)
+        buf = np.full((1100, 1500, 3), 7, np.uint8)
+        got = r2._read_level(0, 0, 0, 1400, 1000, out=buf)
+        assert got.base is buf or got is buf or np.shares_memory(got, buf)
+        assert np.array_equal(got, ref) and (buf[1000:] == 7).all() and (buf[:, 1400:] == 7).all()
+        assert np.array_equal(r2.rows(0.5, "mpp")[100:900], ref[100:900])
+        # a small read stays on the threads
+        assert np.array_equal(r2._read_level(0, 0, 0, 300, 200), ref[:200, :300])
+        # a failing worker: it is told to open a file that is not there
+        r3 = WSIReader.open(path)
+        r3.path = str(tmp_path / "nowhere.tif")
+        with pytest.raises(RuntimeError, match="tile-decode worker"):
+            r3._read_level(0, 0, 0, 1400, 1000)
+    finally:
+        rd._shutdown_procs()
