@@ -529,12 +529,15 @@ def structured_band(dev, y0, rows, W, period=4096):
     return out
 
 
-def ingest_leg(model, dev, side, batch, streams, tmpdir=None, sweep=(1, 2, 4, 8, 16, 32, 64)):
+def ingest_leg(model, dev, side, batch, streams, tmpdir=None, sweep=(1, 2, 4, 8, 16, 32, 64), base_mpp=0.5):
     """Real-slide ingest (SURVEY par.8f rank 2): a JPEG-tiled pyramidal TIFF of side^2 pixels (256-pixel tiles of stain-field
     texture, quality 80, written with cerberus_amd.reader.write_tiled_tiff) through the path run_infer_wsi.py takes for a slide on disk --
     reader rows -> tile decode on the reader's thread pool -> pinned chunks -> copy stream (wsi.SlabUploader, a producer thread ahead of the
     inference) -> gather / forward / scatter (WSIRunner) -- against the same pixels resident in HBM.  Reports decode Mpx/s per thread count
-    (host only), upload GB/s of decoded rows, inference Mpx/s resident and from the file, and the thread count that saturates this GPU."""
+    (host only), upload GB/s of decoded rows, inference Mpx/s resident and from the file, and the thread count that saturates this GPU.
+    base_mpp = 0.25: a 40x scan -- the file holds (2 side)^2 pixels and is read at the 0.5 mpp the network runs on: the stored level's tiles are
+    decoded by worker processes (threads stop at ~350 Mpx/s of decode, a quarter of what this needs) and reduced x2 on the device
+    (cerb_resample_box); the canvases must equal those of the host-reduced rows."""
     import io
     import tempfile
 
@@ -545,16 +548,19 @@ def ingest_leg(model, dev, side, batch, streams, tmpdir=None, sweep=(1, 2, 4, 8,
     from cerberus_amd.wsi import SlabUploader, WSIRunner
 
     H = W = int(side)
+    kf = int(round(0.5 / base_mpp))
+    assert kf >= 1 and abs(0.5 / base_mpp - kf) < 1e-9
+    fH, fW = H * kf, W * kf
     t0 = time.perf_counter()
     rs = np.random.RandomState(17)
     atlas = [np.clip(stain_field(TILE, 100 + i).astype(np.int16) + rs.randint(-10, 11, (TILE, TILE, 3)), 0, 255).astype(np.uint8) for i in range(64)]
-    ny, nx = -(-H // TILE), -(-W // TILE)
+    ny, nx = -(-fH // TILE), -(-fW // TILE)
     pick = rs.randint(0, 64, (ny, nx))
     img = np.empty((ny * TILE, nx * TILE, 3), np.uint8)
     for ty in range(ny):
         for tx in range(nx):
             img[ty * TILE:(ty + 1) * TILE, tx * TILE:(tx + 1) * TILE] = atlas[pick[ty, tx]]
-    img = img[:H, :W]
+    img = img[:fH, :fW]
     cache = {}
 
     def enc(t):
@@ -570,41 +576,55 @@ def ingest_leg(model, dev, side, batch, streams, tmpdir=None, sweep=(1, 2, 4, 8,
 
     td = tempfile.mkdtemp(dir=tmpdir)
     path = os.path.join(td, "slide.tif")
-    rd.write_tiled_tiff(path, [img, np.ascontiguousarray(img[::4, ::4])], tile=TILE, mpp=0.5, encode=(enc, 7))
+    rd.write_tiled_tiff(path, [img, np.ascontiguousarray(img[::4, ::4])], tile=TILE, mpp=base_mpp, encode=(enc, 7))
+    del img
     build_s = time.perf_counter() - t0
-    res = {"slide": [H, W], "file": {"format": "pyramidal TIFF, %d x %d JPEG tiles (Aperio-style: RGB components, 4:4:4, quality 80) + a x4 level" % (TILE, TILE), "MB": round(os.path.getsize(path) / 1e6, 1),
+    res = {"slide": [H, W], "stored": {"pixels": [fH, fW], "mpp": base_mpp, "read_at_mpp": 0.5}, "file": {"format": "pyramidal TIFF, %d x %d JPEG tiles (Aperio-style: RGB components, 4:4:4, quality 80) + a x4 level" % (TILE, TILE), "MB": round(os.path.getsize(path) / 1e6, 1),
                                     "tiles": int(ny * nx), "build_s": round(build_s, 1)}}
     try:
         reader = rd.WSIReader.open(input_img=path)
         rows = reader.rows(0.5, "mpp")
         assert tuple(rows.shape) == (H, W, 3)
-        # (1) decode alone, host only: 2048 rows per point (the first point also warms the page cache)
-        span = min(H, 2048)
+        # (1) decode alone, host only: 2048 stored rows per point (the first point also warms the page cache) -- on threads, then on worker processes
+        span = min(fH, 2048)
         old = os.environ.get("CERB_DECODE_THREADS")
+        old_procs = os.environ.get("CERB_DECODE_PROCS")
         try:
             avail = len(os.sched_getaffinity(0))
         except AttributeError:
             avail = os.cpu_count() or 1
         dec = []
-        rows[0:span]
+        os.environ["CERB_DECODE_PROCS"] = "0"
+        reader._read_level(0, 0, 0, fW, span)
         for n in [c for c in sweep if c <= max(1, avail)]:
             os.environ["CERB_DECODE_THREADS"] = str(n)
             t0 = time.perf_counter()
-            a = rows[0:span]
+            a = reader._read_level(0, 0, 0, fW, span)
             dt = time.perf_counter() - t0
-            dec.append({"threads": n, "Mpx_s": round(span * W / dt / 1e6, 1)})
+            dec.append({"threads": n, "Mpx_s": round(span * fW / dt / 1e6, 1)})
         ref_px = a
-        res["decode"] = {"host_threads_available": avail, "sweep": dec}
+        proc_counts = [c for c in (2, 4, 8, 16, 32) if c <= max(1, avail // 2)]
+        for n in proc_counts:
+            os.environ["CERB_DECODE_PROCS"] = str(n)
+            reader._read_level(0, 0, 0, fW, min(span, 512))  # the workers start here
+            t0 = time.perf_counter()
+            a = reader._read_level(0, 0, 0, fW, span)
+            dt = time.perf_counter() - t0
+            dec.append({"processes": n, "Mpx_s": round(span * fW / dt / 1e6, 1)})
+            assert np.array_equal(a, ref_px)
+        res["decode"] = {"host_threads_available": avail, "sweep": dec, "unit": "Mpx/s of STORED pixels"}
         # the decoded pixels are what the writer's JPEG holds (not bit-equal to the source: lossy), identical whatever the thread count
-        os.environ["CERB_DECODE_THREADS"] = "1"
-        assert np.array_equal(rows[0:min(span, 512)], ref_px[:min(span, 512)])
+        os.environ["CERB_DECODE_THREADS"], os.environ["CERB_DECODE_PROCS"] = "1", "0"
+        assert np.array_equal(reader._read_level(0, 0, 0, fW, min(span, 512)), ref_px[:min(span, 512)])
+        if proc_counts:
+            os.environ["CERB_DECODE_PROCS"] = str(proc_counts[-1])
         # (2) resident: the same pixels already in HBM
         run = WSIRunner(model, (H, W), TILE, TILE, batch)
         if streams == 2:
             run.twin = model.twin()
         y0, y1 = run.slab_rows()
-        os.environ["CERB_DECODE_THREADS"] = str(dec[-1]["threads"])
-        host = np.ascontiguousarray(rows[y0:y1])
+        os.environ["CERB_DECODE_THREADS"] = str(max(d["threads"] for d in dec if "threads" in d))
+        host = np.ascontiguousarray(rows[y0:y1])  # (a stored level finer than 0.5 mpp: reduced on the HOST here -- the reference the device path is held to)
         slab = torch.from_numpy(host).to(dev)
         run.infer_patches(slab, y0, 0, min(run.n_patches, 4 * batch))  # warm-up
         torch.cuda.synchronize()
@@ -626,8 +646,8 @@ def ingest_leg(model, dev, side, batch, streams, tmpdir=None, sweep=(1, 2, 4, 8,
         # (4) end to end from the file, per thread count (ahead = the producer thread; the last row: round 5's caller-thread reads)
         e2e = []
         trial = [c for c in (1, 4, 8, 16, 32, 64) if c <= max(1, avail)]
-        for n, ahead in [(c, "1") for c in trial] + [(trial[-1], "0")]:
-            os.environ["CERB_DECODE_THREADS"], os.environ["CERB_UPLOAD_AHEAD"] = str(n), ahead
+        for n, ahead, np_ in [(c, "1", 0) for c in trial] + [(trial[-1], "0", 0)] + [(1, "1", c) for c in proc_counts if c >= 4]:
+            os.environ["CERB_DECODE_THREADS"], os.environ["CERB_UPLOAD_AHEAD"], os.environ["CERB_DECODE_PROCS"] = str(n), ahead, str(np_)
             for v in run.canv.values():
                 v.zero_()
             torch.cuda.synchronize()
@@ -638,19 +658,20 @@ def ingest_leg(model, dev, side, batch, streams, tmpdir=None, sweep=(1, 2, 4, 8,
             dt = time.perf_counter() - t0
             got = {k: float(v.double().sum().item()) if v.is_floating_point() else int(v.long().sum().item()) for k, v in run.canv.items()}
             assert got == want, "the file-fed run wrote other canvases than the resident run"
-            e2e.append({"decode_threads": n, "upload_ahead": ahead == "1", "s": round(dt, 3), "Mpx_s": round(H * W / dt / 1e6, 2), "decode_s_in_producer": round(up.read_s, 3),
+            e2e.append({"decode_threads": n, "decode_processes": np_, "upload_ahead": ahead == "1", "reduced_on_device": up.plan is not None, "s": round(dt, 3), "Mpx_s": round(H * W / dt / 1e6, 2), "decode_s_in_producer": round(up.read_s, 3),
                         "of_resident": round(resident_s / dt, 3)})
             del up
         os.environ.pop("CERB_UPLOAD_AHEAD", None)
         res["end_to_end_from_file"] = e2e
         best = max((e for e in e2e if e["upload_ahead"]), key=lambda e: e["Mpx_s"])
         sat = next((e for e in e2e if e["upload_ahead"] and e["Mpx_s"] >= 0.99 * best["Mpx_s"]), best)
-        res["best"] = {"Mpx_s": best["Mpx_s"], "of_resident": best["of_resident"], "decode_threads": best["decode_threads"],
-                       "threads_that_saturate_this_gpu": sat["decode_threads"]}
-        if old is None:
-            os.environ.pop("CERB_DECODE_THREADS", None)
-        else:
-            os.environ["CERB_DECODE_THREADS"] = old
+        res["best"] = {"Mpx_s": best["Mpx_s"], "of_resident": best["of_resident"], "decode_threads": best["decode_threads"], "decode_processes": best["decode_processes"],
+                       "first_that_saturates_this_gpu": {"decode_threads": sat["decode_threads"], "decode_processes": sat["decode_processes"]}}
+        for name, val in (("CERB_DECODE_THREADS", old), ("CERB_DECODE_PROCS", old_procs)):
+            if val is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = val
         del run
     finally:
         try:
@@ -1051,6 +1072,12 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
             line["ingest"] = ingest_leg(model, dev, 12288, WSI_BATCH, 1)
         except Exception as e:  # never fails the headline
             line["ingest"] = {"error": str(e)[:300]}
+        # the same for a 40x scan: 16384^2 stored pixels at 0.25 mpp read at 0.5 mpp (decode processes + the x2 reduction on the device)
+        try:
+            ing40 = ingest_leg(model, dev, 8192, WSI_BATCH, 1, sweep=(1, 8), base_mpp=0.25)
+            line["ingest_40x"] = {k: ing40[k] for k in ("slide", "stored", "file", "decode", "inference_resident", "end_to_end_from_file", "best")}
+        except Exception as e:  # never fails the headline
+            line["ingest_40x"] = {"error": str(e)[:300]}
     if world == 1:  # per-head Dice against the reference's own outputs (the metric's second half), outside the timed region
         try:
             line["dice_vs_reference"] = dice_vs_reference()
@@ -1077,6 +1104,7 @@ def main():
     ap.add_argument("--tail-from-inference", action="store_true",
                     help="slide job: the labelling reads the INST canvases the timed inference wrote instead of the seeded structured maps (the data dependency "
                          "inference -> labelling at slide scale); the seeded weights get a sparse-foreground bias calibration so that those maps hold instances")
+    ap.add_argument("--ingest-base-mpp", type=float, default=0.5, help="--mode ingest: microns per pixel the file is STORED at (0.25 = a 40x scan: (2 x slide)^2 pixels on disk, read at 0.5 mpp)")
     ap.add_argument("--slide", type=int, default=0, help="slide side in pixels (default: 40000, or 20000 when HBM is short)")
     ap.add_argument("--max-band-mpx", type=float, default=220.0, help="largest labelling call on one GPU, in Mpx (96 B/px of workspace)")
     ap.add_argument("--force-dist", action="store_true",
@@ -1138,11 +1166,13 @@ def main():
         return train_leg(args, model, dev, dist, world, rank, sd, kw)
     if args.mode == "ingest":
         side = args.slide if args.slide > 0 else 20000
-        ing = ingest_leg(model, dev, side, 64 if args.streams == 2 else 96, args.streams)
+        ing = ingest_leg(model, dev, side, 64 if args.streams == 2 else 96, args.streams, base_mpp=args.ingest_base_mpp)
         print(json.dumps({"metric": "Mpx/sec WSI tiled inference (all heads) from a JPEG-tiled pyramidal TIFF on disk", "value": ing["best"]["Mpx_s"], "unit": "Mpx/s", "n_gpus": 1,
                           "steps": 1, "warmup": 1, "ms_per_step": round(side * side / ing["best"]["Mpx_s"] / 1e3, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "f32", "data": "synthetic", "config": {"workload": "%dx%d JPEG-tiled pyramidal TIFF -> reader (thread-pool decode) -> pinned chunks ahead of the "
-                                                                                        "inference -> full Cerberus forward into device canvases; inference only, no labelling tail" % (side, side),
+                          "dtype": "f32", "data": "synthetic", "config": {"workload": "%dx%d slide from a JPEG-tiled pyramidal TIFF stored at %.4g mpp (%dx%d pixels) -> reader (tile decode on threads / worker processes%s) -> pinned chunks ahead "
+                                                                                        "of the inference -> full Cerberus forward into device canvases; inference only, no labelling tail" % (
+                                                                                            side, side, args.ingest_base_mpp, ing["stored"]["pixels"][0], ing["stored"]["pixels"][1],
+                                                                                            ", reduced to 0.5 mpp on the device" if args.ingest_base_mpp < 0.5 else ""),
                                                                             "streams": args.streams, "conv_algo": model.precision_decision()["conv_algo"]},
                           "ingest": ing}), flush=True)
         return

@@ -64,11 +64,12 @@ def decode_pool():
 # window; nothing but a few integers crosses the pipes.  Workers are fresh interpreters (cerberus_amd/decode_worker.py: no torch, no GPU context,
 # the parent's __main__ is not re-imported).
 _PROCS = {"n": None, "pool": None}
+_PROCS_LOCK = __import__("threading").Lock()
 PROC_MIN_TILES = 96  # below this many tiles a read stays on the thread pool (thumbnails, edge strips, tests)
 
 
 def decode_procs():
-    """Worker processes of large tile reads: CERB_DECODE_PROCS, default min(16, host cores / 4); 0 = threads only."""
+    """Worker processes of large tile reads: CERB_DECODE_PROCS, default min(16, host cores / (4 x ranks on this host)); 0 = threads only."""
     if os.environ.get("CERB_DECODE_WORKER") == "1":
         return 0
     v = os.environ.get("CERB_DECODE_PROCS")
@@ -78,7 +79,11 @@ def decode_procs():
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(0, min(16, n // 4))
+    try:
+        ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1))
+    except ValueError:
+        ranks = 1
+    return max(0, min(16, n // (4 * ranks)))
 
 
 class _WorkerPool(object):
@@ -147,15 +152,25 @@ def _proc_pool():
     n = decode_procs()
     if n <= 0:
         return None
-    if _PROCS["n"] != n:
-        import atexit
+    with _PROCS_LOCK:
+        if _PROCS["n"] != n:
+            import atexit
 
-        if _PROCS["pool"] is not None:
-            _PROCS["pool"].shutdown()
-        else:
-            atexit.register(_shutdown_procs)
-        _PROCS["pool"], _PROCS["n"] = _WorkerPool(n), n
-    return _PROCS["pool"]
+            if _PROCS["pool"] is not None:
+                _PROCS["pool"].shutdown()
+            else:
+                atexit.register(_shutdown_procs)
+            _PROCS["pool"], _PROCS["n"] = _WorkerPool(n), n
+        return _PROCS["pool"]
+
+
+def warm_decode_workers():
+    """Start the worker processes now, on a thread (0.2 - 0.3 s of interpreter + numpy + PIL start-up each, in parallel): a command line that knows it
+    will read tiled slides calls this before it loads the model, so that the first chunk of the first slide does not wait for them."""
+    import threading
+
+    if decode_procs() > 0 and _PROCS["pool"] is None:
+        threading.Thread(target=_proc_pool, name="cerb-decode-warm", daemon=True).start()
 
 
 def _shutdown_procs():

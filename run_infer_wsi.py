@@ -131,6 +131,10 @@ def main(argv=None):
         with open(os.path.join(args["--model"], "settings.yml")) as fh:
             settings = yaml.full_load(fh)
         decoders, model_args = settings["dataset_kwargs"]["req_target_code"], settings["model_kwargs"]
+    if (args["--wsi_file_ext"] or "").lower() in (".tif", ".tiff", ".svs"):  # tiled files: their tile-decode worker processes start underneath the model's loading
+        from cerberus_amd.reader import warm_decode_workers
+
+        warm_decode_workers()
     manager = InferManager(checkpoint_path=checkpoint, decoder_dict=decoders, model_args=model_args)
     # a second handle with the same weights (WSIRunner alternates batches between the two on two streams: +2 .. 3 %; CERB_WSI_STREAMS=1: one handle)
     # is made per slide, and only when cerberus_amd.stream_bands.plan_slide finds room for its workspace beside everything else

@@ -793,6 +793,13 @@ def test_bench_ingest_mode_file_fed_run_equals_resident():
     ing = line["ingest"]
     assert line["unit"] == "Mpx/s" and ing["slide"] == [3072, 3072] and ing["file"]["tiles"] == 144
     assert len(ing["decode"]["sweep"]) >= 3 and all(p_["Mpx_s"] > 10 for p_ in ing["decode"]["sweep"])
-    modes = {(e["decode_threads"], e["upload_ahead"]) for e in ing["end_to_end_from_file"]}
+    modes = {(e["decode_threads"], e["upload_ahead"]) for e in ing["end_to_end_from_file"] if not e["decode_processes"]}
     assert any(not a for _, a in modes) and sum(1 for _, a in modes if a) >= 3
+    assert any(e["decode_processes"] >= 4 for e in ing["end_to_end_from_file"]) and any("processes" in p_ for p_ in ing["decode"]["sweep"])
+    assert not any(e["reduced_on_device"] for e in ing["end_to_end_from_file"])
     assert ing["best"]["of_resident"] > 0.3 and line["value"] == ing["best"]["Mpx_s"]
+    # a 40x scan: 0.25 mpp on disk, read at 0.5 -- decoded by worker processes, reduced x2 on the device, canvases equal to those of the host-reduced rows
+    line = _bench([sys.executable, "bench.py", "--mode", "ingest", "--slide", "2048", "--streams", "1", "--ingest-base-mpp", "0.25"], timeout=900)
+    ing = line["ingest"]
+    assert ing["slide"] == [2048, 2048] and ing["stored"] == {"pixels": [4096, 4096], "mpp": 0.25, "read_at_mpp": 0.5} and ing["file"]["tiles"] == 256
+    assert all(e["reduced_on_device"] for e in ing["end_to_end_from_file"]) and ing["best"]["of_resident"] > 0.2
