@@ -289,10 +289,40 @@ class InferManager(object):
         # holds 8 batches' worth of patches or 64 Mpx of padded pixels
         win, osz = int(self.patch_input_shape), int(self.patch_output_shape)
 
+        # Host work around the GPU (decoding PNG / JPG files, .mat files, overlays) runs on small thread pools -- the reference gives both sides to worker
+        # processes (nr_inference_workers / nr_post_proc_workers, infer/tile.py:300-420): 96 tiles of 1000^2 spent 1.7 s on the GPU and 8 s in the main
+        # thread's decodes, savemat calls and overlay drawing, one after the other.  zlib, libjpeg, file I/O and numpy's copies release the interpreter
+        # lock.  CERB_TILE_IO_THREADS (default 4; 0 = everything in the main thread, the old order).
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+
+        n_io = max(0, int(os.environ.get("CERB_TILE_IO_THREADS", "4")))
+        readers = ThreadPoolExecutor(max_workers=n_io, thread_name_prefix="cerb-tile-read") if n_io else None
+        writers = ThreadPoolExecutor(max_workers=n_io, thread_name_prefix="cerb-tile-write") if n_io else None
+
+        def load(fp):
+            return np.array(Image.open(fp).convert("RGB"))
+
+        def decoded():  # (path, pixels) in order, up to 4 x n_io files decoded ahead
+            if readers is None:
+                for fp in todo:
+                    yield fp, load(fp)
+                return
+            ahead, it = deque(), iter(todo)
+            for fp in it:
+                ahead.append((fp, readers.submit(load, fp)))
+                if len(ahead) >= 4 * n_io:
+                    break
+            while ahead:
+                fp, fut = ahead.popleft()
+                nxt = next(it, None)
+                if nxt is not None:
+                    ahead.append((nxt, readers.submit(load, nxt)))
+                yield fp, fut.result()
+
         def grouped_results():  # lazily: one group of decoded files and its canvases alive at a time
             cur, n_patch, n_px = [], 0, 0
-            for idx, fp in enumerate(todo):
-                img = np.array(Image.open(fp).convert("RGB"))
+            for idx, (fp, img) in enumerate(decoded()):
                 cur.append((fp, img))
                 n_patch += int(math.ceil(img.shape[0] / osz)) * int(math.ceil(img.shape[1] / osz))
                 n_px += (img.shape[0] + win) * (img.shape[1] + win)
@@ -303,6 +333,21 @@ class InferManager(object):
                         yield f, im, r
                     cur, n_patch, n_px = [], 0, 0
 
+        def write_outputs(base, img, mats, info_all, pclass_np):
+            for tissue, mat in mats:
+                os.makedirs("%s/%s_mat/" % (self.output_dir, tissue.lower()), exist_ok=True)
+                sio.savemat("%s/%s_mat/%s.mat" % (self.output_dir, tissue.lower(), base), mat)
+            # overlay of the x2 nearest-upscaled source with every instance contour (infer/tile.py:251-257)
+            from .viz import up2_nearest, visualize_instances_dict_orig
+
+            os.makedirs("%s/overlay/" % self.output_dir, exist_ok=True)
+            Image.fromarray(visualize_instances_dict_orig(up2_nearest(img), info_all)).save("%s/overlay/%s.jpg" % (self.output_dir, base))
+            if pclass_np is not None:
+                os.makedirs("%s/pclass_mat/" % self.output_dir, exist_ok=True)
+                sio.savemat("%s/pclass_mat/%s.mat" % (self.output_dir, base), {"pclass": pclass_np})
+            print("Done Assembling %s" % base)
+
+        pending = deque()
         for fp, img, res in grouped_results():
             base = pathlib.Path(fp).stem
             prev_type = None
@@ -310,7 +355,7 @@ class InferManager(object):
             def up2(t):  # cv2.resize(fx=2, fy=2, INTER_NEAREST) of an integer map, on the device
                 return t.repeat_interleave(2, dim=0).repeat_interleave(2, dim=1).contiguous()
 
-            info_all = {}
+            info_all, mats = {}, []
             for tissue, lab in res["inst"].items():
                 lab_np = lab.cpu().numpy()
                 tmap = res["type"].get(tissue)
@@ -320,18 +365,20 @@ class InferManager(object):
                 # instance table on the GPU; the reference re-uses the previous tissue's type map for Lumen (infer/tile.py:196-202)
                 info = get_inst_info_dict(up2(lab), prev_type)
                 info_all[tissue] = info
-                os.makedirs("%s/%s_mat/" % (self.output_dir, tissue.lower()), exist_ok=True)
                 mat = {"inst_map": lab_np.astype(np.float64) if tissue != "Nuclei" else lab_np,
                        "type": [d.get("type", -1) for d in info.values()], "id": list(info.keys())}
                 if tmap_np is not None:
                     mat["type_map"] = tmap_np.astype(np.float32)
-                sio.savemat("%s/%s_mat/%s.mat" % (self.output_dir, tissue.lower(), base), mat)
-            # overlay of the x2 nearest-upscaled source with every instance contour (infer/tile.py:251-257)
-            from .viz import up2_nearest, visualize_instances_dict_orig
-
-            os.makedirs("%s/overlay/" % self.output_dir, exist_ok=True)
-            Image.fromarray(visualize_instances_dict_orig(up2_nearest(img), info_all)).save("%s/overlay/%s.jpg" % (self.output_dir, base))
-            if res["pclass"] is not None:
-                os.makedirs("%s/pclass_mat/" % self.output_dir, exist_ok=True)
-                sio.savemat("%s/pclass_mat/%s.mat" % (self.output_dir, base), {"pclass": res["pclass"].cpu().numpy()})
-            print("Done Assembling %s" % base)
+                mats.append((tissue, mat))
+            pclass_np = res["pclass"].cpu().numpy() if res["pclass"] is not None else None
+            if writers is None:
+                write_outputs(base, img, mats, info_all, pclass_np)
+            else:
+                pending.append(writers.submit(write_outputs, base, img, mats, info_all, pclass_np))
+                while len(pending) > 4 * n_io:  # bounded: a tile's maps stay in RAM until its files are written
+                    pending.popleft().result()
+        while pending:
+            pending.popleft().result()
+        for pool in (readers, writers):
+            if pool is not None:
+                pool.shutdown(wait=True)
