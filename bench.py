@@ -624,8 +624,20 @@ def ingest_leg(model, dev, side, batch, streams, tmpdir=None, sweep=(1, 2, 4, 8,
             run.twin = model.twin()
         y0, y1 = run.slab_rows()
         os.environ["CERB_DECODE_THREADS"] = str(max(d["threads"] for d in dec if "threads" in d))
-        host = np.ascontiguousarray(rows[y0:y1])  # (a stored level finer than 0.5 mpp: reduced on the HOST here -- the reference the device path is held to)
-        slab = torch.from_numpy(host).to(dev)
+        if kf > 1:
+            # a stored level finer than 0.5 mpp: the slab comes from the device reduction, and a 1024-row band of it is held to the HOST statement
+            # (reader.read_bounds, 9 Mpx/s on one thread: the whole slide that way would take longer than everything else in this leg)
+            up0 = SlabUploader(rows, y0, y1)
+            up0.upload_until(y1 - y0)
+            torch.cuda.synchronize()
+            slab = up0.slab
+            band = min(1024, y1 - y0)
+            assert np.array_equal(slab[:band].cpu().numpy(), rows[y0:y0 + band]), "the device reduction returned other bytes than reader.read_bounds"
+            host = slab.cpu().numpy()
+            del up0
+        else:
+            host = np.ascontiguousarray(rows[y0:y1])
+            slab = torch.from_numpy(host).to(dev)
         run.infer_patches(slab, y0, 0, min(run.n_patches, 4 * batch))  # warm-up
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -1072,9 +1084,9 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
             line["ingest"] = ingest_leg(model, dev, 12288, WSI_BATCH, 1)
         except Exception as e:  # never fails the headline
             line["ingest"] = {"error": str(e)[:300]}
-        # the same for a 40x scan: 16384^2 stored pixels at 0.25 mpp read at 0.5 mpp (decode processes + the x2 reduction on the device)
+        # the same for a 40x scan: 24576^2 stored pixels at 0.25 mpp read at 0.5 mpp (decode processes + the x2 reduction on the device)
         try:
-            ing40 = ingest_leg(model, dev, 8192, WSI_BATCH, 1, sweep=(1, 8), base_mpp=0.25)
+            ing40 = ingest_leg(model, dev, 12288, WSI_BATCH, 1, sweep=(1, 8), base_mpp=0.25)
             line["ingest_40x"] = {k: ing40[k] for k in ("slide", "stored", "file", "decode", "inference_resident", "end_to_end_from_file", "best")}
         except Exception as e:  # never fails the headline
             line["ingest_40x"] = {"error": str(e)[:300]}
