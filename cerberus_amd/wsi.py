@@ -279,8 +279,16 @@ class WSIRunner(object):
             self._turn += 1
             k = (i & 1) if self.twin is not None else 0  # (after the second handle was dropped: everything on side stream 0, one handle = one stream)
             try:
-                with torch.cuda.stream(self._side[k]):
-                    one(nets[k], b0)
+                try:
+                    with torch.cuda.stream(self._side[k]):
+                        one(nets[k], b0)
+                except _lib.CerberusHipAllocError:
+                    # the library allocates from the driver, and the blocks torch's allocator keeps idle (a previous slide's canvases: they are not
+                    # handed back between slides, asking the driver for 200 GB again costs seconds) are invisible to it: release them and try once more
+                    torch.cuda.synchronize(self.dev)
+                    torch.cuda.empty_cache()
+                    with torch.cuda.stream(self._side[k]):
+                        one(nets[k], b0)
             except _lib.CerberusHipAllocError as e:
                 # the second handle's workspace did not fit after all (the plan is an estimate): go on with one handle instead of losing the slide.
                 # (CERB_ERR_ALLOC, not a message match; a failure on the FIRST handle stays fatal: there is nothing left to drop)

@@ -26,8 +26,8 @@ ONE_CALL_PX = int(float(os.environ.get("CERB_ONE_CALL_MPX", "400")) * 1e6)
 
 
 def _release_device_memory():
-    """Between two slides: the labelling workspace (up to 96 B / px of the largest call) and the allocator's cached blocks go back to the driver, so that
-    stream_bands.plan_slide prices the next slide against the HBM it can really have."""
+    """Between two slides: the labelling workspace (up to 96 B / px of the largest call) goes back to the allocator and everything unreachable is
+    collected, so that stream_bands.plan_slide prices the next slide against the HBM it can really have."""
     import gc
 
     import torch
@@ -36,8 +36,8 @@ def _release_device_memory():
 
     postproc._ws_cache.clear()
     gc.collect()
-    if torch.cuda.is_available():
-        torch.cuda.empty_cache()
+    # (the allocator keeps the freed blocks: hbm_budget counts them as free, a slide of the same size gets them back at once, and handing ~200 GB
+    #  to the driver and asking for it again cost 4.5 s per 3.2-Gpx slide; WSIRunner empties the cache when a handle's own allocation fails)
 
 
 def _basename(path, ext):
@@ -171,7 +171,10 @@ def main(argv=None):
             log.info("Processing %s ..." % base)
         # nothing of the previous slide may still hold HBM when this one is priced: its runner and canvases, label maps, closures over them
         # (a directory of slides is the reference's normal job; the second 40000^2 slide used to be planned against what the first had left)
-        run = maps = inst = pre = progress = up = regions = records = ref_nuclei = rank_parts = source = own_parts = None  # noqa: F841
+        # (every name the loop body binds to something slide-sized, on the device or the host: three 3.2-Gpx slides in a row showed `nuc_only` and
+        #  `pmap` -- the label maps and the tissue map of the previous slide, 21 GB -- still alive here)
+        run = maps = inst = nuc_only = nb = lab = v = d = dst = rec = records = pmap = pre = progress = pending = up = slab_dev = source = None  # noqa: F841
+        regions = ref_nuclei = parts = extra = prebuilt = rank_parts = own_parts = host = reader = mask = sel = guard = flag = None  # noqa: F841
         _release_device_memory()
         t0 = time.perf_counter()
         host, H, W, seed, reader = _open_slide(path, float(args["--wsi_proc_mag"]))

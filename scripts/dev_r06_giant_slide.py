@@ -136,6 +136,8 @@ def main():
     assert rows[H - 300:H - 290].shape == (10, W, 3)
     del rows, r
     res = {"file_pixels": [fH, fW], "base_mpp": base_mpp, "slide": [H, W], "pixels": H * W, "over_int32": H * W > 2 ** 31, "glass_share_of_blocks": glass, "file_MB": round(size / 1e6, 1), "build_s": round(build_s, 1)}
+    for c in range(1, int(os.environ.get("GIANT_COPIES", "1"))):  # a directory of slides: the same file under more names
+        os.symlink(path, os.path.join(td, "in", "giant%d.tif" % (c + 1)))
     res["background_bias_shifts"] = write_model_dir(os.path.join(td, "model"))
     cmd = [sys.executable, os.path.join(ROOT, "run_infer_wsi.py"), "--model=%s" % os.path.join(td, "model"), "--gpu=0", "--input_dir=%s" % os.path.join(td, "in"), "--wsi_file_ext=.tif",
            "--output_dir=%s" % os.path.join(td, "out"), "--logging_dir=%s" % os.path.join(td, "log"), "--batch_size=64", "--patch_input_shape=256",
@@ -167,6 +169,8 @@ def main():
         for f in sorted(os.listdir(ld)):
             logs += open(os.path.join(ld, f)).read().splitlines()
     res["log"] = logs[-60:]
+    res["memory_plans"] = [l.split("Memory plan: ")[1] for l in logs if "Memory plan: " in l]
+    res["overall_times"] = [float(l.split("Overall Time: ")[1]) for l in logs if "Overall Time: " in l]
     res["stderr_tail"] = p.stderr.splitlines()[-25:]
     if p.returncode != 0 and out_json:
         open(out_json + ".stderr.txt", "w").write(p.stderr[-200000:])
