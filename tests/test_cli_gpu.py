@@ -209,7 +209,7 @@ def test_bench_contract_eight_ranks_time_sharing_one_gpu():
         assert len(lines) == 1, r.stdout[-2000:]
         return json.loads(lines[0])
 
-    one = run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-train-leg", "--slide", "8192"])
+    one = run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-train-leg", "--no-ingest-leg", "--slide", "8192"])
     eight = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29541",
                  "bench.py", "--gpus", "8", "--steps", "4", "--warmup", "1", "--backend", "gloo", "--slide", "8192", "--streams", "1"])  # (eight ranks share ONE GPU's HBM here: no second handle each)
     assert eight["n_gpus"] == 8 and eight["scaling"] == "strong" and eight["config"]["tiles"] == 1024 and "cpu_baseline" not in eight and "train_step" not in eight
@@ -230,8 +230,8 @@ def test_bench_nccl_branch_at_world_one():
     """The RCCL code path on the hardware there is: `init_process_group("nccl", device_id=...)`, the warm-up gather, run_distributed's
     all-gathers and the label / class-map gathers on CUDA tensors all execute with ONE rank (RCCL accepts a single-rank communicator),
     and the result equals the plain single-process run."""
-    ref = _bench([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-train-leg", "--slide", "2048"])
-    one = _bench([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-train-leg", "--slide", "2048", "--force-dist", "--backend", "nccl"])
+    ref = _bench([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-train-leg", "--no-ingest-leg", "--slide", "2048"])
+    one = _bench([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-train-leg", "--no-ingest-leg", "--slide", "2048", "--force-dist", "--backend", "nccl"])
     assert one["n_gpus"] == 1 and one["multi_gpu"] is not None and "root_gather" in one["multi_gpu"]
     for t in ("Nuclei", "Gland", "Lumen"):
         assert one["postproc"][t]["n_inst"] == ref["postproc"][t]["n_inst"]
@@ -726,7 +726,7 @@ def test_bench_configs2_slide_20000_full_size_one_vs_three_local_bands():
     labelled on the GPU -- once with the nuclei map labelled in one call and once in three local bands through the band protocol: no instance cut by
     a window (n_truncated == 0), the SAME instance counts either way, and the tail consuming the class canvases this job's inference wrote
     (bench.py checks their checksums against the canvases).  The one-band line is what profiles/r05_bench_wsi_20000.json holds."""
-    common = [sys.executable, "bench.py", "--slide", "20000", "--steps", "4", "--warmup", "1", "--no-train-leg", "--no-cpu-baseline", "--no-dat", "--no-ref-tiling"]
+    common = [sys.executable, "bench.py", "--slide", "20000", "--steps", "4", "--warmup", "1", "--no-train-leg", "--no-ingest-leg", "--no-cpu-baseline", "--no-dat", "--no-ref-tiling"]
     one = _bench(common + ["--max-band-mpx", "420"], timeout=1500)
     three = _bench(common + ["--max-band-mpx", "150"], timeout=1500)
     assert one["config"]["slide"] == [20000, 20000] and one["config"]["tiles"] == 6241 and "configs[2]" in one["config"]["workload"]
@@ -745,7 +745,7 @@ def test_bench_slide_20000_labels_the_canvases_its_own_inference_wrote():
     (the seeded weights with a sparse-foreground bias calibration: ~3 % of a noise slide's pixels are foreground), at BASELINE configs[2]'s full
     20000^2: the inference -> labelling data dependency at slide scale.  One labelling call against three local bands: no instance cut by a window,
     no unresolved border instance, the same instance counts -- and well above zero, i.e. the labelling really had network-made instances to own."""
-    common = [sys.executable, "bench.py", "--slide", "20000", "--steps", "4", "--warmup", "1", "--no-train-leg", "--no-cpu-baseline", "--no-dat", "--no-ref-tiling",
+    common = [sys.executable, "bench.py", "--slide", "20000", "--steps", "4", "--warmup", "1", "--no-train-leg", "--no-ingest-leg", "--no-cpu-baseline", "--no-dat", "--no-ref-tiling",
               "--tail-from-inference"]
     one = _bench(common + ["--max-band-mpx", "420"], timeout=1500)
     three = _bench(common + ["--max-band-mpx", "150"], timeout=1500)
