@@ -179,6 +179,20 @@ def _shutdown_procs():
         _PROCS["pool"], _PROCS["n"] = None, None
 
 
+_SHM_LIVE = {}  # shared blocks of live readers: unlinked at exit whatever became of their readers (/dev/shm outlives the process otherwise)
+
+
+def _unlink_live_shm():
+    for sh in list(_SHM_LIVE.values()):
+        try:
+            sh.close()
+            sh.unlink()
+        except Exception:  # noqa: BLE001
+            pass
+    _SHM_LIVE.clear()
+
+
+__import__("atexit").register(_unlink_live_shm)
 _WORKER = {"readers": {}, "shm": {}}
 
 
@@ -645,15 +659,18 @@ class TiffReader(WSIReader):
         sh = getattr(self, "_shm", None)
         if sh is None or sh.size < nbytes:
             if sh is not None:
+                _SHM_LIVE.pop(sh.name, None)
                 sh.close()
                 sh.unlink()
             self._shm = sh = shared_memory.SharedMemory(create=True, size=int(nbytes * 1.25) + 4096)
+            _SHM_LIVE[sh.name] = sh
         return sh
 
     def __del__(self):
         sh = getattr(self, "_shm", None)
         if sh is not None:
             try:
+                _SHM_LIVE.pop(sh.name, None)
                 sh.close()
                 sh.unlink()
             except Exception:  # noqa: BLE001  (interpreter shutdown)
@@ -679,7 +696,11 @@ class TiffReader(WSIReader):
                 n = _PROCS["n"]
                 per = max(8, -(-len(tiles) // (4 * n)))
                 mpp = None if self.info.mpp is None else tuple(float(v) for v in self.info.mpp)
-                procs.run([(self.path, mpp, level, tiles[i:i + per], window, sh.name, shape) for i in range(0, len(tiles), per)])
+                try:
+                    procs.run([(self.path, mpp, level, tiles[i:i + per], window, sh.name, shape) for i in range(0, len(tiles), per)])
+                except BaseException:
+                    _shutdown_procs()  # a worker may be gone or mid-reply: the next large read starts fresh ones
+                    raise
                 got = np.ndarray(shape, np.uint8, buffer=sh.buf)
                 if dest is None:
                     return got.copy()

@@ -547,6 +547,7 @@ class DatWriter(object):
         env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + env.get("PYTHONPATH", "")
         env.pop("HIP_VISIBLE_DEVICES", None)
         self._proc = subprocess.Popen([sys.executable, "-m", "cerberus_amd.inst_info", src, path, xtra], env=env)
+        self._ram_src = src if src == cand else None  # (the writer removes its input when it is done; a writer that FAILED leaves it -- in RAM: join() removes it)
         return self
 
     def join(self):
@@ -556,6 +557,9 @@ class DatWriter(object):
         if proc is not None:
             rc = proc.wait()
             self._proc = None
+            ram = getattr(self, "_ram_src", None)
+            if ram and os.path.exists(ram):
+                os.remove(ram)
             if rc != 0:
                 raise RuntimeError("writing %s failed in the writer process (exit code %d)" % (self.path, rc))
         if self._pid is not None:
