@@ -173,6 +173,16 @@ def warm_decode_workers():
         threading.Thread(target=_proc_pool, name="cerb-decode-warm", daemon=True).start()
 
 
+def _shm_has_room(nbytes):
+    """Worker processes hand pixels over through a POSIX shared-memory block: a container with the default 64 MB /dev/shm has no room for a chunk
+    of a slide, and writing past a tmpfs' size is a SIGBUS, not an exception -- such hosts decode on threads."""
+    try:
+        st = os.statvfs("/dev/shm")
+        return st.f_bavail * st.f_frsize > int(nbytes * 1.25) + (64 << 20)
+    except OSError:
+        return False
+
+
 def _shutdown_procs():
     if _PROCS["pool"] is not None:
         _PROCS["pool"].shutdown()
@@ -685,27 +695,32 @@ class TiffReader(WSIReader):
         dest = None if out is None else out[: shape[0], : shape[1]]
         window = (x0, y0, x1, y1)
         tiles = [(ty, tx) for ty in range(y0 // p.th, -(-y1 // p.th)) for tx in range(x0 // p.tw, -(-x1 // p.tw))]
-        procs = _proc_pool() if len(tiles) >= PROC_MIN_TILES and p.compression == 7 else None
+        nbytes = shape[0] * shape[1] * 3
+        procs = _proc_pool() if (len(tiles) >= PROC_MIN_TILES and p.compression == 7 and not _PROCS.get("off") and _shm_has_room(nbytes)) else None
         if procs is not None:
             import threading
 
             lock = self.__dict__.setdefault("_shm_lock", threading.Lock())
             with lock:
-                nbytes = shape[0] * shape[1] * 3
                 sh = self._shared_block(nbytes)
                 n = _PROCS["n"]
                 per = max(8, -(-len(tiles) // (4 * n)))
                 mpp = None if self.info.mpp is None else tuple(float(v) for v in self.info.mpp)
                 try:
                     procs.run([(self.path, mpp, level, tiles[i:i + per], window, sh.name, shape) for i in range(0, len(tiles), per)])
-                except BaseException:
-                    _shutdown_procs()  # a worker may be gone or mid-reply: the next large read starts fresh ones
-                    raise
-                got = np.ndarray(shape, np.uint8, buffer=sh.buf)
-                if dest is None:
-                    return got.copy()
-                np.copyto(dest, got)
-                return dest
+                    got = np.ndarray(shape, np.uint8, buffer=sh.buf)
+                    if dest is None:
+                        return got.copy()
+                    np.copyto(dest, got)
+                    return dest
+                except Exception as e:  # noqa: BLE001
+                    # a worker is gone or failed (a container whose /dev/shm filled up kills it with SIGBUS): no more worker processes in this run, and
+                    # this read is done again on the threads -- which raise the real error themselves if the file is the problem
+                    import logging
+
+                    _shutdown_procs()
+                    _PROCS["off"] = True
+                    logging.getLogger("cerberus_amd.reader").warning("tile-decode worker processes switched off (%s): decoding on threads", str(e).splitlines()[-1][:200])
         out = np.zeros(shape, np.uint8) if dest is None else dest
         if dest is not None:
             dest[...] = 0
