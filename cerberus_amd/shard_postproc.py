@@ -623,6 +623,12 @@ def gather_parts(local, dist, rank, world, dev, prof=None):
     """Per-rank instance arrays -> the root's `parts` list ([(tissue, tab, cnts, pts, offs, has_type, ds_factor)], the format of
     cerberus_amd.wsi.collect_wsi_inst_arrays): per tissue one all-gather of the two lengths, then three padded gathers (table rows, contour
     counts, contour points).  ~0.36 GB for the 885 k instances of a 40000^2 slide against 21 GB of label + class maps.  None off the root."""
+    if dist is None or world == 1:  # one rank: its own arrays are the root's (a streamed slide's per-sub-band arrays: no pass over the whole label maps,
+        out = []                    # and no 4 - 8 B/px union-find workspace for them -- 77 GB for a 9.7-Gpx slide)
+        for t, (tab, cnts, pts, has_type, ds) in local.items():
+            cn = np.asarray(cnts, np.int32)
+            out.append((t, np.asarray(tab), cn, np.asarray(pts), np.cumsum(cn.astype(np.int64)) - cn, has_type, ds))
+        return out
     parts = [] if rank == 0 else None
     moved = 0
     t0 = _tock(prof)

@@ -223,7 +223,9 @@ def main(argv=None):
                     return up.slab, up.upload_until
             pprof, records, ref_nuclei, rank_parts = {}, None, None, None
             several = dist is not None and world > 1
-            own_parts = [] if (several and not args["--save_label_maps"]) else None
+            # the instance arrays are taken from every sub-band's window while it is in HBM -- on one rank as well (round 6: the whole-slide table +
+            # contour pass over a 9.7-Gpx slide's label maps wanted a 77 GB union-find workspace and 5 s); --save_label_maps keeps the whole-map pass
+            own_parts = [] if not args["--save_label_maps"] else None
             inst, _, maps = infer_and_label_streamed(manager.net, source, (H, W), win, out, batch, plan.sub_bands, prof=pprof, rank=rank, world=world,
                                                      dist=dist if several else None, parts=own_parts, watch=watch)
             torch.cuda.synchronize()
@@ -237,6 +239,10 @@ def main(argv=None):
                         rank_parts = gather_parts(own_parts[0], dist, rank, world, dev_, prof=pprof)
                 with watch.phase("map gather to rank 0 (%s)" % base):
                     inst, maps = gather_streamed_maps(inst, maps, (H, W), out, rank, world, dist, labels=own_parts is None)
+            elif own_parts is not None:
+                from cerberus_amd.shard_postproc import gather_parts
+
+                rank_parts = gather_parts(own_parts[0], None, 0, 1, None)
             t1 = t2 = time.perf_counter()
             if log:
                 log.info("Inference Time: {0} ({1} sub-bands streamed through HBM)".format(pprof.get("stream_infer_s"), plan.sub_bands))

@@ -560,9 +560,17 @@ def test_slide_streamed_in_sub_bands_equals_the_resident_run(manager):
                 calls.append((y0, y1))
                 return slide[y0:y1].contiguous()
 
-            prof = {}
-            got, info, small = infer_and_label_streamed(net, source, (H, W), 256, 256, 4, nb, margin=margin, guard=16, twin=twin, prof=prof)
+            prof, own = {}, []
+            got, info, small = infer_and_label_streamed(net, source, (H, W), 256, 256, 4, nb, margin=margin, guard=16, twin=twin, prof=prof, parts=own)
             assert len(calls) == nb and calls[0][0] == 0 and calls[-1][1] == H and "stream_infer_s" in prof
+            if strict:  # the arrays taken from the sub-bands' windows (what run_infer_wsi.py hands the dictionary writer) = the arrays of the whole maps
+                from cerberus_amd.shard_postproc import gather_parts
+                from cerberus_amd.wsi import collect_wsi_inst_arrays
+
+                mine, whole = _entries(gather_parts(own[0], None, 0, 1, None)), _entries(collect_wsi_inst_arrays(got, small, (H, W)))
+                assert set(mine) == set(whole) == set(want)
+                for t_ in whole:
+                    assert mine[t_] == whole[t_] and len(whole[t_]) > 5, (nb, t_, len(mine[t_]), len(whole[t_]))
             assert set(got) == set(want) and set(small) == set(want_small)
             for k in want_small:
                 assert torch.equal(small[k], want_small[k]), (nb, k)
