@@ -718,6 +718,15 @@ def sparse_foreground_weights(model, sd, dev, q=0.03):
     return new, shifts
 
 
+def _warm_handles(run, slab, y0, p0, p1):
+    """Untimed warm-up of the slide runner on patches [p0, p1): two unjoined calls, so that the batch alternation reaches BOTH handles even when the
+    range is a single batch (a 3072^2 test slide: a joined one-batch call stays on the first handle, and the second one then allocated the
+    workspace of its algorithm inside the next timed region -- 0.5 s of hipMalloc read as 15 Mpx/s).  Recomputes, caches nothing but memory."""
+    for _ in range(2):
+        run.infer_patches(slab, y0, p0, p1, join=False)
+    run.join()
+
+
 def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
     from collections import OrderedDict
 
@@ -774,7 +783,7 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
         if torch.cuda.mem_get_info(dev)[0] > need:
             run.twin = model.twin()
             for k in range(min(max(args.warmup, 1), K)):
-                run.infer_patches(slab, y0, cuts[k], min(cuts[k] + 2 * WSI_BATCH, cuts[k + 1]))
+                _warm_handles(run, slab, y0, cuts[k], min(cuts[k] + 2 * WSI_BATCH, cuts[-1]))
             torch.cuda.synchronize()
         else:
             args.streams = 1
@@ -965,7 +974,7 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
             for h in (model, run.twin):
                 if h is not None:
                     h.set_conv_algo(algo)
-            run.infer_patches(slab, y0, cuts[0], min(cuts[0] + 2 * WSI_BATCH, cuts[1]))  # warm-up (workspaces of this algorithm)
+            _warm_handles(run, slab, y0, cuts[0], min(cuts[0] + 2 * WSI_BATCH, cuts[-1]))  # warm-up (workspaces of this algorithm, on BOTH handles)
             torch.cuda.synchronize()
 
             def part():
