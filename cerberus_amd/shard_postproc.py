@@ -422,16 +422,25 @@ def halo_exchange(dist, rank, world, up, down, above, below):
     """Neighbour strips over point-to-point links, in two rounds of disjoint PAIRS: round 0 pairs (0,1), (2,3), ..., round 1 pairs (1,2),
     (3,4), ...  In a round a rank talks to at most one peer and posts its send and its receive in one group, so no rank ever posts a send
     whose matching receive sits behind another blocking operation -- the pattern cannot deadlock whatever the backend's ordering rules
-    (RCCL groups, gloo's per-pair queues), and adjacent pairs use different xGMI links at the same time."""
+    (RCCL groups, gloo's per-pair queues), and adjacent pairs use different xGMI links at the same time.
+    RCCL moves dense buffers only (a strided view is refused at the call, and only with more than one rank -- a fault the one-rank RCCL tests and
+    the host-staged gloo ranks cannot show): strided strips are sent from a dense copy and received through one."""
+    def dense(t):
+        return t if (t is None or t.is_contiguous()) else t.contiguous()
+
     for rnd in (0, 1):
-        ops = []
+        ops, back = [], None
         if rank % 2 == rnd and rank < world - 1:      # lower rank of the pair (rank, rank + 1)
-            ops = [dist.P2POp(dist.isend, down, rank + 1), dist.P2POp(dist.irecv, below, rank + 1)]
+            buf = dense(below)
+            ops, back = [dist.P2POp(dist.isend, dense(down), rank + 1), dist.P2POp(dist.irecv, buf, rank + 1)], (below, buf)
         elif rank % 2 != rnd and rank > 0:            # upper rank of the pair (rank - 1, rank)
-            ops = [dist.P2POp(dist.irecv, above, rank - 1), dist.P2POp(dist.isend, up, rank - 1)]
+            buf = dense(above)
+            ops, back = [dist.P2POp(dist.irecv, buf, rank - 1), dist.P2POp(dist.isend, dense(up), rank - 1)], (above, buf)
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+            if back[0] is not back[1]:
+                back[0].copy_(back[1])
 
 
 def _publish_and_resolve(st, n_owned, dev, dist, rank, world, relabel_fn):

@@ -718,3 +718,50 @@ def test_slide_memory_plan_picks_resident_twin_streamed_or_refuses():
     # sub-bands are never shorter than two halo margins (the band protocol's invariant)
     tiny = plan_slide(Net(), (4096, 2048), 256, 256, 4, budget=plan_slide(Net(), (4096, 2048), 256, 256, 4, budget=1e12, want_twin=False).need - 1e6)
     assert tiny.mode == "streamed" and (16 // tiny.sub_bands) * 256 >= 1024
+
+
+def test_halo_exchange_hands_the_backend_dense_buffers_only():
+    """RCCL refuses strided views in isend / irecv -- and only with more than one rank, which no box of this pool can show.  A stand-in backend that
+    refuses them the same way: halo_exchange must send strided strips from dense copies and fill strided receive windows through dense buffers, for
+    the lower and the upper rank of a pair, in both rounds."""
+    from cerberus_amd.shard_postproc import halo_exchange
+
+    class Strict(object):
+        isend, irecv = "isend", "irecv"
+
+        def __init__(self):
+            self.sent, self.calls = [], 0
+
+        def P2POp(self, op, t, peer):
+            assert t.is_contiguous(), "a strided tensor reached the backend (%s to/from rank %d)" % (op, peer)
+            return (op, t, peer)
+
+        def batch_isend_irecv(self, ops):
+            self.calls += 1
+            for op, t, peer in ops:
+                if op == "irecv":
+                    t.fill_(100.0 + peer)
+                else:
+                    self.sent.append((peer, t.clone()))
+
+            class R(object):
+                def wait(self):
+                    pass
+
+            return [R()]
+
+    wide = torch.arange(6 * 10, dtype=torch.float32).reshape(6, 10)
+    for rank, world in ((0, 2), (1, 2), (1, 3), (2, 4)):
+        d = Strict()
+        up, down = wide[:2, :7], wide[4:, :7]                      # column-cropped views: strided
+        above = torch.zeros(2, 10)[:, :7] if rank > 0 else None     # strided receive windows
+        below = torch.zeros(2, 10)[:, :7] if rank < world - 1 else None
+        assert not up.is_contiguous() and (above is None or not above.is_contiguous())
+        halo_exchange(d, rank, world, up if rank > 0 else None, down if rank < world - 1 else None, above, below)
+        assert d.calls == (1 if rank in (0, world - 1) else 2)
+        if above is not None:
+            assert bool((above == 100.0 + rank - 1).all())
+        if below is not None:
+            assert bool((below == 100.0 + rank + 1).all())
+        for peer, t in d.sent:
+            assert torch.equal(t, up if peer == rank - 1 else down)
