@@ -1,4 +1,5 @@
-"""Build recipe for libcerberus_hip.so (gfx950 only, in-tree so the .so travels with gpurun snapshots).
+"""Build recipe for libcerberus_hip.so (gfx950 only, in-tree so the .so travels with gpurun snapshots) and libcerberus_host.so (the reader's
+host-side byte codecs: plain C, gcc, no HIP -- include/cerberus_host.h).
 
     python -m cerberus_amd.build            # incremental
     python -m cerberus_amd.build --force
@@ -13,6 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcerberus_hip.so")
 LIB_DEV = os.path.join(HERE, "libcerberus_hip_dev.so")
+LIB_HOST = os.path.join(HERE, "libcerberus_host.so")
+HOST_SOURCES = ["host_codecs.c"]
 SOURCES = ["conv_igemm.hip", "conv_wino.hip", "conv_wino4.hip", "conv_wino4b.hip", "conv_wino4p.hip", "net_kernels.hip", "postproc.hip", "slide_kernels.hip", "train_kernels.hip", "head_train.hip", "conv_wgrad.hip", "conv_wgrad_wino.hip", "pack_kernels.hip", "cerb_api.hip", "cerb_train.hip"]
 # The translation units that read developer A/B switches (cerb_common.h: cerb_dev_getenv).  The product library compiles them WITHOUT the switches
 # (every one folds to its default); the same units compiled with -DCERB_DEV_SWITCHES, linked with the other units' objects, make
@@ -36,7 +39,19 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def build_host(force=False, verbose=True):
+    """libcerberus_host.so: the TIFF LZW / PackBits / predictor codecs of cerberus_amd/reader.py (torch-free decode workers load it too)."""
+    srcs = [os.path.join(CSRC, f) for f in HOST_SOURCES]
+    if force or _stale(LIB_HOST, srcs + [os.path.join(os.path.dirname(HERE), "include", "cerberus_host.h")]):
+        cmd = [os.environ.get("CC", "gcc"), "-O3", "-std=c11", "-fPIC", "-shared", "-Wall", "-Wextra", "-pthread", "-o", LIB_HOST] + srcs + ["-lz"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB_HOST
+
+
 def build(force=False, verbose=True):
+    build_host(force, verbose)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "cerberus_hip.h"))

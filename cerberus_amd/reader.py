@@ -12,7 +12,7 @@ tiatoolbox / OpenSlide are not in this image, so the back ends are this package'
   * TiffReader       -- baseline / BigTIFF, striped or TILED, pyramid pages, compression none / deflate (+ horizontal predictor) /
                         JPEG tiles (decoded by PIL, JPEGTables spliced in), resolution from XResolution / ResolutionUnit or an
                         Aperio `MPP = ...` description: generic tiled TIFFs and `.svs` files whose tiles are JPEG.  JPEG 2000 tiles
-                        (Aperio 33003 / 33005) is refused with a clear message; LZW and PackBits are decoded in pure Python (slow, for compatibility).
+                        (Aperio 33003 / 33005) is refused with a clear message; LZW and PackBits tiles are decoded by libcerberus_host.so (csrc/host_codecs.c, include/cerberus_host.h).
 Resampling: the pyramid level with the largest downsample not above the request is read and reduced by a box (area) filter --
 exact pixel means for integer factors, PIL's BOX filter otherwise (tiatoolbox uses cv2 INTER_AREA there; unpinned, both libraries
 are absent).  Everything here is host I/O; pixels reach the GPU through wsi.SlabUploader chunk by chunk under the inference.
@@ -636,15 +636,26 @@ class TiffReader(WSIReader):
             return np.asarray(img)[:rows, :cols]
         elif c in (33003, 33005):
             raise NotImplementedError("%s: JPEG 2000 tiles (Aperio compression %d) need a JP2K decoder that is not in this image" % (self.path, c))
-        elif c == 5:
-            buf = np.frombuffer(_tiff_lzw_decode(data, rows * cols * p.samples), np.uint8)
+        elif c == 5:  # libcerberus_host.so (csrc/host_codecs.c) through ctypes: the interpreter lock is released, decode threads run side by side
+            from . import _hostlib
+
+            buf = _hostlib.lzw_decode(data, rows * cols * p.samples)
         elif c == 32773:
-            buf = np.frombuffer(_packbits_decode(data, rows * cols * p.samples), np.uint8)
+            from . import _hostlib
+
+            buf = _hostlib.packbits_decode(data, rows * cols * p.samples)
         else:
             raise NotImplementedError("%s: TIFF compression %d is not supported" % (self.path, c))
+        if buf.size < rows * cols * p.samples:
+            raise ValueError("%s: strip / tile %d holds %d bytes, %d x %d x %d pixels need %d" % (self.path, idx, buf.size, rows, cols, p.samples, rows * cols * p.samples))
         arr = buf[: rows * cols * p.samples].reshape(rows, cols, p.samples)
         if p.predictor == 2:
-            arr = np.cumsum(arr, axis=1, dtype=np.uint8)
+            if arr.flags.writeable and arr.flags.c_contiguous:
+                from . import _hostlib
+
+                arr = _hostlib.unpredict_u8(arr)  # in place on the decoder's own buffer
+            else:  # (read-only views of raw / zlib bytes)
+                arr = np.cumsum(arr, axis=1, dtype=np.uint8)
         return arr[:, :, :3]
 
     def _place_tile(self, p, tt, window, out):
@@ -724,6 +735,21 @@ class TiffReader(WSIReader):
         out = np.zeros(shape, np.uint8) if dest is None else dest
         if dest is not None:
             dest[...] = 0
+        from . import _hostlib
+
+        if p.compression in _hostlib.NATIVE_CODECS and tiles and out.strides[1:] == (3, 1):
+            # raw / deflate / LZW / PackBits: the whole window in ONE native call (csrc/host_codecs.c: pread + decode + predictor + placement on its own
+            # pthreads, the interpreter lock released throughout) -- per-tile calls from Python threads stop scaling at two threads
+            across = -(-p.w // p.tw)
+            idx = np.array([ty * across + tx for ty, tx in tiles], np.int64)
+            tys, txs = np.array([t[0] for t in tiles], np.int32), np.array([t[1] for t in tiles], np.int32)
+            rows_t = np.full(len(tiles), p.th, np.int32) if p.tiled else np.minimum(p.th, p.h - tys * p.th).astype(np.int32)
+            try:
+                _hostlib.read_tiles(self.fh.fileno(), p.compression, p.predictor, p.samples, p.tw if p.tiled else p.w, np.asarray(p.offsets, np.int64)[idx],
+                                    np.asarray(p.counts, np.int64)[idx], rows_t, txs * p.tw, tys * p.th, window, out, decode_threads())
+            except _hostlib.HostCodecError as e:
+                raise ValueError("%s: %s" % (self.path, e)) from None
+            return out
         pool = decode_pool()
         if pool is None or len(tiles) < 2:
             for tt in tiles:
@@ -733,64 +759,11 @@ class TiffReader(WSIReader):
         return out
 
 
-def _tiff_lzw_decode(data, expected):
-    """TIFF 6.0 section 13 LZW: MSB-first codes of 9..12 bits, ClearCode 256, EndOfInformation 257, the code width grows one code EARLY
-    (when the table reaches 511 / 1023 / 2047 entries).  Pure Python (a 256 x 256 RGB tile takes ~50 ms): a compatibility path for slides
-    that were not written for speed -- the decoded rows still upload under the inference (wsi.py::SlabUploader)."""
-    out = bytearray()
-    table = [bytes((i,)) for i in range(256)] + [b"", b""]
-    nbits, bitbuf, bitcnt, prev = 9, 0, 0, None
-    for byte in data:
-        bitbuf = (bitbuf << 8) | byte
-        bitcnt += 8
-        while bitcnt >= nbits:
-            code = (bitbuf >> (bitcnt - nbits)) & ((1 << nbits) - 1)
-            bitcnt -= nbits
-            if code == 256:
-                table = table[:258]
-                nbits, prev = 9, None
-                continue
-            if code == 257:
-                return bytes(out[:expected])
-            if prev is None:
-                entry = table[code]
-            else:
-                if code < len(table):
-                    entry = table[code]
-                elif code == len(table):
-                    entry = prev + prev[:1]
-                else:
-                    raise ValueError("corrupt LZW stream in a TIFF strip / tile")
-                table.append(prev + entry[:1])
-            out += entry
-            prev = entry
-            n = len(table)
-            nbits = 12 if n >= 2047 else 11 if n >= 1023 else 10 if n >= 511 else 9
-            if len(out) >= expected:
-                return bytes(out[:expected])
-    return bytes(out[:expected])
-
-
-def _packbits_decode(data, expected):
-    """TIFF 6.0 section 9 PackBits."""
-    out = bytearray()
-    i, n = 0, len(data)
-    while i < n and len(out) < expected:
-        h = data[i]
-        i += 1
-        if h < 128:
-            out += data[i:i + h + 1]
-            i += h + 1
-        elif h > 128:
-            out += data[i:i + 1] * (257 - h)
-            i += 1
-    return bytes(out[:expected])
-
-
-def write_tiled_tiff(path, levels, tile=256, mpp=None, compress=True, description=None, encode=None):
+def write_tiled_tiff(path, levels, tile=256, mpp=None, compress=True, description=None, encode=None, predictor=1):
     """Minimal pyramidal tiled TIFF writer (deflate or raw tiles) -- for tests and for converting arrays; levels[0] is full
     resolution, the others are reduced pages (NewSubfileType 1).  encode = (function tile [t, t, 3] uint8 -> bytes, TIFF compression
-    code) replaces the built-in tile encoders (the tests write Aperio-style JPEG tiles through it)."""
+    code) replaces the built-in tile encoders (the tests write Aperio-style JPEG tiles and LZW tiles through it); predictor=2 stores every row as
+    differences to the pixel on its left (TIFF 6.0 section 14: tag 317) before the tile is encoded."""
     bo = "<"
     with open(path, "wb") as fh:
         fh.write(b"II" + struct.pack(bo + "HI", 42, 0))
@@ -804,6 +777,8 @@ def write_tiled_tiff(path, levels, tile=256, mpp=None, compress=True, descriptio
                     t = np.zeros((tile, tile, 3), np.uint8)
                     blk = img[ty * tile:(ty + 1) * tile, tx * tile:(tx + 1) * tile]
                     t[: blk.shape[0], : blk.shape[1]] = blk
+                    if predictor == 2:
+                        t[:, 1:] = t[:, 1:] - t[:, :-1]  # (uint8 arithmetic wraps: modulo 256; numpy evaluates the right-hand side first)
                     data = encode[0](t) if encode else zlib.compress(t.tobytes(), 6) if compress else t.tobytes()
                     offs.append(fh.tell())
                     cnts.append(len(data))
@@ -831,6 +806,8 @@ def write_tiled_tiff(path, levels, tile=256, mpp=None, compress=True, descriptio
             put(284, 3, [1])
             if mpp is not None:
                 put(296, 3, [3])
+            if predictor == 2:
+                put(317, 3, [2])
             put(322, 4, [tile])
             put(323, 4, [tile])
             put(324, 4, offs)

@@ -43,6 +43,27 @@ def test_every_binding_declares_its_argument_types():
         assert at is not None and len(at) == arity, "%s: header has %d parameters, binding declares %s" % (name, arity, at)
 
 
+def test_host_codec_library_exports_what_its_header_declares():
+    """libcerberus_host.so (plain C, the slide reader's TIFF LZW / PackBits / predictor codecs): include/cerberus_host.h <-> exports <-> ctypes
+    argument types, as for the HIP library."""
+    from cerberus_amd import _hostlib
+
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "cerberus_host.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(cerb_host_[a-z0-9_]+)\s*\(", txt)))
+    assert os.path.exists(_hostlib.LIB_PATH), "run `python -m cerberus_amd.build` first"
+    raw = ctypes.CDLL(_hostlib.LIB_PATH)
+    assert len(names) == 5 and sorted(_hostlib.EXPORTS) == names
+    L = _hostlib.lib()
+    for n in names:
+        assert hasattr(raw, n), "libcerberus_host.so does not export %s" % n
+        m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % n, txt, flags=re.S)
+        params = m.group(1).strip()
+        arity = 0 if params in ("", "void") else params.count(",") + 1
+        at = getattr(L, n).argtypes
+        assert (at is None or len(at) == 0) if arity == 0 else (at is not None and len(at) == arity), (n, arity, at)
+    assert L.cerb_host_version() >= 1
+
+
 def test_version_and_error_string():
     from cerberus_amd import _lib
 
@@ -56,6 +77,6 @@ def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "cerberus_amd")
     for dp, _, fs in os.walk(pkg):
         for f in fs:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".c")):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src, f

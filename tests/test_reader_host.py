@@ -223,3 +223,167 @@ def test_large_reads_on_decode_processes_equal_the_thread_pool(tmp_path, monkeyp
     finally:
         rd._shutdown_procs()
         rd._PROCS.pop("off", None)
+
+
+# ---- libcerberus_host.so: TIFF LZW / PackBits / predictor in C (csrc/host_codecs.c) against the plain-Python restatement and against libtiff ------------
+
+def _codec_cases():
+    rng = np.random.RandomState(1)
+    return {"noise": rng.randint(0, 256, 40000).astype(np.uint8).tobytes(),   # fills the 4094-entry table many times over
+            "smooth": (np.arange(50000) // 7 % 256).astype(np.uint8).tobytes(),
+            "flat": bytes(30000), "empty": b"", "one": b"\x07", "two": b"\x07\x07",
+            "low": rng.randint(0, 4, 60000).astype(np.uint8).tobytes(),
+            "kwkwk": b"ab" * 5 + b"a" * 2400}
+
+
+def test_c_codecs_equal_the_python_restatement_on_encoded_streams():
+    from cerberus_amd import _hostlib as H
+    from oracle import tiff_codecs_ref as R
+
+    assert H.lib().cerb_host_version() >= 1
+    for name, d in _codec_cases().items():
+        e = R.lzw_encode(d)
+        assert R.lzw_decode(e, len(d)) == d and H.lzw_decode(e, len(d)).tobytes() == d, name
+        pe = R.packbits_encode(d)
+        assert R.packbits_decode(pe, len(d)) == d and H.packbits_decode(pe, len(d)).tobytes() == d, name
+        if len(d) > 10:  # a destination smaller than the stream: the prefix, never a byte more
+            assert H.lzw_decode(e, len(d) - 7).tobytes() == d[:-7] and H.packbits_decode(pe, len(d) - 7).tobytes() == d[:-7], name
+            # a stream cut short: what there is, zero-filled (the Python decoders return the short prefix)
+            cut = e[: len(e) // 2]
+            ref = R.lzw_decode(cut, len(d))
+            got = H.lzw_decode(cut, len(d)).tobytes()
+            assert got[: len(ref)] == ref and not any(got[len(ref):]), name
+    # corrupt: a code beyond the table right after the first literal; old-style (LSB-first) streams are named, not decoded into noise
+    with pytest.raises(ValueError, match="corrupt LZW"):
+        H.lzw_decode(bytes([0x80, 0x00, 0xFF, 0xFF, 0xFF]), 64)
+    with pytest.raises(ValueError, match="old-style"):
+        H.lzw_decode(bytes([0x00, 0x01, 0x02, 0x03]), 64)
+    with pytest.raises(ValueError, match="corrupt PackBits"):
+        H.packbits_decode(bytes([5, 1, 2]), 64)
+    # predictor 2: the running sum per sample, modulo 256, in place
+    a = np.random.RandomState(2).randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    assert np.array_equal(H.unpredict_u8(a.copy()), np.cumsum(a, axis=1, dtype=np.uint8))
+    a4 = np.random.RandomState(3).randint(0, 256, (5, 9, 4)).astype(np.uint8)
+    assert np.array_equal(H.unpredict_u8(a4.copy()), np.cumsum(a4, axis=1, dtype=np.uint8))
+
+
+def test_c_lzw_decoder_on_libtiff_streams(tmp_path):
+    """independent ENCODER: the strips of files PIL's libtiff wrote (with and without the horizontal predictor), pulled out with this package's
+    TIFF parser, through the C decoder and the Python restatement -- and the whole file through the reader against PIL's own decode."""
+    from PIL import Image
+
+    from cerberus_amd import _hostlib as H
+    from oracle import tiff_codecs_ref as R
+
+    rng = np.random.RandomState(0)
+    yy, xx = np.mgrid[:120, :200]
+    imgs = {"noise": rng.randint(0, 256, (120, 200, 3)).astype(np.uint8),
+            "smooth": np.stack([(xx // 3) % 256, (yy // 2) % 256, ((xx + yy) // 5) % 256], -1).astype(np.uint8),
+            "flat": np.full((120, 200, 3), 200, np.uint8)}
+    for name, a in imgs.items():
+        for pred in (False, True):
+            path = str(tmp_path / ("%s%d.tif" % (name, pred)))
+            kw = {"tiffinfo": {317: 2}} if pred else {}
+            Image.fromarray(a).save(path, compression="tiff_lzw", **kw)
+            r = WSIReader.open(path)
+            p = r.levels[0]
+            assert p.compression == 5 and p.predictor == (2 if pred else 1), (name, pred, p.predictor)
+            for i in range(len(p.offsets)):
+                s = os.pread(r.fh.fileno(), p.counts[i], p.offsets[i])
+                exp = min(p.th, p.h - i * p.th) * p.w * p.samples
+                assert H.lzw_decode(s, exp).tobytes() == R.lzw_decode(s, exp), (name, pred, i)
+            assert np.array_equal(r.read_bounds((0, 0, 200, 120), 1.0, "baseline"), a), (name, pred)
+            assert np.array_equal(np.array(Image.open(path)), a)
+
+
+@pytest.mark.parametrize("predictor", [1, 2])
+def test_tiled_lzw_pyramid_through_the_reader_and_through_libtiff(tmp_path, predictor):
+    """A TILED pyramidal LZW TIFF (what bioformats / libvips exports look like; PIL cannot write tiles): written by write_tiled_tiff with the
+    restatement's encoder, read by the product on its decode threads (C decoder, lock released) and by PIL's libtiff -- an independent DECODER for
+    the encoder, an independent container reader for the file.  Every level, windows across tile borders."""
+    from PIL import Image
+
+    from oracle import tiff_codecs_ref as R
+
+    levels = _pyramid(520, 610, 11)
+    path = str(tmp_path / "lzw.tif")
+    write_tiled_tiff(path, levels, tile=128, mpp=0.5, encode=(lambda t: R.lzw_encode(t.tobytes()), 5), predictor=predictor)
+    r = WSIReader.open(path)
+    assert r.levels[0].compression == 5 and r.levels[0].predictor == predictor and r.info.level_count == 3
+    assert np.array_equal(r.read_bounds((0, 0, 610, 520), 0.5, "mpp"), levels[0])
+    assert np.array_equal(r.read_bounds((100, 37, 415, 300), 0.5, "mpp"), levels[0][37:300, 100:415])
+    assert np.array_equal(r.read_bounds((3, 5, 300, 255), 1.0, "mpp"), levels[1][5:255, 3:300])
+    im = Image.open(path)
+    assert np.array_equal(np.array(im), levels[0])
+    im.seek(1)
+    assert np.array_equal(np.array(im), levels[1])
+    # PackBits tiles the same way (without the predictor: libtiff implements tag 317 inside its LZW / deflate codecs only)
+    path2 = str(tmp_path / "pb.tif")
+    write_tiled_tiff(path2, levels[:1], tile=128, encode=(lambda t: R.packbits_encode(t.tobytes()), 32773))
+    assert np.array_equal(WSIReader.open(path2).read_bounds((0, 0, 610, 520), 1.0, "baseline"), levels[0])
+    assert np.array_equal(np.array(Image.open(path2)), levels[0])
+
+
+@pytest.mark.parametrize("codec", ["raw", "deflate", "lzw", "packbits"])
+def test_whole_window_native_read_equals_the_per_tile_path(tmp_path, codec):
+    """cerb_host_tiff_read_tiles (one native call per window: pread + decode + predictor + placement on pthreads) against the reader's per-tile
+    Python path (TiffReader._place_tile, what the JPEG tiles and the worker processes use) on ragged windows, a destination that is a view of a wider
+    buffer, 1 / 3 / 8 threads, and a level whose last tiles are padding."""
+    from oracle import tiff_codecs_ref as R
+
+    levels = _pyramid(333, 471, 5)[:2]
+    path = str(tmp_path / "w.tif")
+    kw = {"raw": dict(compress=False), "deflate": dict(compress=True), "lzw": dict(encode=(lambda t: R.lzw_encode(t.tobytes()), 5), predictor=2),
+          "packbits": dict(encode=(lambda t: R.packbits_encode(t.tobytes()), 32773))}[codec]
+    write_tiled_tiff(path, levels, tile=64, mpp=0.5, **kw)
+    r = WSIReader.open(path)
+    for lvl, img in enumerate(levels):
+        p = r.levels[lvl]
+        h, w = img.shape[:2]
+        for (x0, y0, x1, y1) in ((0, 0, w, h), (1, 2, 3, 5), (63, 63, 65, 66), (100, 37, w - 3, h - 1), (w - 10, h - 7, w, h)):
+            want = np.zeros((y1 - y0, x1 - x0, 3), np.uint8)
+            for ty in range(y0 // p.th, -(-y1 // p.th)):
+                for tx in range(x0 // p.tw, -(-x1 // p.tw)):
+                    r._place_tile(p, (ty, tx), (x0, y0, x1, y1), want)
+            assert np.array_equal(want, img[y0:y1, x0:x1])
+            for th in ("1", "3", "8"):
+                os.environ["CERB_DECODE_THREADS"] = th
+                try:
+                    assert np.array_equal(r._read_level(lvl, x0, y0, x1, y1), want), (codec, lvl, th)
+                    wide = np.full((y1 - y0 + 5, x1 - x0 + 9, 3), 7, np.uint8)  # a pinned staging buffer larger than the window
+                    got = r._read_level(lvl, x0, y0, x1, y1, out=wide)
+                    assert np.array_equal(got, want) and np.shares_memory(got, wide) and bool((wide[y1 - y0:] == 7).all()) and bool((wide[:, x1 - x0:] == 7).all())
+                finally:
+                    os.environ.pop("CERB_DECODE_THREADS", None)
+
+
+def test_native_read_names_the_tile_it_could_not_decode(tmp_path):
+    """A damaged tile ends the read with a ValueError that names the file, the tile and the reason -- for a corrupt deflate stream, a corrupt LZW
+    stream and a file that ends inside a tile -- never with pixels."""
+    from oracle import tiff_codecs_ref as R
+
+    img = _pyramid(200, 260, 9)[0]
+    for codec, kw, what in (("deflate", dict(compress=True), "deflate"), ("lzw", dict(encode=(lambda t: R.lzw_encode(t.tobytes()), 5)), "LZW")):
+        path = str(tmp_path / (codec + ".tif"))
+        write_tiled_tiff(path, [img], tile=64, **kw)
+        r = WSIReader.open(path)
+        p = r.levels[0]
+        k = 6  # damage tile 6 = (ty 1, tx 1) of the 4 x 5 grid: bytes in the middle of its stream set to 0xFF
+        raw = bytearray(open(path, "rb").read())
+        a = p.offsets[k] + 2
+        raw[a:a + 24] = b"\xff" * 24
+        bad = str(tmp_path / (codec + "_bad.tif"))
+        open(bad, "wb").write(bytes(raw))
+        rb = WSIReader.open(bad)
+        assert np.array_equal(rb.read_bounds((0, 0, 64, 64), 1.0, "baseline"), img[:64, :64])  # the other tiles still read
+        with pytest.raises(ValueError) as ei:
+            rb.read_bounds((0, 0, 260, 200), 1.0, "baseline")
+        assert "tile %d" % k in str(ei.value) and what in str(ei.value) and "_bad.tif" in str(ei.value), str(ei.value)
+    # a file cut inside its last tile (tiles are written before the directory: cut the bytes, keep the directory's offsets by padding zeros elsewhere)
+    path = str(tmp_path / "raw.tif")
+    write_tiled_tiff(path, [img], tile=64, compress=False)
+    r = WSIReader.open(path)
+    p = r.levels[0]
+    p.counts[3] = p.counts[3] + (1 << 30)  # a count that runs past the end of the file
+    with pytest.raises(ValueError, match="ends inside"):
+        r.read_bounds((0, 0, 260, 64), 1.0, "baseline")
