@@ -529,7 +529,7 @@ def structured_band(dev, y0, rows, W, period=4096):
     return out
 
 
-def ingest_leg(model, dev, side, batch, streams, tmpdir=None, sweep=(1, 2, 4, 8, 16, 32, 64), base_mpp=0.5):
+def ingest_leg(model, dev, side, batch, streams, tmpdir=None, sweep=(1, 2, 4, 8, 16, 32, 64), base_mpp=0.5, codec="jpeg"):
     """Real-slide ingest (SURVEY par.8f rank 2): a JPEG-tiled pyramidal TIFF of side^2 pixels (256-pixel tiles of stain-field
     texture, quality 80, written with cerberus_amd.reader.write_tiled_tiff) through the path run_infer_wsi.py takes for a slide on disk --
     reader rows -> tile decode on the reader's thread pool -> pinned chunks -> copy stream (wsi.SlabUploader, a producer thread ahead of the
@@ -565,6 +565,13 @@ def ingest_leg(model, dev, side, batch, streams, tmpdir=None, sweep=(1, 2, 4, 8,
 
     def enc(t):
         key = t.tobytes()
+        if key not in cache and codec != "jpeg":
+            # lossless tiles (generic tiled TIFFs: bioformats / libvips exports): decoded by libcerberus_host.so, one native call per window
+            import zlib
+
+            # (LZW with the horizontal predictor, as such files are written: write_tiled_tiff(predictor=2) hands over the differenced tile -- still
+            #  one of 64 distinct byte strings, so the plain-Python encoder runs 64 times)
+            cache[key] = rd.tiff_lzw_encode(key) if codec == "lzw" else zlib.compress(key, 6)
         if key not in cache:
             # Aperio-style: the R, G, B planes ARE the stream's three components (PhotometricInterpretation RGB, no chroma subsampling, no JFIF marker)
             b = io.BytesIO()
@@ -576,10 +583,13 @@ def ingest_leg(model, dev, side, batch, streams, tmpdir=None, sweep=(1, 2, 4, 8,
 
     td = tempfile.mkdtemp(dir=tmpdir)
     path = os.path.join(td, "slide.tif")
-    rd.write_tiled_tiff(path, [img, np.ascontiguousarray(img[::4, ::4])], tile=TILE, mpp=base_mpp, encode=(enc, 7))
+    rd.write_tiled_tiff(path, [img, np.ascontiguousarray(img[::4, ::4])], tile=TILE, mpp=base_mpp, encode=(enc, {"jpeg": 7, "deflate": 8, "lzw": 5}[codec]),
+                        predictor=2 if codec == "lzw" else 1)
+    src_band = None if codec == "jpeg" else np.ascontiguousarray(img[: min(fH, 512)])
     del img
     build_s = time.perf_counter() - t0
-    res = {"slide": [H, W], "stored": {"pixels": [fH, fW], "mpp": base_mpp, "read_at_mpp": 0.5}, "file": {"format": "pyramidal TIFF, %d x %d JPEG tiles (Aperio-style: RGB components, 4:4:4, quality 80) + a x4 level" % (TILE, TILE), "MB": round(os.path.getsize(path) / 1e6, 1),
+    res = {"slide": [H, W], "stored": {"pixels": [fH, fW], "mpp": base_mpp, "read_at_mpp": 0.5}, "file": {"format": ("pyramidal TIFF, %d x %d JPEG tiles (Aperio-style: RGB components, 4:4:4, quality 80) + a x4 level" % (TILE, TILE)) if codec == "jpeg" else
+                                    ("pyramidal TIFF, %d x %d %s tiles + a x4 level (decoded by libcerberus_host.so: one native call per window)" % (TILE, TILE, {"deflate": "deflate", "lzw": "LZW + horizontal-predictor"}[codec])), "MB": round(os.path.getsize(path) / 1e6, 1),
                                     "tiles": int(ny * nx), "build_s": round(build_s, 1)}}
     try:
         reader = rd.WSIReader.open(input_img=path)
@@ -603,7 +613,9 @@ def ingest_leg(model, dev, side, batch, streams, tmpdir=None, sweep=(1, 2, 4, 8,
             dt = time.perf_counter() - t0
             dec.append({"threads": n, "Mpx_s": round(span * fW / dt / 1e6, 1)})
         ref_px = a
-        proc_counts = [c for c in (2, 4, 8, 16, 32) if c <= max(1, avail // 2)]
+        if src_band is not None:  # lossless: the decoded pixels ARE the source's
+            assert np.array_equal(ref_px[: src_band.shape[0]], src_band), "the reader returned other pixels than the file was written from"
+        proc_counts = [c for c in (2, 4, 8, 16, 32) if c <= max(1, avail // 2)] if codec == "jpeg" else []  # (worker processes decode JPEG tiles only)
         for n in proc_counts:
             os.environ["CERB_DECODE_PROCS"] = str(n)
             reader._read_level(0, 0, 0, fW, min(span, 512))  # the workers start here
@@ -1126,6 +1138,9 @@ def main():
                     help="slide job: the labelling reads the INST canvases the timed inference wrote instead of the seeded structured maps (the data dependency "
                          "inference -> labelling at slide scale); the seeded weights get a sparse-foreground bias calibration so that those maps hold instances")
     ap.add_argument("--ingest-base-mpp", type=float, default=0.5, help="--mode ingest: microns per pixel the file is STORED at (0.25 = a 40x scan: (2 x slide)^2 pixels on disk, read at 0.5 mpp)")
+    ap.add_argument("--ingest-codec", default="jpeg", choices=["jpeg", "deflate", "lzw"],
+                    help="--mode ingest: the tiles' compression (jpeg: Aperio-style, decoded by libjpeg on threads / worker processes; deflate, lzw (+ horizontal predictor): "
+                         "generic tiled TIFFs, decoded by libcerberus_host.so -- one native call per window on CERB_DECODE_THREADS pthreads)")
     ap.add_argument("--slide", type=int, default=0, help="slide side in pixels (default: 40000, or 20000 when HBM is short)")
     ap.add_argument("--max-band-mpx", type=float, default=220.0, help="largest labelling call on one GPU, in Mpx (96 B/px of workspace)")
     ap.add_argument("--force-dist", action="store_true",
@@ -1187,14 +1202,17 @@ def main():
         return train_leg(args, model, dev, dist, world, rank, sd, kw)
     if args.mode == "ingest":
         side = args.slide if args.slide > 0 else 20000
-        ing = ingest_leg(model, dev, side, 64 if args.streams == 2 else 96, args.streams, base_mpp=args.ingest_base_mpp)
-        print(json.dumps({"metric": "Mpx/sec WSI tiled inference (all heads) from a JPEG-tiled pyramidal TIFF on disk", "value": ing["best"]["Mpx_s"], "unit": "Mpx/s", "n_gpus": 1,
-                          "steps": 1, "warmup": 1, "ms_per_step": round(side * side / ing["best"]["Mpx_s"] / 1e3, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "f32", "data": "synthetic", "config": {"workload": "%dx%d slide from a JPEG-tiled pyramidal TIFF stored at %.4g mpp (%dx%d pixels) -> reader (tile decode on threads / worker processes%s) -> pinned chunks ahead "
-                                                                                        "of the inference -> full Cerberus forward into device canvases; inference only, no labelling tail" % (
-                                                                                            side, side, args.ingest_base_mpp, ing["stored"]["pixels"][0], ing["stored"]["pixels"][1],
-                                                                                            ", reduced to 0.5 mpp on the device" if args.ingest_base_mpp < 0.5 else ""),
-                                                                            "streams": args.streams, "conv_algo": model.precision_decision()["conv_algo"]},
+        ing = ingest_leg(model, dev, side, 64 if args.streams == 2 else 96, args.streams, base_mpp=args.ingest_base_mpp, codec=args.ingest_codec)
+        codec_name = {"jpeg": "JPEG", "deflate": "deflate", "lzw": "LZW"}[args.ingest_codec]
+        workload = ("%dx%d slide from a %s-tiled pyramidal TIFF stored at %.4g mpp (%dx%d pixels) -> reader (%s%s) -> pinned chunks ahead of the inference -> full "
+                    "Cerberus forward into device canvases; inference only, no labelling tail" % (
+                        side, side, codec_name, args.ingest_base_mpp, ing["stored"]["pixels"][0], ing["stored"]["pixels"][1],
+                        "tile decode on threads / worker processes" if args.ingest_codec == "jpeg" else "one native call per window: libcerberus_host.so, pthreads",
+                        ", reduced to 0.5 mpp on the device" if args.ingest_base_mpp < 0.5 else ""))
+        print(json.dumps({"metric": "Mpx/sec WSI tiled inference (all heads) from a %s-tiled pyramidal TIFF on disk" % codec_name, "value": ing["best"]["Mpx_s"], "unit": "Mpx/s",
+                          "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": round(side * side / ing["best"]["Mpx_s"] / 1e3, 1), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": workload, "streams": args.streams, "conv_algo": model.precision_decision()["conv_algo"], "tile_codec": args.ingest_codec},
                           "ingest": ing}), flush=True)
         return
     if args.mode == "wsi":

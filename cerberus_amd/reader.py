@@ -759,12 +759,85 @@ class TiffReader(WSIReader):
         return out
 
 
+def tiff_lzw_encode(data):
+    """TIFF 6.0 section 13 encoder (MSB-first, early change, ClearCode first, a ClearCode when the table holds 4094 entries, EndOfInformation last):
+    write_tiled_tiff(compress="lzw") -- tiles of a TILED file, which PIL cannot write; plain Python (a writer for tests, benchmarks and array
+    conversion: ~0.3 s per 256 x 256 tile), the DEcoder is native (csrc/host_codecs.c)."""
+    out = bytearray()
+    bitbuf, bitcnt = 0, 0
+    nbits = 9
+
+    def put(code):
+        nonlocal bitbuf, bitcnt
+        bitbuf = (bitbuf << nbits) | code
+        bitcnt += nbits
+        while bitcnt >= 8:
+            out.append((bitbuf >> (bitcnt - 8)) & 0xFF)
+            bitcnt -= 8
+        bitbuf &= (1 << bitcnt) - 1
+
+    table = {bytes((i,)): i for i in range(256)}
+    nxt = 258
+    put(256)
+    w = b""
+    for byte in bytes(data):
+        wc = w + bytes((byte,))
+        if wc in table:
+            w = wc
+            continue
+        put(table[w])
+        table[wc] = nxt
+        nxt += 1
+        # the DECODER's table is one entry behind the encoder's, and it widens its codes when ITS table holds 511 / 1023 / 2047 entries
+        # (one code early): seen from here that is nxt = 512 / 1024 / 2048
+        if nxt == 4094:
+            put(256)
+            table = {bytes((i,)): i for i in range(256)}
+            nxt, nbits = 258, 9
+        else:
+            nbits = 12 if nxt >= 2048 else 11 if nxt >= 1024 else 10 if nxt >= 512 else 9
+        w = bytes((byte,))
+    if w:
+        put(table[w])
+        nxt += 1  # (the decoder adds an entry for this code too, and widens on it)
+        if nxt != 4094:
+            nbits = 12 if nxt >= 2048 else 11 if nxt >= 1024 else 10 if nxt >= 512 else 9
+    put(257)
+    if bitcnt:
+        out.append((bitbuf << (8 - bitcnt)) & 0xFF)
+    return bytes(out)
+
+
+def tiff_packbits_encode(data):
+    """TIFF 6.0 section 9 encoder: runs of 3 and more as replicate packets, everything else as literal packets of up to 128 bytes."""
+    data = bytes(data)
+    out = bytearray()
+    i, n = 0, len(data)
+    while i < n:
+        j = i
+        while j + 1 < n and data[j + 1] == data[i] and j - i < 127:
+            j += 1
+        if j - i >= 2:
+            out += bytes((257 - (j - i + 1), data[i]))
+            i = j + 1
+            continue
+        k = i
+        while k < n and k - i < 128 and not (k + 2 < n and data[k] == data[k + 1] == data[k + 2]):
+            k += 1
+        out += bytes((k - i - 1,)) + data[i:k]
+        i = k
+    return bytes(out)
+
+
 def write_tiled_tiff(path, levels, tile=256, mpp=None, compress=True, description=None, encode=None, predictor=1):
-    """Minimal pyramidal tiled TIFF writer (deflate or raw tiles) -- for tests and for converting arrays; levels[0] is full
+    """Minimal pyramidal tiled TIFF writer (deflate, raw, LZW or PackBits tiles: `compress`) -- for tests and for converting arrays; levels[0] is full
     resolution, the others are reduced pages (NewSubfileType 1).  encode = (function tile [t, t, 3] uint8 -> bytes, TIFF compression
     code) replaces the built-in tile encoders (the tests write Aperio-style JPEG tiles and LZW tiles through it); predictor=2 stores every row as
     differences to the pixel on its left (TIFF 6.0 section 14: tag 317) before the tile is encoded."""
     bo = "<"
+    # compress: True / "deflate" (zlib level 6), False (raw), "lzw", "packbits" -- (tile encoder, TIFF Compression tag)
+    builtin = {True: (lambda t: zlib.compress(t.tobytes(), 6), 8), "deflate": (lambda t: zlib.compress(t.tobytes(), 6), 8), False: (lambda t: t.tobytes(), 1),
+               None: (lambda t: t.tobytes(), 1), "lzw": (lambda t: tiff_lzw_encode(t.tobytes()), 5), "packbits": (lambda t: tiff_packbits_encode(t.tobytes()), 32773)}[compress]
     with open(path, "wb") as fh:
         fh.write(b"II" + struct.pack(bo + "HI", 42, 0))
         prev_next_pos = 4
@@ -779,7 +852,7 @@ def write_tiled_tiff(path, levels, tile=256, mpp=None, compress=True, descriptio
                     t[: blk.shape[0], : blk.shape[1]] = blk
                     if predictor == 2:
                         t[:, 1:] = t[:, 1:] - t[:, :-1]  # (uint8 arithmetic wraps: modulo 256; numpy evaluates the right-hand side first)
-                    data = encode[0](t) if encode else zlib.compress(t.tobytes(), 6) if compress else t.tobytes()
+                    data = encode[0](t) if encode else builtin[0](t)
                     offs.append(fh.tell())
                     cnts.append(len(data))
                     fh.write(data)
@@ -794,7 +867,7 @@ def write_tiled_tiff(path, levels, tile=256, mpp=None, compress=True, descriptio
             put(256, 4, [w])
             put(257, 4, [h])
             put(258, 3, [8, 8, 8])
-            put(259, 3, [encode[1] if encode else 8 if compress else 1])
+            put(259, 3, [encode[1] if encode else builtin[1]])
             put(262, 3, [2])
             if description and li == 0:
                 put(270, 2, description.encode("latin1") + b"\0")

@@ -59,70 +59,7 @@ def packbits_decode(data, expected):
     return bytes(out[:expected])
 
 
-def lzw_encode(data):
-    """TIFF 6.0 section 13 encoder (MSB-first, early change, ClearCode first, a ClearCode when the table holds 4094 entries, EndOfInformation last):
-    what the tests feed the decoders beside libtiff's own streams -- tiles of a TILED file, which PIL cannot write."""
-    out = bytearray()
-    bitbuf, bitcnt = 0, 0
-    nbits = 9
-
-    def put(code):
-        nonlocal bitbuf, bitcnt
-        bitbuf = (bitbuf << nbits) | code
-        bitcnt += nbits
-        while bitcnt >= 8:
-            out.append((bitbuf >> (bitcnt - 8)) & 0xFF)
-            bitcnt -= 8
-        bitbuf &= (1 << bitcnt) - 1
-
-    table = {bytes((i,)): i for i in range(256)}
-    nxt = 258
-    put(256)
-    w = b""
-    for byte in bytes(data):
-        wc = w + bytes((byte,))
-        if wc in table:
-            w = wc
-            continue
-        put(table[w])
-        table[wc] = nxt
-        nxt += 1
-        # the DECODER's table is one entry behind the encoder's, and it widens its codes when ITS table holds 511 / 1023 / 2047 entries
-        # (one code early): seen from here that is nxt = 512 / 1024 / 2048
-        if nxt == 4094:
-            put(256)
-            table = {bytes((i,)): i for i in range(256)}
-            nxt, nbits = 258, 9
-        else:
-            nbits = 12 if nxt >= 2048 else 11 if nxt >= 1024 else 10 if nxt >= 512 else 9
-        w = bytes((byte,))
-    if w:
-        put(table[w])
-        nxt += 1  # (the decoder adds an entry for this code too, and widens on it)
-        if nxt != 4094:
-            nbits = 12 if nxt >= 2048 else 11 if nxt >= 1024 else 10 if nxt >= 512 else 9
-    put(257)
-    if bitcnt:
-        out.append((bitbuf << (8 - bitcnt)) & 0xFF)
-    return bytes(out)
-
-
-def packbits_encode(data):
-    """TIFF 6.0 section 9 encoder: runs of 3 and more as replicate packets, everything else as literal packets of up to 128 bytes."""
-    data = bytes(data)
-    out = bytearray()
-    i, n = 0, len(data)
-    while i < n:
-        j = i
-        while j + 1 < n and data[j + 1] == data[i] and j - i < 127:
-            j += 1
-        if j - i >= 2:
-            out += bytes((257 - (j - i + 1), data[i]))
-            i = j + 1
-            continue
-        k = i
-        while k < n and k - i < 128 and not (k + 2 < n and data[k] == data[k + 1] == data[k + 2]):
-            k += 1
-        out += bytes((k - i - 1,)) + data[i:k]
-        i = k
-    return bytes(out)
+# The ENCODERS the tests feed the decoders with are the product's own writer utilities (oracle -> product direction: cerberus_amd/reader.py writes LZW /
+# PackBits tiles with them, `write_tiled_tiff(compress="lzw")`); what pins THEM is libtiff reading the files (tests/test_reader_host.py).
+from cerberus_amd.reader import tiff_lzw_encode as lzw_encode  # noqa: E402,F401
+from cerberus_amd.reader import tiff_packbits_encode as packbits_encode  # noqa: E402,F401

@@ -803,3 +803,16 @@ def test_bench_ingest_mode_file_fed_run_equals_resident():
     ing = line["ingest"]
     assert ing["slide"] == [2048, 2048] and ing["stored"] == {"pixels": [4096, 4096], "mpp": 0.25, "read_at_mpp": 0.5} and ing["file"]["tiles"] == 256
     assert all(e["reduced_on_device"] for e in ing["end_to_end_from_file"]) and ing["best"]["of_resident"] > 0.2
+
+
+@pytest.mark.parametrize("codec", ["deflate", "lzw"])
+def test_bench_ingest_mode_lossless_tiles_through_the_native_reader(codec):
+    """`bench.py --mode ingest --ingest-codec deflate | lzw`: a generic tiled TIFF (deflate tiles; LZW tiles with the horizontal predictor) goes through
+    libcerberus_host.so's one-call-per-window reader (pread + decode + predictor + placement on pthreads) -> SlabUploader -> WSIRunner; the leg asserts that
+    the decoded pixels ARE the source's, that they do not depend on the thread count, and that every file-fed run writes the resident run's canvases."""
+    line = _bench([sys.executable, "bench.py", "--mode", "ingest", "--slide", "2048", "--streams", "1", "--ingest-codec", codec], timeout=900)
+    ing = line["ingest"]
+    assert line["config"]["tile_codec"] == codec and "libcerberus_host.so" in ing["file"]["format"] and ing["file"]["tiles"] == 64
+    assert len(ing["decode"]["sweep"]) >= 3 and all("threads" in p_ and p_["Mpx_s"] > 10 for p_ in ing["decode"]["sweep"])
+    assert all(e["decode_processes"] == 0 and not e["reduced_on_device"] for e in ing["end_to_end_from_file"])
+    assert ing["best"]["of_resident"] > 0.3 and line["value"] == ing["best"]["Mpx_s"]
