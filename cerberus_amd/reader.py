@@ -11,8 +11,8 @@ tiatoolbox / OpenSlide are not in this image, so the back ends are this package'
   * SyntheticReader  -- `.txt` holding `synthetic:<H>x<W>:<seed>`: pixels are generated on the device (wsi.synth_slide);
   * TiffReader       -- baseline / BigTIFF, striped or TILED, pyramid pages, compression none / deflate (+ horizontal predictor) /
                         JPEG tiles (decoded by PIL, JPEGTables spliced in), resolution from XResolution / ResolutionUnit or an
-                        Aperio `MPP = ...` description: generic tiled TIFFs and `.svs` files whose tiles are JPEG.  JPEG 2000 tiles
-                        (Aperio 33003 / 33005) is refused with a clear message; LZW and PackBits tiles are decoded by libcerberus_host.so (csrc/host_codecs.c, include/cerberus_host.h).
+                        Aperio `MPP = ...` description: generic tiled TIFFs and `.svs` files whose tiles are JPEG or JPEG 2000
+                        (Aperio 33003 / 33005, TIFF 34712: OpenJPEG behind PIL; subsampled-chroma 33003 codestreams refused by name); LZW and PackBits tiles are decoded by libcerberus_host.so (csrc/host_codecs.c, include/cerberus_host.h).
 Resampling: the pyramid level with the largest downsample not above the request is read and reduced by a box (area) filter --
 exact pixel means for integer factors, PIL's BOX filter otherwise (tiatoolbox uses cv2 INTER_AREA there; unpinned, both libraries
 are absent).  Everything here is host I/O; pixels reach the GPU through wsi.SlabUploader chunk by chunk under the inference.
@@ -64,6 +64,8 @@ def decode_pool():
 # window; nothing but a few integers crosses the pipes.  Workers are fresh interpreters (cerberus_amd/decode_worker.py: no torch, no GPU context,
 # the parent's __main__ is not re-imported).
 _PROCS = {"n": None, "pool": None}
+JP2K_CODECS = (33003, 33005, 34712)  # Aperio JPEG 2000 (YCbCr components / RGB components) and the TIFF JPEG 2000 tag of generic writers
+PROC_CODECS = (7,) + JP2K_CODECS     # tiles decoded through PIL (libjpeg / OpenJPEG): the compressions whose large reads go to worker processes
 _PROCS_LOCK = __import__("threading").Lock()
 PROC_MIN_TILES = 96  # below this many tiles a read stays on the thread pool (thumbnails, edge strips, tests)
 
@@ -634,8 +636,8 @@ class TiffReader(WSIReader):
             if img.mode != "RGB":
                 img = img.convert("RGB")
             return np.asarray(img)[:rows, :cols]
-        elif c in (33003, 33005):
-            raise NotImplementedError("%s: JPEG 2000 tiles (Aperio compression %d) need a JP2K decoder that is not in this image" % (self.path, c))
+        elif c in JP2K_CODECS:
+            return _decode_jp2k_tile(data, c, self.path, idx)[:rows, :cols]
         elif c == 5:  # libcerberus_host.so (csrc/host_codecs.c) through ctypes: the interpreter lock is released, decode threads run side by side
             from . import _hostlib
 
@@ -707,7 +709,7 @@ class TiffReader(WSIReader):
         window = (x0, y0, x1, y1)
         tiles = [(ty, tx) for ty in range(y0 // p.th, -(-y1 // p.th)) for tx in range(x0 // p.tw, -(-x1 // p.tw))]
         nbytes = shape[0] * shape[1] * 3
-        procs = _proc_pool() if (len(tiles) >= PROC_MIN_TILES and p.compression == 7 and not _PROCS.get("off") and _shm_has_room(nbytes)) else None
+        procs = _proc_pool() if (len(tiles) >= PROC_MIN_TILES and p.compression in PROC_CODECS and not _PROCS.get("off") and _shm_has_room(nbytes)) else None
         if procs is not None:
             import threading
 
@@ -757,6 +759,49 @@ class TiffReader(WSIReader):
         else:  # libjpeg / zlib release the interpreter lock while they decode
             list(pool.map(lambda tt: self._place_tile(p, tt, window, out), tiles))
         return out
+
+
+def _jp2k_component_sampling(data):
+    """[(XRsiz, YRsiz)] per component out of a JPEG 2000 codestream's SIZ marker segment (ISO 15444-1 A.5.1; a JP2 file's boxes are skipped to its
+    codestream) -- None when there is no SIZ where one belongs."""
+    k = data.find(b"\xff\x4f\xff\x51")
+    if k < 0 or len(data) < k + 42:
+        return None
+    csiz = struct.unpack(">H", data[k + 40:k + 42])[0]
+    body = data[k + 42:k + 42 + 3 * csiz]
+    if len(body) < 3 * csiz:
+        return None
+    return [(body[3 * i + 1], body[3 * i + 2]) for i in range(csiz)]
+
+
+def _decode_jp2k_tile(data, compression, path, idx):
+    """One JPEG 2000 tile (a raw codestream, as Aperio .svs files and generic TIFF writers store them) -> uint8 [rows, cols, 3], through OpenJPEG
+    behind PIL.  33005 / 34712: the components are R, G, B.  33003: the components are Y, Cb, Cr (full range, JFIF matrix -- what OpenSlide's
+    Aperio back end converts with); chroma that is SUBSAMPLED inside the codestream (XRsiz / YRsiz != 1, most scanner-written 33003 files) is
+    refused by name: no sample of such a file and no OpenSlide exist in this image to hold an up-sampling rule to, and a silently different
+    colour is worse than a refusal.  Parity of this path is unpinned for the same reason (stated in DESIGN.md section 5): it is held to
+    OpenJPEG's own encoder (lossless round trip) only."""
+    from PIL import Image, features
+
+    if not features.check_codec("jpg_2000"):
+        raise NotImplementedError("%s: JPEG 2000 tiles (TIFF compression %d) need a PIL built with OpenJPEG" % (path, compression))
+    samp = _jp2k_component_sampling(data)
+    if samp is not None and any(s_ != (1, 1) for s_ in samp[:3]):
+        raise NotImplementedError("%s: tile %d is a JPEG 2000 codestream with subsampled components %s: not supported (no reference decoder in this image "
+                                  "to hold the chroma up-sampling to)" % (path, idx, samp))
+    try:
+        img = Image.open(io.BytesIO(data))
+        img.load()
+    except Exception as e:  # noqa: BLE001
+        raise ValueError("%s: tile %d: JPEG 2000 codestream not decodable (%s)" % (path, idx, e)) from None
+    if img.mode not in ("RGB", "RGBA", "YCbCr") and compression != 33003:
+        img = img.convert("RGB")
+    bands = img.split()
+    if len(bands) < 3:
+        raise NotImplementedError("%s: tile %d: %d-component JPEG 2000 tiles are not supported" % (path, idx, len(bands)))
+    if compression == 33003:
+        return np.asarray(Image.merge("YCbCr", bands[:3]).convert("RGB"))
+    return np.asarray(Image.merge("RGB", bands[:3]))
 
 
 def tiff_lzw_encode(data):

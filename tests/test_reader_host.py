@@ -387,3 +387,56 @@ def test_native_read_names_the_tile_it_could_not_decode(tmp_path):
     p.counts[3] = p.counts[3] + (1 << 30)  # a count that runs past the end of the file
     with pytest.raises(ValueError, match="ends inside"):
         r.read_bounds((0, 0, 260, 64), 1.0, "baseline")
+
+
+def test_jpeg2000_tiles_of_aperio_and_generic_tiffs(tmp_path):
+    """TIFF compressions 33005 (Aperio, RGB components), 34712 (generic) and 33003 (Aperio, YCbCr components) through OpenJPEG behind PIL.  The only
+    pin this image offers is OpenJPEG's own encoder: lossless codestreams written tile by tile come back bit for bit (33003: as PIL's JFIF
+    YCbCr -> RGB of the stored planes); a codestream whose chroma is subsampled and a damaged one are refused by name, never decoded into something."""
+    import io
+
+    from PIL import Image, features
+
+    if not features.check_codec("jpg_2000"):
+        pytest.skip("PIL without OpenJPEG")
+    levels = _pyramid(300, 410, 4)[:2]
+
+    def enc(t, **kw):
+        b = io.BytesIO()
+        Image.fromarray(t).save(b, format="JPEG2000", no_jp2=True, irreversible=False, **kw)
+        return b.getvalue()
+
+    for code in (33005, 34712):
+        path = str(tmp_path / ("c%d.tif" % code))
+        write_tiled_tiff(path, levels, tile=128, mpp=0.5, encode=(enc, code))
+        r = WSIReader.open(path)
+        assert r.levels[0].compression == code
+        assert np.array_equal(r.read_bounds((0, 0, 410, 300), 0.5, "mpp"), levels[0])
+        assert np.array_equal(r.read_bounds((33, 60, 400, 290), 0.5, "mpp"), levels[0][60:290, 33:400])
+        assert np.array_equal(r.read_bounds((0, 0, 205, 150), 1.0, "mpp"), levels[1])
+    ycc = np.asarray(Image.fromarray(levels[0]).convert("YCbCr"))
+    path = str(tmp_path / "c33003.tif")
+    write_tiled_tiff(path, [ycc], tile=128, mpp=0.5, encode=(lambda t: enc(t, mct=0), 33003))
+    got = WSIReader.open(path).read_bounds((0, 0, 410, 300), 0.5, "mpp")
+    assert np.array_equal(got, np.asarray(Image.fromarray(ycc, "YCbCr").convert("RGB")))
+    assert np.abs(got.astype(int) - levels[0].astype(int)).max() <= 4  # (the 8-bit YCbCr round trip of the source)
+    # subsampled chroma (XRsiz of the second component patched to 2 in the SIZ segment): refused by name before any decode
+    r = WSIReader.open(path)
+    p = r.levels[0]
+    raw = bytearray(open(path, "rb").read())
+    k = raw.find(b"\xff\x4f\xff\x51", p.offsets[0])
+    assert k == p.offsets[0]
+    raw[k + 42 + 3 * 1 + 1] = 2
+    bad = str(tmp_path / "sub.tif")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(NotImplementedError, match="subsampled components"):
+        WSIReader.open(bad).read_bounds((0, 0, 128, 128), 0.5, "mpp")
+    # a damaged codestream: an error that names file and tile
+    raw = bytearray(open(path, "rb").read())
+    a = p.offsets[1] + 120
+    raw[a:a + 400] = b"\x00" * 400
+    raw[p.offsets[1] + 2:p.offsets[1] + 4] = b"\xff\x00"  # no SIZ behind SOC
+    bad2 = str(tmp_path / "bad.tif")
+    open(bad2, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="tile 1"):
+        WSIReader.open(bad2).read_bounds((128, 0, 256, 128), 0.5, "mpp")
