@@ -17,7 +17,8 @@ size instead (600 nuclei / Mpx of radius 4-9 px, glands of 25-150 px; SURVEY.md 
 protocol, realistic instance counts (~1 M nuclei).  `value` = slide pixels / wall time of that whole region (max over ranks);
 `config.inference_Mpx_s` is the same slide over the K inference steps alone.
 `--mode batch`: the inner loop alone on 32 resident tiles (BASELINE.json configs[1]); `--mode train`: configs[4]; `--mode ingest`: a JPEG-tiled
-pyramidal TIFF on disk through reader -> decode pool -> upload-ahead -> inference, beside the resident figure.
+pyramidal TIFF on disk through reader -> decode pool -> upload-ahead -> inference, beside the resident figure (`--ingest-codec deflate | lzw`: lossless
+tiles through libcerberus_host.so's one-call-per-window reader; `--ingest-base-mpp 0.25`: a 40x scan reduced on the device).
 Beside `value` the default line carries (all outside the timed region): `config.conv_algo` / `config.precision` (the 3x3 algorithm the headline ran on, the
 calibration measurement, what the head kernels' max-|logit| guard saw over the job's batches), `config.other_conv_algos` (the same slide's inference on
 F(2x2) and on the direct kernels), `dat` (instance tables + contours + the .dat writer; with several ranks `dat.per_rank_arrays`: tables + contours where
