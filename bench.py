@@ -22,7 +22,7 @@ tiles through libcerberus_host.so's one-call-per-window reader; `--ingest-base-m
 Beside `value` the default line carries (all outside the timed region): `config.conv_algo` / `config.precision` (the 3x3 algorithm the headline ran on, the
 calibration measurement, what the head kernels' max-|logit| guard saw over the job's batches), `config.other_conv_algos` (the same slide's inference on
 F(2x2) and on the direct kernels), `dat` (instance tables + contours + the .dat writer; with several ranks `dat.per_rank_arrays`: tables + contours where
-the instances live, compact arrays gathered, bytes into rank 0 either way), `ref_tiling`, `ingest` (a 12288^2 TIFF), `batch_step`, `train_step`,
+the instances live, compact arrays gathered, bytes into rank 0 either way), `ref_tiling`, `ingest` (a 12288^2 JPEG-tiled TIFF; `ingest_40x`: stored at 0.25 mpp; `ingest_deflate`: lossless tiles through the native reader), `batch_step`, `train_step`,
 `dice_vs_reference`, `cpu_baseline`.  `--tail-from-inference`: the tail labels the canvases the timed inference wrote.
 Rank 0 prints ONE JSON line.
 """
@@ -1112,6 +1112,12 @@ def wsi_leg(args, model, dev, dist, world, rank, sd, kw):
             line["ingest_40x"] = {k: ing40[k] for k in ("slide", "stored", "file", "decode", "inference_resident", "end_to_end_from_file", "best")}
         except Exception as e:  # never fails the headline
             line["ingest_40x"] = {"error": str(e)[:300]}
+        # ... and for a generic tiled TIFF with lossless (deflate) tiles: one native call per window (libcerberus_host.so: pread + zlib + placement on pthreads)
+        try:
+            ingd = ingest_leg(model, dev, 8192, WSI_BATCH, 1, sweep=(1, 4, 16, 64), codec="deflate")
+            line["ingest_deflate"] = {k: ingd[k] for k in ("slide", "file", "decode", "inference_resident", "end_to_end_from_file", "best")}
+        except Exception as e:  # never fails the headline
+            line["ingest_deflate"] = {"error": str(e)[:300]}
     if world == 1:  # per-head Dice against the reference's own outputs (the metric's second half), outside the timed region
         try:
             line["dice_vs_reference"] = dice_vs_reference()

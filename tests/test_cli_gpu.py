@@ -183,6 +183,7 @@ def test_bench_contract_single_and_two_ranks(tmp_path):
     oa = cfg["other_conv_algos"]
     assert "error" not in oa and 0 < oa["0"]["inference_Mpx_s"] < oa["1"]["inference_Mpx_s"] and oa["0"]["batch_step_ms"] > oa["1"]["batch_step_ms"] > 0, oa
     assert "error" not in one["ingest"] and one["ingest"]["best"]["of_resident"] > 0.3, one["ingest"]
+    assert "error" not in one["ingest_deflate"] and one["ingest_deflate"]["best"]["of_resident"] > 0.3 and "libcerberus_host.so" in one["ingest_deflate"]["file"]["format"], one["ingest_deflate"]
     two = _bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
                   "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--slide", "3072"])
     assert two["n_gpus"] == 2 and "cpu_baseline" not in two and two["scaling"] == "strong"
