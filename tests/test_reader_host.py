@@ -440,3 +440,38 @@ def test_jpeg2000_tiles_of_aperio_and_generic_tiffs(tmp_path):
     open(bad2, "wb").write(bytes(raw))
     with pytest.raises(ValueError, match="tile 1"):
         WSIReader.open(bad2).read_bounds((128, 0, 256, 128), 0.5, "mpp")
+
+
+def test_native_reader_against_libtiff_on_random_files(tmp_path):
+    """30 seeded files out of PIL's libtiff -- RGB and RGBA (the reader drops the alpha samples), raw / deflate / LZW / PackBits strips, with and without
+    the horizontal predictor, sizes down to one pixel -- and a random window of each through cerb_host_tiff_read_tiles on 1 .. 5 threads: the
+    pixels libtiff itself decodes."""
+    from PIL import Image
+
+    rng = np.random.RandomState(5)
+    for trial in range(30):
+        h, w = int(rng.randint(1, 260)), int(rng.randint(1, 330))
+        mode = ["RGB", "RGBA"][rng.randint(2)]
+        a = (rng.randint(0, 25, (h, w, len(mode))) + np.arange(w)[None, :, None] // 2).astype(np.uint8)
+        comp = [None, "tiff_adobe_deflate", "tiff_lzw", "packbits"][rng.randint(4)]
+        kw = {} if comp is None else {"compression": comp}
+        if rng.randint(2) and comp in ("tiff_adobe_deflate", "tiff_lzw"):
+            kw["tiffinfo"] = {317: 2}
+        path = str(tmp_path / ("f%d.tif" % trial))
+        Image.fromarray(a, mode).save(path, **kw)
+        r = WSIReader.open(path)
+        x0, x1 = sorted(int(v) for v in rng.randint(0, w + 1, 2))
+        y0, y1 = sorted(int(v) for v in rng.randint(0, h + 1, 2))
+        if x1 == x0:
+            x1 = min(w, x0 + 1)
+            x0 = x1 - 1
+        if y1 == y0:
+            y1 = min(h, y0 + 1)
+            y0 = y1 - 1
+        os.environ["CERB_DECODE_THREADS"] = str(rng.randint(1, 6))
+        try:
+            got = r._read_level(0, x0, y0, x1, y1)
+        finally:
+            os.environ.pop("CERB_DECODE_THREADS", None)
+        want = np.asarray(Image.open(path))[y0:y1, x0:x1, :3]
+        assert np.array_equal(got, want), (trial, mode, kw, (h, w), (x0, y0, x1, y1), r.levels[0].th)
