@@ -12,7 +12,7 @@ tiatoolbox / OpenSlide are not in this image, so the back ends are this package'
   * TiffReader       -- baseline / BigTIFF, striped or TILED, pyramid pages, compression none / deflate (+ horizontal predictor) /
                         JPEG tiles (decoded by PIL, JPEGTables spliced in), resolution from XResolution / ResolutionUnit or an
                         Aperio `MPP = ...` description: generic tiled TIFFs and `.svs` files whose tiles are JPEG or JPEG 2000
-                        (Aperio 33003 / 33005, TIFF 34712: OpenJPEG behind PIL; subsampled-chroma 33003 codestreams refused by name); LZW and PackBits tiles are decoded by libcerberus_host.so (csrc/host_codecs.c, include/cerberus_host.h).
+                        (Aperio 33003 / 33005, TIFF 34712: OpenJPEG behind PIL; 33003 with 4:2:2 / 4:2:0 chroma on even tile sizes, anything else subsampled refused by name); LZW and PackBits tiles are decoded by libcerberus_host.so (csrc/host_codecs.c, include/cerberus_host.h).
 Resampling: the pyramid level with the largest downsample not above the request is read and reduced by a box (area) filter --
 exact pixel means for integer factors, PIL's BOX filter otherwise (tiatoolbox uses cv2 INTER_AREA there; unpinned, both libraries
 are absent).  Everything here is host I/O; pixels reach the GPU through wsi.SlabUploader chunk by chunk under the inference.
@@ -761,39 +761,56 @@ class TiffReader(WSIReader):
         return out
 
 
-def _jp2k_component_sampling(data):
-    """[(XRsiz, YRsiz)] per component out of a JPEG 2000 codestream's SIZ marker segment (ISO 15444-1 A.5.1; a JP2 file's boxes are skipped to its
-    codestream) -- None when there is no SIZ where one belongs."""
+def _jp2k_siz(data):
+    """(width, height, [(XRsiz, YRsiz)] per component) out of a JPEG 2000 codestream's SIZ marker segment (ISO 15444-1 A.5.1; a JP2 file's boxes
+    are skipped to its codestream) -- None when there is no SIZ where one belongs."""
     k = data.find(b"\xff\x4f\xff\x51")
     if k < 0 or len(data) < k + 42:
         return None
+    xsiz, ysiz, xo, yo = struct.unpack(">IIII", data[k + 8:k + 24])
     csiz = struct.unpack(">H", data[k + 40:k + 42])[0]
     body = data[k + 42:k + 42 + 3 * csiz]
     if len(body) < 3 * csiz:
         return None
-    return [(body[3 * i + 1], body[3 * i + 2]) for i in range(csiz)]
+    return xsiz - xo, ysiz - yo, [(body[3 * i + 1], body[3 * i + 2]) for i in range(csiz)]
+
+
+def _jp2k_component_sampling(data):
+    siz = _jp2k_siz(data)
+    return None if siz is None else siz[2]
 
 
 def _decode_jp2k_tile(data, compression, path, idx):
     """One JPEG 2000 tile (a raw codestream, as Aperio .svs files and generic TIFF writers store them) -> uint8 [rows, cols, 3], through OpenJPEG
     behind PIL.  33005 / 34712: the components are R, G, B.  33003: the components are Y, Cb, Cr (full range, JFIF matrix -- what OpenSlide's
-    Aperio back end converts with); chroma that is SUBSAMPLED inside the codestream (XRsiz / YRsiz != 1, most scanner-written 33003 files) is
-    refused by name: no sample of such a file and no OpenSlide exist in this image to hold an up-sampling rule to, and a silently different
-    colour is worse than a refusal.  Parity of this path is unpinned for the same reason (stated in DESIGN.md section 5): it is held to
-    OpenJPEG's own encoder (lossless round trip) only."""
+    Aperio back end converts with).  Chroma SUBSAMPLED inside the codestream (most scanner-written 33003 files: 4:2:2): OpenJPEG + PIL return
+    the chroma samples replicated (sample x / XRsiz, y / YRsiz) and ALREADY converted to RGB (PIL takes a subsampled three-component codestream for
+    sYCC) -- pinned by tests/golden/jp2k_subsampled.npz (oracle/gen_golden_jp2k.py: codestreams out of the bundled OpenJPEG with per-component
+    dx / dy) for 4:2:2 and 4:2:0 on sizes that are multiples of the factors, the only case accepted: on an odd width the same decoders return
+    wrong pixels (the fixture's third stream), so anything else is refused by name.  Parity with OpenSlide's own arithmetic is unpinned (it is
+    not in the image); the rule -- replication + JFIF -- is the one its Aperio back end documents."""
     from PIL import Image, features
 
     if not features.check_codec("jpg_2000"):
         raise NotImplementedError("%s: JPEG 2000 tiles (TIFF compression %d) need a PIL built with OpenJPEG" % (path, compression))
-    samp = _jp2k_component_sampling(data)
-    if samp is not None and any(s_ != (1, 1) for s_ in samp[:3]):
-        raise NotImplementedError("%s: tile %d is a JPEG 2000 codestream with subsampled components %s: not supported (no reference decoder in this image "
-                                  "to hold the chroma up-sampling to)" % (path, idx, samp))
+    siz = _jp2k_siz(data)
+    subsampled = siz is not None and any(s_ != (1, 1) for s_ in siz[2][:3])
+    if subsampled:
+        w, h, samp = siz
+        ok = (compression == 33003 and len(samp) == 3 and samp[0] == (1, 1) and samp[1] == samp[2] and samp[1] in ((2, 1), (2, 2))
+              and w % samp[1][0] == 0 and h % samp[1][1] == 0)
+        if not ok:
+            raise NotImplementedError("%s: tile %d is a %d x %d JPEG 2000 codestream with component sampling %s under TIFF compression %d: only YCbCr (33003) 4:2:2 / 4:2:0 "
+                                      "on sizes that are multiples of the factors is supported (what the decoders in this image return correctly)" % (path, idx, w, h, samp, compression))
     try:
         img = Image.open(io.BytesIO(data))
         img.load()
     except Exception as e:  # noqa: BLE001
         raise ValueError("%s: tile %d: JPEG 2000 codestream not decodable (%s)" % (path, idx, e)) from None
+    if subsampled:
+        if img.mode != "RGB":
+            raise NotImplementedError("%s: tile %d: PIL returned mode %s for a subsampled YCbCr codestream (expected its sYCC -> RGB conversion)" % (path, idx, img.mode))
+        return np.asarray(img)
     if img.mode not in ("RGB", "RGBA", "YCbCr") and compression != 33003:
         img = img.convert("RGB")
     bands = img.split()

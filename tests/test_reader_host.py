@@ -420,17 +420,33 @@ def test_jpeg2000_tiles_of_aperio_and_generic_tiffs(tmp_path):
     got = WSIReader.open(path).read_bounds((0, 0, 410, 300), 0.5, "mpp")
     assert np.array_equal(got, np.asarray(Image.fromarray(ycc, "YCbCr").convert("RGB")))
     assert np.abs(got.astype(int) - levels[0].astype(int)).max() <= 4  # (the 8-bit YCbCr round trip of the source)
-    # subsampled chroma (XRsiz of the second component patched to 2 in the SIZ segment): refused by name before any decode
+    # chroma subsampled INSIDE the codestream (what scanners write under 33003): fixtures out of the bundled OpenJPEG itself (oracle/gen_golden_jp2k.py) --
+    # the reader returns the stored planes' nearest-replicated chroma through the JFIF matrix, for 4:2:2 and 4:2:0 tiles; an odd-sized codestream (which the
+    # decoders of this image return WRONG) and subsampled RGB (33005) are refused by name
+    from cerberus_amd.reader import _decode_jp2k_tile
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jp2k_subsampled.npz"))
+
+    def expected(name):
+        Y, Cb, Cr = g[name + "/Y"], g[name + "/Cb"], g[name + "/Cr"]
+        dx, dy = (int(v) for v in g[name + "/sub"])
+        rep = [np.repeat(np.repeat(c, dy, axis=0), dx, axis=1)[: Y.shape[0], : Y.shape[1]] for c in (Cb, Cr)]
+        return np.asarray(Image.merge("YCbCr", [Image.fromarray(Y), Image.fromarray(rep[0]), Image.fromarray(rep[1])]).convert("RGB"))
+
+    for name in ("s422", "s420"):
+        want = expected(name)
+        side = want.shape[0]
+        stream = g[name + "/stream"].tobytes()
+        sub = str(tmp_path / (name + ".tif"))
+        write_tiled_tiff(sub, [np.zeros((side, 2 * side, 3), np.uint8)], tile=side, mpp=0.5, encode=(lambda t: stream, 33003))  # two tiles, the same codestream
+        got = WSIReader.open(sub).read_bounds((0, 0, 2 * side, side), 0.5, "mpp")
+        assert np.array_equal(got[:, :side], want) and np.array_equal(got[:, side:], want), name
+    with pytest.raises(NotImplementedError, match="67 x 40"):
+        _decode_jp2k_tile(g["s422_odd/stream"].tobytes(), 33003, "odd", 0)
+    with pytest.raises(NotImplementedError, match="component sampling"):
+        _decode_jp2k_tile(g["s422/stream"].tobytes(), 33005, "rgb", 0)
     r = WSIReader.open(path)
     p = r.levels[0]
-    raw = bytearray(open(path, "rb").read())
-    k = raw.find(b"\xff\x4f\xff\x51", p.offsets[0])
-    assert k == p.offsets[0]
-    raw[k + 42 + 3 * 1 + 1] = 2
-    bad = str(tmp_path / "sub.tif")
-    open(bad, "wb").write(bytes(raw))
-    with pytest.raises(NotImplementedError, match="subsampled components"):
-        WSIReader.open(bad).read_bounds((0, 0, 128, 128), 0.5, "mpp")
     # a damaged codestream: an error that names file and tile
     raw = bytearray(open(path, "rb").read())
     a = p.offsets[1] + 120
