@@ -786,8 +786,8 @@ def _decode_jp2k_tile(data, compression, path, idx):
     Aperio back end converts with).  Chroma SUBSAMPLED inside the codestream (most scanner-written 33003 files: 4:2:2): OpenJPEG + PIL return
     the chroma samples replicated (sample x / XRsiz, y / YRsiz) and ALREADY converted to RGB (PIL takes a subsampled three-component codestream for
     sYCC) -- pinned by tests/golden/jp2k_subsampled.npz (codestreams written by the bundled OpenJPEG itself with per-component dx / dy; the
-    generator is committed beside the other golden-vector scripts) for 4:2:2 and 4:2:0 on sizes that are multiples of the factors, the only case accepted: on an odd width the same decoders return
-    wrong pixels (the fixture's third stream), so anything else is refused by name.  Parity with OpenSlide's own arithmetic is unpinned (it is
+    generator is committed beside the other golden-vector scripts) for 4:2:2 and 4:2:0 on sizes that are multiples of the factors, the only case accepted: on an odd width the same encode -> decode round
+    trip does NOT return the stored planes (the fixture's third stream; encoder or decoder, not established), so anything else is refused by name.  Parity with OpenSlide's own arithmetic is unpinned (it is
     not in the image); the rule -- replication + JFIF -- is the one its Aperio back end documents."""
     from PIL import Image, features
 

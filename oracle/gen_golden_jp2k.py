@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE: writes tests/golden/jp2k_subsampled.npz -- three small JPEG 2000 codestreams whose chroma components are SUBSAMPLED inside the
-codestream (4:2:2 on a 128 x 128 tile, 4:2:0 on 64 x 64, 4:2:2 with an odd width -- which PIL / OpenJPEG do NOT return correctly and the reader therefore
-refuses), as Aperio's compression 33003 stores its tiles, together with the component planes they were
+codestream (4:2:2 on a 128 x 128 tile, 4:2:0 on 64 x 64, 4:2:2 with an odd width -- whose round trip through this library does NOT return the stored planes, so the reader
+refuses such layouts), as Aperio's compression 33003 stores its tiles, together with the component planes they were
 encoded from (lossless 5-3 wavelet).  PIL's encoder cannot subsample, so the codestreams come from the OpenJPEG 2.5 library PIL bundles, driven
 through ctypes (opj_image_create with per-component dx / dy).  Run in the build container: python oracle/gen_golden_jp2k.py
 The reference reads such slides through OpenSlide (infer/wsi.py:521-531), which is not in this image: the fixture pins what the reader does with

@@ -421,8 +421,8 @@ def test_jpeg2000_tiles_of_aperio_and_generic_tiffs(tmp_path):
     assert np.array_equal(got, np.asarray(Image.fromarray(ycc, "YCbCr").convert("RGB")))
     assert np.abs(got.astype(int) - levels[0].astype(int)).max() <= 4  # (the 8-bit YCbCr round trip of the source)
     # chroma subsampled INSIDE the codestream (what scanners write under 33003): fixtures out of the bundled OpenJPEG itself (oracle/gen_golden_jp2k.py) --
-    # the reader returns the stored planes' nearest-replicated chroma through the JFIF matrix, for 4:2:2 and 4:2:0 tiles; an odd-sized codestream (which the
-    # decoders of this image return WRONG) and subsampled RGB (33005) are refused by name
+    # the reader returns the stored planes' nearest-replicated chroma through the JFIF matrix, for 4:2:2 and 4:2:0 tiles; an odd-sized codestream (whose round trip through
+    # this image's OpenJPEG does not return the stored planes) and subsampled RGB (33005) are refused by name
     from cerberus_amd.reader import _decode_jp2k_tile
 
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jp2k_subsampled.npz"))
