@@ -335,6 +335,23 @@ def test_run_infer_wsi_reads_pyramidal_tiff_at_proc_mag(tmp_path):
     b.mkdir()
     write_tiled_tiff(str(a / "s1.tif"), [base, l1], tile=256, mpp=0.25)
     np.save(str(b / "s1.npy"), l1)
+    # a second slide of the directory with JPEG 2000 tiles (Aperio compression 33005, lossless here): OpenJPEG behind the reader, same pixels -> same outputs
+    import io
+
+    from PIL import Image, features
+
+    names = ["s1"]
+    if features.check_codec("jpg_2000"):
+        def j2k(t):
+            buf = io.BytesIO()
+            Image.fromarray(t).save(buf, format="JPEG2000", no_jp2=True, irreversible=False)
+            return buf.getvalue()
+
+        base2 = np.ascontiguousarray(base[::-1])
+        l2 = np.ascontiguousarray(l1[::-1])
+        write_tiled_tiff(str(a / "s2.tif"), [base2, l2], tile=256, mpp=0.25, encode=(j2k, 33005))
+        np.save(str(b / "s2.npy"), l2)
+        names.append("s2")
     outs = []
     for d, ext in ((a, ".tif"), (b, ".npy")):
         out = tmp_path / ("out" + ext[1:])
@@ -343,10 +360,11 @@ def test_run_infer_wsi_reads_pyramidal_tiff_at_proc_mag(tmp_path):
                             "--save_label_maps"], capture_output=True, text=True, timeout=600, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(out)
-    za, zb = np.load(str(outs[0] / "s1.npz")), np.load(str(outs[1] / "s1.npz"))
-    assert set(za.files) == set(zb.files)
-    for k in za.files:
-        assert np.array_equal(za[k], zb[k]), k
+    for name in names:
+        za, zb = np.load(str(outs[0] / (name + ".npz"))), np.load(str(outs[1] / (name + ".npz")))
+        assert set(za.files) == set(zb.files)
+        for k in za.files:
+            assert np.array_equal(za[k], zb[k]), (name, k)
     da, db = joblib.load(str(outs[0] / "dat" / "s1.dat")), joblib.load(str(outs[1] / "dat" / "s1.dat"))
     assert da["proc_dimensions"].tolist() == [550, 750] and da["base_dimensions"].tolist() == [1100, 1500]
     assert abs(da["base_resolution"]["resolution"] - 0.25) < 1e-3 and da["proc_resolution"]["resolution"] == 0.5
