@@ -29,8 +29,9 @@ _POOL = {"n": None, "pool": None}
 
 
 def decode_threads():
-    """Tile-decode threads of the TIFF / .svs reader: CERB_DECODE_THREADS, default min(32, host cores) -- `bench.py --mode ingest` reports the count
-    that saturates one GPU's inference (a JPEG tile decodes at ~160 Mpx/s per core, the network eats ~150 Mpx/s)."""
+    """Tile-decode threads of the TIFF / .svs reader (the Python pool of the JPEG tiles and the native pthreads of cerb_host_tiff_read_tiles):
+    CERB_DECODE_THREADS, default min(32, host cores / ranks on this host) -- `bench.py --mode ingest` reports the count that saturates one GPU's
+    inference (a JPEG tile decodes at ~160 Mpx/s per core, an LZW / deflate tile at ~100, the network eats ~150 Mpx/s: four to eight threads)."""
     v = os.environ.get("CERB_DECODE_THREADS")
     if v:
         return max(1, int(v))
@@ -38,7 +39,11 @@ def decode_threads():
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, min(32, n))
+    try:
+        ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1))
+    except ValueError:
+        ranks = 1
+    return max(1, min(32, n // ranks))
 
 
 def decode_pool():
