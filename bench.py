@@ -566,6 +566,11 @@ def ingest_leg(model, dev, side, batch, streams, tmpdir=None, sweep=(1, 2, 4, 8,
 
     def enc(t):
         key = t.tobytes()
+        if key not in cache and codec == "jp2k":
+            # Aperio compression 33005: a raw JPEG 2000 codestream per tile, R, G, B components (lossless 5-3 here: the decoded pixels are held to the source)
+            b = io.BytesIO()
+            Image.fromarray(t).save(b, format="JPEG2000", no_jp2=True, irreversible=False)
+            cache[key] = b.getvalue()
         if key not in cache and codec != "jpeg":
             # lossless tiles (generic tiled TIFFs: bioformats / libvips exports): decoded by libcerberus_host.so, one native call per window
             import zlib
@@ -584,12 +589,13 @@ def ingest_leg(model, dev, side, batch, streams, tmpdir=None, sweep=(1, 2, 4, 8,
 
     td = tempfile.mkdtemp(dir=tmpdir)
     path = os.path.join(td, "slide.tif")
-    rd.write_tiled_tiff(path, [img, np.ascontiguousarray(img[::4, ::4])], tile=TILE, mpp=base_mpp, encode=(enc, {"jpeg": 7, "deflate": 8, "lzw": 5}[codec]),
+    rd.write_tiled_tiff(path, [img, np.ascontiguousarray(img[::4, ::4])], tile=TILE, mpp=base_mpp, encode=(enc, {"jpeg": 7, "deflate": 8, "lzw": 5, "jp2k": 33005}[codec]),
                         predictor=2 if codec == "lzw" else 1)
     src_band = None if codec == "jpeg" else np.ascontiguousarray(img[: min(fH, 512)])
     del img
     build_s = time.perf_counter() - t0
     res = {"slide": [H, W], "stored": {"pixels": [fH, fW], "mpp": base_mpp, "read_at_mpp": 0.5}, "file": {"format": ("pyramidal TIFF, %d x %d JPEG tiles (Aperio-style: RGB components, 4:4:4, quality 80) + a x4 level" % (TILE, TILE)) if codec == "jpeg" else
+                                    ("pyramidal TIFF, %d x %d lossless JPEG 2000 tiles (Aperio compression 33005) + a x4 level (decoded by OpenJPEG behind PIL, on threads / worker processes)" % (TILE, TILE)) if codec == "jp2k" else
                                     ("pyramidal TIFF, %d x %d %s tiles + a x4 level (decoded by libcerberus_host.so: one native call per window)" % (TILE, TILE, {"deflate": "deflate", "lzw": "LZW + horizontal-predictor"}[codec])), "MB": round(os.path.getsize(path) / 1e6, 1),
                                     "tiles": int(ny * nx), "build_s": round(build_s, 1)}}
     try:
@@ -616,7 +622,7 @@ def ingest_leg(model, dev, side, batch, streams, tmpdir=None, sweep=(1, 2, 4, 8,
         ref_px = a
         if src_band is not None:  # lossless: the decoded pixels ARE the source's
             assert np.array_equal(ref_px[: src_band.shape[0]], src_band), "the reader returned other pixels than the file was written from"
-        proc_counts = [c for c in (2, 4, 8, 16, 32) if c <= max(1, avail // 2)] if codec == "jpeg" else []  # (worker processes decode JPEG tiles only)
+        proc_counts = [c for c in (2, 4, 8, 16, 32) if c <= max(1, avail // 2)] if codec in ("jpeg", "jp2k") else []  # (worker processes decode the tiles that go through PIL: JPEG, JPEG 2000)
         for n in proc_counts:
             os.environ["CERB_DECODE_PROCS"] = str(n)
             reader._read_level(0, 0, 0, fW, min(span, 512))  # the workers start here
@@ -1145,7 +1151,7 @@ def main():
                     help="slide job: the labelling reads the INST canvases the timed inference wrote instead of the seeded structured maps (the data dependency "
                          "inference -> labelling at slide scale); the seeded weights get a sparse-foreground bias calibration so that those maps hold instances")
     ap.add_argument("--ingest-base-mpp", type=float, default=0.5, help="--mode ingest: microns per pixel the file is STORED at (0.25 = a 40x scan: (2 x slide)^2 pixels on disk, read at 0.5 mpp)")
-    ap.add_argument("--ingest-codec", default="jpeg", choices=["jpeg", "deflate", "lzw"],
+    ap.add_argument("--ingest-codec", default="jpeg", choices=["jpeg", "deflate", "lzw", "jp2k"],
                     help="--mode ingest: the tiles' compression (jpeg: Aperio-style, decoded by libjpeg on threads / worker processes; deflate, lzw (+ horizontal predictor): "
                          "generic tiled TIFFs, decoded by libcerberus_host.so -- one native call per window on CERB_DECODE_THREADS pthreads)")
     ap.add_argument("--slide", type=int, default=0, help="slide side in pixels (default: 40000, or 20000 when HBM is short)")
@@ -1210,11 +1216,11 @@ def main():
     if args.mode == "ingest":
         side = args.slide if args.slide > 0 else 20000
         ing = ingest_leg(model, dev, side, 64 if args.streams == 2 else 96, args.streams, base_mpp=args.ingest_base_mpp, codec=args.ingest_codec)
-        codec_name = {"jpeg": "JPEG", "deflate": "deflate", "lzw": "LZW"}[args.ingest_codec]
+        codec_name = {"jpeg": "JPEG", "deflate": "deflate", "lzw": "LZW", "jp2k": "JPEG 2000"}[args.ingest_codec]
         workload = ("%dx%d slide from a %s-tiled pyramidal TIFF stored at %.4g mpp (%dx%d pixels) -> reader (%s%s) -> pinned chunks ahead of the inference -> full "
                     "Cerberus forward into device canvases; inference only, no labelling tail" % (
                         side, side, codec_name, args.ingest_base_mpp, ing["stored"]["pixels"][0], ing["stored"]["pixels"][1],
-                        "tile decode on threads / worker processes" if args.ingest_codec == "jpeg" else "one native call per window: libcerberus_host.so, pthreads",
+                        "tile decode on threads / worker processes" if args.ingest_codec in ("jpeg", "jp2k") else "one native call per window: libcerberus_host.so, pthreads",
                         ", reduced to 0.5 mpp on the device" if args.ingest_base_mpp < 0.5 else ""))
         print(json.dumps({"metric": "Mpx/sec WSI tiled inference (all heads) from a %s-tiled pyramidal TIFF on disk" % codec_name, "value": ing["best"]["Mpx_s"], "unit": "Mpx/s",
                           "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": round(side * side / ing["best"]["Mpx_s"] / 1e3, 1), "higher_is_better": True, "scaling": "weak",
