@@ -567,9 +567,10 @@ def ingest_leg(model, dev, side, batch, streams, tmpdir=None, sweep=(1, 2, 4, 8,
     def enc(t):
         key = t.tobytes()
         if key not in cache and codec == "jp2k":
-            # Aperio compression 33005: a raw JPEG 2000 codestream per tile, R, G, B components (lossless 5-3 here: the decoded pixels are held to the source)
+            # Aperio compression 33005: a raw JPEG 2000 codestream per tile, R, G, B components, 9-7 wavelet at 15:1 as scanners write them (OpenJPEG
+            # decodes such a tile at ~7 Mpx/s per core -- a lossless one at 1.7 --: this leg is bound by the decode processes, ~22 of them per GPU)
             b = io.BytesIO()
-            Image.fromarray(t).save(b, format="JPEG2000", no_jp2=True, irreversible=False)
+            Image.fromarray(t).save(b, format="JPEG2000", no_jp2=True, irreversible=True, quality_mode="rates", quality_layers=[15])
             cache[key] = b.getvalue()
         if key not in cache and codec != "jpeg":
             # lossless tiles (generic tiled TIFFs: bioformats / libvips exports): decoded by libcerberus_host.so, one native call per window
@@ -591,11 +592,11 @@ def ingest_leg(model, dev, side, batch, streams, tmpdir=None, sweep=(1, 2, 4, 8,
     path = os.path.join(td, "slide.tif")
     rd.write_tiled_tiff(path, [img, np.ascontiguousarray(img[::4, ::4])], tile=TILE, mpp=base_mpp, encode=(enc, {"jpeg": 7, "deflate": 8, "lzw": 5, "jp2k": 33005}[codec]),
                         predictor=2 if codec == "lzw" else 1)
-    src_band = None if codec == "jpeg" else np.ascontiguousarray(img[: min(fH, 512)])
+    src_band = None if codec in ("jpeg", "jp2k") else np.ascontiguousarray(img[: min(fH, 512)])  # (lossless codecs: the decoded pixels are held to these)
     del img
     build_s = time.perf_counter() - t0
     res = {"slide": [H, W], "stored": {"pixels": [fH, fW], "mpp": base_mpp, "read_at_mpp": 0.5}, "file": {"format": ("pyramidal TIFF, %d x %d JPEG tiles (Aperio-style: RGB components, 4:4:4, quality 80) + a x4 level" % (TILE, TILE)) if codec == "jpeg" else
-                                    ("pyramidal TIFF, %d x %d lossless JPEG 2000 tiles (Aperio compression 33005) + a x4 level (decoded by OpenJPEG behind PIL, on threads / worker processes)" % (TILE, TILE)) if codec == "jp2k" else
+                                    ("pyramidal TIFF, %d x %d JPEG 2000 tiles (Aperio compression 33005, 9-7 wavelet at 15:1) + a x4 level (decoded by OpenJPEG behind PIL, on threads / worker processes)" % (TILE, TILE)) if codec == "jp2k" else
                                     ("pyramidal TIFF, %d x %d %s tiles + a x4 level (decoded by libcerberus_host.so: one native call per window)" % (TILE, TILE, {"deflate": "deflate", "lzw": "LZW + horizontal-predictor"}[codec])), "MB": round(os.path.getsize(path) / 1e6, 1),
                                     "tiles": int(ny * nx), "build_s": round(build_s, 1)}}
     try:
